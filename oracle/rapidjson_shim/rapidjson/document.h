@@ -1,0 +1,533 @@
+// TEST INFRASTRUCTURE ONLY (oracle/): a from-scratch, minimal stand-in for the subset of the
+// rapidjson API that the reference engine uses (reference: extern/rapidjson is an EMPTY un-vendored
+// submodule, .gitmodules:1-3, pinned commit unknown).  It exists solely so that the UNMODIFIED
+// reference sources under /root/reference/src compile into oracle/_ref/ (see oracle/Makefile).
+// Nothing in the product path (cityflow_amd/) includes this header.
+//
+// Numeric note: decimal -> double conversion uses correctly rounded strtod();
+// real rapidjson (default flags) may differ by <= a few ULP on >= 17-digit literals.  The product
+// host parser also uses strtod, so oracle and product agree by construction ("parity unpinned at the
+// JSON-number boundary" is stated in DESIGN.md).
+#ifndef ORACLE_RAPIDJSON_SHIM_DOCUMENT_H
+#define ORACLE_RAPIDJSON_SHIM_DOCUMENT_H
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <climits>
+#include <string>
+#include <vector>
+#include <utility>
+
+namespace rapidjson {
+
+typedef unsigned SizeType;
+
+enum Type { kNullType = 0, kFalseType, kTrueType, kObjectType, kArrayType, kStringType, kNumberType };
+
+enum ParseErrorCode { kParseErrorNone = 0, kParseErrorSyntax = 1 };
+
+class CrtAllocator {};
+template <typename Base = CrtAllocator> class MemoryPoolAllocator {};
+
+struct StringRefType {
+    const char *s;
+    explicit StringRefType(const char *str) : s(str) {}
+};
+inline StringRefType StringRef(const char *str) { return StringRefType(str); }
+
+class Value;
+struct Member;
+
+class Value {
+public:
+    typedef MemoryPoolAllocator<> AllocatorType;
+    typedef const Member *ConstMemberIterator;
+    typedef Member *MemberIterator;
+
+    // ---- construction (move-only, like rapidjson) ----
+    Value() : kind_(kNullType), isInt_(false), num_(0), int_(0) {}
+    explicit Value(Type t) : kind_(t), isInt_(false), num_(0), int_(0) {}
+    Value(const std::string &s, AllocatorType &) : kind_(kStringType), isInt_(false), num_(0), int_(0), str_(s) {}
+    Value(const char *s, AllocatorType &) : kind_(kStringType), isInt_(false), num_(0), int_(0), str_(s) {}
+    explicit Value(bool b) : kind_(b ? kTrueType : kFalseType), isInt_(false), num_(0), int_(0) {}
+    explicit Value(int v) : kind_(kNumberType), isInt_(true), num_((double) v), int_(v) {}
+    explicit Value(unsigned v) : kind_(kNumberType), isInt_(true), num_((double) v), int_(v) {}
+    explicit Value(short v) : kind_(kNumberType), isInt_(true), num_((double) v), int_(v) {}
+    explicit Value(int64_t v) : kind_(kNumberType), isInt_(true), num_((double) v), int_(v) {}
+    explicit Value(double v) : kind_(kNumberType), isInt_(false), num_(v), int_(0) {}
+    Value(const Value &) = delete;
+    Value &operator=(const Value &) = delete;
+    Value(Value &&o) noexcept { moveFrom(o); }
+    Value &operator=(Value &&o) noexcept {
+        if (this != &o) moveFrom(o);
+        return *this;
+    }
+    ~Value();
+
+    Value &Move() { return *this; }
+
+    // ---- type queries ----
+    bool IsNull() const { return kind_ == kNullType; }
+    bool IsBool() const { return kind_ == kTrueType || kind_ == kFalseType; }
+    bool IsObject() const { return kind_ == kObjectType; }
+    bool IsArray() const { return kind_ == kArrayType; }
+    bool IsString() const { return kind_ == kStringType; }
+    bool IsNumber() const { return kind_ == kNumberType; }
+    bool IsInt() const { return kind_ == kNumberType && isInt_ && int_ >= INT_MIN && int_ <= INT_MAX; }
+    bool IsUint() const { return kind_ == kNumberType && isInt_ && int_ >= 0 && int_ <= (int64_t) UINT_MAX; }
+    bool IsDouble() const { return kind_ == kNumberType && !isInt_; }
+
+    template <typename T> bool Is() const;
+    template <typename T> T Get() const;
+
+    bool GetBool() const { return kind_ == kTrueType; }
+    int GetInt() const { return (int) int_; }
+    unsigned GetUint() const { return (unsigned) int_; }
+    double GetDouble() const { return isInt_ ? (double) int_ : num_; }
+    const char *GetString() const { return str_.c_str(); }
+
+    // ---- arrays ----
+    SizeType Size() const { return (SizeType) arr_.size(); }
+    bool Empty() const { return arr_.empty(); }
+    Value &operator[](SizeType i) { return arr_[i]; }
+    const Value &operator[](SizeType i) const { return arr_[i]; }
+
+    struct ArrayRange {
+        Value *b, *e;
+        Value *begin() const { return b; }
+        Value *end() const { return e; }
+    };
+    struct ConstArrayRange {
+        const Value *b, *e;
+        const Value *begin() const { return b; }
+        const Value *end() const { return e; }
+    };
+    ArrayRange GetArray() { return ArrayRange{arr_.data(), arr_.data() + arr_.size()}; }
+    ConstArrayRange GetArray() const { return ConstArrayRange{arr_.data(), arr_.data() + arr_.size()}; }
+
+    Value &PushBack(Value &v, AllocatorType &) {
+        arr_.emplace_back(std::move(v));
+        return *this;
+    }
+    Value &PushBack(Value &&v, AllocatorType &) {
+        arr_.emplace_back(std::move(v));
+        return *this;
+    }
+    Value &PushBack(double v, AllocatorType &) {
+        arr_.emplace_back(Value(v));
+        return *this;
+    }
+    Value &PushBack(int v, AllocatorType &) {
+        arr_.emplace_back(Value(v));
+        return *this;
+    }
+
+    // ---- objects ----
+    ConstMemberIterator FindMember(const char *name) const;
+    ConstMemberIterator MemberBegin() const;
+    ConstMemberIterator MemberEnd() const;
+    bool HasMember(const char *name) const { return FindMember(name) != MemberEnd(); }
+
+    Value &SetObject() {
+        clear();
+        kind_ = kObjectType;
+        return *this;
+    }
+    Value &SetArray() {
+        clear();
+        kind_ = kArrayType;
+        return *this;
+    }
+    Value &SetString(StringRefType s) {
+        clear();
+        kind_ = kStringType;
+        str_ = s.s;
+        return *this;
+    }
+    Value &SetString(const char *s, AllocatorType &) {
+        clear();
+        kind_ = kStringType;
+        str_ = s;
+        return *this;
+    }
+    // string-literal form used as SetString("null")
+    template <size_t N> Value &SetString(const char (&s)[N]) {
+        clear();
+        kind_ = kStringType;
+        str_ = s;
+        return *this;
+    }
+
+    // AddMember: name may be a string literal or a Value; value may be a Value (moved from) or a scalar
+    template <size_t N> Value &AddMember(const char (&name)[N], Value &v, AllocatorType &a) {
+        Value n(name, a);
+        return addMemberImpl(n, v);
+    }
+    template <size_t N> Value &AddMember(const char (&name)[N], Value &&v, AllocatorType &a) {
+        Value n(name, a);
+        return addMemberImpl(n, v);
+    }
+    template <size_t N, typename T> Value &AddMember(const char (&name)[N], T v, AllocatorType &a) {
+        Value n(name, a);
+        Value val(v);
+        return addMemberImpl(n, val);
+    }
+    Value &AddMember(Value &name, Value &v, AllocatorType &) { return addMemberImpl(name, v); }
+    Value &AddMember(Value &name, Value &&v, AllocatorType &) { return addMemberImpl(name, v); }
+    Value &AddMember(Value &&name, Value &v, AllocatorType &) { return addMemberImpl(name, v); }
+    Value &AddMember(Value &&name, Value &&v, AllocatorType &) { return addMemberImpl(name, v); }
+
+    // ---- serialisation helper (used by Writer) ----
+    void writeTo(std::string &out) const;
+
+protected:
+    friend class Document;
+    friend struct Parser;
+    void clear();
+    void moveFrom(Value &o);
+    Value &addMemberImpl(Value &name, Value &v);
+
+    Type kind_;
+    bool isInt_;
+    double num_;
+    int64_t int_;
+    std::string str_;
+    std::vector<Value> arr_;
+    std::vector<Member> *obj_ = nullptr;  // pointer because Member is incomplete here
+};
+
+struct Member {
+    Value name;
+    Value value;
+    Member() {}
+    Member(Member &&o) noexcept : name(std::move(o.name)), value(std::move(o.value)) {}
+    Member &operator=(Member &&o) noexcept {
+        name = std::move(o.name);
+        value = std::move(o.value);
+        return *this;
+    }
+};
+
+inline Value::~Value() { delete obj_; }
+
+inline void Value::clear() {
+    str_.clear();
+    arr_.clear();
+    delete obj_;
+    obj_ = nullptr;
+    isInt_ = false;
+    num_ = 0;
+    int_ = 0;
+    kind_ = kNullType;
+}
+
+inline void Value::moveFrom(Value &o) {
+    delete obj_;
+    kind_ = o.kind_;
+    isInt_ = o.isInt_;
+    num_ = o.num_;
+    int_ = o.int_;
+    str_ = std::move(o.str_);
+    arr_ = std::move(o.arr_);
+    obj_ = o.obj_;
+    o.obj_ = nullptr;
+    o.kind_ = kNullType;
+}
+
+inline Value &Value::addMemberImpl(Value &name, Value &v) {
+    if (!obj_) obj_ = new std::vector<Member>();
+    obj_->emplace_back();
+    obj_->back().name = std::move(name);
+    obj_->back().value = std::move(v);
+    return *this;
+}
+
+inline Value::ConstMemberIterator Value::MemberBegin() const {
+    static const std::vector<Member> empty;
+    const std::vector<Member> &m = obj_ ? *obj_ : empty;
+    return m.data();
+}
+inline Value::ConstMemberIterator Value::MemberEnd() const {
+    static const std::vector<Member> empty;
+    const std::vector<Member> &m = obj_ ? *obj_ : empty;
+    return m.data() + m.size();
+}
+inline Value::ConstMemberIterator Value::FindMember(const char *name) const {
+    ConstMemberIterator e = MemberEnd();
+    for (ConstMemberIterator it = MemberBegin(); it != e; ++it)
+        if (it->name.str_ == name) return it;
+    return e;
+}
+
+template <> inline bool Value::Is<bool>() const { return IsBool(); }
+template <> inline bool Value::Is<int>() const { return IsInt(); }
+template <> inline bool Value::Is<unsigned>() const { return IsUint(); }
+template <> inline bool Value::Is<double>() const { return IsNumber(); }
+template <> inline bool Value::Is<const char *>() const { return IsString(); }
+template <> inline bool Value::Get<bool>() const { return GetBool(); }
+template <> inline int Value::Get<int>() const { return GetInt(); }
+template <> inline unsigned Value::Get<unsigned>() const { return GetUint(); }
+template <> inline double Value::Get<double>() const { return GetDouble(); }
+template <> inline const char *Value::Get<const char *>() const { return GetString(); }
+
+inline void Value::writeTo(std::string &out) const {
+    char buf[64];
+    switch (kind_) {
+        case kNullType: out += "null"; break;
+        case kFalseType: out += "false"; break;
+        case kTrueType: out += "true"; break;
+        case kNumberType:
+            if (isInt_) {
+                snprintf(buf, sizeof buf, "%lld", (long long) int_);
+                out += buf;
+            } else {
+                // %.17g round-trips every finite double exactly through strtod
+                snprintf(buf, sizeof buf, "%.17g", num_);
+                out += buf;
+                if (!strpbrk(buf, ".eEn")) out += ".0";  // keep it a "double" literal
+            }
+            break;
+        case kStringType: {
+            out += '"';
+            for (char c : str_) {
+                switch (c) {
+                    case '"': out += "\\\""; break;
+                    case '\\': out += "\\\\"; break;
+                    case '\n': out += "\\n"; break;
+                    case '\t': out += "\\t"; break;
+                    case '\r': out += "\\r"; break;
+                    default: out += c;
+                }
+            }
+            out += '"';
+            break;
+        }
+        case kArrayType: {
+            out += '[';
+            for (size_t i = 0; i < arr_.size(); ++i) {
+                if (i) out += ',';
+                arr_[i].writeTo(out);
+            }
+            out += ']';
+            break;
+        }
+        case kObjectType: {
+            out += '{';
+            bool first = true;
+            for (ConstMemberIterator it = MemberBegin(); it != MemberEnd(); ++it) {
+                if (!first) out += ',';
+                first = false;
+                it->name.writeTo(out);
+                out += ':';
+                it->value.writeTo(out);
+            }
+            out += '}';
+            break;
+        }
+    }
+}
+
+// Recursive-descent parser over an in-memory buffer.
+struct Parser {
+    const char *p, *end;
+    bool ok = true;
+    size_t line = 1;
+
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) {
+            if (*p == '\n') ++line;
+            ++p;
+        }
+    }
+    bool lit(const char *s) {
+        size_t n = strlen(s);
+        if ((size_t)(end - p) >= n && memcmp(p, s, n) == 0) {
+            p += n;
+            return true;
+        }
+        return false;
+    }
+    void parseString(std::string &out) {
+        ++p;  // opening quote
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break;
+                    case 'u': {
+                        unsigned cp = 0;
+                        for (int i = 0; i < 4 && p + 1 < end; ++i) {
+                            ++p;
+                            cp = cp * 16 + (unsigned) (isdigit((unsigned char) *p) ? *p - '0' : (tolower(*p) - 'a' + 10));
+                        }
+                        if (cp < 0x80) out += (char) cp;
+                        else if (cp < 0x800) {
+                            out += (char) (0xC0 | (cp >> 6));
+                            out += (char) (0x80 | (cp & 0x3F));
+                        } else {
+                            out += (char) (0xE0 | (cp >> 12));
+                            out += (char) (0x80 | ((cp >> 6) & 0x3F));
+                            out += (char) (0x80 | (cp & 0x3F));
+                        }
+                        break;
+                    }
+                    default: out += *p;
+                }
+                ++p;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) {
+            ok = false;
+            return;
+        }
+        ++p;  // closing quote
+    }
+    void parseValue(Value &v) {
+        ws();
+        if (p >= end) {
+            ok = false;
+            return;
+        }
+        char c = *p;
+        if (c == '{') {
+            ++p;
+            v.kind_ = kObjectType;
+            v.obj_ = new std::vector<Member>();
+            ws();
+            if (p < end && *p == '}') {
+                ++p;
+                return;
+            }
+            while (ok) {
+                ws();
+                if (p >= end || *p != '"') {
+                    ok = false;
+                    return;
+                }
+                v.obj_->emplace_back();
+                Member &m = v.obj_->back();
+                m.name.kind_ = kStringType;
+                parseString(m.name.str_);
+                ws();
+                if (p >= end || *p != ':') {
+                    ok = false;
+                    return;
+                }
+                ++p;
+                parseValue(m.value);
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == '}') {
+                    ++p;
+                    return;
+                }
+                ok = false;
+            }
+        } else if (c == '[') {
+            ++p;
+            v.kind_ = kArrayType;
+            ws();
+            if (p < end && *p == ']') {
+                ++p;
+                return;
+            }
+            while (ok) {
+                v.arr_.emplace_back();
+                parseValue(v.arr_.back());
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == ']') {
+                    ++p;
+                    return;
+                }
+                ok = false;
+            }
+        } else if (c == '"') {
+            v.kind_ = kStringType;
+            parseString(v.str_);
+        } else if (c == 't') {
+            if (lit("true")) v.kind_ = kTrueType; else ok = false;
+        } else if (c == 'f') {
+            if (lit("false")) v.kind_ = kFalseType; else ok = false;
+        } else if (c == 'n') {
+            if (lit("null")) v.kind_ = kNullType; else ok = false;
+        } else if (c == '-' || (c >= '0' && c <= '9')) {
+            const char *s = p;
+            bool integral = true;
+            if (*p == '-') ++p;
+            while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) {
+                if (*p == '.' || *p == 'e' || *p == 'E') integral = false;
+                ++p;
+            }
+            std::string tok(s, p - s);
+            v.kind_ = kNumberType;
+            if (integral && tok.size() <= 18) {
+                v.isInt_ = true;
+                v.int_ = strtoll(tok.c_str(), nullptr, 10);
+                v.num_ = (double) v.int_;
+            } else {
+                v.isInt_ = false;
+                v.num_ = strtod(tok.c_str(), nullptr);
+            }
+        } else {
+            ok = false;
+        }
+    }
+};
+
+class Document : public Value {
+public:
+    typedef MemoryPoolAllocator<> AllocatorType;
+
+    Document() : err_(kParseErrorNone) {}
+
+    template <typename Stream> Document &ParseStream(Stream &is) {
+        std::string text;
+        is.slurp(text);
+        Parser ps;
+        ps.p = text.data();
+        ps.end = text.data() + text.size();
+        clear();
+        ps.parseValue(*this);
+        ps.ws();
+        if (!ps.ok || ps.p != ps.end) {
+            err_ = kParseErrorSyntax;
+            is.setLine(ps.line);
+        } else {
+            err_ = kParseErrorNone;
+        }
+        return *this;
+    }
+    bool HasParseError() const { return err_ != kParseErrorNone; }
+    ParseErrorCode GetParseError() const { return err_; }
+    AllocatorType &GetAllocator() { return alloc_; }
+
+    template <typename W> bool Accept(W &writer) const {
+        std::string out;
+        writeTo(out);
+        writer.emit(out);
+        return true;
+    }
+
+private:
+    ParseErrorCode err_;
+    AllocatorType alloc_;
+};
+
+}  // namespace rapidjson
+
+#endif
