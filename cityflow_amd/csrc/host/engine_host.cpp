@@ -1,0 +1,442 @@
+#include "engine_host.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <climits>
+#include <iostream>
+#include <stdexcept>
+
+#include "json.h"
+
+namespace cfa {
+
+// ---------------------------------------------------------------- backend loading
+std::string defaultBackendPath() {
+    Dl_info info;
+    if (dladdr((void *) &defaultBackendPath, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t slash = p.find_last_of('/');
+        std::string dir = slash == std::string::npos ? "." : p.substr(0, slash);
+        return dir + "/lib/libcfx_hip.so";
+    }
+    return "libcfx_hip.so";
+}
+
+void Backend::open(const std::string &libPath) {
+    path = libPath;
+    handle = dlopen(libPath.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!handle)
+        throw std::runtime_error("cityflow_amd: cannot load device engine library '" + libPath + "': " + dlerror() +
+                                 " (build it with `python -c 'import __graft_entry__ as g; g.build()'`; there is no "
+                                 "CPU fallback)");
+#define CFX_FN(name)                                                                                  \
+    name = reinterpret_cast<decltype(name)>(dlsym(handle, #name));                                    \
+    if (!name) throw std::runtime_error("cityflow_amd: '" + libPath + "' does not export " #name);
+    CFX_FN(cfx_abi_version)
+    CFX_FN(cfx_create)
+    CFX_FN(cfx_destroy)
+    CFX_FN(cfx_last_error)
+    CFX_FN(cfx_backend_name)
+    CFX_FN(cfx_add_templates)
+    CFX_FN(cfx_add_routes)
+    CFX_FN(cfx_step)
+    CFX_FN(cfx_sync)
+    CFX_FN(cfx_reset)
+    CFX_FN(cfx_set_tl_phase)
+    CFX_FN(cfx_get_tl_state)
+    CFX_FN(cfx_get_scalars)
+    CFX_FN(cfx_get_lane_counts)
+    CFX_FN(cfx_get_lane_waiting_counts)
+    CFX_FN(cfx_get_vehicles)
+    CFX_FN(cfx_get_waiting)
+    CFX_FN(cfx_get_vehicle_status)
+#undef CFX_FN
+    if (cfx_abi_version() != CFX_ABI_VERSION)
+        throw std::runtime_error("cityflow_amd: ABI version mismatch in '" + libPath + "'");
+}
+
+Backend::~Backend() {
+    if (handle) dlclose(handle);
+}
+
+// ---------------------------------------------------------------- construction
+// Engine::Engine / loadConfig (engine.cpp:13-84).  Deviation (documented in DESIGN.md): where the
+// reference prints "load config failed!" and hands back a half-built engine, this constructor throws.
+EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::string &backendLib)
+    : threadNum_(threadNum < 1 ? 1 : threadNum) {
+    std::string roadnetFile, flowFile;
+    try {
+        Json cfg = Json::parseFile(configFile);
+        if (!cfg.isObject()) throw JsonError("wrong format of config file");
+        interval_ = cfg.numberAt("interval");
+        rlTrafficLight_ = cfg.boolAt("rlTrafficLight");
+        laneChange_ = cfg.boolAt("laneChange", false);
+        seed_ = cfg.intAt("seed");
+        dir_ = cfg.stringAt("dir");
+        roadnetFile = cfg.stringAt("roadnetFile");
+        flowFile = cfg.stringAt("flowFile");
+        saveReplay_ = cfg.boolAt("saveReplay");
+        net_.load(dir_ + roadnetFile);
+        spawner_.init(&net_, interval_, threadNum_, seed_);
+        spawner_.loadFlows(dir_ + flowFile);
+    } catch (const JsonError &e) {
+        throw std::runtime_error(std::string("load config failed! ") + e.what());
+    }
+    if (laneChange_)
+        throw std::runtime_error(
+            "cityflow_amd: laneChange=true is not implemented yet on the device path (SURVEY.md §8f row 3)");
+    if (saveReplay_)
+        std::cerr << "[cityflow_amd] saveReplay is accepted but no replay file is written (out of scope, SURVEY.md §8f row 4)"
+                  << std::endl;
+
+    be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
+    cfx_config cc{};
+    cc.interval = interval_;
+    cc.rl_traffic_light = rlTrafficLight_ ? 1 : 0;
+    cc.lane_change = 0;
+    cc.device = 0;
+    if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);
+    if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) cc.device = atoi(dev);
+    int32_t rc = be_.cfx_create(&net_.flat(), &cc, &dev_);
+    if (rc != CFX_OK || !dev_) {
+        const char *msg = be_.cfx_last_error(nullptr);
+        throw std::runtime_error(std::string("cityflow_amd: cfx_create failed in ") + be_.path + ": " +
+                                 (msg ? msg : "unknown error") + " (there is no CPU fallback)");
+    }
+    spawner_.setFinishedQuery([this](int vid) {
+        uint8_t st = 0;
+        check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
+        return st == 2;
+    });
+    uploadNewTablesIfAny();
+}
+
+EngineHost::~EngineHost() {
+    if (dev_) be_.cfx_destroy(dev_);
+}
+
+void EngineHost::check(int32_t rc, const char *what) {
+    if (rc == CFX_OK) return;
+    const char *msg = be_.cfx_last_error(dev_);
+    throw std::runtime_error(std::string("cityflow_amd: ") + what + " failed (" + std::to_string(rc) + "): " +
+                             (msg ? msg : ""));
+}
+
+void EngineHost::uploadNewTablesIfAny() {
+    int nt = (int) spawner_.templates.size();
+    if (nt > templatesUploaded_) {
+        check(be_.cfx_add_templates(dev_, nt - templatesUploaded_, spawner_.templates.data() + templatesUploaded_),
+              "cfx_add_templates");
+        templatesUploaded_ = nt;
+    }
+    const RouteTable &rt = spawner_.routes;
+    int nr = rt.count();
+    if (nr > routesUploaded_) {
+        // rebase the CSR slices of the new routes to 0
+        int r0 = routesUploaded_;
+        int roadBase = rt.routeStart[r0];
+        int nextBase = rt.nextStart[roadBase];
+        std::vector<int32_t> routeStart, nextStart;
+        for (int r = r0; r <= nr; ++r) routeStart.push_back(rt.routeStart[r] - roadBase);
+        int nPos = rt.routeStart[nr] - roadBase;
+        for (int p = 0; p <= nPos; ++p) nextStart.push_back(rt.nextStart[roadBase + p] - nextBase);
+        check(be_.cfx_add_routes(dev_, nr - r0, routeStart.data(), rt.roads.data() + roadBase, nextStart.data(),
+                                 rt.nextLL.data() + nextBase),
+              "cfx_add_routes");
+        routesUploaded_ = nr;
+    }
+}
+
+// ---------------------------------------------------------------- stepping
+void EngineHost::nextStep() {
+    spawner_.step(step_, spawnBuf_);
+    uploadNewTablesIfAny();
+    check(be_.cfx_step(dev_, spawnBuf_.data(), (int32_t) spawnBuf_.size()), "cfx_step");
+    step_ += 1;
+}
+
+void EngineHost::sync() { check(be_.cfx_sync(dev_), "cfx_sync"); }
+
+cfx_scalars EngineHost::scalars() {
+    cfx_scalars s{};
+    check(be_.cfx_get_scalars(dev_, &s), "cfx_get_scalars");
+    return s;
+}
+
+void EngineHost::reset(bool resetRnd) {
+    check(be_.cfx_reset(dev_), "cfx_reset");
+    spawner_.reset(resetRnd);
+    step_ = 0;
+}
+
+// ---------------------------------------------------------------- getters
+size_t EngineHost::getVehicleCount() { return (size_t) scalars().active_vehicle_count; }
+
+std::vector<int32_t> EngineHost::laneVehicleCountArray() {
+    std::vector<int32_t> out(net_.lanes.size());
+    check(be_.cfx_get_lane_counts(dev_, out.data()), "cfx_get_lane_counts");
+    return out;
+}
+
+std::vector<int32_t> EngineHost::laneWaitingVehicleCountArray() {
+    std::vector<int32_t> out(net_.lanes.size());
+    check(be_.cfx_get_lane_waiting_counts(dev_, out.data()), "cfx_get_lane_waiting_counts");
+    return out;
+}
+
+std::vector<std::string> EngineHost::laneIds() const {
+    std::vector<std::string> ids(net_.lanes.size());
+    for (size_t l = 0; l < ids.size(); ++l) ids[l] = net_.laneId((int) l);
+    return ids;
+}
+
+std::vector<std::string> EngineHost::intersectionIds() const {
+    std::vector<std::string> ids(net_.inters.size());
+    for (size_t i = 0; i < ids.size(); ++i) ids[i] = net_.inters[i].id;
+    return ids;
+}
+
+std::map<std::string, int> EngineHost::getLaneVehicleCount() {
+    std::vector<int32_t> cnt = laneVehicleCountArray();
+    std::map<std::string, int> ret;
+    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_.laneId((int) l), cnt[l]);
+    return ret;
+}
+
+std::map<std::string, int> EngineHost::getLaneWaitingVehicleCount() {
+    std::vector<int32_t> cnt = laneWaitingVehicleCountArray();
+    std::map<std::string, int> ret;
+    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_.laneId((int) l), cnt[l]);
+    return ret;
+}
+
+void EngineHost::snapshotVehicles(VehicleSnapshot &s) {
+    int cap = (int) scalars().active_vehicle_count + 16;
+    s.vid.resize(cap);
+    s.drivable.resize(cap);
+    s.prevDrivable.resize(cap);
+    s.leader.resize(cap);
+    s.blocker.resize(cap);
+    s.enterLLTime.resize(cap);
+    s.routePos.resize(cap);
+    s.dis.resize(cap);
+    s.speed.resize(cap);
+    s.gap.resize(cap);
+    cfx_vehicle_view v{};
+    v.capacity = cap;
+    v.vid = s.vid.data();
+    v.drivable = s.drivable.data();
+    v.prev_drivable = s.prevDrivable.data();
+    v.leader_vid = s.leader.data();
+    v.blocker_vid = s.blocker.data();
+    v.enter_ll_time = s.enterLLTime.data();
+    v.route_pos = s.routePos.data();
+    v.dis = s.dis.data();
+    v.speed = s.speed.data();
+    v.gap = s.gap.data();
+    check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
+    s.count = v.count;
+    for (auto *vec : {&s.vid, &s.drivable, &s.prevDrivable, &s.leader, &s.blocker, &s.enterLLTime, &s.routePos})
+        vec->resize(v.count);
+    s.dis.resize(v.count);
+    s.speed.resize(v.count);
+    s.gap.resize(v.count);
+}
+
+void EngineHost::waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane) {
+    cfx_scalars sc = scalars();
+    int cap = (int) (sc.spawned_vehicle_count - sc.finished_vehicle_count - sc.active_vehicle_count) + 16;
+    vid.resize(cap);
+    lane.resize(cap);
+    int32_t n = 0;
+    check(be_.cfx_get_waiting(dev_, cap, vid.data(), lane.data(), &n), "cfx_get_waiting");
+    vid.resize(n);
+    lane.resize(n);
+}
+
+// getVehicles engine.cpp:619-626 — vehiclePool (priority) order
+std::vector<std::string> EngineHost::getVehicles(bool includeWaiting) {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::vector<std::pair<int32_t, int32_t>> byPriority;
+    for (int i = 0; i < s.count; ++i) byPriority.emplace_back(spawner_.vehicles[s.vid[i]].priority, s.vid[i]);
+    if (includeWaiting) {
+        std::vector<int32_t> wv, wl;
+        waitingVehicles(wv, wl);
+        for (int32_t v : wv) byPriority.emplace_back(spawner_.vehicles[v].priority, v);
+    }
+    std::sort(byPriority.begin(), byPriority.end());
+    std::vector<std::string> ret;
+    ret.reserve(byPriority.size());
+    for (auto &p : byPriority) ret.emplace_back(spawner_.vehicleId(p.second));
+    return ret;
+}
+
+std::map<std::string, std::vector<std::string>> EngineHost::getLaneVehicles() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::map<std::string, std::vector<std::string>> ret;
+    const int L = (int) net_.lanes.size();
+    std::vector<std::vector<std::string>> perLane(L);
+    for (int i = 0; i < s.count; ++i)
+        if (s.drivable[i] < L) perLane[s.drivable[i]].push_back(spawner_.vehicleId(s.vid[i]));
+    for (int l = 0; l < L; ++l) ret.emplace(net_.laneId(l), std::move(perLane[l]));
+    return ret;
+}
+
+std::map<std::string, double> EngineHost::getVehicleSpeed() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::map<std::string, double> ret;
+    for (int i = 0; i < s.count; ++i) ret.emplace(spawner_.vehicleId(s.vid[i]), s.speed[i]);
+    return ret;
+}
+
+std::map<std::string, double> EngineHost::getVehicleDistance() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::map<std::string, double> ret;
+    for (int i = 0; i < s.count; ++i) ret.emplace(spawner_.vehicleId(s.vid[i]), s.dis[i]);
+    return ret;
+}
+
+int EngineHost::vidOf(const std::string &id) {
+    auto number = [](const std::string &t, int &out) {
+        if (t.empty() || t.size() > 9) return false;
+        for (char c : t)
+            if (c < '0' || c > '9') return false;
+        out = atoi(t.c_str());
+        return std::to_string(out) == t;
+    };
+    const std::string mp = "manually_pushed_";
+    int n = 0;
+    if (id.compare(0, mp.size(), mp) == 0) {
+        if (!number(id.substr(mp.size()), n) || n >= (int) spawner_.manualVids.size()) return -1;
+        return spawner_.manualVids[n];
+    }
+    if (id.compare(0, 5, "flow_") != 0) return -1;
+    size_t us = id.find('_', 5);
+    if (us == std::string::npos) return -1;
+    int f = 0;
+    if (!number(id.substr(5, us - 5), f) || !number(id.substr(us + 1), n)) return -1;
+    if (f >= (int) spawner_.flowVids.size() || n >= (int) spawner_.flowVids[f].size()) return -1;
+    return spawner_.flowVids[f][n];
+}
+
+// getLeader engine.cpp:836-850
+std::string EngineHost::getLeader(const std::string &vehicleId) {
+    int vid = vidOf(vehicleId);
+    uint8_t st = 2;
+    if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
+    if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
+    if (st == 0) return "";
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    for (int i = 0; i < s.count; ++i)
+        if (s.vid[i] == vid) return s.leader[i] >= 0 ? spawner_.vehicleId(s.leader[i]) : "";
+    return "";
+}
+
+// Vehicle::getInfo vehicle.cpp:435-457
+std::map<std::string, std::string> EngineHost::getVehicleInfo(const std::string &vehicleId) {
+    int vid = vidOf(vehicleId);
+    uint8_t st = 2;
+    if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
+    if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
+    std::map<std::string, std::string> info;
+    info["running"] = std::to_string(st == 1);
+    if (st != 1) return info;
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    for (int i = 0; i < s.count; ++i) {
+        if (s.vid[i] != vid) continue;
+        info["distance"] = std::to_string(s.dis[i]);
+        info["speed"] = std::to_string(s.speed[i]);
+        info["drivable"] = net_.drivableId(s.drivable[i]);
+        if (s.drivable[i] < (int) net_.lanes.size()) {
+            const HostRoad &road = net_.roads[net_.lanes[s.drivable[i]].road];
+            info["road"] = road.id;
+            info["intersection"] = net_.inters[road.endInter].id;
+        }
+        const RouteTable &rt = spawner_.routes;
+        int r = spawner_.vehicles[vid].route;
+        std::string route;
+        for (int p = rt.routeStart[r] + s.routePos[i]; p < rt.routeStart[r + 1]; ++p)
+            route += net_.roads[rt.roads[p]].id + " ";
+        info["route"] = route;
+    }
+    return info;
+}
+
+// getAverageTravelTime engine.cpp:682-691: same summation order (vehiclePool = ascending priority),
+// so the result is bit-identical to the single-threaded reference for any interval.
+double EngineHost::getAverageTravelTime() {
+    cfx_scalars sc = scalars();
+    double tt = sc.cumulative_travel_time;
+    int64_t n = sc.finished_vehicle_count;
+    int total = (int) spawner_.vehicles.size();
+    std::vector<uint8_t> st(total);
+    if (total) check(be_.cfx_get_vehicle_status(dev_, 0, total, st.data()), "cfx_get_vehicle_status");
+    std::vector<std::pair<int32_t, double>> live;
+    for (int v = 0; v < total; ++v)
+        if (st[v] != 2) live.emplace_back(spawner_.vehicles[v].priority, spawner_.vehicles[v].enterTime);
+    std::sort(live.begin(), live.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) {
+        return a.first < b.first;
+    });
+    double now = getCurrentTime();
+    for (auto &p : live) {
+        tt += now - p.second;
+        n++;
+    }
+    return n == 0 ? 0 : tt / n;
+}
+
+// ---------------------------------------------------------------- control
+void EngineHost::setTrafficLightPhaseIndexed(int inter, int phase) {
+    check(be_.cfx_set_tl_phase(dev_, inter, phase), "cfx_set_tl_phase");
+}
+
+// setTrafficLightPhase engine.cpp:719-725
+void EngineHost::setTrafficLightPhase(const std::string &id, int phaseIndex) {
+    if (!rlTrafficLight_) {
+        std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
+        return;
+    }
+    auto it = net_.interIndex.find(id);
+    if (it == net_.interIndex.end()) throw std::runtime_error("Intersection '" + id + "' not found");
+    const HostInter &in = net_.inters[it->second];
+    if (in.isVirtual || phaseIndex < 0 || phaseIndex >= (int) in.phases.size())
+        throw std::out_of_range("phase index " + std::to_string(phaseIndex) + " out of range for intersection '" + id + "'");
+    setTrafficLightPhaseIndexed(it->second, phaseIndex);
+}
+
+void EngineHost::trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain) {
+    phase.resize(net_.inters.size());
+    remain.resize(net_.inters.size());
+    check(be_.cfx_get_tl_state(dev_, phase.data(), remain.data()), "cfx_get_tl_state");
+}
+
+// pushVehicle(map, vector) engine.cpp:693-717
+void EngineHost::pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads) {
+    auto get = [&info](const char *k, double d) {
+        auto it = info.find(k);
+        return it == info.end() ? d : it->second;
+    };
+    // VehicleInfo defaults vehicle.h:31-45
+    cfx_vehicle_template t = spawner_.makeTemplate(get("length", 5), get("width", 2), get("maxPosAcc", 4.5),
+                                                   get("maxNegAcc", 4.5), get("usualPosAcc", 2.5), get("usualNegAcc", 2.5),
+                                                   get("minGap", 2), get("maxSpeed", 16.66667), get("headwayTime", 1));
+    if (info.count("speed") && info.at("speed") != 0)
+        throw std::runtime_error("cityflow_amd: push_vehicle with a non-zero initial speed is not supported yet");
+    std::vector<int> anchors;
+    for (auto &r : roads) {
+        auto it = net_.roadIndex.find(r);
+        if (it == net_.roadIndex.end()) throw std::runtime_error("Road '" + r + "' not found");
+        anchors.push_back(it->second);
+    }
+    if (anchors.empty()) throw std::runtime_error("push_vehicle: empty route");
+    spawner_.pushManual(spawner_.addTemplate(t), anchors, step_);
+}
+
+}  // namespace cfa

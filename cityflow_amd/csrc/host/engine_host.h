@@ -1,0 +1,120 @@
+// C++ host of the drop-in `cityflow.Engine` (reference src/engine/engine.h:114-183, bound by
+// src/cityflow.cpp:11-38).  It keeps everything that involves strings, JSON and the mt19937 stream on
+// the CPU and drives the device engine exclusively through the C ABI of include/cityflow_amd.h, which
+// it resolves from a shared library at run time:
+//   * default: <package dir>/lib/libcfx_hip.so  — the HIP/gfx950 implementation (the product);
+//   * tests may name another library exporting the same ABI (the CPU twin under oracle/).
+// There is no CPU fallback: if the library cannot be loaded or cfx_create fails the constructor throws.
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cityflow_amd.h"
+#include "flow.h"
+#include "roadnet.h"
+
+namespace cfa {
+
+struct Backend {
+    void *handle = nullptr;
+    std::string path;
+#define CFX_FN(name) decltype(&::name) name = nullptr;
+    CFX_FN(cfx_abi_version)
+    CFX_FN(cfx_create)
+    CFX_FN(cfx_destroy)
+    CFX_FN(cfx_last_error)
+    CFX_FN(cfx_backend_name)
+    CFX_FN(cfx_add_templates)
+    CFX_FN(cfx_add_routes)
+    CFX_FN(cfx_step)
+    CFX_FN(cfx_sync)
+    CFX_FN(cfx_reset)
+    CFX_FN(cfx_set_tl_phase)
+    CFX_FN(cfx_get_tl_state)
+    CFX_FN(cfx_get_scalars)
+    CFX_FN(cfx_get_lane_counts)
+    CFX_FN(cfx_get_lane_waiting_counts)
+    CFX_FN(cfx_get_vehicles)
+    CFX_FN(cfx_get_waiting)
+    CFX_FN(cfx_get_vehicle_status)
+#undef CFX_FN
+    void open(const std::string &libPath);  // throws std::runtime_error
+    ~Backend();
+};
+
+// Per-vehicle state downloaded from the device, in Drivable::vehicles order.
+struct VehicleSnapshot {
+    std::vector<int32_t> vid, drivable, prevDrivable, leader, blocker, enterLLTime, routePos;
+    std::vector<double> dis, speed, gap;
+    int count = 0;
+};
+
+class EngineHost {
+public:
+    EngineHost(const std::string &configFile, int threadNum, const std::string &backendLib = "");
+    ~EngineHost();
+    EngineHost(const EngineHost &) = delete;
+    EngineHost &operator=(const EngineHost &) = delete;
+
+    // ---- reference API (engine.h:139-182) ----
+    void nextStep();
+    size_t getVehicleCount();
+    std::vector<std::string> getVehicles(bool includeWaiting);
+    std::map<std::string, int> getLaneVehicleCount();
+    std::map<std::string, int> getLaneWaitingVehicleCount();
+    std::map<std::string, std::vector<std::string>> getLaneVehicles();
+    std::map<std::string, double> getVehicleSpeed();
+    std::map<std::string, double> getVehicleDistance();
+    std::string getLeader(const std::string &vehicleId);
+    std::map<std::string, std::string> getVehicleInfo(const std::string &vehicleId);
+    double getCurrentTime() const { return step_ * interval_; }
+    double getAverageTravelTime();
+    void setTrafficLightPhase(const std::string &id, int phaseIndex);
+    void setRandomSeed(int seed) { spawner_.seed(seed); }
+    void pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads);
+    void reset(bool resetRnd);
+
+    // ---- array getters (no string marshalling; for large grids / RL observation tensors) ----
+    std::vector<int32_t> laneVehicleCountArray();
+    std::vector<int32_t> laneWaitingVehicleCountArray();
+    std::vector<std::string> laneIds() const;          // index -> id for the two arrays above
+    std::vector<std::string> intersectionIds() const;
+    void setTrafficLightPhaseIndexed(int inter, int phase);
+    void trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain);
+    void snapshotVehicles(VehicleSnapshot &out);
+    void waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane);
+    cfx_scalars scalars();
+    void sync();
+
+    const HostRoadNet &net() const { return net_; }
+    const Spawner &spawner() const { return spawner_; }
+    std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
+    std::string vehicleId(int vid) const { return spawner_.vehicleId(vid); }
+    int vidOf(const std::string &id);  // -1 if unknown
+    double interval() const { return interval_; }
+    size_t step() const { return step_; }
+
+private:
+    void check(int32_t rc, const char *what);
+    void uploadNewTablesIfAny();
+
+    HostRoadNet net_;
+    Spawner spawner_;
+    Backend be_;
+    cfx_engine *dev_ = nullptr;
+    double interval_ = 1.0;
+    bool rlTrafficLight_ = false, laneChange_ = false, saveReplay_ = false;
+    int seed_ = 0, threadNum_ = 1;
+    std::string dir_;
+    size_t step_ = 0;
+    int templatesUploaded_ = 0, routesUploaded_ = 0;
+    std::vector<cfx_spawn> spawnBuf_;
+    std::map<std::string, int> manualIds_;  // manually_pushed_<n> -> vid
+};
+
+std::string defaultBackendPath();  // <dir of this shared object>/lib/libcfx_hip.so
+
+}  // namespace cfa

@@ -1,0 +1,294 @@
+#include "flow.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <queue>
+#include <set>
+
+#include "json.h"
+
+namespace cfa {
+
+// Per-position next-laneLink table: the value Router::getNextDrivable(const Drivable*) (router.cpp:49-76)
+// returns for a lane of road[p], with the selection rule of selectLaneIndex (router.cpp:96-111):
+// first candidate with the smallest |endLaneIndex - curLaneIndex|.
+int RouteTable::add(const HostRoadNet &net, const std::vector<int> &seq) {
+    const int n = (int) seq.size();
+    for (int p = 0; p < n; ++p) {
+        roads.push_back(seq[p]);
+        const HostRoad &road = net.roads[seq[p]];
+        for (int j = 0; j < road.nLanes; ++j) {
+            int lane = road.laneStart + j;
+            int chosen = -1;
+            if (p < n - 1) {
+                std::vector<int> cands = net.laneLinksToRoad(lane, seq[p + 1]);
+                if (p < n - 2) {
+                    std::vector<int> filtered;
+                    for (int ll : cands)
+                        if (!net.laneLinksToRoad(net.laneLinks[ll].endLane, seq[p + 2]).empty()) filtered.push_back(ll);
+                    cands.swap(filtered);
+                }
+                int laneDiff = INT32_MAX;
+                for (int ll : cands) {
+                    int d = std::abs(net.lanes[net.laneLinks[ll].endLane].index - net.lanes[lane].index);
+                    if (d < laneDiff) {
+                        laneDiff = d;
+                        chosen = ll;
+                    }
+                }
+            }
+            nextLL.push_back(chosen);
+        }
+        nextStart.push_back((int32_t) nextLL.size());
+    }
+    routeStart.push_back((int32_t) roads.size());
+    // Router::getFirstDrivable router.cpp:23-37
+    std::vector<int32_t> first;
+    const HostRoad &r0 = net.roads[seq[0]];
+    for (int j = 0; j < r0.nLanes; ++j) {
+        int lane = r0.laneStart + j;
+        if (n == 1 || !net.laneLinksToRoad(lane, seq[1]).empty()) first.push_back(lane);
+    }
+    firstLanes.push_back(std::move(first));
+    return count() - 1;
+}
+
+void Spawner::init(const HostRoadNet *net, double interval, int threadNum, int seed) {
+    net_ = net;
+    interval_ = interval;
+    threadNum_ = threadNum < 1 ? 1 : threadNum;
+    seed_ = seed;
+    rnd.seed((std::mt19937::result_type) seed);
+    lastWaitVid_.assign(net->lanes.size(), -1);
+}
+
+cfx_vehicle_template Spawner::makeTemplate(double len, double width, double maxPosAcc, double maxNegAcc,
+                                           double usualPosAcc, double usualNegAcc, double minGap, double maxSpeed,
+                                           double headwayTime) const {
+    cfx_vehicle_template t{};
+    t.len = len;
+    t.width = width;
+    t.max_pos_acc = maxPosAcc;
+    t.max_neg_acc = maxNegAcc;
+    t.usual_pos_acc = usualPosAcc;
+    t.usual_neg_acc = usualNegAcc;
+    t.min_gap = minGap;
+    t.max_speed = maxSpeed;
+    t.headway_time = headwayTime;
+    t.yield_distance = 5;    // VehicleInfo defaults vehicle.h:42-43 (not settable from flow JSON)
+    t.turn_speed = 8.3333;
+    // vehicle.cpp:42-44, same grouping
+    t.approach_dist = maxSpeed * maxSpeed / usualNegAcc / 2 + maxSpeed * interval_ * 2;
+    return t;
+}
+
+int Spawner::addTemplate(const cfx_vehicle_template &t) {
+    for (size_t i = 0; i < templates.size(); ++i)
+        if (memcmp(&templates[i], &t, sizeof t) == 0) return (int) i;
+    templates.push_back(t);
+    return (int) templates.size() - 1;
+}
+
+// Router::dijkstra router.cpp:160-226 on road indices.  Same container types and the same push order,
+// so equal-cost ties resolve exactly as in the reference's std::priority_queue.
+static bool dijkstra(const HostRoadNet &net, int start, int end, std::vector<int> &buffer) {
+    std::map<int, double> dis;
+    std::map<int, int> from;
+    std::set<int> visited;
+    bool success = false;
+    using pair = std::pair<int, double>;
+    auto cmp = [](const pair &a, const pair &b) { return a.second > b.second; };
+    std::priority_queue<pair, std::vector<pair>, decltype(cmp)> queue(cmp);
+
+    dis[start] = 0;
+    queue.push(std::make_pair(start, 0));
+    while (!queue.empty()) {
+        int cur = queue.top().first;
+        if (cur == end) {
+            success = true;
+            break;
+        }
+        queue.pop();
+        if (visited.count(cur)) continue;
+        visited.insert(cur);
+        double curDis = dis.find(cur)->second;
+        for (int adj : net.inters[net.roads[cur].endInter].roads) {
+            if (!net.connectedToRoad(cur, adj)) continue;
+            auto iter = dis.find(adj);
+            double newDis = curDis + net.averageLength(adj);
+            if (iter == dis.end() || newDis < iter->second) {
+                from[adj] = cur;
+                dis[adj] = newDis;
+                queue.emplace(std::make_pair(adj, newDis));
+            }
+        }
+    }
+    std::vector<int> path;
+    path.push_back(end);
+    auto iter = from.find(end);
+    while (iter != from.end() && iter->second != start) {
+        path.emplace_back(iter->second);
+        iter = from.find(iter->second);
+    }
+    buffer.insert(buffer.end(), path.rbegin(), path.rend());
+    return success;
+}
+
+// Router::updateShortestPath router.cpp:228-243
+bool Spawner::expandRoute(const std::vector<int> &anchors, std::vector<int> &out) const {
+    out.clear();
+    if (anchors.empty()) return false;
+    out.push_back(anchors[0]);
+    for (size_t i = 1; i < anchors.size(); ++i) {
+        if (anchors[i - 1] == anchors[i]) continue;
+        if (!dijkstra(*net_, anchors[i - 1], anchors[i], out)) return false;
+    }
+    return out.size() > 1;
+}
+
+void Spawner::loadFlows(const std::string &path) {
+    Json root = Json::parseFile(path);
+    if (!root.isArray()) throw JsonError("flow file: expected type array");
+    for (size_t i = 0; i < root.items.size(); ++i) {
+        const Json &fv = root.items[i];
+        HostFlow f;
+        f.id = "flow_" + std::to_string(i);
+        for (const Json &r : fv.arrayAt("route").items) {
+            if (!r.isString()) throw JsonError("route: expected type string");
+            auto it = net_->roadIndex.find(r.s);
+            if (it == net_->roadIndex.end()) throw JsonError("No such road: " + r.s);
+            f.anchors.push_back(it->second);
+        }
+        if (f.anchors.empty()) throw JsonError("flow[" + std::to_string(i) + "]: empty route");
+        const Json &v = fv.objectAt("vehicle");
+        f.templ = addTemplate(makeTemplate(v.numberAt("length"), v.numberAt("width"), v.numberAt("maxPosAcc"),
+                                           v.numberAt("maxNegAcc"), v.numberAt("usualPosAcc"), v.numberAt("usualNegAcc"),
+                                           v.numberAt("minGap"), v.numberAt("maxSpeed"), v.numberAt("headwayTime")));
+        f.startTime = fv.intAt("startTime", 0);
+        f.endTime = fv.intAt("endTime", -1);
+        f.interval = fv.numberAt("interval");
+        f.nowTime = f.interval;  // Flow ctor flow.h:30-36
+        std::vector<int> seq;
+        f.route = expandRoute(f.anchors, seq) ? routes.add(*net_, seq) : -1;
+        flows.push_back(std::move(f));
+    }
+    flowVids.assign(flows.size(), {});
+}
+
+std::string Spawner::vehicleId(int vid) const {
+    const VehicleRecord &r = vehicles[vid];
+    if (r.flow >= 0) return flows[r.flow].id + "_" + std::to_string(r.number);
+    return "manually_pushed_" + std::to_string(r.number);
+}
+
+// Vehicle ctor priority loop (vehicle.cpp:45) + the extra draw of Engine::pushVehicle (engine.cpp:606).
+int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> &anchors, int route, size_t stepIndex,
+                        const std::function<bool(int)> &isFinished) {
+    int32_t priority;
+    for (;;) {
+        priority = (int32_t) rnd();
+        auto it = livePriority_.find(priority);
+        if (it == livePriority_.end()) break;
+        // Host bookkeeping is a superset of the live set; settle it exactly before redrawing.
+        if (it->second >= 0 && isFinished && isFinished(it->second)) {
+            livePriority_.erase(it);
+            break;
+        }
+    }
+    (void) (rnd() % (std::mt19937::result_type) threadNum_);
+    VehicleRecord rec{};
+    rec.priority = priority;
+    rec.flow = flow;
+    rec.number = number;
+    rec.templ = templ;
+    rec.route = route;
+    rec.enterTime = stepIndex * interval_;  // Engine::getCurrentTime engine.cpp:678-680
+    pendingRecords_.push_back(rec);
+    livePriority_[priority] = -1;
+    Pending p;
+    p.index = (int) pendingRecords_.size() - 1;
+    p.firstRoad = anchors[0];
+    pending_.push_back(p);
+    return p.index;
+}
+
+void Spawner::pushManual(int templ, const std::vector<int> &anchors, size_t stepIndex) {
+    std::vector<int> seq;
+    int route = expandRoute(anchors, seq) ? routes.add(*net_, seq) : -1;
+    newVehicle(-1, manualCnt_++, templ, anchors, route, stepIndex, isFinished_);
+}
+
+void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
+    out.clear();
+    // phase 0: Flow::nextStep for every flow in order (engine.cpp:567-568)
+    for (size_t fi = 0; fi < flows.size(); ++fi) {
+        HostFlow &f = flows[fi];
+        if (!f.valid) continue;
+        if (f.endTime != -1 && f.currentTime > f.endTime) continue;
+        if (f.currentTime >= f.startTime) {
+            while (f.nowTime >= f.interval) {
+                newVehicle((int) fi, f.cnt++, f.templ, f.anchors, f.route, stepIndex, isFinished_);
+                f.nowTime -= f.interval;
+            }
+            f.nowTime += interval_;
+        }
+        f.currentTime += interval_;
+    }
+    // phase 1: Engine::planRoute — roads in JSON order, vehicles in buffer order
+    std::stable_sort(pending_.begin(), pending_.end(),
+                     [](const Pending &a, const Pending &b) { return a.firstRoad < b.firstRoad; });
+    for (const Pending &p : pending_) {
+        VehicleRecord &rec = pendingRecords_[p.index];
+        if (rec.route >= 0) {
+            const std::vector<int32_t> &cands = routes.firstLanes[rec.route];
+            int lane = cands[rnd() % cands.size()];
+            int vid = (int) vehicles.size();
+            vehicles.push_back(rec);
+            livePriority_[rec.priority] = vid;
+            {
+                std::vector<int32_t> &tbl = rec.flow >= 0 ? flowVids[rec.flow] : manualVids;
+                if ((int) tbl.size() <= rec.number) tbl.resize(rec.number + 1, -1);
+                tbl[rec.number] = vid;
+            }
+            cfx_spawn s{};
+            s.vid = vid;
+            s.priority = rec.priority;
+            s.templ = rec.templ;
+            s.route = rec.route;
+            s.lane = lane;
+            s.prev_wait = lastWaitVid_[lane];
+            s.enter_time = rec.enterTime;
+            lastWaitVid_[lane] = vid;
+            out.push_back(s);
+        } else {
+            if (rec.flow >= 0 && flows[rec.flow].valid) {
+                std::cerr << "[warning] Invalid route '" << flows[rec.flow].id << "'. Omitted by default." << std::endl;
+                flows[rec.flow].valid = false;
+            }
+            livePriority_.erase(rec.priority);
+        }
+    }
+    pending_.clear();
+    pendingRecords_.clear();
+}
+
+void Spawner::reset(bool reseed) {
+    for (HostFlow &f : flows) {  // Flow::reset flow.cpp:28-32 (valid is NOT restored)
+        f.nowTime = f.interval;
+        f.currentTime = 0;
+        f.cnt = 0;
+    }
+    vehicles.clear();
+    for (auto &v : flowVids) v.clear();
+    std::fill(manualVids.begin(), manualVids.end(), -1);
+    livePriority_.clear();
+    pending_.clear();
+    pendingRecords_.clear();
+    std::fill(lastWaitVid_.begin(), lastWaitVid_.end(), -1);
+    if (reseed) rnd.seed((std::mt19937::result_type) seed_);
+}
+
+}  // namespace cfa

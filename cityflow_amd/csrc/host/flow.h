@@ -1,0 +1,116 @@
+// Host-side flows, routes and the spawner.
+//
+// The spawner is the exact twin of the reference's per-step vehicle creation: it owns the engine's
+// std::mt19937 and draws from it in the reference's order:
+//   Flow::nextStep            flow.cpp:6-22      cadence, id flow_<i>_<cnt>
+//   Vehicle::Vehicle          vehicle.cpp:38-47  priority = rnd() until unused
+//   Engine::pushVehicle       engine.cpp:605-613 one more rnd() (% threadNum, value unused)
+//   Engine::planRoute         engine.cpp:450-470 per road in JSON order, per vehicle in buffer order:
+//   Router::getFirstDrivable  router.cpp:23-37   first lane = candidates[rnd() % n]
+// Route expansion (Router::updateShortestPath router.cpp:228-243, dijkstra 160-226) is static for the
+// LENGTH metric, so it is evaluated once per flow / per pushed vehicle instead of once per spawn.
+#pragma once
+
+#include <functional>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "cityflow_amd.h"
+#include "roadnet.h"
+
+namespace cfa {
+
+struct RouteTable {
+    // CSR tables in the layout cfx_add_routes expects
+    std::vector<int32_t> routeStart{0};
+    std::vector<int32_t> roads;
+    std::vector<int32_t> nextStart{0};
+    std::vector<int32_t> nextLL;
+    // host-only: candidate first lanes per route (Router::getFirstDrivable)
+    std::vector<std::vector<int32_t>> firstLanes;
+
+    int count() const { return (int) routeStart.size() - 1; }
+    // Appends an (already expanded) road sequence and returns its route index.
+    int add(const HostRoadNet &net, const std::vector<int> &roadSeq);
+};
+
+struct HostFlow {
+    std::string id;
+    int templ = -1;
+    std::vector<int> anchors;
+    int route = -1;  // -1: Dijkstra failed / route.size() <= 1  => invalid flow
+    double interval = 0;
+    int startTime = 0, endTime = -1;
+    // dynamic state (Flow fields flow.h:23-31)
+    double nowTime = 0, currentTime = 0;
+    int cnt = 0;
+    bool valid = true;
+};
+
+// What the host remembers about every vehicle it ever spawned (index = vid).
+struct VehicleRecord {
+    int32_t priority;
+    int32_t flow;      // -1 for push_vehicle
+    int32_t number;    // per-flow counter or manuallyPushCnt value
+    int32_t templ, route;
+    double enterTime;
+};
+
+class Spawner {
+public:
+    std::vector<cfx_vehicle_template> templates;
+    RouteTable routes;
+    std::vector<HostFlow> flows;
+    std::vector<VehicleRecord> vehicles;  // by vid, since the last reset
+    std::vector<std::vector<int32_t>> flowVids;  // [flow][per-flow number] -> vid (-1: dropped, invalid route)
+    std::vector<int32_t> manualVids;             // [manuallyPushCnt value] -> vid or -1
+    std::mt19937 rnd;
+
+    void init(const HostRoadNet *net, double interval, int threadNum, int seed);
+    void loadFlows(const std::string &path);  // Engine::loadFlow engine.cpp:106-164
+
+    // Expand anchors into a road route; returns false when the reference would mark it invalid.
+    bool expandRoute(const std::vector<int> &anchors, std::vector<int> &out) const;
+    int addTemplate(const cfx_vehicle_template &t);  // dedupes identical templates
+    cfx_vehicle_template makeTemplate(double len, double width, double maxPosAcc, double maxNegAcc, double usualPosAcc,
+                                      double usualNegAcc, double minGap, double maxSpeed, double headwayTime) const;
+
+    // push_vehicle (engine.cpp:693-717): queued into the first road's planRouteBuffer until the next step.
+    void pushManual(int templ, const std::vector<int> &anchors, size_t step);
+
+    // One step worth of spawn records (phases 0-1 of Engine::nextStep).
+    void step(size_t stepIndex, std::vector<cfx_spawn> &out);
+
+    // `isFinished(vid)` is consulted only when a freshly drawn priority collides with a vehicle the
+    // host still believes alive (the host does not see vehicles finish; the device does).
+    void setFinishedQuery(std::function<bool(int)> q) { isFinished_ = std::move(q); }
+
+    void reset(bool reseed);  // Engine::reset engine.cpp:744-760 (flows, vehicles; RNG only if reseed)
+    void seed(int s) { rnd.seed((std::mt19937::result_type) s); }
+
+    std::string vehicleId(int vid) const;
+    int initialSeed() const { return seed_; }
+
+private:
+    struct Pending {
+        int index;  // into pendingRecords_
+        int firstRoad;
+    };
+    int newVehicle(int flow, int number, int templ, const std::vector<int> &anchors, int route, size_t stepIndex,
+                   const std::function<bool(int)> &isFinished);
+
+    const HostRoadNet *net_ = nullptr;
+    double interval_ = 1.0;
+    int threadNum_ = 1;
+    int seed_ = 0;
+    int manualCnt_ = 0;
+    std::function<bool(int)> isFinished_;
+    std::vector<Pending> pending_;                 // planRouteBuffer contents, in push order
+    std::vector<VehicleRecord> pendingRecords_;
+    std::vector<int32_t> lastWaitVid_;             // per lane: last vid pushed to its waitingBuffer
+    std::unordered_map<int32_t, int32_t> livePriority_;  // priority -> vid (superset of live vehicles)
+};
+
+}  // namespace cfa

@@ -1,0 +1,272 @@
+// Minimal JSON DOM for the host loader (config / roadnet / flow files).
+//
+// Numbers are converted with correctly rounded strtod(); integer literals keep an exact int64.
+// (The reference reads JSON through rapidjson, which is an empty submodule in the reference tree —
+// see DESIGN.md "parity unpinned at the JSON-number boundary".)
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace cfa {
+
+struct JsonError : std::runtime_error {
+    explicit JsonError(const std::string &m) : std::runtime_error(m) {}
+};
+
+class Json {
+public:
+    enum Kind : uint8_t { Null, False, True, Number, String, Array, Object };
+
+    Kind kind = Null;
+    bool integral = false;
+    int64_t i = 0;
+    double d = 0;
+    std::string s;
+    std::vector<Json> items;                             // Array
+    std::vector<std::pair<std::string, Json>> members;   // Object (file order)
+
+    bool isObject() const { return kind == Object; }
+    bool isArray() const { return kind == Array; }
+    bool isString() const { return kind == String; }
+    bool isNumber() const { return kind == Number; }
+    bool isBool() const { return kind == True || kind == False; }
+    bool isInt() const { return kind == Number && integral && i >= INT32_MIN && i <= INT32_MAX; }
+
+    const Json *find(const char *name) const {
+        for (auto &m : members)
+            if (m.first == name) return &m.second;
+        return nullptr;
+    }
+    // Mirrors the reference's getJsonMember<T> error wording (utility.h:92-136) so config errors read alike.
+    const Json &at(const char *name) const {
+        const Json *v = find(name);
+        if (!v) throw JsonError(std::string(name) + " is required but missing in json file");
+        return *v;
+    }
+    double numberAt(const char *name) const {
+        const Json &v = at(name);
+        if (!v.isNumber()) throw JsonError(std::string(name) + ": expected type double");
+        return v.asDouble();
+    }
+    int intAt(const char *name) const {
+        const Json &v = at(name);
+        if (!v.isInt()) throw JsonError(std::string(name) + ": expected type int");
+        return (int) v.i;
+    }
+    int intAt(const char *name, int dflt) const {
+        const Json *v = find(name);
+        return (v && v->isInt()) ? (int) v->i : dflt;
+    }
+    bool boolAt(const char *name) const {
+        const Json &v = at(name);
+        if (!v.isBool()) throw JsonError(std::string(name) + ": expected type bool");
+        return v.kind == True;
+    }
+    bool boolAt(const char *name, bool dflt) const {
+        const Json *v = find(name);
+        return (v && v->isBool()) ? v->kind == True : dflt;
+    }
+    const std::string &stringAt(const char *name) const {
+        const Json &v = at(name);
+        if (!v.isString()) throw JsonError(std::string(name) + ": expected type string");
+        return v.s;
+    }
+    const Json &arrayAt(const char *name) const {
+        const Json &v = at(name);
+        if (!v.isArray()) throw JsonError(std::string(name) + ": expected type array");
+        return v;
+    }
+    const Json &objectAt(const char *name) const {
+        const Json &v = at(name);
+        if (!v.isObject()) throw JsonError(std::string(name) + ": expected type object");
+        return v;
+    }
+    double asDouble() const { return integral ? (double) i : d; }
+
+    static Json parseFile(const std::string &path) {
+        FILE *fp = fopen(path.c_str(), "rb");
+        if (!fp) throw JsonError("cannot open " + path);
+        std::string text;
+        char buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
+        fclose(fp);
+        return parseText(text);
+    }
+
+    static Json parseText(const std::string &text) {
+        Cursor c{text.data(), text.data() + text.size(), 1};
+        Json root;
+        c.value(root);
+        c.ws();
+        if (c.p != c.end) c.fail("trailing characters");
+        return root;
+    }
+
+private:
+    struct Cursor {
+        const char *p, *end;
+        size_t line;
+
+        [[noreturn]] void fail(const char *what) const {
+            throw JsonError("Json parsing error at line " + std::to_string(line) + ": " + what);
+        }
+        void ws() {
+            while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) {
+                if (*p == '\n') ++line;
+                ++p;
+            }
+        }
+        void expect(const char *lit) {
+            size_t n = strlen(lit);
+            if ((size_t) (end - p) < n || memcmp(p, lit, n) != 0) fail("invalid literal");
+            p += n;
+        }
+        void str(std::string &out) {
+            ++p;
+            for (;;) {
+                if (p >= end) fail("unterminated string");
+                char ch = *p++;
+                if (ch == '"') return;
+                if (ch != '\\') {
+                    out.push_back(ch);
+                    continue;
+                }
+                if (p >= end) fail("bad escape");
+                char e = *p++;
+                switch (e) {
+                    case 'n': out.push_back('\n'); break;
+                    case 't': out.push_back('\t'); break;
+                    case 'r': out.push_back('\r'); break;
+                    case 'b': out.push_back('\b'); break;
+                    case 'f': out.push_back('\f'); break;
+                    case 'u': {
+                        if (end - p < 4) fail("bad \\u escape");
+                        unsigned cp = (unsigned) strtoul(std::string(p, 4).c_str(), nullptr, 16);
+                        p += 4;
+                        if (cp < 0x80) out.push_back((char) cp);
+                        else if (cp < 0x800) {
+                            out.push_back((char) (0xC0 | (cp >> 6)));
+                            out.push_back((char) (0x80 | (cp & 0x3F)));
+                        } else {
+                            out.push_back((char) (0xE0 | (cp >> 12)));
+                            out.push_back((char) (0x80 | ((cp >> 6) & 0x3F)));
+                            out.push_back((char) (0x80 | (cp & 0x3F)));
+                        }
+                        break;
+                    }
+                    default: out.push_back(e);
+                }
+            }
+        }
+        void value(Json &v) {
+            ws();
+            if (p >= end) fail("unexpected end of input");
+            switch (*p) {
+                case '{': {
+                    ++p;
+                    v.kind = Object;
+                    ws();
+                    if (p < end && *p == '}') {
+                        ++p;
+                        return;
+                    }
+                    for (;;) {
+                        ws();
+                        if (p >= end || *p != '"') fail("expected member name");
+                        v.members.emplace_back();
+                        str(v.members.back().first);
+                        ws();
+                        if (p >= end || *p != ':') fail("expected ':'");
+                        ++p;
+                        value(v.members.back().second);
+                        ws();
+                        if (p < end && *p == ',') {
+                            ++p;
+                            continue;
+                        }
+                        if (p < end && *p == '}') {
+                            ++p;
+                            return;
+                        }
+                        fail("expected ',' or '}'");
+                    }
+                }
+                case '[': {
+                    ++p;
+                    v.kind = Array;
+                    ws();
+                    if (p < end && *p == ']') {
+                        ++p;
+                        return;
+                    }
+                    for (;;) {
+                        v.items.emplace_back();
+                        value(v.items.back());
+                        ws();
+                        if (p < end && *p == ',') {
+                            ++p;
+                            continue;
+                        }
+                        if (p < end && *p == ']') {
+                            ++p;
+                            return;
+                        }
+                        fail("expected ',' or ']'");
+                    }
+                }
+                case '"':
+                    v.kind = String;
+                    str(v.s);
+                    return;
+                case 't':
+                    expect("true");
+                    v.kind = True;
+                    return;
+                case 'f':
+                    expect("false");
+                    v.kind = False;
+                    return;
+                case 'n':
+                    expect("null");
+                    v.kind = Null;
+                    return;
+                default: {
+                    const char *s0 = p;
+                    bool integral = true;
+                    if (p < end && *p == '-') ++p;
+                    while (p < end) {
+                        char ch = *p;
+                        if (ch >= '0' && ch <= '9') {
+                        } else if (ch == '.' || ch == 'e' || ch == 'E' || ch == '+' || ch == '-') {
+                            integral = false;
+                        } else
+                            break;
+                        ++p;
+                    }
+                    if (p == s0 || (p == s0 + 1 && *s0 == '-')) fail("invalid value");
+                    std::string tok(s0, p - s0);
+                    v.kind = Number;
+                    if (integral && tok.size() <= 18) {
+                        v.integral = true;
+                        v.i = strtoll(tok.c_str(), nullptr, 10);
+                        v.d = (double) v.i;
+                    } else {
+                        v.integral = false;
+                        v.d = strtod(tok.c_str(), nullptr);
+                    }
+                    return;
+                }
+            }
+        }
+    };
+};
+
+}  // namespace cfa

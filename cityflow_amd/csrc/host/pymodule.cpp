@@ -1,0 +1,209 @@
+// pybind11 binding of the drop-in `cityflow` module.  Same class name, method names, argument names and
+// defaults as the reference binding (reference src/cityflow.cpp:10-47); extra members are prefixed or
+// clearly array-flavoured and never change the behaviour of the reference-named ones.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "engine_host.h"
+#include "json.h"
+
+namespace py = pybind11;
+using namespace py::literals;
+using cfa::EngineHost;
+
+namespace {
+
+template <typename T> py::array_t<T> toArray(const std::vector<T> &v) {
+    py::array_t<T> a((py::ssize_t) v.size());
+    if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(T));
+    return a;
+}
+template <typename T> py::array_t<T> toArray(const T *p, size_t n) {
+    py::array_t<T> a((py::ssize_t) n);
+    if (n) std::memcpy(a.mutable_data(), p, n * sizeof(T));
+    return a;
+}
+
+py::dict flatNetToDict(const cfa::HostRoadNet &net) {
+    const cfx_net &f = net.flat();
+    const int D = f.n_lanes + f.n_lanelinks;
+    py::dict d;
+    d["n_roads"] = f.n_roads;
+    d["n_lanes"] = f.n_lanes;
+    d["n_lanelinks"] = f.n_lanelinks;
+    d["n_inters"] = f.n_inters;
+    d["n_xentries"] = f.n_xentries;
+    d["drv_length"] = toArray(f.drv_length, D);
+    d["drv_max_speed"] = toArray(f.drv_max_speed, D);
+    d["lane_road"] = toArray(f.lane_road, f.n_lanes);
+    d["lane_index"] = toArray(f.lane_index, f.n_lanes);
+    d["lane_ll_start"] = toArray(f.lane_ll_start, f.n_lanes + 1);
+    d["lane_ll"] = toArray(f.lane_ll, f.n_lanelinks);
+    d["road_lane_start"] = toArray(f.road_lane_start, f.n_roads + 1);
+    d["ll_start_lane"] = toArray(f.ll_start_lane, f.n_lanelinks);
+    d["ll_end_lane"] = toArray(f.ll_end_lane, f.n_lanelinks);
+    d["ll_inter"] = toArray(f.ll_inter, f.n_lanelinks);
+    d["ll_roadlink"] = toArray(f.ll_roadlink, f.n_lanelinks);
+    d["ll_type"] = toArray(f.ll_type, f.n_lanelinks);
+    d["ll_x_start"] = toArray(f.ll_x_start, f.n_lanelinks + 1);
+    d["x_dist"] = toArray(f.x_dist, f.n_xentries);
+    d["x_peer"] = toArray(f.x_peer, f.n_xentries);
+    d["x_ll"] = toArray(f.x_ll, f.n_xentries);
+    d["inter_virtual"] = toArray(f.inter_virtual, f.n_inters);
+    d["inter_n_roadlinks"] = toArray(f.inter_n_roadlinks, f.n_inters);
+    d["inter_phase_start"] = toArray(f.inter_phase_start, f.n_inters + 1);
+    d["inter_avail_start"] = toArray(f.inter_avail_start, f.n_inters);
+    d["phase_time"] = toArray(f.phase_time, f.n_phases);
+    d["phase_avail"] = toArray(f.phase_avail, f.n_avail);
+    std::vector<std::string> laneIds(f.n_lanes), llIds(f.n_lanelinks), interIds(f.n_inters), roadIds(f.n_roads);
+    for (int l = 0; l < f.n_lanes; ++l) laneIds[l] = net.laneId(l);
+    for (int k = 0; k < f.n_lanelinks; ++k) llIds[k] = net.laneLinkId(k);
+    for (int i = 0; i < f.n_inters; ++i) interIds[i] = net.inters[i].id;
+    for (int r = 0; r < f.n_roads; ++r) roadIds[r] = net.roads[r].id;
+    d["lane_ids"] = laneIds;
+    d["lanelink_ids"] = llIds;
+    d["inter_ids"] = interIds;
+    d["road_ids"] = roadIds;
+    return d;
+}
+
+// Host-only helpers (no device engine involved): used by the CPU test-suite to pin the loader and the
+// spawner against the reference.
+py::dict loadRoadnet(const std::string &path) {
+    cfa::HostRoadNet net;
+    net.load(path);
+    return flatNetToDict(net);
+}
+
+py::list spawnSchedule(const std::string &roadnetFile, const std::string &flowFile, double interval, int seed,
+                       int threadNum, int steps) {
+    cfa::HostRoadNet net;
+    net.load(roadnetFile);
+    cfa::Spawner sp;
+    sp.init(&net, interval, threadNum, seed);
+    sp.loadFlows(flowFile);
+    py::list out;
+    std::vector<cfx_spawn> recs;
+    for (int s = 0; s < steps; ++s) {
+        sp.step((size_t) s, recs);
+        py::list stepList;
+        for (const cfx_spawn &r : recs)
+            stepList.append(py::make_tuple(sp.vehicleId(r.vid), r.priority, net.laneId(r.lane), r.enter_time, r.templ,
+                                           r.route, r.prev_wait));
+        out.append(stepList);
+    }
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_cityflow, m) {
+    m.doc() = "MI355X-native CityFlow step engine (drop-in for the reference `cityflow` module)";
+
+    py::class_<EngineHost>(m, "Engine")
+        .def(py::init<const std::string &, int>(), "config_file"_a, "thread_num"_a = 1)
+        .def_static(
+            "_with_backend",
+            [](const std::string &cfg, int threads, const std::string &lib) {
+                return std::unique_ptr<EngineHost>(new EngineHost(cfg, threads, lib));
+            },
+            "config_file"_a, "thread_num"_a, "backend_library"_a,
+            "Test hook: build an engine on any shared library exporting the cfx_* C ABI.")
+        // ---- reference API ----
+        .def("next_step", &EngineHost::nextStep)
+        .def("get_vehicle_count", &EngineHost::getVehicleCount)
+        .def("get_vehicles", &EngineHost::getVehicles, "include_waiting"_a = false)
+        .def("get_lane_vehicle_count", &EngineHost::getLaneVehicleCount)
+        .def("get_lane_waiting_vehicle_count", &EngineHost::getLaneWaitingVehicleCount)
+        .def("get_lane_vehicles", &EngineHost::getLaneVehicles)
+        .def("get_vehicle_speed", &EngineHost::getVehicleSpeed)
+        .def("get_vehicle_info", &EngineHost::getVehicleInfo, "vehicle_id"_a)
+        .def("get_vehicle_distance", &EngineHost::getVehicleDistance)
+        .def("get_leader", &EngineHost::getLeader, "vehicle_id"_a)
+        .def("get_current_time", &EngineHost::getCurrentTime)
+        .def("get_average_travel_time", &EngineHost::getAverageTravelTime)
+        .def("set_tl_phase", &EngineHost::setTrafficLightPhase, "intersection_id"_a, "phase_id"_a)
+        .def("set_random_seed", &EngineHost::setRandomSeed, "seed"_a)
+        .def("push_vehicle", &EngineHost::pushVehicle)
+        .def("reset", &EngineHost::reset, "seed"_a = false)
+        // ---- array API (index order == lane_ids() / intersection_ids()) ----
+        .def("lane_ids", &EngineHost::laneIds)
+        .def("intersection_ids", &EngineHost::intersectionIds)
+        .def("get_lane_vehicle_count_array", [](EngineHost &e) { return toArray(e.laneVehicleCountArray()); })
+        .def("get_lane_waiting_vehicle_count_array",
+             [](EngineHost &e) { return toArray(e.laneWaitingVehicleCountArray()); })
+        .def("set_tl_phase_indexed", &EngineHost::setTrafficLightPhaseIndexed, "intersection_index"_a, "phase_id"_a)
+        .def("sync", &EngineHost::sync)
+        .def("backend_name", &EngineHost::backendName)
+        // ---- introspection used by the parity tests ----
+        .def("_vehicle_state",
+             [](EngineHost &e) {
+                 cfa::VehicleSnapshot s;
+                 e.snapshotVehicles(s);
+                 py::dict d;
+                 d["vid"] = toArray(s.vid);
+                 d["drivable"] = toArray(s.drivable);
+                 d["prev_drivable"] = toArray(s.prevDrivable);
+                 d["leader"] = toArray(s.leader);
+                 d["blocker"] = toArray(s.blocker);
+                 d["enter_ll_time"] = toArray(s.enterLLTime);
+                 d["route_pos"] = toArray(s.routePos);
+                 d["dis"] = toArray(s.dis);
+                 d["speed"] = toArray(s.speed);
+                 d["gap"] = toArray(s.gap);
+                 return d;
+             })
+        .def("_waiting",
+             [](EngineHost &e) {
+                 std::vector<int32_t> v, l;
+                 e.waitingVehicles(v, l);
+                 return py::make_tuple(toArray(v), toArray(l));
+             })
+        .def("_tl_state",
+             [](EngineHost &e) {
+                 std::vector<int32_t> p;
+                 std::vector<double> r;
+                 e.trafficLightState(p, r);
+                 return py::make_tuple(toArray(p), toArray(r));
+             })
+        .def("_scalars",
+             [](EngineHost &e) {
+                 cfx_scalars s = e.scalars();
+                 py::dict d;
+                 d["step"] = s.step;
+                 d["active_vehicle_count"] = s.active_vehicle_count;
+                 d["finished_vehicle_count"] = s.finished_vehicle_count;
+                 d["spawned_vehicle_count"] = s.spawned_vehicle_count;
+                 d["cumulative_travel_time"] = s.cumulative_travel_time;
+                 d["live_enter_time_sum"] = s.live_enter_time_sum;
+                 return d;
+             })
+        .def("_vehicle_id", &EngineHost::vehicleId, "vid"_a)
+        .def("_vehicle_ids",
+             [](EngineHost &e, py::array_t<int32_t> vids) {
+                 std::vector<std::string> out;
+                 auto r = vids.unchecked<1>();
+                 for (py::ssize_t i = 0; i < r.shape(0); ++i) out.push_back(e.vehicleId(r(i)));
+                 return out;
+             })
+        .def("_vehicle_priority", [](EngineHost &e, int vid) { return e.spawner().vehicles.at(vid).priority; })
+        .def("_drivable_ids",
+             [](EngineHost &e) {
+                 std::vector<std::string> ids;
+                 int D = (int) (e.net().lanes.size() + e.net().laneLinks.size());
+                 for (int d = 0; d < D; ++d) ids.push_back(e.net().drivableId(d));
+                 return ids;
+             })
+        .def("_flat_net", [](EngineHost &e) { return flatNetToDict(e.net()); });
+
+    m.def("_load_roadnet", &loadRoadnet, "path"_a);
+    m.def("_spawn_schedule", &spawnSchedule, "roadnet_file"_a, "flow_file"_a, "interval"_a, "seed"_a, "thread_num"_a,
+          "steps"_a);
+    m.def("_default_backend_path", &cfa::defaultBackendPath);
+#ifdef CITYFLOW_AMD_VERSION
+    m.attr("__version__") = CITYFLOW_AMD_VERSION;
+#else
+    m.attr("__version__") = "dev";
+#endif
+}

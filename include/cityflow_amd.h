@@ -1,0 +1,186 @@
+/*
+ * cityflow_amd.h — C ABI of the MI355X-native CityFlow step engine ("cfx").
+ *
+ * This is the drop-in boundary between the C++ host (JSON loading, flow spawning / RNG, string ids,
+ * the pybind11 `cityflow.Engine` class) and the device engine that owns all vehicle state in HBM and
+ * advances it with hand-written HIP kernels.  The reference has no internal FFI seam (its only
+ * boundary is the pybind11 class, reference src/cityflow.cpp:10-47); the entry points below are what a
+ * maintainer of the reference would bind from `CityFlow::Engine` to off-load `Engine::nextStep`
+ * (reference src/engine/engine.cpp:566-594) and the RL getters around it (engine.cpp:615-760).
+ * INTEGRATION.md shows that binding.
+ *
+ * Conventions: opaque handle; plain pointers and sizes; caller-allocated outputs; every function
+ * returns 0 on success or a negative cfx_status, with a message available from cfx_last_error();
+ * no exceptions cross the ABI; one HIP stream per engine; getters are synchronous on return,
+ * cfx_step() is asynchronous (ordered on the engine's stream).  Strings never cross this ABI:
+ * lanes, laneLinks, intersections, roads, routes, templates and vehicles are dense int32 indices.
+ *
+ * Index spaces
+ *   lane      0..n_lanes-1        reference order RoadNet::getLanes()      (roadnet.cpp:314-318)
+ *   laneLink  0..n_lanelinks-1    reference order RoadNet::getLaneLinks()  (roadnet.cpp:319-323)
+ *   drivable  lane l -> l ; laneLink k -> n_lanes + k   (== RoadNet::getDrivables())
+ *   vid       host-assigned vehicle number, dense, monotone since the last reset
+ */
+#ifndef CITYFLOW_AMD_H
+#define CITYFLOW_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFX_ABI_VERSION 1
+
+typedef enum cfx_status {
+    CFX_OK = 0,
+    CFX_ERR_INVALID = -1,   /* bad argument / index out of range                    */
+    CFX_ERR_DEVICE = -2,    /* HIP runtime failure (no device, launch error, OOM)   */
+    CFX_ERR_CAPACITY = -3,  /* an internal fixed-capacity table overflowed          */
+    CFX_ERR_STATE = -4      /* call not valid in the current state                  */
+} cfx_status;
+
+typedef struct cfx_engine cfx_engine; /* opaque */
+
+/* Flattened, immutable road network (replaces RoadNet / Road / Lane / LaneLink / RoadLink / Cross /
+ * Intersection / LightPhase, reference src/roadnet/roadnet.h:64-481, trafficlight.h:15-50).
+ * All arrays are copied by cfx_create(); the caller may free them afterwards. */
+typedef struct cfx_net {
+    int32_t n_roads, n_lanes, n_lanelinks, n_inters;
+    int32_t n_xentries;  /* 2 * number of Cross objects: one entry per (laneLink, cross) */
+    int32_t n_phases;    /* total LightPhase count over all intersections */
+    int32_t n_avail;     /* total size of phase_avail */
+
+    /* per drivable [n_lanes + n_lanelinks] */
+    const double *drv_length;    /* Drivable::length (roadnet.cpp:252,502) */
+    const double *drv_max_speed; /* lanes: JSON maxSpeed; laneLinks: 10000 (roadnet.h:456) */
+
+    /* per lane [n_lanes] */
+    const int32_t *lane_road;     /* owning road */
+    const int32_t *lane_index;    /* Lane::laneIndex */
+    const int32_t *lane_ll_start; /* [n_lanes+1] CSR offsets into lane_ll */
+    const int32_t *lane_ll;       /* [n_lanelinks] laneLink ids in Lane::laneLinks order */
+
+    /* per road [n_roads] : lanes of a road are contiguous */
+    const int32_t *road_lane_start; /* [n_roads+1] */
+
+    /* per laneLink [n_lanelinks] */
+    const int32_t *ll_start_lane;
+    const int32_t *ll_end_lane;
+    const int32_t *ll_inter;    /* owning intersection */
+    const int32_t *ll_roadlink; /* RoadLink::index inside that intersection (roadnet.h:417) */
+    const int32_t *ll_type;     /* RoadLinkType: 1 turn_right, 2 turn_left, 3 go_straight (roadnet.h:401-403) */
+    const int32_t *ll_x_start;  /* [n_lanelinks+1] CSR offsets into the x_* arrays */
+
+    /* per cross entry [n_xentries]; a laneLink's entries are sorted ascending by x_dist exactly as
+     * Intersection::initCrosses sorts LaneLink::crosses (roadnet.cpp:568-575) */
+    const double *x_dist;   /* Cross::distanceOnLane for the owning laneLink */
+    const int32_t *x_peer;  /* entry index of the same Cross seen from the other laneLink */
+    const int32_t *x_ll;    /* owning laneLink */
+
+    /* per intersection [n_inters] */
+    const int32_t *inter_virtual;
+    const int32_t *inter_n_roadlinks;
+    const int32_t *inter_phase_start; /* [n_inters+1] offsets into phase_time */
+    const int32_t *inter_avail_start; /* [n_inters]   offset of this intersection's block in phase_avail */
+    const double *phase_time;         /* [n_phases] LightPhase::time */
+    const uint8_t *phase_avail;       /* per intersection: n_phases_i x n_roadlinks_i row-major 0/1 */
+} cfx_net;
+
+typedef struct cfx_config {
+    double interval;          /* Engine::interval */
+    int32_t rl_traffic_light; /* Engine::rlTrafficLight: lights advance only via cfx_set_tl_phase */
+    int32_t lane_change;      /* must be 0 in ABI version 1 */
+    int32_t device;           /* HIP device ordinal (ignored by CPU implementations) */
+    int32_t reserved;
+} cfx_config;
+
+/* VehicleInfo (reference src/vehicle/vehicle.h:31-45) + the two per-template constants derived from it. */
+typedef struct cfx_vehicle_template {
+    double len, width, max_pos_acc, max_neg_acc, usual_pos_acc, usual_neg_acc;
+    double min_gap, max_speed, headway_time, yield_distance, turn_speed;
+    /* maxSpeed^2/usualNegAcc/2 + maxSpeed*interval*2 : ControllerInfo::approachingIntersectionDistance
+     * (vehicle.cpp:42-44) and the head-of-lane leader search bound (vehicle.cpp:190-192). */
+    double approach_dist;
+} cfx_vehicle_template;
+
+/* One vehicle entering the simulation this step (Flow::nextStep flow.cpp:6-22 + Engine::planRoute
+ * engine.cpp:450-470, both evaluated on the host because they own the mt19937 stream). */
+typedef struct cfx_spawn {
+    int32_t vid;        /* dense id; must equal the number of vehicles spawned since the last reset */
+    int32_t priority;   /* Vehicle::priority (vehicle.cpp:45) */
+    int32_t templ;      /* template index */
+    int32_t route;      /* route index */
+    int32_t lane;       /* first lane (Router::getFirstDrivable router.cpp:23-37) */
+    int32_t prev_wait;  /* vid previously pushed on this lane's waitingBuffer since the last reset, or -1 */
+    double enter_time;  /* Vehicle::enterTime (vehicle.cpp:46) */
+} cfx_spawn;
+
+typedef struct cfx_scalars {
+    int64_t step;                  /* Engine::step */
+    int64_t active_vehicle_count;  /* Engine::activeVehicleCount (running vehicles) */
+    int64_t finished_vehicle_count;/* Engine::finishedVehicleCnt */
+    int64_t spawned_vehicle_count; /* vehicles handed to cfx_step since the last reset */
+    double cumulative_travel_time; /* Engine::cumulativeTravelTime */
+    double live_enter_time_sum;    /* sum of enter_time over spawned-and-not-finished vehicles */
+} cfx_scalars;
+
+/* Full per-vehicle state of every running vehicle, caller-allocated SoA (any pointer may be NULL).
+ * Order: by drivable (index space above), then front (furthest ahead) to back inside a drivable,
+ * i.e. the order of Drivable::vehicles (roadnet.h:245). */
+typedef struct cfx_vehicle_view {
+    int32_t capacity;       /* in: number of elements each array can hold */
+    int32_t count;          /* out: number of running vehicles */
+    int32_t *vid;
+    int32_t *drivable;
+    int32_t *prev_drivable; /* -1 if none */
+    int32_t *leader_vid;    /* -1 if none */
+    int32_t *blocker_vid;   /* -1 if none */
+    int32_t *enter_ll_time; /* INT32_MAX when not on a laneLink */
+    int32_t *route_pos;     /* Router::iCurRoad as an index into the route */
+    double *dis;
+    double *speed;
+    double *gap;            /* meaningful only where leader_vid >= 0 */
+} cfx_vehicle_view;
+
+int32_t cfx_abi_version(void);
+int32_t cfx_create(const cfx_net *net, const cfx_config *cfg, cfx_engine **out);
+void cfx_destroy(cfx_engine *e);
+const char *cfx_last_error(const cfx_engine *e); /* e may be NULL: error of the last failed cfx_create */
+const char *cfx_backend_name(void);             /* "hip-gfx950" for the product library */
+
+/* Append vehicle templates / routes (flows at load time; push_vehicle / set_vehicle_route later).
+ * A route is its road sequence plus, for every position p and every lane j of road[p], the laneLink
+ * Router::getNextDrivable would choose from that lane (router.cpp:49-76,96-129), or -1.
+ *   route_start[n_routes+1]           offsets into `roads`
+ *   next_start[route_start[n]+1]      offsets into `next_ll`, one block per route position */
+int32_t cfx_add_templates(cfx_engine *e, int32_t n, const cfx_vehicle_template *t);
+int32_t cfx_add_routes(cfx_engine *e, int32_t n_routes, const int32_t *route_start, const int32_t *roads,
+                       const int32_t *next_start, const int32_t *next_ll);
+
+/* One Engine::nextStep (engine.cpp:566-594): enqueue `recs` on their lanes' waiting buffers, admit,
+ * notify crosses, get action, update location, commit, leader/gap, traffic lights, step += 1. */
+int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n);
+int32_t cfx_sync(cfx_engine *e);
+
+/* Engine::reset (engine.cpp:744-760): drop all vehicles and waiting buffers, lights to phase 0, step 0.
+ * Templates and routes are kept. */
+int32_t cfx_reset(cfx_engine *e);
+
+/* TrafficLight::setPhase (trafficlight.cpp:39-41).  Unlike the reference this is range-checked. */
+int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase);
+int32_t cfx_get_tl_state(cfx_engine *e, int32_t *cur_phase /*[n_inters]*/, double *remain /*[n_inters]*/);
+
+int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out);
+int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out /*[n_lanes]*/);         /* getLaneVehicleCount */
+int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out /*[n_lanes]*/); /* speed < 0.1 (engine.cpp:641) */
+int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view);
+/* per-vid life-cycle state for vids [first, first+n): 0 waiting, 1 running, 2 finished */
+int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first_vid, int32_t n, uint8_t *out);
+/* vids still sitting in lanes' waiting buffers, lane by lane, FIFO order; returns count via *n */
+int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *lane, int32_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CITYFLOW_AMD_H */

@@ -283,6 +283,11 @@ inline void Value::writeTo(std::string &out) const {
                 snprintf(buf, sizeof buf, "%lld", (long long) int_);
                 out += buf;
             } else {
+                // Uninitialised reference fields (e.g. ControllerInfo::gap) can be NaN; keep the dump
+                // loadable (python json and this shim both read NaN / Infinity / -Infinity).
+                if (num_ != num_) { out += "NaN"; break; }
+                if (num_ > 1.7976931348623157e308) { out += "Infinity"; break; }
+                if (num_ < -1.7976931348623157e308) { out += "-Infinity"; break; }
                 // %.17g round-trips every finite double exactly through strtod
                 snprintf(buf, sizeof buf, "%.17g", num_);
                 out += buf;
@@ -465,6 +470,13 @@ struct Parser {
             if (lit("false")) v.kind_ = kFalseType; else ok = false;
         } else if (c == 'n') {
             if (lit("null")) v.kind_ = kNullType; else ok = false;
+        } else if (c == 'N' || c == 'I' || (c == '-' && p + 1 < end && p[1] == 'I')) {
+            v.kind_ = kNumberType;
+            v.isInt_ = false;
+            if (lit("NaN")) v.num_ = strtod("nan", nullptr);
+            else if (lit("Infinity")) v.num_ = strtod("inf", nullptr);
+            else if (lit("-Infinity")) v.num_ = -strtod("inf", nullptr);
+            else ok = false;
         } else if (c == '-' || (c >= '0' && c <= '9')) {
             const char *s = p;
             bool integral = true;
