@@ -1,0 +1,785 @@
+// TEST INFRASTRUCTURE ONLY (oracle/): the CPU "twin".
+//
+// A plain, single-threaded C++ restatement of the reference's step algorithm on the flat network of
+// include/cityflow_amd.h, exporting the same cfx_* C ABI as the HIP library so the host can drive either.
+// It follows the REFERENCE's structure (one ordered vehicle list per drivable, one record per vehicle,
+// double-buffered "buffer" fields, phase order of Engine::nextStep) rather than the device's slot layout,
+// so that it is an independent check of the kernels.  Every function cites the reference lines it
+// restates.  It is pinned against oracle/_ref (the unmodified reference) by tests/test_twin_vs_reference.py;
+// the product never links, loads or calls it (tests pass its path to Engine._with_backend explicitly).
+//
+// Build: -O2 -ffp-contract=off (no FMA contraction: the reference is plain x86-64 g++ -O2).
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "cityflow_amd.h"
+
+namespace {
+
+inline double min2(double x, double y) { return x < y ? x : y; }  // utility.h:70-72
+inline double max2(double x, double y) { return x > y ? x : y; }  // utility.h:66-68
+constexpr double kEps = 1e-8;                                      // utility.h:15
+
+struct Net {  // owned copies of cfx_net
+    int R = 0, L = 0, K = 0, I = 0, E = 0;
+    std::vector<double> drvLength, drvMaxSpeed, xDist, phaseTime;
+    std::vector<int32_t> laneRoad, laneIndex, laneLLStart, laneLL, roadLaneStart, llStartLane, llEndLane, llInter,
+        llRoadLink, llType, llXStart, xPeer, xLL, interVirtual, interNRL, interPhaseStart, interAvailStart;
+    std::vector<uint8_t> phaseAvail;
+};
+
+struct Veh {  // Vehicle (vehicle.h:48-112) minus strings / lane change
+    int32_t priority = 0, templ = 0, route = 0;
+    double enterTime = 0;
+    // ControllerInfo vehicle.h:81-95 + VehicleInfo::speed
+    double dis = 0, speed = 0, gap = 0;
+    int32_t drivable = -1, prevDrivable = -1, leader = -1, blocker = -1;
+    int32_t enterLLTime = INT_MAX;
+    int32_t routePos = 0;  // Router::iCurRoad
+    bool running = false, finished = false;
+    // Buffer vehicle.h:54-72
+    bool bEndSet = false, bDrvSet = false, bBlockerSet = false, bEnterSet = false;
+    double bDis = 0, bSpeed = 0;
+    int32_t bDrv = -1, bBlocker = -1, bEnterLLTime = INT_MAX;
+};
+
+}  // namespace
+
+struct cfx_engine {
+    Net net;
+    cfx_config cfg{};
+    std::vector<cfx_vehicle_template> templ;
+    std::vector<int32_t> routeStart{0}, routeRoads, nextStart{0}, nextLL;
+    std::vector<Veh> veh;                        // by vid
+    std::vector<std::vector<int32_t>> order;     // per drivable: Drivable::vehicles, front = furthest ahead
+    std::vector<std::deque<int32_t>> waiting;    // per lane: Lane::waitingBuffer
+    std::vector<int32_t> notifyVid;              // per cross entry: Cross::notifyVehicles[side]
+    std::vector<double> notifyDist;              //                  Cross::notifyDistances[side]
+    std::vector<int32_t> curPhase;               // TrafficLight::curPhaseIndex
+    std::vector<double> remain;                  // TrafficLight::remainDuration
+    int64_t step = 0, active = 0, finishedCnt = 0;
+    double cumulativeTravelTime = 0;
+    std::string err;
+
+    // ------------------------------------------------------------------ small accessors
+    bool isLane(int d) const { return d < net.L; }
+    double len(int d) const { return net.drvLength[d]; }
+    const cfx_vehicle_template &T(const Veh &v) const { return templ[v.templ]; }
+    int lastVehicle(int d) const { return order[d].empty() ? -1 : order[d].back(); }    // roadnet.h:275-278
+    int firstVehicle(int d) const { return order[d].empty() ? -1 : order[d].front(); }  // roadnet.h:270-273
+
+    // RoadLink::isAvailable roadnet.h:429-431 via LaneLink::isAvailable 472
+    bool llAvailable(int k) const {
+        int in = net.llInter[k];
+        int nrl = net.interNRL[in];
+        return net.phaseAvail[net.interAvailStart[in] + curPhase[in] * nrl + net.llRoadLink[k]] != 0;
+    }
+    bool llIsTurn(int k) const { return net.llType[k] == 1 || net.llType[k] == 2; }  // roadnet.h:433-435
+
+    // Router::getNextDrivable(const Drivable*) router.cpp:49-76, with the static per-route table built by
+    // the host (the search for the lane's road starts at iCurRoad, router.cpp:54-57).
+    int nextOf(const Veh &v, int d) const {
+        if (!isLane(d)) return net.llEndLane[d - net.L];
+        int road = net.laneRoad[d];
+        int base = routeStart[v.route], n = routeStart[v.route + 1] - base;
+        int p = v.routePos;
+        while (p < n && routeRoads[base + p] != road) ++p;
+        if (p >= n) return -1;  // (reference asserts)
+        int ll = nextLL[nextStart[base + p] + net.laneIndex[d]];
+        return ll < 0 ? -1 : net.L + ll;
+    }
+    // Router::getNextDrivable(size_t i) router.cpp:39-47 (the `planned` deque is a pure cache)
+    int nextDrivable(const Veh &v, int i) const {
+        int d = v.drivable;
+        for (int k = 0; k <= i; ++k) {
+            d = nextOf(v, d);
+            if (d < 0) return -1;
+        }
+        return d;
+    }
+    bool isLastRoad(const Veh &v, int d) const {  // router.cpp:131-134
+        if (!isLane(d)) return false;
+        return net.laneRoad[d] == routeRoads[routeStart[v.route + 1] - 1];
+    }
+
+    // ------------------------------------------------------------------ vehicle.cpp restatements
+    double minBrakeDistance(const Veh &v) const { return 0.5 * v.speed * v.speed / T(v).max_neg_acc; }  // vehicle.h:239
+
+    // Vehicle::getNoCollisionSpeed vehicle.cpp:200-209
+    static double noCollisionSpeed(double vL, double dL, double vF, double dF, double gap, double interval,
+                                   double targetGap) {
+        double c = vF * interval / 2 + targetGap - 0.5 * vL * vL / dL - gap;
+        double a = 0.5 / dF;
+        double b = 0.5 * interval;
+        if (b * b < 4 * a * c) return -100;
+        double v1 = 0.5 / a * (sqrt(b * b - 4 * a * c) - b);
+        double v2 = 2 * vL - dL * interval + 2 * (gap - targetGap) / interval;
+        return min2(v1, v2);
+    }
+
+    // Vehicle::getCarFollowSpeed vehicle.cpp:212-238 (customSpeed: not yet in the ABI)
+    double carFollowSpeed(const Veh &v, double interval) const {
+        if (v.leader < 0) return T(v).max_speed;
+        const Veh &ld = veh[v.leader];
+        const cfx_vehicle_template &t = T(v), &tl = T(ld);
+        double s = noCollisionSpeed(ld.speed, tl.max_neg_acc, v.speed, t.max_neg_acc, v.gap, interval, 0);
+        double assumeDecel = 0, leaderSpeed = ld.speed;
+        if (v.speed > leaderSpeed) assumeDecel = v.speed - leaderSpeed;
+        s = min2(s, noCollisionSpeed(ld.speed, tl.usual_neg_acc, v.speed, t.usual_neg_acc, v.gap, interval, t.min_gap));
+        s = min2(s, (v.gap + (leaderSpeed + assumeDecel / 2) * interval - v.speed * interval / 2) /
+                        (t.headway_time + interval / 2));
+        return s;
+    }
+
+    // Vehicle::getBrakeDistanceAfterAccel vehicle.cpp:302-306
+    double brakeDistanceAfterAccel(const Veh &v, double acc, double dec, double interval) const {
+        double currentSpeed = v.speed;
+        double nextSpeed = currentSpeed + acc * interval;
+        return (currentSpeed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / dec / 2);
+    }
+
+    // Vehicle::getStopBeforeSpeed vehicle.cpp:240-250
+    double stopBeforeSpeed(const Veh &v, double distance, double interval) const {
+        const cfx_vehicle_template &t = T(v);
+        if (brakeDistanceAfterAccel(v, t.usual_pos_acc, t.usual_neg_acc, interval) < distance)
+            return v.speed + t.usual_pos_acc * interval;
+        double takeInterval = 2 * distance / (v.speed + kEps) / interval;
+        if (takeInterval >= 1) {
+            return v.speed - v.speed / (int) takeInterval;
+        } else {
+            return v.speed - v.speed / takeInterval;
+        }
+    }
+
+    // Vehicle::getDistanceUntilSpeed vehicle.cpp:275-282 (the "/ interval" unit slip is the reference's)
+    double distanceUntilSpeed(const Veh &v, double speed, double acc) const {
+        if (speed <= v.speed) return 0;
+        double interval = cfg.interval;
+        int stage1steps = std::floor((speed - v.speed) / acc / interval);
+        double stage1speed = v.speed + stage1steps * acc / interval;
+        double stage1dis = (v.speed + stage1speed) * (stage1steps * interval) / 2;
+        return stage1dis + (stage1speed < speed ? ((stage1speed + speed) * interval / 2) : 0);
+    }
+
+    // Vehicle::getReachSteps vehicle.cpp:252-268
+    int reachSteps(const Veh &v, double distance, double targetSpeed, double acc) const {
+        if (distance <= 0) return 0;
+        if (v.speed > targetSpeed) return std::ceil(distance / v.speed);
+        double distanceUntilTargetSpeed = distanceUntilSpeed(v, targetSpeed, acc);
+        double interval = cfg.interval;
+        if (distanceUntilTargetSpeed > distance) {
+            return std::ceil((std::sqrt(v.speed * v.speed + 2 * acc * distance) - v.speed) / acc / interval);
+        } else {
+            return std::ceil((targetSpeed - v.speed) / acc / interval) +
+                   std::ceil((distance - distanceUntilTargetSpeed) / targetSpeed / interval);
+        }
+    }
+    // Vehicle::getReachStepsOnLaneLink vehicle.cpp:270-273
+    int reachStepsOnLaneLink(const Veh &v, double distance, int k) const {
+        return reachSteps(v, distance, llIsTurn(k) ? T(v).turn_speed : T(v).max_speed, T(v).usual_pos_acc);
+    }
+    // Vehicle::canYield vehicle.cpp:284-287
+    bool canYield(const Veh &v, double dist) const {
+        return (dist > 0 && minBrakeDistance(v) < dist - T(v).yield_distance) || (dist < 0 && dist + T(v).len < 0);
+    }
+
+    // Lane::canEnter roadnet.cpp:437-445
+    bool canEnter(int lane, const Veh &v) const {
+        int tail = lastVehicle(lane);
+        if (tail < 0) return true;
+        const Veh &tv = veh[tail];
+        return tv.dis > T(tv).len + T(v).len || tv.speed >= 2;
+    }
+    // Lane::available roadnet.cpp:428-435
+    bool available(int lane, const Veh &v) const {
+        int tail = lastVehicle(lane);
+        if (tail < 0) return true;
+        const Veh &tv = veh[tail];
+        return tv.dis > T(tv).len + T(v).min_gap;
+    }
+
+    // Cross::canPass roadnet.cpp:603-676; `e` is this laneLink's entry of the cross, x_peer[e] the foe's
+    bool canPass(const Veh &v, int e, double distanceToLaneLinkStart) const {
+        int pe = net.xPeer[e];
+        int foeId = notifyVid[pe];
+        int t1 = net.llType[net.xLL[e]];
+        int t2 = net.llType[net.xLL[pe]];
+        double d1 = net.xDist[e] - distanceToLaneLinkStart, d2 = notifyDist[pe];
+        if (foeId < 0) return true;
+        if (!canYield(v, d1)) return true;
+        const Veh &foe = veh[foeId];
+        int yield = 0;
+        if (!canYield(foe, d2)) yield = 1;
+        if (yield == 0) {
+            if (t1 > t2) {
+                yield = -1;
+            } else if (t1 < t2) {
+                if (d2 > 0) {
+                    int foeSteps = reachStepsOnLaneLink(foe, d2, net.xLL[pe]);
+                    int mySteps = reachStepsOnLaneLink(v, d1, net.xLL[e]);
+                    if (foeSteps > mySteps) yield = -1;
+                } else {
+                    if (d2 + T(foe).len < 0) yield = -1;
+                }
+                if (yield == 0) yield = 1;
+            } else {
+                if (d2 > 0) {
+                    int foeSteps = reachStepsOnLaneLink(foe, d2, net.xLL[pe]);
+                    int mySteps = reachStepsOnLaneLink(v, d1, net.xLL[e]);
+                    if (foeSteps > mySteps) {
+                        yield = -1;
+                    } else if (foeSteps < mySteps) {
+                        yield = 1;
+                    } else {
+                        // getEnterLaneLinkTime() returns double (vehicle.h:262); the ints compare identically
+                        if (v.enterLLTime == foe.enterLLTime) {
+                            if (d1 == d2) {
+                                yield = v.priority > foe.priority ? -1 : 1;
+                            } else {
+                                yield = d1 < d2 ? -1 : 1;
+                            }
+                        } else {
+                            yield = v.enterLLTime < foe.enterLLTime ? -1 : 1;
+                        }
+                    }
+                } else {
+                    yield = d2 + T(foe).len < 0 ? -1 : 1;
+                }
+            }
+        }
+        if (yield == 1) {  // Floyd walk over committed blockers: deadlock => pass
+            int fast = foeId, slow = foeId;
+            while (fast >= 0 && veh[fast].blocker >= 0) {
+                slow = veh[slow].blocker;
+                fast = veh[veh[fast].blocker].blocker;
+                if (slow == fast) {
+                    yield = -1;
+                    break;
+                }
+            }
+        }
+        return yield == -1;
+    }
+
+    // Vehicle::isIntersectionRelated vehicle.cpp:289-300
+    bool isIntersectionRelated(const Veh &v) const {
+        if (!isLane(v.drivable)) return true;
+        int nd = nextDrivable(v, 0);
+        return nd >= 0 && !isLane(nd) && len(v.drivable) - v.dis <= T(v).approach_dist;
+    }
+
+    // Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-376
+    double intersectionRelatedSpeed(Veh &v, double interval) {
+        const cfx_vehicle_template &t = T(v);
+        double s = t.max_speed;
+        int nd = nextDrivable(v, 0);
+        int laneLink = -1;
+        if (nd >= 0 && !isLane(nd)) {
+            laneLink = nd - net.L;
+            if (!llAvailable(laneLink) || !canEnter(net.llEndLane[laneLink], v)) {
+                if (minBrakeDistance(v) > len(v.drivable) - v.dis) {
+                    // cannot brake before the red light: keep going
+                } else {
+                    s = min2(s, stopBeforeSpeed(v, len(v.drivable) - v.dis, interval));
+                    return s;
+                }
+            }
+            if (llIsTurn(laneLink)) s = min2(s, t.turn_speed);
+        }
+        if (laneLink < 0 && !isLane(v.drivable)) laneLink = v.drivable - net.L;
+        double distanceToLaneLinkStart = isLane(v.drivable) ? -(len(v.drivable) - v.dis) : v.dis;
+        for (int e = net.llXStart[laneLink]; e < net.llXStart[laneLink + 1]; ++e) {
+            double distanceOnLaneLink = net.xDist[e];
+            if (distanceOnLaneLink < distanceToLaneLinkStart) continue;
+            if (!canPass(v, e, distanceToLaneLinkStart)) {
+                s = min2(s, stopBeforeSpeed(v, distanceOnLaneLink - distanceToLaneLinkStart - t.yield_distance, interval));
+                v.bBlocker = notifyVid[net.xPeer[e]];  // setBlocker(cross->getFoeVehicle(laneLink))
+                v.bBlockerSet = true;
+                break;
+            }
+        }
+        return s;
+    }
+
+    // Vehicle::getNextSpeed vehicle.cpp:308-335.  `if (laneChange)` there tests the always-non-null
+    // shared_ptr member: yieldSpeed() == 100 without signals, and the invalid-lane
+    // brake is always evaluated.
+    double nextSpeed(Veh &v, double interval) {
+        const cfx_vehicle_template &t = T(v);
+        double s = t.max_speed;
+        s = min2(s, v.speed + t.max_pos_acc * interval);
+        s = min2(s, net.drvMaxSpeed[v.drivable]);
+        s = min2(s, carFollowSpeed(v, interval));
+        if (isIntersectionRelated(v)) s = min2(s, intersectionRelatedSpeed(v, interval));
+        s = min2(s, 100);  // SimpleLaneChange::yieldSpeed lanechange.cpp:186-206 without signals
+        // Router::onValidLane router.h:66-68
+        if (nextDrivable(v, 0) < 0 && !isLastRoad(v, v.drivable)) {
+            double vn = noCollisionSpeed(0, 1, v.speed, t.max_neg_acc, len(v.drivable) - v.dis, interval, t.min_gap);
+            s = min2(s, vn);
+        }
+        s = max2(s, v.speed - t.max_neg_acc * interval);
+        return s;
+    }
+
+    // Vehicle::setDeltaDistance vehicle.cpp:49-68
+    void setDeltaDistance(Veh &v, double dis) {
+        v.bEndSet = false;
+        v.bDrvSet = false;
+        dis = dis + v.dis;
+        int drivable = v.drivable;
+        for (int i = 0; drivable >= 0 && dis > len(drivable); ++i) {
+            dis -= len(drivable);
+            int nd = nextDrivable(v, i);
+            if (nd < 0) v.bEndSet = true;  // setEnd(true)
+            drivable = nd;
+            v.bDrv = drivable;
+            v.bDrvSet = true;
+        }
+        v.bDis = dis;
+    }
+
+    // Engine::vehicleControl engine.cpp:188-251 (no lane change)
+    void vehicleControl(Veh &v) {
+        double interval = cfg.interval;
+        double ns = nextSpeed(v, interval);
+        double deltaDis, speed = v.speed;
+        if (ns < 0) {
+            deltaDis = 0.5 * speed * speed / T(v).max_neg_acc;
+            ns = 0;
+        } else {
+            deltaDis = (speed + ns) * interval / 2;
+        }
+        v.bSpeed = ns;
+        setDeltaDistance(v, deltaDis);
+    }
+
+    // Vehicle::updateLeaderAndGap vehicle.cpp:157-196
+    void updateLeaderAndGap(Veh &v, int leaderId) {
+        if (leaderId >= 0 && veh[leaderId].drivable == v.drivable) {
+            v.leader = leaderId;
+            v.gap = veh[leaderId].dis - T(veh[leaderId]).len - v.dis;
+            return;
+        }
+        v.leader = -1;
+        double dis = len(v.drivable) - v.dis;
+        for (int i = 0;; ++i) {
+            int d = nextDrivable(v, i);
+            if (d < 0) return;
+            if (!isLane(d)) {
+                // laneLinks of one start lane overlap: check the last vehicle of each of them
+                int startLane = net.llStartLane[d - net.L];
+                for (int q = net.laneLLStart[startLane]; q < net.laneLLStart[startLane + 1]; ++q) {
+                    int cand = lastVehicle(net.L + net.laneLL[q]);
+                    if (cand >= 0) {
+                        double candGap = dis + veh[cand].dis - T(veh[cand]).len;
+                        if (v.leader < 0 || candGap < v.gap) {
+                            v.leader = cand;
+                            v.gap = candGap;
+                        }
+                    }
+                }
+                if (v.leader >= 0) return;
+            } else {
+                if ((v.leader = lastVehicle(d)) >= 0) {
+                    v.gap = dis + veh[v.leader].dis - T(veh[v.leader]).len;
+                    return;
+                }
+            }
+            dis += len(d);
+            if (dis > T(v).approach_dist) return;  // same expression as vehicle.cpp:190-191
+        }
+    }
+
+    // ------------------------------------------------------------------ engine.cpp phases
+    // Engine::handleWaiting engine.cpp:502-516
+    void handleWaiting() {
+        for (int lane = 0; lane < net.L; ++lane) {
+            auto &buffer = waiting[lane];
+            if (buffer.empty()) continue;
+            int vid = buffer.front();
+            Veh &v = veh[vid];
+            if (available(lane, v)) {
+                v.running = true;
+                active += 1;
+                int tail = lastVehicle(lane);
+                order[lane].push_back(vid);
+                updateLeaderAndGap(v, tail);
+                buffer.pop_front();
+            }
+        }
+    }
+
+    // Engine::threadNotifyCross engine.cpp:317-372 + Cross::notify roadnet.cpp:595-601
+    void notifyCross() {
+        std::fill(notifyVid.begin(), notifyVid.end(), -1);  // Cross::clearNotify roadnet.h:140
+        for (int k = 0; k < net.K; ++k) {
+            const int xb = net.llXStart[k], xe = net.llXStart[k + 1];
+            int r = xe - 1;  // crosses.rbegin()
+            const double llLen = len(net.L + k);
+            // vehicle that already left onto the end lane
+            int u = lastVehicle(net.llEndLane[k]);
+            if (u >= 0 && veh[u].prevDrivable == net.L + k) {
+                double vehDistance = veh[u].dis - T(veh[u]).len;
+                while (r >= xb) {
+                    double crossDistance = llLen - net.xDist[r];
+                    if (crossDistance + vehDistance < 0 /*leaveDistance*/) {
+                        notifyVid[r] = u;
+                        notifyDist[r] = -(veh[u].dis + crossDistance);
+                        --r;
+                    } else
+                        break;
+                }
+            }
+            // vehicles on the laneLink, front to back
+            for (int w : order[net.L + k]) {
+                double vehDistance = veh[w].dis;
+                while (r >= xb) {
+                    double crossDistance = net.xDist[r];
+                    if (vehDistance > crossDistance) {
+                        if (vehDistance - crossDistance - T(veh[w]).len <= 0 /*leaveDistance*/) {
+                            notifyVid[r] = w;
+                            notifyDist[r] = crossDistance - vehDistance;
+                        } else
+                            break;
+                    } else {
+                        notifyVid[r] = w;
+                        notifyDist[r] = crossDistance - vehDistance;
+                    }
+                    --r;
+                }
+            }
+            // first vehicle on the incoming lane
+            int startLane = net.llStartLane[k];
+            int f = firstVehicle(startLane);
+            if (f >= 0 && nextDrivable(veh[f], 0) == net.L + k && llAvailable(k)) {
+                double vehDistance = len(startLane) - veh[f].dis;
+                while (r >= xb) {
+                    notifyVid[r] = f;
+                    notifyDist[r] = vehDistance + net.xDist[r];
+                    --r;
+                }
+            }
+        }
+    }
+
+    void stepOnce(const cfx_spawn *recs, int n) {
+        // phases 0/1 happened on the host; enqueue on waiting buffers in record order
+        for (int i = 0; i < n; ++i) {
+            const cfx_spawn &s = recs[i];
+            if ((int) veh.size() != s.vid) {
+                err = "spawn records must arrive with dense vids";
+                return;
+            }
+            Veh v;
+            v.priority = s.priority;
+            v.templ = s.templ;
+            v.route = s.route;
+            v.enterTime = s.enter_time;
+            v.drivable = s.lane;  // Vehicle::setFirstDrivable vehicle.cpp:422-424
+            veh.push_back(v);
+            waiting[s.lane].push_back(s.vid);
+        }
+        handleWaiting();
+        notifyCross();
+
+        // threadGetAction engine.cpp:402-413 (iteration order is irrelevant: reads committed state only)
+        std::vector<int32_t> pushBuffer;
+        for (size_t vid = 0; vid < veh.size(); ++vid) {
+            Veh &v = veh[vid];
+            if (!v.running) continue;
+            vehicleControl(v);
+            if (!v.bEndSet && v.bDrvSet) pushBuffer.push_back((int32_t) vid);
+        }
+
+        // threadUpdateLocation engine.cpp:282-315 (drivables in RoadNet order == 1-thread order)
+        std::vector<uint8_t> removed(veh.size(), 0);
+        const double now = step * cfg.interval;  // getCurrentTime engine.cpp:678-680
+        for (auto &list : order) {
+            size_t w = 0;
+            for (size_t i = 0; i < list.size(); ++i) {
+                Veh &v = veh[list[i]];
+                bool leaves = v.bDrvSet || v.bEndSet;
+                if (!leaves) list[w++] = list[i];
+                if (v.bEndSet) {
+                    removed[list[i]] = 1;
+                    finishedCnt += 1;
+                    cumulativeTravelTime += now - v.enterTime;
+                    v.running = false;
+                    v.finished = true;
+                    active--;
+                }
+            }
+            list.resize(w);
+        }
+        // Engine::updateLocation engine.cpp:477-494.  std::sort there leaves ties (equal new distance into
+        // the same drivable) unspecified; canonical tie-break here and on the device: lower vid first.
+        std::stable_sort(pushBuffer.begin(), pushBuffer.end(),
+                         [this](int32_t a, int32_t b) { return veh[a].bDis > veh[b].bDis; });
+        for (int32_t vid : pushBuffer) {
+            Veh &v = veh[vid];
+            order[v.bDrv].push_back(vid);
+            v.bEnterLLTime = isLane(v.bDrv) ? INT_MAX : (int32_t) step;
+            v.bEnterSet = true;
+        }
+
+        // threadUpdateAction engine.cpp:415-427 + Vehicle::update vehicle.cpp:107-143
+        for (Veh &v : veh) {
+            if (!v.running) continue;
+            if (v.bBlockerSet && v.bBlocker >= 0 && removed[v.bBlocker]) v.bBlocker = -1;
+            v.dis = v.bDis;
+            v.speed = v.bSpeed;
+            if (v.bDrvSet) {
+                v.prevDrivable = v.drivable;
+                v.drivable = v.bDrv;
+                v.bDrvSet = false;
+                // Router::update router.cpp:78-94
+                if (isLane(v.drivable)) {
+                    int base = routeStart[v.route], nr = routeStart[v.route + 1] - base;
+                    while (v.routePos < nr && routeRoads[base + v.routePos] != net.laneRoad[v.drivable]) v.routePos++;
+                }
+            }
+            if (v.bEnterSet) {
+                v.enterLLTime = v.bEnterLLTime;
+                v.bEnterSet = false;
+            }
+            v.blocker = v.bBlockerSet ? v.bBlocker : -1;
+            v.bBlockerSet = false;
+        }
+
+        // threadUpdateLeaderAndGap engine.cpp:429-442 (lane history is dead state)
+        for (auto &list : order) {
+            int leader = -1;
+            for (int32_t vid : list) {
+                updateLeaderAndGap(veh[vid], leader);
+                leader = vid;
+            }
+        }
+
+        // TrafficLight::passTime trafficlight.cpp:29-37
+        if (!cfg.rl_traffic_light) {
+            for (int i = 0; i < net.I; ++i) {
+                if (net.interVirtual[i]) continue;
+                int np = net.interPhaseStart[i + 1] - net.interPhaseStart[i];
+                remain[i] -= cfg.interval;
+                while (remain[i] <= 0.0) {
+                    curPhase[i] = (curPhase[i] + 1) % np;
+                    remain[i] += net.phaseTime[net.interPhaseStart[i] + curPhase[i]];
+                }
+            }
+        }
+        step += 1;
+    }
+
+    void resetState() {
+        veh.clear();
+        for (auto &o : order) o.clear();
+        for (auto &w : waiting) w.clear();
+        std::fill(notifyVid.begin(), notifyVid.end(), -1);
+        for (int i = 0; i < net.I; ++i) {  // TrafficLight::init trafficlight.cpp:6-11
+            curPhase[i] = 0;
+            remain[i] = net.interVirtual[i] ? 0.0 : net.phaseTime[net.interPhaseStart[i]];
+        }
+        step = 0;
+        active = 0;
+        finishedCnt = 0;
+        cumulativeTravelTime = 0;
+    }
+};
+
+// ====================================================================== C ABI
+static std::string g_createError;
+
+template <typename T> static void copyIn(std::vector<T> &dst, const T *src, size_t n) { dst.assign(src, src + n); }
+
+extern "C" {
+
+int32_t cfx_abi_version(void) { return CFX_ABI_VERSION; }
+const char *cfx_backend_name(void) { return "cpu-twin"; }
+
+int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
+    if (!n || !cfg || !out) {
+        g_createError = "null argument";
+        return CFX_ERR_INVALID;
+    }
+    if (cfg->lane_change) {
+        g_createError = "lane_change is not supported";
+        return CFX_ERR_INVALID;
+    }
+    cfx_engine *e = new cfx_engine();
+    e->cfg = *cfg;
+    Net &t = e->net;
+    t.R = n->n_roads;
+    t.L = n->n_lanes;
+    t.K = n->n_lanelinks;
+    t.I = n->n_inters;
+    t.E = n->n_xentries;
+    const int D = t.L + t.K;
+    copyIn(t.drvLength, n->drv_length, D);
+    copyIn(t.drvMaxSpeed, n->drv_max_speed, D);
+    copyIn(t.laneRoad, n->lane_road, t.L);
+    copyIn(t.laneIndex, n->lane_index, t.L);
+    copyIn(t.laneLLStart, n->lane_ll_start, t.L + 1);
+    copyIn(t.laneLL, n->lane_ll, t.K);
+    copyIn(t.roadLaneStart, n->road_lane_start, t.R + 1);
+    copyIn(t.llStartLane, n->ll_start_lane, t.K);
+    copyIn(t.llEndLane, n->ll_end_lane, t.K);
+    copyIn(t.llInter, n->ll_inter, t.K);
+    copyIn(t.llRoadLink, n->ll_roadlink, t.K);
+    copyIn(t.llType, n->ll_type, t.K);
+    copyIn(t.llXStart, n->ll_x_start, t.K + 1);
+    copyIn(t.xDist, n->x_dist, t.E);
+    copyIn(t.xPeer, n->x_peer, t.E);
+    copyIn(t.xLL, n->x_ll, t.E);
+    copyIn(t.interVirtual, n->inter_virtual, t.I);
+    copyIn(t.interNRL, n->inter_n_roadlinks, t.I);
+    copyIn(t.interPhaseStart, n->inter_phase_start, t.I + 1);
+    copyIn(t.interAvailStart, n->inter_avail_start, t.I);
+    copyIn(t.phaseTime, n->phase_time, n->n_phases);
+    copyIn(t.phaseAvail, n->phase_avail, n->n_avail);
+    e->order.assign(D, {});
+    e->waiting.assign(t.L, {});
+    e->notifyVid.assign(t.E, -1);
+    e->notifyDist.assign(t.E, 0.0);
+    e->curPhase.assign(t.I, 0);
+    e->remain.assign(t.I, 0.0);
+    e->resetState();
+    *out = e;
+    return CFX_OK;
+}
+
+void cfx_destroy(cfx_engine *e) { delete e; }
+const char *cfx_last_error(const cfx_engine *e) { return e ? e->err.c_str() : g_createError.c_str(); }
+
+int32_t cfx_add_templates(cfx_engine *e, int32_t n, const cfx_vehicle_template *t) {
+    e->templ.insert(e->templ.end(), t, t + n);
+    return CFX_OK;
+}
+
+int32_t cfx_add_routes(cfx_engine *e, int32_t nRoutes, const int32_t *routeStart, const int32_t *roads,
+                       const int32_t *nextStart, const int32_t *nextLL) {
+    int roadBase = (int) e->routeRoads.size();
+    int nextBase = (int) e->nextLL.size();
+    int nPos = routeStart[nRoutes];
+    for (int r = 1; r <= nRoutes; ++r) e->routeStart.push_back(roadBase + routeStart[r]);
+    e->routeRoads.insert(e->routeRoads.end(), roads, roads + nPos);
+    for (int p = 1; p <= nPos; ++p) e->nextStart.push_back(nextBase + nextStart[p]);
+    e->nextLL.insert(e->nextLL.end(), nextLL, nextLL + nextStart[nPos]);
+    return CFX_OK;
+}
+
+int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
+    e->err.clear();
+    e->stepOnce(recs, n);
+    return e->err.empty() ? CFX_OK : CFX_ERR_INVALID;
+}
+int32_t cfx_sync(cfx_engine *) { return CFX_OK; }
+int32_t cfx_reset(cfx_engine *e) {
+    e->resetState();
+    return CFX_OK;
+}
+
+int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
+    if (inter < 0 || inter >= e->net.I || e->net.interVirtual[inter] || phase < 0 ||
+        phase >= e->net.interPhaseStart[inter + 1] - e->net.interPhaseStart[inter]) {
+        e->err = "cfx_set_tl_phase: index out of range";
+        return CFX_ERR_INVALID;
+    }
+    e->curPhase[inter] = phase;  // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched)
+    return CFX_OK;
+}
+
+int32_t cfx_get_tl_state(cfx_engine *e, int32_t *phase, double *remain) {
+    if (phase) memcpy(phase, e->curPhase.data(), e->net.I * sizeof(int32_t));
+    if (remain) memcpy(remain, e->remain.data(), e->net.I * sizeof(double));
+    return CFX_OK;
+}
+
+int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
+    out->step = e->step;
+    out->active_vehicle_count = e->active;
+    out->finished_vehicle_count = e->finishedCnt;
+    out->spawned_vehicle_count = (int64_t) e->veh.size();
+    out->cumulative_travel_time = e->cumulativeTravelTime;
+    double s = 0;
+    for (const Veh &v : e->veh)
+        if (!v.finished) s += v.enterTime;
+    out->live_enter_time_sum = s;
+    return CFX_OK;
+}
+
+int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {  // Engine::getLaneVehicleCount engine.cpp:628-634
+    for (int l = 0; l < e->net.L; ++l) out[l] = (int32_t) e->order[l].size();
+    return CFX_OK;
+}
+
+int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out) {  // engine.cpp:636-648
+    for (int l = 0; l < e->net.L; ++l) {
+        int cnt = 0;
+        for (int32_t vid : e->order[l])
+            if (e->veh[vid].speed < 0.1) cnt += 1;
+        out[l] = cnt;
+    }
+    return CFX_OK;
+}
+
+int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
+    int n = 0;
+    for (auto &list : e->order) n += (int) list.size();
+    view->count = n;
+    if (n > view->capacity) {
+        e->err = "cfx_get_vehicles: capacity too small";
+        return CFX_ERR_CAPACITY;
+    }
+    int i = 0;
+    for (auto &list : e->order)
+        for (int32_t vid : list) {
+            const Veh &v = e->veh[vid];
+            if (view->vid) view->vid[i] = vid;
+            if (view->drivable) view->drivable[i] = v.drivable;
+            if (view->prev_drivable) view->prev_drivable[i] = v.prevDrivable;
+            if (view->leader_vid) view->leader_vid[i] = v.leader;
+            if (view->blocker_vid) view->blocker_vid[i] = v.blocker;
+            if (view->enter_ll_time) view->enter_ll_time[i] = v.enterLLTime;
+            if (view->route_pos) view->route_pos[i] = v.routePos;
+            if (view->dis) view->dis[i] = v.dis;
+            if (view->speed) view->speed[i] = v.speed;
+            if (view->gap) view->gap[i] = v.gap;
+            ++i;
+        }
+    return CFX_OK;
+}
+
+int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first, int32_t n, uint8_t *out) {
+    if (first < 0 || n < 0 || first + n > (int32_t) e->veh.size()) {
+        e->err = "cfx_get_vehicle_status: range out of bounds";
+        return CFX_ERR_INVALID;
+    }
+    for (int i = 0; i < n; ++i) {
+        const Veh &v = e->veh[first + i];
+        out[i] = v.finished ? 2 : (v.running ? 1 : 0);
+    }
+    return CFX_OK;
+}
+
+int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *lane, int32_t *n) {
+    int i = 0;
+    for (int l = 0; l < e->net.L; ++l)
+        for (int32_t v : e->waiting[l]) {
+            if (i >= capacity) {
+                e->err = "cfx_get_waiting: capacity too small";
+                return CFX_ERR_CAPACITY;
+            }
+            vid[i] = v;
+            lane[i] = l;
+            ++i;
+        }
+    *n = i;
+    return CFX_OK;
+}
+
+}  // extern "C"
