@@ -1,0 +1,276 @@
+// Device-side data model and per-vehicle arithmetic of the cfx HIP engine (gfx950).
+//
+// Layout: every running vehicle occupies one SLOT of a set of struct-of-arrays
+// buffers; slots are ordered by (drivable, position in Drivable::vehicles), so
+//   * a drivable's vehicles are the contiguous range [segStart[d], segStart[d] + cnt[d]),
+//   * a vehicle's in-lane leader is simply slot-1 (adjacent => coalesced),
+//   * every lane segment carries ONE spare slot at its tail for this step's admission
+//     (Engine::handleWaiting admits at most one vehicle per lane per step, engine.cpp:502-516).
+// The order is rebuilt every step by a stable counting compaction (update-location phase).
+//
+// All arithmetic is FP64, compiled with -ffp-contract=off, and keeps the reference's operation order
+// (reference file:line cited per function) so results are bit-identical to the x86 reference build.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cityflow_amd.h"
+
+#define CFX_INT_MAX 2147483647
+
+struct DevNet {
+    int R, L, K, I, E;
+    const double *drvLength, *drvMaxSpeed, *xDist, *phaseTime;
+    const int32_t *laneRoad, *laneIndex, *laneLLStart, *laneLL, *llStartLane, *llEndLane, *llInter, *llRoadLink, *llType,
+        *llXStart, *xPeer, *xLL, *interVirtual, *interNRL, *interPhaseStart, *interAvailStart;
+    const uint8_t *phaseAvail;
+};
+
+struct DevTables {
+    const cfx_vehicle_template *templ;
+    const int32_t *routeStart, *routeRoads, *nextStart, *nextLL;
+};
+
+// Committed per-slot state (double-buffered: rewritten in slot order by the compaction).
+struct SlotArrays {
+    int32_t *vid;       // -1: empty spare slot
+    int32_t *drv;       // ControllerInfo::drivable
+    int32_t *prevDrv;   // ControllerInfo::prevDrivable (-1 none)
+    int32_t *blocker;   // ControllerInfo::blocker as a slot index of the PREVIOUS generation (-1 none);
+                        // resolved through oldToNew[] (see blockerOf)
+    int32_t *enterLLT;  // ControllerInfo::enterLaneLinkTime
+    int32_t *routePos;  // Router::iCurRoad as index into the route
+    int32_t *templ;     // vehicle template index
+    int32_t *route;     // route index
+    double *dis;        // ControllerInfo::dis
+    double *speed;      // VehicleInfo::speed
+};
+
+// Everything the per-step kernels read.  Passed by value (kernel argument segment).
+struct StepCtx {
+    DevNet n;
+    DevTables t;
+    SlotArrays s;             // current generation
+    const int32_t *segStart;  // [D+1]
+    const int32_t *cnt;       // [D] live vehicles per drivable (spare excluded unless filled)
+    const int32_t *admitStep; // [L] step index of the lane's latest admission
+    const int32_t *curPhase;  // [I]
+    const int32_t *oldToNew;  // slot of previous generation -> slot of current generation (-1 removed)
+    const int32_t *vPriority; // [vid]
+    // cross notifications of this step (phase 3 -> phase 4)
+    int32_t *nSlot;           // [E] Cross::notifyVehicles as slot
+    double *nDist;            // [E] Cross::notifyDistances
+    int32_t *llStamp;         // [K] == step+1 iff the laneLink wrote its entries this step
+    int32_t step;
+    double interval;
+};
+
+namespace cfxd {
+
+__device__ __forceinline__ double min2(double x, double y) { return x < y ? x : y; }  // utility.h:70-72
+__device__ __forceinline__ double max2(double x, double y) { return x > y ? x : y; }  // utility.h:66-68
+
+// x86 cvttsd2si semantics for double -> int: out of range / NaN => INT_MIN.
+__device__ __forceinline__ int d2i(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int) 0x80000000;
+    return (int) x;
+}
+
+__device__ __forceinline__ bool isLane(const StepCtx &c, int d) { return d < c.n.L; }
+
+__device__ __forceinline__ const cfx_vehicle_template &T(const StepCtx &c, int slot) { return c.t.templ[c.s.templ[slot]]; }
+
+// Drivable::getLastVehicle as every phase-3/4 reader sees it (this step's admission included).
+__device__ __forceinline__ int lastSlot(const StepCtx &c, int d) {
+    int n = c.cnt[d];
+    return n > 0 ? c.segStart[d] + n - 1 : -1;
+}
+
+// Drivable::getLastVehicle as the LEADER SEARCH saw it.  The reference evaluates leader/gap at the end
+// of the previous step (engine.cpp:429-442), i.e. before this step's admissions, except for a vehicle
+// admitted this step on lane B, whose search runs inside handleWaiting and therefore sees admissions on
+// lanes A < B (engine.cpp:503,512).
+__device__ __forceinline__ int lastSlotForLeader(const StepCtx &c, int d, bool viewerNew, int viewerLane) {
+    int n = c.cnt[d];
+    if (d < c.n.L && c.admitStep[d] == c.step && !(viewerNew && d < viewerLane)) n -= 1;
+    return n > 0 ? c.segStart[d] + n - 1 : -1;
+}
+
+// RoadLink::isAvailable roadnet.h:429-431
+__device__ __forceinline__ bool llAvailable(const StepCtx &c, int k) {
+    int in = c.n.llInter[k];
+    return c.n.phaseAvail[c.n.interAvailStart[in] + c.curPhase[in] * c.n.interNRL[in] + c.n.llRoadLink[k]] != 0;
+}
+__device__ __forceinline__ bool llIsTurn(const StepCtx &c, int k) {  // roadnet.h:433-435
+    int t = c.n.llType[k];
+    return t == 1 || t == 2;
+}
+
+// Router::getNextDrivable(const Drivable*) router.cpp:49-76 through the static per-route table.
+__device__ __forceinline__ int nextOf(const StepCtx &c, int d, int route, int routePos) {
+    if (d >= c.n.L) return c.n.llEndLane[d - c.n.L];
+    int road = c.n.laneRoad[d];
+    int base = c.t.routeStart[route], n = c.t.routeStart[route + 1] - base;
+    int p = routePos;
+    while (p < n && c.t.routeRoads[base + p] != road) ++p;
+    if (p >= n) return -1;
+    int ll = c.t.nextLL[c.t.nextStart[base + p] + c.n.laneIndex[d]];
+    return ll < 0 ? -1 : c.n.L + ll;
+}
+
+__device__ __forceinline__ bool isLastRoad(const StepCtx &c, int d, int route) {  // router.cpp:131-134
+    if (d >= c.n.L) return false;
+    return c.n.laneRoad[d] == c.t.routeRoads[c.t.routeStart[route + 1] - 1];
+}
+
+// ControllerInfo::blocker of the vehicle in `slot`, as a current-generation slot (-1 none).
+__device__ __forceinline__ int blockerOf(const StepCtx &c, int slot) {
+    int b = c.s.blocker[slot];
+    return b >= 0 ? c.oldToNew[b] : -1;
+}
+
+// Vehicle::getNoCollisionSpeed vehicle.cpp:200-209
+__device__ __forceinline__ double noCollisionSpeed(double vL, double dL, double vF, double dF, double gap,
+                                                   double interval, double targetGap) {
+    double cc = vF * interval / 2 + targetGap - 0.5 * vL * vL / dL - gap;
+    double a = 0.5 / dF;
+    double b = 0.5 * interval;
+    if (b * b < 4 * a * cc) return -100;
+    double v1 = 0.5 / a * (sqrt(b * b - 4 * a * cc) - b);
+    double v2 = 2 * vL - dL * interval + 2 * (gap - targetGap) / interval;
+    return min2(v1, v2);
+}
+
+// The few per-vehicle values the intersection logic needs about "a vehicle" (self or foe).
+struct VehRef {
+    double speed;
+    const cfx_vehicle_template *t;
+};
+
+__device__ __forceinline__ double minBrakeDistance(const VehRef &v) {  // vehicle.h:239
+    return 0.5 * v.speed * v.speed / v.t->max_neg_acc;
+}
+
+// Vehicle::getBrakeDistanceAfterAccel vehicle.cpp:302-306
+__device__ __forceinline__ double brakeDistanceAfterAccel(const VehRef &v, double acc, double dec, double interval) {
+    double currentSpeed = v.speed;
+    double nextSpeed = currentSpeed + acc * interval;
+    return (currentSpeed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / dec / 2);
+}
+
+// Vehicle::getStopBeforeSpeed vehicle.cpp:240-250
+__device__ __forceinline__ double stopBeforeSpeed(const VehRef &v, double distance, double interval) {
+    if (brakeDistanceAfterAccel(v, v.t->usual_pos_acc, v.t->usual_neg_acc, interval) < distance)
+        return v.speed + v.t->usual_pos_acc * interval;
+    double takeInterval = 2 * distance / (v.speed + 1e-8) / interval;
+    if (takeInterval >= 1) {
+        return v.speed - v.speed / d2i(takeInterval);
+    } else {
+        return v.speed - v.speed / takeInterval;
+    }
+}
+
+// Vehicle::getDistanceUntilSpeed vehicle.cpp:275-282
+__device__ __forceinline__ double distanceUntilSpeed(const VehRef &v, double speed, double acc, double interval) {
+    if (speed <= v.speed) return 0;
+    int stage1steps = d2i(floor((speed - v.speed) / acc / interval));
+    double stage1speed = v.speed + stage1steps * acc / interval;
+    double stage1dis = (v.speed + stage1speed) * (stage1steps * interval) / 2;
+    return stage1dis + (stage1speed < speed ? ((stage1speed + speed) * interval / 2) : 0);
+}
+
+// Vehicle::getReachSteps vehicle.cpp:252-268
+__device__ __forceinline__ int reachSteps(const VehRef &v, double distance, double targetSpeed, double acc,
+                                          double interval) {
+    if (distance <= 0) return 0;
+    if (v.speed > targetSpeed) return d2i(ceil(distance / v.speed));
+    double distanceUntilTargetSpeed = distanceUntilSpeed(v, targetSpeed, acc, interval);
+    if (distanceUntilTargetSpeed > distance) {
+        return d2i(ceil((sqrt(v.speed * v.speed + 2 * acc * distance) - v.speed) / acc / interval));
+    } else {
+        return d2i(ceil((targetSpeed - v.speed) / acc / interval) +
+                   ceil((distance - distanceUntilTargetSpeed) / targetSpeed / interval));
+    }
+}
+
+// Vehicle::getReachStepsOnLaneLink vehicle.cpp:270-273
+__device__ __forceinline__ int reachStepsOnLaneLink(const StepCtx &c, const VehRef &v, double distance, int k) {
+    return reachSteps(v, distance, llIsTurn(c, k) ? v.t->turn_speed : v.t->max_speed, v.t->usual_pos_acc, c.interval);
+}
+
+// Vehicle::canYield vehicle.cpp:284-287
+__device__ __forceinline__ bool canYield(const VehRef &v, double dist) {
+    return (dist > 0 && minBrakeDistance(v) < dist - v.t->yield_distance) || (dist < 0 && dist + v.t->len < 0);
+}
+
+// Cross::canPass roadnet.cpp:603-676.  `e` = this laneLink's entry of the cross; foe data come from
+// the peer entry written by the notify kernel this step.
+__device__ inline bool canPass(const StepCtx &c, int selfSlot, const VehRef &self, int e, double distanceToLaneLinkStart,
+                               int *foeSlotOut) {
+    int pe = c.n.xPeer[e];
+    int peLL = c.n.xLL[pe];
+    int foeSlot = (c.llStamp[peLL] == c.step + 1) ? c.nSlot[pe] : -1;
+    *foeSlotOut = foeSlot;
+    if (foeSlot < 0) return true;
+    double d1 = c.n.xDist[e] - distanceToLaneLinkStart, d2 = c.nDist[pe];
+    if (!canYield(self, d1)) return true;
+    int t1 = c.n.llType[c.n.xLL[e]];
+    int t2 = c.n.llType[peLL];
+    VehRef foe{c.s.speed[foeSlot], &T(c, foeSlot)};
+    int yield = 0;
+    if (!canYield(foe, d2)) yield = 1;
+    if (yield == 0) {
+        if (t1 > t2) {
+            yield = -1;
+        } else if (t1 < t2) {
+            if (d2 > 0) {
+                int foeSteps = reachStepsOnLaneLink(c, foe, d2, peLL);
+                int mySteps = reachStepsOnLaneLink(c, self, d1, c.n.xLL[e]);
+                if (foeSteps > mySteps) yield = -1;
+            } else {
+                if (d2 + foe.t->len < 0) yield = -1;
+            }
+            if (yield == 0) yield = 1;
+        } else {
+            if (d2 > 0) {
+                int foeSteps = reachStepsOnLaneLink(c, foe, d2, peLL);
+                int mySteps = reachStepsOnLaneLink(c, self, d1, c.n.xLL[e]);
+                if (foeSteps > mySteps) {
+                    yield = -1;
+                } else if (foeSteps < mySteps) {
+                    yield = 1;
+                } else {
+                    int myT = c.s.enterLLT[selfSlot], foeT = c.s.enterLLT[foeSlot];
+                    if (myT == foeT) {
+                        if (d1 == d2) {
+                            yield = c.vPriority[c.s.vid[selfSlot]] > c.vPriority[c.s.vid[foeSlot]] ? -1 : 1;
+                        } else {
+                            yield = d1 < d2 ? -1 : 1;
+                        }
+                    } else {
+                        yield = myT < foeT ? -1 : 1;
+                    }
+                }
+            } else {
+                yield = d2 + foe.t->len < 0 ? -1 : 1;
+            }
+        }
+    }
+    if (yield == 1) {  // Floyd cycle walk over committed blockers (deadlock => pass), roadnet.cpp:662-674
+        int fast = foeSlot, slow = foeSlot;
+        int guard = 0;
+        while (fast >= 0 && blockerOf(c, fast) >= 0) {
+            slow = blockerOf(c, slow);
+            fast = blockerOf(c, blockerOf(c, fast));
+            if (slow == fast) {
+                yield = -1;
+                break;
+            }
+            if (++guard > (1 << 22)) break;  // cannot happen (Floyd terminates); bounds a corrupted chain
+        }
+    }
+    return yield == -1;
+}
+
+}  // namespace cfxd

@@ -1,0 +1,638 @@
+// cfx C ABI (include/cityflow_amd.h) implemented on HIP for gfx950 / MI355X.
+// Host-side bookkeeping of the device engine: buffer ownership and growth, launch sequencing, getters.
+// The arithmetic lives in cfx_device.h / cfx_kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cfx_kernels.h"
+
+using namespace cfxd;
+
+namespace {
+
+std::string g_createError;
+
+#define HIP_TRY(call)                                                                                  \
+    do {                                                                                               \
+        hipError_t err__ = (call);                                                                     \
+        if (err__ != hipSuccess) {                                                                     \
+            fail(std::string(#call) + ": " + hipGetErrorString(err__));                                \
+            return CFX_ERR_DEVICE;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+template <typename T> struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+};
+
+inline int gridFor(size_t n) { return (int) std::max<size_t>(1, (n + kBlock - 1) / kBlock); }
+// grid-stride kernels over slots: enough blocks to fill 256 CUs x 8, never more than needed
+inline int gridStride(size_t n) { return (int) std::min<size_t>(std::max<size_t>(1, (n + kBlock - 1) / kBlock), 2048); }
+
+}  // namespace
+
+struct cfx_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cfx_config cfg{};
+    int R = 0, L = 0, K = 0, D = 0, I = 0, E = 0;
+    std::string err;
+
+    // ---- static network (device) ----
+    DevNet net{};
+    std::vector<void *> owned;  // every device allocation, for teardown
+
+    // ---- tables ----
+    std::vector<cfx_vehicle_template> hTempl;
+    std::vector<int32_t> hRouteStart{0}, hRouteRoads, hNextStart{0}, hNextLL;
+    DBuf<cfx_vehicle_template> dTempl;
+    DBuf<int32_t> dRouteStart, dRouteRoads, dNextStart, dNextLL;
+    bool tablesDirty = false;
+
+    // ---- vehicle table ----
+    VidTable vt{};
+    size_t vidCap = 0;
+    int64_t spawned = 0;
+
+    // ---- slots (two generations) ----
+    SlotArrays gen[2]{};
+    DBuf<int32_t> segStart[2], cnt[2];
+    size_t slotCap = 0;
+    int cur = 0;
+    ActionBuf ab{};
+    CompactScratch cs{};
+    int32_t *oldToNew = nullptr;
+    int32_t *finList = nullptr, *finSorted = nullptr;
+    // getter scratch
+    int32_t *viewLeader = nullptr;
+    double *viewGap = nullptr;
+
+    // ---- per-lane / per-laneLink / per-entry / per-intersection dynamic state ----
+    int32_t *waitHead = nullptr, *admitStep = nullptr, *llStamp = nullptr, *nSlot = nullptr, *curPhase = nullptr;
+    double *nDist = nullptr, *remain = nullptr;
+    int32_t *blockSums = nullptr;
+    int nScanBlocks = 0;
+    int32_t *laneOut = nullptr;
+    DevScalars *sc = nullptr;
+
+    cfx_spawn *dRecs = nullptr;
+    size_t recCap = 0;
+    // pinned staging ring for the per-step spawn records (the caller may reuse `recs` immediately)
+    static constexpr int kStages = 4;
+    cfx_spawn *hStage[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stageEvent[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    bool stageBusy[kStages] = {false, false, false, false};
+    size_t stageCap = 0;
+    int stageIdx = 0;
+
+    int64_t step = 0;
+    int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
+
+    int fail(const std::string &m) {
+        err = m;
+        return CFX_ERR_DEVICE;
+    }
+
+    template <typename T> int allocRaw(T **p, size_t n) {
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+        *p = (T *) q;
+        owned.push_back(q);
+        return CFX_OK;
+    }
+    void forget(void *q) { owned.erase(std::remove(owned.begin(), owned.end(), q), owned.end()); }
+
+    // Grow a device array preserving its first `keep` elements.
+    template <typename T> int grow(T **p, size_t keep, size_t newCap) {
+        T *np = nullptr;
+        int rc = allocRaw(&np, newCap);
+        if (rc) return rc;
+        if (*p && keep) HIP_TRY(hipMemcpyAsync(np, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        if (*p) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            forget(*p);
+            HIP_TRY(hipFree(*p));
+        }
+        *p = np;
+        return CFX_OK;
+    }
+    template <typename T> int upload(T **dst, const T *src, size_t n) {
+        int rc = allocRaw(dst, n);
+        if (rc) return rc;
+        if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return CFX_OK;
+    }
+
+    template <typename T> int uploadConst(const T *&field, const T *src, size_t n) {
+        T *tmp = nullptr;
+        int rc = upload(&tmp, src, n);
+        field = tmp;
+        return rc;
+    }
+
+    StepCtx ctx() const {
+        StepCtx c{};
+        c.n = net;
+        c.t.templ = dTempl.p;
+        c.t.routeStart = dRouteStart.p;
+        c.t.routeRoads = dRouteRoads.p;
+        c.t.nextStart = dNextStart.p;
+        c.t.nextLL = dNextLL.p;
+        c.s = gen[cur];
+        c.segStart = segStart[cur].p;
+        c.cnt = cnt[cur].p;
+        c.admitStep = admitStep;
+        c.curPhase = curPhase;
+        c.oldToNew = oldToNew;
+        c.vPriority = vt.priority;
+        c.nSlot = nSlot;
+        c.nDist = nDist;
+        c.llStamp = llStamp;
+        c.step = (int32_t) step;
+        c.interval = cfg.interval;
+        return c;
+    }
+
+    int ensureVidCap(size_t need) {
+        if (need <= vidCap) return CFX_OK;
+        size_t nc = std::max<size_t>(need, std::max<size_t>(vidCap * 2, 1 << 16));
+        int rc;
+        if ((rc = grow(&vt.priority, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.templ, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.route, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.nextWait, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.enterTime, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.state, (size_t) spawned, nc))) return rc;
+        // nextWait of not-yet-used vids must read -1 (k_spawn_link relies on it)
+        HIP_TRY(hipMemsetAsync(vt.nextWait + spawned, 0xFF, (nc - (size_t) spawned) * sizeof(int32_t), stream));
+        vidCap = nc;
+        return CFX_OK;
+    }
+
+    int ensureSlotCap(size_t need) {
+        if (need <= slotCap) return CFX_OK;
+        // refresh the live bound first: maybe no growth is needed
+        size_t nc = std::max<size_t>(need + need / 2, 1 << 14);
+        // the current generation must be preserved; everything else is scratch
+        SlotArrays &g = gen[cur];
+        size_t keep = slotCap;
+        int rc;
+#define GROW_KEEP(f) if ((rc = grow(&g.f, keep, nc))) return rc;
+        GROW_KEEP(vid) GROW_KEEP(drv) GROW_KEEP(prevDrv) GROW_KEEP(blocker) GROW_KEEP(enterLLT) GROW_KEEP(routePos)
+        GROW_KEEP(templ) GROW_KEEP(route) GROW_KEEP(dis) GROW_KEEP(speed)
+#undef GROW_KEEP
+        SlotArrays &o = gen[cur ^ 1];
+#define GROW_SCRATCH(ptr) if ((rc = grow(&ptr, 0, nc))) return rc;
+        GROW_SCRATCH(o.vid) GROW_SCRATCH(o.drv) GROW_SCRATCH(o.prevDrv) GROW_SCRATCH(o.blocker) GROW_SCRATCH(o.enterLLT)
+        GROW_SCRATCH(o.routePos) GROW_SCRATCH(o.templ) GROW_SCRATCH(o.route) GROW_SCRATCH(o.dis) GROW_SCRATCH(o.speed)
+        GROW_SCRATCH(ab.dis) GROW_SCRATCH(ab.speed) GROW_SCRATCH(ab.drv) GROW_SCRATCH(ab.blocker)
+        GROW_SCRATCH(cs.inNext) GROW_SCRATCH(finList) GROW_SCRATCH(finSorted) GROW_SCRATCH(viewLeader) GROW_SCRATCH(viewGap)
+#undef GROW_SCRATCH
+        if ((rc = grow(&oldToNew, keep, nc))) return rc;  // committed blockers point through it
+        slotCap = nc;
+        return CFX_OK;
+    }
+
+    int syncTables() {
+        if (!tablesDirty) return CFX_OK;
+        auto up = [this](auto &dbuf, const auto &h) -> int {
+            using T = typename std::remove_reference<decltype(*dbuf.p)>::type;
+            if (h.size() > dbuf.cap) {
+                size_t nc = std::max<size_t>(h.size() * 2, 64);
+                int rc = grow(&dbuf.p, 0, nc);
+                if (rc) return rc;
+                dbuf.cap = nc;
+            }
+            if (!h.empty()) HIP_TRY(hipMemcpyAsync(dbuf.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+            return CFX_OK;
+        };
+        // kernels in flight may still read the old buffers: drain before (re)uploading
+        HIP_TRY(hipStreamSynchronize(stream));
+        int rc;
+        if ((rc = up(dTempl, hTempl))) return rc;
+        if ((rc = up(dRouteStart, hRouteStart))) return rc;
+        if ((rc = up(dRouteRoads, hRouteRoads))) return rc;
+        if ((rc = up(dNextStart, hNextStart))) return rc;
+        if ((rc = up(dNextLL, hNextLL))) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));  // sources are pageable host vectors
+        tablesDirty = false;
+        return CFX_OK;
+    }
+
+    int readScalars(DevScalars &out) {
+        HIP_TRY(hipMemcpyAsync(&out, sc, sizeof(DevScalars), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        finishedKnown = out.finishedCnt;
+        if (out.overflow) return fail("device capacity overflow (finish list)");
+        return CFX_OK;
+    }
+
+    int resetState() {
+        HIP_TRY(hipStreamSynchronize(stream));
+        cur = 0;
+        step = 0;
+        spawned = 0;
+        finishedKnown = 0;
+        hipLaunchKernelGGL(k_init_layout, dim3(gridFor(D + 1)), dim3(kBlock), 0, stream, D, L, segStart[0].p, cnt[0].p,
+                           gen[0].vid);
+        hipLaunchKernelGGL(k_init_lights, dim3(gridFor(I)), dim3(kBlock), 0, stream, net, curPhase, remain);
+        HIP_TRY(hipMemsetAsync(waitHead, 0xFF, L * sizeof(int32_t), stream));
+        HIP_TRY(hipMemsetAsync(admitStep, 0xFF, L * sizeof(int32_t), stream));
+        HIP_TRY(hipMemsetAsync(llStamp, 0, K * sizeof(int32_t), stream));
+        HIP_TRY(hipMemsetAsync(sc, 0, sizeof(DevScalars), stream));
+        HIP_TRY(hipMemsetAsync(oldToNew, 0xFF, slotCap * sizeof(int32_t), stream));
+        if (vidCap) HIP_TRY(hipMemsetAsync(vt.nextWait, 0xFF, vidCap * sizeof(int32_t), stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        return CFX_OK;
+    }
+};
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int32_t cfx_abi_version(void) { return CFX_ABI_VERSION; }
+const char *cfx_backend_name(void) { return "hip-gfx950"; }
+const char *cfx_last_error(const cfx_engine *e) { return e ? e->err.c_str() : g_createError.c_str(); }
+
+void cfx_destroy(cfx_engine *e) {
+    if (!e) return;
+    (void) hipSetDevice(e->device);
+    if (e->stream) (void) hipStreamSynchronize(e->stream);
+    for (void *p : e->owned) (void) hipFree(p);
+    for (int i = 0; i < cfx_engine::kStages; ++i) {
+        if (e->hStage[i]) (void) hipHostFree(e->hStage[i]);
+        if (e->stageEvent[i]) (void) hipEventDestroy(e->stageEvent[i]);
+    }
+    if (e->stream) (void) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg) {
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return e->fail("no HIP device visible");
+    e->device = cfg->device % ndev;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->cfg = *cfg;
+    e->R = n->n_roads;
+    e->L = n->n_lanes;
+    e->K = n->n_lanelinks;
+    e->D = e->L + e->K;
+    e->I = n->n_inters;
+    e->E = n->n_xentries;
+    DevNet &d = e->net;
+    d.R = e->R;
+    d.L = e->L;
+    d.K = e->K;
+    d.I = e->I;
+    d.E = e->E;
+    int rc;
+#define UP(field, src, count) \
+    if ((rc = e->uploadConst(d.field, src, (size_t) (count)))) return rc;
+    UP(drvLength, n->drv_length, e->D)
+    UP(drvMaxSpeed, n->drv_max_speed, e->D)
+    UP(laneRoad, n->lane_road, e->L)
+    UP(laneIndex, n->lane_index, e->L)
+    UP(laneLLStart, n->lane_ll_start, e->L + 1)
+    UP(laneLL, n->lane_ll, e->K)
+    UP(llStartLane, n->ll_start_lane, e->K)
+    UP(llEndLane, n->ll_end_lane, e->K)
+    UP(llInter, n->ll_inter, e->K)
+    UP(llRoadLink, n->ll_roadlink, e->K)
+    UP(llType, n->ll_type, e->K)
+    UP(llXStart, n->ll_x_start, e->K + 1)
+    UP(xDist, n->x_dist, e->E)
+    UP(xPeer, n->x_peer, e->E)
+    UP(xLL, n->x_ll, e->E)
+    UP(interVirtual, n->inter_virtual, e->I)
+    UP(interNRL, n->inter_n_roadlinks, e->I)
+    UP(interPhaseStart, n->inter_phase_start, e->I + 1)
+    UP(interAvailStart, n->inter_avail_start, e->I)
+    UP(phaseTime, n->phase_time, n->n_phases)
+    UP(phaseAvail, n->phase_avail, n->n_avail)
+#undef UP
+    for (int g = 0; g < 2; ++g) {
+        if ((rc = e->allocRaw(&e->segStart[g].p, (size_t) e->D + 1))) return rc;
+        if ((rc = e->allocRaw(&e->cnt[g].p, (size_t) e->D))) return rc;
+    }
+    if ((rc = e->allocRaw(&e->cs.leaveCnt, (size_t) e->D))) return rc;
+    if ((rc = e->allocRaw(&e->cs.maxLeaveIdx, (size_t) e->D))) return rc;
+    if ((rc = e->allocRaw(&e->cs.inCnt, (size_t) e->D))) return rc;
+    if ((rc = e->allocRaw(&e->cs.inHead, (size_t) e->D))) return rc;
+    if ((rc = e->allocRaw(&e->waitHead, (size_t) e->L))) return rc;
+    if ((rc = e->allocRaw(&e->admitStep, (size_t) e->L))) return rc;
+    if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
+    if ((rc = e->allocRaw(&e->llStamp, (size_t) e->K))) return rc;
+    if ((rc = e->allocRaw(&e->nSlot, (size_t) e->E))) return rc;
+    if ((rc = e->allocRaw(&e->nDist, (size_t) e->E))) return rc;
+    if ((rc = e->allocRaw(&e->curPhase, (size_t) e->I))) return rc;
+    if ((rc = e->allocRaw(&e->remain, (size_t) e->I))) return rc;
+    e->nScanBlocks = (e->D + kScanTile - 1) / kScanTile;
+    if ((rc = e->allocRaw(&e->blockSums, (size_t) e->nScanBlocks))) return rc;
+    if ((rc = e->allocRaw(&e->sc, 1))) return rc;
+    if ((rc = e->ensureSlotCap((size_t) e->L + 4096))) return rc;
+    if ((rc = e->ensureVidCap(1 << 16))) return rc;
+    return e->resetState();
+}
+
+int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
+    if (!n || !cfg || !out) {
+        g_createError = "cfx_create: null argument";
+        return CFX_ERR_INVALID;
+    }
+    if (cfg->lane_change) {
+        g_createError = "cfx_create: lane_change is not supported by ABI version 1";
+        return CFX_ERR_INVALID;
+    }
+    cfx_engine *e = new cfx_engine();
+    int32_t rc = createImpl(e, n, cfg);
+    if (rc != CFX_OK) {
+        g_createError = e->err;
+        cfx_destroy(e);
+        *out = nullptr;
+        return rc;
+    }
+    *out = e;
+    return CFX_OK;
+}
+
+int32_t cfx_add_templates(cfx_engine *e, int32_t n, const cfx_vehicle_template *t) {
+    if (!e || n < 0 || (n && !t)) return CFX_ERR_INVALID;
+    e->hTempl.insert(e->hTempl.end(), t, t + n);
+    e->tablesDirty = true;
+    return CFX_OK;
+}
+
+int32_t cfx_add_routes(cfx_engine *e, int32_t nRoutes, const int32_t *routeStart, const int32_t *roads,
+                       const int32_t *nextStart, const int32_t *nextLL) {
+    if (!e || nRoutes < 0) return CFX_ERR_INVALID;
+    int roadBase = (int) e->hRouteRoads.size();
+    int nextBase = (int) e->hNextLL.size();
+    int nPos = routeStart[nRoutes];
+    for (int r = 1; r <= nRoutes; ++r) e->hRouteStart.push_back(roadBase + routeStart[r]);
+    e->hRouteRoads.insert(e->hRouteRoads.end(), roads, roads + nPos);
+    for (int p = 1; p <= nPos; ++p) e->hNextStart.push_back(nextBase + nextStart[p]);
+    e->hNextLL.insert(e->hNextLL.end(), nextLL, nextLL + nextStart[nPos]);
+    e->tablesDirty = true;
+    return CFX_OK;
+}
+
+int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
+    if (!e || n < 0 || (n && !recs)) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->syncTables())) return rc;
+    hipStream_t st = e->stream;
+
+    // ---- phase 0/1 tail: hand the spawn records to the device
+    if (n > 0) {
+        if (recs[0].vid != e->spawned) return e->fail("cfx_step: spawn records must continue the dense vid sequence");
+        if ((rc = e->ensureVidCap((size_t) e->spawned + n))) return rc;
+        if ((size_t) n > e->recCap) {
+            size_t nc = std::max<size_t>((size_t) n * 2, 1024);
+            if ((rc = e->grow(&e->dRecs, 0, nc))) return rc;
+            e->recCap = nc;
+        }
+        if ((size_t) n > e->stageCap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            size_t nc = std::max<size_t>((size_t) n * 2, 1024);
+            for (int i = 0; i < cfx_engine::kStages; ++i) {
+                if (e->hStage[i]) HIP_TRY(hipHostFree(e->hStage[i]));
+                HIP_TRY(hipHostMalloc((void **) &e->hStage[i], nc * sizeof(cfx_spawn), hipHostMallocDefault));
+                if (!e->stageEvent[i]) HIP_TRY(hipEventCreateWithFlags(&e->stageEvent[i], hipEventDisableTiming));
+                e->stageBusy[i] = false;
+            }
+            e->stageCap = nc;
+        }
+        const int si = e->stageIdx;
+        e->stageIdx = (si + 1) % cfx_engine::kStages;
+        if (e->stageBusy[si]) HIP_TRY(hipEventSynchronize(e->stageEvent[si]));
+        memcpy(e->hStage[si], recs, (size_t) n * sizeof(cfx_spawn));
+        HIP_TRY(hipMemcpyAsync(e->dRecs, e->hStage[si], (size_t) n * sizeof(cfx_spawn), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(e->stageEvent[si], st));
+        e->stageBusy[si] = true;
+        hipLaunchKernelGGL(k_spawn_link, dim3(gridFor(n)), dim3(kBlock), 0, st, e->dRecs, n, (int) e->spawned, e->vt,
+                           e->waitHead);
+        e->spawned += n;
+    }
+    // ---- slot capacity: live vehicles <= spawned - finished; plus one spare per lane
+    size_t need = (size_t) (e->spawned - e->finishedKnown) + (size_t) e->L + 1;
+    if (need > e->slotCap) {
+        DevScalars s;
+        if ((rc = e->readScalars(s))) return rc;  // refresh finishedKnown
+        need = (size_t) (e->spawned - e->finishedKnown) + (size_t) e->L + 1;
+        if ((rc = e->ensureSlotCap(need))) return rc;
+    }
+
+    StepCtx c = e->ctx();
+    const int nxt = e->cur ^ 1;
+    const size_t slotBound = std::min(need, e->slotCap);
+    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c, e->cnt[e->cur].p, e->admitStep, e->waitHead,
+                       e->vt, e->cs, e->sc);
+    hipLaunchKernelGGL(k_notify, dim3(gridFor(e->K)), dim3(kBlock), 0, st, c, e->cs);
+    hipLaunchKernelGGL(k_action, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->ab);
+    hipLaunchKernelGGL(k_count, dim3(gridStride(std::max<size_t>(slotBound, e->I))), dim3(kBlock), 0, st, c, e->ab, e->cs,
+                       e->vt, e->sc, e->finList, (int) e->slotCap, e->curPhase, e->remain, e->cfg.rl_traffic_light);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
+                       e->blockSums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, e->nScanBlocks, e->blockSums, c, e->vt, e->sc, e->finList,
+                       e->finSorted, (int) e->slotCap);
+    hipLaunchKernelGGL(k_scan_apply, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
+                       e->blockSums, e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid);
+    hipLaunchKernelGGL(k_scatter, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt],
+                       e->segStart[nxt].p, e->oldToNew);
+    HIP_TRY(hipGetLastError());
+    e->cur = nxt;
+    e->step += 1;
+    return CFX_OK;
+}
+
+int32_t cfx_sync(cfx_engine *e) {
+    if (!e) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_reset(cfx_engine *e) {
+    if (!e) return CFX_ERR_INVALID;
+    (void) hipSetDevice(e->device);
+    return e->resetState();
+}
+
+int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
+    if (!e) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    if (inter < 0 || inter >= e->I) {
+        e->err = "cfx_set_tl_phase: intersection index out of range";
+        return CFX_ERR_INVALID;
+    }
+    // range check against the host copy is the caller's job for speed; here only non-negativity
+    if (phase < 0) {
+        e->err = "cfx_set_tl_phase: negative phase";
+        return CFX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream
+    HIP_TRY(hipMemcpyAsync(e->curPhase + inter, &phase, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_get_tl_state(cfx_engine *e, int32_t *phase, double *remain) {
+    if (!e) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    if (phase) HIP_TRY(hipMemcpyAsync(phase, e->curPhase, e->I * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (remain) HIP_TRY(hipMemcpyAsync(remain, e->remain, e->I * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    (void) hipSetDevice(e->device);
+    DevScalars s;
+    int rc = e->readScalars(s);
+    if (rc) return rc;
+    out->step = e->step;
+    out->active_vehicle_count = s.active;
+    out->finished_vehicle_count = s.finishedCnt;
+    out->spawned_vehicle_count = e->spawned;
+    out->cumulative_travel_time = s.cumulativeTravelTime;
+    out->live_enter_time_sum = 0.0;  // not maintained on the device path
+    return CFX_OK;
+}
+
+int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(out, e->cnt[e->cur].p, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->syncTables())) return rc;
+    hipLaunchKernelGGL(k_lane_waiting, dim3(gridFor(e->L)), dim3(kBlock), 0, e->stream, e->ctx(), e->laneOut);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, e->laneOut, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
+    if (!e || !view) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->syncTables())) return rc;
+    // number of slots of the current generation
+    int32_t S = 0;
+    HIP_TRY(hipMemcpyAsync(&S, e->segStart[e->cur].p + e->D, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    StepCtx c = e->ctx();
+    hipLaunchKernelGGL(k_leader_view, dim3(gridStride(S)), dim3(kBlock), 0, e->stream, c, e->viewLeader, e->viewGap);
+    HIP_TRY(hipGetLastError());
+    const SlotArrays &g = e->gen[e->cur];
+    std::vector<int32_t> vid(S), drv(S), prev(S), blk(S), ellt(S), rpos(S), lead(S), o2n(e->slotCap);
+    std::vector<double> dis(S), speed(S), gap(S);
+    auto dl = [&](void *dst, const void *src, size_t bytes) {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream);
+    };
+    if (S) {
+        HIP_TRY(dl(vid.data(), g.vid, S * 4));
+        HIP_TRY(dl(drv.data(), g.drv, S * 4));
+        HIP_TRY(dl(prev.data(), g.prevDrv, S * 4));
+        HIP_TRY(dl(blk.data(), g.blocker, S * 4));
+        HIP_TRY(dl(ellt.data(), g.enterLLT, S * 4));
+        HIP_TRY(dl(rpos.data(), g.routePos, S * 4));
+        HIP_TRY(dl(lead.data(), e->viewLeader, S * 4));
+        HIP_TRY(dl(dis.data(), g.dis, S * 8));
+        HIP_TRY(dl(speed.data(), g.speed, S * 8));
+        HIP_TRY(dl(gap.data(), e->viewGap, S * 8));
+        HIP_TRY(dl(o2n.data(), e->oldToNew, e->slotCap * 4));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int n = 0;
+    for (int s = 0; s < S; ++s) n += vid[s] >= 0;
+    view->count = n;
+    if (n > view->capacity) {
+        e->err = "cfx_get_vehicles: capacity too small";
+        return CFX_ERR_CAPACITY;
+    }
+    int i = 0;
+    for (int s = 0; s < S; ++s) {
+        if (vid[s] < 0) continue;
+        if (view->vid) view->vid[i] = vid[s];
+        if (view->drivable) view->drivable[i] = drv[s];
+        if (view->prev_drivable) view->prev_drivable[i] = prev[s];
+        if (view->leader_vid) view->leader_vid[i] = lead[s] >= 0 ? vid[lead[s]] : -1;
+        if (view->blocker_vid) {
+            int b = blk[s] >= 0 ? o2n[blk[s]] : -1;
+            view->blocker_vid[i] = b >= 0 ? vid[b] : -1;
+        }
+        if (view->enter_ll_time) view->enter_ll_time[i] = ellt[s];
+        if (view->route_pos) view->route_pos[i] = rpos[s];
+        if (view->dis) view->dis[i] = dis[s];
+        if (view->speed) view->speed[i] = speed[s];
+        if (view->gap) view->gap[i] = gap[s];
+        ++i;
+    }
+    return CFX_OK;
+}
+
+int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first, int32_t n, uint8_t *out) {
+    if (!e || !out || first < 0 || n < 0 || (int64_t) first + n > e->spawned) {
+        if (e) e->err = "cfx_get_vehicle_status: range out of bounds";
+        return CFX_ERR_INVALID;
+    }
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    if (n) HIP_TRY(hipMemcpyAsync(out, e->vt.state + first, (size_t) n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *lane, int32_t *nOut) {
+    if (!e || !nOut) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    // The waiting FIFOs are linked lists through the vid table; walk them on the host (debug / API path).
+    std::vector<int32_t> head(e->L), next((size_t) e->spawned);
+    HIP_TRY(hipMemcpyAsync(head.data(), e->waitHead, e->L * 4, hipMemcpyDeviceToHost, e->stream));
+    if (e->spawned)
+        HIP_TRY(hipMemcpyAsync(next.data(), e->vt.nextWait, (size_t) e->spawned * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int i = 0;
+    for (int l = 0; l < e->L; ++l)
+        for (int v = head[l]; v >= 0; v = next[v]) {
+            if (i >= capacity) {
+                e->err = "cfx_get_waiting: capacity too small";
+                return CFX_ERR_CAPACITY;
+            }
+            if (vid) vid[i] = v;
+            if (lane) lane[i] = l;
+            ++i;
+        }
+    *nOut = i;
+    return CFX_OK;
+}
+
+}  // extern "C"
