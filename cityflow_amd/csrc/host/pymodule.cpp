@@ -76,6 +76,35 @@ py::dict loadRoadnet(const std::string &path) {
     return flatNetToDict(net);
 }
 
+// Same text format as oracle/probe_roadnet.cpp prints from the reference's own loader.
+py::bytes roadnetProbe(const std::string &path) {
+    cfa::HostRoadNet net;
+    net.load(path);
+    const cfx_net &f = net.flat();
+    std::string out;
+    char buf[512];
+    for (int l = 0; l < f.n_lanes; ++l) {
+        snprintf(buf, sizeof buf, "L %s %.17g %.17g %.17g %zu\n", net.laneId(l).c_str(), f.drv_length[l],
+                 f.drv_max_speed[l], net.lanes[l].width, net.lanes[l].laneLinks.size());
+        out += buf;
+    }
+    for (int k = 0; k < f.n_lanelinks; ++k) {
+        snprintf(buf, sizeof buf, "K %s %.17g %d %d\n", net.laneLinkId(k).c_str(), f.drv_length[f.n_lanes + k],
+                 f.ll_type[k], f.ll_x_start[k + 1] - f.ll_x_start[k]);
+        out += buf;
+        for (int e = f.ll_x_start[k]; e < f.ll_x_start[k + 1]; ++e) {
+            snprintf(buf, sizeof buf, "X %.17g %s %.17g\n", f.x_dist[e], net.laneLinkId(f.x_ll[f.x_peer[e]]).c_str(),
+                     f.x_dist[f.x_peer[e]]);
+            out += buf;
+        }
+    }
+    for (auto &in : net.inters) {
+        snprintf(buf, sizeof buf, "T %s %d %zu\n", in.id.c_str(), (int) in.isVirtual, in.phases.size());
+        out += buf;
+    }
+    return py::bytes(out);
+}
+
 py::list spawnSchedule(const std::string &roadnetFile, const std::string &flowFile, double interval, int seed,
                        int threadNum, int steps) {
     cfa::HostRoadNet net;
@@ -198,6 +227,7 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("_flat_net", [](EngineHost &e) { return flatNetToDict(e.net()); });
 
     m.def("_load_roadnet", &loadRoadnet, "path"_a);
+    m.def("_roadnet_probe", &roadnetProbe, "path"_a);
     m.def("_spawn_schedule", &spawnSchedule, "roadnet_file"_a, "flow_file"_a, "interval"_a, "seed"_a, "thread_num"_a,
           "steps"_a);
     m.def("_default_backend_path", &cfa::defaultBackendPath);
