@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path (one `next_step()` of the MI355X-native CityFlow engine = one "step").
+
+Workload (N=1): BASELINE.json configs[2] — the reference generator's 30x30 grid (tests/golden/scenarios/
+grid_30x30, produced by /root/reference/tools/generator) with ~100k concurrently running vehicles.  The stock
+generator's demand never gets near 100k, so 3000 seeded interior-origin flows (one vehicle
+every 6 s each, for the first 240 s) are added on top of the 120 stock flows; after the default 300 warm-up
+steps ~97k vehicles are running.  All inputs are resident in HBM when the timed region starts; per step the
+host only uploads the handful of spawn records of that step (they come from the host-side mt19937 stream).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
+
+N>1: the engine does not tile one road network across GPUs yet — each rank advances an
+independent replica of the workload on its own GPU ("scaling": "weak", no data-path collective); `value` is the
+sum over ranks of vehicle-steps divided by the slowest rank's time.
+
+Output: ONE JSON line on rank 0 (see README of the task contract) with two extra objects:
+  roofline      car-following kernel (k_action): algorithmic bytes (48 B per running vehicle)
+                / average launch duration measured with HIP events on the engine's stream
+  cpu_baseline  the unmodified reference engine (oracle/_ref, prebuilt) timed on this box's host cores on a
+                bounded sample of the same workload (falls back to the CPU twin, kind "port")
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured achievable)
+ACTION_BYTES_PER_VEHICLE = 48  # algorithmic bytes of the car-following (get-action) kernel
+
+N_EXTRA_FLOWS = 3000
+EXTRA_INTERVAL = 6.0
+EXTRA_END = 240
+
+
+def build_workload(workdir, seed):
+    from cityflow_amd import scenarios
+    base = scenarios.materialize("grid_30x30", workdir)
+    d = os.path.dirname(base)
+    flow = os.path.join(d, "flow_bench.json")
+    if not os.path.exists(flow):
+        scenarios.dense_flows(os.path.join(d, "roadnet.json"), flow, N_EXTRA_FLOWS, seed=12345, interval=EXTRA_INTERVAL,
+                              base_flow=os.path.join(d, "flow.json"), end_time=EXTRA_END)
+    return scenarios.materialize("grid_30x30", workdir, flow_file=flow, seed=seed)
+
+
+def cpu_baseline(cfg, budget_s, threads):
+    """Reference engine on the host cores, from step 0 of the same workload, for ~budget_s seconds."""
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    sys.path.insert(0, ref_dir)
+    kind, eng = "reference", None
+    try:
+        import cityflow_ref
+        eng = cityflow_ref.Engine(cfg, threads)
+    except Exception:  # not shipped / not built: time the CPU twin instead
+        from cityflow_amd import _cityflow
+        kind, threads = "port", 1
+        eng = _cityflow.Engine._with_backend(cfg, 1, os.path.join(ref_dir, "libcfx_twin.so"))
+    veh_steps, steps = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        eng.next_step()
+        steps += 1
+        veh_steps += eng.get_vehicle_count()
+        if steps % 5 == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    running = eng.get_vehicle_count()
+    time.sleep(0.2)  # reference destructor race
+    return {
+        "value": veh_steps / dt, "unit": "vehicle-steps/s", "cores": threads, "kind": kind,
+        "steps_per_sec": steps / dt,
+        "sample": "steps 0..%d of the same workload (%d running vehicles at the end), %.1f s of wall time, "
+                  "%d thread(s) of %d host cores" % (steps, running, dt, threads, os.cpu_count() or 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--profile-steps", type=int, default=100, help="instrumented steps for the roofline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="reference thread_num (default min(8, host cores))")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from cityflow_amd import _cityflow
+
+    workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_rank%d" % rank)
+    cfg = build_workload(workdir, seed=rank)
+    eng = _cityflow.Engine(cfg, 1)  # HIP engine on device LOCAL_RANK; raises if the extension/GPU is missing
+    assert eng.backend_name() == "hip-gfx950"
+
+    for _ in range(args.warmup):
+        eng.next_step()
+    eng.sync()
+    sc0 = eng._scalars()
+
+    barrier()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.next_step()
+    eng.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sc1 = eng._scalars()
+    veh_steps = sc1["vehicle_steps"] - sc0["vehicle_steps"]
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.tensor([float(veh_steps)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        veh_steps = int(v.item())
+
+    # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream)
+    roofline = None
+    if rank == 0:
+        scp0 = eng._scalars()
+        eng._profile_enable(True)
+        for _ in range(args.profile_steps):
+            eng.next_step()
+        prof = eng._profile_read()
+        eng._profile_enable(False)
+        scp1 = eng._scalars()
+        act_ms, act_n = prof["k_action"]
+        if act_n:
+            vehicles_per_launch = (scp1["vehicle_steps"] - scp0["vehicle_steps"]) / float(act_n)
+            avg_s = act_ms / act_n / 1e3
+            achieved = ACTION_BYTES_PER_VEHICLE * vehicles_per_launch / avg_s / 1e9
+            step_ms = sum(ms for ms, _n in prof.values()) / act_n
+            roofline = {
+                "bound": "hbm", "kernel": "k_action", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": avg_s * 1e6, "vehicles_per_launch": vehicles_per_launch,
+                "algorithmic_bytes_per_vehicle": ACTION_BYTES_PER_VEHICLE,
+                "measured_over": "%d instrumented steps following the timed region" % args.profile_steps,
+                "kernel_us_per_step": {k: ms / max(n, 1) * 1e3 for k, (ms, n) in prof.items()},
+                "sum_kernel_ms_per_step": step_ms,
+            }
+
+    if rank == 0:
+        cpu = None
+        if args.cpu_seconds > 0:
+            threads = args.cpu_threads or min(8, os.cpu_count() or 1)
+            cpu = cpu_baseline(cfg, args.cpu_seconds, threads)
+        out = {
+            "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "steps_per_sec": args.steps * world / elapsed,
+            "config": {
+                "workload": "30x30 grid (reference generator, --tlPlan, interval 1.0) + %d seeded interior flows "
+                            "(1 veh / %.0f s each until t=%d s); %s" % (
+                                N_EXTRA_FLOWS, EXTRA_INTERVAL, EXTRA_END,
+                                "one replica per GPU" if world > 1 else "single engine"),
+                "running_vehicles_start": sc0["active_vehicle_count"], "running_vehicles_end": sc1["active_vehicle_count"],
+                "lanes": 11160, "lanelinks": 32400, "parallelism": "replica x%d" % world if world > 1 else "1 gpu",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    os._exit(0)  # skip interpreter teardown (reference engine's destructor can hang)
+
+
+if __name__ == "__main__":
+    main()

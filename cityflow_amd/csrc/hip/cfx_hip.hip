@@ -17,6 +17,10 @@ namespace {
 
 std::string g_createError;
 
+enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_NOTIFY, PK_ACTION, PK_COUNT, PK_SCAN, PK_SCATTER, kNumProfKernels };
+const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_notify", "k_action",
+                                                 "k_count", "k_scan", "k_scatter"};
+
 #define HIP_TRY(call)                                                                                  \
     do {                                                                                               \
         hipError_t err__ = (call);                                                                     \
@@ -93,6 +97,44 @@ struct cfx_engine {
 
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
+
+    // ---- optional per-kernel timing (HIP events on this engine's stream) ----
+    bool profiling = false;
+    std::vector<hipEvent_t> evPool;             // pairs: [2i] before, [2i+1] after
+    std::vector<int> evKernel;                  // kernel id of pair i
+    size_t evUsed = 0;                          // pairs in use
+    double profMs[kNumProfKernels] = {};
+    int64_t profLaunches[kNumProfKernels] = {};
+
+    int profBegin(int kernelId) {
+        if (!profiling) return -1;
+        if (evUsed * 2 + 2 > evPool.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return -1;
+                evPool.push_back(ev);
+            }
+            evKernel.push_back(0);
+        }
+        int pair = (int) evUsed++;
+        evKernel[pair] = kernelId;
+        (void) hipEventRecord(evPool[2 * pair], stream);
+        return pair;
+    }
+    void profEnd(int pair) {
+        if (pair >= 0) (void) hipEventRecord(evPool[2 * pair + 1], stream);
+    }
+    void profCollect() {
+        (void) hipStreamSynchronize(stream);
+        for (size_t i = 0; i < evUsed; ++i) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, evPool[2 * i], evPool[2 * i + 1]) == hipSuccess) {
+                profMs[evKernel[i]] += ms;
+                profLaunches[evKernel[i]] += 1;
+            }
+        }
+        evUsed = 0;
+    }
 
     int fail(const std::string &m) {
         err = m;
@@ -266,6 +308,7 @@ void cfx_destroy(cfx_engine *e) {
     (void) hipSetDevice(e->device);
     if (e->stream) (void) hipStreamSynchronize(e->stream);
     for (void *p : e->owned) (void) hipFree(p);
+    for (hipEvent_t ev : e->evPool) (void) hipEventDestroy(ev);
     for (int i = 0; i < cfx_engine::kStages; ++i) {
         if (e->hStage[i]) (void) hipHostFree(e->hStage[i]);
         if (e->stageEvent[i]) (void) hipEventDestroy(e->stageEvent[i]);
@@ -421,8 +464,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         HIP_TRY(hipMemcpyAsync(e->dRecs, e->hStage[si], (size_t) n * sizeof(cfx_spawn), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(e->stageEvent[si], st));
         e->stageBusy[si] = true;
+        { int pp__ = e->profBegin(PK_SPAWN);
         hipLaunchKernelGGL(k_spawn_link, dim3(gridFor(n)), dim3(kBlock), 0, st, e->dRecs, n, (int) e->spawned, e->vt,
                            e->waitHead);
+        e->profEnd(pp__); }
         e->spawned += n;
     }
     // ---- slot capacity: live vehicles <= spawned - finished; plus one spare per lane
@@ -437,20 +482,32 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     StepCtx c = e->ctx();
     const int nxt = e->cur ^ 1;
     const size_t slotBound = std::min(need, e->slotCap);
+    { int pp__ = e->profBegin(PK_ADMIT);
     hipLaunchKernelGGL(k_admit, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c, e->cnt[e->cur].p, e->admitStep, e->waitHead,
                        e->vt, e->cs, e->sc);
+    e->profEnd(pp__); }
+    { int pp__ = e->profBegin(PK_NOTIFY);
     hipLaunchKernelGGL(k_notify, dim3(gridFor(e->K)), dim3(kBlock), 0, st, c, e->cs);
+    e->profEnd(pp__); }
+    { int pp__ = e->profBegin(PK_ACTION);
     hipLaunchKernelGGL(k_action, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->ab);
+    e->profEnd(pp__); }
+    { int pp__ = e->profBegin(PK_COUNT);
     hipLaunchKernelGGL(k_count, dim3(gridStride(std::max<size_t>(slotBound, e->I))), dim3(kBlock), 0, st, c, e->ab, e->cs,
                        e->vt, e->sc, e->finList, (int) e->slotCap, e->curPhase, e->remain, e->cfg.rl_traffic_light);
+    e->profEnd(pp__); }
+    { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan_reduce, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
                        e->blockSums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, e->nScanBlocks, e->blockSums, c, e->vt, e->sc, e->finList,
                        e->finSorted, (int) e->slotCap);
     hipLaunchKernelGGL(k_scan_apply, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
                        e->blockSums, e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid);
+    e->profEnd(pp__); }
+    { int pp__ = e->profBegin(PK_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt],
                        e->segStart[nxt].p, e->oldToNew);
+    e->profEnd(pp__); }
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;
@@ -512,6 +569,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->spawned_vehicle_count = e->spawned;
     out->cumulative_travel_time = s.cumulativeTravelTime;
     out->live_enter_time_sum = 0.0;  // not maintained on the device path
+    out->vehicle_steps = s.vehicleSteps;
     return CFX_OK;
 }
 
@@ -632,6 +690,30 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
             ++i;
         }
     *nOut = i;
+    return CFX_OK;
+}
+
+int32_t cfx_profile_kernel_count(void) { return kNumProfKernels; }
+const char *cfx_profile_kernel_name(int32_t k) { return (k >= 0 && k < kNumProfKernels) ? kProfNames[k] : ""; }
+
+int32_t cfx_profile_enable(cfx_engine *e, int32_t on) {
+    if (!e) return CFX_ERR_INVALID;
+    (void) hipSetDevice(e->device);
+    if (e->profiling && !on) e->profCollect();
+    e->profiling = on != 0;
+    return CFX_OK;
+}
+
+int32_t cfx_profile_read(cfx_engine *e, double *totalMs, int64_t *launches) {
+    if (!e) return CFX_ERR_INVALID;
+    (void) hipSetDevice(e->device);
+    e->profCollect();
+    for (int k = 0; k < kNumProfKernels; ++k) {
+        if (totalMs) totalMs[k] = e->profMs[k];
+        if (launches) launches[k] = e->profLaunches[k];
+        e->profMs[k] = 0;
+        e->profLaunches[k] = 0;
+    }
     return CFX_OK;
 }
 

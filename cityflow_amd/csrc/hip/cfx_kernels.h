@@ -28,6 +28,7 @@ struct DevScalars {
     long long active;          // Engine::activeVehicleCount
     long long finishedCnt;     // Engine::finishedVehicleCnt
     double cumulativeTravelTime;
+    long long vehicleSteps;    // sum over steps of vehicles that ran phase 4
     int nFinishedStep;         // finished vehicles of the step in flight
     int overflow;              // set when an internal capacity was exceeded
 };
@@ -462,6 +463,7 @@ __global__ void k_scan_top(int nBlocks, int32_t *blockSums, StepCtx c, VidTable 
         double cum = sc->cumulativeTravelTime;
         for (int i = 0; i < F; ++i) cum += now - vt.enterTime[c.s.vid[finSorted[i]]];
         sc->cumulativeTravelTime = cum;
+        sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
         sc->finishedCnt += F;
         sc->active -= F;
         sc->nFinishedStep = 0;

@@ -51,6 +51,10 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_get_vehicles)
     CFX_FN(cfx_get_waiting)
     CFX_FN(cfx_get_vehicle_status)
+    CFX_FN(cfx_profile_kernel_count)
+    CFX_FN(cfx_profile_kernel_name)
+    CFX_FN(cfx_profile_enable)
+    CFX_FN(cfx_profile_read)
 #undef CFX_FN
     if (cfx_abi_version() != CFX_ABI_VERSION)
         throw std::runtime_error("cityflow_amd: ABI version mismatch in '" + libPath + "'");
@@ -157,6 +161,18 @@ void EngineHost::nextStep() {
 }
 
 void EngineHost::sync() { check(be_.cfx_sync(dev_), "cfx_sync"); }
+
+void EngineHost::profileEnable(bool on) { check(be_.cfx_profile_enable(dev_, on ? 1 : 0), "cfx_profile_enable"); }
+
+std::map<std::string, std::pair<double, int64_t>> EngineHost::profileRead() {
+    int n = be_.cfx_profile_kernel_count();
+    std::vector<double> ms(n > 0 ? n : 1);
+    std::vector<int64_t> cnt(n > 0 ? n : 1);
+    check(be_.cfx_profile_read(dev_, ms.data(), cnt.data()), "cfx_profile_read");
+    std::map<std::string, std::pair<double, int64_t>> out;
+    for (int k = 0; k < n; ++k) out[be_.cfx_profile_kernel_name(k)] = std::make_pair(ms[k], cnt[k]);
+    return out;
+}
 
 cfx_scalars EngineHost::scalars() {
     cfx_scalars s{};

@@ -40,6 +40,10 @@ struct Backend {
     CFX_FN(cfx_get_vehicles)
     CFX_FN(cfx_get_waiting)
     CFX_FN(cfx_get_vehicle_status)
+    CFX_FN(cfx_profile_kernel_count)
+    CFX_FN(cfx_profile_kernel_name)
+    CFX_FN(cfx_profile_enable)
+    CFX_FN(cfx_profile_read)
 #undef CFX_FN
     void open(const std::string &libPath);  // throws std::runtime_error
     ~Backend();
@@ -88,6 +92,8 @@ public:
     void waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane);
     cfx_scalars scalars();
     void sync();
+    void profileEnable(bool on);
+    std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
 
     const HostRoadNet &net() const { return net_; }
     const Spawner &spawner() const { return spawner_; }

@@ -206,8 +206,11 @@ PYBIND11_MODULE(_cityflow, m) {
                  d["spawned_vehicle_count"] = s.spawned_vehicle_count;
                  d["cumulative_travel_time"] = s.cumulative_travel_time;
                  d["live_enter_time_sum"] = s.live_enter_time_sum;
+                 d["vehicle_steps"] = s.vehicle_steps;
                  return d;
              })
+        .def("_profile_enable", &EngineHost::profileEnable, "on"_a)
+        .def("_profile_read", &EngineHost::profileRead)
         .def("_vehicle_id", &EngineHost::vehicleId, "vid"_a)
         .def("_vehicle_ids",
              [](EngineHost &e, py::array_t<int32_t> vids) {

@@ -68,7 +68,8 @@ def materialize(name, workdir=None, flow_file=None, **config):
     return path
 
 
-def dense_flows(roadnet_path, out_path, n_extra, seed=12345, interval=2.0, min_len=3, max_len=7, base_flow=None):
+def dense_flows(roadnet_path, out_path, n_extra, seed=12345, interval=2.0, min_len=3, max_len=7, base_flow=None,
+                end_time=-1):
     """Write a flow file = `base_flow` (optional, kept first and unchanged) + `n_extra` seeded random-walk flows."""
     with open(roadnet_path) as f:
         net = json.load(f)
@@ -99,7 +100,7 @@ def dense_flows(roadnet_path, out_path, n_extra, seed=12345, interval=2.0, min_l
         if len(route) < 2:
             continue
         flows.append({"vehicle": dict(GRID_VEHICLE), "route": route, "interval": interval,
-                      "startTime": 0, "endTime": -1})
+                      "startTime": 0, "endTime": end_time})
         made += 1
     with open(out_path, "w") as f:
         json.dump(flows, f)

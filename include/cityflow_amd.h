@@ -122,7 +122,8 @@ typedef struct cfx_scalars {
     int64_t finished_vehicle_count;/* Engine::finishedVehicleCnt */
     int64_t spawned_vehicle_count; /* vehicles handed to cfx_step since the last reset */
     double cumulative_travel_time; /* Engine::cumulativeTravelTime */
-    double live_enter_time_sum;    /* sum of enter_time over spawned-and-not-finished vehicles */
+    double live_enter_time_sum;    /* sum of enter_time over spawned-and-not-finished vehicles (0 if not kept) */
+    int64_t vehicle_steps;         /* sum over executed steps of the vehicles that took the step (ran phase 4) */
 } cfx_scalars;
 
 /* Full per-vehicle state of every running vehicle, caller-allocated SoA (any pointer may be NULL).
@@ -179,6 +180,14 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view);
 int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first_vid, int32_t n, uint8_t *out);
 /* vids still sitting in lanes' waiting buffers, lane by lane, FIFO order; returns count via *n */
 int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *lane, int32_t *n);
+
+/* Optional per-kernel timing with HIP events recorded on the engine's own stream (bench.py roofline).
+ * Kernel ids are dense 0..cfx_profile_kernel_count()-1; cfx_profile_read() synchronises, adds the
+ * elapsed time of every bracketed launch since the last read into total_ms[] / launches[] and clears. */
+int32_t cfx_profile_kernel_count(void);
+const char *cfx_profile_kernel_name(int32_t k);
+int32_t cfx_profile_enable(cfx_engine *e, int32_t on);
+int32_t cfx_profile_read(cfx_engine *e, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

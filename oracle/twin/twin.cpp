@@ -5,7 +5,7 @@
 // It follows the REFERENCE's structure (one ordered vehicle list per drivable, one record per vehicle,
 // double-buffered "buffer" fields, phase order of Engine::nextStep) rather than the device's slot layout,
 // so that it is an independent check of the kernels.  Every function cites the reference lines it
-// restates.  It is pinned against oracle/_ref (the unmodified reference) by tests/test_twin_vs_reference.py;
+// restates.  It is pinned against oracle/_ref (the unmodified reference) by tests/test_oracle.py;
 // the product never links, loads or calls it (tests pass its path to Engine._with_backend explicitly).
 //
 // Build: -O2 -ffp-contract=off (no FMA contraction: the reference is plain x86-64 g++ -O2).
@@ -62,7 +62,7 @@ struct cfx_engine {
     std::vector<double> notifyDist;              //                  Cross::notifyDistances[side]
     std::vector<int32_t> curPhase;               // TrafficLight::curPhaseIndex
     std::vector<double> remain;                  // TrafficLight::remainDuration
-    int64_t step = 0, active = 0, finishedCnt = 0;
+    int64_t step = 0, active = 0, finishedCnt = 0, vehicleSteps = 0;
     double cumulativeTravelTime = 0;
     std::string err;
 
@@ -493,6 +493,7 @@ struct cfx_engine {
             Veh &v = veh[vid];
             if (!v.running) continue;
             vehicleControl(v);
+            vehicleSteps += 1;
             if (!v.bEndSet && v.bDrvSet) pushBuffer.push_back((int32_t) vid);
         }
 
@@ -587,6 +588,7 @@ struct cfx_engine {
         step = 0;
         active = 0;
         finishedCnt = 0;
+        vehicleSteps = 0;
         cumulativeTravelTime = 0;
     }
 };
@@ -709,6 +711,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     for (const Veh &v : e->veh)
         if (!v.finished) s += v.enterTime;
     out->live_enter_time_sum = s;
+    out->vehicle_steps = e->vehicleSteps;
     return CFX_OK;
 }
 
@@ -781,5 +784,10 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
     *n = i;
     return CFX_OK;
 }
+
+int32_t cfx_profile_kernel_count(void) { return 0; }
+const char *cfx_profile_kernel_name(int32_t) { return ""; }
+int32_t cfx_profile_enable(cfx_engine *, int32_t) { return CFX_OK; }
+int32_t cfx_profile_read(cfx_engine *, double *, int64_t *) { return CFX_OK; }
 
 }  // extern "C"
