@@ -71,7 +71,8 @@ def cpu_baseline(cfg, budget_s, threads):
             break
     dt = time.perf_counter() - t0
     running = eng.get_vehicle_count()
-    time.sleep(0.2)  # reference destructor race
+    time.sleep(0.2)  # reference destructor race: settle before the engine is dropped
+    del eng
     return {
         "value": veh_steps / dt, "unit": "vehicle-steps/s", "cores": threads, "kind": kind,
         "steps_per_sec": steps / dt,
@@ -188,7 +189,6 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     sys.stdout.flush()
-    os._exit(0)  # skip interpreter teardown (reference engine's destructor can hang)
 
 
 if __name__ == "__main__":

@@ -386,6 +386,7 @@ __global__ void k_count(StepCtx c, ActionBuf b, CompactScratch cs, VidTable vt, 
 // Phase 5b: exclusive scan of the new segment sizes over drivables, 3 launches.
 constexpr int kScanItems = 8;                       // drivables per thread
 constexpr int kScanTile = kBlock * kScanItems;      // drivables per block
+constexpr int kFinLds = 2048;                       // finished vehicles per step staged in LDS
 
 __device__ __forceinline__ int newLiveCount(const int32_t *cnt, const CompactScratch &cs, int d) {
     return cnt[d] - cs.leaveCnt[d] + cs.inCnt[d];
@@ -448,21 +449,43 @@ __global__ void k_scan_top(int nBlocks, int32_t *blockSums, StepCtx c, VidTable 
         if (threadIdx.x == 0) carry += total;
         __syncthreads();
     }
-    // finish statistics
+    // finish statistics: order the step's finished slots (rank sort in LDS), then one thread adds the
+    // travel times in that order (FP64 addition is not associative; the reference adds sequentially)
+    __shared__ int fin[kFinLds];
+    __shared__ double term[kFinLds];
     int F = sc->nFinishedStep;
     if (F > finCap) F = finCap;
-    for (int i = threadIdx.x; i < F; i += blockDim.x) {
-        int me = finList[i];
-        int rank = 0;
-        for (int j = 0; j < F; ++j) rank += finList[j] < me;
-        finSorted[rank] = me;
+    const double now = c.step * c.interval;  // Engine::getCurrentTime engine.cpp:678-680
+    if (F <= kFinLds) {
+        for (int i = threadIdx.x; i < F; i += blockDim.x) fin[i] = finList[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < F; i += blockDim.x) {
+            int me = fin[i];
+            int rank = 0;
+            for (int j = 0; j < F; ++j) rank += fin[j] < me;
+            term[rank] = now - vt.enterTime[c.s.vid[me]];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double cum = sc->cumulativeTravelTime;
+            for (int i = 0; i < F; ++i) cum += term[i];
+            sc->cumulativeTravelTime = cum;
+        }
+    } else {  // more finishers in one step than the LDS staging holds: same algorithm through global memory
+        for (int i = threadIdx.x; i < F; i += blockDim.x) {
+            int me = finList[i];
+            int rank = 0;
+            for (int j = 0; j < F; ++j) rank += finList[j] < me;
+            finSorted[rank] = me;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double cum = sc->cumulativeTravelTime;
+            for (int i = 0; i < F; ++i) cum += now - vt.enterTime[c.s.vid[finSorted[i]]];
+            sc->cumulativeTravelTime = cum;
+        }
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        double now = c.step * c.interval;  // Engine::getCurrentTime engine.cpp:678-680
-        double cum = sc->cumulativeTravelTime;
-        for (int i = 0; i < F; ++i) cum += now - vt.enterTime[c.s.vid[finSorted[i]]];
-        sc->cumulativeTravelTime = cum;
         sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
         sc->finishedCnt += F;
         sc->active -= F;
