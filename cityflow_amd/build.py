@@ -94,7 +94,7 @@ def build_hip(force=False):
         return tgt
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = [f for f in HIP_FLAGS if f]
+    flags = [f for f in HIP_FLAGS if f] + os.environ.get("CFX_HIP_EXTRA_FLAGS", "").split()
     _run([hipcc] + flags + ["-shared", "-I" + INCLUDE, "-I" + HIP_DIR] + srcs + ["-o", tgt])
     return tgt
 

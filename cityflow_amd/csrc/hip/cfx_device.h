@@ -3,7 +3,8 @@
 // Layout: every running vehicle occupies one SLOT of a set of struct-of-arrays
 // buffers; slots are ordered by (drivable, position in Drivable::vehicles), so
 //   * a drivable's vehicles are the contiguous range [segStart[d], segStart[d] + cnt[d]),
-//   * a vehicle's in-lane leader is simply slot-1 (adjacent => coalesced),
+//   * a vehicle's in-lane leader is simply slot-1 (adjacent => coalesced), and a vehicle is the head of
+//     its drivable iff drv[slot-1] differs (no segStart gather needed),
 //   * every lane segment carries ONE spare slot at its tail for this step's admission
 //     (Engine::handleWaiting admits at most one vehicle per lane per step, engine.cpp:502-516).
 // The order is rebuilt every step by a stable counting compaction (update-location phase).
@@ -25,18 +26,24 @@ struct DevNet {
     const int32_t *laneRoad, *laneIndex, *laneLLStart, *laneLL, *llStartLane, *llEndLane, *llInter, *llRoadLink, *llType,
         *llXStart, *xPeer, *xLL, *interVirtual, *interNRL, *interPhaseStart, *interAvailStart;
     const uint8_t *phaseAvail;
+    // derived at cfx_create (not part of the ABI)
+    const int32_t *xPeerBit;        // [E] llLocal of the laneLink owning the peer entry
+    const int32_t *llLocal;         // [K] index of the laneLink inside its intersection
+    const int32_t *interMaskStart;  // [I+1] offsets (in 64-bit words) into the active-laneLink masks
 };
 
 struct DevTables {
     const cfx_vehicle_template *templ;
+    int nTempl;
     const int32_t *routeStart, *routeRoads, *nextStart, *nextLL;
 };
 
 // Committed per-slot state (double-buffered: rewritten in slot order by the compaction).
 struct SlotArrays {
     int32_t *vid;       // -1: empty spare slot
-    int32_t *drv;       // ControllerInfo::drivable
+    int32_t *drv;       // ControllerInfo::drivable (-1 in a spare slot)
     int32_t *prevDrv;   // ControllerInfo::prevDrivable (-1 none)
+    int32_t *next;      // Router::getNextDrivable(0) for the current drivable, cached (-1 none)
     int32_t *blocker;   // ControllerInfo::blocker as a slot index of the PREVIOUS generation (-1 none);
                         // resolved through oldToNew[] (see blockerOf)
     int32_t *enterLLT;  // ControllerInfo::enterLaneLinkTime
@@ -58,10 +65,10 @@ struct StepCtx {
     const int32_t *curPhase;  // [I]
     const int32_t *oldToNew;  // slot of previous generation -> slot of current generation (-1 removed)
     const int32_t *vPriority; // [vid]
-    // cross notifications of this step (phase 3 -> phase 4)
-    int32_t *nSlot;           // [E] Cross::notifyVehicles as slot
-    double *nDist;            // [E] Cross::notifyDistances
-    int32_t *llStamp;         // [K] == step+1 iff the laneLink wrote its entries this step
+    // per-laneLink notification sources of this step (phase 3, Engine::threadNotifyCross)
+    int32_t *llU;             // [K] vehicle that just left onto the end lane (slot) or -1
+    int32_t *llF;             // [K] first vehicle of the start lane heading for this laneLink on green, or -1
+    unsigned long long *interMask;  // active-laneLink bit masks, see DevNet::interMaskStart
     int32_t step;
     double interval;
 };
@@ -76,10 +83,6 @@ __device__ __forceinline__ int d2i(double x) {
     if (!(x > -2147483649.0 && x < 2147483648.0)) return (int) 0x80000000;
     return (int) x;
 }
-
-__device__ __forceinline__ bool isLane(const StepCtx &c, int d) { return d < c.n.L; }
-
-__device__ __forceinline__ const cfx_vehicle_template &T(const StepCtx &c, int slot) { return c.t.templ[c.s.templ[slot]]; }
 
 // Drivable::getLastVehicle as every phase-3/4 reader sees it (this step's admission included).
 __device__ __forceinline__ int lastSlot(const StepCtx &c, int d) {
@@ -102,21 +105,18 @@ __device__ __forceinline__ bool llAvailable(const StepCtx &c, int k) {
     int in = c.n.llInter[k];
     return c.n.phaseAvail[c.n.interAvailStart[in] + c.curPhase[in] * c.n.interNRL[in] + c.n.llRoadLink[k]] != 0;
 }
-__device__ __forceinline__ bool llIsTurn(const StepCtx &c, int k) {  // roadnet.h:433-435
-    int t = c.n.llType[k];
-    return t == 1 || t == 2;
-}
+__device__ __forceinline__ bool typeIsTurn(int t) { return t == 1 || t == 2; }  // roadnet.h:433-435
 
 // Router::getNextDrivable(const Drivable*) router.cpp:49-76 through the static per-route table.
-__device__ __forceinline__ int nextOf(const StepCtx &c, int d, int route, int routePos) {
-    if (d >= c.n.L) return c.n.llEndLane[d - c.n.L];
-    int road = c.n.laneRoad[d];
-    int base = c.t.routeStart[route], n = c.t.routeStart[route + 1] - base;
+__device__ __forceinline__ int nextOf(const DevNet &n, const DevTables &t, int d, int route, int routePos) {
+    if (d >= n.L) return n.llEndLane[d - n.L];
+    int road = n.laneRoad[d];
+    int base = t.routeStart[route], len = t.routeStart[route + 1] - base;
     int p = routePos;
-    while (p < n && c.t.routeRoads[base + p] != road) ++p;
-    if (p >= n) return -1;
-    int ll = c.t.nextLL[c.t.nextStart[base + p] + c.n.laneIndex[d]];
-    return ll < 0 ? -1 : c.n.L + ll;
+    while (p < len && t.routeRoads[base + p] != road) ++p;
+    if (p >= len) return -1;
+    int ll = t.nextLL[t.nextStart[base + p] + n.laneIndex[d]];
+    return ll < 0 ? -1 : n.L + ll;
 }
 
 __device__ __forceinline__ bool isLastRoad(const StepCtx &c, int d, int route) {  // router.cpp:131-134
@@ -195,82 +195,13 @@ __device__ __forceinline__ int reachSteps(const VehRef &v, double distance, doub
 }
 
 // Vehicle::getReachStepsOnLaneLink vehicle.cpp:270-273
-__device__ __forceinline__ int reachStepsOnLaneLink(const StepCtx &c, const VehRef &v, double distance, int k) {
-    return reachSteps(v, distance, llIsTurn(c, k) ? v.t->turn_speed : v.t->max_speed, v.t->usual_pos_acc, c.interval);
+__device__ __forceinline__ int reachStepsOnLaneLink(const VehRef &v, double distance, int llType, double interval) {
+    return reachSteps(v, distance, typeIsTurn(llType) ? v.t->turn_speed : v.t->max_speed, v.t->usual_pos_acc, interval);
 }
 
 // Vehicle::canYield vehicle.cpp:284-287
 __device__ __forceinline__ bool canYield(const VehRef &v, double dist) {
     return (dist > 0 && minBrakeDistance(v) < dist - v.t->yield_distance) || (dist < 0 && dist + v.t->len < 0);
-}
-
-// Cross::canPass roadnet.cpp:603-676.  `e` = this laneLink's entry of the cross; foe data come from
-// the peer entry written by the notify kernel this step.
-__device__ inline bool canPass(const StepCtx &c, int selfSlot, const VehRef &self, int e, double distanceToLaneLinkStart,
-                               int *foeSlotOut) {
-    int pe = c.n.xPeer[e];
-    int peLL = c.n.xLL[pe];
-    int foeSlot = (c.llStamp[peLL] == c.step + 1) ? c.nSlot[pe] : -1;
-    *foeSlotOut = foeSlot;
-    if (foeSlot < 0) return true;
-    double d1 = c.n.xDist[e] - distanceToLaneLinkStart, d2 = c.nDist[pe];
-    if (!canYield(self, d1)) return true;
-    int t1 = c.n.llType[c.n.xLL[e]];
-    int t2 = c.n.llType[peLL];
-    VehRef foe{c.s.speed[foeSlot], &T(c, foeSlot)};
-    int yield = 0;
-    if (!canYield(foe, d2)) yield = 1;
-    if (yield == 0) {
-        if (t1 > t2) {
-            yield = -1;
-        } else if (t1 < t2) {
-            if (d2 > 0) {
-                int foeSteps = reachStepsOnLaneLink(c, foe, d2, peLL);
-                int mySteps = reachStepsOnLaneLink(c, self, d1, c.n.xLL[e]);
-                if (foeSteps > mySteps) yield = -1;
-            } else {
-                if (d2 + foe.t->len < 0) yield = -1;
-            }
-            if (yield == 0) yield = 1;
-        } else {
-            if (d2 > 0) {
-                int foeSteps = reachStepsOnLaneLink(c, foe, d2, peLL);
-                int mySteps = reachStepsOnLaneLink(c, self, d1, c.n.xLL[e]);
-                if (foeSteps > mySteps) {
-                    yield = -1;
-                } else if (foeSteps < mySteps) {
-                    yield = 1;
-                } else {
-                    int myT = c.s.enterLLT[selfSlot], foeT = c.s.enterLLT[foeSlot];
-                    if (myT == foeT) {
-                        if (d1 == d2) {
-                            yield = c.vPriority[c.s.vid[selfSlot]] > c.vPriority[c.s.vid[foeSlot]] ? -1 : 1;
-                        } else {
-                            yield = d1 < d2 ? -1 : 1;
-                        }
-                    } else {
-                        yield = myT < foeT ? -1 : 1;
-                    }
-                }
-            } else {
-                yield = d2 + foe.t->len < 0 ? -1 : 1;
-            }
-        }
-    }
-    if (yield == 1) {  // Floyd cycle walk over committed blockers (deadlock => pass), roadnet.cpp:662-674
-        int fast = foeSlot, slow = foeSlot;
-        int guard = 0;
-        while (fast >= 0 && blockerOf(c, fast) >= 0) {
-            slow = blockerOf(c, slow);
-            fast = blockerOf(c, blockerOf(c, fast));
-            if (slow == fast) {
-                yield = -1;
-                break;
-            }
-            if (++guard > (1 << 22)) break;  // cannot happen (Floyd terminates); bounds a corrupted chain
-        }
-    }
-    return yield == -1;
 }
 
 }  // namespace cfxd

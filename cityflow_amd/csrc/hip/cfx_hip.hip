@@ -17,9 +17,9 @@ namespace {
 
 std::string g_createError;
 
-enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_NOTIFY, PK_ACTION, PK_COUNT, PK_SCAN, PK_SCATTER, kNumProfKernels };
-const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_notify", "k_action",
-                                                 "k_count", "k_scan", "k_scatter"};
+enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_LLSTATE, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, kNumProfKernels };
+const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_llstate", "k_action",
+                                                 "k_cross",      "k_scan",  "k_scatter"};
 
 #define HIP_TRY(call)                                                                                  \
     do {                                                                                               \
@@ -72,14 +72,16 @@ struct cfx_engine {
     ActionBuf ab{};
     CompactScratch cs{};
     int32_t *oldToNew = nullptr;
-    int32_t *finList = nullptr, *finSorted = nullptr;
+    int32_t *finList = nullptr, *finSorted = nullptr, *crossJobs = nullptr;
     // getter scratch
     int32_t *viewLeader = nullptr;
     double *viewGap = nullptr;
 
     // ---- per-lane / per-laneLink / per-entry / per-intersection dynamic state ----
-    int32_t *waitHead = nullptr, *admitStep = nullptr, *llStamp = nullptr, *nSlot = nullptr, *curPhase = nullptr;
-    double *nDist = nullptr, *remain = nullptr;
+    int32_t *waitHead = nullptr, *admitStep = nullptr, *llU = nullptr, *llF = nullptr, *curPhase = nullptr;
+    unsigned long long *interMask = nullptr;
+    int nMaskWords = 0;
+    double *remain = nullptr;
     int32_t *blockSums = nullptr;
     int nScanBlocks = 0;
     int32_t *laneOut = nullptr;
@@ -182,6 +184,7 @@ struct cfx_engine {
         StepCtx c{};
         c.n = net;
         c.t.templ = dTempl.p;
+        c.t.nTempl = (int) hTempl.size();
         c.t.routeStart = dRouteStart.p;
         c.t.routeRoads = dRouteRoads.p;
         c.t.nextStart = dNextStart.p;
@@ -193,9 +196,9 @@ struct cfx_engine {
         c.curPhase = curPhase;
         c.oldToNew = oldToNew;
         c.vPriority = vt.priority;
-        c.nSlot = nSlot;
-        c.nDist = nDist;
-        c.llStamp = llStamp;
+        c.llU = llU;
+        c.llF = llF;
+        c.interMask = interMask;
         c.step = (int32_t) step;
         c.interval = cfg.interval;
         return c;
@@ -226,15 +229,16 @@ struct cfx_engine {
         size_t keep = slotCap;
         int rc;
 #define GROW_KEEP(f) if ((rc = grow(&g.f, keep, nc))) return rc;
-        GROW_KEEP(vid) GROW_KEEP(drv) GROW_KEEP(prevDrv) GROW_KEEP(blocker) GROW_KEEP(enterLLT) GROW_KEEP(routePos)
+        GROW_KEEP(vid) GROW_KEEP(drv) GROW_KEEP(prevDrv) GROW_KEEP(next) GROW_KEEP(blocker) GROW_KEEP(enterLLT) GROW_KEEP(routePos)
         GROW_KEEP(templ) GROW_KEEP(route) GROW_KEEP(dis) GROW_KEEP(speed)
 #undef GROW_KEEP
         SlotArrays &o = gen[cur ^ 1];
 #define GROW_SCRATCH(ptr) if ((rc = grow(&ptr, 0, nc))) return rc;
-        GROW_SCRATCH(o.vid) GROW_SCRATCH(o.drv) GROW_SCRATCH(o.prevDrv) GROW_SCRATCH(o.blocker) GROW_SCRATCH(o.enterLLT)
+        GROW_SCRATCH(o.vid) GROW_SCRATCH(o.drv) GROW_SCRATCH(o.prevDrv) GROW_SCRATCH(o.next) GROW_SCRATCH(o.blocker) GROW_SCRATCH(o.enterLLT)
         GROW_SCRATCH(o.routePos) GROW_SCRATCH(o.templ) GROW_SCRATCH(o.route) GROW_SCRATCH(o.dis) GROW_SCRATCH(o.speed)
         GROW_SCRATCH(ab.dis) GROW_SCRATCH(ab.speed) GROW_SCRATCH(ab.drv) GROW_SCRATCH(ab.blocker)
         GROW_SCRATCH(cs.inNext) GROW_SCRATCH(finList) GROW_SCRATCH(finSorted) GROW_SCRATCH(viewLeader) GROW_SCRATCH(viewGap)
+        GROW_SCRATCH(crossJobs)
 #undef GROW_SCRATCH
         if ((rc = grow(&oldToNew, keep, nc))) return rc;  // committed blockers point through it
         slotCap = nc;
@@ -282,11 +286,11 @@ struct cfx_engine {
         spawned = 0;
         finishedKnown = 0;
         hipLaunchKernelGGL(k_init_layout, dim3(gridFor(D + 1)), dim3(kBlock), 0, stream, D, L, segStart[0].p, cnt[0].p,
-                           gen[0].vid);
+                           gen[0].vid, gen[0].drv);
         hipLaunchKernelGGL(k_init_lights, dim3(gridFor(I)), dim3(kBlock), 0, stream, net, curPhase, remain);
         HIP_TRY(hipMemsetAsync(waitHead, 0xFF, L * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(admitStep, 0xFF, L * sizeof(int32_t), stream));
-        HIP_TRY(hipMemsetAsync(llStamp, 0, K * sizeof(int32_t), stream));
+        HIP_TRY(hipMemsetAsync(interMask, 0, std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(sc, 0, sizeof(DevScalars), stream));
         HIP_TRY(hipMemsetAsync(oldToNew, 0xFF, slotCap * sizeof(int32_t), stream));
         if (vidCap) HIP_TRY(hipMemsetAsync(vt.nextWait, 0xFF, vidCap * sizeof(int32_t), stream));
@@ -374,9 +378,26 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->waitHead, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->admitStep, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
-    if ((rc = e->allocRaw(&e->llStamp, (size_t) e->K))) return rc;
-    if ((rc = e->allocRaw(&e->nSlot, (size_t) e->E))) return rc;
-    if ((rc = e->allocRaw(&e->nDist, (size_t) e->E))) return rc;
+    if ((rc = e->allocRaw(&e->llU, (size_t) e->K))) return rc;
+    if ((rc = e->allocRaw(&e->llF, (size_t) e->K))) return rc;
+    {
+        // derived tables: index of each laneLink inside its intersection (laneLinks of one intersection are
+        // contiguous in RoadNet::getLaneLinks() order), the peer's bit for every cross entry, mask offsets
+        std::vector<int32_t> llLocal(e->K), xPeerBit(e->E), maskStart(e->I + 1, 0), nLL(e->I, 0), first(e->I, -1);
+        for (int k = 0; k < e->K; ++k) {
+            int in = n->ll_inter[k];
+            if (first[in] < 0) first[in] = k;
+            llLocal[k] = k - first[in];
+            nLL[in] = std::max(nLL[in], llLocal[k] + 1);
+        }
+        for (int i = 0; i < e->I; ++i) maskStart[i + 1] = maskStart[i] + (nLL[i] + 63) / 64;
+        for (int x = 0; x < e->E; ++x) xPeerBit[x] = llLocal[n->x_ll[n->x_peer[x]]];
+        e->nMaskWords = maskStart[e->I];
+        if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
+        if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
+        if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
+        if ((rc = e->allocRaw(&e->interMask, (size_t) std::max(e->nMaskWords, 1)))) return rc;
+    }
     if ((rc = e->allocRaw(&e->curPhase, (size_t) e->I))) return rc;
     if ((rc = e->allocRaw(&e->remain, (size_t) e->I))) return rc;
     e->nScanBlocks = (e->D + kScanTile - 1) / kScanTile;
@@ -486,15 +507,17 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     hipLaunchKernelGGL(k_admit, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c, e->cnt[e->cur].p, e->admitStep, e->waitHead,
                        e->vt, e->cs, e->sc);
     e->profEnd(pp__); }
-    { int pp__ = e->profBegin(PK_NOTIFY);
-    hipLaunchKernelGGL(k_notify, dim3(gridFor(e->K)), dim3(kBlock), 0, st, c, e->cs);
+    { int pp__ = e->profBegin(PK_LLSTATE);
+    hipLaunchKernelGGL(k_llstate, dim3(gridFor(e->K)), dim3(kBlock), 0, st, c, e->cs);
     e->profEnd(pp__); }
+    ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
     { int pp__ = e->profBegin(PK_ACTION);
-    hipLaunchKernelGGL(k_action, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->ab);
+    hipLaunchKernelGGL(k_action, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192)),
+                       dim3(kActBlock), 0, st, c, ao, e->crossJobs, &e->sc->nCrossJobs);
     e->profEnd(pp__); }
-    { int pp__ = e->profBegin(PK_COUNT);
-    hipLaunchKernelGGL(k_count, dim3(gridStride(std::max<size_t>(slotBound, e->I))), dim3(kBlock), 0, st, c, e->ab, e->cs,
-                       e->vt, e->sc, e->finList, (int) e->slotCap, e->curPhase, e->remain, e->cfg.rl_traffic_light);
+    { int pp__ = e->profBegin(PK_CROSS);
+    hipLaunchKernelGGL(k_cross, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + 15) / 16), 8192)), dim3(kBlock), 0,
+                       st, c, ao, e->crossJobs, &e->sc->nCrossJobs);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan_reduce, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
@@ -502,11 +525,12 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, e->nScanBlocks, e->blockSums, c, e->vt, e->sc, e->finList,
                        e->finSorted, (int) e->slotCap);
     hipLaunchKernelGGL(k_scan_apply, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
-                       e->blockSums, e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid);
+                       e->blockSums, e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid, e->gen[nxt].drv);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt],
-                       e->segStart[nxt].p, e->oldToNew);
+    hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords)))),
+                       dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
+                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords);
     e->profEnd(pp__); }
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
@@ -692,6 +716,18 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
     *nOut = i;
     return CFX_OK;
 }
+
+#ifdef CFX_KPROF
+// developer-only: sums / maxima of the k_action section timers (see KP_MARK in cfx_kernels.h); clears them
+int32_t cfx_debug_read_kprof(unsigned long long *out, int32_t n) {
+    unsigned long long host[32] = {};
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_kprof), sizeof host) != hipSuccess) return CFX_ERR_DEVICE;
+    for (int i = 0; i < n && i < 32; ++i) out[i] = host[i];
+    unsigned long long zero[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_kprof), zero, sizeof zero) != hipSuccess) return CFX_ERR_DEVICE;
+    return CFX_OK;
+}
+#endif
 
 int32_t cfx_profile_kernel_count(void) { return kNumProfKernels; }
 const char *cfx_profile_kernel_name(int32_t k) { return (k >= 0 && k < kNumProfKernels) ? kProfNames[k] : ""; }

@@ -1,11 +1,16 @@
 // Per-step kernels of the cfx HIP engine.  One reference step (Engine::nextStep engine.cpp:566-594) is
 //   k_spawn_link   phase 0/1 tail : append host-produced spawn records to lanes' waiting queues
 //   k_admit        phase 2        : Engine::handleWaiting, one thread per lane
-//   k_notify       phase 3        : Engine::threadNotifyCross, one thread per laneLink
-//   k_action       phase 4        : leader/gap + Engine::vehicleControl, one thread per slot
-//   k_count        phase 5a (+8)  : classify stay / move / finish, per-drivable counts; traffic lights
-//   k_scan_*       phase 5b       : new segment offsets (exclusive scan over drivables); finish stats
-//   k_scatter      phase 5c/6     : stable compaction into the next generation = commit (Vehicle::update)
+//   k_llstate      phase 3        : the per-laneLink half of Engine::threadNotifyCross (who may notify),
+//                                   one thread per laneLink; sets the intersection's active-laneLink mask
+//   k_action       phase 4 + 5a   : leader/gap + Engine::vehicleControl, one thread per slot, up to the walk over
+//                                   the crosses; classification stay / move / finish and per-drivable counts
+//   k_cross        phase 4 cont.  : Cross::canPass for the queued vehicles, one 16-lane group per vehicle and
+//                                   one cross per lane; the other half of threadNotifyCross (which vehicle a
+//                                   given cross sees) is resolved on demand, only where the peer laneLink is active
+//   k_scan_*       phase 5b       : new segment offsets (exclusive scan over drivables); finish statistics
+//   k_scatter      phase 5c/6/8   : stable compaction into the next generation = commit (Vehicle::update);
+//                                   TrafficLight::passTime
 // Leader/gap (phase 7, engine.cpp:429-442) needs no kernel of its own: it is a pure function of the
 // post-compaction order and is evaluated at the top of the next step's k_action (see lastSlotForLeader).
 #pragma once
@@ -15,6 +20,8 @@
 namespace cfxd {
 
 constexpr int kBlock = 256;
+constexpr int kActBlock = 64;   // one wavefront per workgroup: ~100k vehicles spread over all 1024 SIMDs
+constexpr int kLdsTempl = 32;   // vehicle templates staged in LDS by k_action (96 B each)
 
 // ----------------------------------------------------------------------------------------------
 // Vehicle table (indexed by vid, never permuted)
@@ -31,6 +38,8 @@ struct DevScalars {
     long long vehicleSteps;    // sum over steps of vehicles that ran phase 4
     int nFinishedStep;         // finished vehicles of the step in flight
     int overflow;              // set when an internal capacity was exceeded
+    int nCrossJobs;            // vehicles queued for k_cross in the step in flight
+    int pad;
 };
 
 // Per-drivable scratch of the compaction.
@@ -87,17 +96,19 @@ __global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *wa
     int wt = vt.templ[w];
     if (n > 0) {
         int tail = base + n - 1;
-        if (!(c.s.dis[tail] > T(c, tail).len + c.t.templ[wt].min_gap)) return;
+        if (!(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) return;
     }
     int slot = base + n;  // the lane's spare slot
+    int route = vt.route[w];
     c.s.vid[slot] = w;
     c.s.drv[slot] = lane;
     c.s.prevDrv[slot] = -1;
+    c.s.next[slot] = nextOf(c.n, c.t, lane, route, 0);
     c.s.blocker[slot] = -1;
     c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
     c.s.routePos[slot] = 0;
     c.s.templ[slot] = wt;
-    c.s.route[slot] = vt.route[w];
+    c.s.route[slot] = route;
     c.s.dis[slot] = 0.0;
     c.s.speed[slot] = 0.0;
     cnt[lane] = n + 1;
@@ -107,8 +118,10 @@ __global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *wa
     atomicAdd((unsigned long long *) &sc->active, 1ULL);
 }
 
-// Engine::threadNotifyCross engine.cpp:317-372 + Cross::notify roadnet.cpp:595-601
-__global__ void k_notify(StepCtx c, CompactScratch cs) {
+// Per-laneLink sources of Engine::threadNotifyCross (engine.cpp:317-372): the vehicle that just left
+// onto the end lane (331-332), the vehicles on the laneLink (344), the first vehicle of the start lane if
+// it heads here on green (362-363).  Which of them a particular cross sees is resolved by notifiedAt().
+__global__ void k_llstate(StepCtx c, CompactScratch cs) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= c.n.K) return;
     const int d = c.n.L + k;
@@ -116,92 +129,149 @@ __global__ void k_notify(StepCtx c, CompactScratch cs) {
     cs.maxLeaveIdx[d] = -1;
     cs.inCnt[d] = 0;
     cs.inHead[d] = -1;
-
-    const int xb = c.n.llXStart[k], xe = c.n.llXStart[k + 1];
-    if (xb == xe) return;
     const int endLane = c.n.llEndLane[k], startLane = c.n.llStartLane[k];
-    // the three vehicle sources
     int u = lastSlot(c, endLane);
     if (u >= 0 && c.s.prevDrv[u] != d) u = -1;
-    const int nOn = c.cnt[d];
     int f = c.cnt[startLane] > 0 ? c.segStart[startLane] : -1;
-    if (f >= 0 && !(nextOf(c, startLane, c.s.route[f], c.s.routePos[f]) == d && llAvailable(c, k))) f = -1;
-    if (u < 0 && nOn == 0 && f < 0) return;  // nothing to notify: entries stay stale (llStamp != step+1)
-
-    int r = xe - 1;
-    const double llLen = c.n.drvLength[d];
-    if (u >= 0) {
-        double udis = c.s.dis[u];
-        double vehDistance = udis - T(c, u).len;
-        while (r >= xb) {
-            double crossDistance = llLen - c.n.xDist[r];
-            if (crossDistance + vehDistance < 0.0) {
-                c.nSlot[r] = u;
-                c.nDist[r] = -(udis + crossDistance);
-                --r;
-            } else
-                break;
-        }
+    if (f >= 0 && !(c.s.next[f] == d && llAvailable(c, k))) f = -1;
+    c.llU[k] = u;
+    c.llF[k] = f;
+    if (u >= 0 || f >= 0 || c.cnt[d] > 0) {
+        int in = c.n.llInter[k];
+        int bit = c.n.llLocal[k];
+        atomicOr(&c.interMask[c.n.interMaskStart[in] + (bit >> 6)], 1ULL << (bit & 63));
     }
-    const int base = c.segStart[d];
-    for (int i = 0; i < nOn && r >= xb; ++i) {
-        int w = base + i;
-        double vehDistance = c.s.dis[w];
-        double wlen = T(c, w).len;
-        while (r >= xb) {
-            double crossDistance = c.n.xDist[r];
-            if (vehDistance > crossDistance) {
-                if (vehDistance - crossDistance - wlen <= 0.0) {
-                    c.nSlot[r] = w;
-                    c.nDist[r] = crossDistance - vehDistance;
-                } else
-                    break;
-            } else {
-                c.nSlot[r] = w;
-                c.nDist[r] = crossDistance - vehDistance;
-            }
-            --r;
-        }
-    }
-    if (f >= 0) {
-        double vehDistance = c.n.drvLength[startLane] - c.s.dis[f];
-        while (r >= xb) {
-            c.nSlot[r] = f;
-            c.nDist[r] = vehDistance + c.n.xDist[r];
-            --r;
-        }
-    }
-    while (r >= xb) {  // Cross::clearNotify for the entries nobody claimed
-        c.nSlot[r] = -1;
-        --r;
-    }
-    c.llStamp[k] = c.step + 1;
 }
 
-// leader/gap (Vehicle::updateLeaderAndGap vehicle.cpp:157-196) for the vehicle in slot s
-__device__ inline int findLeader(const StepCtx &c, int s, int d, int k, double *gapOut) {
-    if (k > 0) {
+// Cross::notifyVehicles / notifyDistances of cross entry `pe` (owned by laneLink k), i.e. what the sweep of
+// engine.cpp:327-369 would have written there: entries are consumed far -> near by (1) the vehicle on the
+// end lane while `crossDistance + vehDistance < 0`, (2) each vehicle on the laneLink, front to back, while
+// it has not completely passed the cross, (3) the approaching vehicle for everything left.  All three
+// conditions are monotone in the cross distance, so "first source that accepts this entry" is the same
+// assignment as the sequential sweep.
+__device__ inline int notifiedAt(const StepCtx &c, const cfx_vehicle_template *tv, int k, int pe, double *distOut) {
+    const int d = c.n.L + k;
+    const double x = c.n.xDist[pe];
+    int u = c.llU[k];
+    if (u >= 0) {
+        double udis = c.s.dis[u];
+        double vehDistance = udis - tv[c.s.templ[u]].len;
+        double crossDistance = c.n.drvLength[d] - x;
+        if (crossDistance + vehDistance < 0.0) {
+            *distOut = -(udis + crossDistance);
+            return u;
+        }
+    }
+    const int base = c.segStart[d], n = c.cnt[d];
+    for (int i = 0; i < n; ++i) {
+        int w = base + i;
+        double vehDistance = c.s.dis[w];
+        if (!(vehDistance > x) || (vehDistance - x - tv[c.s.templ[w]].len <= 0.0)) {
+            *distOut = x - vehDistance;
+            return w;
+        }
+    }
+    int f = c.llF[k];
+    if (f >= 0) {
+        int startLane = c.n.llStartLane[k];
+        *distOut = (c.n.drvLength[startLane] - c.s.dis[f]) + x;
+        return f;
+    }
+    return -1;
+}
+
+// Cross::canPass roadnet.cpp:603-676 for a cross whose peer laneLink is active.  `e` = this laneLink's
+// entry of the cross, `t1` its roadLink type.
+__device__ inline bool canPassActive(const StepCtx &c, const cfx_vehicle_template *tv, int selfSlot, const VehRef &self,
+                                     int e, int t1, double distanceToLaneLinkStart, int *foeSlotOut) {
+    const int pe = c.n.xPeer[e];
+    const int peLL = c.n.xLL[pe];
+    double d2;
+    const int foeSlot = notifiedAt(c, tv, peLL, pe, &d2);
+    *foeSlotOut = foeSlot;
+    if (foeSlot < 0) return true;
+    const double d1 = c.n.xDist[e] - distanceToLaneLinkStart;
+    if (!canYield(self, d1)) return true;
+    const int t2 = c.n.llType[peLL];
+    VehRef foe{c.s.speed[foeSlot], &tv[c.s.templ[foeSlot]]};
+    int yield = 0;
+    if (!canYield(foe, d2)) yield = 1;
+    if (yield == 0) {
+        if (t1 > t2) {
+            yield = -1;
+        } else if (t1 < t2) {
+            if (d2 > 0) {
+                int foeSteps = reachStepsOnLaneLink(foe, d2, t2, c.interval);
+                int mySteps = reachStepsOnLaneLink(self, d1, t1, c.interval);
+                if (foeSteps > mySteps) yield = -1;
+            } else {
+                if (d2 + foe.t->len < 0) yield = -1;
+            }
+            if (yield == 0) yield = 1;
+        } else {
+            if (d2 > 0) {
+                int foeSteps = reachStepsOnLaneLink(foe, d2, t2, c.interval);
+                int mySteps = reachStepsOnLaneLink(self, d1, t1, c.interval);
+                if (foeSteps > mySteps) {
+                    yield = -1;
+                } else if (foeSteps < mySteps) {
+                    yield = 1;
+                } else {
+                    int myT = c.s.enterLLT[selfSlot], foeT = c.s.enterLLT[foeSlot];
+                    if (myT == foeT) {
+                        if (d1 == d2) {
+                            yield = c.vPriority[c.s.vid[selfSlot]] > c.vPriority[c.s.vid[foeSlot]] ? -1 : 1;
+                        } else {
+                            yield = d1 < d2 ? -1 : 1;
+                        }
+                    } else {
+                        yield = myT < foeT ? -1 : 1;
+                    }
+                }
+            } else {
+                yield = d2 + foe.t->len < 0 ? -1 : 1;
+            }
+        }
+    }
+    if (yield == 1) {  // Floyd cycle walk over committed blockers (deadlock => pass), roadnet.cpp:662-674
+        int fast = foeSlot, slow = foeSlot;
+        int guard = 0;
+        while (fast >= 0 && blockerOf(c, fast) >= 0) {
+            slow = blockerOf(c, slow);
+            fast = blockerOf(c, blockerOf(c, fast));
+            if (slow == fast) {
+                yield = -1;
+                break;
+            }
+            if (++guard > (1 << 22)) break;  // cannot happen (Floyd terminates); bounds a corrupted chain
+        }
+    }
+    return yield == -1;
+}
+
+// leader/gap (Vehicle::updateLeaderAndGap vehicle.cpp:157-196) for the vehicle in slot s of drivable d
+__device__ inline int findLeader(const StepCtx &c, const cfx_vehicle_template *tv, int s, int d, bool head, double myDis,
+                                 double bound, double *gapOut) {
+    if (!head) {
         int ls = s - 1;
-        *gapOut = c.s.dis[ls] - T(c, ls).len - c.s.dis[s];
+        *gapOut = c.s.dis[ls] - tv[c.s.templ[ls]].len - myDis;
         return ls;
     }
-    // k == 0 and the lane's only vehicle was admitted this step => it IS the admitted vehicle
+    // head of a lane whose only vehicle was admitted this step => it IS the admitted vehicle
     const bool viewerNew = d < c.n.L && c.admitStep[d] == c.step && c.cnt[d] == 1;
-    const int route = c.s.route[s], routePos = c.s.routePos[s];
-    const double bound = T(c, s).approach_dist;  // same expression as vehicle.cpp:190-191
     int ls = -1;
     double gap = 0.0;
-    double dist = c.n.drvLength[d] - c.s.dis[s];
-    int cur = d;
+    double dist = c.n.drvLength[d] - myDis;
+    int nd = c.s.next[s];
+    int route = -1, routePos = 0;
     for (;;) {
-        int nd = nextOf(c, cur, route, routePos);
         if (nd < 0) break;
         if (nd >= c.n.L) {
             int sl = c.n.llStartLane[nd - c.n.L];
             for (int q = c.n.laneLLStart[sl]; q < c.n.laneLLStart[sl + 1]; ++q) {
                 int cand = lastSlot(c, c.n.L + c.n.laneLL[q]);
                 if (cand >= 0) {
-                    double cg = dist + c.s.dis[cand] - T(c, cand).len;
+                    double cg = dist + c.s.dis[cand] - tv[c.s.templ[cand]].len;
                     if (ls < 0 || cg < gap) {
                         ls = cand;
                         gap = cg;
@@ -212,37 +282,118 @@ __device__ inline int findLeader(const StepCtx &c, int s, int d, int k, double *
         } else {
             ls = lastSlotForLeader(c, nd, viewerNew, d);
             if (ls >= 0) {
-                gap = dist + c.s.dis[ls] - T(c, ls).len;
+                gap = dist + c.s.dis[ls] - tv[c.s.templ[ls]].len;
                 break;
             }
         }
         dist += c.n.drvLength[nd];
-        if (dist > bound) break;
-        cur = nd;
+        if (dist > bound) break;  // same expression as vehicle.cpp:190-191
+        if (route < 0) {
+            route = c.s.route[s];
+            routePos = c.s.routePos[s];
+        }
+        nd = nextOf(c.n, c.t, nd, route, routePos);
     }
     *gapOut = gap;
     return ls;
 }
 
+// Tail of Engine::vehicleControl for one vehicle once its intersection speed is known: the rest of
+// Vehicle::getNextSpeed (vehicle.cpp:323-331), vehicleControl (engine.cpp:212-221), Vehicle::setDeltaDistance
+// (vehicle.cpp:49-68), the buffered results, and the classification half of threadUpdateLocation
+// (engine.cpp:290-310: per-drivable leave / enter counts for the compaction).
+struct ActionOut {
+    ActionBuf b;
+    CompactScratch cs;
+    VidTable vt;
+    DevScalars *sc;
+    int32_t *finList;
+    int finCap;
+};
+
+__device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template &t, int s, int d,
+                                    int vid, double speed, double dis, double dlen, int nd0, double v, int blockerSlot) {
+    const double interval = c.interval;
+    v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
+    const int route = c.s.route[s];
+    if (nd0 < 0 && !isLastRoad(c, d, route)) {  // !Router::onValidLane router.h:66-68
+        double vn = noCollisionSpeed(0, 1, speed, t.max_neg_acc, dlen - dis, interval, t.min_gap);
+        v = min2(v, vn);
+    }
+    v = max2(v, speed - t.max_neg_acc * interval);
+    double deltaDis;
+    if (v < 0) {
+        deltaDis = 0.5 * speed * speed / t.max_neg_acc;
+        v = 0;
+    } else {
+        deltaDis = (speed + v) * interval / 2;
+    }
+    double ndis = deltaDis + dis;
+    int newDrv = -1;
+    if (ndis > dlen) {
+        int drivable = d;
+        int nxt = nd0;
+        const int routePos = c.s.routePos[s];
+        for (;;) {
+            ndis -= c.n.drvLength[drivable];
+            drivable = nxt;
+            newDrv = drivable >= 0 ? drivable : -2;
+            if (drivable < 0 || !(ndis > c.n.drvLength[drivable])) break;
+            nxt = nextOf(c.n, c.t, drivable, route, routePos);
+        }
+    }
+    o.b.dis[s] = ndis;
+    o.b.speed[s] = v;
+    o.b.drv[s] = newDrv;
+    o.b.blocker[s] = blockerSlot;
+    if (newDrv != -1) {
+        const int k = s - c.segStart[d];
+        atomicAdd(&o.cs.leaveCnt[d], 1);
+        atomicMax(&o.cs.maxLeaveIdx[d], k);
+        if (newDrv >= 0) {
+            atomicAdd(&o.cs.inCnt[newDrv], 1);
+            o.cs.inNext[s] = atomicExch(&o.cs.inHead[newDrv], s);
+        } else {
+            o.vt.state[vid] = 2;
+            int idx = atomicAdd(&o.sc->nFinishedStep, 1);
+            if (idx < o.finCap) o.finList[idx] = s;
+            else o.sc->overflow = 1;
+        }
+    }
+}
+
 // Engine::threadGetAction / vehicleControl engine.cpp:188-251,402-413 with Vehicle::getNextSpeed
-// vehicle.cpp:308-335 and everything below it.
-__global__ void k_action(StepCtx c, ActionBuf b) {
+// vehicle.cpp:308-335: leader/gap, car following, and the first half of getIntersectionRelatedSpeed (red
+// light / blocked exit lane / turn speed).  Vehicles that still have to look at the crosses of their laneLink
+// are queued for k_cross (their speed so far parked in the action buffer); everybody else is finished here.
+__global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, int32_t *jobs, int32_t *nJobs) {
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        tv = sT;
+    }
     const int S = c.segStart[c.n.L + c.n.K];
     const int stride = gridDim.x * blockDim.x;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
-        if (c.s.vid[s] < 0) continue;
+        const int vid = c.s.vid[s];
+        if (vid < 0) continue;
         const int d = c.s.drv[s];
-        const int k = s - c.segStart[d];
-        const cfx_vehicle_template &t = T(c, s);
+        const bool head = s == 0 || c.s.drv[s - 1] != d;
+        const cfx_vehicle_template &t = tv[c.s.templ[s]];
         const double interval = c.interval;
         const double speed = c.s.speed[s];
         const double dis = c.s.dis[s];
         const double dlen = c.n.drvLength[d];
-        const int route = c.s.route[s], routePos = c.s.routePos[s];
+        const int nd0 = c.s.next[s];
 
         // --- leader / gap
         double gap;
-        const int ls = findLeader(c, s, d, k, &gap);
+        const int ls = findLeader(c, tv, s, d, head, dis, t.approach_dist, &gap);
 
         // --- Vehicle::getNextSpeed vehicle.cpp:308-335
         double v = t.max_speed;
@@ -254,7 +405,7 @@ __global__ void k_action(StepCtx c, ActionBuf b) {
         if (ls < 0) {
             cf = t.max_speed;
         } else {
-            const cfx_vehicle_template &tl = T(c, ls);
+            const cfx_vehicle_template &tl = tv[c.s.templ[ls]];
             const double leaderSpeed = c.s.speed[ls];
             cf = noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0);
             double assumeDecel = 0;
@@ -266,12 +417,10 @@ __global__ void k_action(StepCtx c, ActionBuf b) {
         v = min2(v, cf);
 
         // intersection logic, Vehicle::isIntersectionRelated vehicle.cpp:289-300
-        const int nd0 = nextOf(c, d, route, routePos);
-        int blockerSlot = -1;
         const bool onLane = d < c.n.L;
-        bool related = !onLane || (nd0 >= c.n.L && dlen - dis <= t.approach_dist);
+        const bool related = !onLane || (nd0 >= c.n.L && dlen - dis <= t.approach_dist);
         if (related) {
-            // Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-376
+            // Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-362
             VehRef self{speed, &t};
             double iv = t.max_speed;
             int laneLink = -1;
@@ -281,7 +430,7 @@ __global__ void k_action(StepCtx c, ActionBuf b) {
                 bool blocked = !llAvailable(c, laneLink);
                 if (!blocked) {  // Lane::canEnter roadnet.cpp:437-445
                     int tail = lastSlot(c, c.n.llEndLane[laneLink]);
-                    if (tail >= 0) blocked = !(c.s.dis[tail] > T(c, tail).len + t.len || c.s.speed[tail] >= 2);
+                    if (tail >= 0) blocked = !(c.s.dis[tail] > tv[c.s.templ[tail]].len + t.len || c.s.speed[tail] >= 2);
                 }
                 if (blocked) {
                     if (minBrakeDistance(self) > dlen - dis) {
@@ -291,94 +440,96 @@ __global__ void k_action(StepCtx c, ActionBuf b) {
                         done = true;
                     }
                 }
-                if (!done && llIsTurn(c, laneLink)) iv = min2(iv, t.turn_speed);
             }
             if (!done) {
-                if (laneLink < 0 && !onLane) laneLink = d - c.n.L;
-                double d0 = onLane ? -(dlen - dis) : dis;
-                for (int e = c.n.llXStart[laneLink]; e < c.n.llXStart[laneLink + 1]; ++e) {
-                    double dOn = c.n.xDist[e];
-                    if (dOn < d0) continue;
-                    int foe;
-                    if (!canPass(c, s, self, e, d0, &foe)) {
-                        iv = min2(iv, stopBeforeSpeed(self, dOn - d0 - t.yield_distance, interval));
-                        blockerSlot = foe;
-                        break;
-                    }
+                if (laneLink < 0) laneLink = d - c.n.L;  // already on a laneLink
+                if (nd0 >= c.n.L && typeIsTurn(c.n.llType[laneLink])) iv = min2(iv, t.turn_speed);
+                // any active laneLink at this intersection?  (mask set by k_llstate)
+                const int in = c.n.llInter[laneLink];
+                const int mb = c.n.interMaskStart[in];
+                const int nw = c.n.interMaskStart[in + 1] - mb;
+                unsigned long long any = 0ULL;
+                for (int w = 0; w < nw; ++w) any |= c.interMask[mb + w];
+                if (any != 0ULL && c.n.llXStart[laneLink + 1] > c.n.llXStart[laneLink]) {
+                    // park the two partial speeds and hand the cross checks to k_cross
+                    o.b.speed[s] = v;
+                    o.b.dis[s] = iv;
+                    jobs[atomicAdd(nJobs, 1)] = s;
+                    continue;
                 }
             }
             v = min2(v, iv);
         }
-        v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
-        if (nd0 < 0 && !isLastRoad(c, d, route)) {  // !Router::onValidLane router.h:66-68
-            double vn = noCollisionSpeed(0, 1, speed, t.max_neg_acc, dlen - dis, interval, t.min_gap);
-            v = min2(v, vn);
-        }
-        v = max2(v, speed - t.max_neg_acc * interval);
-
-        // --- Engine::vehicleControl engine.cpp:212-221
-        double deltaDis;
-        if (v < 0) {
-            deltaDis = 0.5 * speed * speed / t.max_neg_acc;
-            v = 0;
-        } else {
-            deltaDis = (speed + v) * interval / 2;
-        }
-        // --- Vehicle::setDeltaDistance vehicle.cpp:49-68
-        double nd = deltaDis + dis;
-        int drivable = d;
-        int newDrv = -1;
-        while (drivable >= 0 && nd > c.n.drvLength[drivable]) {
-            nd -= c.n.drvLength[drivable];
-            drivable = nextOf(c, drivable, route, routePos);
-            newDrv = drivable >= 0 ? drivable : -2;
-        }
-        b.dis[s] = nd;
-        b.speed[s] = v;
-        b.drv[s] = newDrv;
-        b.blocker[s] = blockerSlot;
+        finishAction(c, o, t, s, d, vid, speed, dis, dlen, nd0, v, -1);
     }
 }
 
-// Phase 5a: classification + per-drivable counts (Engine::threadUpdateLocation engine.cpp:282-315, first
-// half) and, on the low thread ids, TrafficLight::passTime trafficlight.cpp:29-37.
-__global__ void k_count(StepCtx c, ActionBuf b, CompactScratch cs, VidTable vt, DevScalars *sc, int32_t *finList,
-                        int finCap, int32_t *curPhase, double *remain, int rlTrafficLight) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
-    if (!rlTrafficLight) {
-        for (int i = gid; i < c.n.I; i += stride) {
-            if (c.n.interVirtual[i]) continue;
-            int ps = c.n.interPhaseStart[i];
-            int np = c.n.interPhaseStart[i + 1] - ps;
-            double rem = remain[i] - c.interval;
-            int ph = curPhase[i];
-            while (rem <= 0.0) {
-                ph = (ph + 1) % np;
-                rem += c.n.phaseTime[ps + ph];
-            }
-            remain[i] = rem;
-            curPhase[i] = ph;
-        }
+// Second half of Vehicle::getIntersectionRelatedSpeed (vehicle.cpp:357-375): the walk over the crosses of the
+// vehicle's laneLink.  One kCrossGroup-lane group per queued vehicle, one cross per lane and round; the
+// reference's "first cross (ascending distance) that cannot be passed" is the lowest failing lane of the
+// first failing round.
+constexpr int kCrossGroup = 16;
+
+__global__ __launch_bounds__(kBlock) void k_cross(StepCtx c, ActionOut o, const int32_t *jobs, const int32_t *nJobs) {
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        tv = sT;
     }
-    const int S = c.segStart[c.n.L + c.n.K];
-    for (int s = gid; s < S; s += stride) {
-        int vid = c.s.vid[s];
-        if (vid < 0) continue;
-        int nd = b.drv[s];
-        if (nd == -1) continue;  // stays
-        int d = c.s.drv[s];
-        int k = s - c.segStart[d];
-        atomicAdd(&cs.leaveCnt[d], 1);
-        atomicMax(&cs.maxLeaveIdx[d], k);
-        if (nd >= 0) {
-            atomicAdd(&cs.inCnt[nd], 1);
-            cs.inNext[s] = atomicExch(&cs.inHead[nd], s);
-        } else {
-            vt.state[vid] = 2;
-            int idx = atomicAdd(&sc->nFinishedStep, 1);
-            if (idx < finCap) finList[idx] = s;
-            else sc->overflow = 1;
+    const int nJ = *nJobs;
+    const int g = threadIdx.x % kCrossGroup;                       // lane inside the group
+    const int groupsPerBlock = blockDim.x / kCrossGroup;
+    const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);  // first wave-lane of this group
+    for (int j = blockIdx.x * groupsPerBlock + threadIdx.x / kCrossGroup; j < nJ; j += gridDim.x * groupsPerBlock) {
+        const int s = jobs[j];
+        const int d = c.s.drv[s];
+        const cfx_vehicle_template &t = tv[c.s.templ[s]];
+        const double speed = c.s.speed[s];
+        const double dis = c.s.dis[s];
+        const double dlen = c.n.drvLength[d];
+        const int nd0 = c.s.next[s];
+        const bool onLane = d < c.n.L;
+        const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
+        const int t1 = c.n.llType[laneLink];
+        const double d0 = onLane ? -(dlen - dis) : dis;
+        const int in = c.n.llInter[laneLink];
+        const int mb = c.n.interMaskStart[in];
+        VehRef self{speed, &t};
+        const int xs = c.n.llXStart[laneLink], xe = c.n.llXStart[laneLink + 1];
+        double iv = o.b.dis[s];  // partial intersection speed parked by k_action
+        int blockerSlot = -1;
+        for (int e0 = xs; e0 < xe; e0 += kCrossGroup) {
+            const int e = e0 + g;
+            bool fail = false;
+            int foe = -1;
+            double dOn = 0.0;
+            if (e < xe) {
+                dOn = c.n.xDist[e];
+                if (!(dOn < d0)) {
+                    const int bit = c.n.xPeerBit[e];
+                    if ((c.interMask[mb + (bit >> 6)] >> (bit & 63)) & 1ULL)
+                        fail = !canPassActive(c, tv, s, self, e, t1, d0, &foe);
+                }
+            }
+            const unsigned long long ball = __ballot(fail);
+            const unsigned gm = (unsigned) ((ball >> groupShift) & ((1ULL << kCrossGroup) - 1ULL));
+            if (gm != 0u) {
+                const int first = __ffs(gm) - 1;  // lowest lane = smallest cross distance in this round
+                const int src = groupShift + first;
+                const double fdOn = __shfl(dOn, src, 64);
+                blockerSlot = __shfl(foe, src, 64);
+                iv = min2(iv, stopBeforeSpeed(self, fdOn - d0 - t.yield_distance, c.interval));
+                break;
+            }
+        }
+        if (g == 0) {
+            double v = min2(o.b.speed[s], iv);
+            finishAction(c, o, t, s, d, c.s.vid[s], speed, dis, dlen, nd0, v, blockerSlot);
         }
     }
 }
@@ -426,14 +577,12 @@ __global__ void k_scan_reduce(int D, int L, const int32_t *cnt, CompactScratch c
 __global__ void k_scan_top(int nBlocks, int32_t *blockSums, StepCtx c, VidTable vt, DevScalars *sc, int32_t *finList,
                            int32_t *finSorted, int finCap) {
     __shared__ int carry;
+    __shared__ int buf[kBlock];
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    // sequential-by-chunks exclusive scan (nBlocks is small: D / 2048)
     for (int b0 = 0; b0 < nBlocks; b0 += blockDim.x) {
         int i = b0 + threadIdx.x;
         int v = i < nBlocks ? blockSums[i] : 0;
-        // inclusive scan inside the chunk via shared memory (Hillis-Steele)
-        __shared__ int buf[kBlock];
         buf[threadIdx.x] = v;
         __syncthreads();
         for (int off = 1; off < (int) blockDim.x; off <<= 1) {
@@ -490,11 +639,12 @@ __global__ void k_scan_top(int nBlocks, int32_t *blockSums, StepCtx c, VidTable 
         sc->finishedCnt += F;
         sc->active -= F;
         sc->nFinishedStep = 0;
+        sc->nCrossJobs = 0;
     }
 }
 
 __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs, const int32_t *blockSums,
-                             int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext) {
+                             int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext, int32_t *drvNext) {
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
     int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
@@ -508,7 +658,6 @@ __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs
         vals[i] = d < D ? nl + (d < L ? 1 : 0) : 0;
         sum += vals[i];
     }
-    // exclusive scan of per-thread sums across the block
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
@@ -531,7 +680,10 @@ __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs
         if (d < D) {
             segStartNext[d] = off0;
             cntNext[d] = live[i];
-            if (d < L) vidNext[off0 + live[i]] = -1;  // the lane's spare slot of the next generation
+            if (d < L) {  // the lane's spare slot of the next generation
+                vidNext[off0 + live[i]] = -1;
+                drvNext[off0 + live[i]] = -1;
+            }
             off0 += vals[i];
             if (d == D - 1) segStartNext[D] = off0;
         }
@@ -540,12 +692,30 @@ __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs
 
 // Phase 5c + 6: stable compaction into the next generation and commit of the buffered action
 // (Engine::threadUpdateLocation / updateLocation engine.cpp:282-315,477-494; Vehicle::update
-// vehicle.cpp:107-143; Router::update router.cpp:78-94).
+// vehicle.cpp:107-143; Router::update router.cpp:78-94).  Low thread ids also advance the traffic
+// lights (TrafficLight::passTime trafficlight.cpp:29-37) and clear the active-laneLink masks.
 __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
-                          int32_t *oldToNew) {
-    const int S = c.segStart[c.n.L + c.n.K];
+                          int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
+    for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
+    if (!rlTrafficLight) {
+        for (int i = gid; i < c.n.I; i += stride) {
+            if (c.n.interVirtual[i]) continue;
+            int ps = c.n.interPhaseStart[i];
+            int np = c.n.interPhaseStart[i + 1] - ps;
+            double rem = remain[i] - c.interval;
+            int ph = curPhase[i];
+            while (rem <= 0.0) {
+                ph = (ph + 1) % np;
+                rem += c.n.phaseTime[ps + ph];
+            }
+            remain[i] = rem;
+            curPhase[i] = ph;
+        }
+    }
+    const int S = c.segStart[c.n.L + c.n.K];
+    for (int s = gid; s < S; s += stride) {
         const int vid = c.s.vid[s];
         if (vid < 0) {
             oldToNew[s] = -1;
@@ -563,7 +733,9 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
             const int k = s - c.segStart[d];
             const int lc = cs.leaveCnt[d];
             int before;
-            if (cs.maxLeaveIdx[d] + 1 == lc) {
+            if (lc == 0) {
+                before = 0;
+            } else if (cs.maxLeaveIdx[d] + 1 == lc) {
                 before = k < lc ? k : lc;  // leavers form a prefix (the normal case)
             } else {
                 before = 0;
@@ -585,13 +757,15 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         oldToNew[s] = ns;
         nx.vid[ns] = vid;
         nx.templ[ns] = c.s.templ[s];
-        nx.route[ns] = c.s.route[s];
         nx.dis[ns] = b.dis[s];
         nx.speed[ns] = b.speed[s];
         nx.blocker[ns] = b.blocker[s];  // old-generation slot; resolved through oldToNew when read
+        const int route = c.s.route[s];
+        nx.route[ns] = route;
         if (nd == -1) {
             nx.drv[ns] = d;
             nx.prevDrv[ns] = c.s.prevDrv[s];
+            nx.next[ns] = c.s.next[s];
             nx.enterLLT[ns] = c.s.enterLLT[s];
             nx.routePos[ns] = c.s.routePos[s];
         } else {
@@ -600,7 +774,6 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
             int rp = c.s.routePos[s];
             if (nd < c.n.L) {
                 nx.enterLLT[ns] = CFX_INT_MAX;
-                const int route = c.s.route[s];
                 const int base = c.t.routeStart[route], n = c.t.routeStart[route + 1] - base;
                 const int road = c.n.laneRoad[nd];
                 while (rp < n && c.t.routeRoads[base + rp] != road) ++rp;
@@ -608,6 +781,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
                 nx.enterLLT[ns] = c.step;
             }
             nx.routePos[ns] = rp;
+            nx.next[ns] = nextOf(c.n, c.t, nd, route, rp);
         }
     }
 }
@@ -623,7 +797,8 @@ __global__ void k_leader_view(StepCtx c, int32_t *leaderSlot, double *gapOut) {
         }
         int d = c.s.drv[s];
         double gap = 0;
-        leaderSlot[s] = findLeader(c, s, d, s - c.segStart[d], &gap);
+        bool head = s == 0 || c.s.drv[s - 1] != d;
+        leaderSlot[s] = findLeader(c, c.t.templ, s, d, head, c.s.dis[s], c.t.templ[c.s.templ[s]].approach_dist, &gap);
         gapOut[s] = gap;
     }
 }
@@ -636,18 +811,16 @@ __global__ void k_lane_waiting(StepCtx c, int32_t *out) {  // Engine::getLaneWai
     out[lane] = k;
 }
 
-__global__ void k_fill_i32(int32_t *p, int n, int v) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // Initial / reset layout: every lane owns just its spare slot, laneLinks are empty.
-__global__ void k_init_layout(int D, int L, int32_t *segStart, int32_t *cnt, int32_t *vid) {
+__global__ void k_init_layout(int D, int L, int32_t *segStart, int32_t *cnt, int32_t *vid, int32_t *drv) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d > D) return;
     segStart[d] = d < L ? d : L;
     if (d < D) cnt[d] = 0;
-    if (d < L) vid[d] = -1;
+    if (d < L) {
+        vid[d] = -1;
+        drv[d] = -1;
+    }
 }
 
 __global__ void k_init_lights(DevNet n, int32_t *curPhase, double *remain) {  // TrafficLight::init trafficlight.cpp:6-11
