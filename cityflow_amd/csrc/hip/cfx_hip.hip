@@ -82,7 +82,8 @@ struct cfx_engine {
     unsigned long long *interMask = nullptr;
     int nMaskWords = 0;
     double *remain = nullptr;
-    int32_t *blockSums = nullptr;
+    unsigned long long *scanGranules = nullptr;
+    int32_t *scanTicket = nullptr;
     int nScanBlocks = 0;
     int32_t *laneOut = nullptr;
     DevScalars *sc = nullptr;
@@ -292,6 +293,8 @@ struct cfx_engine {
         HIP_TRY(hipMemsetAsync(admitStep, 0xFF, L * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(interMask, 0, std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(sc, 0, sizeof(DevScalars), stream));
+        HIP_TRY(hipMemsetAsync(scanGranules, 0, (size_t) nScanBlocks * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(scanTicket, 0, sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(oldToNew, 0xFF, slotCap * sizeof(int32_t), stream));
         if (vidCap) HIP_TRY(hipMemsetAsync(vt.nextWait, 0xFF, vidCap * sizeof(int32_t), stream));
         HIP_TRY(hipGetLastError());
@@ -401,7 +404,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->curPhase, (size_t) e->I))) return rc;
     if ((rc = e->allocRaw(&e->remain, (size_t) e->I))) return rc;
     e->nScanBlocks = (e->D + kScanTile - 1) / kScanTile;
-    if ((rc = e->allocRaw(&e->blockSums, (size_t) e->nScanBlocks))) return rc;
+    if ((rc = e->allocRaw(&e->scanGranules, (size_t) e->nScanBlocks))) return rc;
+    if ((rc = e->allocRaw(&e->scanTicket, 1))) return rc;
     if ((rc = e->allocRaw(&e->sc, 1))) return rc;
     if ((rc = e->ensureSlotCap((size_t) e->L + 4096))) return rc;
     if ((rc = e->ensureVidCap(1 << 16))) return rc;
@@ -520,17 +524,14 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                        st, c, ao, e->crossJobs, &e->sc->nCrossJobs);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCAN);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
-                       e->blockSums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, e->nScanBlocks, e->blockSums, c, e->vt, e->sc, e->finList,
-                       e->finSorted, (int) e->slotCap);
-    hipLaunchKernelGGL(k_scan_apply, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs,
-                       e->blockSums, e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid, e->gen[nxt].drv);
+    hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
+                       e->scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
+                       e->gen[nxt].drv, c, e->vt, e->sc, e->finList, e->finSorted, (int) e->slotCap);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords)))),
                        dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
-                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords);
+                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords, e->scanTicket);
     e->profEnd(pp__); }
     HIP_TRY(hipGetLastError());
     e->cur = nxt;

@@ -8,7 +8,7 @@
 //   k_cross        phase 4 cont.  : Cross::canPass for the queued vehicles, one 16-lane group per vehicle and
 //                                   one cross per lane; the other half of threadNotifyCross (which vehicle a
 //                                   given cross sees) is resolved on demand, only where the peer laneLink is active
-//   k_scan_*       phase 5b       : new segment offsets (exclusive scan over drivables); finish statistics
+//   k_scan         phase 5b       : new segment offsets (single-pass exclusive scan over drivables); finish statistics
 //   k_scatter      phase 5c/6/8   : stable compaction into the next generation = commit (Vehicle::update);
 //                                   TrafficLight::passTime
 // Leader/gap (phase 7, engine.cpp:429-442) needs no kernel of its own: it is a pure function of the
@@ -534,10 +534,16 @@ __global__ __launch_bounds__(kBlock) void k_cross(StepCtx c, ActionOut o, const 
     }
 }
 
-// Phase 5b: exclusive scan of the new segment sizes over drivables, 3 launches.
+// Phase 5b in ONE launch: single-pass exclusive scan of the new segment sizes over drivables.
+// Tiles are handed out by a ticket (so every predecessor of a tile has started: no dispatch-order assumption);
+// each tile publishes its total as an 8-byte {epoch, value} granule written by one agent-scope store and
+// sums its predecessors' granules, polling with agent-scope loads until their tag equals this step's epoch
+// (MI355X guide, Guideline 16 form R2: the data is the flag).  Tile 0 additionally does the step's finish
+// statistics.
 constexpr int kScanItems = 8;                       // drivables per thread
-constexpr int kScanTile = kBlock * kScanItems;      // drivables per block
+constexpr int kScanTile = kBlock * kScanItems;      // drivables per tile
 constexpr int kFinLds = 2048;                       // finished vehicles per step staged in LDS
+constexpr unsigned kSpinLimit = 1u << 26;
 
 __device__ __forceinline__ int newLiveCount(const int32_t *cnt, const CompactScratch &cs, int d) {
     return cnt[d] - cs.leaveCnt[d] + cs.inCnt[d];
@@ -559,47 +565,12 @@ __device__ inline int blockReduceSum(int v, int *smem) {
     return tot;
 }
 
-__global__ void k_scan_reduce(int D, int L, const int32_t *cnt, CompactScratch cs, int32_t *blockSums) {
-    __shared__ int smem[kBlock / 64];
-    int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    int sum = 0;
-    for (int i = 0; i < kScanItems; ++i) {
-        int d = base + i;
-        if (d < D) sum += newLiveCount(cnt, cs, d) + (d < L ? 1 : 0);
-    }
-    int tot = blockReduceSum(sum, smem);
-    if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
-}
-
-// Single block: scan of the block sums + the step's finish statistics in the reference's order
-// (threadUpdateLocation with one thread walks drivables in RoadNet order, lists front to back, i.e.
-// ascending slot; engine.cpp:296-310).
-__global__ void k_scan_top(int nBlocks, int32_t *blockSums, StepCtx c, VidTable vt, DevScalars *sc, int32_t *finList,
-                           int32_t *finSorted, int finCap) {
-    __shared__ int carry;
-    __shared__ int buf[kBlock];
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nBlocks; b0 += blockDim.x) {
-        int i = b0 + threadIdx.x;
-        int v = i < nBlocks ? blockSums[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < (int) blockDim.x; off <<= 1) {
-            int add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += add;
-            __syncthreads();
-        }
-        int incl = buf[threadIdx.x];
-        int total = buf[blockDim.x - 1];
-        if (i < nBlocks) blockSums[i] = carry + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += total;
-        __syncthreads();
-    }
-    // finish statistics: order the step's finished slots (rank sort in LDS), then one thread adds the
-    // travel times in that order (FP64 addition is not associative; the reference adds sequentially)
+// The step's finish statistics in the reference's order (threadUpdateLocation with one thread walks
+// drivables in RoadNet order, lists front to back, i.e. ascending slot; engine.cpp:296-310): rank sort of the
+// finished slots in LDS, then one thread adds the travel times in that order (FP64 addition is not
+// associative; the reference adds sequentially).  Executed by one whole block.
+__device__ inline void finishStatistics(const StepCtx &c, const VidTable &vt, DevScalars *sc, const int32_t *finList,
+                                        int32_t *finSorted, int finCap) {
     __shared__ int fin[kFinLds];
     __shared__ double term[kFinLds];
     int F = sc->nFinishedStep;
@@ -643,11 +614,20 @@ __global__ void k_scan_top(int nBlocks, int32_t *blockSums, StepCtx c, VidTable 
     }
 }
 
-__global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs, const int32_t *blockSums,
-                             int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext, int32_t *drvNext) {
+__global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cnt, CompactScratch cs,
+                                                 unsigned long long *granules, int32_t *ticket, unsigned epoch,
+                                                 int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
+                                                 int32_t *drvNext, StepCtx c, VidTable vt, DevScalars *sc,
+                                                 const int32_t *finList, int32_t *finSorted, int finCap) {
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
-    int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    __shared__ int tileShared;
+    if (threadIdx.x == 0) tileShared = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int tile = tileShared;
+    __syncthreads();
+
+    const int base = tile * kScanTile + threadIdx.x * kScanItems;
     int vals[kScanItems];
     int live[kScanItems];
     int sum = 0;
@@ -658,7 +638,8 @@ __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs
         vals[i] = d < D ? nl + (d < L ? 1 : 0) : 0;
         sum += vals[i];
     }
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // in-wave inclusive scan of the per-thread sums, wave totals to LDS
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
         int o = __shfl_up(incl, off, 64);
@@ -672,9 +653,32 @@ __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs
             smem[i] = run;
             run += wsum[i];
         }
+        // publish this tile's total: ONE 8-byte agent-scope store {epoch, total}
+        __hip_atomic_store(&granules[tile], ((unsigned long long) epoch << 32) | (unsigned) run, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    int off0 = blockSums[blockIdx.x] + smem[w] + incl - sum;
+    const int waveOff = smem[w];
+    __syncthreads();
+    // sum of the predecessors' totals
+    int pre = 0;
+    for (int p = threadIdx.x; p < tile; p += blockDim.x) {
+        unsigned spins = 0;
+        for (;;) {
+            unsigned long long x = __hip_atomic_load(&granules[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned) (x >> 32) == epoch) {
+                pre += (int) (unsigned) x;
+                break;
+            }
+            if (++spins > kSpinLimit) {  // cannot happen unless a tile died; do not hang the device
+                sc->overflow = 2;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    const int tileOff = blockReduceSum(pre, smem);
+    int off0 = tileOff + waveOff + incl - sum;
     for (int i = 0; i < kScanItems; ++i) {
         int d = base + i;
         if (d < D) {
@@ -688,6 +692,7 @@ __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs
             if (d == D - 1) segStartNext[D] = off0;
         }
     }
+    if (tile == 0) finishStatistics(c, vt, sc, finList, finSorted, finCap);
 }
 
 // Phase 5c + 6: stable compaction into the next generation and commit of the buffered action
@@ -695,9 +700,11 @@ __global__ void k_scan_apply(int D, int L, const int32_t *cnt, CompactScratch cs
 // vehicle.cpp:107-143; Router::update router.cpp:78-94).  Low thread ids also advance the traffic
 // lights (TrafficLight::passTime trafficlight.cpp:29-37) and clear the active-laneLink masks.
 __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
-                          int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords) {
+                          int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
+                          int32_t *scanTicket) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
+    if (gid == 0) *scanTicket = 0;  // k_scan of this step is done; re-arm it for the next one
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
     if (!rlTrafficLight) {
         for (int i = gid; i < c.n.I; i += stride) {
