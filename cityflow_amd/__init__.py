@@ -14,6 +14,7 @@ except ImportError as exc:  # pragma: no cover - exercised only on unbuilt trees
     ) from exc
 
 Engine = _cityflow.Engine
+Archive = _cityflow.Archive
 __version__ = _cityflow.__version__
 
-__all__ = ["Engine", "__version__"]
+__all__ = ["Engine", "Archive", "__version__"]

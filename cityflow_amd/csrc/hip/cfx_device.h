@@ -50,6 +50,7 @@ struct SlotArrays {
     int32_t *routePos;  // Router::iCurRoad as index into the route
     int32_t *templ;     // vehicle template index
     int32_t *route;     // route index
+    uint8_t *flags;     // bit 0: a custom speed is pending (Buffer::isCustomSpeedSet, vehicle.h:62)
     double *dis;        // ControllerInfo::dis
     double *speed;      // VehicleInfo::speed
 };
@@ -65,6 +66,7 @@ struct StepCtx {
     const int32_t *curPhase;  // [I]
     const int32_t *oldToNew;  // slot of previous generation -> slot of current generation (-1 removed)
     const int32_t *vPriority; // [vid]
+    const double *vCustomSpeed; // [vid] Buffer::customSpeed, valid where the slot flag / pending flag is set
     // per-laneLink notification sources of this step (phase 3, Engine::threadNotifyCross)
     int32_t *llU;             // [K] vehicle that just left onto the end lane (slot) or -1
     int32_t *llF;             // [K] first vehicle of the start lane heading for this laneLink on green, or -1

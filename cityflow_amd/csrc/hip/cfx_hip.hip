@@ -197,6 +197,7 @@ struct cfx_engine {
         c.curPhase = curPhase;
         c.oldToNew = oldToNew;
         c.vPriority = vt.priority;
+        c.vCustomSpeed = vt.customSpeed;
         c.llU = llU;
         c.llF = llF;
         c.interMask = interMask;
@@ -215,6 +216,8 @@ struct cfx_engine {
         if ((rc = grow(&vt.nextWait, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.enterTime, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.state, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.customSpeed, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.pendingCustom, (size_t) spawned, nc))) return rc;
         // nextWait of not-yet-used vids must read -1 (k_spawn_link relies on it)
         HIP_TRY(hipMemsetAsync(vt.nextWait + spawned, 0xFF, (nc - (size_t) spawned) * sizeof(int32_t), stream));
         vidCap = nc;
@@ -231,12 +234,12 @@ struct cfx_engine {
         int rc;
 #define GROW_KEEP(f) if ((rc = grow(&g.f, keep, nc))) return rc;
         GROW_KEEP(vid) GROW_KEEP(drv) GROW_KEEP(prevDrv) GROW_KEEP(next) GROW_KEEP(blocker) GROW_KEEP(enterLLT) GROW_KEEP(routePos)
-        GROW_KEEP(templ) GROW_KEEP(route) GROW_KEEP(dis) GROW_KEEP(speed)
+        GROW_KEEP(templ) GROW_KEEP(route) GROW_KEEP(flags) GROW_KEEP(dis) GROW_KEEP(speed)
 #undef GROW_KEEP
         SlotArrays &o = gen[cur ^ 1];
 #define GROW_SCRATCH(ptr) if ((rc = grow(&ptr, 0, nc))) return rc;
         GROW_SCRATCH(o.vid) GROW_SCRATCH(o.drv) GROW_SCRATCH(o.prevDrv) GROW_SCRATCH(o.next) GROW_SCRATCH(o.blocker) GROW_SCRATCH(o.enterLLT)
-        GROW_SCRATCH(o.routePos) GROW_SCRATCH(o.templ) GROW_SCRATCH(o.route) GROW_SCRATCH(o.dis) GROW_SCRATCH(o.speed)
+        GROW_SCRATCH(o.routePos) GROW_SCRATCH(o.templ) GROW_SCRATCH(o.route) GROW_SCRATCH(o.flags) GROW_SCRATCH(o.dis) GROW_SCRATCH(o.speed)
         GROW_SCRATCH(ab.dis) GROW_SCRATCH(ab.speed) GROW_SCRATCH(ab.drv) GROW_SCRATCH(ab.blocker)
         GROW_SCRATCH(cs.inNext) GROW_SCRATCH(finList) GROW_SCRATCH(finSorted) GROW_SCRATCH(viewLeader) GROW_SCRATCH(viewGap)
         GROW_SCRATCH(crossJobs)
@@ -715,6 +718,207 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
             ++i;
         }
     *nOut = i;
+    return CFX_OK;
+}
+
+int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
+    if (!e || vid < 0 || vid >= e->spawned) {
+        if (e) e->err = "cfx_set_vehicle_speed: no such vehicle";
+        return CFX_ERR_INVALID;
+    }
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    uint8_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, e->vt.state + vid, 1, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (st == 2) {
+        e->err = "cfx_set_vehicle_speed: vehicle already finished";
+        return CFX_ERR_INVALID;
+    }
+    HIP_TRY(hipMemcpyAsync(e->vt.customSpeed + vid, &speed, sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (st == 0) {
+        uint8_t one = 1;
+        HIP_TRY(hipMemcpyAsync(e->vt.pendingCustom + vid, &one, 1, hipMemcpyHostToDevice, e->stream));
+    } else {
+        int rc = e->syncTables();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_set_speed, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));  // the two sources above live on this stack frame
+    return CFX_OK;
+}
+
+int32_t cfx_set_vehicle_route(cfx_engine *e, int32_t vid, int32_t route) {
+    if (!e || vid < 0 || vid >= e->spawned || route < 0 || route + 1 >= (int32_t) e->hRouteStart.size()) {
+        if (e) e->err = "cfx_set_vehicle_route: bad vehicle or route";
+        return CFX_ERR_INVALID;
+    }
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = e->syncTables();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->vt.route + vid, &route, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_set_route, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid, route);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *drivable, int32_t *routePos, int32_t *route) {
+    if (!e || vid < 0 || vid >= e->spawned) {
+        if (e) e->err = "cfx_get_vehicle: vid out of range";
+        return CFX_ERR_INVALID;
+    }
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = e->syncTables();
+    if (rc) return rc;
+    uint8_t st = 0;
+    int32_t r = -1, found[2] = {-1, -1};
+    HIP_TRY(hipMemcpyAsync(&st, e->vt.state + vid, 1, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(&r, e->vt.route + vid, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemsetAsync(e->laneOut, 0xFF, 8, e->stream));
+    hipLaunchKernelGGL(k_find_vehicle, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid, e->laneOut);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(found, e->laneOut, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (state) *state = st;
+    if (drivable) *drivable = st == 1 ? found[0] : -1;
+    if (routePos) *routePos = st == 1 ? found[1] : -1;
+    if (route) *route = r;
+    return CFX_OK;
+}
+
+int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    int32_t S = 0;
+    HIP_TRY(hipMemcpyAsync(&S, e->segStart[e->cur].p + e->D, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<int32_t> vid(S);
+    std::vector<uint8_t> flags(S);
+    std::vector<double> cs((size_t) e->spawned);
+    if (S) {
+        HIP_TRY(hipMemcpyAsync(vid.data(), e->gen[e->cur].vid, S * 4, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(flags.data(), e->gen[e->cur].flags, S, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (e->spawned) HIP_TRY(hipMemcpyAsync(cs.data(), e->vt.customSpeed, (size_t) e->spawned * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int i = 0;
+    for (int s = 0; s < S; ++s) {
+        if (vid[s] < 0) continue;
+        if (i >= capacity) return CFX_ERR_CAPACITY;
+        out[i++] = (flags[s] & 1) ? cs[vid[s]] : __builtin_nan("");
+    }
+    return CFX_OK;
+}
+
+// Archive::resume (archive.cpp:73-126): replace the whole dynamic state.
+int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
+    if (!e || !s) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->syncTables())) return rc;
+    if ((rc = e->resetState())) return rc;
+    const int L = e->L, D = e->D, nV = s->n_vehicles, nR = s->n_running;
+    if ((rc = e->ensureVidCap((size_t) nV + 1))) return rc;
+    if ((rc = e->ensureSlotCap((size_t) nR + L + 1))) return rc;
+    // ---- layout: vehicles of drivable d, then one spare slot for lanes
+    std::vector<int32_t> cnt(D, 0), segStart(D + 1, 0);
+    for (int i = 0; i < nR; ++i) {
+        int d = s->r_drivable[i];
+        if (d < 0 || d >= D || (i && d < s->r_drivable[i - 1])) return e->fail("cfx_load_state: running vehicles must be grouped by drivable, ascending");
+        cnt[d]++;
+    }
+    for (int d = 0; d < D; ++d) segStart[d + 1] = segStart[d] + cnt[d] + (d < L ? 1 : 0);
+    const int S = segStart[D];
+    std::vector<int32_t> vid(S, -1), drv(S, -1), prev(S, -1), next(S, -1), blk(S, -1), ellt(S, CFX_INT_MAX), rpos(S, 0),
+        templ(S, 0), route(S, 0), slotOfVid(std::max(nV, 1), -1);
+    std::vector<uint8_t> flags(S, 0);
+    std::vector<double> dis(S, 0.0), speed(S, 0.0), custom(std::max(nV, 1), 0.0);
+    {
+        std::vector<int32_t> fill(D, 0);
+        for (int i = 0; i < nR; ++i) {
+            int d = s->r_drivable[i];
+            int sl = segStart[d] + fill[d]++;
+            int v = s->r_vid[i];
+            if (v < 0 || v >= nV) return e->fail("cfx_load_state: running vid out of range");
+            slotOfVid[v] = sl;
+            vid[sl] = v;
+            drv[sl] = d;
+            prev[sl] = s->r_prev_drivable[i];
+            ellt[sl] = s->r_enter_ll_time[i];
+            rpos[sl] = s->r_route_pos[i];
+            templ[sl] = s->v_templ[v];
+            route[sl] = s->v_route[v];
+            dis[sl] = s->r_dis[i];
+            speed[sl] = s->r_speed[i];
+            if (s->r_custom_speed && s->r_custom_speed[i] == s->r_custom_speed[i]) {
+                flags[sl] = 1;
+                custom[v] = s->r_custom_speed[i];
+            }
+        }
+        for (int i = 0; i < nR; ++i) {  // blockers: vid -> slot (oldToNew is reset to identity below)
+            int b = s->r_blocker_vid[i];
+            blk[slotOfVid[s->r_vid[i]]] = (b >= 0 && b < nV) ? slotOfVid[b] : -1;
+        }
+    }
+    // ---- uploads
+    SlotArrays &g = e->gen[e->cur];
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream) : hipSuccess;
+    };
+    HIP_TRY(up(e->segStart[e->cur].p, segStart.data(), (D + 1) * 4));
+    HIP_TRY(up(e->cnt[e->cur].p, cnt.data(), D * 4));
+    HIP_TRY(up(g.vid, vid.data(), S * 4));
+    HIP_TRY(up(g.drv, drv.data(), S * 4));
+    HIP_TRY(up(g.prevDrv, prev.data(), S * 4));
+    HIP_TRY(up(g.blocker, blk.data(), S * 4));
+    HIP_TRY(up(g.enterLLT, ellt.data(), S * 4));
+    HIP_TRY(up(g.routePos, rpos.data(), S * 4));
+    HIP_TRY(up(g.templ, templ.data(), S * 4));
+    HIP_TRY(up(g.route, route.data(), S * 4));
+    HIP_TRY(up(g.flags, flags.data(), S));
+    HIP_TRY(up(g.dis, dis.data(), S * 8));
+    HIP_TRY(up(g.speed, speed.data(), S * 8));
+    std::vector<int32_t> ident(S);
+    for (int i = 0; i < S; ++i) ident[i] = i;
+    HIP_TRY(up(e->oldToNew, ident.data(), S * 4));
+    // vehicle table + waiting FIFOs
+    std::vector<int32_t> nextWait(std::max(nV, 1), -1), waitHead(L, -1);
+    for (int i = 0; i < s->n_waiting; ++i) {
+        int v = s->w_vid[i], lane = s->w_lane[i];
+        if (v < 0 || v >= nV || lane < 0 || lane >= L) return e->fail("cfx_load_state: waiting entry out of range");
+        if (i > 0 && s->w_lane[i - 1] == lane) nextWait[s->w_vid[i - 1]] = v;
+        else waitHead[lane] = v;
+    }
+    HIP_TRY(up(e->vt.priority, s->v_priority, (size_t) nV * 4));
+    HIP_TRY(up(e->vt.templ, s->v_templ, (size_t) nV * 4));
+    HIP_TRY(up(e->vt.route, s->v_route, (size_t) nV * 4));
+    HIP_TRY(up(e->vt.enterTime, s->v_enter_time, (size_t) nV * 8));
+    HIP_TRY(up(e->vt.state, s->v_state, (size_t) nV));
+    HIP_TRY(up(e->vt.customSpeed, custom.data(), (size_t) nV * 8));
+    HIP_TRY(hipMemsetAsync(e->vt.pendingCustom, 0, std::max(nV, 1), e->stream));
+    HIP_TRY(up(e->vt.nextWait, nextWait.data(), (size_t) nV * 4));
+    HIP_TRY(up(e->waitHead, waitHead.data(), (size_t) L * 4));
+    HIP_TRY(up(e->curPhase, s->tl_phase, (size_t) e->I * 4));
+    HIP_TRY(up(e->remain, s->tl_remain, (size_t) e->I * 8));
+    DevScalars sc{};
+    sc.active = nR;
+    sc.finishedCnt = s->finished_vehicle_count;
+    sc.cumulativeTravelTime = s->cumulative_travel_time;
+    sc.vehicleSteps = s->vehicle_steps;
+    HIP_TRY(up(e->sc, &sc, sizeof sc));
+    e->step = s->step;
+    e->spawned = nV;
+    e->finishedKnown = s->finished_vehicle_count;
+    // cached next drivable of every slot (uses the device copies of the route tables)
+    hipLaunchKernelGGL(k_refresh_next, dim3(gridStride(std::max(S, 1))), dim3(kBlock), 0, e->stream, e->ctx());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return CFX_OK;
 }
 

@@ -28,7 +28,9 @@ constexpr int kLdsTempl = 32;   // vehicle templates staged in LDS by k_action (
 struct VidTable {
     int32_t *priority, *templ, *route, *nextWait;
     double *enterTime;
-    uint8_t *state;  // 0 waiting, 1 running, 2 finished
+    double *customSpeed;     // Buffer::customSpeed (set_vehicle_speed)
+    uint8_t *state;          // 0 waiting, 1 running, 2 finished
+    uint8_t *pendingCustom;  // custom speed set while the vehicle was still waiting
 };
 
 struct DevScalars {
@@ -68,6 +70,7 @@ __global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidT
     vt.route[r.vid] = r.route;
     vt.enterTime[r.vid] = r.enter_time;
     vt.state[r.vid] = 0;
+    vt.pendingCustom[r.vid] = 0;
     // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367).  nextWait[] was pre-set to -1.
     if (r.prev_wait < 0) {
         waitHead[r.lane] = r.vid;
@@ -109,6 +112,7 @@ __global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *wa
     c.s.routePos[slot] = 0;
     c.s.templ[slot] = wt;
     c.s.route[slot] = route;
+    c.s.flags[slot] = vt.pendingCustom[w];
     c.s.dis[slot] = 0.0;
     c.s.speed[slot] = 0.0;
     cnt[lane] = n + 1;
@@ -402,8 +406,13 @@ __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, in
 
         // car following, Vehicle::getCarFollowSpeed vehicle.cpp:212-238
         double cf;
+        const bool custom = (c.s.flags[s] & 1) != 0;  // Vehicle::hasSetCustomSpeed
         if (ls < 0) {
-            cf = t.max_speed;
+            cf = custom ? c.vCustomSpeed[vid] : t.max_speed;
+        } else if (custom) {
+            const cfx_vehicle_template &tl = tv[c.s.templ[ls]];
+            cf = min2(c.vCustomSpeed[vid],
+                      noCollisionSpeed(c.s.speed[ls], tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0));
         } else {
             const cfx_vehicle_template &tl = tv[c.s.templ[ls]];
             const double leaderSpeed = c.s.speed[ls];
@@ -767,6 +776,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         nx.dis[ns] = b.dis[s];
         nx.speed[ns] = b.speed[s];
         nx.blocker[ns] = b.blocker[s];  // old-generation slot; resolved through oldToNew when read
+        nx.flags[ns] = 0;               // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
         const int route = c.s.route[s];
         nx.route[ns] = route;
         if (nd == -1) {
@@ -791,6 +801,44 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
             nx.next[ns] = nextOf(c.n, c.t, nd, route, rp);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- control
+// Vehicle::setCustomSpeed (vehicle.h:128-131) for a running vehicle: find its slot and raise the flag.
+__global__ void k_set_speed(StepCtx c, int vid) {
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride)
+        if (c.s.vid[s] == vid) c.s.flags[s] |= 1;
+}
+
+// Router::setRoute (router.cpp:245-255) after the host's checks: new route, iCurRoad = begin
+__global__ void k_set_route(StepCtx c, int vid, int route) {
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride)
+        if (c.s.vid[s] == vid) {
+            c.s.route[s] = route;
+            c.s.routePos[s] = 0;
+            c.s.next[s] = nextOf(c.n, c.t, c.s.drv[s], route, 0);
+        }
+}
+
+__global__ void k_refresh_next(StepCtx c) {  // after cfx_load_state: Router::getNextDrivable(0) of every vehicle
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride)
+        if (c.s.vid[s] >= 0) c.s.next[s] = nextOf(c.n, c.t, c.s.drv[s], c.s.route[s], c.s.routePos[s]);
+}
+
+__global__ void k_find_vehicle(StepCtx c, int vid, int32_t *out /*[2]: drivable, routePos*/) {
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride)
+        if (c.s.vid[s] == vid) {
+            out[0] = c.s.drv[s];
+            out[1] = c.s.routePos[s];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------- getters

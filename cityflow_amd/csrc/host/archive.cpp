@@ -1,0 +1,440 @@
+#include "archive.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+#include "engine_host.h"
+#include "json.h"
+
+namespace cfa {
+
+namespace {
+
+void num(std::string &o, double v) {  // round-trip exact; NaN/Inf spelled the way python's json accepts
+    char buf[40];
+    if (v != v) {
+        o += "NaN";
+        return;
+    }
+    if (std::isinf(v)) {
+        o += v > 0 ? "Infinity" : "-Infinity";
+        return;
+    }
+    snprintf(buf, sizeof buf, "%.17g", v);
+    o += buf;
+    if (!strpbrk(buf, ".eEn")) o += ".0";
+}
+void str(std::string &o, const std::string &s) {
+    o += '"';
+    for (char c : s) {
+        if (c == '"' || c == '\\') o += '\\';
+        o += c;
+    }
+    o += '"';
+}
+void key(std::string &o, const char *k) {
+    o += '"';
+    o += k;
+    o += "\":";
+}
+
+}  // namespace
+
+std::string Archive::vehicleId(int vid) const {
+    const VehicleRecord &r = host.vehicles[vid];
+    if (r.flow >= 0) return flowIds[r.flow] + "_" + std::to_string(r.number);
+    return "manually_pushed_" + std::to_string(r.number);
+}
+
+// Archive::dump archive.cpp:153-343 — same keys, same nesting; vehicles in vehiclePool (priority) order.
+void Archive::dump(const std::string &path) const {
+    const int L = (int) net->lanes.size();
+    const int nV = (int) host.vehicles.size();
+    std::vector<int> runIndex(nV, -1);
+    for (size_t i = 0; i < dev.rVid.size(); ++i) runIndex[dev.rVid[i]] = (int) i;
+    std::vector<int> waitLane(nV, -1);
+    for (size_t i = 0; i < dev.wVid.size(); ++i) waitLane[dev.wVid[i]] = dev.wLane[i];
+
+    std::string o;
+    o.reserve(1 << 20);
+    o += '{';
+    key(o, "step");
+    o += std::to_string(dev.step);
+    o += ',';
+    key(o, "activeVehicleCount");
+    o += std::to_string(dev.rVid.size());
+    o += ',';
+    key(o, "rnd");
+    {
+        std::ostringstream os;
+        os << host.rnd;
+        str(o, os.str());
+    }
+    o += ',';
+    key(o, "vehicles");
+    o += '[';
+    std::vector<std::pair<int32_t, int>> byPriority;
+    for (int v = 0; v < nV; ++v)
+        if (dev.vState[v] != 2) byPriority.emplace_back(host.vehicles[v].priority, v);
+    std::sort(byPriority.begin(), byPriority.end());
+    bool first = true;
+    for (auto &pv : byPriority) {
+        const int v = pv.second;
+        const VehicleRecord &r = host.vehicles[v];
+        const cfx_vehicle_template &t = templates[r.templ];
+        const int ri = runIndex[v];
+        if (!first) o += ',';
+        first = false;
+        o += '{';
+        key(o, "priority"); o += std::to_string(r.priority); o += ',';
+        key(o, "id"); str(o, vehicleId(v)); o += ',';
+        key(o, "enterTime"); num(o, r.enterTime); o += ',';
+        key(o, "speed"); num(o, ri >= 0 ? dev.rSpeed[ri] : 0.0); o += ',';
+        key(o, "len"); num(o, t.len); o += ',';
+        key(o, "width"); num(o, t.width); o += ',';
+        key(o, "maxPosAcc"); num(o, t.max_pos_acc); o += ',';
+        key(o, "maxNegAcc"); num(o, t.max_neg_acc); o += ',';
+        key(o, "usualPosAcc"); num(o, t.usual_pos_acc); o += ',';
+        key(o, "usualNegAcc"); num(o, t.usual_neg_acc); o += ',';
+        key(o, "minGap"); num(o, t.min_gap); o += ',';
+        key(o, "maxSpeed"); num(o, t.max_speed); o += ',';
+        key(o, "headwayTime"); num(o, t.headway_time); o += ',';
+        key(o, "yieldDistance"); num(o, t.yield_distance); o += ',';
+        key(o, "turnSpeed"); num(o, t.turn_speed); o += ',';
+        key(o, "route");
+        o += '[';
+        for (int p = routeStart[r.route]; p < routeStart[r.route + 1]; ++p) {
+            if (p > routeStart[r.route]) o += ',';
+            str(o, net->roads[routeRoads[p]].id);
+        }
+        o += "],";
+        key(o, "dis"); num(o, ri >= 0 ? dev.rDis[ri] : 0.0); o += ',';
+        int drivable = ri >= 0 ? dev.rDrivable[ri] : (waitLane[v] >= 0 ? waitLane[v] : r.firstLane);
+        key(o, "drivable"); str(o, net->drivableId(drivable)); o += ',';
+        if (ri >= 0 && dev.rPrevDrivable[ri] >= 0) {
+            key(o, "prevDrivable"); str(o, net->drivableId(dev.rPrevDrivable[ri])); o += ',';
+        }
+        key(o, "approachingIntersectionDistance"); num(o, t.approach_dist); o += ',';
+        key(o, "gap"); num(o, (ri >= 0 && dev.rLeader[ri] >= 0) ? dev.rGap[ri] : 0.0); o += ',';
+        key(o, "enterLaneLinkTime"); o += std::to_string((unsigned) (ri >= 0 ? dev.rEnterLLTime[ri] : INT_MAX)); o += ',';
+        if (ri >= 0 && dev.rLeader[ri] >= 0) {
+            key(o, "leader"); str(o, vehicleId(dev.rLeader[ri])); o += ',';
+        }
+        if (ri >= 0 && dev.rBlocker[ri] >= 0) {
+            key(o, "blocker"); str(o, vehicleId(dev.rBlocker[ri])); o += ',';
+        }
+        key(o, "end"); o += "false,";
+        key(o, "running"); o += ri >= 0 ? "true," : "false,";
+        key(o, "partnerType"); o += "0,";
+        key(o, "offset"); o += "0.0,";
+        key(o, "laneChangeWaitingTime"); o += "0.0,";
+        key(o, "laneChanging"); o += "false,";
+        key(o, "laneChangeLastTime"); o += "0.0";
+        o += '}';
+    }
+    o += "],";
+    key(o, "drivables");
+    o += '{';
+    {
+        const int D = L + (int) net->laneLinks.size();
+        std::vector<std::vector<int>> perDrv(D), perLaneWait(L);
+        for (size_t i = 0; i < dev.rVid.size(); ++i) perDrv[dev.rDrivable[i]].push_back(dev.rVid[i]);
+        for (size_t i = 0; i < dev.wVid.size(); ++i) perLaneWait[dev.wLane[i]].push_back(dev.wVid[i]);
+        for (int d = 0; d < D; ++d) {
+            if (d) o += ',';
+            str(o, net->drivableId(d));
+            o += ":{";
+            key(o, "vehicles");
+            o += '[';
+            for (size_t i = 0; i < perDrv[d].size(); ++i) {
+                if (i) o += ',';
+                str(o, vehicleId(perDrv[d][i]));
+            }
+            o += ']';
+            if (d < L) {
+                o += ',';
+                key(o, "waitingBuffer");
+                o += '[';
+                for (size_t i = 0; i < perLaneWait[d].size(); ++i) {
+                    if (i) o += ',';
+                    str(o, vehicleId(perLaneWait[d][i]));
+                }
+                o += "],";
+                // Lane history feeds only the never-selected RouterType::DURATION
+                key(o, "history"); o += "[],";
+                key(o, "historyVehicleNum"); o += "0,";
+                key(o, "historyAverageSpeed"); o += "0.0";
+            }
+            o += '}';
+        }
+    }
+    o += "},";
+    key(o, "flows");
+    o += '{';
+    for (size_t f = 0; f < flowIds.size(); ++f) {
+        if (f) o += ',';
+        str(o, flowIds[f]);
+        o += ":{";
+        key(o, "nowTime"); num(o, host.flows[f].nowTime); o += ',';
+        key(o, "currentTime"); num(o, host.flows[f].currentTime); o += ',';
+        key(o, "cnt"); o += std::to_string(host.flows[f].cnt);
+        o += '}';
+    }
+    o += "},";
+    key(o, "trafficLights");
+    o += '{';
+    for (size_t i = 0; i < net->inters.size(); ++i) {
+        if (i) o += ',';
+        str(o, net->inters[i].id);
+        o += ":{";
+        key(o, "remainDuration"); num(o, dev.tlRemain[i]); o += ',';
+        key(o, "curPhaseIndex"); o += std::to_string(dev.tlPhase[i]);
+        o += '}';
+    }
+    o += "},";
+    key(o, "finishedVehicleCnt"); o += std::to_string(dev.finished); o += ',';
+    key(o, "cumulativeTravelTime"); num(o, dev.cumulativeTravelTime);
+    o += '}';
+    FILE *fp = fopen(path.c_str(), "w");
+    if (!fp) throw std::runtime_error("Archive.dump: cannot open " + path);
+    fwrite(o.data(), 1, o.size(), fp);
+    fclose(fp);
+}
+
+// ------------------------------------------------------------------------------------------ EngineHost side
+Archive EngineHost::snapshot() {
+    Archive a;
+    a.host = spawner_.saveState();
+    a.net = net_;
+    a.templates = spawner_.templates;
+    a.routeStart = spawner_.routes.routeStart;
+    a.routeRoads = spawner_.routes.roads;
+    for (const HostFlow &f : spawner_.flows) a.flowIds.push_back(f.id);
+    DeviceState &d = a.dev;
+    cfx_scalars sc = scalars();
+    d.step = (int64_t) step_;
+    d.finished = sc.finished_vehicle_count;
+    d.vehicleSteps = sc.vehicle_steps;
+    d.cumulativeTravelTime = sc.cumulative_travel_time;
+    int nV = (int) spawner_.vehicles.size();
+    d.vState.resize(nV);
+    if (nV) check(be_.cfx_get_vehicle_status(dev_, 0, nV, d.vState.data()), "cfx_get_vehicle_status");
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    d.rVid = s.vid;
+    d.rDrivable = s.drivable;
+    d.rPrevDrivable = s.prevDrivable;
+    d.rBlocker = s.blocker;
+    d.rEnterLLTime = s.enterLLTime;
+    d.rRoutePos = s.routePos;
+    d.rLeader = s.leader;
+    d.rDis = s.dis;
+    d.rSpeed = s.speed;
+    d.rGap = s.gap;
+    d.rCustomSpeed.resize(s.count);
+    if (s.count) check(be_.cfx_get_custom_speeds(dev_, s.count, d.rCustomSpeed.data()), "cfx_get_custom_speeds");
+    waitingVehicles(d.wVid, d.wLane);
+    trafficLightState(d.tlPhase, d.tlRemain);
+    return a;
+}
+
+void EngineHost::load(const Archive &a) {
+    if (a.net.get() != net_.get() && a.net->lanes.size() != net_->lanes.size())
+        throw std::runtime_error("Engine.load: archive belongs to a different road network");
+    spawner_.loadState(a.host);
+    uploadNewTablesIfAny();
+    const DeviceState &d = a.dev;
+    const int nV = (int) a.host.vehicles.size();
+    std::vector<int32_t> prio(nV), templ(nV), route(nV);
+    std::vector<double> enter(nV);
+    for (int v = 0; v < nV; ++v) {
+        prio[v] = a.host.vehicles[v].priority;
+        templ[v] = a.host.vehicles[v].templ;
+        route[v] = a.host.vehicles[v].route;
+        enter[v] = a.host.vehicles[v].enterTime;
+    }
+    cfx_state st{};
+    st.step = d.step;
+    st.finished_vehicle_count = d.finished;
+    st.vehicle_steps = d.vehicleSteps;
+    st.cumulative_travel_time = d.cumulativeTravelTime;
+    st.n_vehicles = nV;
+    st.v_priority = prio.data();
+    st.v_templ = templ.data();
+    st.v_route = route.data();
+    st.v_enter_time = enter.data();
+    st.v_state = d.vState.data();
+    st.n_running = (int) d.rVid.size();
+    st.r_vid = d.rVid.data();
+    st.r_drivable = d.rDrivable.data();
+    st.r_prev_drivable = d.rPrevDrivable.data();
+    st.r_blocker_vid = d.rBlocker.data();
+    st.r_enter_ll_time = d.rEnterLLTime.data();
+    st.r_route_pos = d.rRoutePos.data();
+    st.r_dis = d.rDis.data();
+    st.r_speed = d.rSpeed.data();
+    st.r_custom_speed = d.rCustomSpeed.empty() ? nullptr : d.rCustomSpeed.data();
+    st.n_waiting = (int) d.wVid.size();
+    st.w_vid = d.wVid.data();
+    st.w_lane = d.wLane.data();
+    st.tl_phase = d.tlPhase.data();
+    st.tl_remain = d.tlRemain.data();
+    check(be_.cfx_load_state(dev_, &st), "cfx_load_state");
+    step_ = (size_t) d.step;
+}
+
+// Archive(Engine&, filename) archive.cpp:345-550: rebuild an Archive from the reference's JSON format.
+void EngineHost::loadFromFile(const std::string &path) {
+    Json root = Json::parseFile(path);
+    Archive a;
+    a.net = net_;
+    const int L = (int) net_->lanes.size();
+    std::map<std::string, int> drvIndex;
+    for (int d = 0; d < L + (int) net_->laneLinks.size(); ++d) drvIndex[net_->drivableId(d)] = d;
+
+    a.host = spawner_.saveState();  // flows' valid flags, manual counter; the rest is overwritten below
+    {
+        std::istringstream is(root.stringAt("rnd"));
+        is >> a.host.rnd;
+    }
+    a.host.vehicles.clear();
+    for (auto &v : a.host.flowVids) v.clear();
+    std::fill(a.host.manualVids.begin(), a.host.manualVids.end(), -1);
+    std::fill(a.host.lastWaitVid.begin(), a.host.lastWaitVid.end(), -1);
+    a.host.livePriority.clear();
+
+    DeviceState &d = a.dev;
+    d.step = root.at("step").i;
+    d.finished = root.intAt("finishedVehicleCnt");
+    d.cumulativeTravelTime = root.numberAt("cumulativeTravelTime");
+    d.vehicleSteps = 0;
+
+    std::map<std::string, int> vidOf;
+    const Json &vehicles = root.arrayAt("vehicles");
+    struct Dyn {
+        double dis, speed;
+        int drivable, prev, ellt;
+        std::string blocker;
+        bool running;
+    };
+    std::vector<Dyn> dyn;
+    for (const Json &jv : vehicles.items) {
+        cfx_vehicle_template t = spawner_.makeTemplate(jv.numberAt("len"), jv.numberAt("width"), jv.numberAt("maxPosAcc"),
+                                                       jv.numberAt("maxNegAcc"), jv.numberAt("usualPosAcc"),
+                                                       jv.numberAt("usualNegAcc"), jv.numberAt("minGap"),
+                                                       jv.numberAt("maxSpeed"), jv.numberAt("headwayTime"));
+        t.yield_distance = jv.numberAt("yieldDistance");
+        t.turn_speed = jv.numberAt("turnSpeed");
+        t.approach_dist = jv.numberAt("approachingIntersectionDistance");
+        VehicleRecord r{};
+        r.templ = spawner_.addTemplate(t);
+        std::vector<int> seq;
+        for (const Json &rd : jv.arrayAt("route").items) {
+            auto it = net_->roadIndex.find(rd.s);
+            if (it == net_->roadIndex.end()) throw std::runtime_error("load_from_file: unknown road " + rd.s);
+            seq.push_back(it->second);
+        }
+        if (seq.empty()) throw std::runtime_error("load_from_file: vehicle without route");
+        r.route = spawner_.internRoute(seq);
+        r.priority = jv.intAt("priority");
+        r.enterTime = jv.numberAt("enterTime");
+        const std::string &id = jv.stringAt("id");
+        const std::string mp = "manually_pushed_";
+        if (id.compare(0, mp.size(), mp) == 0) {
+            r.flow = -1;
+            r.number = atoi(id.c_str() + mp.size());
+        } else {
+            size_t us = id.rfind('_');
+            if (id.compare(0, 5, "flow_") != 0 || us == std::string::npos || us <= 5)
+                throw std::runtime_error("load_from_file: unsupported vehicle id " + id);
+            r.flow = atoi(id.substr(5, us - 5).c_str());
+            r.number = atoi(id.c_str() + us + 1);
+            if (r.flow < 0 || r.flow >= (int) spawner_.flows.size())
+                throw std::runtime_error("load_from_file: vehicle of unknown flow " + id);
+        }
+        Dyn y{};
+        y.dis = jv.numberAt("dis");
+        y.speed = jv.numberAt("speed");
+        auto di = drvIndex.find(jv.stringAt("drivable"));
+        if (di == drvIndex.end()) throw std::runtime_error("load_from_file: unknown drivable");
+        y.drivable = di->second;
+        const Json *pd = jv.find("prevDrivable");
+        y.prev = pd ? drvIndex.at(pd->s) : -1;
+        y.ellt = (int) jv.at("enterLaneLinkTime").i;
+        const Json *bl = jv.find("blocker");
+        if (bl) y.blocker = bl->s;
+        y.running = jv.boolAt("running");
+        r.firstLane = y.running ? -1 : y.drivable;
+        int vid = (int) a.host.vehicles.size();
+        a.host.vehicles.push_back(r);
+        a.host.livePriority[r.priority] = vid;
+        std::vector<int32_t> &tbl = r.flow >= 0 ? a.host.flowVids[r.flow] : a.host.manualVids;
+        if ((int) tbl.size() <= r.number) tbl.resize(r.number + 1, -1);
+        tbl[r.number] = vid;
+        vidOf[id] = vid;
+        dyn.push_back(y);
+    }
+    const int nV = (int) a.host.vehicles.size();
+    d.vState.assign(nV, 0);
+    const Json &drivables = root.objectAt("drivables");
+    const RouteTable &rt = spawner_.routes;
+    for (int dv = 0; dv < L + (int) net_->laneLinks.size(); ++dv) {
+        const Json &jd = drivables.objectAt(net_->drivableId(dv).c_str());
+        for (const Json &jid : jd.arrayAt("vehicles").items) {
+            int vid = vidOf.at(jid.s);
+            const Dyn &y = dyn[vid];
+            d.vState[vid] = 1;
+            d.rVid.push_back(vid);
+            d.rDrivable.push_back(dv);
+            d.rPrevDrivable.push_back(y.prev);
+            d.rBlocker.push_back(y.blocker.empty() ? -1 : vidOf.at(y.blocker));
+            d.rEnterLLTime.push_back(y.ellt);
+            // Router::iCurRoad: the copy constructor restarts it at route.begin() (router.cpp:11-14) and
+            // Router::update advances it to the current road; the first occurrence is equivalent.
+            int road = dv < L ? net_->lanes[dv].road : net_->lanes[net_->laneLinks[dv - L].startLane].road;
+            int r = a.host.vehicles[vid].route, pos = 0;
+            int n = rt.routeStart[r + 1] - rt.routeStart[r];
+            while (pos < n && rt.roads[rt.routeStart[r] + pos] != road) ++pos;
+            d.rRoutePos.push_back(pos < n ? pos : 0);
+            d.rLeader.push_back(-1);
+            d.rDis.push_back(y.dis);
+            d.rSpeed.push_back(y.speed);
+            d.rGap.push_back(0.0);
+        }
+        if (dv < L) {
+            for (const Json &jid : jd.arrayAt("waitingBuffer").items) {
+                int vid = vidOf.at(jid.s);
+                d.wVid.push_back(vid);
+                d.wLane.push_back(dv);
+                a.host.lastWaitVid[dv] = vid;
+            }
+        }
+    }
+    const Json &flows = root.objectAt("flows");
+    for (size_t f = 0; f < spawner_.flows.size(); ++f) {
+        const Json &jf = flows.objectAt(spawner_.flows[f].id.c_str());
+        a.host.flows[f].nowTime = jf.numberAt("nowTime");
+        a.host.flows[f].currentTime = jf.numberAt("currentTime");
+        a.host.flows[f].cnt = jf.intAt("cnt");
+    }
+    const Json &lights = root.objectAt("trafficLights");
+    d.tlPhase.resize(net_->inters.size());
+    d.tlRemain.resize(net_->inters.size());
+    for (size_t i = 0; i < net_->inters.size(); ++i) {
+        const Json &jl = lights.objectAt(net_->inters[i].id.c_str());
+        d.tlPhase[i] = jl.intAt("curPhaseIndex");
+        d.tlRemain[i] = jl.numberAt("remainDuration");
+    }
+    a.templates = spawner_.templates;
+    a.routeStart = spawner_.routes.routeStart;
+    a.routeRoads = spawner_.routes.roads;
+    for (const HostFlow &f : spawner_.flows) a.flowIds.push_back(f.id);
+    load(a);
+}
+
+}  // namespace cfa

@@ -1,0 +1,44 @@
+// Archive: snapshot / restore of the whole simulation state (reference src/engine/archive.{h,cpp}).
+//   Engine.snapshot() -> Archive           in-memory deep copy (Archive(const Engine&) archive.cpp:9-37)
+//   Engine.load(archive)                    Archive::resume archive.cpp:73-126
+//   Archive.dump(path)                      JSON in the reference's own format (archive.cpp:153-343), so dumps
+//   Engine.load_from_file(path)             travel in both directions between this engine and the reference
+// The device part is read with the cfx getters and written back with cfx_load_state (include/cityflow_amd.h).
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "flow.h"
+#include "roadnet.h"
+
+namespace cfa {
+
+struct DeviceState {
+    int64_t step = 0, finished = 0, vehicleSteps = 0;
+    double cumulativeTravelTime = 0;
+    std::vector<uint8_t> vState;  // per vid
+    // running vehicles in Drivable::vehicles order
+    std::vector<int32_t> rVid, rDrivable, rPrevDrivable, rBlocker, rEnterLLTime, rRoutePos, rLeader;
+    std::vector<double> rDis, rSpeed, rGap, rCustomSpeed;
+    std::vector<int32_t> wVid, wLane;  // waiting buffers, lane by lane
+    std::vector<int32_t> tlPhase;
+    std::vector<double> tlRemain;
+};
+
+class Archive {
+public:
+    Spawner::State host;
+    DeviceState dev;
+    // immutable context needed to write ids / templates / routes
+    std::shared_ptr<const HostRoadNet> net;
+    std::vector<cfx_vehicle_template> templates;
+    std::vector<int32_t> routeStart, routeRoads;
+    std::vector<std::string> flowIds;
+
+    void dump(const std::string &path) const;
+    std::string vehicleId(int vid) const;
+};
+
+}  // namespace cfa

@@ -51,6 +51,11 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_get_vehicles)
     CFX_FN(cfx_get_waiting)
     CFX_FN(cfx_get_vehicle_status)
+    CFX_FN(cfx_set_vehicle_speed)
+    CFX_FN(cfx_set_vehicle_route)
+    CFX_FN(cfx_get_vehicle)
+    CFX_FN(cfx_load_state)
+    CFX_FN(cfx_get_custom_speeds)
     CFX_FN(cfx_profile_kernel_count)
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)
@@ -81,8 +86,8 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
         roadnetFile = cfg.stringAt("roadnetFile");
         flowFile = cfg.stringAt("flowFile");
         saveReplay_ = cfg.boolAt("saveReplay");
-        net_.load(dir_ + roadnetFile);
-        spawner_.init(&net_, interval_, threadNum_, seed_);
+        net_->load(dir_ + roadnetFile);
+        spawner_.init(net_.get(), interval_, threadNum_, seed_);
         spawner_.loadFlows(dir_ + flowFile);
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
@@ -102,7 +107,7 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
     cc.device = 0;
     if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);
     if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) cc.device = atoi(dev);
-    int32_t rc = be_.cfx_create(&net_.flat(), &cc, &dev_);
+    int32_t rc = be_.cfx_create(&net_->flat(), &cc, &dev_);
     if (rc != CFX_OK || !dev_) {
         const char *msg = be_.cfx_last_error(nullptr);
         throw std::runtime_error(std::string("cityflow_amd: cfx_create failed in ") + be_.path + ": " +
@@ -190,40 +195,40 @@ void EngineHost::reset(bool resetRnd) {
 size_t EngineHost::getVehicleCount() { return (size_t) scalars().active_vehicle_count; }
 
 std::vector<int32_t> EngineHost::laneVehicleCountArray() {
-    std::vector<int32_t> out(net_.lanes.size());
+    std::vector<int32_t> out(net_->lanes.size());
     check(be_.cfx_get_lane_counts(dev_, out.data()), "cfx_get_lane_counts");
     return out;
 }
 
 std::vector<int32_t> EngineHost::laneWaitingVehicleCountArray() {
-    std::vector<int32_t> out(net_.lanes.size());
+    std::vector<int32_t> out(net_->lanes.size());
     check(be_.cfx_get_lane_waiting_counts(dev_, out.data()), "cfx_get_lane_waiting_counts");
     return out;
 }
 
 std::vector<std::string> EngineHost::laneIds() const {
-    std::vector<std::string> ids(net_.lanes.size());
-    for (size_t l = 0; l < ids.size(); ++l) ids[l] = net_.laneId((int) l);
+    std::vector<std::string> ids(net_->lanes.size());
+    for (size_t l = 0; l < ids.size(); ++l) ids[l] = net_->laneId((int) l);
     return ids;
 }
 
 std::vector<std::string> EngineHost::intersectionIds() const {
-    std::vector<std::string> ids(net_.inters.size());
-    for (size_t i = 0; i < ids.size(); ++i) ids[i] = net_.inters[i].id;
+    std::vector<std::string> ids(net_->inters.size());
+    for (size_t i = 0; i < ids.size(); ++i) ids[i] = net_->inters[i].id;
     return ids;
 }
 
 std::map<std::string, int> EngineHost::getLaneVehicleCount() {
     std::vector<int32_t> cnt = laneVehicleCountArray();
     std::map<std::string, int> ret;
-    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_.laneId((int) l), cnt[l]);
+    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_->laneId((int) l), cnt[l]);
     return ret;
 }
 
 std::map<std::string, int> EngineHost::getLaneWaitingVehicleCount() {
     std::vector<int32_t> cnt = laneWaitingVehicleCountArray();
     std::map<std::string, int> ret;
-    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_.laneId((int) l), cnt[l]);
+    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_->laneId((int) l), cnt[l]);
     return ret;
 }
 
@@ -293,11 +298,11 @@ std::map<std::string, std::vector<std::string>> EngineHost::getLaneVehicles() {
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, std::vector<std::string>> ret;
-    const int L = (int) net_.lanes.size();
+    const int L = (int) net_->lanes.size();
     std::vector<std::vector<std::string>> perLane(L);
     for (int i = 0; i < s.count; ++i)
         if (s.drivable[i] < L) perLane[s.drivable[i]].push_back(spawner_.vehicleId(s.vid[i]));
-    for (int l = 0; l < L; ++l) ret.emplace(net_.laneId(l), std::move(perLane[l]));
+    for (int l = 0; l < L; ++l) ret.emplace(net_->laneId(l), std::move(perLane[l]));
     return ret;
 }
 
@@ -369,17 +374,17 @@ std::map<std::string, std::string> EngineHost::getVehicleInfo(const std::string 
         if (s.vid[i] != vid) continue;
         info["distance"] = std::to_string(s.dis[i]);
         info["speed"] = std::to_string(s.speed[i]);
-        info["drivable"] = net_.drivableId(s.drivable[i]);
-        if (s.drivable[i] < (int) net_.lanes.size()) {
-            const HostRoad &road = net_.roads[net_.lanes[s.drivable[i]].road];
+        info["drivable"] = net_->drivableId(s.drivable[i]);
+        if (s.drivable[i] < (int) net_->lanes.size()) {
+            const HostRoad &road = net_->roads[net_->lanes[s.drivable[i]].road];
             info["road"] = road.id;
-            info["intersection"] = net_.inters[road.endInter].id;
+            info["intersection"] = net_->inters[road.endInter].id;
         }
         const RouteTable &rt = spawner_.routes;
         int r = spawner_.vehicles[vid].route;
         std::string route;
         for (int p = rt.routeStart[r] + s.routePos[i]; p < rt.routeStart[r + 1]; ++p)
-            route += net_.roads[rt.roads[p]].id + " ";
+            route += net_->roads[rt.roads[p]].id + " ";
         info["route"] = route;
     }
     return info;
@@ -419,18 +424,65 @@ void EngineHost::setTrafficLightPhase(const std::string &id, int phaseIndex) {
         std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
         return;
     }
-    auto it = net_.interIndex.find(id);
-    if (it == net_.interIndex.end()) throw std::runtime_error("Intersection '" + id + "' not found");
-    const HostInter &in = net_.inters[it->second];
+    auto it = net_->interIndex.find(id);
+    if (it == net_->interIndex.end()) throw std::runtime_error("Intersection '" + id + "' not found");
+    const HostInter &in = net_->inters[it->second];
     if (in.isVirtual || phaseIndex < 0 || phaseIndex >= (int) in.phases.size())
         throw std::out_of_range("phase index " + std::to_string(phaseIndex) + " out of range for intersection '" + id + "'");
     setTrafficLightPhaseIndexed(it->second, phaseIndex);
 }
 
 void EngineHost::trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain) {
-    phase.resize(net_.inters.size());
-    remain.resize(net_.inters.size());
+    phase.resize(net_->inters.size());
+    remain.resize(net_->inters.size());
     check(be_.cfx_get_tl_state(dev_, phase.data(), remain.data()), "cfx_get_tl_state");
+}
+
+// setVehicleSpeed engine.cpp:827-834
+void EngineHost::setVehicleSpeed(const std::string &id, double speed) {
+    int vid = vidOf(id);
+    uint8_t st = 2;
+    if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
+    if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + id + "' not found");
+    check(be_.cfx_set_vehicle_speed(dev_, vid, speed), "cfx_set_vehicle_speed");
+}
+
+// Engine::setRoute engine.cpp:852-866 + Router::setRoute router.cpp:245-264
+bool EngineHost::setRoute(const std::string &vehicleId, const std::vector<std::string> &anchorIds) {
+    int vid = vidOf(vehicleId);
+    if (vid < 0) return false;
+    int32_t state = 2, drivable = -1, routePos = -1, route = -1;
+    check(be_.cfx_get_vehicle(dev_, vid, &state, &drivable, &routePos, &route), "cfx_get_vehicle");
+    if (state == 2) return false;
+    std::vector<int> anchors;
+    for (const auto &id : anchorIds) {
+        auto it = net_->roadIndex.find(id);
+        if (it == net_->roadIndex.end()) return false;
+        anchors.push_back(it->second);
+    }
+    const int L = (int) net_->lanes.size();
+    if (state == 0) {  // still in a waiting buffer: its drivable is its first lane, iCurRoad = begin
+        drivable = spawner_.vehicles[vid].firstLane;
+        routePos = 0;
+    }
+    if (drivable >= L) return false;  // on a laneLink (router.cpp:246)
+    const RouteTable &rt = spawner_.routes;
+    int curRoad = rt.roads[rt.routeStart[route] + routePos];
+    std::vector<int> newAnchors{curRoad};
+    newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
+    std::vector<int> seq;
+    if (!spawner_.expandRoute(newAnchors, seq)) return false;
+    int newRoute = spawner_.internRoute(seq);
+    // Router::onValidLane (router.h:66-68) under the new route: a next drivable exists or this is the last road
+    const RouteTable &rt2 = spawner_.routes;
+    int laneIdx = net_->lanes[drivable].index;
+    bool hasNext = rt2.nextLL[rt2.nextStart[rt2.routeStart[newRoute]] + laneIdx] >= 0;
+    bool lastRoad = seq.size() == 1;
+    if (!hasNext && !lastRoad) return false;
+    uploadNewTablesIfAny();
+    check(be_.cfx_set_vehicle_route(dev_, vid, newRoute), "cfx_set_vehicle_route");
+    spawner_.setVehicleRoute(vid, newRoute);
+    return true;
 }
 
 // pushVehicle(map, vector) engine.cpp:693-717
@@ -447,8 +499,8 @@ void EngineHost::pushVehicle(const std::map<std::string, double> &info, const st
         throw std::runtime_error("cityflow_amd: push_vehicle with a non-zero initial speed is not supported yet");
     std::vector<int> anchors;
     for (auto &r : roads) {
-        auto it = net_.roadIndex.find(r);
-        if (it == net_.roadIndex.end()) throw std::runtime_error("Road '" + r + "' not found");
+        auto it = net_->roadIndex.find(r);
+        if (it == net_->roadIndex.end()) throw std::runtime_error("Road '" + r + "' not found");
         anchors.push_back(it->second);
     }
     if (anchors.empty()) throw std::runtime_error("push_vehicle: empty route");

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "archive.h"
 #include "cityflow_amd.h"
 #include "flow.h"
 #include "roadnet.h"
@@ -40,6 +41,11 @@ struct Backend {
     CFX_FN(cfx_get_vehicles)
     CFX_FN(cfx_get_waiting)
     CFX_FN(cfx_get_vehicle_status)
+    CFX_FN(cfx_set_vehicle_speed)
+    CFX_FN(cfx_set_vehicle_route)
+    CFX_FN(cfx_get_vehicle)
+    CFX_FN(cfx_load_state)
+    CFX_FN(cfx_get_custom_speeds)
     CFX_FN(cfx_profile_kernel_count)
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)
@@ -80,6 +86,11 @@ public:
     void setRandomSeed(int seed) { spawner_.seed(seed); }
     void pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads);
     void reset(bool resetRnd);
+    void setVehicleSpeed(const std::string &id, double speed);                        // engine.cpp:827-834
+    bool setRoute(const std::string &vehicleId, const std::vector<std::string> &anchors);  // engine.cpp:852-866
+    Archive snapshot();                        // engine.h:177
+    void load(const Archive &archive);         // engine.h:176
+    void loadFromFile(const std::string &path);  // engine.cpp:822-825
 
     // ---- array getters (no string marshalling; for large grids / RL observation tensors) ----
     std::vector<int32_t> laneVehicleCountArray();
@@ -95,7 +106,7 @@ public:
     void profileEnable(bool on);
     std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
 
-    const HostRoadNet &net() const { return net_; }
+    const HostRoadNet &net() const { return *net_; }
     const Spawner &spawner() const { return spawner_; }
     std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
     std::string vehicleId(int vid) const { return spawner_.vehicleId(vid); }
@@ -107,7 +118,7 @@ private:
     void check(int32_t rc, const char *what);
     void uploadNewTablesIfAny();
 
-    HostRoadNet net_;
+    std::shared_ptr<HostRoadNet> net_ = std::make_shared<HostRoadNet>();
     Spawner spawner_;
     Backend be_;
     cfx_engine *dev_ = nullptr;

@@ -172,7 +172,7 @@ void Spawner::loadFlows(const std::string &path) {
         f.interval = fv.numberAt("interval");
         f.nowTime = f.interval;  // Flow ctor flow.h:30-36
         std::vector<int> seq;
-        f.route = expandRoute(f.anchors, seq) ? routes.add(*net_, seq) : -1;
+        f.route = expandRoute(f.anchors, seq) ? internRoute(seq) : -1;
         flows.push_back(std::move(f));
     }
     flowVids.assign(flows.size(), {});
@@ -206,6 +206,7 @@ int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> 
     rec.templ = templ;
     rec.route = route;
     rec.enterTime = stepIndex * interval_;  // Engine::getCurrentTime engine.cpp:678-680
+    rec.firstLane = -1;
     pendingRecords_.push_back(rec);
     livePriority_[priority] = -1;
     Pending p;
@@ -217,7 +218,7 @@ int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> 
 
 void Spawner::pushManual(int templ, const std::vector<int> &anchors, size_t stepIndex) {
     std::vector<int> seq;
-    int route = expandRoute(anchors, seq) ? routes.add(*net_, seq) : -1;
+    int route = expandRoute(anchors, seq) ? internRoute(seq) : -1;
     newVehicle(-1, manualCnt_++, templ, anchors, route, stepIndex, isFinished_);
 }
 
@@ -246,6 +247,7 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
             const std::vector<int32_t> &cands = routes.firstLanes[rec.route];
             int lane = cands[rnd() % cands.size()];
             int vid = (int) vehicles.size();
+            rec.firstLane = lane;
             vehicles.push_back(rec);
             livePriority_[rec.priority] = vid;
             {
@@ -271,6 +273,45 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
             livePriority_.erase(rec.priority);
         }
     }
+    pending_.clear();
+    pendingRecords_.clear();
+}
+
+int Spawner::internRoute(const std::vector<int> &seq) {
+    auto it = routeIndex_.find(seq);
+    if (it != routeIndex_.end()) return it->second;
+    int r = routes.add(*net_, seq);
+    routeIndex_.emplace(seq, r);
+    return r;
+}
+
+Spawner::State Spawner::saveState() const {
+    State st;
+    for (const HostFlow &f : flows) st.flows.push_back(FlowDyn{f.nowTime, f.currentTime, f.cnt, f.valid});
+    st.vehicles = vehicles;
+    st.flowVids = flowVids;
+    st.manualVids = manualVids;
+    st.lastWaitVid = lastWaitVid_;
+    st.rnd = rnd;
+    st.manualCnt = manualCnt_;
+    st.livePriority = livePriority_;
+    return st;
+}
+
+void Spawner::loadState(const State &st) {
+    for (size_t i = 0; i < flows.size() && i < st.flows.size(); ++i) {
+        flows[i].nowTime = st.flows[i].nowTime;
+        flows[i].currentTime = st.flows[i].currentTime;
+        flows[i].cnt = st.flows[i].cnt;
+        flows[i].valid = st.flows[i].valid;
+    }
+    vehicles = st.vehicles;
+    flowVids = st.flowVids;
+    manualVids = st.manualVids;
+    lastWaitVid_ = st.lastWaitVid;
+    rnd = st.rnd;
+    manualCnt_ = std::max(manualCnt_, st.manualCnt);  // manuallyPushCnt never goes back (engine.h:56)
+    livePriority_ = st.livePriority;
     pending_.clear();
     pendingRecords_.clear();
 }

@@ -12,6 +12,7 @@
 #pragma once
 
 #include <functional>
+#include <map>
 #include <random>
 #include <string>
 #include <unordered_map>
@@ -56,6 +57,13 @@ struct VehicleRecord {
     int32_t number;    // per-flow counter or manuallyPushCnt value
     int32_t templ, route;
     double enterTime;
+    int32_t firstLane;  // lane whose waiting buffer it was pushed to (-1 while still in planRouteBuffer)
+};
+
+struct FlowDyn {  // Flow fields that change while stepping (flow.h:23-31)
+    double nowTime, currentTime;
+    int cnt;
+    bool valid;
 };
 
 class Spawner {
@@ -93,6 +101,25 @@ public:
     std::string vehicleId(int vid) const;
     int initialSeed() const { return seed_; }
 
+    // Route index for an expanded road sequence, adding it if it is new (used by set_vehicle_route and
+    // load_from_file, which would otherwise add one route per vehicle).
+    int internRoute(const std::vector<int> &roadSeq);
+    void setVehicleRoute(int vid, int route) { vehicles[vid].route = route; }
+
+    // Everything that changes while stepping, for Archive-style snapshot / restore (archive.cpp:62-66,161-165).
+    struct State {
+        std::vector<FlowDyn> flows;
+        std::vector<VehicleRecord> vehicles;
+        std::vector<std::vector<int32_t>> flowVids;
+        std::vector<int32_t> manualVids, lastWaitVid;
+        std::mt19937 rnd;
+        int manualCnt = 0;
+        std::unordered_map<int32_t, int32_t> livePriority;
+    };
+    State saveState() const;
+    void loadState(const State &st);
+    int manualCount() const { return manualCnt_; }
+
 private:
     struct Pending {
         int index;  // into pendingRecords_
@@ -111,6 +138,7 @@ private:
     std::vector<VehicleRecord> pendingRecords_;
     std::vector<int32_t> lastWaitVid_;             // per lane: last vid pushed to its waitingBuffer
     std::unordered_map<int32_t, int32_t> livePriority_;  // priority -> vid (superset of live vehicles)
+    std::map<std::vector<int>, int> routeIndex_;          // expanded road sequence -> route index
 };
 
 }  // namespace cfa

@@ -238,7 +238,23 @@ private:
                     expect("null");
                     v.kind = Null;
                     return;
+                case 'N':  // NaN / Infinity are not JSON, but the reference dumps uninitialised doubles
+                    expect("NaN");  // (ControllerInfo::gap of vehicles without a leader, archive.cpp:218)
+                    v.kind = Number;
+                    v.d = std::strtod("nan", nullptr);
+                    return;
+                case 'I':
+                    expect("Infinity");
+                    v.kind = Number;
+                    v.d = std::strtod("inf", nullptr);
+                    return;
                 default: {
+                    if (end - p >= 9 && memcmp(p, "-Infinity", 9) == 0) {
+                        p += 9;
+                        v.kind = Number;
+                        v.d = -std::strtod("inf", nullptr);
+                        return;
+                    }
                     const char *s0 = p;
                     bool integral = true;
                     if (p < end && *p == '-') ++p;

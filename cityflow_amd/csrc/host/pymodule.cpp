@@ -5,6 +5,8 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <iostream>
+
 #include "engine_host.h"
 #include "json.h"
 
@@ -156,6 +158,16 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("set_random_seed", &EngineHost::setRandomSeed, "seed"_a)
         .def("push_vehicle", &EngineHost::pushVehicle)
         .def("reset", &EngineHost::reset, "seed"_a = false)
+        .def("set_vehicle_speed", &EngineHost::setVehicleSpeed, "vehicle_id"_a, "speed"_a)
+        .def("set_vehicle_route", &EngineHost::setRoute, "vehicle_id"_a, "route"_a)
+        .def("load", &EngineHost::load, "archive"_a)
+        .def("snapshot", &EngineHost::snapshot)
+        .def("load_from_file", &EngineHost::loadFromFile, "path"_a)
+        // replay logging is out of scope: accepted, message like the reference's when disabled
+        .def("set_replay_file", [](EngineHost &, const std::string &) {
+            std::cerr << "saveReplay is not set to true in config file!" << std::endl; }, "replay_file"_a)
+        .def("set_save_replay", [](EngineHost &, bool) {
+            std::cerr << "saveReplay is not set to true in config file!" << std::endl; }, "open"_a)
         // ---- array API (index order == lane_ids() / intersection_ids()) ----
         .def("lane_ids", &EngineHost::laneIds)
         .def("intersection_ids", &EngineHost::intersectionIds)
@@ -228,6 +240,10 @@ PYBIND11_MODULE(_cityflow, m) {
                  return ids;
              })
         .def("_flat_net", [](EngineHost &e) { return flatNetToDict(e.net()); });
+
+    py::class_<cfa::Archive>(m, "Archive")
+        .def(py::init([](EngineHost &e) { return e.snapshot(); }), "engine"_a)
+        .def("dump", &cfa::Archive::dump, "path"_a);
 
     m.def("_load_roadnet", &loadRoadnet, "path"_a);
     m.def("_roadnet_probe", &roadnetProbe, "path"_a);

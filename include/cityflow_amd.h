@@ -181,6 +181,44 @@ int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first_vid, int32_t n, uint
 /* vids still sitting in lanes' waiting buffers, lane by lane, FIFO order; returns count via *n */
 int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *lane, int32_t *n);
 
+/* Vehicle::setCustomSpeed (vehicle.h:128-131, used by getCarFollowSpeed vehicle.cpp:214,220-221): overrides
+ * the car-following target for the vehicle's next step only (Vehicle::update clears it, vehicle.cpp:120-122). */
+int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed);
+/* Switch a waiting or running vehicle to route `route` (already added with cfx_add_routes) whose first road is the
+ * road the vehicle is on; Router::iCurRoad restarts at 0 (Router::setRoute router.cpp:245-264 after its checks,
+ * which the host performs). */
+int32_t cfx_set_vehicle_route(cfx_engine *e, int32_t vid, int32_t route);
+/* state: 0 waiting, 1 running, 2 finished; drivable / route_pos / route are -1 unless running (route: any state) */
+int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *drivable, int32_t *route_pos,
+                        int32_t *route);
+
+/* Complete dynamic state, for Archive-style snapshot / restore (reference src/engine/archive.cpp:9-126).
+ * Reading it back is done with the getters above; cfx_load_state replaces the engine's whole dynamic state
+ * (templates and routes referenced by it must already have been added). */
+typedef struct cfx_state {
+    int64_t step, finished_vehicle_count, vehicle_steps;
+    double cumulative_travel_time;
+    /* vehicle table, index = vid */
+    int32_t n_vehicles;
+    const int32_t *v_priority, *v_templ, *v_route;
+    const double *v_enter_time;
+    const uint8_t *v_state;          /* 0 waiting, 1 running, 2 finished */
+    /* running vehicles in Drivable::vehicles order: by drivable, front to back */
+    int32_t n_running;
+    const int32_t *r_vid, *r_drivable, *r_prev_drivable, *r_blocker_vid, *r_enter_ll_time, *r_route_pos;
+    const double *r_dis, *r_speed;
+    const double *r_custom_speed;    /* NaN where no custom speed is pending; may be NULL */
+    /* waiting buffers, lane by lane, FIFO order */
+    int32_t n_waiting;
+    const int32_t *w_vid, *w_lane;
+    /* traffic lights [n_inters] */
+    const int32_t *tl_phase;
+    const double *tl_remain;
+} cfx_state;
+int32_t cfx_load_state(cfx_engine *e, const cfx_state *s);
+/* pending custom speeds of the running vehicles, same order as cfx_get_vehicles (NaN = none) */
+int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out);
+
 /* Optional per-kernel timing with HIP events recorded on the engine's own stream (bench.py roofline).
  * Kernel ids are dense 0..cfx_profile_kernel_count()-1; cfx_profile_read() synchronises, adds the
  * elapsed time of every bracketed launch since the last read into total_ms[] / launches[] and clears. */

@@ -42,6 +42,8 @@ struct Veh {  // Vehicle (vehicle.h:48-112) minus strings / lane change
     int32_t enterLLTime = INT_MAX;
     int32_t routePos = 0;  // Router::iCurRoad
     bool running = false, finished = false;
+    bool customSet = false;  // Buffer::isCustomSpeedSet / customSpeed (vehicle.h:62,66)
+    double customSpeed = 0;
     // Buffer vehicle.h:54-72
     bool bEndSet = false, bDrvSet = false, bBlockerSet = false, bEnterSet = false;
     double bDis = 0, bSpeed = 0;
@@ -122,12 +124,13 @@ struct cfx_engine {
         return min2(v1, v2);
     }
 
-    // Vehicle::getCarFollowSpeed vehicle.cpp:212-238 (customSpeed: not yet in the ABI)
+    // Vehicle::getCarFollowSpeed vehicle.cpp:212-238
     double carFollowSpeed(const Veh &v, double interval) const {
-        if (v.leader < 0) return T(v).max_speed;
+        if (v.leader < 0) return v.customSet ? v.customSpeed : T(v).max_speed;
         const Veh &ld = veh[v.leader];
         const cfx_vehicle_template &t = T(v), &tl = T(ld);
         double s = noCollisionSpeed(ld.speed, tl.max_neg_acc, v.speed, t.max_neg_acc, v.gap, interval, 0);
+        if (v.customSet) return min2(v.customSpeed, s);
         double assumeDecel = 0, leaderSpeed = ld.speed;
         if (v.speed > leaderSpeed) assumeDecel = v.speed - leaderSpeed;
         s = min2(s, noCollisionSpeed(ld.speed, tl.usual_neg_acc, v.speed, t.usual_neg_acc, v.gap, interval, t.min_gap));
@@ -550,6 +553,7 @@ struct cfx_engine {
             }
             v.blocker = v.bBlockerSet ? v.bBlocker : -1;
             v.bBlockerSet = false;
+            v.customSet = false;  // vehicle.cpp:120-122
         }
 
         // threadUpdateLeaderAndGap engine.cpp:429-442 (lane history is dead state)
@@ -782,6 +786,103 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
             ++i;
         }
     *n = i;
+    return CFX_OK;
+}
+
+int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
+    if (vid < 0 || vid >= (int32_t) e->veh.size() || e->veh[vid].finished) {
+        e->err = "cfx_set_vehicle_speed: no such live vehicle";
+        return CFX_ERR_INVALID;
+    }
+    e->veh[vid].customSpeed = speed;  // Vehicle::setCustomSpeed vehicle.h:128-131
+    e->veh[vid].customSet = true;
+    return CFX_OK;
+}
+
+int32_t cfx_set_vehicle_route(cfx_engine *e, int32_t vid, int32_t route) {
+    if (vid < 0 || vid >= (int32_t) e->veh.size() || e->veh[vid].finished || route < 0 ||
+        route + 1 >= (int32_t) e->routeStart.size()) {
+        e->err = "cfx_set_vehicle_route: bad vehicle or route";
+        return CFX_ERR_INVALID;
+    }
+    e->veh[vid].route = route;  // Router::setRoute router.cpp:245-255: new route, iCurRoad = begin, planned cleared
+    e->veh[vid].routePos = 0;
+    return CFX_OK;
+}
+
+int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *drivable, int32_t *routePos, int32_t *route) {
+    if (vid < 0 || vid >= (int32_t) e->veh.size()) {
+        e->err = "cfx_get_vehicle: vid out of range";
+        return CFX_ERR_INVALID;
+    }
+    const Veh &v = e->veh[vid];
+    int st = v.finished ? 2 : (v.running ? 1 : 0);
+    if (state) *state = st;
+    if (drivable) *drivable = st == 1 ? v.drivable : -1;
+    if (routePos) *routePos = st == 1 ? v.routePos : -1;
+    if (route) *route = v.route;
+    return CFX_OK;
+}
+
+int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {
+    int i = 0;
+    for (auto &list : e->order)
+        for (int32_t vid : list) {
+            if (i >= capacity) return CFX_ERR_CAPACITY;
+            out[i++] = e->veh[vid].customSet ? e->veh[vid].customSpeed : NAN;
+        }
+    return CFX_OK;
+}
+
+// Archive::resume (archive.cpp:73-126) on the flat state
+int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
+    e->resetState();
+    e->step = s->step;
+    e->finishedCnt = s->finished_vehicle_count;
+    e->vehicleSteps = s->vehicle_steps;
+    e->cumulativeTravelTime = s->cumulative_travel_time;
+    e->veh.resize(s->n_vehicles);
+    for (int v = 0; v < s->n_vehicles; ++v) {
+        Veh &x = e->veh[v];
+        x = Veh();
+        x.priority = s->v_priority[v];
+        x.templ = s->v_templ[v];
+        x.route = s->v_route[v];
+        x.enterTime = s->v_enter_time[v];
+        x.running = s->v_state[v] == 1;
+        x.finished = s->v_state[v] == 2;
+    }
+    for (int i = 0; i < s->n_running; ++i) {
+        Veh &x = e->veh[s->r_vid[i]];
+        x.drivable = s->r_drivable[i];
+        x.prevDrivable = s->r_prev_drivable[i];
+        x.blocker = s->r_blocker_vid[i];
+        x.enterLLTime = s->r_enter_ll_time[i];
+        x.routePos = s->r_route_pos[i];
+        x.dis = s->r_dis[i];
+        x.speed = s->r_speed[i];
+        if (s->r_custom_speed && s->r_custom_speed[i] == s->r_custom_speed[i]) {
+            x.customSet = true;
+            x.customSpeed = s->r_custom_speed[i];
+        }
+        e->order[x.drivable].push_back(s->r_vid[i]);
+        e->active += 1;
+    }
+    for (int i = 0; i < s->n_waiting; ++i) {
+        e->veh[s->w_vid[i]].drivable = s->w_lane[i];
+        e->waiting[s->w_lane[i]].push_back(s->w_vid[i]);
+    }
+    for (int i = 0; i < e->net.I; ++i) {
+        e->curPhase[i] = s->tl_phase[i];
+        e->remain[i] = s->tl_remain[i];
+    }
+    for (auto &list : e->order) {  // leader / gap are a function of the order (engine.cpp:429-442)
+        int leader = -1;
+        for (int32_t vid : list) {
+            e->updateLeaderAndGap(e->veh[vid], leader);
+            leader = vid;
+        }
+    }
     return CFX_OK;
 }
 

@@ -1,0 +1,133 @@
+"""CPU: Archive (snapshot / load / dump / load_from_file), set_vehicle_speed, set_vehicle_route on the host + CPU twin,
+mirroring the reference's tests/python/test_archive.py and checked live against the unmodified reference engine.
+The same scenarios run on the HIP engine in tests/test_hip_api.py (-m gpu)."""
+import os
+import time
+
+import pytest
+
+from conftest import TWIN_LIB, checkpoint_record
+
+
+def make(mod, cfg):
+    return mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+
+
+def run(e, n):
+    for _ in range(n):
+        e.next_step()
+
+
+def record(e):  # reference tests/python/test_archive.py:25-27
+    return e.get_lane_vehicle_count(), e.get_average_travel_time()
+
+
+def archive_roundtrips(mod, make_engine, cfg, tmp_path):
+    period = 100
+    # test_save_and_load (test_archive.py:29-49)
+    e = make_engine(cfg)
+    run(e, period)
+    a = e.snapshot()
+    run(e, period)
+    rec0 = record(e)
+    full0 = checkpoint_record(e)
+    e.load(a)
+    run(e, period)
+    assert record(e) == rec0 and checkpoint_record(e) == full0
+    # test_multi_save_and_multi_load (test_archive.py:80-96)
+    e = make_engine(cfg)
+    archives, records = [], []
+    for _ in range(4):
+        archives.append(mod.Archive(e))
+        records.append(record(e))
+        run(e, period)
+    for j in (2, 0, 1):
+        e.load(archives[j])
+        run(e, period)
+        assert record(e) == records[j + 1]
+    # test_save_to_file (test_archive.py:98-107)
+    e = make_engine(cfg)
+    run(e, period)
+    path = str(tmp_path / "save.json")
+    e.snapshot().dump(path)
+    run(e, period)
+    rec = checkpoint_record(e)
+    e.load_from_file(path)
+    run(e, period)
+    assert checkpoint_record(e) == rec
+
+
+def test_archive_roundtrips_twin(mod, scen, workdir, tmp_path):
+    archive_roundtrips(mod, lambda c: make(mod, c), scen.materialize("example_1x1", workdir), tmp_path)
+
+
+def test_archive_json_is_interchangeable_with_reference(mod, ref_module, scen, workdir, tmp_path):
+    """A dump written here loads into the reference engine and vice versa; both continue identically."""
+    cfg = scen.materialize("example_1x1", workdir)
+    ours, ref = make(mod, cfg), ref_module.Engine(cfg, 1)
+    run(ours, 150)
+    run(ref, 150)
+    p_ours, p_ref = str(tmp_path / "ours.json"), str(tmp_path / "ref.json")
+    ours.snapshot().dump(p_ours)
+    ref.snapshot().dump(p_ref)
+    # continue both to get the expected future
+    run(ours, 120)
+    run(ref, 120)
+    want = checkpoint_record(ref)
+    assert checkpoint_record(ours) == want
+    # cross-load
+    ours2, ref2 = make(mod, cfg), ref_module.Engine(cfg, 1)
+    ours2.load_from_file(p_ref)
+    ref2.load_from_file(p_ours)
+    assert ours2.get_current_time() == 150.0 and ref2.get_current_time() == 150.0
+    assert ours2.get_lane_vehicle_count() == ref2.get_lane_vehicle_count()
+    run(ours2, 120)
+    run(ref2, 120)
+    assert checkpoint_record(ours2) == want
+    assert checkpoint_record(ref2) == want
+    time.sleep(0.1)
+
+
+def control_script(e, steps=160):
+    """Same calls on any engine with the reference API; returns per-step observations."""
+    out = []
+    for s in range(steps):
+        if s == 40:
+            ids = sorted(e.get_vehicles())
+            for vid in ids[:5]:
+                e.set_vehicle_speed(vid, 3.0)
+        if s in (41, 42, 60):
+            for vid in sorted(e.get_vehicles())[:3]:
+                e.set_vehicle_speed(vid, 0.5)
+        if s == 80:
+            # reroute vehicles that are on road_0_1_0 (lane) towards road_1_1_1 instead of their flow's exit
+            changed = []
+            for vid in sorted(e.get_vehicles(True)):
+                info = e.get_vehicle_info(vid)
+                ok = e.set_vehicle_route(vid, ["road_1_1_1"]) if info.get("road") == "road_0_1_0" else None
+                changed.append((vid, ok))
+            out.append(("route", changed))
+        e.next_step()
+        out.append((e.get_lane_vehicle_count(), e.get_vehicle_speed() if s % 5 == 0 else None))
+    out.append(checkpoint_record(e))
+    return out
+
+
+def test_set_vehicle_speed_and_route_match_reference(mod, ref_module, scen, workdir):
+    cfg = scen.materialize("example_1x1", workdir)
+    a = control_script(make(mod, cfg))
+    ref = ref_module.Engine(cfg, 1)
+    b = control_script(ref)
+    assert a == b
+    time.sleep(0.1)
+
+
+def test_unknown_vehicle_errors(mod, scen, workdir):
+    e = make(mod, scen.materialize("example_1x1", workdir))
+    run(e, 5)
+    with pytest.raises(RuntimeError, match="not found"):
+        e.set_vehicle_speed("flow_99_0", 1.0)
+    with pytest.raises(RuntimeError, match="not found"):
+        e.get_leader("nope")
+    assert e.set_vehicle_route("flow_99_0", ["road_1_1_1"]) is False
+    assert e.set_vehicle_route("flow_0_0", ["no_such_road"]) is False

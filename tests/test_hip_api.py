@@ -1,0 +1,65 @@
+"""GPU (-m gpu): Archive and the control calls on the HIP engine — same scenarios as tests/test_archive_and_control.py."""
+import time
+
+import pytest
+
+from conftest import TWIN_LIB, assert_same_state, checkpoint_record
+from test_archive_and_control import archive_roundtrips, control_script, run
+
+pytestmark = pytest.mark.gpu
+
+
+def test_archive_roundtrips_hip(mod, scen, workdir, tmp_path):
+    archive_roundtrips(mod, lambda c: mod.Engine(c, 1), scen.materialize("example_1x1", workdir), tmp_path)
+
+
+def test_archive_roundtrip_hip_grid(mod, scen, workdir, tmp_path):
+    """snapshot mid-run on the 6x6 grid, restore into the HIP engine and into the twin: all three futures agree."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    hip = mod.Engine(cfg, 1)
+    run(hip, 300)
+    a = hip.snapshot()
+    path = str(tmp_path / "grid.json")
+    a.dump(path)
+    run(hip, 200)
+    want = checkpoint_record(hip)
+    hip.load(a)
+    tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    tw.load_from_file(path)
+    assert_same_state(hip, tw, "after restore")
+    for s in range(200):
+        hip.next_step()
+        tw.next_step()
+        if s % 20 == 19:
+            assert_same_state(hip, tw, "restored step %d" % (s + 1))
+    assert checkpoint_record(hip) == want
+
+
+def test_control_calls_hip_equals_twin_and_reference(mod, scen, workdir):
+    cfg = scen.materialize("example_1x1", workdir)
+    a = control_script(mod.Engine(cfg, 1))
+    b = control_script(mod.Engine._with_backend(cfg, 1, TWIN_LIB))
+    assert a == b
+
+
+def test_control_calls_hip_equals_reference(mod, ref_module, scen, workdir):
+    cfg = scen.materialize("example_1x1", workdir)
+    a = control_script(mod.Engine(cfg, 1))
+    b = control_script(ref_module.Engine(cfg, 1))
+    assert a == b
+    time.sleep(0.1)
+
+
+def test_reference_dump_loads_into_hip(mod, ref_module, scen, workdir, tmp_path):
+    cfg = scen.materialize("example_1x1", workdir)
+    ref = ref_module.Engine(cfg, 1)
+    run(ref, 200)
+    path = str(tmp_path / "ref.json")
+    ref.snapshot().dump(path)
+    run(ref, 150)
+    want = checkpoint_record(ref)
+    hip = mod.Engine(cfg, 1)
+    hip.load_from_file(path)
+    run(hip, 150)
+    assert checkpoint_record(hip) == want
+    time.sleep(0.1)
