@@ -100,6 +100,7 @@ struct cfx_engine {
 
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
+    int64_t finishedOffset = 0; // finished vehicles that are not in the vid table (state loaded from an archive)
 
     // ---- optional per-kernel timing (HIP events on this engine's stream) ----
     bool profiling = false;
@@ -289,6 +290,7 @@ struct cfx_engine {
         step = 0;
         spawned = 0;
         finishedKnown = 0;
+        finishedOffset = 0;
         hipLaunchKernelGGL(k_init_layout, dim3(gridFor(D + 1)), dim3(kBlock), 0, stream, D, L, segStart[0].p, cnt[0].p,
                            gen[0].vid, gen[0].drv);
         hipLaunchKernelGGL(k_init_lights, dim3(gridFor(I)), dim3(kBlock), 0, stream, net, curPhase, remain);
@@ -499,11 +501,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->spawned += n;
     }
     // ---- slot capacity: live vehicles <= spawned - finished; plus one spare per lane
-    size_t need = (size_t) (e->spawned - e->finishedKnown) + (size_t) e->L + 1;
+    size_t need = (size_t) (e->spawned - (e->finishedKnown - e->finishedOffset)) + (size_t) e->L + 1;
     if (need > e->slotCap) {
         DevScalars s;
         if ((rc = e->readScalars(s))) return rc;  // refresh finishedKnown
-        need = (size_t) (e->spawned - e->finishedKnown) + (size_t) e->L + 1;
+        need = (size_t) (e->spawned - (e->finishedKnown - e->finishedOffset)) + (size_t) e->L + 1;
         if ((rc = e->ensureSlotCap(need))) return rc;
     }
 
@@ -915,6 +917,11 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     e->step = s->step;
     e->spawned = nV;
     e->finishedKnown = s->finished_vehicle_count;
+    {
+        int64_t inTable = 0;
+        for (int v = 0; v < nV; ++v) inTable += s->v_state[v] == 2;
+        e->finishedOffset = s->finished_vehicle_count - inTable;
+    }
     // cached next drivable of every slot (uses the device copies of the route tables)
     hipLaunchKernelGGL(k_refresh_next, dim3(gridStride(std::max(S, 1))), dim3(kBlock), 0, e->stream, e->ctx());
     HIP_TRY(hipGetLastError());

@@ -26,13 +26,22 @@ def test_archive_roundtrip_hip_grid(mod, scen, workdir, tmp_path):
     hip.load(a)
     tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
     tw.load_from_file(path)
-    assert_same_state(hip, tw, "after restore")
+    # load_from_file renumbers vids (dense over the live vehicles), so compare through the id-keyed API
+    def same(where):
+        assert hip.get_lane_vehicles() == tw.get_lane_vehicles(), where
+        assert hip.get_vehicle_speed() == tw.get_vehicle_speed(), where
+        assert hip.get_vehicle_distance() == tw.get_vehicle_distance(), where
+        assert hip.get_vehicles(True) == tw.get_vehicles(True), where
+        assert hip.get_average_travel_time() == tw.get_average_travel_time(), where
+
+    same("after restore")
     for s in range(200):
         hip.next_step()
         tw.next_step()
         if s % 20 == 19:
-            assert_same_state(hip, tw, "restored step %d" % (s + 1))
+            same("restored step %d" % (s + 1))
     assert checkpoint_record(hip) == want
+    assert checkpoint_record(tw) == want
 
 
 def test_control_calls_hip_equals_twin_and_reference(mod, scen, workdir):
