@@ -17,8 +17,9 @@ sum over ranks of vehicle-steps divided by the slowest rank's time.
 Output: ONE JSON line on rank 0 (see README of the task contract) with two extra objects:
   roofline      car-following kernel (k_action): algorithmic bytes (48 B per running vehicle)
                 / average launch duration measured with HIP events on the engine's stream
-  cpu_baseline  the unmodified reference engine (oracle/_ref, prebuilt) timed on this box's host cores on a
-                bounded sample of the same workload (falls back to the CPU twin, kind "port")
+  cpu_baseline  the unmodified reference engine (oracle/_ref, prebuilt) timed on this box's host cores for a bounded
+                number of steps starting from the very state the GPU run had at the start of its timed region
+                (injected through the reference's Archive JSON); falls back to the CPU twin (kind "port")
 """
 import argparse
 import json
@@ -38,22 +39,24 @@ EXTRA_INTERVAL = 6.0
 EXTRA_END = 240
 
 
-def build_workload(workdir, seed):
+def build_workload(workdir, seed, scenario="grid_30x30", n_extra=N_EXTRA_FLOWS):
     from cityflow_amd import scenarios
-    base = scenarios.materialize("grid_30x30", workdir)
+    base = scenarios.materialize(scenario, workdir)
     d = os.path.dirname(base)
-    flow = os.path.join(d, "flow_bench.json")
+    flow = os.path.join(d, "flow_bench_%d.json" % n_extra)
     if not os.path.exists(flow):
-        scenarios.dense_flows(os.path.join(d, "roadnet.json"), flow, N_EXTRA_FLOWS, seed=12345, interval=EXTRA_INTERVAL,
+        scenarios.dense_flows(os.path.join(d, "roadnet.json"), flow, n_extra, seed=12345, interval=EXTRA_INTERVAL,
                               base_flow=os.path.join(d, "flow.json"), end_time=EXTRA_END)
-    return scenarios.materialize("grid_30x30", workdir, flow_file=flow, seed=seed)
+    return scenarios.materialize(scenario, workdir, flow_file=flow, seed=seed)
 
 
-def cpu_baseline(cfg, budget_s, threads):
-    """Reference engine on the host cores, from step 0 of the same workload, for ~budget_s seconds."""
+def cpu_baseline(cfg, budget_s, threads, state_dump):
+    """The unmodified reference engine (oracle/_ref) on the host cores, started from EXACTLY the state the GPU engine
+    had when its timed region began: that state is injected through the reference's own Archive JSON format
+    (Engine.load_from_file, reference src/engine/archive.cpp:345-550).  Falls back to the CPU twin ("port")."""
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     sys.path.insert(0, ref_dir)
-    kind, eng = "reference", None
+    kind = "reference"
     try:
         import cityflow_ref
         eng = cityflow_ref.Engine(cfg, threads)
@@ -61,13 +64,17 @@ def cpu_baseline(cfg, budget_s, threads):
         from cityflow_amd import _cityflow
         kind, threads = "port", 1
         eng = _cityflow.Engine._with_backend(cfg, 1, os.path.join(ref_dir, "libcfx_twin.so"))
+    t_load = time.perf_counter()
+    eng.load_from_file(state_dump)
+    t_load = time.perf_counter() - t_load
+    start_running = eng.get_vehicle_count()
     veh_steps, steps = 0, 0
     t0 = time.perf_counter()
     while True:
+        veh_steps += eng.get_vehicle_count()  # vehicles that take the coming step (admissions aside)
         eng.next_step()
         steps += 1
-        veh_steps += eng.get_vehicle_count()
-        if steps % 5 == 0 and time.perf_counter() - t0 > budget_s:
+        if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     running = eng.get_vehicle_count()
@@ -76,8 +83,9 @@ def cpu_baseline(cfg, budget_s, threads):
     return {
         "value": veh_steps / dt, "unit": "vehicle-steps/s", "cores": threads, "kind": kind,
         "steps_per_sec": steps / dt,
-        "sample": "steps 0..%d of the same workload (%d running vehicles at the end), %.1f s of wall time, "
-                  "%d thread(s) of %d host cores" % (steps, running, dt, threads, os.cpu_count() or 1),
+        "sample": "%d steps from the GPU run's own state at the start of its timed region (%d -> %d running vehicles, "
+                  "injected via Archive JSON, load %.1f s untimed), %.1f s of wall time, %d thread(s) of %d host cores"
+                  % (steps, start_running, running, t_load, dt, threads, os.cpu_count() or 1),
     }
 
 
@@ -89,7 +97,13 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=100, help="instrumented steps for the roofline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="reference thread_num (default min(8, host cores))")
+    # test hooks (tests/test_distributed.py drives the N>1 code path on CPU with gloo and the CPU twin)
+    ap.add_argument("--scenario", default="grid_30x30", help=argparse.SUPPRESS)
+    ap.add_argument("--extra-flows", type=int, default=N_EXTRA_FLOWS, help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--backend-lib", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    on_gpu = args.backend_lib == ""
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,8 +112,11 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=args.dist_backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     def barrier():
         if dist is not None:
@@ -108,14 +125,21 @@ def main():
     from cityflow_amd import _cityflow
 
     workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_rank%d" % rank)
-    cfg = build_workload(workdir, seed=rank)
-    eng = _cityflow.Engine(cfg, 1)  # HIP engine on device LOCAL_RANK; raises if the extension/GPU is missing
-    assert eng.backend_name() == "hip-gfx950"
+    cfg = build_workload(workdir, seed=rank, scenario=args.scenario, n_extra=args.extra_flows)
+    if on_gpu:
+        eng = _cityflow.Engine(cfg, 1)  # HIP engine on device LOCAL_RANK; raises if the extension/GPU is missing
+        assert eng.backend_name() == "hip-gfx950"
+    else:
+        eng = _cityflow.Engine._with_backend(cfg, 1, args.backend_lib)
 
     for _ in range(args.warmup):
         eng.next_step()
     eng.sync()
     sc0 = eng._scalars()
+    state_dump = None
+    if rank == 0 and args.cpu_seconds > 0:
+        state_dump = os.path.join(workdir, "state_at_timed_region.json")
+        eng.snapshot().dump(state_dump)
 
     barrier()
     eng.sync()
@@ -130,16 +154,17 @@ def main():
 
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = "cuda" if on_gpu else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        v = torch.tensor([float(veh_steps)], dtype=torch.float64, device="cuda")
+        v = torch.tensor([float(veh_steps)], dtype=torch.float64, device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         veh_steps = int(v.item())
 
     # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream)
     roofline = None
-    if rank == 0:
+    if rank == 0 and on_gpu:
         scp0 = eng._scalars()
         eng._profile_enable(True)
         for _ in range(args.profile_steps):
@@ -167,19 +192,19 @@ def main():
         cpu = None
         if args.cpu_seconds > 0:
             threads = args.cpu_threads or min(8, os.cpu_count() or 1)
-            cpu = cpu_baseline(cfg, args.cpu_seconds, threads)
+            cpu = cpu_baseline(cfg, args.cpu_seconds, threads, state_dump)
         out = {
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "steps_per_sec": args.steps * world / elapsed,
             "config": {
-                "workload": "30x30 grid (reference generator, --tlPlan, interval 1.0) + %d seeded interior flows "
+                "workload": "%s (reference generator, --tlPlan, interval 1.0) + %d seeded interior flows "
                             "(1 veh / %.0f s each until t=%d s); %s" % (
-                                N_EXTRA_FLOWS, EXTRA_INTERVAL, EXTRA_END,
+                                args.scenario, args.extra_flows, EXTRA_INTERVAL, EXTRA_END,
                                 "one replica per GPU" if world > 1 else "single engine"),
                 "running_vehicles_start": sc0["active_vehicle_count"], "running_vehicles_end": sc1["active_vehicle_count"],
-                "lanes": 11160, "lanelinks": 32400, "parallelism": "replica x%d" % world if world > 1 else "1 gpu",
+                "lanes": len(eng.lane_ids()), "parallelism": "replica x%d" % world if world > 1 else "1 gpu",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -1,0 +1,36 @@
+"""CPU: the N>1 path of bench.py (one process per device, barrier + max-over-ranks timing, whole-job value) with
+world_size 2 on gloo and the CPU twin standing in for the device engine."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT, TWIN_LIB
+
+
+def test_bench_two_ranks_gloo(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "30",
+           "--cpu-seconds", "0", "--scenario", "grid_6x6", "--extra-flows", "50", "--dist-backend", "gloo",
+           "--backend-lib", TWIN_LIB]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 30 and d["scaling"] == "weak"
+    assert d["metric"] == "vehicle_steps_per_sec" and d["unit"] == "vehicle-steps/s" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
+    # whole-job aggregate: two replicas => about twice the per-replica vehicle-steps of one step count
+    assert d["config"]["parallelism"] == "replica x2"
+
+
+def test_bench_single_rank_twin(tmp_path):
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "10", "--cpu-seconds", "0",
+           "--scenario", "grid_6x6", "--extra-flows", "20", "--backend-lib", TWIN_LIB]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["roofline"] is None and d["cpu_baseline"] is None
