@@ -15,6 +15,7 @@ except ImportError as exc:  # pragma: no cover - exercised only on unbuilt trees
 
 Engine = _cityflow.Engine
 Archive = _cityflow.Archive
+VectorEngine = _cityflow.VectorEngine
 __version__ = _cityflow.__version__
 
-__all__ = ["Engine", "Archive", "__version__"]
+__all__ = ["Engine", "Archive", "VectorEngine", "__version__"]

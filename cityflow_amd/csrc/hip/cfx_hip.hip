@@ -491,13 +491,13 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->stageIdx = (si + 1) % cfx_engine::kStages;
         if (e->stageBusy[si]) HIP_TRY(hipEventSynchronize(e->stageEvent[si]));
         memcpy(e->hStage[si], recs, (size_t) n * sizeof(cfx_spawn));
-        HIP_TRY(hipMemcpyAsync(e->dRecs, e->hStage[si], (size_t) n * sizeof(cfx_spawn), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipEventRecord(e->stageEvent[si], st));
-        e->stageBusy[si] = true;
+        // the kernel reads the pinned (device-visible) staging buffer itself: no separate copy launch
         { int pp__ = e->profBegin(PK_SPAWN);
-        hipLaunchKernelGGL(k_spawn_link, dim3(gridFor(n)), dim3(kBlock), 0, st, e->dRecs, n, (int) e->spawned, e->vt,
+        hipLaunchKernelGGL(k_spawn_link, dim3(gridFor(n)), dim3(kBlock), 0, st, e->hStage[si], n, (int) e->spawned, e->vt,
                            e->waitHead);
         e->profEnd(pp__); }
+        HIP_TRY(hipEventRecord(e->stageEvent[si], st));
+        e->stageBusy[si] = true;
         e->spawned += n;
     }
     // ---- slot capacity: live vehicles <= spawned - finished; plus one spare per lane
@@ -531,12 +531,13 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
                        e->scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
-                       e->gen[nxt].drv, c, e->vt, e->sc, e->finList, e->finSorted, (int) e->slotCap);
+                       e->gen[nxt].drv, e->sc);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords)))),
+    hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),
                        dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
-                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords, e->scanTicket);
+                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords, e->scanTicket, e->vt, e->sc, e->finList,
+                       e->finSorted, (int) e->slotCap);
     e->profEnd(pp__); }
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
@@ -573,6 +574,26 @@ int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
     HIP_TRY(hipSetDevice(e->device));
     // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream
     HIP_TRY(hipMemcpyAsync(e->curPhase + inter, &phase, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const int32_t *phases) {
+    if (!e || n < 0 || (n && (!inters || !phases))) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    // read-modify-write of the (small) phase vector on the host, one upload
+    std::vector<int32_t> cur((size_t) e->I);
+    HIP_TRY(hipMemcpyAsync(cur.data(), e->curPhase, (size_t) e->I * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n; ++i) {
+        if (inters[i] < 0 || inters[i] >= e->I || phases[i] < 0) {
+            e->err = "cfx_set_tl_phases: index out of range";
+            return CFX_ERR_INVALID;
+        }
+        cur[inters[i]] = phases[i];
+    }
+    HIP_TRY(hipMemcpyAsync(e->curPhase, cur.data(), (size_t) e->I * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return CFX_OK;
 }

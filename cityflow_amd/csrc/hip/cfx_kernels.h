@@ -8,9 +8,9 @@
 //   k_cross        phase 4 cont.  : Cross::canPass for the queued vehicles, one 16-lane group per vehicle and
 //                                   one cross per lane; the other half of threadNotifyCross (which vehicle a
 //                                   given cross sees) is resolved on demand, only where the peer laneLink is active
-//   k_scan         phase 5b       : new segment offsets (single-pass exclusive scan over drivables); finish statistics
+//   k_scan         phase 5b       : new segment offsets (single-pass exclusive scan over drivables)
 //   k_scatter      phase 5c/6/8   : stable compaction into the next generation = commit (Vehicle::update);
-//                                   TrafficLight::passTime
+//                                   TrafficLight::passTime; the step's finish statistics (one block)
 // Leader/gap (phase 7, engine.cpp:429-442) needs no kernel of its own: it is a pure function of the
 // post-compaction order and is evaluated at the top of the next step's k_action (see lastSlotForLeader).
 #pragma once
@@ -547,8 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_cross(StepCtx c, ActionOut o, const 
 // Tiles are handed out by a ticket (so every predecessor of a tile has started: no dispatch-order assumption);
 // each tile publishes its total as an 8-byte {epoch, value} granule written by one agent-scope store and
 // sums its predecessors' granules, polling with agent-scope loads until their tag equals this step's epoch
-// (MI355X guide, Guideline 16 form R2: the data is the flag).  Tile 0 additionally does the step's finish
-// statistics.
+// (MI355X guide, Guideline 16 form R2: the data is the flag).
 constexpr int kScanItems = 8;                       // drivables per thread
 constexpr int kScanTile = kBlock * kScanItems;      // drivables per tile
 constexpr int kFinLds = 2048;                       // finished vehicles per step staged in LDS
@@ -626,8 +625,7 @@ __device__ inline void finishStatistics(const StepCtx &c, const VidTable &vt, De
 __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cnt, CompactScratch cs,
                                                  unsigned long long *granules, int32_t *ticket, unsigned epoch,
                                                  int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
-                                                 int32_t *drvNext, StepCtx c, VidTable vt, DevScalars *sc,
-                                                 const int32_t *finList, int32_t *finSorted, int finCap) {
+                                                 int32_t *drvNext, DevScalars *sc) {
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
     __shared__ int tileShared;
@@ -701,7 +699,6 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
             if (d == D - 1) segStartNext[D] = off0;
         }
     }
-    if (tile == 0) finishStatistics(c, vt, sc, finList, finSorted, finCap);
 }
 
 // Phase 5c + 6: stable compaction into the next generation and commit of the buffered action
@@ -710,9 +707,16 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
 // lights (TrafficLight::passTime trafficlight.cpp:29-37) and clear the active-laneLink masks.
 __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
-                          int32_t *scanTicket) {
+                          int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, int32_t *finSorted,
+                          int finCap) {
+    // The launch carries one extra block that only does the step's finish statistics (it reads just the current
+    // generation and the finish list, both complete before this kernel starts), in parallel with the compaction.
+    if (blockIdx.x == gridDim.x - 1) {
+        finishStatistics(c, vt, sc, finList, finSorted, finCap);
+        return;
+    }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
+    const int stride = (gridDim.x - 1) * blockDim.x;
     if (gid == 0) *scanTicket = 0;  // k_scan of this step is done; re-arm it for the next one
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
     if (!rlTrafficLight) {

@@ -44,6 +44,7 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_sync)
     CFX_FN(cfx_reset)
     CFX_FN(cfx_set_tl_phase)
+    CFX_FN(cfx_set_tl_phases)
     CFX_FN(cfx_get_tl_state)
     CFX_FN(cfx_get_scalars)
     CFX_FN(cfx_get_lane_counts)
@@ -67,6 +68,25 @@ void Backend::open(const std::string &libPath) {
 
 Backend::~Backend() {
     if (handle) dlclose(handle);
+}
+
+EngineConfig readEngineConfig(const std::string &configFile) {
+    EngineConfig c;
+    try {
+        Json cfg = Json::parseFile(configFile);
+        if (!cfg.isObject()) throw JsonError("wrong format of config file");
+        c.interval = cfg.numberAt("interval");
+        c.rlTrafficLight = cfg.boolAt("rlTrafficLight");
+        c.laneChange = cfg.boolAt("laneChange", false);
+        c.seed = cfg.intAt("seed");
+        c.dir = cfg.stringAt("dir");
+        c.roadnetFile = cfg.stringAt("roadnetFile");
+        c.flowFile = cfg.stringAt("flowFile");
+        c.saveReplay = cfg.boolAt("saveReplay");
+    } catch (const JsonError &e) {
+        throw std::runtime_error(std::string("load config failed! ") + e.what());
+    }
+    return c;
 }
 
 // ---------------------------------------------------------------- construction

@@ -34,6 +34,7 @@ struct Backend {
     CFX_FN(cfx_sync)
     CFX_FN(cfx_reset)
     CFX_FN(cfx_set_tl_phase)
+    CFX_FN(cfx_set_tl_phases)
     CFX_FN(cfx_get_tl_state)
     CFX_FN(cfx_get_scalars)
     CFX_FN(cfx_get_lane_counts)
@@ -131,6 +132,14 @@ private:
     std::vector<cfx_spawn> spawnBuf_;
     std::map<std::string, int> manualIds_;  // manually_pushed_<n> -> vid
 };
+
+struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
+    double interval = 1.0;
+    bool rlTrafficLight = false, laneChange = false, saveReplay = false;
+    int seed = 0;
+    std::string dir, roadnetFile, flowFile;
+};
+EngineConfig readEngineConfig(const std::string &configFile);  // throws std::runtime_error("load config failed! ...")
 
 std::string defaultBackendPath();  // <dir of this shared object>/lib/libcfx_hip.so
 

@@ -8,6 +8,7 @@
 #include <iostream>
 
 #include "engine_host.h"
+#include "vector_engine.h"
 #include "json.h"
 
 namespace py = pybind11;
@@ -240,6 +241,59 @@ PYBIND11_MODULE(_cityflow, m) {
                  return ids;
              })
         .def("_flat_net", [](EngineHost &e) { return flatNetToDict(e.net()); });
+
+    using cfa::VectorEngineHost;
+    py::class_<VectorEngineHost>(m, "VectorEngine",
+                                 "num_envs independent copies of one scenario (env e uses seed + e) advanced in lock-step by "
+                                 "one device engine; observations and actions are arrays of shape [num_envs, ...].")
+        .def(py::init<const std::string &, int, int>(), "config_file"_a, "num_envs"_a, "thread_num"_a = 1)
+        .def_static(
+            "_with_backend",
+            [](const std::string &cfg, int envs, int threads, const std::string &lib) {
+                return std::unique_ptr<VectorEngineHost>(new VectorEngineHost(cfg, envs, threads, lib));
+            },
+            "config_file"_a, "num_envs"_a, "thread_num"_a, "backend_library"_a)
+        .def_property_readonly("num_envs", &VectorEngineHost::numEnvs)
+        .def("next_step", &VectorEngineHost::nextStep)
+        .def("reset", &VectorEngineHost::reset, "seed"_a = false)
+        .def("get_current_time", &VectorEngineHost::getCurrentTime)
+        .def("get_vehicle_count", &VectorEngineHost::totalVehicleCount)
+        .def("lane_ids", &VectorEngineHost::laneIds)
+        .def("intersection_ids", &VectorEngineHost::intersectionIds)
+        .def("get_lane_vehicle_count_array",
+             [](VectorEngineHost &e) {
+                 auto a = toArray(e.laneVehicleCounts());
+                 a.resize({(py::ssize_t) e.numEnvs(), (py::ssize_t) e.numLanes()});
+                 return a;
+             })
+        .def("get_lane_waiting_vehicle_count_array",
+             [](VectorEngineHost &e) {
+                 auto a = toArray(e.laneWaitingVehicleCounts());
+                 a.resize({(py::ssize_t) e.numEnvs(), (py::ssize_t) e.numLanes()});
+                 return a;
+             })
+        .def("set_tl_phases",
+             [](VectorEngineHost &e, py::array_t<int32_t, py::array::c_style | py::array::forcecast> phases) {
+                 std::vector<int32_t> v(phases.data(), phases.data() + phases.size());
+                 e.setTrafficLightPhases(v);
+             },
+             "phases"_a, "int array [num_envs, num_intersections] (entries of virtual intersections are ignored)")
+        .def("get_lane_vehicle_count", &VectorEngineHost::getLaneVehicleCount, "env"_a)
+        .def("get_vehicle_speed", &VectorEngineHost::getVehicleSpeed, "env"_a)
+        .def("sync", &VectorEngineHost::sync)
+        .def("backend_name", &VectorEngineHost::backendName)
+        .def("_profile_enable", &VectorEngineHost::profileEnable, "on"_a)
+        .def("_profile_read", &VectorEngineHost::profileRead)
+        .def("_scalars", [](VectorEngineHost &e) {
+            cfx_scalars s = e.scalars();
+            py::dict d;
+            d["step"] = s.step;
+            d["active_vehicle_count"] = s.active_vehicle_count;
+            d["finished_vehicle_count"] = s.finished_vehicle_count;
+            d["spawned_vehicle_count"] = s.spawned_vehicle_count;
+            d["vehicle_steps"] = s.vehicle_steps;
+            return d;
+        });
 
     py::class_<cfa::Archive>(m, "Archive")
         .def(py::init([](EngineHost &e) { return e.snapshot(); }), "engine"_a)

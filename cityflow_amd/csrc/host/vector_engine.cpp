@@ -1,0 +1,302 @@
+#include "vector_engine.h"
+
+#include <iostream>
+#include <stdexcept>
+
+namespace cfa {
+
+namespace {
+
+// R disjoint copies of a flat network, index spaces concatenated replica by replica.
+struct ReplicatedNet {
+    cfx_net flat{};
+    std::vector<double> drvLength, drvMaxSpeed, xDist, phaseTime;
+    std::vector<int32_t> laneRoad, laneIndex, laneLLStart, laneLL, roadLaneStart, llStartLane, llEndLane, llInter,
+        llRoadLink, llType, llXStart, xPeer, xLL, interVirtual, interNRL, interPhaseStart, interAvailStart;
+    std::vector<uint8_t> phaseAvail;
+
+    void build(const cfx_net &n, int R) {
+        const int L = n.n_lanes, K = n.n_lanelinks, Rd = n.n_roads, I = n.n_inters, E = n.n_xentries, P = n.n_phases,
+                  A = n.n_avail;
+        auto rep = [R](auto &dst, const auto *src, int count, int offsetPerReplica) {
+            dst.resize((size_t) count * R);
+            for (int r = 0; r < R; ++r)
+                for (int i = 0; i < count; ++i) dst[(size_t) r * count + i] = src[i] + offsetPerReplica * r;
+        };
+        // per drivable: all lanes of all replicas first, then all laneLinks
+        drvLength.resize((size_t) (L + K) * R);
+        drvMaxSpeed.resize((size_t) (L + K) * R);
+        for (int r = 0; r < R; ++r) {
+            for (int l = 0; l < L; ++l) {
+                drvLength[(size_t) r * L + l] = n.drv_length[l];
+                drvMaxSpeed[(size_t) r * L + l] = n.drv_max_speed[l];
+            }
+            for (int k = 0; k < K; ++k) {
+                drvLength[(size_t) R * L + (size_t) r * K + k] = n.drv_length[L + k];
+                drvMaxSpeed[(size_t) R * L + (size_t) r * K + k] = n.drv_max_speed[L + k];
+            }
+        }
+        rep(laneRoad, n.lane_road, L, Rd);
+        rep(laneIndex, n.lane_index, L, 0);
+        rep(laneLL, n.lane_ll, K, K);
+        rep(llStartLane, n.ll_start_lane, K, L);
+        rep(llEndLane, n.ll_end_lane, K, L);
+        rep(llInter, n.ll_inter, K, I);
+        rep(llRoadLink, n.ll_roadlink, K, 0);
+        rep(llType, n.ll_type, K, 0);
+        rep(xPeer, n.x_peer, E, E);
+        rep(xLL, n.x_ll, E, K);
+        rep(interVirtual, n.inter_virtual, I, 0);
+        rep(interNRL, n.inter_n_roadlinks, I, 0);
+        rep(interAvailStart, n.inter_avail_start, I, A);
+        xDist.resize((size_t) E * R);
+        phaseTime.resize((size_t) P * R);
+        phaseAvail.resize((size_t) A * R);
+        for (int r = 0; r < R; ++r) {
+            std::copy(n.x_dist, n.x_dist + E, xDist.begin() + (size_t) r * E);
+            std::copy(n.phase_time, n.phase_time + P, phaseTime.begin() + (size_t) r * P);
+            std::copy(n.phase_avail, n.phase_avail + A, phaseAvail.begin() + (size_t) r * A);
+        }
+        // CSR arrays: [count*R + 1]
+        auto repCsr = [R](std::vector<int32_t> &dst, const int32_t *src, int count) {
+            const int total = src[count];
+            dst.resize((size_t) count * R + 1);
+            for (int r = 0; r < R; ++r)
+                for (int i = 0; i < count; ++i) dst[(size_t) r * count + i] = src[i] + total * r;
+            dst[(size_t) count * R] = total * R;
+        };
+        repCsr(laneLLStart, n.lane_ll_start, L);
+        repCsr(roadLaneStart, n.road_lane_start, Rd);
+        repCsr(llXStart, n.ll_x_start, K);
+        repCsr(interPhaseStart, n.inter_phase_start, I);
+
+        flat = cfx_net{};
+        flat.n_roads = Rd * R;
+        flat.n_lanes = L * R;
+        flat.n_lanelinks = K * R;
+        flat.n_inters = I * R;
+        flat.n_xentries = E * R;
+        flat.n_phases = P * R;
+        flat.n_avail = A * R;
+        flat.drv_length = drvLength.data();
+        flat.drv_max_speed = drvMaxSpeed.data();
+        flat.lane_road = laneRoad.data();
+        flat.lane_index = laneIndex.data();
+        flat.lane_ll_start = laneLLStart.data();
+        flat.lane_ll = laneLL.data();
+        flat.road_lane_start = roadLaneStart.data();
+        flat.ll_start_lane = llStartLane.data();
+        flat.ll_end_lane = llEndLane.data();
+        flat.ll_inter = llInter.data();
+        flat.ll_roadlink = llRoadLink.data();
+        flat.ll_type = llType.data();
+        flat.ll_x_start = llXStart.data();
+        flat.x_dist = xDist.data();
+        flat.x_peer = xPeer.data();
+        flat.x_ll = xLL.data();
+        flat.inter_virtual = interVirtual.data();
+        flat.inter_n_roadlinks = interNRL.data();
+        flat.inter_phase_start = interPhaseStart.data();
+        flat.inter_avail_start = interAvailStart.data();
+        flat.phase_time = phaseTime.data();
+        flat.phase_avail = phaseAvail.data();
+    }
+};
+
+}  // namespace
+
+VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, int threadNum, const std::string &backendLib)
+    : R_(numEnvs) {
+    if (numEnvs < 1) throw std::runtime_error("VectorEngine: num_envs must be >= 1");
+    EngineConfig cfg = readEngineConfig(configFile);
+    if (cfg.laneChange) throw std::runtime_error("VectorEngine: laneChange=true is not implemented");
+    interval_ = cfg.interval;
+    rlTrafficLight_ = cfg.rlTrafficLight;
+    try {
+        net_->load(cfg.dir + cfg.roadnetFile);
+        for (int r = 0; r < R_; ++r) {
+            spawners_.emplace_back(new Spawner());
+            spawners_.back()->init(net_.get(), interval_, threadNum, cfg.seed + r);
+            spawners_.back()->loadFlows(cfg.dir + cfg.flowFile);
+        }
+    } catch (const std::exception &e) {
+        throw std::runtime_error(std::string("load config failed! ") + e.what());
+    }
+    L_ = (int) net_->lanes.size();
+    K_ = (int) net_->laneLinks.size();
+    I_ = (int) net_->inters.size();
+    localToGlobal_.resize(R_);
+
+    ReplicatedNet rn;
+    rn.build(net_->flat(), R_);
+    be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
+    cfx_config cc{};
+    cc.interval = interval_;
+    cc.rl_traffic_light = rlTrafficLight_ ? 1 : 0;
+    cc.device = 0;
+    if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);
+    if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) cc.device = atoi(dev);
+    int32_t rc = be_.cfx_create(&rn.flat, &cc, &dev_);
+    if (rc != CFX_OK || !dev_) {
+        const char *msg = be_.cfx_last_error(nullptr);
+        throw std::runtime_error(std::string("cityflow_amd: cfx_create failed in ") + be_.path + ": " +
+                                 (msg ? msg : "unknown error") + " (there is no CPU fallback)");
+    }
+    for (int r = 0; r < R_; ++r) {
+        Spawner *sp = spawners_[r].get();
+        sp->setFinishedQuery([this, r](int localVid) {
+            uint8_t st = 0;
+            check(be_.cfx_get_vehicle_status(dev_, localToGlobal_[r][localVid], 1, &st), "cfx_get_vehicle_status");
+            return st == 2;
+        });
+    }
+    // templates are shared; each environment gets its own copy of the route tables with shifted indices
+    const Spawner &s0 = *spawners_[0];
+    check(be_.cfx_add_templates(dev_, (int) s0.templates.size(), s0.templates.data()), "cfx_add_templates");
+    const RouteTable &rt = s0.routes;
+    routesPerEnv_ = rt.count();
+    const int Rd = (int) net_->roads.size();
+    for (int r = 0; r < R_; ++r) {
+        std::vector<int32_t> roads(rt.roads), nextLL(rt.nextLL);
+        for (auto &x : roads) x += r * Rd;
+        for (auto &x : nextLL)
+            if (x >= 0) x += r * K_;
+        check(be_.cfx_add_routes(dev_, routesPerEnv_, rt.routeStart.data(), roads.data(), rt.nextStart.data(), nextLL.data()),
+              "cfx_add_routes");
+    }
+}
+
+VectorEngineHost::~VectorEngineHost() {
+    if (dev_) be_.cfx_destroy(dev_);
+}
+
+void VectorEngineHost::check(int32_t rc, const char *what) {
+    if (rc == CFX_OK) return;
+    const char *msg = be_.cfx_last_error(dev_);
+    throw std::runtime_error(std::string("cityflow_amd: ") + what + " failed (" + std::to_string(rc) + "): " + (msg ? msg : ""));
+}
+
+void VectorEngineHost::nextStep() {
+    recs_.clear();
+    for (int r = 0; r < R_; ++r) {
+        Spawner &sp = *spawners_[r];
+        sp.step(step_, envRecs_);
+        if (sp.routes.count() != routesPerEnv_ || sp.templates.size() != spawners_[0]->templates.size())
+            throw std::runtime_error("VectorEngine: dynamic routes/templates are not supported");
+        for (cfx_spawn s : envRecs_) {
+            int32_t g = (int32_t) globalToLocal_.size();
+            localToGlobal_[r].push_back(g);  // local vids are dense per environment
+            globalToLocal_.emplace_back(r, s.vid);
+            s.vid = g;
+            s.lane += r * L_;
+            s.route += r * routesPerEnv_;
+            s.prev_wait = s.prev_wait >= 0 ? localToGlobal_[r][s.prev_wait] : -1;
+            recs_.push_back(s);
+        }
+    }
+    check(be_.cfx_step(dev_, recs_.data(), (int32_t) recs_.size()), "cfx_step");
+    step_ += 1;
+}
+
+void VectorEngineHost::reset(bool resetRnd) {
+    check(be_.cfx_reset(dev_), "cfx_reset");
+    for (auto &sp : spawners_) sp->reset(resetRnd);
+    for (auto &v : localToGlobal_) v.clear();
+    globalToLocal_.clear();
+    step_ = 0;
+}
+
+std::vector<int32_t> VectorEngineHost::laneVehicleCounts() {
+    std::vector<int32_t> out((size_t) R_ * L_);
+    check(be_.cfx_get_lane_counts(dev_, out.data()), "cfx_get_lane_counts");
+    return out;
+}
+
+std::vector<int32_t> VectorEngineHost::laneWaitingVehicleCounts() {
+    std::vector<int32_t> out((size_t) R_ * L_);
+    check(be_.cfx_get_lane_waiting_counts(dev_, out.data()), "cfx_get_lane_waiting_counts");
+    return out;
+}
+
+cfx_scalars VectorEngineHost::scalars() {
+    cfx_scalars s{};
+    check(be_.cfx_get_scalars(dev_, &s), "cfx_get_scalars");
+    return s;
+}
+
+int64_t VectorEngineHost::totalVehicleCount() { return scalars().active_vehicle_count; }
+
+void VectorEngineHost::sync() { check(be_.cfx_sync(dev_), "cfx_sync"); }
+
+void VectorEngineHost::profileEnable(bool on) { check(be_.cfx_profile_enable(dev_, on ? 1 : 0), "cfx_profile_enable"); }
+
+std::map<std::string, std::pair<double, int64_t>> VectorEngineHost::profileRead() {
+    int n = be_.cfx_profile_kernel_count();
+    std::vector<double> ms(n > 0 ? n : 1);
+    std::vector<int64_t> cnt(n > 0 ? n : 1);
+    check(be_.cfx_profile_read(dev_, ms.data(), cnt.data()), "cfx_profile_read");
+    std::map<std::string, std::pair<double, int64_t>> out;
+    for (int k = 0; k < n; ++k) out[be_.cfx_profile_kernel_name(k)] = std::make_pair(ms[k], cnt[k]);
+    return out;
+}
+
+void VectorEngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) {
+    if (!rlTrafficLight_) {
+        std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
+        return;
+    }
+    if ((int) phases.size() != R_ * I_) throw std::runtime_error("set_tl_phases: expected num_envs * num_intersections phases");
+    std::vector<int32_t> inters, ph;
+    for (int r = 0; r < R_; ++r)
+        for (int i = 0; i < I_; ++i) {
+            const HostInter &in = net_->inters[i];
+            if (in.isVirtual) continue;
+            int p = phases[(size_t) r * I_ + i];
+            if (p < 0 || p >= (int) in.phases.size())
+                throw std::out_of_range("set_tl_phases: phase out of range for intersection '" + in.id + "'");
+            inters.push_back(r * I_ + i);
+            ph.push_back(p);
+        }
+    check(be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data()), "cfx_set_tl_phases");
+}
+
+std::vector<std::string> VectorEngineHost::laneIds() const {
+    std::vector<std::string> ids(L_);
+    for (int l = 0; l < L_; ++l) ids[l] = net_->laneId(l);
+    return ids;
+}
+
+std::vector<std::string> VectorEngineHost::intersectionIds() const {
+    std::vector<std::string> ids(I_);
+    for (int i = 0; i < I_; ++i) ids[i] = net_->inters[i].id;
+    return ids;
+}
+
+std::map<std::string, int> VectorEngineHost::getLaneVehicleCount(int env) {
+    if (env < 0 || env >= R_) throw std::out_of_range("env index out of range");
+    std::vector<int32_t> all = laneVehicleCounts();
+    std::map<std::string, int> ret;
+    for (int l = 0; l < L_; ++l) ret.emplace(net_->laneId(l), all[(size_t) env * L_ + l]);
+    return ret;
+}
+
+std::map<std::string, double> VectorEngineHost::getVehicleSpeed(int env) {
+    if (env < 0 || env >= R_) throw std::out_of_range("env index out of range");
+    int cap = (int) scalars().active_vehicle_count + 16;
+    std::vector<int32_t> vid(cap), drv(cap);
+    std::vector<double> speed(cap);
+    cfx_vehicle_view v{};
+    v.capacity = cap;
+    v.vid = vid.data();
+    v.drivable = drv.data();
+    v.speed = speed.data();
+    check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
+    std::map<std::string, double> ret;
+    for (int i = 0; i < v.count; ++i) {
+        const auto &gl = globalToLocal_[vid[i]];
+        if (gl.first == env) ret.emplace(spawners_[env]->vehicleId(gl.second), speed[i]);
+    }
+    return ret;
+}
+
+}  // namespace cfa

@@ -1,0 +1,63 @@
+// VectorEngine: R independent copies ("environments") of one scenario advanced in lock-step by ONE device
+// engine.  The device sees a single road network made of R disjoint replicas (lane r*L+l, laneLink r*K+k, ...),
+// so every kernel launch of a step covers all environments: launch latency is paid once per step instead of
+// once per environment, and the car-following kernel finally gets enough vehicles per launch to approach the
+// HBM roofline.  Each environment has its own flows and its own std::mt19937 (seed + env index)
+// and evolves exactly like a standalone Engine built from the same config with that seed
+// (tests/test_vector_engine.py).
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine_host.h"
+
+namespace cfa {
+
+class VectorEngineHost {
+public:
+    VectorEngineHost(const std::string &configFile, int numEnvs, int threadNum, const std::string &backendLib = "");
+    ~VectorEngineHost();
+    VectorEngineHost(const VectorEngineHost &) = delete;
+    VectorEngineHost &operator=(const VectorEngineHost &) = delete;
+
+    int numEnvs() const { return R_; }
+    int numLanes() const { return L_; }
+    int numIntersections() const { return I_; }
+    void nextStep();
+    void reset(bool resetRnd);
+    double getCurrentTime() const { return step_ * interval_; }
+    std::vector<int32_t> laneVehicleCounts();         // [R * L], env-major
+    std::vector<int32_t> laneWaitingVehicleCounts();  // [R * L]
+    int64_t totalVehicleCount();
+    // phases: [R * I] (entries of virtual intersections are ignored); requires rlTrafficLight
+    void setTrafficLightPhases(const std::vector<int32_t> &phases);
+    std::vector<std::string> laneIds() const;
+    std::vector<std::string> intersectionIds() const;
+    cfx_scalars scalars();
+    void sync();
+    void profileEnable(bool on);
+    std::map<std::string, std::pair<double, int64_t>> profileRead();
+    std::string backendName() const { return be_.cfx_backend_name(); }
+    // per-environment id-keyed view, for parity tests against a standalone Engine
+    std::map<std::string, double> getVehicleSpeed(int env);
+    std::map<std::string, int> getLaneVehicleCount(int env);
+
+private:
+    void check(int32_t rc, const char *what);
+
+    std::shared_ptr<HostRoadNet> net_ = std::make_shared<HostRoadNet>();
+    std::vector<std::unique_ptr<Spawner>> spawners_;
+    std::vector<std::vector<int32_t>> localToGlobal_;  // [env][local vid] -> global vid
+    std::vector<std::pair<int32_t, int32_t>> globalToLocal_;  // global vid -> (env, local vid)
+    Backend be_;
+    cfx_engine *dev_ = nullptr;
+    int R_ = 1, L_ = 0, K_ = 0, I_ = 0, routesPerEnv_ = 0;
+    double interval_ = 1.0;
+    bool rlTrafficLight_ = false;
+    size_t step_ = 0;
+    std::vector<cfx_spawn> recs_, envRecs_;
+};
+
+}  // namespace cfa

@@ -170,6 +170,8 @@ int32_t cfx_reset(cfx_engine *e);
 
 /* TrafficLight::setPhase (trafficlight.cpp:39-41).  Unlike the reference this is range-checked. */
 int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase);
+/* same for n (intersection, phase) pairs in one call (an RL agent sets every signal each step) */
+int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const int32_t *phases);
 int32_t cfx_get_tl_state(cfx_engine *e, int32_t *cur_phase /*[n_inters]*/, double *remain /*[n_inters]*/);
 
 int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out);

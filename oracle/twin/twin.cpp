@@ -699,6 +699,14 @@ int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
     return CFX_OK;
 }
 
+int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const int32_t *phases) {
+    for (int i = 0; i < n; ++i) {
+        int32_t rc = cfx_set_tl_phase(e, inters[i], phases[i]);
+        if (rc != CFX_OK) return rc;
+    }
+    return CFX_OK;
+}
+
 int32_t cfx_get_tl_state(cfx_engine *e, int32_t *phase, double *remain) {
     if (phase) memcpy(phase, e->curPhase.data(), e->net.I * sizeof(int32_t));
     if (remain) memcpy(remain, e->remain.data(), e->net.I * sizeof(double));

@@ -1,0 +1,74 @@
+"""VectorEngine: every environment of a batched engine evolves exactly like a standalone Engine with seed + env index.
+CPU (twin backend) here; the same check on the HIP engine carries the gpu marker."""
+import numpy as np
+import pytest
+
+from conftest import TWIN_LIB
+
+
+def _check(mod, scen, workdir, make_vec, make_single, name="example_1x1", envs=3, steps=150, rl=False):
+    kw = {"rlTrafficLight": True} if rl else {}
+    vec = make_vec(scen.materialize(name, workdir, **kw), envs)
+    singles = [make_single(scen.materialize(name, workdir, seed=e, **kw)) for e in range(envs)]
+    inter_ids = vec.intersection_ids()
+    assert vec.lane_ids() == singles[0].lane_ids()
+    for s in range(steps):
+        if rl and s % 10 == 0:
+            ph = np.zeros((envs, len(inter_ids)), dtype=np.int32)
+            for e in range(envs):
+                ph[e, :] = (s // 10 + e) % 8
+                for i, iid in enumerate(inter_ids):
+                    try:
+                        singles[e].set_tl_phase(iid, int(ph[e, i]))
+                    except (IndexError, RuntimeError):
+                        pass  # virtual intersections
+            vec.set_tl_phases(ph)
+        vec.next_step()
+        for e in singles:
+            e.next_step()
+        if s % 10 == 9:
+            counts = vec.get_lane_vehicle_count_array()
+            waits = vec.get_lane_waiting_vehicle_count_array()
+            assert counts.shape == (envs, len(vec.lane_ids()))
+            for e in range(envs):
+                assert np.array_equal(counts[e], singles[e].get_lane_vehicle_count_array()), (s, e)
+                assert np.array_equal(waits[e], singles[e].get_lane_waiting_vehicle_count_array()), (s, e)
+                assert vec.get_vehicle_speed(e) == singles[e].get_vehicle_speed(), (s, e)
+    assert vec.get_vehicle_count() == sum(e.get_vehicle_count() for e in singles)
+    if name == "example_1x1":  # seeds pick different first lanes there; on the grids every route has one candidate
+        c = vec.get_lane_vehicle_count_array()
+        assert not np.array_equal(c[0], c[1])
+
+
+def test_vector_engine_twin(mod, scen, workdir):
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine._with_backend(c, n, 1, TWIN_LIB),
+           lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB))
+
+
+def test_vector_engine_twin_rl(mod, scen, workdir):
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine._with_backend(c, n, 1, TWIN_LIB),
+           lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), name="grid_6x6", envs=2, steps=60, rl=True)
+
+
+def test_vector_engine_reset(mod, scen, workdir):
+    vec = mod.VectorEngine._with_backend(scen.materialize("example_1x1", workdir), 2, 1, TWIN_LIB)
+    for _ in range(60):
+        vec.next_step()
+    a = vec.get_lane_vehicle_count_array().copy()
+    vec.reset(True)
+    assert vec.get_vehicle_count() == 0
+    for _ in range(60):
+        vec.next_step()
+    assert np.array_equal(a, vec.get_lane_vehicle_count_array())
+
+
+@pytest.mark.gpu
+def test_vector_engine_hip(mod, scen, workdir):
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine(c, n, 1), lambda c: mod.Engine(c, 1), name="grid_6x6",
+           envs=4, steps=200)
+
+
+@pytest.mark.gpu
+def test_vector_engine_hip_rl(mod, scen, workdir):
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine(c, n, 1), lambda c: mod.Engine(c, 1), name="grid_6x6",
+           envs=3, steps=80, rl=True)
