@@ -372,7 +372,7 @@ void EngineHost::loadFromFile(const std::string &path) {
         r.firstLane = y.running ? -1 : y.drivable;
         int vid = (int) a.host.vehicles.size();
         a.host.vehicles.push_back(r);
-        a.host.livePriority[r.priority] = vid;
+        a.host.livePriority.set(r.priority, vid);
         std::vector<int32_t> &tbl = r.flow >= 0 ? a.host.flowVids[r.flow] : a.host.manualVids;
         if ((int) tbl.size() <= r.number) tbl.resize(r.number + 1, -1);
         tbl[r.number] = vid;

@@ -176,6 +176,12 @@ void Spawner::loadFlows(const std::string &path) {
         flows.push_back(std::move(f));
     }
     flowVids.assign(flows.size(), {});
+    rebuildActiveFlows();
+}
+
+void Spawner::rebuildActiveFlows() {
+    activeFlows_.clear();
+    for (size_t i = 0; i < flows.size(); ++i) activeFlows_.push_back((int32_t) i);
 }
 
 std::string Spawner::vehicleId(int vid) const {
@@ -190,11 +196,11 @@ int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> 
     int32_t priority;
     for (;;) {
         priority = (int32_t) rnd();
-        auto it = livePriority_.find(priority);
-        if (it == livePriority_.end()) break;
+        int32_t *owner = livePriority_.find(priority);
+        if (!owner) break;
         // Host bookkeeping is a superset of the live set; settle it exactly before redrawing.
-        if (it->second >= 0 && isFinished && isFinished(it->second)) {
-            livePriority_.erase(it);
+        if (*owner >= 0 && isFinished && isFinished(*owner)) {
+            livePriority_.erase(priority);
             break;
         }
     }
@@ -208,7 +214,7 @@ int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> 
     rec.enterTime = stepIndex * interval_;  // Engine::getCurrentTime engine.cpp:678-680
     rec.firstLane = -1;
     pendingRecords_.push_back(rec);
-    livePriority_[priority] = -1;
+    livePriority_.set(priority, -1);
     Pending p;
     p.index = (int) pendingRecords_.size() - 1;
     p.firstRoad = anchors[0];
@@ -225,10 +231,14 @@ void Spawner::pushManual(int templ, const std::vector<int> &anchors, size_t step
 void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
     out.clear();
     // phase 0: Flow::nextStep for every flow in order (engine.cpp:567-568)
-    for (size_t fi = 0; fi < flows.size(); ++fi) {
+    size_t keep = 0;
+    for (size_t ai = 0; ai < activeFlows_.size(); ++ai) {
+        const size_t fi = (size_t) activeFlows_[ai];
         HostFlow &f = flows[fi];
+        // both early returns of Flow::nextStep are permanent (currentTime only grows; valid is never restored)
         if (!f.valid) continue;
         if (f.endTime != -1 && f.currentTime > f.endTime) continue;
+        activeFlows_[keep++] = (int32_t) fi;
         if (f.currentTime >= f.startTime) {
             while (f.nowTime >= f.interval) {
                 newVehicle((int) fi, f.cnt++, f.templ, f.anchors, f.route, stepIndex, isFinished_);
@@ -238,6 +248,7 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
         }
         f.currentTime += interval_;
     }
+    activeFlows_.resize(keep);
     // phase 1: Engine::planRoute — roads in JSON order, vehicles in buffer order
     std::stable_sort(pending_.begin(), pending_.end(),
                      [](const Pending &a, const Pending &b) { return a.firstRoad < b.firstRoad; });
@@ -249,7 +260,7 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
             int vid = (int) vehicles.size();
             rec.firstLane = lane;
             vehicles.push_back(rec);
-            livePriority_[rec.priority] = vid;
+            livePriority_.set(rec.priority, vid);
             {
                 std::vector<int32_t> &tbl = rec.flow >= 0 ? flowVids[rec.flow] : manualVids;
                 if ((int) tbl.size() <= rec.number) tbl.resize(rec.number + 1, -1);
@@ -312,6 +323,7 @@ void Spawner::loadState(const State &st) {
     rnd = st.rnd;
     manualCnt_ = std::max(manualCnt_, st.manualCnt);  // manuallyPushCnt never goes back (engine.h:56)
     livePriority_ = st.livePriority;
+    rebuildActiveFlows();
     pending_.clear();
     pendingRecords_.clear();
 }
@@ -326,6 +338,7 @@ void Spawner::reset(bool reseed) {
     for (auto &v : flowVids) v.clear();
     std::fill(manualVids.begin(), manualVids.end(), -1);
     livePriority_.clear();
+    rebuildActiveFlows();
     pending_.clear();
     pendingRecords_.clear();
     std::fill(lastWaitVid_.begin(), lastWaitVid_.end(), -1);

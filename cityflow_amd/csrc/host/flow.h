@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "cityflow_amd.h"
+#include "flat_map.h"
 #include "roadnet.h"
 
 namespace cfa {
@@ -114,7 +115,7 @@ public:
         std::vector<int32_t> manualVids, lastWaitVid;
         std::mt19937 rnd;
         int manualCnt = 0;
-        std::unordered_map<int32_t, int32_t> livePriority;
+        FlatMapI32 livePriority;
     };
     State saveState() const;
     void loadState(const State &st);
@@ -125,6 +126,7 @@ private:
         int index;  // into pendingRecords_
         int firstRoad;
     };
+    void rebuildActiveFlows();
     int newVehicle(int flow, int number, int templ, const std::vector<int> &anchors, int route, size_t stepIndex,
                    const std::function<bool(int)> &isFinished);
 
@@ -137,7 +139,8 @@ private:
     std::vector<Pending> pending_;                 // planRouteBuffer contents, in push order
     std::vector<VehicleRecord> pendingRecords_;
     std::vector<int32_t> lastWaitVid_;             // per lane: last vid pushed to its waitingBuffer
-    std::unordered_map<int32_t, int32_t> livePriority_;  // priority -> vid (superset of live vehicles)
+    FlatMapI32 livePriority_;  // priority -> vid (superset of live vehicles; -1 while in planRouteBuffer)
+    std::vector<int32_t> activeFlows_;  // flows that may still spawn, ascending (Flow::nextStep early returns)
     std::map<std::vector<int>, int> routeIndex_;          // expanded road sequence -> route index
 };
 

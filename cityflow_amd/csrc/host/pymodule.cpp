@@ -5,6 +5,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <chrono>
 #include <iostream>
 
 #include "engine_host.h"
@@ -126,6 +127,21 @@ py::list spawnSchedule(const std::string &roadnetFile, const std::string &flowFi
         out.append(stepList);
     }
     return out;
+}
+
+// seconds spent in `steps` Spawner::step calls (host-side cost of phases 0-1, no device, no Python objects)
+double spawnBenchmark(const std::string &roadnetFile, const std::string &flowFile, double interval, int seed, int skip,
+                      int steps) {
+    cfa::HostRoadNet net;
+    net.load(roadnetFile);
+    cfa::Spawner sp;
+    sp.init(&net, interval, 1, seed);
+    sp.loadFlows(flowFile);
+    std::vector<cfx_spawn> recs;
+    for (int s = 0; s < skip; ++s) sp.step((size_t) s, recs);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int s = 0; s < steps; ++s) sp.step((size_t) (skip + s), recs);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 }  // namespace
@@ -303,6 +319,7 @@ PYBIND11_MODULE(_cityflow, m) {
     m.def("_roadnet_probe", &roadnetProbe, "path"_a);
     m.def("_spawn_schedule", &spawnSchedule, "roadnet_file"_a, "flow_file"_a, "interval"_a, "seed"_a, "thread_num"_a,
           "steps"_a);
+    m.def("_spawn_benchmark", &spawnBenchmark, "roadnet_file"_a, "flow_file"_a, "interval"_a, "seed"_a, "skip"_a, "steps"_a);
     m.def("_default_backend_path", &cfa::defaultBackendPath);
 #ifdef CITYFLOW_AMD_VERSION
     m.attr("__version__") = CITYFLOW_AMD_VERSION;

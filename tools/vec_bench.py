@@ -1,0 +1,41 @@
+"""Batched-replica throughput: R copies of the bench.py workload advanced by one device engine.
+usage: python tools/vec_bench.py R [R ...]   -> one JSON line per R"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rs = [int(x) for x in sys.argv[1:]] or [1, 4, 8]
+sys.argv = [sys.argv[0]]
+import bench
+from cityflow_amd import _cityflow
+cfg = bench.build_workload("/tmp/cfa_vec", 0)
+for R in rs:
+    t0 = time.perf_counter()
+    eng = _cityflow.VectorEngine(cfg, R, 1)
+    t_load = time.perf_counter() - t0
+    for _ in range(300):
+        eng.next_step()
+    eng.sync()
+    s0 = eng._scalars()
+    K = 100
+    t0 = time.perf_counter()
+    for _ in range(K):
+        eng.next_step()
+    eng.sync()
+    dt = time.perf_counter() - t0
+    s1 = eng._scalars()
+    eng._profile_enable(True)
+    for _ in range(50):
+        eng.next_step()
+    prof = eng._profile_read()
+    eng._profile_enable(False)
+    s2 = eng._scalars()
+    vs = s1["vehicle_steps"] - s0["vehicle_steps"]
+    act_ms, act_n = prof["k_action"]
+    vpl = (s2["vehicle_steps"] - s1["vehicle_steps"]) / max(act_n, 1)
+    gbs = 48.0 * vpl / (act_ms / act_n / 1e3) / 1e9
+    print(json.dumps({"envs": R, "running_vehicles": s1["active_vehicle_count"], "ms_per_step": dt / K * 1e3,
+                      "env_steps_per_sec": K * R / dt, "vehicle_steps_per_sec": vs / dt,
+                      "k_action_us": act_ms / act_n * 1e3, "k_action_GBps": gbs, "k_action_frac_of_8TBps": gbs / 8000.0,
+                      "kernel_us": {k: round(ms / max(n, 1) * 1e3, 1) for k, (ms, n) in prof.items()},
+                      "load_s": round(t_load, 1)}), flush=True)
+    del eng
