@@ -30,6 +30,9 @@ struct DevNet {
     const int32_t *xPeerBit;        // [E] llLocal of the laneLink owning the peer entry
     const int32_t *llLocal;         // [K] index of the laneLink inside its intersection
     const int32_t *interMaskStart;  // [I+1] offsets (in 64-bit words) into the active-laneLink masks
+    const double2 *drvLM;           // [D] {length, maxSpeed} packed: one 16-byte load per drivable
+    const double2 *xDD;             // [E] {xDist of the entry, xDist of its peer entry}
+    const int4 *xPack;              // [E] {peer laneLink, peer's llLocal bit, peer's RoadLinkType, 0}
 };
 
 struct DevTables {
@@ -68,9 +71,13 @@ struct StepCtx {
     const int32_t *vPriority; // [vid]
     const double *vCustomSpeed; // [vid] Buffer::customSpeed, valid where the slot flag / pending flag is set
     // per-laneLink notification sources of this step (phase 3, Engine::threadNotifyCross)
-    int32_t *llU;             // [K] vehicle that just left onto the end lane (slot) or -1
-    int32_t *llF;             // [K] first vehicle of the start lane heading for this laneLink on green, or -1
+    // [K] {u: vehicle that just left onto the end lane (slot or -1), f: first vehicle of the start lane heading for
+    //      this laneLink on green (slot or -1), segStart, cnt of the laneLink}: everything notifiedAt() needs
+    int4 *llDyn;
     unsigned long long *interMask;  // active-laneLink bit masks, see DevNet::interMaskStart
+    // per-step gate records written by k_admit (phase 2), read by k_action (phase 4)
+    int2 *llGate;             // [K] {bit0 RoadLink::isAvailable, bits1-2 RoadLinkType, bit3 has crosses ; end lane}
+    int32_t *laneTail;        // [L] Drivable::getLastVehicle() of the lane after this step's admission (slot or -1)
     int32_t step;
     double interval;
 };

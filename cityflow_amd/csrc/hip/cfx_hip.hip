@@ -17,9 +17,8 @@ namespace {
 
 std::string g_createError;
 
-enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_LLSTATE, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, kNumProfKernels };
-const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_llstate", "k_action",
-                                                 "k_cross",      "k_scan",  "k_scatter"};
+enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, kNumProfKernels };
+const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_action", "k_cross", "k_scan", "k_scatter"};
 
 #define HIP_TRY(call)                                                                                  \
     do {                                                                                               \
@@ -72,13 +71,15 @@ struct cfx_engine {
     ActionBuf ab{};
     CompactScratch cs{};
     int32_t *oldToNew = nullptr;
-    int32_t *finList = nullptr, *finSorted = nullptr, *crossJobs = nullptr;
+    int32_t *finList = nullptr, *finSorted = nullptr, *crossJobs = nullptr, *jobCount = nullptr;
     // getter scratch
     int32_t *viewLeader = nullptr;
     double *viewGap = nullptr;
 
     // ---- per-lane / per-laneLink / per-entry / per-intersection dynamic state ----
-    int32_t *waitHead = nullptr, *admitStep = nullptr, *llU = nullptr, *llF = nullptr, *curPhase = nullptr;
+    int32_t *waitHead = nullptr, *admitStep = nullptr, *laneTail = nullptr, *curPhase = nullptr;
+    int4 *llDyn = nullptr;
+    int2 *llGate = nullptr;
     unsigned long long *interMask = nullptr;
     int nMaskWords = 0;
     double *remain = nullptr;
@@ -199,8 +200,9 @@ struct cfx_engine {
         c.oldToNew = oldToNew;
         c.vPriority = vt.priority;
         c.vCustomSpeed = vt.customSpeed;
-        c.llU = llU;
-        c.llF = llF;
+        c.llDyn = llDyn;
+        c.llGate = llGate;
+        c.laneTail = laneTail;
         c.interMask = interMask;
         c.step = (int32_t) step;
         c.interval = cfg.interval;
@@ -243,7 +245,7 @@ struct cfx_engine {
         GROW_SCRATCH(o.routePos) GROW_SCRATCH(o.templ) GROW_SCRATCH(o.route) GROW_SCRATCH(o.flags) GROW_SCRATCH(o.dis) GROW_SCRATCH(o.speed)
         GROW_SCRATCH(ab.dis) GROW_SCRATCH(ab.speed) GROW_SCRATCH(ab.drv) GROW_SCRATCH(ab.blocker)
         GROW_SCRATCH(cs.inNext) GROW_SCRATCH(finList) GROW_SCRATCH(finSorted) GROW_SCRATCH(viewLeader) GROW_SCRATCH(viewGap)
-        GROW_SCRATCH(crossJobs)
+        if ((rc = grow(&crossJobs, 0, nc * kJobShards))) return rc;
 #undef GROW_SCRATCH
         if ((rc = grow(&oldToNew, keep, nc))) return rc;  // committed blockers point through it
         slotCap = nc;
@@ -300,6 +302,7 @@ struct cfx_engine {
         HIP_TRY(hipMemsetAsync(sc, 0, sizeof(DevScalars), stream));
         HIP_TRY(hipMemsetAsync(scanGranules, 0, (size_t) nScanBlocks * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(scanTicket, 0, sizeof(int32_t), stream));
+        HIP_TRY(hipMemsetAsync(jobCount, 0, (size_t) kJobShards * kJobShardStride * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(oldToNew, 0xFF, slotCap * sizeof(int32_t), stream));
         if (vidCap) HIP_TRY(hipMemsetAsync(vt.nextWait, 0xFF, vidCap * sizeof(int32_t), stream));
         HIP_TRY(hipGetLastError());
@@ -386,8 +389,9 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->waitHead, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->admitStep, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
-    if ((rc = e->allocRaw(&e->llU, (size_t) e->K))) return rc;
-    if ((rc = e->allocRaw(&e->llF, (size_t) e->K))) return rc;
+    if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
+    if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
+    if ((rc = e->allocRaw(&e->laneTail, (size_t) e->L))) return rc;
     {
         // derived tables: index of each laneLink inside its intersection (laneLinks of one intersection are
         // contiguous in RoadNet::getLaneLinks() order), the peer's bit for every cross entry, mask offsets
@@ -401,6 +405,17 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         for (int i = 0; i < e->I; ++i) maskStart[i + 1] = maskStart[i] + (nLL[i] + 63) / 64;
         for (int x = 0; x < e->E; ++x) xPeerBit[x] = llLocal[n->x_ll[n->x_peer[x]]];
         e->nMaskWords = maskStart[e->I];
+        std::vector<double2> lm((size_t) e->D), xdd((size_t) e->E);
+        std::vector<int4> xpack((size_t) e->E);
+        for (int dv = 0; dv < e->D; ++dv) lm[dv] = make_double2(n->drv_length[dv], n->drv_max_speed[dv]);
+        for (int x = 0; x < e->E; ++x) {
+            int pe = n->x_peer[x], pll = n->x_ll[pe];
+            xdd[x] = make_double2(n->x_dist[x], n->x_dist[pe]);
+            xpack[x] = make_int4(pll, llLocal[pll], n->ll_type[pll], 0);
+        }
+        if ((rc = e->uploadConst(d.drvLM, lm.data(), lm.size()))) return rc;
+        if ((rc = e->uploadConst(d.xDD, xdd.data(), xdd.size()))) return rc;
+        if ((rc = e->uploadConst(d.xPack, xpack.data(), xpack.size()))) return rc;
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
@@ -411,6 +426,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     e->nScanBlocks = (e->D + kScanTile - 1) / kScanTile;
     if ((rc = e->allocRaw(&e->scanGranules, (size_t) e->nScanBlocks))) return rc;
     if ((rc = e->allocRaw(&e->scanTicket, 1))) return rc;
+    if ((rc = e->allocRaw(&e->jobCount, (size_t) kJobShards * kJobShardStride))) return rc;
     if ((rc = e->allocRaw(&e->sc, 1))) return rc;
     if ((rc = e->ensureSlotCap((size_t) e->L + 4096))) return rc;
     if ((rc = e->ensureVidCap(1 << 16))) return rc;
@@ -513,20 +529,21 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     const int nxt = e->cur ^ 1;
     const size_t slotBound = std::min(need, e->slotCap);
     { int pp__ = e->profBegin(PK_ADMIT);
-    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c, e->cnt[e->cur].p, e->admitStep, e->waitHead,
+    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->cnt[e->cur].p, e->admitStep, e->waitHead,
                        e->vt, e->cs, e->sc);
     e->profEnd(pp__); }
-    { int pp__ = e->profBegin(PK_LLSTATE);
-    hipLaunchKernelGGL(k_llstate, dim3(gridFor(e->K)), dim3(kBlock), 0, st, c, e->cs);
-    e->profEnd(pp__); }
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
-    { int pp__ = e->profBegin(PK_ACTION);
-    hipLaunchKernelGGL(k_action, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192)),
-                       dim3(kActBlock), 0, st, c, ao, e->crossJobs, &e->sc->nCrossJobs);
-    e->profEnd(pp__); }
+    JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap};
+    {
+        const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
+        const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
+        int pp__ = e->profBegin(PK_ACTION);
+        hipLaunchKernelGGL(k_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), 0, st, c, ao, jq, nVehBlocks);
+        e->profEnd(pp__);
+    }
     { int pp__ = e->profBegin(PK_CROSS);
     hipLaunchKernelGGL(k_cross, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + 15) / 16), 8192)), dim3(kBlock), 0,
-                       st, c, ao, e->crossJobs, &e->sc->nCrossJobs);
+                       st, c, ao, jq);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
@@ -537,7 +554,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),
                        dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
                        e->remain, e->cfg.rl_traffic_light, e->nMaskWords, e->scanTicket, e->vt, e->sc, e->finList,
-                       e->finSorted, (int) e->slotCap);
+                       e->finSorted, (int) e->slotCap, e->jobCount);
     e->profEnd(pp__); }
     HIP_TRY(hipGetLastError());
     e->cur = nxt;

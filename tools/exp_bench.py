@@ -1,4 +1,6 @@
-"""Developer tool: time the per-step kernels of alternative builds of the C-ABI library (A/B experiments).
+"""Developer tool: time the per-step kernels of alternative builds of the C-ABI library from the SAME warm state
+(warmed by the product library, transferred through an in-memory Archive), so experiments that change the logic
+are still compared on identical inputs for the first few steps.
 usage: python tools/exp_bench.py lib1.so [lib2.so ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,16 +10,23 @@ sys.argv = [sys.argv[0]]
 import bench
 from cityflow_amd import _cityflow
 cfg = bench.build_workload("/tmp/cfa_exp", 0)
-for lib in libs:
+base = _cityflow.Engine(cfg, 1)
+for _ in range(300):
+    base.next_step()
+arch = base.snapshot()
+for lib in [_cityflow._default_backend_path()] + libs:
     eng = _cityflow.Engine._with_backend(cfg, 1, os.path.abspath(lib))
-    for _ in range(300):
-        eng.next_step()
-    eng.sync()
-    eng._profile_enable(True)
-    for _ in range(60):
-        eng.next_step()
-    prof = eng._profile_read()
-    eng._profile_enable(False)
-    print(os.path.basename(lib), {k: round(ms / max(n, 1) * 1e3, 1) for k, (ms, n) in prof.items()},
-          "running", eng.get_vehicle_count(), flush=True)
+    res = {}
+    for rep in range(3):
+        eng.load(arch)
+        eng.next_step(); eng.next_step()   # warm caches / clocks
+        eng.sync()
+        eng._profile_enable(True)
+        for _ in range(8):
+            eng.next_step()
+        prof = eng._profile_read()
+        eng._profile_enable(False)
+        for k, (ms, n) in prof.items():
+            res.setdefault(k, []).append(ms / max(n, 1) * 1e3)
+    print(os.path.basename(lib), {k: round(min(v), 1) for k, v in res.items()}, "running", eng.get_vehicle_count(), flush=True)
     del eng
