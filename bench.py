@@ -89,6 +89,23 @@ def cpu_baseline(cfg, budget_s, threads, state_dump):
     }
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (FETCH_SIZE + WRITE_SIZE passes,
+    tools/pmc_summary.py); counters cannot be collected from inside this process, so this is the offline measurement
+    of the same command, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    k = d.get("kernels", {}).get(kernel)
+    if not k:
+        return None, None
+    return k["hbm_bytes_raw"], "%s (%s; (FETCH_SIZE+WRITE_SIZE)*1024 per launch, uncorrected)" % (
+        os.path.relpath(files[-1], ROOT), d.get("window", ""))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,9 +195,10 @@ def main():
             avg_s = act_ms / act_n / 1e3
             achieved = ACTION_BYTES_PER_VEHICLE * vehicles_per_launch / avg_s / 1e9
             step_ms = sum(ms for ms, _n in prof.values()) / act_n
+            traffic, traffic_src = pmc_traffic("cfxd::k_action")
             roofline = {
                 "bound": "hbm", "kernel": "k_action", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": avg_s * 1e6, "vehicles_per_launch": vehicles_per_launch,
                 "algorithmic_bytes_per_vehicle": ACTION_BYTES_PER_VEHICLE,
                 "measured_over": "%d instrumented steps following the timed region" % args.profile_steps,
