@@ -98,6 +98,11 @@ struct cfx_engine {
     bool stageBusy[kStages] = {false, false, false, false};
     size_t stageCap = 0;
     int stageIdx = 0;
+    int32_t *hPhaseStage[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t phaseStageEvent[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    bool phaseStageBusy[kStages] = {false, false, false, false};
+    size_t phaseStageCap = 0;
+    int phaseStageIdx = 0;
 
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
@@ -327,6 +332,8 @@ void cfx_destroy(cfx_engine *e) {
     for (int i = 0; i < cfx_engine::kStages; ++i) {
         if (e->hStage[i]) (void) hipHostFree(e->hStage[i]);
         if (e->stageEvent[i]) (void) hipEventDestroy(e->stageEvent[i]);
+        if (e->hPhaseStage[i]) (void) hipHostFree(e->hPhaseStage[i]);
+        if (e->phaseStageEvent[i]) (void) hipEventDestroy(e->phaseStageEvent[i]);
     }
     if (e->stream) (void) hipStreamDestroy(e->stream);
     delete e;
@@ -542,8 +549,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->profEnd(pp__);
     }
     { int pp__ = e->profBegin(PK_CROSS);
-    hipLaunchKernelGGL(k_cross, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + 15) / 16), 8192)), dim3(kBlock), 0,
-                       st, c, ao, jq);
+    hipLaunchKernelGGL(k_cross, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
+                       dim3(kCrossBlock), 0, st, c, ao, jq);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
@@ -599,19 +606,34 @@ int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const
     if (!e || n < 0 || (n && (!inters || !phases))) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    // read-modify-write of the (small) phase vector on the host, one upload
-    std::vector<int32_t> cur((size_t) e->I);
-    HIP_TRY(hipMemcpyAsync(cur.data(), e->curPhase, (size_t) e->I * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (inters[i] < 0 || inters[i] >= e->I || phases[i] < 0) {
             e->err = "cfx_set_tl_phases: index out of range";
             return CFX_ERR_INVALID;
         }
-        cur[inters[i]] = phases[i];
+    // One pinned staging buffer per call slot (ring of kStages), uploaded asynchronously on the engine's stream and
+    // scattered by a tiny kernel: no synchronisation, the RL loop keeps running ahead of the device.
+    const size_t need = (size_t) n * 2;
+    if (need > e->phaseStageCap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        size_t nc = std::max<size_t>(need * 2, 4096);
+        for (int i = 0; i < cfx_engine::kStages; ++i) {
+            if (e->hPhaseStage[i]) HIP_TRY(hipHostFree(e->hPhaseStage[i]));
+            HIP_TRY(hipHostMalloc((void **) &e->hPhaseStage[i], nc * sizeof(int32_t), hipHostMallocDefault));
+            if (!e->phaseStageEvent[i]) HIP_TRY(hipEventCreateWithFlags(&e->phaseStageEvent[i], hipEventDisableTiming));
+            e->phaseStageBusy[i] = false;
+        }
+        e->phaseStageCap = nc;
     }
-    HIP_TRY(hipMemcpyAsync(e->curPhase, cur.data(), (size_t) e->I * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    const int si = e->phaseStageIdx;
+    e->phaseStageIdx = (si + 1) % cfx_engine::kStages;
+    if (e->phaseStageBusy[si]) HIP_TRY(hipEventSynchronize(e->phaseStageEvent[si]));
+    memcpy(e->hPhaseStage[si], inters, (size_t) n * sizeof(int32_t));
+    memcpy(e->hPhaseStage[si] + n, phases, (size_t) n * sizeof(int32_t));
+    if (n) hipLaunchKernelGGL(k_set_phases, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->hPhaseStage[si], n, e->curPhase);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->phaseStageEvent[si], e->stream));
+    e->phaseStageBusy[si] = true;
     return CFX_OK;
 }
 

@@ -20,7 +20,14 @@
 namespace cfxd {
 
 constexpr int kBlock = 256;
-constexpr int kActBlock = 64;   // one wavefront per workgroup: ~100k vehicles spread over all 1024 SIMDs
+#ifndef CFX_ACT_BLOCK
+#define CFX_ACT_BLOCK 64
+#endif
+#ifndef CFX_CROSS_BLOCK
+#define CFX_CROSS_BLOCK 256
+#endif
+constexpr int kActBlock = CFX_ACT_BLOCK;      // one wavefront per workgroup: ~100k vehicles spread over all 1024 SIMDs
+constexpr int kCrossBlock = CFX_CROSS_BLOCK;  // k_cross workgroup (16-lane groups inside)
 constexpr int kLdsTempl = 32;   // vehicle templates staged in LDS by k_action (96 B each)
 
 // ----------------------------------------------------------------------------------------------
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, Jo
 // first failing round.
 constexpr int kCrossGroup = 16;
 
-__global__ __launch_bounds__(kBlock) void k_cross(StepCtx c, ActionOut o, JobQueue q) {
+__global__ __launch_bounds__(kCrossBlock) void k_cross(StepCtx c, ActionOut o, JobQueue q) {
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
     if (c.t.nTempl <= kLdsTempl) {
@@ -876,6 +883,12 @@ __global__ void k_set_route(StepCtx c, int vid, int route) {
             c.s.routePos[s] = 0;
             c.s.next[s] = nextOf(c.n, c.t, c.s.drv[s], route, 0);
         }
+}
+
+// TrafficLight::setPhase (trafficlight.cpp:39-41) for n (intersection, phase) pairs read from pinned host memory
+__global__ void k_set_phases(const int32_t *pairs, int n, int32_t *curPhase) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) curPhase[pairs[i]] = pairs[n + i];
 }
 
 __global__ void k_refresh_next(StepCtx c) {  // after cfx_load_state: Router::getNextDrivable(0) of every vehicle

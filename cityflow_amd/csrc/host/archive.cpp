@@ -244,6 +244,8 @@ Archive EngineHost::snapshot() {
 }
 
 void EngineHost::load(const Archive &a) {
+    pendingPhaseInter_.clear();
+    pendingPhaseValue_.clear();
     if (a.net.get() != net_.get() && a.net->lanes.size() != net_->lanes.size())
         throw std::runtime_error("Engine.load: archive belongs to a different road network");
     spawner_.loadState(a.host);

@@ -178,7 +178,27 @@ void EngineHost::uploadNewTablesIfAny() {
 }
 
 // ---------------------------------------------------------------- stepping
+void EngineHost::flushPhases() {
+    if (pendingPhaseInter_.empty()) return;
+    check(be_.cfx_set_tl_phases(dev_, (int32_t) pendingPhaseInter_.size(), pendingPhaseInter_.data(),
+                                pendingPhaseValue_.data()),
+          "cfx_set_tl_phases");
+    pendingPhaseInter_.clear();
+    pendingPhaseValue_.clear();
+}
+
+const std::vector<int32_t> &EngineHost::laneIdOrder() {
+    if (laneIdOrder_.empty() && !net_->lanes.empty()) {
+        std::vector<std::pair<std::string, int32_t>> ids;
+        for (size_t l = 0; l < net_->lanes.size(); ++l) ids.emplace_back(net_->laneId((int) l), (int32_t) l);
+        std::sort(ids.begin(), ids.end());
+        for (auto &p : ids) laneIdOrder_.push_back(p.second);
+    }
+    return laneIdOrder_;
+}
+
 void EngineHost::nextStep() {
+    flushPhases();
     spawner_.step(step_, spawnBuf_);
     uploadNewTablesIfAny();
     check(be_.cfx_step(dev_, spawnBuf_.data(), (int32_t) spawnBuf_.size()), "cfx_step");
@@ -206,6 +226,8 @@ cfx_scalars EngineHost::scalars() {
 }
 
 void EngineHost::reset(bool resetRnd) {
+    pendingPhaseInter_.clear();  // TrafficLight::reset puts every light back to phase 0 anyway
+    pendingPhaseValue_.clear();
     check(be_.cfx_reset(dev_), "cfx_reset");
     spawner_.reset(resetRnd);
     step_ = 0;
@@ -434,8 +456,33 @@ double EngineHost::getAverageTravelTime() {
 }
 
 // ---------------------------------------------------------------- control
+// Single sets are only queued here; one asynchronous cfx_set_tl_phases carries them to the device right before the
+// next step (or before anything reads the light state), in call order.
 void EngineHost::setTrafficLightPhaseIndexed(int inter, int phase) {
-    check(be_.cfx_set_tl_phase(dev_, inter, phase), "cfx_set_tl_phase");
+    if (inter < 0 || inter >= (int) net_->inters.size() || net_->inters[inter].isVirtual || phase < 0 ||
+        phase >= (int) net_->inters[inter].phases.size())
+        throw std::out_of_range("set_tl_phase: intersection or phase index out of range");
+    pendingPhaseInter_.push_back(inter);
+    pendingPhaseValue_.push_back(phase);
+}
+
+void EngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) {
+    if (!rlTrafficLight_) {
+        std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
+        return;
+    }
+    if (phases.size() != net_->inters.size()) throw std::runtime_error("set_tl_phases: expected one phase per intersection");
+    flushPhases();
+    std::vector<int32_t> inters, ph;
+    for (size_t i = 0; i < phases.size(); ++i) {
+        const HostInter &in = net_->inters[i];
+        if (in.isVirtual) continue;
+        if (phases[i] < 0 || phases[i] >= (int) in.phases.size())
+            throw std::out_of_range("set_tl_phases: phase out of range for intersection '" + in.id + "'");
+        inters.push_back((int32_t) i);
+        ph.push_back(phases[i]);
+    }
+    check(be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data()), "cfx_set_tl_phases");
 }
 
 // setTrafficLightPhase engine.cpp:719-725
@@ -453,6 +500,7 @@ void EngineHost::setTrafficLightPhase(const std::string &id, int phaseIndex) {
 }
 
 void EngineHost::trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain) {
+    flushPhases();
     phase.resize(net_->inters.size());
     remain.resize(net_->inters.size());
     check(be_.cfx_get_tl_state(dev_, phase.data(), remain.data()), "cfx_get_tl_state");

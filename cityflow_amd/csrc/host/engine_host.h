@@ -97,8 +97,10 @@ public:
     std::vector<int32_t> laneVehicleCountArray();
     std::vector<int32_t> laneWaitingVehicleCountArray();
     std::vector<std::string> laneIds() const;          // index -> id for the two arrays above
+    const std::vector<int32_t> &laneIdOrder();         // lane indices in lexicographic id order (std::map order)
     std::vector<std::string> intersectionIds() const;
     void setTrafficLightPhaseIndexed(int inter, int phase);
+    void setTrafficLightPhases(const std::vector<int32_t> &phases);  // [n_intersections]; virtual ones ignored
     void trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain);
     void snapshotVehicles(VehicleSnapshot &out);
     void waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane);
@@ -106,6 +108,8 @@ public:
     void sync();
     void profileEnable(bool on);
     std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
+
+    std::shared_ptr<void> bindingCache;  // opaque per-engine cache owned by the language binding (lane id key objects)
 
     const HostRoadNet &net() const { return *net_; }
     const Spawner &spawner() const { return spawner_; }
@@ -130,7 +134,9 @@ private:
     size_t step_ = 0;
     int templatesUploaded_ = 0, routesUploaded_ = 0;
     std::vector<cfx_spawn> spawnBuf_;
-    std::map<std::string, int> manualIds_;  // manually_pushed_<n> -> vid
+    std::vector<int32_t> pendingPhaseInter_, pendingPhaseValue_;  // set_tl_phase calls since the last flush
+    void flushPhases();
+    std::vector<int32_t> laneIdOrder_;
 };
 
 struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84

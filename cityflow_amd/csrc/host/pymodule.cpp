@@ -72,6 +72,21 @@ py::dict flatNetToDict(const cfa::HostRoadNet &net) {
     return d;
 }
 
+// Reference getLaneVehicleCount returns std::map<std::string,int> (engine.cpp:628-648) which pybind11 turns into a dict
+// by creating one Python string per lane per call; here the key objects are created once per engine.
+py::dict laneDict(EngineHost &e, const std::vector<int32_t> &values) {
+    const std::vector<int32_t> &order = e.laneIdOrder();
+    if (!e.bindingCache) {
+        auto *keys = new py::list();
+        for (int32_t l : order) keys->append(py::str(e.net().laneId(l)));
+        e.bindingCache = std::shared_ptr<void>(keys, [](void *p) { delete static_cast<py::list *>(p); });
+    }
+    py::dict d;
+    const py::list &keys = *static_cast<py::list *>(e.bindingCache.get());
+    for (size_t i = 0; i < order.size(); ++i) d[keys[i]] = py::int_(values[order[i]]);
+    return d;
+}
+
 // Host-only helpers (no device engine involved): used by the CPU test-suite to pin the loader and the
 // spawner against the reference.
 py::dict loadRoadnet(const std::string &path) {
@@ -162,8 +177,9 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("next_step", &EngineHost::nextStep)
         .def("get_vehicle_count", &EngineHost::getVehicleCount)
         .def("get_vehicles", &EngineHost::getVehicles, "include_waiting"_a = false)
-        .def("get_lane_vehicle_count", &EngineHost::getLaneVehicleCount)
-        .def("get_lane_waiting_vehicle_count", &EngineHost::getLaneWaitingVehicleCount)
+        // dict[str, int] in std::map (lexicographic) key order like the reference, built from cached key objects
+        .def("get_lane_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneVehicleCountArray()); })
+        .def("get_lane_waiting_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneWaitingVehicleCountArray()); })
         .def("get_lane_vehicles", &EngineHost::getLaneVehicles)
         .def("get_vehicle_speed", &EngineHost::getVehicleSpeed)
         .def("get_vehicle_info", &EngineHost::getVehicleInfo, "vehicle_id"_a)
@@ -192,6 +208,11 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("get_lane_waiting_vehicle_count_array",
              [](EngineHost &e) { return toArray(e.laneWaitingVehicleCountArray()); })
         .def("set_tl_phase_indexed", &EngineHost::setTrafficLightPhaseIndexed, "intersection_index"_a, "phase_id"_a)
+        .def("set_tl_phases",
+             [](EngineHost &e, py::array_t<int32_t, py::array::c_style | py::array::forcecast> phases) {
+                 e.setTrafficLightPhases(std::vector<int32_t>(phases.data(), phases.data() + phases.size()));
+             },
+             "phases"_a, "int array [len(intersection_ids())]; one asynchronous call sets every signal")
         .def("sync", &EngineHost::sync)
         .def("backend_name", &EngineHost::backendName)
         // ---- introspection used by the parity tests ----
