@@ -1,0 +1,128 @@
+"""CPU: edge cases against the unmodified reference engine (oracle/_ref), on the host + CPU twin:
+empty / windowed / invalid flows, non-unit simulation interval, laneLinks without explicit points (generated curves),
+getters before the first step, push_vehicle defaults."""
+import gzip
+import json
+import os
+import subprocess
+import time
+
+import pytest
+
+from conftest import REF_DIR, TWIN_LIB, checkpoint_record
+
+
+def _variant(scen, workdir, name, tag, flows=None, roadnet_edit=None, **cfg):
+    base = scen.materialize(name, workdir)
+    d = os.path.dirname(base)
+    flow_file = None
+    if flows is not None:
+        flow_file = os.path.join(d, "flow_%s.json" % tag)
+        with open(flow_file, "w") as f:
+            json.dump(flows, f)
+    path = scen.materialize(name, workdir, flow_file=flow_file, **cfg)
+    if roadnet_edit is not None:
+        with open(os.path.join(d, "roadnet.json")) as f:
+            net = json.load(f)
+        roadnet_edit(net)
+        rn = "roadnet_%s.json" % tag
+        with open(os.path.join(d, rn), "w") as f:
+            json.dump(net, f)
+        with open(path) as f:
+            c = json.load(f)
+        c["roadnetFile"] = rn
+        path = path.replace(".json", "_%s.json" % tag)
+        with open(path, "w") as f:
+            json.dump(c, f)
+    return path
+
+
+def _both(mod, ref_module, cfg):
+    return mod.Engine._with_backend(cfg, 1, TWIN_LIB), ref_module.Engine(cfg, 1)
+
+
+def _lockstep(ours, ref, steps, every=1):
+    for s in range(steps):
+        ours.next_step()
+        ref.next_step()
+        if s % every == every - 1:
+            assert checkpoint_record(ours) == checkpoint_record(ref), "step %d" % (s + 1)
+    time.sleep(0.1)
+
+
+def _example_flows(scen, workdir):
+    d = os.path.dirname(scen.materialize("example_1x1", workdir))
+    with open(os.path.join(d, "flow.json")) as f:
+        return json.load(f)
+
+
+def test_getters_before_first_step_and_empty_flows(mod, ref_module, scen, workdir):
+    cfg = _variant(scen, workdir, "example_1x1", "empty", flows=[])
+    ours, ref = _both(mod, ref_module, cfg)
+    assert ours.get_vehicle_count() == 0 and ours.get_vehicles(True) == []
+    assert ours.get_lane_vehicle_count() == ref.get_lane_vehicle_count()
+    assert ours.get_average_travel_time() == ref.get_average_travel_time() == 0
+    _lockstep(ours, ref, 30)
+    assert ours.get_vehicle_speed() == {} and ours.get_lane_vehicles() == ref.get_lane_vehicles()
+
+
+def test_flow_windows_and_intervals(mod, ref_module, scen, workdir):
+    flows = _example_flows(scen, workdir)
+    flows[0].update(startTime=5, endTime=40, interval=3.0)
+    flows[1].update(startTime=0, endTime=0, interval=1.0)      # exactly one vehicle
+    flows[2].update(startTime=20, endTime=-1, interval=7.5)
+    flows[3].update(startTime=10, endTime=10, interval=0.5)    # interval < 1 is legal iff startTime == endTime
+    cfg = _variant(scen, workdir, "example_1x1", "windows", flows=flows)
+    ours, ref = _both(mod, ref_module, cfg)
+    _lockstep(ours, ref, 200)
+
+
+def test_half_second_steps(mod, ref_module, scen, workdir):
+    """interval 0.5: time accumulates in binary fractions; average travel time stays bit-identical"""
+    cfg = _variant(scen, workdir, "example_1x1", "half", interval=0.5)
+    ours, ref = _both(mod, ref_module, cfg)
+    _lockstep(ours, ref, 400, every=10)
+
+
+def test_invalid_and_single_road_routes_are_dropped(mod, ref_module, scen, workdir, capfd):
+    flows = _example_flows(scen, workdir)
+    flows[0]["route"] = ["road_0_1_0", "road_1_0_1"]   # not connected through intersection_1_1 -> Dijkstra fails
+    flows[1]["route"] = ["road_2_1_2"]                 # route.size() <= 1 -> invalid (router.cpp:239-240)
+    cfg = _variant(scen, workdir, "example_1x1", "invalid", flows=flows)
+    ours, ref = _both(mod, ref_module, cfg)
+    _lockstep(ours, ref, 120)
+    assert "Invalid route 'flow_0'" in capfd.readouterr().err
+    assert not any(v.startswith("flow_0_") or v.startswith("flow_1_") for v in ours.get_vehicles(True))
+
+
+def test_generated_lanelink_curves(mod, ref_module, scen, workdir):
+    """laneLinks without `points` get the reference's generated curve (roadnet.cpp:212-247); geometry and dynamics agree"""
+    def strip(net):
+        for inter in net["intersections"]:
+            for rl in inter.get("roadLinks", []):
+                for ll in rl["laneLinks"]:
+                    ll.pop("points", None)
+    cfg = _variant(scen, workdir, "example_1x1", "nopoints", roadnet_edit=strip)
+    with open(cfg) as f:
+        c = json.load(f)
+    roadnet = os.path.join(c["dir"], c["roadnetFile"])
+    probe = os.path.join(REF_DIR, "probe_roadnet")
+    if os.path.exists(probe):
+        assert mod._roadnet_probe(roadnet) == subprocess.check_output([probe, roadnet])
+    ours, ref = _both(mod, ref_module, cfg)
+    _lockstep(ours, ref, 300, every=5)
+
+
+def test_push_vehicle_defaults_match_reference(mod, ref_module, scen, workdir):
+    cfg = scen.materialize("example_1x1", workdir)
+    ours, ref = _both(mod, ref_module, cfg)
+    for s in range(100):
+        if s in (3, 30):
+            for e in (ours, ref):
+                e.push_vehicle({"maxSpeed": 10.0}, ["road_2_1_2", "road_1_1_3"])   # everything else defaulted
+                e.push_vehicle({}, ["road_1_0_1", "road_1_1_0"])
+        ours.next_step()
+        ref.next_step()
+        assert checkpoint_record(ours) == checkpoint_record(ref), s
+    assert ours.get_vehicles(True) == ref.get_vehicles(True)
+    time.sleep(0.1)

@@ -168,3 +168,32 @@ def test_conservation_at_benchmark_scale(mod, scen, workdir):
             assert np.all(st["speed"] >= 0) and np.all(st["speed"] <= 16.67 + 1e-9)
             assert np.all(st["dis"] >= 0)
     assert eng.get_vehicle_count() > 20000
+
+
+def test_edge_case_variants_hip_equals_twin(mod, scen, workdir):
+    """The scenarios of tests/test_edge_cases.py (checked against the reference on CPU) on the HIP engine."""
+    from test_edge_cases import _example_flows, _variant
+
+    flows = _example_flows(scen, workdir)
+    flows[0].update(startTime=5, endTime=40, interval=3.0)
+    flows[1].update(startTime=0, endTime=0, interval=1.0)
+    flows[2].update(startTime=20, endTime=-1, interval=7.5)
+    flows[3]["route"] = ["road_0_1_0", "road_1_0_1"]  # invalid: dropped
+
+    def strip(net):
+        for inter in net["intersections"]:
+            for rl in inter.get("roadLinks", []):
+                for ll in rl["laneLinks"]:
+                    ll.pop("points", None)
+
+    for cfg in (_variant(scen, workdir, "example_1x1", "gpu_windows", flows=flows),
+                _variant(scen, workdir, "example_1x1", "gpu_half", interval=0.5),
+                _variant(scen, workdir, "example_1x1", "gpu_nopoints", roadnet_edit=strip),
+                _variant(scen, workdir, "example_1x1", "gpu_empty", flows=[])):
+        hip, tw = _pair(mod, cfg)
+        for s in range(150):
+            hip.next_step()
+            tw.next_step()
+            if s % 3 == 2:
+                assert_same_state(hip, tw, "%s step %d" % (os.path.basename(cfg), s + 1))
+        assert hip.get_average_travel_time() == tw.get_average_travel_time()
