@@ -989,18 +989,6 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     return CFX_OK;
 }
 
-#ifdef CFX_KPROF
-// developer-only: sums / maxima of the k_action section timers (see KP_MARK in cfx_kernels.h); clears them
-int32_t cfx_debug_read_kprof(unsigned long long *out, int32_t n) {
-    unsigned long long host[32] = {};
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_kprof), sizeof host) != hipSuccess) return CFX_ERR_DEVICE;
-    for (int i = 0; i < n && i < 32; ++i) out[i] = host[i];
-    unsigned long long zero[32] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_kprof), zero, sizeof zero) != hipSuccess) return CFX_ERR_DEVICE;
-    return CFX_OK;
-}
-#endif
-
 int32_t cfx_profile_kernel_count(void) { return kNumProfKernels; }
 const char *cfx_profile_kernel_name(int32_t k) { return (k >= 0 && k < kNumProfKernels) ? kProfNames[k] : ""; }
 
