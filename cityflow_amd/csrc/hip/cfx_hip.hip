@@ -104,6 +104,16 @@ struct cfx_engine {
     size_t phaseStageCap = 0;
     int phaseStageIdx = 0;
 
+    // ---- tiling (cfx_halo_config) ----
+    bool tiled = false;
+    HaloDev halo{};
+    std::vector<uint8_t> hLaneSpare;   // per lane; empty when not tiled
+    int64_t spareTotal = 0;            // sum of spare slots over lanes
+    char *dHaloSend = nullptr, *dHaloRecv = nullptr;
+    char *hHaloSend = nullptr, *hHaloRecv = nullptr;  // pinned staging
+    int haloSendBytes = 0, haloRecvBytes = 0;
+    int64_t liveUpper = 0;             // tiled: upper bound of occupied slots (refreshed from the device when it runs out)
+
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
     int64_t finishedOffset = 0; // finished vehicles that are not in the vid table (state loaded from an archive)
@@ -298,8 +308,24 @@ struct cfx_engine {
         spawned = 0;
         finishedKnown = 0;
         finishedOffset = 0;
-        hipLaunchKernelGGL(k_init_layout, dim3(gridFor(D + 1)), dim3(kBlock), 0, stream, D, L, segStart[0].p, cnt[0].p,
-                           gen[0].vid, gen[0].drv);
+        if (!tiled) {
+            hipLaunchKernelGGL(k_init_layout, dim3(gridFor(D + 1)), dim3(kBlock), 0, stream, D, L, segStart[0].p, cnt[0].p,
+                               gen[0].vid, gen[0].drv);
+        } else {  // lanes own laneSpare[l] empty slots each
+            std::vector<int32_t> ss((size_t) D + 1);
+            int32_t run = 0;
+            for (int d = 0; d <= D; ++d) {
+                ss[d] = run;
+                if (d < L) run += hLaneSpare[d];
+            }
+            HIP_TRY(hipMemcpyAsync(segStart[0].p, ss.data(), ss.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemsetAsync(cnt[0].p, 0, (size_t) D * sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(gen[0].vid, 0xFF, (size_t) run * sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(gen[0].drv, 0xFF, (size_t) run * sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(gen[0].blocker, 0xFF, (size_t) run * sizeof(int32_t), stream));
+            HIP_TRY(hipStreamSynchronize(stream));  // ss lives on this frame
+            liveUpper = 2 * (int64_t) halo.nGhost;
+        }
         hipLaunchKernelGGL(k_init_lights, dim3(gridFor(I)), dim3(kBlock), 0, stream, net, curPhase, remain);
         HIP_TRY(hipMemsetAsync(waitHead, 0xFF, L * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(admitStep, 0xFF, L * sizeof(int32_t), stream));
@@ -335,6 +361,8 @@ void cfx_destroy(cfx_engine *e) {
         if (e->hPhaseStage[i]) (void) hipHostFree(e->hPhaseStage[i]);
         if (e->phaseStageEvent[i]) (void) hipEventDestroy(e->phaseStageEvent[i]);
     }
+    if (e->hHaloSend) (void) hipHostFree(e->hHaloSend);
+    if (e->hHaloRecv) (void) hipHostFree(e->hHaloRecv);
     if (e->stream) (void) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -524,12 +552,27 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->spawned += n;
     }
     // ---- slot capacity: live vehicles <= spawned - finished; plus one spare per lane
-    size_t need = (size_t) (e->spawned - (e->finishedKnown - e->finishedOffset)) + (size_t) e->L + 1;
-    if (need > e->slotCap) {
-        DevScalars s;
-        if ((rc = e->readScalars(s))) return rc;  // refresh finishedKnown
+    size_t need;
+    if (!e->tiled) {
         need = (size_t) (e->spawned - (e->finishedKnown - e->finishedOffset)) + (size_t) e->L + 1;
-        if ((rc = e->ensureSlotCap(need))) return rc;
+        if (need > e->slotCap) {
+            DevScalars s;
+            if ((rc = e->readScalars(s))) return rc;  // refresh finishedKnown
+            need = (size_t) (e->spawned - (e->finishedKnown - e->finishedOffset)) + (size_t) e->L + 1;
+            if ((rc = e->ensureSlotCap(need))) return rc;
+        }
+    } else {
+        // a tile sees every spawn record but runs only its own vehicles: bound = vehicles known to be here + what
+        // may have arrived since (local spawns, halo migrants), refreshed from the device when it runs out
+        for (int i = 0; i < n; ++i) e->liveUpper += recs[i].lane >= 0;
+        need = (size_t) (e->liveUpper + e->spareTotal) + 1;
+        if (need > e->slotCap) {
+            DevScalars s;
+            if ((rc = e->readScalars(s))) return rc;
+            e->liveUpper = s.active + 2 * (int64_t) e->halo.nGhost + n;
+            need = (size_t) (e->liveUpper + e->spareTotal) + 1;
+            if ((rc = e->ensureSlotCap(need))) return rc;
+        }
     }
 
     StepCtx c = e->ctx();
@@ -555,7 +598,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
                        e->scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
-                       e->gen[nxt].drv, e->sc);
+                       e->gen[nxt].drv, e->sc, e->net.laneSpare);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),
@@ -986,6 +1029,84 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     hipLaunchKernelGGL(k_refresh_next, dim3(gridStride(std::max(S, 1))), dim3(kBlock), 0, e->stream, e->ctx());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- tiling
+int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
+    if (!e || !h || h->n_ghost < 0 || h->n_import < 0) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    if (e->tiled || e->step != 0 || e->spawned != 0) {
+        e->err = "cfx_halo_config: must be called once, right after cfx_create";
+        return CFX_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    std::vector<uint8_t> ghost((size_t) e->L, 0);
+    e->hLaneSpare.assign((size_t) e->L, 1);
+    for (int i = 0; i < h->n_ghost; ++i) {
+        if (h->ghost_lane[i] < 0 || h->ghost_lane[i] >= e->L) return CFX_ERR_INVALID;
+        ghost[h->ghost_lane[i]] = 1;
+    }
+    for (int i = 0; i < h->n_import; ++i) {
+        if (h->import_lane[i] < 0 || h->import_lane[i] >= e->L) return CFX_ERR_INVALID;
+        e->hLaneSpare[h->import_lane[i]] = 1 + CFX_HALO_MAX_MIGRANTS;
+    }
+    e->spareTotal = 0;
+    for (uint8_t v : e->hLaneSpare) e->spareTotal += v;
+    int rc;
+    if ((rc = e->uploadConst(e->net.laneGhost, ghost.data(), ghost.size()))) return rc;
+    if ((rc = e->uploadConst(e->net.laneSpare, e->hLaneSpare.data(), e->hLaneSpare.size()))) return rc;
+    HaloDev &d = e->halo;
+    d.nGhost = h->n_ghost;
+    d.nImport = h->n_import;
+    if ((rc = e->uploadConst(d.ghostLane, h->ghost_lane, (size_t) h->n_ghost))) return rc;
+    if ((rc = e->uploadConst(d.ghostSendOff, h->ghost_send_off, (size_t) h->n_ghost))) return rc;
+    if ((rc = e->uploadConst(d.ghostRecvOff, h->ghost_recv_off, (size_t) h->n_ghost))) return rc;
+    if ((rc = e->uploadConst(d.importLane, h->import_lane, (size_t) h->n_import))) return rc;
+    if ((rc = e->uploadConst(d.importRecvOff, h->import_recv_off, (size_t) h->n_import))) return rc;
+    if ((rc = e->uploadConst(d.importSendOff, h->import_send_off, (size_t) h->n_import))) return rc;
+    if ((rc = e->uploadConst(d.llGlobal, h->lanelink_global, (size_t) e->K))) return rc;
+    if ((rc = e->uploadConst(d.llLocalOfGlobal, h->lanelink_local, (size_t) h->n_global_lanelinks))) return rc;
+    if ((rc = e->allocRaw(&d.ghostHadEntrants, (size_t) h->n_ghost))) return rc;
+    e->haloSendBytes = h->send_bytes;
+    e->haloRecvBytes = h->recv_bytes;
+    if ((rc = e->allocRaw(&e->dHaloSend, (size_t) h->send_bytes))) return rc;
+    if ((rc = e->allocRaw(&e->dHaloRecv, (size_t) h->recv_bytes))) return rc;
+    HIP_TRY(hipHostMalloc((void **) &e->hHaloSend, std::max(h->send_bytes, 1), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **) &e->hHaloRecv, std::max(h->recv_bytes, 1), hipHostMallocDefault));
+    e->tiled = true;
+    if ((rc = e->ensureSlotCap((size_t) e->spareTotal + 4096))) return rc;
+    return e->resetState();
+}
+
+int32_t cfx_halo_export(cfx_engine *e, void *sendHost) {
+    if (!e || !e->tiled || (!sendHost && e->haloSendBytes)) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    const int n = e->halo.nGhost + e->halo.nImport;
+    if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
+                              e->cs.inCnt, e->dHaloSend, e->sc);
+    HIP_TRY(hipGetLastError());
+    if (e->haloSendBytes) HIP_TRY(hipMemcpyAsync(e->hHaloSend, e->dHaloSend, (size_t) e->haloSendBytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->haloSendBytes) memcpy(sendHost, e->hHaloSend, (size_t) e->haloSendBytes);
+    return CFX_OK;
+}
+
+int32_t cfx_halo_import(cfx_engine *e, const void *recvHost) {
+    if (!e || !e->tiled || (!recvHost && e->haloRecvBytes)) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // the pinned staging buffer of the previous import may still be read
+    if (e->haloRecvBytes) {
+        memcpy(e->hHaloRecv, recvHost, (size_t) e->haloRecvBytes);
+        HIP_TRY(hipMemcpyAsync(e->dHaloRecv, e->hHaloRecv, (size_t) e->haloRecvBytes, hipMemcpyHostToDevice, e->stream));
+    }
+    const int n = e->halo.nGhost + e->halo.nImport;
+    if (n) hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
+                              e->dHaloRecv, e->vt, e->sc);
+    HIP_TRY(hipGetLastError());
+    e->liveUpper += (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS;
     return CFX_OK;
 }
 

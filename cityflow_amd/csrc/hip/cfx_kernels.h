@@ -88,6 +88,7 @@ __global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidT
     vt.enterTime[r.vid] = r.enter_time;
     vt.state[r.vid] = 0;
     vt.pendingCustom[r.vid] = 0;
+    if (r.lane < 0) return;  // tiling: the vehicle starts in another tile; only its static record is kept here
     // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367).  nextWait[] was pre-set to -1.
     if (r.prev_wait < 0) {
         waitHead[r.lane] = r.vid;
@@ -145,7 +146,8 @@ __global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *wa
     admitStep[lane] = c.step;
     waitHead[lane] = vt.nextWait[w];
     vt.state[w] = 1;
-    atomicAdd((unsigned long long *) &sc->active, 1ULL);
+    // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail => same decision)
+    if (!(c.n.laneGhost && c.n.laneGhost[lane])) atomicAdd((unsigned long long *) &sc->active, 1ULL);
 }
 
 // Per-laneLink sources of Engine::threadNotifyCross (engine.cpp:317-372): the vehicle that just left
@@ -423,6 +425,13 @@ __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, Jo
         const int nd0 = c.s.next[s];
         const int flags = c.s.flags[s];
         if (vid < 0) continue;
+        if (c.n.laneGhost && d < c.n.L && c.n.laneGhost[d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
+            o.b.dis[s] = dis;
+            o.b.speed[s] = speed;
+            o.b.drv[s] = -1;
+            o.b.blocker[s] = -1;
+            continue;
+        }
         const bool head = s == 0 || dPrev != d;
         const cfx_vehicle_template &t = tv[templIdx];
         const double interval = c.interval;
@@ -681,7 +690,7 @@ __device__ inline void finishStatistics(const StepCtx &c, const VidTable &vt, De
 __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cnt, CompactScratch cs,
                                                  unsigned long long *granules, int32_t *ticket, unsigned epoch,
                                                  int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
-                                                 int32_t *drvNext, DevScalars *sc) {
+                                                 int32_t *drvNext, DevScalars *sc, const uint8_t *laneSpare) {
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
     __shared__ int tileShared;
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
         int d = base + i;
         int nl = d < D ? newLiveCount(cnt, cs, d) : 0;
         live[i] = nl;
-        vals[i] = d < D ? nl + (d < L ? 1 : 0) : 0;
+        vals[i] = d < D ? nl + (d < L ? (laneSpare ? (int) laneSpare[d] : 1) : 0) : 0;
         sum += vals[i];
     }
     // in-wave inclusive scan of the per-thread sums, wave totals to LDS
@@ -747,9 +756,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
         if (d < D) {
             segStartNext[d] = off0;
             cntNext[d] = live[i];
-            if (d < L) {  // the lane's spare slot of the next generation
-                vidNext[off0 + live[i]] = -1;
-                drvNext[off0 + live[i]] = -1;
+            for (int j = live[i]; j < vals[i]; ++j) {  // the lane's spare slot(s) of the next generation
+                vidNext[off0 + j] = -1;
+                drvNext[off0 + j] = -1;
             }
             off0 += vals[i];
             if (d == D - 1) segStartNext[D] = off0;
@@ -906,6 +915,176 @@ __global__ void k_find_vehicle(StepCtx c, int vid, int32_t *out /*[2]: drivable,
             out[0] = c.s.drv[s];
             out[1] = c.s.routePos[s];
         }
+}
+
+// ---------------------------------------------------------------------------------------------- tiling halo
+// One road network over several engines (include/cityflow_amd.h, "Tiling").  Runs on the generation produced by
+// this step's k_scatter; cs.inCnt still holds the step's per-drivable entrant counts.
+struct HaloDev {
+    int nGhost, nImport;
+    const int32_t *ghostLane, *ghostSendOff, *ghostRecvOff, *importLane, *importRecvOff, *importSendOff;
+    const int32_t *llGlobal;         // [K] local laneLink -> global id
+    const int32_t *llLocalOfGlobal;  // [global K] -> local laneLink or -1
+    uint8_t *ghostHadEntrants;       // [nGhost] this step's export found entrants (the proxy is already current)
+};
+
+struct HaloMigrant {
+    int32_t vid, routePos, prevLL, pad;
+    double dis, speed;
+};
+struct HaloTail {
+    int32_t vid, prevLL;
+    double dis, speed;
+};
+static_assert(sizeof(HaloMigrant) == 32 && sizeof(HaloTail) == CFX_HALO_TAIL_BYTES, "halo record layout");
+
+__device__ inline void haloClearSlot(const SlotArrays &s, int slot) {
+    s.vid[slot] = -1;
+    s.drv[slot] = -1;
+    s.blocker[slot] = -1;
+}
+
+__device__ inline int haloGlobalPrev(const StepCtx &c, const HaloDev &h, int prevDrv) {
+    if (prevDrv >= c.n.L) return h.llGlobal[prevDrv - c.n.L];
+    if (prevDrv <= -2) return -prevDrv - 2;  // a migrant's laneLink of origin, kept as its global id
+    return -1;
+}
+
+__global__ void k_halo_export(StepCtx c, int32_t *cnt, HaloDev h, const int32_t *inCnt, char *send, DevScalars *sc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < h.nGhost) {
+        // upstream side: the vehicles that entered the ghost lane this step are the last `in` of its segment
+        // (entrants are appended behind the stayers, already sorted like Lane::vehicles)
+        const int g = h.ghostLane[i];
+        const int base = c.segStart[g], n = cnt[g], in = inCnt[g];
+        char *blk = send + h.ghostSendOff[i];
+        int m = in;
+        if (m > CFX_HALO_MAX_MIGRANTS) {
+            m = CFX_HALO_MAX_MIGRANTS;
+            sc->overflow = 3;
+        }
+        ((int32_t *) blk)[0] = m;
+        ((int32_t *) blk)[1] = 0;
+        HaloMigrant *rec = (HaloMigrant *) (blk + 8);
+        for (int j = 0; j < m; ++j) {
+            const int s = base + n - in + j;
+            HaloMigrant r;
+            r.vid = c.s.vid[s];
+            r.routePos = c.s.routePos[s];
+            r.prevLL = haloGlobalPrev(c, h, c.s.prevDrv[s]);
+            r.pad = 0;
+            r.dis = c.s.dis[s];
+            r.speed = c.s.speed[s];
+            rec[j] = r;
+        }
+        h.ghostHadEntrants[i] = in > 0;
+        if (in > 0) {
+            // keep only the new tail as this lane's proxy, in the segment's first slot
+            const int last = base + n - 1;
+            if (last != base) {
+                c.s.vid[base] = c.s.vid[last];
+                c.s.prevDrv[base] = c.s.prevDrv[last];
+                c.s.next[base] = c.s.next[last];
+                c.s.enterLLT[base] = c.s.enterLLT[last];
+                c.s.routePos[base] = c.s.routePos[last];
+                c.s.templ[base] = c.s.templ[last];
+                c.s.route[base] = c.s.route[last];
+                c.s.dis[base] = c.s.dis[last];
+                c.s.speed[base] = c.s.speed[last];
+            }
+            c.s.drv[base] = g;
+            c.s.blocker[base] = -1;
+            c.s.flags[base] = 0;
+            for (int s = base + 1; s < base + n; ++s) haloClearSlot(c.s, s);
+            cnt[g] = 1;
+            atomicAdd((unsigned long long *) &sc->active, (unsigned long long) (-(long long) in));
+        }
+        return;
+    }
+    const int j = i - h.nGhost;
+    if (j < h.nImport) {
+        // downstream side: report the lane's tail (before this step's migrants are appended)
+        const int l = h.importLane[j];
+        const int n = cnt[l];
+        HaloTail t;
+        if (n > 0) {
+            const int s = c.segStart[l] + n - 1;
+            t.vid = c.s.vid[s];
+            t.prevLL = haloGlobalPrev(c, h, c.s.prevDrv[s]);
+            t.dis = c.s.dis[s];
+            t.speed = c.s.speed[s];
+        } else {
+            t.vid = -1;
+            t.prevLL = -1;
+            t.dis = 0.0;
+            t.speed = 0.0;
+        }
+        *(HaloTail *) (send + h.importSendOff[j]) = t;
+    }
+}
+
+__global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, const char *recv, VidTable vt, DevScalars *sc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < h.nImport) {
+        const int l = h.importLane[i];
+        const char *blk = recv + h.importRecvOff[i];
+        const int m = ((const int32_t *) blk)[0];
+        const HaloMigrant *rec = (const HaloMigrant *) (blk + 8);
+        const int base = c.segStart[l], n = cnt[l];
+        for (int j = 0; j < m; ++j) {
+            const HaloMigrant r = rec[j];
+            const int s = base + n + j;
+            const int route = vt.route[r.vid];
+            c.s.vid[s] = r.vid;
+            c.s.drv[s] = l;
+            c.s.prevDrv[s] = r.prevLL >= 0 ? -(r.prevLL + 2) : -1;
+            c.s.next[s] = nextOf(c.n, c.t, l, route, r.routePos);
+            c.s.blocker[s] = -1;  // a vehicle that left its laneLink this step was not yielding (no blocker set)
+            c.s.enterLLT[s] = CFX_INT_MAX;
+            c.s.routePos[s] = r.routePos;
+            c.s.templ[s] = vt.templ[r.vid];
+            c.s.route[s] = route;
+            c.s.flags[s] = 0;
+            c.s.dis[s] = r.dis;
+            c.s.speed[s] = r.speed;
+            vt.state[r.vid] = 1;
+        }
+        if (m > 0) {
+            cnt[l] = n + m;
+            atomicAdd((unsigned long long *) &sc->active, (unsigned long long) m);
+        }
+        return;
+    }
+    const int j = i - h.nImport;
+    if (j < h.nGhost && !h.ghostHadEntrants[j]) {
+        // no entrant of our own this step: the owner's tail is the lane's tail
+        const int g = h.ghostLane[j];
+        const HaloTail t = *(const HaloTail *) (recv + h.ghostRecvOff[j]);
+        const int base = c.segStart[g], n = cnt[g];
+        for (int s = base + (t.vid >= 0 ? 1 : 0); s < base + n; ++s) haloClearSlot(c.s, s);
+        if (t.vid < 0) {
+            cnt[g] = 0;
+            return;
+        }
+        int prev = -1;
+        if (t.prevLL >= 0) {
+            const int k = h.llLocalOfGlobal[t.prevLL];
+            prev = k >= 0 ? c.n.L + k : -(t.prevLL + 2);
+        }
+        c.s.vid[base] = t.vid;
+        c.s.drv[base] = g;
+        c.s.prevDrv[base] = prev;
+        c.s.next[base] = -1;
+        c.s.blocker[base] = -1;
+        c.s.enterLLT[base] = CFX_INT_MAX;
+        c.s.routePos[base] = 0;
+        c.s.templ[base] = vt.templ[t.vid];
+        c.s.route[base] = vt.route[t.vid];
+        c.s.flags[base] = 0;
+        c.s.dis[base] = t.dis;
+        c.s.speed[base] = t.speed;
+        cnt[g] = 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- getters

@@ -57,6 +57,9 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_get_vehicle)
     CFX_FN(cfx_load_state)
     CFX_FN(cfx_get_custom_speeds)
+    CFX_FN(cfx_halo_config)
+    CFX_FN(cfx_halo_export)
+    CFX_FN(cfx_halo_import)
     CFX_FN(cfx_profile_kernel_count)
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)

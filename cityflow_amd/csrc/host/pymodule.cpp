@@ -1,6 +1,7 @@
 // pybind11 binding of the drop-in `cityflow` module.  Same class name, method names, argument names and
 // defaults as the reference binding (reference src/cityflow.cpp:10-47); extra members are prefixed or
 // clearly array-flavoured and never change the behaviour of the reference-named ones.
+#include <pybind11/functional.h>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -9,6 +10,7 @@
 #include <iostream>
 
 #include "engine_host.h"
+#include "tile_engine.h"
 #include "vector_engine.h"
 #include "json.h"
 
@@ -328,6 +330,90 @@ PYBIND11_MODULE(_cityflow, m) {
             d["active_vehicle_count"] = s.active_vehicle_count;
             d["finished_vehicle_count"] = s.finished_vehicle_count;
             d["spawned_vehicle_count"] = s.spawned_vehicle_count;
+            d["vehicle_steps"] = s.vehicle_steps;
+            return d;
+        });
+
+    using cfa::TiledEngineHost;
+    py::class_<TiledEngineHost>(m, "TiledEngine",
+                                "One road network cut into rows x cols tiles of intersections, one device engine per tile, a "
+                                "one-lane halo exchanged per step.  With local_tiles empty every tile runs in this process "
+                                "(next_step does the exchange); otherwise the caller moves the halo between step_begin and "
+                                "step_end (cityflow_amd.tiled.DistributedEngine does it over torch.distributed).")
+        .def(py::init<const std::string &, int, int, const std::vector<int> &, const std::string &>(), "config_file"_a,
+             "rows"_a, "cols"_a, "local_tiles"_a = std::vector<int>(), "backend_library"_a = "")
+        .def("next_step", &TiledEngineHost::nextStep)
+        .def("step_begin", &TiledEngineHost::stepBegin)
+        .def("step_end", &TiledEngineHost::stepEnd)
+        .def_property_readonly("num_tiles", &TiledEngineHost::nTiles)
+        .def_property_readonly("num_local", &TiledEngineHost::nLocal)
+        .def("local_rank", &TiledEngineHost::localRank, "i"_a)
+        .def("peers",
+             [](TiledEngineHost &e, int i) {
+                 py::list out;
+                 for (const cfa::TilePeer &p : e.peers(i))
+                     out.append(py::make_tuple(p.rank, p.sendOff, p.sendBytes, p.recvOff, p.recvBytes));
+                 return out;
+             },
+             "i"_a, "[(peer tile, send offset, send bytes, recv offset, recv bytes)] of local tile i")
+        // zero-copy views of the halo staging buffers of local tile i (valid while the engine lives)
+        .def("send_buffer",
+             [](py::object self, int i) {
+                 auto &e = self.cast<TiledEngineHost &>();
+                 auto &b = e.sendBuffer(i);
+                 return py::array_t<uint8_t>({(py::ssize_t) b.size()}, {1}, (const uint8_t *) b.data(), self);
+             },
+             "i"_a)
+        .def("recv_buffer",
+             [](py::object self, int i) {
+                 auto &e = self.cast<TiledEngineHost &>();
+                 auto &b = e.recvBuffer(i);
+                 return py::array_t<uint8_t>({(py::ssize_t) b.size()}, {1}, (const uint8_t *) b.data(), self);
+             },
+             "i"_a)
+        .def("get_vehicle_count", &TiledEngineHost::getVehicleCount)
+        .def("get_lane_vehicle_count", &TiledEngineHost::getLaneVehicleCount)
+        .def("get_lane_waiting_vehicle_count", &TiledEngineHost::getLaneWaitingVehicleCount)
+        .def("get_lane_vehicle_count_array", [](TiledEngineHost &e) { return toArray(e.laneVehicleCountArray()); })
+        .def("get_lane_waiting_vehicle_count_array", [](TiledEngineHost &e) { return toArray(e.laneWaitingVehicleCountArray()); })
+        .def("get_current_time", &TiledEngineHost::getCurrentTime)
+        .def("set_tl_phase", &TiledEngineHost::setTrafficLightPhase, "intersection_id"_a, "phase_id"_a)
+        .def("set_tl_phases",
+             [](TiledEngineHost &e, py::array_t<int32_t, py::array::c_style | py::array::forcecast> phases) {
+                 e.setTrafficLightPhases(std::vector<int32_t>(phases.data(), phases.data() + phases.size()));
+             },
+             "phases"_a)
+        .def("reset", &TiledEngineHost::reset, "seed"_a = false)
+        .def("sync", &TiledEngineHost::sync)
+        .def("lane_ids", &TiledEngineHost::laneIds)
+        .def("owner", &TiledEngineHost::owner, "owning tile of every intersection (index order of the roadnet file)")
+        .def("_set_status_reducer", &TiledEngineHost::setStatusReducer, "fn"_a)
+        .def("_vehicle_state",
+             [](TiledEngineHost &e) {
+                 cfa::VehicleSnapshot s;
+                 e.snapshotVehicles(s);
+                 py::dict d;
+                 d["vid"] = toArray(s.vid);
+                 d["drivable"] = toArray(s.drivable);
+                 d["prev_drivable"] = toArray(s.prevDrivable);
+                 d["leader"] = toArray(s.leader);
+                 d["blocker"] = toArray(s.blocker);
+                 d["enter_ll_time"] = toArray(s.enterLLTime);
+                 d["route_pos"] = toArray(s.routePos);
+                 d["dis"] = toArray(s.dis);
+                 d["speed"] = toArray(s.speed);
+                 d["gap"] = toArray(s.gap);
+                 return d;
+             })
+        .def("_scalars", [](TiledEngineHost &e) {
+            cfx_scalars s = e.scalars();
+            py::dict d;
+            d["step"] = s.step;
+            d["active_vehicle_count"] = s.active_vehicle_count;
+            d["finished_vehicle_count"] = s.finished_vehicle_count;
+            d["spawned_vehicle_count"] = s.spawned_vehicle_count;
+            d["cumulative_travel_time"] = s.cumulative_travel_time;
+            d["live_enter_time_sum"] = s.live_enter_time_sum;
             d["vehicle_steps"] = s.vehicle_steps;
             return d;
         });

@@ -1,0 +1,629 @@
+#include "tile_engine.h"
+
+#include <algorithm>
+#include <iostream>
+#include <numeric>
+#include <stdexcept>
+
+#include "json.h"
+
+namespace cfa {
+
+// ---------------------------------------------------------------- partition
+std::vector<int> gridPartition(const HostRoadNet &net, int rows, int cols) {
+    if (rows < 1 || cols < 1) throw std::runtime_error("tiling: rows and cols must be positive");
+    const int I = (int) net.inters.size();
+    std::vector<double> xs, ys;
+    for (const HostInter &in : net.inters)
+        if (!in.isVirtual) {
+            xs.push_back(in.point.x);
+            ys.push_back(in.point.y);
+        }
+    auto distinct = [](std::vector<double> &v) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    };
+    distinct(xs);
+    distinct(ys);
+    if ((int) xs.size() < cols || (int) ys.size() < rows)
+        throw std::runtime_error("tiling: more tiles than intersection rows/columns");
+    auto block = [](const std::vector<double> &v, double x, int parts) {
+        int idx = (int) (std::lower_bound(v.begin(), v.end(), x) - v.begin());
+        return (int) ((long long) idx * parts / (long long) v.size());
+    };
+    std::vector<int> owner(I, -1);
+    for (int i = 0; i < I; ++i) {
+        const HostInter &in = net.inters[i];
+        if (!in.isVirtual) owner[i] = block(ys, in.point.y, rows) * cols + block(xs, in.point.x, cols);
+    }
+    for (int i = 0; i < I; ++i) {
+        if (owner[i] >= 0) continue;
+        for (int r : net.inters[i].roads) {
+            int other = net.roads[r].startInter == i ? net.roads[r].endInter : net.roads[r].startInter;
+            if (other >= 0 && owner[other] >= 0) {
+                owner[i] = owner[other];
+                break;
+            }
+        }
+        if (owner[i] < 0) owner[i] = 0;  // isolated virtual intersection
+    }
+    return owner;
+}
+
+// ---------------------------------------------------------------- sub-network
+void TileNet::build(const HostRoadNet &net, const std::vector<int> &owner, int rk) {
+    rank = rk;
+    const cfx_net &g = net.flat();
+    const int L = g.n_lanes, K = g.n_lanelinks, I = g.n_inters, R = g.n_roads;
+    auto upOf = [&](int lane) { return owner[net.roads[g.lane_road[lane]].startInter]; };
+    auto downOf = [&](int lane) { return owner[net.roads[g.lane_road[lane]].endInter]; };
+
+    laneG2L.assign(L, -1);
+    llG2L.assign(K, -1);
+    interG2L.assign(I, -1);
+    roadG2L.assign(R, -1);
+    laneL2G.clear();
+    llL2G.clear();
+    interL2G.clear();
+    roadL2G.clear();
+    laneGhost.clear();
+    for (int l = 0; l < L; ++l) {
+        const bool owned = downOf(l) == rank;
+        if (!owned && upOf(l) != rank) continue;
+        laneG2L[l] = (int32_t) laneL2G.size();
+        laneL2G.push_back(l);
+        laneGhost.push_back(owned ? 0 : 1);
+        const int r = g.lane_road[l];
+        if (roadG2L[r] < 0) {  // lanes are grouped by road and roads ascend with lanes
+            roadG2L[r] = (int32_t) roadL2G.size();
+            roadL2G.push_back(r);
+        }
+    }
+    for (int k = 0; k < K; ++k)
+        if (owner[g.ll_inter[k]] == rank) {
+            llG2L[k] = (int32_t) llL2G.size();
+            llL2G.push_back(k);
+        }
+    for (int i = 0; i < I; ++i)
+        if (owner[i] == rank) {
+            interG2L[i] = (int32_t) interL2G.size();
+            interL2G.push_back(i);
+        }
+    const int nL = (int) laneL2G.size(), nK = (int) llL2G.size(), nI = (int) interL2G.size(), nR = (int) roadL2G.size();
+
+    drvLength_.resize(nL + nK);
+    drvMaxSpeed_.resize(nL + nK);
+    laneRoad_.resize(nL);
+    laneIndex_.resize(nL);
+    laneLLStart_.assign(nL + 1, 0);
+    laneLL_.clear();
+    roadLaneStart_.assign(nR + 1, 0);
+    for (int l = 0; l < nL; ++l) {
+        const int gl = laneL2G[l];
+        drvLength_[l] = g.drv_length[gl];
+        drvMaxSpeed_[l] = g.drv_max_speed[gl];
+        laneRoad_[l] = roadG2L[g.lane_road[gl]];
+        laneIndex_[l] = g.lane_index[gl];
+        laneLLStart_[l] = (int32_t) laneLL_.size();
+        for (int q = g.lane_ll_start[gl]; q < g.lane_ll_start[gl + 1]; ++q) {
+            int k = llG2L[g.lane_ll[q]];
+            if (k >= 0) laneLL_.push_back(k);
+        }
+        roadLaneStart_[laneRoad_[l] + 1] = l + 1;
+    }
+    laneLLStart_[nL] = (int32_t) laneLL_.size();
+    for (int r = 0; r < nR; ++r) roadLaneStart_[r + 1] = std::max(roadLaneStart_[r + 1], roadLaneStart_[r]);
+
+    llStartLane_.resize(nK);
+    llEndLane_.resize(nK);
+    llInter_.resize(nK);
+    llRoadLink_.resize(nK);
+    llType_.resize(nK);
+    llXStart_.assign(nK + 1, 0);
+    xDist_.clear();
+    xLL_.clear();
+    xPeer_.clear();
+    std::vector<int32_t> eG2L((size_t) g.n_xentries, -1), eL2G;
+    for (int k = 0; k < nK; ++k) {
+        const int gk = llL2G[k];
+        drvLength_[nL + k] = g.drv_length[L + gk];
+        drvMaxSpeed_[nL + k] = g.drv_max_speed[L + gk];
+        llStartLane_[k] = laneG2L[g.ll_start_lane[gk]];
+        llEndLane_[k] = laneG2L[g.ll_end_lane[gk]];
+        if (llStartLane_[k] < 0 || llEndLane_[k] < 0) throw std::runtime_error("tiling: laneLink with a lane outside its tile");
+        llInter_[k] = interG2L[g.ll_inter[gk]];
+        llRoadLink_[k] = g.ll_roadlink[gk];
+        llType_[k] = g.ll_type[gk];
+        llXStart_[k] = (int32_t) xDist_.size();
+        for (int e = g.ll_x_start[gk]; e < g.ll_x_start[gk + 1]; ++e) {
+            eG2L[e] = (int32_t) xDist_.size();
+            eL2G.push_back(e);
+            xDist_.push_back(g.x_dist[e]);
+            xLL_.push_back(k);
+        }
+    }
+    llXStart_[nK] = (int32_t) xDist_.size();
+    xPeer_.resize(xDist_.size());
+    for (size_t e = 0; e < eL2G.size(); ++e) {
+        xPeer_[e] = eG2L[g.x_peer[eL2G[e]]];
+        if (xPeer_[e] < 0) throw std::runtime_error("tiling: cross between laneLinks of different tiles");
+    }
+
+    interVirtual_.resize(nI);
+    interNRL_.resize(nI);
+    interPhaseStart_.assign(nI + 1, 0);
+    interAvailStart_.resize(nI);
+    phaseTime_.clear();
+    phaseAvail_.clear();
+    for (int i = 0; i < nI; ++i) {
+        const int gi = interL2G[i];
+        interVirtual_[i] = g.inter_virtual[gi];
+        interNRL_[i] = g.inter_n_roadlinks[gi];
+        interPhaseStart_[i] = (int32_t) phaseTime_.size();
+        interAvailStart_[i] = (int32_t) phaseAvail_.size();
+        const int np = g.inter_phase_start[gi + 1] - g.inter_phase_start[gi];
+        for (int p = 0; p < np; ++p) phaseTime_.push_back(g.phase_time[g.inter_phase_start[gi] + p]);
+        const uint8_t *av = g.phase_avail + g.inter_avail_start[gi];
+        phaseAvail_.insert(phaseAvail_.end(), av, av + (size_t) np * g.inter_n_roadlinks[gi]);
+    }
+    interPhaseStart_[nI] = (int32_t) phaseTime_.size();
+
+    flat = cfx_net{};
+    flat.n_roads = nR;
+    flat.n_lanes = nL;
+    flat.n_lanelinks = nK;
+    flat.n_inters = nI;
+    flat.n_xentries = (int32_t) xDist_.size();
+    flat.n_phases = (int32_t) phaseTime_.size();
+    flat.n_avail = (int32_t) phaseAvail_.size();
+    flat.drv_length = drvLength_.data();
+    flat.drv_max_speed = drvMaxSpeed_.data();
+    flat.lane_road = laneRoad_.data();
+    flat.lane_index = laneIndex_.data();
+    flat.lane_ll_start = laneLLStart_.data();
+    flat.lane_ll = laneLL_.data();
+    flat.road_lane_start = roadLaneStart_.data();
+    flat.ll_start_lane = llStartLane_.data();
+    flat.ll_end_lane = llEndLane_.data();
+    flat.ll_inter = llInter_.data();
+    flat.ll_roadlink = llRoadLink_.data();
+    flat.ll_type = llType_.data();
+    flat.ll_x_start = llXStart_.data();
+    flat.x_dist = xDist_.data();
+    flat.x_peer = xPeer_.data();
+    flat.x_ll = xLL_.data();
+    flat.inter_virtual = interVirtual_.data();
+    flat.inter_n_roadlinks = interNRL_.data();
+    flat.inter_phase_start = interPhaseStart_.data();
+    flat.inter_avail_start = interAvailStart_.data();
+    flat.phase_time = phaseTime_.data();
+    flat.phase_avail = phaseAvail_.data();
+
+    // ---- halo layout.  The message between two tiles lists their cut lanes in ascending global lane id; each
+    //      lane contributes a migrant block in the upstream -> downstream message and a tail block the other way.
+    struct Cut {
+        int lane, peer;
+        bool up;  // this tile is the upstream side
+    };
+    std::vector<Cut> cuts;
+    for (int l = 0; l < L; ++l) {
+        const int u = upOf(l), d = downOf(l);
+        if (u == d) continue;
+        if (u == rank) cuts.push_back({l, d, true});
+        else if (d == rank) cuts.push_back({l, u, false});
+    }
+    peers.clear();
+    {
+        std::vector<int> ranks;
+        for (const Cut &c : cuts) ranks.push_back(c.peer);
+        std::sort(ranks.begin(), ranks.end());
+        ranks.erase(std::unique(ranks.begin(), ranks.end()), ranks.end());
+        for (int r : ranks) {
+            TilePeer p;
+            p.rank = r;
+            peers.push_back(p);
+        }
+    }
+    auto peerOf = [&](int r) -> TilePeer & {
+        for (TilePeer &p : peers)
+            if (p.rank == r) return p;
+        throw std::logic_error("tiling: unknown peer");
+    };
+    for (const Cut &c : cuts) {
+        TilePeer &p = peerOf(c.peer);
+        p.sendBytes += c.up ? CFX_HALO_MIG_BYTES : CFX_HALO_TAIL_BYTES;
+        p.recvBytes += c.up ? CFX_HALO_TAIL_BYTES : CFX_HALO_MIG_BYTES;
+    }
+    sendBytes = recvBytes = 0;
+    for (TilePeer &p : peers) {
+        p.sendOff = sendBytes;
+        p.recvOff = recvBytes;
+        sendBytes += p.sendBytes;
+        recvBytes += p.recvBytes;
+    }
+    ghostLane.clear();
+    ghostSendOff.clear();
+    ghostRecvOff.clear();
+    importLane.clear();
+    importRecvOff.clear();
+    importSendOff.clear();
+    std::vector<int> sendCur(peers.size()), recvCur(peers.size());
+    for (size_t i = 0; i < peers.size(); ++i) {
+        sendCur[i] = peers[i].sendOff;
+        recvCur[i] = peers[i].recvOff;
+    }
+    for (const Cut &c : cuts) {
+        size_t pi = 0;
+        while (peers[pi].rank != c.peer) ++pi;
+        if (c.up) {
+            ghostLane.push_back(laneG2L[c.lane]);
+            ghostSendOff.push_back(sendCur[pi]);
+            ghostRecvOff.push_back(recvCur[pi]);
+            sendCur[pi] += CFX_HALO_MIG_BYTES;
+            recvCur[pi] += CFX_HALO_TAIL_BYTES;
+        } else {
+            importLane.push_back(laneG2L[c.lane]);
+            importSendOff.push_back(sendCur[pi]);
+            importRecvOff.push_back(recvCur[pi]);
+            sendCur[pi] += CFX_HALO_TAIL_BYTES;
+            recvCur[pi] += CFX_HALO_MIG_BYTES;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- one tile
+TileEngine::TileEngine(std::shared_ptr<HostRoadNet> net, const std::vector<int> &owner, int rank, const EngineConfig &cfg,
+                       Backend *be, int device)
+    : net_(std::move(net)), be_(be) {
+    tn_.build(*net_, owner, rank);
+    cfx_config cc{};
+    cc.interval = cfg.interval;
+    cc.rl_traffic_light = cfg.rlTrafficLight ? 1 : 0;
+    cc.device = device;
+    int32_t rc = be_->cfx_create(&tn_.flat, &cc, &dev_);
+    if (rc != CFX_OK || !dev_) {
+        const char *msg = be_->cfx_last_error(nullptr);
+        throw std::runtime_error(std::string("cityflow_amd: cfx_create (tile ") + std::to_string(rank) + ") failed in " +
+                                 be_->path + ": " + (msg ? msg : "unknown error") + " (there is no CPU fallback)");
+    }
+    cfx_halo_layout h{};
+    h.n_ghost = (int32_t) tn_.ghostLane.size();
+    h.ghost_lane = tn_.ghostLane.data();
+    h.ghost_send_off = tn_.ghostSendOff.data();
+    h.ghost_recv_off = tn_.ghostRecvOff.data();
+    h.n_import = (int32_t) tn_.importLane.size();
+    h.import_lane = tn_.importLane.data();
+    h.import_recv_off = tn_.importRecvOff.data();
+    h.import_send_off = tn_.importSendOff.data();
+    h.send_bytes = tn_.sendBytes;
+    h.recv_bytes = tn_.recvBytes;
+    h.n_global_lanelinks = (int32_t) tn_.llG2L.size();
+    h.lanelink_global = tn_.llL2G.data();
+    h.lanelink_local = tn_.llG2L.data();
+    check(be_->cfx_halo_config(dev_, &h), "cfx_halo_config");
+    send.assign((size_t) tn_.sendBytes, 0);
+    recv.assign((size_t) tn_.recvBytes, 0);
+}
+
+TileEngine::~TileEngine() {
+    if (dev_) be_->cfx_destroy(dev_);
+}
+
+void TileEngine::check(int32_t rc, const char *what) {
+    if (rc == CFX_OK) return;
+    const char *msg = be_->cfx_last_error(dev_);
+    throw std::runtime_error(std::string("cityflow_amd: ") + what + " failed on tile " + std::to_string(tn_.rank) + " (" +
+                             std::to_string(rc) + "): " + (msg ? msg : ""));
+}
+
+void TileEngine::uploadTables(const Spawner &sp) {
+    const int nt = (int) sp.templates.size();
+    if (nt > templatesUploaded_) {
+        // the halo is one lane deep: nothing may look or move past a cut lane within one step
+        double minCut = 1e300;
+        for (int l : tn_.ghostLane) minCut = std::min(minCut, tn_.flat.drv_length[l]);
+        for (int l : tn_.importLane) minCut = std::min(minCut, tn_.flat.drv_length[l]);
+        for (int t = templatesUploaded_; t < nt; ++t)
+            if (sp.templates[t].approach_dist + sp.templates[t].len >= minCut)
+                throw std::runtime_error("cityflow_amd: tiling needs every cut lane to be longer than a vehicle's look-ahead (" +
+                                         std::to_string(sp.templates[t].approach_dist) + " m); shortest cut lane is " +
+                                         std::to_string(minCut) + " m");
+        check(be_->cfx_add_templates(dev_, nt - templatesUploaded_, sp.templates.data() + templatesUploaded_), "cfx_add_templates");
+        templatesUploaded_ = nt;
+    }
+    const RouteTable &rt = sp.routes;
+    const int nr = rt.count();
+    if (nr > routesUploaded_) {
+        std::vector<int32_t> routeStart{0}, roads, nextStart{0}, nextLL;
+        for (int r = routesUploaded_; r < nr; ++r) {
+            for (int p = rt.routeStart[r]; p < rt.routeStart[r + 1]; ++p) {
+                const int lroad = tn_.roadG2L[rt.roads[p]];
+                roads.push_back(lroad);
+                if (lroad >= 0)
+                    for (int q = rt.nextStart[p]; q < rt.nextStart[p + 1]; ++q)
+                        nextLL.push_back(rt.nextLL[q] >= 0 ? tn_.llG2L[rt.nextLL[q]] : -1);
+                nextStart.push_back((int32_t) nextLL.size());
+            }
+            routeStart.push_back((int32_t) roads.size());
+        }
+        check(be_->cfx_add_routes(dev_, nr - routesUploaded_, routeStart.data(), roads.data(), nextStart.data(), nextLL.data()),
+              "cfx_add_routes");
+        routesUploaded_ = nr;
+    }
+}
+
+void TileEngine::step(const std::vector<cfx_spawn> &globalRecs) {
+    recs_ = globalRecs;
+    for (cfx_spawn &r : recs_) r.lane = tn_.laneG2L[r.lane];
+    check(be_->cfx_step(dev_, recs_.data(), (int32_t) recs_.size()), "cfx_step");
+}
+
+void TileEngine::haloExport() { check(be_->cfx_halo_export(dev_, send.data()), "cfx_halo_export"); }
+void TileEngine::haloImport() { check(be_->cfx_halo_import(dev_, recv.data()), "cfx_halo_import"); }
+void TileEngine::reset() { check(be_->cfx_reset(dev_), "cfx_reset"); }
+void TileEngine::sync() { check(be_->cfx_sync(dev_), "cfx_sync"); }
+
+void TileEngine::addLaneCounts(std::vector<int32_t> &global, bool waiting) {
+    std::vector<int32_t> local(tn_.laneL2G.size());
+    if (waiting) check(be_->cfx_get_lane_waiting_counts(dev_, local.data()), "cfx_get_lane_waiting_counts");
+    else check(be_->cfx_get_lane_counts(dev_, local.data()), "cfx_get_lane_counts");
+    for (size_t l = 0; l < local.size(); ++l)
+        if (!tn_.laneGhost[l]) global[tn_.laneL2G[l]] = local[l];
+}
+
+cfx_scalars TileEngine::scalars() {
+    cfx_scalars s{};
+    check(be_->cfx_get_scalars(dev_, &s), "cfx_get_scalars");
+    return s;
+}
+
+void TileEngine::mergeStatus(int first, int n, uint8_t *inout) {
+    std::vector<uint8_t> st((size_t) std::max(n, 1));
+    check(be_->cfx_get_vehicle_status(dev_, first, n, st.data()), "cfx_get_vehicle_status");
+    for (int i = 0; i < n; ++i) inout[i] = std::max(inout[i], st[i]);
+}
+
+void TileEngine::setPhases(const std::vector<int32_t> &globalInter, const std::vector<int32_t> &phase) {
+    std::vector<int32_t> in, ph;
+    for (size_t i = 0; i < globalInter.size(); ++i) {
+        int li = tn_.interG2L[globalInter[i]];
+        if (li < 0) continue;
+        in.push_back(li);
+        ph.push_back(phase[i]);
+    }
+    if (!in.empty()) check(be_->cfx_set_tl_phases(dev_, (int32_t) in.size(), in.data(), ph.data()), "cfx_set_tl_phases");
+}
+
+void TileEngine::appendVehicles(VehicleSnapshot &out) {
+    const int cap = (int) scalars().active_vehicle_count + 2 * (int) tn_.ghostLane.size() + 16;
+    std::vector<int32_t> vid(cap), drv(cap), prev(cap), lead(cap), blk(cap), ellt(cap), rpos(cap);
+    std::vector<double> dis(cap), speed(cap), gap(cap);
+    cfx_vehicle_view v{};
+    v.capacity = cap;
+    v.vid = vid.data();
+    v.drivable = drv.data();
+    v.prev_drivable = prev.data();
+    v.leader_vid = lead.data();
+    v.blocker_vid = blk.data();
+    v.enter_ll_time = ellt.data();
+    v.route_pos = rpos.data();
+    v.dis = dis.data();
+    v.speed = speed.data();
+    v.gap = gap.data();
+    check(be_->cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
+    const int nL = (int) tn_.laneL2G.size(), gL = (int) tn_.laneG2L.size();
+    auto toGlobal = [&](int d) {
+        if (d <= -2) return gL + (-d - 2);  // a migrant's laneLink of origin (kept as global id)
+        if (d < 0) return -1;
+        return d < nL ? tn_.laneL2G[d] : gL + tn_.llL2G[d - nL];
+    };
+    for (int i = 0; i < v.count; ++i) {
+        if (drv[i] < nL && tn_.laneGhost[drv[i]]) continue;  // proxy of a neighbour's vehicle
+        out.vid.push_back(vid[i]);
+        out.drivable.push_back(toGlobal(drv[i]));
+        out.prevDrivable.push_back(toGlobal(prev[i]));
+        out.leader.push_back(lead[i]);
+        out.blocker.push_back(blk[i]);
+        out.enterLLTime.push_back(ellt[i]);
+        out.routePos.push_back(rpos[i]);
+        out.dis.push_back(dis[i]);
+        out.speed.push_back(speed[i]);
+        out.gap.push_back(gap[i]);
+        out.count += 1;
+    }
+}
+
+// ---------------------------------------------------------------- the tiles of this process
+TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int cols, const std::vector<int> &localTiles,
+                                 const std::string &backendLib) {
+    cfg_ = readEngineConfig(configFile);
+    try {
+        net_->load(cfg_.dir + cfg_.roadnetFile);
+        spawner_.init(net_.get(), cfg_.interval, 1, cfg_.seed);
+        spawner_.loadFlows(cfg_.dir + cfg_.flowFile);
+    } catch (const JsonError &e) {
+        throw std::runtime_error(std::string("load config failed! ") + e.what());
+    }
+    if (cfg_.laneChange) throw std::runtime_error("cityflow_amd: laneChange=true is not implemented on the device path");
+    nTiles_ = rows * cols;
+    owner_ = gridPartition(*net_, rows, cols);
+    be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
+    localRanks_ = localTiles;
+    if (localRanks_.empty()) {
+        localRanks_.resize(nTiles_);
+        std::iota(localRanks_.begin(), localRanks_.end(), 0);
+    }
+    allLocal_ = (int) localRanks_.size() == nTiles_;
+    int baseDevice = 0;
+    if (const char *dev = getenv("LOCAL_RANK")) baseDevice = atoi(dev);
+    if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) baseDevice = atoi(dev);
+    for (size_t i = 0; i < localRanks_.size(); ++i) {
+        if (localRanks_[i] < 0 || localRanks_[i] >= nTiles_) throw std::runtime_error("tiling: local tile out of range");
+        // several local tiles spread over the visible devices (the engine takes device % device count)
+        tiles_.emplace_back(new TileEngine(net_, owner_, localRanks_[i], cfg_, &be_, baseDevice + (int) i));
+    }
+    spawner_.setFinishedQuery([this](int vid) {
+        uint8_t st = 0;
+        for (auto &t : tiles_) t->mergeStatus(vid, 1, &st);
+        int s = st;
+        if (reduceStatus_) s = reduceStatus_(s);
+        return s == 2;
+    });
+    for (auto &t : tiles_) t->uploadTables(spawner_);
+}
+
+void TiledEngineHost::flushPhases() {
+    if (pendingInter_.empty()) return;
+    for (auto &t : tiles_) t->setPhases(pendingInter_, pendingPhase_);
+    pendingInter_.clear();
+    pendingPhase_.clear();
+}
+
+void TiledEngineHost::stepBegin() {
+    flushPhases();
+    spawner_.step(step_, spawnBuf_);
+    for (auto &t : tiles_) {
+        t->uploadTables(spawner_);
+        t->step(spawnBuf_);
+    }
+    for (auto &t : tiles_) t->haloExport();
+    // messages between two local tiles never leave the process
+    for (size_t a = 0; a < tiles_.size(); ++a)
+        for (const TilePeer &p : tiles_[a]->tile().peers)
+            for (size_t b = 0; b < tiles_.size(); ++b) {
+                if (localRanks_[b] != p.rank) continue;
+                for (const TilePeer &q : tiles_[b]->tile().peers)
+                    if (q.rank == localRanks_[a]) {
+                        if (q.recvBytes != p.sendBytes) throw std::logic_error("tiling: halo layouts of two tiles disagree");
+                        std::copy(tiles_[a]->send.begin() + p.sendOff, tiles_[a]->send.begin() + p.sendOff + p.sendBytes,
+                                  tiles_[b]->recv.begin() + q.recvOff);
+                    }
+            }
+}
+
+void TiledEngineHost::stepEnd() {
+    for (auto &t : tiles_) t->haloImport();
+    step_ += 1;
+}
+
+void TiledEngineHost::nextStep() {
+    if (!allLocal_) throw std::runtime_error("tiling: next_step() needs every tile in this process; use step_begin / step_end");
+    stepBegin();
+    stepEnd();
+}
+
+std::vector<int32_t> TiledEngineHost::laneVehicleCountArray() {
+    std::vector<int32_t> out(net_->lanes.size(), 0);
+    for (auto &t : tiles_) t->addLaneCounts(out, false);
+    return out;
+}
+
+std::vector<int32_t> TiledEngineHost::laneWaitingVehicleCountArray() {
+    std::vector<int32_t> out(net_->lanes.size(), 0);
+    for (auto &t : tiles_) t->addLaneCounts(out, true);
+    return out;
+}
+
+std::vector<std::string> TiledEngineHost::laneIds() const {
+    std::vector<std::string> ids(net_->lanes.size());
+    for (size_t l = 0; l < ids.size(); ++l) ids[l] = net_->laneId((int) l);
+    return ids;
+}
+
+std::map<std::string, int> TiledEngineHost::getLaneVehicleCount() {
+    std::vector<int32_t> cnt = laneVehicleCountArray();
+    std::map<std::string, int> ret;
+    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_->laneId((int) l), cnt[l]);
+    return ret;
+}
+
+std::map<std::string, int> TiledEngineHost::getLaneWaitingVehicleCount() {
+    std::vector<int32_t> cnt = laneWaitingVehicleCountArray();
+    std::map<std::string, int> ret;
+    for (size_t l = 0; l < cnt.size(); ++l) ret.emplace(net_->laneId((int) l), cnt[l]);
+    return ret;
+}
+
+cfx_scalars TiledEngineHost::scalars() {
+    cfx_scalars sum{};
+    for (auto &t : tiles_) {
+        cfx_scalars s = t->scalars();
+        sum.active_vehicle_count += s.active_vehicle_count;
+        sum.finished_vehicle_count += s.finished_vehicle_count;
+        sum.cumulative_travel_time += s.cumulative_travel_time;
+        sum.vehicle_steps += s.vehicle_steps;
+    }
+    sum.step = (int64_t) step_;
+    sum.spawned_vehicle_count = (int64_t) spawner_.vehicles.size();
+    return sum;
+}
+
+size_t TiledEngineHost::getVehicleCount() { return (size_t) scalars().active_vehicle_count; }
+
+void TiledEngineHost::setTrafficLightPhase(const std::string &id, int phaseIndex) {
+    if (!cfg_.rlTrafficLight) {
+        std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
+        return;
+    }
+    auto it = net_->interIndex.find(id);
+    if (it == net_->interIndex.end()) throw std::runtime_error("Intersection '" + id + "' not found");
+    const HostInter &in = net_->inters[it->second];
+    if (in.isVirtual || phaseIndex < 0 || phaseIndex >= (int) in.phases.size())
+        throw std::out_of_range("phase index " + std::to_string(phaseIndex) + " out of range for intersection '" + id + "'");
+    pendingInter_.push_back(it->second);
+    pendingPhase_.push_back(phaseIndex);
+}
+
+void TiledEngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) {
+    if (!cfg_.rlTrafficLight) {
+        std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
+        return;
+    }
+    if (phases.size() != net_->inters.size()) throw std::runtime_error("set_tl_phases: expected one phase per intersection");
+    for (size_t i = 0; i < phases.size(); ++i) {
+        const HostInter &in = net_->inters[i];
+        if (in.isVirtual) continue;
+        if (phases[i] < 0 || phases[i] >= (int) in.phases.size())
+            throw std::out_of_range("set_tl_phases: phase out of range for intersection '" + in.id + "'");
+        pendingInter_.push_back((int32_t) i);
+        pendingPhase_.push_back(phases[i]);
+    }
+}
+
+void TiledEngineHost::reset(bool resetRnd) {
+    pendingInter_.clear();
+    pendingPhase_.clear();
+    for (auto &t : tiles_) t->reset();
+    spawner_.reset(resetRnd);
+    step_ = 0;
+}
+
+void TiledEngineHost::sync() {
+    for (auto &t : tiles_) t->sync();
+}
+
+void TiledEngineHost::snapshotVehicles(VehicleSnapshot &out) {
+    VehicleSnapshot all;
+    for (auto &t : tiles_) t->appendVehicles(all);
+    // every drivable belongs to exactly one tile and a tile lists it front to back: a stable sort by global
+    // drivable gives Drivable::vehicles order over the whole network
+    std::vector<int> idx((size_t) all.count);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return all.drivable[a] < all.drivable[b]; });
+    out = VehicleSnapshot{};
+    out.count = all.count;
+    for (int i : idx) {
+        out.vid.push_back(all.vid[i]);
+        out.drivable.push_back(all.drivable[i]);
+        out.prevDrivable.push_back(all.prevDrivable[i]);
+        out.leader.push_back(all.leader[i]);
+        out.blocker.push_back(all.blocker[i]);
+        out.enterLLTime.push_back(all.enterLLTime[i]);
+        out.routePos.push_back(all.routePos[i]);
+        out.dis.push_back(all.dis[i]);
+        out.speed.push_back(all.speed[i]);
+        out.gap.push_back(all.gap[i]);
+    }
+}
+
+}  // namespace cfa

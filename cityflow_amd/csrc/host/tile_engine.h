@@ -1,0 +1,149 @@
+// One road network over several device engines (reference: none — CityFlow's only parallelism is the
+// thread pool of Engine::startThread engine.cpp:19-31, which splits vehicles/roads/intersections over threads that
+// share one address space).  Here the network is cut into TILES of intersections; every tile is a complete cfx
+// engine on its own sub-network and GPU, and the tiles exchange a one-lane halo once per step (cfx_halo_*).
+//
+// Ownership: a tile owns a set of intersections, all their laneLinks, and every lane that ENDS in one of them
+// (lanes into a virtual border intersection belong to the tile of the intersection they start from).  A cut
+// lane — upstream intersection in tile A, downstream in tile B — is owned by B; A keeps it as a GHOST lane that
+// only carries a frozen proxy of the lane's current tail vehicle, which is all that phases 2-7 of A ever read
+// from it (Lane::canEnter roadnet.cpp:437-445, the leader search vehicle.cpp:157-196, the `u` source of
+// threadNotifyCross engine.cpp:331-342).  Per step and cut lane the halo carries: A -> B the vehicles that crossed
+// (with their committed state), B -> A the lane's tail.  Every process runs the same host spawner (same mt19937
+// stream), so static per-vehicle data and the waiting queues need no communication.
+//
+// Precondition (checked): cut lanes are longer than any vehicle's look-ahead, so nothing in A reads past the tail
+// of a ghost lane and nothing in B reads upstream of an import lane.
+#pragma once
+
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine_host.h"
+
+namespace cfa {
+
+// rows x cols blocks over the (sorted distinct) coordinates of the non-virtual intersections; virtual
+// intersections follow their only neighbour.  Returns the owning tile per intersection.
+std::vector<int> gridPartition(const HostRoadNet &net, int rows, int cols);
+
+struct TilePeer {
+    int rank = -1;
+    int sendOff = 0, sendBytes = 0, recvOff = 0, recvBytes = 0;
+};
+
+// Sub-network of one tile + the halo layout agreed with its neighbours.
+struct TileNet {
+    int rank = 0;
+    std::vector<int32_t> laneL2G, llL2G, interL2G, roadL2G;  // local -> global index
+    std::vector<int32_t> laneG2L, llG2L, interG2L, roadG2L;  // global -> local index or -1
+    std::vector<uint8_t> laneGhost;                          // per local lane
+    std::vector<int32_t> ghostLane, ghostSendOff, ghostRecvOff, importLane, importRecvOff, importSendOff;
+    std::vector<TilePeer> peers;  // ascending rank
+    int sendBytes = 0, recvBytes = 0;
+    cfx_net flat{};
+
+    void build(const HostRoadNet &net, const std::vector<int> &owner, int rank);
+
+private:
+    std::vector<double> drvLength_, drvMaxSpeed_, xDist_, phaseTime_;
+    std::vector<int32_t> laneRoad_, laneIndex_, laneLLStart_, laneLL_, roadLaneStart_, llStartLane_, llEndLane_, llInter_,
+        llRoadLink_, llType_, llXStart_, xPeer_, xLL_, interVirtual_, interNRL_, interPhaseStart_, interAvailStart_;
+    std::vector<uint8_t> phaseAvail_;
+};
+
+// One tile: a cfx engine on the tile's sub-network.  Speaks global indices to its caller.
+class TileEngine {
+public:
+    TileEngine(std::shared_ptr<HostRoadNet> net, const std::vector<int> &owner, int rank, const EngineConfig &cfg,
+               Backend *be, int device);
+    ~TileEngine();
+    TileEngine(const TileEngine &) = delete;
+    TileEngine &operator=(const TileEngine &) = delete;
+
+    void uploadTables(const Spawner &sp);
+    void step(const std::vector<cfx_spawn> &globalRecs);
+    void haloExport();  // -> send
+    void haloImport();  // <- recv
+    void reset();
+    void sync();
+
+    void addLaneCounts(std::vector<int32_t> &global, bool waiting);  // writes the lanes this tile owns
+    cfx_scalars scalars();
+    void mergeStatus(int first, int n, uint8_t *inout);              // inout[i] = max(inout[i], local state)
+    void setPhases(const std::vector<int32_t> &globalInter, const std::vector<int32_t> &phase);  // owned ones are applied
+    void appendVehicles(VehicleSnapshot &out);  // owned running vehicles, global drivable ids (unsorted across tiles)
+
+    const TileNet &tile() const { return tn_; }
+    std::vector<char> send, recv;
+
+private:
+    void check(int32_t rc, const char *what);
+    std::shared_ptr<HostRoadNet> net_;
+    TileNet tn_;
+    Backend *be_;
+    cfx_engine *dev_ = nullptr;
+    int templatesUploaded_ = 0, routesUploaded_ = 0;
+    std::vector<cfx_spawn> recs_;
+};
+
+// The tiles this process runs (all of them: one process drives the whole network, e.g. several tiles on one GPU for
+// tests; or one: the torch.distributed launch, one process per GPU) behind the reference's Engine methods.
+class TiledEngineHost {
+public:
+    // localTiles empty => all tiles are local
+    TiledEngineHost(const std::string &configFile, int rows, int cols, const std::vector<int> &localTiles,
+                    const std::string &backendLib = "");
+
+    // ---- stepping.  All tiles local: nextStep() does everything.  Otherwise the caller moves the halo between
+    //      stepBegin() and stepEnd(): send/recv buffers of local tile i via sendBuffer(i)/recvBuffer(i), peers(i).
+    void nextStep();
+    void stepBegin();
+    void stepEnd();
+    int nTiles() const { return nTiles_; }
+    int nLocal() const { return (int) tiles_.size(); }
+    int localRank(int i) const { return localRanks_[i]; }
+    std::vector<char> &sendBuffer(int i) { return tiles_[i]->send; }
+    std::vector<char> &recvBuffer(int i) { return tiles_[i]->recv; }
+    const std::vector<TilePeer> &peers(int i) const { return tiles_[i]->tile().peers; }
+
+    // ---- reference API subset (values of the lanes / vehicles of the LOCAL tiles; callers in a multi-process
+    //      launch reduce them: counts by sum, status by max)
+    std::vector<int32_t> laneVehicleCountArray();
+    std::vector<int32_t> laneWaitingVehicleCountArray();
+    std::map<std::string, int> getLaneVehicleCount();
+    std::map<std::string, int> getLaneWaitingVehicleCount();
+    size_t getVehicleCount();
+    cfx_scalars scalars();                     // sums over local tiles (step / spawned are global)
+    double getCurrentTime() const { return step_ * cfg_.interval; }
+    void setTrafficLightPhase(const std::string &id, int phaseIndex);
+    void setTrafficLightPhases(const std::vector<int32_t> &phases);  // [n_intersections]
+    void reset(bool resetRnd);
+    void snapshotVehicles(VehicleSnapshot &out);  // local tiles, sorted by global drivable
+    void sync();
+    std::vector<int> owner() const { return owner_; }
+    std::vector<std::string> laneIds() const;
+    const HostRoadNet &net() const { return *net_; }
+    std::string vehicleId(int vid) const { return spawner_.vehicleId(vid); }
+    // max-reduction of a vehicle status over all processes; identity when every tile is local
+    void setStatusReducer(std::function<int(int)> r) { reduceStatus_ = std::move(r); }
+
+private:
+    EngineConfig cfg_;
+    std::shared_ptr<HostRoadNet> net_ = std::make_shared<HostRoadNet>();
+    Spawner spawner_;
+    Backend be_;
+    std::vector<int> owner_, localRanks_;
+    std::vector<std::unique_ptr<TileEngine>> tiles_;
+    int nTiles_ = 1;
+    bool allLocal_ = true;
+    size_t step_ = 0;
+    std::vector<cfx_spawn> spawnBuf_;
+    std::vector<int32_t> pendingInter_, pendingPhase_;
+    std::function<int(int)> reduceStatus_;
+    void flushPhases();
+};
+
+}  // namespace cfa

@@ -221,6 +221,45 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s);
 /* pending custom speeds of the running vehicles, same order as cfx_get_vehicles (NaN = none) */
 int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out);
 
+/* ---- Tiling one road network over several engines / GPUs -----------------------------------
+ * An engine may be created on a SUB-network: the intersections one tile owns, their laneLinks, every lane ending
+ * in them, plus the "ghost" lanes it feeds that end in a foreign tile.  Vehicles on ghost lanes are frozen proxies
+ * of the owner's state.  After every cfx_step the caller performs ONE exchange:
+ *   cfx_halo_export(e, send)   fills `send` (host memory, cfx_halo_layout::send_bytes) with
+ *                              - for every ghost lane (this tile is upstream): the vehicles that entered it this step
+ *                                (migrants), and keeps only the last of them as the lane's proxy;
+ *                              - for every import lane (this tile is downstream): the record of the lane's tail;
+ *   ... the caller moves each neighbour's slice to that neighbour (RCCL / host copy) ...
+ *   cfx_halo_import(e, recv)   appends received migrants to the import lanes and refreshes the proxies of ghost
+ *                              lanes that had no entrant of their own this step.
+ * Block formats (little endian, offsets are byte offsets into the send / recv buffers):
+ *   migrant block (CFX_HALO_MIG_BYTES): int32 count, int32 pad, then CFX_HALO_MAX_MIGRANTS records
+ *       {int32 vid, int32 route_pos, int32 prev_lanelink (global id), int32 pad, double dis, double speed}
+ *   tail block (CFX_HALO_TAIL_BYTES):   {int32 vid (-1: lane empty), int32 prev_lanelink (global id or -1),
+ *                                        double dis, double speed} */
+#define CFX_HALO_MAX_MIGRANTS 8
+#define CFX_HALO_MIG_BYTES (8 + CFX_HALO_MAX_MIGRANTS * 32)
+#define CFX_HALO_TAIL_BYTES 24
+typedef struct cfx_halo_layout {
+    int32_t n_ghost;                /* ghost lanes (local lane ids), this tile upstream */
+    const int32_t *ghost_lane;
+    const int32_t *ghost_send_off;  /* migrant block in the send buffer */
+    const int32_t *ghost_recv_off;  /* tail block in the recv buffer */
+    int32_t n_import;               /* owned lanes fed by a foreign tile */
+    const int32_t *import_lane;
+    const int32_t *import_recv_off; /* migrant block in the recv buffer */
+    const int32_t *import_send_off; /* tail block in the send buffer */
+    int32_t send_bytes, recv_bytes;
+    int32_t n_global_lanelinks;     /* size of the two maps below */
+    const int32_t *lanelink_global; /* [n_lanelinks of this engine] local -> global laneLink id */
+    const int32_t *lanelink_local;  /* [n_global_lanelinks] global -> local laneLink id or -1 */
+} cfx_halo_layout;
+int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *layout);
+int32_t cfx_halo_export(cfx_engine *e, void *send_host);
+int32_t cfx_halo_import(cfx_engine *e, const void *recv_host);
+/* spawn records whose lane is not part of this engine's sub-network carry lane = -1: only the per-vehicle
+ * static table is filled (every tile knows every vehicle, so migrants need no static payload). */
+
 /* Optional per-kernel timing with HIP events recorded on the engine's own stream (bench.py roofline).
  * Kernel ids are dense 0..cfx_profile_kernel_count()-1; cfx_profile_read() synchronises, adds the
  * elapsed time of every bracketed launch since the last read into total_ms[] / launches[] and clears. */

@@ -67,6 +67,12 @@ struct cfx_engine {
     int64_t step = 0, active = 0, finishedCnt = 0, vehicleSteps = 0;
     double cumulativeTravelTime = 0;
     std::string err;
+    // tiling (cfx_halo_config): same protocol as the HIP engine, restated on the object model
+    bool tiled = false;
+    std::vector<uint8_t> laneGhost, ghostHadEntrants;
+    std::vector<int32_t> ghostLane, ghostSendOff, ghostRecvOff, importLane, importRecvOff, importSendOff, llGlobal,
+        llLocalOfGlobal, inCntStep;
+    bool onGhost(const Veh &v) const { return tiled && v.drivable >= 0 && isLane(v.drivable) && laneGhost[v.drivable]; }
 
     // ------------------------------------------------------------------ small accessors
     bool isLane(int d) const { return d < net.L; }
@@ -408,7 +414,7 @@ struct cfx_engine {
             Veh &v = veh[vid];
             if (available(lane, v)) {
                 v.running = true;
-                active += 1;
+                if (!(tiled && laneGhost[lane])) active += 1;  // an admission onto a ghost lane mirrors the owner's
                 int tail = lastVehicle(lane);
                 order[lane].push_back(vid);
                 updateLeaderAndGap(v, tail);
@@ -470,6 +476,121 @@ struct cfx_engine {
         }
     }
 
+    // threadUpdateLeaderAndGap engine.cpp:429-442 (lane history is dead state)
+    void leaderAndGapPass() {
+        for (auto &list : order) {
+            int leader = -1;
+            for (int32_t vid : list) {
+                updateLeaderAndGap(veh[vid], leader);
+                leader = vid;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ tiling halo (include/cityflow_amd.h)
+    struct HaloMigrant {
+        int32_t vid, routePos, prevLL, pad;
+        double dis, speed;
+    };
+    struct HaloTail {
+        int32_t vid, prevLL;
+        double dis, speed;
+    };
+    int globalPrev(int prevDrv) const {
+        if (prevDrv >= net.L) return llGlobal[prevDrv - net.L];
+        if (prevDrv <= -2) return -prevDrv - 2;
+        return -1;
+    }
+    void dropProxy(int vid) {  // the vehicle is no longer represented in this tile
+        Veh &v = veh[vid];
+        v.running = false;
+        v.drivable = -1;
+        v.blocker = -1;
+        v.leader = -1;
+    }
+    void haloExport(char *send) {
+        for (size_t i = 0; i < ghostLane.size(); ++i) {
+            const int g = ghostLane[i];
+            auto &list = order[g];
+            const int n = (int) list.size(), in = inCntStep.empty() ? 0 : inCntStep[g];
+            char *blk = send + ghostSendOff[i];
+            int m = std::min(in, (int) CFX_HALO_MAX_MIGRANTS);
+            if (in > m) err = "halo: more migrants on one lane in one step than CFX_HALO_MAX_MIGRANTS";
+            ((int32_t *) blk)[0] = m;
+            ((int32_t *) blk)[1] = 0;
+            HaloMigrant *rec = (HaloMigrant *) (blk + 8);
+            for (int j = 0; j < m; ++j) {
+                const Veh &v = veh[list[n - in + j]];
+                rec[j] = HaloMigrant{list[n - in + j], v.routePos, globalPrev(v.prevDrivable), 0, v.dis, v.speed};
+            }
+            ghostHadEntrants[i] = in > 0;
+            if (in > 0) {
+                const int keep = list.back();
+                for (int j = 0; j + 1 < n; ++j) dropProxy(list[j]);
+                list.assign(1, keep);
+                veh[keep].blocker = -1;
+                active -= in;
+            }
+        }
+        for (size_t j = 0; j < importLane.size(); ++j) {
+            const int l = importLane[j];
+            HaloTail t{-1, -1, 0.0, 0.0};
+            if (!order[l].empty()) {
+                const Veh &v = veh[order[l].back()];
+                t = HaloTail{order[l].back(), globalPrev(v.prevDrivable), v.dis, v.speed};
+            }
+            memcpy(send + importSendOff[j], &t, sizeof t);
+        }
+    }
+    void haloImport(const char *recv) {
+        for (size_t i = 0; i < importLane.size(); ++i) {
+            const int l = importLane[i];
+            const char *blk = recv + importRecvOff[i];
+            const int m = ((const int32_t *) blk)[0];
+            const HaloMigrant *rec = (const HaloMigrant *) (blk + 8);
+            for (int j = 0; j < m; ++j) {
+                Veh &v = veh[rec[j].vid];
+                v.running = true;
+                v.finished = false;
+                v.drivable = l;
+                v.prevDrivable = rec[j].prevLL >= 0 ? -(rec[j].prevLL + 2) : -1;
+                v.dis = rec[j].dis;
+                v.speed = rec[j].speed;
+                v.routePos = rec[j].routePos;
+                v.blocker = -1;
+                v.enterLLTime = INT_MAX;
+                v.customSet = false;
+                order[l].push_back(rec[j].vid);
+            }
+            active += m;
+        }
+        for (size_t j = 0; j < ghostLane.size(); ++j) {
+            if (ghostHadEntrants[j]) continue;
+            const int g = ghostLane[j];
+            HaloTail t;
+            memcpy(&t, recv + ghostRecvOff[j], sizeof t);
+            for (int vid : order[g]) dropProxy(vid);
+            order[g].clear();
+            if (t.vid < 0) continue;
+            Veh &v = veh[t.vid];
+            v.running = true;
+            v.drivable = g;
+            v.prevDrivable = -1;
+            if (t.prevLL >= 0) {
+                int k = llLocalOfGlobal[t.prevLL];
+                v.prevDrivable = k >= 0 ? net.L + k : -(t.prevLL + 2);
+            }
+            v.dis = t.dis;
+            v.speed = t.speed;
+            v.blocker = -1;
+            v.enterLLTime = INT_MAX;
+            v.routePos = 0;
+            v.customSet = false;
+            order[g].push_back(t.vid);
+        }
+        leaderAndGapPass();  // leaders found across a cut see the refreshed proxies
+    }
+
     void stepOnce(const cfx_spawn *recs, int n) {
         // phases 0/1 happened on the host; enqueue on waiting buffers in record order
         for (int i = 0; i < n; ++i) {
@@ -485,7 +606,7 @@ struct cfx_engine {
             v.enterTime = s.enter_time;
             v.drivable = s.lane;  // Vehicle::setFirstDrivable vehicle.cpp:422-424
             veh.push_back(v);
-            waiting[s.lane].push_back(s.vid);
+            if (s.lane >= 0) waiting[s.lane].push_back(s.vid);  // lane -1: the vehicle starts in another tile
         }
         handleWaiting();
         notifyCross();
@@ -495,6 +616,12 @@ struct cfx_engine {
         for (size_t vid = 0; vid < veh.size(); ++vid) {
             Veh &v = veh[vid];
             if (!v.running) continue;
+            if (onGhost(v)) {  // frozen proxy of a neighbour's vehicle
+                v.bDis = v.dis;
+                v.bSpeed = v.speed;
+                v.bDrvSet = v.bEndSet = v.bBlockerSet = false;
+                continue;
+            }
             vehicleControl(v);
             vehicleSteps += 1;
             if (!v.bEndSet && v.bDrvSet) pushBuffer.push_back((int32_t) vid);
@@ -524,9 +651,11 @@ struct cfx_engine {
         // the same drivable) unspecified; canonical tie-break here and on the device: lower vid first.
         std::stable_sort(pushBuffer.begin(), pushBuffer.end(),
                          [this](int32_t a, int32_t b) { return veh[a].bDis > veh[b].bDis; });
+        if (tiled) inCntStep.assign(order.size(), 0);
         for (int32_t vid : pushBuffer) {
             Veh &v = veh[vid];
             order[v.bDrv].push_back(vid);
+            if (tiled) inCntStep[v.bDrv] += 1;
             v.bEnterLLTime = isLane(v.bDrv) ? INT_MAX : (int32_t) step;
             v.bEnterSet = true;
         }
@@ -556,14 +685,7 @@ struct cfx_engine {
             v.customSet = false;  // vehicle.cpp:120-122
         }
 
-        // threadUpdateLeaderAndGap engine.cpp:429-442 (lane history is dead state)
-        for (auto &list : order) {
-            int leader = -1;
-            for (int32_t vid : list) {
-                updateLeaderAndGap(veh[vid], leader);
-                leader = vid;
-            }
-        }
+        leaderAndGapPass();
 
         // TrafficLight::passTime trafficlight.cpp:29-37
         if (!cfg.rl_traffic_light) {
@@ -891,6 +1013,34 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
             leader = vid;
         }
     }
+    return CFX_OK;
+}
+
+int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
+    if (!e || !h || e->tiled || e->step != 0 || !e->veh.empty()) return CFX_ERR_INVALID;
+    e->laneGhost.assign(e->net.L, 0);
+    e->ghostLane.assign(h->ghost_lane, h->ghost_lane + h->n_ghost);
+    e->ghostSendOff.assign(h->ghost_send_off, h->ghost_send_off + h->n_ghost);
+    e->ghostRecvOff.assign(h->ghost_recv_off, h->ghost_recv_off + h->n_ghost);
+    e->importLane.assign(h->import_lane, h->import_lane + h->n_import);
+    e->importRecvOff.assign(h->import_recv_off, h->import_recv_off + h->n_import);
+    e->importSendOff.assign(h->import_send_off, h->import_send_off + h->n_import);
+    e->llGlobal.assign(h->lanelink_global, h->lanelink_global + e->net.K);
+    e->llLocalOfGlobal.assign(h->lanelink_local, h->lanelink_local + h->n_global_lanelinks);
+    for (int l : e->ghostLane) e->laneGhost[l] = 1;
+    e->ghostHadEntrants.assign(e->ghostLane.size(), 0);
+    e->tiled = true;
+    return CFX_OK;
+}
+int32_t cfx_halo_export(cfx_engine *e, void *send) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    e->err.clear();
+    e->haloExport((char *) send);
+    return e->err.empty() ? CFX_OK : CFX_ERR_CAPACITY;
+}
+int32_t cfx_halo_import(cfx_engine *e, const void *recv) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    e->haloImport((const char *) recv);
     return CFX_OK;
 }
 

@@ -1,0 +1,42 @@
+"""Developer check: a network tiled rows x cols (all tiles in this process) must evolve bit-identically to the same
+network on one engine.   python tools/tile_parity.py grid_6x6 2 2 400 [backend.so]   (default backend: the CPU twin)"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cityflow_amd import _cityflow as m  # noqa: E402
+from cityflow_amd import scenarios  # noqa: E402
+
+twin = os.path.join(ROOT, "oracle", "_ref", "libcfx_twin.so")
+name, rows, cols, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+lib = twin if len(sys.argv) < 6 else (m._default_backend_path() if sys.argv[5] == "hip" else sys.argv[5])
+wd = tempfile.mkdtemp(prefix="tile_parity_")
+cfg = scenarios.materialize(name, wd)
+ref = m.Engine._with_backend(cfg, 1, lib)
+til = m.TiledEngine(cfg, rows, cols, [], lib)
+print('tiles', til.num_tiles, 'peers0', til.peers(0))
+keys = ['vid','drivable','prev_drivable','leader','blocker','enter_ll_time','route_pos','dis','speed','gap']
+for s in range(steps):
+    ref.next_step(); til.next_step()
+    a = ref.get_lane_vehicle_count_array(); b = til.get_lane_vehicle_count_array()
+    if not np.array_equal(a, b):
+        bad = np.nonzero(a != b)[0]
+        print('step', s, 'lane counts differ at', bad[:10], a[bad[:10]], b[bad[:10]], [ref.lane_ids()[i] for i in bad[:5]])
+        sys.exit(1)
+    va = ref._vehicle_state(); vb = til._vehicle_state()
+    for k in keys:
+        x, y = va[k], vb[k]
+        if x.shape != y.shape or not np.array_equal(x, y, equal_nan=True) if x.dtype.kind == 'f' else not np.array_equal(x, y):
+            i = np.nonzero(x != y)[0][:5] if x.shape == y.shape else None
+            print('step', s, 'field', k, 'differs', i, x[i] if i is not None else x.shape, y[i] if i is not None else y.shape)
+            if i is not None: print('vid', va['vid'][i], 'drv', va['drivable'][i])
+            sys.exit(1)
+    sa, sb = ref._scalars(), til._scalars()
+    for k in ['active_vehicle_count','finished_vehicle_count','cumulative_travel_time','vehicle_steps']:
+        if sa[k] != sb[k]:
+            print('step', s, 'scalar', k, sa[k], sb[k]); sys.exit(1)
+print('OK', steps, 'steps; active', ref.get_vehicle_count(), 'finished', ref._scalars()['finished_vehicle_count'])
