@@ -10,9 +10,11 @@ host only uploads the handful of spawn records of that step (they come from the 
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
 
-N>1: the engine does not tile one road network across GPUs yet — each rank advances an
-independent replica of the workload on its own GPU ("scaling": "weak", no data-path collective); `value` is the
-sum over ranks of vehicle-steps divided by the slowest rank's time.
+N>1 (default): ONE road network tiled over the N GPUs: the grid grows with N — every rank owns a
+30x30 block of intersections of a (30*rows)x(30*cols) grid (N=2: 1x2, 4: 2x2, 8: 2x4) with the same demand per
+block as the N=1 workload, so per-GPU work is fixed ("scaling": "weak") — and the tiles exchange their one-lane
+ghost halo every step (cityflow_amd.tiled.DistributedEngine).  `value` = vehicle-steps of all tiles / the slowest
+rank's time.  `--replicas` runs N independent copies of the N=1 workload instead (no exchange).
 
 Output: ONE JSON line on rank 0 (see README of the task contract) with two extra objects:
   roofline      car-following kernel (k_action): algorithmic bytes (48 B per running vehicle)
@@ -48,6 +50,31 @@ def build_workload(workdir, seed, scenario="grid_30x30", n_extra=N_EXTRA_FLOWS):
         scenarios.dense_flows(os.path.join(d, "roadnet.json"), flow, n_extra, seed=12345, interval=EXTRA_INTERVAL,
                               base_flow=os.path.join(d, "flow.json"), end_time=EXTRA_END)
     return scenarios.materialize(scenario, workdir, flow_file=flow, seed=seed)
+
+
+def tile_grid(n):
+    rows = 1
+    for r in range(1, int(n ** 0.5) + 1):
+        if n % r == 0:
+            rows = r
+    return rows, n // rows
+
+
+def build_tiled_workload(workdir, rows, cols, block, n_extra_per_tile):
+    """(block*rows) x (block*cols) generated grid + the stock flows + n_extra_per_tile seeded interior flows per tile."""
+    from cityflow_amd import scenarios
+    base = scenarios.generate_grid(block * rows, block * cols, workdir)
+    d = os.path.dirname(base)
+    n_extra = n_extra_per_tile * rows * cols
+    flow = os.path.join(d, "flow_bench_%d.json" % n_extra)
+    if not os.path.exists(flow):
+        scenarios.dense_flows(os.path.join(d, "roadnet.json"), flow, n_extra, seed=12345, interval=EXTRA_INTERVAL,
+                              base_flow=os.path.join(d, "flow.json"), end_time=EXTRA_END)
+    cfg = dict(json.load(open(base)), flowFile=os.path.basename(flow))
+    path = os.path.join(d, "config_bench.json")
+    with open(path, "w") as f:
+        json.dump(cfg, f)
+    return path
 
 
 def cpu_baseline(cfg, budget_s, threads, state_dump):
@@ -119,6 +146,8 @@ def main():
     ap.add_argument("--extra-flows", type=int, default=N_EXTRA_FLOWS, help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--backend-lib", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of one tiled network")
+    ap.add_argument("--tile-block", type=int, default=30, help=argparse.SUPPRESS)
     args = ap.parse_args()
     on_gpu = args.backend_lib == ""
 
@@ -130,8 +159,12 @@ def main():
         import torch
         import torch.distributed as dist
         if on_gpu:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=args.dist_backend, device_id=torch.device("cuda", local_rank))
+            local_dev = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_dev)
+            if args.dist_backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+            else:
+                dist.init_process_group(backend=args.dist_backend)
         else:
             dist.init_process_group(backend=args.dist_backend)
 
@@ -141,20 +174,32 @@ def main():
 
     from cityflow_amd import _cityflow
 
-    workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_rank%d" % rank)
-    cfg = build_workload(workdir, seed=rank, scenario=args.scenario, n_extra=args.extra_flows)
-    if on_gpu:
-        eng = _cityflow.Engine(cfg, 1)  # HIP engine on device LOCAL_RANK; raises if the extension/GPU is missing
-        assert eng.backend_name() == "hip-gfx950"
+    tiled = world > 1 and not args.replicas
+    if tiled:
+        from cityflow_amd.tiled import DistributedEngine
+        rows, cols = tile_grid(world)
+        workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_tiled")
+        if rank == 0:  # one node: every rank reads the files rank 0 wrote
+            cfg = build_tiled_workload(workdir, rows, cols, args.tile_block, args.extra_flows)
+        barrier()
+        cfg = os.path.join(workdir, "gen_%dx%d" % (args.tile_block * rows, args.tile_block * cols), "config_bench.json")
+        eng = DistributedEngine(cfg, rows, cols, backend_library=args.backend_lib)
+        eng._scalars = eng.local_scalars  # this rank's tile; summed over ranks below
     else:
-        eng = _cityflow.Engine._with_backend(cfg, 1, args.backend_lib)
+        workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_rank%d" % rank)
+        cfg = build_workload(workdir, seed=rank, scenario=args.scenario, n_extra=args.extra_flows)
+        if on_gpu:
+            eng = _cityflow.Engine(cfg, 1)  # HIP engine on device LOCAL_RANK; raises if the extension/GPU is missing
+            assert eng.backend_name() == "hip-gfx950"
+        else:
+            eng = _cityflow.Engine._with_backend(cfg, 1, args.backend_lib)
 
     for _ in range(args.warmup):
         eng.next_step()
     eng.sync()
     sc0 = eng._scalars()
     state_dump = None
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and args.cpu_seconds > 0 and not tiled:
         state_dump = os.path.join(workdir, "state_at_timed_region.json")
         eng.snapshot().dump(state_dump)
 
@@ -171,17 +216,20 @@ def main():
 
     if dist is not None:
         import torch
-        dev = "cuda" if on_gpu else "cpu"
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        v = torch.tensor([float(veh_steps)], dtype=torch.float64, device=dev)
+        v = torch.tensor([float(veh_steps), float(sc0["active_vehicle_count"]), float(sc1["active_vehicle_count"])],
+                         dtype=torch.float64, device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        veh_steps = int(v.item())
+        veh_steps, run0, run1 = int(v[0].item()), int(v[1].item()), int(v[2].item())
+    else:
+        run0, run1 = sc0["active_vehicle_count"], sc1["active_vehicle_count"]
 
     # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream)
     roofline = None
-    if rank == 0 and on_gpu:
+    if rank == 0 and on_gpu and not tiled:
         scp0 = eng._scalars()
         eng._profile_enable(True)
         for _ in range(args.profile_steps):
@@ -208,21 +256,28 @@ def main():
 
     if rank == 0:
         cpu = None
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and not tiled:
             threads = args.cpu_threads or min(8, os.cpu_count() or 1)
             cpu = cpu_baseline(cfg, args.cpu_seconds, threads, state_dump)
         out = {
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "steps_per_sec": args.steps * world / elapsed,
+            "steps_per_sec": args.steps * (1 if tiled else world) / elapsed,
             "config": {
-                "workload": "%s (reference generator, --tlPlan, interval 1.0) + %d seeded interior flows "
+                "workload": ("grid_%dx%d (generator-format grid, --tlPlan, interval 1.0) + %d seeded interior flows "
+                             "(1 veh / %.0f s each until t=%d s); one network, %dx%d tiles of %dx%d intersections, one "
+                             "tile per GPU, one-lane ghost halo exchanged every step" % (
+                                 args.tile_block * rows, args.tile_block * cols, args.extra_flows * world, EXTRA_INTERVAL,
+                                 EXTRA_END, rows, cols, args.tile_block, args.tile_block)) if tiled else (
+                            "%s (reference generator, --tlPlan, interval 1.0) + %d seeded interior flows "
                             "(1 veh / %.0f s each until t=%d s); %s" % (
                                 args.scenario, args.extra_flows, EXTRA_INTERVAL, EXTRA_END,
-                                "one replica per GPU" if world > 1 else "single engine"),
-                "running_vehicles_start": sc0["active_vehicle_count"], "running_vehicles_end": sc1["active_vehicle_count"],
-                "lanes": len(eng.lane_ids()), "parallelism": "replica x%d" % world if world > 1 else "1 gpu",
+                                "one replica per GPU" if world > 1 else "single engine")),
+                "running_vehicles_start": run0, "running_vehicles_end": run1,
+                "lanes": len(eng.lane_ids()),
+                "parallelism": ("tiles %dx%d + halo" % (rows, cols)) if tiled else (
+                    "replica x%d" % world if world > 1 else "1 gpu"),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

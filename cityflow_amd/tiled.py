@@ -1,0 +1,116 @@
+"""One road network over several GPUs: one process per GPU, one tile of intersections per process.
+
+`DistributedEngine` is the `torch.distributed` face of the C++ tiling host (csrc/host/tile_engine.h): every rank
+loads the same config, runs the same host spawner (same mt19937 stream, so vehicle ids, priorities and waiting
+queues agree without communication), steps its own tile on its own GPU and exchanges the one-lane ghost halo with
+its neighbour tiles once per step.  Results are bit-identical to the same network on a single engine
+(tests/test_tiling.py).
+
+The halo of a tile is a few KiB per neighbour and is staged in host memory by the C ABI
+(`cfx_halo_export` / `cfx_halo_import`), so the exchange is a batch of point-to-point messages on a host-side
+(gloo) process group; the data-path collectives of `torch.distributed`'s default backend (RCCL on GPUs) are used
+for the reductions of the getters.  The reference has no counterpart (its parallelism is a thread pool inside one
+address space, reference src/engine/engine.cpp:19-31).
+
+    torchrun --nproc-per-node 8 my_rl.py        # inside: eng = DistributedEngine(cfg, rows=2, cols=4)
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _cityflow
+
+
+class DistributedEngine:
+    def __init__(self, config_file, rows, cols, backend_library="", halo_group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("DistributedEngine needs an initialised torch.distributed process group")
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if rows * cols != self.world:
+            raise ValueError("rows * cols must equal the world size (one tile per process)")
+        self._eng = _cityflow.TiledEngine(config_file, rows, cols, [self.rank], backend_library)
+        # host-side group for the halo (the buffers live in host memory); reuse the default group if it is gloo
+        if halo_group is not None:
+            self._halo = halo_group
+        elif dist.get_backend() == "gloo":
+            self._halo = dist.group.WORLD
+        else:
+            self._halo = dist.new_group(backend="gloo")
+        self._peers = self._eng.peers(0)
+        self._send = torch.from_numpy(self._eng.send_buffer(0))  # zero-copy views of the C++ staging buffers
+        self._recv = torch.from_numpy(self._eng.recv_buffer(0))
+        self._device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        self._eng._set_status_reducer(self._reduce_status)
+        self._n_lanes = len(self._eng.lane_ids())
+
+    # ---- stepping -------------------------------------------------------------------------------------------
+    def next_step(self):
+        self._eng.step_begin()  # spawn, the step's kernels, halo export (synchronises the tile's stream)
+        ops = []
+        for peer, so, sb, ro, rb in self._peers:
+            ops.append(dist.P2POp(dist.isend, self._send[so:so + sb], peer, group=self._halo))
+            ops.append(dist.P2POp(dist.irecv, self._recv[ro:ro + rb], peer, group=self._halo))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self._eng.step_end()  # halo import (asynchronous on the tile's stream)
+
+    # ---- reference API subset (every rank gets the whole-network answer) ----------------------------------
+    def _sum(self, arr, dtype):
+        t = torch.as_tensor(np.ascontiguousarray(arr), dtype=dtype).to(self._device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def get_lane_vehicle_count_array(self):
+        return self._sum(self._eng.get_lane_vehicle_count_array(), torch.int32)
+
+    def get_lane_waiting_vehicle_count_array(self):
+        return self._sum(self._eng.get_lane_waiting_vehicle_count_array(), torch.int32)
+
+    def lane_ids(self):
+        return self._eng.lane_ids()
+
+    def get_lane_vehicle_count(self):
+        return dict(zip(self._eng.lane_ids(), self.get_lane_vehicle_count_array().tolist()))
+
+    def get_lane_waiting_vehicle_count(self):
+        return dict(zip(self._eng.lane_ids(), self.get_lane_waiting_vehicle_count_array().tolist()))
+
+    def scalars(self):
+        s = self._eng._scalars()
+        ints = self._sum([s["active_vehicle_count"], s["finished_vehicle_count"], s["vehicle_steps"]], torch.int64)
+        tt = self._sum([s["cumulative_travel_time"]], torch.float64)
+        return {"step": s["step"], "spawned_vehicle_count": s["spawned_vehicle_count"],
+                "active_vehicle_count": int(ints[0]), "finished_vehicle_count": int(ints[1]),
+                "vehicle_steps": int(ints[2]), "cumulative_travel_time": float(tt[0])}
+
+    def local_scalars(self):
+        return self._eng._scalars()
+
+    def get_vehicle_count(self):
+        return self.scalars()["active_vehicle_count"]
+
+    def get_current_time(self):
+        return self._eng.get_current_time()
+
+    def set_tl_phase(self, intersection_id, phase_id):
+        self._eng.set_tl_phase(intersection_id, phase_id)  # every rank makes the same calls; the owner applies them
+
+    def set_tl_phases(self, phases):
+        self._eng.set_tl_phases(phases)
+
+    def reset(self, seed=False):
+        self._eng.reset(seed)
+
+    def sync(self):
+        self._eng.sync()
+
+    def local_vehicle_state(self):
+        return self._eng._vehicle_state()
+
+    # a priority collision in the spawner asks "has vehicle X finished?"; every rank asks at the same point of the
+    # same RNG stream, so a collective is legal here and keeps the streams identical
+    def _reduce_status(self, status):
+        t = torch.tensor([int(status)], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._halo)
+        return int(t[0])

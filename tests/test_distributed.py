@@ -13,7 +13,7 @@ def test_bench_two_ranks_gloo(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "30",
            "--cpu-seconds", "0", "--scenario", "grid_6x6", "--extra-flows", "50", "--dist-backend", "gloo",
-           "--backend-lib", TWIN_LIB]
+           "--backend-lib", TWIN_LIB, "--replicas"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -24,6 +24,27 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
     # whole-job aggregate: two replicas => about twice the per-replica vehicle-steps of one step count
     assert d["config"]["parallelism"] == "replica x2"
+
+
+def test_bench_two_ranks_tiled_gloo(tmp_path):
+    """The default N>1 mode: one network (3x6 here) tiled 1x2, one tile per rank, halo exchanged every step."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "120",
+           "--cpu-seconds", "0", "--tile-block", "3", "--extra-flows", "40", "--dist-backend", "gloo",
+           "--backend-lib", TWIN_LIB]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "tiles 1x2 + halo"
+    assert d["value"] > 0 and d["config"]["running_vehicles_start"] > 100
+    assert "grid_3x6" in d["config"]["workload"]
+    # whole-job vehicle-steps = (running vehicles summed over both tiles) x steps, within the drift of the window
+    per_step = d["value"] * d["ms_per_step"] / 1e3
+    lo, hi = sorted((d["config"]["running_vehicles_start"], d["config"]["running_vehicles_end"]))
+    assert lo * 0.9 <= per_step <= hi * 1.1
 
 
 def test_bench_single_rank_twin(tmp_path):

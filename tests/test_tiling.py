@@ -1,0 +1,162 @@
+"""One network tiled over several engines: partition and halo layout, and the property that matters —
+the tiled network evolves bit-identically to the same network on one engine (every per-vehicle field, lane counts,
+scalars), with all tiles in one process and with one tile per process over torch.distributed."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, TWIN_LIB
+
+KEYS = ["vid", "drivable", "prev_drivable", "leader", "blocker", "enter_ll_time", "route_pos", "dis", "speed", "gap"]
+
+
+def dense_cfg(scen, workdir, name, n_extra, seed, interval, **config):
+    base = scen.materialize(name, workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_tiled_%d_%d.json" % (n_extra, seed)), n_extra,
+                            seed=seed, interval=interval, base_flow=os.path.join(d, "flow.json"))
+    return scen.materialize(name, workdir, flow_file=flow, **config)
+
+
+def same_state(va, vb, where):
+    for k in KEYS:
+        if k == "gap":  # only defined where a leader exists (the reference leaves it stale otherwise, vehicle.cpp:157-196)
+            has = va["leader"] >= 0
+            assert np.array_equal(va[k][has], vb[k][has]), "%s field gap" % where
+        else:
+            assert np.array_equal(va[k], vb[k]), "%s field %s" % (where, k)
+
+
+def run_pair(mod, cfg, rows, cols, steps, lib, phases_rng=None, check_every=1):
+    ref = mod.Engine._with_backend(cfg, 1, lib)
+    til = mod.TiledEngine(cfg, rows, cols, [], lib)
+    assert til.num_tiles == rows * cols and til.num_local == rows * cols
+    n_inter = len(ref.intersection_ids())
+    moved = False
+    for s in range(steps):
+        if phases_rng is not None and s % 10 == 0:
+            ph = phases_rng.integers(0, 8, size=n_inter).astype(np.int32)
+            ref.set_tl_phases(ph)
+            til.set_tl_phases(ph)
+        ref.next_step()
+        til.next_step()
+        if s % check_every:
+            continue
+        assert np.array_equal(ref.get_lane_vehicle_count_array(), til.get_lane_vehicle_count_array()), "step %d" % s
+        va, vb = ref._vehicle_state(), til._vehicle_state()
+        same_state(va, vb, "step %d" % s)
+        sa, sb = ref._scalars(), til._scalars()
+        for k in ("active_vehicle_count", "finished_vehicle_count", "cumulative_travel_time", "vehicle_steps",
+                  "spawned_vehicle_count", "step"):
+            assert sa[k] == sb[k], (s, k, sa[k], sb[k])
+        moved = moved or sa["finished_vehicle_count"] > 0
+    assert np.array_equal(ref.get_lane_waiting_vehicle_count_array(), til.get_lane_waiting_vehicle_count_array())
+    assert ref.get_lane_vehicle_count() == til.get_lane_vehicle_count()
+    return ref, til, moved
+
+
+def test_partition_and_halo_layout(mod, scen, workdir):
+    cfg = scen.materialize("grid_6x6", workdir)
+    til = mod.TiledEngine(cfg, 2, 3, [], TWIN_LIB)
+    owner = np.array(til.owner())
+    assert set(owner.tolist()) == set(range(6))
+    # message a -> b and b's expectation of it have the same size, for every pair of neighbours
+    peers = {til.local_rank(i): til.peers(i) for i in range(til.num_local)}
+    for a, plist in peers.items():
+        for (b, so, sb, ro, rb) in plist:
+            back = [p for p in peers[b] if p[0] == a]
+            assert len(back) == 1 and back[0][2] == rb and back[0][4] == sb
+        assert sum(p[2] for p in plist) == til.send_buffer(a).shape[0]
+        assert sum(p[4] for p in plist) == til.recv_buffer(a).shape[0]
+    # a tile never talks to itself, and 2x3 blocks have 2..3 neighbours each (no diagonal roads in a grid)
+    assert all(a not in [p[0] for p in pl] and 2 <= len(pl) <= 3 for a, pl in peers.items())
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 2), (2, 2), (3, 3)])
+def test_tiled_equals_single_twin(mod, scen, workdir, rows, cols):
+    cfg = scen.materialize("grid_6x6", workdir)
+    _, _, moved = run_pair(mod, cfg, rows, cols, 700, TWIN_LIB)
+    assert moved  # vehicles crossed the whole grid, i.e. several tile borders
+
+
+def test_tiled_rl_lights_and_reset_twin(mod, scen, workdir):
+    cfg = scen.materialize("grid_6x6", workdir, rlTrafficLight=True)
+    ref, til, _ = run_pair(mod, cfg, 2, 2, 300, TWIN_LIB, phases_rng=np.random.default_rng(5))
+    ref.reset(True)
+    til.reset(True)
+    for _ in range(50):
+        ref.next_step()
+        til.next_step()
+    assert np.array_equal(ref.get_lane_vehicle_count_array(), til.get_lane_vehicle_count_array())
+    assert ref._scalars()["active_vehicle_count"] == til._scalars()["active_vehicle_count"] > 0
+
+
+def test_tiled_dense_30x30_twin(mod, scen, workdir):
+    cfg = dense_cfg(scen, workdir, "grid_30x30", 300, 3, 4.0)
+    run_pair(mod, cfg, 2, 4, 160, TWIN_LIB, check_every=8)
+
+
+def test_short_cut_lanes_are_rejected(mod, scen, workdir):
+    # the 1x1 example has 300 m roads but no second real intersection: no valid 1x2 partition
+    cfg = scen.materialize("example_1x1", workdir)
+    with pytest.raises(RuntimeError):
+        mod.TiledEngine(cfg, 1, 2, [], TWIN_LIB)
+
+
+def _torchrun(tmp_path, cfg, lib, rows, cols, steps, nproc, port, extra_env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "tiled_worker.py"), cfg, lib, str(rows),
+           str(cols), str(steps)]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_two_ranks_gloo(scen, workdir, tmp_path):
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 200, 2, 29541)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 200" in out.stdout
+
+
+# ------------------------------------------------------------------------------------------------ MI355X
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rows,cols,steps", [("grid_6x6", 2, 2, 700), ("grid_6x6", 3, 3, 400)])
+def test_tiled_equals_single_hip(mod, scen, workdir, name, rows, cols, steps):
+    cfg = scen.materialize(name, workdir)
+    _, _, moved = run_pair(mod, cfg, rows, cols, steps, mod._default_backend_path())
+    assert moved or steps < 500
+
+
+@pytest.mark.gpu
+def test_tiled_dense_30x30_hip_vs_twin(mod, scen, workdir):
+    """2x4 tiles of the dense 30x30 workload on the GPU against the single-engine CPU twin."""
+    cfg = dense_cfg(scen, workdir, "grid_30x30", 600, 3, 4.0)
+    ref = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    til = mod.TiledEngine(cfg, 2, 4)
+    for s in range(240):
+        ref.next_step()
+        til.next_step()
+        if s % 20 == 19:
+            assert np.array_equal(ref.get_lane_vehicle_count_array(), til.get_lane_vehicle_count_array()), "step %d" % s
+    va, vb = ref._vehicle_state(), til._vehicle_state()
+    same_state(va, vb, "final")
+    assert va["vid"].shape[0] > 20000
+
+
+@pytest.mark.gpu
+def test_tiled_rl_lights_hip(mod, scen, workdir):
+    cfg = scen.materialize("grid_6x6", workdir, rlTrafficLight=True)
+    run_pair(mod, cfg, 2, 3, 300, mod._default_backend_path(), phases_rng=np.random.default_rng(11))
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu(scen, workdir, tmp_path):
+    """Two processes (sharing this box's one GPU), one tile each, halo over the host-side gloo group."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, "", 1, 2, 150, 2, 29543, {"CITYFLOW_AMD_DEVICE": "0"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 150" in out.stdout

@@ -1,0 +1,50 @@
+"""Worker of tests/test_tiling.py::test_two_ranks_gloo: one tile per process over torch.distributed (gloo), compared
+step by step on every rank with the same network on a single engine."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cityflow_amd import _cityflow as m  # noqa: E402
+from cityflow_amd.tiled import DistributedEngine  # noqa: E402
+
+
+def main():
+    cfg, lib, rows, cols, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    dist.init_process_group(backend=os.environ.get("CFX_TEST_DIST_BACKEND", "gloo"))
+    rank = dist.get_rank()
+    eng = DistributedEngine(cfg, rows, cols, backend_library=lib)
+    single = m.Engine._with_backend(cfg, 1, lib) if lib else m.Engine(cfg, 1)
+    crossed = 0
+    for s in range(steps):
+        eng.next_step()
+        single.next_step()
+        a = single.get_lane_vehicle_count_array()
+        b = eng.get_lane_vehicle_count_array()
+        assert np.array_equal(a, b), "rank %d step %d: lane counts differ" % (rank, s)
+        if s % 25 == 24:
+            wa = single.get_lane_waiting_vehicle_count_array()
+            wb = eng.get_lane_waiting_vehicle_count_array()
+            assert np.array_equal(wa, wb), "rank %d step %d: waiting counts differ" % (rank, s)
+            sa, sb = single._scalars(), eng.scalars()
+            for k in ("active_vehicle_count", "finished_vehicle_count", "cumulative_travel_time", "vehicle_steps"):
+                assert sa[k] == sb[k], (rank, s, k, sa[k], sb[k])
+            # this rank's vehicles: same per-vehicle state as on the single engine
+            va, vb = single._vehicle_state(), eng.local_vehicle_state()
+            pos = {int(v): i for i, v in enumerate(va["vid"])}
+            idx = np.array([pos[int(v)] for v in vb["vid"]], dtype=np.int64)
+            for k in ("drivable", "dis", "speed", "leader", "blocker", "route_pos", "enter_ll_time"):
+                assert np.array_equal(va[k][idx], vb[k]), "rank %d step %d: %s differs" % (rank, s, k)
+            crossed = max(crossed, len(vb["vid"]))
+    assert crossed > 0
+    dist.barrier()
+    if rank == 0:
+        print("TILED_OK", steps, single.get_vehicle_count())
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
