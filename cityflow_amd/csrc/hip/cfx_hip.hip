@@ -112,6 +112,16 @@ struct cfx_engine {
     char *dHaloSend = nullptr, *dHaloRecv = nullptr;
     char *hHaloSend = nullptr, *hHaloRecv = nullptr;  // pinned staging
     int haloSendBytes = 0, haloRecvBytes = 0;
+    // mailbox exchange (cfx_halo_attach): per peer, device-visible addresses of the two mailboxes
+    struct MailPeer {
+        int sendBytes = 0, recvBytes = 0;
+        void *sendHost = nullptr, *recvHost = nullptr;  // registered with hipHostRegister
+        char *sendDev = nullptr, *recvDev = nullptr;
+    };
+    std::vector<MailPeer> mail;
+    std::vector<int32_t> hGhostSendOff, hGhostRecvOff, hImportSendOff, hImportRecvOff;
+    HaloDev haloMail{};                // block addressing as (peer, offset inside the peer's message)
+    uint32_t generation = 1;           // bumped by cfx_reset: epochs stay monotonic
     int64_t liveUpper = 0;             // tiled: upper bound of occupied slots (refreshed from the device when it runs out)
 
     int64_t step = 0;
@@ -297,12 +307,15 @@ struct cfx_engine {
         HIP_TRY(hipMemcpyAsync(&out, sc, sizeof(DevScalars), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         finishedKnown = out.finishedCnt;
+        if (out.overflow == 4) return fail("halo: a neighbour tile did not publish its step in time (cfx_halo_wait)");
+        if (out.overflow == 3) return fail("halo: more vehicles crossed one cut lane in one step than CFX_HALO_MAX_MIGRANTS");
         if (out.overflow) return fail("device capacity overflow (finish list)");
         return CFX_OK;
     }
 
     int resetState() {
         HIP_TRY(hipStreamSynchronize(stream));
+        generation += 1;
         cur = 0;
         step = 0;
         spawned = 0;
@@ -360,6 +373,10 @@ void cfx_destroy(cfx_engine *e) {
         if (e->stageEvent[i]) (void) hipEventDestroy(e->stageEvent[i]);
         if (e->hPhaseStage[i]) (void) hipHostFree(e->hPhaseStage[i]);
         if (e->phaseStageEvent[i]) (void) hipEventDestroy(e->phaseStageEvent[i]);
+    }
+    for (auto &m : e->mail) {
+        if (m.sendHost) (void) hipHostUnregister(m.sendHost);
+        if (m.recvHost) (void) hipHostUnregister(m.recvHost);
     }
     if (e->hHaloSend) (void) hipHostFree(e->hHaloSend);
     if (e->hHaloRecv) (void) hipHostFree(e->hHaloRecv);
@@ -1068,6 +1085,15 @@ int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
     if ((rc = e->uploadConst(d.llGlobal, h->lanelink_global, (size_t) e->K))) return rc;
     if ((rc = e->uploadConst(d.llLocalOfGlobal, h->lanelink_local, (size_t) h->n_global_lanelinks))) return rc;
     if ((rc = e->allocRaw(&d.ghostHadEntrants, (size_t) h->n_ghost))) return rc;
+    {
+        std::vector<int32_t> zeros((size_t) std::max(h->n_ghost, h->n_import) + 1, 0);
+        if ((rc = e->uploadConst(d.ghostPeer, zeros.data(), (size_t) h->n_ghost))) return rc;
+        if ((rc = e->uploadConst(d.importPeer, zeros.data(), (size_t) h->n_import))) return rc;
+    }
+    e->hGhostSendOff.assign(h->ghost_send_off, h->ghost_send_off + h->n_ghost);
+    e->hGhostRecvOff.assign(h->ghost_recv_off, h->ghost_recv_off + h->n_ghost);
+    e->hImportSendOff.assign(h->import_send_off, h->import_send_off + h->n_import);
+    e->hImportRecvOff.assign(h->import_recv_off, h->import_recv_off + h->n_import);
     e->haloSendBytes = h->send_bytes;
     e->haloRecvBytes = h->recv_bytes;
     if ((rc = e->allocRaw(&e->dHaloSend, (size_t) h->send_bytes))) return rc;
@@ -1084,8 +1110,10 @@ int32_t cfx_halo_export(cfx_engine *e, void *sendHost) {
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
     const int n = e->halo.nGhost + e->halo.nImport;
+    HaloIO io{};
+    io.send[0] = e->dHaloSend;
     if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
-                              e->cs.inCnt, e->dHaloSend, e->sc);
+                              e->cs.inCnt, io, e->sc);
     HIP_TRY(hipGetLastError());
     if (e->haloSendBytes) HIP_TRY(hipMemcpyAsync(e->hHaloSend, e->dHaloSend, (size_t) e->haloSendBytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1103,8 +1131,120 @@ int32_t cfx_halo_import(cfx_engine *e, const void *recvHost) {
         HIP_TRY(hipMemcpyAsync(e->dHaloRecv, e->hHaloRecv, (size_t) e->haloRecvBytes, hipMemcpyHostToDevice, e->stream));
     }
     const int n = e->halo.nGhost + e->halo.nImport;
+    HaloIO io{};
+    io.recv[0] = e->dHaloRecv;
     if (n) hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
-                              e->dHaloRecv, e->vt, e->sc);
+                              io, e->vt, e->sc);
+    HIP_TRY(hipGetLastError());
+    e->liveUpper += (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS;
+    return CFX_OK;
+}
+
+int32_t cfx_halo_attach(cfx_engine *e, int32_t nPeers, const cfx_halo_peer *peers) {
+    if (!e || !e->tiled || nPeers < 0 || (nPeers && !peers)) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    if (nPeers > CFX_HALO_MAX_PEERS) {
+        e->err = "cfx_halo_attach: more neighbour tiles than CFX_HALO_MAX_PEERS";
+        return CFX_ERR_CAPACITY;
+    }
+    if (!e->mail.empty()) {
+        e->err = "cfx_halo_attach: already attached";
+        return CFX_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    e->mail.resize((size_t) nPeers);
+    for (int p = 0; p < nPeers; ++p) {
+        cfx_engine::MailPeer &m = e->mail[p];
+        m.sendBytes = peers[p].send_bytes;
+        m.recvBytes = peers[p].recv_bytes;
+        m.sendHost = peers[p].send_mailbox;
+        m.recvHost = peers[p].recv_mailbox;
+        if (!m.sendHost || !m.recvHost) return CFX_ERR_INVALID;
+        HIP_TRY(hipHostRegister(m.sendHost, CFX_HALO_MAILBOX_BYTES(m.sendBytes), hipHostRegisterMapped | hipHostRegisterPortable));
+        HIP_TRY(hipHostRegister(m.recvHost, CFX_HALO_MAILBOX_BYTES(m.recvBytes), hipHostRegisterMapped | hipHostRegisterPortable));
+        HIP_TRY(hipHostGetDevicePointer((void **) &m.sendDev, m.sendHost, 0));
+        HIP_TRY(hipHostGetDevicePointer((void **) &m.recvDev, m.recvHost, 0));
+    }
+    // address every block as (peer, offset inside that peer's message)
+    auto split = [&](const std::vector<int32_t> &off, bool send, std::vector<int32_t> &peer, std::vector<int32_t> &rel) {
+        peer.resize(off.size());
+        rel.resize(off.size());
+        for (size_t i = 0; i < off.size(); ++i) {
+            int found = -1;
+            for (int p = 0; p < nPeers; ++p) {
+                const int lo = send ? peers[p].send_off : peers[p].recv_off;
+                const int n = send ? peers[p].send_bytes : peers[p].recv_bytes;
+                if (off[i] >= lo && off[i] < lo + n) {
+                    found = p;
+                    rel[i] = off[i] - lo;
+                }
+            }
+            if (found < 0) return false;
+            peer[i] = found;
+        }
+        return true;
+    };
+    std::vector<int32_t> gp, gs, gp2, gr, ip, is, ip2, ir;
+    if (!split(e->hGhostSendOff, true, gp, gs) || !split(e->hGhostRecvOff, false, gp2, gr) ||
+        !split(e->hImportSendOff, true, ip, is) || !split(e->hImportRecvOff, false, ip2, ir) || gp != gp2 || ip != ip2) {
+        e->err = "cfx_halo_attach: peer slices do not cover the halo layout";
+        return CFX_ERR_INVALID;
+    }
+    HaloDev &d = e->haloMail;
+    d = e->halo;  // lanes, maps, ghostHadEntrants are shared with the staged path
+    int rc;
+    if ((rc = e->uploadConst(d.ghostPeer, gp.data(), gp.size()))) return rc;
+    if ((rc = e->uploadConst(d.ghostSendOff, gs.data(), gs.size()))) return rc;
+    if ((rc = e->uploadConst(d.ghostRecvOff, gr.data(), gr.size()))) return rc;
+    if ((rc = e->uploadConst(d.importPeer, ip.data(), ip.size()))) return rc;
+    if ((rc = e->uploadConst(d.importSendOff, is.data(), is.size()))) return rc;
+    if ((rc = e->uploadConst(d.importRecvOff, ir.data(), ir.size()))) return rc;
+    return CFX_OK;
+}
+
+// epoch of the step that has just been launched: (generation, step) packed, monotonic over resets
+static inline unsigned long long haloEpoch(const cfx_engine *e) {
+    return ((unsigned long long) e->generation << 32) | (unsigned long long) (uint32_t) e->step;
+}
+
+int32_t cfx_halo_post(cfx_engine *e) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    const unsigned long long epoch = haloEpoch(e);
+    const int par = (int) (epoch & 1ULL);
+    HaloIO io{};
+    HaloFlags fl{};
+    const int nPeers = (int) e->mail.size();
+    for (int p = 0; p < nPeers; ++p) {
+        io.send[p] = e->mail[p].sendDev + CFX_HALO_MAILBOX_HEADER + (size_t) par * e->mail[p].sendBytes;
+        fl.flag[p] = (unsigned long long *) e->mail[p].sendDev;
+    }
+    const int n = e->halo.nGhost + e->halo.nImport;
+    if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
+                              e->cs.inCnt, io, e->sc);
+    if (nPeers) hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, e->stream, fl, nPeers, epoch);
+    HIP_TRY(hipGetLastError());
+    return CFX_OK;
+}
+
+int32_t cfx_halo_wait(cfx_engine *e) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    const unsigned long long epoch = haloEpoch(e);
+    const int par = (int) (epoch & 1ULL);
+    HaloIO io{};
+    const int nPeers = (int) e->mail.size();
+    for (int p = 0; p < nPeers; ++p) {
+        io.recv[p] = e->mail[p].recvDev + CFX_HALO_MAILBOX_HEADER + (size_t) par * e->mail[p].recvBytes;
+        io.waitFlag[p] = (const unsigned long long *) e->mail[p].recvDev;
+    }
+    io.nWait = nPeers;
+    io.epoch = epoch;
+    const int n = e->halo.nGhost + e->halo.nImport;
+    if (n) hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
+                              io, e->vt, e->sc);
     HIP_TRY(hipGetLastError());
     e->liveUpper += (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS;
     return CFX_OK;

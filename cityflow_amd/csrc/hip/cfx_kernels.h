@@ -922,10 +922,23 @@ __global__ void k_find_vehicle(StepCtx c, int vid, int32_t *out /*[2]: drivable,
 // this step's k_scatter; cs.inCnt still holds the step's per-drivable entrant counts.
 struct HaloDev {
     int nGhost, nImport;
+    // block addresses are (peer, offset inside that peer's message); the staged path is one pseudo-peer 0 whose
+    // "message" is the whole send / recv buffer
     const int32_t *ghostLane, *ghostSendOff, *ghostRecvOff, *importLane, *importRecvOff, *importSendOff;
+    const int32_t *ghostPeer, *importPeer;
     const int32_t *llGlobal;         // [K] local laneLink -> global id
     const int32_t *llLocalOfGlobal;  // [global K] -> local laneLink or -1
     uint8_t *ghostHadEntrants;       // [nGhost] this step's export found entrants (the proxy is already current)
+};
+
+// Where this step's messages live: device staging buffers (cfx_halo_export / _import) or the peers' mailboxes in
+// shared host memory (cfx_halo_post / _wait), and what to wait for before importing.
+struct HaloIO {
+    char *send[CFX_HALO_MAX_PEERS];
+    const char *recv[CFX_HALO_MAX_PEERS];
+    const unsigned long long *waitFlag[CFX_HALO_MAX_PEERS];
+    int nWait;
+    unsigned long long epoch;
 };
 
 struct HaloMigrant {
@@ -950,14 +963,14 @@ __device__ inline int haloGlobalPrev(const StepCtx &c, const HaloDev &h, int pre
     return -1;
 }
 
-__global__ void k_halo_export(StepCtx c, int32_t *cnt, HaloDev h, const int32_t *inCnt, char *send, DevScalars *sc) {
+__global__ void k_halo_export(StepCtx c, int32_t *cnt, HaloDev h, const int32_t *inCnt, HaloIO io, DevScalars *sc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < h.nGhost) {
         // upstream side: the vehicles that entered the ghost lane this step are the last `in` of its segment
         // (entrants are appended behind the stayers, already sorted like Lane::vehicles)
         const int g = h.ghostLane[i];
         const int base = c.segStart[g], n = cnt[g], in = inCnt[g];
-        char *blk = send + h.ghostSendOff[i];
+        char *blk = io.send[h.ghostPeer[i]] + h.ghostSendOff[i];
         int m = in;
         if (m > CFX_HALO_MAX_MIGRANTS) {
             m = CFX_HALO_MAX_MIGRANTS;
@@ -1019,15 +1032,46 @@ __global__ void k_halo_export(StepCtx c, int32_t *cnt, HaloDev h, const int32_t 
             t.dis = 0.0;
             t.speed = 0.0;
         }
-        *(HaloTail *) (send + h.importSendOff[j]) = t;
+        *(HaloTail *) (io.send[h.importPeer[j]] + h.importSendOff[j]) = t;
     }
 }
 
-__global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, const char *recv, VidTable vt, DevScalars *sc) {
+// Publish this step's epoch in every peer's mailbox.  Runs after k_halo_export on the same stream: a kernel boundary
+// orders the export's stores before this system-scope release store.
+struct HaloFlags {
+    unsigned long long *flag[CFX_HALO_MAX_PEERS];  // epoch word in the header of each send mailbox
+};
+__global__ void k_halo_signal(HaloFlags f, int nPeers, unsigned long long epoch) {
+    const int p = threadIdx.x;
+    if (p < nPeers) __hip_atomic_store(f.flag[p], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, HaloIO io, VidTable vt, DevScalars *sc) {
+    if (io.nWait > 0) {  // mailbox path: every block waits until all peers have published this epoch
+        __shared__ int ok;
+        if (threadIdx.x == 0) {
+            ok = 1;
+            for (int p = 0; p < io.nWait && ok; ++p) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(io.waitFlag[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < io.epoch) {
+                    if (++spins > (1u << 22)) {  // a peer died or fell far behind: flag it instead of hanging the device
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+        }
+        __syncthreads();
+        if (!ok) {
+            sc->overflow = 4;
+            return;
+        }
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < h.nImport) {
         const int l = h.importLane[i];
-        const char *blk = recv + h.importRecvOff[i];
+        const char *blk = io.recv[h.importPeer[i]] + h.importRecvOff[i];
         const int m = ((const int32_t *) blk)[0];
         const HaloMigrant *rec = (const HaloMigrant *) (blk + 8);
         const int base = c.segStart[l], n = cnt[l];
@@ -1059,7 +1103,7 @@ __global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, const char *re
     if (j < h.nGhost && !h.ghostHadEntrants[j]) {
         // no entrant of our own this step: the owner's tail is the lane's tail
         const int g = h.ghostLane[j];
-        const HaloTail t = *(const HaloTail *) (recv + h.ghostRecvOff[j]);
+        const HaloTail t = *(const HaloTail *) (io.recv[h.ghostPeer[j]] + h.ghostRecvOff[j]);
         const int base = c.segStart[g], n = cnt[g];
         for (int s = base + (t.vid >= 0 ? 1 : 0); s < base + n; ++s) haloClearSlot(c.s, s);
         if (t.vid < 0) {

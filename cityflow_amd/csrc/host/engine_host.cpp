@@ -60,6 +60,9 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_halo_config)
     CFX_FN(cfx_halo_export)
     CFX_FN(cfx_halo_import)
+    CFX_FN(cfx_halo_attach)
+    CFX_FN(cfx_halo_post)
+    CFX_FN(cfx_halo_wait)
     CFX_FN(cfx_profile_kernel_count)
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)

@@ -345,6 +345,10 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("next_step", &TiledEngineHost::nextStep)
         .def("step_begin", &TiledEngineHost::stepBegin)
         .def("step_end", &TiledEngineHost::stepEnd)
+        .def("enable_mailboxes", &TiledEngineHost::enableMailboxes, "job_id"_a,
+             "Exchange the halo device to device through shared-memory mailboxes (all tiles on one node); job_id must "
+             "be unique per job and equal on every process")
+        .def("unlink_mailboxes", &TiledEngineHost::unlinkMailboxes)
         .def_property_readonly("num_tiles", &TiledEngineHost::nTiles)
         .def_property_readonly("num_local", &TiledEngineHost::nLocal)
         .def("local_rank", &TiledEngineHost::localRank, "i"_a)

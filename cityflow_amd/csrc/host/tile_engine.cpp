@@ -1,6 +1,11 @@
 #include "tile_engine.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cstring>
 #include <iostream>
 #include <numeric>
 #include <stdexcept>
@@ -306,8 +311,54 @@ TileEngine::TileEngine(std::shared_ptr<HostRoadNet> net, const std::vector<int> 
 }
 
 TileEngine::~TileEngine() {
-    if (dev_) be_->cfx_destroy(dev_);
+    if (dev_) be_->cfx_destroy(dev_);  // unregisters the mailboxes before they are unmapped
+    for (Mapping &m : maps_) munmap(m.ptr, m.bytes);
 }
+
+static void *mapShared(const std::string &name, size_t bytes) {
+    int fd = shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0) throw std::runtime_error("tiling: shm_open(" + name + ") failed: " + strerror(errno));
+    if (ftruncate(fd, (off_t) bytes) != 0) {
+        close(fd);
+        throw std::runtime_error("tiling: ftruncate(" + name + ") failed: " + strerror(errno));
+    }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) throw std::runtime_error("tiling: mmap(" + name + ") failed: " + strerror(errno));
+    return p;
+}
+
+void TileEngine::attachMailboxes(const std::string &prefix) {
+    std::vector<cfx_halo_peer> peers;
+    for (const TilePeer &p : tn_.peers) {
+        cfx_halo_peer hp{};
+        hp.send_off = p.sendOff;
+        hp.send_bytes = p.sendBytes;
+        hp.recv_off = p.recvOff;
+        hp.recv_bytes = p.recvBytes;
+        // both ends create-or-open the same name with the same size (fresh shm is zero: epoch 0 = nothing published)
+        Mapping out{prefix + "_" + std::to_string(tn_.rank) + "_" + std::to_string(p.rank), nullptr,
+                    CFX_HALO_MAILBOX_BYTES(p.sendBytes)};
+        out.ptr = mapShared(out.name, out.bytes);
+        maps_.push_back(out);
+        Mapping in{prefix + "_" + std::to_string(p.rank) + "_" + std::to_string(tn_.rank), nullptr,
+                   CFX_HALO_MAILBOX_BYTES(p.recvBytes)};
+        in.ptr = mapShared(in.name, in.bytes);
+        maps_.push_back(in);
+        hp.send_mailbox = out.ptr;
+        hp.recv_mailbox = in.ptr;
+        peers.push_back(hp);
+    }
+    check(be_->cfx_halo_attach(dev_, (int32_t) peers.size(), peers.data()), "cfx_halo_attach");
+    mailboxes_ = true;
+}
+
+void TileEngine::unlinkMailboxes() {
+    for (Mapping &m : maps_) shm_unlink(m.name.c_str());  // the mappings stay valid; only the names go away
+}
+
+void TileEngine::haloPost() { check(be_->cfx_halo_post(dev_), "cfx_halo_post"); }
+void TileEngine::haloWait() { check(be_->cfx_halo_wait(dev_), "cfx_halo_wait"); }
 
 void TileEngine::check(int32_t rc, const char *what) {
     if (rc == CFX_OK) return;
@@ -486,6 +537,10 @@ void TiledEngineHost::stepBegin() {
         t->uploadTables(spawner_);
         t->step(spawnBuf_);
     }
+    if (mailboxes_) {  // device-initiated: export + publish now, the import kernel of stepEnd() does the waiting
+        for (auto &t : tiles_) t->haloPost();
+        return;
+    }
     for (auto &t : tiles_) t->haloExport();
     // messages between two local tiles never leave the process
     for (size_t a = 0; a < tiles_.size(); ++a)
@@ -502,8 +557,26 @@ void TiledEngineHost::stepBegin() {
 }
 
 void TiledEngineHost::stepEnd() {
-    for (auto &t : tiles_) t->haloImport();
+    for (auto &t : tiles_) {
+        if (mailboxes_) t->haloWait();
+        else t->haloImport();
+    }
     step_ += 1;
+}
+
+void TiledEngineHost::enableMailboxes(const std::string &jobId) {
+    if (mailboxes_) return;
+    if (step_ != 0) throw std::runtime_error("tiling: enable the mailboxes before the first step");
+    std::string prefix = "/cfx_" + jobId;
+    for (char &c : prefix)
+        if (!(isalnum((unsigned char) c) || c == '_' || c == '/')) c = '_';
+    for (auto &t : tiles_) t->attachMailboxes(prefix);
+    mailboxes_ = true;
+    if (allLocal_) unlinkMailboxes();
+}
+
+void TiledEngineHost::unlinkMailboxes() {
+    for (auto &t : tiles_) t->unlinkMailboxes();
 }
 
 void TiledEngineHost::nextStep() {

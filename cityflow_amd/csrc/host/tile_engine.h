@@ -67,6 +67,12 @@ public:
     void step(const std::vector<cfx_spawn> &globalRecs);
     void haloExport();  // -> send
     void haloImport();  // <- recv
+    // device-initiated exchange through shared-memory mailboxes named <prefix>_<from>_<to> (POSIX shm)
+    void attachMailboxes(const std::string &prefix);
+    void unlinkMailboxes();  // remove the names once every process has mapped them
+    void haloPost();
+    void haloWait();
+    bool hasMailboxes() const { return mailboxes_; }
     void reset();
     void sync();
 
@@ -87,6 +93,13 @@ private:
     cfx_engine *dev_ = nullptr;
     int templatesUploaded_ = 0, routesUploaded_ = 0;
     std::vector<cfx_spawn> recs_;
+    bool mailboxes_ = false;
+    struct Mapping {
+        std::string name;
+        void *ptr;
+        size_t bytes;
+    };
+    std::vector<Mapping> maps_;
 };
 
 // The tiles this process runs (all of them: one process drives the whole network, e.g. several tiles on one GPU for
@@ -102,6 +115,10 @@ public:
     void nextStep();
     void stepBegin();
     void stepEnd();
+    // Switch the halo to device-initiated mailboxes (all tiles of the job must share one node).  `jobId` must be
+    // unique per job and identical on every process; call unlinkMailboxes() after all processes have enabled.
+    void enableMailboxes(const std::string &jobId);
+    void unlinkMailboxes();
     int nTiles() const { return nTiles_; }
     int nLocal() const { return (int) tiles_.size(); }
     int localRank(int i) const { return localRanks_[i]; }
@@ -138,7 +155,7 @@ private:
     std::vector<int> owner_, localRanks_;
     std::vector<std::unique_ptr<TileEngine>> tiles_;
     int nTiles_ = 1;
-    bool allLocal_ = true;
+    bool allLocal_ = true, mailboxes_ = false;
     size_t step_ = 0;
     std::vector<cfx_spawn> spawnBuf_;
     std::vector<int32_t> pendingInter_, pendingPhase_;

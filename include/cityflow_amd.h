@@ -257,6 +257,29 @@ typedef struct cfx_halo_layout {
 int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *layout);
 int32_t cfx_halo_export(cfx_engine *e, void *send_host);
 int32_t cfx_halo_import(cfx_engine *e, const void *recv_host);
+
+/* Device-initiated exchange (no host round trip).  Every directed neighbour message gets a MAILBOX in host memory that
+ * both engines can reach (the caller maps it into both processes, e.g. POSIX shared memory; the HIP engine registers
+ * it with the device): a 128-byte header whose first 8 bytes are the epoch flag, then two message buffers used
+ * alternately (a sender is never more than one step ahead of its receiver, because its own next import needs the
+ * receiver's next export).  After cfx_halo_attach the per-step exchange is
+ *     cfx_halo_post(e)   export straight into the peers' mailboxes, then publish the step's epoch (system-scope release)
+ *     cfx_halo_wait(e)   wait until every peer has published this epoch (system-scope acquire), then import
+ * both asynchronous on the engine's stream for the HIP engine (the waiting is done by the import kernel, bounded), so a
+ * step never synchronises with the host; CPU implementations block in cfx_halo_wait.  Call post on every local engine
+ * before wait on any.  Epochs grow monotonically over cfx_reset, so mailboxes are never cleared. */
+#define CFX_HALO_MAILBOX_HEADER 128
+#define CFX_HALO_MAILBOX_BYTES(message_bytes) (CFX_HALO_MAILBOX_HEADER + 2 * (size_t) (message_bytes))
+#define CFX_HALO_MAX_PEERS 16
+typedef struct cfx_halo_peer {
+    int32_t send_off, send_bytes; /* this peer's slice of the send layout of cfx_halo_config */
+    int32_t recv_off, recv_bytes; /* ... and of the recv layout */
+    void *send_mailbox;           /* CFX_HALO_MAILBOX_BYTES(send_bytes), written by this engine */
+    void *recv_mailbox;           /* CFX_HALO_MAILBOX_BYTES(recv_bytes), written by the peer */
+} cfx_halo_peer;
+int32_t cfx_halo_attach(cfx_engine *e, int32_t n_peers, const cfx_halo_peer *peers);
+int32_t cfx_halo_post(cfx_engine *e);
+int32_t cfx_halo_wait(cfx_engine *e);
 /* spawn records whose lane is not part of this engine's sub-network carry lane = -1: only the per-vehicle
  * static table is filled (every tile knows every vehicle, so migrants need no static payload). */
 

@@ -13,6 +13,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <unistd.h>
 #include <deque>
 #include <string>
 #include <vector>
@@ -72,6 +73,14 @@ struct cfx_engine {
     std::vector<uint8_t> laneGhost, ghostHadEntrants;
     std::vector<int32_t> ghostLane, ghostSendOff, ghostRecvOff, importLane, importRecvOff, importSendOff, llGlobal,
         llLocalOfGlobal, inCntStep;
+    struct MailPeer {
+        int sendOff, sendBytes, recvOff, recvBytes;
+        char *sendBox, *recvBox;
+    };
+    std::vector<MailPeer> mail;
+    int sendTotal = 0, recvTotal = 0;
+    uint32_t generation = 1;
+    unsigned long long haloEpoch() const { return ((unsigned long long) generation << 32) | (uint32_t) step; }
     bool onGhost(const Veh &v) const { return tiled && v.drivable >= 0 && isLane(v.drivable) && laneGhost[v.drivable]; }
 
     // ------------------------------------------------------------------ small accessors
@@ -703,6 +712,7 @@ struct cfx_engine {
     }
 
     void resetState() {
+        generation += 1;
         veh.clear();
         for (auto &o : order) o.clear();
         for (auto &w : waiting) w.clear();
@@ -1041,6 +1051,47 @@ int32_t cfx_halo_export(cfx_engine *e, void *send) {
 int32_t cfx_halo_import(cfx_engine *e, const void *recv) {
     if (!e || !e->tiled) return CFX_ERR_INVALID;
     e->haloImport((const char *) recv);
+    return CFX_OK;
+}
+
+int32_t cfx_halo_attach(cfx_engine *e, int32_t nPeers, const cfx_halo_peer *peers) {
+    if (!e || !e->tiled || nPeers < 0 || nPeers > CFX_HALO_MAX_PEERS || !e->mail.empty()) return CFX_ERR_INVALID;
+    for (int p = 0; p < nPeers; ++p) {
+        e->mail.push_back({peers[p].send_off, peers[p].send_bytes, peers[p].recv_off, peers[p].recv_bytes,
+                           (char *) peers[p].send_mailbox, (char *) peers[p].recv_mailbox});
+        e->sendTotal = std::max(e->sendTotal, peers[p].send_off + peers[p].send_bytes);
+        e->recvTotal = std::max(e->recvTotal, peers[p].recv_off + peers[p].recv_bytes);
+    }
+    return CFX_OK;
+}
+int32_t cfx_halo_post(cfx_engine *e) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    e->err.clear();
+    std::vector<char> send((size_t) e->sendTotal + 1);
+    e->haloExport(send.data());
+    const unsigned long long epoch = e->haloEpoch();
+    for (auto &m : e->mail) {
+        memcpy(m.sendBox + CFX_HALO_MAILBOX_HEADER + (size_t) (epoch & 1) * m.sendBytes, send.data() + m.sendOff, (size_t) m.sendBytes);
+        __atomic_store_n((unsigned long long *) m.sendBox, epoch, __ATOMIC_RELEASE);
+    }
+    return e->err.empty() ? CFX_OK : CFX_ERR_CAPACITY;
+}
+int32_t cfx_halo_wait(cfx_engine *e) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    const unsigned long long epoch = e->haloEpoch();
+    std::vector<char> recv((size_t) e->recvTotal + 1);
+    for (auto &m : e->mail) {
+        unsigned long long spins = 0;
+        while (__atomic_load_n((const unsigned long long *) m.recvBox, __ATOMIC_ACQUIRE) < epoch) {
+            if (++spins > 20000000ULL) {  // ~20 s
+                e->err = "halo: a neighbour tile did not publish its step in time";
+                return CFX_ERR_STATE;
+            }
+            if (spins > 1000) usleep(1);
+        }
+        memcpy(recv.data() + m.recvOff, m.recvBox + CFX_HALO_MAILBOX_HEADER + (size_t) (epoch & 1) * m.recvBytes, (size_t) m.recvBytes);
+    }
+    e->haloImport(recv.data());
     return CFX_OK;
 }
 

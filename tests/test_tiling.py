@@ -30,9 +30,11 @@ def same_state(va, vb, where):
             assert np.array_equal(va[k], vb[k]), "%s field %s" % (where, k)
 
 
-def run_pair(mod, cfg, rows, cols, steps, lib, phases_rng=None, check_every=1):
+def run_pair(mod, cfg, rows, cols, steps, lib, phases_rng=None, check_every=1, mailboxes=False):
     ref = mod.Engine._with_backend(cfg, 1, lib)
     til = mod.TiledEngine(cfg, rows, cols, [], lib)
+    if mailboxes:
+        til.enable_mailboxes("test_%d_%d%d" % (os.getpid(), rows, cols))
     assert til.num_tiles == rows * cols and til.num_local == rows * cols
     n_inter = len(ref.intersection_ids())
     moved = False
@@ -82,9 +84,14 @@ def test_tiled_equals_single_twin(mod, scen, workdir, rows, cols):
     assert moved  # vehicles crossed the whole grid, i.e. several tile borders
 
 
+def test_tiled_mailboxes_twin(mod, scen, workdir):
+    cfg = scen.materialize("grid_6x6", workdir)
+    run_pair(mod, cfg, 2, 3, 400, TWIN_LIB, mailboxes=True)
+
+
 def test_tiled_rl_lights_and_reset_twin(mod, scen, workdir):
     cfg = scen.materialize("grid_6x6", workdir, rlTrafficLight=True)
-    ref, til, _ = run_pair(mod, cfg, 2, 2, 300, TWIN_LIB, phases_rng=np.random.default_rng(5))
+    ref, til, _ = run_pair(mod, cfg, 2, 2, 300, TWIN_LIB, phases_rng=np.random.default_rng(5), mailboxes=True)
     ref.reset(True)
     til.reset(True)
     for _ in range(50):
@@ -115,9 +122,11 @@ def _torchrun(tmp_path, cfg, lib, rows, cols, steps, nproc, port, extra_env=None
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
 
 
-def test_two_ranks_gloo(scen, workdir, tmp_path):
+@pytest.mark.parametrize("mailboxes", ["0", "1"])
+def test_two_ranks_gloo(scen, workdir, tmp_path, mailboxes):
+    """One tile per process; halo staged over gloo ("0") or through shared-memory mailboxes ("1")."""
     cfg = scen.materialize("grid_6x6", workdir)
-    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 200, 2, 29541)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 200, 2, 29541 + int(mailboxes), {"CFX_TEST_MAILBOXES": mailboxes})
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "TILED_OK 200" in out.stdout
 
@@ -154,9 +163,18 @@ def test_tiled_rl_lights_hip(mod, scen, workdir):
 
 
 @pytest.mark.gpu
-def test_two_ranks_one_gpu(scen, workdir, tmp_path):
-    """Two processes (sharing this box's one GPU), one tile each, halo over the host-side gloo group."""
+def test_tiled_mailboxes_hip(mod, scen, workdir):
+    """All tiles in one process, halo device to device through the mailboxes (import kernels wait on epochs)."""
     cfg = scen.materialize("grid_6x6", workdir)
-    out = _torchrun(tmp_path, cfg, "", 1, 2, 150, 2, 29543, {"CITYFLOW_AMD_DEVICE": "0"})
+    run_pair(mod, cfg, 2, 3, 500, mod._default_backend_path(), mailboxes=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mailboxes", ["0", "1"])
+def test_two_ranks_one_gpu(scen, workdir, tmp_path, mailboxes):
+    """Two processes (sharing this box's one GPU), one tile each; halo over gloo ("0") or GPU-written mailboxes ("1")."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, "", 1, 2, 150, 2, 29545 + int(mailboxes),
+                    {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": mailboxes})
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "TILED_OK 150" in out.stdout
