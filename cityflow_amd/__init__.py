@@ -16,6 +16,7 @@ except ImportError as exc:  # pragma: no cover - exercised only on unbuilt trees
 Engine = _cityflow.Engine
 Archive = _cityflow.Archive
 VectorEngine = _cityflow.VectorEngine
+TiledEngine = _cityflow.TiledEngine  # one network over several engines; cityflow_amd.tiled.DistributedEngine = one per GPU
 __version__ = _cityflow.__version__
 
-__all__ = ["Engine", "Archive", "VectorEngine", "__version__"]
+__all__ = ["Engine", "Archive", "VectorEngine", "TiledEngine", "__version__"]
