@@ -276,6 +276,7 @@ def main():
                                 "one replica per GPU" if world > 1 else "single engine")),
                 "running_vehicles_start": run0, "running_vehicles_end": run1,
                 "lanes": len(eng.lane_ids()),
+                "halo": ("gpu-written shared-memory mailboxes" if eng.mailboxes else "staged over gloo") if tiled else None,
                 "parallelism": ("tiles %dx%d + halo" % (rows, cols)) if tiled else (
                     "replica x%d" % world if world > 1 else "1 gpu"),
             },

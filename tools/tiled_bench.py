@@ -31,6 +31,8 @@ def main():
         rank = dist.get_rank()
     else:
         eng = m.TiledEngine(cfg, rows, cols, [], lib)
+        if os.environ.get("CFX_MAILBOXES", "1") == "1":
+            eng.enable_mailboxes("tiled_bench_%d" % os.getpid())
         rank = 0
     for _ in range(warmup):
         eng.next_step()
