@@ -50,7 +50,8 @@ struct SlotArrays {
     int32_t *drv;       // ControllerInfo::drivable (-1 in a spare slot)
     int32_t *prevDrv;   // ControllerInfo::prevDrivable (-1 none)
     int32_t *next;      // Router::getNextDrivable(0) for the current drivable, cached (-1 none)
-    int32_t *blocker;   // ControllerInfo::blocker as a slot index of the PREVIOUS generation (-1 none);
+    int32_t *blocker;   // ControllerInfo::blocker as a slot index of the PREVIOUS generation (-1 none;
+                        // <= -2: -(vid + 2) of a proxy on a ghost lane, tiling only — ends blocker chains like -1);
                         // resolved through oldToNew[] (see blockerOf)
     int32_t *enterLLT;  // ControllerInfo::enterLaneLinkTime
     int32_t *routePos;  // Router::iCurRoad as index into the route

@@ -793,8 +793,13 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
         if (view->prev_drivable) view->prev_drivable[i] = prev[s];
         if (view->leader_vid) view->leader_vid[i] = lead[s] >= 0 ? vid[lead[s]] : -1;
         if (view->blocker_vid) {
-            int b = blk[s] >= 0 ? o2n[blk[s]] : -1;
-            view->blocker_vid[i] = b >= 0 ? vid[b] : -1;
+            if (blk[s] <= -2) {  // kept by vehicle id (a proxy on a ghost lane, see k_cross)
+                view->blocker_vid[i] = -blk[s] - 2;
+            } else {
+                int b = blk[s] >= 0 ? o2n[blk[s]] : -1;
+                int bv = b >= 0 ? vid[b] : -1;
+                view->blocker_vid[i] = bv <= -2 ? -bv - 2 : bv;  // tombstone of a vehicle that migrated to a neighbour
+            }
         }
         if (view->enter_ll_time) view->enter_ll_time[i] = ellt[s];
         if (view->route_pos) view->route_pos[i] = rpos[s];

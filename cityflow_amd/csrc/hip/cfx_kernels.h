@@ -604,6 +604,12 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(StepCtx c, ActionOut o, J
         }
         if (g == 0) {
             double v = min2(o.b.speed[s], iv);
+            if (blockerSlot >= 0 && c.n.laneGhost) {
+                // tiling: a blocker that sits on a ghost lane is a proxy whose slot is recycled by the halo exchange;
+                // keep it by vehicle id (-(vid + 2)).  Chain walks end there either way: proxies carry no blocker.
+                const int bd = c.s.drv[blockerSlot];
+                if (bd < c.n.L && c.n.laneGhost[bd]) blockerSlot = -(c.s.vid[blockerSlot] + 2);
+            }
             finishAction(c, o, t, s, d, c.s.vid[s], speed, dis, dlen, nd0, v, blockerSlot);
         }
     }
@@ -951,8 +957,11 @@ struct HaloTail {
 };
 static_assert(sizeof(HaloMigrant) == 32 && sizeof(HaloTail) == CFX_HALO_TAIL_BYTES, "halo record layout");
 
+// A slot whose vehicle now lives in a neighbouring tile: empty for every kernel (vid < 0), but it keeps the vehicle's
+// identity as a tombstone -(vid + 2), so a committed blocker that still points here reports the right vehicle.
 __device__ inline void haloClearSlot(const SlotArrays &s, int slot) {
-    s.vid[slot] = -1;
+    const int v = s.vid[slot];
+    s.vid[slot] = v >= 0 ? -(v + 2) : v;
     s.drv[slot] = -1;
     s.blocker[slot] = -1;
 }

@@ -1,0 +1,70 @@
+"""BASELINE.json configs[4] — 100x100 grid, ~1M running vehicles, 8 tiles, per-step set_tl_phase / get_lane_vehicle_count
+RL calls — through the size-independent property the tiling offers: the tiled network (2x4 tiles, halo through GPU
+mailboxes; all on the one GPU of the test box) and the single engine, driven by the same random signal plan and read
+back through the RL getters every step, must agree exactly.  The same loop runs small on the CPU twin."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import TWIN_LIB
+
+
+def build(scen, workdir, n, flows_per_100_inters, **config):
+    base = scen.generate_grid(n, n, workdir)
+    d = os.path.dirname(base)
+    n_extra = n * n * flows_per_100_inters // 100
+    flow = os.path.join(d, "flow_rl_%d.json" % n_extra)
+    if not os.path.exists(flow):
+        scen.dense_flows(os.path.join(d, "roadnet.json"), flow, n_extra, seed=4242, interval=6.0,
+                         base_flow=os.path.join(d, "flow.json"), end_time=240)
+    import json
+    cfg = dict(json.load(open(base)), flowFile=os.path.basename(flow), rlTrafficLight=True, **config)
+    path = os.path.join(d, "config_rl.json")
+    with open(path, "w") as f:
+        json.dump(cfg, f)
+    return path
+
+
+def rl_loop(mod, cfg, rows, cols, lib, warmup, steps, min_running):
+    single = mod.Engine._with_backend(cfg, 1, lib)
+    tiled = mod.TiledEngine(cfg, rows, cols, [], lib)
+    tiled.enable_mailboxes("full_%d_%d" % (os.getpid(), rows * cols))
+    rng = np.random.default_rng(2024)
+    n_inter = len(single.intersection_ids())
+    for s in range(warmup + steps):
+        if s % 15 == 0:  # the agent's action: a new phase for every signal
+            ph = rng.integers(0, 8, size=n_inter).astype(np.int32)
+            single.set_tl_phases(ph)
+            tiled.set_tl_phases(ph)
+        single.next_step()
+        tiled.next_step()
+        if s >= warmup or s % 50 == 49:  # the agent's observation
+            a, b = single.get_lane_vehicle_count_array(), tiled.get_lane_vehicle_count_array()
+            assert np.array_equal(a, b), "step %d: lane counts differ on %d lanes" % (s, int((a != b).sum()))
+    assert np.array_equal(single.get_lane_waiting_vehicle_count_array(), tiled.get_lane_waiting_vehicle_count_array())
+    sa, sb = single._scalars(), tiled._scalars()
+    for k in ("active_vehicle_count", "finished_vehicle_count", "vehicle_steps", "cumulative_travel_time"):
+        assert sa[k] == sb[k], (k, sa[k], sb[k])
+    assert sa["active_vehicle_count"] >= min_running, sa["active_vehicle_count"]
+    va, vb = single._vehicle_state(), tiled._vehicle_state()
+    for k in ("vid", "drivable", "dis", "speed", "leader", "blocker"):
+        if not np.array_equal(va[k], vb[k]):
+            bad = np.nonzero(va[k] != vb[k])[0]
+            raise AssertionError("field %s differs for %d vehicles; first: vid %s drivable %s single %s tiled %s" % (
+                k, bad.size, va["vid"][bad[:5]], va["drivable"][bad[:5]], va[k][bad[:5]], vb[k][bad[:5]]))
+    return sa["active_vehicle_count"]
+
+
+def test_rl_loop_12x12_twin(mod, scen, workdir):
+    cfg = build(scen, workdir, 12, 330)
+    rl_loop(mod, cfg, 2, 2, TWIN_LIB, warmup=150, steps=30, min_running=5000)
+
+
+@pytest.mark.gpu
+def test_config5_100x100_one_million_vehicles(mod, scen, workdir):
+    t0 = time.time()
+    cfg = build(scen, workdir, 100, 333)
+    running = rl_loop(mod, cfg, 2, 4, mod._default_backend_path(), warmup=300, steps=40, min_running=900000)
+    print("100x100: %d running vehicles, %.0f s" % (running, time.time() - t0))
