@@ -43,12 +43,23 @@ EXTRA_END = 240
 
 def build_workload(workdir, seed, scenario="grid_30x30", n_extra=N_EXTRA_FLOWS):
     from cityflow_amd import scenarios
-    base = scenarios.materialize(scenario, workdir)
+    generated = scenario.startswith("gen_")  # gen_RxC: a generator-format grid of any size (developer runs)
+    if generated:
+        r, c = (int(x) for x in scenario[4:].split("x"))
+        base = scenarios.generate_grid(r, c, workdir, seed=seed)
+    else:
+        base = scenarios.materialize(scenario, workdir)
     d = os.path.dirname(base)
     flow = os.path.join(d, "flow_bench_%d.json" % n_extra)
     if not os.path.exists(flow):
         scenarios.dense_flows(os.path.join(d, "roadnet.json"), flow, n_extra, seed=12345, interval=EXTRA_INTERVAL,
                               base_flow=os.path.join(d, "flow.json"), end_time=EXTRA_END)
+    if generated:
+        cfg = dict(json.load(open(base)), flowFile=os.path.basename(flow))
+        path = os.path.join(d, "config_bench.json")
+        with open(path, "w") as f:
+            json.dump(cfg, f)
+        return path
     return scenarios.materialize(scenario, workdir, flow_file=flow, seed=seed)
 
 
