@@ -120,6 +120,7 @@ struct cfx_engine {
     };
     std::vector<MailPeer> mail;
     std::vector<int32_t> hGhostSendOff, hGhostRecvOff, hImportSendOff, hImportRecvOff;
+    int32_t *haloTicket = nullptr;
     HaloDev haloMail{};                // block addressing as (peer, offset inside the peer's message)
     uint32_t generation = 1;           // bumped by cfx_reset: epochs stay monotonic
     int64_t liveUpper = 0;             // tiled: upper bound of occupied slots (refreshed from the device when it runs out)
@@ -1204,6 +1205,8 @@ int32_t cfx_halo_attach(cfx_engine *e, int32_t nPeers, const cfx_halo_peer *peer
     if ((rc = e->uploadConst(d.importPeer, ip.data(), ip.size()))) return rc;
     if ((rc = e->uploadConst(d.importSendOff, is.data(), is.size()))) return rc;
     if ((rc = e->uploadConst(d.importRecvOff, ir.data(), ir.size()))) return rc;
+    if ((rc = e->allocRaw(&e->haloTicket, 1))) return rc;
+    HIP_TRY(hipMemset(e->haloTicket, 0, sizeof(int32_t)));
     return CFX_OK;
 }
 
@@ -1219,16 +1222,17 @@ int32_t cfx_halo_post(cfx_engine *e) {
     const unsigned long long epoch = haloEpoch(e);
     const int par = (int) (epoch & 1ULL);
     HaloIO io{};
-    HaloFlags fl{};
     const int nPeers = (int) e->mail.size();
     for (int p = 0; p < nPeers; ++p) {
         io.send[p] = e->mail[p].sendDev + CFX_HALO_MAILBOX_HEADER + (size_t) par * e->mail[p].sendBytes;
-        fl.flag[p] = (unsigned long long *) e->mail[p].sendDev;
+        io.signalFlag[p] = (unsigned long long *) e->mail[p].sendDev;
     }
-    const int n = e->halo.nGhost + e->halo.nImport;
+    io.nSignal = nPeers;
+    io.ticket = e->haloTicket;
+    io.epoch = epoch;
+    const int n = e->halo.nGhost + e->halo.nImport;  // every peer implies at least one cut lane, so n > 0 with peers
     if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
                               e->cs.inCnt, io, e->sc);
-    if (nPeers) hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, e->stream, fl, nPeers, epoch);
     HIP_TRY(hipGetLastError());
     return CFX_OK;
 }

@@ -944,6 +944,9 @@ struct HaloIO {
     const char *recv[CFX_HALO_MAX_PEERS];
     const unsigned long long *waitFlag[CFX_HALO_MAX_PEERS];
     int nWait;
+    unsigned long long *signalFlag[CFX_HALO_MAX_PEERS];  // epoch word of every send mailbox (mailbox path only)
+    int nSignal;
+    int32_t *ticket;  // arrival counter of the export threads (re-armed by the last one)
     unsigned long long epoch;
 };
 
@@ -972,8 +975,8 @@ __device__ inline int haloGlobalPrev(const StepCtx &c, const HaloDev &h, int pre
     return -1;
 }
 
-__global__ void k_halo_export(StepCtx c, int32_t *cnt, HaloDev h, const int32_t *inCnt, HaloIO io, DevScalars *sc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline void haloExportLane(const StepCtx &c, int32_t *cnt, const HaloDev &h, const int32_t *inCnt, const HaloIO &io,
+                                      DevScalars *sc, int i) {
     if (i < h.nGhost) {
         // upstream side: the vehicles that entered the ghost lane this step are the last `in` of its segment
         // (entrants are appended behind the stayers, already sorted like Lane::vehicles)
@@ -1045,14 +1048,21 @@ __global__ void k_halo_export(StepCtx c, int32_t *cnt, HaloDev h, const int32_t 
     }
 }
 
-// Publish this step's epoch in every peer's mailbox.  Runs after k_halo_export on the same stream: a kernel boundary
-// orders the export's stores before this system-scope release store.
-struct HaloFlags {
-    unsigned long long *flag[CFX_HALO_MAX_PEERS];  // epoch word in the header of each send mailbox
-};
-__global__ void k_halo_signal(HaloFlags f, int nPeers, unsigned long long epoch) {
-    const int p = threadIdx.x;
-    if (p < nPeers) __hip_atomic_store(f.flag[p], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// One thread per cut lane.  On the mailbox path the last thread to finish publishes the step's epoch in every peer's
+// mailbox: each thread fences its stores at system scope before taking a ticket, the last one fences again after
+// reading the final ticket and then does the release stores, so the peers' acquire loads see complete messages.
+__global__ void k_halo_export(StepCtx c, int32_t *cnt, HaloDev h, const int32_t *inCnt, HaloIO io, DevScalars *sc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = h.nGhost + h.nImport;
+    if (i >= n) return;
+    haloExportLane(c, cnt, h, inCnt, io, sc, i);
+    if (io.nSignal == 0) return;
+    __threadfence_system();
+    if (atomicAdd(io.ticket, 1) != n - 1) return;
+    __threadfence_system();
+    *io.ticket = 0;
+    for (int p = 0; p < io.nSignal; ++p)
+        __hip_atomic_store(io.signalFlag[p], io.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, HaloIO io, VidTable vt, DevScalars *sc) {
