@@ -20,7 +20,7 @@ HOST_DIR = os.path.join(HERE, "csrc", "host")
 HIP_DIR = os.path.join(HERE, "csrc", "hip")
 LIB_DIR = os.path.join(HERE, "lib")
 
-HOST_SRCS = ["roadnet.cpp", "flow.cpp", "engine_host.cpp", "archive.cpp", "vector_engine.cpp", "tile_engine.cpp", "pymodule.cpp"]
+HOST_SRCS = ["roadnet.cpp", "flow.cpp", "engine_host.cpp", "archive.cpp", "vector_engine.cpp", "tile_engine.cpp", "replay.cpp", "pymodule.cpp"]
 
 # -ffp-contract=off: the reference is built by g++ for x86-64 without FMA contraction; every double
 # expression on the parity path must round exactly like it.

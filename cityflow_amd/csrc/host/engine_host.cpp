@@ -111,8 +111,17 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
         dir_ = cfg.stringAt("dir");
         roadnetFile = cfg.stringAt("roadnetFile");
         flowFile = cfg.stringAt("flowFile");
-        saveReplay_ = cfg.boolAt("saveReplay");
+        saveReplayInConfig_ = saveReplay_ = cfg.boolAt("saveReplay");
+        std::string roadnetLogFile, replayLogFile;
+        if (saveReplay_) {  // engine.cpp:73-77: both keys are required then
+            roadnetLogFile = cfg.stringAt("roadnetLogFile");
+            replayLogFile = cfg.stringAt("replayLogFile");
+        }
         net_->load(dir_ + roadnetFile);
+        if (saveReplay_) {  // Engine::setLogFile engine.cpp:773-778
+            if (!writeRoadnetLog(*net_, dir_ + roadnetLogFile)) std::cerr << "write roadnet log file error" << std::endl;
+            replay_.open(dir_ + replayLogFile);
+        }
         spawner_.init(net_.get(), interval_, threadNum_, seed_);
         spawner_.loadFlows(dir_ + flowFile);
     } catch (const JsonError &e) {
@@ -121,9 +130,6 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
     if (laneChange_)
         throw std::runtime_error(
             "cityflow_amd: laneChange=true is not implemented yet on the device path (SURVEY.md §8f row 3)");
-    if (saveReplay_)
-        std::cerr << "[cityflow_amd] saveReplay is accepted but no replay file is written (out of scope, SURVEY.md §8f row 4)"
-                  << std::endl;
 
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
     cfx_config cc{};
@@ -208,7 +214,34 @@ void EngineHost::nextStep() {
     spawner_.step(step_, spawnBuf_);
     uploadNewTablesIfAny();
     check(be_.cfx_step(dev_, spawnBuf_.data(), (int32_t) spawnBuf_.size()), "cfx_step");
+    if (saveReplay_) updateLog();
     step_ += 1;
+}
+
+// Engine::updateLog (engine.cpp:518-554): the state after the step, lights after TrafficLight::passTime
+void EngineHost::updateLog() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::vector<int32_t> phase;
+    std::vector<double> remain;
+    trafficLightState(phase, remain);
+    replay_.writeStep(*net_, spawner_, s, phase);
+}
+
+void EngineHost::setReplayLogFile(const std::string &logFile) {
+    if (!saveReplayInConfig_) {
+        std::cerr << "saveReplay is not set to true in config file!" << std::endl;
+        return;
+    }
+    replay_.open(dir_ + logFile);
+}
+
+void EngineHost::setSaveReplay(bool open) {
+    if (!saveReplayInConfig_) {
+        std::cerr << "saveReplay is not set to true in config file!" << std::endl;
+        return;
+    }
+    saveReplay_ = open;
 }
 
 void EngineHost::sync() { check(be_.cfx_sync(dev_), "cfx_sync"); }

@@ -15,6 +15,7 @@
 #include "archive.h"
 #include "cityflow_amd.h"
 #include "flow.h"
+#include "replay.h"
 #include "roadnet.h"
 
 namespace cfa {
@@ -98,6 +99,8 @@ public:
     Archive snapshot();                        // engine.h:177
     void load(const Archive &archive);         // engine.h:176
     void loadFromFile(const std::string &path);  // engine.cpp:822-825
+    void setReplayLogFile(const std::string &logFile);  // engine.cpp:727-734
+    void setSaveReplay(bool open);                       // engine.cpp:736-742
 
     // ---- array getters (no string marshalling; for large grids / RL observation tensors) ----
     std::vector<int32_t> laneVehicleCountArray();
@@ -134,7 +137,9 @@ private:
     Backend be_;
     cfx_engine *dev_ = nullptr;
     double interval_ = 1.0;
-    bool rlTrafficLight_ = false, laneChange_ = false, saveReplay_ = false;
+    bool rlTrafficLight_ = false, laneChange_ = false, saveReplay_ = false, saveReplayInConfig_ = false;
+    ReplayWriter replay_;
+    void updateLog();  // Engine::updateLog engine.cpp:518-554
     int seed_ = 0, threadNum_ = 1;
     std::string dir_;
     size_t step_ = 0;

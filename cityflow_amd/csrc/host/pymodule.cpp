@@ -198,11 +198,8 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("load", &EngineHost::load, "archive"_a)
         .def("snapshot", &EngineHost::snapshot)
         .def("load_from_file", &EngineHost::loadFromFile, "path"_a)
-        // replay logging is out of scope: accepted, message like the reference's when disabled
-        .def("set_replay_file", [](EngineHost &, const std::string &) {
-            std::cerr << "saveReplay is not set to true in config file!" << std::endl; }, "replay_file"_a)
-        .def("set_save_replay", [](EngineHost &, bool) {
-            std::cerr << "saveReplay is not set to true in config file!" << std::endl; }, "open"_a)
+        .def("set_replay_file", &EngineHost::setReplayLogFile, "replay_file"_a)
+        .def("set_save_replay", &EngineHost::setSaveReplay, "open"_a)
         // ---- array API (index order == lane_ids() / intersection_ids()) ----
         .def("lane_ids", &EngineHost::laneIds)
         .def("intersection_ids", &EngineHost::intersectionIds)
