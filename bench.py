@@ -83,8 +83,7 @@ def build_tiled_workload(workdir, rows, cols, block, n_extra_per_tile):
                               base_flow=os.path.join(d, "flow.json"), end_time=EXTRA_END)
     cfg = dict(json.load(open(base)), flowFile=os.path.basename(flow))
     path = os.path.join(d, "config_bench.json")
-    with open(path, "w") as f:
-        json.dump(cfg, f)
+    scenarios._write_json_atomic(path, cfg)
     return path
 
 

@@ -403,28 +403,7 @@ std::map<std::string, double> EngineHost::getVehicleDistance() {
     return ret;
 }
 
-int EngineHost::vidOf(const std::string &id) {
-    auto number = [](const std::string &t, int &out) {
-        if (t.empty() || t.size() > 9) return false;
-        for (char c : t)
-            if (c < '0' || c > '9') return false;
-        out = atoi(t.c_str());
-        return std::to_string(out) == t;
-    };
-    const std::string mp = "manually_pushed_";
-    int n = 0;
-    if (id.compare(0, mp.size(), mp) == 0) {
-        if (!number(id.substr(mp.size()), n) || n >= (int) spawner_.manualVids.size()) return -1;
-        return spawner_.manualVids[n];
-    }
-    if (id.compare(0, 5, "flow_") != 0) return -1;
-    size_t us = id.find('_', 5);
-    if (us == std::string::npos) return -1;
-    int f = 0;
-    if (!number(id.substr(5, us - 5), f) || !number(id.substr(us + 1), n)) return -1;
-    if (f >= (int) spawner_.flowVids.size() || n >= (int) spawner_.flowVids[f].size()) return -1;
-    return spawner_.flowVids[f][n];
-}
+int EngineHost::vidOf(const std::string &id) { return spawner_.vidOfId(id); }
 
 // getLeader engine.cpp:836-850
 std::string EngineHost::getLeader(const std::string &vehicleId) {

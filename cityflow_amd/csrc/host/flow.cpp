@@ -288,7 +288,30 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
     pendingRecords_.clear();
 }
 
-int Spawner::internRoute(const std::vector<int> &seq) {
+int Spawner::vidOfId(const std::string &id) const {
+    auto number = [](const std::string &t, int &out) {
+        if (t.empty() || t.size() > 9) return false;
+        for (char c : t)
+            if (c < '0' || c > '9') return false;
+        out = atoi(t.c_str());
+        return std::to_string(out) == t;
+    };
+    const std::string mp = "manually_pushed_";
+    int n = 0;
+    if (id.compare(0, mp.size(), mp) == 0) {
+        if (!number(id.substr(mp.size()), n) || n >= (int) manualVids.size()) return -1;
+        return manualVids[n];
+    }
+    if (id.compare(0, 5, "flow_") != 0) return -1;
+    size_t us = id.find('_', 5);
+    if (us == std::string::npos) return -1;
+    int f = 0;
+    if (!number(id.substr(5, us - 5), f) || !number(id.substr(us + 1), n)) return -1;
+    if (f >= (int) flowVids.size() || n >= (int) flowVids[f].size()) return -1;
+    return flowVids[f][n];
+}
+int Spawner::internRoute(
+const std::vector<int> &seq) {
     auto it = routeIndex_.find(seq);
     if (it != routeIndex_.end()) return it->second;
     int r = routes.add(*net_, seq);

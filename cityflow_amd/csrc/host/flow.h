@@ -100,6 +100,7 @@ public:
     void seed(int s) { rnd.seed((std::mt19937::result_type) s); }
 
     std::string vehicleId(int vid) const;
+    int vidOfId(const std::string &id) const;  // inverse of vehicleId (-1 if unknown)
     int initialSeed() const { return seed_; }
 
     // Route index for an expanded road sequence, adding it if it is new (used by set_vehicle_route and

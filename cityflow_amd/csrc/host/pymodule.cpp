@@ -373,6 +373,16 @@ PYBIND11_MODULE(_cityflow, m) {
              },
              "i"_a)
         .def("get_vehicle_count", &TiledEngineHost::getVehicleCount)
+        .def("get_vehicles", &TiledEngineHost::getVehicles, "include_waiting"_a = false)
+        .def("get_lane_vehicles", &TiledEngineHost::getLaneVehicles)
+        .def("get_vehicle_speed", &TiledEngineHost::getVehicleSpeed)
+        .def("get_vehicle_distance", &TiledEngineHost::getVehicleDistance)
+        .def("get_vehicle_info", &TiledEngineHost::getVehicleInfo, "vehicle_id"_a)
+        .def("get_leader", &TiledEngineHost::getLeader, "vehicle_id"_a)
+        .def("get_average_travel_time", &TiledEngineHost::getAverageTravelTime)
+        .def("push_vehicle", &TiledEngineHost::pushVehicle)
+        .def("set_vehicle_speed", &TiledEngineHost::setVehicleSpeed, "vehicle_id"_a, "speed"_a)
+        .def("set_random_seed", &TiledEngineHost::setRandomSeed, "seed"_a)
         .def("get_lane_vehicle_count", &TiledEngineHost::getLaneVehicleCount)
         .def("get_lane_waiting_vehicle_count", &TiledEngineHost::getLaneWaitingVehicleCount)
         .def("get_lane_vehicle_count_array", [](TiledEngineHost &e) { return toArray(e.laneVehicleCountArray()); })

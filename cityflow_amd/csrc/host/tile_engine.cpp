@@ -484,6 +484,21 @@ void TileEngine::appendVehicles(VehicleSnapshot &out) {
     }
 }
 
+void TileEngine::appendWaiting(std::vector<int32_t> &vids) {
+    cfx_scalars sc = scalars();
+    int cap = (int) sc.spawned_vehicle_count + 16;
+    std::vector<int32_t> v(cap), l(cap);
+    int32_t n = 0;
+    check(be_->cfx_get_waiting(dev_, cap, v.data(), l.data(), &n), "cfx_get_waiting");
+    for (int i = 0; i < n; ++i)
+        if (!tn_.laneGhost[l[i]]) vids.push_back(v[i]);  // ghost lanes only mirror their owner's queue
+}
+
+void TileEngine::setVehicleSpeed(int vid, double speed) {
+    // Harmless where the vehicle is not running: a pending custom speed is only consulted at admission, a proxy is frozen.
+    check(be_->cfx_set_vehicle_speed(dev_, vid, speed), "cfx_set_vehicle_speed");
+}
+
 // ---------------------------------------------------------------- the tiles of this process
 TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int cols, const std::vector<int> &localTiles,
                                  const std::string &backendLib) {
@@ -697,6 +712,153 @@ void TiledEngineHost::snapshotVehicles(VehicleSnapshot &out) {
         out.speed.push_back(all.speed[i]);
         out.gap.push_back(all.gap[i]);
     }
+}
+
+}  // namespace cfa
+
+namespace cfa {
+
+int TiledEngineHost::statusOf(int vid) {
+    uint8_t st = 0;
+    for (auto &t : tiles_) t->mergeStatus(vid, 1, &st);
+    int s = st;
+    if (reduceStatus_) s = reduceStatus_(s);
+    return s;
+}
+
+// getVehicles engine.cpp:619-626 — vehiclePool (priority) order
+std::vector<std::string> TiledEngineHost::getVehicles(bool includeWaiting) {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::vector<std::pair<int32_t, int32_t>> byPriority;
+    for (int i = 0; i < s.count; ++i) byPriority.emplace_back(spawner_.vehicles[s.vid[i]].priority, s.vid[i]);
+    if (includeWaiting) {
+        std::vector<int32_t> wv;
+        for (auto &t : tiles_) t->appendWaiting(wv);
+        for (int32_t v : wv) byPriority.emplace_back(spawner_.vehicles[v].priority, v);
+    }
+    std::sort(byPriority.begin(), byPriority.end());
+    std::vector<std::string> ret;
+    for (auto &p : byPriority) ret.emplace_back(spawner_.vehicleId(p.second));
+    return ret;
+}
+
+std::map<std::string, std::vector<std::string>> TiledEngineHost::getLaneVehicles() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    const int L = (int) net_->lanes.size();
+    std::vector<std::vector<std::string>> perLane(L);
+    for (int i = 0; i < s.count; ++i)
+        if (s.drivable[i] < L) perLane[s.drivable[i]].push_back(spawner_.vehicleId(s.vid[i]));
+    std::map<std::string, std::vector<std::string>> ret;
+    for (int l = 0; l < L; ++l) ret.emplace(net_->laneId(l), std::move(perLane[l]));
+    return ret;
+}
+
+std::map<std::string, double> TiledEngineHost::getVehicleSpeed() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::map<std::string, double> ret;
+    for (int i = 0; i < s.count; ++i) ret.emplace(spawner_.vehicleId(s.vid[i]), s.speed[i]);
+    return ret;
+}
+
+std::map<std::string, double> TiledEngineHost::getVehicleDistance() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::map<std::string, double> ret;
+    for (int i = 0; i < s.count; ++i) ret.emplace(spawner_.vehicleId(s.vid[i]), s.dis[i]);
+    return ret;
+}
+
+std::string TiledEngineHost::getLeader(const std::string &vehicleId) {
+    int vid = spawner_.vidOfId(vehicleId);
+    int st = vid >= 0 ? statusOf(vid) : 2;
+    if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
+    if (st == 0) return "";
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    for (int i = 0; i < s.count; ++i)
+        if (s.vid[i] == vid) return s.leader[i] >= 0 ? spawner_.vehicleId(s.leader[i]) : "";
+    return "";
+}
+
+std::map<std::string, std::string> TiledEngineHost::getVehicleInfo(const std::string &vehicleId) {
+    int vid = spawner_.vidOfId(vehicleId);
+    int st = vid >= 0 ? statusOf(vid) : 2;
+    if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
+    std::map<std::string, std::string> info;
+    info["running"] = std::to_string(st == 1);
+    if (st != 1) return info;
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    for (int i = 0; i < s.count; ++i) {
+        if (s.vid[i] != vid) continue;
+        info["distance"] = std::to_string(s.dis[i]);
+        info["speed"] = std::to_string(s.speed[i]);
+        info["drivable"] = net_->drivableId(s.drivable[i]);
+        if (s.drivable[i] < (int) net_->lanes.size()) {
+            const HostRoad &road = net_->roads[net_->lanes[s.drivable[i]].road];
+            info["road"] = road.id;
+            info["intersection"] = net_->inters[road.endInter].id;
+        }
+        const RouteTable &rt = spawner_.routes;
+        int r = spawner_.vehicles[vid].route;
+        std::string route;
+        for (int p = rt.routeStart[r] + s.routePos[i]; p < rt.routeStart[r + 1]; ++p) route += net_->roads[rt.roads[p]].id + " ";
+        info["route"] = route;
+    }
+    return info;
+}
+
+// getAverageTravelTime engine.cpp:682-691 (finished part summed per tile)
+double TiledEngineHost::getAverageTravelTime() {
+    cfx_scalars sc = scalars();
+    double tt = sc.cumulative_travel_time;
+    int64_t n = sc.finished_vehicle_count;
+    const int total = (int) spawner_.vehicles.size();
+    std::vector<uint8_t> st((size_t) std::max(total, 1), 0);
+    if (total)
+        for (auto &t : tiles_) t->mergeStatus(0, total, st.data());
+    std::vector<std::pair<int32_t, double>> live;
+    for (int v = 0; v < total; ++v)
+        if (st[v] != 2) live.emplace_back(spawner_.vehicles[v].priority, spawner_.vehicles[v].enterTime);
+    std::sort(live.begin(), live.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) {
+        return a.first < b.first;
+    });
+    const double now = getCurrentTime();
+    for (auto &p : live) {
+        tt += now - p.second;
+        n++;
+    }
+    return n == 0 ? 0 : tt / n;
+}
+
+void TiledEngineHost::pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads) {
+    auto get = [&info](const char *k, double d) {
+        auto it = info.find(k);
+        return it == info.end() ? d : it->second;
+    };
+    cfx_vehicle_template t = spawner_.makeTemplate(get("length", 5), get("width", 2), get("maxPosAcc", 4.5), get("maxNegAcc", 4.5),
+                                                   get("usualPosAcc", 2.5), get("usualNegAcc", 2.5), get("minGap", 2),
+                                                   get("maxSpeed", 16.66667), get("headwayTime", 1));
+    if (info.count("speed") && info.at("speed") != 0)
+        throw std::runtime_error("cityflow_amd: push_vehicle with a non-zero initial speed is not supported yet");
+    std::vector<int> anchors;
+    for (auto &r : roads) {
+        auto it = net_->roadIndex.find(r);
+        if (it == net_->roadIndex.end()) throw std::runtime_error("Road '" + r + "' not found");
+        anchors.push_back(it->second);
+    }
+    if (anchors.empty()) throw std::runtime_error("push_vehicle: empty route");
+    spawner_.pushManual(spawner_.addTemplate(t), anchors, step_);
+}
+
+void TiledEngineHost::setVehicleSpeed(const std::string &id, double speed) {
+    int vid = spawner_.vidOfId(id);
+    int st = vid >= 0 ? statusOf(vid) : 2;
+    if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + id + "' not found");
+    for (auto &t : tiles_) t->setVehicleSpeed(vid, speed);
 }
 
 }  // namespace cfa

@@ -81,6 +81,8 @@ public:
     void mergeStatus(int first, int n, uint8_t *inout);              // inout[i] = max(inout[i], local state)
     void setPhases(const std::vector<int32_t> &globalInter, const std::vector<int32_t> &phase);  // owned ones are applied
     void appendVehicles(VehicleSnapshot &out);  // owned running vehicles, global drivable ids (unsorted across tiles)
+    void appendWaiting(std::vector<int32_t> &vids);  // vehicles queued on the lanes this tile owns
+    void setVehicleSpeed(int vid, double speed);
 
     const TileNet &tile() const { return tn_; }
     std::vector<char> send, recv;
@@ -138,6 +140,18 @@ public:
     void setTrafficLightPhase(const std::string &id, int phaseIndex);
     void setTrafficLightPhases(const std::vector<int32_t> &phases);  // [n_intersections]
     void reset(bool resetRnd);
+    // the rest of the reference's query / control API, over the vehicles of the local tiles (all of them when every
+    // tile is local): same semantics as EngineHost (engine.cpp:615-720,827-850)
+    std::vector<std::string> getVehicles(bool includeWaiting);
+    std::map<std::string, std::vector<std::string>> getLaneVehicles();
+    std::map<std::string, double> getVehicleSpeed();
+    std::map<std::string, double> getVehicleDistance();
+    std::string getLeader(const std::string &vehicleId);
+    std::map<std::string, std::string> getVehicleInfo(const std::string &vehicleId);
+    double getAverageTravelTime();
+    void pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads);
+    void setVehicleSpeed(const std::string &id, double speed);
+    void setRandomSeed(int seed) { spawner_.seed(seed); }
     void snapshotVehicles(VehicleSnapshot &out);  // local tiles, sorted by global drivable
     void sync();
     std::vector<int> owner() const { return owner_; }
@@ -161,6 +175,7 @@ private:
     std::vector<int32_t> pendingInter_, pendingPhase_;
     std::function<int(int)> reduceStatus_;
     void flushPhases();
+    int statusOf(int vid);  // merged over the local tiles (and the reducer)
 };
 
 }  // namespace cfa

@@ -28,6 +28,14 @@ GRID_VEHICLE = {
 }
 
 
+def _write_json_atomic(path, obj):
+    """Write-then-rename, so a reader (or a later run) never sees a half-written file."""
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(obj, f)
+    os.replace(tmp, path)
+
+
 def _gunzip(src, dst):
     with gzip.open(src, "rb") as f, open(dst, "wb") as out:
         shutil.copyfileobj(f, out)
@@ -102,8 +110,7 @@ def dense_flows(roadnet_path, out_path, n_extra, seed=12345, interval=2.0, min_l
         flows.append({"vehicle": dict(GRID_VEHICLE), "route": route, "interval": interval,
                       "startTime": 0, "endTime": end_time})
         made += 1
-    with open(out_path, "w") as f:
-        json.dump(flows, f)
+    _write_json_atomic(out_path, flows)
     return out_path
 
 
@@ -252,15 +259,12 @@ def generate_grid(rows, cols, workdir=None, flow_interval=1.0, **config):
     os.makedirs(d, exist_ok=True)
     roadnet = os.path.join(d, "roadnet.json")
     if not os.path.exists(roadnet):
-        with open(roadnet, "w") as f:
-            json.dump(grid_roadnet(rows, cols), f)
-    with open(os.path.join(d, "flow.json"), "w") as f:
-        json.dump(grid_flows(rows, cols, flow_interval), f)
+        _write_json_atomic(roadnet, grid_roadnet(rows, cols))
+    _write_json_atomic(os.path.join(d, "flow.json"), grid_flows(rows, cols, flow_interval))
     cfg = {"interval": 1.0, "seed": 0, "dir": d + "/", "roadnetFile": "roadnet.json", "flowFile": "flow.json",
            "rlTrafficLight": False, "laneChange": False, "saveReplay": False}
     cfg.update(config)
     tag = "_".join("%s-%s" % (k, config[k]) for k in sorted(config)) if config else "default"
     path = os.path.join(d, "config_flow_%s.json" % tag)
-    with open(path, "w") as f:
-        json.dump(cfg, f)
+    _write_json_atomic(path, cfg)
     return path

@@ -178,3 +178,47 @@ def test_two_ranks_one_gpu(scen, workdir, tmp_path, mailboxes):
                     {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": mailboxes})
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "TILED_OK 150" in out.stdout
+
+
+def _api_compare(mod, cfg, lib, rows, cols):
+    """Every query / control call of the reference API on the tiled engine vs the single engine."""
+    ref = mod.Engine._with_backend(cfg, 1, lib)
+    til = mod.TiledEngine(cfg, rows, cols, [], lib)
+    info = {"length": 4.0, "maxSpeed": 12.0, "minGap": 2.0}
+    route = ["road_0_1_0", "road_1_1_0", "road_2_1_0", "road_3_1_0"]  # crosses the vertical cut of a 2x2 tiling of 6x6
+    slowed = None
+    for s in range(260):
+        if s in (5, 40):
+            ref.push_vehicle(info, route)
+            til.push_vehicle(info, route)
+        if s == 120:  # slow one running vehicle down on both
+            slowed = sorted(ref.get_vehicle_speed())[7]
+            ref.set_vehicle_speed(slowed, 1.5)
+            til.set_vehicle_speed(slowed, 1.5)
+        ref.next_step()
+        til.next_step()
+        if s % 20 == 19 or s in (120, 121):
+            assert ref.get_vehicle_speed() == til.get_vehicle_speed(), "step %d" % s
+            assert ref.get_vehicle_distance() == til.get_vehicle_distance(), "step %d" % s
+            assert ref.get_lane_vehicles() == til.get_lane_vehicles(), "step %d" % s
+            assert ref.get_vehicles(True) == til.get_vehicles(True), "step %d" % s
+            assert ref.get_vehicles() == til.get_vehicles()
+            assert ref.get_average_travel_time() == til.get_average_travel_time()
+            assert ref.get_vehicle_count() == til.get_vehicle_count()
+    running = ref.get_vehicles()
+    assert "manually_pushed_0" in ref.get_vehicles(True) or ref.get_vehicle_info("manually_pushed_0")["running"] == "0"
+    for vid in running[:40] + ["manually_pushed_1"]:
+        assert ref.get_vehicle_info(vid) == til.get_vehicle_info(vid), vid
+        assert ref.get_leader(vid) == til.get_leader(vid), vid
+    with pytest.raises(RuntimeError):
+        til.get_leader("flow_999_0")
+    assert slowed is not None
+
+
+def test_tiled_full_api_twin(mod, scen, workdir):
+    _api_compare(mod, scen.materialize("grid_6x6", workdir), TWIN_LIB, 2, 2)
+
+
+@pytest.mark.gpu
+def test_tiled_full_api_hip(mod, scen, workdir):
+    _api_compare(mod, scen.materialize("grid_6x6", workdir), mod._default_backend_path(), 2, 2)
