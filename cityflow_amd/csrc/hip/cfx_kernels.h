@@ -808,63 +808,70 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
     }
     const int S = c.segStart[c.n.L + c.n.K];
     for (int s = gid; s < S; s += stride) {
+        // Round 1: everything indexed by the slot itself, issued before the first branch (the kernel is bound by
+        // dependent-load rounds; spare slots hold garbage in most of these arrays, which is never used).
         const int vid = c.s.vid[s];
-        if (vid < 0) {
-            oldToNew[s] = -1;
-            continue;
-        }
         const int nd = b.drv[s];
-        if (nd == -2) {  // finished: removed
+        const int d = c.s.drv[s];
+        const int templ = c.s.templ[s];
+        const double ndis = b.dis[s];
+        const double nspeed = b.speed[s];
+        const int nblocker = b.blocker[s];
+        const int route = c.s.route[s];
+        const int prevDrv = c.s.prevDrv[s];
+        const int next = c.s.next[s];
+        const int enterLLT = c.s.enterLLT[s];
+        int rp = c.s.routePos[s];
+        if (vid < 0 || nd == -2) {  // spare slot, or finished: removed
             oldToNew[s] = -1;
             continue;
         }
-        const int d = c.s.drv[s];
+        // Round 2: per-drivable values of the segment the vehicle ends up in (its own when it stays)
+        const int t = nd >= 0 ? nd : d;
+        const int tStartNext = segStartNext[t];
+        const int tLeave = cs.leaveCnt[t];
         int ns;
         if (nd == -1) {
             // stays: rank among the stayers of its segment = k - (#leavers in front of it)
             const int k = s - c.segStart[d];
-            const int lc = cs.leaveCnt[d];
             int before;
-            if (lc == 0) {
+            if (tLeave == 0) {
                 before = 0;
-            } else if (cs.maxLeaveIdx[d] + 1 == lc) {
-                before = k < lc ? k : lc;  // leavers form a prefix (the normal case)
+            } else if (cs.maxLeaveIdx[d] + 1 == tLeave) {
+                before = k < tLeave ? k : tLeave;  // leavers form a prefix (the normal case)
             } else {
                 before = 0;
                 for (int j = c.segStart[d]; j < s; ++j) before += (b.drv[j] != -1);
             }
-            ns = segStartNext[d] + (k - before);
+            ns = tStartNext + (k - before);
         } else {
             // enters drivable nd: after its stayers, ordered by new distance descending
             // (std::sort with vehicleCmp engine.h:21-23; ties: lower vid first, as in the twin)
-            const double myDis = b.dis[s];
             int rank = 0;
             for (int j = cs.inHead[nd]; j >= 0; j = cs.inNext[j]) {
                 if (j == s) continue;
                 double od = b.dis[j];
-                rank += (od > myDis) || (od == myDis && c.s.vid[j] < vid);
+                rank += (od > ndis) || (od == ndis && c.s.vid[j] < vid);
             }
-            ns = segStartNext[nd] + (c.cnt[nd] - cs.leaveCnt[nd]) + rank;
+            ns = tStartNext + (c.cnt[nd] - tLeave) + rank;
         }
         oldToNew[s] = ns;
         nx.vid[ns] = vid;
-        nx.templ[ns] = c.s.templ[s];
-        nx.dis[ns] = b.dis[s];
-        nx.speed[ns] = b.speed[s];
-        nx.blocker[ns] = b.blocker[s];  // old-generation slot; resolved through oldToNew when read
-        nx.flags[ns] = 0;               // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
-        const int route = c.s.route[s];
+        nx.templ[ns] = templ;
+        nx.dis[ns] = ndis;
+        nx.speed[ns] = nspeed;
+        nx.blocker[ns] = nblocker;  // old-generation slot; resolved through oldToNew when read
+        nx.flags[ns] = 0;           // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
         nx.route[ns] = route;
         if (nd == -1) {
             nx.drv[ns] = d;
-            nx.prevDrv[ns] = c.s.prevDrv[s];
-            nx.next[ns] = c.s.next[s];
-            nx.enterLLT[ns] = c.s.enterLLT[s];
-            nx.routePos[ns] = c.s.routePos[s];
+            nx.prevDrv[ns] = prevDrv;
+            nx.next[ns] = next;
+            nx.enterLLT[ns] = enterLLT;
+            nx.routePos[ns] = rp;
         } else {
             nx.drv[ns] = nd;
             nx.prevDrv[ns] = d;
-            int rp = c.s.routePos[s];
             if (nd < c.n.L) {
                 nx.enterLLT[ns] = CFX_INT_MAX;
                 const int base = c.t.routeStart[route], n = c.t.routeStart[route + 1] - base;

@@ -9,7 +9,8 @@ libs = sys.argv[1:]
 sys.argv = [sys.argv[0]]
 import bench
 from cityflow_amd import _cityflow
-cfg = bench.build_workload("/tmp/cfa_exp", 0)
+cfg = bench.build_workload("/tmp/cfa_exp", 0, scenario=os.environ.get("CFX_EXP_SCENARIO", "grid_30x30"),
+                           n_extra=int(os.environ.get("CFX_EXP_EXTRA", bench.N_EXTRA_FLOWS)))
 base = _cityflow.Engine(cfg, 1)
 for _ in range(300):
     base.next_step()
