@@ -469,6 +469,10 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         if ((rc = e->uploadConst(d.drvLM, lm.data(), lm.size()))) return rc;
         if ((rc = e->uploadConst(d.xDD, xdd.data(), xdd.size()))) return rc;
         if ((rc = e->uploadConst(d.xPack, xpack.data(), xpack.size()))) return rc;
+        std::vector<int4> llpack((size_t) e->K);
+        for (int k = 0; k < e->K; ++k)
+            llpack[k] = make_int4(n->ll_x_start[k], n->ll_x_start[k + 1], maskStart[n->ll_inter[k]], n->ll_type[k]);
+        if ((rc = e->uploadConst(d.llPack, llpack.data(), llpack.size()))) return rc;
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;

@@ -569,12 +569,12 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(StepCtx c, ActionOut o, J
         const int nd0 = c.s.next[s];
         const bool onLane = d < c.n.L;
         const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
-        const int t1 = c.n.llType[laneLink];
+        const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}: one load
+        const int t1 = lp.w;
         const double d0 = onLane ? -(dlen - dis) : dis;
-        const int in = c.n.llInter[laneLink];
-        const int mb = c.n.interMaskStart[in];
+        const int mb = lp.z;
         VehRef self{speed, &t};
-        const int xs = c.n.llXStart[laneLink], xe = c.n.llXStart[laneLink + 1];
+        const int xs = lp.x, xe = lp.y;
         double iv = o.b.dis[s];  // partial intersection speed parked by k_action
         int blockerSlot = -1;
         for (int e0 = xs; e0 < xe; e0 += kCrossGroup) {
