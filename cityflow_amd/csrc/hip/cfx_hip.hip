@@ -617,15 +617,16 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     hipLaunchKernelGGL(k_cross, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                        dim3(kCrossBlock), 0, st, c, ao, jq);
     e->profEnd(pp__); }
+    int32_t *const scanTicket = e->nScanBlocks > kScanResidentTiles ? e->scanTicket : nullptr;
     { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
-                       e->scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
+                       scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
                        e->gen[nxt].drv, e->sc, e->net.laneSpare);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),
                        dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
-                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords, e->scanTicket, e->vt, e->sc, e->finList,
+                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords, scanTicket, e->vt, e->sc, e->finList,
                        e->finSorted, (int) e->slotCap, e->jobCount);
     e->profEnd(pp__); }
     HIP_TRY(hipGetLastError());

@@ -616,7 +616,9 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(StepCtx c, ActionOut o, J
 }
 
 // Phase 5b in ONE launch: single-pass exclusive scan of the new segment sizes over drivables.
-// Tiles are handed out by a ticket (so every predecessor of a tile has started: no dispatch-order assumption);
+// A tile waits for its predecessors' totals, so every predecessor must be running or done: with at most
+// kScanResidentTiles tiles the whole grid is co-resident (256 CUs x >= 2 such blocks) and tile = block index;
+// larger grids hand tiles out by a ticket (every predecessor of a tile has then started: no dispatch-order assumption);
 // each tile publishes its total as an 8-byte {epoch, value} granule written by one agent-scope store and
 // sums its predecessors' granules, polling with agent-scope loads until their tag equals this step's epoch
 // (MI355X guide, Guideline 16 form R2: the data is the flag).
@@ -624,6 +626,7 @@ constexpr int kScanItems = 8;                       // drivables per thread
 constexpr int kScanTile = kBlock * kScanItems;      // drivables per tile
 constexpr int kFinLds = 2048;                       // finished vehicles per step staged in LDS
 constexpr unsigned kSpinLimit = 1u << 26;
+constexpr int kScanResidentTiles = 512;             // tiles (256-thread blocks, 28 VGPRs) that are certainly co-resident
 
 __device__ __forceinline__ int newLiveCount(const int32_t *cnt, const CompactScratch &cs, int d) {
     return cnt[d] - cs.leaveCnt[d] + cs.inCnt[d];
@@ -700,10 +703,13 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
     __shared__ int tileShared;
-    if (threadIdx.x == 0) tileShared = atomicAdd(ticket, 1);
-    __syncthreads();
-    const int tile = tileShared;
-    __syncthreads();
+    int tile = (int) blockIdx.x;
+    if (ticket) {  // grids too large to be co-resident: hand tiles out in start order
+        if (threadIdx.x == 0) tileShared = atomicAdd(ticket, 1);
+        __syncthreads();
+        tile = tileShared;
+        __syncthreads();
+    }
 
     const int base = tile * kScanTile + threadIdx.x * kScanItems;
     int vals[kScanItems];
@@ -789,7 +795,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = (gridDim.x - 1) * blockDim.x;
-    if (gid == 0) *scanTicket = 0;  // k_scan of this step is done; re-arm it for the next one
+    if (gid == 0 && scanTicket) *scanTicket = 0;  // k_scan of this step is done; re-arm it for the next one
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
     if (!rlTrafficLight) {
         for (int i = gid; i < c.n.I; i += stride) {
