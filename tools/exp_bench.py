@@ -29,5 +29,18 @@ for lib in [_cityflow._default_backend_path()] + libs:
         eng._profile_enable(False)
         for k, (ms, n) in prof.items():
             res.setdefault(k, []).append(ms / max(n, 1) * 1e3)
-    print(os.path.basename(lib), {k: round(min(v), 1) for k, v in res.items()}, "running", eng.get_vehicle_count(), flush=True)
+    import time
+    wall = []
+    for rep in range(3):  # un-instrumented wall clock per step from the same state
+        eng.load(arch)
+        for _ in range(5):
+            eng.next_step()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            eng.next_step()
+        eng.sync()
+        wall.append((time.perf_counter() - t0) / 200 * 1e6)
+    print(os.path.basename(lib), {k: round(min(v), 1) for k, v in res.items()}, "running", eng.get_vehicle_count(),
+          "wall us/step", [round(w, 1) for w in wall], flush=True)
     del eng
