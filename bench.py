@@ -185,7 +185,10 @@ def main():
     from cityflow_amd import _cityflow
 
     tiled = world > 1 and not args.replicas
+    eng = None
+    halo_notes = []
     if tiled:
+        import torch
         from cityflow_amd.tiled import DistributedEngine
         rows, cols = tile_grid(world)
         workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_tiled")
@@ -193,9 +196,34 @@ def main():
             cfg = build_tiled_workload(workdir, rows, cols, args.tile_block, args.extra_flows)
         barrier()
         cfg = os.path.join(workdir, "gen_%dx%d" % (args.tile_block * rows, args.tile_block * cols), "config_bench.json")
-        eng = DistributedEngine(cfg, rows, cols, backend_library=args.backend_lib)
-        eng._scalars = eng.local_scalars  # this rank's tile; summed over ranks below
-    else:
+        # Probe the halo transports on this machine before committing to one: GPU-written mailboxes first, the staged
+        # gloo exchange second; a transport counts only if EVERY rank ran a few steps on it without an error.
+        for mailboxes in (True, False):
+            cand, ok = None, 1
+            try:
+                cand = DistributedEngine(cfg, rows, cols, backend_library=args.backend_lib, mailboxes=mailboxes)
+                for _ in range(20):
+                    cand.next_step()
+                cand.sync()
+                cand.local_scalars()  # raises if a device-side halo wait timed out
+            except Exception as exc:  # noqa: BLE001 - any failure disqualifies the transport
+                ok = 0
+                halo_notes.append("%s: %s" % ("mailboxes" if mailboxes else "gloo", str(exc)[:200]))
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                cand.reset(True)  # back to step 0 with the configured seed: the probe leaves no trace
+                eng = cand
+                break
+            del cand
+        if eng is None:
+            tiled = False  # neither transport works here: measure independent replicas instead (and say so)
+            if rank == 0:
+                print("[bench] tiled halo exchange unavailable (%s); falling back to replicas" % "; ".join(halo_notes),
+                      file=sys.stderr)
+        else:
+            eng._scalars = eng.local_scalars  # this rank's tile; summed over ranks below
+    if not tiled:
         workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_rank%d" % rank)
         cfg = build_workload(workdir, seed=rank, scenario=args.scenario, n_extra=args.extra_flows)
         if on_gpu:
@@ -287,6 +315,7 @@ def main():
                 "running_vehicles_start": run0, "running_vehicles_end": run1,
                 "lanes": len(eng.lane_ids()),
                 "halo": ("gpu-written shared-memory mailboxes" if eng.mailboxes else "staged over gloo") if tiled else None,
+                "halo_probe_failures": halo_notes or None,
                 "parallelism": ("tiles %dx%d + halo" % (rows, cols)) if tiled else (
                     "replica x%d" % world if world > 1 else "1 gpu"),
             },
