@@ -130,6 +130,36 @@ class DistributedEngine:
     def local_vehicle_state(self):
         return self._eng._vehicle_state()
 
+    # ---- string-keyed getters: every rank contributes the vehicles of its tile (an all-gather of small dicts; meant
+    #      for inspection, the array getters above are the RL path)
+    def _merged(self, local):
+        parts = [None] * self.world
+        dist.all_gather_object(parts, local, group=self._halo)
+        out = {}
+        for p in parts:
+            out.update(p)
+        return out
+
+    def get_vehicle_speed(self):
+        return self._merged(self._eng.get_vehicle_speed())
+
+    def get_vehicle_distance(self):
+        return self._merged(self._eng.get_vehicle_distance())
+
+    def get_lane_vehicles(self):
+        parts = [None] * self.world
+        dist.all_gather_object(parts, {k: v for k, v in self._eng.get_lane_vehicles().items() if v}, group=self._halo)
+        out = {k: [] for k in self._eng.lane_ids()}
+        for p in parts:
+            out.update(p)  # a lane belongs to exactly one tile
+        return out
+
+    def push_vehicle(self, info, roads):
+        self._eng.push_vehicle(info, roads)  # every rank makes the same call (the spawners stay identical)
+
+    def set_vehicle_speed(self, vehicle_id, speed):
+        self._eng.set_vehicle_speed(vehicle_id, speed)
+
     # a priority collision in the spawner asks "has vehicle X finished?"; every rank asks at the same point of the
     # same RNG stream, so a collective is legal here and keeps the streams identical
     def _reduce_status(self, status):

@@ -39,6 +39,10 @@ def main():
             for k in ("drivable", "dis", "speed", "leader", "blocker", "route_pos", "enter_ll_time"):
                 assert np.array_equal(va[k][idx], vb[k]), "rank %d step %d: %s differs" % (rank, s, k)
             crossed = max(crossed, len(vb["vid"]))
+        if s == steps - 1:  # string getters: merged over ranks == single engine
+            assert eng.get_vehicle_speed() == single.get_vehicle_speed()
+            assert eng.get_vehicle_distance() == single.get_vehicle_distance()
+            assert eng.get_lane_vehicles() == single.get_lane_vehicles()
     assert crossed > 0
     dist.barrier()
     if rank == 0:
