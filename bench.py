@@ -265,18 +265,22 @@ def main():
     else:
         run0, run1 = sc0["active_vehicle_count"], sc1["active_vehicle_count"]
 
-    # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream)
+    # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream).  Tiled runs: every
+    #      rank keeps stepping (the tiles are coupled), rank 0 instruments its own tile, halo kernels included.
     roofline = None
-    if rank == 0 and on_gpu and not tiled:
+    if on_gpu and args.profile_steps > 0 and (rank == 0 or tiled):
         scp0 = eng._scalars()
-        eng._profile_enable(True)
+        if rank == 0:
+            (eng._eng._profile_enable(0, True) if tiled else eng._profile_enable(True))
         for _ in range(args.profile_steps):
             eng.next_step()
-        prof = eng._profile_read()
-        eng._profile_enable(False)
+        if rank == 0:
+            prof = eng._eng._profile_read(0) if tiled else eng._profile_read()
+            (eng._eng._profile_enable(0, False) if tiled else eng._profile_enable(False))
+        eng.sync()
         scp1 = eng._scalars()
-        act_ms, act_n = prof["k_action"]
-        if act_n:
+        act_ms, act_n = prof["k_action"] if rank == 0 else (0.0, 0)
+        if rank == 0 and act_n:
             vehicles_per_launch = (scp1["vehicle_steps"] - scp0["vehicle_steps"]) / float(act_n)
             avg_s = act_ms / act_n / 1e3
             achieved = ACTION_BYTES_PER_VEHICLE * vehicles_per_launch / avg_s / 1e9
@@ -284,11 +288,13 @@ def main():
             traffic, traffic_src = pmc_traffic("cfxd::k_action")
             roofline = {
                 "bound": "hbm", "kernel": "k_action", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None if tiled else traffic,
+                "traffic_source": None if tiled else traffic_src,
                 "avg_launch_us": avg_s * 1e6, "vehicles_per_launch": vehicles_per_launch,
                 "algorithmic_bytes_per_vehicle": ACTION_BYTES_PER_VEHICLE,
-                "measured_over": "%d instrumented steps following the timed region" % args.profile_steps,
-                "kernel_us_per_step": {k: ms / max(n, 1) * 1e3 for k, (ms, n) in prof.items()},
+                "measured_over": "%d instrumented steps following the timed region%s" % (
+                    args.profile_steps, " (rank 0's tile)" if tiled else ""),
+                "kernel_us_per_step": {k: ms / max(n, 1) * 1e3 for k, (ms, n) in prof.items() if n},
                 "sum_kernel_ms_per_step": step_ms,
             }
 

@@ -17,8 +17,9 @@ namespace {
 
 std::string g_createError;
 
-enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, kNumProfKernels };
-const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_action", "k_cross", "k_scan", "k_scatter"};
+enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, PK_HALO_EXPORT, PK_HALO_IMPORT, kNumProfKernels };
+const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_action", "k_cross", "k_scan", "k_scatter",
+                                                 "k_halo_export", "k_halo_import"};
 
 #define HIP_TRY(call)                                                                                  \
     do {                                                                                               \
@@ -1236,8 +1237,12 @@ int32_t cfx_halo_post(cfx_engine *e) {
     io.ticket = e->haloTicket;
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;  // every peer implies at least one cut lane, so n > 0 with peers
-    if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
-                              e->cs.inCnt, io, e->sc);
+    if (n) {
+        int pp__ = e->profBegin(PK_HALO_EXPORT);
+        hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
+                           e->cs.inCnt, io, e->sc);
+        e->profEnd(pp__);
+    }
     HIP_TRY(hipGetLastError());
     return CFX_OK;
 }
@@ -1257,8 +1262,12 @@ int32_t cfx_halo_wait(cfx_engine *e) {
     io.nWait = nPeers;
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;
-    if (n) hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
-                              io, e->vt, e->sc);
+    if (n) {  // includes the wait for the neighbours' epochs
+        int pp__ = e->profBegin(PK_HALO_IMPORT);
+        hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
+                           io, e->vt, e->sc);
+        e->profEnd(pp__);
+    }
     HIP_TRY(hipGetLastError());
     e->liveUpper += (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS;
     return CFX_OK;

@@ -413,6 +413,17 @@ void TileEngine::haloExport() { check(be_->cfx_halo_export(dev_, send.data()), "
 void TileEngine::haloImport() { check(be_->cfx_halo_import(dev_, recv.data()), "cfx_halo_import"); }
 void TileEngine::reset() { check(be_->cfx_reset(dev_), "cfx_reset"); }
 void TileEngine::sync() { check(be_->cfx_sync(dev_), "cfx_sync"); }
+void TileEngine::profileEnable(bool on) { check(be_->cfx_profile_enable(dev_, on ? 1 : 0), "cfx_profile_enable"); }
+
+std::map<std::string, std::pair<double, int64_t>> TileEngine::profileRead() {
+    int n = be_->cfx_profile_kernel_count();
+    std::vector<double> ms(n > 0 ? n : 1);
+    std::vector<int64_t> cnt(n > 0 ? n : 1);
+    check(be_->cfx_profile_read(dev_, ms.data(), cnt.data()), "cfx_profile_read");
+    std::map<std::string, std::pair<double, int64_t>> out;
+    for (int k = 0; k < n; ++k) out[be_->cfx_profile_kernel_name(k)] = std::make_pair(ms[k], cnt[k]);
+    return out;
+}
 
 void TileEngine::addLaneCounts(std::vector<int32_t> &global, bool waiting) {
     std::vector<int32_t> local(tn_.laneL2G.size());

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <functional>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -75,6 +76,8 @@ public:
     bool hasMailboxes() const { return mailboxes_; }
     void reset();
     void sync();
+    void profileEnable(bool on);
+    std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
 
     void addLaneCounts(std::vector<int32_t> &global, bool waiting);  // writes the lanes this tile owns
     cfx_scalars scalars();
@@ -154,6 +157,8 @@ public:
     void setRandomSeed(int seed) { spawner_.seed(seed); }
     void snapshotVehicles(VehicleSnapshot &out);  // local tiles, sorted by global drivable
     void sync();
+    void profileEnable(int localTile, bool on) { tiles_.at(localTile)->profileEnable(on); }
+    std::map<std::string, std::pair<double, int64_t>> profileRead(int localTile) { return tiles_.at(localTile)->profileRead(); }
     std::vector<int> owner() const { return owner_; }
     std::vector<std::string> laneIds() const;
     const HostRoadNet &net() const { return *net_; }
