@@ -243,12 +243,14 @@ def main():
 
     barrier()
     eng.sync()
+    host0 = eng._eng._host_seconds() if tiled else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.next_step()
     eng.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    host1 = eng._eng._host_seconds() if tiled else None  # rank 0's host time inside the timed region
     sc1 = eng._scalars()
     veh_steps = sc1["vehicle_steps"] - sc0["vehicle_steps"]
 
@@ -322,6 +324,8 @@ def main():
                 "lanes": len(eng.lane_ids()),
                 "halo": ("gpu-written shared-memory mailboxes" if eng.mailboxes else "staged over gloo") if tiled else None,
                 "halo_probe_failures": halo_notes or None,
+                "host_us_per_step": ({"spawner": round((host1[0] - host0[0]) / args.steps * 1e6, 1),
+                                      "submit": round((host1[1] - host0[1]) / args.steps * 1e6, 1)} if tiled else None),
                 "parallelism": ("tiles %dx%d + halo" % (rows, cols)) if tiled else (
                     "replica x%d" % world if world > 1 else "1 gpu"),
             },

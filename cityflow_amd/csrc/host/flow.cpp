@@ -177,6 +177,15 @@ void Spawner::loadFlows(const std::string &path) {
     }
     flowVids.assign(flows.size(), {});
     rebuildActiveFlows();
+    // Size the priority table for the first simulated hour of this demand, so that it is not rebuilt (a stall of tens of
+    // milliseconds at city scale) in the middle of a run; it still grows on demand after that.
+    double expected = 0;
+    for (const HostFlow &f : flows) {
+        if (!f.valid || !(f.interval > 0)) continue;
+        double until = f.endTime >= 0 ? std::min(3600.0, (double) f.endTime) : 3600.0;
+        if (until > f.startTime) expected += (until - f.startTime) / f.interval + 1;
+    }
+    livePriority_.reserve((size_t) std::min(expected, 16.0e6));
 }
 
 void Spawner::rebuildActiveFlows() {
@@ -230,6 +239,24 @@ void Spawner::pushManual(int templ, const std::vector<int> &anchors, size_t step
 
 void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
     out.clear();
+    // The priority table is far larger than the caches at city scale and every spawn probes it at a random place.
+    // Which flows spawn this step is pure timer arithmetic, and (collisions aside) each vehicle consumes exactly two
+    // draws, so a COPY of the generator tells where the probes will land: prefetch them all, then run the real loop.
+    {
+        size_t n = 0;
+        for (int32_t fi : activeFlows_) {
+            const HostFlow &f = flows[(size_t) fi];
+            if (!f.valid || (f.endTime != -1 && f.currentTime > f.endTime) || !(f.currentTime >= f.startTime)) continue;
+            for (double t = f.nowTime; t >= f.interval; t -= f.interval) ++n;
+        }
+        if (n >= 8) {
+            std::mt19937 peek = rnd;
+            for (size_t i = 0; i < n; ++i) {
+                livePriority_.prefetch((int32_t) peek());
+                (void) peek();
+            }
+        }
+    }
     // phase 0: Flow::nextStep for every flow in order (engine.cpp:567-568)
     size_t keep = 0;
     for (size_t ai = 0; ai < activeFlows_.size(); ++ai) {

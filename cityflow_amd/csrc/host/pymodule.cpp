@@ -399,6 +399,8 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("lane_ids", &TiledEngineHost::laneIds)
         .def("owner", &TiledEngineHost::owner, "owning tile of every intersection (index order of the roadnet file)")
         .def("_set_status_reducer", &TiledEngineHost::setStatusReducer, "fn"_a)
+        .def("_host_seconds", &TiledEngineHost::hostSeconds,
+             "(spawner, submit) cumulative host wall seconds of this process since the last reset")
         .def("_profile_enable", &TiledEngineHost::profileEnable, "local_tile"_a, "on"_a)
         .def("_profile_read", &TiledEngineHost::profileRead, "local_tile"_a)
         .def("_vehicle_state",

@@ -5,6 +5,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <iostream>
 #include <numeric>
@@ -557,8 +558,17 @@ void TiledEngineHost::flushPhases() {
 }
 
 void TiledEngineHost::stepBegin() {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
     flushPhases();
     spawner_.step(step_, spawnBuf_);
+    const auto t1 = clk::now();
+    hostSpawnSec_ += std::chrono::duration<double>(t1 - t0).count();
+    struct Acc {
+        double &a;
+        clk::time_point t;
+        ~Acc() { a += std::chrono::duration<double>(clk::now() - t).count(); }
+    } acc{hostSubmitSec_, t1};
     for (auto &t : tiles_) {
         t->uploadTables(spawner_);
         t->step(spawnBuf_);
@@ -583,6 +593,12 @@ void TiledEngineHost::stepBegin() {
 }
 
 void TiledEngineHost::stepEnd() {
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Acc {
+        double &a;
+        std::chrono::steady_clock::time_point t;
+        ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
+    } acc{hostSubmitSec_, t0};
     for (auto &t : tiles_) {
         if (mailboxes_) t->haloWait();
         else t->haloImport();
@@ -695,6 +711,7 @@ void TiledEngineHost::reset(bool resetRnd) {
     for (auto &t : tiles_) t->reset();
     spawner_.reset(resetRnd);
     step_ = 0;
+    hostSpawnSec_ = hostSubmitSec_ = 0;
 }
 
 void TiledEngineHost::sync() {

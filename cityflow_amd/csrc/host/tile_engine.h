@@ -157,6 +157,9 @@ public:
     void setRandomSeed(int seed) { spawner_.seed(seed); }
     void snapshotVehicles(VehicleSnapshot &out);  // local tiles, sorted by global drivable
     void sync();
+    // cumulative host wall time of this process since the last reset: {inside the spawner, submitting the steps (kernel
+    // launches; includes back-pressure waits when the device is the bottleneck)}
+    std::pair<double, double> hostSeconds() const { return std::make_pair(hostSpawnSec_, hostSubmitSec_); }
     void profileEnable(int localTile, bool on) { tiles_.at(localTile)->profileEnable(on); }
     std::map<std::string, std::pair<double, int64_t>> profileRead(int localTile) { return tiles_.at(localTile)->profileRead(); }
     std::vector<int> owner() const { return owner_; }
@@ -177,6 +180,7 @@ private:
     bool allLocal_ = true, mailboxes_ = false;
     size_t step_ = 0;
     std::vector<cfx_spawn> spawnBuf_;
+    double hostSpawnSec_ = 0, hostSubmitSec_ = 0;  // wall time of this process inside the spawner / the ABI calls of a step
     std::vector<int32_t> pendingInter_, pendingPhase_;
     std::function<int(int)> reduceStatus_;
     void flushPhases();
