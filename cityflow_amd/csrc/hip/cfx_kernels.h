@@ -140,7 +140,7 @@ __global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *wa
     c.s.route[slot] = route;
     c.s.flags[slot] = vt.pendingCustom[w];
     c.s.dis[slot] = 0.0;
-    c.s.speed[slot] = 0.0;
+    c.s.speed[slot] = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
     cnt[lane] = n + 1;
     c.laneTail[lane] = slot;
     admitStep[lane] = c.step;

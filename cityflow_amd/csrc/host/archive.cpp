@@ -94,7 +94,7 @@ void Archive::dump(const std::string &path) const {
         key(o, "priority"); o += std::to_string(r.priority); o += ',';
         key(o, "id"); str(o, vehicleId(v)); o += ',';
         key(o, "enterTime"); num(o, r.enterTime); o += ',';
-        key(o, "speed"); num(o, ri >= 0 ? dev.rSpeed[ri] : 0.0); o += ',';
+        key(o, "speed"); num(o, ri >= 0 ? dev.rSpeed[ri] : t.initial_speed); o += ',';
         key(o, "len"); num(o, t.len); o += ',';
         key(o, "width"); num(o, t.width); o += ',';
         key(o, "maxPosAcc"); num(o, t.max_pos_acc); o += ',';
@@ -333,6 +333,7 @@ void EngineHost::loadFromFile(const std::string &path) {
         t.yield_distance = jv.numberAt("yieldDistance");
         t.turn_speed = jv.numberAt("turnSpeed");
         t.approach_dist = jv.numberAt("approachingIntersectionDistance");
+        if (!jv.boolAt("running")) t.initial_speed = jv.numberAt("speed");  // a waiting vehicle enters with VehicleInfo::speed
         VehicleRecord r{};
         r.templ = spawner_.addTemplate(t);
         std::vector<int> seq;

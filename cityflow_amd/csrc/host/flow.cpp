@@ -67,7 +67,7 @@ void Spawner::init(const HostRoadNet *net, double interval, int threadNum, int s
 
 cfx_vehicle_template Spawner::makeTemplate(double len, double width, double maxPosAcc, double maxNegAcc,
                                            double usualPosAcc, double usualNegAcc, double minGap, double maxSpeed,
-                                           double headwayTime) const {
+                                           double headwayTime, double initialSpeed) const {
     cfx_vehicle_template t{};
     t.len = len;
     t.width = width;
@@ -82,6 +82,7 @@ cfx_vehicle_template Spawner::makeTemplate(double len, double width, double maxP
     t.turn_speed = 8.3333;
     // vehicle.cpp:42-44, same grouping
     t.approach_dist = maxSpeed * maxSpeed / usualNegAcc / 2 + maxSpeed * interval_ * 2;
+    t.initial_speed = initialSpeed;
     return t;
 }
 

@@ -84,7 +84,8 @@ public:
     bool expandRoute(const std::vector<int> &anchors, std::vector<int> &out) const;
     int addTemplate(const cfx_vehicle_template &t);  // dedupes identical templates
     cfx_vehicle_template makeTemplate(double len, double width, double maxPosAcc, double maxNegAcc, double usualPosAcc,
-                                      double usualNegAcc, double minGap, double maxSpeed, double headwayTime) const;
+                                      double usualNegAcc, double minGap, double maxSpeed, double headwayTime,
+                                      double initialSpeed = 0.0) const;
 
     // push_vehicle (engine.cpp:693-717): queued into the first road's planRouteBuffer until the next step.
     void pushManual(int templ, const std::vector<int> &anchors, size_t step);

@@ -869,9 +869,7 @@ void TiledEngineHost::pushVehicle(const std::map<std::string, double> &info, con
     };
     cfx_vehicle_template t = spawner_.makeTemplate(get("length", 5), get("width", 2), get("maxPosAcc", 4.5), get("maxNegAcc", 4.5),
                                                    get("usualPosAcc", 2.5), get("usualNegAcc", 2.5), get("minGap", 2),
-                                                   get("maxSpeed", 16.66667), get("headwayTime", 1));
-    if (info.count("speed") && info.at("speed") != 0)
-        throw std::runtime_error("cityflow_amd: push_vehicle with a non-zero initial speed is not supported yet");
+                                                   get("maxSpeed", 16.66667), get("headwayTime", 1), get("speed", 0));
     std::vector<int> anchors;
     for (auto &r : roads) {
         auto it = net_->roadIndex.find(r);

@@ -102,6 +102,8 @@ typedef struct cfx_vehicle_template {
     /* maxSpeed^2/usualNegAcc/2 + maxSpeed*interval*2 : ControllerInfo::approachingIntersectionDistance
      * (vehicle.cpp:42-44) and the head-of-lane leader search bound (vehicle.cpp:190-192). */
     double approach_dist;
+    double initial_speed; /* VehicleInfo::speed (vehicle.h:32) a vehicle enters its first lane with; only
+                           * push_vehicle can set it (engine.cpp:696), flows always create vehicles at rest */
 } cfx_vehicle_template;
 
 /* One vehicle entering the simulation this step (Flow::nextStep flow.cpp:6-22 + Engine::planRoute

@@ -613,6 +613,7 @@ struct cfx_engine {
             v.templ = s.templ;
             v.route = s.route;
             v.enterTime = s.enter_time;
+            v.speed = templ[s.templ].initial_speed;  // VehicleInfo::speed (engine.cpp:696)
             v.drivable = s.lane;  // Vehicle::setFirstDrivable vehicle.cpp:422-424
             veh.push_back(v);
             if (s.lane >= 0) waiting[s.lane].push_back(s.vid);  // lane -1: the vehicle starts in another tile
@@ -991,6 +992,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         x.enterTime = s->v_enter_time[v];
         x.running = s->v_state[v] == 1;
         x.finished = s->v_state[v] == 2;
+        x.speed = e->templ[x.templ].initial_speed;  // what a waiting vehicle will enter with; running ones: r_speed below
     }
     for (int i = 0; i < s->n_running; ++i) {
         Veh &x = e->veh[s->r_vid[i]];

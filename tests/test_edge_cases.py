@@ -126,3 +126,25 @@ def test_push_vehicle_defaults_match_reference(mod, ref_module, scen, workdir):
         assert checkpoint_record(ours) == checkpoint_record(ref), s
     assert ours.get_vehicles(True) == ref.get_vehicles(True)
     time.sleep(0.1)
+
+
+def test_push_vehicle_with_initial_speed(mod, ref_module, scen, workdir, tmp_path):
+    """VehicleInfo::speed from push_vehicle (engine.cpp:696): the vehicle enters its first lane already moving; the value
+    also survives a snapshot taken while the vehicle is still waiting."""
+    cfg = scen.materialize("example_1x1", workdir)
+    ours, ref = _both(mod, ref_module, cfg)
+    dump = str(tmp_path / "with_waiting.json")
+    for s in range(120):
+        if s in (2, 3, 50):
+            for e in (ours, ref):
+                e.push_vehicle({"speed": 9.5, "maxSpeed": 12.0}, ["road_2_1_2", "road_1_1_3"])
+                e.push_vehicle({"speed": 3.0}, ["road_2_1_2", "road_1_1_3"])   # same first road: queues behind
+                e.push_vehicle({"speed": 20.0, "length": 4.0}, ["road_1_0_1", "road_1_1_0"])
+        if s == 4:  # some of the pushed vehicles are still in a waiting buffer here
+            ours.snapshot().dump(dump)
+            ours.load_from_file(dump)
+        ours.next_step()
+        ref.next_step()
+        assert checkpoint_record(ours) == checkpoint_record(ref), s
+    assert ours.get_vehicle_speed() == ref.get_vehicle_speed()
+    time.sleep(0.1)

@@ -72,3 +72,26 @@ def test_reference_dump_loads_into_hip(mod, ref_module, scen, workdir, tmp_path)
     run(hip, 150)
     assert checkpoint_record(hip) == want
     time.sleep(0.1)
+
+
+def test_push_vehicle_with_initial_speed_hip(mod, ref_module, scen, workdir, tmp_path):
+    """push_vehicle({"speed": ...}) on the HIP engine vs the reference, with a snapshot taken while pushed vehicles wait."""
+    import time
+    from conftest import checkpoint_record
+    cfg = scen.materialize("example_1x1", workdir)
+    hip, ref = mod.Engine(cfg, 1), ref_module.Engine(cfg, 1)
+    dump = str(tmp_path / "hip_waiting.json")
+    for s in range(120):
+        if s in (2, 3, 50):
+            for e in (hip, ref):
+                e.push_vehicle({"speed": 9.5, "maxSpeed": 12.0}, ["road_2_1_2", "road_1_1_3"])
+                e.push_vehicle({"speed": 3.0}, ["road_2_1_2", "road_1_1_3"])
+                e.push_vehicle({"speed": 20.0, "length": 4.0}, ["road_1_0_1", "road_1_1_0"])
+        if s == 4:
+            hip.snapshot().dump(dump)
+            hip.load_from_file(dump)
+        hip.next_step()
+        ref.next_step()
+        assert checkpoint_record(hip) == checkpoint_record(ref), s
+    time.sleep(0.2)
+    del ref
