@@ -180,6 +180,15 @@ def test_two_ranks_one_gpu(scen, workdir, tmp_path, mailboxes):
     assert "TILED_OK 150" in out.stdout
 
 
+@pytest.mark.gpu
+def test_four_ranks_one_gpu_mailboxes(scen, workdir, tmp_path):
+    """2x2 tiles, four processes on this box's GPU: every tile has two neighbours, mailboxes in both directions."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, "", 2, 2, 150, 4, 29549, {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": "1"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 150" in out.stdout
+
+
 def _api_compare(mod, cfg, lib, rows, cols):
     """Every query / control call of the reference API on the tiled engine vs the single engine."""
     ref = mod.Engine._with_backend(cfg, 1, lib)
