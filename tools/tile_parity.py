@@ -18,6 +18,8 @@ wd = tempfile.mkdtemp(prefix="tile_parity_")
 cfg = scenarios.materialize(name, wd)
 ref = m.Engine._with_backend(cfg, 1, lib)
 til = m.TiledEngine(cfg, rows, cols, [], lib)
+if os.environ.get("CFX_MAILBOXES", "0") == "1":
+    til.enable_mailboxes("tile_parity_%d" % os.getpid())
 print('tiles', til.num_tiles, 'peers0', til.peers(0))
 keys = ['vid','drivable','prev_drivable','leader','blocker','enter_ll_time','route_pos','dis','speed','gap']
 for s in range(steps):
