@@ -88,6 +88,7 @@ struct cfx_engine {
     int32_t *scanTicket = nullptr;
     int nScanBlocks = 0;
     int32_t *laneOut = nullptr;
+    int32_t *hLaneOut = nullptr;  // pinned landing buffer of the per-lane getters (a D2H copy into pageable memory is staged twice)
     DevScalars *sc = nullptr;
 
     cfx_spawn *dRecs = nullptr;
@@ -380,6 +381,7 @@ void cfx_destroy(cfx_engine *e) {
         if (m.sendHost) (void) hipHostUnregister(m.sendHost);
         if (m.recvHost) (void) hipHostUnregister(m.recvHost);
     }
+    if (e->hLaneOut) (void) hipHostFree(e->hLaneOut);
     if (e->hHaloSend) (void) hipHostFree(e->hHaloSend);
     if (e->hHaloRecv) (void) hipHostFree(e->hHaloRecv);
     if (e->stream) (void) hipStreamDestroy(e->stream);
@@ -443,6 +445,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->waitHead, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->admitStep, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
+    HIP_TRY(hipHostMalloc((void **) &e->hLaneOut, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
     if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->laneTail, (size_t) e->L))) return rc;
@@ -734,8 +737,9 @@ int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpyAsync(out, e->cnt[e->cur].p, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->hLaneOut, e->cnt[e->cur].p, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(out, e->hLaneOut, e->L * sizeof(int32_t));
     return CFX_OK;
 }
 
@@ -747,8 +751,9 @@ int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out) {
     if ((rc = e->syncTables())) return rc;
     hipLaunchKernelGGL(k_lane_waiting, dim3(gridFor(e->L)), dim3(kBlock), 0, e->stream, e->ctx(), e->laneOut);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, e->laneOut, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->hLaneOut, e->laneOut, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(out, e->hLaneOut, e->L * sizeof(int32_t));
     return CFX_OK;
 }
 
