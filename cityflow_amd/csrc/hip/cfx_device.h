@@ -83,6 +83,7 @@ struct StepCtx {
     // per-step gate records written by k_admit (phase 2), read by k_action (phase 4)
     int2 *llGate;             // [K] {bit0 RoadLink::isAvailable, bits1-2 RoadLinkType, bit3 has crosses ; end lane}
     int32_t *laneTail;        // [L] Drivable::getLastVehicle() of the lane after this step's admission (slot or -1)
+    int2 *admitRec;           // [L] {admitted vid, its successor in the lane's FIFO}: what k_scan needs to commit the pop
     int32_t step;
     double interval;
 };
@@ -98,9 +99,17 @@ __device__ __forceinline__ int d2i(double x) {
     return (int) x;
 }
 
+// Vehicles on drivable d as phases 3/4 see them.  cnt[] is the committed count; a lane's admission of THIS step
+// (Engine::handleWaiting, phase 2) is not folded into it until the compaction (k_scan) — it is the flag
+// admitStep[lane] == step plus the vehicle written into the lane's spare slot — so that nothing phase 2 writes is
+// read by another lane's admission or by phases 3/4 of vehicles elsewhere.
+__device__ __forceinline__ int cntNow(const StepCtx &c, int d) {
+    return c.cnt[d] + ((d < c.n.L && c.admitStep[d] == c.step) ? 1 : 0);
+}
+
 // Drivable::getLastVehicle as every phase-3/4 reader sees it (this step's admission included).
 __device__ __forceinline__ int lastSlot(const StepCtx &c, int d) {
-    int n = c.cnt[d];
+    int n = cntNow(c, d);
     return n > 0 ? c.segStart[d] + n - 1 : -1;
 }
 
@@ -110,7 +119,7 @@ __device__ __forceinline__ int lastSlot(const StepCtx &c, int d) {
 // lanes A < B (engine.cpp:503,512).
 __device__ __forceinline__ int lastSlotForLeader(const StepCtx &c, int d, bool viewerNew, int viewerLane) {
     int n = c.cnt[d];
-    if (d < c.n.L && c.admitStep[d] == c.step && !(viewerNew && d < viewerLane)) n -= 1;
+    if (viewerNew && d < viewerLane && d < c.n.L && c.admitStep[d] == c.step) n += 1;
     return n > 0 ? c.segStart[d] + n - 1 : -1;
 }
 

@@ -79,6 +79,7 @@ struct cfx_engine {
 
     // ---- per-lane / per-laneLink / per-entry / per-intersection dynamic state ----
     int32_t *waitHead = nullptr, *admitStep = nullptr, *laneTail = nullptr, *curPhase = nullptr;
+    int2 *admitRec = nullptr;
     int4 *llDyn = nullptr;
     int2 *llGate = nullptr;
     unsigned long long *interMask = nullptr;
@@ -87,6 +88,8 @@ struct cfx_engine {
     unsigned long long *scanGranules = nullptr;
     int32_t *scanTicket = nullptr;
     int nScanBlocks = 0;
+    // per-drivable arrays k_scan reads with 16-byte loads are padded to whole scan tiles
+    size_t dPadded() const { return (size_t) ((D + kScanTile - 1) / kScanTile) * kScanTile; }
     int32_t *laneOut = nullptr;
     int32_t *hLaneOut = nullptr;  // pinned landing buffer of the per-lane getters (a D2H copy into pageable memory is staged twice)
     DevScalars *sc = nullptr;
@@ -231,6 +234,7 @@ struct cfx_engine {
         c.llDyn = llDyn;
         c.llGate = llGate;
         c.laneTail = laneTail;
+        c.admitRec = admitRec;
         c.interMask = interMask;
         c.step = (int32_t) step;
         c.interval = cfg.interval;
@@ -344,7 +348,7 @@ struct cfx_engine {
         }
         hipLaunchKernelGGL(k_init_lights, dim3(gridFor(I)), dim3(kBlock), 0, stream, net, curPhase, remain);
         HIP_TRY(hipMemsetAsync(waitHead, 0xFF, L * sizeof(int32_t), stream));
-        HIP_TRY(hipMemsetAsync(admitStep, 0xFF, L * sizeof(int32_t), stream));
+        HIP_TRY(hipMemsetAsync(admitStep, 0xFF, dPadded() * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(interMask, 0, std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(sc, 0, sizeof(DevScalars), stream));
         HIP_TRY(hipMemsetAsync(scanGranules, 0, (size_t) nScanBlocks * sizeof(unsigned long long), stream));
@@ -434,21 +438,26 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     UP(phaseTime, n->phase_time, n->n_phases)
     UP(phaseAvail, n->phase_avail, n->n_avail)
 #undef UP
+    const size_t dPad = e->dPadded();
     for (int g = 0; g < 2; ++g) {
         if ((rc = e->allocRaw(&e->segStart[g].p, (size_t) e->D + 1))) return rc;
-        if ((rc = e->allocRaw(&e->cnt[g].p, (size_t) e->D))) return rc;
+        if ((rc = e->allocRaw(&e->cnt[g].p, dPad))) return rc;
+        HIP_TRY(hipMemset(e->cnt[g].p, 0, dPad * sizeof(int32_t)));
     }
-    if ((rc = e->allocRaw(&e->cs.leaveCnt, (size_t) e->D))) return rc;
+    if ((rc = e->allocRaw(&e->cs.leaveCnt, dPad))) return rc;
+    HIP_TRY(hipMemset(e->cs.leaveCnt, 0, dPad * sizeof(int32_t)));
     if ((rc = e->allocRaw(&e->cs.maxLeaveIdx, (size_t) e->D))) return rc;
-    if ((rc = e->allocRaw(&e->cs.inCnt, (size_t) e->D))) return rc;
+    if ((rc = e->allocRaw(&e->cs.inCnt, dPad))) return rc;
+    HIP_TRY(hipMemset(e->cs.inCnt, 0, dPad * sizeof(int32_t)));
     if ((rc = e->allocRaw(&e->cs.inHead, (size_t) e->D))) return rc;
     if ((rc = e->allocRaw(&e->waitHead, (size_t) e->L))) return rc;
-    if ((rc = e->allocRaw(&e->admitStep, (size_t) e->L))) return rc;
+    if ((rc = e->allocRaw(&e->admitStep, dPad))) return rc;  // lanes only are ever set; the rest stays -1 (k_scan reads 8 at a time)
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
     HIP_TRY(hipHostMalloc((void **) &e->hLaneOut, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
     if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->laneTail, (size_t) e->L))) return rc;
+    if ((rc = e->allocRaw(&e->admitRec, dPad))) return rc;
     {
         // derived tables: index of each laneLink inside its intersection (laneLinks of one intersection are
         // contiguous in RoadNet::getLaneLinks() order), the peer's bit for every cross entry, mask offsets
@@ -605,8 +614,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     const int nxt = e->cur ^ 1;
     const size_t slotBound = std::min(need, e->slotCap);
     { int pp__ = e->profBegin(PK_ADMIT);
-    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->cnt[e->cur].p, e->admitStep, e->waitHead,
-                       e->vt, e->cs, e->sc);
+    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->admitStep, e->waitHead, e->vt, e->cs);
     e->profEnd(pp__); }
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
     JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap};
@@ -625,7 +633,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     { int pp__ = e->profBegin(PK_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
                        scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
-                       e->gen[nxt].drv, e->sc, e->net.laneSpare);
+                       e->gen[nxt].drv, e->sc, e->net.laneSpare, e->admitStep, (int) e->step, e->waitHead, e->vt,
+                       e->net.laneGhost, e->admitRec);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),

@@ -102,8 +102,7 @@ __global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidT
 }
 
 // Engine::handleWaiting engine.cpp:502-516 + Lane::available roadnet.cpp:428-435
-__global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *waitHead, VidTable vt, CompactScratch cs,
-                        DevScalars *sc) {
+__global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, CompactScratch cs) {
     int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= c.n.L + c.n.K) return;
     cs.leaveCnt[lane] = 0;  // compaction scratch of every drivable (lanes and laneLinks) for this step
@@ -118,7 +117,7 @@ __global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *wa
         return;
     }
     int w = waitHead[lane];
-    int n = cnt[lane];
+    int n = c.cnt[lane];
     int base = c.segStart[lane];
     c.laneTail[lane] = n > 0 ? base + n - 1 : -1;  // overwritten below if a vehicle is admitted
     if (w < 0) return;
@@ -141,13 +140,9 @@ __global__ void k_admit(StepCtx c, int32_t *cnt, int32_t *admitStep, int32_t *wa
     c.s.flags[slot] = vt.pendingCustom[w];
     c.s.dis[slot] = 0.0;
     c.s.speed[slot] = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
-    cnt[lane] = n + 1;
     c.laneTail[lane] = slot;
-    admitStep[lane] = c.step;
-    waitHead[lane] = vt.nextWait[w];
-    vt.state[w] = 1;
-    // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail => same decision)
-    if (!(c.n.laneGhost && c.n.laneGhost[lane])) atomicAdd((unsigned long long *) &sc->active, 1ULL);
+    c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
+    admitStep[lane] = c.step;  // cnt[], the FIFO pop and the running count follow in k_scan (see cntNow)
 }
 
 // Per-laneLink sources of Engine::threadNotifyCross (engine.cpp:317-372): the vehicle that just left
@@ -159,7 +154,7 @@ __device__ inline void llstate(const StepCtx &c, int k) {
     const int endLane = c.n.llEndLane[k], startLane = c.n.llStartLane[k];
     int u = lastSlot(c, endLane);
     if (u >= 0 && c.s.prevDrv[u] != d) u = -1;
-    int f = c.cnt[startLane] > 0 ? c.segStart[startLane] : -1;
+    int f = cntNow(c, startLane) > 0 ? c.segStart[startLane] : -1;
     if (f >= 0 && !(c.s.next[f] == d && llAvailable(c, k))) f = -1;
     const int nOn = c.cnt[d];
     c.llDyn[k] = make_int4(u, f, c.segStart[d], nOn);
@@ -283,7 +278,7 @@ __device__ inline int findLeader(const StepCtx &c, const cfx_vehicle_template *t
         return ls;
     }
     // head of a lane whose only vehicle was admitted this step => it IS the admitted vehicle
-    const bool viewerNew = d < c.n.L && c.admitStep[d] == c.step && c.cnt[d] == 1;
+    const bool viewerNew = d < c.n.L && c.admitStep[d] == c.step && c.cnt[d] == 0;
     int ls = -1;
     double gap = 0.0;
     double dist = c.n.drvLength[d] - myDis;
@@ -628,8 +623,8 @@ constexpr int kFinLds = 2048;                       // finished vehicles per ste
 constexpr unsigned kSpinLimit = 1u << 26;
 constexpr int kScanResidentTiles = 512;             // tiles (256-thread blocks, 28 VGPRs) that are certainly co-resident
 
-__device__ __forceinline__ int newLiveCount(const int32_t *cnt, const CompactScratch &cs, int d) {
-    return cnt[d] - cs.leaveCnt[d] + cs.inCnt[d];
+__device__ __forceinline__ int newLiveCount(const int32_t *cnt, const CompactScratch &cs, int d, int admitted) {
+    return cnt[d] + admitted - cs.leaveCnt[d] + cs.inCnt[d];
 }
 
 __device__ inline int blockReduceSum(int v, int *smem) {
@@ -699,7 +694,9 @@ __device__ inline void finishStatistics(const StepCtx &c, const VidTable &vt, De
 __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cnt, CompactScratch cs,
                                                  unsigned long long *granules, int32_t *ticket, unsigned epoch,
                                                  int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
-                                                 int32_t *drvNext, DevScalars *sc, const uint8_t *laneSpare) {
+                                                 int32_t *drvNext, DevScalars *sc, const uint8_t *laneSpare,
+                                                 const int32_t *admitStep, int step, int32_t *waitHead, VidTable vt,
+                                                 const uint8_t *laneGhost, const int2 *admitRec) {
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
     __shared__ int tileShared;
@@ -715,12 +712,46 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
     int vals[kScanItems];
     int live[kScanItems];
     int sum = 0;
+    // Loads first, 16 bytes at a time (a thread's 8 drivables are contiguous and the arrays are padded to whole tiles),
+    // in one round; the admissions are committed (stores) after the loop.
+    unsigned admittedMask = 0;
+    int cntv[kScanItems], leavev[kScanItems], inv[kScanItems], admv[kScanItems];
+    int2 rec[kScanItems];
+    {
+        const int4 *pc = (const int4 *) (cnt + base), *pl = (const int4 *) (cs.leaveCnt + base),
+                   *pi = (const int4 *) (cs.inCnt + base), *pa = (const int4 *) (admitStep + base),
+                   *pr = (const int4 *) (admitRec + base);
+        const int4 c0 = pc[0], c1 = pc[1], l0 = pl[0], l1 = pl[1], i0 = pi[0], i1 = pi[1], a0 = pa[0], a1 = pa[1];
+        const int4 r0 = pr[0], r1 = pr[1], r2 = pr[2], r3 = pr[3];
+        cntv[0] = c0.x; cntv[1] = c0.y; cntv[2] = c0.z; cntv[3] = c0.w; cntv[4] = c1.x; cntv[5] = c1.y; cntv[6] = c1.z; cntv[7] = c1.w;
+        leavev[0] = l0.x; leavev[1] = l0.y; leavev[2] = l0.z; leavev[3] = l0.w; leavev[4] = l1.x; leavev[5] = l1.y; leavev[6] = l1.z; leavev[7] = l1.w;
+        inv[0] = i0.x; inv[1] = i0.y; inv[2] = i0.z; inv[3] = i0.w; inv[4] = i1.x; inv[5] = i1.y; inv[6] = i1.z; inv[7] = i1.w;
+        admv[0] = a0.x; admv[1] = a0.y; admv[2] = a0.z; admv[3] = a0.w; admv[4] = a1.x; admv[5] = a1.y; admv[6] = a1.z; admv[7] = a1.w;
+        rec[0] = make_int2(r0.x, r0.y); rec[1] = make_int2(r0.z, r0.w); rec[2] = make_int2(r1.x, r1.y); rec[3] = make_int2(r1.z, r1.w);
+        rec[4] = make_int2(r2.x, r2.y); rec[5] = make_int2(r2.z, r2.w); rec[6] = make_int2(r3.x, r3.y); rec[7] = make_int2(r3.z, r3.w);
+    }
+    static_assert(kScanItems == 8, "k_scan loads its 8 items as two int4");
     for (int i = 0; i < kScanItems; ++i) {
         int d = base + i;
-        int nl = d < D ? newLiveCount(cnt, cs, d) : 0;
+        const int admitted = (d < L && admv[i] == step) ? 1 : 0;
+        admittedMask |= (unsigned) admitted << i;
+        int nl = d < D ? cntv[i] + admitted - leavev[i] + inv[i] : 0;
         live[i] = nl;
         vals[i] = d < D ? nl + (d < L ? (laneSpare ? (int) laneSpare[d] : 1) : 0) : 0;
         sum += vals[i];
+    }
+    if (admittedMask) {
+        // commit this step's admissions (phase 2): the FIFO pop, the vehicle's state and the running count
+        int nAdm = 0;
+        for (int i = 0; i < kScanItems; ++i)
+            if ((admittedMask >> i) & 1u) {
+                const int d = base + i;
+                waitHead[d] = rec[i].y;
+                vt.state[rec[i].x] = 1;
+                // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail, same decision)
+                nAdm += !(laneGhost && laneGhost[d]);
+            }
+        if (nAdm) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) nAdm);
     }
     // in-wave inclusive scan of the per-thread sums, wave totals to LDS
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -859,7 +890,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
                 double od = b.dis[j];
                 rank += (od > ndis) || (od == ndis && c.s.vid[j] < vid);
             }
-            ns = tStartNext + (c.cnt[nd] - tLeave) + rank;
+            ns = tStartNext + (cntNow(c, nd) - tLeave) + rank;
         }
         oldToNew[s] = ns;
         nx.vid[ns] = vid;
