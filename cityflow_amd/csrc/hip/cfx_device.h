@@ -39,13 +39,6 @@ struct DevNet {
     const uint8_t *laneSpare;       // [L] spare slots behind the lane's vehicles (1 admission + halo migrants)
 };
 
-// The tail vehicle of a lane after this step's admission, by value: the admitted vehicle itself is being written by
-// the workgroup that owns the lane, so other workgroups must not read its slot (see admitLane / k_junction).
-struct alignas(16) LaneTailInfo {
-    double dis, len, speed;
-    int32_t templ, pad;
-};
-
 struct DevTables {
     const cfx_vehicle_template *templ;
     int nTempl;
@@ -91,10 +84,6 @@ struct StepCtx {
     int2 *llGate;             // [K] {bit0 RoadLink::isAvailable, bits1-2 RoadLinkType, bit3 has crosses ; end lane}
     int32_t *laneTail;        // [L] Drivable::getLastVehicle() of the lane after this step's admission (slot or -1)
     int2 *admitRec;           // [L] {admitted vid, its successor in the lane's FIFO}: what k_scan needs to commit the pop
-    LaneTailInfo *laneTailInfo;  // [L] what Lane::canEnter and a leader search need of laneTail's vehicle, by value
-    const int32_t *waitHead;  // [L] head of the lane's waiting FIFO (unchanged until k_scan)
-    const int32_t *vTempl;    // [vid] template of a vehicle (for the head of a FIFO)
-    int32_t inStep;           // 1 inside cfx_step's kernels (laneTail[] is this step's), 0 for getters between steps
     int32_t step;
     double interval;
 };
@@ -110,53 +99,27 @@ __device__ __forceinline__ int d2i(double x) {
     return (int) x;
 }
 
-// Engine::handleWaiting's decision for one lane (engine.cpp:502-516, Lane::available roadnet.cpp:428-435), as a pure
-// function of the state committed by the previous step: nothing a step's kernels write before the compaction feeds
-// it, so any thread may evaluate it for any lane and gets the owner's answer ("mirrored admission").
-__device__ __forceinline__ bool admitsNow(const StepCtx &c, int lane, int *wtOut) {
-    const int w = c.waitHead[lane];
-    if (w < 0) return false;
-    const int wt = c.vTempl[w];
-    const int n = c.cnt[lane];
-    if (n > 0) {
-        const int tail = c.segStart[lane] + n - 1;
-        if (!(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) return false;
-    }
-    *wtOut = wt;
-    return true;
-}
-
 // Vehicles on drivable d as phases 3/4 see them.  cnt[] is the committed count; a lane's admission of THIS step
-// (phase 2) is not folded into it until the compaction (k_scan): it shows in laneTail[lane], the lane's last vehicle
-// after admission, which every workgroup that looks at the lane has written before (same value whoever writes it).
+// (Engine::handleWaiting, phase 2) is not folded into it until the compaction (k_scan) — it is the flag
+// admitStep[lane] == step plus the vehicle written into the lane's spare slot — so that nothing phase 2 writes is
+// read by another lane's admission or by phases 3/4 of vehicles elsewhere.
 __device__ __forceinline__ int cntNow(const StepCtx &c, int d) {
-    if (d >= c.n.L || !c.inStep) return c.cnt[d];
-    const int t = c.laneTail[d];
-    return t >= 0 ? t - c.segStart[d] + 1 : 0;
+    return c.cnt[d] + ((d < c.n.L && c.admitStep[d] == c.step) ? 1 : 0);
 }
 
 // Drivable::getLastVehicle as every phase-3/4 reader sees it (this step's admission included).
 __device__ __forceinline__ int lastSlot(const StepCtx &c, int d) {
-    if (d < c.n.L && c.inStep) return c.laneTail[d];
-    const int n = c.cnt[d];
+    int n = cntNow(c, d);
     return n > 0 ? c.segStart[d] + n - 1 : -1;
 }
 
 // Drivable::getLastVehicle as the LEADER SEARCH saw it.  The reference evaluates leader/gap at the end
 // of the previous step (engine.cpp:429-442), i.e. before this step's admissions, except for a vehicle
 // admitted this step on lane B, whose search runs inside handleWaiting and therefore sees admissions on
-// lanes A < B (engine.cpp:503,512).  *freshTempl >= 0 reports that the answer is the vehicle admitted on d this very
-// step (its slot is still being written elsewhere: take dis 0 and the template's length / initial speed instead).
-__device__ __forceinline__ int lastSlotForLeader(const StepCtx &c, int d, bool viewerNew, int viewerLane, int *freshTempl) {
-    const int n = c.cnt[d];
-    *freshTempl = -1;
-    if (viewerNew && d < viewerLane && d < c.n.L) {
-        int wt;
-        if (admitsNow(c, d, &wt)) {
-            *freshTempl = wt;
-            return c.segStart[d] + n;
-        }
-    }
+// lanes A < B (engine.cpp:503,512).
+__device__ __forceinline__ int lastSlotForLeader(const StepCtx &c, int d, bool viewerNew, int viewerLane) {
+    int n = c.cnt[d];
+    if (viewerNew && d < viewerLane && d < c.n.L && c.admitStep[d] == c.step) n += 1;
     return n > 0 ? c.segStart[d] + n - 1 : -1;
 }
 

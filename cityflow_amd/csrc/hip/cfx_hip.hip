@@ -70,8 +70,7 @@ struct cfx_engine {
     size_t slotCap = 0;
     int cur = 0;
     ActionBuf ab{};
-    CompactScratch cs{};       // per-slot part (inNext) + set 0 of the per-drivable part
-    CompactScratch csSet[2]{}; // per-drivable scratch, double-buffered by step parity (see k_scan)
+    CompactScratch cs{};
     int32_t *oldToNew = nullptr;
     int32_t *finList = nullptr, *finSorted = nullptr, *crossJobs = nullptr, *jobCount = nullptr;
     // getter scratch
@@ -81,7 +80,6 @@ struct cfx_engine {
     // ---- per-lane / per-laneLink / per-entry / per-intersection dynamic state ----
     int32_t *waitHead = nullptr, *admitStep = nullptr, *laneTail = nullptr, *curPhase = nullptr;
     int2 *admitRec = nullptr;
-    LaneTailInfo *laneTailInfo = nullptr;
     int4 *llDyn = nullptr;
     int2 *llGate = nullptr;
     unsigned long long *interMask = nullptr;
@@ -237,10 +235,6 @@ struct cfx_engine {
         c.llGate = llGate;
         c.laneTail = laneTail;
         c.admitRec = admitRec;
-        c.laneTailInfo = laneTailInfo;
-        c.waitHead = waitHead;
-        c.vTempl = vt.templ;
-        c.inStep = 0;
         c.interMask = interMask;
         c.step = (int32_t) step;
         c.interval = cfg.interval;
@@ -355,12 +349,6 @@ struct cfx_engine {
         hipLaunchKernelGGL(k_init_lights, dim3(gridFor(I)), dim3(kBlock), 0, stream, net, curPhase, remain);
         HIP_TRY(hipMemsetAsync(waitHead, 0xFF, L * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(admitStep, 0xFF, dPadded() * sizeof(int32_t), stream));
-        for (int g = 0; g < 2; ++g) {
-            HIP_TRY(hipMemsetAsync(csSet[g].leaveCnt, 0, dPadded() * sizeof(int32_t), stream));
-            HIP_TRY(hipMemsetAsync(csSet[g].inCnt, 0, dPadded() * sizeof(int32_t), stream));
-            HIP_TRY(hipMemsetAsync(csSet[g].maxLeaveIdx, 0xFF, dPadded() * sizeof(int32_t), stream));
-            HIP_TRY(hipMemsetAsync(csSet[g].inHead, 0xFF, dPadded() * sizeof(int32_t), stream));
-        }
         HIP_TRY(hipMemsetAsync(interMask, 0, std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(sc, 0, sizeof(DevScalars), stream));
         HIP_TRY(hipMemsetAsync(scanGranules, 0, (size_t) nScanBlocks * sizeof(unsigned long long), stream));
@@ -456,12 +444,12 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         if ((rc = e->allocRaw(&e->cnt[g].p, dPad))) return rc;
         HIP_TRY(hipMemset(e->cnt[g].p, 0, dPad * sizeof(int32_t)));
     }
-    for (int g = 0; g < 2; ++g) {
-        if ((rc = e->allocRaw(&e->csSet[g].leaveCnt, dPad))) return rc;
-        if ((rc = e->allocRaw(&e->csSet[g].maxLeaveIdx, dPad))) return rc;
-        if ((rc = e->allocRaw(&e->csSet[g].inCnt, dPad))) return rc;
-        if ((rc = e->allocRaw(&e->csSet[g].inHead, dPad))) return rc;
-    }
+    if ((rc = e->allocRaw(&e->cs.leaveCnt, dPad))) return rc;
+    HIP_TRY(hipMemset(e->cs.leaveCnt, 0, dPad * sizeof(int32_t)));
+    if ((rc = e->allocRaw(&e->cs.maxLeaveIdx, (size_t) e->D))) return rc;
+    if ((rc = e->allocRaw(&e->cs.inCnt, dPad))) return rc;
+    HIP_TRY(hipMemset(e->cs.inCnt, 0, dPad * sizeof(int32_t)));
+    if ((rc = e->allocRaw(&e->cs.inHead, (size_t) e->D))) return rc;
     if ((rc = e->allocRaw(&e->waitHead, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->admitStep, dPad))) return rc;  // lanes only are ever set; the rest stays -1 (k_scan reads 8 at a time)
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
@@ -470,7 +458,6 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->laneTail, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->admitRec, dPad))) return rc;
-    if ((rc = e->allocRaw(&e->laneTailInfo, (size_t) e->L))) return rc;
     {
         // derived tables: index of each laneLink inside its intersection (laneLinks of one intersection are
         // contiguous in RoadNet::getLaneLinks() order), the peer's bit for every cross entry, mask offsets
@@ -624,16 +611,12 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
 
     StepCtx c = e->ctx();
-    c.inStep = 1;
-    // this step's per-drivable compaction scratch (cleared by the previous step's k_scan) and the one to clear now
-    CompactScratch csNow = e->csSet[e->step & 1], csNext = e->csSet[(e->step + 1) & 1];
-    csNow.inNext = e->cs.inNext;
     const int nxt = e->cur ^ 1;
     const size_t slotBound = std::min(need, e->slotCap);
     { int pp__ = e->profBegin(PK_ADMIT);
-    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->admitStep, e->vt);
+    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->admitStep, e->waitHead, e->vt, e->cs);
     e->profEnd(pp__); }
-    ActionOut ao{e->ab, csNow, e->vt, e->sc, e->finList, (int) e->slotCap};
+    ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
     JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap};
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
@@ -648,14 +631,14 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     e->profEnd(pp__); }
     int32_t *const scanTicket = e->nScanBlocks > kScanResidentTiles ? e->scanTicket : nullptr;
     { int pp__ = e->profBegin(PK_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, csNow, e->scanGranules,
+    hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
                        scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
                        e->gen[nxt].drv, e->sc, e->net.laneSpare, e->admitStep, (int) e->step, e->waitHead, e->vt,
-                       e->net.laneGhost, e->admitRec, csNext);
+                       e->net.laneGhost, e->admitRec);
     e->profEnd(pp__); }
     { int pp__ = e->profBegin(PK_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),
-                       dim3(kBlock), 0, st, c, e->ab, csNow, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
+                       dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
                        e->remain, e->cfg.rl_traffic_light, e->nMaskWords, scanTicket, e->vt, e->sc, e->finList,
                        e->finSorted, (int) e->slotCap, e->jobCount);
     e->profEnd(pp__); }
@@ -1156,7 +1139,7 @@ int32_t cfx_halo_export(cfx_engine *e, void *sendHost) {
     HaloIO io{};
     io.send[0] = e->dHaloSend;
     if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
-                              e->csSet[(e->step - 1) & 1].inCnt, io, e->sc);
+                              e->cs.inCnt, io, e->sc);
     HIP_TRY(hipGetLastError());
     if (e->haloSendBytes) HIP_TRY(hipMemcpyAsync(e->hHaloSend, e->dHaloSend, (size_t) e->haloSendBytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1271,7 +1254,7 @@ int32_t cfx_halo_post(cfx_engine *e) {
     if (n) {
         int pp__ = e->profBegin(PK_HALO_EXPORT);
         hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
-                           e->csSet[(e->step - 1) & 1].inCnt, io, e->sc);
+                           e->cs.inCnt, io, e->sc);
         e->profEnd(pp__);
     }
     HIP_TRY(hipGetLastError());

@@ -101,28 +101,33 @@ __global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidT
     }
 }
 
-// Engine::handleWaiting for one lane (engine.cpp:502-516).  Every caller that will look at the lane this step calls
-// it first: the lane's owner with `real` (it writes the admitted vehicle into the lane's spare slot and flags the
-// admission for k_scan), anybody else as a mirror; both leave the same laneTail / laneTailInfo.
-__device__ inline void admitLane(const StepCtx &c, int lane, bool real, int32_t *admitStep, const VidTable &vt) {
-    const int n = c.cnt[lane];
-    const int base = c.segStart[lane];
-    int wt;
-    if (!admitsNow(c, lane, &wt)) {
-        const int tail = n > 0 ? base + n - 1 : -1;
-        c.laneTail[lane] = tail;
-        if (tail >= 0) {
-            const int tt = c.s.templ[tail];
-            c.laneTailInfo[lane] = LaneTailInfo{c.s.dis[tail], c.t.templ[tt].len, c.s.speed[tail], tt, 0};
-        }
+// Engine::handleWaiting engine.cpp:502-516 + Lane::available roadnet.cpp:428-435
+__global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, CompactScratch cs) {
+    int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= c.n.L + c.n.K) return;
+    cs.leaveCnt[lane] = 0;  // compaction scratch of every drivable (lanes and laneLinks) for this step
+    cs.maxLeaveIdx[lane] = -1;
+    cs.inCnt[lane] = 0;
+    cs.inHead[lane] = -1;
+    if (lane >= c.n.L) {
+        // laneLink thread: the gate record k_action needs about "the next laneLink" in one load
+        const int k = lane - c.n.L;
+        int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+        c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);
         return;
     }
-    const int slot = base + n;  // the lane's spare slot
-    c.laneTail[lane] = slot;
-    c.laneTailInfo[lane] = LaneTailInfo{0.0, c.t.templ[wt].len, c.t.templ[wt].initial_speed, wt, 0};
-    if (!real) return;
-    const int w = c.waitHead[lane];
-    const int route = vt.route[w];
+    int w = waitHead[lane];
+    int n = c.cnt[lane];
+    int base = c.segStart[lane];
+    c.laneTail[lane] = n > 0 ? base + n - 1 : -1;  // overwritten below if a vehicle is admitted
+    if (w < 0) return;
+    int wt = vt.templ[w];
+    if (n > 0) {
+        int tail = base + n - 1;
+        if (!(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) return;
+    }
+    int slot = base + n;  // the lane's spare slot
+    int route = vt.route[w];
     c.s.vid[slot] = w;
     c.s.drv[slot] = lane;
     c.s.prevDrv[slot] = -1;
@@ -135,21 +140,9 @@ __device__ inline void admitLane(const StepCtx &c, int lane, bool real, int32_t 
     c.s.flags[slot] = vt.pendingCustom[w];
     c.s.dis[slot] = 0.0;
     c.s.speed[slot] = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
+    c.laneTail[lane] = slot;
     c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
     admitStep[lane] = c.step;  // cnt[], the FIFO pop and the running count follow in k_scan (see cntNow)
-}
-
-// The gate record the action phase needs about "the next laneLink" in one load
-__device__ __forceinline__ void writeGate(const StepCtx &c, int k) {
-    int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
-    c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);
-}
-
-__global__ void k_admit(StepCtx c, int32_t *admitStep, VidTable vt) {
-    int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= c.n.L + c.n.K) return;
-    if (lane >= c.n.L) writeGate(c, lane - c.n.L);
-    else admitLane(c, lane, true, admitStep, vt);
 }
 
 // Per-laneLink sources of Engine::threadNotifyCross (engine.cpp:317-372): the vehicle that just left
@@ -160,8 +153,6 @@ __device__ inline void llstate(const StepCtx &c, int k) {
     const int d = c.n.L + k;
     const int endLane = c.n.llEndLane[k], startLane = c.n.llStartLane[k];
     int u = lastSlot(c, endLane);
-    if (u >= c.segStart[endLane] + c.cnt[endLane]) u = -1;  // admitted this step: did not come from a laneLink (and its
-                                                            // slot may still be being written by the lane's owner)
     if (u >= 0 && c.s.prevDrv[u] != d) u = -1;
     int f = cntNow(c, startLane) > 0 ? c.segStart[startLane] : -1;
     if (f >= 0 && !(c.s.next[f] == d && llAvailable(c, k))) f = -1;
@@ -278,12 +269,9 @@ __device__ inline bool canPassActive(const StepCtx &c, const cfx_vehicle_templat
     return yield == -1;
 }
 
-// leader/gap (Vehicle::updateLeaderAndGap vehicle.cpp:157-196) for the vehicle in slot s of drivable d.
-// *freshTempl >= 0: the leader is the vehicle admitted this very step on another lane (template index; dis 0, initial
-// speed) whose slot must not be read yet.
+// leader/gap (Vehicle::updateLeaderAndGap vehicle.cpp:157-196) for the vehicle in slot s of drivable d
 __device__ inline int findLeader(const StepCtx &c, const cfx_vehicle_template *tv, int s, int d, bool head, double myDis,
-                                 double bound, double *gapOut, int *freshTempl) {
-    *freshTempl = -1;
+                                 double bound, double *gapOut) {
     if (!head) {
         int ls = s - 1;
         *gapOut = c.s.dis[ls] - tv[c.s.templ[ls]].len - myDis;
@@ -312,9 +300,9 @@ __device__ inline int findLeader(const StepCtx &c, const cfx_vehicle_template *t
             }
             if (ls >= 0) break;
         } else {
-            ls = lastSlotForLeader(c, nd, viewerNew, d, freshTempl);
+            ls = lastSlotForLeader(c, nd, viewerNew, d);
             if (ls >= 0) {
-                gap = *freshTempl >= 0 ? dist + 0.0 - tv[*freshTempl].len : dist + c.s.dis[ls] - tv[c.s.templ[ls]].len;
+                gap = dist + c.s.dis[ls] - tv[c.s.templ[ls]].len;
                 break;
             }
         }
@@ -398,149 +386,6 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
 // vehicle.cpp:308-335: leader/gap, car following, and the first half of getIntersectionRelatedSpeed (red
 // light / blocked exit lane / turn speed).  Vehicles that still have to look at the crosses of their laneLink
 // are queued for k_cross (their speed so far parked in the action buffer); everybody else is finished here.
-struct SlotIn {  // everything the action phase loads by slot index alone
-    int vid, d, dPrev, templIdx, templPrev, nd0, flags;
-    double speed, dis, speedPrev, disPrev;
-};
-
-// Every load that depends only on the slot index is issued up front, before the first branch, so the memory
-// system sees them as ONE round (the kernels are bound by dependent-load rounds, not bytes).
-__device__ __forceinline__ SlotIn loadSlot(const StepCtx &c, int s) {
-    SlotIn in;
-    const int sp = s > 0 ? s - 1 : 0;
-    in.vid = c.s.vid[s];
-    in.d = c.s.drv[s];
-    in.dPrev = c.s.drv[sp];
-    in.templIdx = c.s.templ[s];
-    in.templPrev = c.s.templ[sp];
-    in.speed = c.s.speed[s];
-    in.dis = c.s.dis[s];
-    in.speedPrev = c.s.speed[sp];
-    in.disPrev = c.s.dis[sp];
-    in.nd0 = c.s.next[s];
-    in.flags = c.s.flags[s];
-    return in;
-}
-
-// One vehicle's phase 4 up to the walk over the crosses; `push(s)` hands a vehicle that still has to look at the
-// crosses of its laneLink to the cross phase (its two partial speeds are parked in the action buffer).
-template <class Push>
-__device__ __forceinline__ void actionOne(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template *tv, const int s,
-                                          const SlotIn &in, Push push) {
-    const int sp = s > 0 ? s - 1 : 0;
-    const int vid = in.vid, d = in.d, dPrev = in.dPrev, templIdx = in.templIdx, templPrev = in.templPrev;
-    const double speed = in.speed, dis = in.dis, speedPrev = in.speedPrev, disPrev = in.disPrev;
-    const int nd0 = in.nd0, flags = in.flags;
-    if (vid < 0) return;
-    if (c.n.laneGhost && d < c.n.L && c.n.laneGhost[d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
-        o.b.dis[s] = dis;
-        o.b.speed[s] = speed;
-        o.b.drv[s] = -1;
-        o.b.blocker[s] = -1;
-        return;
-    }
-    const bool head = s == 0 || dPrev != d;
-    const cfx_vehicle_template &t = tv[templIdx];
-    const double interval = c.interval;
-    const double2 lm = c.n.drvLM[d];
-    const double dlen = lm.x;
-
-    // --- leader / gap
-    double gap;
-    int ls, fresh = -1;  // fresh >= 0: the leader was admitted this very step elsewhere; use its template, not its slot
-    if (!head) {  // Vehicle::updateLeaderAndGap vehicle.cpp:158-160
-        ls = sp;
-        gap = disPrev - tv[templPrev].len - dis;
-    } else {
-        ls = findLeader(c, tv, s, d, true, dis, t.approach_dist, &gap, &fresh);
-    }
-
-    // --- Vehicle::getNextSpeed vehicle.cpp:308-335
-    double v = t.max_speed;
-    v = min2(v, speed + t.max_pos_acc * interval);
-    v = min2(v, lm.y);
-
-    // car following, Vehicle::getCarFollowSpeed vehicle.cpp:212-238
-    double cf;
-    const bool custom = (flags & 1) != 0;  // Vehicle::hasSetCustomSpeed
-    if (ls < 0) {
-        cf = custom ? c.vCustomSpeed[vid] : t.max_speed;
-    } else if (custom) {
-        const cfx_vehicle_template &tl = tv[head ? (fresh >= 0 ? fresh : c.s.templ[ls]) : templPrev];
-        const double leaderSpeed = head ? (fresh >= 0 ? tl.initial_speed : c.s.speed[ls]) : speedPrev;
-        cf = min2(c.vCustomSpeed[vid], noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0));
-    } else {
-        const cfx_vehicle_template &tl = tv[head ? (fresh >= 0 ? fresh : c.s.templ[ls]) : templPrev];
-        const double leaderSpeed = head ? (fresh >= 0 ? tl.initial_speed : c.s.speed[ls]) : speedPrev;
-        cf = noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0);
-        double assumeDecel = 0;
-        if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
-        cf = min2(cf, noCollisionSpeed(leaderSpeed, tl.usual_neg_acc, speed, t.usual_neg_acc, gap, interval, t.min_gap));
-        cf = min2(cf, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) /
-                          (t.headway_time + interval / 2));
-    }
-    v = min2(v, cf);
-
-    // intersection logic, Vehicle::isIntersectionRelated vehicle.cpp:289-300
-    const bool onLane = d < c.n.L;
-    const bool related = !onLane || (nd0 >= c.n.L && dlen - dis <= t.approach_dist);
-    if (related) {
-        // Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-362
-        VehRef self{speed, &t};
-        double iv = t.max_speed;
-        int laneLink = -1;
-        bool done = false;
-        int gateFlags;
-        if (nd0 >= c.n.L) {
-            laneLink = nd0 - c.n.L;
-            const int2 gate = c.llGate[laneLink];  // {available | type | has crosses, end lane}, from k_admit
-            gateFlags = gate.x;
-            bool blocked = !(gate.x & 1);
-            if (!blocked) {  // Lane::canEnter roadnet.cpp:437-445
-                if (c.laneTail[gate.y] >= 0) {
-                    const LaneTailInfo ti = c.laneTailInfo[gate.y];  // by value: the tail may have been admitted just now
-                    blocked = !(ti.dis > ti.len + t.len || ti.speed >= 2);
-                }
-            }
-            if (blocked) {
-                if (minBrakeDistance(self) > dlen - dis) {
-                    // cannot stop before the line: run it
-                } else {
-                    iv = min2(iv, stopBeforeSpeed(self, dlen - dis, interval));
-                    done = true;
-                }
-            }
-        }
-        if (!done) {
-            if (laneLink < 0) {  // already on a laneLink
-                laneLink = d - c.n.L;
-                gateFlags = c.llGate[laneLink].x;
-            }
-            if (nd0 >= c.n.L && typeIsTurn((gateFlags >> 1) & 3)) iv = min2(iv, t.turn_speed);
-            if (gateFlags & 8) {
-                // park the two partial speeds and hand the cross checks to k_cross
-                o.b.speed[s] = v;
-                o.b.dis[s] = iv;
-                push(s);  // the cross checks are done by 16-lane groups
-                return;
-            }
-        }
-        v = min2(v, iv);
-    }
-    finishAction(c, o, t, s, d, vid, speed, dis, dlen, nd0, v, -1);
-}
-
-// Stages the vehicle templates in LDS when they fit (the usual case: one per flow family); returns the table to use.
-__device__ __forceinline__ const cfx_vehicle_template *stageTemplates(const StepCtx &c, cfx_vehicle_template *sT) {
-    if (c.t.nTempl > kLdsTempl) return c.t.templ;
-    const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
-    const double *src = (const double *) c.t.templ;
-    double *dst = (double *) sT;
-    for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-    return sT;
-}
-
 __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
     // The trailing blocks of the launch do the (independent) per-laneLink notify sources for k_cross.
     if ((int) blockIdx.x >= nVehicleBlocks) {
@@ -548,17 +393,132 @@ __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, Jo
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
-    const cfx_vehicle_template *tv = stageTemplates(c, sT);
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        tv = sT;
+    }
     const int S = c.segStart[c.n.L + c.n.K];
     const int stride = nVehicleBlocks * blockDim.x;
-    // queue for k_cross.  The counter is sharded: one word takes only ~88 returning atomics per us (MI355X guide,
-    // "dequeue"), and a step issues one per wave.
-    auto push = [&q](int s) {
-        const int shard = blockIdx.x & (kJobShards - 1);
-        const int idx = atomicAdd(&q.count[shard * kJobShardStride], 1);
-        q.jobs[(size_t) shard * q.capacity + idx] = s;
-    };
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) actionOne(c, o, tv, s, loadSlot(c, s), push);
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
+        // Every load that depends only on the slot index is issued up front, before the first branch, so the
+        // memory system sees them as ONE round (the kernel is bound by dependent-load rounds, not bytes).
+        const int sp = s > 0 ? s - 1 : 0;
+        const int vid = c.s.vid[s];
+        const int d = c.s.drv[s];
+        const int dPrev = c.s.drv[sp];
+        const int templIdx = c.s.templ[s];
+        const int templPrev = c.s.templ[sp];
+        const double speed = c.s.speed[s];
+        const double dis = c.s.dis[s];
+        const double speedPrev = c.s.speed[sp];
+        const double disPrev = c.s.dis[sp];
+        const int nd0 = c.s.next[s];
+        const int flags = c.s.flags[s];
+        if (vid < 0) continue;
+        if (c.n.laneGhost && d < c.n.L && c.n.laneGhost[d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
+            o.b.dis[s] = dis;
+            o.b.speed[s] = speed;
+            o.b.drv[s] = -1;
+            o.b.blocker[s] = -1;
+            continue;
+        }
+        const bool head = s == 0 || dPrev != d;
+        const cfx_vehicle_template &t = tv[templIdx];
+        const double interval = c.interval;
+        const double2 lm = c.n.drvLM[d];
+        const double dlen = lm.x;
+
+        // --- leader / gap
+        double gap;
+        int ls;
+        if (!head) {  // Vehicle::updateLeaderAndGap vehicle.cpp:158-160
+            ls = sp;
+            gap = disPrev - tv[templPrev].len - dis;
+        } else {
+            ls = findLeader(c, tv, s, d, true, dis, t.approach_dist, &gap);
+        }
+
+        // --- Vehicle::getNextSpeed vehicle.cpp:308-335
+        double v = t.max_speed;
+        v = min2(v, speed + t.max_pos_acc * interval);
+        v = min2(v, lm.y);
+
+        // car following, Vehicle::getCarFollowSpeed vehicle.cpp:212-238
+        double cf;
+        const bool custom = (flags & 1) != 0;  // Vehicle::hasSetCustomSpeed
+        if (ls < 0) {
+            cf = custom ? c.vCustomSpeed[vid] : t.max_speed;
+        } else if (custom) {
+            const cfx_vehicle_template &tl = tv[head ? c.s.templ[ls] : templPrev];
+            cf = min2(c.vCustomSpeed[vid],
+                      noCollisionSpeed(head ? c.s.speed[ls] : speedPrev, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0));
+        } else {
+            const cfx_vehicle_template &tl = tv[head ? c.s.templ[ls] : templPrev];
+            const double leaderSpeed = head ? c.s.speed[ls] : speedPrev;
+            cf = noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0);
+            double assumeDecel = 0;
+            if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
+            cf = min2(cf, noCollisionSpeed(leaderSpeed, tl.usual_neg_acc, speed, t.usual_neg_acc, gap, interval, t.min_gap));
+            cf = min2(cf, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) /
+                              (t.headway_time + interval / 2));
+        }
+        v = min2(v, cf);
+
+        // intersection logic, Vehicle::isIntersectionRelated vehicle.cpp:289-300
+        const bool onLane = d < c.n.L;
+        const bool related = !onLane || (nd0 >= c.n.L && dlen - dis <= t.approach_dist);
+        if (related) {
+            // Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-362
+            VehRef self{speed, &t};
+            double iv = t.max_speed;
+            int laneLink = -1;
+            bool done = false;
+            int gateFlags;
+            if (nd0 >= c.n.L) {
+                laneLink = nd0 - c.n.L;
+                const int2 gate = c.llGate[laneLink];  // {available | type | has crosses, end lane}, from k_admit
+                gateFlags = gate.x;
+                bool blocked = !(gate.x & 1);
+                if (!blocked) {  // Lane::canEnter roadnet.cpp:437-445
+                    int tail = c.laneTail[gate.y];
+                    if (tail >= 0) blocked = !(c.s.dis[tail] > tv[c.s.templ[tail]].len + t.len || c.s.speed[tail] >= 2);
+                }
+                if (blocked) {
+                    if (minBrakeDistance(self) > dlen - dis) {
+                        // cannot stop before the line: run it
+                    } else {
+                        iv = min2(iv, stopBeforeSpeed(self, dlen - dis, interval));
+                        done = true;
+                    }
+                }
+            }
+            if (!done) {
+                if (laneLink < 0) {  // already on a laneLink
+                    laneLink = d - c.n.L;
+                    gateFlags = c.llGate[laneLink].x;
+                }
+                if (nd0 >= c.n.L && typeIsTurn((gateFlags >> 1) & 3)) iv = min2(iv, t.turn_speed);
+                if (gateFlags & 8) {
+                    // park the two partial speeds and hand the cross checks to k_cross
+                    o.b.speed[s] = v;
+                    o.b.dis[s] = iv;
+                    // queue for k_cross.  The counter is sharded: one word takes only ~88 returning atomics per us
+                    // (MI355X guide, "dequeue"), and a step issues one per wave.
+                    const int shard = blockIdx.x & (kJobShards - 1);
+                    const int idx = atomicAdd(&q.count[shard * kJobShardStride], 1);
+                    q.jobs[(size_t) shard * q.capacity + idx] = s;
+                    continue;
+                }
+            }
+            v = min2(v, iv);
+        }
+        finishAction(c, o, t, s, d, vid, speed, dis, dlen, nd0, v, -1);
+    }
 }
 
 // Second half of Vehicle::getIntersectionRelatedSpeed (vehicle.cpp:357-375): the walk over the crosses of the
@@ -567,66 +527,17 @@ __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, Jo
 // first failing round.
 constexpr int kCrossGroup = 16;
 
-// The cross walk of the vehicle in slot s by one kCrossGroup-lane group (lane g of the group, whose first wave lane is
-// groupShift); lane 0 finishes the vehicle.
-__device__ __forceinline__ void crossOne(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template *tv, const int s,
-                                         const int g, const int groupShift) {
-    const int d = c.s.drv[s];
-    const cfx_vehicle_template &t = tv[c.s.templ[s]];
-    const double speed = c.s.speed[s];
-    const double dis = c.s.dis[s];
-    const double dlen = c.n.drvLength[d];
-    const int nd0 = c.s.next[s];
-    const bool onLane = d < c.n.L;
-    const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
-    const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}: one load
-    const int t1 = lp.w;
-    const double d0 = onLane ? -(dlen - dis) : dis;
-    const int mb = lp.z;
-    VehRef self{speed, &t};
-    const int xs = lp.x, xe = lp.y;
-    double iv = o.b.dis[s];  // partial intersection speed parked by k_action
-    int blockerSlot = -1;
-    for (int e0 = xs; e0 < xe; e0 += kCrossGroup) {
-        const int e = e0 + g;
-        bool fail = false;
-        int foe = -1;
-        double dOn = 0.0;
-        if (e < xe) {
-            const double2 dd = c.n.xDD[e];   // {distance on this laneLink, distance on the peer laneLink}
-            const int4 xp = c.n.xPack[e];    // {peer laneLink, peer bit, peer roadLink type, -}
-            dOn = dd.x;
-            if (!(dOn < d0)) {
-                if ((c.interMask[mb + (xp.y >> 6)] >> (xp.y & 63)) & 1ULL)
-                    fail = !canPassActive(c, tv, s, self, dOn, t1, d0, xp.x, dd.y, xp.z, &foe);
-            }
-        }
-        const unsigned long long ball = __ballot(fail);
-        const unsigned gm = (unsigned) ((ball >> groupShift) & ((1ULL << kCrossGroup) - 1ULL));
-        if (gm != 0u) {
-            const int first = __ffs(gm) - 1;  // lowest lane = smallest cross distance in this round
-            const int src = groupShift + first;
-            const double fdOn = __shfl(dOn, src, 64);
-            blockerSlot = __shfl(foe, src, 64);
-            iv = min2(iv, stopBeforeSpeed(self, fdOn - d0 - t.yield_distance, c.interval));
-            break;
-        }
-    }
-    if (g == 0) {
-        double v = min2(o.b.speed[s], iv);
-        if (blockerSlot >= 0 && c.n.laneGhost) {
-            // tiling: a blocker that sits on a ghost lane is a proxy whose slot is recycled by the halo exchange;
-            // keep it by vehicle id (-(vid + 2)).  Chain walks end there either way: proxies carry no blocker.
-            const int bd = c.s.drv[blockerSlot];
-            if (bd < c.n.L && c.n.laneGhost[bd]) blockerSlot = -(c.s.vid[blockerSlot] + 2);
-        }
-        finishAction(c, o, t, s, d, c.s.vid[s], speed, dis, dlen, nd0, v, blockerSlot);
-    }
-}
-
 __global__ __launch_bounds__(kCrossBlock) void k_cross(StepCtx c, ActionOut o, JobQueue q) {
     __shared__ cfx_vehicle_template sT[kLdsTempl];
-    const cfx_vehicle_template *tv = stageTemplates(c, sT);
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        tv = sT;
+    }
     // job j of the concatenated shards -> (shard, index)
     __shared__ int shardEnd[kJobShards];
     if (threadIdx.x == 0) {
@@ -644,7 +555,58 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(StepCtx c, ActionOut o, J
     for (int j = blockIdx.x * groupsPerBlock + threadIdx.x / kCrossGroup; j < nJ; j += gridDim.x * groupsPerBlock) {
         int shard = 0;
         while (j >= shardEnd[shard]) ++shard;
-        crossOne(c, o, tv, q.jobs[(size_t) shard * q.capacity + (j - (shard ? shardEnd[shard - 1] : 0))], g, groupShift);
+        const int s = q.jobs[(size_t) shard * q.capacity + (j - (shard ? shardEnd[shard - 1] : 0))];
+        const int d = c.s.drv[s];
+        const cfx_vehicle_template &t = tv[c.s.templ[s]];
+        const double speed = c.s.speed[s];
+        const double dis = c.s.dis[s];
+        const double dlen = c.n.drvLength[d];
+        const int nd0 = c.s.next[s];
+        const bool onLane = d < c.n.L;
+        const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
+        const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}: one load
+        const int t1 = lp.w;
+        const double d0 = onLane ? -(dlen - dis) : dis;
+        const int mb = lp.z;
+        VehRef self{speed, &t};
+        const int xs = lp.x, xe = lp.y;
+        double iv = o.b.dis[s];  // partial intersection speed parked by k_action
+        int blockerSlot = -1;
+        for (int e0 = xs; e0 < xe; e0 += kCrossGroup) {
+            const int e = e0 + g;
+            bool fail = false;
+            int foe = -1;
+            double dOn = 0.0;
+            if (e < xe) {
+                const double2 dd = c.n.xDD[e];   // {distance on this laneLink, distance on the peer laneLink}
+                const int4 xp = c.n.xPack[e];    // {peer laneLink, peer bit, peer roadLink type, -}
+                dOn = dd.x;
+                if (!(dOn < d0)) {
+                    if ((c.interMask[mb + (xp.y >> 6)] >> (xp.y & 63)) & 1ULL)
+                        fail = !canPassActive(c, tv, s, self, dOn, t1, d0, xp.x, dd.y, xp.z, &foe);
+                }
+            }
+            const unsigned long long ball = __ballot(fail);
+            const unsigned gm = (unsigned) ((ball >> groupShift) & ((1ULL << kCrossGroup) - 1ULL));
+            if (gm != 0u) {
+                const int first = __ffs(gm) - 1;  // lowest lane = smallest cross distance in this round
+                const int src = groupShift + first;
+                const double fdOn = __shfl(dOn, src, 64);
+                blockerSlot = __shfl(foe, src, 64);
+                iv = min2(iv, stopBeforeSpeed(self, fdOn - d0 - t.yield_distance, c.interval));
+                break;
+            }
+        }
+        if (g == 0) {
+            double v = min2(o.b.speed[s], iv);
+            if (blockerSlot >= 0 && c.n.laneGhost) {
+                // tiling: a blocker that sits on a ghost lane is a proxy whose slot is recycled by the halo exchange;
+                // keep it by vehicle id (-(vid + 2)).  Chain walks end there either way: proxies carry no blocker.
+                const int bd = c.s.drv[blockerSlot];
+                if (bd < c.n.L && c.n.laneGhost[bd]) blockerSlot = -(c.s.vid[blockerSlot] + 2);
+            }
+            finishAction(c, o, t, s, d, c.s.vid[s], speed, dis, dlen, nd0, v, blockerSlot);
+        }
     }
 }
 
@@ -734,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
                                                  int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
                                                  int32_t *drvNext, DevScalars *sc, const uint8_t *laneSpare,
                                                  const int32_t *admitStep, int step, int32_t *waitHead, VidTable vt,
-                                                 const uint8_t *laneGhost, const int2 *admitRec, CompactScratch csNext) {
+                                                 const uint8_t *laneGhost, const int2 *admitRec) {
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
     __shared__ int tileShared;
@@ -769,16 +731,6 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
         rec[4] = make_int2(r2.x, r2.y); rec[5] = make_int2(r2.z, r2.w); rec[6] = make_int2(r3.x, r3.y); rec[7] = make_int2(r3.z, r3.w);
     }
     static_assert(kScanItems == 8, "k_scan loads its 8 items as two int4");
-    {
-        // The per-drivable compaction scratch is double-buffered by step parity: while this step's set is being consumed
-        // (here and in k_scatter), the other one — last used a step ago — is cleared for the next step, whose kernels
-        // start adding to it before any single thread could clear it.
-        const int4 zero = make_int4(0, 0, 0, 0), minus = make_int4(-1, -1, -1, -1);
-        int4 *z0 = (int4 *) (csNext.leaveCnt + base), *z1 = (int4 *) (csNext.inCnt + base);
-        int4 *m0 = (int4 *) (csNext.maxLeaveIdx + base), *m1 = (int4 *) (csNext.inHead + base);
-        z0[0] = zero; z0[1] = zero; z1[0] = zero; z1[1] = zero;
-        m0[0] = minus; m0[1] = minus; m1[0] = minus; m1[1] = minus;
-    }
     for (int i = 0; i < kScanItems; ++i) {
         int d = base + i;
         const int admitted = (d < L && admv[i] == step) ? 1 : 0;
@@ -1254,8 +1206,7 @@ __global__ void k_leader_view(StepCtx c, int32_t *leaderSlot, double *gapOut) {
         int d = c.s.drv[s];
         double gap = 0;
         bool head = s == 0 || c.s.drv[s - 1] != d;
-        int fresh;
-        leaderSlot[s] = findLeader(c, c.t.templ, s, d, head, c.s.dis[s], c.t.templ[c.s.templ[s]].approach_dist, &gap, &fresh);
+        leaderSlot[s] = findLeader(c, c.t.templ, s, d, head, c.s.dis[s], c.t.templ[c.s.templ[s]].approach_dist, &gap);
         gapOut[s] = gap;
     }
 }
