@@ -1,8 +1,8 @@
 """Developer tool: step the HIP engine and the CPU twin side by side and report the first divergence.
-usage: python tools/dev_parity.py <scenario> <steps> [check_every]
+usage: python tests/tools/dev_parity.py <scenario> <steps> [check_every]
 (oracle/ is used here only as the checker.)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cityflow_amd import _cityflow as m, scenarios

@@ -1,7 +1,7 @@
 """RL-loop throughput on the bench workload with rlTrafficLight: per step set every signal, step, read per-lane counts.
 Compares the array API with the reference-style dict API on this engine (and, with --ref, times the reference engine)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 want_ref = "--ref" in sys.argv
 sys.argv = [sys.argv[0]]

@@ -1,10 +1,10 @@
 """Developer soak run: the bench.py workload (30x30, ~100k vehicles) on the HIP engine vs the CPU twin over a long horizon,
-every per-vehicle field every `every` steps.   python tools/soak_parity.py STEPS [EVERY]"""
+every per-vehicle field every `every` steps.   python tests/tools/soak_parity.py STEPS [EVERY]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 steps = int(sys.argv[1])

@@ -1,10 +1,10 @@
 """Developer stress run on the GPU box: many seeded irregular networks (tests/test_irregular.py generator) HIP vs CPU twin,
-every per-vehicle field.   python tools/stress_parity.py FIRST_SEED N_SEEDS [STEPS]"""
+every per-vehicle field.   python tests/tools/stress_parity.py FIRST_SEED N_SEEDS [STEPS]"""
 import os
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from cityflow_amd import _cityflow as m, scenarios  # noqa: E402

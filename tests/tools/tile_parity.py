@@ -1,12 +1,12 @@
 """Developer check: a network tiled rows x cols (all tiles in this process) must evolve bit-identically to the same
-network on one engine.   python tools/tile_parity.py grid_6x6 2 2 400 [backend.so]   (default backend: the CPU twin)"""
+network on one engine.   python tests/tools/tile_parity.py grid_6x6 2 2 400 [backend.so]   (default backend: the CPU twin)"""
 import os
 import sys
 import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from cityflow_amd import _cityflow as m  # noqa: E402
 from cityflow_amd import scenarios  # noqa: E402
