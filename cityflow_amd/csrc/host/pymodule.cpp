@@ -75,18 +75,43 @@ py::dict flatNetToDict(const cfa::HostRoadNet &net) {
 }
 
 // Reference getLaneVehicleCount returns std::map<std::string,int> (engine.cpp:628-648) which pybind11 turns into a dict
-// by creating one Python string per lane per call; here the key objects are created once per engine.
-py::dict laneDict(EngineHost &e, const std::vector<int32_t> &values) {
+// by creating one Python string per lane and inserting every entry per call.  Here the key objects are created once per
+// engine, a master dict per getter is kept up to date by rewriting only the entries whose value changed since the
+// previous call (a step changes a small fraction of the lanes), and the caller gets a C-level copy of it: a fresh dict
+// in std::map (lexicographic) key order every call, like the reference's.
+struct LaneDictCache {
+    py::list keys;
+    py::dict master[2];
+    std::vector<int32_t> last[2];
+    bool filled[2] = {false, false};
+};
+
+py::dict laneDict(EngineHost &e, const std::vector<int32_t> &values, int which) {
     const std::vector<int32_t> &order = e.laneIdOrder();
     if (!e.bindingCache) {
-        auto *keys = new py::list();
-        for (int32_t l : order) keys->append(py::str(e.net().laneId(l)));
-        e.bindingCache = std::shared_ptr<void>(keys, [](void *p) { delete static_cast<py::list *>(p); });
+        auto *c = new LaneDictCache();
+        for (int32_t l : order) c->keys.append(py::str(e.net().laneId(l)));
+        e.bindingCache = std::shared_ptr<void>(c, [](void *p) { delete static_cast<LaneDictCache *>(p); });
     }
-    py::dict d;
-    const py::list &keys = *static_cast<py::list *>(e.bindingCache.get());
-    for (size_t i = 0; i < order.size(); ++i) d[keys[i]] = py::int_(values[order[i]]);
-    return d;
+    LaneDictCache &c = *static_cast<LaneDictCache *>(e.bindingCache.get());
+    std::vector<int32_t> &last = c.last[which];
+    if (!c.filled[which]) last.assign(order.size(), INT32_MIN);
+    PyObject *master = c.master[which].ptr();
+    for (size_t i = 0; i < order.size(); ++i) {
+        const int32_t v = values[order[i]];
+        if (v == last[i]) continue;
+        last[i] = v;
+        PyObject *num = PyLong_FromLong(v);
+        if (!num || PyDict_SetItem(master, PyList_GET_ITEM(c.keys.ptr(), (Py_ssize_t) i), num) != 0) {
+            Py_XDECREF(num);
+            throw py::error_already_set();
+        }
+        Py_DECREF(num);
+    }
+    c.filled[which] = true;
+    PyObject *copy = PyDict_Copy(master);
+    if (!copy) throw py::error_already_set();
+    return py::reinterpret_steal<py::dict>(copy);
 }
 
 // Host-only helpers (no device engine involved): used by the CPU test-suite to pin the loader and the
@@ -180,8 +205,8 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("get_vehicle_count", &EngineHost::getVehicleCount)
         .def("get_vehicles", &EngineHost::getVehicles, "include_waiting"_a = false)
         // dict[str, int] in std::map (lexicographic) key order like the reference, built from cached key objects
-        .def("get_lane_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneVehicleCountArray()); })
-        .def("get_lane_waiting_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneWaitingVehicleCountArray()); })
+        .def("get_lane_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneVehicleCountArray(), 0); })
+        .def("get_lane_waiting_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneWaitingVehicleCountArray(), 1); })
         .def("get_lane_vehicles", &EngineHost::getLaneVehicles)
         .def("get_vehicle_speed", &EngineHost::getVehicleSpeed)
         .def("get_vehicle_info", &EngineHost::getVehicleInfo, "vehicle_id"_a)

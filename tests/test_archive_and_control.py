@@ -131,3 +131,25 @@ def test_unknown_vehicle_errors(mod, scen, workdir):
         e.get_leader("nope")
     assert e.set_vehicle_route("flow_99_0", ["road_1_1_1"]) is False
     assert e.set_vehicle_route("flow_0_0", ["no_such_road"]) is False
+
+
+def test_lane_count_dicts_are_fresh_sorted_and_consistent(mod, scen, workdir):
+    """get_lane_vehicle_count / get_lane_waiting_vehicle_count: a new dict per call in std::map key order, equal to the
+    array getters, unaffected by what the caller does to earlier results (the binding keeps a master copy up to date
+    incrementally)."""
+    eng = mod.Engine._with_backend(scen.materialize("grid_6x6", workdir), 1, TWIN_LIB)
+    prev = None
+    for s in range(120):
+        eng.next_step()
+        d, w = eng.get_lane_vehicle_count(), eng.get_lane_waiting_vehicle_count()
+        assert d == dict(zip(eng.lane_ids(), eng.get_lane_vehicle_count_array().tolist())), s
+        assert w == dict(zip(eng.lane_ids(), eng.get_lane_waiting_vehicle_count_array().tolist())), s
+        assert list(d) == sorted(d)
+        if prev is not None:
+            assert prev is not d
+            prev["not_a_lane"] = 1
+            prev[next(iter(prev))] = -5
+        prev = d
+    eng.reset(False)
+    d = eng.get_lane_vehicle_count()
+    assert sum(d.values()) == 0 and "not_a_lane" not in d
