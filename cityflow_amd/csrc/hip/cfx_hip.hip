@@ -776,27 +776,40 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
     int32_t S = 0;
     HIP_TRY(hipMemcpyAsync(&S, e->segStart[e->cur].p + e->D, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    StepCtx c = e->ctx();
-    hipLaunchKernelGGL(k_leader_view, dim3(gridStride(S)), dim3(kBlock), 0, e->stream, c, e->viewLeader, e->viewGap);
-    HIP_TRY(hipGetLastError());
+    // only what the caller asked for is computed and copied (the string getters want vid + one column)
+    const bool wantLeader = view->leader_vid || view->gap, wantBlocker = view->blocker_vid != nullptr;
+    if (wantLeader) {
+        StepCtx c = e->ctx();
+        hipLaunchKernelGGL(k_leader_view, dim3(gridStride(S)), dim3(kBlock), 0, e->stream, c, e->viewLeader, e->viewGap);
+        HIP_TRY(hipGetLastError());
+    }
     const SlotArrays &g = e->gen[e->cur];
-    std::vector<int32_t> vid(S), drv(S), prev(S), blk(S), ellt(S), rpos(S), lead(S), o2n(e->slotCap);
-    std::vector<double> dis(S), speed(S), gap(S);
+    std::vector<int32_t> vid(S), drv, prev, blk, ellt, rpos, lead, o2n;
+    std::vector<double> dis, speed, gap;
     auto dl = [&](void *dst, const void *src, size_t bytes) {
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream);
     };
     if (S) {
         HIP_TRY(dl(vid.data(), g.vid, S * 4));
-        HIP_TRY(dl(drv.data(), g.drv, S * 4));
-        HIP_TRY(dl(prev.data(), g.prevDrv, S * 4));
-        HIP_TRY(dl(blk.data(), g.blocker, S * 4));
-        HIP_TRY(dl(ellt.data(), g.enterLLT, S * 4));
-        HIP_TRY(dl(rpos.data(), g.routePos, S * 4));
-        HIP_TRY(dl(lead.data(), e->viewLeader, S * 4));
-        HIP_TRY(dl(dis.data(), g.dis, S * 8));
-        HIP_TRY(dl(speed.data(), g.speed, S * 8));
-        HIP_TRY(dl(gap.data(), e->viewGap, S * 8));
-        HIP_TRY(dl(o2n.data(), e->oldToNew, e->slotCap * 4));
+#define WANT(field, vec, src, bytes) \
+    if (field) {                      \
+        vec.resize(S);                \
+        HIP_TRY(dl(vec.data(), src, (size_t) S * bytes)); \
+    }
+        WANT(view->drivable, drv, g.drv, 4)
+        WANT(view->prev_drivable, prev, g.prevDrv, 4)
+        WANT(wantBlocker, blk, g.blocker, 4)
+        WANT(view->enter_ll_time, ellt, g.enterLLT, 4)
+        WANT(view->route_pos, rpos, g.routePos, 4)
+        WANT(view->leader_vid, lead, e->viewLeader, 4)
+        WANT(view->dis, dis, g.dis, 8)
+        WANT(view->speed, speed, g.speed, 8)
+        WANT(view->gap, gap, e->viewGap, 8)
+#undef WANT
+        if (wantBlocker) {
+            o2n.resize(e->slotCap);
+            HIP_TRY(dl(o2n.data(), e->oldToNew, e->slotCap * 4));
+        }
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     int n = 0;

@@ -288,6 +288,7 @@ void EngineHost::load(const Archive &a) {
     st.tl_remain = d.tlRemain.data();
     check(be_.cfx_load_state(dev_, &st), "cfx_load_state");
     step_ = (size_t) d.step;
+    vehicleEpoch_ += 1;  // vehicle numbers of the archive replace the current ones
 }
 
 // Archive(Engine&, filename) archive.cpp:345-550: rebuild an Archive from the reference's JSON format.

@@ -270,6 +270,7 @@ void EngineHost::reset(bool resetRnd) {
     check(be_.cfx_reset(dev_), "cfx_reset");
     spawner_.reset(resetRnd);
     step_ = 0;
+    vehicleEpoch_ += 1;
 }
 
 // ---------------------------------------------------------------- getters
@@ -313,37 +314,32 @@ std::map<std::string, int> EngineHost::getLaneWaitingVehicleCount() {
     return ret;
 }
 
-void EngineHost::snapshotVehicles(VehicleSnapshot &s) {
+void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
     int cap = (int) scalars().active_vehicle_count + 16;
-    s.vid.resize(cap);
-    s.drivable.resize(cap);
-    s.prevDrivable.resize(cap);
-    s.leader.resize(cap);
-    s.blocker.resize(cap);
-    s.enterLLTime.resize(cap);
-    s.routePos.resize(cap);
-    s.dis.resize(cap);
-    s.speed.resize(cap);
-    s.gap.resize(cap);
     cfx_vehicle_view v{};
     v.capacity = cap;
+    s.vid.resize(cap);
     v.vid = s.vid.data();
-    v.drivable = s.drivable.data();
-    v.prev_drivable = s.prevDrivable.data();
-    v.leader_vid = s.leader.data();
-    v.blocker_vid = s.blocker.data();
-    v.enter_ll_time = s.enterLLTime.data();
-    v.route_pos = s.routePos.data();
-    v.dis = s.dis.data();
-    v.speed = s.speed.data();
-    v.gap = s.gap.data();
+    auto want = [&](unsigned bit, auto &vec, auto *&ptr) {
+        vec.resize(fields & bit ? cap : 0);
+        ptr = fields & bit ? vec.data() : nullptr;
+    };
+    want(kSnapDrivable, s.drivable, v.drivable);
+    want(kSnapPrev, s.prevDrivable, v.prev_drivable);
+    want(kSnapLeader, s.leader, v.leader_vid);
+    want(kSnapBlocker, s.blocker, v.blocker_vid);
+    want(kSnapEnterLL, s.enterLLTime, v.enter_ll_time);
+    want(kSnapRoutePos, s.routePos, v.route_pos);
+    want(kSnapDis, s.dis, v.dis);
+    want(kSnapSpeed, s.speed, v.speed);
+    want(kSnapGap, s.gap, v.gap);
     check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
     s.count = v.count;
-    for (auto *vec : {&s.vid, &s.drivable, &s.prevDrivable, &s.leader, &s.blocker, &s.enterLLTime, &s.routePos})
-        vec->resize(v.count);
-    s.dis.resize(v.count);
-    s.speed.resize(v.count);
-    s.gap.resize(v.count);
+    s.vid.resize(v.count);
+    for (auto *vec : {&s.drivable, &s.prevDrivable, &s.leader, &s.blocker, &s.enterLLTime, &s.routePos})
+        if (!vec->empty()) vec->resize(v.count);
+    for (auto *vec : {&s.dis, &s.speed, &s.gap})
+        if (!vec->empty()) vec->resize(v.count);
 }
 
 void EngineHost::waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane) {

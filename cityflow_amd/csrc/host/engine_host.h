@@ -64,6 +64,11 @@ struct Backend {
 };
 
 // Per-vehicle state downloaded from the device, in Drivable::vehicles order.
+enum SnapshotField : unsigned {  // what snapshotVehicles should fetch besides the vehicle ids
+    kSnapDrivable = 1, kSnapPrev = 2, kSnapLeader = 4, kSnapBlocker = 8, kSnapEnterLL = 16, kSnapRoutePos = 32,
+    kSnapDis = 64, kSnapSpeed = 128, kSnapGap = 256, kSnapAll = 511
+};
+
 struct VehicleSnapshot {
     std::vector<int32_t> vid, drivable, prevDrivable, leader, blocker, enterLLTime, routePos;
     std::vector<double> dis, speed, gap;
@@ -111,7 +116,9 @@ public:
     void setTrafficLightPhaseIndexed(int inter, int phase);
     void setTrafficLightPhases(const std::vector<int32_t> &phases);  // [n_intersections]; virtual ones ignored
     void trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain);
-    void snapshotVehicles(VehicleSnapshot &out);
+    void snapshotVehicles(VehicleSnapshot &out, unsigned fields = kSnapAll);
+    // changes whenever vehicle numbers are reassigned (reset, load): per-vehicle caches of a language binding key on it
+    uint64_t vehicleEpoch() const { return vehicleEpoch_; }
     void waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane);
     cfx_scalars scalars();
     void sync();
@@ -148,6 +155,7 @@ private:
     std::vector<int32_t> pendingPhaseInter_, pendingPhaseValue_;  // set_tl_phase calls since the last flush
     void flushPhases();
     std::vector<int32_t> laneIdOrder_;
+    uint64_t vehicleEpoch_ = 0;
 };
 
 struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84

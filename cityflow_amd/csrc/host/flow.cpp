@@ -1,5 +1,7 @@
 #include "flow.h"
 
+#include <cstdio>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -314,6 +316,28 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
     }
     pending_.clear();
     pendingRecords_.clear();
+}
+
+// Lexicographic order of the decimal strings, folded into integers.  Inside the flow index a shorter number is followed by
+// '_' (which sorts after every digit): position i holds digit (0..9), 10 for "the string ended here", then 0s.  The
+// trailing counter is followed by the end of the string (which sorts before every character): digit + 1, then 0s.
+uint64_t Spawner::idSortKey(int vid) const {
+    auto fold = [](uint64_t x, int width, bool endIsGreater) {
+        char buf[24];
+        int len = snprintf(buf, sizeof buf, "%llu", (unsigned long long) x);
+        uint64_t k = 0;
+        for (int i = 0; i < width; ++i) {
+            int c;
+            if (i < len) c = (buf[i] - '0') + (endIsGreater ? 0 : 1);
+            else c = (endIsGreater && i == len) ? 10 : 0;
+            k = k * 11 + (uint64_t) c;
+        }
+        return k;
+    };
+    const VehicleRecord &r = vehicles[vid];
+    const uint64_t pow11_10 = 25937424601ULL;  // 11^10
+    if (r.flow < 0) return (1ULL << 63) | fold((uint64_t) r.number, 10, false);  // 'm' > 'f'
+    return fold((uint64_t) r.flow, 8, true) * pow11_10 + fold((uint64_t) r.number, 10, false);
 }
 
 int Spawner::vidOfId(const std::string &id) const {

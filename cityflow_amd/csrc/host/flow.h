@@ -102,6 +102,9 @@ public:
 
     std::string vehicleId(int vid) const;
     int vidOfId(const std::string &id) const;  // inverse of vehicleId (-1 if unknown)
+    // An integer that orders vehicles exactly like their id strings compare ("flow_<f>_<n>" / "manually_pushed_<n>", i.e.
+    // the key order of the reference's std::map<std::string, ...> getters) without building or comparing strings.
+    uint64_t idSortKey(int vid) const;
     int initialSeed() const { return seed_; }
 
     // Route index for an expanded road sequence, adding it if it is new (used by set_vehicle_route and

@@ -84,16 +84,136 @@ struct LaneDictCache {
     py::dict master[2];
     std::vector<int32_t> last[2];
     bool filled[2] = {false, false};
+    // vehicle id strings, created once per vehicle (valid for one vehicleEpoch of the engine)
+    std::vector<PyObject *> vidStr;
+    std::vector<uint64_t> vidSortKey;  // Spawner::idSortKey, computed once per vehicle (never 0)
+    uint64_t vidEpoch = 0;
+    ~LaneDictCache() { clearVehicles(); }
+    void clearVehicles() {
+        for (PyObject *o : vidStr) Py_XDECREF(o);
+        vidStr.clear();
+        vidSortKey.clear();
+    }
 };
+
+LaneDictCache &bindingCacheOf(EngineHost &e) {
+    if (!e.bindingCache) {
+        auto *c = new LaneDictCache();
+        for (int32_t l : e.laneIdOrder()) c->keys.append(py::str(e.net().laneId(l)));
+        e.bindingCache = std::shared_ptr<void>(c, [](void *p) { delete static_cast<LaneDictCache *>(p); });
+    }
+    return *static_cast<LaneDictCache *>(e.bindingCache.get());
+}
+
+// borrowed reference to the (cached) Python string of a vehicle's id
+PyObject *vehicleKey(EngineHost &e, LaneDictCache &c, int vid) {
+    if (c.vidEpoch != e.vehicleEpoch()) {
+        c.clearVehicles();
+        c.vidEpoch = e.vehicleEpoch();
+    }
+    if ((size_t) vid >= c.vidStr.size()) c.vidStr.resize((size_t) vid + 1 + c.vidStr.size() / 2, nullptr);
+    PyObject *&o = c.vidStr[vid];
+    if (!o) {
+        const std::string id = e.vehicleId(vid);
+        o = PyUnicode_FromStringAndSize(id.data(), (Py_ssize_t) id.size());
+        if (!o) throw py::error_already_set();
+    }
+    return o;
+}
+
+uint64_t vehicleSortKey(EngineHost &e, LaneDictCache &c, int vid) {
+    if (c.vidEpoch != e.vehicleEpoch()) {
+        c.clearVehicles();
+        c.vidEpoch = e.vehicleEpoch();
+    }
+    if ((size_t) vid >= c.vidSortKey.size()) c.vidSortKey.resize((size_t) vid + 1 + c.vidSortKey.size() / 2, 0);
+    uint64_t &k = c.vidSortKey[vid];
+    if (!k) k = e.spawner().idSortKey(vid);
+    return k;
+}
+
+// get_vehicle_speed / get_vehicle_distance (engine.cpp:650-676): {vehicle id: value} in std::map (string) key order
+py::dict vehicleValueDict(EngineHost &e, bool speed) {
+    cfa::VehicleSnapshot s;
+    e.snapshotVehicles(s, speed ? cfa::kSnapSpeed : cfa::kSnapDis);
+    const std::vector<double> &val = speed ? s.speed : s.dis;
+    LaneDictCache &c = bindingCacheOf(e);
+    std::vector<std::pair<uint64_t, int>> order((size_t) s.count);
+    for (int i = 0; i < s.count; ++i) order[i] = std::make_pair(vehicleSortKey(e, c, s.vid[i]), i);
+    std::sort(order.begin(), order.end());
+    py::dict d;
+    for (auto &p : order) {
+        PyObject *num = PyFloat_FromDouble(val[p.second]);
+        if (!num || PyDict_SetItem(d.ptr(), vehicleKey(e, c, s.vid[p.second]), num) != 0) {
+            Py_XDECREF(num);
+            throw py::error_already_set();
+        }
+        Py_DECREF(num);
+    }
+    return d;
+}
+
+// get_vehicles (engine.cpp:619-626): ids in vehiclePool (= priority) order
+py::list vehicleList(EngineHost &e, bool includeWaiting) {
+    cfa::VehicleSnapshot s;
+    e.snapshotVehicles(s, 0);
+    std::vector<std::pair<int32_t, int32_t>> byPriority;
+    byPriority.reserve((size_t) s.count);
+    for (int i = 0; i < s.count; ++i) byPriority.emplace_back(e.spawner().vehicles[s.vid[i]].priority, s.vid[i]);
+    if (includeWaiting) {
+        std::vector<int32_t> wv, wl;
+        e.waitingVehicles(wv, wl);
+        for (int32_t v : wv) byPriority.emplace_back(e.spawner().vehicles[v].priority, v);
+    }
+    std::sort(byPriority.begin(), byPriority.end());
+    LaneDictCache &c = bindingCacheOf(e);
+    py::list out(byPriority.size());
+    for (size_t i = 0; i < byPriority.size(); ++i) {
+        PyObject *key = vehicleKey(e, c, byPriority[i].second);
+        Py_INCREF(key);
+        PyList_SET_ITEM(out.ptr(), (Py_ssize_t) i, key);
+    }
+    return out;
+}
+
+// get_lane_vehicles (engine.cpp:658-668): {lane id: [vehicle ids front to back]} for every lane, std::map key order
+py::dict laneVehiclesDict(EngineHost &e) {
+    cfa::VehicleSnapshot s;
+    e.snapshotVehicles(s, cfa::kSnapDrivable);
+    const std::vector<int32_t> &order = e.laneIdOrder();
+    const int L = (int) order.size();
+    std::vector<int32_t> start((size_t) L + 1, 0);
+    for (int i = 0; i < s.count; ++i)
+        if (s.drivable[i] < L) start[s.drivable[i] + 1]++;
+    for (int l = 0; l < L; ++l) start[l + 1] += start[l];
+    // the snapshot is ordered by drivable, front to back: the vehicles of lane l are a contiguous run
+    std::vector<int32_t> first((size_t) L, -1);
+    for (int i = s.count - 1; i >= 0; --i)
+        if (s.drivable[i] < L) first[s.drivable[i]] = i;
+    LaneDictCache &c = bindingCacheOf(e);
+    py::dict d;
+    for (int k = 0; k < L; ++k) {
+        const int l = order[k];
+        const int n = start[l + 1] - start[l];
+        PyObject *lst = PyList_New(n);
+        if (!lst) throw py::error_already_set();
+        for (int j = 0; j < n; ++j) {
+            PyObject *key = vehicleKey(e, c, s.vid[first[l] + j]);
+            Py_INCREF(key);
+            PyList_SET_ITEM(lst, j, key);
+        }
+        if (PyDict_SetItem(d.ptr(), PyList_GET_ITEM(c.keys.ptr(), (Py_ssize_t) k), lst) != 0) {
+            Py_DECREF(lst);
+            throw py::error_already_set();
+        }
+        Py_DECREF(lst);
+    }
+    return d;
+}
 
 py::dict laneDict(EngineHost &e, const std::vector<int32_t> &values, int which) {
     const std::vector<int32_t> &order = e.laneIdOrder();
-    if (!e.bindingCache) {
-        auto *c = new LaneDictCache();
-        for (int32_t l : order) c->keys.append(py::str(e.net().laneId(l)));
-        e.bindingCache = std::shared_ptr<void>(c, [](void *p) { delete static_cast<LaneDictCache *>(p); });
-    }
-    LaneDictCache &c = *static_cast<LaneDictCache *>(e.bindingCache.get());
+    LaneDictCache &c = bindingCacheOf(e);
     std::vector<int32_t> &last = c.last[which];
     if (!c.filled[which]) last.assign(order.size(), INT32_MIN);
     PyObject *master = c.master[which].ptr();
@@ -203,14 +323,14 @@ PYBIND11_MODULE(_cityflow, m) {
         // ---- reference API ----
         .def("next_step", &EngineHost::nextStep)
         .def("get_vehicle_count", &EngineHost::getVehicleCount)
-        .def("get_vehicles", &EngineHost::getVehicles, "include_waiting"_a = false)
+        .def("get_vehicles", [](EngineHost &e, bool w) { return vehicleList(e, w); }, "include_waiting"_a = false)
         // dict[str, int] in std::map (lexicographic) key order like the reference, built from cached key objects
         .def("get_lane_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneVehicleCountArray(), 0); })
         .def("get_lane_waiting_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneWaitingVehicleCountArray(), 1); })
-        .def("get_lane_vehicles", &EngineHost::getLaneVehicles)
-        .def("get_vehicle_speed", &EngineHost::getVehicleSpeed)
+        .def("get_lane_vehicles", [](EngineHost &e) { return laneVehiclesDict(e); })
+        .def("get_vehicle_speed", [](EngineHost &e) { return vehicleValueDict(e, true); })
         .def("get_vehicle_info", &EngineHost::getVehicleInfo, "vehicle_id"_a)
-        .def("get_vehicle_distance", &EngineHost::getVehicleDistance)
+        .def("get_vehicle_distance", [](EngineHost &e) { return vehicleValueDict(e, false); })
         .def("get_leader", &EngineHost::getLeader, "vehicle_id"_a)
         .def("get_current_time", &EngineHost::getCurrentTime)
         .def("get_average_travel_time", &EngineHost::getAverageTravelTime)
@@ -293,6 +413,7 @@ PYBIND11_MODULE(_cityflow, m) {
                  for (py::ssize_t i = 0; i < r.shape(0); ++i) out.push_back(e.vehicleId(r(i)));
                  return out;
              })
+        .def("_id_sort_key", [](EngineHost &e, int vid) { return e.spawner().idSortKey(vid); }, "vid"_a)
         .def("_vehicle_priority", [](EngineHost &e, int vid) { return e.spawner().vehicles.at(vid).priority; })
         .def("_drivable_ids",
              [](EngineHost &e) {

@@ -153,3 +153,34 @@ def test_lane_count_dicts_are_fresh_sorted_and_consistent(mod, scen, workdir):
     eng.reset(False)
     d = eng.get_lane_vehicle_count()
     assert sum(d.values()) == 0 and "not_a_lane" not in d
+
+
+def test_string_getters_order_and_cache(mod, ref_module, scen, workdir):
+    """get_vehicle_speed / get_vehicle_distance / get_lane_vehicles / get_vehicles: same content AND same key / element
+    order as the reference (std::map order is string order; the binding sorts by an integer key and reuses id objects),
+    across a reset (vehicle numbers are reassigned) and with pushed vehicles mixed in."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    ours, ref = mod.Engine._with_backend(cfg, 1, TWIN_LIB), ref_module.Engine(cfg, 1)
+    for rnd in range(2):
+        for s in range(140):
+            if s in (3, 60):
+                for e in (ours, ref):
+                    e.push_vehicle({"maxSpeed": 9.0}, ["road_0_1_0", "road_1_1_0", "road_2_1_0"])
+            ours.next_step()
+            ref.next_step()
+            if s % 35 == 34:
+                for name in ("get_vehicle_speed", "get_vehicle_distance", "get_lane_vehicles"):
+                    a, b = getattr(ours, name)(), getattr(ref, name)()
+                    assert a == b and list(a) == list(b), (name, rnd, s)
+                assert ours.get_vehicles() == ref.get_vehicles() and ours.get_vehicles(True) == ref.get_vehicles(True)
+        ours.reset(False)
+        ref.reset(False)
+    # the integer key orders ids exactly like the strings do
+    for _ in range(30):
+        ours.next_step()
+    n = ours._scalars()["spawned_vehicle_count"]
+    vids = list(range(n))
+    ids = ours._vehicle_ids(__import__("numpy").array(vids, dtype="int32"))
+    assert sorted(vids, key=ours._id_sort_key) == sorted(vids, key=lambda v: ids[v])
+    time.sleep(0.2)
+    del ref
