@@ -440,7 +440,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
 #undef UP
     const size_t dPad = e->dPadded();
     for (int g = 0; g < 2; ++g) {
-        if ((rc = e->allocRaw(&e->segStart[g].p, (size_t) e->D + 1))) return rc;
+        if ((rc = e->allocRaw(&e->segStart[g].p, dPad + 8))) return rc;  // k_scan writes whole 8-entry groups
         if ((rc = e->allocRaw(&e->cnt[g].p, dPad))) return rc;
         HIP_TRY(hipMemset(e->cnt[g].p, 0, dPad * sizeof(int32_t)));
     }

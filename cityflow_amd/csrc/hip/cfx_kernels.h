@@ -794,19 +794,23 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
     }
     const int tileOff = blockReduceSum(pre, smem);
     int off0 = tileOff + waveOff + incl - sum;
+    int offs[kScanItems];
     for (int i = 0; i < kScanItems; ++i) {
-        int d = base + i;
-        if (d < D) {
-            segStartNext[d] = off0;
-            cntNext[d] = live[i];
-            for (int j = live[i]; j < vals[i]; ++j) {  // the lane's spare slot(s) of the next generation
-                vidNext[off0 + j] = -1;
-                drvNext[off0 + j] = -1;
-            }
-            off0 += vals[i];
-            if (d == D - 1) segStartNext[D] = off0;
+        offs[i] = off0;
+        for (int j = live[i]; j < vals[i]; ++j) {  // the lane's spare slot(s) of the next generation (vals is 0 past D)
+            vidNext[off0 + j] = -1;
+            drvNext[off0 + j] = -1;
         }
+        off0 += vals[i];
     }
+    // Two 16-byte stores per array.  Past D the entries are padding: live = 0 and the offset stays at the grand total,
+    // which is exactly what segStartNext[D] has to hold.
+    int4 *ps = (int4 *) (segStartNext + base), *pn = (int4 *) (cntNext + base);
+    ps[0] = make_int4(offs[0], offs[1], offs[2], offs[3]);
+    ps[1] = make_int4(offs[4], offs[5], offs[6], offs[7]);
+    pn[0] = make_int4(live[0], live[1], live[2], live[3]);
+    pn[1] = make_int4(live[4], live[5], live[6], live[7]);
+    if (base + kScanItems == D) segStartNext[D] = off0;  // D a multiple of 8 and this is the last thread with work
 }
 
 // Phase 5c + 6: stable compaction into the next generation and commit of the buffered action
