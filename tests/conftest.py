@@ -17,6 +17,14 @@ TWIN_LIB = os.path.join(ROOT, "oracle", "_ref", "libcfx_twin.so")
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (rendezvous of the torch.distributed.run tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -5,13 +5,13 @@ import os
 import subprocess
 import sys
 
-from conftest import ROOT, TWIN_LIB
+from conftest import ROOT, TWIN_LIB, free_port
 
 
 def test_bench_two_ranks_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "30",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "30",
            "--cpu-seconds", "0", "--scenario", "grid_6x6", "--extra-flows", "50", "--dist-backend", "gloo",
            "--backend-lib", TWIN_LIB, "--replicas"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -30,7 +30,7 @@ def test_bench_two_ranks_tiled_gloo(tmp_path):
     """The default N>1 mode: one network (3x6 here) tiled 1x2, one tile per rank, halo exchanged every step."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "120",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "120",
            "--cpu-seconds", "0", "--tile-block", "3", "--extra-flows", "40", "--dist-backend", "gloo",
            "--backend-lib", TWIN_LIB]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

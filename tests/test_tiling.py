@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, TWIN_LIB
+from conftest import ROOT, TWIN_LIB, free_port
 
 KEYS = ["vid", "drivable", "prev_drivable", "leader", "blocker", "enter_ll_time", "route_pos", "dis", "speed", "gap"]
 
@@ -126,7 +126,7 @@ def _torchrun(tmp_path, cfg, lib, rows, cols, steps, nproc, port, extra_env=None
 def test_two_ranks_gloo(scen, workdir, tmp_path, mailboxes):
     """One tile per process; halo staged over gloo ("0") or through shared-memory mailboxes ("1")."""
     cfg = scen.materialize("grid_6x6", workdir)
-    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 200, 2, 29541 + int(mailboxes), {"CFX_TEST_MAILBOXES": mailboxes})
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 200, 2, free_port(), {"CFX_TEST_MAILBOXES": mailboxes})
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "TILED_OK 200" in out.stdout
 
@@ -174,7 +174,7 @@ def test_tiled_mailboxes_hip(mod, scen, workdir):
 def test_two_ranks_one_gpu(scen, workdir, tmp_path, mailboxes):
     """Two processes (sharing this box's one GPU), one tile each; halo over gloo ("0") or GPU-written mailboxes ("1")."""
     cfg = scen.materialize("grid_6x6", workdir)
-    out = _torchrun(tmp_path, cfg, "", 1, 2, 150, 2, 29545 + int(mailboxes),
+    out = _torchrun(tmp_path, cfg, "", 1, 2, 150, 2, free_port(),
                     {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": mailboxes})
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "TILED_OK 150" in out.stdout
@@ -184,7 +184,7 @@ def test_two_ranks_one_gpu(scen, workdir, tmp_path, mailboxes):
 def test_four_ranks_one_gpu_mailboxes(scen, workdir, tmp_path):
     """2x2 tiles, four processes on this box's GPU: every tile has two neighbours, mailboxes in both directions."""
     cfg = scen.materialize("grid_6x6", workdir)
-    out = _torchrun(tmp_path, cfg, "", 2, 2, 150, 4, 29549, {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": "1"})
+    out = _torchrun(tmp_path, cfg, "", 2, 2, 150, 4, free_port(), {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": "1"})
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "TILED_OK 150" in out.stdout
 
