@@ -92,6 +92,8 @@ struct cfx_engine {
     size_t dPadded() const { return (size_t) ((D + kScanTile - 1) / kScanTile) * kScanTile; }
     int32_t *laneOut = nullptr;
     int32_t *hLaneOut = nullptr;  // pinned landing buffer of the per-lane getters (a D2H copy into pageable memory is staged twice)
+    HostMirror *hMirror = nullptr;  // pinned; valid while the last thing that changed the scalars was a step
+    bool mirrorValid = false;
     DevScalars *sc = nullptr;
 
     cfx_spawn *dRecs = nullptr;
@@ -311,8 +313,13 @@ struct cfx_engine {
     }
 
     int readScalars(DevScalars &out) {
-        HIP_TRY(hipMemcpyAsync(&out, sc, sizeof(DevScalars), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        if (mirrorValid) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            out = hMirror->sc;
+        } else {
+            HIP_TRY(hipMemcpyAsync(&out, sc, sizeof(DevScalars), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
         finishedKnown = out.finishedCnt;
         if (out.overflow == 4) return fail("halo: a neighbour tile did not publish its step in time (cfx_halo_wait)");
         if (out.overflow == 3) return fail("halo: more vehicles crossed one cut lane in one step than CFX_HALO_MAX_MIGRANTS");
@@ -322,6 +329,7 @@ struct cfx_engine {
 
     int resetState() {
         HIP_TRY(hipStreamSynchronize(stream));
+        mirrorValid = false;
         generation += 1;
         cur = 0;
         step = 0;
@@ -386,6 +394,7 @@ void cfx_destroy(cfx_engine *e) {
         if (m.recvHost) (void) hipHostUnregister(m.recvHost);
     }
     if (e->hLaneOut) (void) hipHostFree(e->hLaneOut);
+    if (e->hMirror) (void) hipHostFree(e->hMirror);
     if (e->hHaloSend) (void) hipHostFree(e->hHaloSend);
     if (e->hHaloRecv) (void) hipHostFree(e->hHaloRecv);
     if (e->stream) (void) hipStreamDestroy(e->stream);
@@ -453,6 +462,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->waitHead, (size_t) e->L))) return rc;
     if ((rc = e->allocRaw(&e->admitStep, dPad))) return rc;  // lanes only are ever set; the rest stays -1 (k_scan reads 8 at a time)
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
+    HIP_TRY(hipHostMalloc((void **) &e->hMirror, sizeof(HostMirror), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &e->hLaneOut, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
     if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
@@ -640,11 +650,12 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),
                        dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
                        e->remain, e->cfg.rl_traffic_light, e->nMaskWords, scanTicket, e->vt, e->sc, e->finList,
-                       e->finSorted, (int) e->slotCap, e->jobCount);
+                       e->finSorted, (int) e->slotCap, e->jobCount, e->tiled ? nullptr : e->hMirror);
     e->profEnd(pp__); }
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;
+    e->mirrorValid = !e->tiled;
     return CFX_OK;
 }
 
@@ -774,8 +785,13 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
     if ((rc = e->syncTables())) return rc;
     // number of slots of the current generation
     int32_t S = 0;
-    HIP_TRY(hipMemcpyAsync(&S, e->segStart[e->cur].p + e->D, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->mirrorValid) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        S = e->hMirror->slots;
+    } else {
+        HIP_TRY(hipMemcpyAsync(&S, e->segStart[e->cur].p + e->D, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     // only what the caller asked for is computed and copied (the string getters want vid + one column)
     const bool wantLeader = view->leader_vid || view->gap, wantBlocker = view->blocker_vid != nullptr;
     if (wantLeader) {

@@ -51,6 +51,12 @@ struct DevScalars {
     int pad;
 };
 
+struct HostMirror {  // pinned host copy of the end-of-step scalars (written by k_scatter's statistics block)
+    DevScalars sc;
+    int32_t slots;  // segStart[D] of the new generation
+    int32_t pad;
+};
+
 // Per-drivable scratch of the compaction.
 struct CompactScratch {
     int32_t *leaveCnt;     // [D] vehicles leaving (moved or finished)
@@ -820,12 +826,18 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
 __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
                           int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, int32_t *finSorted,
-                          int finCap, int32_t *jobCount) {
+                          int finCap, int32_t *jobCount, HostMirror *hostMirror) {
     // The launch carries one extra block that only does the step's finish statistics (it reads just the current
     // generation and the finish list, both complete before this kernel starts), in parallel with the compaction.
     if (blockIdx.x == gridDim.x - 1) {
         finishStatistics(c, vt, sc, finList, finSorted, finCap);
         if (threadIdx.x < kJobShards) jobCount[threadIdx.x * kJobShardStride] = 0;  // k_cross of this step is done
+        if (threadIdx.x == 0 && hostMirror) {
+            // the step's scalars and slot count, also left in pinned host memory: a getter then needs the stream
+            // synchronisation only, not a device-to-host copy on top of it
+            hostMirror->sc = *sc;
+            hostMirror->slots = segStartNext[c.n.L + c.n.K];
+        }
         return;
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
