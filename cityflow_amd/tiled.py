@@ -18,6 +18,7 @@ address space, reference src/engine/engine.cpp:19-31).
 
     torchrun --nproc-per-node 8 my_rl.py        # inside: eng = DistributedEngine(cfg, rows=2, cols=4)
 """
+import datetime
 import os
 import time
 
@@ -41,8 +42,8 @@ class DistributedEngine:
             self._halo = halo_group
         elif dist.get_backend() == "gloo":
             self._halo = dist.group.WORLD
-        else:
-            self._halo = dist.new_group(backend="gloo")
+        else:  # bounded waits: a rank that failed to set up must not leave the others in a barrier for the default 30 min
+            self._halo = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
         self._peers = self._eng.peers(0)
         self._send = torch.from_numpy(self._eng.send_buffer(0))  # zero-copy views of the C++ staging buffers
         self._recv = torch.from_numpy(self._eng.recv_buffer(0))
