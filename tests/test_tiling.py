@@ -131,6 +131,14 @@ def test_two_ranks_gloo(scen, workdir, tmp_path, mailboxes):
     assert "TILED_OK 200" in out.stdout
 
 
+def test_four_ranks_separate_halo_group(scen, workdir, tmp_path):
+    """2x2 tiles over four processes, the halo on its own gloo group (as under an RCCL default group), staged transport."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 2, 2, 120, 4, free_port(), {"CFX_TEST_MAILBOXES": "0", "CFX_TEST_SUBGROUP": "1"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 120" in out.stdout
+
+
 # ------------------------------------------------------------------------------------------------ MI355X
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,rows,cols,steps", [("grid_6x6", 2, 2, 700), ("grid_6x6", 3, 3, 400)])

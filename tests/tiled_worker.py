@@ -16,7 +16,12 @@ def main():
     cfg, lib, rows, cols, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     dist.init_process_group(backend=os.environ.get("CFX_TEST_DIST_BACKEND", "gloo"))
     rank = dist.get_rank()
-    eng = DistributedEngine(cfg, rows, cols, backend_library=lib, mailboxes=os.environ.get("CFX_TEST_MAILBOXES", "1") == "1")
+    halo = None
+    if os.environ.get("CFX_TEST_SUBGROUP") == "1":  # the layout of a GPU job: halo on its own host-side group
+        import datetime
+        halo = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+    eng = DistributedEngine(cfg, rows, cols, backend_library=lib, halo_group=halo,
+                            mailboxes=os.environ.get("CFX_TEST_MAILBOXES", "1") == "1")
     single = m.Engine._with_backend(cfg, 1, lib) if lib else m.Engine(cfg, 1)
     crossed = 0
     for s in range(steps):
