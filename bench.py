@@ -18,7 +18,8 @@ rank's time.  `--replicas` runs N independent copies of the N=1 workload instead
 
 Output: ONE JSON line on rank 0 (see README of the task contract) with two extra objects:
   roofline      car-following kernel (k_action): algorithmic bytes (48 B per running vehicle)
-                / average launch duration measured with HIP events on the engine's stream
+                / average launch duration measured with HIP events on the engine's stream (the dispatch's own
+                start / stop events, hipExtLaunchKernel: the durations a rocprofv3 kernel trace reports)
   cpu_baseline  the unmodified reference engine (oracle/_ref, prebuilt) timed on this box's host cores for a bounded
                 number of steps starting from the very state the GPU run had at the start of its timed region
                 (injected through the reference's Archive JSON); falls back to the CPU twin (kind "port")

@@ -2,6 +2,7 @@
 // Host-side bookkeeping of the device engine: buffer ownership and growth, launch sequencing, getters.
 // The arithmetic lives in cfx_device.h / cfx_kernels.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -144,23 +145,28 @@ struct cfx_engine {
     double profMs[kNumProfKernels] = {};
     int64_t profLaunches[kNumProfKernels] = {};
 
-    int profBegin(int kernelId) {
-        if (!profiling) return -1;
-        if (evUsed * 2 + 2 > evPool.size()) {
-            for (int i = 0; i < 2; ++i) {
-                hipEvent_t ev;
-                if (hipEventCreate(&ev) != hipSuccess) return -1;
-                evPool.push_back(ev);
+    // Launch `kernel`; while profiling, with the dispatch's own start / stop timestamps (hipExtLaunchKernel records the
+    // events at the kernel's begin and end, the same clock readings a rocprofv3 kernel trace reports — a pair of
+    // hipEventRecord calls around the launch would add the marker packets' latency, ~3 us, to every kernel).
+    template <typename K, typename... A>
+    void launch(int kernelId, K kernel, dim3 grid, dim3 block, A... args) {
+        if (profiling) {
+            if (evUsed * 2 + 2 > evPool.size()) {
+                for (int i = 0; i < 2; ++i) {
+                    hipEvent_t ev = nullptr;
+                    if (hipEventCreate(&ev) != hipSuccess) break;
+                    evPool.push_back(ev);
+                }
+                evKernel.push_back(0);
             }
-            evKernel.push_back(0);
+            if (evUsed * 2 + 2 <= evPool.size()) {
+                const size_t pair = evUsed++;
+                evKernel[pair] = kernelId;
+                hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, evPool[2 * pair], evPool[2 * pair + 1], 0, args...);
+                return;
+            }
         }
-        int pair = (int) evUsed++;
-        evKernel[pair] = kernelId;
-        (void) hipEventRecord(evPool[2 * pair], stream);
-        return pair;
-    }
-    void profEnd(int pair) {
-        if (pair >= 0) (void) hipEventRecord(evPool[2 * pair + 1], stream);
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
     }
     void profCollect() {
         (void) hipStreamSynchronize(stream);
@@ -588,10 +594,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if (e->stageBusy[si]) HIP_TRY(hipEventSynchronize(e->stageEvent[si]));
         memcpy(e->hStage[si], recs, (size_t) n * sizeof(cfx_spawn));
         // the kernel reads the pinned (device-visible) staging buffer itself: no separate copy launch
-        { int pp__ = e->profBegin(PK_SPAWN);
-        hipLaunchKernelGGL(k_spawn_link, dim3(gridFor(n)), dim3(kBlock), 0, st, e->hStage[si], n, (int) e->spawned, e->vt,
-                           e->waitHead);
-        e->profEnd(pp__); }
+        e->launch(PK_SPAWN, k_spawn_link, dim3(gridFor(n)), dim3(kBlock), (const cfx_spawn *) e->hStage[si], (int) n,
+                  (int) e->spawned, e->vt, e->waitHead);
         HIP_TRY(hipEventRecord(e->stageEvent[si], st));
         e->stageBusy[si] = true;
         e->spawned += n;
@@ -623,35 +627,27 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     StepCtx c = e->ctx();
     const int nxt = e->cur ^ 1;
     const size_t slotBound = std::min(need, e->slotCap);
-    { int pp__ = e->profBegin(PK_ADMIT);
-    hipLaunchKernelGGL(k_admit, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->admitStep, e->waitHead, e->vt, e->cs);
-    e->profEnd(pp__); }
+    e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
     JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap};
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
-        int pp__ = e->profBegin(PK_ACTION);
-        hipLaunchKernelGGL(k_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), 0, st, c, ao, jq, nVehBlocks);
-        e->profEnd(pp__);
+        e->launch(PK_ACTION, k_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq, nVehBlocks);
     }
-    { int pp__ = e->profBegin(PK_CROSS);
-    hipLaunchKernelGGL(k_cross, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
-                       dim3(kCrossBlock), 0, st, c, ao, jq);
-    e->profEnd(pp__); }
+    e->launch(PK_CROSS, k_cross,
+              dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
+              dim3(kCrossBlock), c, ao, jq);
     int32_t *const scanTicket = e->nScanBlocks > kScanResidentTiles ? e->scanTicket : nullptr;
-    { int pp__ = e->profBegin(PK_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(e->nScanBlocks), dim3(kBlock), 0, st, e->D, e->L, e->cnt[e->cur].p, e->cs, e->scanGranules,
-                       scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
-                       e->gen[nxt].drv, e->sc, e->net.laneSpare, e->admitStep, (int) e->step, e->waitHead, e->vt,
-                       e->net.laneGhost, e->admitRec);
-    e->profEnd(pp__); }
-    { int pp__ = e->profBegin(PK_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1),
-                       dim3(kBlock), 0, st, c, e->ab, e->cs, e->gen[nxt], e->segStart[nxt].p, e->oldToNew, e->curPhase,
-                       e->remain, e->cfg.rl_traffic_light, e->nMaskWords, scanTicket, e->vt, e->sc, e->finList,
-                       e->finSorted, (int) e->slotCap, e->jobCount, e->tiled ? nullptr : e->hMirror);
-    e->profEnd(pp__); }
+    e->launch(PK_SCAN, k_scan, dim3(e->nScanBlocks), dim3(kBlock), (int) e->D, (int) e->L, (const int32_t *) e->cnt[e->cur].p, e->cs,
+              e->scanGranules, scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
+              e->gen[nxt].drv, e->sc, e->net.laneSpare, (const int32_t *) e->admitStep, (int) e->step, e->waitHead, e->vt,
+              e->net.laneGhost, (const int2 *) e->admitRec);
+    e->launch(PK_SCATTER, k_scatter,
+              dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1), dim3(kBlock), c, e->ab,
+              e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
+              (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
+              e->finSorted, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror);
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;
@@ -1281,10 +1277,8 @@ int32_t cfx_halo_post(cfx_engine *e) {
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;  // every peer implies at least one cut lane, so n > 0 with peers
     if (n) {
-        int pp__ = e->profBegin(PK_HALO_EXPORT);
-        hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
-                           e->cs.inCnt, io, e->sc);
-        e->profEnd(pp__);
+        e->launch(PK_HALO_EXPORT, k_halo_export, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail,
+                  (const int32_t *) e->cs.inCnt, io, e->sc);
     }
     HIP_TRY(hipGetLastError());
     return CFX_OK;
@@ -1306,10 +1300,8 @@ int32_t cfx_halo_wait(cfx_engine *e) {
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;
     if (n) {  // includes the wait for the neighbours' epochs
-        int pp__ = e->profBegin(PK_HALO_IMPORT);
-        hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->haloMail,
-                           io, e->vt, e->sc);
-        e->profEnd(pp__);
+        e->launch(PK_HALO_IMPORT, k_halo_import, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail, io,
+                  e->vt, e->sc);
     }
     HIP_TRY(hipGetLastError());
     e->liveUpper += (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS;
