@@ -523,6 +523,9 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
     if (cfg_.laneChange) throw std::runtime_error("cityflow_amd: laneChange=true is not implemented on the device path");
+    if (cfg_.saveReplay)
+        std::cerr << "[cityflow_amd] saveReplay: the tiled engine writes no replay files (use cityflow.Engine for replays)"
+                  << std::endl;
     nTiles_ = rows * cols;
     owner_ = gridPartition(*net_, rows, cols);
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
