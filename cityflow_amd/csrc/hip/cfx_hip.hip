@@ -93,6 +93,7 @@ struct cfx_engine {
     size_t dPadded() const { return (size_t) ((D + kScanTile - 1) / kScanTile) * kScanTile; }
     int32_t *laneOut = nullptr;
     int32_t *hLaneOut = nullptr;  // pinned landing buffer of the per-lane getters (a D2H copy into pageable memory is staged twice)
+    int cross2 = -1;                // cross phase: 1 = k_cross2 (throughput), 0 = k_cross (latency), -1 = by size
     HostMirror *hMirror = nullptr;  // pinned; valid while the last thing that changed the scalars was a step
     bool mirrorValid = false;
     DevScalars *sc = nullptr;
@@ -416,6 +417,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->cfg = *cfg;
+    if (const char *v = getenv("CFX_CROSS2")) e->cross2 = v[0] == '1' ? 1 : 0;
     e->R = n->n_roads;
     e->L = n->n_lanes;
     e->K = n->n_lanelinks;
@@ -635,9 +637,16 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
         e->launch(PK_ACTION, k_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq, nVehBlocks);
     }
-    e->launch(PK_CROSS, k_cross,
-              dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
-              dim3(kCrossBlock), c, ao, jq);
+    // k_cross finishes a vehicle in the fewest dependent rounds; k_cross2 spends far fewer wave-rounds per vehicle.  They
+    // break even at ~220 k slots on the MI355X (45x45 grid: 28.2 vs 29.2 us; 60x60: 45.1 vs 32.1 us; 100x100: 87 vs 61 us).
+    const bool useCross2 = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
+    if (useCross2)
+        e->launch(PK_CROSS, k_cross2, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
+                  dim3(kCross2Block), c, ao, jq);
+    else
+        e->launch(PK_CROSS, k_cross,
+                  dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
+                  dim3(kCrossBlock), c, ao, jq);
     int32_t *const scanTicket = e->nScanBlocks > kScanResidentTiles ? e->scanTicket : nullptr;
     e->launch(PK_SCAN, k_scan, dim3(e->nScanBlocks), dim3(kBlock), (int) e->D, (int) e->L, (const int32_t *) e->cnt[e->cur].p, e->cs,
               e->scanGranules, scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,

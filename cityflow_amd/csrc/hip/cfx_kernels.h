@@ -616,6 +616,131 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(StepCtx c, ActionOut o, J
     }
 }
 
+// Same phase, organised for throughput (large networks): k_cross keeps a quarter wave busy for a vehicle's whole chain —
+// finding the crosses that matter, the canPass arithmetic of the one or two that do, and the vehicle's finish by a single
+// lane.  Here a block takes kCross2Jobs vehicles per batch and goes through three barrier-separated passes:
+//   A  16-lane groups walk the crosses of each vehicle and only LIST the (vehicle, cross) pairs that need Cross::canPass
+//      (cross still ahead, peer laneLink active);
+//   B  one thread per listed pair evaluates it; the lowest failing cross of a vehicle is kept with an LDS atomicMin
+//      (crosses are sorted by distance, so "lowest entry" is the reference's "first cross that cannot be passed");
+//   C  one thread per vehicle turns that cross into the yield speed / blocker and finishes the vehicle.
+// Same results as k_cross (which stops at the first failing round: the later rounds it skips cannot lower the minimum).
+constexpr int kCross2Block = 256;
+constexpr int kCross2Jobs = 64;
+constexpr int kCross2Work = 2048;
+
+__global__ __launch_bounds__(kCross2Block) void k_cross2(StepCtx c, ActionOut o, JobQueue q) {
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    __shared__ int shardEnd[kJobShards];
+    __shared__ int sS[kCross2Jobs], sT1[kCross2Jobs], sTempl[kCross2Jobs], sFirst[kCross2Jobs];
+    __shared__ double sD0[kCross2Jobs], sSpeed[kCross2Jobs];
+    __shared__ int sWorkJob[kCross2Work], sWorkE[kCross2Work];
+    __shared__ int sNWork;
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        tv = sT;
+    }
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < kJobShards; ++i) {
+            run += q.count[i * kJobShardStride];
+            shardEnd[i] = run;
+        }
+    }
+    __syncthreads();
+    const int nJ = shardEnd[kJobShards - 1];
+    const int tid = threadIdx.x;
+    const int g = tid % kCrossGroup, group = tid / kCrossGroup;
+    constexpr int kGroups = kCross2Block / kCrossGroup;
+    // Cross::canPass for the vehicle in slot `s` at cross entry e; a failing cross competes for "first of the vehicle"
+    auto evaluate = [&](int jl, int s, double speed, int templ, int t1, double d0, int e) {
+        const double2 dd = c.n.xDD[e];
+        const int4 xp = c.n.xPack[e];
+        VehRef self{speed, &tv[templ]};
+        int foe;
+        if (!canPassActive(c, tv, s, self, dd.x, t1, d0, xp.x, dd.y, xp.z, &foe)) atomicMin(&sFirst[jl], e);
+    };
+    for (int j0 = blockIdx.x * kCross2Jobs; j0 < nJ; j0 += gridDim.x * kCross2Jobs) {
+        if (tid < kCross2Jobs) sFirst[tid] = CFX_INT_MAX;
+        if (tid == 0) sNWork = 0;
+        __syncthreads();
+        // ---- pass A: list the (vehicle, cross) pairs that need a look
+        for (int rep = 0; rep < kCross2Jobs / kGroups; ++rep) {
+            const int jl = rep * kGroups + group;
+            if (j0 + jl >= nJ) continue;
+            int shard = 0;
+            while (j0 + jl >= shardEnd[shard]) ++shard;
+            const int s = q.jobs[(size_t) shard * q.capacity + (j0 + jl - (shard ? shardEnd[shard - 1] : 0))];
+            const int d = c.s.drv[s];
+            const int templ = c.s.templ[s];
+            const double speed = c.s.speed[s];
+            const double dis = c.s.dis[s];
+            const int nd0 = c.s.next[s];
+            const bool onLane = d < c.n.L;
+            const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
+            const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
+            const double d0 = onLane ? -(c.n.drvLength[d] - dis) : dis;
+            if (g == 0) {
+                sS[jl] = s;
+                sT1[jl] = lp.w;
+                sTempl[jl] = templ;
+                sD0[jl] = d0;
+                sSpeed[jl] = speed;
+            }
+            for (int e = lp.x + g; e < lp.y; e += kCrossGroup) {
+                if (c.n.xDD[e].x < d0) continue;  // the cross is already behind the vehicle
+                const int bit = c.n.xPack[e].y;
+                if (!((c.interMask[lp.z + (bit >> 6)] >> (bit & 63)) & 1ULL)) continue;  // nobody to yield to there
+                const int w = atomicAdd(&sNWork, 1);
+                if (w < kCross2Work) {
+                    sWorkJob[w] = jl;
+                    sWorkE[w] = e;
+                } else {
+                    evaluate(jl, s, speed, templ, lp.w, d0, e);  // list full (very busy junctions): look at it right away
+                }
+            }
+        }
+        __syncthreads();
+        // ---- pass B: one thread per listed pair
+        const int nW = sNWork < kCross2Work ? sNWork : kCross2Work;
+        for (int w = tid; w < nW; w += kCross2Block) {
+            const int jl = sWorkJob[w];
+            evaluate(jl, sS[jl], sSpeed[jl], sTempl[jl], sT1[jl], sD0[jl], sWorkE[w]);
+        }
+        __syncthreads();
+        // ---- pass C: one thread per vehicle
+        if (tid < kCross2Jobs && j0 + tid < nJ) {
+            const int s = sS[tid];
+            const cfx_vehicle_template &t = tv[sTempl[tid]];
+            const double speed = sSpeed[tid], d0 = sD0[tid];
+            const int d = c.s.drv[s];
+            const double dis = c.s.dis[s];
+            const double dlen = c.n.drvLength[d];
+            const int nd0 = c.s.next[s];
+            double iv = o.b.dis[s];  // partial intersection speed parked by k_action
+            int blockerSlot = -1;
+            const int e = sFirst[tid];
+            if (e != CFX_INT_MAX) {
+                const double2 dd = c.n.xDD[e];
+                double d2;
+                blockerSlot = notifiedAt(c, tv, c.n.xPack[e].x, dd.y, &d2);  // the vehicle that cross made us yield to
+                VehRef self{speed, &t};
+                iv = min2(iv, stopBeforeSpeed(self, dd.x - d0 - t.yield_distance, c.interval));
+                if (blockerSlot >= 0 && c.n.laneGhost) {  // tiling: see k_cross
+                    const int bd = c.s.drv[blockerSlot];
+                    if (bd < c.n.L && c.n.laneGhost[bd]) blockerSlot = -(c.s.vid[blockerSlot] + 2);
+                }
+            }
+            finishAction(c, o, t, s, d, c.s.vid[s], speed, dis, dlen, nd0, min2(o.b.speed[s], iv), blockerSlot);
+        }
+        __syncthreads();
+    }
+}
+
 // Phase 5b in ONE launch: single-pass exclusive scan of the new segment sizes over drivables.
 // A tile waits for its predecessors' totals, so every predecessor must be running or done: with at most
 // kScanResidentTiles tiles the whole grid is co-resident (256 CUs x >= 2 such blocks) and tile = block index;
