@@ -631,16 +631,16 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     const size_t slotBound = std::min(need, e->slotCap);
     e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
+    // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
+    // throughput (far fewer wave-rounds per vehicle).  They break even at ~220 k slots on the MI355X.
+    const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
     JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap};
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
         e->launch(PK_ACTION, k_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq, nVehBlocks);
     }
-    // k_cross finishes a vehicle in the fewest dependent rounds; k_cross2 spends far fewer wave-rounds per vehicle.  They
-    // break even at ~220 k slots on the MI355X (45x45 grid: 28.2 vs 29.2 us; 60x60: 45.1 vs 32.1 us; 100x100: 87 vs 61 us).
-    const bool useCross2 = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
-    if (useCross2)
+    if (useBig)
         e->launch(PK_CROSS, k_cross2, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
                   dim3(kCross2Block), c, ao, jq);
     else

@@ -392,6 +392,147 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
 // vehicle.cpp:308-335: leader/gap, car following, and the first half of getIntersectionRelatedSpeed (red
 // light / blocked exit lane / turn speed).  Vehicles that still have to look at the crosses of their laneLink
 // are queued for k_cross (their speed so far parked in the action buffer); everybody else is finished here.
+struct SlotIn {  // everything the action phase loads by slot index alone
+    int vid, d, dPrev, templIdx, templPrev, nd0, flags;
+    double speed, dis, speedPrev, disPrev;
+};
+
+// Every load that depends only on the slot index is issued up front, before the first branch, so the memory
+// system sees them as ONE round (the kernels are bound by dependent-load rounds, not bytes).
+__device__ __forceinline__ SlotIn loadSlot(const StepCtx &c, int s) {
+    SlotIn in;
+    const int sp = s > 0 ? s - 1 : 0;
+    in.vid = c.s.vid[s];
+    in.d = c.s.drv[s];
+    in.dPrev = c.s.drv[sp];
+    in.templIdx = c.s.templ[s];
+    in.templPrev = c.s.templ[sp];
+    in.speed = c.s.speed[s];
+    in.dis = c.s.dis[s];
+    in.speedPrev = c.s.speed[sp];
+    in.disPrev = c.s.dis[sp];
+    in.nd0 = c.s.next[s];
+    in.flags = c.s.flags[s];
+    return in;
+}
+
+// One vehicle's phase 4 up to the walk over the crosses; `push(s)` hands a vehicle that still has to look at the
+// crosses of its laneLink to the cross phase (its two partial speeds are parked in the action buffer).
+template <class Push>
+__device__ __forceinline__ void actionOne(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template *tv, const int s,
+                                          const SlotIn &in, Push push) {
+    const int sp = s > 0 ? s - 1 : 0;
+    const int vid = in.vid, d = in.d, dPrev = in.dPrev, templIdx = in.templIdx, templPrev = in.templPrev;
+    const double speed = in.speed, dis = in.dis, speedPrev = in.speedPrev, disPrev = in.disPrev;
+    const int nd0 = in.nd0, flags = in.flags;
+    if (vid < 0) return;
+    if (c.n.laneGhost && d < c.n.L && c.n.laneGhost[d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
+        o.b.dis[s] = dis;
+        o.b.speed[s] = speed;
+        o.b.drv[s] = -1;
+        o.b.blocker[s] = -1;
+        return;
+    }
+    const bool head = s == 0 || dPrev != d;
+    const cfx_vehicle_template &t = tv[templIdx];
+    const double interval = c.interval;
+    const double2 lm = c.n.drvLM[d];
+    const double dlen = lm.x;
+
+    // --- leader / gap
+    double gap;
+    int ls;
+    if (!head) {  // Vehicle::updateLeaderAndGap vehicle.cpp:158-160
+        ls = sp;
+        gap = disPrev - tv[templPrev].len - dis;
+    } else {
+        ls = findLeader(c, tv, s, d, true, dis, t.approach_dist, &gap);
+    }
+
+    // --- Vehicle::getNextSpeed vehicle.cpp:308-335
+    double v = t.max_speed;
+    v = min2(v, speed + t.max_pos_acc * interval);
+    v = min2(v, lm.y);
+
+    // car following, Vehicle::getCarFollowSpeed vehicle.cpp:212-238
+    double cf;
+    const bool custom = (flags & 1) != 0;  // Vehicle::hasSetCustomSpeed
+    if (ls < 0) {
+        cf = custom ? c.vCustomSpeed[vid] : t.max_speed;
+    } else if (custom) {
+        const cfx_vehicle_template &tl = tv[head ? c.s.templ[ls] : templPrev];
+        cf = min2(c.vCustomSpeed[vid],
+                  noCollisionSpeed(head ? c.s.speed[ls] : speedPrev, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0));
+    } else {
+        const cfx_vehicle_template &tl = tv[head ? c.s.templ[ls] : templPrev];
+        const double leaderSpeed = head ? c.s.speed[ls] : speedPrev;
+        cf = noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0);
+        double assumeDecel = 0;
+        if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
+        cf = min2(cf, noCollisionSpeed(leaderSpeed, tl.usual_neg_acc, speed, t.usual_neg_acc, gap, interval, t.min_gap));
+        cf = min2(cf, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) /
+                          (t.headway_time + interval / 2));
+    }
+    v = min2(v, cf);
+
+    // intersection logic, Vehicle::isIntersectionRelated vehicle.cpp:289-300
+    const bool onLane = d < c.n.L;
+    const bool related = !onLane || (nd0 >= c.n.L && dlen - dis <= t.approach_dist);
+    if (related) {
+        // Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-362
+        VehRef self{speed, &t};
+        double iv = t.max_speed;
+        int laneLink = -1;
+        bool done = false;
+        int gateFlags;
+        if (nd0 >= c.n.L) {
+            laneLink = nd0 - c.n.L;
+            const int2 gate = c.llGate[laneLink];  // {available | type | has crosses, end lane}, from k_admit
+            gateFlags = gate.x;
+            bool blocked = !(gate.x & 1);
+            if (!blocked) {  // Lane::canEnter roadnet.cpp:437-445
+                int tail = c.laneTail[gate.y];
+                if (tail >= 0) blocked = !(c.s.dis[tail] > tv[c.s.templ[tail]].len + t.len || c.s.speed[tail] >= 2);
+            }
+            if (blocked) {
+                if (minBrakeDistance(self) > dlen - dis) {
+                    // cannot stop before the line: run it
+                } else {
+                    iv = min2(iv, stopBeforeSpeed(self, dlen - dis, interval));
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+            if (laneLink < 0) {  // already on a laneLink
+                laneLink = d - c.n.L;
+                gateFlags = c.llGate[laneLink].x;
+            }
+            if (nd0 >= c.n.L && typeIsTurn((gateFlags >> 1) & 3)) iv = min2(iv, t.turn_speed);
+            if (gateFlags & 8) {
+                // park the two partial speeds and hand the cross checks to k_cross
+                o.b.speed[s] = v;
+                o.b.dis[s] = iv;
+                push(s);  // the cross checks are done by 16-lane groups (k_cross / k_cross2)
+                return;
+            }
+        }
+        v = min2(v, iv);
+    }
+    finishAction(c, o, t, s, d, vid, speed, dis, dlen, nd0, v, -1);
+}
+
+// queue for the cross phase.  The counter is sharded: one word takes only ~88 returning atomics per us (MI355X guide,
+// "dequeue"), and a step issues one per wave.
+struct PushJob {
+    JobQueue q;
+    __device__ __forceinline__ void operator()(int s) const {
+        const int shard = blockIdx.x & (kJobShards - 1);
+        const int idx = atomicAdd(&q.count[shard * kJobShardStride], 1);
+        q.jobs[(size_t) shard * q.capacity + idx] = s;
+    }
+};
+
 __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
     // The trailing blocks of the launch do the (independent) per-laneLink notify sources for k_cross.
     if ((int) blockIdx.x >= nVehicleBlocks) {
@@ -410,121 +551,8 @@ __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, Jo
     }
     const int S = c.segStart[c.n.L + c.n.K];
     const int stride = nVehicleBlocks * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
-        // Every load that depends only on the slot index is issued up front, before the first branch, so the
-        // memory system sees them as ONE round (the kernel is bound by dependent-load rounds, not bytes).
-        const int sp = s > 0 ? s - 1 : 0;
-        const int vid = c.s.vid[s];
-        const int d = c.s.drv[s];
-        const int dPrev = c.s.drv[sp];
-        const int templIdx = c.s.templ[s];
-        const int templPrev = c.s.templ[sp];
-        const double speed = c.s.speed[s];
-        const double dis = c.s.dis[s];
-        const double speedPrev = c.s.speed[sp];
-        const double disPrev = c.s.dis[sp];
-        const int nd0 = c.s.next[s];
-        const int flags = c.s.flags[s];
-        if (vid < 0) continue;
-        if (c.n.laneGhost && d < c.n.L && c.n.laneGhost[d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
-            o.b.dis[s] = dis;
-            o.b.speed[s] = speed;
-            o.b.drv[s] = -1;
-            o.b.blocker[s] = -1;
-            continue;
-        }
-        const bool head = s == 0 || dPrev != d;
-        const cfx_vehicle_template &t = tv[templIdx];
-        const double interval = c.interval;
-        const double2 lm = c.n.drvLM[d];
-        const double dlen = lm.x;
-
-        // --- leader / gap
-        double gap;
-        int ls;
-        if (!head) {  // Vehicle::updateLeaderAndGap vehicle.cpp:158-160
-            ls = sp;
-            gap = disPrev - tv[templPrev].len - dis;
-        } else {
-            ls = findLeader(c, tv, s, d, true, dis, t.approach_dist, &gap);
-        }
-
-        // --- Vehicle::getNextSpeed vehicle.cpp:308-335
-        double v = t.max_speed;
-        v = min2(v, speed + t.max_pos_acc * interval);
-        v = min2(v, lm.y);
-
-        // car following, Vehicle::getCarFollowSpeed vehicle.cpp:212-238
-        double cf;
-        const bool custom = (flags & 1) != 0;  // Vehicle::hasSetCustomSpeed
-        if (ls < 0) {
-            cf = custom ? c.vCustomSpeed[vid] : t.max_speed;
-        } else if (custom) {
-            const cfx_vehicle_template &tl = tv[head ? c.s.templ[ls] : templPrev];
-            cf = min2(c.vCustomSpeed[vid],
-                      noCollisionSpeed(head ? c.s.speed[ls] : speedPrev, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0));
-        } else {
-            const cfx_vehicle_template &tl = tv[head ? c.s.templ[ls] : templPrev];
-            const double leaderSpeed = head ? c.s.speed[ls] : speedPrev;
-            cf = noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0);
-            double assumeDecel = 0;
-            if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
-            cf = min2(cf, noCollisionSpeed(leaderSpeed, tl.usual_neg_acc, speed, t.usual_neg_acc, gap, interval, t.min_gap));
-            cf = min2(cf, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) /
-                              (t.headway_time + interval / 2));
-        }
-        v = min2(v, cf);
-
-        // intersection logic, Vehicle::isIntersectionRelated vehicle.cpp:289-300
-        const bool onLane = d < c.n.L;
-        const bool related = !onLane || (nd0 >= c.n.L && dlen - dis <= t.approach_dist);
-        if (related) {
-            // Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-362
-            VehRef self{speed, &t};
-            double iv = t.max_speed;
-            int laneLink = -1;
-            bool done = false;
-            int gateFlags;
-            if (nd0 >= c.n.L) {
-                laneLink = nd0 - c.n.L;
-                const int2 gate = c.llGate[laneLink];  // {available | type | has crosses, end lane}, from k_admit
-                gateFlags = gate.x;
-                bool blocked = !(gate.x & 1);
-                if (!blocked) {  // Lane::canEnter roadnet.cpp:437-445
-                    int tail = c.laneTail[gate.y];
-                    if (tail >= 0) blocked = !(c.s.dis[tail] > tv[c.s.templ[tail]].len + t.len || c.s.speed[tail] >= 2);
-                }
-                if (blocked) {
-                    if (minBrakeDistance(self) > dlen - dis) {
-                        // cannot stop before the line: run it
-                    } else {
-                        iv = min2(iv, stopBeforeSpeed(self, dlen - dis, interval));
-                        done = true;
-                    }
-                }
-            }
-            if (!done) {
-                if (laneLink < 0) {  // already on a laneLink
-                    laneLink = d - c.n.L;
-                    gateFlags = c.llGate[laneLink].x;
-                }
-                if (nd0 >= c.n.L && typeIsTurn((gateFlags >> 1) & 3)) iv = min2(iv, t.turn_speed);
-                if (gateFlags & 8) {
-                    // park the two partial speeds and hand the cross checks to k_cross
-                    o.b.speed[s] = v;
-                    o.b.dis[s] = iv;
-                    // queue for k_cross.  The counter is sharded: one word takes only ~88 returning atomics per us
-                    // (MI355X guide, "dequeue"), and a step issues one per wave.
-                    const int shard = blockIdx.x & (kJobShards - 1);
-                    const int idx = atomicAdd(&q.count[shard * kJobShardStride], 1);
-                    q.jobs[(size_t) shard * q.capacity + idx] = s;
-                    continue;
-                }
-            }
-            v = min2(v, iv);
-        }
-        finishAction(c, o, t, s, d, vid, speed, dis, dlen, nd0, v, -1);
-    }
+    const PushJob push{q};
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) actionOne(c, o, tv, s, loadSlot(c, s), push);
 }
 
 // Second half of Vehicle::getIntersectionRelatedSpeed (vehicle.cpp:357-375): the walk over the crosses of the
