@@ -1,7 +1,6 @@
 """CPU: Archive (snapshot / load / dump / load_from_file), set_vehicle_speed, set_vehicle_route on the host + CPU twin,
 mirroring the reference's tests/python/test_archive.py and checked live against the unmodified reference engine.
 The same scenarios run on the HIP engine in tests/test_hip_api.py (-m gpu)."""
-import os
 import time
 
 import pytest

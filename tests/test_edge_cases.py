@@ -1,13 +1,10 @@
 """CPU: edge cases against the unmodified reference engine (oracle/_ref), on the host + CPU twin:
 empty / windowed / invalid flows, non-unit simulation interval, laneLinks without explicit points (generated curves),
 getters before the first step, push_vehicle defaults."""
-import gzip
 import json
 import os
 import subprocess
 import time
-
-import pytest
 
 from conftest import REF_DIR, TWIN_LIB, checkpoint_record
 

@@ -3,7 +3,7 @@ import time
 
 import pytest
 
-from conftest import TWIN_LIB, assert_same_state, checkpoint_record
+from conftest import TWIN_LIB, checkpoint_record
 from test_archive_and_control import archive_roundtrips, control_script, run
 
 pytestmark = pytest.mark.gpu

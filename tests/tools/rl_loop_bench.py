@@ -8,7 +8,7 @@ sys.argv = [sys.argv[0]]
 import json
 import numpy as np
 import bench
-from cityflow_amd import _cityflow, scenarios
+from cityflow_amd import _cityflow
 cfg0 = bench.build_workload("/tmp/cfa_rl", 0)
 c = json.load(open(cfg0)); c["rlTrafficLight"] = True
 cfg = cfg0.replace(".json", "_rl.json"); json.dump(c, open(cfg, "w"))
