@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--backend-lib", default="", help=argparse.SUPPRESS)
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of one tiled network")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1: tile the N=1 workload itself (30x30, BASELINE.json configs[3]) instead of growing the grid with N")
     ap.add_argument("--tile-block", type=int, default=30, help=argparse.SUPPRESS)
     args = ap.parse_args()
     on_gpu = args.backend_lib == ""
@@ -193,10 +195,16 @@ def main():
         from cityflow_amd.tiled import DistributedEngine
         rows, cols = tile_grid(world)
         workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_tiled")
-        if rank == 0:  # one node: every rank reads the files rank 0 wrote
-            cfg = build_tiled_workload(workdir, rows, cols, args.tile_block, args.extra_flows)
-        barrier()
-        cfg = os.path.join(workdir, "gen_%dx%d" % (args.tile_block * rows, args.tile_block * cols), "config_bench.json")
+        if args.strong:  # the very workload of the N=1 run, cut into rows x cols tiles
+            if rank == 0:
+                build_workload(workdir, seed=0, scenario=args.scenario, n_extra=args.extra_flows)
+            barrier()
+            cfg = build_workload(workdir, seed=0, scenario=args.scenario, n_extra=args.extra_flows)
+        else:
+            if rank == 0:  # one node: every rank reads the files rank 0 wrote
+                build_tiled_workload(workdir, rows, cols, args.tile_block, args.extra_flows)
+            barrier()
+            cfg = os.path.join(workdir, "gen_%dx%d" % (args.tile_block * rows, args.tile_block * cols), "config_bench.json")
         # Probe the halo transports on this machine before committing to one: GPU-written mailboxes first, the staged
         # gloo exchange second; a transport counts only if EVERY rank ran a few steps on it without an error.
         for mailboxes in (True, False):
@@ -309,10 +317,12 @@ def main():
         out = {
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (tiled and args.strong) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "steps_per_sec": args.steps * (1 if tiled else world) / elapsed,
             "config": {
-                "workload": ("grid_%dx%d (generator-format grid, --tlPlan, interval 1.0) + %d seeded interior flows "
+                "workload": ("%s + %d seeded interior flows cut into %dx%d tiles, one tile per GPU, one-lane ghost halo "
+                             "exchanged every step" % (args.scenario, args.extra_flows, rows, cols)) if (tiled and args.strong) else
+                            ("grid_%dx%d (generator-format grid, --tlPlan, interval 1.0) + %d seeded interior flows "
                              "(1 veh / %.0f s each until t=%d s); one network, %dx%d tiles of %dx%d intersections, one "
                              "tile per GPU, one-lane ghost halo exchanged every step" % (
                                  args.tile_block * rows, args.tile_block * cols, args.extra_flows * world, EXTRA_INTERVAL,
