@@ -73,7 +73,7 @@ struct cfx_engine {
     ActionBuf ab{};
     CompactScratch cs{};
     int32_t *oldToNew = nullptr;
-    int32_t *finList = nullptr, *finSorted = nullptr, *crossJobs = nullptr, *jobCount = nullptr;
+    int32_t *finList = nullptr, *finTicket = nullptr, *crossJobs = nullptr, *jobCount = nullptr;
     // getter scratch
     int32_t *viewLeader = nullptr;
     double *viewGap = nullptr;
@@ -130,9 +130,12 @@ struct cfx_engine {
     std::vector<MailPeer> mail;
     std::vector<int32_t> hGhostSendOff, hGhostRecvOff, hImportSendOff, hImportRecvOff;
     int32_t *haloTicket = nullptr;
+    double *finTerm = nullptr;  // [slot] travel times of the step's finishers in summation order
     HaloDev haloMail{};                // block addressing as (peer, offset inside the peer's message)
     uint32_t generation = 1;           // bumped by cfx_reset: epochs stay monotonic
-    int64_t liveUpper = 0;             // tiled: upper bound of occupied slots (refreshed from the device when it runs out)
+    int64_t liveUpper = 0;             // upper bound of running vehicles (refreshed from the device when it runs out)
+    std::vector<uint8_t> laneQueued;   // lanes that have ever had a vehicle queued (only they can admit)
+    int64_t nQueueLanes = 0, spawnedHere = 0;  // ... their number; vehicles spawned onto this engine's lanes
 
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
@@ -285,7 +288,7 @@ struct cfx_engine {
         GROW_SCRATCH(o.vid) GROW_SCRATCH(o.drv) GROW_SCRATCH(o.prevDrv) GROW_SCRATCH(o.next) GROW_SCRATCH(o.blocker) GROW_SCRATCH(o.enterLLT)
         GROW_SCRATCH(o.routePos) GROW_SCRATCH(o.templ) GROW_SCRATCH(o.route) GROW_SCRATCH(o.flags) GROW_SCRATCH(o.dis) GROW_SCRATCH(o.speed)
         GROW_SCRATCH(ab.dis) GROW_SCRATCH(ab.speed) GROW_SCRATCH(ab.drv) GROW_SCRATCH(ab.blocker)
-        GROW_SCRATCH(cs.inNext) GROW_SCRATCH(finList) GROW_SCRATCH(finSorted) GROW_SCRATCH(viewLeader) GROW_SCRATCH(viewGap)
+        GROW_SCRATCH(cs.inNext) GROW_SCRATCH(finList) GROW_SCRATCH(finTerm) GROW_SCRATCH(viewLeader) GROW_SCRATCH(viewGap)
         if ((rc = grow(&crossJobs, 0, nc * kJobShards))) return rc;
 #undef GROW_SCRATCH
         if ((rc = grow(&oldToNew, keep, nc))) return rc;  // committed blockers point through it
@@ -337,6 +340,11 @@ struct cfx_engine {
     int resetState() {
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
+        if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
+        laneQueued.assign((size_t) L, 0);
+        nQueueLanes = 0;
+        spawnedHere = 0;
+        liveUpper = 0;
         generation += 1;
         cur = 0;
         step = 0;
@@ -472,6 +480,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
     HIP_TRY(hipHostMalloc((void **) &e->hMirror, sizeof(HostMirror), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &e->hLaneOut, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
+    if ((rc = e->allocRaw(&e->finTicket, 1))) return rc;
+    HIP_TRY(hipMemset(e->finTicket, 0, sizeof(int32_t)));
     if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->laneTail, (size_t) e->L))) return rc;
@@ -602,28 +612,42 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->stageBusy[si] = true;
         e->spawned += n;
     }
-    // ---- slot capacity: live vehicles <= spawned - finished; plus one spare per lane
-    size_t need;
-    if (!e->tiled) {
-        need = (size_t) (e->spawned - (e->finishedKnown - e->finishedOffset)) + (size_t) e->L + 1;
-        if (need > e->slotCap) {
-            DevScalars s;
-            if ((rc = e->readScalars(s))) return rc;  // refresh finishedKnown
-            need = (size_t) (e->spawned - (e->finishedKnown - e->finishedOffset)) + (size_t) e->L + 1;
-            if ((rc = e->ensureSlotCap(need))) return rc;
+    // ---- slot capacity.  Two host-side upper bounds of the vehicles that can be running after this step:
+    //   (a) spawned - finished (as of the last read)           — tight while nobody queues for long;
+    //   (b) running (as of the last read) + what can have been admitted since: at most one vehicle per step on every
+    //       lane that has ever had a vehicle queued, plus halo migrants — stays small when entry lanes saturate and the
+    //       waiting queues grow without bound (they hold vehicle-table entries, not slots).
+    // When the smaller of the two outgrows the buffers, the true count is read back and the buffers grow only if needed.
+    for (int i = 0; i < n; ++i) {
+        const int lane = recs[i].lane;
+        if (lane >= 0 && !e->laneQueued[lane]) {
+            e->laneQueued[lane] = 1;
+            e->nQueueLanes += 1;
         }
-    } else {
-        // a tile sees every spawn record but runs only its own vehicles: bound = vehicles known to be here + what
-        // may have arrived since (local spawns, halo migrants), refreshed from the device when it runs out
-        for (int i = 0; i < n; ++i) e->liveUpper += recs[i].lane >= 0;
-        need = (size_t) (e->liveUpper + e->spareTotal) + 1;
-        if (need > e->slotCap) {
-            DevScalars s;
-            if ((rc = e->readScalars(s))) return rc;
-            e->liveUpper = s.active + 2 * (int64_t) e->halo.nGhost + n;
-            need = (size_t) (e->liveUpper + e->spareTotal) + 1;
-            if ((rc = e->ensureSlotCap(need))) return rc;
+        e->spawnedHere += lane >= 0;
+    }
+    e->liveUpper += e->nQueueLanes;
+    const int64_t spare = e->tiled ? e->spareTotal : (int64_t) e->L;
+    auto bound = [e]() {
+        const int64_t a = e->spawnedHere - (e->finishedKnown - e->finishedOffset);
+        return e->tiled ? e->liveUpper : std::min(a, e->liveUpper);
+    };
+    size_t need = (size_t) (bound() + spare) + 1;
+    if (need > e->slotCap && !e->tiled) {
+        // the device's own count as of the last step it has completed, read without waiting for it
+        const unsigned long long pr = __atomic_load_n(&e->hMirror->progress, __ATOMIC_RELAXED);
+        const int64_t done = (int64_t) (pr >> 32);
+        if (done > 0 && done <= e->step) {
+            e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + e->nQueueLanes * (e->step + 1 - done));
+            need = (size_t) (bound() + spare) + 1;
         }
+    }
+    if (need > e->slotCap) {
+        DevScalars s;
+        if ((rc = e->readScalars(s))) return rc;  // refreshes finishedKnown too
+        e->liveUpper = s.active + 2 * (int64_t) e->halo.nGhost + e->nQueueLanes;
+        need = (size_t) (bound() + spare) + 1;
+        if ((rc = e->ensureSlotCap(need))) return rc;
     }
 
     StepCtx c = e->ctx();
@@ -652,11 +676,13 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               e->scanGranules, scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
               e->gen[nxt].drv, e->sc, e->net.laneSpare, (const int32_t *) e->admitStep, (int) e->step, e->waitHead, e->vt,
               e->net.laneGhost, (const int2 *) e->admitRec);
+    // finish statistics: one extra block per 64 k slots (a rank sort of the step's finishers, see finishStatistics)
+    const int nStat = (int) std::min<size_t>(std::max<size_t>(1, slotBound >> 16), 64);
     e->launch(PK_SCATTER, k_scatter,
-              dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + 1), dim3(kBlock), c, e->ab,
+              dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, e->ab,
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
-              e->finSorted, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror);
+              e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat);
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;
@@ -1096,6 +1122,13 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     HIP_TRY(up(e->sc, &sc, sizeof sc));
     e->step = s->step;
     e->spawned = nV;
+    e->spawnedHere = nV;
+    e->liveUpper = nR;
+    for (int i = 0; i < s->n_waiting; ++i)
+        if (!e->laneQueued[s->w_lane[i]]) {
+            e->laneQueued[s->w_lane[i]] = 1;
+            e->nQueueLanes += 1;
+        }
     e->finishedKnown = s->finished_vehicle_count;
     {
         int64_t inTable = 0;

@@ -55,6 +55,9 @@ struct HostMirror {  // pinned host copy of the end-of-step scalars (written by 
     DevScalars sc;
     int32_t slots;  // segStart[D] of the new generation
     int32_t pad;
+    // (steps completed << 32) | running vehicles, one 8-byte store: the host may read it WITHOUT synchronising (a
+    // possibly stale but never torn lower bound of progress) to refresh its slot-capacity bound
+    unsigned long long progress;
 };
 
 // Per-drivable scratch of the compaction.
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(kCross2Block) void k_cross2(StepCtx c, ActionOut o,
 // (MI355X guide, Guideline 16 form R2: the data is the flag).
 constexpr int kScanItems = 8;                       // drivables per thread
 constexpr int kScanTile = kBlock * kScanItems;      // drivables per tile
-constexpr int kFinLds = 2048;                       // finished vehicles per step staged in LDS
+constexpr int kFinLds = 1024;                       // finished vehicles staged in LDS at a time
 constexpr unsigned kSpinLimit = 1u << 26;
 constexpr int kScanResidentTiles = 512;             // tiles (256-thread blocks, 28 VGPRs) that are certainly co-resident
 
@@ -806,48 +809,66 @@ __device__ inline int blockReduceSum(int v, int *smem) {
 // drivables in RoadNet order, lists front to back, i.e. ascending slot; engine.cpp:296-310): rank sort of the
 // finished slots in LDS, then one thread adds the travel times in that order (FP64 addition is not
 // associative; the reference adds sequentially).  Executed by one whole block.
-__device__ inline void finishStatistics(const StepCtx &c, const VidTable &vt, DevScalars *sc, const int32_t *finList,
-                                        int32_t *finSorted, int finCap) {
+__device__ inline bool finishStatistics(const StepCtx &c, const VidTable &vt, DevScalars *sc, const int32_t *finList,
+                                        double *finTerm, int finCap, int32_t *finTicket, int part, int nParts) {
     __shared__ int fin[kFinLds];
     __shared__ double term[kFinLds];
+    __shared__ int lastShared;
     int F = sc->nFinishedStep;
     if (F > finCap) F = finCap;
     const double now = c.step * c.interval;  // Engine::getCurrentTime engine.cpp:678-680
-    if (F <= kFinLds) {
-        for (int i = threadIdx.x; i < F; i += blockDim.x) fin[i] = finList[i];
-        __syncthreads();
-        for (int i = threadIdx.x; i < F; i += blockDim.x) {
-            int me = fin[i];
-            int rank = 0;
-            for (int j = 0; j < F; ++j) rank += fin[j] < me;
-            term[rank] = now - vt.enterTime[c.s.vid[me]];
+    // this block ranks finishers [lo, hi); every block walks the whole list, chunk by chunk through LDS
+    const bool inLds = nParts == 1 && F <= kFinLds;  // the common case never leaves the block
+    const int per = (F + nParts - 1) / nParts;
+    const int lo = part * per, hi = min(F, lo + per);
+    for (int base = lo; base < hi; base += blockDim.x) {
+        const int i = base + (int) threadIdx.x;
+        const int me = i < hi ? finList[i] : 0;
+        int rank = 0;
+        for (int cb = 0; cb < F; cb += kFinLds) {
+            const int cn = min(kFinLds, F - cb);
+            __syncthreads();
+            for (int j = threadIdx.x; j < cn; j += blockDim.x) fin[j] = finList[cb + j];
+            __syncthreads();
+            if (i < hi)
+                for (int j = 0; j < cn; ++j) rank += fin[j] < me;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double cum = sc->cumulativeTravelTime;
-            for (int i = 0; i < F; ++i) cum += term[i];
-            sc->cumulativeTravelTime = cum;
-        }
-    } else {  // more finishers in one step than the LDS staging holds: same algorithm through global memory
-        for (int i = threadIdx.x; i < F; i += blockDim.x) {
-            int me = finList[i];
-            int rank = 0;
-            for (int j = 0; j < F; ++j) rank += finList[j] < me;
-            finSorted[rank] = me;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double cum = sc->cumulativeTravelTime;
-            for (int i = 0; i < F; ++i) cum += now - vt.enterTime[c.s.vid[finSorted[i]]];
-            sc->cumulativeTravelTime = cum;
+        if (i < hi) {
+            const double t = now - vt.enterTime[c.s.vid[me]];
+            if (inLds) term[rank] = t;
+            else finTerm[rank] = t;
         }
     }
+    bool last = true;
+    if (nParts > 1) {  // the block that arrives last adds up
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) lastShared = atomicAdd(finTicket, 1) == nParts - 1;
+        __syncthreads();
+        last = lastShared != 0;
+        if (!last) return false;
+        if (threadIdx.x == 0) *finTicket = 0;
+        __threadfence();
+    }
+    double cum = sc->cumulativeTravelTime;
+    for (int cb = 0; cb < F; cb += kFinLds) {
+        const int cn = min(kFinLds, F - cb);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cn && !inLds; j += blockDim.x)
+            term[j] = __longlong_as_double((long long) __hip_atomic_load((const unsigned long long *) &finTerm[cb + j],
+                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int j = 0; j < cn; ++j) cum += term[j];
+    }
     if (threadIdx.x == 0) {
+        sc->cumulativeTravelTime = cum;
         sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
         sc->finishedCnt += F;
         sc->active -= F;
         sc->nFinishedStep = 0;
     }
+    return last;
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cnt, CompactScratch cs,
@@ -978,23 +999,27 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
 // lights (TrafficLight::passTime trafficlight.cpp:29-37) and clear the active-laneLink masks.
 __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
-                          int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, int32_t *finSorted,
-                          int finCap, int32_t *jobCount, HostMirror *hostMirror) {
-    // The launch carries one extra block that only does the step's finish statistics (it reads just the current
+                          int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, double *finTerm,
+                          int finCap, int32_t *jobCount, HostMirror *hostMirror, int32_t *finTicket, int nStatBlocks) {
+    // The launch carries extra blocks that only do the step's finish statistics (they read just the current
     // generation and the finish list, both complete before this kernel starts), in parallel with the compaction.
-    if (blockIdx.x == gridDim.x - 1) {
-        finishStatistics(c, vt, sc, finList, finSorted, finCap);
-        if (threadIdx.x < kJobShards) jobCount[threadIdx.x * kJobShardStride] = 0;  // k_cross of this step is done
-        if (threadIdx.x == 0 && hostMirror) {
+    const int nBody = (int) gridDim.x - nStatBlocks;
+    if ((int) blockIdx.x >= nBody) {
+        const int part = (int) blockIdx.x - nBody;
+        if (part == 0 && threadIdx.x < kJobShards) jobCount[threadIdx.x * kJobShardStride] = 0;  // k_cross of this step is done
+        const bool last = finishStatistics(c, vt, sc, finList, finTerm, finCap, finTicket, part, nStatBlocks);
+        if (last && threadIdx.x == 0 && hostMirror) {
             // the step's scalars and slot count, also left in pinned host memory: a getter then needs the stream
             // synchronisation only, not a device-to-host copy on top of it
             hostMirror->sc = *sc;
             hostMirror->slots = segStartNext[c.n.L + c.n.K];
+            __hip_atomic_store(&hostMirror->progress, ((unsigned long long) (c.step + 1) << 32) | (unsigned) sc->active,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = (gridDim.x - 1) * blockDim.x;
+    const int stride = nBody * blockDim.x;
     if (gid == 0 && scanTicket) *scanTicket = 0;  // k_scan of this step is done; re-arm it for the next one
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
     if (!rlTrafficLight) {

@@ -436,6 +436,8 @@ PYBIND11_MODULE(_cityflow, m) {
             },
             "config_file"_a, "num_envs"_a, "thread_num"_a, "backend_library"_a)
         .def_property_readonly("num_envs", &VectorEngineHost::numEnvs)
+        .def("_host_seconds", &VectorEngineHost::hostSeconds,
+             "[spawners, record translation, cfx_step] cumulative host wall seconds since the last reset")
         .def("next_step", &VectorEngineHost::nextStep)
         .def("reset", &VectorEngineHost::reset, "seed"_a = false)
         .def("get_current_time", &VectorEngineHost::getCurrentTime)
@@ -474,6 +476,7 @@ PYBIND11_MODULE(_cityflow, m) {
             d["finished_vehicle_count"] = s.finished_vehicle_count;
             d["spawned_vehicle_count"] = s.spawned_vehicle_count;
             d["vehicle_steps"] = s.vehicle_steps;
+            d["cumulative_travel_time"] = s.cumulative_travel_time;
             return d;
         });
 

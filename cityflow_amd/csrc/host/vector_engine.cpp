@@ -1,5 +1,8 @@
 #include "vector_engine.h"
 
+#include <algorithm>
+#include <chrono>
+
 #include <iostream>
 #include <stdexcept>
 
@@ -145,6 +148,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     for (int r = 0; r < R_; ++r) {
         Spawner *sp = spawners_[r].get();
         sp->setFinishedQuery([this, r](int localVid) {
+            std::lock_guard<std::mutex> guard(queryMutex_);  // rare (priority collision); the ABI is not re-entrant
             uint8_t st = 0;
             check(be_.cfx_get_vehicle_status(dev_, localToGlobal_[r][localVid], 1, &st), "cfx_get_vehicle_status");
             return st == 2;
@@ -167,7 +171,102 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
 }
 
 VectorEngineHost::~VectorEngineHost() {
+    {
+        std::lock_guard<std::mutex> guard(poolMutex_);
+        poolStop_ = true;
+    }
+    poolCv_.notify_all();
+    for (std::thread &t : workers_) t.join();
     if (dev_) be_.cfx_destroy(dev_);
+}
+
+// ---------------------------------------------------------------- host threads for the R spawners
+void VectorEngineHost::runEnvs() {
+    for (;;) {
+        const int r = nextEnv_.fetch_add(1, std::memory_order_acq_rel);  // pairs with the release store that opens a batch
+        if (r >= R_) return;
+        try {
+            (this->*poolFn_)(r);
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> guard(poolMutex_);
+            if (poolError_.empty()) poolError_ = e.what();
+        }
+        envsDone_.fetch_add(1, std::memory_order_release);
+    }
+}
+
+void VectorEngineHost::workerLoop() {
+    uint64_t seen = 0;
+    for (;;) {
+        // While the engine is being stepped the next batch arrives within microseconds: poll for a moment before
+        // going to sleep on the condition variable (a wake-up through the kernel costs tens of microseconds).
+        bool got = false;
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+        while (std::chrono::steady_clock::now() < until) {
+            if (poolGeneration_.load(std::memory_order_acquire) != seen) {
+                got = true;
+                break;
+            }
+            std::this_thread::yield();
+        }
+        if (!got) {
+            std::unique_lock<std::mutex> lock(poolMutex_);
+            poolCv_.wait(lock, [&] { return poolStop_ || poolGeneration_.load(std::memory_order_acquire) != seen; });
+            if (poolStop_) return;
+        }
+        seen = poolGeneration_.load(std::memory_order_acquire);
+        runEnvs();
+    }
+}
+
+void VectorEngineHost::forEachEnv(void (VectorEngineHost::*fn)(int)) {
+    static const bool serial = [] {
+        const char *v = getenv("CFX_VEC_THREADS");
+        return v && v[0] == '0';
+    }();
+    if (R_ < 32 || serial) {  // a handful of environments: waking threads costs more than it saves
+        for (int r = 0; r < R_; ++r) (this->*fn)(r);
+        return;
+    }
+    if (workers_.empty()) {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = (int) std::min<unsigned>(std::min<unsigned>(hw > 2 ? hw / 2 : 1, 16u), (unsigned) R_ / 8);
+        for (int i = 0; i + 1 < n; ++i) workers_.emplace_back([this] { workerLoop(); });
+    }
+    poolFn_ = fn;
+    envsDone_.store(0, std::memory_order_relaxed);
+    nextEnv_.store(0, std::memory_order_release);  // a straggler of the previous batch may pick work up from here on
+    {
+        std::lock_guard<std::mutex> guard(poolMutex_);
+        poolGeneration_.fetch_add(1, std::memory_order_release);
+    }
+    poolCv_.notify_all();
+    runEnvs();  // the calling thread works too
+    while (envsDone_.load(std::memory_order_acquire) < R_) std::this_thread::yield();
+    if (!poolError_.empty()) {
+        std::string msg = poolError_;
+        poolError_.clear();
+        throw std::runtime_error(msg);
+    }
+}
+
+// phases 0-1 of one environment (its own mt19937 and flows)
+void VectorEngineHost::spawnEnv(int r) { spawners_[r]->step(step_, envRecs_[r]); }
+
+// an environment's records, renumbered into the device engine's index spaces, at their place in the batch
+void VectorEngineHost::translateEnv(int r) {
+    int32_t g = batchFirstVid_ + envBase_[r];
+    cfx_spawn *out = recs_.data() + envBase_[r];
+    std::vector<int32_t> &l2g = localToGlobal_[r];
+    for (cfx_spawn s : envRecs_[r]) {
+        l2g.push_back(g);  // local vids are dense per environment
+        globalToLocal_[g] = std::make_pair((int32_t) r, s.vid);
+        s.vid = g++;
+        s.lane += r * L_;
+        s.route += r * routesPerEnv_;
+        s.prev_wait = s.prev_wait >= 0 ? l2g[s.prev_wait] : -1;
+        *out++ = s;
+    }
 }
 
 void VectorEngineHost::check(int32_t rc, const char *what) {
@@ -177,24 +276,30 @@ void VectorEngineHost::check(int32_t rc, const char *what) {
 }
 
 void VectorEngineHost::nextStep() {
-    recs_.clear();
-    for (int r = 0; r < R_; ++r) {
-        Spawner &sp = *spawners_[r];
-        sp.step(step_, envRecs_);
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    envRecs_.resize((size_t) R_);
+    envBase_.resize((size_t) R_);
+    forEachEnv(&VectorEngineHost::spawnEnv);
+    const auto t1 = clk::now();
+    int32_t total = 0;
+    for (int r = 0; r < R_; ++r) {  // the device numbers vehicles in environment order
+        const Spawner &sp = *spawners_[r];
         if (sp.routes.count() != routesPerEnv_ || sp.templates.size() != spawners_[0]->templates.size())
             throw std::runtime_error("VectorEngine: dynamic routes/templates are not supported");
-        for (cfx_spawn s : envRecs_) {
-            int32_t g = (int32_t) globalToLocal_.size();
-            localToGlobal_[r].push_back(g);  // local vids are dense per environment
-            globalToLocal_.emplace_back(r, s.vid);
-            s.vid = g;
-            s.lane += r * L_;
-            s.route += r * routesPerEnv_;
-            s.prev_wait = s.prev_wait >= 0 ? localToGlobal_[r][s.prev_wait] : -1;
-            recs_.push_back(s);
-        }
+        envBase_[r] = total;
+        total += (int32_t) envRecs_[r].size();
     }
+    batchFirstVid_ = (int32_t) globalToLocal_.size();
+    globalToLocal_.resize(globalToLocal_.size() + (size_t) total);
+    recs_.resize((size_t) total);
+    forEachEnv(&VectorEngineHost::translateEnv);
+    const auto t2 = clk::now();
     check(be_.cfx_step(dev_, recs_.data(), (int32_t) recs_.size()), "cfx_step");
+    const auto t3 = clk::now();
+    hostSpawnSec_ += std::chrono::duration<double>(t1 - t0).count();
+    hostTranslateSec_ += std::chrono::duration<double>(t2 - t1).count();
+    hostSubmitSec_ += std::chrono::duration<double>(t3 - t2).count();
     step_ += 1;
 }
 
@@ -204,6 +309,7 @@ void VectorEngineHost::reset(bool resetRnd) {
     for (auto &v : localToGlobal_) v.clear();
     globalToLocal_.clear();
     step_ = 0;
+    hostSpawnSec_ = hostTranslateSec_ = hostSubmitSec_ = 0;
 }
 
 std::vector<int32_t> VectorEngineHost::laneVehicleCounts() {

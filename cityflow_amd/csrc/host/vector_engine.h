@@ -7,8 +7,12 @@
 // (tests/test_vector_engine.py).
 #pragma once
 
+#include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine_host.h"
@@ -40,6 +44,8 @@ public:
     void profileEnable(bool on);
     std::map<std::string, std::pair<double, int64_t>> profileRead();
     std::string backendName() const { return be_.cfx_backend_name(); }
+    // cumulative host wall seconds since the last reset: {spawners, record translation, cfx_step (launches + back-pressure)}
+    std::vector<double> hostSeconds() const { return {hostSpawnSec_, hostTranslateSec_, hostSubmitSec_}; }
     // per-environment id-keyed view, for parity tests against a standalone Engine
     std::map<std::string, double> getVehicleSpeed(int env);
     std::map<std::string, int> getLaneVehicleCount(int env);
@@ -57,7 +63,27 @@ private:
     double interval_ = 1.0;
     bool rlTrafficLight_ = false;
     size_t step_ = 0;
-    std::vector<cfx_spawn> recs_, envRecs_;
+    std::vector<cfx_spawn> recs_;
+    std::vector<std::vector<cfx_spawn>> envRecs_;  // [env] this step's records in the environment's own numbering
+
+    // The R spawners are independent (own mt19937, own flows): phases 0-1 of all environments run on a small pool of
+    // host threads, the numbering of the new vehicles is then assigned serially in environment order.
+    void forEachEnv(void (VectorEngineHost::*fn)(int));  // fn(env) for every environment, on the pool from 32 envs on
+    void spawnEnv(int r);
+    void translateEnv(int r);
+    void workerLoop();
+    void runEnvs();
+    void (VectorEngineHost::*poolFn_)(int) = nullptr;
+    std::vector<int32_t> envBase_;  // [env] offset of the environment's records in this step's batch
+    int32_t batchFirstVid_ = 0;
+    double hostSpawnSec_ = 0, hostTranslateSec_ = 0, hostSubmitSec_ = 0;
+    std::vector<std::thread> workers_;
+    std::mutex poolMutex_, queryMutex_;
+    std::condition_variable poolCv_;
+    std::atomic<uint64_t> poolGeneration_{0};
+    bool poolStop_ = false;
+    std::atomic<int> nextEnv_{0}, envsDone_{0};
+    std::string poolError_;
 };
 
 }  // namespace cfa

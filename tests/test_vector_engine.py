@@ -50,6 +50,13 @@ def test_vector_engine_twin_rl(mod, scen, workdir):
            lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), name="grid_6x6", envs=2, steps=60, rl=True)
 
 
+def test_vector_engine_threaded_spawners_twin(mod, scen, workdir):
+    """40 environments: spawners and record translation run on the host thread pool (used from 32 environments on); every
+    environment still equals its standalone engine."""
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine._with_backend(c, n, 1, TWIN_LIB),
+           lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), envs=40, steps=100)
+
+
 def test_vector_engine_reset(mod, scen, workdir):
     vec = mod.VectorEngine._with_backend(scen.materialize("example_1x1", workdir), 2, 1, TWIN_LIB)
     for _ in range(60):
@@ -72,3 +79,24 @@ def test_vector_engine_hip(mod, scen, workdir):
 def test_vector_engine_hip_rl(mod, scen, workdir):
     _check(mod, scen, workdir, lambda c, n: mod.VectorEngine(c, n, 1), lambda c: mod.Engine(c, 1), name="grid_6x6",
            envs=3, steps=80, rl=True)
+
+
+@pytest.mark.gpu
+def test_vector_engine_hip_many_finishers(mod, scen, workdir):
+    """96 environments of the 6x6 grid (identical flows, so their vehicles finish in the same steps): > 1024 vehicles
+    finish per step from step 391 on, so the step's finish statistics (travel times
+    added in the reference's order, engine.cpp:296-310) run as several blocks; the sum stays bit-identical to the twin."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    hip, twin = mod.VectorEngine(cfg, 96, 1), mod.VectorEngine._with_backend(cfg, 96, 1, TWIN_LIB)
+    prev, biggest = 0, 0
+    for s in range(402):
+        hip.next_step()
+        twin.next_step()
+        if s % 20 == 19 or s >= 388:
+            a, b = hip._scalars(), twin._scalars()
+            assert a == b, (s, a, b)
+            if s > 388:  # compared every step there: finishers of ONE step
+                biggest = max(biggest, a["finished_vehicle_count"] - prev)
+            prev = a["finished_vehicle_count"]
+    assert biggest > 1024
+    assert np.array_equal(hip.get_lane_vehicle_count_array(), twin.get_lane_vehicle_count_array())

@@ -7,7 +7,9 @@ rs = [int(x) for x in sys.argv[1:]] or [1, 4, 8]
 sys.argv = [sys.argv[0]]
 import bench
 from cityflow_amd import _cityflow
-cfg = bench.build_workload("/tmp/cfa_vec", 0)
+# default: the bench.py workload; CFX_VEC_SCENARIO=grid_6x6 CFX_VEC_EXTRA=0 gives the stock small grid RL work uses
+cfg = bench.build_workload("/tmp/cfa_vec", 0, scenario=os.environ.get("CFX_VEC_SCENARIO", "grid_30x30"),
+                           n_extra=int(os.environ.get("CFX_VEC_EXTRA", bench.N_EXTRA_FLOWS)))
 for R in rs:
     t0 = time.perf_counter()
     eng = _cityflow.VectorEngine(cfg, R, 1)
@@ -17,11 +19,13 @@ for R in rs:
     eng.sync()
     s0 = eng._scalars()
     K = 100
+    h0 = eng._host_seconds()
     t0 = time.perf_counter()
     for _ in range(K):
         eng.next_step()
     eng.sync()
     dt = time.perf_counter() - t0
+    h1 = eng._host_seconds()
     s1 = eng._scalars()
     eng._profile_enable(True)
     for _ in range(50):
@@ -37,5 +41,6 @@ for R in rs:
                       "env_steps_per_sec": K * R / dt, "vehicle_steps_per_sec": vs / dt,
                       "k_action_us": act_ms / act_n * 1e3, "k_action_GBps": gbs, "k_action_frac_of_8TBps": gbs / 8000.0,
                       "kernel_us": {k: round(ms / max(n, 1) * 1e3, 1) for k, (ms, n) in prof.items()},
+                      "host_us_per_step": {k: round((b - a) / K * 1e6, 1) for k, a, b in zip(("spawn", "translate", "submit"), h0, h1)},
                       "load_s": round(t_load, 1)}), flush=True)
     del eng
