@@ -537,7 +537,7 @@ int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
         return CFX_ERR_INVALID;
     }
     if (cfg->lane_change) {
-        g_createError = "cfx_create: lane_change is not supported by ABI version 1";
+        g_createError = "cfx_create: lane change (cfx_config::lane_change) is not built on the HIP path yet; the step it needs is specified by the CPU twin (oracle/twin) and include/cityflow_amd.h";
         return CFX_ERR_INVALID;
     }
     cfx_engine *e = new cfx_engine();
@@ -583,7 +583,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
 
     // ---- phase 0/1 tail: hand the spawn records to the device
     if (n > 0) {
-        if (recs[0].vid != e->spawned) return e->fail("cfx_step: spawn records must continue the dense vid sequence");
+        // the batch carries the next n vehicle numbers, each once, in any order (checked in full by the CPU twin)
+        if (recs[0].vid < e->spawned || recs[0].vid >= e->spawned + n)
+            return e->fail("cfx_step: spawn records must continue the dense vid sequence");
         if ((rc = e->ensureVidCap((size_t) e->spawned + n))) return rc;
         if ((size_t) n > e->recCap) {
             size_t nc = std::max<size_t>((size_t) n * 2, 1024);
@@ -887,6 +889,10 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
         if (view->dis) view->dis[i] = dis[s];
         if (view->speed) view->speed[i] = speed[s];
         if (view->gap) view->gap[i] = gap[s];
+        if (view->lc_partner_vid) view->lc_partner_vid[i] = -1;  // lane change is not on the device path (cfx_create)
+        if (view->lc_flags) view->lc_flags[i] = 0;
+        if (view->lc_offset) view->lc_offset[i] = 0.0;
+        if (view->lc_last_dir) view->lc_last_dir[i] = 0;
         ++i;
     }
     return CFX_OK;
@@ -996,6 +1002,17 @@ int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *dri
     if (routePos) *routePos = st == 1 ? found[1] : -1;
     if (route) *route = r;
     return CFX_OK;
+}
+
+// Lane change (reference lanechange.cpp) is not built on the device path yet: cfx_create refuses lane_change = 1, so
+// these two can only report that.
+int32_t cfx_lane_change_supply(cfx_engine *e, int32_t, const int32_t *) {
+    if (!e) return CFX_ERR_INVALID;
+    return e->fail("cfx_lane_change_supply: this engine was created without lane change"), CFX_ERR_STATE;
+}
+int32_t cfx_lane_change_poll(cfx_engine *e, int32_t, int32_t *, int32_t *) {
+    if (!e) return CFX_ERR_INVALID;
+    return e->fail("cfx_lane_change_poll: this engine was created without lane change"), CFX_ERR_STATE;
 }
 
 int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {

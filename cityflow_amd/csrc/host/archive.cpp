@@ -208,6 +208,7 @@ void Archive::dump(const std::string &path) const {
 
 // ------------------------------------------------------------------------------------------ EngineHost side
 Archive EngineHost::snapshot() {
+    if (laneChange_) throw std::runtime_error("snapshot: not available with laneChange=true yet (lane-change state is not archived)");
     Archive a;
     a.host = spawner_.saveState();
     a.net = net_;
@@ -244,6 +245,7 @@ Archive EngineHost::snapshot() {
 }
 
 void EngineHost::load(const Archive &a) {
+    if (laneChange_) throw std::runtime_error("load: not available with laneChange=true yet (lane-change state is not archived)");
     pendingPhaseInter_.clear();
     pendingPhaseValue_.clear();
     if (a.net.get() != net_.get() && a.net->lanes.size() != net_->lanes.size())

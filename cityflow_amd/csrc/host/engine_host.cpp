@@ -57,6 +57,8 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_get_vehicle)
     CFX_FN(cfx_load_state)
     CFX_FN(cfx_get_custom_speeds)
+    CFX_FN(cfx_lane_change_supply)
+    CFX_FN(cfx_lane_change_poll)
     CFX_FN(cfx_halo_config)
     CFX_FN(cfx_halo_export)
     CFX_FN(cfx_halo_import)
@@ -127,15 +129,11 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
-    if (laneChange_)
-        throw std::runtime_error(
-            "cityflow_amd: laneChange=true is not implemented yet on the device path (SURVEY.md §8f row 3)");
-
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
     cfx_config cc{};
     cc.interval = interval_;
     cc.rl_traffic_light = rlTrafficLight_ ? 1 : 0;
-    cc.lane_change = 0;
+    cc.lane_change = laneChange_ ? 1 : 0;
     cc.device = 0;
     if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);
     if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) cc.device = atoi(dev);
@@ -213,7 +211,19 @@ void EngineHost::nextStep() {
     flushPhases();
     spawner_.step(step_, spawnBuf_);
     uploadNewTablesIfAny();
+    if (laneChange_) {  // the priorities this step's shadows would draw, after the step's own spawn draws
+        spawner_.peekShadowPriorities(shadowPoolSize_, shadowPool_);
+        check(be_.cfx_lane_change_supply(dev_, (int32_t) shadowPool_.size(), shadowPool_.data()), "cfx_lane_change_supply");
+    }
     check(be_.cfx_step(dev_, spawnBuf_.data(), (int32_t) spawnBuf_.size()), "cfx_step");
+    if (laneChange_) {
+        shadowParents_.resize((size_t) shadowPoolSize_);
+        int32_t k = 0;
+        check(be_.cfx_lane_change_poll(dev_, shadowPoolSize_, shadowParents_.data(), &k), "cfx_lane_change_poll");
+        shadowParents_.resize((size_t) k);
+        spawner_.commitShadows(shadowParents_);
+        if (4 * k > shadowPoolSize_) shadowPoolSize_ = 8 * k;  // stay well clear of the step's demand
+    }
     if (saveReplay_) updateLog();
     step_ += 1;
 }
@@ -333,13 +343,21 @@ void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
     want(kSnapDis, s.dis, v.dis);
     want(kSnapSpeed, s.speed, v.speed);
     want(kSnapGap, s.gap, v.gap);
+    if (laneChange_) fields |= kSnapLaneChange;  // ids depend on the shadow flag
+    want(kSnapLaneChange, s.lcPartner, v.lc_partner_vid);
+    want(kSnapLaneChange, s.lcFlags, v.lc_flags);
+    want(kSnapLaneChange, s.lcOffset, v.lc_offset);
+    want(kSnapLaneChange, s.lcLastDir, v.lc_last_dir);
     check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
     s.count = v.count;
     s.vid.resize(v.count);
     for (auto *vec : {&s.drivable, &s.prevDrivable, &s.leader, &s.blocker, &s.enterLLTime, &s.routePos})
         if (!vec->empty()) vec->resize(v.count);
-    for (auto *vec : {&s.dis, &s.speed, &s.gap})
+    for (auto *vec : {&s.dis, &s.speed, &s.gap, &s.lcOffset})
         if (!vec->empty()) vec->resize(v.count);
+    for (auto *vec : {&s.lcPartner, &s.lcLastDir})
+        if (!vec->empty()) vec->resize(v.count);
+    if (!s.lcFlags.empty()) s.lcFlags.resize(v.count);
 }
 
 void EngineHost::waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane) {
@@ -358,7 +376,8 @@ std::vector<std::string> EngineHost::getVehicles(bool includeWaiting) {
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::vector<std::pair<int32_t, int32_t>> byPriority;
-    for (int i = 0; i < s.count; ++i) byPriority.emplace_back(spawner_.vehicles[s.vid[i]].priority, s.vid[i]);
+    for (int i = 0; i < s.count; ++i)  // Engine::getRunningVehicles engine.cpp:780-790 skips shadows (isReal)
+        if (!s.isShadow(i)) byPriority.emplace_back(spawner_.vehicles[s.vid[i]].priority, s.vid[i]);
     if (includeWaiting) {
         std::vector<int32_t> wv, wl;
         waitingVehicles(wv, wl);
@@ -378,7 +397,7 @@ std::map<std::string, std::vector<std::string>> EngineHost::getLaneVehicles() {
     const int L = (int) net_->lanes.size();
     std::vector<std::vector<std::string>> perLane(L);
     for (int i = 0; i < s.count; ++i)
-        if (s.drivable[i] < L) perLane[s.drivable[i]].push_back(spawner_.vehicleId(s.vid[i]));
+        if (s.drivable[i] < L) perLane[s.drivable[i]].push_back(spawner_.vehicleId(s.vid[i], s.isShadow(i)));
     for (int l = 0; l < L; ++l) ret.emplace(net_->laneId(l), std::move(perLane[l]));
     return ret;
 }
@@ -387,7 +406,8 @@ std::map<std::string, double> EngineHost::getVehicleSpeed() {
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, double> ret;
-    for (int i = 0; i < s.count; ++i) ret.emplace(spawner_.vehicleId(s.vid[i]), s.speed[i]);
+    for (int i = 0; i < s.count; ++i)
+        if (!s.isShadow(i)) ret.emplace(spawner_.vehicleId(s.vid[i]), s.speed[i]);  // getRunningVehicles: real vehicles only
     return ret;
 }
 
@@ -395,11 +415,29 @@ std::map<std::string, double> EngineHost::getVehicleDistance() {
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, double> ret;
-    for (int i = 0; i < s.count; ++i) ret.emplace(spawner_.vehicleId(s.vid[i]), s.dis[i]);
+    for (int i = 0; i < s.count; ++i)
+        if (!s.isShadow(i)) ret.emplace(spawner_.vehicleId(s.vid[i]), s.dis[i]);
     return ret;
 }
 
-int EngineHost::vidOf(const std::string &id) { return spawner_.vidOfId(id); }
+int EngineHost::vidOf(const std::string &id) {
+    if (!laneChange_) return spawner_.vidOfId(id);
+    // An id is carried by a chain of vehicles: the flow's vehicle, then each shadow that took it over when its lane change
+    // completed (LaneChange::finishChanging lanechange.cpp:115-127).  Of the chain at most two are alive: the holder of
+    // the id and, while it changes lane, its shadow "<id>_shadow".
+    const std::string suffix = "_shadow";
+    const bool wantShadow = id.size() > suffix.size() && id.compare(id.size() - suffix.size(), suffix.size(), suffix) == 0;
+    const int root = spawner_.vidOfId(wantShadow ? id.substr(0, id.size() - suffix.size()) : id);
+    if (root < 0) return -1;
+    std::vector<int32_t> alive;
+    for (int32_t v : spawner_.idChain(root)) {
+        uint8_t st = 2;
+        check(be_.cfx_get_vehicle_status(dev_, v, 1, &st), "cfx_get_vehicle_status");
+        if (st != 2) alive.push_back(v);
+    }
+    if (wantShadow) return alive.size() >= 2 ? alive[1] : -1;
+    return alive.empty() ? root : alive[0];
+}
 
 // getLeader engine.cpp:836-850
 std::string EngineHost::getLeader(const std::string &vehicleId) {
@@ -411,7 +449,20 @@ std::string EngineHost::getLeader(const std::string &vehicleId) {
     VehicleSnapshot s;
     snapshotVehicles(s);
     for (int i = 0; i < s.count; ++i)
-        if (s.vid[i] == vid) return s.leader[i] >= 0 ? spawner_.vehicleId(s.leader[i]) : "";
+        if (s.vid[i] == vid) {
+            if (s.isShadow(i) && s.lcPartner[i] >= 0) {  // engine.cpp:842-845: a shadow answers with its partner's leader
+                for (int j = 0; j < s.count; ++j)
+                    if (s.vid[j] == s.lcPartner[i]) {
+                        i = j;
+                        break;
+                    }
+            }
+            if (s.leader[i] < 0) return "";
+            bool shadow = false;
+            for (int j = 0; j < s.count && laneChange_; ++j)
+                if (s.vid[j] == s.leader[i]) shadow = s.isShadow(j);
+            return spawner_.vehicleId(s.leader[i], shadow);
+        }
     return "";
 }
 

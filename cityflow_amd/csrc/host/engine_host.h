@@ -48,6 +48,8 @@ struct Backend {
     CFX_FN(cfx_get_vehicle)
     CFX_FN(cfx_load_state)
     CFX_FN(cfx_get_custom_speeds)
+    CFX_FN(cfx_lane_change_supply)
+    CFX_FN(cfx_lane_change_poll)
     CFX_FN(cfx_halo_config)
     CFX_FN(cfx_halo_export)
     CFX_FN(cfx_halo_import)
@@ -66,13 +68,18 @@ struct Backend {
 // Per-vehicle state downloaded from the device, in Drivable::vehicles order.
 enum SnapshotField : unsigned {  // what snapshotVehicles should fetch besides the vehicle ids
     kSnapDrivable = 1, kSnapPrev = 2, kSnapLeader = 4, kSnapBlocker = 8, kSnapEnterLL = 16, kSnapRoutePos = 32,
-    kSnapDis = 64, kSnapSpeed = 128, kSnapGap = 256, kSnapAll = 511
+    kSnapDis = 64, kSnapSpeed = 128, kSnapGap = 256, kSnapAll = 511,
+    kSnapLaneChange = 512  // partner / flags / offset / lastDir (always fetched when the engine runs with laneChange)
 };
 
 struct VehicleSnapshot {
     std::vector<int32_t> vid, drivable, prevDrivable, leader, blocker, enterLLTime, routePos;
     std::vector<double> dis, speed, gap;
+    std::vector<int32_t> lcPartner, lcLastDir;  // lane change (empty unless kSnapLaneChange)
+    std::vector<uint8_t> lcFlags;               // CFX_LC_* bits
+    std::vector<double> lcOffset;
     int count = 0;
+    bool isShadow(int i) const { return !lcFlags.empty() && (lcFlags[i] & CFX_LC_SHADOW); }
 };
 
 class EngineHost {
@@ -130,7 +137,8 @@ public:
     const HostRoadNet &net() const { return *net_; }
     const Spawner &spawner() const { return spawner_; }
     std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
-    std::string vehicleId(int vid) const { return spawner_.vehicleId(vid); }
+    std::string vehicleId(int vid, bool shadow = false) const { return spawner_.vehicleId(vid, shadow); }
+    bool laneChange() const { return laneChange_; }
     int vidOf(const std::string &id);  // -1 if unknown
     double interval() const { return interval_; }
     size_t step() const { return step_; }
@@ -152,6 +160,8 @@ private:
     size_t step_ = 0;
     int templatesUploaded_ = 0, routesUploaded_ = 0;
     std::vector<cfx_spawn> spawnBuf_;
+    std::vector<int32_t> shadowPool_, shadowParents_;  // lane change: priorities offered to / parents reported by a step
+    int shadowPoolSize_ = 1024;
     std::vector<int32_t> pendingPhaseInter_, pendingPhaseValue_;  // set_tl_phase calls since the last flush
     void flushPhases();
     std::vector<int32_t> laneIdOrder_;

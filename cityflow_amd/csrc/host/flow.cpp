@@ -196,10 +196,59 @@ void Spawner::rebuildActiveFlows() {
     for (size_t i = 0; i < flows.size(); ++i) activeFlows_.push_back((int32_t) i);
 }
 
-std::string Spawner::vehicleId(int vid) const {
+std::string Spawner::vehicleId(int vid, bool shadow) const {
     const VehicleRecord &r = vehicles[vid];
-    if (r.flow >= 0) return flows[r.flow].id + "_" + std::to_string(r.number);
-    return "manually_pushed_" + std::to_string(r.number);
+    std::string id = r.flow >= 0 ? flows[r.flow].id + "_" + std::to_string(r.number)
+                                 : "manually_pushed_" + std::to_string(r.number);
+    return shadow ? id + "_shadow" : id;
+}
+
+void Spawner::peekShadowPriorities(int n, std::vector<int32_t> &out) {
+    std::mt19937 peek = rnd;
+    peekPriorities_.clear();
+    peekDraws_.clear();
+    int draws = 0;
+    for (int i = 0; i < n; ++i) {
+        int32_t priority;
+        for (;;) {  // `while (engine->checkPriority(priority = engine->rnd()));` vehicle.cpp:33
+            priority = (int32_t) peek();
+            ++draws;
+            if (std::find(peekPriorities_.begin(), peekPriorities_.end(), priority) != peekPriorities_.end()) continue;
+            int32_t *owner = livePriority_.find(priority);
+            if (!owner) break;
+            if (*owner >= 0 && isFinished_ && isFinished_(*owner)) {
+                livePriority_.erase(priority);
+                break;
+            }
+        }
+        peekPriorities_.push_back(priority);
+        peekDraws_.push_back(draws);
+    }
+    out = peekPriorities_;
+}
+
+void Spawner::commitShadows(const std::vector<int32_t> &parents) {
+    if (parents.empty()) return;
+    if (parents.size() > peekPriorities_.size()) throw std::runtime_error("lane change: more shadows than peeked priorities");
+    rnd.discard((unsigned long long) peekDraws_[parents.size() - 1]);
+    for (size_t i = 0; i < parents.size(); ++i) {
+        VehicleRecord rec = vehicles[(size_t) parents[i]];  // Vehicle copy constructor: same info, route, enterTime
+        rec.priority = peekPriorities_[i];
+        rec.root = rec.root >= 0 ? rec.root : parents[i];
+        const int vid = (int) vehicles.size();
+        vehicles.push_back(rec);
+        livePriority_.set(rec.priority, vid);
+        shadowChains_[rec.root].push_back(vid);
+    }
+    peekPriorities_.clear();
+    peekDraws_.clear();
+}
+
+std::vector<int32_t> Spawner::idChain(int root) const {
+    std::vector<int32_t> c{root};
+    auto it = shadowChains_.find(root);
+    if (it != shadowChains_.end()) c.insert(c.end(), it->second.begin(), it->second.end());
+    return c;
 }
 
 // Vehicle ctor priority loop (vehicle.cpp:45) + the extra draw of Engine::pushVehicle (engine.cpp:606).
@@ -282,14 +331,25 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
     // phase 1: Engine::planRoute — roads in JSON order, vehicles in buffer order
     std::stable_sort(pending_.begin(), pending_.end(),
                      [](const Pending &a, const Pending &b) { return a.firstRoad < b.firstRoad; });
+    // Vehicle numbers follow the order the reference CREATES the vehicles in (Flow::nextStep, flow by flow), not the
+    // order planRoute hands them to their lanes: lane change walks its candidates in creation order (include/
+    // cityflow_amd.h "Lane change").  The records still go out in planRoute order (= waiting-buffer push order).
+    const int firstVid = (int) vehicles.size();
+    vidOfPending_.assign(pendingRecords_.size(), -1);
+    {
+        int next = firstVid;
+        for (size_t i = 0; i < pendingRecords_.size(); ++i)
+            if (pendingRecords_[i].route >= 0) vidOfPending_[i] = next++;
+        vehicles.resize((size_t) next);
+    }
     for (const Pending &p : pending_) {
         VehicleRecord &rec = pendingRecords_[p.index];
         if (rec.route >= 0) {
             const std::vector<int32_t> &cands = routes.firstLanes[rec.route];
             int lane = cands[rnd() % cands.size()];
-            int vid = (int) vehicles.size();
+            int vid = vidOfPending_[p.index];
             rec.firstLane = lane;
-            vehicles.push_back(rec);
+            vehicles[(size_t) vid] = rec;
             livePriority_.set(rec.priority, vid);
             {
                 std::vector<int32_t> &tbl = rec.flow >= 0 ? flowVids[rec.flow] : manualVids;
@@ -381,6 +441,7 @@ Spawner::State Spawner::saveState() const {
     st.rnd = rnd;
     st.manualCnt = manualCnt_;
     st.livePriority = livePriority_;
+    st.shadowChains = shadowChains_;
     return st;
 }
 
@@ -398,6 +459,7 @@ void Spawner::loadState(const State &st) {
     rnd = st.rnd;
     manualCnt_ = std::max(manualCnt_, st.manualCnt);  // manuallyPushCnt never goes back (engine.h:56)
     livePriority_ = st.livePriority;
+    shadowChains_ = st.shadowChains;
     rebuildActiveFlows();
     pending_.clear();
     pendingRecords_.clear();
@@ -413,6 +475,9 @@ void Spawner::reset(bool reseed) {
     for (auto &v : flowVids) v.clear();
     std::fill(manualVids.begin(), manualVids.end(), -1);
     livePriority_.clear();
+    shadowChains_.clear();
+    peekPriorities_.clear();
+    peekDraws_.clear();
     rebuildActiveFlows();
     pending_.clear();
     pendingRecords_.clear();

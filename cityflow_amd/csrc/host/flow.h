@@ -59,6 +59,7 @@ struct VehicleRecord {
     int32_t templ, route;
     double enterTime;
     int32_t firstLane;  // lane whose waiting buffer it was pushed to (-1 while still in planRouteBuffer)
+    int32_t root = -1;  // lane change: the flow / pushed vehicle whose id this shadow carries (-1: not a shadow)
 };
 
 struct FlowDyn {  // Flow fields that change while stepping (flow.h:23-31)
@@ -100,7 +101,17 @@ public:
     void reset(bool reseed);  // Engine::reset engine.cpp:744-760 (flows, vehicles; RNG only if reseed)
     void seed(int s) { rnd.seed((std::mt19937::result_type) s); }
 
-    std::string vehicleId(int vid) const;
+    // ---- lane change: shadows are `new Vehicle(*v, id + "_shadow")` drawing a priority from this generator
+    //      (engine.cpp:812-820, vehicle.cpp:28-36)
+    // The priorities the next n shadows WOULD get, from a copy of the generator (collisions with live vehicles redrawn).
+    void peekShadowPriorities(int n, std::vector<int32_t> &out);
+    // The device created shadows of `parents` (in this order) with the first priorities of the last peek: advance the
+    // generator past those draws and give the shadows their vehicle numbers.
+    void commitShadows(const std::vector<int32_t> &parents);
+    // vehicles that carry (or carried) the id of `root`: the root itself and every shadow made of its holders, ascending
+    std::vector<int32_t> idChain(int root) const;
+
+    std::string vehicleId(int vid, bool shadow = false) const;  // shadow: "<id>_shadow" (until its change completes)
     int vidOfId(const std::string &id) const;  // inverse of vehicleId (-1 if unknown)
     // An integer that orders vehicles exactly like their id strings compare ("flow_<f>_<n>" / "manually_pushed_<n>", i.e.
     // the key order of the reference's std::map<std::string, ...> getters) without building or comparing strings.
@@ -121,6 +132,7 @@ public:
         std::mt19937 rnd;
         int manualCnt = 0;
         FlatMapI32 livePriority;
+        std::unordered_map<int32_t, std::vector<int32_t>> shadowChains;
     };
     State saveState() const;
     void loadState(const State &st);
@@ -143,9 +155,12 @@ private:
     std::function<bool(int)> isFinished_;
     std::vector<Pending> pending_;                 // planRouteBuffer contents, in push order
     std::vector<VehicleRecord> pendingRecords_;
+    std::vector<int32_t> vidOfPending_;            // scratch of step(): vehicle number of every pending record
     std::vector<int32_t> lastWaitVid_;             // per lane: last vid pushed to its waitingBuffer
     FlatMapI32 livePriority_;  // priority -> vid (superset of live vehicles; -1 while in planRouteBuffer)
     std::vector<int32_t> activeFlows_;  // flows that may still spawn, ascending (Flow::nextStep early returns)
+    std::vector<int32_t> peekPriorities_, peekDraws_;  // last peekShadowPriorities: values, cumulative raw draws
+    std::unordered_map<int32_t, std::vector<int32_t>> shadowChains_;  // root vid -> shadows carrying its id
     std::map<std::vector<int>, int> routeIndex_;          // expanded road sequence -> route index
 };
 

@@ -323,14 +323,26 @@ PYBIND11_MODULE(_cityflow, m) {
         // ---- reference API ----
         .def("next_step", &EngineHost::nextStep)
         .def("get_vehicle_count", &EngineHost::getVehicleCount)
-        .def("get_vehicles", [](EngineHost &e, bool w) { return vehicleList(e, w); }, "include_waiting"_a = false)
+        .def("get_vehicles", [](EngineHost &e, bool w) -> py::object {
+                 if (e.laneChange()) return py::cast(e.getVehicles(w));  // ids change with state ("_shadow"): no id cache
+                 return vehicleList(e, w);
+             }, "include_waiting"_a = false)
         // dict[str, int] in std::map (lexicographic) key order like the reference, built from cached key objects
         .def("get_lane_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneVehicleCountArray(), 0); })
         .def("get_lane_waiting_vehicle_count", [](EngineHost &e) { return laneDict(e, e.laneWaitingVehicleCountArray(), 1); })
-        .def("get_lane_vehicles", [](EngineHost &e) { return laneVehiclesDict(e); })
-        .def("get_vehicle_speed", [](EngineHost &e) { return vehicleValueDict(e, true); })
+        .def("get_lane_vehicles", [](EngineHost &e) -> py::object {
+                 if (e.laneChange()) return py::cast(e.getLaneVehicles());
+                 return laneVehiclesDict(e);
+             })
+        .def("get_vehicle_speed", [](EngineHost &e) -> py::object {
+                 if (e.laneChange()) return py::cast(e.getVehicleSpeed());
+                 return vehicleValueDict(e, true);
+             })
         .def("get_vehicle_info", &EngineHost::getVehicleInfo, "vehicle_id"_a)
-        .def("get_vehicle_distance", [](EngineHost &e) { return vehicleValueDict(e, false); })
+        .def("get_vehicle_distance", [](EngineHost &e) -> py::object {
+                 if (e.laneChange()) return py::cast(e.getVehicleDistance());
+                 return vehicleValueDict(e, false);
+             })
         .def("get_leader", &EngineHost::getLeader, "vehicle_id"_a)
         .def("get_current_time", &EngineHost::getCurrentTime)
         .def("get_average_travel_time", &EngineHost::getAverageTravelTime)
@@ -405,7 +417,7 @@ PYBIND11_MODULE(_cityflow, m) {
              })
         .def("_profile_enable", &EngineHost::profileEnable, "on"_a)
         .def("_profile_read", &EngineHost::profileRead)
-        .def("_vehicle_id", &EngineHost::vehicleId, "vid"_a)
+        .def("_vehicle_id", [](EngineHost &e, int vid) { return e.vehicleId(vid); }, "vid"_a)
         .def("_vehicle_ids",
              [](EngineHost &e, py::array_t<int32_t> vids) {
                  std::vector<std::string> out;

@@ -456,6 +456,17 @@ void HostRoadNet::flatten() {
     }
     interPhaseStart_[I] = (int) phaseTime_.size();
 
+    // lane change: Lane::width and the segment count (Road::buildSegmentationByInterval roadnet.cpp:687-691 with the
+    // interval of roadnet.cpp:310-312: (default len 5 + default minGap 2) * MAX_NUM_CARS_ON_SEGMENT 10, over the
+    // road's own polyline)
+    laneWidth_.resize(L);
+    laneNumSegs_.resize(L);
+    for (int l = 0; l < L; ++l) {
+        laneWidth_[l] = lanes[l].width;
+        const double interval = (5.0 + 2.0) * 10;
+        laneNumSegs_[l] = (int32_t) std::max((size_t) std::ceil(polylineLength(roads[lanes[l].road].points) / interval), (size_t) 1);
+    }
+
     flat_ = cfx_net{};
     flat_.n_roads = R;
     flat_.n_lanes = L;
@@ -484,6 +495,8 @@ void HostRoadNet::flatten() {
     flat_.inter_n_roadlinks = interNRoadLinks_.data();
     flat_.inter_phase_start = interPhaseStart_.data();
     flat_.inter_avail_start = interAvailStart_.data();
+    flat_.lane_width = laneWidth_.data();
+    flat_.lane_n_segments = laneNumSegs_.data();
     flat_.phase_time = phaseTime_.data();
     flat_.phase_avail = phaseAvail_.data();
 }

@@ -100,10 +100,10 @@ private:
     void flatten();
 
     cfx_net flat_{};
-    std::vector<double> drvLength_, drvMaxSpeed_, xDist_, phaseTime_;
+    std::vector<double> drvLength_, drvMaxSpeed_, xDist_, phaseTime_, laneWidth_;
     std::vector<int32_t> laneRoad_, laneIndex_, laneLLStart_, laneLL_, roadLaneStart_, llStartLane_, llEndLane_,
         llInter_, llRoadLink_, llType_, llXStart_, xPeer_, xLL_, interVirtual_, interNRoadLinks_, interPhaseStart_,
-        interAvailStart_;
+        interAvailStart_, laneNumSegs_;
     std::vector<uint8_t> phaseAvail_;
 };
 

@@ -258,10 +258,13 @@ void VectorEngineHost::translateEnv(int r) {
     int32_t g = batchFirstVid_ + envBase_[r];
     cfx_spawn *out = recs_.data() + envBase_[r];
     std::vector<int32_t> &l2g = localToGlobal_[r];
+    const int32_t firstLocal = (int32_t) l2g.size();  // a batch holds the next dense run of local vids, in any order
+    l2g.resize(l2g.size() + envRecs_[r].size());
     for (cfx_spawn s : envRecs_[r]) {
-        l2g.push_back(g);  // local vids are dense per environment
-        globalToLocal_[g] = std::make_pair((int32_t) r, s.vid);
-        s.vid = g++;
+        const int32_t gv = g + (s.vid - firstLocal);
+        l2g[(size_t) s.vid] = gv;
+        globalToLocal_[gv] = std::make_pair((int32_t) r, s.vid);
+        s.vid = gv;
         s.lane += r * L_;
         s.route += r * routesPerEnv_;
         s.prev_wait = s.prev_wait >= 0 ? l2g[s.prev_wait] : -1;

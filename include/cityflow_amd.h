@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CFX_ABI_VERSION 1
+#define CFX_ABI_VERSION 2
 
 typedef enum cfx_status {
     CFX_OK = 0,
@@ -85,12 +85,16 @@ typedef struct cfx_net {
     const int32_t *inter_avail_start; /* [n_inters]   offset of this intersection's block in phase_avail */
     const double *phase_time;         /* [n_phases] LightPhase::time */
     const uint8_t *phase_avail;       /* per intersection: n_phases_i x n_roadlinks_i row-major 0/1 */
+
+    /* lane change only (may be NULL when cfx_config::lane_change == 0), per lane [n_lanes] */
+    const double *lane_width;         /* Lane::width (roadnet.h:303): lateral offset that completes a change */
+    const int32_t *lane_n_segments;   /* Lane::segments.size() (Road::buildSegmentationByInterval roadnet.cpp:687-691) */
 } cfx_net;
 
 typedef struct cfx_config {
     double interval;          /* Engine::interval */
     int32_t rl_traffic_light; /* Engine::rlTrafficLight: lights advance only via cfx_set_tl_phase */
-    int32_t lane_change;      /* must be 0 in ABI version 1 */
+    int32_t lane_change;      /* Engine::laneChange (engine.cpp:53): see "Lane change" below */
     int32_t device;           /* HIP device ordinal (ignored by CPU implementations) */
     int32_t reserved;
 } cfx_config;
@@ -143,8 +147,16 @@ typedef struct cfx_vehicle_view {
     int32_t *route_pos;     /* Router::iCurRoad as an index into the route */
     double *dis;
     double *speed;
-    double *gap;            /* meaningful only where leader_vid >= 0 */
+    double *gap;            /* ControllerInfo::gap: refreshed only where leader_vid >= 0, otherwise the value it last had */
+    /* lane change (zero / -1 when it is off) */
+    int32_t *lc_partner_vid; /* LaneChangeInfo::partner */
+    uint8_t *lc_flags;       /* CFX_LC_* bits */
+    double *lc_offset;       /* LaneChangeInfo::offset */
+    int32_t *lc_last_dir;    /* LaneChange::lastDir (what the replay log prints, engine.cpp:524) */
 } cfx_vehicle_view;
+#define CFX_LC_SHADOW 1u   /* partnerType == 2: a shadow; its id is "<parent id>_shadow" until the change finishes */
+#define CFX_LC_PARENT 2u   /* partnerType == 1: the real vehicle of a changing pair */
+#define CFX_LC_CHANGING 4u /* LaneChange::changing */
 
 int32_t cfx_abi_version(void);
 int32_t cfx_create(const cfx_net *net, const cfx_config *cfg, cfx_engine **out);
@@ -222,6 +234,23 @@ typedef struct cfx_state {
 int32_t cfx_load_state(cfx_engine *e, const cfx_state *s);
 /* pending custom speeds of the running vehicles, same order as cfx_get_vehicles (NaN = none) */
 int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out);
+
+/* ---- Lane change (cfx_config::lane_change = 1; reference src/vehicle/lanechange.cpp, engine.cpp:374-400,792-820) ----
+ * A vehicle that starts to change lane gets a SHADOW in the target lane: a new vehicle (`new Vehicle(*v, id + "_shadow")`,
+ * engine.cpp:812-820) that draws its priority from the engine's mt19937 — the stream the host's spawner owns.  So
+ *   before cfx_step   cfx_lane_change_supply(e, n, priorities): the next n priorities the generator WOULD hand out
+ *                     (already filtered for collisions with live vehicles); the step uses the first k of them, in the
+ *                     order the shadows are created;
+ *   after cfx_step    cfx_lane_change_poll(e, cap, parent_vid, &k): the vehicles that got a shadow in that step, in
+ *                     creation order; shadow i has vid = (vehicles known before the step's spawn records) + (number of
+ *                     spawn records) + i.  The host advances its generator past the draws that produced the first k
+ *                     priorities and numbers the NEXT step's spawn records after the shadows.
+ * cfx_lane_change_poll waits only for the part of the step that creates shadows, not for the whole step.
+ * Order: the reference walks the candidates in `std::set<Vehicle*>` (heap address) order, which is not a function of
+ * the simulation state; this ABI fixes the order to ascending vid (= creation order, which is the
+ * address order of a fresh heap).  More than n shadows in one step: CFX_ERR_CAPACITY from the poll. */
+int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *priorities);
+int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vid, int32_t *n);
 
 /* ---- Tiling one road network over several engines / GPUs -----------------------------------
  * An engine may be created on a SUB-network: the intersections one tile owns, their laneLinks, every lane ending

@@ -12,9 +12,11 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <unistd.h>
 #include <deque>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -32,6 +34,8 @@ struct Net {  // owned copies of cfx_net
     std::vector<int32_t> laneRoad, laneIndex, laneLLStart, laneLL, roadLaneStart, llStartLane, llEndLane, llInter,
         llRoadLink, llType, llXStart, xPeer, xLL, interVirtual, interNRL, interPhaseStart, interAvailStart;
     std::vector<uint8_t> phaseAvail;
+    std::vector<double> laneWidth;      // lane change only
+    std::vector<int32_t> laneNumSegs;
 };
 
 struct Veh {  // Vehicle (vehicle.h:48-112) minus strings / lane change
@@ -49,6 +53,17 @@ struct Veh {  // Vehicle (vehicle.h:48-112) minus strings / lane change
     bool bEndSet = false, bDrvSet = false, bBlockerSet = false, bEnterSet = false;
     double bDis = 0, bSpeed = 0;
     int32_t bDrv = -1, bBlocker = -1, bEnterLLTime = INT_MAX;
+    bool bSpeedSet = false;  // Buffer::isSpeedSet: a changing pair's first-processed member sets the other's speed
+    // LaneChangeInfo vehicle.h:74-79
+    int32_t partnerType = 0, partner = -1, segIndex = 0;
+    double offset = 0;
+    // LaneChange lanechange.h:27-44.  signalSend is {present, target lane, urgency, direction}; signalRecv points at a
+    // sender's Signal, of which only `source` is ever read: recvFrom = that vehicle.
+    bool sigSend = false;
+    int32_t sendTarget = -1, sendUrgency = 0, sendDir = 0, recvFrom = -1, lastDir = 0;
+    int32_t targetLeader = -1, targetFollower = -1;
+    double leaderGap = 0, followerGap = 0, waitingTime = 0, lastChangeTime = 0;
+    bool changing = false, lcFinished = false;
 };
 
 }  // namespace
@@ -68,6 +83,11 @@ struct cfx_engine {
     int64_t step = 0, active = 0, finishedCnt = 0, vehicleSteps = 0;
     double cumulativeTravelTime = 0;
     std::string err;
+    // lane change: per lane the Segments (roadnet.h:198-236), each a list of vehicles front to back; the priorities the
+    // host's generator would hand out next; the parents of the shadows the last step created
+    std::vector<std::vector<std::vector<int32_t>>> segments;
+    std::vector<int32_t> shadowPool, shadowParents;
+    bool shadowOverflow = false;
     // tiling (cfx_halo_config): same protocol as the HIP engine, restated on the object model
     bool tiled = false;
     std::vector<uint8_t> laneGhost, ghostHadEntrants;
@@ -324,6 +344,243 @@ struct cfx_engine {
         return s;
     }
 
+    // ------------------------------------------------------------------ lane change (lanechange.cpp)
+    int vidOf(const Veh &v) const { return (int) (&v - veh.data()); }
+    bool planChange(const Veh &v) const {  // lanechange.cpp:23-25
+        return (v.sigSend && v.sendTarget >= 0 && v.sendTarget != v.drivable) || v.changing;
+    }
+    double safeGapBefore(const Veh &v) const {  // lanechange.cpp:213-215
+        return v.targetFollower >= 0 ? minBrakeDistance(veh[v.targetFollower]) : 0;
+    }
+    // SimpleLaneChange::yieldSpeed lanechange.cpp:186-206 (100 when nobody signalled this vehicle)
+    double yieldSpeed(Veh &v, double interval) {
+        if (planChange(v)) v.waitingTime += interval;
+        if (v.recvFrom >= 0) {
+            const Veh &src = veh[v.recvFrom];
+            if (vidOf(v) == src.targetLeader) return 100;
+            double gap = src.followerGap - safeGapBefore(src);
+            double s = noCollisionSpeed(src.speed, T(src).max_neg_acc, v.speed, T(v).max_neg_acc, gap, interval, 0);
+            if (s < 0) s = 100;  // "if the follower is too fast, let it go"
+            return s;
+        }
+        return 100;
+    }
+    double segStart(int lane, int i) const { return i * len(lane) / net.laneNumSegs[lane]; }  // roadnet.cpp:859
+    // Lane::initSegments roadnet.cpp:863-875
+    void initSegments() {
+        for (int lane = 0; lane < net.L; ++lane) {
+            auto &segs = segments[lane];
+            const auto &list = order[lane];
+            size_t it = 0;
+            for (int i = (int) segs.size() - 1; i >= 0; --i) {
+                segs[i].clear();
+                while (it < list.size() && veh[list[it]].dis >= segStart(lane, i)) {
+                    segs[i].push_back(list[it]);
+                    veh[list[it]].segIndex = i;
+                    ++it;
+                }
+            }
+        }
+    }
+    int vehicleBeforeDistance(int lane, double dis, int segIndex) const {  // roadnet.cpp:877-887
+        for (int i = segIndex; i >= 0; --i)
+            for (int32_t w : segments[lane][i])
+                if (veh[w].dis < dis) return w;
+        return -1;
+    }
+    int vehicleAfterDistance(int lane, double dis, int segIndex) const {  // roadnet.cpp:889-898
+        for (int i = segIndex; i < (int) segments[lane].size(); ++i)
+            for (auto it = segments[lane][i].rbegin(); it != segments[lane][i].rend(); ++it)
+                if (veh[*it].dis >= dis) return *it;
+        return -1;
+    }
+    double estimateGap(const Veh &v, int lane) const {  // lanechange.cpp:221-226
+        int leader = vehicleAfterDistance(lane, v.dis, v.segIndex);
+        if (leader < 0) return len(lane) - v.dis;
+        return veh[leader].dis - v.dis - T(veh[leader]).len;
+    }
+    // SimpleLaneChange::makeSignal lanechange.cpp:151-184 (+ LaneChange::makeSignal lanechange.h:76, getDirection 104-113)
+    void makeSignal(Veh &v, double interval) {
+        if (v.changing) return;
+        if (step * cfg.interval - v.lastChangeTime < 3 /*coolingTime*/) return;
+        v.sigSend = true;  // make_shared<Signal>(): value-initialised, target == nullptr
+        v.sendTarget = -1;
+        v.sendUrgency = 0;
+        v.sendDir = 0;
+        if (isLane(v.drivable)) {
+            const int cur = v.drivable;
+            if (len(cur) - v.dis < 30) return;
+            const cfx_vehicle_template &t = T(v);
+            double curEst = v.gap, outerEst = 0;
+            double expectedGap = 2 * t.len + 4 * interval * t.max_speed;
+            if (v.gap > expectedGap || v.gap < 1.5 * t.len) return;
+            const int road = net.laneRoad[cur];
+            const int nLanes = net.roadLaneStart[road + 1] - net.roadLaneStart[road];
+            const bool lastRoad = isLastRoad(v, cur);
+            if (net.laneIndex[cur] < nLanes - 1) {
+                if (lastRoad || nextOf(v, cur + 1) >= 0) {  // Lane::getOuterLane roadnet.h:359-362
+                    outerEst = estimateGap(v, cur + 1);
+                    if (outerEst > curEst + t.len) v.sendTarget = cur + 1;
+                }
+            }
+            if (net.laneIndex[cur] > 0) {
+                if (lastRoad || nextOf(v, cur - 1) >= 0) {  // Lane::getInnerLane roadnet.h:354-357
+                    double innerEst = estimateGap(v, cur - 1);
+                    if (innerEst > curEst + t.len && innerEst > outerEst) v.sendTarget = cur - 1;
+                }
+            }
+            v.sendUrgency = 1;
+        }
+        if (isLane(v.drivable) && v.sendTarget >= 0)
+            v.sendDir = v.sendTarget == v.drivable + 1 ? 1 : (v.sendTarget == v.drivable - 1 ? -1 : 0);
+    }
+    // LaneChange::updateLeaderAndFollower lanechange.cpp:27-60
+    void updateLeaderAndFollower(Veh &v) {
+        const int target = v.sendTarget, cur = v.drivable;
+        v.targetLeader = vehicleAfterDistance(target, v.dis, v.segIndex);
+        v.leaderGap = v.followerGap = std::numeric_limits<double>::max();
+        if (v.targetLeader < 0) {
+            double rest = len(cur) - v.dis;
+            v.leaderGap = rest;
+            double gap = std::numeric_limits<double>::max();
+            for (int q = net.laneLLStart[target]; q < net.laneLLStart[target + 1]; ++q) {
+                int leader = lastVehicle(net.L + net.laneLL[q]);
+                if (leader >= 0 && veh[leader].dis + rest < gap) {
+                    gap = veh[leader].dis + rest;
+                    if (gap < T(veh[leader]).len) {
+                        v.targetLeader = leader;
+                        v.leaderGap = rest - (T(veh[leader]).len - gap);
+                    }
+                }
+            }
+        } else {
+            v.leaderGap = veh[v.targetLeader].dis - v.dis - T(veh[v.targetLeader]).len;
+        }
+        v.targetFollower = vehicleBeforeDistance(target, v.dis, v.segIndex);
+        if (v.targetFollower >= 0)
+            v.followerGap = v.dis - veh[v.targetFollower].dis - T(v).len;
+        else
+            v.followerGap = std::numeric_limits<double>::max();
+    }
+    // Vehicle::receiveSignal vehicle.cpp:391-401
+    void receiveSignal(Veh &r, int sender) {
+        if (r.changing) return;
+        int curPriority = r.recvFrom >= 0 ? veh[r.recvFrom].priority : -1;
+        int newPriority = veh[sender].priority;
+        if ((r.recvFrom < 0 || curPriority < newPriority) && (!r.sigSend || r.priority < newPriority)) r.recvFrom = sender;
+    }
+    // Engine::insertShadow engine.cpp:812-820 + Vehicle copy constructor vehicle.cpp:28-36 + LaneChange::insertShadow
+    // lanechange.cpp:71-102
+    void insertShadow(int pv) {
+        if (shadowParents.size() >= shadowPool.size()) {
+            shadowOverflow = true;
+            return;
+        }
+        const int sv = (int) veh.size();
+        {
+            Veh copy = veh[pv];  // vehicleInfo, controllerInfo, laneChangeInfo, buffer are copied; LaneChange is new
+            veh.push_back(copy);
+        }
+        Veh &p = veh[pv], &s = veh[sv];
+        s.priority = shadowPool[shadowParents.size()];
+        shadowParents.push_back(pv);
+        s.sigSend = false;
+        s.sendTarget = -1;
+        s.sendUrgency = s.sendDir = 0;
+        s.recvFrom = -1;
+        s.lastDir = 0;  // (uninitialised in the reference until the step's clearSignal)
+        s.targetLeader = s.targetFollower = -1;
+        s.leaderGap = s.followerGap = 0;
+        s.waitingTime = 0;
+        s.lastChangeTime = 0;
+        s.changing = s.lcFinished = false;
+        active += 1;
+        p.changing = true;
+        p.waitingTime = 0;
+        const int target = p.sendTarget;
+        s.partnerType = 2;  // setParent
+        s.partner = pv;
+        p.partnerType = 1;  // setShadow
+        p.partner = sv;
+        s.blocker = -1;
+        s.drivable = target;  // Router::update: the same road, iCurRoad stays
+        auto &list = order[target];
+        size_t pos = list.size();
+        if (p.targetFollower >= 0) pos = std::find(list.begin(), list.end(), p.targetFollower) - list.begin();
+        list.insert(list.begin() + pos, sv);
+        {  // Segment::insertVehicle roadnet.cpp:943-947
+            auto &seg = segments[target][p.segIndex];
+            size_t i = 0;
+            while (i < seg.size() && veh[seg[i]].dis > s.dis) ++i;
+            seg.insert(seg.begin() + i, sv);
+        }
+        updateLeaderAndGap(s, p.targetLeader);
+        if (p.targetFollower >= 0) updateLeaderAndGap(veh[p.targetFollower], sv);
+    }
+    // Engine::threadPlanLaneChange engine.cpp:374-390 + scheduleLaneChange 792-810.  The reference walks the vehicles in
+    // std::set<Vehicle*> order (heap addresses); canonical here and on the device: ascending vid.
+    void planLaneChange() {
+        std::vector<int32_t> buffer;
+        const size_t nVeh = veh.size();
+        for (size_t vid = 0; vid < nVeh; ++vid) {
+            Veh &v = veh[vid];
+            if (v.running && v.partnerType != 2) {
+                makeSignal(v, cfg.interval);
+                if (planChange(v)) buffer.push_back((int32_t) vid);
+            }
+        }
+        // engine.cpp:793-794 sorts by urgency with std::sort, which is not stable: all urgencies are 1, and with more than
+        // 16 candidates libstdc++'s introsort permutes them.  The ABI's order is the stable one (creation order); when the
+        // twin is pinned against the reference (tests/test_lane_change.py) CFX_TWIN_LC_STDSORT=1 makes it issue the
+        // reference's very call, which yields the reference's permutation.
+        static const bool likeReference = getenv("CFX_TWIN_LC_STDSORT") != nullptr;
+        auto moreUrgent = [this](int32_t a, int32_t b) { return veh[a].sendUrgency > veh[b].sendUrgency; };
+        if (likeReference) std::sort(buffer.begin(), buffer.end(), moreUrgent);
+        else std::stable_sort(buffer.begin(), buffer.end(), moreUrgent);
+        veh.reserve(veh.size() + buffer.size());  // references stay valid across insertShadow
+        for (int32_t vid : buffer) {
+            Veh &v = veh[vid];
+            updateLeaderAndFollower(v);
+            if (v.targetLeader >= 0) receiveSignal(veh[v.targetLeader], vid);  // SimpleLaneChange::sendSignal 208-211
+            if (v.targetFollower >= 0) receiveSignal(veh[v.targetFollower], vid);
+            if (planChange(v) && v.sigSend && v.recvFrom < 0 && !v.changing) {
+                bool gapValid = v.leaderGap >= minBrakeDistance(v) && v.followerGap >= safeGapBefore(v);  // lanechange.h:80
+                if (gapValid && isLane(v.drivable)) insertShadow(vid);
+            }
+        }
+    }
+    // LaneChange::clearSignal lanechange.cpp:129-138
+    void clearSignal(Veh &v) {
+        v.targetLeader = v.targetFollower = -1;
+        v.lastDir = v.sigSend ? v.sendDir : 0;
+        if (v.changing) return;
+        v.sigSend = false;
+        v.recvFrom = -1;
+    }
+    // LaneChange::finishChanging lanechange.cpp:115-127 + Vehicle::finishChanging vehicle.cpp:378-381
+    void finishChanging(Veh &v) {
+        v.changing = false;
+        v.lcFinished = true;
+        v.lastChangeTime = step * cfg.interval;
+        Veh &partner = veh[v.partner];
+        partner.partnerType = 0;  // (and takes over the id: the host names a vehicle after its oldest ancestor)
+        partner.offset = 0;
+        partner.partner = -1;
+        v.partner = -1;
+        clearSignal(v);
+        v.bEndSet = true;
+    }
+    // Vehicle::abortLaneChange vehicle.cpp:412-416 + LaneChange::abortChanging lanechange.cpp:141-148
+    void abortLaneChange(Veh &v) {
+        v.bEndSet = true;
+        Veh &partner = veh[v.partner];
+        partner.changing = false;
+        partner.partnerType = 0;
+        partner.offset = 0;
+        partner.partner = -1;
+        clearSignal(v);
+    }
+
     // Vehicle::getNextSpeed vehicle.cpp:308-335.  `if (laneChange)` there tests the always-non-null
     // shared_ptr member: yieldSpeed() == 100 without signals, and the invalid-lane
     // brake is always evaluated.
@@ -334,7 +591,7 @@ struct cfx_engine {
         s = min2(s, net.drvMaxSpeed[v.drivable]);
         s = min2(s, carFollowSpeed(v, interval));
         if (isIntersectionRelated(v)) s = min2(s, intersectionRelatedSpeed(v, interval));
-        s = min2(s, 100);  // SimpleLaneChange::yieldSpeed lanechange.cpp:186-206 without signals
+        s = min2(s, yieldSpeed(v, interval));
         // Router::onValidLane router.h:66-68
         if (nextDrivable(v, 0) < 0 && !isLastRoad(v, v.drivable)) {
             double vn = noCollisionSpeed(0, 1, v.speed, t.max_neg_acc, len(v.drivable) - v.dis, interval, t.min_gap);
@@ -361,10 +618,18 @@ struct cfx_engine {
         v.bDis = dis;
     }
 
-    // Engine::vehicleControl engine.cpp:188-251 (no lane change)
+    // Engine::vehicleControl engine.cpp:188-251
     void vehicleControl(Veh &v) {
         double interval = cfg.interval;
-        double ns = nextSpeed(v, interval);
+        double ns = v.bSpeedSet ? v.bSpeed : nextSpeed(v, interval);  // hasSetSpeed(): the partner went first
+        if (cfg.lane_change && v.partner >= 0 && !veh[v.partner].bSpeedSet) {
+            Veh &partner = veh[v.partner];
+            double partnerSpeed = nextSpeed(partner, interval);
+            ns = min2(ns, partnerSpeed);
+            partner.bSpeed = ns;
+            partner.bSpeedSet = true;
+            // (`if (partner->hasSetEnd()) vehicle.setEnd(true)` is undone by setDeltaDistance's unSetEnd below)
+        }
         double deltaDis, speed = v.speed;
         if (ns < 0) {
             deltaDis = 0.5 * speed * speed / T(v).max_neg_acc;
@@ -373,7 +638,19 @@ struct cfx_engine {
             deltaDis = (speed + ns) * interval / 2;
         }
         v.bSpeed = ns;
+        v.bSpeedSet = true;
         setDeltaDistance(v, deltaDis);
+        if (cfg.lane_change) {
+            if (v.partnerType == 2 && v.bDrvSet && v.bDrv >= 0) abortLaneChange(v);  // the shadow left the target lane
+            if (v.changing) {
+                int dir = v.sigSend ? v.sendDir : 0;  // Vehicle::getLaneChangeDirection vehicle.h:340-343
+                double maxOffset = (net.laneWidth[v.sendTarget] + net.laneWidth[v.drivable]) / 2;  // vehicle.h:347-350
+                double newOffset = std::fabs(v.offset + max2(0.2 * ns, 1) * interval * dir);
+                newOffset = min2(newOffset, maxOffset);
+                v.offset = newOffset * dir;
+                if (newOffset >= maxOffset) finishChanging(v);
+            }
+        }
     }
 
     // Vehicle::updateLeaderAndGap vehicle.cpp:157-196
@@ -602,12 +879,16 @@ struct cfx_engine {
 
     void stepOnce(const cfx_spawn *recs, int n) {
         // phases 0/1 happened on the host; enqueue on waiting buffers in record order
+        const int firstNew = (int) veh.size();
+        veh.resize(veh.size() + (size_t) n);
+        std::vector<uint8_t> seen((size_t) n, 0);
         for (int i = 0; i < n; ++i) {
             const cfx_spawn &s = recs[i];
-            if ((int) veh.size() != s.vid) {
-                err = "spawn records must arrive with dense vids";
+            if (s.vid < firstNew || s.vid >= firstNew + n || seen[s.vid - firstNew]) {
+                err = "spawn records must carry the next dense run of vids, each once";
                 return;
             }
+            seen[s.vid - firstNew] = 1;
             Veh v;
             v.priority = s.priority;
             v.templ = s.templ;
@@ -615,10 +896,20 @@ struct cfx_engine {
             v.enterTime = s.enter_time;
             v.speed = templ[s.templ].initial_speed;  // VehicleInfo::speed (engine.cpp:696)
             v.drivable = s.lane;  // Vehicle::setFirstDrivable vehicle.cpp:422-424
-            veh.push_back(v);
+            veh[s.vid] = v;
             if (s.lane >= 0) waiting[s.lane].push_back(s.vid);  // lane -1: the vehicle starts in another tile
         }
         handleWaiting();
+        shadowParents.clear();
+        if (cfg.lane_change) {  // engine.cpp:571-575
+            initSegments();
+            planLaneChange();
+            leaderAndGapPass();
+            if (shadowOverflow) {
+                err = "lane change: more shadows in one step than priorities supplied (cfx_lane_change_supply)";
+                return;
+            }
+        }
         notifyCross();
 
         // threadGetAction engine.cpp:402-413 (iteration order is irrelevant: reads committed state only)
@@ -648,8 +939,10 @@ struct cfx_engine {
                 if (!leaves) list[w++] = list[i];
                 if (v.bEndSet) {
                     removed[list[i]] = 1;
-                    finishedCnt += 1;
-                    cumulativeTravelTime += now - v.enterTime;
+                    if (!v.lcFinished) {  // LaneChange::hasFinished: the real vehicle of a completed change lives on as its shadow
+                        finishedCnt += 1;
+                        cumulativeTravelTime += now - v.enterTime;
+                    }
                     v.running = false;
                     v.finished = true;
                     active--;
@@ -693,6 +986,8 @@ struct cfx_engine {
             v.blocker = v.bBlockerSet ? v.bBlocker : -1;
             v.bBlockerSet = false;
             v.customSet = false;  // vehicle.cpp:120-122
+            v.bSpeedSet = false;
+            if (cfg.lane_change) clearSignal(v);  // engine.cpp:424
         }
 
         leaderAndGapPass();
@@ -715,6 +1010,9 @@ struct cfx_engine {
     void resetState() {
         generation += 1;
         veh.clear();
+        shadowParents.clear();
+        shadowPool.clear();
+        shadowOverflow = false;
         for (auto &o : order) o.clear();
         for (auto &w : waiting) w.clear();
         std::fill(notifyVid.begin(), notifyVid.end(), -1);
@@ -745,8 +1043,8 @@ int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
         g_createError = "null argument";
         return CFX_ERR_INVALID;
     }
-    if (cfg->lane_change) {
-        g_createError = "lane_change is not supported";
+    if (cfg->lane_change && (!n->lane_width || !n->lane_n_segments)) {
+        g_createError = "lane_change needs cfx_net::lane_width and lane_n_segments";
         return CFX_ERR_INVALID;
     }
     cfx_engine *e = new cfx_engine();
@@ -780,6 +1078,12 @@ int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
     copyIn(t.interAvailStart, n->inter_avail_start, t.I);
     copyIn(t.phaseTime, n->phase_time, n->n_phases);
     copyIn(t.phaseAvail, n->phase_avail, n->n_avail);
+    if (cfg->lane_change) {
+        copyIn(t.laneWidth, n->lane_width, t.L);
+        copyIn(t.laneNumSegs, n->lane_n_segments, t.L);
+        e->segments.resize(t.L);
+        for (int l = 0; l < t.L; ++l) e->segments[l].resize(std::max(1, t.laneNumSegs[l]));
+    }
     e->order.assign(D, {});
     e->waiting.assign(t.L, {});
     e->notifyVid.assign(t.E, -1);
@@ -817,6 +1121,26 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     return e->err.empty() ? CFX_OK : CFX_ERR_INVALID;
 }
 int32_t cfx_sync(cfx_engine *) { return CFX_OK; }
+
+int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *priorities) {
+    if (n < 0 || (n && !priorities)) return CFX_ERR_INVALID;
+    e->shadowPool.assign(priorities, priorities + n);
+    return CFX_OK;
+}
+int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vid, int32_t *n) {
+    if (!n) return CFX_ERR_INVALID;
+    if (e->shadowOverflow) {
+        e->err = "lane change: more shadows in one step than priorities supplied (cfx_lane_change_supply)";
+        return CFX_ERR_CAPACITY;
+    }
+    *n = (int32_t) e->shadowParents.size();
+    if (*n > capacity) {
+        e->err = "cfx_lane_change_poll: capacity too small";
+        return CFX_ERR_CAPACITY;
+    }
+    for (int i = 0; i < *n; ++i) parent_vid[i] = e->shadowParents[i];
+    return CFX_OK;
+}
 int32_t cfx_reset(cfx_engine *e) {
     e->resetState();
     return CFX_OK;
@@ -897,6 +1221,12 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
             if (view->dis) view->dis[i] = v.dis;
             if (view->speed) view->speed[i] = v.speed;
             if (view->gap) view->gap[i] = v.gap;
+            if (view->lc_partner_vid) view->lc_partner_vid[i] = v.partner;
+            if (view->lc_flags)
+                view->lc_flags[i] = (uint8_t) ((v.partnerType == 2 ? CFX_LC_SHADOW : 0) | (v.partnerType == 1 ? CFX_LC_PARENT : 0) |
+                                               (v.changing ? CFX_LC_CHANGING : 0));
+            if (view->lc_offset) view->lc_offset[i] = v.offset;
+            if (view->lc_last_dir) view->lc_last_dir[i] = v.lastDir;
             ++i;
         }
     return CFX_OK;
@@ -977,6 +1307,10 @@ int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {
 
 // Archive::resume (archive.cpp:73-126) on the flat state
 int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
+    if (e->cfg.lane_change) {
+        e->err = "cfx_load_state: not available with lane change (cfx_state carries no lane-change fields yet)";
+        return CFX_ERR_STATE;
+    }
     e->resetState();
     e->step = s->step;
     e->finishedCnt = s->finished_vehicle_count;
