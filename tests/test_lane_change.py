@@ -1,0 +1,97 @@
+"""Lane change (reference src/vehicle/lanechange.cpp): the CPU twin against the reference.
+
+The reference walks lane-change candidates in heap-address order, so a reference run is only reproducible under
+oracle/_ref/libmonotonic_new.so (see oracle/monotonic_new.cpp and tests/tools/lane_change_parity.py); the committed
+vectors in tests/golden/reference_lane_change.json were produced that way.  Every run below happens in its own process
+(the twin reads its sort-mode switch once per process)."""
+import hashlib
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import REF_DIR, TWIN_LIB
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import lane_change_parity as lcp  # noqa: E402
+from make_lane_change_goldens import record  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lc_golden():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_lane_change.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name,steps", [("example_1x1", [12, 60, 200, 500]), ("grid_6x6", [379, 400, 600])])
+def test_twin_lane_change_matches_reference_goldens(scen, workdir, lc_golden, name, steps):
+    """Vehicle count (with shadows), per-lane counts, every lane's vehicle list (shadows by id), the priority order of
+    the real vehicles, average travel time and every real vehicle's speed / distance, all exact."""
+    cfg = scen.materialize(name, workdir, laneChange=True)
+    for h in steps:
+        got = record(lcp.run("twin", cfg, h))
+        assert got == lc_golden[name][str(h)], (name, h)
+    assert lc_golden[name][str(steps[0])]["vehicle_count"] > lc_golden[name][str(steps[0])]["real_vehicles"]  # shadows alive
+
+
+def test_twin_lane_change_matches_reference_live(scen, workdir):
+    if not os.path.exists(os.path.join(REF_DIR, "libmonotonic_new.so")):
+        pytest.skip("oracle/_ref reference build not present")
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True)
+    for h in (35, 150):
+        r, t = lcp.run("ref", cfg, h), lcp.run("twin", cfg, h)
+        assert lcp.compare(r, t) == [], h
+
+
+def test_canonical_order_equals_reference_order_up_to_16_candidates(scen, workdir, lc_golden):
+    """The ABI walks candidates in creation order; the reference's std::sort by (all equal) urgency keeps that order while
+    a step has at most 16 candidates (libstdc++ insertion sort).  The 6x6 grid has 12 per step: the twin's default
+    (stable) mode reproduces the reference there too."""
+    cfg = scen.materialize("grid_6x6", workdir, laneChange=True)
+    got = record(lcp.run("twin", cfg, 400, env={}))  # env={}: no CFX_TWIN_LC_STDSORT
+    assert got == lc_golden["grid_6x6"]["400"]
+
+
+def test_lane_change_api_surface(mod, scen, workdir):
+    """Shadows: hidden from get_vehicles / get_vehicle_speed / get_vehicle_distance (Engine::getRunningVehicles,
+    engine.cpp:780-790), counted by get_vehicle_count, listed by id in get_lane_vehicles; '<id>_shadow' resolves."""
+    eng = mod.Engine._with_backend(scen.materialize("example_1x1", workdir, laneChange=True), 1, TWIN_LIB)
+    for _ in range(12):
+        eng.next_step()
+    speeds = eng.get_vehicle_speed()
+    shadows = [v for lane in eng.get_lane_vehicles().values() for v in lane if v.endswith("_shadow")]
+    assert shadows and eng.get_vehicle_count() == len(speeds) + len(shadows)
+    assert not any(k.endswith("_shadow") for k in speeds) and set(eng.get_vehicles()) == set(speeds)
+    assert set(eng.get_vehicle_distance()) == set(speeds)
+    sh = shadows[0]
+    parent = sh[:-len("_shadow")]
+    info_s, info_p = eng.get_vehicle_info(sh), eng.get_vehicle_info(parent)
+    assert info_s["running"] == "1" and info_s["distance"] == info_p["distance"] and info_s["drivable"] != info_p["drivable"]
+    assert eng.get_leader(sh) == eng.get_leader(parent)  # engine.cpp:842-845: a shadow answers for its partner
+    with pytest.raises(RuntimeError):
+        eng.snapshot()
+    # the change completes (LaneChange::finishChanging): the shadow takes over the id, "<id>_shadow" is gone
+    gone = False
+    for _ in range(8):
+        eng.next_step()
+        lanes = eng.get_lane_vehicles()
+        if not any(sh in v for v in lanes.values()):
+            gone = True
+            with pytest.raises(RuntimeError):
+                eng.get_vehicle_info(sh)
+            assert eng.get_vehicle_info(parent)["drivable"] == info_s["drivable"]  # the id now lives in the target lane
+            break
+    assert gone
+    # reset clears lane-change state too
+    eng.reset(True)
+    for _ in range(12):
+        eng.next_step()
+    assert sorted(v for lane in eng.get_lane_vehicles().values() for v in lane if v.endswith("_shadow")) == sorted(shadows)
+
+
+def test_hip_engine_refuses_lane_change(mod, scen, workdir):
+    """No silent fallback: the device path has no lane change yet, so the product library must say so."""
+    with pytest.raises(RuntimeError, match="lane change"):
+        mod.Engine(scen.materialize("example_1x1", workdir, laneChange=True), 1)

@@ -61,14 +61,17 @@ def run(which, cfg, steps, env=None):
 
 
 def lane_change_config(scenario, workdir):
-    import bench
-    cfg = bench.build_workload(workdir, 0, scenario=scenario, n_extra=0)
-    c = json.load(open(cfg))
-    c["laneChange"] = True
-    path = cfg.replace(".json", "_lanechange.json")
-    with open(path, "w") as f:
-        json.dump(c, f)
-    return path
+    from cityflow_amd import scenarios
+    if scenario.startswith("gen_"):  # generated RxC grid of the bench workloads
+        import bench
+        cfg = bench.build_workload(workdir, 0, scenario=scenario, n_extra=0)
+        c = json.load(open(cfg))
+        c["laneChange"] = True
+        path = cfg.replace(".json", "_lanechange.json")
+        with open(path, "w") as f:
+            json.dump(c, f)
+        return path
+    return scenarios.materialize(scenario, workdir, laneChange=True)
 
 
 def compare(a, b):
