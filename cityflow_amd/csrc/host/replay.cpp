@@ -183,7 +183,8 @@ void ReplayWriter::writeStep(const HostRoadNet &net, const Spawner &sp, const Ve
     if (!out_.is_open()) return;
     const int L = (int) net.lanes.size();
     order_.clear();
-    for (int i = 0; i < s.count; ++i) order_.emplace_back(sp.vehicles[s.vid[i]].priority, i);
+    for (int i = 0; i < s.count; ++i)  // Engine::getRunningVehicles engine.cpp:780-790: real vehicles, vehiclePool order
+        if (!s.isShadow(i)) order_.emplace_back(sp.vehicles[s.vid[i]].priority, i);
     std::sort(order_.begin(), order_.end());
     std::string &o = line_;
     o.clear();
@@ -191,7 +192,18 @@ void ReplayWriter::writeStep(const HostRoadNet &net, const Spawner &sp, const Ve
         const int i = pi.second;
         const int d = s.drivable[i];
         const std::vector<Pt> &pts = d < L ? net.lanes[d].points : net.laneLinks[d - L].points;
-        Pt pos = pointByDistance(pts, s.dis[i]);  // Vehicle::getPoint vehicle.cpp:81-84 (no lane change: no offset)
+        Pt pos = pointByDistance(pts, s.dis[i]);  // Vehicle::getPoint vehicle.cpp:81-105
+        const double offset = s.lcOffset.empty() ? 0.0 : s.lcOffset[i];
+        if (!(std::fabs(offset) < 1e-8) && d < L) {  // changing lane: blend towards the neighbour lane's point
+            const HostLane &lane = net.lanes[d];
+            const HostLane &other = net.lanes[offset > 0 ? d + 1 : d - 1];
+            const Pt next = pointByDistance(other.points, s.dis[i]);
+            const double percentage = (offset > 0 ? 2 : -2) * offset / (lane.width + other.width);
+            Pt cur;
+            cur.x = next.x * percentage + pos.x * (1 - percentage);
+            cur.y = next.y * percentage + pos.y * (1 - percentage);
+            pos = cur;
+        }
         Pt dir = directionByDistance(pts, s.dis[i]);
         const cfx_vehicle_template &t = sp.templates[sp.vehicles[s.vid[i]].templ];
         num(o, pos.x);
@@ -201,7 +213,9 @@ void ReplayWriter::writeStep(const HostRoadNet &net, const Spawner &sp, const Ve
         num(o, atan2(dir.y, dir.x));
         o.push_back(' ');
         o += sp.vehicleId(s.vid[i]);
-        o += " 0 ";  // lastLaneChangeDirection
+        o.push_back(' ');
+        o += std::to_string(s.lcLastDir.empty() ? 0 : s.lcLastDir[i]);  // Vehicle::lastLaneChangeDirection
+        o.push_back(' ');
         num(o, t.len);
         o.push_back(' ');
         num(o, t.width);

@@ -95,3 +95,25 @@ def test_hip_engine_refuses_lane_change(mod, scen, workdir):
     """No silent fallback: the device path has no lane change yet, so the product library must say so."""
     with pytest.raises(RuntimeError, match="lane change"):
         mod.Engine(scen.materialize("example_1x1", workdir, laneChange=True), 1)
+
+
+def test_replay_log_with_lane_change_matches_reference(scen, workdir):
+    """Engine::updateLog with lane change: positions blended towards the target lane by the lateral offset
+    (Vehicle::getPoint vehicle.cpp:81-105), the laneChangeDir column, shadows left out."""
+    if not os.path.exists(os.path.join(REF_DIR, "libmonotonic_new.so")):
+        pytest.skip("oracle/_ref reference build not present")
+    from test_replay import _cfg, _parse_line
+    steps = 60
+    cfg_r, _, log_r = _cfg(scen, workdir, "example_1x1", "lc_ref", laneChange=True)
+    cfg_m, _, log_m = _cfg(scen, workdir, "example_1x1", "lc_mine", laneChange=True)
+    lcp.run("ref", cfg_r, steps)
+    lcp.run("twin", cfg_m, steps)
+    la, lb = open(log_r).read().splitlines(), open(log_m).read().splitlines()
+    assert len(la) == len(lb) == steps
+    dirs = set()
+    for i, (x, y) in enumerate(zip(la, lb)):
+        va, ga = _parse_line(x)
+        vb, gb = _parse_line(y)
+        assert ga == gb and va == vb, "step %d differs" % i
+        dirs.update(v[4] for v in va)
+    assert dirs == {-1, 0, 1}  # both directions of lane change were logged
