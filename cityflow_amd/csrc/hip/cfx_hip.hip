@@ -893,6 +893,10 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
         if (view->lc_flags) view->lc_flags[i] = 0;
         if (view->lc_offset) view->lc_offset[i] = 0.0;
         if (view->lc_last_dir) view->lc_last_dir[i] = 0;
+        if (view->lc_target_lane) view->lc_target_lane[i] = -1;
+        if (view->lc_direction) view->lc_direction[i] = 0;
+        if (view->lc_last_change_time) view->lc_last_change_time[i] = 0.0;
+        if (view->lc_waiting_time) view->lc_waiting_time[i] = 0.0;
         ++i;
     }
     return CFX_OK;

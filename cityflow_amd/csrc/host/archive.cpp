@@ -53,6 +53,9 @@ std::string Archive::vehicleId(int vid) const {
 
 // Archive::dump archive.cpp:153-343 — same keys, same nesting; vehicles in vehiclePool (priority) order.
 void Archive::dump(const std::string &path) const {
+    if (!dev.rLcFlags.empty())
+        throw std::runtime_error("Archive.dump: archives taken with laneChange=true are not written to the JSON format yet "
+                                 "(snapshot() / load() work in memory)");
     const int L = (int) net->lanes.size();
     const int nV = (int) host.vehicles.size();
     std::vector<int> runIndex(nV, -1);
@@ -208,7 +211,6 @@ void Archive::dump(const std::string &path) const {
 
 // ------------------------------------------------------------------------------------------ EngineHost side
 Archive EngineHost::snapshot() {
-    if (laneChange_) throw std::runtime_error("snapshot: not available with laneChange=true yet (lane-change state is not archived)");
     Archive a;
     a.host = spawner_.saveState();
     a.net = net_;
@@ -237,6 +239,14 @@ Archive EngineHost::snapshot() {
     d.rDis = s.dis;
     d.rSpeed = s.speed;
     d.rGap = s.gap;
+    d.rLcPartner = s.lcPartner;  // all empty without lane change
+    d.rLcFlags = s.lcFlags;
+    d.rLcOffset = s.lcOffset;
+    d.rLcLastDir = s.lcLastDir;
+    d.rLcTarget = s.lcTarget;
+    d.rLcDirection = s.lcDirection;
+    d.rLcLastChangeTime = s.lcLastChangeTime;
+    d.rLcWaitingTime = s.lcWaitingTime;
     d.rCustomSpeed.resize(s.count);
     if (s.count) check(be_.cfx_get_custom_speeds(dev_, s.count, d.rCustomSpeed.data()), "cfx_get_custom_speeds");
     waitingVehicles(d.wVid, d.wLane);
@@ -245,7 +255,8 @@ Archive EngineHost::snapshot() {
 }
 
 void EngineHost::load(const Archive &a) {
-    if (laneChange_) throw std::runtime_error("load: not available with laneChange=true yet (lane-change state is not archived)");
+    if (laneChange_ != !a.dev.rLcFlags.empty() && !a.dev.rVid.empty())
+        throw std::runtime_error("Engine.load: the archive was taken with a different laneChange setting");
     pendingPhaseInter_.clear();
     pendingPhaseValue_.clear();
     if (a.net.get() != net_.get() && a.net->lanes.size() != net_->lanes.size())
@@ -283,6 +294,17 @@ void EngineHost::load(const Archive &a) {
     st.r_dis = d.rDis.data();
     st.r_speed = d.rSpeed.data();
     st.r_custom_speed = d.rCustomSpeed.empty() ? nullptr : d.rCustomSpeed.data();
+    if (laneChange_ && !d.rLcFlags.empty()) {
+        st.r_gap = d.rGap.data();
+        st.r_lc_partner_vid = d.rLcPartner.data();
+        st.r_lc_flags = d.rLcFlags.data();
+        st.r_lc_offset = d.rLcOffset.data();
+        st.r_lc_last_dir = d.rLcLastDir.data();
+        st.r_lc_target_lane = d.rLcTarget.data();
+        st.r_lc_direction = d.rLcDirection.data();
+        st.r_lc_last_change_time = d.rLcLastChangeTime.data();
+        st.r_lc_waiting_time = d.rLcWaitingTime.data();
+    }
     st.n_waiting = (int) d.wVid.size();
     st.w_vid = d.wVid.data();
     st.w_lane = d.wLane.data();
@@ -295,6 +317,9 @@ void EngineHost::load(const Archive &a) {
 
 // Archive(Engine&, filename) archive.cpp:345-550: rebuild an Archive from the reference's JSON format.
 void EngineHost::loadFromFile(const std::string &path) {
+    if (laneChange_)
+        throw std::runtime_error("load_from_file: not available with laneChange=true yet (the JSON format's lane-change "
+                                 "fields are not read; snapshot() / load() work in memory)");
     Json root = Json::parseFile(path);
     Archive a;
     a.net = net_;

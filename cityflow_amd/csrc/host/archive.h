@@ -22,6 +22,10 @@ struct DeviceState {
     // running vehicles in Drivable::vehicles order
     std::vector<int32_t> rVid, rDrivable, rPrevDrivable, rBlocker, rEnterLLTime, rRoutePos, rLeader;
     std::vector<double> rDis, rSpeed, rGap, rCustomSpeed;
+    // lane change (empty without it): the part of LaneChange / LaneChangeInfo that outlives a step
+    std::vector<int32_t> rLcPartner, rLcLastDir, rLcTarget, rLcDirection;
+    std::vector<uint8_t> rLcFlags;
+    std::vector<double> rLcOffset, rLcLastChangeTime, rLcWaitingTime;
     std::vector<int32_t> wVid, wLane;  // waiting buffers, lane by lane
     std::vector<int32_t> tlPhase;
     std::vector<double> tlRemain;

@@ -348,14 +348,18 @@ void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
     want(kSnapLaneChange, s.lcFlags, v.lc_flags);
     want(kSnapLaneChange, s.lcOffset, v.lc_offset);
     want(kSnapLaneChange, s.lcLastDir, v.lc_last_dir);
+    want(kSnapLaneChange, s.lcTarget, v.lc_target_lane);
+    want(kSnapLaneChange, s.lcDirection, v.lc_direction);
+    want(kSnapLaneChange, s.lcLastChangeTime, v.lc_last_change_time);
+    want(kSnapLaneChange, s.lcWaitingTime, v.lc_waiting_time);
     check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
     s.count = v.count;
     s.vid.resize(v.count);
     for (auto *vec : {&s.drivable, &s.prevDrivable, &s.leader, &s.blocker, &s.enterLLTime, &s.routePos})
         if (!vec->empty()) vec->resize(v.count);
-    for (auto *vec : {&s.dis, &s.speed, &s.gap, &s.lcOffset})
+    for (auto *vec : {&s.dis, &s.speed, &s.gap, &s.lcOffset, &s.lcLastChangeTime, &s.lcWaitingTime})
         if (!vec->empty()) vec->resize(v.count);
-    for (auto *vec : {&s.lcPartner, &s.lcLastDir})
+    for (auto *vec : {&s.lcPartner, &s.lcLastDir, &s.lcTarget, &s.lcDirection})
         if (!vec->empty()) vec->resize(v.count);
     if (!s.lcFlags.empty()) s.lcFlags.resize(v.count);
 }

@@ -75,9 +75,9 @@ enum SnapshotField : unsigned {  // what snapshotVehicles should fetch besides t
 struct VehicleSnapshot {
     std::vector<int32_t> vid, drivable, prevDrivable, leader, blocker, enterLLTime, routePos;
     std::vector<double> dis, speed, gap;
-    std::vector<int32_t> lcPartner, lcLastDir;  // lane change (empty unless kSnapLaneChange)
+    std::vector<int32_t> lcPartner, lcLastDir, lcTarget, lcDirection;  // lane change (empty unless kSnapLaneChange)
     std::vector<uint8_t> lcFlags;               // CFX_LC_* bits
-    std::vector<double> lcOffset;
+    std::vector<double> lcOffset, lcLastChangeTime, lcWaitingTime;
     int count = 0;
     bool isShadow(int i) const { return !lcFlags.empty() && (lcFlags[i] & CFX_LC_SHADOW); }
 };

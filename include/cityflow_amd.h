@@ -153,6 +153,10 @@ typedef struct cfx_vehicle_view {
     uint8_t *lc_flags;       /* CFX_LC_* bits */
     double *lc_offset;       /* LaneChangeInfo::offset */
     int32_t *lc_last_dir;    /* LaneChange::lastDir (what the replay log prints, engine.cpp:524) */
+    int32_t *lc_target_lane; /* signalSend->target while CFX_LC_CHANGING (the only signal that outlives a step), else -1 */
+    int32_t *lc_direction;   /* signalSend->direction, same condition, else 0 */
+    double *lc_last_change_time; /* LaneChange::lastChangeTime */
+    double *lc_waiting_time;     /* LaneChange::waitingTime */
 } cfx_vehicle_view;
 #define CFX_LC_SHADOW 1u   /* partnerType == 2: a shadow; its id is "<parent id>_shadow" until the change finishes */
 #define CFX_LC_PARENT 2u   /* partnerType == 1: the real vehicle of a changing pair */
@@ -224,6 +228,12 @@ typedef struct cfx_state {
     const int32_t *r_vid, *r_drivable, *r_prev_drivable, *r_blocker_vid, *r_enter_ll_time, *r_route_pos;
     const double *r_dis, *r_speed;
     const double *r_custom_speed;    /* NaN where no custom speed is pending; may be NULL */
+    /* lane change (all may be NULL = no lane-change state): what of LaneChange / LaneChangeInfo outlives a step —
+     * signals received, target leader / follower are cleared by every step's clearSignal (engine.cpp:424) */
+    const double *r_gap;             /* ControllerInfo::gap (stored state: makeSignal reads it without a leader) */
+    const int32_t *r_lc_partner_vid, *r_lc_last_dir, *r_lc_target_lane, *r_lc_direction;
+    const uint8_t *r_lc_flags;       /* CFX_LC_* */
+    const double *r_lc_offset, *r_lc_last_change_time, *r_lc_waiting_time;
     /* waiting buffers, lane by lane, FIFO order */
     int32_t n_waiting;
     const int32_t *w_vid, *w_lane;

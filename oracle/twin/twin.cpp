@@ -1227,6 +1227,10 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
                                                (v.changing ? CFX_LC_CHANGING : 0));
             if (view->lc_offset) view->lc_offset[i] = v.offset;
             if (view->lc_last_dir) view->lc_last_dir[i] = v.lastDir;
+            if (view->lc_target_lane) view->lc_target_lane[i] = v.changing ? v.sendTarget : -1;
+            if (view->lc_direction) view->lc_direction[i] = v.changing ? v.sendDir : 0;
+            if (view->lc_last_change_time) view->lc_last_change_time[i] = v.lastChangeTime;
+            if (view->lc_waiting_time) view->lc_waiting_time[i] = v.waitingTime;
             ++i;
         }
     return CFX_OK;
@@ -1307,10 +1311,6 @@ int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {
 
 // Archive::resume (archive.cpp:73-126) on the flat state
 int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
-    if (e->cfg.lane_change) {
-        e->err = "cfx_load_state: not available with lane change (cfx_state carries no lane-change fields yet)";
-        return CFX_ERR_STATE;
-    }
     e->resetState();
     e->step = s->step;
     e->finishedCnt = s->finished_vehicle_count;
@@ -1340,6 +1340,23 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         if (s->r_custom_speed && s->r_custom_speed[i] == s->r_custom_speed[i]) {
             x.customSet = true;
             x.customSpeed = s->r_custom_speed[i];
+        }
+        if (s->r_gap) x.gap = s->r_gap[i];
+        if (s->r_lc_flags) {
+            const uint8_t f = s->r_lc_flags[i];
+            x.partnerType = (f & CFX_LC_SHADOW) ? 2 : ((f & CFX_LC_PARENT) ? 1 : 0);
+            x.changing = (f & CFX_LC_CHANGING) != 0;
+        }
+        if (s->r_lc_partner_vid) x.partner = s->r_lc_partner_vid[i];
+        if (s->r_lc_offset) x.offset = s->r_lc_offset[i];
+        if (s->r_lc_last_dir) x.lastDir = s->r_lc_last_dir[i];
+        if (s->r_lc_last_change_time) x.lastChangeTime = s->r_lc_last_change_time[i];
+        if (s->r_lc_waiting_time) x.waitingTime = s->r_lc_waiting_time[i];
+        if (x.changing && s->r_lc_target_lane && s->r_lc_direction) {  // the signal of a change in progress
+            x.sigSend = true;
+            x.sendTarget = s->r_lc_target_lane[i];
+            x.sendDir = s->r_lc_direction[i];
+            x.sendUrgency = 1;
         }
         e->order[x.drivable].push_back(s->r_vid[i]);
         e->active += 1;
