@@ -63,6 +63,44 @@ struct SlotArrays {
     double *speed;      // VehicleInfo::speed
 };
 
+// Lane change (reference src/vehicle/lanechange.{h,cpp}, vehicle.h:74-79): per-vehicle state, sparse and rarely
+// touched, so it lives in tables indexed by vid and the slot arrays / the compaction stay as they are.  `on == 0`
+// unless the engine was created with cfx_config::lane_change.
+struct LcInsert {  // one shadow created in this step (Engine::insertShadow engine.cpp:812-820)
+    int32_t parentVid, parentSlot, lane, recvFrom;  // recvFrom: signal the shadow received later in the same walk
+    double dis;
+};
+struct LcDev {
+    int on;
+    const double *laneWidth;        // [L] Lane::width
+    const int32_t *roadLaneStart;   // [R+1] lanes of a road are contiguous
+    // LaneChangeInfo vehicle.h:74-79
+    int8_t *ptype;                  // 0 none, 1 real vehicle of a changing pair, 2 shadow
+    int32_t *partner;               // vid or -1
+    double *offset;
+    // LaneChange lanechange.h:27-44; signalSend = {present, target lane, urgency, direction}; of signalRecv only its
+    // source is ever read
+    int8_t *sigSend, *sendDir, *sendUrg, *lastDir, *changing, *lcFinished;
+    int32_t *sendTarget, *recvFrom, *tLeader, *tFollower;
+    double *leaderGap, *followerGap, *lastChangeTime;
+    double *gap;                    // ControllerInfo::gap as stored state (makeSignal reads it without a leader)
+    int32_t *slotOf;                // current slot of a running vehicle
+    // vehicles whose step is finished by k_lc_resolve (changing pairs; vehicles signalled by an earlier changing vehicle):
+    // their speed before the lane-change yield and their blocker, and the list of them (shadows go with their partner)
+    double *bSpeed;
+    int32_t *bBlocker;
+    int32_t *parkList;              // [slot capacity]
+    int32_t *parkCount;             // [1]
+    // this step's scratch
+    int32_t *roadCand;              // [R] candidates on the road (plan -> schedule)
+    int32_t *insHead, *insNext;     // [L] / [insCap] records of a target lane, linked
+    LcInsert *ins;
+    int32_t *insCount;              // [1]
+    int insCap;
+    const int32_t *pool;            // priorities the host's generator would hand out next (cfx_lane_change_supply)
+    int firstShadowVid;
+};
+
 // Everything the per-step kernels read.  Passed by value (kernel argument segment).
 struct StepCtx {
     DevNet n;
@@ -86,6 +124,7 @@ struct StepCtx {
     int2 *admitRec;           // [L] {admitted vid, its successor in the lane's FIFO}: what k_scan needs to commit the pop
     int32_t step;
     double interval;
+    LcDev lc;
 };
 
 namespace cfxd {

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "cfx_kernels.h"
+#include "cfx_lc_kernels.h"
 
 using namespace cfxd;
 
@@ -137,6 +138,16 @@ struct cfx_engine {
     std::vector<uint8_t> laneQueued;   // lanes that have ever had a vehicle queued (only they can admit)
     int64_t nQueueLanes = 0, spawnedHere = 0;  // ... their number; vehicles spawned onto this engine's lanes
 
+    // ---- lane change (cfx_config::lane_change) ----
+    LcDev lc{};                        // device tables (vid-indexed ones grow with the vehicle table)
+    int32_t *oldToNew2 = nullptr;      // [slot] scratch of the mid-step rebuild
+    int32_t *dPool = nullptr;          // priorities of the step's shadows (device)
+    int32_t *hPool = nullptr;          // ... pinned staging
+    int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1..] their parents in creation order
+    hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
+    int poolN = 0;                     // priorities supplied for the next / current step
+    bool pollPending = false;          // a lane-change step has run and was not polled yet
+
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
     int64_t finishedOffset = 0; // finished vehicles that are not in the vid table (state loaded from an archive)
@@ -250,6 +261,7 @@ struct cfx_engine {
         c.interMask = interMask;
         c.step = (int32_t) step;
         c.interval = cfg.interval;
+        c.lc = lc;
         return c;
     }
 
@@ -265,6 +277,14 @@ struct cfx_engine {
         if ((rc = grow(&vt.state, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.customSpeed, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.pendingCustom, (size_t) spawned, nc))) return rc;
+        if (lc.on) {
+#define GROW_LC(f) if ((rc = grow(&lc.f, (size_t) spawned, nc))) return rc;
+            GROW_LC(ptype) GROW_LC(partner) GROW_LC(offset) GROW_LC(sigSend) GROW_LC(sendDir) GROW_LC(sendUrg) GROW_LC(lastDir)
+            GROW_LC(changing) GROW_LC(lcFinished) GROW_LC(sendTarget) GROW_LC(recvFrom) GROW_LC(tLeader) GROW_LC(tFollower)
+            GROW_LC(leaderGap) GROW_LC(followerGap) GROW_LC(lastChangeTime) GROW_LC(gap) GROW_LC(slotOf) GROW_LC(bSpeed)
+            GROW_LC(bBlocker)
+#undef GROW_LC
+        }
         // nextWait of not-yet-used vids must read -1 (k_spawn_link relies on it)
         HIP_TRY(hipMemsetAsync(vt.nextWait + spawned, 0xFF, (nc - (size_t) spawned) * sizeof(int32_t), stream));
         vidCap = nc;
@@ -292,6 +312,8 @@ struct cfx_engine {
         if ((rc = grow(&crossJobs, 0, nc * kJobShards))) return rc;
 #undef GROW_SCRATCH
         if ((rc = grow(&oldToNew, keep, nc))) return rc;  // committed blockers point through it
+        if (lc.on && (rc = grow(&oldToNew2, 0, nc))) return rc;
+        if (lc.on && (rc = grow(&lc.parkList, 0, nc))) return rc;
         slotCap = nc;
         return CFX_OK;
     }
@@ -333,6 +355,8 @@ struct cfx_engine {
         finishedKnown = out.finishedCnt;
         if (out.overflow == 4) return fail("halo: a neighbour tile did not publish its step in time (cfx_halo_wait)");
         if (out.overflow == 3) return fail("halo: more vehicles crossed one cut lane in one step than CFX_HALO_MAX_MIGRANTS");
+        if (out.overflow == 5) return fail("lane change: more shadows in one step than priorities supplied (cfx_lane_change_supply)");
+        if (out.overflow == 6) return fail("lane change: more shadows on one road in one step than the schedule walk tracks");
         if (out.overflow) return fail("device capacity overflow (finish list)");
         return CFX_OK;
     }
@@ -341,6 +365,13 @@ struct cfx_engine {
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
+        pollPending = false;
+        poolN = 0;
+        if (lc.on) {
+            HIP_TRY(hipMemsetAsync(lc.roadCand, 0, (size_t) std::max(R, 1) * sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.insHead, 0xFF, (size_t) std::max(L, 1) * sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.parkCount, 0, sizeof(int32_t), stream));
+        }
         laneQueued.assign((size_t) L, 0);
         nQueueLanes = 0;
         spawnedHere = 0;
@@ -526,6 +557,21 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->scanTicket, 1))) return rc;
     if ((rc = e->allocRaw(&e->jobCount, (size_t) kJobShards * kJobShardStride))) return rc;
     if ((rc = e->allocRaw(&e->sc, 1))) return rc;
+    if (cfg->lane_change) {
+        LcDev &lc = e->lc;
+        lc.on = 1;
+        if ((rc = e->uploadConst(lc.laneWidth, n->lane_width, (size_t) e->L))) return rc;
+        if ((rc = e->uploadConst(lc.roadLaneStart, n->road_lane_start, (size_t) e->R + 1))) return rc;
+        if ((rc = e->allocRaw(&lc.roadCand, (size_t) e->R))) return rc;
+        HIP_TRY(hipMemset(lc.roadCand, 0, (size_t) std::max(e->R, 1) * sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.insHead, (size_t) e->L))) return rc;
+        HIP_TRY(hipMemset(lc.insHead, 0xFF, (size_t) std::max(e->L, 1) * sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.insCount, 1))) return rc;
+        HIP_TRY(hipMemset(lc.insCount, 0, sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.parkCount, 1))) return rc;
+        HIP_TRY(hipMemset(lc.parkCount, 0, sizeof(int32_t)));
+        HIP_TRY(hipEventCreateWithFlags(&e->pollEvent, hipEventDisableTiming));
+    }
     if ((rc = e->ensureSlotCap((size_t) e->L + 4096))) return rc;
     if ((rc = e->ensureVidCap(1 << 16))) return rc;
     return e->resetState();
@@ -536,8 +582,8 @@ int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
         g_createError = "cfx_create: null argument";
         return CFX_ERR_INVALID;
     }
-    if (cfg->lane_change) {
-        g_createError = "cfx_create: lane change (cfx_config::lane_change) is not built on the HIP path yet; the step it needs is specified by the CPU twin (oracle/twin) and include/cityflow_amd.h";
+    if (cfg->lane_change && (!n->lane_width || !n->road_lane_start)) {
+        g_createError = "cfx_create: lane_change needs cfx_net::lane_width and road_lane_start";
         return CFX_ERR_INVALID;
     }
     cfx_engine *e = new cfx_engine();
@@ -581,6 +627,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     if ((rc = e->syncTables())) return rc;
     hipStream_t st = e->stream;
 
+    if (e->lc.on) {
+        if (e->pollPending) return e->fail("cfx_step: the previous lane-change step was not polled (cfx_lane_change_poll)");
+        if (!e->hPoll) return e->fail("cfx_step: cfx_lane_change_supply must be called before a step with lane change");
+        if ((rc = e->ensureVidCap((size_t) e->spawned + (size_t) n + (size_t) e->poolN))) return rc;
+    }
     // ---- phase 0/1 tail: hand the spawn records to the device
     if (n > 0) {
         // the batch carries the next n vehicle numbers, each once, in any order (checked in full by the CPU twin)
@@ -634,29 +685,55 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const int64_t a = e->spawnedHere - (e->finishedKnown - e->finishedOffset);
         return e->tiled ? e->liveUpper : std::min(a, e->liveUpper);
     };
-    size_t need = (size_t) (bound() + spare) + 1;
+    const int64_t shadowRoom = e->lc.on ? e->poolN : 0;  // this step's shadows
+    size_t need = (size_t) (bound() + spare + shadowRoom) + 1;
     if (need > e->slotCap && !e->tiled) {
         // the device's own count as of the last step it has completed, read without waiting for it
         const unsigned long long pr = __atomic_load_n(&e->hMirror->progress, __ATOMIC_RELAXED);
         const int64_t done = (int64_t) (pr >> 32);
         if (done > 0 && done <= e->step) {
             e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + e->nQueueLanes * (e->step + 1 - done));
-            need = (size_t) (bound() + spare) + 1;
+            need = (size_t) (bound() + spare + shadowRoom) + 1;
         }
     }
     if (need > e->slotCap) {
         DevScalars s;
         if ((rc = e->readScalars(s))) return rc;  // refreshes finishedKnown too
         e->liveUpper = s.active + 2 * (int64_t) e->halo.nGhost + e->nQueueLanes;
-        need = (size_t) (bound() + spare) + 1;
+        need = (size_t) (bound() + spare + shadowRoom) + 1;
         if ((rc = e->ensureSlotCap(need))) return rc;
     }
 
+    if (e->lc.on) {  // per-step fields of the lane-change context
+        e->lc.firstShadowVid = (int) e->spawned;
+        e->lc.pool = e->dPool;
+        e->lc.insCap = e->poolN;
+    }
     StepCtx c = e->ctx();
-    const int nxt = e->cur ^ 1;
     const size_t slotBound = std::min(need, e->slotCap);
     e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
+    if (e->lc.on) {
+        // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
+        // with the step's shadows in place (cfx_lc_kernels.h)
+        const int mid = e->cur ^ 1;
+        if (n > 0) hipLaunchKernelGGL(k_lc_init, dim3(gridFor(n)), dim3(kBlock), 0, st, e->lc, (int) (e->spawned - n), (int) n);
+        HIP_TRY(hipMemsetAsync(e->lc.insCount, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_lc_plan, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
+        hipLaunchKernelGGL(k_lc_schedule, dim3(gridFor(e->R)), dim3(kBlock), 0, st, c, e->sc, (const int32_t *) e->vt.priority);
+        hipLaunchKernelGGL(k_lc_assign, dim3(1), dim3(1024), 0, st, c, e->vt, e->sc, e->hPoll);
+        HIP_TRY(hipEventRecord(e->pollEvent, st));  // cfx_lane_change_poll waits for this, not for the whole step
+        e->pollPending = true;
+        hipLaunchKernelGGL(k_lc_layout, dim3(1), dim3(1024), 0, st, c, e->waitHead, e->vt, e->sc, e->net.laneSpare, e->segStart[mid].p, e->cnt[mid].p, e->gen[mid].vid, e->gen[mid].drv);
+        hipLaunchKernelGGL(k_lc_move, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->gen[mid],
+                           (const int32_t *) e->segStart[mid].p, e->oldToNew2);
+        hipLaunchKernelGGL(k_lc_compose, dim3(gridFor(std::max<size_t>(e->slotCap, (size_t) e->L))), dim3(kBlock), 0, st, e->oldToNew,
+                           (const int32_t *) e->oldToNew2, (int) e->slotCap, e->admitStep, e->lc.insHead, (int) e->L, (int) e->step);
+        HIP_TRY(hipGetLastError());
+        e->cur = mid;
+        c = e->ctx();
+    }
+    const int nxt = e->cur ^ 1;
     // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
     // throughput (far fewer wave-rounds per vehicle).  They break even at ~220 k slots on the MI355X.
     const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
@@ -673,6 +750,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->launch(PK_CROSS, k_cross,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                   dim3(kCrossBlock), c, ao, jq);
+    if (e->lc.on) hipLaunchKernelGGL(k_lc_resolve, dim3(1), dim3(kBlock), 0, st, c, ao, e->oldToNew2);  // (scratch is free here)
     int32_t *const scanTicket = e->nScanBlocks > kScanResidentTiles ? e->scanTicket : nullptr;
     e->launch(PK_SCAN, k_scan, dim3(e->nScanBlocks), dim3(kBlock), (int) e->D, (int) e->L, (const int32_t *) e->cnt[e->cur].p, e->cs,
               e->scanGranules, scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
@@ -685,6 +763,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
               e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat);
+    if (e->lc.on)
+        hipLaunchKernelGGL(k_lc_clear, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, e->lc, (const int32_t *) e->gen[nxt].vid,
+                           (const int32_t *) e->segStart[nxt].p, (int) e->D);
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;
@@ -860,6 +941,28 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
             HIP_TRY(dl(o2n.data(), e->oldToNew, e->slotCap * 4));
         }
     }
+    // lane change: per-vehicle state lives in vid-indexed tables
+    const bool wantLc = e->lc.on && (view->lc_partner_vid || view->lc_flags || view->lc_offset || view->lc_last_dir ||
+                                     view->lc_target_lane || view->lc_direction || view->lc_last_change_time || view->gap);
+    std::vector<int8_t> lcType, lcChanging, lcLastDir, lcSendDir;
+    std::vector<int32_t> lcPartner, lcTarget;
+    std::vector<double> lcOffset, lcLastTime, lcGap;
+    if (wantLc) {
+        const size_t nv = (size_t) e->spawned;
+        lcType.resize(nv); lcChanging.resize(nv); lcLastDir.resize(nv); lcSendDir.resize(nv);
+        lcPartner.resize(nv); lcTarget.resize(nv); lcOffset.resize(nv); lcLastTime.resize(nv); lcGap.resize(nv);
+        if (nv) {
+            HIP_TRY(dl(lcType.data(), e->lc.ptype, nv));
+            HIP_TRY(dl(lcChanging.data(), e->lc.changing, nv));
+            HIP_TRY(dl(lcLastDir.data(), e->lc.lastDir, nv));
+            HIP_TRY(dl(lcSendDir.data(), e->lc.sendDir, nv));
+            HIP_TRY(dl(lcPartner.data(), e->lc.partner, nv * 4));
+            HIP_TRY(dl(lcTarget.data(), e->lc.sendTarget, nv * 4));
+            HIP_TRY(dl(lcOffset.data(), e->lc.offset, nv * 8));
+            HIP_TRY(dl(lcLastTime.data(), e->lc.lastChangeTime, nv * 8));
+            HIP_TRY(dl(lcGap.data(), e->lc.gap, nv * 8));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     int n = 0;
     for (int s = 0; s < S; ++s) n += vid[s] >= 0;
@@ -889,14 +992,20 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
         if (view->dis) view->dis[i] = dis[s];
         if (view->speed) view->speed[i] = speed[s];
         if (view->gap) view->gap[i] = gap[s];
-        if (view->lc_partner_vid) view->lc_partner_vid[i] = -1;  // lane change is not on the device path (cfx_create)
-        if (view->lc_flags) view->lc_flags[i] = 0;
-        if (view->lc_offset) view->lc_offset[i] = 0.0;
-        if (view->lc_last_dir) view->lc_last_dir[i] = 0;
-        if (view->lc_target_lane) view->lc_target_lane[i] = -1;
-        if (view->lc_direction) view->lc_direction[i] = 0;
-        if (view->lc_last_change_time) view->lc_last_change_time[i] = 0.0;
-        if (view->lc_waiting_time) view->lc_waiting_time[i] = 0.0;
+        const int v = vid[s];
+        if (wantLc && view->gap && lead[s] < 0) view->gap[i] = lcGap[v];  // ControllerInfo::gap keeps its last value
+        const bool chg = wantLc && lcChanging[v];
+        if (view->lc_partner_vid) view->lc_partner_vid[i] = wantLc ? lcPartner[v] : -1;
+        if (view->lc_flags)
+            view->lc_flags[i] = wantLc ? (uint8_t) ((lcType[v] == 2 ? CFX_LC_SHADOW : 0) | (lcType[v] == 1 ? CFX_LC_PARENT : 0) |
+                                                   (chg ? CFX_LC_CHANGING : 0))
+                                       : 0;
+        if (view->lc_offset) view->lc_offset[i] = wantLc ? lcOffset[v] : 0.0;
+        if (view->lc_last_dir) view->lc_last_dir[i] = wantLc ? lcLastDir[v] : 0;
+        if (view->lc_target_lane) view->lc_target_lane[i] = chg ? lcTarget[v] : -1;
+        if (view->lc_direction) view->lc_direction[i] = chg ? lcSendDir[v] : 0;
+        if (view->lc_last_change_time) view->lc_last_change_time[i] = wantLc ? lcLastTime[v] : 0.0;
+        if (view->lc_waiting_time) view->lc_waiting_time[i] = 0.0;  // LaneChange::waitingTime is write-only in the reference; not kept
         ++i;
     }
     return CFX_OK;
@@ -1008,15 +1117,57 @@ int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *dri
     return CFX_OK;
 }
 
-// Lane change (reference lanechange.cpp) is not built on the device path yet: cfx_create refuses lane_change = 1, so
-// these two can only report that.
-int32_t cfx_lane_change_supply(cfx_engine *e, int32_t, const int32_t *) {
-    if (!e) return CFX_ERR_INVALID;
-    return e->fail("cfx_lane_change_supply: this engine was created without lane change"), CFX_ERR_STATE;
+// Lane change: the priorities the step's shadows will get, and who got one (include/cityflow_amd.h "Lane change")
+int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *priorities) {
+    if (!e || n < 0 || (n && !priorities)) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    if (!e->lc.on) return e->fail("cfx_lane_change_supply: this engine was created without lane change"), CFX_ERR_STATE;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if (e->pollPending) return e->fail("cfx_lane_change_supply: the previous lane-change step was not polled"), CFX_ERR_STATE;
+    if (n > e->lc.insCap || !e->dPool) {  // (re)allocate pool, records and the landing buffer of the poll
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const size_t cap = std::max<size_t>((size_t) n, 1024);
+        if ((rc = e->grow(&e->dPool, 0, cap))) return rc;
+        if ((rc = e->grow(&e->lc.ins, 0, cap))) return rc;
+        if ((rc = e->grow(&e->lc.insNext, 0, cap))) return rc;
+        if (e->hPool) HIP_TRY(hipHostFree(e->hPool));
+        if (e->hPoll) HIP_TRY(hipHostFree(e->hPoll));
+        HIP_TRY(hipHostMalloc((void **) &e->hPool, cap * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **) &e->hPoll, (cap + 1) * sizeof(int32_t), hipHostMallocDefault));
+        e->lc.insCap = (int) cap;
+    }
+    // (the previous step was polled, so the device is done with the pinned staging buffer)
+    memcpy(e->hPool, priorities, (size_t) n * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(e->dPool, e->hPool, (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    e->poolN = n;
+    return CFX_OK;
 }
-int32_t cfx_lane_change_poll(cfx_engine *e, int32_t, int32_t *, int32_t *) {
-    if (!e) return CFX_ERR_INVALID;
-    return e->fail("cfx_lane_change_poll: this engine was created without lane change"), CFX_ERR_STATE;
+
+int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vid, int32_t *n) {
+    if (!e || !n || capacity < 0 || (capacity && !parent_vid)) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    if (!e->lc.on) return e->fail("cfx_lane_change_poll: this engine was created without lane change"), CFX_ERR_STATE;
+    *n = 0;
+    if (!e->pollPending) return CFX_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->pollEvent));  // plan + schedule + assign of the step; the rest keeps running
+    e->pollPending = false;
+    const int k = e->hPoll[0];
+    if (k > e->poolN) {
+        e->err = "lane change: more shadows in one step than priorities supplied (cfx_lane_change_supply)";
+        return CFX_ERR_CAPACITY;
+    }
+    if (k > capacity) {
+        e->err = "cfx_lane_change_poll: capacity too small";
+        return CFX_ERR_CAPACITY;
+    }
+    for (int i = 0; i < k; ++i) parent_vid[i] = e->hPoll[1 + i];
+    *n = k;
+    e->spawned += k;  // shadows are vehicles: the next step's spawn records are numbered after them
+    e->spawnedHere += k;
+    e->liveUpper += k;
+    return CFX_OK;
 }
 
 int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {

@@ -48,7 +48,7 @@ struct DevScalars {
     int nFinishedStep;         // finished vehicles of the step in flight
     int overflow;              // set when an internal capacity was exceeded
     int nCrossJobs;            // vehicles queued for k_cross in the step in flight
-    int pad;
+    int nLeftUncounted;        // lane change: real vehicles of completed changes that left this step (not "finished")
 };
 
 struct HostMirror {  // pinned host copy of the end-of-step scalars (written by k_scatter's statistics block)
@@ -340,16 +340,35 @@ struct ActionOut {
     int finCap;
 };
 
-__device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template &t, int s, int d,
-                                    int vid, double speed, double dis, double dlen, int nd0, double v, int blockerSlot) {
-    const double interval = c.interval;
-    v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
-    const int route = c.s.route[s];
-    if (nd0 < 0 && !isLastRoad(c, d, route)) {  // !Router::onValidLane router.h:66-68
-        double vn = noCollisionSpeed(0, 1, speed, t.max_neg_acc, dlen - dis, interval, t.min_gap);
-        v = min2(v, vn);
+// SimpleLaneChange::yieldSpeed lanechange.cpp:186-206: 100 unless another vehicle's lane-change signal reached this one
+// (then: slow down so that the sender's gap behind it becomes safe; the sender's target leader never yields).
+__device__ inline double lcYieldSpeed(const StepCtx &c, int vid, double speed, const cfx_vehicle_template &t) {
+    const int src = c.lc.recvFrom[vid];
+    if (src < 0) return 100;
+    if (vid == c.lc.tLeader[src]) return 100;
+    const cfx_vehicle_template *tv = c.t.templ;
+    const int ss = c.lc.slotOf[src];
+    double safeBefore = 0;  // safeGapBefore lanechange.cpp:213-215
+    const int f = c.lc.tFollower[src];
+    if (f >= 0) {
+        const int fs = c.lc.slotOf[f];
+        const double fsp = c.s.speed[fs];
+        safeBefore = 0.5 * fsp * fsp / tv[c.s.templ[fs]].max_neg_acc;
     }
-    v = max2(v, speed - t.max_neg_acc * interval);
+    const double gap = c.lc.followerGap[src] - safeBefore;
+    double v = noCollisionSpeed(c.s.speed[ss], tv[c.s.templ[ss]].max_neg_acc, speed, t.max_neg_acc, gap, c.interval, 0);
+    if (v < 0) v = 100;  // "if the follower is too fast, let it go"
+    return v;
+}
+
+// Engine::vehicleControl engine.cpp:212-221 + Vehicle::setDeltaDistance vehicle.cpp:49-68 for a known next speed
+struct MoveOut {
+    double v, ndis;
+    int newDrv;  // -1 stays, -2 end of route, >= 0 new drivable
+};
+__device__ inline MoveOut computeMove(const StepCtx &c, const cfx_vehicle_template &t, int s, int d, double speed, double dis,
+                                      double dlen, int nd0, double v) {
+    const double interval = c.interval;
     double deltaDis;
     if (v < 0) {
         deltaDis = 0.5 * speed * speed / t.max_neg_acc;
@@ -362,6 +381,7 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
     if (ndis > dlen) {
         int drivable = d;
         int nxt = nd0;
+        const int route = c.s.route[s];
         const int routePos = c.s.routePos[s];
         for (;;) {
             ndis -= c.n.drvLength[drivable];
@@ -371,24 +391,71 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
             nxt = nextOf(c.n, c.t, drivable, route, routePos);
         }
     }
-    o.b.dis[s] = ndis;
-    o.b.speed[s] = v;
-    o.b.drv[s] = newDrv;
+    return MoveOut{v, ndis, newDrv};
+}
+
+// The buffered results and the classification half of threadUpdateLocation (engine.cpp:290-310: per-drivable leave /
+// enter counts for the compaction).  `counted` is false only for the real vehicle of a COMPLETED lane change: it leaves
+// the simulation without being a finished vehicle (its shadow carries on, engine.cpp:299).
+__device__ inline void commitMove(const StepCtx &c, const ActionOut &o, int s, int d, int vid, const MoveOut &m,
+                                  int blockerSlot, bool counted) {
+    o.b.dis[s] = m.ndis;
+    o.b.speed[s] = m.v;
+    o.b.drv[s] = m.newDrv;
     o.b.blocker[s] = blockerSlot;
-    if (newDrv != -1) {
+    if (m.newDrv != -1) {
         const int k = s - c.segStart[d];
         atomicAdd(&o.cs.leaveCnt[d], 1);
         atomicMax(&o.cs.maxLeaveIdx[d], k);
-        if (newDrv >= 0) {
-            atomicAdd(&o.cs.inCnt[newDrv], 1);
-            o.cs.inNext[s] = atomicExch(&o.cs.inHead[newDrv], s);
+        if (m.newDrv >= 0) {
+            atomicAdd(&o.cs.inCnt[m.newDrv], 1);
+            o.cs.inNext[s] = atomicExch(&o.cs.inHead[m.newDrv], s);
         } else {
             o.vt.state[vid] = 2;
-            int idx = atomicAdd(&o.sc->nFinishedStep, 1);
-            if (idx < o.finCap) o.finList[idx] = s;
-            else o.sc->overflow = 1;
+            if (counted) {
+                int idx = atomicAdd(&o.sc->nFinishedStep, 1);
+                if (idx < o.finCap) o.finList[idx] = s;
+                else o.sc->overflow = 1;
+            } else {
+                atomicAdd(&o.sc->nLeftUncounted, 1);
+            }
         }
     }
+}
+
+// The rest of Vehicle::getNextSpeed after the lane-change yield (vehicle.cpp:325-331): the brake on a lane that does not
+// lead on (!Router::onValidLane router.h:66-68) and the deceleration limit.
+__device__ inline double speedTail(const StepCtx &c, const cfx_vehicle_template &t, int s, int d, double speed, double dis,
+                                   double dlen, int nd0, double v) {
+    if (nd0 < 0 && !isLastRoad(c, d, c.s.route[s])) {
+        double vn = noCollisionSpeed(0, 1, speed, t.max_neg_acc, dlen - dis, c.interval, t.min_gap);
+        v = min2(v, vn);
+    }
+    return max2(v, speed - t.max_neg_acc * c.interval);
+}
+
+__device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template &t, int s, int d,
+                                    int vid, double speed, double dis, double dlen, int nd0, double v, int blockerSlot) {
+    if (c.lc.on) {
+        // Two kinds of vehicles cannot be finished here, because the reference's walk over the vehicles (creation order)
+        // makes their speed depend on what happened to an EARLIER vehicle in the same walk (k_lc_resolve does them, in
+        // that order): the two vehicles of a changing pair (common speed, engine.cpp:195-205), and a vehicle signalled by
+        // an earlier changing vehicle — if that one completes its change in this step, its signal's neighbours are
+        // already cleared when this vehicle evaluates yieldSpeed (LaneChange::finishChanging -> clearSignal).
+        const int pt = c.lc.ptype[vid];
+        const int src = c.lc.recvFrom[vid];
+        if (pt != 0 || (src >= 0 && c.lc.changing[src] && src < vid)) {
+            c.lc.bSpeed[vid] = v;  // before the yield
+            c.lc.bBlocker[vid] = blockerSlot;
+            if (pt != 2) c.lc.parkList[atomicAdd(c.lc.parkCount, 1)] = vid;  // a shadow goes with its real vehicle
+            return;
+        }
+        v = min2(v, lcYieldSpeed(c, vid, speed, t));
+    } else {
+        v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
+    }
+    v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);
+    commitMove(c, o, s, d, vid, computeMove(c, t, s, d, speed, dis, dlen, nd0, v), blockerSlot, true);
 }
 
 // Engine::threadGetAction / vehicleControl engine.cpp:188-251,402-413 with Vehicle::getNextSpeed
@@ -451,6 +518,7 @@ __device__ __forceinline__ void actionOne(const StepCtx &c, const ActionOut &o, 
     } else {
         ls = findLeader(c, tv, s, d, true, dis, t.approach_dist, &gap);
     }
+    if (c.lc.on && ls >= 0) c.lc.gap[vid] = gap;  // lane change reads ControllerInfo::gap as stored state
 
     // --- Vehicle::getNextSpeed vehicle.cpp:308-335
     double v = t.max_speed;
@@ -865,8 +933,9 @@ __device__ inline bool finishStatistics(const StepCtx &c, const VidTable &vt, De
         sc->cumulativeTravelTime = cum;
         sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
         sc->finishedCnt += F;
-        sc->active -= F;
+        sc->active -= F + sc->nLeftUncounted;
         sc->nFinishedStep = 0;
+        sc->nLeftUncounted = 0;
     }
     return last;
 }

@@ -1,0 +1,588 @@
+// Lane change on the device (reference src/vehicle/lanechange.cpp, engine.cpp:374-400,571-575,792-820; the semantics are
+// the CPU twin's, oracle/twin/twin.cpp, which is pinned against the reference).  Only launched when the engine was created
+// with cfx_config::lane_change; the per-step order is
+//   k_spawn_link, k_admit                     as always (the admission sits in the lane's spare slot)
+//   k_lc_plan       Lane::initSegments + threadPlanLaneChange: every real vehicle makes its signal
+//   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in creation (vid) order
+//   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in creation order
+//   k_lc_layout / k_lc_move / k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
+//   k_action, k_cross                         as always; a changing pair parks its two next speeds
+//   k_lc_resolve    the vehicles whose step depends on an earlier vehicle of the reference's walk: changing pairs (common
+//                   speed, lateral offset, finish / abort, engine.cpp:195-205,223-244) and vehicles they signalled
+//   k_scan, k_scatter                         as always
+//   k_lc_clear      LaneChange::clearSignal for every vehicle (engine.cpp:424) + slot of every vehicle
+// Lanes are ordered by distance (front = furthest), so the reference's segment lists (Lane::getVehicleAfterDistance /
+// BeforeDistance, roadnet.cpp:877-898) reduce to binary searches.
+#pragma once
+
+#include "cfx_kernels.h"
+
+namespace cfxd {
+
+constexpr int kLcRoadInserts = 32;  // shadows one road can get in one step (more: CFX_ERR_CAPACITY)
+
+// LaneChange::planChange lanechange.cpp:23-25
+__device__ __forceinline__ bool lcPlanChange(const LcDev &lc, int vid, int drv) {
+    return (lc.sigSend[vid] && lc.sendTarget[vid] >= 0 && lc.sendTarget[vid] != drv) || lc.changing[vid];
+}
+
+// Index (inside lane `lane`) of the rearmost vehicle with distance >= dis, or -1: Lane::getVehicleAfterDistance
+__device__ inline int lcRearmostAtLeast(const StepCtx &c, int lane, double dis) {
+    const int base = c.segStart[lane];
+    int lo = 0, hi = cntNow(c, lane);  // first index whose distance is < dis
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c.s.dis[base + mid] >= dis) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo - 1;
+}
+
+// SimpleLaneChange::estimateGap lanechange.cpp:221-226
+__device__ inline double lcEstimateGap(const StepCtx &c, int lane, double dis) {
+    const int k = lcRearmostAtLeast(c, lane, dis);
+    if (k < 0) return c.n.drvLength[lane] - dis;
+    const int ls = c.segStart[lane] + k;
+    return c.s.dis[ls] - dis - c.t.templ[c.s.templ[ls]].len;
+}
+
+// New vehicle numbers start clean (LaneChange ctor lanechange.h:50, LaneChangeInfo vehicle.h:74-79)
+__global__ void k_lc_init(LcDev lc, int first, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = first + i;
+    lc.ptype[v] = 0;
+    lc.partner[v] = -1;
+    lc.offset[v] = 0.0;
+    lc.sigSend[v] = 0;
+    lc.sendDir[v] = 0;
+    lc.sendUrg[v] = 0;
+    lc.lastDir[v] = 0;
+    lc.changing[v] = 0;
+    lc.lcFinished[v] = 0;
+    lc.sendTarget[v] = -1;
+    lc.recvFrom[v] = -1;
+    lc.tLeader[v] = -1;
+    lc.tFollower[v] = -1;
+    lc.leaderGap[v] = 0.0;
+    lc.followerGap[v] = 0.0;
+    lc.lastChangeTime[v] = 0.0;
+    lc.gap[v] = 0.0;
+    lc.slotOf[v] = -1;
+}
+
+// threadPlanLaneChange engine.cpp:374-390 + SimpleLaneChange::makeSignal lanechange.cpp:151-184, one thread per slot.
+// Also: the stored gap as the leader pass at the end of the previous step (and handleWaiting for this step's admissions)
+// left it, and the slot of every vehicle.
+__global__ void k_lc_plan(StepCtx c) {
+    const cfx_vehicle_template *tv = c.t.templ;
+    const LcDev &lc = c.lc;
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
+        const int vid = c.s.vid[s];
+        if (vid < 0) continue;
+        const int d = c.s.drv[s];
+        lc.slotOf[vid] = s;
+        const cfx_vehicle_template &t = tv[c.s.templ[s]];
+        const double dis = c.s.dis[s];
+        {
+            const bool head = s == 0 || c.s.drv[s - 1] != d;
+            double gap;
+            const int ls = findLeader(c, tv, s, d, head, dis, t.approach_dist, &gap);
+            if (ls >= 0) lc.gap[vid] = gap;
+        }
+        if (lc.ptype[vid] == 2) continue;  // shadows make no signals (isReal)
+        if (lc.changing[vid]) {            // keeps the signal it started with; still a candidate (it signals its neighbours)
+            if (d < c.n.L) atomicAdd(&lc.roadCand[c.n.laneRoad[d]], 1);
+            continue;
+        }
+        if (c.step * c.interval - lc.lastChangeTime[vid] < 3 /*coolingTime*/) continue;
+        int target = -1, dir = 0, urgency = 0;
+        if (d < c.n.L) {
+            const double dlen = c.n.drvLength[d];
+            bool go = !(dlen - dis < 30);
+            const double gap = lc.gap[vid];
+            const double expectedGap = 2 * t.len + 4 * c.interval * t.max_speed;
+            if (go && (gap > expectedGap || gap < 1.5 * t.len)) go = false;
+            if (go) {
+                const int road = c.n.laneRoad[d];
+                const int nLanes = lc.roadLaneStart[road + 1] - lc.roadLaneStart[road];
+                const int route = c.s.route[s], routePos = c.s.routePos[s];
+                const bool lastRoad = isLastRoad(c, d, route);
+                const int li = c.n.laneIndex[d];
+                double outerEst = 0;
+                if (li < nLanes - 1) {
+                    if (lastRoad || nextOf(c.n, c.t, d + 1, route, routePos) >= 0) {
+                        outerEst = lcEstimateGap(c, d + 1, dis);
+                        if (outerEst > gap + t.len) target = d + 1;
+                    }
+                }
+                if (li > 0) {
+                    if (lastRoad || nextOf(c.n, c.t, d - 1, route, routePos) >= 0) {
+                        const double innerEst = lcEstimateGap(c, d - 1, dis);
+                        if (innerEst > gap + t.len && innerEst > outerEst) target = d - 1;
+                    }
+                }
+                urgency = 1;
+                if (target >= 0) dir = target == d + 1 ? 1 : -1;  // LaneChange::getDirection lanechange.cpp:104-113
+            }
+        }
+        lc.sigSend[vid] = 1;
+        lc.sendTarget[vid] = target;
+        lc.sendDir[vid] = (int8_t) dir;
+        lc.sendUrg[vid] = (int8_t) urgency;
+        if (target >= 0) atomicAdd(&lc.roadCand[c.n.laneRoad[d]], 1);
+    }
+}
+
+// What the schedule walk knows about "a vehicle in the target lane": an existing one (slot) or a shadow inserted earlier
+// in this very walk (index into the road's local list).
+struct LcNeighbour {
+    int vid;      // vid, or -(record index + 2) for a shadow of this step, or -1 none
+    double dis, len, speed, maxNegAcc;
+};
+
+// Engine::scheduleLaneChange engine.cpp:792-810 for ONE road: its candidates in creation order (ascending vid — the ABI's
+// order, include/cityflow_amd.h).  Roads are independent in this phase: a target lane is on the candidate's own road, and
+// the laneLinks the leader search looks into do not change.
+__global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriority) {
+    const int road = blockIdx.x * blockDim.x + threadIdx.x;
+    if (road >= c.n.R) return;
+    const LcDev &lc = c.lc;
+    if (lc.roadCand[road] == 0) return;
+    lc.roadCand[road] = 0;
+    const cfx_vehicle_template *tv = c.t.templ;
+    const int l0 = lc.roadLaneStart[road], l1 = lc.roadLaneStart[road + 1];
+    const int s0 = c.segStart[l0], s1 = c.segStart[l1 - 1] + cntNow(c, l1 - 1);
+    int localRec[kLcRoadInserts];  // global record indices of this road's shadows so far
+    int nLocal = 0;
+    int lastVid = -1;
+    for (;;) {
+        // next candidate: smallest vid above the last one
+        int vid = CFX_INT_MAX, s = -1;
+        for (int q = s0; q < s1; ++q) {
+            const int w = c.s.vid[q];
+            if (w < 0 || w <= lastVid || w >= vid) continue;
+            if (lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
+            vid = w;
+            s = q;
+        }
+        if (s < 0) break;
+        lastVid = vid;
+        const int d = c.s.drv[s];
+        const int target = lc.sendTarget[vid];
+        const double dis = c.s.dis[s];
+        const cfx_vehicle_template &t = tv[c.s.templ[s]];
+        // --- LaneChange::updateLeaderAndFollower lanechange.cpp:27-60 on the target lane as it is NOW (earlier shadows of
+        // this walk included: behind every existing vehicle with a distance >= theirs, in front of the rest)
+        LcNeighbour leader{-1, 0, 0, 0, 0}, follower{-1, 0, 0, 0, 0};
+        const int tb = c.segStart[target];
+        const int k = lcRearmostAtLeast(c, target, dis);  // existing vehicles 0..k have distance >= dis
+        if (k >= 0) {
+            const int ls = tb + k;
+            const cfx_vehicle_template &tl = tv[c.s.templ[ls]];
+            leader = LcNeighbour{c.s.vid[ls], c.s.dis[ls], tl.len, c.s.speed[ls], tl.max_neg_acc};
+        }
+        if (k + 1 < cntNow(c, target)) {
+            const int fs = tb + k + 1;
+            const cfx_vehicle_template &tf = tv[c.s.templ[fs]];
+            follower = LcNeighbour{c.s.vid[fs], c.s.dis[fs], tf.len, c.s.speed[fs], tf.max_neg_acc};
+        }
+        for (int i = 0; i < nLocal; ++i) {
+            const LcInsert &r = lc.ins[localRec[i]];
+            if (r.lane != target) continue;
+            const int ps = r.parentSlot;
+            const cfx_vehicle_template &tp = tv[c.s.templ[ps]];
+            const LcNeighbour me{-(localRec[i] + 2), r.dis, tp.len, c.s.speed[ps], tp.max_neg_acc};
+            if (r.dis >= dis) {  // candidate leader: the rearmost wins; a shadow sits behind existing vehicles of equal distance
+                if (leader.vid == -1 || r.dis <= leader.dis) leader = me;
+            } else {             // candidate follower: the frontmost wins; among equals the existing / earlier one is in front
+                if (follower.vid == -1 || r.dis > follower.dis) follower = me;
+            }
+        }
+        double leaderGap, followerGap = 1.7976931348623157e308;
+        if (leader.vid == -1) {  // look into the laneLinks behind the target lane
+            const double rest = c.n.drvLength[d] - dis;
+            leaderGap = rest;
+            double gap = 1.7976931348623157e308;
+            for (int q = c.n.laneLLStart[target]; q < c.n.laneLLStart[target + 1]; ++q) {
+                const int ll = c.n.L + c.n.laneLL[q];
+                const int n = c.cnt[ll];
+                if (n <= 0) continue;
+                const int ls = c.segStart[ll] + n - 1;
+                const double ld = c.s.dis[ls];
+                if (ld + rest < gap) {
+                    gap = ld + rest;
+                    const cfx_vehicle_template &tl = tv[c.s.templ[ls]];
+                    if (gap < tl.len) {
+                        leader = LcNeighbour{c.s.vid[ls], ld, tl.len, c.s.speed[ls], tl.max_neg_acc};
+                        leaderGap = rest - (tl.len - gap);
+                    }
+                }
+            }
+        } else {
+            leaderGap = leader.dis - dis - leader.len;
+        }
+        if (follower.vid != -1) followerGap = dis - follower.dis - t.len;
+        lc.tLeader[vid] = leader.vid;
+        lc.tFollower[vid] = follower.vid;
+        lc.leaderGap[vid] = leaderGap;
+        lc.followerGap[vid] = followerGap;
+        // --- SimpleLaneChange::sendSignal lanechange.cpp:208-211 -> Vehicle::receiveSignal vehicle.cpp:391-401
+        const int myPriority = vPriority[vid];
+        const LcNeighbour *nb[2] = {&leader, &follower};
+        for (int i = 0; i < 2; ++i) {
+            const int r = nb[i]->vid;
+            if (r == -1) continue;
+            if (r <= -2) {  // a shadow of this step: not changing, sends nothing itself
+                LcInsert &rec = lc.ins[-r - 2];
+                const int cur = rec.recvFrom >= 0 ? vPriority[rec.recvFrom] : -1;
+                if (rec.recvFrom < 0 || cur < myPriority) rec.recvFrom = vid;
+                continue;
+            }
+            if (lc.changing[r]) continue;
+            const int from = lc.recvFrom[r];
+            const int cur = from >= 0 ? vPriority[from] : -1;
+            if ((from < 0 || cur < myPriority) && (!lc.sigSend[r] || vPriority[r] < myPriority)) lc.recvFrom[r] = vid;
+        }
+        // --- insert a shadow? engine.cpp:800-806, LaneChange::isGapValid lanechange.h:80
+        if (lcPlanChange(lc, vid, d) && lc.sigSend[vid] && lc.recvFrom[vid] < 0 && !lc.changing[vid] && d < c.n.L) {
+            const double speed = c.s.speed[s];
+            const double safeAfter = 0.5 * speed * speed / t.max_neg_acc;
+            const double safeBefore = follower.vid != -1 ? 0.5 * follower.speed * follower.speed / follower.maxNegAcc : 0.0;
+            if (leaderGap >= safeAfter && followerGap >= safeBefore) {
+                const int idx = atomicAdd(lc.insCount, 1);
+                if (idx >= lc.insCap) {
+                    sc->overflow = 5;  // more shadows in one step than priorities supplied
+                } else if (nLocal >= kLcRoadInserts) {
+                    sc->overflow = 6;  // more shadows on one road in one step than the walk keeps track of
+                } else {
+                    lc.ins[idx] = LcInsert{vid, s, target, -1, dis};
+                    lc.insNext[idx] = lc.insHead[target];  // only this thread touches this road's lanes
+                    lc.insHead[target] = idx;
+                    localRec[nLocal++] = idx;
+                    lc.changing[vid] = 1;  // LaneChange::insertShadow lanechange.cpp:71-76 (later candidates must see it)
+                }
+            }
+        }
+    }
+}
+
+// Engine::insertShadow engine.cpp:812-820 + the Vehicle copy constructor vehicle.cpp:28-36 for every shadow of the step:
+// vehicle numbers and the supplied priorities go out in creation order = ascending parent vid.  One block.
+__global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pollOut /*pinned: [0] count, [1..] parents*/) {
+    const LcDev &lc = c.lc;
+    int n = *lc.insCount;
+    if (n > lc.insCap) n = lc.insCap;
+    __shared__ int sRank[1024];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int me = lc.ins[i].parentVid;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < me;
+        if (i < 1024) sRank[i] = rank;
+        const LcInsert r = lc.ins[i];
+        const int p = r.parentVid, v = lc.firstShadowVid + rank;
+        vt.priority[v] = lc.pool[rank];
+        vt.templ[v] = vt.templ[p];
+        vt.route[v] = vt.route[p];
+        vt.enterTime[v] = vt.enterTime[p];
+        vt.customSpeed[v] = vt.customSpeed[p];
+        vt.pendingCustom[v] = 0;
+        vt.nextWait[v] = -1;
+        vt.state[v] = 1;
+        lc.ptype[v] = 2;  // setParent
+        lc.partner[v] = p;
+        lc.offset[v] = lc.offset[p];
+        lc.sigSend[v] = 0;
+        lc.sendDir[v] = 0;
+        lc.sendUrg[v] = 0;
+        lc.lastDir[v] = 0;
+        lc.changing[v] = 0;
+        lc.lcFinished[v] = 0;
+        lc.sendTarget[v] = -1;
+        lc.recvFrom[v] = r.recvFrom;
+        lc.tLeader[v] = -1;
+        lc.tFollower[v] = -1;
+        lc.leaderGap[v] = 0.0;
+        lc.followerGap[v] = 0.0;
+        lc.lastChangeTime[v] = 0.0;
+        lc.gap[v] = lc.gap[p];  // ControllerInfo is copied; the leader pass below refreshes it where a leader exists
+        lc.slotOf[v] = -1;
+        lc.ptype[p] = 1;  // setShadow
+        lc.partner[p] = v;
+        pollOut[1 + rank] = p;
+    }
+    __syncthreads();
+    // shadows named provisionally (-(record + 2)) in the walk get their numbers
+    for (int i = 0; i < n; ++i) {
+        const int lane = lc.ins[i].lane;
+        const int road = c.n.laneRoad[lane];
+        const int l0 = lc.roadLaneStart[road], l1 = lc.roadLaneStart[road + 1];
+        const int s0 = c.segStart[l0], s1 = c.segStart[l1 - 1] + cntNow(c, l1 - 1);
+        for (int q = s0 + (int) threadIdx.x; q < s1; q += blockDim.x) {
+            const int w = c.s.vid[q];
+            if (w < 0) continue;
+            int x = lc.tLeader[w];
+            if (x <= -2) {
+                const int rec = -x - 2;
+                int rank = 0;
+                if (rec < 1024) rank = sRank[rec];
+                else for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < lc.ins[rec].parentVid;
+                lc.tLeader[w] = lc.firstShadowVid + rank;
+            }
+            x = lc.tFollower[w];
+            if (x <= -2) {
+                const int rec = -x - 2;
+                int rank = 0;
+                if (rec < 1024) rank = sRank[rec];
+                else for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < lc.ins[rec].parentVid;
+                lc.tFollower[w] = lc.firstShadowVid + rank;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sc->active += n;  // activeVehicleCount++ per shadow
+        pollOut[0] = *lc.insCount;  // > insCap tells the host the supply was too small
+        __threadfence_system();
+    }
+}
+
+// New layout after the walk: per lane its vehicles (this step's admission committed: the FIFO pop, the vehicle's state,
+// the running count) plus its shadows.  One block; D is walked in chunks (lane change is not the hot configuration).
+__global__ void k_lc_layout(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars *sc,
+                            const uint8_t *laneSpare, int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
+                            int32_t *drvNext) {
+    const LcDev &lc = c.lc;
+    const int D = c.n.L + c.n.K;
+    __shared__ int sSum[1024];
+    __shared__ int sBase;
+    if (threadIdx.x == 0) sBase = 0;
+    __syncthreads();
+    for (int d0 = 0; d0 < D; d0 += blockDim.x) {
+        const int d = d0 + (int) threadIdx.x;
+        int live = 0, width = 0;
+        if (d < D) {
+            live = c.cnt[d];
+            if (d < c.n.L) {
+                if (c.admitStep[d] == c.step) {  // commit the admission (what k_scan does in a step without lane change)
+                    live += 1;
+                    const int2 rec = c.admitRec[d];
+                    waitHead[d] = rec.y;
+                    vt.state[rec.x] = 1;
+                    atomicAdd((unsigned long long *) &sc->active, 1ULL);  // (admitStep is cleared after k_lc_move)
+                }
+                for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) live += 1;
+                width = live + (laneSpare ? (int) laneSpare[d] : 1);
+            } else {
+                width = live;
+            }
+        }
+        sSum[threadIdx.x] = width;
+        __syncthreads();
+        // inclusive scan in LDS (Hillis-Steele)
+        for (int off = 1; off < (int) blockDim.x; off <<= 1) {
+            int v = threadIdx.x >= (unsigned) off ? sSum[threadIdx.x - off] : 0;
+            __syncthreads();
+            sSum[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int start = sBase + sSum[threadIdx.x] - width;
+        if (d < D) {
+            segStartNext[d] = start;
+            cntNext[d] = live;
+            for (int j = live; j < width; ++j) {
+                vidNext[start + j] = -1;
+                drvNext[start + j] = -1;
+            }
+            if (d < c.n.L) c.laneTail[d] = live > 0 ? start + live - 1 : -1;
+        }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) sBase += sSum[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) segStartNext[D] = sBase;
+}
+
+// Every vehicle to its place in the new layout; shadows are written from their parents (Vehicle copy constructor +
+// LaneChange::insertShadow lanechange.cpp:83-93).  Inside a lane the order stays "by distance, front first"; a shadow goes
+// behind every vehicle whose distance is >= its own, shadows of equal distance in creation order.
+__global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext, int32_t *oldToNew2) {
+    const LcDev &lc = c.lc;
+    const int nIns = min(*lc.insCount, lc.insCap);
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S + nIns; s += stride) {
+        if (s < S) {
+            const int vid = c.s.vid[s];
+            if (vid < 0) {
+                oldToNew2[s] = -1;
+                continue;
+            }
+            const int d = c.s.drv[s];
+            const double dis = c.s.dis[s];
+            int shift = 0;
+            if (d < c.n.L)
+                for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) shift += lc.ins[r].dis > dis;
+            const int ns = segStartNext[d] + (s - c.segStart[d]) + shift;
+            oldToNew2[s] = ns;
+            lc.slotOf[vid] = ns;
+            nx.vid[ns] = vid;
+            nx.drv[ns] = d;
+            nx.prevDrv[ns] = c.s.prevDrv[s];
+            nx.next[ns] = c.s.next[s];
+            nx.blocker[ns] = c.s.blocker[s];  // still a slot of the PREVIOUS generation (oldToNew is composed, k_lc_compose)
+            nx.enterLLT[ns] = c.s.enterLLT[s];
+            nx.routePos[ns] = c.s.routePos[s];
+            nx.templ[ns] = c.s.templ[s];
+            nx.route[ns] = c.s.route[s];
+            nx.flags[ns] = c.s.flags[s];
+            nx.dis[ns] = dis;
+            nx.speed[ns] = c.s.speed[s];
+        } else {
+            const int i = s - S;
+            const LcInsert r = lc.ins[i];
+            const int ps = r.parentSlot, lane = r.lane;
+            int before = lcRearmostAtLeast(c, lane, r.dis) + 1;  // existing vehicles in front of it
+            for (int q = lc.insHead[lane]; q >= 0; q = lc.insNext[q]) {
+                if (q == i) continue;
+                const LcInsert &o = lc.ins[q];
+                before += (o.dis > r.dis) || (o.dis == r.dis && o.parentVid < r.parentVid);
+            }
+            const int ns = segStartNext[lane] + before;
+            const int vid = lc.partner[r.parentVid];  // set by k_lc_assign
+            const int route = c.s.route[ps], routePos = c.s.routePos[ps];
+            lc.slotOf[vid] = ns;
+            nx.vid[ns] = vid;
+            nx.drv[ns] = lane;
+            nx.prevDrv[ns] = c.s.prevDrv[ps];
+            nx.next[ns] = nextOf(c.n, c.t, lane, route, routePos);
+            nx.blocker[ns] = -1;
+            nx.enterLLT[ns] = c.s.enterLLT[ps];
+            nx.routePos[ns] = routePos;
+            nx.templ[ns] = c.s.templ[ps];
+            nx.route[ns] = route;
+            nx.flags[ns] = c.s.flags[ps];
+            nx.dis[ns] = r.dis;
+            nx.speed[ns] = c.s.speed[ps];
+        }
+    }
+}
+
+// oldToNew maps slots of the previous generation to the current one (stored blockers go through it); the current one just
+// moved
+__global__ void k_lc_compose(int32_t *oldToNew, const int32_t *oldToNew2, int n, int32_t *admitStep, int32_t *insHead, int L,
+                             int step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) {  // the rebuilt order contains this step's admissions and shadows: nothing is pending any more
+        if (admitStep[i] == step) admitStep[i] = -1;
+        insHead[i] = -1;
+    }
+    if (i >= n) return;
+    const int v = oldToNew[i];
+    if (v >= 0) oldToNew[i] = oldToNew2[v];
+}
+
+// The vehicles k_action / k_cross parked (finishAction), in the order of the reference's walk (creation order = ascending
+// vid; a shadow is handled inside its real vehicle's turn, engine.cpp:195-205): yield as the tables stand NOW, the rest of
+// getNextSpeed, the move; for a changing pair the common speed, the lateral offset and its end (finish), the shadow leaving
+// its lane (abort) — engine.cpp:223-244.  Sequential by nature; one block sorts, one thread walks.
+__device__ inline double lcParkedSpeed(const StepCtx &c, int vid, int s) {
+    const cfx_vehicle_template &t = c.t.templ[c.s.templ[s]];
+    const int d = c.s.drv[s];
+    const double speed = c.s.speed[s];
+    double v = min2(c.lc.bSpeed[vid], lcYieldSpeed(c, vid, speed, t));
+    return speedTail(c, t, s, d, speed, c.s.dis[s], c.n.drvLength[d], c.s.next[s], v);
+}
+
+__global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *order /*[slot capacity] scratch*/) {
+    const LcDev &lc = c.lc;
+    const cfx_vehicle_template *tv = c.t.templ;
+    const int n = *lc.parkCount;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int me = lc.parkList[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += lc.parkList[j] < me;
+        order[rank] = me;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        const int p = order[i];
+        const int s = lc.slotOf[p];
+        const int pd = c.s.drv[s];
+        const cfx_vehicle_template &tp = tv[c.s.templ[s]];
+        if (lc.ptype[p] != 1) {  // a single vehicle that was signalled by an earlier changing vehicle
+            const double v = lcParkedSpeed(c, p, s);
+            commitMove(c, o, s, pd, p, computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], v),
+                       lc.bBlocker[p], true);
+            continue;
+        }
+        const int q = lc.partner[p];
+        const int qs = lc.slotOf[q];
+        const int qd = c.s.drv[qs];
+        const cfx_vehicle_template &tq = tv[c.s.templ[qs]];
+        const double ns = min2(lcParkedSpeed(c, p, s), lcParkedSpeed(c, q, qs));
+        MoveOut mp = computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], ns);
+        MoveOut mq = computeMove(c, tq, qs, qd, c.s.speed[qs], c.s.dis[qs], c.n.drvLength[qd], c.s.next[qs], ns);
+        bool pCounted = true;
+        // the real vehicle: lateral offset, LaneChange::finishChanging lanechange.cpp:115-127
+        if (lc.changing[p]) {
+            const int dir = lc.sigSend[p] ? lc.sendDir[p] : 0;
+            const double maxOffset = (lc.laneWidth[lc.sendTarget[p]] + lc.laneWidth[pd]) / 2;
+            double newOffset = fabs(lc.offset[p] + max2(0.2 * mp.v, 1) * c.interval * dir);
+            newOffset = min2(newOffset, maxOffset);
+            lc.offset[p] = newOffset * dir;
+            if (newOffset >= maxOffset) {
+                lc.changing[p] = 0;
+                lc.lcFinished[p] = 1;
+                lc.lastChangeTime[p] = c.step * c.interval;
+                lc.ptype[q] = 0;  // the shadow is the vehicle from now on (the host moves the id with it)
+                lc.offset[q] = 0.0;
+                lc.partner[q] = -1;
+                lc.partner[p] = -1;
+                lc.tLeader[p] = lc.tFollower[p] = -1;  // clearSignal: later vehicles of this walk see it
+                lc.lastDir[p] = lc.sigSend[p] ? lc.sendDir[p] : 0;
+                lc.sigSend[p] = 0;
+                lc.recvFrom[p] = -1;
+                mp.newDrv = -2;  // Vehicle::finishChanging: setEnd(true)
+                pCounted = false;
+            }
+        }
+        // the shadow: leaving the target lane before the change is complete aborts it (vehicle.cpp:412-416)
+        if (lc.ptype[q] == 2 && mq.newDrv >= 0) {
+            mq.newDrv = -2;  // the shadow ends — and counts as a finished vehicle, as in the reference
+            lc.changing[p] = 0;
+            lc.ptype[p] = 0;
+            lc.offset[p] = 0.0;
+            lc.partner[p] = -1;
+            lc.tLeader[q] = lc.tFollower[q] = -1;
+            lc.lastDir[q] = 0;
+            lc.recvFrom[q] = -1;
+        }
+        commitMove(c, o, s, pd, p, mp, lc.bBlocker[p], pCounted);
+        commitMove(c, o, qs, qd, q, mq, lc.bBlocker[q], true);
+    }
+    *lc.parkCount = 0;
+}
+
+// threadUpdateAction's clearSignal (engine.cpp:424, lanechange.cpp:129-138) for every vehicle of the new generation, and
+// where it now is
+__global__ void k_lc_clear(LcDev lc, const int32_t *vidNew, const int32_t *segStartNew, int D) {
+    const int S = segStartNew[D];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
+        const int v = vidNew[s];
+        if (v < 0) continue;
+        lc.slotOf[v] = s;
+        lc.tLeader[v] = -1;
+        lc.tFollower[v] = -1;
+        lc.lastDir[v] = lc.sigSend[v] ? lc.sendDir[v] : 0;
+        if (lc.changing[v]) continue;
+        lc.sigSend[v] = 0;
+        lc.recvFrom[v] = -1;
+    }
+}
+
+}  // namespace cfxd

@@ -387,6 +387,15 @@ PYBIND11_MODULE(_cityflow, m) {
                  d["dis"] = toArray(s.dis);
                  d["speed"] = toArray(s.speed);
                  d["gap"] = toArray(s.gap);
+                 if (e.laneChange()) {
+                     d["lc_partner"] = toArray(s.lcPartner);
+                     d["lc_flags"] = toArray(s.lcFlags);
+                     d["lc_offset"] = toArray(s.lcOffset);
+                     d["lc_last_dir"] = toArray(s.lcLastDir);
+                     d["lc_target"] = toArray(s.lcTarget);
+                     d["lc_direction"] = toArray(s.lcDirection);
+                     d["lc_last_change_time"] = toArray(s.lcLastChangeTime);
+                 }
                  return d;
              })
         .def("_waiting",

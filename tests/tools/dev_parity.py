@@ -19,7 +19,8 @@ def state(e):
 def main():
     name, steps = sys.argv[1], int(sys.argv[2])
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    cfg = scenarios.materialize(name, "/tmp/cfa_dev")
+    lane_change = os.environ.get("CFX_DEV_LANE_CHANGE") == "1"  # laneChange=true: lane-change columns compared too
+    cfg = scenarios.materialize(name, "/tmp/cfa_dev", **({"laneChange": True} if lane_change else {}))
     hip = m.Engine(cfg, 1)
     tw = m.Engine._with_backend(cfg, 1, TWIN)
     print("backends:", hip.backend_name(), tw.backend_name(), flush=True)
@@ -30,7 +31,10 @@ def main():
         if s % every == every - 1 or s == steps - 1:
             a, b = state(hip), state(tw)
             bad = None
-            for k in ("vid", "drivable", "prev_drivable", "dis", "speed", "leader", "blocker", "enter_ll_time", "route_pos"):
+            keys = ("vid", "drivable", "prev_drivable", "dis", "speed", "leader", "blocker", "enter_ll_time", "route_pos")
+            if lane_change:
+                keys += ("lc_partner", "lc_flags", "lc_offset", "lc_last_dir", "lc_target", "lc_direction", "lc_last_change_time", "gap")
+            for k in keys:
                 if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k]):
                     bad = k
                     break
