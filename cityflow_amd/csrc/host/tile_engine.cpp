@@ -522,7 +522,7 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
-    if (cfg_.laneChange) throw std::runtime_error("cityflow_amd: laneChange=true is not implemented on the device path");
+    if (cfg_.laneChange) throw std::runtime_error("TiledEngine: laneChange=true is not implemented for the tiled engine (single Engine only)");
     if (cfg_.saveReplay)
         std::cerr << "[cityflow_amd] saveReplay: the tiled engine writes no replay files (use cityflow.Engine for replays)"
                   << std::endl;

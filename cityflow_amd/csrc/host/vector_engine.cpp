@@ -112,7 +112,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     : R_(numEnvs) {
     if (numEnvs < 1) throw std::runtime_error("VectorEngine: num_envs must be >= 1");
     EngineConfig cfg = readEngineConfig(configFile);
-    if (cfg.laneChange) throw std::runtime_error("VectorEngine: laneChange=true is not implemented");
+    if (cfg.laneChange) throw std::runtime_error("VectorEngine: laneChange=true is not implemented for batched environments (single Engine only)");
     interval_ = cfg.interval;
     rlTrafficLight_ = cfg.rlTrafficLight;
     try {

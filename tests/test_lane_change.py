@@ -9,6 +9,7 @@ import json
 import os
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import REF_DIR, TWIN_LIB
@@ -89,10 +90,61 @@ def test_lane_change_api_surface(mod, scen, workdir):
     assert sorted(v for lane in eng.get_lane_vehicles().values() for v in lane if v.endswith("_shadow")) == sorted(shadows)
 
 
-def test_hip_engine_refuses_lane_change(mod, scen, workdir):
-    """No silent fallback: the device path has no lane change yet, so the product library must say so."""
-    with pytest.raises(RuntimeError, match="lane change"):
-        mod.Engine(scen.materialize("example_1x1", workdir, laneChange=True), 1)
+def test_batched_and_tiled_engines_refuse_lane_change(mod, scen, workdir):
+    """Lane change is built for the single engine; the batched and the tiled hosts must say so, not ignore the flag."""
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True)
+    with pytest.raises(RuntimeError, match="laneChange"):
+        mod.VectorEngine._with_backend(cfg, 2, 1, TWIN_LIB)
+    with pytest.raises(RuntimeError, match="laneChange"):
+        mod.TiledEngine(cfg, 1, 2, [], TWIN_LIB)
+
+
+def _state(e):
+    s = e._vehicle_state()
+    order = np.argsort(s["vid"], kind="stable")
+    return {k: v[order] for k, v in s.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,steps", [("example_1x1", 400), ("grid_6x6", 460)])
+def test_hip_lane_change_equals_twin_every_step(mod, scen, workdir, name, steps):
+    """The HIP engine against the twin (which is pinned against the reference, above), laneChange=true: after EVERY step
+    every running vehicle's drivable, distance, speed, leader, stored gap, blocker, route cursor and lane-change state
+    (partner, shadow / parent / changing flags, lateral offset, direction, target lane, cooling timer), the per-lane counts
+    and the scalars are equal, bit for bit.  1x1: dozens of interacting changes from step 6 on (signals, yielding, aborts);
+    6x6: every vehicle changes lane on its last road from step 378 on."""
+    cfg = scen.materialize(name, workdir, laneChange=True)
+    hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    assert hip.backend_name() == "hip-gfx950"
+    shadows = 0
+    for s in range(steps):
+        hip.next_step()
+        tw.next_step()
+        a, b = _state(hip), _state(tw)
+        assert a.keys() == b.keys() and "lc_flags" in a
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (s, k)
+        assert np.array_equal(hip.get_lane_vehicle_count_array(), tw.get_lane_vehicle_count_array()), s
+        sa, sb = hip._scalars(), tw._scalars()
+        for k in ("active_vehicle_count", "finished_vehicle_count", "spawned_vehicle_count", "cumulative_travel_time", "vehicle_steps"):
+            assert sa[k] == sb[k], (s, k, sa, sb)
+        shadows = max(shadows, int((a["lc_flags"] & 1).sum()))
+    assert shadows >= 5
+    assert hip.get_lane_vehicles() == tw.get_lane_vehicles() and hip.get_vehicles() == tw.get_vehicles()
+    assert hip.get_average_travel_time() == tw.get_average_travel_time()
+
+
+@pytest.mark.gpu
+def test_hip_lane_change_matches_reference_goldens(mod, scen, workdir, lc_golden):
+    """... and against the vectors the reference itself produced (6x6: at most 12 candidates per step, so the ABI's stable
+    order is the reference's order, see test_canonical_order_equals_reference_order_up_to_16_candidates)."""
+    eng = mod.Engine(scen.materialize("grid_6x6", workdir, laneChange=True), 1)
+    done = 0
+    for h in (379, 400, 600):
+        for _ in range(h - done):
+            eng.next_step()
+        done = h
+        assert record(lcp.state(eng)) == lc_golden["grid_6x6"][str(h)], h
 
 
 def test_replay_log_with_lane_change_matches_reference(scen, workdir):
