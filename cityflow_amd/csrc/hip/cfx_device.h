@@ -90,7 +90,13 @@ struct LcDev {
     double *bSpeed;
     int32_t *bBlocker;
     int32_t *parkList;              // [slot capacity]
+    int32_t *parkIdx;               // [vid] index in parkList (valid for this step's parked real vehicles)
+    int32_t *parkDep;               // [slot capacity] scratch of k_lc_resolve: the item each item has to wait for
     int32_t *parkCount;             // [1]
+    // neighbours that the schedule walk could only name provisionally (shadows of this very step): {vid, which, record}
+    int32_t *fixList;               // [3 * fixCap]
+    int32_t *fixCount;              // [1]
+    int fixCap;
     // this step's scratch
     int32_t *roadCand;              // [R] candidates on the road (plan -> schedule)
     int32_t *insHead, *insNext;     // [L] / [insCap] records of a target lane, linked

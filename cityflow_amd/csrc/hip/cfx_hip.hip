@@ -282,7 +282,7 @@ struct cfx_engine {
             GROW_LC(ptype) GROW_LC(partner) GROW_LC(offset) GROW_LC(sigSend) GROW_LC(sendDir) GROW_LC(sendUrg) GROW_LC(lastDir)
             GROW_LC(changing) GROW_LC(lcFinished) GROW_LC(sendTarget) GROW_LC(recvFrom) GROW_LC(tLeader) GROW_LC(tFollower)
             GROW_LC(leaderGap) GROW_LC(followerGap) GROW_LC(lastChangeTime) GROW_LC(gap) GROW_LC(slotOf) GROW_LC(bSpeed)
-            GROW_LC(bBlocker)
+            GROW_LC(bBlocker) GROW_LC(parkIdx)
 #undef GROW_LC
         }
         // nextWait of not-yet-used vids must read -1 (k_spawn_link relies on it)
@@ -314,6 +314,7 @@ struct cfx_engine {
         if ((rc = grow(&oldToNew, keep, nc))) return rc;  // committed blockers point through it
         if (lc.on && (rc = grow(&oldToNew2, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkList, 0, nc))) return rc;
+        if (lc.on && (rc = grow(&lc.parkDep, 0, nc))) return rc;
         slotCap = nc;
         return CFX_OK;
     }
@@ -371,6 +372,7 @@ struct cfx_engine {
             HIP_TRY(hipMemsetAsync(lc.roadCand, 0, (size_t) std::max(R, 1) * sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.insHead, 0xFF, (size_t) std::max(L, 1) * sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.parkCount, 0, sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.fixCount, 0, sizeof(int32_t), stream));
         }
         laneQueued.assign((size_t) L, 0);
         nQueueLanes = 0;
@@ -570,6 +572,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         HIP_TRY(hipMemset(lc.insCount, 0, sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.parkCount, 1))) return rc;
         HIP_TRY(hipMemset(lc.parkCount, 0, sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.fixCount, 1))) return rc;
+        HIP_TRY(hipMemset(lc.fixCount, 0, sizeof(int32_t)));
         HIP_TRY(hipEventCreateWithFlags(&e->pollEvent, hipEventDisableTiming));
     }
     if ((rc = e->ensureSlotCap((size_t) e->L + 4096))) return rc;
@@ -692,7 +696,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const unsigned long long pr = __atomic_load_n(&e->hMirror->progress, __ATOMIC_RELAXED);
         const int64_t done = (int64_t) (pr >> 32);
         if (done > 0 && done <= e->step) {
-            e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + e->nQueueLanes * (e->step + 1 - done));
+            // since then: at most one admission per queueing lane and step, and (lane change) that step's shadows
+            e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + (e->nQueueLanes + shadowRoom) * (e->step + 1 - done));
             need = (size_t) (bound() + spare + shadowRoom) + 1;
         }
     }
@@ -717,18 +722,32 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
         // with the step's shadows in place (cfx_lc_kernels.h)
         const int mid = e->cur ^ 1;
+        static const bool dbgSync = getenv("CFX_LC_DEBUG_SYNC") != nullptr;  // developer aid: name the kernel that faults
+#define LC_CHECK(name)                                                                                     \
+    if (dbgSync) {                                                                                         \
+        hipError_t er = hipStreamSynchronize(st);                                                          \
+        if (er != hipSuccess) return e->fail(std::string("lane change: ") + name + ": " + hipGetErrorString(er)); \
+        fprintf(stderr, "[lc step %lld] %s ok\n", (long long) e->step, name);                              \
+    }
         if (n > 0) hipLaunchKernelGGL(k_lc_init, dim3(gridFor(n)), dim3(kBlock), 0, st, e->lc, (int) (e->spawned - n), (int) n);
         HIP_TRY(hipMemsetAsync(e->lc.insCount, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_lc_plan, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
+        LC_CHECK("k_lc_plan")
         hipLaunchKernelGGL(k_lc_schedule, dim3(gridFor(e->R)), dim3(kBlock), 0, st, c, e->sc, (const int32_t *) e->vt.priority);
+        LC_CHECK("k_lc_schedule")
         hipLaunchKernelGGL(k_lc_assign, dim3(1), dim3(1024), 0, st, c, e->vt, e->sc, e->hPoll);
+        LC_CHECK("k_lc_assign")
         HIP_TRY(hipEventRecord(e->pollEvent, st));  // cfx_lane_change_poll waits for this, not for the whole step
         e->pollPending = true;
         hipLaunchKernelGGL(k_lc_layout, dim3(1), dim3(1024), 0, st, c, e->waitHead, e->vt, e->sc, e->net.laneSpare, e->segStart[mid].p, e->cnt[mid].p, e->gen[mid].vid, e->gen[mid].drv);
+        LC_CHECK("k_lc_layout")
         hipLaunchKernelGGL(k_lc_move, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->gen[mid],
                            (const int32_t *) e->segStart[mid].p, e->oldToNew2);
+        LC_CHECK("k_lc_move")
         hipLaunchKernelGGL(k_lc_compose, dim3(gridFor(std::max<size_t>(e->slotCap, (size_t) e->L))), dim3(kBlock), 0, st, e->oldToNew,
-                           (const int32_t *) e->oldToNew2, (int) e->slotCap, e->admitStep, e->lc.insHead, (int) e->L, (int) e->step);
+                           (const int32_t *) e->oldToNew2, (int) e->slotCap, e->admitStep, e->lc.insHead, (int) e->L, (int) e->step,
+                           (const int32_t *) e->segStart[e->cur].p, (int) e->D);
+        LC_CHECK("k_lc_compose")
         HIP_TRY(hipGetLastError());
         e->cur = mid;
         c = e->ctx();
@@ -1131,6 +1150,8 @@ int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *prioriti
         if ((rc = e->grow(&e->dPool, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.ins, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.insNext, 0, cap))) return rc;
+        if ((rc = e->grow(&e->lc.fixList, 0, 3 * 8 * cap))) return rc;
+        e->lc.fixCap = (int) (8 * cap);
         if (e->hPool) HIP_TRY(hipHostFree(e->hPool));
         if (e->hPoll) HIP_TRY(hipHostFree(e->hPoll));
         HIP_TRY(hipHostMalloc((void **) &e->hPool, cap * sizeof(int32_t), hipHostMallocDefault));
@@ -1306,6 +1327,53 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         int64_t inTable = 0;
         for (int v = 0; v < nV; ++v) inTable += s->v_state[v] == 2;
         e->finishedOffset = s->finished_vehicle_count - inTable;
+    }
+    if (e->lc.on) {
+        // lane-change tables: defaults for every vehicle number, then what the archive carries for the running ones (the
+        // part of LaneChange / LaneChangeInfo that outlives a step, include/cityflow_amd.h cfx_state)
+        const size_t nv = (size_t) std::max(nV, 1);
+        std::vector<int8_t> ptype(nv, 0), sig(nv, 0), sdir(nv, 0), surg(nv, 0), ldir(nv, 0), chg(nv, 0), fin(nv, 0);
+        std::vector<int32_t> partner(nv, -1), target(nv, -1), none(nv, -1);
+        std::vector<double> offset(nv, 0.0), lastTime(nv, 0.0), gapv(nv, 0.0), zero(nv, 0.0);
+        for (int i = 0; i < nR; ++i) {
+            const int v = s->r_vid[i];
+            if (s->r_gap) gapv[v] = s->r_gap[i];
+            if (s->r_lc_flags) {
+                const uint8_t f = s->r_lc_flags[i];
+                ptype[v] = (f & CFX_LC_SHADOW) ? 2 : ((f & CFX_LC_PARENT) ? 1 : 0);
+                chg[v] = (f & CFX_LC_CHANGING) ? 1 : 0;
+            }
+            if (s->r_lc_partner_vid) partner[v] = s->r_lc_partner_vid[i];
+            if (s->r_lc_offset) offset[v] = s->r_lc_offset[i];
+            if (s->r_lc_last_dir) ldir[v] = (int8_t) s->r_lc_last_dir[i];
+            if (s->r_lc_last_change_time) lastTime[v] = s->r_lc_last_change_time[i];
+            if (chg[v] && s->r_lc_target_lane && s->r_lc_direction) {  // the signal of a change in progress
+                sig[v] = 1;
+                surg[v] = 1;
+                target[v] = s->r_lc_target_lane[i];
+                sdir[v] = (int8_t) s->r_lc_direction[i];
+            }
+        }
+        const LcDev &lc = e->lc;
+        HIP_TRY(up(lc.ptype, ptype.data(), nv));
+        HIP_TRY(up(lc.sigSend, sig.data(), nv));
+        HIP_TRY(up(lc.sendDir, sdir.data(), nv));
+        HIP_TRY(up(lc.sendUrg, surg.data(), nv));
+        HIP_TRY(up(lc.lastDir, ldir.data(), nv));
+        HIP_TRY(up(lc.changing, chg.data(), nv));
+        HIP_TRY(up(lc.lcFinished, fin.data(), nv));
+        HIP_TRY(up(lc.partner, partner.data(), nv * 4));
+        HIP_TRY(up(lc.sendTarget, target.data(), nv * 4));
+        HIP_TRY(up(lc.recvFrom, none.data(), nv * 4));
+        HIP_TRY(up(lc.tLeader, none.data(), nv * 4));
+        HIP_TRY(up(lc.tFollower, none.data(), nv * 4));
+        HIP_TRY(up(lc.slotOf, slotOfVid.data(), nv * 4));
+        HIP_TRY(up(lc.offset, offset.data(), nv * 8));
+        HIP_TRY(up(lc.lastChangeTime, lastTime.data(), nv * 8));
+        HIP_TRY(up(lc.gap, gapv.data(), nv * 8));
+        HIP_TRY(up(lc.leaderGap, zero.data(), nv * 8));
+        HIP_TRY(up(lc.followerGap, zero.data(), nv * 8));
+        HIP_TRY(hipStreamSynchronize(e->stream));  // the staging vectors die with this scope
     }
     // cached next drivable of every slot (uses the device copies of the route tables)
     hipLaunchKernelGGL(k_refresh_next, dim3(gridStride(std::max(S, 1))), dim3(kBlock), 0, e->stream, e->ctx());

@@ -447,7 +447,11 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
         if (pt != 0 || (src >= 0 && c.lc.changing[src] && src < vid)) {
             c.lc.bSpeed[vid] = v;  // before the yield
             c.lc.bBlocker[vid] = blockerSlot;
-            if (pt != 2) c.lc.parkList[atomicAdd(c.lc.parkCount, 1)] = vid;  // a shadow goes with its real vehicle
+            if (pt != 2) {  // a shadow goes with its real vehicle
+                const int idx = atomicAdd(c.lc.parkCount, 1);
+                c.lc.parkList[idx] = vid;
+                c.lc.parkIdx[vid] = idx;
+            }
             return;
         }
         v = min2(v, lcYieldSpeed(c, vid, speed, t));

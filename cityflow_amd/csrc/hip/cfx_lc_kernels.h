@@ -157,18 +157,45 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
     const int s0 = c.segStart[l0], s1 = c.segStart[l1 - 1] + cntNow(c, l1 - 1);
     int localRec[kLcRoadInserts];  // global record indices of this road's shadows so far
     int nLocal = 0;
-    int lastVid = -1;
-    for (;;) {
-        // next candidate: smallest vid above the last one
-        int vid = CFX_INT_MAX, s = -1;
-        for (int q = s0; q < s1; ++q) {
-            const int w = c.s.vid[q];
-            if (w < 0 || w <= lastVid || w >= vid) continue;
-            if (lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
-            vid = w;
-            s = q;
+    // the road's candidates, ascending vid (threadPlanLaneChange's buffer; the walk never creates new ones)
+    constexpr int kCand = 96;
+    int candVid[kCand], candSlot[kCand];
+    int nCand = 0;
+    bool tooMany = false;
+    for (int q = s0; q < s1; ++q) {
+        const int w = c.s.vid[q];
+        if (w < 0 || lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
+        if (nCand == kCand) {
+            tooMany = true;
+            break;
         }
-        if (s < 0) break;
+        int i = nCand++;
+        for (; i > 0 && candVid[i - 1] > w; --i) {
+            candVid[i] = candVid[i - 1];
+            candSlot[i] = candSlot[i - 1];
+        }
+        candVid[i] = w;
+        candSlot[i] = q;
+    }
+    int lastVid = -1;
+    for (int ci = 0;; ++ci) {
+        int vid, s;
+        if (!tooMany) {
+            if (ci >= nCand) break;
+            vid = candVid[ci];
+            s = candSlot[ci];
+        } else {  // more candidates than the local list holds: pick the next one by scanning (slow, rare)
+            vid = CFX_INT_MAX;
+            s = -1;
+            for (int q = s0; q < s1; ++q) {
+                const int w = c.s.vid[q];
+                if (w < 0 || w <= lastVid || w >= vid) continue;
+                if (lc.ptype[w] == 2 || (!lcPlanChange(lc, w, c.s.drv[q]) && !lc.changing[w])) continue;
+                vid = w;
+                s = q;
+            }
+            if (s < 0) break;
+        }
         lastVid = vid;
         const int d = c.s.drv[s];
         const int target = lc.sendTarget[vid];
@@ -227,6 +254,18 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
         if (follower.vid != -1) followerGap = dis - follower.dis - t.len;
         lc.tLeader[vid] = leader.vid;
         lc.tFollower[vid] = follower.vid;
+        for (int w = 0; w < 2; ++w) {  // shadows of this step get their numbers in k_lc_assign
+            const int x = w ? follower.vid : leader.vid;
+            if (x > -2) continue;
+            const int fi = atomicAdd(lc.fixCount, 1);
+            if (fi >= lc.fixCap) {
+                sc->overflow = 6;
+                continue;
+            }
+            lc.fixList[3 * fi] = vid;
+            lc.fixList[3 * fi + 1] = w;
+            lc.fixList[3 * fi + 2] = -x - 2;
+        }
         lc.leaderGap[vid] = leaderGap;
         lc.followerGap[vid] = followerGap;
         // --- SimpleLaneChange::sendSignal lanechange.cpp:208-211 -> Vehicle::receiveSignal vehicle.cpp:391-401
@@ -315,33 +354,18 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
     }
     __syncthreads();
     // shadows named provisionally (-(record + 2)) in the walk get their numbers
-    for (int i = 0; i < n; ++i) {
-        const int lane = lc.ins[i].lane;
-        const int road = c.n.laneRoad[lane];
-        const int l0 = lc.roadLaneStart[road], l1 = lc.roadLaneStart[road + 1];
-        const int s0 = c.segStart[l0], s1 = c.segStart[l1 - 1] + cntNow(c, l1 - 1);
-        for (int q = s0 + (int) threadIdx.x; q < s1; q += blockDim.x) {
-            const int w = c.s.vid[q];
-            if (w < 0) continue;
-            int x = lc.tLeader[w];
-            if (x <= -2) {
-                const int rec = -x - 2;
-                int rank = 0;
-                if (rec < 1024) rank = sRank[rec];
-                else for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < lc.ins[rec].parentVid;
-                lc.tLeader[w] = lc.firstShadowVid + rank;
-            }
-            x = lc.tFollower[w];
-            if (x <= -2) {
-                const int rec = -x - 2;
-                int rank = 0;
-                if (rec < 1024) rank = sRank[rec];
-                else for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < lc.ins[rec].parentVid;
-                lc.tFollower[w] = lc.firstShadowVid + rank;
-            }
-        }
-        __syncthreads();
+    int nFix = *lc.fixCount;
+    if (nFix > lc.fixCap) nFix = lc.fixCap;
+    for (int i = threadIdx.x; i < nFix; i += blockDim.x) {
+        const int w = lc.fixList[3 * i], which = lc.fixList[3 * i + 1], rec = lc.fixList[3 * i + 2];
+        int rank = 0;
+        if (rec < 1024) rank = sRank[rec];
+        else for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < lc.ins[rec].parentVid;
+        if (which) lc.tFollower[w] = lc.firstShadowVid + rank;
+        else lc.tLeader[w] = lc.firstShadowVid + rank;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) *lc.fixCount = 0;
     if (threadIdx.x == 0) {
         sc->active += n;  // activeVehicleCount++ per shadow
         pollOut[0] = *lc.insCount;  // > insCap tells the host the supply was too small
@@ -350,59 +374,56 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
 }
 
 // New layout after the walk: per lane its vehicles (this step's admission committed: the FIFO pop, the vehicle's state,
-// the running count) plus its shadows.  One block; D is walked in chunks (lane change is not the hot configuration).
-__global__ void k_lc_layout(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars *sc,
-                            const uint8_t *laneSpare, int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
-                            int32_t *drvNext) {
+// the running count) plus its shadows.  One block; every thread takes a contiguous run of drivables (lane change is not the
+// hot configuration).
+__global__ void k_lc_layout(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars *sc, const uint8_t *laneSpare,
+                            int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext, int32_t *drvNext) {
     const LcDev &lc = c.lc;
     const int D = c.n.L + c.n.K;
     __shared__ int sSum[1024];
-    __shared__ int sBase;
-    if (threadIdx.x == 0) sBase = 0;
+    const int per = (D + (int) blockDim.x - 1) / (int) blockDim.x;
+    const int d0 = (int) threadIdx.x * per, d1 = min(D, d0 + per);
+    auto liveOf = [&](int d) {
+        int live = c.cnt[d];
+        if (d < c.n.L) {
+            if (c.admitStep[d] == c.step) live += 1;
+            for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) live += 1;
+        }
+        return live;
+    };
+    auto spareOf = [&](int d) { return d < c.n.L ? (laneSpare ? (int) laneSpare[d] : 1) : 0; };
+    int sum = 0, admitted = 0;
+    for (int d = d0; d < d1; ++d) {
+        sum += liveOf(d) + spareOf(d);
+        if (d < c.n.L && c.admitStep[d] == c.step) {  // commit the admission (what k_scan does in a step without lane change;
+            const int2 rec = c.admitRec[d];            //  admitStep itself is cleared after k_lc_move, which still needs it)
+            waitHead[d] = rec.y;
+            vt.state[rec.x] = 1;
+            admitted += 1;
+        }
+    }
+    if (admitted) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) admitted);
+    sSum[threadIdx.x] = sum;
     __syncthreads();
-    for (int d0 = 0; d0 < D; d0 += blockDim.x) {
-        const int d = d0 + (int) threadIdx.x;
-        int live = 0, width = 0;
-        if (d < D) {
-            live = c.cnt[d];
-            if (d < c.n.L) {
-                if (c.admitStep[d] == c.step) {  // commit the admission (what k_scan does in a step without lane change)
-                    live += 1;
-                    const int2 rec = c.admitRec[d];
-                    waitHead[d] = rec.y;
-                    vt.state[rec.x] = 1;
-                    atomicAdd((unsigned long long *) &sc->active, 1ULL);  // (admitStep is cleared after k_lc_move)
-                }
-                for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) live += 1;
-                width = live + (laneSpare ? (int) laneSpare[d] : 1);
-            } else {
-                width = live;
-            }
-        }
-        sSum[threadIdx.x] = width;
+    for (int off = 1; off < (int) blockDim.x; off <<= 1) {  // inclusive scan in LDS (Hillis-Steele)
+        const int v = threadIdx.x >= (unsigned) off ? sSum[threadIdx.x - off] : 0;
         __syncthreads();
-        // inclusive scan in LDS (Hillis-Steele)
-        for (int off = 1; off < (int) blockDim.x; off <<= 1) {
-            int v = threadIdx.x >= (unsigned) off ? sSum[threadIdx.x - off] : 0;
-            __syncthreads();
-            sSum[threadIdx.x] += v;
-            __syncthreads();
-        }
-        const int start = sBase + sSum[threadIdx.x] - width;
-        if (d < D) {
-            segStartNext[d] = start;
-            cntNext[d] = live;
-            for (int j = live; j < width; ++j) {
-                vidNext[start + j] = -1;
-                drvNext[start + j] = -1;
-            }
-            if (d < c.n.L) c.laneTail[d] = live > 0 ? start + live - 1 : -1;
-        }
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) sBase += sSum[threadIdx.x];
+        sSum[threadIdx.x] += v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) segStartNext[D] = sBase;
+    int start = sSum[threadIdx.x] - sum;
+    for (int d = d0; d < d1; ++d) {
+        const int live = liveOf(d), width = live + spareOf(d);
+        segStartNext[d] = start;
+        cntNext[d] = live;
+        for (int j = live; j < width; ++j) {
+            vidNext[start + j] = -1;
+            drvNext[start + j] = -1;
+        }
+        if (d < c.n.L) c.laneTail[d] = live > 0 ? start + live - 1 : -1;
+        start += width;
+    }
+    if (threadIdx.x == blockDim.x - 1) segStartNext[D] = sSum[threadIdx.x];
 }
 
 // Every vehicle to its place in the new layout; shadows are written from their parents (Vehicle copy constructor +
@@ -473,15 +494,17 @@ __global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext,
 // oldToNew maps slots of the previous generation to the current one (stored blockers go through it); the current one just
 // moved
 __global__ void k_lc_compose(int32_t *oldToNew, const int32_t *oldToNew2, int n, int32_t *admitStep, int32_t *insHead, int L,
-                             int step) {
+                             int step, const int32_t *segStartBefore, int D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = segStartBefore[D];  // slots of the layout that just moved; oldToNew beyond the previous generation's
+                                      // slots is never written (and never read through a stored blocker): leave it alone
     if (i < L) {  // the rebuilt order contains this step's admissions and shadows: nothing is pending any more
         if (admitStep[i] == step) admitStep[i] = -1;
         insHead[i] = -1;
     }
     if (i >= n) return;
     const int v = oldToNew[i];
-    if (v >= 0) oldToNew[i] = oldToNew2[v];
+    if (v >= 0 && v < S) oldToNew[i] = oldToNew2[v];
 }
 
 // The vehicles k_action / k_cross parked (finishAction), in the order of the reference's walk (creation order = ascending
@@ -496,75 +519,102 @@ __device__ inline double lcParkedSpeed(const StepCtx &c, int vid, int s) {
     return speedTail(c, t, s, d, speed, c.s.dis[s], c.n.drvLength[d], c.s.next[s], v);
 }
 
-__global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *order /*[slot capacity] scratch*/) {
+// The only thing an item needs from the walk order is: has the changing vehicle whose signal I (or my shadow) received —
+// if it comes earlier in the walk — already been handled?  So every thread takes items and the block goes through rounds;
+// an item runs in the round after the one it depends on.  Chains are short (one changing vehicle signalling the shadow of
+// the next), so a few rounds do.
+__device__ inline int lcResolveDep(const LcDev &lc, int p) {
+    // the vehicle evaluated in p's turn that can hold a signal: p itself if it is single, its shadow if p leads a pair
+    const int r = lc.ptype[p] == 1 ? lc.partner[p] : p;
+    const int src = lc.recvFrom[r];
+    if (src >= 0 && src < p && lc.changing[src] && lc.ptype[src] == 1) return lc.parkIdx[src];
+    return -1;
+}
+
+__global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capacity] scratch*/) {
     const LcDev &lc = c.lc;
     const cfx_vehicle_template *tv = c.t.templ;
     const int n = *lc.parkCount;
+    __shared__ int sLeft;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int me = lc.parkList[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += lc.parkList[j] < me;
-        order[rank] = me;
+        done[i] = 0;
+        lc.parkDep[i] = lcResolveDep(lc, lc.parkList[i]);  // against the tables as k_action saw them
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    for (int i = 0; i < n; ++i) {
-        const int p = order[i];
-        const int s = lc.slotOf[p];
-        const int pd = c.s.drv[s];
-        const cfx_vehicle_template &tp = tv[c.s.templ[s]];
-        if (lc.ptype[p] != 1) {  // a single vehicle that was signalled by an earlier changing vehicle
-            const double v = lcParkedSpeed(c, p, s);
-            commitMove(c, o, s, pd, p, computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], v),
-                       lc.bBlocker[p], true);
-            continue;
-        }
-        const int q = lc.partner[p];
-        const int qs = lc.slotOf[q];
-        const int qd = c.s.drv[qs];
-        const cfx_vehicle_template &tq = tv[c.s.templ[qs]];
-        const double ns = min2(lcParkedSpeed(c, p, s), lcParkedSpeed(c, q, qs));
-        MoveOut mp = computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], ns);
-        MoveOut mq = computeMove(c, tq, qs, qd, c.s.speed[qs], c.s.dis[qs], c.n.drvLength[qd], c.s.next[qs], ns);
-        bool pCounted = true;
-        // the real vehicle: lateral offset, LaneChange::finishChanging lanechange.cpp:115-127
-        if (lc.changing[p]) {
-            const int dir = lc.sigSend[p] ? lc.sendDir[p] : 0;
-            const double maxOffset = (lc.laneWidth[lc.sendTarget[p]] + lc.laneWidth[pd]) / 2;
-            double newOffset = fabs(lc.offset[p] + max2(0.2 * mp.v, 1) * c.interval * dir);
-            newOffset = min2(newOffset, maxOffset);
-            lc.offset[p] = newOffset * dir;
-            if (newOffset >= maxOffset) {
-                lc.changing[p] = 0;
-                lc.lcFinished[p] = 1;
-                lc.lastChangeTime[p] = c.step * c.interval;
-                lc.ptype[q] = 0;  // the shadow is the vehicle from now on (the host moves the id with it)
-                lc.offset[q] = 0.0;
-                lc.partner[q] = -1;
-                lc.partner[p] = -1;
-                lc.tLeader[p] = lc.tFollower[p] = -1;  // clearSignal: later vehicles of this walk see it
-                lc.lastDir[p] = lc.sigSend[p] ? lc.sendDir[p] : 0;
-                lc.sigSend[p] = 0;
-                lc.recvFrom[p] = -1;
-                mp.newDrv = -2;  // Vehicle::finishChanging: setEnd(true)
-                pCounted = false;
+    for (int round = 1;; ++round) {
+        if (threadIdx.x == 0) sLeft = 0;
+        __syncthreads();
+        int left = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            if (done[i]) continue;
+            const int p = lc.parkList[i];
+            const int dep = lc.parkDep[i];
+            if (dep >= 0 && !(done[dep] != 0 && done[dep] < round)) {
+                left += 1;
+                continue;
             }
+            const int s = lc.slotOf[p];
+            const int pd = c.s.drv[s];
+            const cfx_vehicle_template &tp = tv[c.s.templ[s]];
+            if (lc.ptype[p] != 1) {  // a single vehicle that was signalled by an earlier changing vehicle
+                const double v = lcParkedSpeed(c, p, s);
+                commitMove(c, o, s, pd, p, computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], v),
+                           lc.bBlocker[p], true);
+            } else {
+                const int q = lc.partner[p];
+                const int qs = lc.slotOf[q];
+                const int qd = c.s.drv[qs];
+                const cfx_vehicle_template &tq = tv[c.s.templ[qs]];
+                const double ns = min2(lcParkedSpeed(c, p, s), lcParkedSpeed(c, q, qs));
+                MoveOut mp = computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], ns);
+                MoveOut mq = computeMove(c, tq, qs, qd, c.s.speed[qs], c.s.dis[qs], c.n.drvLength[qd], c.s.next[qs], ns);
+                bool pCounted = true;
+                // the real vehicle: lateral offset, LaneChange::finishChanging lanechange.cpp:115-127
+                if (lc.changing[p]) {
+                    const int dir = lc.sigSend[p] ? lc.sendDir[p] : 0;
+                    const double maxOffset = (lc.laneWidth[lc.sendTarget[p]] + lc.laneWidth[pd]) / 2;
+                    double newOffset = fabs(lc.offset[p] + max2(0.2 * mp.v, 1) * c.interval * dir);
+                    newOffset = min2(newOffset, maxOffset);
+                    lc.offset[p] = newOffset * dir;
+                    if (newOffset >= maxOffset) {
+                        lc.changing[p] = 0;
+                        lc.lcFinished[p] = 1;
+                        lc.lastChangeTime[p] = c.step * c.interval;
+                        lc.ptype[q] = 0;  // the shadow is the vehicle from now on (the host moves the id with it)
+                        lc.offset[q] = 0.0;
+                        lc.partner[q] = -1;
+                        lc.partner[p] = -1;
+                        lc.tLeader[p] = lc.tFollower[p] = -1;  // clearSignal: later vehicles of this walk see it
+                        lc.lastDir[p] = lc.sigSend[p] ? lc.sendDir[p] : 0;
+                        lc.sigSend[p] = 0;
+                        lc.recvFrom[p] = -1;
+                        mp.newDrv = -2;  // Vehicle::finishChanging: setEnd(true)
+                        pCounted = false;
+                    }
+                }
+                // the shadow: leaving the target lane before the change is complete aborts it (vehicle.cpp:412-416)
+                if (lc.ptype[q] == 2 && mq.newDrv >= 0) {
+                    mq.newDrv = -2;  // the shadow ends — and counts as a finished vehicle, as in the reference
+                    lc.changing[p] = 0;
+                    lc.ptype[p] = 0;
+                    lc.offset[p] = 0.0;
+                    lc.partner[p] = -1;
+                    lc.tLeader[q] = lc.tFollower[q] = -1;
+                    lc.lastDir[q] = 0;
+                    lc.recvFrom[q] = -1;
+                }
+                commitMove(c, o, s, pd, p, mp, lc.bBlocker[p], pCounted);
+                commitMove(c, o, qs, qd, q, mq, lc.bBlocker[q], true);
+            }
+            __threadfence_block();
+            done[i] = round;
         }
-        // the shadow: leaving the target lane before the change is complete aborts it (vehicle.cpp:412-416)
-        if (lc.ptype[q] == 2 && mq.newDrv >= 0) {
-            mq.newDrv = -2;  // the shadow ends — and counts as a finished vehicle, as in the reference
-            lc.changing[p] = 0;
-            lc.ptype[p] = 0;
-            lc.offset[p] = 0.0;
-            lc.partner[p] = -1;
-            lc.tLeader[q] = lc.tFollower[q] = -1;
-            lc.lastDir[q] = 0;
-            lc.recvFrom[q] = -1;
-        }
-        commitMove(c, o, s, pd, p, mp, lc.bBlocker[p], pCounted);
-        commitMove(c, o, qs, qd, q, mq, lc.bBlocker[q], true);
+        if (left) atomicAdd(&sLeft, left);
+        __syncthreads();
+        if (sLeft == 0) break;
+        __syncthreads();
     }
-    *lc.parkCount = 0;
+    if (threadIdx.x == 0) *lc.parkCount = 0;
 }
 
 // threadUpdateAction's clearSignal (engine.cpp:424, lanechange.cpp:129-138) for every vehicle of the new generation, and

@@ -211,6 +211,7 @@ void Archive::dump(const std::string &path) const {
 
 // ------------------------------------------------------------------------------------------ EngineHost side
 Archive EngineHost::snapshot() {
+    settleLaneChange();
     Archive a;
     a.host = spawner_.saveState();
     a.net = net_;
@@ -255,6 +256,7 @@ Archive EngineHost::snapshot() {
 }
 
 void EngineHost::load(const Archive &a) {
+    settleLaneChange();
     if (laneChange_ != !a.dev.rLcFlags.empty() && !a.dev.rVid.empty())
         throw std::runtime_error("Engine.load: the archive was taken with a different laneChange setting");
     pendingPhaseInter_.clear();

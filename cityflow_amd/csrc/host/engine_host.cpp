@@ -207,8 +207,22 @@ const std::vector<int32_t> &EngineHost::laneIdOrder() {
     return laneIdOrder_;
 }
 
+// Lane change: which vehicles got a shadow in the last step.  Asked as late as possible — the device engine only has to
+// finish the schedule part of the step for it, and the rest of the step runs on while the host is back in the caller.
+void EngineHost::settleLaneChange() {
+    if (!lcPollPending_) return;
+    lcPollPending_ = false;
+    shadowParents_.resize((size_t) shadowPoolSize_);
+    int32_t k = 0;
+    check(be_.cfx_lane_change_poll(dev_, shadowPoolSize_, shadowParents_.data(), &k), "cfx_lane_change_poll");
+    shadowParents_.resize((size_t) k);
+    spawner_.commitShadows(shadowParents_);
+    if (4 * k > shadowPoolSize_) shadowPoolSize_ = 8 * k;  // stay well clear of a step's demand
+}
+
 void EngineHost::nextStep() {
     flushPhases();
+    settleLaneChange();  // the generator must be past the last step's shadow draws before this step's spawns
     spawner_.step(step_, spawnBuf_);
     uploadNewTablesIfAny();
     if (laneChange_) {  // the priorities this step's shadows would draw, after the step's own spawn draws
@@ -216,14 +230,7 @@ void EngineHost::nextStep() {
         check(be_.cfx_lane_change_supply(dev_, (int32_t) shadowPool_.size(), shadowPool_.data()), "cfx_lane_change_supply");
     }
     check(be_.cfx_step(dev_, spawnBuf_.data(), (int32_t) spawnBuf_.size()), "cfx_step");
-    if (laneChange_) {
-        shadowParents_.resize((size_t) shadowPoolSize_);
-        int32_t k = 0;
-        check(be_.cfx_lane_change_poll(dev_, shadowPoolSize_, shadowParents_.data(), &k), "cfx_lane_change_poll");
-        shadowParents_.resize((size_t) k);
-        spawner_.commitShadows(shadowParents_);
-        if (4 * k > shadowPoolSize_) shadowPoolSize_ = 8 * k;  // stay well clear of the step's demand
-    }
+    lcPollPending_ = laneChange_;
     if (saveReplay_) updateLog();
     step_ += 1;
 }
@@ -275,6 +282,7 @@ cfx_scalars EngineHost::scalars() {
 }
 
 void EngineHost::reset(bool resetRnd) {
+    lcPollPending_ = false;  // cfx_reset drops the pending report with everything else
     pendingPhaseInter_.clear();  // TrafficLight::reset puts every light back to phase 0 anyway
     pendingPhaseValue_.clear();
     check(be_.cfx_reset(dev_), "cfx_reset");
@@ -325,6 +333,7 @@ std::map<std::string, int> EngineHost::getLaneWaitingVehicleCount() {
 }
 
 void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
+    settleLaneChange();
     int cap = (int) scalars().active_vehicle_count + 16;
     cfx_vehicle_view v{};
     v.capacity = cap;
@@ -365,6 +374,7 @@ void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
 }
 
 void EngineHost::waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane) {
+    settleLaneChange();
     cfx_scalars sc = scalars();
     int cap = (int) (sc.spawned_vehicle_count - sc.finished_vehicle_count - sc.active_vehicle_count) + 16;
     vid.resize(cap);
@@ -425,6 +435,7 @@ std::map<std::string, double> EngineHost::getVehicleDistance() {
 }
 
 int EngineHost::vidOf(const std::string &id) {
+    settleLaneChange();
     if (!laneChange_) return spawner_.vidOfId(id);
     // An id is carried by a chain of vehicles: the flow's vehicle, then each shadow that took it over when its lane change
     // completed (LaneChange::finishChanging lanechange.cpp:115-127).  Of the chain at most two are alive: the holder of
@@ -504,6 +515,7 @@ std::map<std::string, std::string> EngineHost::getVehicleInfo(const std::string 
 // getAverageTravelTime engine.cpp:682-691: same summation order (vehiclePool = ascending priority),
 // so the result is bit-identical to the single-threaded reference for any interval.
 double EngineHost::getAverageTravelTime() {
+    settleLaneChange();
     cfx_scalars sc = scalars();
     double tt = sc.cumulative_travel_time;
     int64_t n = sc.finished_vehicle_count;

@@ -162,6 +162,8 @@ private:
     std::vector<cfx_spawn> spawnBuf_;
     std::vector<int32_t> shadowPool_, shadowParents_;  // lane change: priorities offered to / parents reported by a step
     int shadowPoolSize_ = 1024;
+    bool lcPollPending_ = false;
+    void settleLaneChange();
     std::vector<int32_t> pendingPhaseInter_, pendingPhaseValue_;  // set_tl_phase calls since the last flush
     void flushPhases();
     std::vector<int32_t> laneIdOrder_;

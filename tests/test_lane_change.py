@@ -169,13 +169,23 @@ def test_replay_log_with_lane_change_matches_reference(scen, workdir):
     assert dirs == {-1, 0, 1}  # both directions of lane change were logged
 
 
+@pytest.mark.gpu
+def test_snapshot_and_load_with_lane_change_hip(mod, scen, workdir):
+    """the same on the HIP engine: cfx_load_state restores the vid-indexed lane-change tables"""
+    _snapshot_roundtrip(mod, scen, workdir, lambda cfg: mod.Engine(cfg, 1))
+
+
 def test_snapshot_and_load_with_lane_change(mod, scen, workdir):
     """Engine.snapshot() / load() in memory (reference engine.h:176-177) carry the lane-change state that outlives a step:
     partner links, lateral offset, the signal of a change in progress, cooling timers, the stored gap, the id chains and
     the generator.  A run resumed from a snapshot taken in the middle of several lane changes equals the uninterrupted
     one; the JSON form refuses (its lane-change fields are not written yet)."""
+    _snapshot_roundtrip(mod, scen, workdir, lambda cfg: mod.Engine._with_backend(cfg, 1, TWIN_LIB))
+
+
+def _snapshot_roundtrip(mod, scen, workdir, make):
     cfg = scen.materialize("example_1x1", workdir, laneChange=True)
-    eng = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    eng = make(cfg)
     for _ in range(31):
         eng.next_step()
     assert eng.get_vehicle_count() > len(eng.get_vehicle_speed())  # shadows alive: changes in progress
@@ -192,6 +202,6 @@ def test_snapshot_and_load_with_lane_change(mod, scen, workdir):
     want = advance(eng, 80)
     eng.load(arch)
     assert advance(eng, 80) == want
-    other = mod.Engine._with_backend(cfg, 1, TWIN_LIB)  # a fresh engine: nothing but the archive
+    other = make(cfg)  # a fresh engine: nothing but the archive
     other.load(arch)
     assert advance(other, 80) == want
