@@ -69,6 +69,7 @@ struct SlotArrays {
 struct LcInsert {  // one shadow created in this step (Engine::insertShadow engine.cpp:812-820)
     int32_t parentVid, parentSlot, lane, recvFrom;  // recvFrom: signal the shadow received later in the same walk
     double dis;
+    double gap;  // the parent's ControllerInfo::gap at the moment of the copy
 };
 struct LcDev {
     int on;

@@ -297,7 +297,10 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
                 } else if (nLocal >= kLcRoadInserts) {
                     sc->overflow = 6;  // more shadows on one road in one step than the walk keeps track of
                 } else {
-                    lc.ins[idx] = LcInsert{vid, s, target, -1, dis};
+                    lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid]};
+                    // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
+                    // later candidate of this walk that copies itself (its own shadow) copies this gap too
+                    if (follower.vid >= 0) lc.gap[follower.vid] = dis - t.len - follower.dis;
                     lc.insNext[idx] = lc.insHead[target];  // only this thread touches this road's lanes
                     lc.insHead[target] = idx;
                     localRec[nLocal++] = idx;
@@ -346,7 +349,7 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
         lc.leaderGap[v] = 0.0;
         lc.followerGap[v] = 0.0;
         lc.lastChangeTime[v] = 0.0;
-        lc.gap[v] = lc.gap[p];  // ControllerInfo is copied; the leader pass below refreshes it where a leader exists
+        lc.gap[v] = r.gap;  // ControllerInfo is copied; the leader pass (k_action) refreshes it where a leader exists
         lc.slotOf[v] = -1;
         lc.ptype[p] = 1;  // setShadow
         lc.partner[p] = v;

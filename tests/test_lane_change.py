@@ -135,6 +135,28 @@ def test_hip_lane_change_equals_twin_every_step(mod, scen, workdir, name, steps)
 
 
 @pytest.mark.gpu
+def test_hip_lane_change_on_the_bench_workload(mod, scen, workdir):
+    """30x30 with the bench.py demand (~90 k running vehicles, ~70 new shadows per step, thousands of pairs in flight):
+    HIP == twin on every vehicle field, every 10th step."""
+    import bench
+    base = bench.build_workload(workdir, 0, scenario="grid_30x30")
+    c = json.load(open(base))
+    c["laneChange"] = True
+    cfg = base.replace(".json", "_lanechange.json")
+    with open(cfg, "w") as f:
+        json.dump(c, f)
+    hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    for s in range(250):
+        hip.next_step()
+        tw.next_step()
+        if s % 10 == 9:
+            a, b = _state(hip), _state(tw)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (s, k)
+    assert int((a["lc_flags"] & 1).sum()) > 20 and len(a["vid"]) > 50000
+
+
+@pytest.mark.gpu
 def test_hip_lane_change_matches_reference_goldens(mod, scen, workdir, lc_golden):
     """... and against the vectors the reference itself produced (6x6: at most 12 candidates per step, so the ABI's stable
     order is the reference's order, see test_canonical_order_equals_reference_order_up_to_16_candidates)."""

@@ -21,6 +21,14 @@ def main():
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     lane_change = os.environ.get("CFX_DEV_LANE_CHANGE") == "1"  # laneChange=true: lane-change columns compared too
     cfg = scenarios.materialize(name, "/tmp/cfa_dev", **({"laneChange": True} if lane_change else {}))
+    if os.environ.get("CFX_DEV_BENCH_FLOWS") == "1":  # the bench.py workload: + seeded interior flows
+        import json
+        import bench
+        base = bench.build_workload("/tmp/cfa_dev", 0, scenario=name)
+        c = json.load(open(base))
+        c["laneChange"] = lane_change
+        cfg = base.replace(".json", "_dev.json")
+        json.dump(c, open(cfg, "w"))
     hip = m.Engine(cfg, 1)
     tw = m.Engine._with_backend(cfg, 1, TWIN)
     print("backends:", hip.backend_name(), tw.backend_name(), flush=True)
