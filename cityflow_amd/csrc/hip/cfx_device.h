@@ -66,6 +66,7 @@ struct SlotArrays {
 // Lane change (reference src/vehicle/lanechange.{h,cpp}, vehicle.h:74-79): per-vehicle state, sparse and rarely
 // touched, so it lives in tables indexed by vid and the slot arrays / the compaction stay as they are.  `on == 0`
 // unless the engine was created with cfx_config::lane_change.
+constexpr int kLcRoadCand = 64;  // candidates per road kept in its list (more: the walk scans the road)
 struct LcInsert {  // one shadow created in this step (Engine::insertShadow engine.cpp:812-820)
     int32_t parentVid, parentSlot, lane, recvFrom;  // recvFrom: signal the shadow received later in the same walk
     double dis;
@@ -100,6 +101,7 @@ struct LcDev {
     int fixCap;
     // this step's scratch
     int32_t *roadCand;              // [R] candidates on the road (plan -> schedule)
+    int2 *roadCandList;             // [R * kLcRoadCand] {vid, slot} of the first candidates of each road
     int32_t *insHead, *insNext;     // [L] / [insCap] records of a target lane, linked
     LcInsert *ins;
     int32_t *insCount;              // [1]

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "cfx_kernels.h"
 #include "cfx_lc_kernels.h"
 
@@ -141,6 +143,9 @@ struct cfx_engine {
     // ---- lane change (cfx_config::lane_change) ----
     LcDev lc{};                        // device tables (vid-indexed ones grow with the vehicle table)
     int32_t *oldToNew2 = nullptr;      // [slot] scratch of the mid-step rebuild
+    int32_t *lcWidth = nullptr;        // [D + 1] slots per drivable of the rebuilt layout (scan input)
+    void *scanTemp = nullptr;          // hipcub::DeviceScan work space
+    size_t scanTempBytes = 0;
     int32_t *dPool = nullptr;          // priorities of the step's shadows (device)
     int32_t *hPool = nullptr;          // ... pinned staging
     int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1..] their parents in creation order
@@ -572,6 +577,14 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         HIP_TRY(hipMemset(lc.insCount, 0, sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.parkCount, 1))) return rc;
         HIP_TRY(hipMemset(lc.parkCount, 0, sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.roadCandList, (size_t) std::max(e->R, 1) * kLcRoadCand))) return rc;
+        if ((rc = e->allocRaw(&e->lcWidth, (size_t) e->D + 1))) return rc;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, e->scanTempBytes, e->lcWidth, e->segStart[0].p, e->D + 1, e->stream));
+        {
+            char *tmp = nullptr;
+            if ((rc = e->allocRaw(&tmp, e->scanTempBytes))) return rc;
+            e->scanTemp = tmp;
+        }
         if ((rc = e->allocRaw(&lc.fixCount, 1))) return rc;
         HIP_TRY(hipMemset(lc.fixCount, 0, sizeof(int32_t)));
         HIP_TRY(hipEventCreateWithFlags(&e->pollEvent, hipEventDisableTiming));
@@ -739,8 +752,12 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         LC_CHECK("k_lc_assign")
         HIP_TRY(hipEventRecord(e->pollEvent, st));  // cfx_lane_change_poll waits for this, not for the whole step
         e->pollPending = true;
-        hipLaunchKernelGGL(k_lc_layout, dim3(1), dim3(1024), 0, st, c, e->waitHead, e->vt, e->sc, e->net.laneSpare, e->segStart[mid].p, e->cnt[mid].p, e->gen[mid].vid, e->gen[mid].drv);
-        LC_CHECK("k_lc_layout")
+        hipLaunchKernelGGL(k_lc_width, dim3(gridFor(e->D + 1)), dim3(kBlock), 0, st, c, e->waitHead, e->vt, e->sc, e->net.laneSpare,
+                           e->lcWidth, e->cnt[mid].p);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(e->scanTemp, e->scanTempBytes, e->lcWidth, e->segStart[mid].p, e->D + 1, st));
+        hipLaunchKernelGGL(k_lc_fill, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c, (const int32_t *) e->segStart[mid].p,
+                           (const int32_t *) e->cnt[mid].p, e->gen[mid].vid, e->gen[mid].drv);
+        LC_CHECK("k_lc_width/scan/fill")
         hipLaunchKernelGGL(k_lc_move, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->gen[mid],
                            (const int32_t *) e->segStart[mid].p, e->oldToNew2);
         LC_CHECK("k_lc_move")

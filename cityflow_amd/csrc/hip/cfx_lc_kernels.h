@@ -5,7 +5,7 @@
 //   k_lc_plan       Lane::initSegments + threadPlanLaneChange: every real vehicle makes its signal
 //   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in creation (vid) order
 //   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in creation order
-//   k_lc_layout / k_lc_move / k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
+//   k_lc_width, scan, k_lc_fill, k_lc_move, k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
 //   k_action, k_cross                         as always; a changing pair parks its two next speeds
 //   k_lc_resolve    the vehicles whose step depends on an earlier vehicle of the reference's walk: changing pairs (common
 //                   speed, lateral offset, finish / abort, engine.cpp:195-205,223-244) and vehicles they signalled
@@ -93,8 +93,13 @@ __global__ void k_lc_plan(StepCtx c) {
             if (ls >= 0) lc.gap[vid] = gap;
         }
         if (lc.ptype[vid] == 2) continue;  // shadows make no signals (isReal)
+        auto candidate = [&]() {
+            const int road = c.n.laneRoad[d];
+            const int i = atomicAdd(&lc.roadCand[road], 1);
+            if (i < kLcRoadCand) lc.roadCandList[(size_t) road * kLcRoadCand + i] = make_int2(vid, s);
+        };
         if (lc.changing[vid]) {            // keeps the signal it started with; still a candidate (it signals its neighbours)
-            if (d < c.n.L) atomicAdd(&lc.roadCand[c.n.laneRoad[d]], 1);
+            if (d < c.n.L) candidate();
             continue;
         }
         if (c.step * c.interval - lc.lastChangeTime[vid] < 3 /*coolingTime*/) continue;
@@ -132,7 +137,7 @@ __global__ void k_lc_plan(StepCtx c) {
         lc.sendTarget[vid] = target;
         lc.sendDir[vid] = (int8_t) dir;
         lc.sendUrg[vid] = (int8_t) urgency;
-        if (target >= 0) atomicAdd(&lc.roadCand[c.n.laneRoad[d]], 1);
+        if (target >= 0) candidate();
     }
 }
 
@@ -150,7 +155,8 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
     const int road = blockIdx.x * blockDim.x + threadIdx.x;
     if (road >= c.n.R) return;
     const LcDev &lc = c.lc;
-    if (lc.roadCand[road] == 0) return;
+    const int nListed = lc.roadCand[road];
+    if (nListed == 0) return;
     lc.roadCand[road] = 0;
     const cfx_vehicle_template *tv = c.t.templ;
     const int l0 = lc.roadLaneStart[road], l1 = lc.roadLaneStart[road + 1];
@@ -158,25 +164,21 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
     int localRec[kLcRoadInserts];  // global record indices of this road's shadows so far
     int nLocal = 0;
     // the road's candidates, ascending vid (threadPlanLaneChange's buffer; the walk never creates new ones)
-    constexpr int kCand = 96;
+    constexpr int kCand = kLcRoadCand;
     int candVid[kCand], candSlot[kCand];
     int nCand = 0;
-    bool tooMany = false;
-    for (int q = s0; q < s1; ++q) {
-        const int w = c.s.vid[q];
-        if (w < 0 || lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
-        if (nCand == kCand) {
-            tooMany = true;
-            break;
+    const bool tooMany = nListed > kCand;
+    if (!tooMany)
+        for (int j = 0; j < nListed; ++j) {
+            const int2 e = lc.roadCandList[(size_t) road * kLcRoadCand + j];
+            int i = nCand++;
+            for (; i > 0 && candVid[i - 1] > e.x; --i) {
+                candVid[i] = candVid[i - 1];
+                candSlot[i] = candSlot[i - 1];
+            }
+            candVid[i] = e.x;
+            candSlot[i] = e.y;
         }
-        int i = nCand++;
-        for (; i > 0 && candVid[i - 1] > w; --i) {
-            candVid[i] = candVid[i - 1];
-            candSlot[i] = candSlot[i - 1];
-        }
-        candVid[i] = w;
-        candSlot[i] = q;
-    }
     int lastVid = -1;
     for (int ci = 0;; ++ci) {
         int vid, s;
@@ -377,56 +379,42 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
 }
 
 // New layout after the walk: per lane its vehicles (this step's admission committed: the FIFO pop, the vehicle's state,
-// the running count) plus its shadows.  One block; every thread takes a contiguous run of drivables (lane change is not the
-// hot configuration).
-__global__ void k_lc_layout(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars *sc, const uint8_t *laneSpare,
-                            int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext, int32_t *drvNext) {
+// the running count) plus its shadows.  k_lc_width -> exclusive scan (hipcub) -> k_lc_fill.
+__global__ void k_lc_width(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars *sc, const uint8_t *laneSpare, int32_t *width,
+                           int32_t *cntNext) {
     const LcDev &lc = c.lc;
     const int D = c.n.L + c.n.K;
-    __shared__ int sSum[1024];
-    const int per = (D + (int) blockDim.x - 1) / (int) blockDim.x;
-    const int d0 = (int) threadIdx.x * per, d1 = min(D, d0 + per);
-    auto liveOf = [&](int d) {
-        int live = c.cnt[d];
-        if (d < c.n.L) {
-            if (c.admitStep[d] == c.step) live += 1;
-            for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) live += 1;
-        }
-        return live;
-    };
-    auto spareOf = [&](int d) { return d < c.n.L ? (laneSpare ? (int) laneSpare[d] : 1) : 0; };
-    int sum = 0, admitted = 0;
-    for (int d = d0; d < d1; ++d) {
-        sum += liveOf(d) + spareOf(d);
-        if (d < c.n.L && c.admitStep[d] == c.step) {  // commit the admission (what k_scan does in a step without lane change;
-            const int2 rec = c.admitRec[d];            //  admitStep itself is cleared after k_lc_move, which still needs it)
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > D) return;
+    if (d == D) {
+        width[d] = 0;  // so that the exclusive scan leaves the total at [D]
+        return;
+    }
+    int live = c.cnt[d], spare = 0;
+    if (d < c.n.L) {
+        if (c.admitStep[d] == c.step) {  // commit the admission (what k_scan does in a step without lane change; admitStep
+            live += 1;                   //  itself is cleared after k_lc_move, which still needs it)
+            const int2 rec = c.admitRec[d];
             waitHead[d] = rec.y;
             vt.state[rec.x] = 1;
-            admitted += 1;
+            atomicAdd((unsigned long long *) &sc->active, 1ULL);
         }
+        for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) live += 1;
+        spare = laneSpare ? (int) laneSpare[d] : 1;
     }
-    if (admitted) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) admitted);
-    sSum[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < (int) blockDim.x; off <<= 1) {  // inclusive scan in LDS (Hillis-Steele)
-        const int v = threadIdx.x >= (unsigned) off ? sSum[threadIdx.x - off] : 0;
-        __syncthreads();
-        sSum[threadIdx.x] += v;
-        __syncthreads();
+    cntNext[d] = live;
+    width[d] = live + spare;
+}
+
+__global__ void k_lc_fill(StepCtx c, const int32_t *segStartNext, const int32_t *cntNext, int32_t *vidNext, int32_t *drvNext) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= c.n.L) return;  // laneLinks have no spare slots
+    const int start = segStartNext[d], live = cntNext[d], end = segStartNext[d + 1];
+    for (int j = start + live; j < end; ++j) {
+        vidNext[j] = -1;
+        drvNext[j] = -1;
     }
-    int start = sSum[threadIdx.x] - sum;
-    for (int d = d0; d < d1; ++d) {
-        const int live = liveOf(d), width = live + spareOf(d);
-        segStartNext[d] = start;
-        cntNext[d] = live;
-        for (int j = live; j < width; ++j) {
-            vidNext[start + j] = -1;
-            drvNext[start + j] = -1;
-        }
-        if (d < c.n.L) c.laneTail[d] = live > 0 ? start + live - 1 : -1;
-        start += width;
-    }
-    if (threadIdx.x == blockDim.x - 1) segStartNext[D] = sSum[threadIdx.x];
+    c.laneTail[d] = live > 0 ? start + live - 1 : -1;
 }
 
 // Every vehicle to its place in the new layout; shadows are written from their parents (Vehicle copy constructor +
