@@ -777,13 +777,14 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
-        e->launch(PK_ACTION, k_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq, nVehBlocks);
+        e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
+                  nVehBlocks);
     }
     if (useBig)
-        e->launch(PK_CROSS, k_cross2, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
+        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
                   dim3(kCross2Block), c, ao, jq);
     else
-        e->launch(PK_CROSS, k_cross,
+        e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                   dim3(kCrossBlock), c, ao, jq);
     if (e->lc.on) hipLaunchKernelGGL(k_lc_resolve, dim3(1), dim3(kBlock), 0, st, c, ao, e->oldToNew2);  // (scratch is free here)
