@@ -740,7 +740,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     if (dbgSync) {                                                                                         \
         hipError_t er = hipStreamSynchronize(st);                                                          \
         if (er != hipSuccess) return e->fail(std::string("lane change: ") + name + ": " + hipGetErrorString(er)); \
-        fprintf(stderr, "[lc step %lld] %s ok\n", (long long) e->step, name);                              \
     }
         if (n > 0) hipLaunchKernelGGL(k_lc_init, dim3(gridFor(n)), dim3(kBlock), 0, st, e->lc, (int) (e->spawned - n), (int) n);
         HIP_TRY(hipMemsetAsync(e->lc.insCount, 0, sizeof(int32_t), st));
