@@ -363,6 +363,7 @@ struct cfx_engine {
         if (out.overflow == 3) return fail("halo: more vehicles crossed one cut lane in one step than CFX_HALO_MAX_MIGRANTS");
         if (out.overflow == 5) return fail("lane change: more shadows in one step than priorities supplied (cfx_lane_change_supply)");
         if (out.overflow == 6) return fail("lane change: more shadows on one road in one step than the schedule walk tracks");
+        if (out.overflow == 7) return fail("lane change: inconsistent pair state (k_lc_resolve did not converge)");
         if (out.overflow) return fail("device capacity overflow (finish list)");
         return CFX_OK;
     }

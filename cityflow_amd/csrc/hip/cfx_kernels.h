@@ -342,14 +342,18 @@ struct ActionOut {
 
 // SimpleLaneChange::yieldSpeed lanechange.cpp:186-206: 100 unless another vehicle's lane-change signal reached this one
 // (then: slow down so that the sender's gap behind it becomes safe; the sender's target leader never yields).
-__device__ inline double lcYieldSpeed(const StepCtx &c, int vid, double speed, const cfx_vehicle_template &t) {
+// `turn`: the position in the reference's walk over the vehicles at which this yield is evaluated (the vehicle's own vid;
+// for a shadow its real vehicle's).  A sender that completed its change EARLIER in that walk has already cleared its
+// signal's neighbours (LaneChange::finishChanging -> clearSignal); one that completes it later has not.
+__device__ inline double lcYieldSpeed(const StepCtx &c, int vid, double speed, const cfx_vehicle_template &t, int turn) {
     const int src = c.lc.recvFrom[vid];
     if (src < 0) return 100;
-    if (vid == c.lc.tLeader[src]) return 100;
+    const bool cleared = src < turn && c.lc.lcFinished[src];
+    if (!cleared && vid == c.lc.tLeader[src]) return 100;
     const cfx_vehicle_template *tv = c.t.templ;
     const int ss = c.lc.slotOf[src];
     double safeBefore = 0;  // safeGapBefore lanechange.cpp:213-215
-    const int f = c.lc.tFollower[src];
+    const int f = cleared ? -1 : c.lc.tFollower[src];
     if (f >= 0) {
         const int fs = c.lc.slotOf[f];
         const double fsp = c.s.speed[fs];
@@ -457,7 +461,7 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
             }
             return;
         }
-        v = min2(v, lcYieldSpeed(c, vid, speed, t));
+        v = min2(v, lcYieldSpeed(c, vid, speed, t, vid));  // (nobody has completed a change yet at this point of the step)
     } else {
         v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
     }

@@ -502,11 +502,11 @@ __global__ void k_lc_compose(int32_t *oldToNew, const int32_t *oldToNew2, int n,
 // vid; a shadow is handled inside its real vehicle's turn, engine.cpp:195-205): yield as the tables stand NOW, the rest of
 // getNextSpeed, the move; for a changing pair the common speed, the lateral offset and its end (finish), the shadow leaving
 // its lane (abort) — engine.cpp:223-244.  Sequential by nature; one block sorts, one thread walks.
-__device__ inline double lcParkedSpeed(const StepCtx &c, int vid, int s) {
+__device__ inline double lcParkedSpeed(const StepCtx &c, int vid, int s, int turn) {
     const cfx_vehicle_template &t = c.t.templ[c.s.templ[s]];
     const int d = c.s.drv[s];
     const double speed = c.s.speed[s];
-    double v = min2(c.lc.bSpeed[vid], lcYieldSpeed(c, vid, speed, t));
+    double v = min2(c.lc.bSpeed[vid], lcYieldSpeed(c, vid, speed, t, turn));
     return speedTail(c, t, s, d, speed, c.s.dis[s], c.n.drvLength[d], c.s.next[s], v);
 }
 
@@ -548,7 +548,7 @@ __global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capac
             const int pd = c.s.drv[s];
             const cfx_vehicle_template &tp = tv[c.s.templ[s]];
             if (lc.ptype[p] != 1) {  // a single vehicle that was signalled by an earlier changing vehicle
-                const double v = lcParkedSpeed(c, p, s);
+                const double v = lcParkedSpeed(c, p, s, p);
                 commitMove(c, o, s, pd, p, computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], v),
                            lc.bBlocker[p], true);
             } else {
@@ -556,7 +556,7 @@ __global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capac
                 const int qs = lc.slotOf[q];
                 const int qd = c.s.drv[qs];
                 const cfx_vehicle_template &tq = tv[c.s.templ[qs]];
-                const double ns = min2(lcParkedSpeed(c, p, s), lcParkedSpeed(c, q, qs));
+                const double ns = min2(lcParkedSpeed(c, p, s, p), lcParkedSpeed(c, q, qs, p));
                 MoveOut mp = computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], ns);
                 MoveOut mq = computeMove(c, tq, qs, qd, c.s.speed[qs], c.s.dis[qs], c.n.drvLength[qd], c.s.next[qs], ns);
                 bool pCounted = true;
@@ -575,7 +575,8 @@ __global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capac
                         lc.offset[q] = 0.0;
                         lc.partner[q] = -1;
                         lc.partner[p] = -1;
-                        lc.tLeader[p] = lc.tFollower[p] = -1;  // clearSignal: later vehicles of this walk see it
+                        // clearSignal: LATER vehicles of the walk see the signal's neighbours cleared, earlier ones (whose
+                        // items may run in this very round) must not: lcYieldSpeed decides by lcFinished and the turn
                         lc.lastDir[p] = lc.sigSend[p] ? lc.sendDir[p] : 0;
                         lc.sigSend[p] = 0;
                         lc.recvFrom[p] = -1;
@@ -603,6 +604,10 @@ __global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capac
         if (left) atomicAdd(&sLeft, left);
         __syncthreads();
         if (sLeft == 0) break;
+        if (round > 4096) {  // cannot happen (dependencies go to strictly smaller vids); never spin on corrupted state
+            if (threadIdx.x == 0) o.sc->overflow = 7;
+            break;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) *lc.parkCount = 0;

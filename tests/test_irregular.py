@@ -15,7 +15,7 @@ import pytest
 from conftest import TWIN_LIB, assert_same_state, checkpoint_record
 
 
-def irregular(scen, workdir, seed, n=5):
+def irregular(scen, workdir, seed, n=5, bends=True):
     rng = random.Random(seed)
     net = scen.grid_roadnet(n, n)
     inters = {i["id"]: i for i in net["intersections"]}
@@ -32,7 +32,7 @@ def irregular(scen, workdir, seed, n=5):
     for r in net["roads"]:
         a, b = inters[r["startIntersection"]]["point"], inters[r["endIntersection"]]["point"]
         pts = [dict(a)]
-        if rng.random() < 0.4:  # a bend
+        if rng.random() < 0.4 and bends:  # a bend (the random draws are the same either way)
             mx, my = (a["x"] + b["x"]) / 2, (a["y"] + b["y"]) / 2
             pts.append({"x": mx + rng.uniform(-30, 30), "y": my + rng.uniform(-30, 30)})
         pts.append(dict(b))
@@ -52,7 +52,7 @@ def irregular(scen, workdir, seed, n=5):
         for ph in tl["lightphases"]:
             ph["availableRoadLinks"] = [remap[i] for i in ph["availableRoadLinks"] if i in remap]
             ph["time"] = rng.choice([5, 10, 20, 30]) if ph["time"] == 30 else rng.choice([3, 5])
-    d = os.path.join(workdir, "irregular_%d" % seed)
+    d = os.path.join(workdir, "irregular_%d%s" % (seed, "" if bends else "_straight"))
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "roadnet.json"), "w") as f:
         json.dump(net, f)

@@ -227,3 +227,45 @@ def _snapshot_roundtrip(mod, scen, workdir, make):
     other = make(cfg)  # a fresh engine: nothing but the archive
     other.load(arch)
     assert advance(other, 80) == want
+
+
+def _irregular_lane_change(scen, workdir, seed, bends=True):
+    from test_irregular import irregular
+    cfg = irregular(scen, os.path.join(workdir, "lc"), seed, bends=bends)
+    c = json.load(open(cfg))
+    c["laneChange"] = True
+    with open(cfg, "w") as f:
+        json.dump(c, f)
+    return cfg
+
+
+@pytest.mark.parametrize("seed", [11, 13])
+def test_irregular_lane_change_reference_vs_twin(scen, workdir, seed):
+    """Jittered networks (bent multi-point roads, random lane widths, speed limits, signal plans, vehicle templates,
+    tests/test_irregular.py) with laneChange=true: thousands of vehicles, changes on every multi-lane road."""
+    if not os.path.exists(os.path.join(REF_DIR, "libmonotonic_new.so")):
+        pytest.skip("oracle/_ref reference build not present")
+    cfg = _irregular_lane_change(scen, workdir, seed)
+    r, t = lcp.run("ref", cfg, 200), lcp.run("twin", cfg, 200)
+    assert lcp.compare(r, t) == []
+    assert r["count"] > 2000 and r["count"] > len(r["speed"])  # shadows alive at the checkpoint
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 14])
+def test_irregular_lane_change_hip_vs_twin(mod, scen, workdir, seed):
+    """Jittered networks with STRAIGHT roads.  On a bent multi-lane road the lanes differ in length, hence in their segment
+    boundaries, and the reference looks a vehicle's neighbours up with the segment index it has on its OWN lane
+    (lanechange.cpp:30,52; roadnet.cpp:877-898): near a boundary it can pick another neighbour and leave the lane list out
+    of distance order.  The twin follows the reference there (test above); the device engine keeps lanes ordered by
+    distance (deviations)."""
+    cfg = _irregular_lane_change(scen, workdir, seed, bends=False)
+    hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    for s in range(400):
+        hip.next_step()
+        tw.next_step()
+        if s % 10 == 9:
+            a, b = _state(hip), _state(tw)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (seed, s, k)
+    assert len(a["vid"]) > 2000
