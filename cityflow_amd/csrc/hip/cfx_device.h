@@ -102,6 +102,9 @@ struct LcDev {
     // this step's scratch
     int32_t *roadCand;              // [R] candidates on the road (plan -> schedule)
     int2 *roadCandList;             // [R * kLcRoadCand] {vid, slot} of the first candidates of each road
+    int32_t *candAll;               // [slot capacity] all candidates of the step
+    int32_t *candAllCount;          // [1]
+    int32_t *candPos;               // [vid] position of a candidate in the reference's walk (k_lc_order)
     int32_t *insHead, *insNext;     // [L] / [insCap] records of a target lane, linked
     LcInsert *ins;
     int32_t *insCount;              // [1]

@@ -287,7 +287,7 @@ struct cfx_engine {
             GROW_LC(ptype) GROW_LC(partner) GROW_LC(offset) GROW_LC(sigSend) GROW_LC(sendDir) GROW_LC(sendUrg) GROW_LC(lastDir)
             GROW_LC(changing) GROW_LC(lcFinished) GROW_LC(sendTarget) GROW_LC(recvFrom) GROW_LC(tLeader) GROW_LC(tFollower)
             GROW_LC(leaderGap) GROW_LC(followerGap) GROW_LC(lastChangeTime) GROW_LC(gap) GROW_LC(slotOf) GROW_LC(bSpeed)
-            GROW_LC(bBlocker) GROW_LC(parkIdx)
+            GROW_LC(bBlocker) GROW_LC(parkIdx) GROW_LC(candPos)
 #undef GROW_LC
         }
         // nextWait of not-yet-used vids must read -1 (k_spawn_link relies on it)
@@ -320,6 +320,7 @@ struct cfx_engine {
         if (lc.on && (rc = grow(&oldToNew2, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkList, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkDep, 0, nc))) return rc;
+        if (lc.on && (rc = grow(&lc.candAll, 0, nc))) return rc;
         slotCap = nc;
         return CFX_OK;
     }
@@ -588,6 +589,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         }
         if ((rc = e->allocRaw(&lc.fixCount, 1))) return rc;
         HIP_TRY(hipMemset(lc.fixCount, 0, sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.candAllCount, 1))) return rc;
+        HIP_TRY(hipMemset(lc.candAllCount, 0, sizeof(int32_t)));
         HIP_TRY(hipEventCreateWithFlags(&e->pollEvent, hipEventDisableTiming));
     }
     if ((rc = e->ensureSlotCap((size_t) e->L + 4096))) return rc;
@@ -744,8 +747,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
         if (n > 0) hipLaunchKernelGGL(k_lc_init, dim3(gridFor(n)), dim3(kBlock), 0, st, e->lc, (int) (e->spawned - n), (int) n);
         HIP_TRY(hipMemsetAsync(e->lc.insCount, 0, sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(e->lc.candAllCount, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_lc_plan, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         LC_CHECK("k_lc_plan")
+        hipLaunchKernelGGL(k_lc_order, dim3(gridStride(std::max<size_t>(slotBound / 16, 256))), dim3(kBlock), 0, st, e->lc);
+        LC_CHECK("k_lc_order")
         hipLaunchKernelGGL(k_lc_schedule, dim3(gridFor(e->R)), dim3(kBlock), 0, st, c, e->sc, (const int32_t *) e->vt.priority);
         LC_CHECK("k_lc_schedule")
         hipLaunchKernelGGL(k_lc_assign, dim3(1), dim3(1024), 0, st, c, e->vt, e->sc, e->hPoll);

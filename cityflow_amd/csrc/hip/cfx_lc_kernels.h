@@ -3,7 +3,8 @@
 // with cfx_config::lane_change; the per-step order is
 //   k_spawn_link, k_admit                     as always (the admission sits in the lane's spare slot)
 //   k_lc_plan       Lane::initSegments + threadPlanLaneChange: every real vehicle makes its signal
-//   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in creation (vid) order
+//   k_lc_order      the position of every candidate in the reference's walk (creation order put through std::sort)
+//   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in that order
 //   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in creation order
 //   k_lc_width, scan, k_lc_fill, k_lc_move, k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
 //   k_action, k_cross                         as always; a changing pair parks its two next speeds
@@ -97,6 +98,7 @@ __global__ void k_lc_plan(StepCtx c) {
             const int road = c.n.laneRoad[d];
             const int i = atomicAdd(&lc.roadCand[road], 1);
             if (i < kLcRoadCand) lc.roadCandList[(size_t) road * kLcRoadCand + i] = make_int2(vid, s);
+            lc.candAll[atomicAdd(lc.candAllCount, 1)] = vid;
         };
         if (lc.changing[vid]) {            // keeps the signal it started with; still a candidate (it signals its neighbours)
             if (d < c.n.L) candidate();
@@ -141,6 +143,37 @@ __global__ void k_lc_plan(StepCtx c) {
     }
 }
 
+// The order of the reference's walk (engine.cpp:793-795): the candidates in creation order (ascending vid), then
+// `std::sort` by urgency.  All urgencies are 1, so the comparator is always false — and libstdc++'s introsort still
+// permutes: every partition step swaps the first element with the middle one and reverses the rest (__move_median_to_first
+// + __unguarded_partition with a comparator that never fires), recursing on both halves while they hold more than 16
+// elements; the final insertion sort moves nothing.  The walk position of the candidate with creation rank i among n is
+// therefore a closed function of (i, n) — checked against std::sort itself for every n up to 3000.
+__device__ inline int lcSortedPosition(int i, int n) {
+    int f = 0, l = n, x = i;
+    while (l - f > 16) {
+        const int mid = f + (l - f) / 2;
+        if (x == f) x = mid;
+        else if (x == mid) x = f;
+        if (x >= f + 1) x = (f + 1) + (l - 1) - x;
+        const int cut = f + 1 + (l - f - 1) / 2;
+        if (x >= cut) f = cut;
+        else l = cut;
+    }
+    return x;
+}
+
+__global__ void k_lc_order(LcDev lc) {
+    const int n = *lc.candAllCount;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int me = lc.candAll[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += lc.candAll[j] < me;
+        lc.candPos[me] = lcSortedPosition(rank, n);
+    }
+}
+
 // What the schedule walk knows about "a vehicle in the target lane": an existing one (slot) or a shadow inserted earlier
 // in this very walk (index into the road's local list).
 struct LcNeighbour {
@@ -165,21 +198,24 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
     int nLocal = 0;
     // the road's candidates, ascending vid (threadPlanLaneChange's buffer; the walk never creates new ones)
     constexpr int kCand = kLcRoadCand;
-    int candVid[kCand], candSlot[kCand];
+    int candVid[kCand], candSlot[kCand], candKey[kCand];
     int nCand = 0;
     const bool tooMany = nListed > kCand;
     if (!tooMany)
         for (int j = 0; j < nListed; ++j) {
             const int2 e = lc.roadCandList[(size_t) road * kLcRoadCand + j];
+            const int key = lc.candPos[e.x];
             int i = nCand++;
-            for (; i > 0 && candVid[i - 1] > e.x; --i) {
+            for (; i > 0 && candKey[i - 1] > key; --i) {
                 candVid[i] = candVid[i - 1];
                 candSlot[i] = candSlot[i - 1];
+                candKey[i] = candKey[i - 1];
             }
             candVid[i] = e.x;
             candSlot[i] = e.y;
+            candKey[i] = key;
         }
-    int lastVid = -1;
+    int lastKey = -1;
     for (int ci = 0;; ++ci) {
         int vid, s;
         if (!tooMany) {
@@ -187,18 +223,21 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
             vid = candVid[ci];
             s = candSlot[ci];
         } else {  // more candidates than the local list holds: pick the next one by scanning (slow, rare)
-            vid = CFX_INT_MAX;
+            vid = -1;
             s = -1;
+            int best = CFX_INT_MAX;
             for (int q = s0; q < s1; ++q) {
                 const int w = c.s.vid[q];
-                if (w < 0 || w <= lastVid || w >= vid) continue;
-                if (lc.ptype[w] == 2 || (!lcPlanChange(lc, w, c.s.drv[q]) && !lc.changing[w])) continue;
+                if (w < 0 || lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
+                const int key = lc.candPos[w];
+                if (key <= lastKey || key >= best) continue;
+                best = key;
                 vid = w;
                 s = q;
             }
             if (s < 0) break;
+            lastKey = best;
         }
-        lastVid = vid;
         const int d = c.s.drv[s];
         const int target = lc.sendTarget[vid];
         const double dis = c.s.dis[s];
@@ -321,9 +360,9 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
     if (n > lc.insCap) n = lc.insCap;
     __shared__ int sRank[1024];
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int me = lc.ins[i].parentVid;
+        const int me = lc.candPos[lc.ins[i].parentVid];  // shadows are created in walk order
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < me;
+        for (int j = 0; j < n; ++j) rank += lc.candPos[lc.ins[j].parentVid] < me;
         if (i < 1024) sRank[i] = rank;
         const LcInsert r = lc.ins[i];
         const int p = r.parentVid, v = lc.firstShadowVid + rank;
@@ -365,7 +404,7 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
         const int w = lc.fixList[3 * i], which = lc.fixList[3 * i + 1], rec = lc.fixList[3 * i + 2];
         int rank = 0;
         if (rec < 1024) rank = sRank[rec];
-        else for (int j = 0; j < n; ++j) rank += lc.ins[j].parentVid < lc.ins[rec].parentVid;
+        else for (int j = 0; j < n; ++j) rank += lc.candPos[lc.ins[j].parentVid] < lc.candPos[lc.ins[rec].parentVid];
         if (which) lc.tFollower[w] = lc.firstShadowVid + rank;
         else lc.tLeader[w] = lc.firstShadowVid + rank;
     }
@@ -460,7 +499,7 @@ __global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext,
             for (int q = lc.insHead[lane]; q >= 0; q = lc.insNext[q]) {
                 if (q == i) continue;
                 const LcInsert &o = lc.ins[q];
-                before += (o.dis > r.dis) || (o.dis == r.dis && o.parentVid < r.parentVid);
+                before += (o.dis > r.dis) || (o.dis == r.dis && lc.candPos[o.parentVid] < lc.candPos[r.parentVid]);
             }
             const int ns = segStartNext[lane] + before;
             const int vid = lc.partner[r.parentVid];  // set by k_lc_assign

@@ -257,8 +257,11 @@ int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out);
  *                     priorities and numbers the NEXT step's spawn records after the shadows.
  * cfx_lane_change_poll waits only for the part of the step that creates shadows, not for the whole step.
  * Order: the reference walks the candidates in `std::set<Vehicle*>` (heap address) order, which is not a function of
- * the simulation state; this ABI fixes the order to ascending vid (= creation order, which is the
- * address order of a fresh heap).  More than n shadows in one step: CFX_ERR_CAPACITY from the poll. */
+ * the simulation state, and then sorts them by urgency with std::sort — all urgencies are equal, yet
+ * libstdc++'s introsort permutes more than 16 equal elements.  This ABI fixes the walk to: candidates in creation order
+ * (ascending vid = the address order of a heap that never reuses memory), put through that very permutation (a closed
+ * function of the candidate count; `lcSortedPosition`, csrc/hip/cfx_lc_kernels.h).  Shadows are numbered, and take the
+ * supplied priorities, in walk order.  More than n shadows in one step: CFX_ERR_CAPACITY from the poll. */
 int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *priorities);
 int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vid, int32_t *n);
 

@@ -530,13 +530,11 @@ struct cfx_engine {
             }
         }
         // engine.cpp:793-794 sorts by urgency with std::sort, which is not stable: all urgencies are 1, and with more than
-        // 16 candidates libstdc++'s introsort permutes them.  The ABI's order is the stable one (creation order); when the
-        // twin is pinned against the reference (tests/test_lane_change.py) CFX_TWIN_LC_STDSORT=1 makes it issue the
-        // reference's very call, which yields the reference's permutation.
-        static const bool likeReference = getenv("CFX_TWIN_LC_STDSORT") != nullptr;
-        auto moreUrgent = [this](int32_t a, int32_t b) { return veh[a].sendUrgency > veh[b].sendUrgency; };
-        if (likeReference) std::sort(buffer.begin(), buffer.end(), moreUrgent);
-        else std::stable_sort(buffer.begin(), buffer.end(), moreUrgent);
+        // 16 candidates libstdc++'s introsort permutes them (a closed function of the count, see lcSortedPosition in
+        // cityflow_amd/csrc/hip/cfx_lc_kernels.h).  The same call on the same sequence gives the same permutation; the ABI
+        // defines the walk order as exactly this.
+        std::sort(buffer.begin(), buffer.end(),
+                  [this](int32_t a, int32_t b) { return veh[a].sendUrgency > veh[b].sendUrgency; });
         veh.reserve(veh.size() + buffer.size());  // references stay valid across insertShadow
         for (int32_t vid : buffer) {
             Veh &v = veh[vid];

@@ -3,7 +3,7 @@
 The reference walks lane-change candidates in heap-address order, so a reference run is only reproducible under
 oracle/_ref/libmonotonic_new.so (see oracle/monotonic_new.cpp and tests/tools/lane_change_parity.py); the committed
 vectors in tests/golden/reference_lane_change.json were produced that way.  Every run below happens in its own process
-(the twin reads its sort-mode switch once per process)."""
+."""
 import hashlib
 import json
 import os
@@ -46,13 +46,36 @@ def test_twin_lane_change_matches_reference_live(scen, workdir):
         assert lcp.compare(r, t) == [], h
 
 
-def test_canonical_order_equals_reference_order_up_to_16_candidates(scen, workdir, lc_golden):
-    """The ABI walks candidates in creation order; the reference's std::sort by (all equal) urgency keeps that order while
-    a step has at most 16 candidates (libstdc++ insertion sort).  The 6x6 grid has 12 per step: the twin's default
-    (stable) mode reproduces the reference there too."""
-    cfg = scen.materialize("grid_6x6", workdir, laneChange=True)
-    got = record(lcp.run("twin", cfg, 400, env={}))  # env={}: no CFX_TWIN_LC_STDSORT
-    assert got == lc_golden["grid_6x6"]["400"]
+def test_walk_order_permutation_is_std_sort(workdir):
+    """engine.cpp:793-794 sorts the candidates by urgency with std::sort; all urgencies are equal, and libstdc++'s introsort
+    still permutes more than 16 of them.  The device computes that permutation in closed form (lcSortedPosition,
+    cfx_lc_kernels.h); here the same procedure is checked against std::sort itself for every count up to 3000."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "cityflow_amd", "csrc", "hip", "cfx_lc_kernels.h")).read()
+    body = hdr[hdr.index("__device__ inline int lcSortedPosition"):]
+    body = body[:body.index("\n}\n") + 3].replace("__device__ inline", "static")
+    src = os.path.join(workdir, "sorted_position.cpp")
+    with open(src, "w") as f:
+        f.write("#include <algorithm>\n#include <cstdio>\n#include <vector>\n" + body + """
+int main() {
+    for (int n = 0; n <= 3000; ++n) {
+        std::vector<int> v(n);
+        for (int i = 0; i < n; ++i) v[i] = i;
+        std::sort(v.begin(), v.end(), [](int, int) { return false; });
+        for (int p = 0; p < n; ++p)
+            if (lcSortedPosition(v[p], n) != p) { printf("mismatch n=%d\\n", n); return 1; }
+    }
+    printf("ok\\n");
+    return 0;
+}
+""")
+    exe = os.path.join(workdir, "sorted_position")
+    subprocess.check_call(["g++", "-O2", "-std=c++11", src, "-o", exe])
+    assert subprocess.check_output([exe]).decode().strip() == "ok"
 
 
 def test_lane_change_api_surface(mod, scen, workdir):
@@ -158,15 +181,16 @@ def test_hip_lane_change_on_the_bench_workload(mod, scen, workdir):
 
 @pytest.mark.gpu
 def test_hip_lane_change_matches_reference_goldens(mod, scen, workdir, lc_golden):
-    """... and against the vectors the reference itself produced (6x6: at most 12 candidates per step, so the ABI's stable
-    order is the reference's order, see test_canonical_order_equals_reference_order_up_to_16_candidates)."""
-    eng = mod.Engine(scen.materialize("grid_6x6", workdir, laneChange=True), 1)
-    done = 0
-    for h in (379, 400, 600):
-        for _ in range(h - done):
-            eng.next_step()
-        done = h
-        assert record(lcp.state(eng)) == lc_golden["grid_6x6"][str(h)], h
+    """... and against the vectors the reference itself produced (1x1: more than 16 candidates in many steps, i.e. the walk
+    order is the std::sort permutation)."""
+    for name, horizons in (("example_1x1", (12, 60, 200, 500)), ("grid_6x6", (379, 400, 600))):
+        eng = mod.Engine(scen.materialize(name, workdir, laneChange=True), 1)
+        done = 0
+        for h in horizons:
+            for _ in range(h - done):
+                eng.next_step()
+            done = h
+            assert record(lcp.state(eng)) == lc_golden[name][str(h)], (name, h)
 
 
 def test_replay_log_with_lane_change_matches_reference(scen, workdir):

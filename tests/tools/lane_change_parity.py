@@ -51,8 +51,6 @@ def reference_env():
 def run(which, cfg, steps, env=None):
     if which == "ref" and env is None:
         env = reference_env()
-    if which == "twin" and env is None:
-        env = {"CFX_TWIN_LC_STDSORT": "1"}  # the reference's (unstable) std::sort of equal urgencies, see oracle/twin/twin.cpp
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", which, cfg, str(steps)], capture_output=True,
                          text=True, timeout=1800, env=dict(os.environ, **(env or {})))
     if out.returncode != 0:
