@@ -71,11 +71,18 @@ struct LcInsert {  // one shadow created in this step (Engine::insertShadow engi
     int32_t parentVid, parentSlot, lane, recvFrom;  // recvFrom: signal the shadow received later in the same walk
     double dis;
     double gap;  // the parent's ControllerInfo::gap at the moment of the copy
+    // where LaneChange::insertShadow puts it (lanechange.cpp:83-95): into the lane list right before its target follower
+    // — `anchor` = index of the first EXISTING vehicle behind it (the lane's count if none), `seq` orders the shadows that
+    // share an anchor — and into the target lane's segment with the PARENT's segment index
+    int32_t anchor, seg;
+    double seq;
 };
 struct LcDev {
     int on;
     const double *laneWidth;        // [L] Lane::width
     const int32_t *roadLaneStart;   // [R+1] lanes of a road are contiguous
+    const int32_t *laneNumSegs;     // [L] Lane::segments.size()
+    int32_t *segOfSlot;             // [slot capacity] Vehicle::segmentIndex as Lane::initSegments assigns it (k_lc_segments)
     // LaneChangeInfo vehicle.h:74-79
     int8_t *ptype;                  // 0 none, 1 real vehicle of a changing pair, 2 shadow
     int32_t *partner;               // vid or -1

@@ -321,6 +321,7 @@ struct cfx_engine {
         if (lc.on && (rc = grow(&lc.parkList, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkDep, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.candAll, 0, nc))) return rc;
+        if (lc.on && (rc = grow(&lc.segOfSlot, 0, nc))) return rc;
         slotCap = nc;
         return CFX_OK;
     }
@@ -571,6 +572,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         lc.on = 1;
         if ((rc = e->uploadConst(lc.laneWidth, n->lane_width, (size_t) e->L))) return rc;
         if ((rc = e->uploadConst(lc.roadLaneStart, n->road_lane_start, (size_t) e->R + 1))) return rc;
+        if ((rc = e->uploadConst(lc.laneNumSegs, n->lane_n_segments, (size_t) e->L))) return rc;
         if ((rc = e->allocRaw(&lc.roadCand, (size_t) e->R))) return rc;
         HIP_TRY(hipMemset(lc.roadCand, 0, (size_t) std::max(e->R, 1) * sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.insHead, (size_t) e->L))) return rc;
@@ -603,8 +605,8 @@ int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
         g_createError = "cfx_create: null argument";
         return CFX_ERR_INVALID;
     }
-    if (cfg->lane_change && (!n->lane_width || !n->road_lane_start)) {
-        g_createError = "cfx_create: lane_change needs cfx_net::lane_width and road_lane_start";
+    if (cfg->lane_change && (!n->lane_width || !n->road_lane_start || !n->lane_n_segments)) {
+        g_createError = "cfx_create: lane_change needs cfx_net::lane_width, lane_n_segments and road_lane_start";
         return CFX_ERR_INVALID;
     }
     cfx_engine *e = new cfx_engine();
@@ -748,6 +750,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if (n > 0) hipLaunchKernelGGL(k_lc_init, dim3(gridFor(n)), dim3(kBlock), 0, st, e->lc, (int) (e->spawned - n), (int) n);
         HIP_TRY(hipMemsetAsync(e->lc.insCount, 0, sizeof(int32_t), st));
         HIP_TRY(hipMemsetAsync(e->lc.candAllCount, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_lc_segments, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c);
         hipLaunchKernelGGL(k_lc_plan, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         LC_CHECK("k_lc_plan")
         hipLaunchKernelGGL(k_lc_order, dim3(gridStride(std::max<size_t>(slotBound / 16, 256))), dim3(kBlock), 0, st, e->lc);

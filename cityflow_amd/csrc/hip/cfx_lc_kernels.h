@@ -12,8 +12,11 @@
 //                   speed, lateral offset, finish / abort, engine.cpp:195-205,223-244) and vehicles they signalled
 //   k_scan, k_scatter                         as always
 //   k_lc_clear      LaneChange::clearSignal for every vehicle (engine.cpp:424) + slot of every vehicle
-// Lanes are ordered by distance (front = furthest), so the reference's segment lists (Lane::getVehicleAfterDistance /
-// BeforeDistance, roadnet.cpp:877-898) reduce to binary searches.
+// The reference finds a vehicle's neighbours in another lane through per-lane segment lists (Lane::initSegments,
+// getVehicleAfterDistance / BeforeDistance, roadnet.cpp:863-898) — indexed with the segment number the vehicle has on its
+// OWN lane, and inserts a shadow before the follower found that way.  On roads whose lanes differ in length that is not
+// "the neighbours by distance", and the lane list can even lose its distance order.  k_lc_segments assigns the segment
+// numbers exactly as initSegments does and every search below walks the lists the way the reference does.
 #pragma once
 
 #include "cfx_kernels.h"
@@ -27,21 +30,39 @@ __device__ __forceinline__ bool lcPlanChange(const LcDev &lc, int vid, int drv) 
     return (lc.sigSend[vid] && lc.sendTarget[vid] >= 0 && lc.sendTarget[vid] != drv) || lc.changing[vid];
 }
 
-// Index (inside lane `lane`) of the rearmost vehicle with distance >= dis, or -1: Lane::getVehicleAfterDistance
-__device__ inline int lcRearmostAtLeast(const StepCtx &c, int lane, double dis) {
-    const int base = c.segStart[lane];
-    int lo = 0, hi = cntNow(c, lane);  // first index whose distance is < dis
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (c.s.dis[base + mid] >= dis) lo = mid + 1;
-        else hi = mid;
+// Lane::startPos of segment i (roadnet.cpp:859)
+__device__ __forceinline__ double lcSegStart(const StepCtx &c, int lane, int i) {
+    return i * c.n.drvLength[lane] / c.lc.laneNumSegs[lane];
+}
+
+// Lane::initSegments roadnet.cpp:863-875, one thread per lane: front to back, every vehicle goes to the highest segment
+// whose start it has reached — as long as the vehicles in front of it did (the list is walked once).  Segment numbers
+// therefore never increase along the list, whatever the distances are.
+__global__ void k_lc_segments(StepCtx c) {
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= c.n.L) return;
+    const int base = c.segStart[lane], n = cntNow(c, lane);
+    int it = 0;
+    for (int i = c.lc.laneNumSegs[lane] - 1; i >= 0 && it < n; --i) {
+        const double start = lcSegStart(c, lane, i);
+        while (it < n && c.s.dis[base + it] >= start) c.lc.segOfSlot[base + it++] = i;
     }
-    return lo - 1;
+}
+
+// Lane::getVehicleAfterDistance(dis, seg) roadnet.cpp:889-898 over the lane's existing vehicles: segments seg, seg+1, ...
+// each back to front = the list from the last vehicle of segment >= seg towards the front.  Returns the index in the lane.
+__device__ inline int lcAfterIdx(const StepCtx &c, int lane, double dis, int seg) {
+    const int base = c.segStart[lane], n = cntNow(c, lane);
+    int e = n - 1;
+    while (e >= 0 && c.lc.segOfSlot[base + e] < seg) --e;
+    for (int k = e; k >= 0; --k)
+        if (c.s.dis[base + k] >= dis) return k;
+    return -1;
 }
 
 // SimpleLaneChange::estimateGap lanechange.cpp:221-226
-__device__ inline double lcEstimateGap(const StepCtx &c, int lane, double dis) {
-    const int k = lcRearmostAtLeast(c, lane, dis);
+__device__ inline double lcEstimateGap(const StepCtx &c, int lane, double dis, int seg) {
+    const int k = lcAfterIdx(c, lane, dis, seg);
     if (k < 0) return c.n.drvLength[lane] - dis;
     const int ls = c.segStart[lane] + k;
     return c.s.dis[ls] - dis - c.t.templ[c.s.templ[ls]].len;
@@ -121,13 +142,13 @@ __global__ void k_lc_plan(StepCtx c) {
                 double outerEst = 0;
                 if (li < nLanes - 1) {
                     if (lastRoad || nextOf(c.n, c.t, d + 1, route, routePos) >= 0) {
-                        outerEst = lcEstimateGap(c, d + 1, dis);
+                        outerEst = lcEstimateGap(c, d + 1, dis, c.lc.segOfSlot[s]);
                         if (outerEst > gap + t.len) target = d + 1;
                     }
                 }
                 if (li > 0) {
                     if (lastRoad || nextOf(c.n, c.t, d - 1, route, routePos) >= 0) {
-                        const double innerEst = lcEstimateGap(c, d - 1, dis);
+                        const double innerEst = lcEstimateGap(c, d - 1, dis, c.lc.segOfSlot[s]);
                         if (innerEst > gap + t.len && innerEst > outerEst) target = d - 1;
                     }
                 }
@@ -242,32 +263,75 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
         const int target = lc.sendTarget[vid];
         const double dis = c.s.dis[s];
         const cfx_vehicle_template &t = tv[c.s.templ[s]];
-        // --- LaneChange::updateLeaderAndFollower lanechange.cpp:27-60 on the target lane as it is NOW (earlier shadows of
-        // this walk included: behind every existing vehicle with a distance >= theirs, in front of the rest)
+        // --- LaneChange::updateLeaderAndFollower lanechange.cpp:27-60 on the target lane as it is NOW: its segment lists,
+        // walked with the candidate's own segment number, earlier shadows of this walk included (each sits in the segment
+        // its parent's number names, at the place Segment::insertVehicle gave it, roadnet.cpp:943-947)
         LcNeighbour leader{-1, 0, 0, 0, 0}, follower{-1, 0, 0, 0, 0};
-        const int tb = c.segStart[target];
-        const int k = lcRearmostAtLeast(c, target, dis);  // existing vehicles 0..k have distance >= dis
-        if (k >= 0) {
-            const int ls = tb + k;
-            const cfx_vehicle_template &tl = tv[c.s.templ[ls]];
-            leader = LcNeighbour{c.s.vid[ls], c.s.dis[ls], tl.len, c.s.speed[ls], tl.max_neg_acc};
-        }
-        if (k + 1 < cntNow(c, target)) {
-            const int fs = tb + k + 1;
-            const cfx_vehicle_template &tf = tv[c.s.templ[fs]];
-            follower = LcNeighbour{c.s.vid[fs], c.s.dis[fs], tf.len, c.s.speed[fs], tf.max_neg_acc};
-        }
-        for (int i = 0; i < nLocal; ++i) {
-            const LcInsert &r = lc.ins[localRec[i]];
-            if (r.lane != target) continue;
-            const int ps = r.parentSlot;
-            const cfx_vehicle_template &tp = tv[c.s.templ[ps]];
-            const LcNeighbour me{-(localRec[i] + 2), r.dis, tp.len, c.s.speed[ps], tp.max_neg_acc};
-            if (r.dis >= dis) {  // candidate leader: the rearmost wins; a shadow sits behind existing vehicles of equal distance
-                if (leader.vid == -1 || r.dis <= leader.dis) leader = me;
-            } else {             // candidate follower: the frontmost wins; among equals the existing / earlier one is in front
-                if (follower.vid == -1 || r.dis > follower.dis) follower = me;
+        int followerAnchor = cntNow(c, target);  // lane-list position of the follower: existing index, or ...
+        int followerRec = -1;                    // ... the earlier shadow it is
+        const int tb = c.segStart[target], tn = cntNow(c, target);
+        const int mySeg = lc.segOfSlot[s], nSeg = lc.laneNumSegs[target];
+        constexpr int kItems = 64;
+        int itemRef[kItems];  // >= 0 existing index in the lane; < 0: -(local shadow index + 1)
+        double itemDis[kItems];
+        auto buildSegment = [&](int i) {  // the sequence of segment i of the target lane
+            int m = 0;
+            for (int k = 0; k < tn; ++k) {
+                if (lc.segOfSlot[tb + k] != i) continue;
+                if (m == kItems) {
+                    sc->overflow = 6;
+                    break;
+                }
+                itemRef[m] = k;
+                itemDis[m++] = c.s.dis[tb + k];
             }
+            for (int j = 0; j < nLocal; ++j) {
+                const LcInsert &r = lc.ins[localRec[j]];
+                if (r.lane != target || r.seg != i) continue;
+                int p = 0;
+                while (p < m && itemDis[p] > r.dis) ++p;  // before the first member that is not further ahead
+                if (m == kItems) {
+                    sc->overflow = 6;
+                    break;
+                }
+                for (int q = m; q > p; --q) {
+                    itemRef[q] = itemRef[q - 1];
+                    itemDis[q] = itemDis[q - 1];
+                }
+                itemRef[p] = -(j + 1);
+                itemDis[p] = r.dis;
+                ++m;
+            }
+            return m;
+        };
+        auto neighbourOf = [&](int ref) {
+            if (ref >= 0) {
+                const int ns = tb + ref;
+                const cfx_vehicle_template &tl = tv[c.s.templ[ns]];
+                return LcNeighbour{c.s.vid[ns], c.s.dis[ns], tl.len, c.s.speed[ns], tl.max_neg_acc};
+            }
+            const int j = -ref - 1;
+            const LcInsert &r = lc.ins[localRec[j]];
+            const cfx_vehicle_template &tp = tv[c.s.templ[r.parentSlot]];
+            return LcNeighbour{-(localRec[j] + 2), r.dis, tp.len, c.s.speed[r.parentSlot], tp.max_neg_acc};
+        };
+        for (int i = mySeg; i < nSeg && leader.vid == -1; ++i) {  // getVehicleAfterDistance: back to front
+            const int m = buildSegment(i);
+            for (int p = m - 1; p >= 0; --p)
+                if (itemDis[p] >= dis) {
+                    leader = neighbourOf(itemRef[p]);
+                    break;
+                }
+        }
+        for (int i = mySeg < nSeg ? mySeg : nSeg - 1; i >= 0 && follower.vid == -1; --i) {  // getVehicleBeforeDistance
+            const int m = buildSegment(i);
+            for (int p = 0; p < m; ++p)
+                if (itemDis[p] < dis) {
+                    follower = neighbourOf(itemRef[p]);
+                    if (itemRef[p] >= 0) followerAnchor = itemRef[p];
+                    else followerRec = localRec[-itemRef[p] - 1];
+                    break;
+                }
         }
         double leaderGap, followerGap = 1.7976931348623157e308;
         if (leader.vid == -1) {  // look into the laneLinks behind the target lane
@@ -338,7 +402,26 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
                 } else if (nLocal >= kLcRoadInserts) {
                     sc->overflow = 6;  // more shadows on one road in one step than the walk keeps track of
                 } else {
-                    lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid]};
+                    // the lane-list place: right before the follower (LaneChange::insertShadow lanechange.cpp:91-93)
+                    int anchor = followerAnchor;
+                    double seq;
+                    if (followerRec >= 0) {  // before an earlier shadow: same anchor, between it and its predecessor
+                        const LcInsert &fr = lc.ins[followerRec];
+                        anchor = fr.anchor;
+                        double prev = fr.seq - 2.0;
+                        for (int j = 0; j < nLocal; ++j) {
+                            const LcInsert &o = lc.ins[localRec[j]];
+                            if (o.lane == target && o.anchor == anchor && o.seq < fr.seq && o.seq > prev) prev = o.seq;
+                        }
+                        seq = (prev + fr.seq) / 2;
+                    } else {                 // before an existing vehicle (or at the end): behind the shadows already there
+                        seq = 0.0;
+                        for (int j = 0; j < nLocal; ++j) {
+                            const LcInsert &o = lc.ins[localRec[j]];
+                            if (o.lane == target && o.anchor == anchor && o.seq >= seq) seq = o.seq + 1.0;
+                        }
+                    }
+                    lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid], anchor, mySeg, seq};
                     // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
                     // later candidate of this walk that copies itself (its own shadow) copies this gap too
                     if (follower.vid >= 0) lc.gap[follower.vid] = dis - t.len - follower.dis;
@@ -457,8 +540,8 @@ __global__ void k_lc_fill(StepCtx c, const int32_t *segStartNext, const int32_t 
 }
 
 // Every vehicle to its place in the new layout; shadows are written from their parents (Vehicle copy constructor +
-// LaneChange::insertShadow lanechange.cpp:83-93).  Inside a lane the order stays "by distance, front first"; a shadow goes
-// behind every vehicle whose distance is >= its own, shadows of equal distance in creation order.
+// LaneChange::insertShadow lanechange.cpp:83-93) and go where the reference's list insertion put them: right before their
+// target follower (LcInsert::anchor / seq).
 __global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext, int32_t *oldToNew2) {
     const LcDev &lc = c.lc;
     const int nIns = min(*lc.insCount, lc.insCap);
@@ -473,10 +556,11 @@ __global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext,
             }
             const int d = c.s.drv[s];
             const double dis = c.s.dis[s];
+            const int k = s - c.segStart[d];
             int shift = 0;
             if (d < c.n.L)
-                for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) shift += lc.ins[r].dis > dis;
-            const int ns = segStartNext[d] + (s - c.segStart[d]) + shift;
+                for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) shift += lc.ins[r].anchor <= k;
+            const int ns = segStartNext[d] + k + shift;
             oldToNew2[s] = ns;
             lc.slotOf[vid] = ns;
             nx.vid[ns] = vid;
@@ -495,11 +579,11 @@ __global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext,
             const int i = s - S;
             const LcInsert r = lc.ins[i];
             const int ps = r.parentSlot, lane = r.lane;
-            int before = lcRearmostAtLeast(c, lane, r.dis) + 1;  // existing vehicles in front of it
+            int before = r.anchor;  // existing vehicles in front of it
             for (int q = lc.insHead[lane]; q >= 0; q = lc.insNext[q]) {
                 if (q == i) continue;
                 const LcInsert &o = lc.ins[q];
-                before += (o.dis > r.dis) || (o.dis == r.dis && lc.candPos[o.parentVid] < lc.candPos[r.parentVid]);
+                before += (o.anchor < r.anchor) || (o.anchor == r.anchor && o.seq < r.seq);
             }
             const int ns = segStartNext[lane] + before;
             const int vid = lc.partner[r.parentVid];  // set by k_lc_assign

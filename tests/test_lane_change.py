@@ -276,14 +276,13 @@ def test_irregular_lane_change_reference_vs_twin(scen, workdir, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [11, 12, 14])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
 def test_irregular_lane_change_hip_vs_twin(mod, scen, workdir, seed):
-    """Jittered networks with STRAIGHT roads.  On a bent multi-lane road the lanes differ in length, hence in their segment
-    boundaries, and the reference looks a vehicle's neighbours up with the segment index it has on its OWN lane
-    (lanechange.cpp:30,52; roadnet.cpp:877-898): near a boundary it can pick another neighbour and leave the lane list out
-    of distance order.  The twin follows the reference there (test above); the device engine keeps lanes ordered by
-    distance (deviations)."""
-    cfg = _irregular_lane_change(scen, workdir, seed, bends=False)
+    """Jittered networks with bent roads: the lanes of such a road differ in length, hence in their segment boundaries,
+    and the reference looks a vehicle's neighbours up with the segment number it has on its OWN lane (lanechange.cpp:30,52;
+    roadnet.cpp:877-898) — near a boundary it skips the true neighbour and inserts the shadow out of distance order.  The
+    device engine walks the segment lists the same way (k_lc_segments, k_lc_schedule)."""
+    cfg = _irregular_lane_change(scen, workdir, seed)
     hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
     for s in range(400):
         hip.next_step()
