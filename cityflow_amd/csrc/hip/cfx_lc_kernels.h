@@ -276,8 +276,14 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
         double itemDis[kItems];
         auto buildSegment = [&](int i) {  // the sequence of segment i of the target lane
             int m = 0;
-            for (int k = 0; k < tn; ++k) {
-                if (lc.segOfSlot[tb + k] != i) continue;
+            // segment numbers never increase along the list (k_lc_segments): the members are one run
+            int lo = 0, hi = tn;
+            while (lo < hi) {  // first index whose segment number is <= i
+                const int mid = (lo + hi) >> 1;
+                if (lc.segOfSlot[tb + mid] > i) lo = mid + 1;
+                else hi = mid;
+            }
+            for (int k = lo; k < tn && lc.segOfSlot[tb + k] == i; ++k) {
                 if (m == kItems) {
                     sc->overflow = 6;
                     break;

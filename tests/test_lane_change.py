@@ -292,3 +292,42 @@ def test_irregular_lane_change_hip_vs_twin(mod, scen, workdir, seed):
             for k in a:
                 assert np.array_equal(a[k], b[k]), (seed, s, k)
     assert len(a["vid"]) > 2000
+
+
+@pytest.mark.gpu
+def test_hip_lane_change_with_control_calls(mod, scen, workdir):
+    """Lane change together with the control API: RL-driven signals, push_vehicle (with an initial speed), set_vehicle_speed
+    on real vehicles of changing pairs, reset(seed) in the middle — HIP == twin after every step."""
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True, rlTrafficLight=True)
+    hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    inter = [i for i in hip.intersection_ids() if not i.endswith("_0_1") or True]
+    roads = sorted({l.rsplit("_", 1)[0] for l in hip.lane_ids()})
+    for s in range(260):
+        if s % 15 == 0:
+            for e in (hip, tw):
+                for iid in inter:
+                    try:
+                        e.set_tl_phase(iid, (s // 15) % 8)
+                    except (IndexError, RuntimeError):
+                        pass  # virtual intersections
+        if s in (20, 21, 90):
+            for e in (hip, tw):
+                e.push_vehicle({"length": 5.0, "width": 2.0, "maxPosAcc": 2.0, "maxNegAcc": 4.5, "usualPosAcc": 2.0,
+                                "usualNegAcc": 4.5, "minGap": 2.5, "maxSpeed": 16.67, "headwayTime": 1.5, "speed": 3.0},
+                               ["road_0_1_0", "road_1_1_0"])
+        if s % 7 == 3:  # slow down whoever is changing lane right now
+            st = _state(tw)
+            for v in st["vid"][(st["lc_flags"] & 2) != 0][:3]:
+                vid = tw._vehicle_id(int(v))
+                for e in (hip, tw):
+                    e.set_vehicle_speed(vid, 4.0)
+        if s == 130:
+            for e in (hip, tw):
+                e.reset(True)
+        hip.next_step()
+        tw.next_step()
+        a, b = _state(hip), _state(tw)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (s, k)
+    assert roads and len(a["vid"]) > 100
+    assert hip.get_vehicle_speed() == tw.get_vehicle_speed() and hip.get_lane_vehicles() == tw.get_lane_vehicles()
