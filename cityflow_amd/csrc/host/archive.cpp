@@ -47,21 +47,31 @@ void key(std::string &o, const char *k) {
 
 std::string Archive::vehicleId(int vid) const {
     const VehicleRecord &r = host.vehicles[vid];
-    if (r.flow >= 0) return flowIds[r.flow] + "_" + std::to_string(r.number);
-    return "manually_pushed_" + std::to_string(r.number);
+    std::string id = r.flow >= 0 ? flowIds[r.flow] + "_" + std::to_string(r.number) : "manually_pushed_" + std::to_string(r.number);
+    // lane change: a shadow is "<id>_shadow" until its change completes (engine.cpp:814, lanechange.cpp:119-121)
+    if (!dev.rLcFlags.empty())
+        for (size_t i = 0; i < dev.rVid.size(); ++i)
+            if (dev.rVid[i] == vid) return (dev.rLcFlags[i] & CFX_LC_SHADOW) ? id + "_shadow" : id;
+    return id;
 }
 
 // Archive::dump archive.cpp:153-343 — same keys, same nesting; vehicles in vehiclePool (priority) order.
 void Archive::dump(const std::string &path) const {
-    if (!dev.rLcFlags.empty())
-        throw std::runtime_error("Archive.dump: archives taken with laneChange=true are not written to the JSON format yet "
-                                 "(snapshot() / load() work in memory)");
+    const bool lc = !dev.rLcFlags.empty();
     const int L = (int) net->lanes.size();
     const int nV = (int) host.vehicles.size();
     std::vector<int> runIndex(nV, -1);
     for (size_t i = 0; i < dev.rVid.size(); ++i) runIndex[dev.rVid[i]] = (int) i;
     std::vector<int> waitLane(nV, -1);
     for (size_t i = 0; i < dev.wVid.size(); ++i) waitLane[dev.wVid[i]] = dev.wLane[i];
+
+    std::vector<std::string> idOf((size_t) nV);  // with lane change ids depend on the state: computed once
+    for (int v = 0; v < nV; ++v) {
+        const VehicleRecord &r = host.vehicles[v];
+        idOf[v] = r.flow >= 0 ? flowIds[r.flow] + "_" + std::to_string(r.number) : "manually_pushed_" + std::to_string(r.number);
+        if (lc && runIndex[v] >= 0 && (dev.rLcFlags[runIndex[v]] & CFX_LC_SHADOW)) idOf[v] += "_shadow";
+    }
+    auto vehicleId = [&idOf](int v) -> const std::string & { return idOf[(size_t) v]; };
 
     std::string o;
     o.reserve(1 << 20);
@@ -123,7 +133,7 @@ void Archive::dump(const std::string &path) const {
             key(o, "prevDrivable"); str(o, net->drivableId(dev.rPrevDrivable[ri])); o += ',';
         }
         key(o, "approachingIntersectionDistance"); num(o, t.approach_dist); o += ',';
-        key(o, "gap"); num(o, (ri >= 0 && dev.rLeader[ri] >= 0) ? dev.rGap[ri] : 0.0); o += ',';
+        key(o, "gap"); num(o, (ri >= 0 && (lc || dev.rLeader[ri] >= 0)) ? dev.rGap[ri] : 0.0); o += ',';
         key(o, "enterLaneLinkTime"); o += std::to_string((unsigned) (ri >= 0 ? dev.rEnterLLTime[ri] : INT_MAX)); o += ',';
         if (ri >= 0 && dev.rLeader[ri] >= 0) {
             key(o, "leader"); str(o, vehicleId(dev.rLeader[ri])); o += ',';
@@ -133,11 +143,30 @@ void Archive::dump(const std::string &path) const {
         }
         key(o, "end"); o += "false,";
         key(o, "running"); o += ri >= 0 ? "true," : "false,";
-        key(o, "partnerType"); o += "0,";
-        key(o, "offset"); o += "0.0,";
-        key(o, "laneChangeWaitingTime"); o += "0.0,";
-        key(o, "laneChanging"); o += "false,";
-        key(o, "laneChangeLastTime"); o += "0.0";
+        if (lc && ri >= 0) {  // archive.cpp:229-246
+            const uint8_t f = dev.rLcFlags[ri];
+            key(o, "partnerType"); o += (f & CFX_LC_SHADOW) ? "2," : ((f & CFX_LC_PARENT) ? "1," : "0,");
+            if (dev.rLcPartner[ri] >= 0) {
+                key(o, "partner"); str(o, vehicleId(dev.rLcPartner[ri])); o += ',';
+            }
+            key(o, "offset"); num(o, dev.rLcOffset[ri]); o += ',';
+            if (f & CFX_LC_CHANGING) {  // the only signal that outlives a step
+                key(o, "laneChangeUrgency"); o += "1,";
+                key(o, "laneChangeDirection"); o += std::to_string(dev.rLcDirection[ri]); o += ',';
+                if (dev.rLcTarget[ri] >= 0) {
+                    key(o, "laneChangeTarget"); str(o, net->drivableId(dev.rLcTarget[ri])); o += ',';
+                }
+            }
+            key(o, "laneChangeWaitingTime"); num(o, dev.rLcWaitingTime[ri]); o += ',';
+            key(o, "laneChanging"); o += (f & CFX_LC_CHANGING) ? "true," : "false,";
+            key(o, "laneChangeLastTime"); num(o, dev.rLcLastChangeTime[ri]);
+        } else {
+            key(o, "partnerType"); o += "0,";
+            key(o, "offset"); o += "0.0,";
+            key(o, "laneChangeWaitingTime"); o += "0.0,";
+            key(o, "laneChanging"); o += "false,";
+            key(o, "laneChangeLastTime"); o += "0.0";
+        }
         o += '}';
     }
     o += "],";
@@ -319,9 +348,6 @@ void EngineHost::load(const Archive &a) {
 
 // Archive(Engine&, filename) archive.cpp:345-550: rebuild an Archive from the reference's JSON format.
 void EngineHost::loadFromFile(const std::string &path) {
-    if (laneChange_)
-        throw std::runtime_error("load_from_file: not available with laneChange=true yet (the JSON format's lane-change "
-                                 "fields are not read; snapshot() / load() work in memory)");
     Json root = Json::parseFile(path);
     Archive a;
     a.net = net_;
@@ -353,7 +379,15 @@ void EngineHost::loadFromFile(const std::string &path) {
         int drivable, prev, ellt;
         std::string blocker;
         bool running;
+        // lane change (archive.cpp:407-424,447-460)
+        double gap = 0, offset = 0, lastTime = 0, waitingTime = 0;
+        int partnerType = 0, direction = 0;
+        bool changing = false, shadow = false;
+        std::string partner, target;
     };
+    a.host.shadowChains.clear();
+    const std::string shadowSuffix = "_shadow";
+    std::vector<std::pair<int, std::string>> shadowBase;  // (vid of a shadow, id it carries)
     std::vector<Dyn> dyn;
     for (const Json &jv : vehicles.items) {
         cfx_vehicle_template t = spawner_.makeTemplate(jv.numberAt("len"), jv.numberAt("width"), jv.numberAt("maxPosAcc"),
@@ -376,7 +410,10 @@ void EngineHost::loadFromFile(const std::string &path) {
         r.route = spawner_.internRoute(seq);
         r.priority = jv.intAt("priority");
         r.enterTime = jv.numberAt("enterTime");
-        const std::string &id = jv.stringAt("id");
+        const std::string &fullId = jv.stringAt("id");
+        const bool isShadow = laneChange_ && fullId.size() > shadowSuffix.size() &&
+                              fullId.compare(fullId.size() - shadowSuffix.size(), shadowSuffix.size(), shadowSuffix) == 0;
+        const std::string id = isShadow ? fullId.substr(0, fullId.size() - shadowSuffix.size()) : fullId;
         const std::string mp = "manually_pushed_";
         if (id.compare(0, mp.size(), mp) == 0) {
             r.flow = -1;
@@ -402,17 +439,41 @@ void EngineHost::loadFromFile(const std::string &path) {
         const Json *bl = jv.find("blocker");
         if (bl) y.blocker = bl->s;
         y.running = jv.boolAt("running");
+        if (laneChange_) {
+            y.shadow = isShadow;
+            y.gap = jv.numberAt("gap");
+            y.partnerType = jv.intAt("partnerType");
+            y.offset = jv.numberAt("offset");
+            if (const Json *pp = jv.find("partner")) y.partner = pp->s;
+            y.changing = jv.boolAt("laneChanging");
+            y.lastTime = jv.numberAt("laneChangeLastTime");
+            y.waitingTime = jv.numberAt("laneChangeWaitingTime");
+            if (jv.find("laneChangeUrgency")) {
+                y.direction = jv.intAt("laneChangeDirection");
+                if (const Json *tg = jv.find("laneChangeTarget")) y.target = tg->s;
+            }
+        }
         r.firstLane = y.running ? -1 : y.drivable;
         int vid = (int) a.host.vehicles.size();
         a.host.vehicles.push_back(r);
         a.host.livePriority.set(r.priority, vid);
-        std::vector<int32_t> &tbl = r.flow >= 0 ? a.host.flowVids[r.flow] : a.host.manualVids;
-        if ((int) tbl.size() <= r.number) tbl.resize(r.number + 1, -1);
-        tbl[r.number] = vid;
-        vidOf[id] = vid;
+        if (isShadow) {
+            shadowBase.emplace_back(vid, id);  // its chain is attached once every vehicle is known
+        } else {
+            std::vector<int32_t> &tbl = r.flow >= 0 ? a.host.flowVids[r.flow] : a.host.manualVids;
+            if ((int) tbl.size() <= r.number) tbl.resize(r.number + 1, -1);
+            tbl[r.number] = vid;
+        }
+        vidOf[fullId] = vid;
         dyn.push_back(y);
     }
     const int nV = (int) a.host.vehicles.size();
+    for (auto &sb : shadowBase) {  // the id a shadow carries belongs to the vehicle named so (its parent or an ancestor's heir)
+        auto it = vidOf.find(sb.second);
+        const int root = it == vidOf.end() ? sb.first : it->second;
+        a.host.vehicles[(size_t) sb.first].root = root;
+        a.host.shadowChains[root].push_back(sb.first);
+    }
     d.vState.assign(nV, 0);
     const Json &drivables = root.objectAt("drivables");
     const RouteTable &rt = spawner_.routes;
@@ -437,7 +498,18 @@ void EngineHost::loadFromFile(const std::string &path) {
             d.rLeader.push_back(-1);
             d.rDis.push_back(y.dis);
             d.rSpeed.push_back(y.speed);
-            d.rGap.push_back(0.0);
+            d.rGap.push_back(y.gap);
+            if (laneChange_) {
+                d.rLcFlags.push_back((uint8_t) ((y.partnerType == 2 ? CFX_LC_SHADOW : 0) | (y.partnerType == 1 ? CFX_LC_PARENT : 0) |
+                                                (y.changing ? CFX_LC_CHANGING : 0)));
+                d.rLcPartner.push_back(y.partner.empty() ? -1 : vidOf.at(y.partner));
+                d.rLcOffset.push_back(y.offset);
+                d.rLcLastDir.push_back(0);  // not archived by the reference (the next clearSignal rewrites it)
+                d.rLcTarget.push_back(y.target.empty() ? -1 : drvIndex.at(y.target));
+                d.rLcDirection.push_back(y.direction);
+                d.rLcLastChangeTime.push_back(y.lastTime);
+                d.rLcWaitingTime.push_back(y.waitingTime);
+            }
         }
         if (dv < L) {
             for (const Json &jid : jd.arrayAt("waitingBuffer").items) {

@@ -225,7 +225,7 @@ def test_snapshot_and_load_with_lane_change(mod, scen, workdir):
     """Engine.snapshot() / load() in memory (reference engine.h:176-177) carry the lane-change state that outlives a step:
     partner links, lateral offset, the signal of a change in progress, cooling timers, the stored gap, the id chains and
     the generator.  A run resumed from a snapshot taken in the middle of several lane changes equals the uninterrupted
-    one; the JSON form refuses (its lane-change fields are not written yet)."""
+    one (the JSON form: test_archive_json_with_lane_change_both_directions)."""
     _snapshot_roundtrip(mod, scen, workdir, lambda cfg: mod.Engine._with_backend(cfg, 1, TWIN_LIB))
 
 
@@ -236,8 +236,6 @@ def _snapshot_roundtrip(mod, scen, workdir, make):
         eng.next_step()
     assert eng.get_vehicle_count() > len(eng.get_vehicle_speed())  # shadows alive: changes in progress
     arch = eng.snapshot()
-    with pytest.raises(RuntimeError):
-        arch.dump(os.path.join(workdir, "lc_archive.json"))
 
     def advance(e, n):
         for _ in range(n):
@@ -331,3 +329,19 @@ def test_hip_lane_change_with_control_calls(mod, scen, workdir):
             assert np.array_equal(a[k], b[k]), (s, k)
     assert roads and len(a["vid"]) > 100
     assert hip.get_vehicle_speed() == tw.get_vehicle_speed() and hip.get_lane_vehicles() == tw.get_lane_vehicles()
+
+
+def test_archive_json_with_lane_change_both_directions(scen, workdir):
+    """Archive.dump / load_from_file with lane-change state (reference archive.cpp:229-246,407-474): a dump taken by this
+    engine in the middle of several lane changes resumes identically in the reference and here, and so does a dump taken by
+    the reference.  (After a load both sides number / allocate the vehicles in the file's order.)"""
+    if not os.path.exists(os.path.join(REF_DIR, "libmonotonic_new.so")):
+        pytest.skip("oracle/_ref reference build not present")
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True)
+    for writer in ("twin", "ref"):
+        path = os.path.join(workdir, "lc_archive_%s.json" % writer)
+        st = lcp.run(writer, cfg, 31, save=path)
+        assert st["count"] > len(st["speed"])  # shadows alive in the dump
+        assert any(v.get("partnerType") == 2 for v in json.load(open(path))["vehicles"])
+        r, t = lcp.run("ref", cfg, 70, load=path), lcp.run("twin", cfg, 70, load=path)
+        assert lcp.compare(r, t) == [], writer

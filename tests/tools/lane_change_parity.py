@@ -26,7 +26,8 @@ def state(eng):
             "average_travel_time": eng.get_average_travel_time(), "lane_count": eng.get_lane_vehicle_count()}
 
 
-def dump(which, cfg, steps):
+def dump(which, cfg, steps, load=None, save=None):
+    """load: an Archive JSON to start from (load_from_file); save: where to Archive.dump the state after `steps` steps"""
     if which == "ref":
         sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
         import cityflow_ref
@@ -35,8 +36,12 @@ def dump(which, cfg, steps):
         from conftest import TWIN_LIB
         from cityflow_amd import _cityflow
         eng = _cityflow.Engine._with_backend(cfg, 1, TWIN_LIB)
+    if load:
+        eng.load_from_file(load)
     for _ in range(steps):
         eng.next_step()
+    if save:
+        eng.snapshot().dump(save)
     print(json.dumps(state(eng)))
     time.sleep(0.1)  # the reference's worker threads must be parked before the engine goes away
 
@@ -48,10 +53,11 @@ def reference_env():
             "CFX_VEHICLE_SIZE": open(os.path.join(ref_dir, "vehicle_size.txt")).read().strip()}
 
 
-def run(which, cfg, steps, env=None):
+def run(which, cfg, steps, env=None, load=None, save=None):
     if which == "ref" and env is None:
         env = reference_env()
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", which, cfg, str(steps)], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", which, cfg, str(steps), load or "-", save or "-"],
+                         capture_output=True,
                          text=True, timeout=1800, env=dict(os.environ, **(env or {})))
     if out.returncode != 0:
         raise RuntimeError(out.stderr[-2000:])
@@ -79,7 +85,8 @@ def compare(a, b):
 
 if __name__ == "__main__":
     if sys.argv[1] == "--dump":
-        dump(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+        opt = [None if a == "-" else a for a in sys.argv[5:7]] + [None, None]
+        dump(sys.argv[2], sys.argv[3], int(sys.argv[4]), load=opt[0], save=opt[1])
         sys.exit(0)
     cfg = lane_change_config(sys.argv[1], "/tmp/cfa_lc_parity")
     for H in [int(x) for x in sys.argv[2:]]:
