@@ -66,7 +66,10 @@ struct SlotArrays {
 // Lane change (reference src/vehicle/lanechange.{h,cpp}, vehicle.h:74-79): per-vehicle state, sparse and rarely
 // touched, so it lives in tables indexed by vid and the slot arrays / the compaction stay as they are.  `on == 0`
 // unless the engine was created with cfx_config::lane_change.
-constexpr int kLcRoadCand = 64;  // candidates per road kept in its list (more: the walk scans the road)
+#ifndef CFX_LC_ROAD_CAND
+#define CFX_LC_ROAD_CAND 64
+#endif
+constexpr int kLcRoadCand = CFX_LC_ROAD_CAND;  // candidates per road kept in its list (more: the walk scans the road)
 struct LcInsert {  // one shadow created in this step (Engine::insertShadow engine.cpp:812-820)
     int32_t parentVid, parentSlot, lane, recvFrom;  // recvFrom: signal the shadow received later in the same walk
     double dis;
