@@ -345,3 +345,28 @@ def test_archive_json_with_lane_change_both_directions(scen, workdir):
         assert any(v.get("partnerType") == 2 for v in json.load(open(path))["vehicles"])
         r, t = lcp.run("ref", cfg, 70, load=path), lcp.run("twin", cfg, 70, load=path)
         assert lcp.compare(r, t) == [], writer
+
+
+def test_lane_change_with_control_calls_reference_vs_twin(scen, workdir):
+    """laneChange with the control API on both sides: RL-set signal phases, push_vehicle with an initial speed,
+    set_vehicle_speed on the real vehicles of changing pairs (the shadow copies the pending custom speed), half-second
+    steps, another seed."""
+    if not os.path.exists(os.path.join(REF_DIR, "libmonotonic_new.so")):
+        pytest.skip("oracle/_ref reference build not present")
+    veh = {"length": 5.0, "width": 2.0, "maxPosAcc": 2.0, "maxNegAcc": 4.5, "usualPosAcc": 2.0, "usualNegAcc": 4.5,
+           "minGap": 2.5, "maxSpeed": 16.67, "headwayTime": 1.5, "speed": 3.0}
+    script = {}
+    for s in range(0, 200, 15):
+        script.setdefault(str(s), []).append(["set_tl_phase", "intersection_1_1", (s // 15) % 8])
+    for s in (20, 21, 90):
+        script.setdefault(str(s), []).append(["push_vehicle", veh, ["road_0_1_0", "road_1_1_0"]])
+    for s in range(10, 200, 7):
+        script.setdefault(str(s), []).append(["slow_changing", 3, 4.0])
+    for kw in ({"rlTrafficLight": True}, {"interval": 0.5, "seed": 7}):
+        cfg = scen.materialize("example_1x1", workdir, laneChange=True, **kw)
+        calls = script if kw.get("rlTrafficLight") else {k: [c for c in v if c[0] != "set_tl_phase"] for k, v in script.items()}
+        env = {"CFX_LC_SCRIPT": json.dumps(calls)}
+        r = lcp.run("ref", cfg, 200, env=dict(lcp.reference_env(), **env))
+        t = lcp.run("twin", cfg, 200, env=env)
+        assert lcp.compare(r, t) == [], kw
+        assert r["count"] > 100

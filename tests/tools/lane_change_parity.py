@@ -38,7 +38,16 @@ def dump(which, cfg, steps, load=None, save=None):
         eng = _cityflow.Engine._with_backend(cfg, 1, TWIN_LIB)
     if load:
         eng.load_from_file(load)
-    for _ in range(steps):
+    script = json.loads(os.environ.get("CFX_LC_SCRIPT", "{}"))  # {"<step>": [[method, args...], ...]}: control calls before a step
+    for s in range(steps):
+        for call in script.get(str(s), []):
+            if call[0] == "slow_changing":  # set_vehicle_speed on the real vehicles of the first changing pairs
+                lanes = eng.get_lane_vehicles()
+                ids = sorted(v[:-len("_shadow")] for lane in lanes.values() for v in lane if v.endswith("_shadow"))[:call[1]]
+                for vid in ids:
+                    eng.set_vehicle_speed(vid, call[2])
+            else:
+                getattr(eng, call[0])(*call[1:])
         eng.next_step()
     if save:
         eng.snapshot().dump(save)
