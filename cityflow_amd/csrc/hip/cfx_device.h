@@ -160,6 +160,28 @@ __device__ __forceinline__ int d2i(double x) {
     return (int) x;
 }
 
+// New vehicle numbers start clean (LaneChange ctor lanechange.h:50, LaneChangeInfo vehicle.h:74-79)
+__device__ __forceinline__ void lcInitVid(const LcDev &lc, int v) {
+    lc.ptype[v] = 0;
+    lc.partner[v] = -1;
+    lc.offset[v] = 0.0;
+    lc.sigSend[v] = 0;
+    lc.sendDir[v] = 0;
+    lc.sendUrg[v] = 0;
+    lc.lastDir[v] = 0;
+    lc.changing[v] = 0;
+    lc.lcFinished[v] = 0;
+    lc.sendTarget[v] = -1;
+    lc.recvFrom[v] = -1;
+    lc.tLeader[v] = -1;
+    lc.tFollower[v] = -1;
+    lc.leaderGap[v] = 0.0;
+    lc.followerGap[v] = 0.0;
+    lc.lastChangeTime[v] = 0.0;
+    lc.gap[v] = 0.0;
+    lc.slotOf[v] = -1;
+}
+
 // Vehicles on drivable d as phases 3/4 see them.  cnt[] is the committed count; a lane's admission of THIS step
 // (Engine::handleWaiting, phase 2) is not folded into it until the compaction (k_scan) — it is the flag
 // admitStep[lane] == step plus the vehicle written into the lane's spare slot — so that nothing phase 2 writes is

@@ -381,6 +381,8 @@ struct cfx_engine {
             HIP_TRY(hipMemsetAsync(lc.insHead, 0xFF, (size_t) std::max(L, 1) * sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.parkCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.fixCount, 0, sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.insCount, 0, sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.candAllCount, 0, sizeof(int32_t), stream));
         }
         laneQueued.assign((size_t) L, 0);
         nQueueLanes = 0;
@@ -683,7 +685,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         memcpy(e->hStage[si], recs, (size_t) n * sizeof(cfx_spawn));
         // the kernel reads the pinned (device-visible) staging buffer itself: no separate copy launch
         e->launch(PK_SPAWN, k_spawn_link, dim3(gridFor(n)), dim3(kBlock), (const cfx_spawn *) e->hStage[si], (int) n,
-                  (int) e->spawned, e->vt, e->waitHead);
+                  (int) e->spawned, e->vt, e->waitHead, e->lc);
         HIP_TRY(hipEventRecord(e->stageEvent[si], st));
         e->stageBusy[si] = true;
         e->spawned += n;
@@ -747,9 +749,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         hipError_t er = hipStreamSynchronize(st);                                                          \
         if (er != hipSuccess) return e->fail(std::string("lane change: ") + name + ": " + hipGetErrorString(er)); \
     }
-        if (n > 0) hipLaunchKernelGGL(k_lc_init, dim3(gridFor(n)), dim3(kBlock), 0, st, e->lc, (int) (e->spawned - n), (int) n);
-        HIP_TRY(hipMemsetAsync(e->lc.insCount, 0, sizeof(int32_t), st));
-        HIP_TRY(hipMemsetAsync(e->lc.candAllCount, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_lc_segments, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c);
         hipLaunchKernelGGL(k_lc_plan, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         LC_CHECK("k_lc_plan")
@@ -764,15 +763,14 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         hipLaunchKernelGGL(k_lc_width, dim3(gridFor(e->D + 1)), dim3(kBlock), 0, st, c, e->waitHead, e->vt, e->sc, e->net.laneSpare,
                            e->lcWidth, e->cnt[mid].p);
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(e->scanTemp, e->scanTempBytes, e->lcWidth, e->segStart[mid].p, e->D + 1, st));
-        hipLaunchKernelGGL(k_lc_fill, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c, (const int32_t *) e->segStart[mid].p,
-                           (const int32_t *) e->cnt[mid].p, e->gen[mid].vid, e->gen[mid].drv);
-        LC_CHECK("k_lc_width/scan/fill")
+        LC_CHECK("k_lc_width/scan")
         hipLaunchKernelGGL(k_lc_move, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->gen[mid],
                            (const int32_t *) e->segStart[mid].p, e->oldToNew2);
         LC_CHECK("k_lc_move")
         hipLaunchKernelGGL(k_lc_compose, dim3(gridFor(std::max<size_t>(e->slotCap, (size_t) e->L))), dim3(kBlock), 0, st, e->oldToNew,
                            (const int32_t *) e->oldToNew2, (int) e->slotCap, e->admitStep, e->lc.insHead, (int) e->L, (int) e->step,
-                           (const int32_t *) e->segStart[e->cur].p, (int) e->D);
+                           (const int32_t *) e->segStart[e->cur].p, (int) e->D, (const int32_t *) e->segStart[mid].p,
+                           (const int32_t *) e->cnt[mid].p, e->gen[mid].vid, e->gen[mid].drv, e->laneTail);
         LC_CHECK("k_lc_compose")
         HIP_TRY(hipGetLastError());
         e->cur = mid;

@@ -87,10 +87,11 @@ struct ActionBuf {
 };
 
 // ----------------------------------------------------------------------------------------------
-__global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidTable vt, int32_t *waitHead) {
+__global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidTable vt, int32_t *waitHead, LcDev lc) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     cfx_spawn r = recs[i];
+    if (lc.on) lcInitVid(lc, r.vid);
     vt.priority[r.vid] = r.priority;
     vt.templ[r.vid] = r.templ;
     vt.route[r.vid] = r.route;

@@ -6,7 +6,7 @@
 //   k_lc_order      the position of every candidate in the reference's walk (creation order put through std::sort)
 //   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in that order
 //   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in creation order
-//   k_lc_width, scan, k_lc_fill, k_lc_move, k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
+//   k_lc_width, scan, k_lc_move, k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
 //   k_action, k_cross                         as always; a changing pair parks its two next speeds
 //   k_lc_resolve    the vehicles whose step depends on an earlier vehicle of the reference's walk: changing pairs (common
 //                   speed, lateral offset, finish / abort, engine.cpp:195-205,223-244) and vehicles they signalled
@@ -66,31 +66,6 @@ __device__ inline double lcEstimateGap(const StepCtx &c, int lane, double dis, i
     if (k < 0) return c.n.drvLength[lane] - dis;
     const int ls = c.segStart[lane] + k;
     return c.s.dis[ls] - dis - c.t.templ[c.s.templ[ls]].len;
-}
-
-// New vehicle numbers start clean (LaneChange ctor lanechange.h:50, LaneChangeInfo vehicle.h:74-79)
-__global__ void k_lc_init(LcDev lc, int first, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int v = first + i;
-    lc.ptype[v] = 0;
-    lc.partner[v] = -1;
-    lc.offset[v] = 0.0;
-    lc.sigSend[v] = 0;
-    lc.sendDir[v] = 0;
-    lc.sendUrg[v] = 0;
-    lc.lastDir[v] = 0;
-    lc.changing[v] = 0;
-    lc.lcFinished[v] = 0;
-    lc.sendTarget[v] = -1;
-    lc.recvFrom[v] = -1;
-    lc.tLeader[v] = -1;
-    lc.tFollower[v] = -1;
-    lc.leaderGap[v] = 0.0;
-    lc.followerGap[v] = 0.0;
-    lc.lastChangeTime[v] = 0.0;
-    lc.gap[v] = 0.0;
-    lc.slotOf[v] = -1;
 }
 
 // threadPlanLaneChange engine.cpp:374-390 + SimpleLaneChange::makeSignal lanechange.cpp:151-184, one thread per slot.
@@ -507,7 +482,7 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
 }
 
 // New layout after the walk: per lane its vehicles (this step's admission committed: the FIFO pop, the vehicle's state,
-// the running count) plus its shadows.  k_lc_width -> exclusive scan (hipcub) -> k_lc_fill.
+// the running count) plus its shadows.  k_lc_width -> exclusive scan (hipcub); spare slots and lane tails: k_lc_compose.
 __global__ void k_lc_width(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars *sc, const uint8_t *laneSpare, int32_t *width,
                            int32_t *cntNext) {
     const LcDev &lc = c.lc;
@@ -532,17 +507,6 @@ __global__ void k_lc_width(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars
     }
     cntNext[d] = live;
     width[d] = live + spare;
-}
-
-__global__ void k_lc_fill(StepCtx c, const int32_t *segStartNext, const int32_t *cntNext, int32_t *vidNext, int32_t *drvNext) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= c.n.L) return;  // laneLinks have no spare slots
-    const int start = segStartNext[d], live = cntNext[d], end = segStartNext[d + 1];
-    for (int j = start + live; j < end; ++j) {
-        vidNext[j] = -1;
-        drvNext[j] = -1;
-    }
-    c.laneTail[d] = live > 0 ? start + live - 1 : -1;
 }
 
 // Every vehicle to its place in the new layout; shadows are written from their parents (Vehicle copy constructor +
@@ -613,14 +577,22 @@ __global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext,
 
 // oldToNew maps slots of the previous generation to the current one (stored blockers go through it); the current one just
 // moved
+// ... and per lane: the spare slots and the tail of the new layout; nothing is pending any more
 __global__ void k_lc_compose(int32_t *oldToNew, const int32_t *oldToNew2, int n, int32_t *admitStep, int32_t *insHead, int L,
-                             int step, const int32_t *segStartBefore, int D) {
+                             int step, const int32_t *segStartBefore, int D, const int32_t *segStartNext,
+                             const int32_t *cntNext, int32_t *vidNext, int32_t *drvNext, int32_t *laneTail) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int S = segStartBefore[D];  // slots of the layout that just moved; oldToNew beyond the previous generation's
                                       // slots is never written (and never read through a stored blocker): leave it alone
-    if (i < L) {  // the rebuilt order contains this step's admissions and shadows: nothing is pending any more
-        if (admitStep[i] == step) admitStep[i] = -1;
+    if (i < L) {
+        if (admitStep[i] == step) admitStep[i] = -1;  // the rebuilt order contains this step's admissions and shadows
         insHead[i] = -1;
+        const int start = segStartNext[i], live = cntNext[i], end = segStartNext[i + 1];
+        for (int j = start + live; j < end; ++j) {
+            vidNext[j] = -1;
+            drvNext[j] = -1;
+        }
+        laneTail[i] = live > 0 ? start + live - 1 : -1;
     }
     if (i >= n) return;
     const int v = oldToNew[i];
@@ -746,6 +718,10 @@ __global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capac
 // where it now is
 __global__ void k_lc_clear(LcDev lc, const int32_t *vidNew, const int32_t *segStartNew, int D) {
     const int S = segStartNew[D];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the step's lists are consumed
+        *lc.insCount = 0;
+        *lc.candAllCount = 0;
+    }
     const int stride = gridDim.x * blockDim.x;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
         const int v = vidNew[s];
