@@ -20,7 +20,7 @@ def main():
     name, steps = sys.argv[1], int(sys.argv[2])
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     lane_change = os.environ.get("CFX_DEV_LANE_CHANGE") == "1"  # laneChange=true: lane-change columns compared too
-    if name.endswith(".json"):  # an explicit config file
+    if name.endswith(".json") or name.startswith("gen_"):  # an explicit config file / a generated grid (bench flows below)
         cfg = name
     else:
         cfg = scenarios.materialize(name, "/tmp/cfa_dev", **({"laneChange": True} if lane_change else {}))
