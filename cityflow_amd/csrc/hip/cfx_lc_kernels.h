@@ -5,7 +5,7 @@
 //   k_lc_plan       Lane::initSegments + threadPlanLaneChange: every real vehicle makes its signal
 //   k_lc_order      the position of every candidate in the reference's walk (creation order put through std::sort)
 //   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in that order
-//   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in creation order
+//   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in walk order
 //   k_lc_width, scan, k_lc_move, k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
 //   k_action, k_cross                         as always; a changing pair parks its two next speeds
 //   k_lc_resolve    the vehicles whose step depends on an earlier vehicle of the reference's walk: changing pairs (common
@@ -177,9 +177,9 @@ struct LcNeighbour {
     double dis, len, speed, maxNegAcc;
 };
 
-// Engine::scheduleLaneChange engine.cpp:792-810 for ONE road: its candidates in creation order (ascending vid — the ABI's
-// order, include/cityflow_amd.h).  Roads are independent in this phase: a target lane is on the candidate's own road, and
-// the laneLinks the leader search looks into do not change.
+// Engine::scheduleLaneChange engine.cpp:792-810 for ONE road: its candidates in the order of the reference's walk
+// (k_lc_order; include/cityflow_amd.h "Lane change").  Roads are independent in this phase: a target lane is on the
+// candidate's own road, and the laneLinks the leader search looks into do not change.
 __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriority) {
     const int road = blockIdx.x * blockDim.x + threadIdx.x;
     if (road >= c.n.R) return;
@@ -192,7 +192,7 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
     const int s0 = c.segStart[l0], s1 = c.segStart[l1 - 1] + cntNow(c, l1 - 1);
     int localRec[kLcRoadInserts];  // global record indices of this road's shadows so far
     int nLocal = 0;
-    // the road's candidates, ascending vid (threadPlanLaneChange's buffer; the walk never creates new ones)
+    // the road's candidates in walk order (threadPlanLaneChange's buffer after the sort; the walk never creates new ones)
     constexpr int kCand = kLcRoadCand;
     int candVid[kCand], candSlot[kCand], candKey[kCand];
     int nCand = 0;
