@@ -11,7 +11,7 @@ from conftest import ROOT, TWIN_LIB, free_port
 def test_bench_two_ranks_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "30",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "30", "--build-up-steps", "0",
            "--cpu-seconds", "0", "--scenario", "grid_6x6", "--extra-flows", "50", "--dist-backend", "gloo",
            "--backend-lib", TWIN_LIB, "--replicas"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -30,7 +30,7 @@ def test_bench_two_ranks_tiled_gloo(tmp_path):
     """The default N>1 mode: one network (3x6 here) tiled 1x2, one tile per rank, halo exchanged every step."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "120",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20", "--build-up-steps", "100",
            "--cpu-seconds", "0", "--tile-block", "3", "--extra-flows", "40", "--dist-backend", "gloo",
            "--backend-lib", TWIN_LIB]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -49,9 +49,10 @@ def test_bench_two_ranks_tiled_gloo(tmp_path):
 
 def test_bench_single_rank_twin(tmp_path):
     env = dict(os.environ, TMPDIR=str(tmp_path))
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "10", "--cpu-seconds", "0",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "10", "--build-up-steps", "20", "--cpu-seconds", "0",
            "--scenario", "grid_6x6", "--extra-flows", "20", "--backend-lib", TWIN_LIB]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["roofline"] is None and d["cpu_baseline"] is None
+    assert d["warmup"] == 10 and "20 simulated seconds" in d["config"]["state"]  # the workload state does not depend on --warmup
