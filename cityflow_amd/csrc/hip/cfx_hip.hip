@@ -455,6 +455,9 @@ void cfx_destroy(cfx_engine *e) {
     if (e->hMirror) (void) hipHostFree(e->hMirror);
     if (e->hHaloSend) (void) hipHostFree(e->hHaloSend);
     if (e->hHaloRecv) (void) hipHostFree(e->hHaloRecv);
+    if (e->hPool) (void) hipHostFree(e->hPool);
+    if (e->hPoll) (void) hipHostFree(e->hPoll);
+    if (e->pollEvent) (void) hipEventDestroy(e->pollEvent);
     if (e->stream) (void) hipStreamDestroy(e->stream);
     delete e;
 }
