@@ -204,6 +204,36 @@ std::string Spawner::vehicleId(int vid, bool shadow) const {
 }
 
 void Spawner::peekShadowPriorities(int n, std::vector<int32_t> &out) {
+    // Fast path (practically always): n plain draws, none of which meets a live priority or repeats — then entry i is draw
+    // i.  Anything else goes through the exact loop below.
+    {
+        std::mt19937 peek = rnd;
+        peekPriorities_.resize((size_t) n);
+        for (int i = 0; i < n; ++i) {
+            peekPriorities_[(size_t) i] = (int32_t) peek();
+            livePriority_.prefetch(peekPriorities_[(size_t) i]);
+        }
+        bool clean = true;
+        for (int i = 0; i < n && clean; ++i) clean = livePriority_.find(peekPriorities_[(size_t) i]) == nullptr;
+        if (clean) {  // no value twice: a small open-addressing table (entries are value + 2^32, empty = -1)
+            size_t cap = 64;
+            while (cap < (size_t) n * 4) cap <<= 1;
+            peekTable_.assign(cap, -1);
+            for (int i = 0; i < n && clean; ++i) {
+                const int64_t key = (int64_t) peekPriorities_[(size_t) i] + (1LL << 32);
+                size_t h = ((uint64_t) key * 0x9E3779B97F4A7C15ULL) >> 20 & (cap - 1);
+                while (peekTable_[h] != -1 && peekTable_[h] != key) h = (h + 1) & (cap - 1);
+                clean = peekTable_[h] == -1;
+                peekTable_[h] = key;
+            }
+        }
+        if (clean) {
+            peekDraws_.resize((size_t) n);
+            for (int i = 0; i < n; ++i) peekDraws_[(size_t) i] = i + 1;
+            out = peekPriorities_;
+            return;
+        }
+    }
     std::mt19937 peek = rnd;
     peekPriorities_.clear();
     peekDraws_.clear();

@@ -160,6 +160,7 @@ private:
     FlatMapI32 livePriority_;  // priority -> vid (superset of live vehicles; -1 while in planRouteBuffer)
     std::vector<int32_t> activeFlows_;  // flows that may still spawn, ascending (Flow::nextStep early returns)
     std::vector<int32_t> peekPriorities_, peekDraws_;  // last peekShadowPriorities: values, cumulative raw draws
+    std::vector<int64_t> peekTable_;  // scratch of peekShadowPriorities
     std::unordered_map<int32_t, std::vector<int32_t>> shadowChains_;  // root vid -> shadows carrying its id
     std::map<std::vector<int>, int> routeIndex_;          // expanded road sequence -> route index
 };
