@@ -470,9 +470,9 @@ void EngineHost::loadFromFile(const std::string &path) {
     const int nV = (int) a.host.vehicles.size();
     for (auto &sb : shadowBase) {  // the id a shadow carries belongs to the vehicle named so (its parent or an ancestor's heir)
         auto it = vidOf.find(sb.second);
-        const int root = it == vidOf.end() ? sb.first : it->second;
-        a.host.vehicles[(size_t) sb.first].root = root;
-        a.host.shadowChains[root].push_back(sb.first);
+        const int holder = it == vidOf.end() ? sb.first : it->second;
+        a.host.vehicles[(size_t) sb.first].root = holder;
+        a.host.shadowChains[holder].push_back(sb.first);
     }
     d.vState.assign(nV, 0);
     const Json &drivables = root.objectAt("drivables");
