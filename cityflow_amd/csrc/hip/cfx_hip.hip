@@ -148,7 +148,7 @@ struct cfx_engine {
     size_t scanTempBytes = 0;
     int32_t *dPool = nullptr;          // priorities of the step's shadows (device)
     int32_t *hPool = nullptr;          // ... pinned staging
-    int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1..] their parents in creation order
+    int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1] overflow code, [2..] their parents in walk order
     hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
     int poolN = 0;                     // priorities supplied for the next / current step
     bool pollPending = false;          // a lane-change step has run and was not polled yet
@@ -1183,7 +1183,7 @@ int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *prioriti
         if (e->hPool) HIP_TRY(hipHostFree(e->hPool));
         if (e->hPoll) HIP_TRY(hipHostFree(e->hPoll));
         HIP_TRY(hipHostMalloc((void **) &e->hPool, cap * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **) &e->hPoll, (cap + 1) * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **) &e->hPoll, (cap + 2) * sizeof(int32_t), hipHostMallocDefault));
         e->lc.insCap = (int) cap;
     }
     // (the previous step was polled, so the device is done with the pinned staging buffer)
@@ -1203,6 +1203,11 @@ int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vi
     HIP_TRY(hipEventSynchronize(e->pollEvent));  // plan + schedule + assign of the step; the rest keeps running
     e->pollPending = false;
     const int k = e->hPoll[0];
+    if (e->hPoll[1] == 6) {
+        e->err = "lane change: a capacity of the schedule walk was exceeded (shadows per road / members of a segment / "
+                 "provisional neighbours in one step)";
+        return CFX_ERR_CAPACITY;
+    }
     if (k > e->poolN) {
         e->err = "lane change: more shadows in one step than priorities supplied (cfx_lane_change_supply)";
         return CFX_ERR_CAPACITY;
@@ -1211,7 +1216,7 @@ int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vi
         e->err = "cfx_lane_change_poll: capacity too small";
         return CFX_ERR_CAPACITY;
     }
-    for (int i = 0; i < k; ++i) parent_vid[i] = e->hPoll[1 + i];
+    for (int i = 0; i < k; ++i) parent_vid[i] = e->hPoll[2 + i];
     *n = k;
     e->spawned += k;  // shadows are vehicles: the next step's spawn records are numbered after them
     e->spawnedHere += k;

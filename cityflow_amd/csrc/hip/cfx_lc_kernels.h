@@ -418,7 +418,8 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
 
 // Engine::insertShadow engine.cpp:812-820 + the Vehicle copy constructor vehicle.cpp:28-36 for every shadow of the step:
 // vehicle numbers and the supplied priorities go out in creation order = ascending parent vid.  One block.
-__global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pollOut /*pinned: [0] count, [1..] parents*/) {
+__global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc,
+                            int32_t *pollOut /*pinned: [0] count, [1] overflow code of the walk, [2..] parents*/) {
     const LcDev &lc = c.lc;
     int n = *lc.insCount;
     if (n > lc.insCap) n = lc.insCap;
@@ -458,7 +459,7 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
         lc.slotOf[v] = -1;
         lc.ptype[p] = 1;  // setShadow
         lc.partner[p] = v;
-        pollOut[1 + rank] = p;
+        pollOut[2 + rank] = p;
     }
     __syncthreads();
     // shadows named provisionally (-(record + 2)) in the walk get their numbers
@@ -477,6 +478,7 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc, int32_t *pol
     if (threadIdx.x == 0) {
         sc->active += n;  // activeVehicleCount++ per shadow
         pollOut[0] = *lc.insCount;  // > insCap tells the host the supply was too small
+        pollOut[1] = sc->overflow;  // a capacity of the schedule walk was exceeded: the step is not valid
         __threadfence_system();
     }
 }
