@@ -205,8 +205,9 @@ std::string Spawner::vehicleId(int vid, bool shadow) const {
 
 void Spawner::peekShadowPriorities(int n, std::vector<int32_t> &out) {
     // Fast path (practically always): n plain draws, none of which meets a live priority or repeats — then entry i is draw
-    // i.  Anything else goes through the exact loop below.
-    {
+    // i.  Anything else goes through the exact loop below (CFX_LC_PEEK_EXACT=1 forces it: the tests compare the two).
+    static const bool exactOnly = getenv("CFX_LC_PEEK_EXACT") != nullptr;
+    if (!exactOnly) {
         std::mt19937 peek = rnd;
         peekPriorities_.resize((size_t) n);
         for (int i = 0; i < n; ++i) {
