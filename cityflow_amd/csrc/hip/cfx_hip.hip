@@ -471,7 +471,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->cfg = *cfg;
-    if (const char *v = getenv("CFX_CROSS2")) e->cross2 = v[0] == '1' ? 1 : 0;
+    e->cross2 = cfg->cross_mode == CFX_CROSS_THROUGHPUT ? 1 : cfg->cross_mode == CFX_CROSS_LATENCY ? 0 : -1;
     e->R = n->n_roads;
     e->L = n->n_lanes;
     e->K = n->n_lanelinks;
@@ -746,7 +746,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
         // with the step's shadows in place (cfx_lc_kernels.h)
         const int mid = e->cur ^ 1;
-        static const bool dbgSync = getenv("CFX_LC_DEBUG_SYNC") != nullptr;  // developer aid: name the kernel that faults
+        const bool dbgSync = e->cfg.debug_sync != 0;  // developer aid: name the kernel that faults
 #define LC_CHECK(name)                                                                                     \
     if (dbgSync) {                                                                                         \
         hipError_t er = hipStreamSynchronize(st);                                                          \

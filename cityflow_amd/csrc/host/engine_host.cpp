@@ -91,10 +91,44 @@ EngineConfig readEngineConfig(const std::string &configFile) {
         c.roadnetFile = cfg.stringAt("roadnetFile");
         c.flowFile = cfg.stringAt("flowFile");
         c.saveReplay = cfg.boolAt("saveReplay");
+        if (const Json *x = cfg.find("cfx")) {
+            if (!x->isObject()) throw JsonError("cfx: expected an object");
+            auto choice = [x](const char *key, std::initializer_list<const char *> names) {
+                const Json *v = x->find(key);
+                if (!v) return 0;
+                if (!v->isString()) throw JsonError(std::string("cfx.") + key + ": expected a string");
+                int i = 0;
+                for (const char *n : names) {
+                    if (v->s == n) return i;
+                    ++i;
+                }
+                throw JsonError(std::string("cfx.") + key + ": unknown value '" + v->s + "'");
+            };
+            c.crossMode = choice("crossMode", {"auto", "latency", "throughput"});
+            c.layout = choice("layout", {"auto", "dense", "ring"});
+            c.debugSync = x->boolAt("debugSync", false) ? 1 : 0;
+            if (x->find("device")) c.device = x->intAt("device");
+            c.exactShadowPeek = x->boolAt("exactShadowPeek", false);
+            if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
+        }
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
     return c;
+}
+
+void EngineConfig::apply(cfx_config &cc) const {
+    cc.interval = interval;
+    cc.rl_traffic_light = rlTrafficLight ? 1 : 0;
+    cc.lane_change = laneChange ? 1 : 0;
+    cc.cross_mode = crossMode;
+    cc.layout = layout;
+    cc.debug_sync = debugSync;
+    cc.device = 0;
+    // one process per GPU under torch.distributed.run: the launcher's LOCAL_RANK names the device
+    if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);
+    if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) cc.device = atoi(dev);
+    if (device >= 0) cc.device = device;
 }
 
 // ---------------------------------------------------------------- construction
@@ -125,18 +159,14 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
             replay_.open(dir_ + replayLogFile);
         }
         spawner_.init(net_.get(), interval_, threadNum_, seed_);
+        spawner_.exactPeekOnly = readEngineConfig(configFile).exactShadowPeek;
         spawner_.loadFlows(dir_ + flowFile);
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
     cfx_config cc{};
-    cc.interval = interval_;
-    cc.rl_traffic_light = rlTrafficLight_ ? 1 : 0;
-    cc.lane_change = laneChange_ ? 1 : 0;
-    cc.device = 0;
-    if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);
-    if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) cc.device = atoi(dev);
+    readEngineConfig(configFile).apply(cc);
     int32_t rc = be_.cfx_create(&net_->flat(), &cc, &dev_);
     if (rc != CFX_OK || !dev_) {
         const char *msg = be_.cfx_last_error(nullptr);

@@ -105,6 +105,7 @@ public:
     //      (engine.cpp:812-820, vehicle.cpp:28-36)
     // The priorities the next n shadows WOULD get, from a copy of the generator (collisions with live vehicles redrawn).
     void peekShadowPriorities(int n, std::vector<int32_t> &out);
+    bool exactPeekOnly = false;  // always take the exact redraw loop (test hook, config "cfx": {"exactShadowPeek": true})
     // The device created shadows of `parents` (in this order) with the first priorities of the last peek: advance the
     // generator past those draws and give the shadows their vehicle numbers.
     void commitShadows(const std::vector<int32_t> &parents);

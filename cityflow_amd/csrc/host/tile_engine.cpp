@@ -283,8 +283,8 @@ TileEngine::TileEngine(std::shared_ptr<HostRoadNet> net, const std::vector<int> 
     : net_(std::move(net)), be_(be) {
     tn_.build(*net_, owner, rank);
     cfx_config cc{};
-    cc.interval = cfg.interval;
-    cc.rl_traffic_light = cfg.rlTrafficLight ? 1 : 0;
+    cfg.apply(cc);
+    cc.lane_change = 0;
     cc.device = device;
     int32_t rc = be_->cfx_create(&tn_.flat, &cc, &dev_);
     if (rc != CFX_OK || !dev_) {
@@ -535,9 +535,9 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         std::iota(localRanks_.begin(), localRanks_.end(), 0);
     }
     allLocal_ = (int) localRanks_.size() == nTiles_;
-    int baseDevice = 0;
-    if (const char *dev = getenv("LOCAL_RANK")) baseDevice = atoi(dev);
-    if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) baseDevice = atoi(dev);
+    cfx_config probe{};
+    cfg_.apply(probe);
+    const int baseDevice = probe.device;
     for (size_t i = 0; i < localRanks_.size(); ++i) {
         if (localRanks_[i] < 0 || localRanks_[i] >= nTiles_) throw std::runtime_error("tiling: local tile out of range");
         // several local tiles spread over the visible devices (the engine takes device % device count)

@@ -115,6 +115,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     if (cfg.laneChange) throw std::runtime_error("VectorEngine: laneChange=true is not implemented for batched environments (single Engine only)");
     interval_ = cfg.interval;
     rlTrafficLight_ = cfg.rlTrafficLight;
+    hostThreads_ = cfg.hostThreads;
     try {
         net_->load(cfg.dir + cfg.roadnetFile);
         for (int r = 0; r < R_; ++r) {
@@ -134,11 +135,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     rn.build(net_->flat(), R_);
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
     cfx_config cc{};
-    cc.interval = interval_;
-    cc.rl_traffic_light = rlTrafficLight_ ? 1 : 0;
-    cc.device = 0;
-    if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);
-    if (const char *dev = getenv("CITYFLOW_AMD_DEVICE")) cc.device = atoi(dev);
+    cfg.apply(cc);
     int32_t rc = be_.cfx_create(&rn.flat, &cc, &dev_);
     if (rc != CFX_OK || !dev_) {
         const char *msg = be_.cfx_last_error(nullptr);
@@ -220,17 +217,14 @@ void VectorEngineHost::workerLoop() {
 }
 
 void VectorEngineHost::forEachEnv(void (VectorEngineHost::*fn)(int)) {
-    static const bool serial = [] {
-        const char *v = getenv("CFX_VEC_THREADS");
-        return v && v[0] == '0';
-    }();
-    if (R_ < 32 || serial) {  // a handful of environments: waking threads costs more than it saves
+    if (R_ < 32 || hostThreads_ == 0) {  // a handful of environments: waking threads costs more than it saves
         for (int r = 0; r < R_; ++r) (this->*fn)(r);
         return;
     }
     if (workers_.empty()) {
         unsigned hw = std::thread::hardware_concurrency();
         int n = (int) std::min<unsigned>(std::min<unsigned>(hw > 2 ? hw / 2 : 1, 16u), (unsigned) R_ / 8);
+        if (hostThreads_ > 0) n = std::min(hostThreads_, R_);
         for (int i = 0; i + 1 < n; ++i) workers_.emplace_back([this] { workerLoop(); });
     }
     poolFn_ = fn;

@@ -60,6 +60,7 @@ private:
     Backend be_;
     cfx_engine *dev_ = nullptr;
     int R_ = 1, L_ = 0, K_ = 0, I_ = 0, routesPerEnv_ = 0;
+    int hostThreads_ = -1;  // config "cfx": {"hostThreads": n}: -1 auto, 0 serial
     double interval_ = 1.0;
     bool rlTrafficLight_ = false;
     size_t step_ = 0;

@@ -69,7 +69,12 @@ def materialize(name, workdir=None, flow_file=None, **config):
         "rlTrafficLight": False, "laneChange": False, "saveReplay": False,
     }
     cfg.update(config)
-    tag = "_".join("%s-%s" % (k, config[k]) for k in sorted(config)) if config else "default"
+    def _val(v):  # nested values ("cfx": {...}) become key=value lists; nothing but [A-Za-z0-9_.=-] reaches the file name
+        if isinstance(v, dict):
+            return ".".join("%s=%s" % (k, _val(v[k])) for k in sorted(v))
+        return "".join(ch if (ch.isalnum() or ch in "._-") else "-" for ch in str(v))
+
+    tag = "_".join("%s-%s" % (k, _val(config[k])) for k in sorted(config)) if config else "default"
     path = os.path.join(d, "config_%s_%s.json" % (flow_name.replace(".json", ""), tag))
     with open(path, "w") as f:
         json.dump(cfg, f)
@@ -264,7 +269,12 @@ def generate_grid(rows, cols, workdir=None, flow_interval=1.0, **config):
     cfg = {"interval": 1.0, "seed": 0, "dir": d + "/", "roadnetFile": "roadnet.json", "flowFile": "flow.json",
            "rlTrafficLight": False, "laneChange": False, "saveReplay": False}
     cfg.update(config)
-    tag = "_".join("%s-%s" % (k, config[k]) for k in sorted(config)) if config else "default"
+    def _val(v):  # nested values ("cfx": {...}) become key=value lists; nothing but [A-Za-z0-9_.=-] reaches the file name
+        if isinstance(v, dict):
+            return ".".join("%s=%s" % (k, _val(v[k])) for k in sorted(v))
+        return "".join(ch if (ch.isalnum() or ch in "._-") else "-" for ch in str(v))
+
+    tag = "_".join("%s-%s" % (k, _val(config[k])) for k in sorted(config)) if config else "default"
     path = os.path.join(d, "config_flow_%s.json" % tag)
     _write_json_atomic(path, cfg)
     return path

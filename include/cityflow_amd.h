@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CFX_ABI_VERSION 2
+#define CFX_ABI_VERSION 3
 
 typedef enum cfx_status {
     CFX_OK = 0,
@@ -96,8 +96,19 @@ typedef struct cfx_config {
     int32_t rl_traffic_light; /* Engine::rlTrafficLight: lights advance only via cfx_set_tl_phase */
     int32_t lane_change;      /* Engine::laneChange (engine.cpp:53): see "Lane change" below */
     int32_t device;           /* HIP device ordinal (ignored by CPU implementations) */
-    int32_t reserved;
+    /* Implementation choices that never change results (all 0 = let the engine decide; CPU implementations ignore them).
+     * The host reads them from an optional "cfx" object of the config file, which the reference ignores. */
+    int32_t cross_mode;       /* cross walk: CFX_CROSS_AUTO by size, CFX_CROSS_LATENCY (k_cross), CFX_CROSS_THROUGHPUT (k_cross2) */
+    int32_t layout;           /* vehicle order in HBM: CFX_LAYOUT_AUTO, CFX_LAYOUT_DENSE (rebuilt every step),
+                               * CFX_LAYOUT_RING (per-drivable ring segments, committed in place; not with lane_change) */
+    int32_t debug_sync;       /* synchronise after every kernel of a step and name the one that faulted (developer aid) */
 } cfx_config;
+#define CFX_CROSS_AUTO 0
+#define CFX_CROSS_LATENCY 1
+#define CFX_CROSS_THROUGHPUT 2
+#define CFX_LAYOUT_AUTO 0
+#define CFX_LAYOUT_DENSE 1
+#define CFX_LAYOUT_RING 2
 
 /* VehicleInfo (reference src/vehicle/vehicle.h:31-45) + the two per-template constants derived from it. */
 typedef struct cfx_vehicle_template {

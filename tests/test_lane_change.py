@@ -376,6 +376,6 @@ def test_shadow_priority_peek_exact_loop(scen, workdir, lc_golden):
     """The host offers the step the priorities its generator would hand out next.  Normally that is n plain draws (fast
     path); a draw that meets a live priority or repeats sends it through the exact redraw loop of the Vehicle constructor
     (vehicle.cpp:33).  Forced through that loop, the run still reproduces the reference's vectors."""
-    cfg = scen.materialize("example_1x1", workdir, laneChange=True)
-    got = record(lcp.run("twin", cfg, 200, env={"CFX_LC_PEEK_EXACT": "1"}))
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True, cfx={"exactShadowPeek": True})
+    got = record(lcp.run("twin", cfg, 200))
     assert got == lc_golden["example_1x1"]["200"]

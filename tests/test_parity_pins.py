@@ -1,0 +1,126 @@
+"""GPU (-m gpu): oracle pins for the kernel variants and workloads the published numbers rest on.
+
+  * the benchmark workload itself (bench.build_workload: 30x30 + 3000 seeded flows, laneChange false — the
+    `k_action<false>` / `k_cross<false>` instantiations bench.py times), HIP == CPU twin on every vehicle field from
+    step 0 through the demand build-up and 100 steps beyond;
+  * every implementation choice of the engine that must not change results (config "cfx": crossMode latency /
+    throughput = k_cross / k_cross2, layout dense / ring), forced on networks where it would not be picked by size:
+    the 1x1 example (up to 118 crosses per laneLink), the congested 6x6, irregular networks, the bench workload;
+  * one HIP == twin checkpoint beyond 300 k vehicles (60x60) and one at BASELINE.json configs[4] size (100x100, ~1 M
+    vehicles): the state the HIP engine built up is injected into the twin through an Archive, both take the same steps.
+
+The twin is pinned to the unmodified reference (tests/test_oracle.py); reference semantics of the cross walk:
+/root/reference/src/roadnet/roadnet.cpp:603-676, of the step: src/engine/engine.cpp:566-594."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import TWIN_LIB, assert_same_state
+
+pytestmark = pytest.mark.gpu
+
+# every (crossMode, layout) the HIP engine can be forced into
+CHOICES = [("latency", "dense"), ("throughput", "dense"), ("latency", "ring"), ("throughput", "ring")]
+
+
+def _with_cfx(path, **cfx):
+    c = json.load(open(path))
+    c["cfx"] = cfx
+    out = path.replace(".json", "_" + "_".join("%s-%s" % kv for kv in sorted(cfx.items())) + ".json")
+    with open(out, "w") as f:
+        json.dump(c, f)
+    return out
+
+
+def _pair(mod, cfg, **cfx):
+    hip = mod.Engine(_with_cfx(cfg, **cfx) if cfx else cfg, 1)
+    assert hip.backend_name() == "hip-gfx950"
+    return hip, mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+
+
+def _bench_cfg(workdir):
+    import bench
+    return bench.build_workload(workdir, 0, scenario="grid_30x30")
+
+
+@pytest.mark.parametrize("cross,layout", [("auto", "auto"), ("throughput", "dense"), ("latency", "dense"), ("throughput", "ring")])
+def test_bench_workload_equals_twin_from_step_0(mod, workdir, cross, layout):
+    import bench
+    hip, tw = _pair(mod, _bench_cfg(workdir), crossMode=cross, layout=layout)
+    steps = bench.BUILD_UP_STEPS + 100
+    for s in range(steps):
+        hip.next_step()
+        tw.next_step()
+        if s % 10 == 9:
+            assert_same_state(hip, tw, "bench workload (%s, %s) step %d" % (cross, layout, s + 1))
+    assert hip.get_vehicle_count() > 80000
+    assert hip.get_average_travel_time() == tw.get_average_travel_time()
+
+
+@pytest.mark.parametrize("cross,layout", CHOICES)
+@pytest.mark.parametrize("name,steps", [("example_1x1", 500), ("grid_6x6", 300)])
+def test_forced_choices_equal_twin_every_step(mod, scen, workdir, name, steps, cross, layout):
+    hip, tw = _pair(mod, scen.materialize(name, workdir), crossMode=cross, layout=layout)
+    for s in range(steps):
+        hip.next_step()
+        tw.next_step()
+        assert_same_state(hip, tw, "%s (%s, %s) step %d" % (name, cross, layout, s + 1))
+    assert hip.get_vehicle_count() > 50
+
+
+@pytest.mark.parametrize("cross,layout", CHOICES)
+def test_forced_choices_congested_grid(mod, scen, workdir, cross, layout):
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_dense.json"), 400, seed=7,
+                            interval=2.0, base_flow=os.path.join(d, "flow.json"))
+    hip, tw = _pair(mod, scen.materialize("grid_6x6", workdir, flow_file=flow), crossMode=cross, layout=layout)
+    for s in range(400):
+        hip.next_step()
+        tw.next_step()
+        if s % 2 == 1:
+            assert_same_state(hip, tw, "dense (%s, %s) step %d" % (cross, layout, s + 1))
+    assert hip.get_vehicle_count() > 3000
+
+
+@pytest.mark.parametrize("cross,layout", CHOICES)
+@pytest.mark.parametrize("seed", [11, 14])
+def test_forced_choices_irregular_networks(mod, scen, workdir, seed, cross, layout):
+    from test_irregular import irregular
+    hip, tw = _pair(mod, irregular(scen, workdir, seed), crossMode=cross, layout=layout)
+    for s in range(500):
+        hip.next_step()
+        tw.next_step()
+        if s % 5 == 4:
+            assert_same_state(hip, tw, "irregular %d (%s, %s) step %d" % (seed, cross, layout, s + 1))
+    assert hip.get_vehicle_count() > 150
+
+
+@pytest.mark.parametrize("n,flows_per_100,min_running,twin_steps,layout", [
+    (60, 333, 300000, 20, "dense"), (60, 333, 300000, 20, "ring"), (100, 333, 900000, 8, "auto")])
+def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_running, twin_steps, layout):
+    """Sizes where the engine switches to its throughput kernels by itself (k_cross2 above 240 k slots)."""
+    base = scen.generate_grid(n, n, workdir)
+    d = os.path.dirname(base)
+    n_extra = n * n * flows_per_100 // 100
+    flow = os.path.join(d, "flow_pin_%d.json" % n_extra)
+    if not os.path.exists(flow):
+        scen.dense_flows(os.path.join(d, "roadnet.json"), flow, n_extra, seed=4242, interval=6.0,
+                         base_flow=os.path.join(d, "flow.json"), end_time=240)
+    cfg = os.path.join(d, "config_pin.json")
+    with open(cfg, "w") as f:
+        json.dump(dict(json.load(open(base)), flowFile=os.path.basename(flow)), f)
+    hip = mod.Engine(_with_cfx(cfg, layout=layout), 1)
+    for _ in range(300):
+        hip.next_step()
+    assert hip.get_vehicle_count() >= min_running
+    tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    tw.load(hip.snapshot())
+    assert_same_state(hip, tw, "%dx%d after the transfer" % (n, n))
+    for s in range(twin_steps):
+        hip.next_step()
+        tw.next_step()
+        if s % 4 == 3 or s == twin_steps - 1:
+            assert_same_state(hip, tw, "%dx%d %s step %d after the transfer" % (n, n, layout, s + 1))
