@@ -207,7 +207,7 @@ __device__ __forceinline__ int lastSlotForLeader(const StepCtx &c, int d, bool v
 }
 
 // RoadLink::isAvailable roadnet.h:429-431
-__device__ __forceinline__ bool llAvailable(const StepCtx &c, int k) {
+template <class C> __device__ __forceinline__ bool llAvailable(const C &c, int k) {
     int in = c.n.llInter[k];
     return c.n.phaseAvail[c.n.interAvailStart[in] + c.curPhase[in] * c.n.interNRL[in] + c.n.llRoadLink[k]] != 0;
 }
@@ -225,10 +225,20 @@ __device__ __forceinline__ int nextOf(const DevNet &n, const DevTables &t, int d
     return ll < 0 ? -1 : n.L + ll;
 }
 
-__device__ __forceinline__ bool isLastRoad(const StepCtx &c, int d, int route) {  // router.cpp:131-134
+template <class C> __device__ __forceinline__ bool isLastRoad(const C &c, int d, int route) {  // router.cpp:131-134
     if (d >= c.n.L) return false;
     return c.n.laneRoad[d] == c.t.routeRoads[c.t.routeStart[route + 1] - 1];
 }
+
+// Layout accessors of the dense layout (the ring layout overloads them on its own context, cfx_ring_kernels.h)
+__device__ __forceinline__ int committedCount(const StepCtx &c, int d) { return c.cnt[d]; }
+__device__ __forceinline__ int firstSlot(const StepCtx &c, int d) { return c.segStart[d]; }  // Drivable::getFirstVehicle
+__device__ __forceinline__ int slotAhead(const StepCtx &, int, int s) { return s - 1; }      // the in-drivable leader's slot
+struct SegWalk {  // slots of one drivable from a starting slot towards the tail
+    int first, base, mask;
+    __device__ __forceinline__ int at(int i) const { return mask < 0 ? first + i : base + ((first - base + i) & mask); }
+};
+__device__ __forceinline__ SegWalk segWalk(const StepCtx &, int, int first) { return SegWalk{first, 0, -1}; }
 
 // ControllerInfo::blocker of the vehicle in `slot`, as a current-generation slot (-1 none).
 __device__ __forceinline__ int blockerOf(const StepCtx &c, int slot) {

@@ -14,6 +14,7 @@
 
 #include "cfx_kernels.h"
 #include "cfx_lc_kernels.h"
+#include "cfx_ring_kernels.h"
 
 using namespace cfxd;
 
@@ -21,9 +22,11 @@ namespace {
 
 std::string g_createError;
 
-enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, PK_HALO_EXPORT, PK_HALO_IMPORT, kNumProfKernels };
+enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, PK_HALO_EXPORT, PK_HALO_IMPORT, PK_COMMIT, kNumProfKernels };
+// names of the step's phases; the ring layout runs kr_admit / kr_action / k_cross<.., RingCtx> / kr_commit under the first
+// four and the last name (it has no scan / scatter)
 const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_action", "k_cross", "k_scan", "k_scatter",
-                                                 "k_halo_export", "k_halo_import"};
+                                                 "k_halo_export", "k_halo_import", "k_commit"};
 
 #define HIP_TRY(call)                                                                                  \
     do {                                                                                               \
@@ -153,6 +156,33 @@ struct cfx_engine {
     int poolN = 0;                     // priorities supplied for the next / current step
     bool pollPending = false;          // a lane-change step has run and was not polled yet
 
+    // ---- ring layout (cfx_ring_kernels.h): per-drivable ring segments, committed in place ----
+    bool ring = false;                 // this engine uses it (decided at cfx_create; cfx_halo_config may still switch to dense)
+    bool ringBuilt = false;
+    std::vector<double> hDrvLength;    // host copy of cfx_net::drv_length (ring capacities)
+    std::vector<int2> hRingGeo;        // [D] {base, cap - 1}
+    size_t ringSlots = 0;
+    double ringMinLen = 0.0;           // shortest vehicle template the capacities were computed for
+    int ringScale = 1;                 // doubled when a ring came close to full
+    int2 *dRingGeo = nullptr;
+    int32_t *rHead = nullptr, *rCnt = nullptr, *slotOf = nullptr;
+    int4 *rScratch = nullptr;
+    SlotArrays rs{};                   // per-slot state that changes only when a vehicle enters a drivable
+    double *rDis[2] = {nullptr, nullptr}, *rSpeed[2] = {nullptr, nullptr};  // the two generations a step alternates
+    int rcur = 0;
+    int2 *rBlk[2] = {nullptr, nullptr};  // by step parity
+    MoverRec *rMovers = nullptr;
+    long long *rFinKey = nullptr;
+    int32_t *rFinVid = nullptr;
+    double *rFinTerm = nullptr;
+    int rFinCap = 0, rJobCap = 0;
+    int32_t *rJobs = nullptr;
+    RingDense rd{};                    // dense staging view (getters, archive, growth)
+    size_t rdCap = 0;
+    int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
+    void *rScanTemp = nullptr;
+    size_t rScanTempBytes = 0;
+
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
     int64_t finishedOffset = 0; // finished vehicles that are not in the vid table (state loaded from an archive)
@@ -274,6 +304,7 @@ struct cfx_engine {
         if (need <= vidCap) return CFX_OK;
         size_t nc = std::max<size_t>(need, std::max<size_t>(vidCap * 2, 1 << 16));
         int rc;
+        if (ring && (rc = grow(&slotOf, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.priority, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.templ, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.route, (size_t) spawned, nc))) return rc;
@@ -292,6 +323,7 @@ struct cfx_engine {
         }
         // nextWait of not-yet-used vids must read -1 (k_spawn_link relies on it)
         HIP_TRY(hipMemsetAsync(vt.nextWait + spawned, 0xFF, (nc - (size_t) spawned) * sizeof(int32_t), stream));
+        if (ring) HIP_TRY(hipMemsetAsync(slotOf + spawned, 0xFF, (nc - (size_t) spawned) * sizeof(int32_t), stream));
         vidCap = nc;
         return CFX_OK;
     }
@@ -366,7 +398,165 @@ struct cfx_engine {
         if (out.overflow == 5) return fail("lane change: more shadows in one step than priorities supplied (cfx_lane_change_supply)");
         if (out.overflow == 6) return fail("lane change: more shadows on one road in one step than the schedule walk tracks");
         if (out.overflow == 7) return fail("lane change: inconsistent pair state (k_lc_resolve did not converge)");
+        if (out.overflow == 8) return fail("ring layout: a drivable's ring of slots is full");
+        if (out.overflow == 9) return fail("cross phase: job queue capacity exceeded");
         if (out.overflow) return fail("device capacity overflow (finish list)");
+        return CFX_OK;
+    }
+
+
+    // ------------------------------------------------------------------------------------------ ring layout
+    RingCtx rctx() const {
+        RingCtx c{};
+        c.n = net;
+        c.t.templ = dTempl.p;
+        c.t.nTempl = (int) hTempl.size();
+        c.t.routeStart = dRouteStart.p;
+        c.t.routeRoads = dRouteRoads.p;
+        c.t.nextStart = dNextStart.p;
+        c.t.nextLL = dNextLL.p;
+        c.s = rs;
+        c.s.dis = rDis[rcur];
+        c.s.speed = rSpeed[rcur];
+        c.disN = rDis[rcur ^ 1];
+        c.speedN = rSpeed[rcur ^ 1];
+        c.blkR = rBlk[(step + 1) & 1];  // written by step - 1
+        c.blkW = rBlk[step & 1];
+        c.slotOf = slotOf;
+        c.vState = vt.state;
+        c.ringGeo = dRingGeo;
+        c.head = rHead;
+        c.cnt = rCnt;
+        c.admitStep = admitStep;
+        c.curPhase = curPhase;
+        c.vPriority = vt.priority;
+        c.vCustomSpeed = vt.customSpeed;
+        c.llDyn = llDyn;
+        c.interMask = interMask;
+        c.llGate = llGate;
+        c.laneTail = laneTail;
+        c.admitRec = admitRec;
+        c.step = (int32_t) step;
+        c.interval = cfg.interval;
+        return c;
+    }
+    template <typename T> int freeRaw(T **p) {
+        if (*p) {
+            forget(*p);
+            HIP_TRY(hipFree(*p));
+            *p = nullptr;
+        }
+        return CFX_OK;
+    }
+    int ringFree() {
+        int rc = 0;
+        rc |= freeRaw(&rs.vid) | freeRaw(&rs.drv) | freeRaw(&rs.prevDrv) | freeRaw(&rs.next) | freeRaw(&rs.enterLLT) |
+              freeRaw(&rs.routePos) | freeRaw(&rs.templ) | freeRaw(&rs.route) | freeRaw(&rs.flags) | freeRaw(&rBlk[0]) | freeRaw(&rBlk[1]) |
+              freeRaw(&rDis[0]) | freeRaw(&rDis[1]) | freeRaw(&rSpeed[0]) | freeRaw(&rSpeed[1]) | freeRaw(&rMovers) |
+              freeRaw(&dRingGeo) | freeRaw(&rJobs);
+        return rc ? CFX_ERR_DEVICE : CFX_OK;
+    }
+    // Ring capacities: a drivable of length len holds at most ~len / (shortest vehicle) vehicles bumper to bumper; a few
+    // more for the transient overlaps the reference allows (Lane::canEnter lets a vehicle in behind a moving tail,
+    // roadnet.cpp:437-445), rounded up to a power of two.  kr_commit raises a flag well before a ring is full and the next
+    // cfx_step doubles every capacity; a full ring is an error (DevScalars::overflow = 8), never silent.
+    int ringAllocate(double minLen) {
+        hRingGeo.resize((size_t) D);
+        size_t run = 0;
+        for (int d = 0; d < D; ++d) {
+            double want = std::ceil(hDrvLength[d] / minLen) + 6.0;
+            want *= ringScale;
+            size_t cap = 8;
+            while ((double) cap < want && cap < (1u << (kRingIdxBits - 1))) cap <<= 1;
+            run = (run + cap - 1) & ~(cap - 1);
+            hRingGeo[d] = make_int2((int) run, (int) cap - 1);
+            run += cap;
+            if (run > 0x7fff0000u) return fail("ring layout: more than 2^31 slots");
+        }
+        ringSlots = run;
+        ringMinLen = minLen;
+        int rc;
+#define RALLOC(ptr) if ((rc = allocRaw(&ptr, ringSlots))) return rc;
+        RALLOC(rs.vid) RALLOC(rs.drv) RALLOC(rs.prevDrv) RALLOC(rs.next) RALLOC(rs.enterLLT) RALLOC(rs.routePos) RALLOC(rs.templ)
+        RALLOC(rs.route) RALLOC(rs.flags) RALLOC(rBlk[0]) RALLOC(rBlk[1]) RALLOC(rDis[0]) RALLOC(rDis[1]) RALLOC(rSpeed[0]) RALLOC(rSpeed[1]) RALLOC(rMovers)
+#undef RALLOC
+        HIP_TRY(hipMemsetAsync(rBlk[0], 0xFF, ringSlots * sizeof(int2), stream));
+        HIP_TRY(hipMemsetAsync(rBlk[1], 0xFF, ringSlots * sizeof(int2), stream));
+        HIP_TRY(hipMemsetAsync(rs.templ, 0, ringSlots * 4, stream));
+        HIP_TRY(hipMemsetAsync(rs.flags, 0, ringSlots, stream));
+        if ((rc = upload(&dRingGeo, hRingGeo.data(), hRingGeo.size()))) return rc;
+        rJobCap = (int) std::max<size_t>(4096, ringSlots / 8);
+        if ((rc = allocRaw(&rJobs, (size_t) rJobCap * kJobShards))) return rc;
+        if (!rHead) {
+            if ((rc = allocRaw(&rHead, (size_t) D + 1))) return rc;
+            if ((rc = allocRaw(&rCnt, (size_t) D + 1))) return rc;
+            if ((rc = allocRaw(&rOff, (size_t) D + 2))) return rc;
+            if ((rc = allocRaw(&rScratch, (size_t) D))) return rc;
+            rFinCap = std::max(1 << 16, L * 8);
+            if ((rc = allocRaw(&rFinKey, (size_t) rFinCap))) return rc;
+            if ((rc = allocRaw(&rFinVid, (size_t) rFinCap))) return rc;
+            if ((rc = allocRaw(&rFinTerm, (size_t) rFinCap))) return rc;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, rScanTempBytes, rCnt, rOff, D + 1, stream));
+            char *tmp = nullptr;
+            if ((rc = allocRaw(&tmp, rScanTempBytes))) return rc;
+            rScanTemp = tmp;
+            HIP_TRY(hipMemsetAsync(rCnt, 0, ((size_t) D + 1) * sizeof(int32_t), stream));
+        }
+        return CFX_OK;
+    }
+    int ensureDense(size_t n) {
+        if (n <= rdCap) return CFX_OK;
+        const size_t nc = std::max<size_t>(n + n / 4, 1 << 14);
+        int rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+#define DGROW(ptr) if ((rc = freeRaw(&ptr)) || (rc = allocRaw(&ptr, nc))) return rc;
+        DGROW(rd.vid) DGROW(rd.drv) DGROW(rd.prevDrv) DGROW(rd.blockerVid) DGROW(rd.enterLLT) DGROW(rd.routePos) DGROW(rd.leaderVid)
+        DGROW(rd.flags) DGROW(rd.dis) DGROW(rd.speed) DGROW(rd.gap)
+#undef DGROW
+        rdCap = nc;
+        return CFX_OK;
+    }
+    // ring order -> dense staging arrays (Drivable::vehicles order); returns the number of running vehicles
+    int ringGather(bool wantLeader, int32_t *totalOut) {
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(rScanTemp, rScanTempBytes, rCnt, rOff, D + 1, stream));
+        int32_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&total, rOff + D, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int rc = ensureDense((size_t) total);
+        if (rc) return rc;
+        if (total) hipLaunchKernelGGL(kr_gather, dim3(gridFor(D)), dim3(kBlock), 0, stream, rctx(), (const int32_t *) rOff, rd, wantLeader ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        *totalOut = total;
+        return CFX_OK;
+    }
+    // (Re)build the rings: first use, a shorter vehicle template than the capacities were computed for, or growth.
+    bool ringGrowRequested = false;
+    int ringEnsure() {
+        double minLen = 1e300;
+        for (const auto &t : hTempl) minLen = std::min(minLen, t.len);
+        if (hTempl.empty()) minLen = 5.0;
+        minLen = std::max(minLen, 0.25);
+        if (ringBuilt && !(minLen < ringMinLen) && !ringGrowRequested) return CFX_OK;
+        int rc;
+        int32_t total = 0;
+        if (ringBuilt) {  // carry the running vehicles over
+            if ((rc = ringGather(false, &total))) return rc;
+            HIP_TRY(hipStreamSynchronize(stream));
+            if ((rc = ringFree())) return rc;
+            if (ringGrowRequested) ringScale *= 2;
+            minLen = std::min(minLen, ringMinLen);
+        }
+        ringGrowRequested = false;
+        if ((rc = ringAllocate(minLen))) return rc;
+        ringBuilt = true;
+        hipLaunchKernelGGL(kr_reset, dim3(gridFor(D)), dim3(kBlock), 0, stream, D, rHead, rCnt, rScratch);
+        if (total) {
+            hipLaunchKernelGGL(kr_scatter_in, dim3(gridFor(D)), dim3(kBlock), 0, stream, rctx(), (const int32_t *) rOff, rd, vt);
+            const int zero = 0;
+            HIP_TRY(hipMemcpyAsync(&sc->ringNearFull, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
         return CFX_OK;
     }
 
@@ -411,6 +601,13 @@ struct cfx_engine {
             HIP_TRY(hipMemsetAsync(gen[0].blocker, 0xFF, (size_t) run * sizeof(int32_t), stream));
             HIP_TRY(hipStreamSynchronize(stream));  // ss lives on this frame
             liveUpper = 2 * (int64_t) halo.nGhost;
+        }
+        if (ring && ringBuilt) {
+            hipLaunchKernelGGL(kr_reset, dim3(gridFor(D)), dim3(kBlock), 0, stream, D, rHead, rCnt, rScratch);
+            // blocker records carry step numbers, which start over
+            HIP_TRY(hipMemsetAsync(rBlk[0], 0xFF, ringSlots * sizeof(int2), stream));
+            HIP_TRY(hipMemsetAsync(rBlk[1], 0xFF, ringSlots * sizeof(int2), stream));
+            rcur = 0;
         }
         hipLaunchKernelGGL(k_init_lights, dim3(gridFor(I)), dim3(kBlock), 0, stream, net, curPhase, remain);
         HIP_TRY(hipMemsetAsync(waitHead, 0xFF, L * sizeof(int32_t), stream));
@@ -472,6 +669,10 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->cfg = *cfg;
     e->cross2 = cfg->cross_mode == CFX_CROSS_THROUGHPUT ? 1 : cfg->cross_mode == CFX_CROSS_LATENCY ? 0 : -1;
+    if (cfg->layout == CFX_LAYOUT_RING && cfg->lane_change)
+        return e->fail("cfx_create: layout ring does not run lane change (its mid-lane insertions use the dense layout)");
+    e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change);
+    e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
     e->R = n->n_roads;
     e->L = n->n_lanes;
     e->K = n->n_lanelinks;
@@ -654,6 +855,16 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     int rc;
     if ((rc = e->syncTables())) return rc;
     hipStream_t st = e->stream;
+    // Fail at the step that failed (or the one after): every step leaves its scalars in pinned host memory, so an
+    // overflow code raised by a step the device has already finished is seen here without waiting for anything.
+    if (e->mirrorValid && __atomic_load_n(&e->hMirror->sc.overflow, __ATOMIC_RELAXED) != 0) {
+        DevScalars s;
+        if ((rc = e->readScalars(s))) return rc == CFX_ERR_DEVICE ? CFX_ERR_CAPACITY : rc;
+    }
+    if (e->ring) {
+        if (e->mirrorValid && __atomic_load_n(&e->hMirror->sc.ringNearFull, __ATOMIC_RELAXED) != 0) e->ringGrowRequested = true;
+        if ((rc = e->ringEnsure())) return rc;
+    }
 
     if (e->lc.on) {
         if (e->pollPending) return e->fail("cfx_step: the previous lane-change step was not polled (cfx_lane_change_poll)");
@@ -708,6 +919,73 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->spawnedHere += lane >= 0;
     }
     e->liveUpper += e->nQueueLanes;
+
+    if (e->ring) {
+        // ---- ring layout: admit, action (+ notify sources), cross, commit — no scan, no scatter
+        RingCtx c = e->rctx();
+        const bool dbg = e->cfg.debug_sync != 0;  // developer aid: name the kernel that faults
+#define RING_CHECK(name)                                                                                          \
+    if (dbg) {                                                                                                    \
+        fprintf(stderr, "[cfx ring] step %lld: %s\n", (long long) e->step, name);                                 \
+        hipError_t er = hipStreamSynchronize(st);                                                                 \
+        if (er != hipSuccess) return e->fail(std::string("ring step: ") + name + ": " + hipGetErrorString(er));   \
+    }
+        RING_CHECK("before the step")
+        const unsigned long long pr = __atomic_load_n(&e->hMirror->progress, __ATOMIC_RELAXED);
+        // running vehicles as of the last step the device has completed (stale by the few steps the host runs ahead):
+        // only sizes the cross phase's grid and picks its organisation
+        const size_t activeEst = (size_t) (pr & 0xFFFFFFFFu) + (size_t) e->nQueueLanes * 4;
+        e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->sc);
+        RING_CHECK("kr_admit")
+        RingOut ro{c.disN, c.speedN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
+        JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
+        {
+            // lanes per wave: few on small networks (one pass per wave), more on large ones (fewer, fuller waves)
+            const int G = e->L <= 16384 ? 4 : (e->L <= 131072 ? 8 : 16);
+            const int nLaneWaves = (e->L + G - 1) / G, nLLWaves = (e->K + kRingWave - 1) / kRingWave;
+            const int nLLBlocks = (e->K + kRingWave - 1) / kRingWave;
+            const dim3 grid(nLaneWaves + nLLWaves + nLLBlocks), block(kRingWave);
+            if (G == 4) e->launch(PK_ACTION, kr_action<4>, grid, block, c, ro, jq, nLaneWaves, nLLWaves);
+            else if (G == 8) e->launch(PK_ACTION, kr_action<8>, grid, block, c, ro, jq, nLaneWaves, nLLWaves);
+            else e->launch(PK_ACTION, kr_action<16>, grid, block, c, ro, jq, nLaneWaves, nLLWaves);
+        }
+        RING_CHECK("kr_action")
+        if (dbg) {
+            HIP_TRY(hipMemsetAsync(e->laneOut, 0, 8 * sizeof(int32_t), st));
+            hipLaunchKernelGGL(kr_validate, dim3(gridFor(std::max(e->D, 16))), dim3(kBlock), 0, st, c, jq, (int) e->spawned,
+                               (int) e->hRouteStart.size() - 1, (int) e->ringSlots, e->laneOut);
+            int32_t rep[5] = {0, 0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(rep, e->laneOut, sizeof rep, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (rep[0]) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "ring invariant %d violated at step %lld: %d %d %d %d", rep[0], (long long) e->step, rep[1], rep[2], rep[3], rep[4]);
+                return e->fail(buf);
+            }
+        }
+        const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;
+        if (useBig)
+            e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
+                      dim3(kCross2Block), c, ro, jq);
+        else
+            e->launch(PK_CROSS, k_cross<false, RingCtx, RingOut>,
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
+                      dim3(kCrossBlock), c, ro, jq);
+        RING_CHECK("k_cross")
+        const int nStat = (int) std::min<size_t>(std::max<size_t>(1, activeEst >> 16), 64);
+        RingCommit rk{e->rScratch, e->rMovers, e->waitHead, e->curPhase, e->remain, (int) e->cfg.rl_traffic_light, (int) e->nMaskWords,
+                      e->sc, e->rFinKey, e->rFinVid, e->rFinTerm, e->rFinCap, e->jobCount,
+                      e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat, e->vt.state};
+        e->launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
+        RING_CHECK("kr_commit")
+#undef RING_CHECK
+        HIP_TRY(hipGetLastError());
+        e->rcur ^= 1;
+        e->step += 1;
+        e->mirrorValid = !e->tiled;
+        return CFX_OK;
+    }
     const int64_t spare = e->tiled ? e->spareTotal : (int64_t) e->L;
     auto bound = [e]() {
         const int64_t a = e->spawnedHere - (e->finishedKnown - e->finishedOffset);
@@ -783,7 +1061,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
     // throughput (far fewer wave-rounds per vehicle).  They break even at ~220 k slots on the MI355X.
     const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
-    JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap};
+    JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap, &e->sc->overflow};
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
@@ -918,7 +1196,11 @@ int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpyAsync(e->hLaneOut, e->cnt[e->cur].p, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (e->ring && !e->ringBuilt) {  // nothing has run yet
+        memset(out, 0, e->L * sizeof(int32_t));
+        return CFX_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(e->hLaneOut, e->ring ? e->rCnt : e->cnt[e->cur].p, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     memcpy(out, e->hLaneOut, e->L * sizeof(int32_t));
     return CFX_OK;
@@ -930,7 +1212,9 @@ int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out) {
     HIP_TRY(hipSetDevice(e->device));
     int rc;
     if ((rc = e->syncTables())) return rc;
-    hipLaunchKernelGGL(k_lane_waiting, dim3(gridFor(e->L)), dim3(kBlock), 0, e->stream, e->ctx(), e->laneOut);
+    if (e->ring && (rc = e->ringEnsure())) return rc;
+    if (e->ring) hipLaunchKernelGGL(kr_lane_waiting, dim3(gridFor(e->L)), dim3(kBlock), 0, e->stream, e->rctx(), e->laneOut);
+    else hipLaunchKernelGGL(k_lane_waiting, dim3(gridFor(e->L)), dim3(kBlock), 0, e->stream, e->ctx(), e->laneOut);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->hLaneOut, e->laneOut, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -944,6 +1228,43 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
     HIP_TRY(hipSetDevice(e->device));
     int rc;
     if ((rc = e->syncTables())) return rc;
+    if (e->ring) {
+        // the ring order as dense arrays (kr_gather), then only the columns the caller asked for
+        if ((rc = e->ringEnsure())) return rc;
+        int32_t n = 0;
+        if ((rc = e->ringGather(view->leader_vid || view->gap, &n))) return rc;
+        view->count = n;
+        if (n > view->capacity) {
+            e->err = "cfx_get_vehicles: capacity too small";
+            return CFX_ERR_CAPACITY;
+        }
+        auto dl = [&](void *dst, const void *src, size_t bytes) {
+            return (dst && bytes) ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream) : hipSuccess;
+        };
+        const size_t sn = (size_t) n;
+        HIP_TRY(dl(view->vid, e->rd.vid, sn * 4));
+        HIP_TRY(dl(view->drivable, e->rd.drv, sn * 4));
+        HIP_TRY(dl(view->prev_drivable, e->rd.prevDrv, sn * 4));
+        HIP_TRY(dl(view->leader_vid, e->rd.leaderVid, sn * 4));
+        HIP_TRY(dl(view->blocker_vid, e->rd.blockerVid, sn * 4));
+        HIP_TRY(dl(view->enter_ll_time, e->rd.enterLLT, sn * 4));
+        HIP_TRY(dl(view->route_pos, e->rd.routePos, sn * 4));
+        HIP_TRY(dl(view->dis, e->rd.dis, sn * 8));
+        HIP_TRY(dl(view->speed, e->rd.speed, sn * 8));
+        HIP_TRY(dl(view->gap, e->rd.gap, sn * 8));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int i = 0; i < n; ++i) {  // no lane change on this layout
+            if (view->lc_partner_vid) view->lc_partner_vid[i] = -1;
+            if (view->lc_flags) view->lc_flags[i] = 0;
+            if (view->lc_offset) view->lc_offset[i] = 0.0;
+            if (view->lc_last_dir) view->lc_last_dir[i] = 0;
+            if (view->lc_target_lane) view->lc_target_lane[i] = -1;
+            if (view->lc_direction) view->lc_direction[i] = 0;
+            if (view->lc_last_change_time) view->lc_last_change_time[i] = 0.0;
+            if (view->lc_waiting_time) view->lc_waiting_time[i] = 0.0;
+        }
+        return CFX_OK;
+    }
     // number of slots of the current generation
     int32_t S = 0;
     if (e->mirrorValid) {
@@ -1116,7 +1437,9 @@ int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
     } else {
         int rc = e->syncTables();
         if (rc) return rc;
-        hipLaunchKernelGGL(k_set_speed, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid);
+        if (e->ring && (rc = e->ringEnsure())) return rc;
+        if (e->ring) hipLaunchKernelGGL(kr_set_speed, dim3(1), dim3(1), 0, e->stream, e->rctx(), vid);
+        else hipLaunchKernelGGL(k_set_speed, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(e->stream));  // the two sources above live on this stack frame
@@ -1133,7 +1456,15 @@ int32_t cfx_set_vehicle_route(cfx_engine *e, int32_t vid, int32_t route) {
     int rc = e->syncTables();
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->vt.route + vid, &route, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_set_route, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid, route);
+    if (e->ring) {
+        if ((rc = e->ringEnsure())) return rc;
+        uint8_t st = 0;
+        HIP_TRY(hipMemcpyAsync(&st, e->vt.state + vid, 1, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (st == 1) hipLaunchKernelGGL(kr_set_route, dim3(1), dim3(1), 0, e->stream, e->rctx(), vid, route);
+    } else {
+        hipLaunchKernelGGL(k_set_route, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid, route);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     return CFX_OK;
@@ -1153,7 +1484,13 @@ int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *dri
     HIP_TRY(hipMemcpyAsync(&st, e->vt.state + vid, 1, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(&r, e->vt.route + vid, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemsetAsync(e->laneOut, 0xFF, 8, e->stream));
-    hipLaunchKernelGGL(k_find_vehicle, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid, e->laneOut);
+    if (e->ring) {
+        if ((rc = e->ringEnsure())) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (st == 1) hipLaunchKernelGGL(kr_find_vehicle, dim3(1), dim3(1), 0, e->stream, e->rctx(), vid, e->laneOut);
+    } else {
+        hipLaunchKernelGGL(k_find_vehicle, dim3(gridStride(e->slotCap)), dim3(kBlock), 0, e->stream, e->ctx(), vid, e->laneOut);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(found, e->laneOut, 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1228,6 +1565,24 @@ int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (e->ring) {
+        int rc;
+        if ((rc = e->syncTables()) || (rc = e->ringEnsure())) return rc;
+        int32_t n = 0;
+        if ((rc = e->ringGather(false, &n))) return rc;
+        if (n > capacity) return CFX_ERR_CAPACITY;
+        std::vector<int32_t> vid((size_t) n);
+        std::vector<uint8_t> flags((size_t) n);
+        std::vector<double> cs((size_t) e->spawned);
+        if (n) {
+            HIP_TRY(hipMemcpyAsync(vid.data(), e->rd.vid, (size_t) n * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync(flags.data(), e->rd.flags, (size_t) n, hipMemcpyDeviceToHost, e->stream));
+        }
+        if (e->spawned) HIP_TRY(hipMemcpyAsync(cs.data(), e->vt.customSpeed, (size_t) e->spawned * 8, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int i = 0; i < n; ++i) out[i] = (flags[i] & 1) ? cs[vid[i]] : __builtin_nan("");
+        return CFX_OK;
+    }
     int32_t S = 0;
     HIP_TRY(hipMemcpyAsync(&S, e->segStart[e->cur].p + e->D, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1259,7 +1614,8 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     if ((rc = e->resetState())) return rc;
     const int L = e->L, D = e->D, nV = s->n_vehicles, nR = s->n_running;
     if ((rc = e->ensureVidCap((size_t) nV + 1))) return rc;
-    if ((rc = e->ensureSlotCap((size_t) nR + L + 1))) return rc;
+    if (e->ring && (rc = e->ringEnsure())) return rc;
+    if (!e->ring && (rc = e->ensureSlotCap((size_t) nR + L + 1))) return rc;
     // ---- layout: vehicles of drivable d, then one spare slot for lanes
     std::vector<int32_t> cnt(D, 0), segStart(D + 1, 0);
     for (int i = 0; i < nR; ++i) {
@@ -1267,13 +1623,48 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         if (d < 0 || d >= D || (i && d < s->r_drivable[i - 1])) return e->fail("cfx_load_state: running vehicles must be grouped by drivable, ascending");
         cnt[d]++;
     }
-    for (int d = 0; d < D; ++d) segStart[d + 1] = segStart[d] + cnt[d] + (d < L ? 1 : 0);
-    const int S = segStart[D];
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream) : hipSuccess;
+    };
+    std::vector<double> customR(std::max(nV, 1), 0.0);
+    if (e->ring) {
+        // the caller's arrays ARE the dense staging view (Drivable::vehicles order); kr_scatter_in (below, once the vehicle
+        // table is on the device) puts them on the rings
+        for (int d = 0; d < D; ++d) {
+            segStart[d + 1] = segStart[d] + cnt[d];
+            if (cnt[d] > e->hRingGeo[d].y) return e->fail("cfx_load_state: more vehicles on one drivable than its ring holds");
+        }
+        if ((rc = e->ensureDense((size_t) nR))) return rc;
+        std::vector<int32_t> blk((size_t) std::max(nR, 1), -1);
+        std::vector<uint8_t> flags((size_t) std::max(nR, 1), 0);
+        for (int i = 0; i < nR; ++i) {
+            const int v = s->r_vid[i];
+            if (v < 0 || v >= nV) return e->fail("cfx_load_state: running vid out of range");
+            const int b = s->r_blocker_vid[i];
+            blk[i] = (b >= 0 && b < nV) ? b : -1;
+            if (s->r_custom_speed && s->r_custom_speed[i] == s->r_custom_speed[i]) {
+                flags[i] = 1;
+                customR[v] = s->r_custom_speed[i];
+            }
+        }
+        HIP_TRY(up(e->rOff, segStart.data(), ((size_t) D + 1) * 4));
+        HIP_TRY(up(e->rd.vid, s->r_vid, (size_t) nR * 4));
+        HIP_TRY(up(e->rd.prevDrv, s->r_prev_drivable, (size_t) nR * 4));
+        HIP_TRY(up(e->rd.blockerVid, blk.data(), (size_t) nR * 4));
+        HIP_TRY(up(e->rd.enterLLT, s->r_enter_ll_time, (size_t) nR * 4));
+        HIP_TRY(up(e->rd.routePos, s->r_route_pos, (size_t) nR * 4));
+        HIP_TRY(up(e->rd.flags, flags.data(), (size_t) nR));
+        HIP_TRY(up(e->rd.dis, s->r_dis, (size_t) nR * 8));
+        HIP_TRY(up(e->rd.speed, s->r_speed, (size_t) nR * 8));
+        HIP_TRY(hipStreamSynchronize(e->stream));  // blk / flags die with this scope
+    }
+    for (int d = 0; d < D && !e->ring; ++d) segStart[d + 1] = segStart[d] + cnt[d] + (d < L ? 1 : 0);
+    const int S = e->ring ? 0 : segStart[D];
     std::vector<int32_t> vid(S, -1), drv(S, -1), prev(S, -1), next(S, -1), blk(S, -1), ellt(S, CFX_INT_MAX), rpos(S, 0),
         templ(S, 0), route(S, 0), slotOfVid(std::max(nV, 1), -1);
     std::vector<uint8_t> flags(S, 0);
     std::vector<double> dis(S, 0.0), speed(S, 0.0), custom(std::max(nV, 1), 0.0);
-    {
+    if (!e->ring) {
         std::vector<int32_t> fill(D, 0);
         for (int i = 0; i < nR; ++i) {
             int d = s->r_drivable[i];
@@ -1302,9 +1693,8 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     }
     // ---- uploads
     SlotArrays &g = e->gen[e->cur];
-    auto up = [&](void *dst, const void *src, size_t bytes) {
-        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream) : hipSuccess;
-    };
+    if (e->ring) custom = customR;
+    if (!e->ring) {
     HIP_TRY(up(e->segStart[e->cur].p, segStart.data(), (D + 1) * 4));
     HIP_TRY(up(e->cnt[e->cur].p, cnt.data(), D * 4));
     HIP_TRY(up(g.vid, vid.data(), S * 4));
@@ -1321,6 +1711,8 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     std::vector<int32_t> ident(S);
     for (int i = 0; i < S; ++i) ident[i] = i;
     HIP_TRY(up(e->oldToNew, ident.data(), S * 4));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     // vehicle table + waiting FIFOs
     std::vector<int32_t> nextWait(std::max(nV, 1), -1), waitHead(L, -1);
     for (int i = 0; i < s->n_waiting; ++i) {
@@ -1408,6 +1800,10 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         HIP_TRY(up(lc.followerGap, zero.data(), nv * 8));
         HIP_TRY(hipStreamSynchronize(e->stream));  // the staging vectors die with this scope
     }
+    if (e->ring) {  // (needs the vehicle table and e->step: the blockers' validity tag is "set in the previous step")
+        if (e->spawned) HIP_TRY(hipMemsetAsync(e->slotOf, 0xFF, (size_t) e->spawned * sizeof(int32_t), e->stream));
+        hipLaunchKernelGGL(kr_scatter_in, dim3(gridFor(D)), dim3(kBlock), 0, e->stream, e->rctx(), (const int32_t *) e->rOff, e->rd, e->vt);
+    } else
     // cached next drivable of every slot (uses the device copies of the route tables)
     hipLaunchKernelGGL(k_refresh_next, dim3(gridStride(std::max(S, 1))), dim3(kBlock), 0, e->stream, e->ctx());
     HIP_TRY(hipGetLastError());
@@ -1424,6 +1820,13 @@ int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
         return CFX_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(e->device));
+    if (e->ring) {  // tiles run on the dense layout (its halo kernels address the spare slots behind a lane's vehicles)
+        if (e->cfg.layout == CFX_LAYOUT_RING) {
+            e->err = "cfx_halo_config: a tiled engine cannot be forced onto the ring layout";
+            return CFX_ERR_STATE;
+        }
+        e->ring = false;
+    }
     std::vector<uint8_t> ghost((size_t) e->L, 0);
     e->hLaneSpare.assign((size_t) e->L, 1);
     for (int i = 0; i < h->n_ghost; ++i) {

@@ -1,0 +1,696 @@
+// RING layout of the vehicle order (cfx_config::layout = CFX_LAYOUT_RING; default whenever lane change is off).
+//
+// The reference keeps one std::list<Vehicle*> per drivable (roadnet.h:245); per step a vehicle either stays in its list,
+// leaves it at the FRONT (it ran past the end of the drivable, engine.cpp:290-310) or is appended at the BACK of another
+// one (engine.cpp:477-494; handleWaiting appends at most one, engine.cpp:502-516): a drivable is a deque.  So every
+// drivable owns a fixed ring of slots in HBM
+//     slots  base[d] .. base[d] + cap[d] - 1      cap a power of two, base aligned to it
+//     live   base + ((head + i) & (cap - 1)),  i = 0 .. cnt - 1,  i = 0 the front (furthest ahead)
+// and a step commits IN PLACE: a vehicle that stays keeps its slot and only its new {dis, speed} are written (into the
+// other generation of those two arrays, 16 B); everything else a vehicle carries (vid, template, route cursor, ...) is
+// written only when it enters a drivable (3-5 % of the vehicles per step).  There is no global scan and no scatter:
+// `kr_commit` advances `head` past the leavers, appends the entrants behind the stayers in the reference's order and
+// adjusts `cnt`, one thread per drivable.  The in-lane leader of a vehicle is the previous ring position — adjacent in
+// memory, so a wave reads its leaders' {dis, speed, template} from the window it has staged in LDS.
+//
+// Blockers are kept by vehicle id with the step they were set in: Vehicle::update drops a blocker that was not set in
+// that very step (vehicle.cpp:133-138), so a record is valid for exactly one step and nothing ever has to be cleared;
+// two buffers alternate by step parity, so the records a step writes never overwrite the ones it reads.
+//
+// The arithmetic is the same code as the dense layout's (cfx_kernels.h: actionOne, canPassActive, findLeader, ...),
+// instantiated on this file's context type.
+#pragma once
+
+#include "cfx_kernels.h"
+
+namespace cfxd {
+
+struct RingCtx {
+    DevNet n;
+    DevTables t;
+    SlotArrays s;            // dis / speed: the CURRENT generation; `blocker` is not used (see blk)
+    double *disN, *speedN;   // the NEXT generation of the two arrays a step rewrites
+    // [slot] {blocker vid, step it was set in}, two buffers by step parity: a step WRITES the blockers it sets into
+    // blkW (parity of this step) while every reader — the deadlock walk of Cross::canPass — looks at what the previous step
+    // left in blkR, as the reference's buffered commit does (Vehicle::update vehicle.cpp:133-138)
+    const int2 *blkR;
+    int2 *blkW;
+    int32_t *slotOf;         // [vid] slot of a running vehicle (-1: not on this engine)
+    const uint8_t *vState;   // [vid] 0 waiting, 1 running, 2 finished
+    const int2 *ringGeo;     // [D] {base, cap - 1}
+    int32_t *head;           // [D] ring index of the front vehicle
+    int32_t *cnt;            // [D] live vehicles (this step's admission excluded until kr_commit, see cntNow)
+    const int32_t *admitStep;
+    const int32_t *curPhase;
+    const int32_t *vPriority;
+    const double *vCustomSpeed;
+    int4 *llDyn;
+    unsigned long long *interMask;
+    int2 *llGate;
+    int32_t *laneTail;
+    int2 *admitRec;
+    int32_t step;
+    double interval;
+};
+
+__device__ __forceinline__ int ringSlot(const int2 geo, int head, int i) { return geo.x + ((head + i) & geo.y); }
+
+__device__ __forceinline__ int committedCount(const RingCtx &c, int d) { return c.cnt[d]; }
+__device__ __forceinline__ int cntNow(const RingCtx &c, int d) {
+    return c.cnt[d] + ((d < c.n.L && c.admitStep[d] == c.step) ? 1 : 0);
+}
+__device__ __forceinline__ int firstSlot(const RingCtx &c, int d) { return ringSlot(c.ringGeo[d], c.head[d], 0); }
+__device__ __forceinline__ int lastSlot(const RingCtx &c, int d) {
+    const int n = cntNow(c, d);
+    return n > 0 ? ringSlot(c.ringGeo[d], c.head[d], n - 1) : -1;
+}
+__device__ __forceinline__ int lastSlotForLeader(const RingCtx &c, int d, bool viewerNew, int viewerLane) {
+    int n = c.cnt[d];
+    if (viewerNew && d < viewerLane && d < c.n.L && c.admitStep[d] == c.step) n += 1;
+    return n > 0 ? ringSlot(c.ringGeo[d], c.head[d], n - 1) : -1;
+}
+__device__ __forceinline__ int slotAhead(const RingCtx &c, int d, int s) {
+    const int2 geo = c.ringGeo[d];
+    return geo.x + ((s - geo.x - 1) & geo.y);
+}
+__device__ __forceinline__ SegWalk segWalk(const RingCtx &c, int d, int first) {
+    const int2 geo = c.ringGeo[d];
+    return SegWalk{first, geo.x, geo.y};
+}
+// ControllerInfo::blocker of the vehicle in `slot` as a slot (-1: none, expired, finished, or not on this engine)
+__device__ __forceinline__ int blockerVid(const RingCtx &c, int slot) {
+    const int2 b = c.blkR[slot];
+    return (b.x >= 0 && b.y == c.step - 1 && c.vState[b.x] == 1) ? b.x : -1;
+}
+__device__ __forceinline__ int blockerOf(const RingCtx &c, int slot) {
+    const int v = blockerVid(c, slot);
+    return v >= 0 ? c.slotOf[v] : -1;
+}
+__device__ __forceinline__ int keepBlocker(const RingCtx &, int blockerSlot) { return blockerSlot; }
+
+// What a vehicle that changes drivable leaves behind for kr_commit, at its OLD slot's index (written by 3-5 % of the
+// vehicles; the ring arrays themselves are not touched, so the leavers' slots may be recycled while this is read).
+struct MoverRec {
+    int32_t vid, templ, route, routePos, oldDrv, newDrv, blockerVid, nextIn;  // nextIn: next entrant of the same drivable
+    double dis, speed;
+};
+static_assert(sizeof(MoverRec) == 48, "mover record layout");
+
+struct RingOut {
+    double *disN, *speedN;
+    int2 *blk;
+    int4 *scratch;       // [D] {vehicles leaving, largest list index among them, head of the entrant list, entrants}
+    MoverRec *movers;    // [slot]
+    DevScalars *sc;
+    long long *finKey;   // finishers of the step: (drivable << 20 | list index) = the reference's removal order
+    int32_t *finVid;
+    int finCap;
+    __device__ __forceinline__ void park(int s, double v, double iv) const {
+        speedN[s] = v;
+        disN[s] = iv;
+    }
+    __device__ __forceinline__ double parkedSpeed(int s) const { return speedN[s]; }
+    __device__ __forceinline__ double parkedInterSpeed(int s) const { return disN[s]; }
+    __device__ __forceinline__ void keep(int s, double dis, double speed) const {
+        disN[s] = dis;
+        speedN[s] = speed;
+    }
+};
+constexpr int kRingIdxBits = 20;  // list index inside a drivable (ring capacities stay far below 2^20)
+
+// Tail of Engine::vehicleControl on the ring layout: stayers are committed right here (their slot does not move), leavers
+// leave a MoverRec / a finish record and a mark in the next generation.
+template <bool LC>
+__device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cfx_vehicle_template &t, int s, int d, int /*vid*/,
+                                    double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int idx = -1) {
+    static_assert(!LC, "the ring layout does not run lane change");
+    v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
+    v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);
+    const MoveOut m = computeMove(c, t, s, d, speed, dis, dlen, nd0, v);
+    const int bv = blockerSlot >= 0 ? c.s.vid[blockerSlot] : -1;
+    if (m.newDrv == -1) {
+        o.disN[s] = m.ndis;
+        o.speedN[s] = m.v;
+        if (bv >= 0) o.blk[s] = make_int2(bv, c.step);
+        return;
+    }
+    o.speedN[s] = -1.0;  // "left its drivable": what kr_commit's general path looks at (a speed is never negative)
+    if (idx < 0) {
+        const int2 geo = c.ringGeo[d];
+        idx = (s - geo.x - c.head[d]) & geo.y;
+    }
+    atomicAdd(&o.scratch[d].x, 1);
+    atomicMax(&o.scratch[d].y, idx);
+    const int vid = c.s.vid[s];
+    if (m.newDrv >= 0) {
+        MoverRec r;
+        r.vid = vid;
+        r.templ = c.s.templ[s];
+        r.route = c.s.route[s];
+        r.routePos = c.s.routePos[s];
+        r.oldDrv = d;
+        r.newDrv = m.newDrv;
+        r.blockerVid = bv;
+        r.dis = m.ndis;
+        r.speed = m.v;
+        atomicAdd(&o.scratch[m.newDrv].w, 1);
+        r.nextIn = atomicExch(&o.scratch[m.newDrv].z, s);
+        o.movers[s] = r;
+    } else {
+        const int f = atomicAdd(&o.sc->nFinishedStep, 1);
+        if (f < o.finCap) {
+            o.finKey[f] = ((long long) d << kRingIdxBits) | idx;
+            o.finVid[f] = vid;
+        } else {
+            o.sc->overflow = 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- phase 2
+// Engine::handleWaiting engine.cpp:502-516 + Lane::available roadnet.cpp:428-435, one thread per drivable (laneLink
+// threads write the gate records, as in the dense layout's k_admit).  The running count is raised here — the finish
+// statistics of this step (extra blocks of kr_commit) read it while kr_commit's other blocks commit the rest.
+__global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, DevScalars *sc) {
+    __shared__ int sAdmitted;
+    if (threadIdx.x == 0) sAdmitted = 0;
+    __syncthreads();
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= c.n.L && lane < c.n.L + c.n.K) {
+        const int k = lane - c.n.L;
+        int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+        c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);
+    } else if (lane < c.n.L) {
+        const int w = waitHead[lane];
+        const int n = c.cnt[lane];
+        const int2 geo = c.ringGeo[lane];
+        const int head = c.head[lane];
+        const int tail = ringSlot(geo, head, n - 1);
+        c.laneTail[lane] = n > 0 ? tail : -1;  // overwritten below if a vehicle is admitted
+        bool admit = w >= 0;
+        int wt = 0;
+        if (admit) {
+            wt = vt.templ[w];
+            if (n > 0 && !(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) admit = false;
+        }
+        if (admit && n >= geo.y) {  // the ring is full (cannot happen with capacities from the shortest vehicle): refuse loudly
+            sc->overflow = 8;
+            admit = false;
+        }
+        if (admit) {
+            const int slot = ringSlot(geo, head, n);
+            const int route = vt.route[w];
+            c.s.vid[slot] = w;
+            c.s.drv[slot] = lane;
+            c.s.prevDrv[slot] = -1;
+            c.s.next[slot] = nextOf(c.n, c.t, lane, route, 0);
+            c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
+            c.s.routePos[slot] = 0;
+            c.s.templ[slot] = wt;
+            c.s.route[slot] = route;
+            c.s.flags[slot] = vt.pendingCustom[w];
+            c.s.dis[slot] = 0.0;
+            c.s.speed[slot] = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
+            c.slotOf[w] = slot;
+            c.laneTail[lane] = slot;
+            c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
+            admitStep[lane] = c.step;  // cnt[] and the FIFO pop follow in kr_commit (see cntNow)
+            // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail, same decision)
+            if (!(c.n.laneGhost && c.n.laneGhost[lane])) atomicAdd(&sAdmitted, 1);
+        }
+    }
+    __syncthreads();
+    // Engine::activeVehicleCount: one global atomic per block (phase 4 of this very step counts the admitted vehicles)
+    if (threadIdx.x == 0 && sAdmitted) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) sAdmitted);
+}
+
+// ---------------------------------------------------------------------------------------------- phase 3 + 4
+// One wavefront per workgroup.  A wave owns a run of consecutive drivables (G lanes, or 64 laneLinks): its first lanes
+// read the rings' {base, cap, head, cnt} and the drivables' {length, max speed}, a wave-wide prefix sum turns the counts
+// into the wave's vehicle list, and the wave walks that list 63 vehicles at a time.  Each pass stages the window's
+// {dis, speed, template} in LDS; a vehicle's leader is the previous element of the window (lane 0 of a pass re-reads the
+// last vehicle of the previous pass for that purpose only), so leader/follower state is read from HBM once, coalesced.
+constexpr int kRingWave = 64;
+
+template <int G>
+__global__ __launch_bounds__(kRingWave) void kr_action(RingCtx c, RingOut o, JobQueue q, int nLaneWaves, int nLLWaves) {
+    const int w = (int) blockIdx.x, t = (int) threadIdx.x;
+    if (w >= nLaneWaves + nLLWaves) {  // trailing waves: the per-laneLink notify sources for the cross phase
+        llstate(c, (w - nLaneWaves - nLLWaves) * kRingWave + t);
+        return;
+    }
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    __shared__ int sPre[kRingWave + 1];
+    __shared__ int2 sGeo[kRingWave];
+    __shared__ int sHead[kRingWave];
+    __shared__ double2 sLM[kRingWave];
+    __shared__ double sDis[kRingWave], sSpeed[kRingWave];
+    __shared__ int sTempl[kRingWave];
+    const cfx_vehicle_template *tv = c.t.templ;
+    // ---- the wave's drivables
+    const bool laneWave = w < nLaneWaves;
+    const int g = laneWave ? G : kRingWave;
+    const int d0 = laneWave ? w * G : c.n.L + (w - nLaneWaves) * kRingWave;
+    const int dEnd = laneWave ? c.n.L : c.n.L + c.n.K;
+    const int dMine = d0 + t;
+    int n = 0;
+    if (t < g && dMine < dEnd) {
+        const int2 geo = c.ringGeo[dMine];
+        const int head = c.head[dMine];
+        n = c.cnt[dMine];
+        if (laneWave && c.admitStep[dMine] == c.step) n += 1;
+        sLM[t] = c.n.drvLM[dMine];
+        sGeo[t] = geo;
+        sHead[t] = head;
+    }
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = t; i < nd; i += kRingWave) dst[i] = src[i];
+        tv = sT;
+    }
+    int incl = n;
+    for (int off = 1; off < kRingWave; off <<= 1) {
+        const int up = __shfl_up(incl, off, kRingWave);
+        if (t >= off) incl += up;
+    }
+    sPre[t + 1] = incl;
+    if (t == 0) sPre[0] = 0;
+    __syncthreads();
+    const int T = sPre[kRingWave];
+    const PushJob push{q};
+    for (int qb = 0; qb < T; qb += kRingWave - 1) {
+        const int qv = qb + t - 1;  // lane 0 holds the vehicle ahead of the window (leader data only)
+        const bool valid = qv >= 0 && qv < T;
+        int i = 0, idx = 0, slot = 0;
+        SlotIn in;
+        in.vid = -1;
+        if (valid) {
+            // the drivable this list position belongs to: the last i with sPre[i] <= qv
+            int lo = 0, hi = g;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (sPre[mid] <= qv) lo = mid;
+                else hi = mid;
+            }
+            i = lo;
+            idx = qv - sPre[i];
+            slot = ringSlot(sGeo[i], sHead[i], idx);
+            in.dis = c.s.dis[slot];
+            in.speed = c.s.speed[slot];
+            in.templIdx = c.s.templ[slot];
+            if (t > 0) {
+                in.nd0 = c.s.next[slot];
+                in.flags = c.s.flags[slot];
+            }
+            sDis[t] = in.dis;
+            sSpeed[t] = in.speed;
+            sTempl[t] = in.templIdx;
+        }
+        __syncthreads();
+        if (valid && t > 0) {
+            in.vid = 0;  // (the vehicle number is loaded where it is needed: custom speed, leaving the drivable)
+            in.d = d0 + i;
+            in.head = idx == 0;
+            in.idx = idx;
+            in.leaderSlot = 0;
+            if (idx > 0) {
+                in.disPrev = sDis[t - 1];
+                in.speedPrev = sSpeed[t - 1];
+                in.templPrev = sTempl[t - 1];
+                in.leaderSlot = ringSlot(sGeo[i], sHead[i], idx - 1);
+            }
+            if (in.flags & 1) {
+                in.vid = c.s.vid[slot];
+                c.s.flags[slot] = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+            }
+            in.lm = sLM[i];
+            actionOne<false>(c, o, tv, slot, in, push);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- phase 5 + 6 + 8
+// Commit: one thread per drivable.  Leavers are (almost always) a prefix of the list: the head moves past them.  Entrants
+// are appended behind the stayers by descending new distance (std::sort with vehicleCmp engine.h:21-23; ties: lower vid
+// first, as in the twin).  Also commits the step's admission (FIFO pop, running count), Router::update of the entrants,
+// TrafficLight::passTime, and re-arms the step's scratch.  Extra blocks do the finish statistics in the reference's order.
+struct RingCommit {
+    int4 *scratch;
+    const MoverRec *movers;
+    int32_t *waitHead;
+    int32_t *curPhase;
+    double *remain;
+    int rlTrafficLight, nMaskWords;
+    DevScalars *sc;
+    const long long *finKey;
+    const int32_t *finVid;
+    double *finTerm;
+    int finCap;
+    int32_t *jobCount;
+    HostMirror *hostMirror;
+    int32_t *finTicket;
+    int nStatBlocks;
+    uint8_t *vStateW;
+};
+
+__device__ inline void ringCopySlot(const RingCtx &c, int from, int to) {  // general path only: one list element moves
+    c.s.vid[to] = c.s.vid[from];
+    c.s.drv[to] = c.s.drv[from];
+    c.s.prevDrv[to] = c.s.prevDrv[from];
+    c.s.next[to] = c.s.next[from];
+    c.s.enterLLT[to] = c.s.enterLLT[from];
+    c.s.routePos[to] = c.s.routePos[from];
+    c.s.templ[to] = c.s.templ[from];
+    c.s.route[to] = c.s.route[from];
+    c.s.flags[to] = c.s.flags[from];
+    c.blkW[to] = c.blkW[from];  // (the other buffer's records expire with this step)
+    c.disN[to] = c.disN[from];
+    c.speedN[to] = c.speedN[from];
+    c.slotOf[c.s.vid[from]] = to;
+}
+
+// The step's finish statistics (finishStatistics of the dense layout with 64-bit order keys): rank sort of the
+// finishers by (drivable, list index) = the order a one-thread reference removes them in (engine.cpp:296-310), travel
+// times added up in that order by one thread.
+__device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt, const RingCommit &k, int part, int nParts) {
+    __shared__ long long fin[kFinLds];
+    __shared__ double term[kFinLds];
+    __shared__ int lastShared;
+    DevScalars *sc = k.sc;
+    int F = sc->nFinishedStep;
+    if (F > k.finCap) F = k.finCap;
+    const double now = c.step * c.interval;
+    const bool inLds = nParts == 1 && F <= kFinLds;
+    const int per = (F + nParts - 1) / nParts;
+    const int lo = part * per, hi = min(F, lo + per);
+    for (int base = lo; base < hi; base += blockDim.x) {
+        const int i = base + (int) threadIdx.x;
+        const long long me = i < hi ? k.finKey[i] : 0;
+        int rank = 0;
+        for (int cb = 0; cb < F; cb += kFinLds) {
+            const int cn = min(kFinLds, F - cb);
+            __syncthreads();
+            for (int j = threadIdx.x; j < cn; j += blockDim.x) fin[j] = k.finKey[cb + j];
+            __syncthreads();
+            if (i < hi)
+                for (int j = 0; j < cn; ++j) rank += fin[j] < me;
+        }
+        if (i < hi) {
+            const int vid = k.finVid[i];
+            const double tt = now - vt.enterTime[vid];
+            k.vStateW[vid] = 2;
+            if (inLds) term[rank] = tt;
+            else k.finTerm[rank] = tt;
+        }
+    }
+    bool last = true;
+    if (nParts > 1) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) lastShared = atomicAdd(k.finTicket, 1) == nParts - 1;
+        __syncthreads();
+        last = lastShared != 0;
+        if (!last) return false;
+        if (threadIdx.x == 0) *k.finTicket = 0;
+        __threadfence();
+    }
+    double cum = sc->cumulativeTravelTime;
+    for (int cb = 0; cb < F; cb += kFinLds) {
+        const int cn = min(kFinLds, F - cb);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cn && !inLds; j += blockDim.x)
+            term[j] = __longlong_as_double((long long) __hip_atomic_load((const unsigned long long *) &k.finTerm[cb + j],
+                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int j = 0; j < cn; ++j) cum += term[j];
+    }
+    if (threadIdx.x == 0) {
+        sc->cumulativeTravelTime = cum;
+        sc->vehicleSteps += sc->active;
+        sc->finishedCnt += F;
+        sc->active -= F;
+        sc->nFinishedStep = 0;
+    }
+    return last;
+}
+
+__global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, VidTable vt) {
+    const int nBody = (int) gridDim.x - k.nStatBlocks;
+    if ((int) blockIdx.x >= nBody) {
+        const int part = (int) blockIdx.x - nBody;
+        if (part == 0 && threadIdx.x < kJobShards) k.jobCount[threadIdx.x * kJobShardStride] = 0;
+        const bool last = ringFinishStatistics(c, vt, k, part, k.nStatBlocks);
+        if (last && threadIdx.x == 0 && k.hostMirror) {
+            k.hostMirror->sc = *k.sc;
+            k.hostMirror->slots = (int32_t) k.sc->active;
+            __hip_atomic_store(&k.hostMirror->progress, ((unsigned long long) (c.step + 1) << 32) | (unsigned) k.sc->active,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = nBody * blockDim.x;
+    for (int i = gid; i < k.nMaskWords; i += stride) c.interMask[i] = 0ULL;
+    if (!k.rlTrafficLight) {
+        for (int i = gid; i < c.n.I; i += stride) {  // TrafficLight::passTime trafficlight.cpp:29-37
+            if (c.n.interVirtual[i]) continue;
+            const int ps = c.n.interPhaseStart[i];
+            const int np = c.n.interPhaseStart[i + 1] - ps;
+            double rem = k.remain[i] - c.interval;
+            int ph = k.curPhase[i];
+            while (rem <= 0.0) {
+                ph = (ph + 1) % np;
+                rem += c.n.phaseTime[ps + ph];
+            }
+            k.remain[i] = rem;
+            k.curPhase[i] = ph;
+        }
+    }
+    const int D = c.n.L + c.n.K;
+    for (int d = gid; d < D; d += stride) {
+        const int4 sc = k.scratch[d];  // {leavers, largest list index among them, entrant list, entrants}
+        const bool admitted = d < c.n.L && c.admitStep[d] == c.step;
+        if (!admitted && sc.x == 0 && sc.z < 0) continue;  // nothing happened on this drivable: nothing is written
+        const int2 geo = c.ringGeo[d];
+        int head = c.head[d];
+        int n = c.cnt[d];
+        if (admitted) {  // commit this step's admission (phase 2): the FIFO pop and the vehicle's state
+            const int2 rec = c.admitRec[d];
+            k.waitHead[d] = rec.y;
+            k.vStateW[rec.x] = 1;
+            n += 1;
+        }
+        if (sc.x > 0) {
+            if (sc.y + 1 != sc.x) {
+                // leavers are not a prefix of the list (a vehicle ran past the end of its drivable before the one ahead of
+                // it did): close the gaps, stayers keep their order and move towards the tail
+                int wr = n - 1;
+                for (int r = n - 1; r >= 0; --r) {
+                    const int from = ringSlot(geo, head, r);
+                    if (c.speedN[from] < 0.0) continue;
+                    if (wr != r) ringCopySlot(c, from, ringSlot(geo, head, wr));
+                    --wr;
+                }
+            }
+            head = (head + sc.x) & geo.y;
+            n -= sc.x;
+        }
+        int m = 0;
+        for (int e = sc.z; e >= 0; e = k.movers[e].nextIn) {
+            const MoverRec r = k.movers[e];
+            int rank = 0;
+            for (int f = sc.z; f >= 0; f = k.movers[f].nextIn) {
+                if (f == e) continue;
+                const double od = k.movers[f].dis;
+                rank += (od > r.dis) || (od == r.dis && k.movers[f].vid < r.vid);
+            }
+            ++m;
+            if (n + rank > geo.y) {  // the ring is full: refuse (reported as an error by the next cfx_step / getter)
+                k.sc->overflow = 8;
+                continue;
+            }
+            const int slot = ringSlot(geo, head, n + rank);
+            int rp = r.routePos;
+            c.s.vid[slot] = r.vid;
+            c.s.drv[slot] = d;
+            c.s.prevDrv[slot] = r.oldDrv;
+            c.s.templ[slot] = r.templ;
+            c.s.route[slot] = r.route;
+            c.s.flags[slot] = 0;
+            c.blkW[slot] = make_int2(r.blockerVid, c.step);
+            if (d < c.n.L) {  // Router::update router.cpp:78-94
+                c.s.enterLLT[slot] = CFX_INT_MAX;
+                const int base = c.t.routeStart[r.route], len = c.t.routeStart[r.route + 1] - base;
+                const int road = c.n.laneRoad[d];
+                while (rp < len && c.t.routeRoads[base + rp] != road) ++rp;
+            } else {
+                c.s.enterLLT[slot] = c.step;
+            }
+            c.s.routePos[slot] = rp;
+            c.s.next[slot] = nextOf(c.n, c.t, d, r.route, rp);
+            c.disN[slot] = r.dis;
+            c.speedN[slot] = r.speed;
+            c.slotOf[r.vid] = slot;
+        }
+        n += m;
+        if (n > geo.y) k.sc->overflow = 8;
+        else if (n + 8 > geo.y && geo.y >= 15) k.sc->ringNearFull = 1;
+        c.head[d] = head;
+        c.cnt[d] = n;
+        k.scratch[d] = make_int4(0, -1, -1, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- slow paths
+// Getters / archive / growth: the ring order as dense arrays (Drivable::vehicles order: by drivable, front to back).
+// `off` = exclusive prefix sum of cnt over drivables.
+struct RingDense {
+    int32_t *vid, *drv, *prevDrv, *blockerVid, *enterLLT, *routePos, *leaderVid;
+    uint8_t *flags;
+    double *dis, *speed, *gap;
+};
+
+__global__ void kr_gather(RingCtx c, const int32_t *off, RingDense out, int wantLeader) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= c.n.L + c.n.K) return;
+    const int n = c.cnt[d];
+    if (n == 0) return;
+    const int2 geo = c.ringGeo[d];
+    const int head = c.head[d], o = off[d];
+    for (int i = 0; i < n; ++i) {
+        const int s = ringSlot(geo, head, i);
+        out.vid[o + i] = c.s.vid[s];
+        out.drv[o + i] = d;
+        out.prevDrv[o + i] = c.s.prevDrv[s];
+        out.blockerVid[o + i] = blockerVid(c, s);
+        out.enterLLT[o + i] = c.s.enterLLT[s];
+        out.routePos[o + i] = c.s.routePos[s];
+        out.flags[o + i] = c.s.flags[s];
+        out.dis[o + i] = c.s.dis[s];
+        out.speed[o + i] = c.s.speed[s];
+        if (wantLeader) {
+            double gap = 0;
+            const int ls = findLeader(c, c.t.templ, s, d, i == 0, c.s.dis[s], c.t.templ[c.s.templ[s]].approach_dist, &gap);
+            out.leaderVid[o + i] = ls >= 0 ? c.s.vid[ls] : -1;
+            out.gap[o + i] = gap;
+        }
+    }
+}
+
+// The inverse (cfx_load_state, growth): dense arrays -> rings.  templ / route come from the vehicle table.
+__global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTable vt) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= c.n.L + c.n.K) return;
+    const int n = off[d + 1] - off[d];
+    c.head[d] = 0;
+    c.cnt[d] = n;
+    const int2 geo = c.ringGeo[d];
+    for (int i = 0; i < n; ++i) {
+        const int s = geo.x + i, j = off[d] + i;
+        const int v = in.vid[j];
+        const int route = vt.route[v];
+        c.s.vid[s] = v;
+        c.s.drv[s] = d;
+        c.s.prevDrv[s] = in.prevDrv[j];
+        c.s.enterLLT[s] = in.enterLLT[j];
+        c.s.routePos[s] = in.routePos[j];
+        c.s.templ[s] = vt.templ[v];
+        c.s.route[s] = route;
+        c.s.flags[s] = in.flags[j];
+        const_cast<int2 *>(c.blkR)[s] = make_int2(in.blockerVid[j], c.step - 1);
+        c.s.dis[s] = in.dis[j];
+        c.s.speed[s] = in.speed[j];
+        c.s.next[s] = nextOf(c.n, c.t, d, route, in.routePos[j]);
+        c.slotOf[v] = s;
+    }
+}
+
+__global__ void kr_reset(int D, int32_t *head, int32_t *cnt, int4 *scratch) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    head[d] = 0;
+    cnt[d] = 0;
+    scratch[d] = make_int4(0, -1, -1, 0);
+}
+
+__global__ void kr_lane_waiting(RingCtx c, int32_t *out) {  // Engine::getLaneWaitingVehicleCount engine.cpp:636-648
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= c.n.L) return;
+    const int2 geo = c.ringGeo[lane];
+    const int head = c.head[lane], n = c.cnt[lane];
+    int k = 0;
+    for (int i = 0; i < n; ++i) k += c.s.speed[ringSlot(geo, head, i)] < 0.1;
+    out[lane] = k;
+}
+
+// Vehicle::setCustomSpeed / Router::setRoute / lookup of one running vehicle: its slot is known
+__global__ void kr_set_speed(RingCtx c, int vid) {
+    const int s = c.slotOf[vid];
+    if (s >= 0) c.s.flags[s] |= 1;
+}
+__global__ void kr_set_route(RingCtx c, int vid, int route) {
+    const int s = c.slotOf[vid];
+    if (s < 0) return;
+    c.s.route[s] = route;
+    c.s.routePos[s] = 0;
+    c.s.next[s] = nextOf(c.n, c.t, c.s.drv[s], route, 0);
+}
+__global__ void kr_find_vehicle(RingCtx c, int vid, int32_t *out /*[2]: drivable, routePos*/) {
+    const int s = c.slotOf[vid];
+    if (s < 0) return;
+    out[0] = c.s.drv[s];
+    out[1] = c.s.routePos[s];
+}
+
+// Developer aid (cfx_config::debug_sync): invariants of the ring state between the action and the cross phase.
+// report[0] = first violation code (0 none), report[1..5] = context.
+__global__ void kr_validate(RingCtx c, JobQueue q, int nVid, int nRoutes, int ringSlots, int32_t *report) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = c.n.L + c.n.K;
+    auto bad = [&](int code, int a, int b, int cc, int dd) {
+        if (atomicCAS(&report[0], 0, code) == 0) {
+            report[1] = a;
+            report[2] = b;
+            report[3] = cc;
+            report[4] = dd;
+        }
+    };
+    if (gid < D) {
+        const int d = gid, n = cntNow(c, d);
+        const int2 geo = c.ringGeo[d];
+        if (n < 0 || n > geo.y + 1) bad(1, d, n, geo.y, 0);
+        for (int i = 0; i < n && i <= geo.y; ++i) {
+            const int s = ringSlot(geo, c.head[d], i);
+            if (c.s.drv[s] != d) bad(2, d, i, s, c.s.drv[s]);
+            if ((unsigned) c.s.templ[s] >= (unsigned) c.t.nTempl) bad(3, d, i, s, c.s.templ[s]);
+            if ((unsigned) c.s.vid[s] >= (unsigned) nVid) bad(4, d, i, s, c.s.vid[s]);
+            else if (c.slotOf[c.s.vid[s]] != s) bad(5, d, i, s, c.slotOf[c.s.vid[s]]);
+            if ((unsigned) c.s.route[s] >= (unsigned) nRoutes) bad(6, d, i, s, c.s.route[s]);
+            if (c.s.next[s] < -1 || c.s.next[s] >= D) bad(7, d, i, s, c.s.next[s]);
+            if (c.s.prevDrv[s] < -1 || c.s.prevDrv[s] >= D) bad(8, d, i, s, c.s.prevDrv[s]);
+            const int2 b = c.blkR[s];
+            if (b.x < -1 || b.x >= nVid) bad(9, d, i, s, b.x);
+        }
+    }
+    if (gid < c.n.K) {
+        const int4 dyn = c.llDyn[gid];
+        if (dyn.x < -1 || dyn.x >= ringSlots) bad(10, gid, dyn.x, 0, 0);
+        if (dyn.y < -1 || dyn.y >= ringSlots) bad(11, gid, dyn.y, 0, 0);
+        if (dyn.z < 0 || dyn.z >= ringSlots) bad(12, gid, dyn.z, dyn.w, 0);
+        if (dyn.w < 0 || dyn.w > c.ringGeo[c.n.L + gid].y + 1) bad(13, gid, dyn.w, 0, 0);
+    }
+    if (gid < kJobShards) {
+        const int n = min(q.count[gid * kJobShardStride], q.capacity);
+        for (int j = 0; j < n; ++j) {
+            const int s = q.jobs[(size_t) gid * q.capacity + j];
+            if ((unsigned) s >= (unsigned) ringSlots) bad(14, gid, j, s, n);
+            else if ((unsigned) c.s.drv[s] >= (unsigned) D) bad(15, gid, j, s, c.s.drv[s]);
+        }
+    }
+}
+
+}  // namespace cfxd
