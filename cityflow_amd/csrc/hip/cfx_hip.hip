@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -182,6 +183,18 @@ struct cfx_engine {
     int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
     void *rScanTemp = nullptr;
     size_t rScanTempBytes = 0;
+
+    // Are the interval, every enter time seen so far and the travel-time sum multiples of 2^-10 below 2^42?  Then the
+    // finish statistics need no order (exactFinishStatistics).  Sticky false once anything else shows up.
+    bool timesDyadic = true;
+    static bool dyadic(double x) { return x * 1024.0 == std::nearbyint(x * 1024.0) && std::fabs(x) < 4398046511104.0; }
+    bool exactTimes() const {
+        if (!timesDyadic) return false;
+        // the running sum: as of the last step the device has finished (pinned mirror) it must be far below the bound
+        const double cum = mirrorValid ? hMirror->sc.cumulativeTravelTime : cumLoaded;
+        return dyadic(cum) && cum < 1099511627776.0;
+    }
+    double cumLoaded = 0.0;  // cumulativeTravelTime of the last reset / cfx_load_state (valid until a step has run)
 
     int64_t step = 0;
     int64_t finishedKnown = 0;  // lower bound of finished vehicles (refreshed on syncs)
@@ -574,6 +587,8 @@ struct cfx_engine {
             HIP_TRY(hipMemsetAsync(lc.insCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.candAllCount, 0, sizeof(int32_t), stream));
         }
+        timesDyadic = dyadic(cfg.interval);
+        cumLoaded = 0.0;
         laneQueued.assign((size_t) L, 0);
         nQueueLanes = 0;
         spawnedHere = 0;
@@ -673,6 +688,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         return e->fail("cfx_create: layout ring does not run lane change (its mid-lane insertions use the dense layout)");
     e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change);
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
+    e->timesDyadic = cfx_engine::dyadic(cfg->interval);
     e->R = n->n_roads;
     e->L = n->n_lanes;
     e->K = n->n_lanelinks;
@@ -727,8 +743,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
     HIP_TRY(hipHostMalloc((void **) &e->hMirror, sizeof(HostMirror), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &e->hLaneOut, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
-    if ((rc = e->allocRaw(&e->finTicket, 1))) return rc;
-    HIP_TRY(hipMemset(e->finTicket, 0, sizeof(int32_t)));
+    if ((rc = e->allocRaw(&e->finTicket, 4))) return rc;  // [0] ticket, [2..3] 64-bit total of exactFinishStatistics
+    HIP_TRY(hipMemset(e->finTicket, 0, 4 * sizeof(int32_t)));
     if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->laneTail, (size_t) e->L))) return rc;
@@ -911,6 +927,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     //       waiting queues grow without bound (they hold vehicle-table entries, not slots).
     // When the smaller of the two outgrows the buffers, the true count is read back and the buffers grow only if needed.
     for (int i = 0; i < n; ++i) {
+        if (!cfx_engine::dyadic(recs[i].enter_time)) e->timesDyadic = false;
         const int lane = recs[i].lane;
         if (lane >= 0 && !e->laneQueued[lane]) {
             e->laneQueued[lane] = 1;
@@ -940,14 +957,21 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         RingOut ro{c.disN, c.speedN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
         {
-            // lanes per wave: few on small networks (one pass per wave), more on large ones (fewer, fuller waves)
-            const int G = e->L <= 16384 ? 4 : (e->L <= 131072 ? 8 : 16);
+            // lanes per wave: few on small networks (every wave finishes its lanes in one pass: the step is bound by the
+            // slowest wave's chain of dependent loads), more on large ones (fewer, fuller waves: bandwidth)
+            int G = e->L <= 32768 ? 1 : (e->L <= 131072 ? 4 : 8);
+            const int want = e->cfg.ring_lanes_per_wave;
+            if (want == 1 || want == 2 || want == 4 || want == 8 || want == 16) G = want;
             const int nLaneWaves = (e->L + G - 1) / G, nLLWaves = (e->K + kRingWave - 1) / kRingWave;
             const int nLLBlocks = (e->K + kRingWave - 1) / kRingWave;
             const dim3 grid(nLaneWaves + nLLWaves + nLLBlocks), block(kRingWave);
-            if (G == 4) e->launch(PK_ACTION, kr_action<4>, grid, block, c, ro, jq, nLaneWaves, nLLWaves);
-            else if (G == 8) e->launch(PK_ACTION, kr_action<8>, grid, block, c, ro, jq, nLaneWaves, nLLWaves);
-            else e->launch(PK_ACTION, kr_action<16>, grid, block, c, ro, jq, nLaneWaves, nLLWaves);
+            switch (G) {
+            case 1: e->launch(PK_ACTION, kr_action<1>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
+            case 2: e->launch(PK_ACTION, kr_action<2>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
+            case 4: e->launch(PK_ACTION, kr_action<4>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
+            case 8: e->launch(PK_ACTION, kr_action<8>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
+            default: e->launch(PK_ACTION, kr_action<16>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
+            }
         }
         RING_CHECK("kr_action")
         if (dbg) {
@@ -976,7 +1000,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const int nStat = (int) std::min<size_t>(std::max<size_t>(1, activeEst >> 16), 64);
         RingCommit rk{e->rScratch, e->rMovers, e->waitHead, e->curPhase, e->remain, (int) e->cfg.rl_traffic_light, (int) e->nMaskWords,
                       e->sc, e->rFinKey, e->rFinVid, e->rFinTerm, e->rFinCap, e->jobCount,
-                      e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat, e->vt.state};
+                      e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat, e->vt.state, e->exactTimes() ? 1 : 0};
         e->launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
         RING_CHECK("kr_commit")
 #undef RING_CHECK
@@ -1087,7 +1111,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, e->ab,
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
-              e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat);
+              e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat,
+              e->exactTimes() ? 1 : 0);
     if (e->lc.on)
         hipLaunchKernelGGL(k_lc_clear, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, e->lc, (const int32_t *) e->gen[nxt].vid,
                            (const int32_t *) e->segStart[nxt].p, (int) e->D);
@@ -1737,6 +1762,9 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     sc.finishedCnt = s->finished_vehicle_count;
     sc.cumulativeTravelTime = s->cumulative_travel_time;
     sc.vehicleSteps = s->vehicle_steps;
+    e->cumLoaded = s->cumulative_travel_time;
+    for (int v = 0; v < nV; ++v)
+        if (s->v_state[v] != 2 && !cfx_engine::dyadic(s->v_enter_time[v])) e->timesDyadic = false;
     HIP_TRY(up(e->sc, &sc, sizeof sc));
     e->step = s->step;
     e->spawned = nV;

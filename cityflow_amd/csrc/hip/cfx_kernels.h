@@ -924,18 +924,142 @@ __device__ inline int blockReduceSum(int v, int *smem) {
     return tot;
 }
 
+// cumulativeTravelTime += the step's travel times IN THE REFERENCE'S ORDER (term[] / finTerm[] hold them in that order).
+// FP64 addition is not associative, so in general one thread has to add them one after the other.  But when the running
+// sum and every term are multiples of 2^-10 and everything stays below 2^42 (interval 1.0, 0.5, ...: practically always),
+// every partial sum of every order is exactly representable: no addition rounds, and the sum is the same in ANY order —
+// then the whole block adds integers in parallel.  (Thousands of vehicles finish per step on large networks; the
+// sequential tail was the longest single chain of the step.)  Executed by one whole block; returns the new sum.
+__device__ inline double orderedSum(double cum, int F, double *term, const double *finTerm, bool inLds) {
+    __shared__ long long sAcc[kBlock / 64];
+    __shared__ int sBad[kBlock / 64];
+    auto load = [&](int j) {
+        return inLds ? term[j]
+                     : __longlong_as_double((long long) __hip_atomic_load((const unsigned long long *) &finTerm[j],
+                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    const double lim = 4398046511104.0 * 1024.0;  // 2^42 in units of 2^-10
+    long long acc = 0;
+    int bad = 0;
+    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+        const double sv = load(j) * 1024.0;
+        if (sv == rint(sv) && fabs(sv) < lim) acc += (long long) fabs(sv);
+        else bad = 1;
+    }
+    const double cs = cum * 1024.0;
+    if (!(cs == rint(cs) && fabs(cs) < lim)) bad = 1;
+    for (int off = 32; off > 0; off >>= 1) {
+        acc += __shfl_down(acc, off, 64);
+        bad |= __shfl_down(bad, off, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sAcc[threadIdx.x >> 6] = acc;
+        sBad[threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    long long absTotal = 0;
+    bad = 0;
+    for (int i = 0; i < (int) (blockDim.x >> 6); ++i) {
+        absTotal += sAcc[i];
+        bad |= sBad[i];
+    }
+    if (!bad && (double) absTotal + fabs(cs) < lim) {
+        // travel times are never negative, so the sum of magnitudes IS the sum (a negative term would have set `bad`
+        // through the comparison below); kept general: recompute signed when any term is negative
+        long long total = 0;
+        for (int j = threadIdx.x; j < F; j += blockDim.x) total += (long long) (load(j) * 1024.0);
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sAcc[threadIdx.x >> 6] = total;
+        __syncthreads();
+        total = 0;
+        for (int i = 0; i < (int) (blockDim.x >> 6); ++i) total += sAcc[i];
+        return (double) ((long long) cs + total) / 1024.0;
+    }
+    // the general case: one thread, in order (the loads run ahead of the dependent additions)
+    __shared__ double sCum;
+    if (threadIdx.x == 0) {
+        int j = 0;
+        for (; j + 4 <= F; j += 4) {
+            const double a = load(j), b = load(j + 1), c2 = load(j + 2), d2 = load(j + 3);
+            cum += a;
+            cum += b;
+            cum += c2;
+            cum += d2;
+        }
+        for (; j < F; ++j) cum += load(j);
+        sCum = cum;
+    }
+    __syncthreads();
+    return sCum;
+}
+
+// Order-free finish statistics.  The host keeps track of whether the interval, every vehicle's enter time and the running
+// sum are multiples of 2^-10 below 2^42 (cfx_engine::timesDyadic; interval 1.0, 0.5, ...: practically always).  Then every
+// partial sum of the travel times is exactly representable in any order, no addition ever rounds, and the reference's
+// sequential FP64 sum equals the integer sum: no rank sort, no ordered tail — the blocks add integers and the last one to
+// arrive (ticket) folds the total into cumulativeTravelTime.  `finTicket[0]` = ticket, `finTicket[2..3]` = 64-bit total.
+template <class VidAt>
+__device__ inline bool exactFinishStatistics(double now, const VidTable &vt, DevScalars *sc, int F, VidAt vidAt, uint8_t *stateW,
+                                             int32_t *finTicket, int part, int nParts, int nUncounted) {
+    __shared__ long long sAcc[kBlock / 64];
+    __shared__ int lastShared;
+    const int per = (F + nParts - 1) / nParts;
+    const int lo = part * per, hi = min(F, lo + per);
+    long long acc = 0;
+    for (int i = lo + (int) threadIdx.x; i < hi; i += blockDim.x) {
+        const int vid = vidAt(i);
+        if (stateW) stateW[vid] = 2;
+        acc += (long long) ((now - vt.enterTime[vid]) * 1024.0);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sAcc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    long long total = 0;
+    for (int i = 0; i < (int) (blockDim.x >> 6); ++i) total += sAcc[i];
+    unsigned long long *accum = (unsigned long long *) (finTicket + 2);
+    if (nParts > 1) {
+        if (threadIdx.x == 0) {
+            atomicAdd(accum, (unsigned long long) total);
+            __threadfence();
+            lastShared = atomicAdd(finTicket, 1) == nParts - 1;
+        }
+        __syncthreads();
+        if (!lastShared) return false;
+        if (threadIdx.x == 0) {
+            __threadfence();
+            total = (long long) __hip_atomic_load(accum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *accum = 0ULL;
+            *finTicket = 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        sc->cumulativeTravelTime = (double) ((long long) (sc->cumulativeTravelTime * 1024.0) + total) / 1024.0;
+        sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
+        sc->finishedCnt += F;
+        sc->active -= F + nUncounted;
+        sc->nFinishedStep = 0;
+        sc->nLeftUncounted = 0;
+    }
+    return true;
+}
+
 // The step's finish statistics in the reference's order (threadUpdateLocation with one thread walks
 // drivables in RoadNet order, lists front to back, i.e. ascending slot; engine.cpp:296-310): rank sort of the
 // finished slots in LDS, then one thread adds the travel times in that order (FP64 addition is not
 // associative; the reference adds sequentially).  Executed by one whole block.
 __device__ inline bool finishStatistics(const StepCtx &c, const VidTable &vt, DevScalars *sc, const int32_t *finList,
-                                        double *finTerm, int finCap, int32_t *finTicket, int part, int nParts) {
+                                        double *finTerm, int finCap, int32_t *finTicket, int part, int nParts, int exactTimes) {
     __shared__ int fin[kFinLds];
     __shared__ double term[kFinLds];
     __shared__ int lastShared;
     int F = sc->nFinishedStep;
     if (F > finCap) F = finCap;
     const double now = c.step * c.interval;  // Engine::getCurrentTime engine.cpp:678-680
+    if (exactTimes)
+        return exactFinishStatistics(now, vt, sc, F, [&](int i) { return c.s.vid[finList[i]]; }, nullptr, finTicket, part, nParts,
+                                     sc->nLeftUncounted);
     // this block ranks finishers [lo, hi); every block walks the whole list, chunk by chunk through LDS
     const bool inLds = nParts == 1 && F <= kFinLds;  // the common case never leaves the block
     const int per = (F + nParts - 1) / nParts;
@@ -969,17 +1093,8 @@ __device__ inline bool finishStatistics(const StepCtx &c, const VidTable &vt, De
         if (threadIdx.x == 0) *finTicket = 0;
         __threadfence();
     }
-    double cum = sc->cumulativeTravelTime;
-    for (int cb = 0; cb < F; cb += kFinLds) {
-        const int cn = min(kFinLds, F - cb);
-        __syncthreads();
-        for (int j = threadIdx.x; j < cn && !inLds; j += blockDim.x)
-            term[j] = __longlong_as_double((long long) __hip_atomic_load((const unsigned long long *) &finTerm[cb + j],
-                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int j = 0; j < cn; ++j) cum += term[j];
-    }
+    __syncthreads();
+    const double cum = orderedSum(sc->cumulativeTravelTime, F, term, finTerm, inLds);
     if (threadIdx.x == 0) {
         sc->cumulativeTravelTime = cum;
         sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
@@ -1120,14 +1235,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
 __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
                           int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, double *finTerm,
-                          int finCap, int32_t *jobCount, HostMirror *hostMirror, int32_t *finTicket, int nStatBlocks) {
+                          int finCap, int32_t *jobCount, HostMirror *hostMirror, int32_t *finTicket, int nStatBlocks,
+                          int exactTimes) {
     // The launch carries extra blocks that only do the step's finish statistics (they read just the current
     // generation and the finish list, both complete before this kernel starts), in parallel with the compaction.
     const int nBody = (int) gridDim.x - nStatBlocks;
     if ((int) blockIdx.x >= nBody) {
         const int part = (int) blockIdx.x - nBody;
         if (part == 0 && threadIdx.x < kJobShards) jobCount[threadIdx.x * kJobShardStride] = 0;  // k_cross of this step is done
-        const bool last = finishStatistics(c, vt, sc, finList, finTerm, finCap, finTicket, part, nStatBlocks);
+        const bool last = finishStatistics(c, vt, sc, finList, finTerm, finCap, finTicket, part, nStatBlocks, exactTimes);
         if (last && threadIdx.x == 0 && hostMirror) {
             // the step's scalars and slot count, also left in pinned host memory: a getter then needs the stream
             // synchronisation only, not a device-to-host copy on top of it

@@ -354,6 +354,7 @@ struct RingCommit {
     int32_t *finTicket;
     int nStatBlocks;
     uint8_t *vStateW;
+    int exactTimes;  // every time involved is a multiple of 2^-10: the travel-time sum is order-free (exactFinishStatistics)
 };
 
 __device__ inline void ringCopySlot(const RingCtx &c, int from, int to) {  // general path only: one list element moves
@@ -383,6 +384,8 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
     int F = sc->nFinishedStep;
     if (F > k.finCap) F = k.finCap;
     const double now = c.step * c.interval;
+    if (k.exactTimes)
+        return exactFinishStatistics(now, vt, sc, F, [&](int i) { return k.finVid[i]; }, k.vStateW, k.finTicket, part, nParts, 0);
     const bool inLds = nParts == 1 && F <= kFinLds;
     const int per = (F + nParts - 1) / nParts;
     const int lo = part * per, hi = min(F, lo + per);
@@ -417,17 +420,8 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
         if (threadIdx.x == 0) *k.finTicket = 0;
         __threadfence();
     }
-    double cum = sc->cumulativeTravelTime;
-    for (int cb = 0; cb < F; cb += kFinLds) {
-        const int cn = min(kFinLds, F - cb);
-        __syncthreads();
-        for (int j = threadIdx.x; j < cn && !inLds; j += blockDim.x)
-            term[j] = __longlong_as_double((long long) __hip_atomic_load((const unsigned long long *) &k.finTerm[cb + j],
-                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int j = 0; j < cn; ++j) cum += term[j];
-    }
+    __syncthreads();
+    const double cum = orderedSum(sc->cumulativeTravelTime, F, term, k.finTerm, inLds);
     if (threadIdx.x == 0) {
         sc->cumulativeTravelTime = cum;
         sc->vehicleSteps += sc->active;

@@ -108,6 +108,7 @@ EngineConfig readEngineConfig(const std::string &configFile) {
             c.layout = choice("layout", {"auto", "dense", "ring"});
             c.debugSync = x->boolAt("debugSync", false) ? 1 : 0;
             if (x->find("device")) c.device = x->intAt("device");
+            if (x->find("ringLanesPerWave")) c.ringLanesPerWave = x->intAt("ringLanesPerWave");
             c.exactShadowPeek = x->boolAt("exactShadowPeek", false);
             if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
         }
@@ -124,6 +125,7 @@ void EngineConfig::apply(cfx_config &cc) const {
     cc.cross_mode = crossMode;
     cc.layout = layout;
     cc.debug_sync = debugSync;
+    cc.ring_lanes_per_wave = ringLanesPerWave;
     cc.device = 0;
     // one process per GPU under torch.distributed.run: the launcher's LOCAL_RANK names the device
     if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);

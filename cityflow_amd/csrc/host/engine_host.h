@@ -176,7 +176,7 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
     int seed = 0;
     std::string dir, roadnetFile, flowFile;
     // optional "cfx" object (ignored by the reference): implementation choices that never change results
-    int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1;
+    int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0;
     bool exactShadowPeek = false;  // host: Spawner::exactPeekOnly
     int hostThreads = -1;          // VectorEngine: worker threads for the per-environment host work (-1 auto, 0 serial)
     void apply(cfx_config &cc) const;  // interval, flags, the choices above, device (config > CITYFLOW_AMD_DEVICE > LOCAL_RANK)

@@ -124,3 +124,19 @@ def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_
         tw.next_step()
         if s % 4 == 3 or s == twin_steps - 1:
             assert_same_state(hip, tw, "%dx%d %s step %d after the transfer" % (n, n, layout, s + 1))
+
+
+@pytest.mark.parametrize("layout", ["dense", "ring"])
+@pytest.mark.parametrize("interval,steps", [(0.3, 2000), (0.7, 900)])
+def test_travel_time_sum_keeps_the_reference_order(mod, scen, workdir, interval, steps, layout):
+    """cumulativeTravelTime is a running FP64 sum in removal order (engine.cpp:296-310).  With interval 1.0 / 0.5 every
+    partial sum is exact and the device adds in parallel; an interval that is not a multiple of 2^-10 sends it down the
+    strictly ordered path — both must give the twin's bits."""
+    hip, tw = _pair(mod, scen.materialize("grid_6x6", workdir, interval=interval), layout=layout)
+    for s in range(steps):
+        hip.next_step()
+        tw.next_step()
+        if s % 50 == 49:
+            assert_same_state(hip, tw, "interval %s (%s) step %d" % (interval, layout, s + 1))
+    assert hip._scalars()["finished_vehicle_count"] > 100
+    assert hip.get_average_travel_time() == tw.get_average_travel_time()
