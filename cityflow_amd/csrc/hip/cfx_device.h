@@ -240,6 +240,30 @@ struct SegWalk {  // slots of one drivable from a starting slot towards the tail
 };
 __device__ __forceinline__ SegWalk segWalk(const StepCtx &, int, int first) { return SegWalk{first, 0, -1}; }
 
+// "The last vehicle of a drivable" as its readers need it: the head-of-drivable leader search, Lane::canEnter and the
+// notify sources of a laneLink all look at a drivable's tail {slot, template, where it came from, dis, speed}.  The dense
+// layout gathers these through the slot; the ring layout keeps a 32-byte record per drivable (cfx_ring_kernels.h).
+struct Tail {
+    int slot, templ, prevDrv;  // slot < 0: the drivable is empty
+    double dis, speed;
+};
+__device__ __forceinline__ Tail tailAt(const StepCtx &c, int slot) {
+    Tail t{slot, 0, -1, 0.0, 0.0};
+    if (slot >= 0) {
+        t.templ = c.s.templ[slot];
+        t.prevDrv = c.s.prevDrv[slot];
+        t.dis = c.s.dis[slot];
+        t.speed = c.s.speed[slot];
+    }
+    return t;
+}
+// Drivable::getLastVehicle as phases 3 / 4 see it (this step's admission included)
+__device__ __forceinline__ Tail tailNowOf(const StepCtx &c, int d) { return tailAt(c, d < c.n.L ? c.laneTail[d] : lastSlot(c, d)); }
+// ... and as the leader search saw it (lastSlotForLeader)
+__device__ __forceinline__ Tail tailForLeader(const StepCtx &c, int d, bool viewerNew, int viewerLane) {
+    return tailAt(c, lastSlotForLeader(c, d, viewerNew, viewerLane));
+}
+
 // ControllerInfo::blocker of the vehicle in `slot`, as a current-generation slot (-1 none).
 __device__ __forceinline__ int blockerOf(const StepCtx &c, int slot) {
     int b = c.s.blocker[slot];

@@ -172,12 +172,16 @@ struct cfx_engine {
     double *rDis[2] = {nullptr, nullptr}, *rSpeed[2] = {nullptr, nullptr};  // the two generations a step alternates
     int rcur = 0;
     int2 *rBlk[2] = {nullptr, nullptr};  // by step parity
+    TailRec *rTail[2] = {nullptr, nullptr}, *rTailNow = nullptr;  // [D] per-drivable tail records (by step parity; this step's view)
     MoverRec *rMovers = nullptr;
     long long *rFinKey = nullptr;
     int32_t *rFinVid = nullptr;
     double *rFinTerm = nullptr;
     int rFinCap = 0, rJobCap = 0;
     int32_t *rJobs = nullptr;
+    RingJob *rJobRecs = nullptr;
+    LLAux *rLLAux = nullptr;
+    int4 *rLLGate = nullptr;
     RingDense rd{};                    // dense staging view (getters, archive, growth)
     size_t rdCap = 0;
     int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
@@ -419,8 +423,12 @@ struct cfx_engine {
 
 
     // ------------------------------------------------------------------------------------------ ring layout
-    RingCtx rctx() const {
+    RingCtx rctx(bool stepping = false) const {
         RingCtx c{};
+        c.tailR = rTail[(step + 1) & 1];
+        c.tailW = rTail[step & 1];
+        c.tailNow = rTailNow;
+        c.betweenSteps = stepping ? 0 : 1;
         c.n = net;
         c.t.templ = dTempl.p;
         c.t.nTempl = (int) hTempl.size();
@@ -446,7 +454,8 @@ struct cfx_engine {
         c.vCustomSpeed = vt.customSpeed;
         c.llDyn = llDyn;
         c.interMask = interMask;
-        c.llGate = llGate;
+        c.llGate = rLLGate;
+        c.llAux = rLLAux;
         c.laneTail = laneTail;
         c.admitRec = admitRec;
         c.step = (int32_t) step;
@@ -466,7 +475,7 @@ struct cfx_engine {
         rc |= freeRaw(&rs.vid) | freeRaw(&rs.drv) | freeRaw(&rs.prevDrv) | freeRaw(&rs.next) | freeRaw(&rs.enterLLT) |
               freeRaw(&rs.routePos) | freeRaw(&rs.templ) | freeRaw(&rs.route) | freeRaw(&rs.flags) | freeRaw(&rBlk[0]) | freeRaw(&rBlk[1]) |
               freeRaw(&rDis[0]) | freeRaw(&rDis[1]) | freeRaw(&rSpeed[0]) | freeRaw(&rSpeed[1]) | freeRaw(&rMovers) |
-              freeRaw(&dRingGeo) | freeRaw(&rJobs);
+              freeRaw(&dRingGeo) | freeRaw(&rJobs) | freeRaw(&rJobRecs);
         return rc ? CFX_ERR_DEVICE : CFX_OK;
     }
     // Ring capacities: a drivable of length len holds at most ~len / (shortest vehicle) vehicles bumper to bumper; a few
@@ -500,11 +509,17 @@ struct cfx_engine {
         if ((rc = upload(&dRingGeo, hRingGeo.data(), hRingGeo.size()))) return rc;
         rJobCap = (int) std::max<size_t>(4096, ringSlots / 8);
         if ((rc = allocRaw(&rJobs, (size_t) rJobCap * kJobShards))) return rc;
+        if ((rc = allocRaw(&rJobRecs, (size_t) rJobCap * kJobShards))) return rc;
         if (!rHead) {
             if ((rc = allocRaw(&rHead, (size_t) D + 1))) return rc;
             if ((rc = allocRaw(&rCnt, (size_t) D + 1))) return rc;
             if ((rc = allocRaw(&rOff, (size_t) D + 2))) return rc;
             if ((rc = allocRaw(&rScratch, (size_t) D))) return rc;
+            if ((rc = allocRaw(&rTail[0], (size_t) D))) return rc;
+            if ((rc = allocRaw(&rTail[1], (size_t) D))) return rc;
+            if ((rc = allocRaw(&rTailNow, (size_t) D))) return rc;
+            if ((rc = allocRaw(&rLLAux, (size_t) K))) return rc;
+            if ((rc = allocRaw(&rLLGate, (size_t) K))) return rc;
             rFinCap = std::max(1 << 16, L * 8);
             if ((rc = allocRaw(&rFinKey, (size_t) rFinCap))) return rc;
             if ((rc = allocRaw(&rFinVid, (size_t) rFinCap))) return rc;
@@ -563,6 +578,8 @@ struct cfx_engine {
         if ((rc = ringAllocate(minLen))) return rc;
         ringBuilt = true;
         hipLaunchKernelGGL(kr_reset, dim3(gridFor(D)), dim3(kBlock), 0, stream, D, rHead, rCnt, rScratch);
+        HIP_TRY(hipMemsetAsync(rTail[0], 0xFF, (size_t) D * sizeof(TailRec), stream));  // slot -1: empty
+        HIP_TRY(hipMemsetAsync(rTail[1], 0xFF, (size_t) D * sizeof(TailRec), stream));
         if (total) {
             hipLaunchKernelGGL(kr_scatter_in, dim3(gridFor(D)), dim3(kBlock), 0, stream, rctx(), (const int32_t *) rOff, rd, vt);
             const int zero = 0;
@@ -619,6 +636,8 @@ struct cfx_engine {
         }
         if (ring && ringBuilt) {
             hipLaunchKernelGGL(kr_reset, dim3(gridFor(D)), dim3(kBlock), 0, stream, D, rHead, rCnt, rScratch);
+            HIP_TRY(hipMemsetAsync(rTail[0], 0xFF, (size_t) D * sizeof(TailRec), stream));
+            HIP_TRY(hipMemsetAsync(rTail[1], 0xFF, (size_t) D * sizeof(TailRec), stream));
             // blocker records carry step numbers, which start over
             HIP_TRY(hipMemsetAsync(rBlk[0], 0xFF, ringSlots * sizeof(int2), stream));
             HIP_TRY(hipMemsetAsync(rBlk[1], 0xFF, ringSlots * sizeof(int2), stream));
@@ -939,7 +958,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
 
     if (e->ring) {
         // ---- ring layout: admit, action (+ notify sources), cross, commit — no scan, no scatter
-        RingCtx c = e->rctx();
+        RingCtx c = e->rctx(true);
         const bool dbg = e->cfg.debug_sync != 0;  // developer aid: name the kernel that faults
 #define RING_CHECK(name)                                                                                          \
     if (dbg) {                                                                                                    \
@@ -957,20 +976,19 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         RingOut ro{c.disN, c.speedN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
         {
-            // lanes per wave: few on small networks (every wave finishes its lanes in one pass: the step is bound by the
-            // slowest wave's chain of dependent loads), more on large ones (fewer, fuller waves: bandwidth)
-            int G = e->L <= 32768 ? 1 : (e->L <= 131072 ? 4 : 8);
+            // One workgroup = 256 threads over G lanes (or 256 laneLinks): G is picked so that a block's vehicles fit one
+            // pass (255) with room for uneven lanes; `ring_lanes_per_wave` overrides it (developer knob).
+            int G = 16;
             const int want = e->cfg.ring_lanes_per_wave;
-            if (want == 1 || want == 2 || want == 4 || want == 8 || want == 16) G = want;
-            const int nLaneWaves = (e->L + G - 1) / G, nLLWaves = (e->K + kRingWave - 1) / kRingWave;
-            const int nLLBlocks = (e->K + kRingWave - 1) / kRingWave;
-            const dim3 grid(nLaneWaves + nLLWaves + nLLBlocks), block(kRingWave);
+            if (want == 4 || want == 8 || want == 16 || want == 32) G = want;
+            constexpr int B = 256;
+            const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + B - 1) / B;
+            const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(B);
             switch (G) {
-            case 1: e->launch(PK_ACTION, kr_action<1>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
-            case 2: e->launch(PK_ACTION, kr_action<2>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
-            case 4: e->launch(PK_ACTION, kr_action<4>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
-            case 8: e->launch(PK_ACTION, kr_action<8>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
-            default: e->launch(PK_ACTION, kr_action<16>, grid, block, c, ro, jq, nLaneWaves, nLLWaves); break;
+            case 4: e->launch(PK_ACTION, kr_action<B, 4>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
+            case 8: e->launch(PK_ACTION, kr_action<B, 8>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
+            case 32: e->launch(PK_ACTION, kr_action<B, 32>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
+            default: e->launch(PK_ACTION, kr_action<B, 16>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
             }
         }
         RING_CHECK("kr_action")
@@ -993,9 +1011,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
                       dim3(kCross2Block), c, ro, jq);
         else
-            e->launch(PK_CROSS, k_cross<false, RingCtx, RingOut>,
+            e->launch(PK_CROSS, kr_cross,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
-                      dim3(kCrossBlock), c, ro, jq);
+                      dim3(kCrossBlock), c, ro, jq, (const RingJob *) e->rJobRecs);
         RING_CHECK("k_cross")
         const int nStat = (int) std::min<size_t>(std::max<size_t>(1, activeEst >> 16), 64);
         RingCommit rk{e->rScratch, e->rMovers, e->waitHead, e->curPhase, e->remain, (int) e->cfg.rl_traffic_light, (int) e->nMaskWords,

@@ -23,7 +23,28 @@
 
 #include "cfx_kernels.h"
 
+
 namespace cfxd {
+
+// The last vehicle of a drivable, kept as ONE 32-byte record so that its readers — the leader search of every head of a
+// drivable, Lane::canEnter, the admission check, the notify sources — do one load instead of a chain through
+// {ring geometry, head, count} -> slot -> {dis, speed, template}.  `tag` is the step the record was written in: a record is
+// the truth about the END of step `tag`, so "tag != step - 1" means nobody wrote one last step = the drivable was empty
+// (every non-empty drivable's tail vehicle rewrites it every step; kr_commit does where the tail changed hands).
+struct TailRec {
+    double dis, speed;
+    int32_t slot, templ, prevDrv, tag;
+};
+static_assert(sizeof(TailRec) == 32, "tail record layout");
+
+// Per-laneLink notify sources beyond llDyn = {u, f, first vehicle on the laneLink, vehicles on it}: the state of u (the
+// vehicle that just left onto the end lane) and f (the approaching vehicle on the start lane) and the two lengths the
+// distances are measured with, so that a cross resolves "who was I notified of" from two records.
+struct LLAux {
+    double uDis, uSpeed, fDis, fSpeed, llLen, startLen;
+    int32_t uTempl, fTempl;
+};
+static_assert(sizeof(LLAux) == 56, "laneLink aux record layout");
 
 struct RingCtx {
     DevNet n;
@@ -38,6 +59,12 @@ struct RingCtx {
     int32_t *slotOf;         // [vid] slot of a running vehicle (-1: not on this engine)
     const uint8_t *vState;   // [vid] 0 waiting, 1 running, 2 finished
     const int2 *ringGeo;     // [D] {base, cap - 1}
+    // tails: two buffers by step parity (a step reads what the previous one left in tailR and writes tailW), plus the view
+    // of THIS step after its admissions (written by kr_admit for every drivable, valid while the step runs)
+    const TailRec *tailR;
+    TailRec *tailW;
+    TailRec *tailNow;
+    int betweenSteps;        // getters: no admission is pending, tailNow is stale — the committed records are the tails
     int32_t *head;           // [D] ring index of the front vehicle
     int32_t *cnt;            // [D] live vehicles (this step's admission excluded until kr_commit, see cntNow)
     const int32_t *admitStep;
@@ -45,8 +72,9 @@ struct RingCtx {
     const int32_t *vPriority;
     const double *vCustomSpeed;
     int4 *llDyn;
+    struct LLAux *llAux;     // [K] what a cross needs of a laneLink's notify sources beyond llDyn (written where active)
     unsigned long long *interMask;
-    int2 *llGate;
+    int4 *llGate;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
     int32_t *laneTail;
     int2 *admitRec;
     int32_t step;
@@ -68,6 +96,19 @@ __device__ __forceinline__ int lastSlotForLeader(const RingCtx &c, int d, bool v
     int n = c.cnt[d];
     if (viewerNew && d < viewerLane && d < c.n.L && c.admitStep[d] == c.step) n += 1;
     return n > 0 ? ringSlot(c.ringGeo[d], c.head[d], n - 1) : -1;
+}
+__device__ __forceinline__ Tail tailOfRec(const TailRec &r) { return Tail{r.slot, r.templ, r.prevDrv, r.dis, r.speed}; }
+__device__ __forceinline__ Tail tailCommitted(const RingCtx &c, int d) {  // Drivable::getLastVehicle after the last commit
+    const TailRec r = c.tailR[d];
+    Tail t = tailOfRec(r);
+    if (r.tag != c.step - 1) t.slot = -1;
+    return t;
+}
+__device__ __forceinline__ Tail tailNowOf(const RingCtx &c, int d) {
+    return c.betweenSteps ? tailCommitted(c, d) : tailOfRec(c.tailNow[d]);
+}
+__device__ __forceinline__ Tail tailForLeader(const RingCtx &c, int d, bool viewerNew, int viewerLane) {
+    return (viewerNew && d < viewerLane && d < c.n.L) ? tailNowOf(c, d) : tailCommitted(c, d);
 }
 __device__ __forceinline__ int slotAhead(const RingCtx &c, int d, int s) {
     const int2 geo = c.ringGeo[d];
@@ -122,23 +163,35 @@ constexpr int kRingIdxBits = 20;  // list index inside a drivable (ring capaciti
 // leave a MoverRec / a finish record and a mark in the next generation.
 template <bool LC>
 __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cfx_vehicle_template &t, int s, int d, int /*vid*/,
-                                    double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int idx = -1) {
+                                    double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int idx = -1,
+                                    int nNow = -1) {
     static_assert(!LC, "the ring layout does not run lane change");
     v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
     v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);
     const MoveOut m = computeMove(c, t, s, d, speed, dis, dlen, nd0, v);
     const int bv = blockerSlot >= 0 ? c.s.vid[blockerSlot] : -1;
+    if (idx < 0) {  // (cross phase: the job carries the slot only)
+        const int2 geo = c.ringGeo[d];
+        idx = (s - geo.x - c.head[d]) & geo.y;
+        nNow = cntNow(c, d);
+    }
     if (m.newDrv == -1) {
         o.disN[s] = m.ndis;
         o.speedN[s] = m.v;
         if (bv >= 0) o.blk[s] = make_int2(bv, c.step);
+        if (idx == nNow - 1) {  // the last vehicle of its drivable leaves the tail record of this step's end
+            TailRec r;
+            r.dis = m.ndis;
+            r.speed = m.v;
+            r.slot = s;
+            r.templ = c.s.templ[s];
+            r.prevDrv = c.s.prevDrv[s];
+            r.tag = c.step;
+            c.tailW[d] = r;
+        }
         return;
     }
     o.speedN[s] = -1.0;  // "left its drivable": what kr_commit's general path looks at (a speed is never negative)
-    if (idx < 0) {
-        const int2 geo = c.ringGeo[d];
-        idx = (s - geo.x - c.head[d]) & geo.y;
-    }
     atomicAdd(&o.scratch[d].x, 1);
     atomicMax(&o.scratch[d].y, idx);
     const int vid = c.s.vid[s];
@@ -175,90 +228,282 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep
     __shared__ int sAdmitted;
     if (threadIdx.x == 0) sAdmitted = 0;
     __syncthreads();
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= c.n.L && lane < c.n.L + c.n.K) {
-        const int k = lane - c.n.L;
-        int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
-        c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);
-    } else if (lane < c.n.L) {
-        const int w = waitHead[lane];
-        const int n = c.cnt[lane];
-        const int2 geo = c.ringGeo[lane];
-        const int head = c.head[lane];
-        const int tail = ringSlot(geo, head, n - 1);
-        c.laneTail[lane] = n > 0 ? tail : -1;  // overwritten below if a vehicle is admitted
-        bool admit = w >= 0;
-        int wt = 0;
-        if (admit) {
-            wt = vt.templ[w];
-            if (n > 0 && !(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) admit = false;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < c.n.L + c.n.K) {
+        // this step's view of the drivable's tail: what the last step left, or the vehicle admitted below
+        const TailRec committed = c.tailR[d];
+        TailRec now = committed;
+        if (committed.tag != c.step - 1) now.slot = -1;
+        if (d >= c.n.L) {
+            const int k = d - c.n.L;
+            int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+            c.llGate[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+        } else {
+            const int lane = d;
+            const int w = waitHead[lane];
+            bool admit = w >= 0;
+            int wt = 0;
+            if (admit) {
+                wt = vt.templ[w];
+                if (now.slot >= 0 && !(now.dis > c.t.templ[now.templ].len + c.t.templ[wt].min_gap)) admit = false;
+            }
+            if (admit) {
+                const int n = c.cnt[lane];
+                const int2 geo = c.ringGeo[lane];
+                if (n >= geo.y) {  // the ring is full (cannot happen with capacities from the shortest vehicle): refuse loudly
+                    sc->overflow = 8;
+                } else {
+                    const int slot = ringSlot(geo, c.head[lane], n);
+                    const int route = vt.route[w];
+                    const double v0 = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
+                    c.s.vid[slot] = w;
+                    c.s.drv[slot] = lane;
+                    c.s.prevDrv[slot] = -1;
+                    c.s.next[slot] = nextOf(c.n, c.t, lane, route, 0);
+                    c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
+                    c.s.routePos[slot] = 0;
+                    c.s.templ[slot] = wt;
+                    c.s.route[slot] = route;
+                    c.s.flags[slot] = vt.pendingCustom[w];
+                    c.s.dis[slot] = 0.0;
+                    c.s.speed[slot] = v0;
+                    c.slotOf[w] = slot;
+                    c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
+                    admitStep[lane] = c.step;  // cnt[] and the FIFO pop follow in kr_commit (see cntNow)
+                    now.dis = 0.0;
+                    now.speed = v0;
+                    now.slot = slot;
+                    now.templ = wt;
+                    now.prevDrv = -1;
+                    // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail, same decision)
+                    if (!(c.n.laneGhost && c.n.laneGhost[lane])) atomicAdd(&sAdmitted, 1);
+                }
+            }
         }
-        if (admit && n >= geo.y) {  // the ring is full (cannot happen with capacities from the shortest vehicle): refuse loudly
-            sc->overflow = 8;
-            admit = false;
-        }
-        if (admit) {
-            const int slot = ringSlot(geo, head, n);
-            const int route = vt.route[w];
-            c.s.vid[slot] = w;
-            c.s.drv[slot] = lane;
-            c.s.prevDrv[slot] = -1;
-            c.s.next[slot] = nextOf(c.n, c.t, lane, route, 0);
-            c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
-            c.s.routePos[slot] = 0;
-            c.s.templ[slot] = wt;
-            c.s.route[slot] = route;
-            c.s.flags[slot] = vt.pendingCustom[w];
-            c.s.dis[slot] = 0.0;
-            c.s.speed[slot] = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
-            c.slotOf[w] = slot;
-            c.laneTail[lane] = slot;
-            c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
-            admitStep[lane] = c.step;  // cnt[] and the FIFO pop follow in kr_commit (see cntNow)
-            // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail, same decision)
-            if (!(c.n.laneGhost && c.n.laneGhost[lane])) atomicAdd(&sAdmitted, 1);
-        }
+        now.tag = c.step;
+        c.tailNow[d] = now;
     }
     __syncthreads();
     // Engine::activeVehicleCount: one global atomic per block (phase 4 of this very step counts the admitted vehicles)
     if (threadIdx.x == 0 && sAdmitted) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) sAdmitted);
 }
 
+// Per-laneLink sources of Engine::threadNotifyCross (llstate of cfx_kernels.h) on the ring layout: the tails come from
+// the tail records, and the sources' state is left beside llDyn for the cross phase.
+__device__ inline void llstateRing(const RingCtx &c, int k) {
+    if (k >= c.n.K) return;
+    const int d = c.n.L + k;
+    const int endLane = c.n.llEndLane[k], startLane = c.n.llStartLane[k];
+    const Tail tu = tailNowOf(c, endLane);
+    const int u = (tu.slot >= 0 && tu.prevDrv == d) ? tu.slot : -1;
+    int f = cntNow(c, startLane) > 0 ? firstSlot(c, startLane) : -1;
+    if (f >= 0 && !(c.s.next[f] == d && llAvailable(c, k))) f = -1;
+    const int nOn = c.cnt[d];
+    c.llDyn[k] = make_int4(u, f, firstSlot(c, d), nOn);
+    if (u >= 0 || f >= 0 || nOn > 0) {
+        LLAux a{};
+        a.uDis = tu.dis;
+        a.uSpeed = tu.speed;
+        a.uTempl = tu.templ;
+        if (f >= 0) {
+            a.fDis = c.s.dis[f];
+            a.fSpeed = c.s.speed[f];
+            a.fTempl = c.s.templ[f];
+        }
+        a.llLen = c.n.drvLength[d];
+        a.startLen = c.n.drvLength[startLane];
+        c.llAux[k] = a;
+        const int in = c.n.llInter[k];
+        const int bit = c.n.llLocal[k];
+        atomicOr(&c.interMask[c.n.interMaskStart[in] + (bit >> 6)], 1ULL << (bit & 63));  // (read by k_cross2 only)
+    }
+}
+
+// notifiedAt + the notified vehicle's state (cfx_kernels.h) from the two laneLink records
+__device__ inline Notified notified(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x) {
+    Notified nf{-1, 0, 0.0, 0.0};
+    const int4 dyn = c.llDyn[k];
+    if (dyn.x < 0 && dyn.y < 0 && dyn.w == 0) return nf;  // nobody to yield to on that laneLink
+    const LLAux a = c.llAux[k];
+    if (dyn.x >= 0) {
+        const double vehDistance = a.uDis - tv[a.uTempl].len;
+        const double crossDistance = a.llLen - x;
+        if (crossDistance + vehDistance < 0.0) {
+            nf.slot = dyn.x;
+            nf.templ = a.uTempl;
+            nf.speed = a.uSpeed;
+            nf.dist = -(a.uDis + crossDistance);
+            return nf;
+        }
+    }
+    if (dyn.w > 0) {
+        const SegWalk walk = segWalk(c, c.n.L + k, dyn.z);
+        for (int i = 0; i < dyn.w; ++i) {
+            const int w = walk.at(i);
+            const double vehDistance = c.s.dis[w];
+            const int wt = c.s.templ[w];
+            if (!(vehDistance > x) || (vehDistance - x - tv[wt].len <= 0.0)) {
+                nf.slot = w;
+                nf.templ = wt;
+                nf.speed = c.s.speed[w];
+                nf.dist = x - vehDistance;
+                return nf;
+            }
+        }
+    }
+    if (dyn.y >= 0) {
+        nf.slot = dyn.y;
+        nf.templ = a.fTempl;
+        nf.speed = a.fSpeed;
+        nf.dist = (a.startLen - a.fDis) + x;
+    }
+    return nf;
+}
+
+// A vehicle handed to the cross phase, with everything the action phase already knew about it: the cross phase starts
+// from ONE record instead of the chain slot -> {drivable, template, speed, dis, next} -> {length, laneLink record}.
+struct RingJob {
+    int32_t slot, d, idx, nNow, xs, xe, t1, templ, nd0, pad0, pad1, pad2;
+    double d0, speed, v, iv, dis, dlen;
+};
+static_assert(sizeof(RingJob) == 96, "cross job record layout");
+
+struct RingPush {
+    JobQueue q;
+    RingJob *recs;
+    int L;
+    __device__ __forceinline__ void operator()(int s, const JobInfo &j) const {
+        const int shard = blockIdx.x & (kJobShards - 1);
+        const int idx = atomicAdd(&q.count[shard * kJobShardStride], 1);
+        if (idx >= q.capacity) {
+            *q.overflow = 9;
+            return;
+        }
+        const size_t at = (size_t) shard * q.capacity + idx;
+        q.jobs[at] = s;
+        RingJob r{};
+        r.slot = s;
+        r.d = j.d;
+        r.idx = j.idx;
+        r.nNow = j.nNow;
+        r.xs = j.xs;
+        r.xe = j.xe;
+        r.t1 = (j.gateFlags >> 1) & 3;
+        r.templ = j.templ;
+        r.nd0 = j.nd0;
+        r.d0 = j.d < L ? -(j.dlen - j.dis) : j.dis;
+        r.speed = j.speed;
+        r.v = j.v;
+        r.iv = j.iv;
+        r.dis = j.dis;
+        r.dlen = j.dlen;
+        recs[at] = r;
+    }
+};
+
+// Second half of Vehicle::getIntersectionRelatedSpeed (k_cross of cfx_kernels.h) from job records: one 16-lane group per
+// queued vehicle, one cross per lane and round, first failing lane of the first failing round = the first cross that
+// cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
+__global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs) {
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const cfx_vehicle_template *tv = c.t.templ;
+    __shared__ int shardEnd[kJobShards];
+    if (threadIdx.x < kJobShards) shardEnd[threadIdx.x] = min(q.count[threadIdx.x * kJobShardStride], q.capacity);
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        tv = sT;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < kJobShards; ++i) {
+            run += shardEnd[i];
+            shardEnd[i] = run;
+        }
+    }
+    __syncthreads();
+    const int nJ = shardEnd[kJobShards - 1];
+    const int g = threadIdx.x % kCrossGroup;
+    const int groupsPerBlock = blockDim.x / kCrossGroup;
+    const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);
+    for (int j = blockIdx.x * groupsPerBlock + threadIdx.x / kCrossGroup; j < nJ; j += gridDim.x * groupsPerBlock) {
+        int shard = 0;
+        while (j >= shardEnd[shard]) ++shard;
+        const RingJob jr = recs[(size_t) shard * q.capacity + (j - (shard ? shardEnd[shard - 1] : 0))];
+        const int s = jr.slot;
+        const cfx_vehicle_template &t = tv[jr.templ];
+        const double d0 = jr.d0;
+        VehRef self{jr.speed, &t};
+        double iv = jr.iv;
+        int blockerSlot = -1;
+        for (int e0 = jr.xs; e0 < jr.xe; e0 += kCrossGroup) {
+            const int e = e0 + g;
+            bool fail = false;
+            int foe = -1;
+            double dOn = 0.0;
+            if (e < jr.xe) {
+                const double2 dd = c.n.xDD[e];  // {distance on this laneLink, distance on the peer laneLink}
+                const int4 xp = c.n.xPack[e];   // {peer laneLink, peer bit, peer roadLink type, -}
+                dOn = dd.x;
+                if (!(dOn < d0)) fail = !canPassActive(c, tv, s, self, dOn, jr.t1, d0, xp.x, dd.y, xp.z, &foe);
+            }
+            const unsigned long long ball = __ballot(fail);
+            const unsigned gm = (unsigned) ((ball >> groupShift) & ((1ULL << kCrossGroup) - 1ULL));
+            if (gm != 0u) {
+                const int first = __ffs(gm) - 1;
+                const int src = groupShift + first;
+                const double fdOn = __shfl(dOn, src, 64);
+                blockerSlot = __shfl(foe, src, 64);
+                iv = min2(iv, stopBeforeSpeed(self, fdOn - d0 - t.yield_distance, c.interval));
+                break;
+            }
+        }
+        if (g == 0)
+            finishAction<false>(c, o, t, s, jr.d, 0, jr.speed, jr.dis, jr.dlen, jr.nd0, min2(jr.v, iv), blockerSlot, jr.idx, jr.nNow);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- phase 3 + 4
-// One wavefront per workgroup.  A wave owns a run of consecutive drivables (G lanes, or 64 laneLinks): its first lanes
-// read the rings' {base, cap, head, cnt} and the drivables' {length, max speed}, a wave-wide prefix sum turns the counts
-// into the wave's vehicle list, and the wave walks that list 63 vehicles at a time.  Each pass stages the window's
-// {dis, speed, template} in LDS; a vehicle's leader is the previous element of the window (lane 0 of a pass re-reads the
-// last vehicle of the previous pass for that purpose only), so leader/follower state is read from HBM once, coalesced.
+// A workgroup of B threads owns a run of consecutive drivables (G lanes, or B laneLinks): its first threads read the
+// rings' {base, cap, head, cnt} and the drivables' {length, max speed}, a block-wide prefix sum turns the counts into the
+// block's vehicle list, and the block walks that list B - 1 vehicles at a time (sized so that one pass is the rule:
+// every block of the launch is resident at once, and the step is bound by the slowest block's chain of dependent
+// loads).  Each pass stages the window's {dis, speed, template} in LDS; a vehicle's leader is the previous element of the
+// window (thread 0 re-reads the last vehicle of the previous pass for that purpose only), so leader / follower state is
+// read from HBM once, coalesced.
 constexpr int kRingWave = 64;
 
-template <int G>
-__global__ __launch_bounds__(kRingWave) void kr_action(RingCtx c, RingOut o, JobQueue q, int nLaneWaves, int nLLWaves) {
+template <int B, int G>
+__global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int nLaneBlocks, int nLLBlocks) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
-    if (w >= nLaneWaves + nLLWaves) {  // trailing waves: the per-laneLink notify sources for the cross phase
-        llstate(c, (w - nLaneWaves - nLLWaves) * kRingWave + t);
+    if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
+        llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
-    __shared__ int sPre[kRingWave + 1];
-    __shared__ int2 sGeo[kRingWave];
-    __shared__ int sHead[kRingWave];
-    __shared__ double2 sLM[kRingWave];
-    __shared__ double sDis[kRingWave], sSpeed[kRingWave];
-    __shared__ int sTempl[kRingWave];
+    __shared__ int sPre[B + 1];
+    __shared__ int2 sGeo[B];
+    __shared__ int sHead[B];
+    __shared__ double2 sLM[B];
+    __shared__ double sDis[B], sSpeed[B];
+    __shared__ int sTempl[B];
+    __shared__ int sWave[B / 64];
     const cfx_vehicle_template *tv = c.t.templ;
-    // ---- the wave's drivables
-    const bool laneWave = w < nLaneWaves;
-    const int g = laneWave ? G : kRingWave;
-    const int d0 = laneWave ? w * G : c.n.L + (w - nLaneWaves) * kRingWave;
-    const int dEnd = laneWave ? c.n.L : c.n.L + c.n.K;
+    // ---- the block's drivables: G lanes, or B laneLinks
+    const bool laneBlock = w < nLaneBlocks;
+    const int g = laneBlock ? G : B;
+    const int d0 = laneBlock ? w * G : c.n.L + (w - nLaneBlocks) * B;
+    const int dEnd = laneBlock ? c.n.L : c.n.L + c.n.K;
     const int dMine = d0 + t;
     int n = 0;
     if (t < g && dMine < dEnd) {
         const int2 geo = c.ringGeo[dMine];
         const int head = c.head[dMine];
         n = c.cnt[dMine];
-        if (laneWave && c.admitStep[dMine] == c.step) n += 1;
+        if (laneBlock && c.admitStep[dMine] == c.step) n += 1;
         sLM[t] = c.n.drvLM[dMine];
         sGeo[t] = geo;
         sHead[t] = head;
@@ -267,21 +512,27 @@ __global__ __launch_bounds__(kRingWave) void kr_action(RingCtx c, RingOut o, Job
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
         double *dst = (double *) sT;
-        for (int i = t; i < nd; i += kRingWave) dst[i] = src[i];
+        for (int i = t; i < nd; i += B) dst[i] = src[i];
         tv = sT;
     }
+    // block-wide inclusive prefix sum of the counts
     int incl = n;
-    for (int off = 1; off < kRingWave; off <<= 1) {
-        const int up = __shfl_up(incl, off, kRingWave);
-        if (t >= off) incl += up;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += up;
+    }
+    if constexpr (B > 64) {
+        if ((t & 63) == 63) sWave[t >> 6] = incl;
+        __syncthreads();
+        for (int i = 0; i < (t >> 6); ++i) incl += sWave[i];
     }
     sPre[t + 1] = incl;
     if (t == 0) sPre[0] = 0;
     __syncthreads();
-    const int T = sPre[kRingWave];
-    const PushJob push{q};
-    for (int qb = 0; qb < T; qb += kRingWave - 1) {
-        const int qv = qb + t - 1;  // lane 0 holds the vehicle ahead of the window (leader data only)
+    const int T = sPre[B];
+    const RingPush push{q, jobRecs, c.n.L};
+    for (int qb = 0; qb < T; qb += B - 1) {
+        const int qv = qb + t - 1;  // thread 0 holds the vehicle ahead of the window (leader data only)
         const bool valid = qv >= 0 && qv < T;
         int i = 0, idx = 0, slot = 0;
         SlotIn in;
@@ -314,6 +565,7 @@ __global__ __launch_bounds__(kRingWave) void kr_action(RingCtx c, RingOut o, Job
             in.d = d0 + i;
             in.head = idx == 0;
             in.idx = idx;
+            in.nNow = sPre[i + 1] - sPre[i];
             in.leaderSlot = 0;
             if (idx > 0) {
                 in.disPrev = sDis[t - 1];
@@ -493,7 +745,8 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
             head = (head + sc.x) & geo.y;
             n -= sc.x;
         }
-        int m = 0;
+        int m = 0, tailRank = -1;
+        TailRec tail{};
         for (int e = sc.z; e >= 0; e = k.movers[e].nextIn) {
             const MoverRec r = k.movers[e];
             int rank = 0;
@@ -529,8 +782,34 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
             c.disN[slot] = r.dis;
             c.speedN[slot] = r.speed;
             c.slotOf[r.vid] = slot;
+            if (rank > tailRank) {  // the last of the entrants becomes the drivable's tail
+                tailRank = rank;
+                tail.dis = r.dis;
+                tail.speed = r.speed;
+                tail.slot = slot;
+                tail.templ = r.templ;
+                tail.prevDrv = r.oldDrv;
+            }
         }
         n += m;
+        // the tail record of this step's end where the tail changed hands (a tail that stayed wrote its own, finishAction)
+        if (tailRank >= 0) {
+            tail.tag = c.step;
+            c.tailW[d] = tail;
+        } else if (sc.x > 0) {
+            if (n == 0) {
+                tail.slot = -1;
+            } else {  // (the general path above may have moved the tail vehicle; with a prefix of leavers this rewrites the same)
+                const int ts = ringSlot(geo, head, n - 1);
+                tail.dis = c.disN[ts];
+                tail.speed = c.speedN[ts];
+                tail.slot = ts;
+                tail.templ = c.s.templ[ts];
+                tail.prevDrv = c.s.prevDrv[ts];
+            }
+            tail.tag = c.step;
+            c.tailW[d] = tail;
+        }
         if (n > geo.y) k.sc->overflow = 8;
         else if (n + 8 > geo.y && geo.y >= 15) k.sc->ringNearFull = 1;
         c.head[d] = head;
@@ -600,6 +879,16 @@ __global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTa
         c.s.speed[s] = in.speed[j];
         c.s.next[s] = nextOf(c.n, c.t, d, route, in.routePos[j]);
         c.slotOf[v] = s;
+        if (i == n - 1) {
+            TailRec r;
+            r.dis = in.dis[j];
+            r.speed = in.speed[j];
+            r.slot = s;
+            r.templ = vt.templ[v];
+            r.prevDrv = in.prevDrv[j];
+            r.tag = c.step - 1;
+            const_cast<TailRec *>(c.tailR)[d] = r;
+        }
     }
 }
 

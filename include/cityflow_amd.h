@@ -102,7 +102,7 @@ typedef struct cfx_config {
     int32_t layout;           /* vehicle order in HBM: CFX_LAYOUT_AUTO, CFX_LAYOUT_DENSE (rebuilt every step),
                                * CFX_LAYOUT_RING (per-drivable ring segments, committed in place; not with lane_change) */
     int32_t debug_sync;       /* synchronise after every kernel of a step and name the one that faulted (developer aid) */
-    int32_t ring_lanes_per_wave; /* ring layout: lanes one wavefront of the action kernel owns (1, 2, 4, 8, 16; 0 = by size) */
+    int32_t ring_lanes_per_wave; /* ring layout: lanes one 256-thread workgroup of the action kernel owns (4, 8, 16, 32; 0 = default) */
 } cfx_config;
 #define CFX_CROSS_AUTO 0
 #define CFX_CROSS_LATENCY 1
