@@ -705,7 +705,11 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     e->cross2 = cfg->cross_mode == CFX_CROSS_THROUGHPUT ? 1 : cfg->cross_mode == CFX_CROSS_LATENCY ? 0 : -1;
     if (cfg->layout == CFX_LAYOUT_RING && cfg->lane_change)
         return e->fail("cfx_create: layout ring does not run lane change (its mid-lane insertions use the dense layout)");
-    e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change);
+    // auto: the ring layout commits a step with a fraction of the dense layout's data movement, but its state is spread
+    // over every ring's capacity (~7 slots per vehicle at the usual densities) — measured on the MI355X it is ahead up to
+    // ~150 k running vehicles (30x30: 56 vs 61 us / step) and behind once that state no longer sits in the caches
+    // (60x60: 112 vs 101, 100x100: 227 vs 191).  Lanes are the proxy for size known at creation.
+    e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change && n->n_lanes <= 20000);
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
     e->timesDyadic = cfx_engine::dyadic(cfg->interval);
     e->R = n->n_roads;
@@ -976,20 +980,22 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         RingOut ro{c.disN, c.speedN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
         {
-            // One workgroup = 256 threads over G lanes (or 256 laneLinks): G is picked so that a block's vehicles fit one
-            // pass (255) with room for uneven lanes; `ring_lanes_per_wave` overrides it (developer knob).
-            int G = 16;
+            // One workgroup = B threads over G lanes (or B laneLinks).  G is picked so that a block's vehicles fit one pass
+            // (B - 1) with room for uneven lanes; small networks take small blocks (every block resident at once, the step
+            // is bound by the slowest block's chain), large ones big blocks (fuller waves: throughput).
+            // cfx_config::ring_lanes_per_wave = G + 1000 * (B / 256) overrides both (developer knob).
+            int G = 16, Bsel = 256;
             const int want = e->cfg.ring_lanes_per_wave;
-            if (want == 4 || want == 8 || want == 16 || want == 32) G = want;
-            constexpr int B = 256;
-            const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + B - 1) / B;
-            const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(B);
-            switch (G) {
-            case 4: e->launch(PK_ACTION, kr_action<B, 4>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
-            case 8: e->launch(PK_ACTION, kr_action<B, 8>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
-            case 32: e->launch(PK_ACTION, kr_action<B, 32>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
-            default: e->launch(PK_ACTION, kr_action<B, 16>, grid, block, c, ro, jq, e->rJobRecs, nLaneBlocks, nLLBlocks); break;
+            if (want > 0) {
+                G = std::max(1, want % 1000);
+                Bsel = want >= 4000 ? 1024 : (want >= 2000 ? 512 : 256);
             }
+            G = std::min(G, Bsel);
+            const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;
+            const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(Bsel);
+            if (Bsel == 256) e->launch(PK_ACTION, kr_action<256>, grid, block, c, ro, jq, e->rJobRecs, G, nLaneBlocks, nLLBlocks);
+            else if (Bsel == 512) e->launch(PK_ACTION, kr_action<512>, grid, block, c, ro, jq, e->rJobRecs, G, nLaneBlocks, nLLBlocks);
+            else e->launch(PK_ACTION, kr_action<1024>, grid, block, c, ro, jq, e->rJobRecs, G, nLaneBlocks, nLLBlocks);
         }
         RING_CHECK("kr_action")
         if (dbg) {

@@ -476,8 +476,8 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
 // read from HBM once, coalesced.
 constexpr int kRingWave = 64;
 
-template <int B, int G>
-__global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int nLaneBlocks, int nLLBlocks) {
+template <int B>
+__global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
     if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
         llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
