@@ -91,12 +91,34 @@ def build_tiled_workload(workdir, rows, cols, block, n_extra_per_tile):
     return path
 
 
-def cpu_baseline(cfg, budget_s, threads, state_dump):
+def _lane_hash(counts):
+    import hashlib
+    return hashlib.sha256(json.dumps(sorted(counts.items())).encode()).hexdigest()
+
+
+def _state_hash(speed, distance):
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(speed):
+        h.update(("%s %s %s\n" % (k, float(speed[k]).hex(), float(distance[k]).hex())).encode())
+    return h.hexdigest()
+
+
+def parity_record(eng):
+    """What the in-run parity check compares after the same number of steps from the same state: per-lane vehicle counts,
+    vehicle count, and every running vehicle's exact (speed, distance) bits."""
+    return {"vehicles": eng.get_vehicle_count(), "lane_hash": _lane_hash(eng.get_lane_vehicle_count()),
+            "state_hash": _state_hash(eng.get_vehicle_speed(), eng.get_vehicle_distance())}
+
+
+def cpu_baseline(cfg, budget_s, threads, state_dump, parity_steps=0):
     """The unmodified reference engine (oracle/_ref) on the host cores, started from EXACTLY the state the GPU engine
     had when its timed region began: that state is injected through the reference's own Archive JSON format
-    (Engine.load_from_file, reference src/engine/archive.cpp:345-550).  Falls back to the CPU twin ("port")."""
+    (Engine.load_from_file, reference src/engine/archive.cpp:345-550).  Falls back to the CPU twin ("port").
+    With parity_steps > 0 the record of parity_record() after exactly that many steps is returned as well."""
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
-    sys.path.insert(0, ref_dir)
+    if ref_dir not in sys.path:
+        sys.path.insert(0, ref_dir)
     kind = "reference"
     try:
         import cityflow_ref
@@ -109,15 +131,18 @@ def cpu_baseline(cfg, budget_s, threads, state_dump):
     eng.load_from_file(state_dump)
     t_load = time.perf_counter() - t_load
     start_running = eng.get_vehicle_count()
-    veh_steps, steps = 0, 0
-    t0 = time.perf_counter()
+    veh_steps, steps, parity = 0, 0, None
+    dt = 0.0
     while True:
+        t0 = time.perf_counter()
         veh_steps += eng.get_vehicle_count()  # vehicles that take the coming step (admissions aside)
         eng.next_step()
+        dt += time.perf_counter() - t0
         steps += 1
-        if time.perf_counter() - t0 > budget_s:
+        if steps == parity_steps:
+            parity = parity_record(eng)  # untimed
+        if dt > budget_s and steps >= parity_steps:
             break
-    dt = time.perf_counter() - t0
     running = eng.get_vehicle_count()
     time.sleep(0.2)  # reference destructor race: settle before the engine is dropped
     del eng
@@ -127,24 +152,37 @@ def cpu_baseline(cfg, budget_s, threads, state_dump):
         "sample": "%d steps from the GPU run's own state at the start of its timed region (%d -> %d running vehicles, "
                   "injected via Archive JSON, load %.1f s untimed), %.1f s of wall time, %d thread(s) of %d host cores"
                   % (steps, start_running, running, t_load, dt, threads, os.cpu_count() or 1),
-    }
+    }, parity
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (FETCH_SIZE + WRITE_SIZE passes,
-    tools/pmc_summary.py); counters cannot be collected from inside this process, so this is the offline measurement
-    of the same command, or None."""
+def kernel_source_sha():
+    """sha256 over the HIP sources the device library is built from: a PMC summary counts only for the kernels it measured."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    k = d.get("kernels", {}).get(kernel)
-    if not k:
-        return None, None
-    return k["hbm_bytes_raw"], "%s (%s; (FETCH_SIZE+WRITE_SIZE)*1024 per launch, uncorrected)" % (
-        os.path.relpath(files[-1], ROOT), d.get("window", ""))
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cityflow_amd", "csrc", "hip", "*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_names):
+    """HBM bytes per launch of the action kernel from the committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE in
+    separate passes, tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on
+    gfx950) — only if that summary was taken from THESE kernel sources (it carries their hash); otherwise None."""
+    import glob
+    sha = kernel_source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha") != sha or d.get("workload", "bench") != "bench":
+            continue
+        for name in kernel_names:
+            k = next((v for kn, v in sorted(d.get("kernels", {}).items()) if name in kn), None)
+            if k:
+                return k.get("hbm_bytes_fetch_doubled", k.get("hbm_bytes_raw")), "%s (%s; (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch)" % (
+                    os.path.relpath(path, ROOT), d.get("window", ""))
+    return None, None
 
 
 def main():
@@ -154,18 +192,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--build-up-steps", type=int, default=BUILD_UP_STEPS, help=argparse.SUPPRESS)
     ap.add_argument("--profile-steps", type=int, default=100, help="instrumented steps for the roofline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the 8-thread cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="reference thread_num (default min(8, host cores))")
+    ap.add_argument("--cpu-leg-seconds", type=float, default=6.0, help="budget of each extra leg (1 thread, all host cores)")
     # test hooks (tests/test_distributed.py drives the N>1 code path on CPU with gloo and the CPU twin)
     ap.add_argument("--scenario", default="grid_30x30", help=argparse.SUPPRESS)
     ap.add_argument("--extra-flows", type=int, default=N_EXTRA_FLOWS, help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--backend-lib", default="", help=argparse.SUPPRESS)
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of one tiled network")
-    ap.add_argument("--strong", action="store_true",
-                    help="N>1: tile the N=1 workload itself (30x30, BASELINE.json configs[3]) instead of growing the grid with N")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: grow the grid with N (every GPU owns a 30x30 block) instead of tiling the N=1 workload itself")
+    ap.add_argument("--strong", action="store_true", help=argparse.SUPPRESS)  # the default since round 2
     ap.add_argument("--tile-block", type=int, default=30, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args.strong = not args.weak
     on_gpu = args.backend_lib == ""
 
     rank = int(os.environ.get("RANK", "0"))
@@ -268,6 +309,11 @@ def main():
     host1 = eng._eng._host_seconds() if tiled else None  # rank 0's host time inside the timed region
     sc1 = eng._scalars()
     veh_steps = sc1["vehicle_steps"] - sc0["vehicle_steps"]
+    gpu_parity = parity_record(eng) if (rank == 0 and state_dump is not None) else None  # end of the timed region
+    # per-lane vehicle counts at the end of the timed region (every rank takes part in a tiled run's getter)
+    import hashlib
+    lane_counts_end = eng.get_lane_vehicle_count_array()
+    lane_hash_end = hashlib.sha256(lane_counts_end.tobytes()).hexdigest()[:16]
 
     if dist is not None:
         import torch
@@ -302,7 +348,7 @@ def main():
             avg_s = act_ms / act_n / 1e3
             achieved = ACTION_BYTES_PER_VEHICLE * vehicles_per_launch / avg_s / 1e9
             step_ms = sum(ms for ms, _n in prof.values()) / act_n
-            traffic, traffic_src = pmc_traffic("cfxd::k_action")
+            traffic, traffic_src = pmc_traffic(("kr_action", "k_action"))
             roofline = {
                 "bound": "hbm", "kernel": "k_action", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None if tiled else traffic,
@@ -316,14 +362,22 @@ def main():
             }
 
     if rank == 0:
-        cpu = None
+        cpu, legs, parity_in_run, parity_detail = None, None, None, None
         if args.cpu_seconds > 0 and not tiled:
             threads = args.cpu_threads or min(8, os.cpu_count() or 1)
-            cpu = cpu_baseline(cfg, args.cpu_seconds, threads, state_dump)
+            cpu, ref_parity = cpu_baseline(cfg, args.cpu_seconds, threads, state_dump, parity_steps=args.steps)
+            # in-run parity: the reference, from the same state, after the same number of steps
+            parity_in_run = bool(gpu_parity is not None and ref_parity is not None and gpu_parity == ref_parity)
+            parity_detail = {"after_steps": args.steps, "against": cpu["kind"], "gpu": gpu_parity, "cpu": ref_parity,
+                             "checked": "per-lane vehicle counts, vehicle count, every vehicle's (speed, distance) bit for bit"}
+            legs = []
+            for t in sorted({1, os.cpu_count() or 1} - {threads}):
+                if args.cpu_leg_seconds > 0 and cpu["kind"] == "reference":
+                    legs.append(cpu_baseline(cfg, args.cpu_leg_seconds, t, state_dump)[0])
         out = {
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if (tiled and args.strong) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": None if world == 1 else ("strong" if (tiled and args.strong) else "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "steps_per_sec": args.steps * (1 if tiled else world) / elapsed,
             "config": {
                 "workload": ("%s + %d seeded interior flows cut into %dx%d tiles, one tile per GPU, one-lane ghost halo "
@@ -341,7 +395,9 @@ def main():
                          "%d warm-up steps" % (args.build_up_steps, args.warmup),
                 "running_vehicles_start": run0, "running_vehicles_end": run1,
                 "lanes": len(eng.lane_ids()),
-                "halo": ("gpu-written shared-memory mailboxes" if eng.mailboxes else "staged over gloo") if tiled else None,
+                "lane_count_hash_end": lane_hash_end,
+                "halo": eng.halo_transport() if tiled else None,
+                "layout": eng._layout() if hasattr(eng, "_layout") else None,
                 "halo_probe_failures": halo_notes or None,
                 "host_us_per_step": ({"spawner": round((host1[0] - host0[0]) / args.steps * 1e6, 1),
                                       "submit": round((host1[1] - host0[1]) / args.steps * 1e6, 1)} if tiled else None),
@@ -350,6 +406,9 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_legs": legs,
+            "parity_in_run": parity_in_run,
+            "parity": parity_detail,
         }
         print(json.dumps(out), flush=True)
     barrier()

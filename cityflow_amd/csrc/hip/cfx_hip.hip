@@ -1241,6 +1241,8 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     return CFX_OK;
 }
 
+int32_t cfx_get_layout(cfx_engine *e) { return !e ? CFX_ERR_INVALID : (e->ring ? CFX_LAYOUT_RING : CFX_LAYOUT_DENSE); }
+
 int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };

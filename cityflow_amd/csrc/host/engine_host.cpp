@@ -47,6 +47,7 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_set_tl_phases)
     CFX_FN(cfx_get_tl_state)
     CFX_FN(cfx_get_scalars)
+    CFX_FN(cfx_get_layout)
     CFX_FN(cfx_get_lane_counts)
     CFX_FN(cfx_get_lane_waiting_counts)
     CFX_FN(cfx_get_vehicles)

@@ -38,6 +38,7 @@ struct Backend {
     CFX_FN(cfx_set_tl_phases)
     CFX_FN(cfx_get_tl_state)
     CFX_FN(cfx_get_scalars)
+    CFX_FN(cfx_get_layout)
     CFX_FN(cfx_get_lane_counts)
     CFX_FN(cfx_get_lane_waiting_counts)
     CFX_FN(cfx_get_vehicles)
@@ -137,6 +138,10 @@ public:
     const HostRoadNet &net() const { return *net_; }
     const Spawner &spawner() const { return spawner_; }
     std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
+    std::string layoutName() {
+        const int l = be_.cfx_get_layout(dev_);
+        return l == CFX_LAYOUT_RING ? "ring" : (l == CFX_LAYOUT_DENSE ? "dense" : "n/a");
+    }
     std::string vehicleId(int vid, bool shadow = false) const { return spawner_.vehicleId(vid, shadow); }
     bool laneChange() const { return laneChange_; }
     int vidOf(const std::string &id);  // -1 if unknown

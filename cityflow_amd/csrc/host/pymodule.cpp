@@ -424,6 +424,7 @@ PYBIND11_MODULE(_cityflow, m) {
                  d["vehicle_steps"] = s.vehicle_steps;
                  return d;
              })
+        .def("_layout", &EngineHost::layoutName)
         .def("_profile_enable", &EngineHost::profileEnable, "on"_a)
         .def("_profile_read", &EngineHost::profileRead)
         .def("_vehicle_id", [](EngineHost &e, int vid) { return e.vehicleId(vid); }, "vid"_a)

@@ -61,6 +61,10 @@ class DistributedEngine:
             self._eng.unlink_mailboxes()     # ... so the names can go
 
     # ---- stepping -------------------------------------------------------------------------------------------
+    def halo_transport(self):
+        """How the per-step halo travels between the tiles (bench.py reports it in config.halo)."""
+        return "gpu-written shared-memory mailboxes" if self.mailboxes else "staged over gloo"
+
     def next_step(self):
         self._eng.step_begin()  # spawn, the step's kernels, halo export
         if self.mailboxes:      # device-initiated exchange: nothing for the host to do

@@ -205,6 +205,9 @@ int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const
 int32_t cfx_get_tl_state(cfx_engine *e, int32_t *cur_phase /*[n_inters]*/, double *remain /*[n_inters]*/);
 
 int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out);
+/* the vehicle layout this engine runs on: CFX_LAYOUT_DENSE or CFX_LAYOUT_RING (what cfx_config::layout = AUTO resolved to;
+ * CPU implementations report CFX_LAYOUT_AUTO) */
+int32_t cfx_get_layout(cfx_engine *e);
 int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out /*[n_lanes]*/);         /* getLaneVehicleCount */
 int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out /*[n_lanes]*/); /* speed < 0.1 (engine.cpp:641) */
 int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view);

@@ -1034,6 +1034,7 @@ template <typename T> static void copyIn(std::vector<T> &dst, const T *src, size
 extern "C" {
 
 int32_t cfx_abi_version(void) { return CFX_ABI_VERSION; }
+int32_t cfx_get_layout(cfx_engine *e) { return e ? CFX_LAYOUT_AUTO : CFX_ERR_INVALID; }
 const char *cfx_backend_name(void) { return "cpu-twin"; }
 
 int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
