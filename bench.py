@@ -296,6 +296,13 @@ def main():
     if rank == 0 and args.cpu_seconds > 0 and not tiled:
         state_dump = os.path.join(workdir, "state_at_timed_region.json")
         eng.snapshot().dump(state_dump)
+        # Both engines start the timed region from this very file: the GPU engine re-reads it too, so that vehicles are
+        # numbered in archive order on both sides.  (Where two vehicles enter a lane with EXACTLY equal distances in one
+        # step the reference's std::sort leaves their order to the order of its Vehicle objects; an engine that kept
+        # running and one that was restored from an archive may break such a tie differently — seen once in ~500 steps
+        # of this workload — and would then drift apart although both are right.)
+        eng.load_from_file(state_dump)
+        eng.sync()
 
     barrier()
     eng.sync()

@@ -409,11 +409,20 @@ void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
 void EngineHost::waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane) {
     settleLaneChange();
     cfx_scalars sc = scalars();
-    int cap = (int) (sc.spawned_vehicle_count - sc.finished_vehicle_count - sc.active_vehicle_count) + 16;
-    vid.resize(cap);
-    lane.resize(cap);
+    // spawned - finished - running, unless the state came from an archive (finished vehicles are not in its vehicle
+    // table): then every vehicle of the table may be waiting
+    int64_t cap = sc.spawned_vehicle_count - sc.finished_vehicle_count - sc.active_vehicle_count;
+    if (cap < 0) cap = 0;
     int32_t n = 0;
-    check(be_.cfx_get_waiting(dev_, cap, vid.data(), lane.data(), &n), "cfx_get_waiting");
+    for (int attempt = 0;; ++attempt) {
+        if (attempt) cap = sc.spawned_vehicle_count;
+        vid.resize((size_t) cap + 16);
+        lane.resize((size_t) cap + 16);
+        const int32_t rc = be_.cfx_get_waiting(dev_, (int32_t) cap + 16, vid.data(), lane.data(), &n);
+        if (rc == CFX_ERR_CAPACITY && attempt == 0) continue;
+        check(rc, "cfx_get_waiting");
+        break;
+    }
     vid.resize(n);
     lane.resize(n);
 }
