@@ -250,19 +250,22 @@ def main():
                 build_tiled_workload(workdir, rows, cols, args.tile_block, args.extra_flows)
             barrier()
             cfg = os.path.join(workdir, "gen_%dx%d" % (args.tile_block * rows, args.tile_block * cols), "config_bench.json")
-        # Probe the halo transports on this machine before committing to one: GPU-written mailboxes first, the staged
-        # gloo exchange second; a transport counts only if EVERY rank ran a few steps on it without an error.
-        for mailboxes in (True, False):
+        # Probe the halo transports on this machine before committing to one, best first: mailboxes in the receiving
+        # GPU's HBM (hipIpc peer memory over xGMI), mailboxes in shared host memory, RCCL send / recv of device-resident
+        # messages, gloo through host buffers.  A transport counts only if EVERY rank ran a few steps on it without an error.
+        for transport in ("device", "host", "rccl", "gloo"):
+            if transport == "rccl" and (not on_gpu or dist.get_backend() != "nccl"):
+                continue
             cand, ok = None, 1
             try:
-                cand = DistributedEngine(cfg, rows, cols, backend_library=args.backend_lib, mailboxes=mailboxes)
+                cand = DistributedEngine(cfg, rows, cols, backend_library=args.backend_lib, transport=transport)
                 for _ in range(20):
                     cand.next_step()
                 cand.sync()
                 cand.local_scalars()  # raises if a device-side halo wait timed out
             except Exception as exc:  # noqa: BLE001 - any failure disqualifies the transport
                 ok = 0
-                halo_notes.append("%s: %s" % ("mailboxes" if mailboxes else "gloo", str(exc)[:200]))
+                halo_notes.append("%s: %s" % (transport, str(exc)[:200]))
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:

@@ -135,6 +135,7 @@ struct cfx_engine {
         char *sendDev = nullptr, *recvDev = nullptr;
     };
     std::vector<MailPeer> mail;
+    std::vector<void *> ipcOpened;     // peers' mailboxes opened with hipIpcOpenMemHandle
     std::vector<int32_t> hGhostSendOff, hGhostRecvOff, hImportSendOff, hImportRecvOff;
     int32_t *haloTicket = nullptr;
     double *finTerm = nullptr;  // [slot] travel times of the step's finishers in summation order
@@ -682,6 +683,7 @@ void cfx_destroy(cfx_engine *e) {
         if (m.sendHost) (void) hipHostUnregister(m.sendHost);
         if (m.recvHost) (void) hipHostUnregister(m.recvHost);
     }
+    for (void *p : e->ipcOpened) (void) hipIpcCloseMemHandle(p);
     if (e->hLaneOut) (void) hipHostFree(e->hLaneOut);
     if (e->hMirror) (void) hipHostFree(e->hMirror);
     if (e->hHaloSend) (void) hipHostFree(e->hHaloSend);
@@ -1929,7 +1931,7 @@ int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
 }
 
 int32_t cfx_halo_export(cfx_engine *e, void *sendHost) {
-    if (!e || !e->tiled || (!sendHost && e->haloSendBytes)) return CFX_ERR_INVALID;
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
     const int n = e->halo.nGhost + e->halo.nImport;
@@ -1938,18 +1940,18 @@ int32_t cfx_halo_export(cfx_engine *e, void *sendHost) {
     if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
                               e->cs.inCnt, io, e->sc);
     HIP_TRY(hipGetLastError());
-    if (e->haloSendBytes) HIP_TRY(hipMemcpyAsync(e->hHaloSend, e->dHaloSend, (size_t) e->haloSendBytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->haloSendBytes) memcpy(sendHost, e->hHaloSend, (size_t) e->haloSendBytes);
+    if (e->haloSendBytes && sendHost) HIP_TRY(hipMemcpyAsync(e->hHaloSend, e->dHaloSend, (size_t) e->haloSendBytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // (device-to-device transports run on another stream: the message is complete)
+    if (e->haloSendBytes && sendHost) memcpy(sendHost, e->hHaloSend, (size_t) e->haloSendBytes);
     return CFX_OK;
 }
 
 int32_t cfx_halo_import(cfx_engine *e, const void *recvHost) {
-    if (!e || !e->tiled || (!recvHost && e->haloRecvBytes)) return CFX_ERR_INVALID;
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));  // the pinned staging buffer of the previous import may still be read
-    if (e->haloRecvBytes) {
+    if (e->haloRecvBytes && recvHost) {
         memcpy(e->hHaloRecv, recvHost, (size_t) e->haloRecvBytes);
         HIP_TRY(hipMemcpyAsync(e->dHaloRecv, e->hHaloRecv, (size_t) e->haloRecvBytes, hipMemcpyHostToDevice, e->stream));
     }
@@ -1980,9 +1982,22 @@ int32_t cfx_halo_attach(cfx_engine *e, int32_t nPeers, const cfx_halo_peer *peer
         cfx_engine::MailPeer &m = e->mail[p];
         m.sendBytes = peers[p].send_bytes;
         m.recvBytes = peers[p].recv_bytes;
+        if (!peers[p].send_mailbox || !peers[p].recv_mailbox) return CFX_ERR_INVALID;
+        if (peers[p].device_memory) {
+            // mailboxes in HBM: mine (recv) on this GPU, the peer's (send) on its GPU — opened through IPC by the caller, or a
+            // plain pointer of another GPU of this process, which needs peer access
+            m.sendDev = (char *) peers[p].send_mailbox;
+            m.recvDev = (char *) peers[p].recv_mailbox;
+            hipPointerAttribute_t attr{};
+            if (hipPointerGetAttributes(&attr, m.sendDev) == hipSuccess && attr.device != e->device) {
+                hipError_t pe = hipDeviceEnablePeerAccess(attr.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return e->fail("cfx_halo_attach: no peer access to the neighbour tile's GPU");
+                (void) hipGetLastError();
+            }
+            continue;
+        }
         m.sendHost = peers[p].send_mailbox;
         m.recvHost = peers[p].recv_mailbox;
-        if (!m.sendHost || !m.recvHost) return CFX_ERR_INVALID;
         HIP_TRY(hipHostRegister(m.sendHost, CFX_HALO_MAILBOX_BYTES(m.sendBytes), hipHostRegisterMapped | hipHostRegisterPortable));
         HIP_TRY(hipHostRegister(m.recvHost, CFX_HALO_MAILBOX_BYTES(m.recvBytes), hipHostRegisterMapped | hipHostRegisterPortable));
         HIP_TRY(hipHostGetDevicePointer((void **) &m.sendDev, m.sendHost, 0));
@@ -2024,6 +2039,60 @@ int32_t cfx_halo_attach(cfx_engine *e, int32_t nPeers, const cfx_halo_peer *peer
     if ((rc = e->uploadConst(d.importRecvOff, ir.data(), ir.size()))) return rc;
     if ((rc = e->allocRaw(&e->haloTicket, 1))) return rc;
     HIP_TRY(hipMemset(e->haloTicket, 0, sizeof(int32_t)));
+    return CFX_OK;
+}
+
+int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **devicePtr, uint8_t *handle) {
+    if (!e || !e->tiled || messageBytes < 0 || !devicePtr || !handle) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    static_assert(sizeof(hipIpcMemHandle_t) <= CFX_IPC_HANDLE_BYTES, "IPC handle size");
+    const size_t bytes = CFX_HALO_MAILBOX_BYTES(messageBytes);
+    void *p = nullptr;
+    // fine-grained device memory first (stores of a kernel on ANOTHER GPU become visible while both kernels run); a plain
+    // allocation if the platform cannot export that
+    hipIpcMemHandle_t h;
+    bool ok = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess && hipIpcGetMemHandle(&h, p) == hipSuccess;
+    if (!ok) {
+        (void) hipGetLastError();
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess || hipIpcGetMemHandle(&h, p) != hipSuccess) {
+            (void) hipGetLastError();
+            if (p) (void) hipFree(p);
+            e->err = "cfx_halo_mailbox_alloc: device memory cannot be shared with other processes on this platform";
+            return CFX_ERR_STATE;
+        }
+    }
+    e->owned.push_back(p);
+    HIP_TRY(hipMemset(p, 0, bytes));  // epoch 0 = nothing published
+    memset(handle, 0, CFX_IPC_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof h);
+    *devicePtr = p;
+    return CFX_OK;
+}
+
+int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t *handle, void **devicePtr) {
+    if (!e || !e->tiled || !handle || !devicePtr) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    void *p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void) hipGetLastError();
+        e->err = "cfx_halo_mailbox_open: hipIpcOpenMemHandle failed";
+        return CFX_ERR_STATE;
+    }
+    e->ipcOpened.push_back(p);
+    *devicePtr = p;
+    return CFX_OK;
+}
+
+int32_t cfx_halo_device_buffers(cfx_engine *e, void **sendDev, void **recvDev) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    if (sendDev) *sendDev = e->dHaloSend;
+    if (recvDev) *recvDev = e->dHaloRecv;
     return CFX_OK;
 }
 

@@ -64,6 +64,9 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_halo_export)
     CFX_FN(cfx_halo_import)
     CFX_FN(cfx_halo_attach)
+    CFX_FN(cfx_halo_mailbox_alloc)
+    CFX_FN(cfx_halo_mailbox_open)
+    CFX_FN(cfx_halo_device_buffers)
     CFX_FN(cfx_halo_post)
     CFX_FN(cfx_halo_wait)
     CFX_FN(cfx_profile_kernel_count)

@@ -517,6 +517,15 @@ PYBIND11_MODULE(_cityflow, m) {
              "Exchange the halo device to device through shared-memory mailboxes (all tiles on one node); job_id must "
              "be unique per job and equal on every process")
         .def("unlink_mailboxes", &TiledEngineHost::unlinkMailboxes)
+        .def("enable_device_mailboxes", &TiledEngineHost::enableDeviceMailboxes, "job_id"_a,
+             "All tiles in this process: mailboxes in the receiving tile's device memory (peer HBM); False if not possible here")
+        .def("device_mailbox_phase", &TiledEngineHost::deviceMailboxPhase, "job_id"_a, "phase"_a,
+             "One tile per process: phase 1 (allocate + publish), a barrier, phase 2 (open + attach); False = not possible")
+        .def("halo_transport", &TiledEngineHost::haloTransport)
+        .def("halo_device_buffers", [](TiledEngineHost &e, int i) { return e.haloDeviceBuffers(i); }, "i"_a,
+             "(send pointer, send bytes, recv pointer, recv bytes) of local tile i's device-resident halo messages")
+        .def("step_begin_device", &TiledEngineHost::stepBeginDevice, "step_begin with the halo left in the device buffers")
+        .def("step_end_device", &TiledEngineHost::stepEndDevice, "step_end importing from the device buffers")
         .def_property_readonly("num_tiles", &TiledEngineHost::nTiles)
         .def_property_readonly("num_local", &TiledEngineHost::nLocal)
         .def("local_rank", &TiledEngineHost::localRank, "i"_a)

@@ -354,6 +354,62 @@ void TileEngine::attachMailboxes(const std::string &prefix) {
     mailboxes_ = true;
 }
 
+namespace {
+struct BoxRecord {  // what the receiver of a message publishes about its mailbox
+    long long pid;
+    unsigned long long ptr;
+    uint8_t handle[CFX_IPC_HANDLE_BYTES];
+    int32_t ready;
+};
+}  // namespace
+
+bool TileEngine::allocDeviceMailboxes(const std::string &prefix) {
+    if (!be_->cfx_halo_mailbox_alloc) return false;
+    recvBoxes_.clear();
+    for (const TilePeer &p : tn_.peers) {
+        void *ptr = nullptr;
+        BoxRecord rec{};
+        if (be_->cfx_halo_mailbox_alloc(dev_, p.recvBytes, &ptr, rec.handle) != CFX_OK) return false;
+        recvBoxes_.push_back(ptr);
+        rec.pid = (long long) getpid();
+        rec.ptr = (unsigned long long) (uintptr_t) ptr;
+        rec.ready = 1;
+        Mapping m{prefix + "_h_" + std::to_string(p.rank) + "_" + std::to_string(tn_.rank), nullptr, sizeof(BoxRecord)};
+        m.ptr = mapShared(m.name, m.bytes);
+        memcpy(m.ptr, &rec, sizeof rec);
+        maps_.push_back(m);
+    }
+    return true;
+}
+
+bool TileEngine::attachDeviceMailboxes(const std::string &prefix) {
+    std::vector<cfx_halo_peer> peers;
+    size_t i = 0;
+    for (const TilePeer &p : tn_.peers) {
+        Mapping m{prefix + "_h_" + std::to_string(tn_.rank) + "_" + std::to_string(p.rank), nullptr, sizeof(BoxRecord)};
+        m.ptr = mapShared(m.name, m.bytes);
+        maps_.push_back(m);
+        BoxRecord rec;
+        memcpy(&rec, m.ptr, sizeof rec);
+        if (!rec.ready) return false;  // the neighbour did not get this far
+        void *sendBox = nullptr;
+        if (rec.pid == (long long) getpid()) sendBox = (void *) (uintptr_t) rec.ptr;  // a tile of this very process
+        else if (be_->cfx_halo_mailbox_open(dev_, rec.handle, &sendBox) != CFX_OK) return false;
+        cfx_halo_peer hp{};
+        hp.send_off = p.sendOff;
+        hp.send_bytes = p.sendBytes;
+        hp.recv_off = p.recvOff;
+        hp.recv_bytes = p.recvBytes;
+        hp.send_mailbox = sendBox;
+        hp.recv_mailbox = recvBoxes_[i++];
+        hp.device_memory = 1;
+        peers.push_back(hp);
+    }
+    if (be_->cfx_halo_attach(dev_, (int32_t) peers.size(), peers.data()) != CFX_OK) return false;
+    mailboxes_ = deviceMailboxes_ = true;
+    return true;
+}
+
 void TileEngine::unlinkMailboxes() {
     for (Mapping &m : maps_) shm_unlink(m.name.c_str());  // the mappings stay valid; only the names go away
 }
@@ -412,6 +468,9 @@ void TileEngine::step(const std::vector<cfx_spawn> &globalRecs) {
 
 void TileEngine::haloExport() { check(be_->cfx_halo_export(dev_, send.data()), "cfx_halo_export"); }
 void TileEngine::haloImport() { check(be_->cfx_halo_import(dev_, recv.data()), "cfx_halo_import"); }
+void TileEngine::haloExportDevice() { check(be_->cfx_halo_export(dev_, nullptr), "cfx_halo_export"); }
+void TileEngine::haloImportDevice() { check(be_->cfx_halo_import(dev_, nullptr), "cfx_halo_import"); }
+void TileEngine::deviceBuffers(void **s, void **r) { check(be_->cfx_halo_device_buffers(dev_, s, r), "cfx_halo_device_buffers"); }
 void TileEngine::reset() { check(be_->cfx_reset(dev_), "cfx_reset"); }
 void TileEngine::sync() { check(be_->cfx_sync(dev_), "cfx_sync"); }
 void TileEngine::profileEnable(bool on) { check(be_->cfx_profile_enable(dev_, on ? 1 : 0), "cfx_profile_enable"); }
@@ -595,6 +654,28 @@ void TiledEngineHost::stepBegin() {
             }
 }
 
+void TiledEngineHost::stepBeginDevice() {
+    if (mailboxes_) throw std::runtime_error("tiling: step_begin_device() is the staged exchange; mailboxes are enabled");
+    flushPhases();
+    spawner_.step(step_, spawnBuf_);
+    for (auto &t : tiles_) {
+        t->uploadTables(spawner_);
+        t->step(spawnBuf_);
+    }
+    for (auto &t : tiles_) t->haloExportDevice();
+}
+
+void TiledEngineHost::stepEndDevice() {
+    for (auto &t : tiles_) t->haloImportDevice();
+    step_ += 1;
+}
+
+std::tuple<uintptr_t, int, uintptr_t, int> TiledEngineHost::haloDeviceBuffers(int i) {
+    void *s = nullptr, *r = nullptr;
+    tiles_.at((size_t) i)->deviceBuffers(&s, &r);
+    return {(uintptr_t) s, (int) tiles_[i]->send.size(), (uintptr_t) r, (int) tiles_[i]->recv.size()};
+}
+
 void TiledEngineHost::stepEnd() {
     const auto t0 = std::chrono::steady_clock::now();
     struct Acc {
@@ -622,6 +703,36 @@ void TiledEngineHost::enableMailboxes(const std::string &jobId) {
 
 void TiledEngineHost::unlinkMailboxes() {
     for (auto &t : tiles_) t->unlinkMailboxes();
+}
+
+static std::string shmPrefix(const std::string &jobId) {
+    std::string prefix = "/cfx_" + jobId;
+    for (char &c : prefix)
+        if (!(isalnum((unsigned char) c) || c == '_' || c == '/')) c = '_';
+    return prefix;
+}
+
+bool TiledEngineHost::deviceMailboxPhase(const std::string &jobId, int phase) {
+    if (step_ != 0) throw std::runtime_error("tiling: enable the mailboxes before the first step");
+    if (mailboxes_) return true;
+    const std::string prefix = shmPrefix(jobId);
+    bool ok = true;
+    for (auto &t : tiles_) ok = (phase == 1 ? t->allocDeviceMailboxes(prefix) : t->attachDeviceMailboxes(prefix)) && ok;
+    if (phase == 2 && ok) mailboxes_ = true;
+    return ok;
+}
+
+bool TiledEngineHost::enableDeviceMailboxes(const std::string &jobId) {
+    if (!allLocal_) throw std::runtime_error("tiling: enable_device_mailboxes() needs every tile in this process; use the two phases");
+    if (mailboxes_) return true;
+    const bool ok = deviceMailboxPhase(jobId, 1) && deviceMailboxPhase(jobId, 2);
+    unlinkMailboxes();
+    return ok;
+}
+
+std::string TiledEngineHost::haloTransport() const {
+    if (tiles_.empty() || !mailboxes_) return "staged";
+    return std::string(tiles_[0]->mailboxKind()) + " mailboxes";
 }
 
 void TiledEngineHost::nextStep() {

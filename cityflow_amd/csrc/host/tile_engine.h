@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "engine_host.h"
@@ -68,9 +69,20 @@ public:
     void step(const std::vector<cfx_spawn> &globalRecs);
     void haloExport();  // -> send
     void haloImport();  // <- recv
+    // the same with the messages left in / taken from the engine's device-resident buffers (a device-to-device transport
+    // such as RCCL send / recv moves them); the export returns when the message is complete
+    void haloExportDevice();
+    void haloImportDevice();
+    void deviceBuffers(void **send, void **recv);
     // device-initiated exchange through shared-memory mailboxes named <prefix>_<from>_<to> (POSIX shm)
     void attachMailboxes(const std::string &prefix);
     void unlinkMailboxes();  // remove the names once every process has mapped them
+    // ... or through mailboxes in the RECEIVER's device memory (peer HBM over xGMI; hipIpc between processes).  Two phases
+    // with a barrier between them: every tile allocates the mailboxes of its incoming messages and publishes their handles
+    // (tiny shm records <prefix>_h_<from>_<to>), then opens the ones it sends into.  false: not possible here.
+    bool allocDeviceMailboxes(const std::string &prefix);
+    bool attachDeviceMailboxes(const std::string &prefix);
+    const char *mailboxKind() const { return !mailboxes_ ? "none" : (deviceMailboxes_ ? "device" : "host"); }
     void haloPost();
     void haloWait();
     bool hasMailboxes() const { return mailboxes_; }
@@ -98,7 +110,8 @@ private:
     cfx_engine *dev_ = nullptr;
     int templatesUploaded_ = 0, routesUploaded_ = 0;
     std::vector<cfx_spawn> recs_;
-    bool mailboxes_ = false;
+    bool mailboxes_ = false, deviceMailboxes_ = false;
+    std::vector<void *> recvBoxes_;  // device mailboxes of the incoming messages, by peer
     struct Mapping {
         std::string name;
         void *ptr;
@@ -120,10 +133,19 @@ public:
     void nextStep();
     void stepBegin();
     void stepEnd();
+    void stepBeginDevice();  // ... with the halo of every local tile left in its device buffers (haloDeviceBuffers)
+    void stepEndDevice();
+    std::tuple<uintptr_t, int, uintptr_t, int> haloDeviceBuffers(int i);
     // Switch the halo to device-initiated mailboxes (all tiles of the job must share one node).  `jobId` must be
     // unique per job and identical on every process; call unlinkMailboxes() after all processes have enabled.
     void enableMailboxes(const std::string &jobId);
     void unlinkMailboxes();
+    // The same with the mailboxes in device memory.  All tiles local: enableDeviceMailboxes() does both phases (false:
+    // not possible, nothing changed — use enableMailboxes).  One tile per process: phase 1, a barrier of the caller's, phase
+    // 2, and every process must have succeeded in both.
+    bool enableDeviceMailboxes(const std::string &jobId);
+    bool deviceMailboxPhase(const std::string &jobId, int phase);
+    std::string haloTransport() const;
     int nTiles() const { return nTiles_; }
     int nLocal() const { return (int) tiles_.size(); }
     int localRank(int i) const { return localRanks_[i]; }

@@ -6,13 +6,18 @@ queues agree without communication), steps its own tile on its own GPU and excha
 its neighbour tiles once per step.  Results are bit-identical to the same network on a single engine
 (tests/test_tiling.py).
 
-The halo of a tile is a few KiB per neighbour.  Two transports:
-  * mailboxes (default when all ranks share one node): every directed neighbour message has a mailbox in POSIX shared
-    memory that both processes map and register with their GPU; the export kernel writes the message straight into
-    it and publishes the step's epoch, the import kernel of the neighbour waits for that epoch (`cfx_halo_post` /
-    `cfx_halo_wait`).  The step never synchronises with the host: no collective, no copy engine, ~10 us per exchange;
-  * staged: `cfx_halo_export` / `cfx_halo_import` through host buffers and a batch of point-to-point messages on a
-    host-side (gloo) process group — works across nodes.
+The halo of a tile is a few KiB per neighbour.  Transports (`transport=`; None tries them in this order and takes the
+first one EVERY rank can set up):
+  * "device": mailboxes in the RECEIVING tile's device memory — peer HBM, written over xGMI by the sender's export
+    kernel (hipIpc between the processes of a node); the export publishes the step's epoch, the neighbour's import kernel
+    waits for it (`cfx_halo_post` / `cfx_halo_wait`).  The step never synchronises with the host: no collective, no copy
+    engine;
+  * "host": the same protocol with the mailboxes in POSIX shared memory both processes map and register with their GPU
+    (PCIe instead of xGMI);
+  * "rccl": `cfx_halo_export` leaves the messages in device memory, one batch of RCCL send / recv (torch.distributed
+    P2P on the default nccl group) moves them GPU to GPU, `cfx_halo_import` reads them there — one host round trip per
+    step, works across nodes;
+  * "gloo": the messages staged through host buffers and a host-side gloo group — works everywhere.
 `torch.distributed`'s default backend (RCCL on GPUs) carries the reductions of the getters.  The reference has no counterpart (its parallelism is a thread pool inside one
 address space, reference src/engine/engine.cpp:19-31).
 
@@ -29,8 +34,24 @@ import torch.distributed as dist
 from . import _cityflow
 
 
+class _DeviceMemory:
+    """Raw device memory owned by the engine, for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _device_bytes(ptr, nbytes, device):
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    if device.type == "cpu":
+        import ctypes
+        return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_ubyte * nbytes).from_address(ptr)))
+    return torch.as_tensor(_DeviceMemory(ptr, nbytes), device=device)
+
+
 class DistributedEngine:
-    def __init__(self, config_file, rows, cols, backend_library="", halo_group=None, mailboxes=None):
+    def __init__(self, config_file, rows, cols, backend_library="", halo_group=None, mailboxes=None, transport=None):
         if not dist.is_initialized():
             raise RuntimeError("DistributedEngine needs an initialised torch.distributed process group")
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -50,22 +71,95 @@ class DistributedEngine:
         self._device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         self._eng._set_status_reducer(self._reduce_status)
         self._n_lanes = len(self._eng.lane_ids())
-        if mailboxes is None:  # shared memory needs one node
-            mailboxes = int(os.environ.get("LOCAL_WORLD_SIZE", self.world)) == self.world
-        self.mailboxes = bool(mailboxes)
-        if self.mailboxes:
-            job = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if self.rank == 0 else None]
-            dist.broadcast_object_list(job, src=0, group=self._halo)
-            self._eng.enable_mailboxes(job[0])
+        one_node = int(os.environ.get("LOCAL_WORLD_SIZE", self.world)) == self.world
+        staged = "rccl" if (dist.get_backend() == "nccl" and backend_library == "") else "gloo"
+        if transport is not None:
+            candidates = [transport]
+        elif mailboxes is not None:  # (the older switch: mailboxes or staged)
+            candidates = ["device", "host"] if mailboxes else [staged]
+        else:
+            candidates = (["device", "host"] if one_node else []) + ([staged, "gloo"] if staged != "gloo" else ["gloo"])
+        self.transport = None
+        errors = []
+        for cand in candidates:
+            try:
+                ok = self._setup(cand)
+            except Exception as exc:  # noqa: BLE001 - any local failure disqualifies the transport for everybody
+                ok = False
+                errors.append("%s: %s" % (cand, str(exc)[:160]))
+            if self._all_ok(ok):
+                self.transport = cand
+                break
+            stuck = torch.tensor([1 if self._eng.halo_transport() != "staged" else 0], dtype=torch.int32)
+            dist.all_reduce(stuck, op=dist.ReduceOp.MAX, group=self._halo)
+            if int(stuck.item()):
+                # some rank attached its mailboxes and another could not: these engines cannot go back (every rank raises)
+                raise RuntimeError("halo transport %r could not be set up on every rank (%s); build a new DistributedEngine "
+                                   "with another transport" % (cand, "; ".join(errors)))
+        if self.transport is None:
+            raise RuntimeError("no halo transport could be set up: " + "; ".join(errors))
+        self.mailboxes = self.transport in ("device", "host")
+
+    def _all_ok(self, ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._halo)
+        return int(flag.item()) == 1
+
+    def _job_name(self):
+        job = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if self.rank == 0 else None]
+        dist.broadcast_object_list(job, src=0, group=self._halo)
+        return job[0]
+
+    def _setup(self, transport):
+        if transport == "device":
+            job = self._job_name()
+            ok = self._eng.device_mailbox_phase(job, 1)
+            if not self._all_ok(ok):  # nobody has attached anything yet: the next transport can still be tried
+                self._eng.unlink_mailboxes()
+                return False
+            ok = self._eng.device_mailbox_phase(job, 2)
+            dist.barrier(group=self._halo)
+            self._eng.unlink_mailboxes()
+            return ok
+        if transport == "host":
+            self._eng.enable_mailboxes(self._job_name())
             dist.barrier(group=self._halo)   # every process has mapped its mailboxes ...
             self._eng.unlink_mailboxes()     # ... so the names can go
+            return True
+        if transport == "rccl":
+            if dist.get_backend() != "nccl" and self._device.type != "cpu":
+                raise RuntimeError("the rccl transport needs the nccl (RCCL) process group")
+            # (a CPU engine's "device" buffers are host memory and the default group is gloo: same code path, for tests)
+            sp, sn, rp, rn = self._eng.halo_device_buffers(0)
+            self._dsend = _device_bytes(sp, sn, self._device)
+            self._drecv = _device_bytes(rp, rn, self._device)
+            return True
+        if transport == "gloo":
+            return True
+        raise ValueError("unknown halo transport %r" % (transport,))
 
     # ---- stepping -------------------------------------------------------------------------------------------
     def halo_transport(self):
         """How the per-step halo travels between the tiles (bench.py reports it in config.halo)."""
-        return "gpu-written shared-memory mailboxes" if self.mailboxes else "staged over gloo"
+        return {"device": "gpu-written mailboxes in the receiving GPU's HBM (hipIpc peer memory, xGMI)",
+                "host": "gpu-written mailboxes in shared host memory",
+                "rccl": "RCCL send/recv of device-resident messages, one batch per step",
+                "gloo": "staged through host buffers over gloo"}[self.transport]
 
     def next_step(self):
+        if self.transport == "rccl":
+            self._eng.step_begin_device()  # spawn, the step's kernels, halo export; returns when the messages are complete
+            ops = []
+            for peer, so, sb, ro, rb in self._peers:
+                ops.append(dist.P2POp(dist.isend, self._dsend[so:so + sb], peer))
+                ops.append(dist.P2POp(dist.irecv, self._drecv[ro:ro + rb], peer))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                if self._device.type != "cpu":
+                    torch.cuda.current_stream().synchronize()  # the import runs on the engine's own stream
+            self._eng.step_end_device()
+            return
         self._eng.step_begin()  # spawn, the step's kernels, halo export
         if self.mailboxes:      # device-initiated exchange: nothing for the host to do
             self._eng.step_end()

@@ -314,7 +314,7 @@ typedef struct cfx_halo_layout {
     const int32_t *lanelink_local;  /* [n_global_lanelinks] global -> local laneLink id or -1 */
 } cfx_halo_layout;
 int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *layout);
-int32_t cfx_halo_export(cfx_engine *e, void *send_host);
+int32_t cfx_halo_export(cfx_engine *e, void *send_host);      /* NULL: see cfx_halo_device_buffers */
 int32_t cfx_halo_import(cfx_engine *e, const void *recv_host);
 
 /* Device-initiated exchange (no host round trip).  Every directed neighbour message gets a MAILBOX in host memory that
@@ -335,7 +335,26 @@ typedef struct cfx_halo_peer {
     int32_t recv_off, recv_bytes; /* ... and of the recv layout */
     void *send_mailbox;           /* CFX_HALO_MAILBOX_BYTES(send_bytes), written by this engine */
     void *recv_mailbox;           /* CFX_HALO_MAILBOX_BYTES(recv_bytes), written by the peer */
+    int32_t device_memory;        /* 0: host memory both processes map (registered with the device by the engine);
+                                   * 1: device pointers from cfx_halo_mailbox_alloc / _open — the mailbox lives in the
+                                   *    RECEIVER's HBM and the sender's export kernel writes it over xGMI */
+    int32_t reserved;
 } cfx_halo_peer;
+
+/* Mailboxes in device memory.  The receiver of a message owns its mailbox:
+ *   cfx_halo_mailbox_alloc(e, message_bytes, &ptr, handle)  zeroed device memory on e's GPU for one incoming message
+ *                              (CFX_HALO_MAILBOX_BYTES(message_bytes)), and a handle another PROCESS can open it with;
+ *   cfx_halo_mailbox_open(e, handle, &ptr)                  in the sender's process: the peer's mailbox as a pointer e's GPU
+ *                              can write through (hipIpcOpenMemHandle; peer HBM over xGMI between two GPUs of a node).
+ * Tiles of ONE process pass `ptr` itself (the engine enables peer access between their GPUs in cfx_halo_attach).
+ * CFX_ERR_STATE: this implementation / platform cannot do it — fall back to host-memory mailboxes. */
+#define CFX_IPC_HANDLE_BYTES 64
+int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t message_bytes, void **device_ptr, uint8_t handle[CFX_IPC_HANDLE_BYTES]);
+int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t handle[CFX_IPC_HANDLE_BYTES], void **device_ptr);
+/* The staged exchange with the messages left in device memory (for a device-to-device transport such as RCCL send / recv
+ * on these very buffers): cfx_halo_export(e, NULL) then writes the send buffer only on the device, cfx_halo_import(e, NULL)
+ * reads the recv buffer from the device.  Both buffers are fixed for the life of the engine. */
+int32_t cfx_halo_device_buffers(cfx_engine *e, void **send_dev, void **recv_dev);
 int32_t cfx_halo_attach(cfx_engine *e, int32_t n_peers, const cfx_halo_peer *peers);
 int32_t cfx_halo_post(cfx_engine *e);
 int32_t cfx_halo_wait(cfx_engine *e);

@@ -98,6 +98,8 @@ struct cfx_engine {
         char *sendBox, *recvBox;
     };
     std::vector<MailPeer> mail;
+    std::vector<char> stageSend, stageRecv;          // the staged exchange's messages when the caller passes NULL
+    std::deque<std::vector<char>> ownedBoxes;        // cfx_halo_mailbox_alloc
     int sendTotal = 0, recvTotal = 0;
     uint32_t generation = 1;
     unsigned long long haloEpoch() const { return ((unsigned long long) generation << 32) | (uint32_t) step; }
@@ -1394,15 +1396,60 @@ int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
     e->tiled = true;
     return CFX_OK;
 }
+// (device buffers of the HIP engine = plain host vectors here; NULL = "the message stays in / comes from them")
+static void stageBuffers(cfx_engine *e) {
+    int sendBytes = 0, recvBytes = 0;
+    for (size_t i = 0; i < e->ghostLane.size(); ++i) {
+        sendBytes = std::max(sendBytes, e->ghostSendOff[i] + CFX_HALO_MIG_BYTES);
+        recvBytes = std::max(recvBytes, e->ghostRecvOff[i] + CFX_HALO_TAIL_BYTES);
+    }
+    for (size_t i = 0; i < e->importLane.size(); ++i) {
+        sendBytes = std::max(sendBytes, e->importSendOff[i] + CFX_HALO_TAIL_BYTES);
+        recvBytes = std::max(recvBytes, e->importRecvOff[i] + CFX_HALO_MIG_BYTES);
+    }
+    if (e->stageSend.size() < (size_t) sendBytes + 8) e->stageSend.resize((size_t) sendBytes + 8);
+    if (e->stageRecv.size() < (size_t) recvBytes + 8) e->stageRecv.resize((size_t) recvBytes + 8);
+}
 int32_t cfx_halo_export(cfx_engine *e, void *send) {
     if (!e || !e->tiled) return CFX_ERR_INVALID;
     e->err.clear();
-    e->haloExport((char *) send);
+    if (!send) stageBuffers(e);
+    e->haloExport(send ? (char *) send : e->stageSend.data());
     return e->err.empty() ? CFX_OK : CFX_ERR_CAPACITY;
 }
 int32_t cfx_halo_import(cfx_engine *e, const void *recv) {
     if (!e || !e->tiled) return CFX_ERR_INVALID;
-    e->haloImport((const char *) recv);
+    if (!recv) stageBuffers(e);
+    e->haloImport(recv ? (const char *) recv : e->stageRecv.data());
+    return CFX_OK;
+}
+int32_t cfx_halo_device_buffers(cfx_engine *e, void **sendDev, void **recvDev) {
+    if (!e || !e->tiled) return CFX_ERR_INVALID;
+    stageBuffers(e);
+    if (sendDev) *sendDev = e->stageSend.data();
+    if (recvDev) *recvDev = e->stageRecv.data();
+    return CFX_OK;
+}
+// "device" mailboxes of a CPU engine: heap memory, usable by the tiles of ONE process only
+int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **ptr, uint8_t *handle) {
+    if (!e || !e->tiled || messageBytes < 0 || !ptr || !handle) return CFX_ERR_INVALID;
+    e->ownedBoxes.emplace_back(CFX_HALO_MAILBOX_BYTES(messageBytes), 0);
+    *ptr = e->ownedBoxes.back().data();
+    memset(handle, 0, CFX_IPC_HANDLE_BYTES);
+    const long long pid = (long long) getpid();
+    memcpy(handle, &pid, sizeof pid);
+    memcpy(handle + 8, ptr, sizeof(void *));
+    return CFX_OK;
+}
+int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t *handle, void **ptr) {
+    if (!e || !e->tiled || !handle || !ptr) return CFX_ERR_INVALID;
+    long long pid = 0;
+    memcpy(&pid, handle, sizeof pid);
+    if (pid != (long long) getpid()) {
+        e->err = "cfx_halo_mailbox_open: a CPU engine cannot map another process's heap";
+        return CFX_ERR_STATE;
+    }
+    memcpy(ptr, handle + 8, sizeof(void *));
     return CFX_OK;
 }
 

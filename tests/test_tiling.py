@@ -33,7 +33,10 @@ def same_state(va, vb, where):
 def run_pair(mod, cfg, rows, cols, steps, lib, phases_rng=None, check_every=1, mailboxes=False):
     ref = mod.Engine._with_backend(cfg, 1, lib)
     til = mod.TiledEngine(cfg, rows, cols, [], lib)
-    if mailboxes:
+    if mailboxes == "device":
+        assert til.enable_device_mailboxes("testd_%d_%d%d" % (os.getpid(), rows, cols))
+        assert til.halo_transport() == "device mailboxes"
+    elif mailboxes:
         til.enable_mailboxes("test_%d_%d%d" % (os.getpid(), rows, cols))
     assert til.num_tiles == rows * cols and til.num_local == rows * cols
     n_inter = len(ref.intersection_ids())
@@ -131,6 +134,31 @@ def test_two_ranks_gloo(scen, workdir, tmp_path, mailboxes):
     assert "TILED_OK 200" in out.stdout
 
 
+def test_two_ranks_device_resident_messages_gloo(scen, workdir, tmp_path):
+    """The "rccl" transport's code path (messages stay in the engine's buffers, one P2P batch on the default group) with
+    the CPU twin, whose device buffers are host memory, over gloo."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 200, 2, free_port(), {"CFX_TEST_TRANSPORT": "rccl"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 200" in out.stdout and "transport rccl" in out.stdout
+
+
+def test_transport_fallback_order_gloo(scen, workdir, tmp_path):
+    """transport=None: a CPU engine cannot share heap mailboxes between processes, so "device" is skipped by every rank
+    together and the host-memory mailboxes are taken."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 60, 2, free_port(), {"CFX_TEST_TRANSPORT": "", "CFX_TEST_MAILBOXES": "auto"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "transport host" in out.stdout
+
+
+def test_tiled_device_mailboxes_in_process_twin(mod, scen, workdir):
+    """All tiles in one process with the mailboxes allocated through cfx_halo_mailbox_alloc (heap memory for the CPU
+    engine, HBM for the HIP engine)."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    run_pair(mod, cfg, 2, 2, 300, TWIN_LIB, mailboxes="device")
+
+
 def test_four_ranks_separate_halo_group(scen, workdir, tmp_path):
     """2x2 tiles over four processes, the halo on its own gloo group (as under an RCCL default group), staged transport."""
     cfg = scen.materialize("grid_6x6", workdir)
@@ -175,6 +203,36 @@ def test_tiled_mailboxes_hip(mod, scen, workdir):
     """All tiles in one process, halo device to device through the mailboxes (import kernels wait on epochs)."""
     cfg = scen.materialize("grid_6x6", workdir)
     run_pair(mod, cfg, 2, 3, 500, mod._default_backend_path(), mailboxes=True)
+
+
+@pytest.mark.gpu
+def test_tiled_device_mailboxes_hip(mod, scen, workdir):
+    """All tiles in one process, mailboxes in device memory (cfx_halo_mailbox_alloc), export kernels write them directly."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    run_pair(mod, cfg, 2, 3, 500, mod._default_backend_path(), mailboxes="device")
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_peer_memory(scen, workdir, tmp_path):
+    """Two processes, one tile each, the halo through mailboxes in the RECEIVER's HBM opened with hipIpc (here both on
+    this box's one GPU; on a node the same handles are peer memory over xGMI)."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, "", 1, 2, 150, 2, free_port(), {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_TRANSPORT": "device"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 150" in out.stdout and "transport device" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["device", "rccl"])
+def test_one_tile_per_physical_gpu(scen, workdir, tmp_path, transport):
+    """One tile per PHYSICAL GPU (needs >= 2): peer-HBM mailboxes over xGMI, and RCCL send / recv of the messages."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs on this box")
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, "", 1, 2, 150, 2, free_port(), {"CFX_TEST_TRANSPORT": transport, "CFX_TEST_DIST_BACKEND": "nccl"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 150" in out.stdout and ("transport " + transport) in out.stdout
 
 
 @pytest.mark.gpu

@@ -14,14 +14,25 @@ from cityflow_amd.tiled import DistributedEngine  # noqa: E402
 
 def main():
     cfg, lib, rows, cols, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-    dist.init_process_group(backend=os.environ.get("CFX_TEST_DIST_BACKEND", "gloo"))
+    backend = os.environ.get("CFX_TEST_DIST_BACKEND", "gloo")
+    if backend == "nccl":  # one rank per physical GPU (RCCL refuses two ranks on one device)
+        import torch
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend=backend)
     rank = dist.get_rank()
     halo = None
     if os.environ.get("CFX_TEST_SUBGROUP") == "1":  # the layout of a GPU job: halo on its own host-side group
         import datetime
         halo = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
-    eng = DistributedEngine(cfg, rows, cols, backend_library=lib, halo_group=halo,
-                            mailboxes=os.environ.get("CFX_TEST_MAILBOXES", "1") == "1")
+    transport = os.environ.get("CFX_TEST_TRANSPORT") or None
+    eng = DistributedEngine(cfg, rows, cols, backend_library=lib, halo_group=halo, transport=transport,
+                            mailboxes=None if (transport or os.environ.get("CFX_TEST_MAILBOXES") == "auto")
+                            else os.environ.get("CFX_TEST_MAILBOXES", "1") == "1")
+    if transport:
+        assert eng.transport == transport, (eng.transport, transport)
     single = m.Engine._with_backend(cfg, 1, lib) if lib else m.Engine(cfg, 1)
     crossed = 0
     for s in range(steps):
@@ -51,7 +62,7 @@ def main():
     assert crossed > 0
     dist.barrier()
     if rank == 0:
-        print("TILED_OK", steps, single.get_vehicle_count())
+        print("TILED_OK", steps, single.get_vehicle_count(), "transport", eng.transport)
     dist.destroy_process_group()
 
 
