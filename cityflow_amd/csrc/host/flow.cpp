@@ -95,49 +95,76 @@ int Spawner::addTemplate(const cfx_vehicle_template &t) {
     return (int) templates.size() - 1;
 }
 
-// Router::dijkstra router.cpp:160-226 on road indices.  Same container types and the same push order,
-// so equal-cost ties resolve exactly as in the reference's std::priority_queue.
-static bool dijkstra(const HostRoadNet &net, int start, int end, std::vector<int> &buffer) {
-    std::map<int, double> dis;
-    std::map<int, int> from;
-    std::set<int> visited;
-    bool success = false;
-    using pair = std::pair<int, double>;
-    auto cmp = [](const pair &a, const pair &b) { return a.second > b.second; };
-    std::priority_queue<pair, std::vector<pair>, decltype(cmp)> queue(cmp);
+// Shortest road path between two anchors of a route (reference: Router::dijkstra router.cpp:160-226, RouterType::LENGTH;
+// DURATION is never selected by the reference's own API).  What has to match the reference is WHICH of several equally
+// long paths comes out — grids are full of ties — and that is decided by the order in which the frontier is popped.  The
+// reference keeps the frontier in a std::priority_queue ordered by cost alone, i.e. std::push_heap / std::pop_heap on a
+// vector; the frontier below is that vector with those two calls and the same push sequence (roads of the end
+// intersection in file order, every strict improvement pushed again, stale entries skipped when popped), so ties fall the
+// same way.  Costs and parents live in dense per-road arrays that are reused from call to call (a stamp marks the
+// entries of the current search), not in node-based maps.
+namespace {
+struct RoadSearch {
+    std::vector<double> cost;
+    std::vector<int> parent;
+    std::vector<uint32_t> reached, settled;  // == stamp: valid for the search in progress
+    std::vector<std::pair<int, double>> frontier;
+    uint32_t stamp = 0;
+    void begin(size_t nRoads) {
+        if (cost.size() < nRoads) {
+            cost.resize(nRoads);
+            parent.resize(nRoads);
+            reached.assign(nRoads, 0);
+            settled.assign(nRoads, 0);
+            stamp = 0;
+        }
+        if (++stamp == 0) {  // wrapped: forget everything
+            std::fill(reached.begin(), reached.end(), 0u);
+            std::fill(settled.begin(), settled.end(), 0u);
+            stamp = 1;
+        }
+        frontier.clear();
+    }
+};
+}  // namespace
 
-    dis[start] = 0;
-    queue.push(std::make_pair(start, 0));
-    while (!queue.empty()) {
-        int cur = queue.top().first;
-        if (cur == end) {
-            success = true;
+static bool shortestRoadPath(const HostRoadNet &net, int start, int end, std::vector<int> &out) {
+    static thread_local RoadSearch rs;
+    rs.begin(net.roads.size());
+    const auto costlier = [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.second > b.second; };
+    rs.cost[start] = 0.0;
+    rs.reached[start] = rs.stamp;
+    rs.parent[start] = -1;
+    rs.frontier.emplace_back(start, 0.0);
+    bool arrived = false;
+    while (!rs.frontier.empty()) {
+        const int road = rs.frontier.front().first;
+        if (road == end) {  // (checked before the pop, like the reference: the cheapest frontier entry is the target)
+            arrived = true;
             break;
         }
-        queue.pop();
-        if (visited.count(cur)) continue;
-        visited.insert(cur);
-        double curDis = dis.find(cur)->second;
-        for (int adj : net.inters[net.roads[cur].endInter].roads) {
-            if (!net.connectedToRoad(cur, adj)) continue;
-            auto iter = dis.find(adj);
-            double newDis = curDis + net.averageLength(adj);
-            if (iter == dis.end() || newDis < iter->second) {
-                from[adj] = cur;
-                dis[adj] = newDis;
-                queue.emplace(std::make_pair(adj, newDis));
-            }
+        std::pop_heap(rs.frontier.begin(), rs.frontier.end(), costlier);
+        rs.frontier.pop_back();
+        if (rs.settled[road] == rs.stamp) continue;
+        rs.settled[road] = rs.stamp;
+        const double here = rs.cost[road];
+        for (int next : net.inters[net.roads[road].endInter].roads) {
+            if (!net.connectedToRoad(road, next)) continue;
+            const double there = here + net.averageLength(next);
+            if (rs.reached[next] == rs.stamp && !(there < rs.cost[next])) continue;
+            rs.reached[next] = rs.stamp;
+            rs.cost[next] = there;
+            rs.parent[next] = road;
+            rs.frontier.emplace_back(next, there);
+            std::push_heap(rs.frontier.begin(), rs.frontier.end(), costlier);
         }
     }
-    std::vector<int> path;
-    path.push_back(end);
-    auto iter = from.find(end);
-    while (iter != from.end() && iter->second != start) {
-        path.emplace_back(iter->second);
-        iter = from.find(iter->second);
-    }
-    buffer.insert(buffer.end(), path.rbegin(), path.rend());
-    return success;
+    // the roads after `start` up to and including `end` (just `end` when it was never reached, like the reference)
+    const size_t mark = out.size();
+    out.push_back(end);
+    for (int r = rs.reached[end] == rs.stamp ? rs.parent[end] : -1; r >= 0 && r != start; r = rs.parent[r]) out.push_back(r);
+    std::reverse(out.begin() + (std::ptrdiff_t) mark, out.end());
+    return arrived;
 }
 
 // Router::updateShortestPath router.cpp:228-243
@@ -147,7 +174,7 @@ bool Spawner::expandRoute(const std::vector<int> &anchors, std::vector<int> &out
     out.push_back(anchors[0]);
     for (size_t i = 1; i < anchors.size(); ++i) {
         if (anchors[i - 1] == anchors[i]) continue;
-        if (!dijkstra(*net_, anchors[i - 1], anchors[i], out)) return false;
+        if (!shortestRoadPath(*net_, anchors[i - 1], anchors[i], out)) return false;
     }
     return out.size() > 1;
 }

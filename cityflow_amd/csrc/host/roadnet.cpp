@@ -79,100 +79,99 @@ inline bool onSegment(const Pt &A, const Pt &B, const Pt &P) {
 Pt readPoint(const Json &v) { return Pt{v.numberAt("x"), v.numberAt("y")}; }
 }  // namespace
 
-// Road::initLanesPoints roadnet.cpp:456-505.  Called twice by the reference loader (roadnet.cpp:127-129
-// before intersections are read — widths 0, nothing virtual — and again at 307-308).
+// Lane centre lines of a road (reference: Road::initLanesPoints roadnet.cpp:456-505; called twice by the reference loader,
+// roadnet.cpp:127-129 before intersections are read — widths 0, nothing virtual — and again at 307-308).  The road's
+// polyline is shortened by the intersection widths at its ends; every lane is that polyline shifted sideways by the
+// distance of the lane's middle from the road's left edge.  The shift direction of a vertex (the normal of the bisector
+// of its two segments) does not depend on the lane, so it is computed once per vertex; every coordinate still goes
+// through the same operations in the same order as in the reference, which the geometry hashes pin.
 void HostRoadNet::initLanesPoints(int r) {
     HostRoad &road = roads[r];
-    double dsum = 0.0;
-    std::vector<Pt> rp = road.points;
-    if (rp.size() < 2) throw JsonError("road " + road.id + ": needs at least 2 points");
-
-    const HostInter &si = inters[road.startInter];
-    const HostInter &ei = inters[road.endInter];
-    if (!si.isVirtual) {
-        double width = si.width;
-        Pt p1 = rp[0], p2 = rp[1];
-        rp[0] = add(p1, mul(unit(sub(p2, p1)), width));
+    std::vector<Pt> axis = road.points;
+    if (axis.size() < 2) throw JsonError("road " + road.id + ": needs at least 2 points");
+    const size_t last = axis.size() - 1;
+    if (!inters[road.startInter].isVirtual)
+        axis[0] = add(axis[0], mul(unit(sub(axis[1], axis[0])), inters[road.startInter].width));
+    if (!inters[road.endInter].isVirtual)
+        axis[last] = sub(axis[last], mul(unit(sub(axis[last], axis[last - 1])), inters[road.endInter].width));
+    std::vector<Pt> side(axis.size());  // unit vector pointing to the right of the direction of travel, per vertex
+    for (size_t j = 0; j <= last; ++j) {
+        Pt heading;
+        if (j == 0) heading = unit(sub(axis[1], axis[0]));
+        else if (j == last) heading = unit(sub(axis[j], axis[j - 1]));
+        else heading = unit(add(unit(sub(axis[j + 1], axis[j])), unit(sub(axis[j], axis[j - 1]))));
+        side[j] = neg(normal(heading));
     }
-    if (!ei.isVirtual) {
-        double width = ei.width;
-        Pt p1 = rp[rp.size() - 2], p2 = rp[rp.size() - 1];
-        rp[rp.size() - 1] = sub(p2, mul(unit(sub(p2, p1)), width));
-    }
+    double leftEdge = 0.0;
     for (int li = 0; li < road.nLanes; ++li) {
         HostLane &lane = lanes[road.laneStart + li];
-        double dmin = dsum;
-        double dmax = dsum + lane.width;
-        lane.points.clear();
-        for (int j = 0; j < (int) rp.size(); j++) {
-            Pt u;
-            if (j == 0) {
-                u = unit(sub(rp[1], rp[0]));
-            } else if (j + 1 == (int) rp.size()) {
-                u = unit(sub(rp[j], rp[j - 1]));
-            } else {
-                Pt u1 = unit(sub(rp[j + 1], rp[j]));
-                Pt u2 = unit(sub(rp[j], rp[j - 1]));
-                u = unit(add(u1, u2));
-            }
-            Pt v = neg(normal(u));
-            lane.points.push_back(add(rp[j], mul(v, (dmin + dmax) / 2.0)));
-        }
+        const double rightEdge = leftEdge + lane.width;
+        const double middle = (leftEdge + rightEdge) / 2.0;
+        lane.points.resize(axis.size());
+        for (size_t j = 0; j <= last; ++j) lane.points[j] = add(axis[j], mul(side[j], middle));
         lane.length = polylineLength(lane.points);
-        dsum += lane.width;
+        leftEdge += lane.width;
     }
 }
 
-// Intersection::initCrosses roadnet.cpp:515-576.  Note the reference's `continue` on parallel segment
-// pairs skips the `disb +=` accumulation (roadnet.cpp:535 vs 557); that is reproduced here.
+namespace {
+// Where polyline `a` first meets polyline `b`: a's segments in order and, for each of them, b's segments in order — two
+// laneLinks can meet more than once and this scan order decides which meeting is "the" cross (reference:
+// Intersection::initCrosses roadnet.cpp:515-576).  The distances are measured along each polyline up to the meeting
+// point; like in the reference, segments of b that are parallel to the current segment of a are skipped WITHOUT
+// counting their length (roadnet.cpp:535 vs 557).
+struct Meeting {
+    double alongA, alongB;
+};
+bool firstMeeting(const std::vector<Pt> &a, const std::vector<Pt> &b, Meeting &m) {
+    double walkedA = 0.0;
+    for (size_t sa = 0; sa + 1 < a.size(); ++sa) {
+        const Pt a0 = a[sa], a1 = a[sa + 1];
+        double walkedB = 0.0;
+        for (size_t sb = 0; sb + 1 < b.size(); ++sb) {
+            const Pt b0 = b[sb], b1 = b[sb + 1];
+            if (sgn(crossMul(sub(a1, a0), sub(b1, b0))) == 0) continue;
+            const Pt p = intersectPoint(a0, a1, b0, b1);
+            if (onSegment(a0, a1, p) && onSegment(b0, b1, p)) {
+                m.alongA = walkedA + len(sub(p, a0));
+                m.alongB = walkedB + len(sub(p, b0));
+                return true;
+            }
+            walkedB += len(sub(b1, b0));
+        }
+        walkedA += len(sub(a1, a0));
+    }
+    return false;
+}
+}  // namespace
+
+// The conflict points of an intersection: one per pair of its laneLinks whose curves meet, then every laneLink's list of
+// them ordered by distance along the laneLink.
 void HostRoadNet::initCrosses(int ii) {
     HostInter &inter = inters[ii];
-    std::vector<int> all;
-    for (auto &rl : inter.roadLinks)
-        for (int k = 0; k < rl.nLaneLinks; ++k) all.push_back(rl.llStart + k);
-    int n = (int) all.size();
-    for (int i = 0; i < n; i++) {
-        for (int j = i + 1; j < n; j++) {
-            const std::vector<Pt> &va = laneLinks[all[i]].points;
-            const std::vector<Pt> &vb = laneLinks[all[j]].points;
-            double disa = 0.0;
-            bool found = false;
-            for (int ia = 0; ia + 1 < (int) va.size() && !found; ia++) {
-                double disb = 0.0;
-                for (int ib = 0; ib + 1 < (int) vb.size(); ib++) {
-                    Pt A1 = va[ia], A2 = va[ia + 1];
-                    Pt B1 = vb[ib], B2 = vb[ib + 1];
-                    if (sgn(crossMul(sub(A2, A1), sub(B2, B1))) == 0) continue;
-                    Pt P = intersectPoint(A1, A2, B1, B2);
-                    if (onSegment(A1, A2, P) && onSegment(B1, B2, P)) {
-                        HostCross c;
-                        c.ll[0] = all[i];
-                        c.ll[1] = all[j];
-                        c.dist[0] = disa + len(sub(P, A1));
-                        c.dist[1] = disb + len(sub(P, B1));
-                        inter.crosses.push_back(c);
-                        found = true;
-                        break;
-                    }
-                    disb += len(sub(vb[ib + 1], vb[ib]));
-                }
-                if (!found) disa += len(sub(va[ia + 1], va[ia]));
-            }
+    std::vector<int> links;
+    for (const auto &rl : inter.roadLinks)
+        for (int k = 0; k < rl.nLaneLinks; ++k) links.push_back(rl.llStart + k);
+    for (size_t i = 0; i < links.size(); ++i)
+        for (size_t j = i + 1; j < links.size(); ++j) {
+            Meeting m;
+            if (!firstMeeting(laneLinks[links[i]].points, laneLinks[links[j]].points, m)) continue;
+            HostCross c;
+            c.ll[0] = links[i];
+            c.ll[1] = links[j];
+            c.dist[0] = m.alongA;
+            c.dist[1] = m.alongB;
+            inter.crosses.push_back(c);
         }
-    }
-    for (int c = 0; c < (int) inter.crosses.size(); ++c) {
-        laneLinks[inter.crosses[c].ll[0]].crosses.push_back(c);
-        laneLinks[inter.crosses[c].ll[1]].crosses.push_back(c);
-    }
-    // Same std::sort, same comparator, same initial order as the reference => the same permutation,
-    // including among equal distances (sibling laneLinks of one start lane all cross at distance 0).
-    for (int ll : all) {
-        std::vector<int> &cs = laneLinks[ll].crosses;
-        const std::vector<HostCross> &xs = inter.crosses;
-        std::sort(cs.begin(), cs.end(), [ll, &xs](int ca, int cb) -> bool {
-            double da = xs[ca].dist[xs[ca].ll[0] != ll];
-            double db = xs[cb].dist[xs[cb].ll[0] != ll];
-            return da < db;
+    const std::vector<HostCross> &xs = inter.crosses;
+    for (int c = 0; c < (int) xs.size(); ++c)
+        for (int side = 0; side < 2; ++side) laneLinks[xs[c].ll[side]].crosses.push_back(c);
+    // std::sort on the same initial order with the same comparison gives the reference's permutation, also among equal
+    // distances (the sibling laneLinks of one start lane all leave it at distance 0, and std::sort is not stable)
+    for (int ll : links) {
+        std::vector<int> &mine = laneLinks[ll].crosses;
+        std::sort(mine.begin(), mine.end(), [ll, &xs](int ca, int cb) {
+            return xs[ca].dist[xs[ca].ll[0] != ll] < xs[cb].dist[xs[cb].ll[0] != ll];
         });
     }
 }
