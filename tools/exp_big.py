@@ -1,0 +1,24 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+libs = sys.argv[1:]
+sys.argv = [sys.argv[0]]
+import bench
+from cityflow_amd import _cityflow
+cfg = bench.build_workload("/tmp/cfa_exp", 0, scenario="gen_100x100", n_extra=33000)
+base = _cityflow.Engine(cfg, 1)
+for _ in range(300): base.next_step()
+arch = base.snapshot()
+del base
+for lib in [_cityflow._default_backend_path()] + libs:
+    eng = _cityflow.Engine._with_backend(cfg, 1, os.path.abspath(lib))
+    res = {}
+    for rep in range(2):
+        eng.load(arch); eng.next_step(); eng.next_step(); eng.sync()
+        eng._profile_enable(True)
+        for _ in range(6): eng.next_step()
+        prof = eng._profile_read(); eng._profile_enable(False)
+        for k, (ms, n) in prof.items():
+            if n: res.setdefault(k, []).append(ms / n * 1e3)
+    print(os.path.basename(lib), {k: round(min(v), 1) for k, v in res.items()}, flush=True)
+    del eng
