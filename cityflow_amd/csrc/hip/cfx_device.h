@@ -34,6 +34,7 @@ struct DevNet {
     const double2 *xDD;             // [E] {xDist of the entry, xDist of its peer entry}
     const int4 *xPack;              // [E] {peer laneLink, peer's llLocal bit, peer's RoadLinkType, 0}
     const int4 *llPack;             // [K] {first cross entry, end of cross entries, mask word base of its intersection, RoadLinkType}
+    const int4 *laneLL4;            // [L] the lane's laneLinks (Lane::laneLinks order, -1 padded); x = -2: more than four, use the CSR
     // tiling (cfx_halo_config); both null for an engine that owns its whole network
     const uint8_t *laneGhost;       // [L] 1: lane owned by a neighbouring tile; its vehicles are frozen proxies
     const uint8_t *laneSpare;       // [L] spare slots behind the lane's vehicles (1 admission + halo migrants)

@@ -802,6 +802,14 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         for (int k = 0; k < e->K; ++k)
             llpack[k] = make_int4(n->ll_x_start[k], n->ll_x_start[k + 1], maskStart[n->ll_inter[k]], n->ll_type[k]);
         if ((rc = e->uploadConst(d.llPack, llpack.data(), llpack.size()))) return rc;
+        std::vector<int4> ll4((size_t) e->L);
+        for (int l = 0; l < e->L; ++l) {
+            const int b = n->lane_ll_start[l], cnt = n->lane_ll_start[l + 1] - b;
+            int v[4] = {-1, -1, -1, -1};
+            for (int q = 0; q < cnt && q < 4; ++q) v[q] = n->lane_ll[b + q];
+            ll4[l] = cnt > 4 ? make_int4(-2, -2, -2, -2) : make_int4(v[0], v[1], v[2], v[3]);
+        }
+        if ((rc = e->uploadConst(d.laneLL4, ll4.data(), ll4.size()))) return rc;
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
@@ -1026,7 +1034,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const int nStat = (int) std::min<size_t>(std::max<size_t>(1, activeEst >> 16), 64);
         RingCommit rk{e->rScratch, e->rMovers, e->waitHead, e->curPhase, e->remain, (int) e->cfg.rl_traffic_light, (int) e->nMaskWords,
                       e->sc, e->rFinKey, e->rFinVid, e->rFinTerm, e->rFinCap, e->jobCount,
-                      e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat, e->vt.state, e->exactTimes() ? 1 : 0};
+                      e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat, e->vt.state, e->slotOf, e->exactTimes() ? 1 : 0};
         e->launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
         RING_CHECK("kr_commit")
 #undef RING_CHECK
@@ -2148,6 +2156,27 @@ int32_t cfx_halo_wait(cfx_engine *e) {
     e->liveUpper += (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS;
     return CFX_OK;
 }
+
+#ifdef CFX_TRACE
+// developer build: dump the action kernel's per-block phase stamps of the LAST step to a file (raw int64[blocks][8])
+int32_t cfx_trace_dump(const char *path, int32_t blocks) {
+    static long long *buf = nullptr;
+    if (!buf) {
+        (void) hipMalloc((void **) &buf, (size_t) 65536 * 8 * sizeof(long long));
+        (void) hipMemset(buf, 0, (size_t) 65536 * 8 * sizeof(long long));
+        (void) hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof buf);
+        return 0;
+    }
+    (void) hipDeviceSynchronize();
+    std::vector<long long> h((size_t) blocks * 8);
+    (void) hipMemcpy(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    fwrite(h.data(), sizeof(long long), h.size(), f);
+    fclose(f);
+    return 0;
+}
+#endif
 
 int32_t cfx_profile_kernel_count(void) { return kNumProfKernels; }
 const char *cfx_profile_kernel_name(int32_t k) { return (k >= 0 && k < kNumProfKernels) ? kProfNames[k] : ""; }

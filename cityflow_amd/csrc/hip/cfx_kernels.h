@@ -290,16 +290,19 @@ __device__ inline bool canPassActive(const C &c, const cfx_vehicle_template *tv,
         }
     }
     if (yield == 1) {  // Floyd cycle walk over committed blockers (deadlock => pass), roadnet.cpp:662-674
+        // (every link of the chain is looked up once: a lookup is two or three dependent loads)
         int fast = foeSlot, slow = foeSlot;
         int guard = 0;
-        while (fast >= 0 && blockerOf(c, fast) >= 0) {
+        int fastBlocker = blockerOf(c, fast);
+        while (fastBlocker >= 0) {
             slow = blockerOf(c, slow);
-            fast = blockerOf(c, blockerOf(c, fast));
+            fast = blockerOf(c, fastBlocker);
             if (slow == fast) {
                 yield = -1;
                 break;
             }
-            if (++guard > (1 << 22)) break;  // cannot happen (Floyd terminates); bounds a corrupted chain
+            if (fast < 0 || ++guard > (1 << 22)) break;  // (the bound cannot be hit: Floyd terminates)
+            fastBlocker = blockerOf(c, fast);
         }
     }
     return yield == -1;
@@ -309,7 +312,7 @@ __device__ inline bool canPassActive(const C &c, const cfx_vehicle_template *tv,
 // drivables ahead on its route, within the look-ahead bound.  Returns the leader as a Tail (slot < 0: none).
 template <class C>
 __device__ inline Tail findHeadLeader(const C &c, const cfx_vehicle_template *tv, int s, int d, double myDis, double bound,
-                                      int nd0, double dlen, double *gapOut) {
+                                      int nd0, double dlen, double *gapOut, int4 firstHop = make_int4(-2, -2, -2, -2)) {
     // head of a lane whose only vehicle was admitted this step => it IS the admitted vehicle
     const bool viewerNew = d < c.n.L && c.admitStep[d] == c.step && committedCount(c, d) == 0;
     Tail best{-1, 0, -1, 0.0, 0.0};
@@ -320,9 +323,9 @@ __device__ inline Tail findHeadLeader(const C &c, const cfx_vehicle_template *tv
     for (;;) {
         if (nd < 0) break;
         if (nd >= c.n.L) {
-            int sl = c.n.llStartLane[nd - c.n.L];
-            for (int q = c.n.laneLLStart[sl]; q < c.n.laneLLStart[sl + 1]; ++q) {
-                const Tail cand = tailNowOf(c, c.n.L + c.n.laneLL[q]);
+            // the last vehicles of ALL laneLinks that leave the lane this laneLink leaves (vehicle.cpp:170-181)
+            auto consider = [&](int ll) {
+                const Tail cand = tailNowOf(c, c.n.L + ll);
                 if (cand.slot >= 0) {
                     double cg = dist + cand.dis - tv[cand.templ].len;
                     if (best.slot < 0 || cg < gap) {
@@ -330,6 +333,16 @@ __device__ inline Tail findHeadLeader(const C &c, const cfx_vehicle_template *tv
                         gap = cg;
                     }
                 }
+            };
+            if (firstHop.x != -2) {  // the caller already holds the list (the head's own lane, first hop)
+                if (firstHop.x >= 0) consider(firstHop.x);
+                if (firstHop.y >= 0) consider(firstHop.y);
+                if (firstHop.z >= 0) consider(firstHop.z);
+                if (firstHop.w >= 0) consider(firstHop.w);
+                firstHop.x = -2;
+            } else {
+                int sl = c.n.llStartLane[nd - c.n.L];
+                for (int q = c.n.laneLLStart[sl]; q < c.n.laneLLStart[sl + 1]; ++q) consider(c.n.laneLL[q]);
             }
             if (best.slot >= 0) break;
         } else {
@@ -533,6 +546,8 @@ struct SlotIn {  // everything the action phase loads by slot index alone
     int leaderSlot;  // slot of the vehicle ahead in the same drivable (valid unless head)
     int idx, nNow;   // position in the drivable's list and its length (ring layout only; idx -1 = not known)
     double2 lm;      // {length, max speed} of the drivable
+    int4 hop;        // the laneLinks leaving the vehicle's lane if the loader holds them (x = -2: not), see findHeadLeader
+    bool laneAdmitted;  // ring layout: the vehicle's lane admitted a vehicle this step
 };
 
 // Every load that depends only on the slot index is issued up front, before the first branch, so the memory
@@ -556,6 +571,8 @@ __device__ __forceinline__ SlotIn loadSlot(const StepCtx &c, int s) {
     in.idx = -1;
     in.nNow = -1;
     in.lm = c.n.drvLM[in.d >= 0 ? in.d : 0];  // (an empty spare slot carries drivable -1)
+    in.hop = make_int4(-2, -2, -2, -2);
+    in.laneAdmitted = false;
     return in;
 }
 
@@ -596,7 +613,7 @@ __device__ __forceinline__ void actionOne(const C &c, const Out &o, const cfx_ve
         ls = sp;
         gap = disPrev - tv[templPrev].len - dis;
     } else {
-        const Tail lead = findHeadLeader(c, tv, s, d, dis, t.approach_dist, nd0, dlen, &gap);
+        const Tail lead = findHeadLeader(c, tv, s, d, dis, t.approach_dist, nd0, dlen, &gap, in.hop);
         ls = lead.slot;
         leaderTempl = lead.templ;
         leaderSpeed = lead.speed;
@@ -1044,7 +1061,8 @@ __device__ inline double orderedSum(double cum, int F, double *term, const doubl
 // arrive (ticket) folds the total into cumulativeTravelTime.  `finTicket[0]` = ticket, `finTicket[2..3]` = 64-bit total.
 template <class VidAt>
 __device__ inline bool exactFinishStatistics(double now, const VidTable &vt, DevScalars *sc, int F, VidAt vidAt, uint8_t *stateW,
-                                             int32_t *finTicket, int part, int nParts, int nUncounted) {
+                                             int32_t *finTicket, int part, int nParts, int nUncounted,
+                                             int32_t *slotOfW = nullptr) {
     __shared__ long long sAcc[kBlock / 64];
     __shared__ int lastShared;
     const int per = (F + nParts - 1) / nParts;
@@ -1053,6 +1071,7 @@ __device__ inline bool exactFinishStatistics(double now, const VidTable &vt, Dev
     for (int i = lo + (int) threadIdx.x; i < hi; i += blockDim.x) {
         const int vid = vidAt(i);
         if (stateW) stateW[vid] = 2;
+        if (slotOfW) slotOfW[vid] = -1;
         acc += (long long) ((now - vt.enterTime[vid]) * 1024.0);
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);

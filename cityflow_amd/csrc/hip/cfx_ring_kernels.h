@@ -123,9 +123,10 @@ __device__ __forceinline__ int blockerVid(const RingCtx &c, int slot) {
     const int2 b = c.blkR[slot];
     return (b.x >= 0 && b.y == c.step - 1 && c.vState[b.x] == 1) ? b.x : -1;
 }
+// (chain walks: a finished vehicle's slotOf entry is -1 — the finish statistics clear it — so two loads per link)
 __device__ __forceinline__ int blockerOf(const RingCtx &c, int slot) {
-    const int v = blockerVid(c, slot);
-    return v >= 0 ? c.slotOf[v] : -1;
+    const int2 b = c.blkR[slot];
+    return (b.x >= 0 && b.y == c.step - 1) ? c.slotOf[b.x] : -1;
 }
 __device__ __forceinline__ int keepBlocker(const RingCtx &, int blockerSlot) { return blockerSlot; }
 
@@ -161,28 +162,69 @@ constexpr int kRingIdxBits = 20;  // list index inside a drivable (ring capaciti
 
 // Tail of Engine::vehicleControl on the ring layout: stayers are committed right here (their slot does not move), leavers
 // leave a MoverRec / a finish record and a mark in the next generation.
+// What finishing a vehicle that leaves its drivable needs beyond its slot; valid = the caller requested it early
+// (actionOneRing, round A), otherwise it is loaded here.
+struct LeaverPrefetch {
+    bool valid;
+    double nextLen;  // length of the next drivable (nd0 >= 0)
+    int vid, route, routePos;
+};
+
+// Tail of Engine::vehicleControl on the ring layout (engine.cpp:212-221, Vehicle::setDeltaDistance vehicle.cpp:49-68):
+// stayers are committed right here (their slot does not move), leavers leave a MoverRec / a finish record and a mark in
+// the next generation.
 template <bool LC>
 __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cfx_vehicle_template &t, int s, int d, int /*vid*/,
                                     double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int idx = -1,
-                                    int nNow = -1) {
+                                    int nNow = -1, LeaverPrefetch lp = LeaverPrefetch{false, 0.0, 0, 0, 0}) {
     static_assert(!LC, "the ring layout does not run lane change");
     v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
     v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);
-    const MoveOut m = computeMove(c, t, s, d, speed, dis, dlen, nd0, v);
+    // computeMove (cfx_kernels.h) with the first hop's two lengths in registers
+    double deltaDis;
+    if (v < 0) {
+        deltaDis = 0.5 * speed * speed / t.max_neg_acc;
+        v = 0;
+    } else {
+        deltaDis = (speed + v) * c.interval / 2;
+    }
+    double ndis = deltaDis + dis;
+    int newDrv = -1;
+    if (ndis > dlen) {
+        if (!lp.valid) {
+            lp.nextLen = nd0 >= 0 ? c.n.drvLength[nd0] : 0.0;
+            lp.vid = c.s.vid[s];
+            lp.route = c.s.route[s];
+            lp.routePos = c.s.routePos[s];
+        }
+        ndis -= dlen;  // (== c.n.drvLength[d])
+        int drivable = nd0;
+        newDrv = drivable >= 0 ? drivable : -2;
+        if (drivable >= 0 && ndis > lp.nextLen) {  // runs through a whole drivable in one step: the general walk goes on
+            int nxt = nextOf(c.n, c.t, drivable, lp.route, lp.routePos);
+            for (;;) {
+                ndis -= c.n.drvLength[drivable];
+                drivable = nxt;
+                newDrv = drivable >= 0 ? drivable : -2;
+                if (drivable < 0 || !(ndis > c.n.drvLength[drivable])) break;
+                nxt = nextOf(c.n, c.t, drivable, lp.route, lp.routePos);
+            }
+        }
+    }
     const int bv = blockerSlot >= 0 ? c.s.vid[blockerSlot] : -1;
-    if (idx < 0) {  // (cross phase: the job carries the slot only)
+    if (idx < 0) {  // (cross phase of the generic kernels: the job carries the slot only)
         const int2 geo = c.ringGeo[d];
         idx = (s - geo.x - c.head[d]) & geo.y;
         nNow = cntNow(c, d);
     }
-    if (m.newDrv == -1) {
-        o.disN[s] = m.ndis;
-        o.speedN[s] = m.v;
+    if (newDrv == -1) {
+        o.disN[s] = ndis;
+        o.speedN[s] = v;
         if (bv >= 0) o.blk[s] = make_int2(bv, c.step);
         if (idx == nNow - 1) {  // the last vehicle of its drivable leaves the tail record of this step's end
             TailRec r;
-            r.dis = m.ndis;
-            r.speed = m.v;
+            r.dis = ndis;
+            r.speed = v;
             r.slot = s;
             r.templ = c.s.templ[s];
             r.prevDrv = c.s.prevDrv[s];
@@ -194,26 +236,25 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
     o.speedN[s] = -1.0;  // "left its drivable": what kr_commit's general path looks at (a speed is never negative)
     atomicAdd(&o.scratch[d].x, 1);
     atomicMax(&o.scratch[d].y, idx);
-    const int vid = c.s.vid[s];
-    if (m.newDrv >= 0) {
+    if (newDrv >= 0) {
         MoverRec r;
-        r.vid = vid;
+        r.vid = lp.vid;
         r.templ = c.s.templ[s];
-        r.route = c.s.route[s];
-        r.routePos = c.s.routePos[s];
+        r.route = lp.route;
+        r.routePos = lp.routePos;
         r.oldDrv = d;
-        r.newDrv = m.newDrv;
+        r.newDrv = newDrv;
         r.blockerVid = bv;
-        r.dis = m.ndis;
-        r.speed = m.v;
-        atomicAdd(&o.scratch[m.newDrv].w, 1);
-        r.nextIn = atomicExch(&o.scratch[m.newDrv].z, s);
+        r.dis = ndis;
+        r.speed = v;
+        atomicAdd(&o.scratch[newDrv].w, 1);
+        r.nextIn = atomicExch(&o.scratch[newDrv].z, s);
         o.movers[s] = r;
     } else {
         const int f = atomicAdd(&o.sc->nFinishedStep, 1);
         if (f < o.finCap) {
             o.finKey[f] = ((long long) d << kRingIdxBits) | idx;
-            o.finVid[f] = vid;
+            o.finVid[f] = lp.vid;
         } else {
             o.sc->overflow = 1;
         }
@@ -323,8 +364,8 @@ __device__ inline void llstateRing(const RingCtx &c, int k) {
 __device__ inline Notified notified(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x) {
     Notified nf{-1, 0, 0.0, 0.0};
     const int4 dyn = c.llDyn[k];
+    const LLAux a = c.llAux[k];  // (issued together with llDyn: this phase is bound by rounds of dependent loads, not bytes)
     if (dyn.x < 0 && dyn.y < 0 && dyn.w == 0) return nf;  // nobody to yield to on that laneLink
-    const LLAux a = c.llAux[k];
     if (dyn.x >= 0) {
         const double vehDistance = a.uDis - tv[a.uTempl].len;
         const double crossDistance = a.llLen - x;
@@ -466,6 +507,188 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
     }
 }
 
+// ---- one vehicle's phase 4 on the ring layout, organised by ROUNDS of memory accesses --------------------------------
+// Same arithmetic as actionOne / finishAction (cfx_kernels.h), expression for expression.  What differs is when memory
+// is touched.  A wave holds followers, heads of drivables, vehicles near an intersection and vehicles about to leave
+// their drivable side by side; written naively each kind walks its own chain of dependent loads inside its own branch
+// and the wave pays for the chains one after the other.  Here every lane first REQUESTS whatever its kind may need
+// (round A: tails of the drivables ahead, the gate record of the next laneLink, the length of the next drivable and the
+// identity columns of a vehicle that may leave), then everything that depends on those (round B: the tail of the lane
+// behind the next laneLink), and only then is anything decided — the wave waits for memory twice instead of six times.
+__device__ __forceinline__ Tail tailIfCurrent(const TailRec &r, int wantTag) {
+    Tail t = tailOfRec(r);
+    if (r.tag != wantTag) t.slot = -1;
+    return t;
+}
+
+template <class Push>
+__device__ __forceinline__ void actionOneRing(const RingCtx &c, const RingOut &o, const cfx_vehicle_template *tv, const int s,
+                                              const SlotIn &in, Push push) {
+    const int d = in.d, templIdx = in.templIdx, nd0 = in.nd0, flags = in.flags, L = c.n.L;
+    const double speed = in.speed, dis = in.dis;
+    const cfx_vehicle_template &t = tv[templIdx];
+    const double interval = c.interval;
+    const double dlen = in.lm.x;
+    const bool head = in.head, onLane = d < L, nextIsLink = nd0 >= L;
+    const bool related = !onLane || (nextIsLink && dlen - dis <= t.approach_dist);  // Vehicle::isIntersectionRelated
+    const bool custom = (flags & 1) != 0;
+
+    // ================= round A: requests that depend on nothing but the slot
+    const bool hopHead = head && onLane && nextIsLink && in.hop.x != -2;  // head of a lane: tails of the laneLinks leaving it
+    const bool linkHead = head && !onLane;                                // head of a laneLink: tail of its end lane
+    TailRec hopRec[4];
+    double linkLen = 0.0;
+    if (hopHead) {
+        if (in.hop.x >= 0) hopRec[0] = c.tailNow[L + in.hop.x];
+        if (in.hop.y >= 0) hopRec[1] = c.tailNow[L + in.hop.y];
+        if (in.hop.z >= 0) hopRec[2] = c.tailNow[L + in.hop.z];
+        if (in.hop.w >= 0) hopRec[3] = c.tailNow[L + in.hop.w];
+        linkLen = c.n.drvLength[nd0];
+    }
+    TailRec endRec{};
+    if (linkHead) endRec = c.tailR[nd0];
+    int4 gate = make_int4(0, 0, 0, 0);
+    const int gateLink = onLane ? nd0 - L : d - L;
+    if (related) gate = c.llGate[gateLink];
+    // may it run past the end of its drivable this step?  (only a hint: decides what is requested early)
+    LeaverPrefetch lp{false, 0.0, 0, 0, 0};
+    if (dlen - dis <= (speed + t.max_pos_acc * interval) * interval + 1.0) {
+        lp.valid = true;
+        lp.nextLen = nd0 >= 0 ? c.n.drvLength[nd0] : 0.0;
+        lp.vid = c.s.vid[s];
+        lp.route = c.s.route[s];
+        lp.routePos = c.s.routePos[s];
+    }
+    double customSpeed = 0.0;
+    if (custom) customSpeed = c.vCustomSpeed[in.vid];
+
+    // ================= round B: what hangs on the gate record (a lane's vehicle near the intersection)
+    const bool approaching = related && nextIsLink;  // (a vehicle ON a laneLink has nd0 = its end lane)
+    TailRec laneNow{}, laneCommitted{};
+    if (approaching) {
+        laneNow = c.tailNow[gate.y];                     // Lane::canEnter looks at the lane as of this step
+        if (hopHead) laneCommitted = c.tailR[gate.y];    // the leader search two drivables ahead, as of the last commit
+    }
+
+    // ================= leader / gap (Vehicle::updateLeaderAndGap vehicle.cpp:157-196)
+    double gap = 0.0;
+    int ls, leaderTempl = in.templPrev;
+    double leaderSpeed = in.speedPrev;
+    if (!head) {
+        ls = in.leaderSlot;
+        gap = in.disPrev - tv[in.templPrev].len - dis;
+    } else {
+        Tail best{-1, 0, -1, 0.0, 0.0};
+        bool resolved = false;
+        double dist = dlen - dis;
+        if (hopHead) {
+            // first hop: the last vehicles of all laneLinks leaving this lane, closest first (findHeadLeader, `consider`)
+            for (int q = 0; q < 4; ++q) {
+                const int ll = q == 0 ? in.hop.x : (q == 1 ? in.hop.y : (q == 2 ? in.hop.z : in.hop.w));
+                if (ll < 0) continue;
+                const Tail cand = tailOfRec(hopRec[q]);
+                if (cand.slot >= 0) {
+                    const double cg = dist + cand.dis - tv[cand.templ].len;
+                    if (best.slot < 0 || cg < gap) {
+                        best = cand;
+                        gap = cg;
+                    }
+                }
+            }
+            resolved = best.slot >= 0;
+            if (!resolved) {
+                dist += linkLen;
+                if (dist > t.approach_dist) {
+                    resolved = true;  // nothing within the look-ahead bound (vehicle.cpp:190-191)
+                } else {
+                    // second hop: the lane behind the laneLink (dist <= bound implies `approaching`: its records are here).
+                    // A vehicle admitted this step sees this step's admissions on lanes before its own (lastSlotForLeader).
+                    const bool viewerNew = in.laneAdmitted && in.nNow == 1;
+                    const int endLane = gate.y;
+                    best = (viewerNew && endLane < d) ? tailOfRec(laneNow) : tailIfCurrent(laneCommitted, c.step - 1);
+                    if (best.slot >= 0) {
+                        gap = dist + best.dis - tv[best.templ].len;
+                        resolved = true;
+                    } else {
+                        dist += c.n.drvLength[endLane];
+                        resolved = dist > t.approach_dist;
+                    }
+                }
+            }
+        } else if (linkHead) {
+            best = tailIfCurrent(endRec, c.step - 1);
+            if (best.slot >= 0) {
+                gap = dist + best.dis - tv[best.templ].len;
+                resolved = true;
+            } else {
+                dist += c.n.drvLength[nd0];
+                resolved = dist > t.approach_dist;
+            }
+        } else if (nd0 < 0) {
+            resolved = true;  // end of the route: nothing ahead
+        }
+        if (!resolved) {  // anything else (more than four laneLinks, a search that goes on): the general walk from the start
+            best = findHeadLeader(c, tv, s, d, dis, t.approach_dist, nd0, dlen, &gap, in.hop);
+        }
+        ls = best.slot;
+        leaderTempl = best.templ;
+        leaderSpeed = best.speed;
+    }
+
+    // ================= Vehicle::getNextSpeed vehicle.cpp:308-335
+    double v = t.max_speed;
+    v = min2(v, speed + t.max_pos_acc * interval);
+    v = min2(v, in.lm.y);
+    double cf;  // Vehicle::getCarFollowSpeed vehicle.cpp:212-238
+    if (ls < 0) {
+        cf = custom ? customSpeed : t.max_speed;
+    } else if (custom) {
+        const cfx_vehicle_template &tl = tv[leaderTempl];
+        cf = min2(customSpeed, noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0));
+    } else {
+        const cfx_vehicle_template &tl = tv[leaderTempl];
+        cf = noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0);
+        double assumeDecel = 0;
+        if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
+        cf = min2(cf, noCollisionSpeed(leaderSpeed, tl.usual_neg_acc, speed, t.usual_neg_acc, gap, interval, t.min_gap));
+        cf = min2(cf, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) /
+                          (t.headway_time + interval / 2));
+    }
+    v = min2(v, cf);
+
+    // ================= Vehicle::getIntersectionRelatedSpeed vehicle.cpp:337-362
+    if (related) {
+        VehRef self{speed, &t};
+        double iv = t.max_speed;
+        bool done = false;
+        if (nextIsLink) {
+            bool blocked = !(gate.x & 1);
+            if (!blocked) {  // Lane::canEnter roadnet.cpp:437-445
+                const Tail tail = tailOfRec(laneNow);
+                if (tail.slot >= 0) blocked = !(tail.dis > tv[tail.templ].len + t.len || tail.speed >= 2);
+            }
+            if (blocked) {
+                if (minBrakeDistance(self) > dlen - dis) {
+                    // cannot stop before the line: run it
+                } else {
+                    iv = min2(iv, stopBeforeSpeed(self, dlen - dis, interval));
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+            if (nextIsLink && typeIsTurn((gate.x >> 1) & 3)) iv = min2(iv, t.turn_speed);
+            if (gate.x & 8) {  // the crosses of the laneLink: the cross phase takes over, with everything known here
+                o.park(s, v, iv);
+                push(s, JobInfo{d, in.idx, in.nNow, templIdx, nd0, gateLink, gate.x, gate.z, gate.w, speed, dis, dlen, v, iv});
+                return;
+            }
+        }
+        v = min2(v, iv);
+    }
+    finishAction<false>(c, o, t, s, d, 0, speed, dis, dlen, nd0, v, -1, in.idx, in.nNow, lp);
+}
+
 // ---------------------------------------------------------------------------------------------- phase 3 + 4
 // A workgroup of B threads owns a run of consecutive drivables (G lanes, or B laneLinks): its first threads read the
 // rings' {base, cap, head, cnt} and the drivables' {length, max speed}, a block-wide prefix sum turns the counts into the
@@ -476,11 +699,20 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
 // read from HBM once, coalesced.
 constexpr int kRingWave = 64;
 
+#ifdef CFX_TRACE
+__device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action kernel's phases (developer build only)
+#define TRACE_STAMP(k) if (t == 0) g_trace[(size_t) w * 8 + (k)] = (long long) wall_clock64()
+#else
+#define TRACE_STAMP(k)
+#endif
+
 template <int B>
 __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
+    TRACE_STAMP(0);
     if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
         llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
+        TRACE_STAMP(4);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
@@ -488,6 +720,8 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
     __shared__ int2 sGeo[B];
     __shared__ int sHead[B];
     __shared__ double2 sLM[B];
+    __shared__ int4 sHop[B];
+    __shared__ unsigned char sAdm[B];
     __shared__ double sDis[B], sSpeed[B];
     __shared__ int sTempl[B];
     __shared__ int sWave[B / 64];
@@ -503,8 +737,11 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
         const int2 geo = c.ringGeo[dMine];
         const int head = c.head[dMine];
         n = c.cnt[dMine];
-        if (laneBlock && c.admitStep[dMine] == c.step) n += 1;
+        const bool admitted = laneBlock && c.admitStep[dMine] == c.step;
+        if (admitted) n += 1;
+        sAdm[t] = admitted ? 1 : 0;
         sLM[t] = c.n.drvLM[dMine];
+        sHop[t] = laneBlock ? c.n.laneLL4[dMine] : make_int4(-2, -2, -2, -2);  // a lane head's first hop, see findHeadLeader
         sGeo[t] = geo;
         sHead[t] = head;
     }
@@ -530,6 +767,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
     if (t == 0) sPre[0] = 0;
     __syncthreads();
     const int T = sPre[B];
+    TRACE_STAMP(1);
     const RingPush push{q, jobRecs, c.n.L};
     for (int qb = 0; qb < T; qb += B - 1) {
         const int qv = qb + t - 1;  // thread 0 holds the vehicle ahead of the window (leader data only)
@@ -560,6 +798,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             sTempl[t] = in.templIdx;
         }
         __syncthreads();
+        TRACE_STAMP(2);
         if (valid && t > 0) {
             in.vid = 0;  // (the vehicle number is loaded where it is needed: custom speed, leaving the drivable)
             in.d = d0 + i;
@@ -578,10 +817,17 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
                 c.s.flags[slot] = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
             }
             in.lm = sLM[i];
-            actionOne<false>(c, o, tv, slot, in, push);
+            in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
+            in.laneAdmitted = sAdm[i] != 0;
+            actionOneRing(c, o, tv, slot, in, push);
         }
         __syncthreads();
+        TRACE_STAMP(3);
     }
+    TRACE_STAMP(4);
+#ifdef CFX_TRACE
+    if (t == 0) g_trace[(size_t) w * 8 + 5] = T;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- phase 5 + 6 + 8
@@ -606,6 +852,7 @@ struct RingCommit {
     int32_t *finTicket;
     int nStatBlocks;
     uint8_t *vStateW;
+    int32_t *slotOfW;  // a finished vehicle's entry becomes -1 (blocker chains end there)
     int exactTimes;  // every time involved is a multiple of 2^-10: the travel-time sum is order-free (exactFinishStatistics)
 };
 
@@ -637,7 +884,8 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
     if (F > k.finCap) F = k.finCap;
     const double now = c.step * c.interval;
     if (k.exactTimes)
-        return exactFinishStatistics(now, vt, sc, F, [&](int i) { return k.finVid[i]; }, k.vStateW, k.finTicket, part, nParts, 0);
+        return exactFinishStatistics(now, vt, sc, F, [&](int i) { return k.finVid[i]; }, k.vStateW, k.finTicket, part, nParts, 0,
+                                     k.slotOfW);
     const bool inLds = nParts == 1 && F <= kFinLds;
     const int per = (F + nParts - 1) / nParts;
     const int lo = part * per, hi = min(F, lo + per);
@@ -657,6 +905,7 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
             const int vid = k.finVid[i];
             const double tt = now - vt.enterTime[vid];
             k.vStateW[vid] = 2;
+            k.slotOfW[vid] = -1;
             if (inLds) term[rank] = tt;
             else k.finTerm[rank] = tt;
         }
