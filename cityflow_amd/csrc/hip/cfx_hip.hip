@@ -166,6 +166,7 @@ struct cfx_engine {
     size_t ringSlots = 0;
     double ringMinLen = 0.0;           // shortest vehicle template the capacities were computed for
     int ringScale = 1;                 // doubled when a ring came close to full
+    int ringG = 14, ringCalm = 0, ringHold = 0;      // lanes per block of the action kernel (adapted to the traffic) and steps without a dense block
     int2 *dRingGeo = nullptr;
     int32_t *rHead = nullptr, *rCnt = nullptr, *slotOf = nullptr;
     int4 *rScratch = nullptr;
@@ -994,11 +995,30 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // (B - 1) with room for uneven lanes; small networks take small blocks (every block resident at once, the step
             // is bound by the slowest block's chain), large ones big blocks (fuller waves: throughput).
             // cfx_config::ring_lanes_per_wave = G + 1000 * (B / 256) overrides both (developer knob).
-            int G = 16, Bsel = 256;
+            int G = e->ringG, Bsel = 256;
             const int want = e->cfg.ring_lanes_per_wave;
             if (want > 0) {
                 G = std::max(1, want % 1000);
                 Bsel = want >= 4000 ? 1024 : (want >= 2000 ? 512 : 256);
+            } else if (e->mirrorValid) {
+                // adapt to the traffic: the densest block of a recent step (pinned mirror, possibly a few steps old) should
+                // fit one pass with some room; results do not depend on G
+                const int maxT = __atomic_load_n(&e->hMirror->sc.actionMaxT, __ATOMIC_RELAXED);
+                if (e->ringHold > 0) {
+                    e->ringHold -= 1;  // (the mirror lags a few steps behind: let a change show before the next one)
+                } else if (maxT > Bsel - 1) {
+                    e->ringG = std::max(4, e->ringG - 1);
+                    e->ringCalm = 0;
+                    e->ringHold = 8;
+                } else if (maxT == 0 && e->ringG < 16) {  // no block above 3/4 of a pass for a while: fuller blocks
+                    if (++e->ringCalm >= 256) {
+                        e->ringG += 1;
+                        e->ringCalm = 0;
+                    }
+                } else {
+                    e->ringCalm = 0;
+                }
+                G = e->ringG;
             }
             G = std::min(G, Bsel);
             const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;

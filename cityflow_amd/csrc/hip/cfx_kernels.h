@@ -53,7 +53,7 @@ struct DevScalars {
     int nCrossJobs;            // vehicles queued for k_cross in the step in flight
     int nLeftUncounted;        // lane change: real vehicles of completed changes that left this step (not "finished")
     int ringNearFull;          // ring layout: some drivable's ring is within 8 vehicles of its capacity (sticky)
-    int pad;
+    int actionMaxT;            // ring layout: most vehicles one block of the action kernel had (blocks above 3/4 of a pass report)
 };
 
 struct HostMirror {  // pinned host copy of the end-of-step scalars (written by k_scatter's statistics block)

@@ -767,6 +767,8 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
     if (t == 0) sPre[0] = 0;
     __syncthreads();
     const int T = sPre[B];
+    // feedback for the host's choice of lanes per block (a block that needs a second pass is the step's slowest)
+    if (t == 0 && T > (B - 1) * 3 / 4) atomicMax(&o.sc->actionMaxT, T);
     TRACE_STAMP(1);
     const RingPush push{q, jobRecs, c.n.L};
     for (int qb = 0; qb < T; qb += B - 1) {
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
         const bool last = ringFinishStatistics(c, vt, k, part, k.nStatBlocks);
         if (last && threadIdx.x == 0 && k.hostMirror) {
             k.hostMirror->sc = *k.sc;
+            k.sc->actionMaxT = 0;
             k.hostMirror->slots = (int32_t) k.sc->active;
             __hip_atomic_store(&k.hostMirror->progress, ((unsigned long long) (c.step + 1) << 32) | (unsigned) k.sc->active,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
