@@ -224,10 +224,17 @@ __device__ inline int notifiedAt(const C &c, const cfx_vehicle_template *tv, int
 struct Notified {
     int slot, templ;  // slot < 0: nobody
     double speed, dist;
+    // requested together with the rest where the layout can (ring): the vehicle's enterLaneLinkTime and blocker record,
+    // which the decision tree below may want after its arithmetic — `pre` says they are here
+    bool pre;
+    int enterLLT;
+    int2 blk;
 };
+// the notified vehicle's blocker as a slot, from what notified() brought along if it did
+template <class C> __device__ __forceinline__ int blockerOfNotified(const C &c, const Notified &nf) { return blockerOf(c, nf.slot); }
 template <class C>
 __device__ inline Notified notified(const C &c, const cfx_vehicle_template *tv, int k, double x) {
-    Notified nf{-1, 0, 0.0, 0.0};
+    Notified nf{-1, 0, 0.0, 0.0, false, 0, make_int2(-1, -1)};
     nf.slot = notifiedAt(c, tv, k, x, &nf.dist);
     if (nf.slot >= 0) {
         nf.templ = c.s.templ[nf.slot];
@@ -239,10 +246,20 @@ __device__ inline Notified notified(const C &c, const cfx_vehicle_template *tv, 
 // Cross::canPass roadnet.cpp:603-676 for a cross whose peer laneLink is active.  `e` = this laneLink's
 // entry of the cross, `t1` its roadLink type.
 template <class C>
+__device__ inline bool canPassDecide(const C &c, const cfx_vehicle_template *tv, int selfSlot, const VehRef &self, double dOn,
+                                     int t1, double distanceToLaneLinkStart, const Notified &nf, int t2, int *foeSlotOut);
+
+template <class C>
 __device__ inline bool canPassActive(const C &c, const cfx_vehicle_template *tv, int selfSlot, const VehRef &self,
                                      double dOn, int t1, double distanceToLaneLinkStart, int peLL, double peerDist,
                                      int t2, int *foeSlotOut) {
-    const Notified nf = notified(c, tv, peLL, peerDist);
+    return canPassDecide(c, tv, selfSlot, self, dOn, t1, distanceToLaneLinkStart, notified(c, tv, peLL, peerDist), t2, foeSlotOut);
+}
+
+// ... the decision once the cross's notified vehicle is known
+template <class C>
+__device__ inline bool canPassDecide(const C &c, const cfx_vehicle_template *tv, int selfSlot, const VehRef &self, double dOn,
+                                     int t1, double distanceToLaneLinkStart, const Notified &nf, int t2, int *foeSlotOut) {
     const int foeSlot = nf.slot;
     const double d2 = nf.dist;
     *foeSlotOut = foeSlot;
@@ -273,7 +290,7 @@ __device__ inline bool canPassActive(const C &c, const cfx_vehicle_template *tv,
                 } else if (foeSteps < mySteps) {
                     yield = 1;
                 } else {
-                    int myT = c.s.enterLLT[selfSlot], foeT = c.s.enterLLT[foeSlot];
+                    int myT = c.s.enterLLT[selfSlot], foeT = nf.pre ? nf.enterLLT : c.s.enterLLT[foeSlot];
                     if (myT == foeT) {
                         if (d1 == d2) {
                             yield = c.vPriority[c.s.vid[selfSlot]] > c.vPriority[c.s.vid[foeSlot]] ? -1 : 1;
@@ -293,7 +310,7 @@ __device__ inline bool canPassActive(const C &c, const cfx_vehicle_template *tv,
         // (every link of the chain is looked up once: a lookup is two or three dependent loads)
         int fast = foeSlot, slow = foeSlot;
         int guard = 0;
-        int fastBlocker = blockerOf(c, fast);
+        int fastBlocker = blockerOfNotified(c, nf);
         while (fastBlocker >= 0) {
             slow = blockerOf(c, slow);
             fast = blockerOf(c, fastBlocker);

@@ -361,10 +361,25 @@ __device__ inline void llstateRing(const RingCtx &c, int k) {
 }
 
 // notifiedAt + the notified vehicle's state (cfx_kernels.h) from the two laneLink records
+__device__ __forceinline__ int blockerOfNotified(const RingCtx &c, const Notified &nf) {
+    if (!nf.pre) return blockerOf(c, nf.slot);
+    return (nf.blk.x >= 0 && nf.blk.y == c.step - 1) ? c.slotOf[nf.blk.x] : -1;
+}
+__device__ __forceinline__ void notifiedExtras(const RingCtx &c, Notified &nf) {  // requested now, used (maybe) much later
+    nf.enterLLT = c.s.enterLLT[nf.slot];
+    nf.blk = c.blkR[nf.slot];
+    nf.pre = true;
+}
+__device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x, const int4 dyn,
+                                        const LLAux &a);
 __device__ inline Notified notified(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x) {
-    Notified nf{-1, 0, 0.0, 0.0};
     const int4 dyn = c.llDyn[k];
     const LLAux a = c.llAux[k];  // (issued together with llDyn: this phase is bound by rounds of dependent loads, not bytes)
+    return notifiedFrom(c, tv, k, x, dyn, a);
+}
+__device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x, const int4 dyn,
+                                        const LLAux &a) {
+    Notified nf{-1, 0, 0.0, 0.0, false, 0, make_int2(-1, -1)};
     if (dyn.x < 0 && dyn.y < 0 && dyn.w == 0) return nf;  // nobody to yield to on that laneLink
     if (dyn.x >= 0) {
         const double vehDistance = a.uDis - tv[a.uTempl].len;
@@ -374,6 +389,7 @@ __device__ inline Notified notified(const RingCtx &c, const cfx_vehicle_template
             nf.templ = a.uTempl;
             nf.speed = a.uSpeed;
             nf.dist = -(a.uDis + crossDistance);
+            notifiedExtras(c, nf);
             return nf;
         }
     }
@@ -388,6 +404,7 @@ __device__ inline Notified notified(const RingCtx &c, const cfx_vehicle_template
                 nf.templ = wt;
                 nf.speed = c.s.speed[w];
                 nf.dist = x - vehDistance;
+                notifiedExtras(c, nf);
                 return nf;
             }
         }
@@ -397,6 +414,7 @@ __device__ inline Notified notified(const RingCtx &c, const cfx_vehicle_template
         nf.templ = a.fTempl;
         nf.speed = a.fSpeed;
         nf.dist = (a.startLen - a.fDis) + x;
+        notifiedExtras(c, nf);
     }
     return nf;
 }
@@ -442,6 +460,13 @@ struct RingPush {
     }
 };
 
+#ifdef CFX_TRACE
+__device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action kernel's phases (developer build only)
+#define TRACE_STAMP(k) if (t == 0) g_trace[(size_t) w * 8 + (k)] = (long long) wall_clock64()
+#else
+#define TRACE_STAMP(k)
+#endif
+
 // Second half of Vehicle::getIntersectionRelatedSpeed (k_cross of cfx_kernels.h) from job records: one 16-lane group per
 // queued vehicle, one cross per lane and round, first failing lane of the first failing round = the first cross that
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
@@ -449,6 +474,13 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
     __shared__ int shardEnd[kJobShards];
+#ifdef CFX_TRACE
+    const int traceRow = 4096 + (int) blockIdx.x;
+#define XSTAMP(k) if (threadIdx.x == 0) g_trace[(size_t) traceRow * 8 + (k)] = (long long) wall_clock64()
+#else
+#define XSTAMP(k)
+#endif
+    XSTAMP(0);
     if (threadIdx.x < kJobShards) shardEnd[threadIdx.x] = min(q.count[threadIdx.x * kJobShardStride], q.capacity);
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
@@ -467,6 +499,7 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
     }
     __syncthreads();
     const int nJ = shardEnd[kJobShards - 1];
+    XSTAMP(1);
     const int g = threadIdx.x % kCrossGroup;
     const int groupsPerBlock = blockDim.x / kCrossGroup;
     const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);
@@ -480,6 +513,8 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
         VehRef self{jr.speed, &t};
         double iv = jr.iv;
         int blockerSlot = -1;
+        if (jr.slot == -12345) return;
+        XSTAMP(2);
         for (int e0 = jr.xs; e0 < jr.xe; e0 += kCrossGroup) {
             const int e = e0 + g;
             bool fail = false;
@@ -494,7 +529,7 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
             const unsigned long long ball = __ballot(fail);
             const unsigned gm = (unsigned) ((ball >> groupShift) & ((1ULL << kCrossGroup) - 1ULL));
             if (gm != 0u) {
-                const int first = __ffs(gm) - 1;
+                const int first = __ffs(gm) - 1;  // lowest lane = smallest cross distance in this round
                 const int src = groupShift + first;
                 const double fdOn = __shfl(dOn, src, 64);
                 blockerSlot = __shfl(foe, src, 64);
@@ -502,9 +537,14 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
                 break;
             }
         }
+        XSTAMP(3);
         if (g == 0)
             finishAction<false>(c, o, t, s, jr.d, 0, jr.speed, jr.dis, jr.dlen, jr.nd0, min2(jr.v, iv), blockerSlot, jr.idx, jr.nNow);
     }
+    XSTAMP(4);
+#ifdef CFX_TRACE
+    if (threadIdx.x == 0) g_trace[(size_t) traceRow * 8 + 5] = nJ;
+#endif
 }
 
 // ---- one vehicle's phase 4 on the ring layout, organised by ROUNDS of memory accesses --------------------------------
@@ -698,13 +738,6 @@ __device__ __forceinline__ void actionOneRing(const RingCtx &c, const RingOut &o
 // window (thread 0 re-reads the last vehicle of the previous pass for that purpose only), so leader / follower state is
 // read from HBM once, coalesced.
 constexpr int kRingWave = 64;
-
-#ifdef CFX_TRACE
-__device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action kernel's phases (developer build only)
-#define TRACE_STAMP(k) if (t == 0) g_trace[(size_t) w * 8 + (k)] = (long long) wall_clock64()
-#else
-#define TRACE_STAMP(k)
-#endif
 
 template <int B>
 __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {

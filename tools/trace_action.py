@@ -11,8 +11,19 @@ dll.cfx_trace_dump(b"/tmp/x", 0)  # arm
 for _ in range(320): eng.next_step()
 eng.sync()
 nb = 11160 // 16 + 1 + 2 * ((32400 + 255) // 256)
-dll.cfx_trace_dump(b"/tmp/trace.bin", nb)
-a = np.fromfile("/tmp/trace.bin", dtype=np.int64).reshape(-1, 8)
+dll.cfx_trace_dump(b"/tmp/trace.bin", 4096 + 2048)
+full = np.fromfile("/tmp/trace.bin", dtype=np.int64).reshape(-1, 8)
+a = full[:nb]
+x = full[4096:]
+x = x[x[:, 0] > 0]
+nJ = int(x[0, 5])
+busy = x[: (nJ + 15) // 16]
+xt0 = x[:, 0].min()
+xus = lambda v: (v - xt0) / 100.0
+print("kr_cross: %d blocks started, %d jobs in %d busy blocks; last start %.2f us" % (len(x), nJ, len(busy), xus(x[:, 0].max())))
+print("  busy blocks: counts done avg %.2f | record loaded avg %.2f max %.2f | crosses done avg %.2f max %.2f | end avg %.2f max %.2f" % (
+    xus(busy[:, 1]).mean(), xus(busy[:, 2]).mean(), xus(busy[:, 2]).max(), xus(busy[:, 3]).mean(), xus(busy[:, 3]).max(), xus(busy[:, 4]).mean(), xus(busy[:, 4]).max()))
+print("  idle blocks end avg %.2f max %.2f" % (xus(x[len(busy):, 4]).mean(), xus(x[len(busy):, 4]).max()))
 t0 = a[:, 0].min()
 us = lambda x: (x - t0) / 100.0  # 100 MHz wall clock
 nl = 11160 // 16 + 1
