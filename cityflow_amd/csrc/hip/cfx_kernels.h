@@ -54,6 +54,7 @@ struct DevScalars {
     int nLeftUncounted;        // lane change: real vehicles of completed changes that left this step (not "finished")
     int ringNearFull;          // ring layout: some drivable's ring is within 8 vehicles of its capacity (sticky)
     int actionMaxT;            // ring layout: most vehicles one block of the action kernel had (blocks above 3/4 of a pass report)
+    long long tieEvents;       // cfx_scalars::tie_events
 };
 
 struct HostMirror {  // pinned host copy of the end-of-step scalars (written by k_scatter's statistics block)
@@ -1396,7 +1397,9 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
             for (int j = cs.inHead[nd]; j >= 0; j = cs.inNext[j]) {
                 if (j == s) continue;
                 double od = b.dis[j];
-                rank += (od > ndis) || (od == ndis && c.s.vid[j] < vid);
+                const bool tieBefore = od == ndis && c.s.vid[j] < vid;
+                rank += (od > ndis) || tieBefore;
+                if (tieBefore) atomicAdd((unsigned long long *) &sc->tieEvents, 1ULL);
             }
             ns = tStartNext + (cntNow(c, nd) - tLeave) + rank;
         }

@@ -1038,7 +1038,9 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
             for (int f = sc.z; f >= 0; f = k.movers[f].nextIn) {
                 if (f == e) continue;
                 const double od = k.movers[f].dis;
-                rank += (od > r.dis) || (od == r.dis && k.movers[f].vid < r.vid);
+                const bool tieBefore = od == r.dis && k.movers[f].vid < r.vid;
+                rank += (od > r.dis) || tieBefore;
+                if (tieBefore) atomicAdd((unsigned long long *) &k.sc->tieEvents, 1ULL);
             }
             ++m;
             if (n + rank > geo.y) {  // the ring is full: refuse (reported as an error by the next cfx_step / getter)

@@ -422,6 +422,7 @@ PYBIND11_MODULE(_cityflow, m) {
                  d["cumulative_travel_time"] = s.cumulative_travel_time;
                  d["live_enter_time_sum"] = s.live_enter_time_sum;
                  d["vehicle_steps"] = s.vehicle_steps;
+                 d["tie_events"] = s.tie_events;
                  return d;
              })
         .def("_layout", &EngineHost::layoutName)
@@ -498,6 +499,7 @@ PYBIND11_MODULE(_cityflow, m) {
             d["finished_vehicle_count"] = s.finished_vehicle_count;
             d["spawned_vehicle_count"] = s.spawned_vehicle_count;
             d["vehicle_steps"] = s.vehicle_steps;
+                 d["tie_events"] = s.tie_events;
             d["cumulative_travel_time"] = s.cumulative_travel_time;
             return d;
         });
@@ -610,6 +612,7 @@ PYBIND11_MODULE(_cityflow, m) {
             d["cumulative_travel_time"] = s.cumulative_travel_time;
             d["live_enter_time_sum"] = s.live_enter_time_sum;
             d["vehicle_steps"] = s.vehicle_steps;
+                 d["tie_events"] = s.tie_events;
             return d;
         });
 

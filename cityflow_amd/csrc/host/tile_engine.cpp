@@ -781,6 +781,7 @@ cfx_scalars TiledEngineHost::scalars() {
         sum.finished_vehicle_count += s.finished_vehicle_count;
         sum.cumulative_travel_time += s.cumulative_travel_time;
         sum.vehicle_steps += s.vehicle_steps;
+        sum.tie_events += s.tie_events;
     }
     sum.step = (int64_t) step_;
     sum.spawned_vehicle_count = (int64_t) spawner_.vehicles.size();

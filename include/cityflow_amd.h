@@ -142,6 +142,11 @@ typedef struct cfx_scalars {
     double cumulative_travel_time; /* Engine::cumulativeTravelTime */
     double live_enter_time_sum;    /* sum of enter_time over spawned-and-not-finished vehicles (0 if not kept) */
     int64_t vehicle_steps;         /* sum over executed steps of the vehicles that took the step (ran phase 4) */
+    /* pairs of vehicles that entered the same drivable in one step with EXACTLY equal distances, since the last reset /
+     * load.  Engine::updateLocation orders the entrants with an unstable std::sort on distance alone (engine.cpp:480), so
+     * the reference's own order of such a pair depends on heap addresses and thread timing; this ABI breaks the tie by
+     * vehicle number.  A comparison with the reference is well defined only while this counter stands still. */
+    int64_t tie_events;
 } cfx_scalars;
 
 /* Full per-vehicle state of every running vehicle, caller-allocated SoA (any pointer may be NULL).

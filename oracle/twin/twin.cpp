@@ -80,7 +80,7 @@ struct cfx_engine {
     std::vector<double> notifyDist;              //                  Cross::notifyDistances[side]
     std::vector<int32_t> curPhase;               // TrafficLight::curPhaseIndex
     std::vector<double> remain;                  // TrafficLight::remainDuration
-    int64_t step = 0, active = 0, finishedCnt = 0, vehicleSteps = 0;
+    int64_t step = 0, active = 0, finishedCnt = 0, vehicleSteps = 0, tieEvents = 0;
     double cumulativeTravelTime = 0;
     std::string err;
     // lane change: per lane the Segments (roadnet.h:198-236), each a list of vehicles front to back; the priorities the
@@ -954,6 +954,9 @@ struct cfx_engine {
         // the same drivable) unspecified; canonical tie-break here and on the device: lower vid first.
         std::stable_sort(pushBuffer.begin(), pushBuffer.end(),
                          [this](int32_t a, int32_t b) { return veh[a].bDis > veh[b].bDis; });
+        for (size_t i = 0; i < pushBuffer.size(); ++i)  // cfx_scalars::tie_events: equal distance into the same drivable
+            for (size_t j = i + 1; j < pushBuffer.size() && veh[pushBuffer[j]].bDis == veh[pushBuffer[i]].bDis; ++j)
+                tieEvents += veh[pushBuffer[j]].bDrv == veh[pushBuffer[i]].bDrv;
         if (tiled) inCntStep.assign(order.size(), 0);
         for (int32_t vid : pushBuffer) {
             Veh &v = veh[vid];
@@ -1024,6 +1027,7 @@ struct cfx_engine {
         active = 0;
         finishedCnt = 0;
         vehicleSteps = 0;
+        tieEvents = 0;
         cumulativeTravelTime = 0;
     }
 };
@@ -1182,6 +1186,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
         if (!v.finished) s += v.enterTime;
     out->live_enter_time_sum = s;
     out->vehicle_steps = e->vehicleSteps;
+    out->tie_events = e->tieEvents;
     return CFX_OK;
 }
 
@@ -1316,6 +1321,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     e->step = s->step;
     e->finishedCnt = s->finished_vehicle_count;
     e->vehicleSteps = s->vehicle_steps;
+    e->tieEvents = 0;
     e->cumulativeTravelTime = s->cumulative_travel_time;
     e->veh.resize(s->n_vehicles);
     for (int v = 0; v < s->n_vehicles; ++v) {
