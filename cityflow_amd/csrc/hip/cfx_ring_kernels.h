@@ -267,58 +267,92 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
 // statistics of this step (extra blocks of kr_commit) read it while kr_commit's other blocks commit the rest.
 __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, DevScalars *sc) {
     __shared__ int sAdmitted;
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const cfx_vehicle_template *tv = c.t.templ;
     if (threadIdx.x == 0) sAdmitted = 0;
-    __syncthreads();
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        tv = sT;
+    }
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d < c.n.L + c.n.K) {
+    const bool isLane = d < c.n.L, inRange = d < c.n.L + c.n.K;
+    // ---- round 1: everything that hangs on the drivable alone (a lane's ring position is requested whether or not it
+    //      will admit: the kernel is bound by its longest chain of dependent loads, not by bytes)
+    TailRec committed{};
+    int w = -1, n = 0, head = 0, road = 0, laneIdx = 0;
+    int2 geo = make_int2(0, 0);
+    if (inRange) committed = c.tailR[d];
+    if (isLane) {
+        w = waitHead[d];
+        n = c.cnt[d];
+        geo = c.ringGeo[d];
+        head = c.head[d];
+        road = c.n.laneRoad[d];
+        laneIdx = c.n.laneIndex[d];
+    }
+    // ---- round 2: the head of the lane's waiting queue
+    int wt = 0, route = 0, nextWait = -1;
+    uint8_t pending = 0;
+    if (w >= 0) {
+        wt = vt.templ[w];
+        route = vt.route[w];
+        nextWait = vt.nextWait[w];
+        pending = vt.pendingCustom[w];
+    }
+    __syncthreads();  // (templates staged)
+    if (inRange) {
         // this step's view of the drivable's tail: what the last step left, or the vehicle admitted below
-        const TailRec committed = c.tailR[d];
         TailRec now = committed;
         if (committed.tag != c.step - 1) now.slot = -1;
-        if (d >= c.n.L) {
+        if (!isLane) {
             const int k = d - c.n.L;
             int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
             c.llGate[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
         } else {
             const int lane = d;
-            const int w = waitHead[lane];
-            bool admit = w >= 0;
-            int wt = 0;
-            if (admit) {
-                wt = vt.templ[w];
-                if (now.slot >= 0 && !(now.dis > c.t.templ[now.templ].len + c.t.templ[wt].min_gap)) admit = false;
+            bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435
+            if (admit && now.slot >= 0 && !(now.dis > tv[now.templ].len + tv[wt].min_gap)) admit = false;
+            if (admit && n >= geo.y) {  // the ring is full (cannot happen with capacities from the shortest vehicle): refuse loudly
+                sc->overflow = 8;
+                admit = false;
             }
             if (admit) {
-                const int n = c.cnt[lane];
-                const int2 geo = c.ringGeo[lane];
-                if (n >= geo.y) {  // the ring is full (cannot happen with capacities from the shortest vehicle): refuse loudly
-                    sc->overflow = 8;
+                // Router::getNextDrivable for a vehicle on the first road of its route (router.cpp:49-76): its lane is on
+                // route position 0, so the table row is known without walking the route; anything else takes the walk
+                const int base = c.t.routeStart[route];
+                int next;
+                if (c.t.routeRoads[base] == road) {
+                    const int ll = c.t.nextLL[c.t.nextStart[base] + laneIdx];
+                    next = ll < 0 ? -1 : c.n.L + ll;
                 } else {
-                    const int slot = ringSlot(geo, c.head[lane], n);
-                    const int route = vt.route[w];
-                    const double v0 = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
-                    c.s.vid[slot] = w;
-                    c.s.drv[slot] = lane;
-                    c.s.prevDrv[slot] = -1;
-                    c.s.next[slot] = nextOf(c.n, c.t, lane, route, 0);
-                    c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
-                    c.s.routePos[slot] = 0;
-                    c.s.templ[slot] = wt;
-                    c.s.route[slot] = route;
-                    c.s.flags[slot] = vt.pendingCustom[w];
-                    c.s.dis[slot] = 0.0;
-                    c.s.speed[slot] = v0;
-                    c.slotOf[w] = slot;
-                    c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
-                    admitStep[lane] = c.step;  // cnt[] and the FIFO pop follow in kr_commit (see cntNow)
-                    now.dis = 0.0;
-                    now.speed = v0;
-                    now.slot = slot;
-                    now.templ = wt;
-                    now.prevDrv = -1;
-                    // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail, same decision)
-                    if (!(c.n.laneGhost && c.n.laneGhost[lane])) atomicAdd(&sAdmitted, 1);
+                    next = nextOf(c.n, c.t, lane, route, 0);
                 }
+                const int slot = ringSlot(geo, head, n);
+                const double v0 = tv[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
+                c.s.vid[slot] = w;
+                c.s.drv[slot] = lane;
+                c.s.prevDrv[slot] = -1;
+                c.s.next[slot] = next;
+                c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
+                c.s.routePos[slot] = 0;
+                c.s.templ[slot] = wt;
+                c.s.route[slot] = route;
+                c.s.flags[slot] = pending;
+                c.s.dis[slot] = 0.0;
+                c.s.speed[slot] = v0;
+                c.slotOf[w] = slot;
+                c.admitRec[lane] = make_int2(w, nextWait);
+                admitStep[lane] = c.step;  // cnt[] and the FIFO pop follow in kr_commit (see cntNow)
+                now.dis = 0.0;
+                now.speed = v0;
+                now.slot = slot;
+                now.templ = wt;
+                now.prevDrv = -1;
+                // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail, same decision)
+                if (!(c.n.laneGhost && c.n.laneGhost[lane])) atomicAdd(&sAdmitted, 1);
             }
         }
         now.tag = c.step;
@@ -1056,16 +1090,23 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
             c.s.route[slot] = r.route;
             c.s.flags[slot] = 0;
             c.blkW[slot] = make_int2(r.blockerVid, c.step);
-            if (d < c.n.L) {  // Router::update router.cpp:78-94
+            int next;
+            if (d < c.n.L) {  // Router::update router.cpp:78-94, then Router::getNextDrivable from the road it stopped at
                 c.s.enterLLT[slot] = CFX_INT_MAX;
                 const int base = c.t.routeStart[r.route], len = c.t.routeStart[r.route + 1] - base;
                 const int road = c.n.laneRoad[d];
                 while (rp < len && c.t.routeRoads[base + rp] != road) ++rp;
+                next = -1;
+                if (rp < len) {
+                    const int ll = c.t.nextLL[c.t.nextStart[base + rp] + c.n.laneIndex[d]];
+                    next = ll < 0 ? -1 : c.n.L + ll;
+                }
             } else {
                 c.s.enterLLT[slot] = c.step;
+                next = c.n.llEndLane[d - c.n.L];
             }
             c.s.routePos[slot] = rp;
-            c.s.next[slot] = nextOf(c.n, c.t, d, r.route, rp);
+            c.s.next[slot] = next;
             c.disN[slot] = r.dis;
             c.speedN[slot] = r.speed;
             c.slotOf[r.vid] = slot;
