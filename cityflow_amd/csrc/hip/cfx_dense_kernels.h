@@ -1,0 +1,195 @@
+// The dense layout's admission and action phases with what the ring layout taught (cfx_ring_kernels.h): per-drivable
+// TAIL RECORDS instead of chains through {segment offset, count} -> slot -> {dis, speed, template}, and an action phase
+// organised by rounds of memory accesses (actionOneRounds).  Used by dense engines without lane change and tiling — the
+// large networks, where the step is bound by (dependent rounds per wave) x (waves / resident waves); lane change and tiles
+// keep k_admit / k_action of cfx_kernels.h.  Same arithmetic, same results (tests/test_parity_pins.py forces this path
+// on every pinned workload).
+#pragma once
+
+#include "cfx_ring_kernels.h"
+
+namespace cfxd {
+
+__device__ __forceinline__ bool viewerIsNew(const StepCtx &c, const SlotIn &in, int d) {
+    return d < c.n.L && c.admitStep[d] == c.step && c.cnt[d] == 0;  // head of a lane whose only vehicle was admitted this step
+}
+
+// finishAction of cfx_kernels.h for the dense layout with the first hop's lengths and the identity columns in registers
+template <bool LC>
+__device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template &t, int s, int d, int vid,
+                                    double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int /*idx*/,
+                                    int /*nNow*/, LeaverPrefetch lp) {
+    static_assert(!LC, "lane change runs on k_action");
+    v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
+    v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);
+    MoveOut m;
+    double deltaDis;
+    if (v < 0) {
+        deltaDis = 0.5 * speed * speed / t.max_neg_acc;
+        v = 0;
+    } else {
+        deltaDis = (speed + v) * c.interval / 2;
+    }
+    m.v = v;
+    m.ndis = deltaDis + dis;
+    m.newDrv = -1;
+    if (m.ndis > dlen) {
+        if (!lp.valid) {
+            lp.nextLen = nd0 >= 0 ? c.n.drvLength[nd0] : 0.0;
+            lp.route = c.s.route[s];
+            lp.routePos = c.s.routePos[s];
+        }
+        m.ndis -= dlen;  // (== c.n.drvLength[d])
+        int drivable = nd0;
+        m.newDrv = drivable >= 0 ? drivable : -2;
+        if (drivable >= 0 && m.ndis > lp.nextLen) {  // runs through a whole drivable in one step: the general walk goes on
+            int nxt = nextOf(c.n, c.t, drivable, lp.route, lp.routePos);
+            for (;;) {
+                m.ndis -= c.n.drvLength[drivable];
+                drivable = nxt;
+                m.newDrv = drivable >= 0 ? drivable : -2;
+                if (drivable < 0 || !(m.ndis > c.n.drvLength[drivable])) break;
+                nxt = nextOf(c.n, c.t, drivable, lp.route, lp.routePos);
+            }
+        }
+    }
+    commitMove(c, o, s, d, vid, m, blockerSlot, true);
+}
+
+// Engine::handleWaiting + Lane::available from the lane's tail record; this step's view of every drivable's tail, the wide
+// gate records, and the compaction scratch of the step (k_admit of cfx_kernels.h does the same through the slots).
+__global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, CompactScratch cs) {
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        tv = sT;
+    }
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool isLane = d < c.n.L, inRange = d < c.n.L + c.n.K;
+    TailRec committed{};
+    int w = -1, n = 0, base = 0, road = 0, laneIdx = 0;
+    if (inRange) committed = c.tailR[d];
+    if (isLane) {
+        w = waitHead[d];
+        n = c.cnt[d];
+        base = c.segStart[d];
+        road = c.n.laneRoad[d];
+        laneIdx = c.n.laneIndex[d];
+    }
+    int wt = 0, route = 0, nextWait = -1;
+    uint8_t pending = 0;
+    if (w >= 0) {
+        wt = vt.templ[w];
+        route = vt.route[w];
+        nextWait = vt.nextWait[w];
+        pending = vt.pendingCustom[w];
+    }
+    __syncthreads();
+    if (!inRange) return;
+    cs.leaveCnt[d] = 0;
+    cs.maxLeaveIdx[d] = -1;
+    cs.inCnt[d] = 0;
+    cs.inHead[d] = -1;
+    TailRec now = committed;
+    if (committed.tag != c.step - 1) now.slot = -1;
+    if (!isLane) {
+        const int k = d - c.n.L;
+        int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+        c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);  // (k_cross / llstate of the generic kernels)
+        c.llGate4[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+    } else {
+        const int lane = d;
+        c.laneTail[lane] = n > 0 ? base + n - 1 : -1;  // overwritten below if a vehicle is admitted
+        bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435
+        if (admit && now.slot >= 0 && !(now.dis > tv[now.templ].len + tv[wt].min_gap)) admit = false;
+        if (admit) {
+            const int rbase = c.t.routeStart[route];
+            int next;
+            if (c.t.routeRoads[rbase] == road) {  // the lane is on route position 0 (kr_admit)
+                const int ll = c.t.nextLL[c.t.nextStart[rbase] + laneIdx];
+                next = ll < 0 ? -1 : c.n.L + ll;
+            } else {
+                next = nextOf(c.n, c.t, lane, route, 0);
+            }
+            const int slot = base + n;  // the lane's spare slot
+            const double v0 = tv[wt].initial_speed;
+            c.s.vid[slot] = w;
+            c.s.drv[slot] = lane;
+            c.s.prevDrv[slot] = -1;
+            c.s.next[slot] = next;
+            c.s.blocker[slot] = -1;
+            c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
+            c.s.routePos[slot] = 0;
+            c.s.templ[slot] = wt;
+            c.s.route[slot] = route;
+            c.s.flags[slot] = pending;
+            c.s.dis[slot] = 0.0;
+            c.s.speed[slot] = v0;
+            c.laneTail[lane] = slot;
+            c.admitRec[lane] = make_int2(w, nextWait);
+            admitStep[lane] = c.step;  // cnt[], the FIFO pop and the running count follow in k_scan (see cntNow)
+            now.dis = 0.0;
+            now.speed = v0;
+            now.slot = slot;
+            now.templ = wt;
+            now.prevDrv = -1;
+        }
+    }
+    now.tag = c.step;
+    c.tailNow[d] = now;
+}
+
+// k_action of cfx_kernels.h with the rounds-organised per-vehicle phase
+__global__ __launch_bounds__(kActBlock) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
+    if ((int) blockIdx.x >= nVehicleBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
+        llstate(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
+        return;
+    }
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        tv = sT;
+    }
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = nVehicleBlocks * blockDim.x;
+    const PushJob push{q};
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
+        SlotIn in = loadSlot(c, s);
+        if (in.vid < 0) continue;
+        if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
+        actionOneRounds(c, o, tv, s, in, push);
+    }
+}
+
+// The tail records after cfx_load_state / cfx_reset (k_scatter keeps them up afterwards): one thread per drivable
+__global__ void kd_init_tails(StepCtx c, TailRec *tailBoth0, TailRec *tailBoth1) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= c.n.L + c.n.K) return;
+    TailRec r{};
+    r.slot = -1;
+    r.tag = -5;
+    tailBoth0[d] = r;
+    tailBoth1[d] = r;
+    const int n = c.cnt[d];
+    if (n > 0) {
+        const int s = c.segStart[d] + n - 1;
+        r.dis = c.s.dis[s];
+        r.speed = c.s.speed[s];
+        r.slot = s;
+        r.templ = c.s.templ[s];
+        r.prevDrv = c.s.prevDrv[s];
+        r.tag = c.step - 1;
+        const_cast<TailRec *>(c.tailR)[d] = r;
+    }
+}
+
+}  // namespace cfxd

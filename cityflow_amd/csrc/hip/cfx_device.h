@@ -124,6 +124,34 @@ struct LcDev {
     int firstShadowVid;
 };
 
+// The last vehicle of a drivable, kept as ONE 32-byte record so that its readers — the leader search of every head of a
+// drivable, Lane::canEnter, the admission check, the notify sources — do one load instead of a chain through
+// {ring geometry, head, count} -> slot -> {dis, speed, template}.  `tag` is the step the record was written in: a record is
+// the truth about the END of step `tag`, so "tag != step - 1" means nobody wrote one last step = the drivable was empty
+// (every non-empty drivable's tail vehicle rewrites it every step; kr_commit does where the tail changed hands).
+struct TailRec {
+    double dis, speed;
+    int32_t slot, templ, prevDrv, tag;
+};
+static_assert(sizeof(TailRec) == 32, "tail record layout");
+
+// Per-laneLink notify sources beyond llDyn = {u, f, first vehicle on the laneLink, vehicles on it}: the state of u (the
+// vehicle that just left onto the end lane) and f (the approaching vehicle on the start lane) and the two lengths the
+// distances are measured with, so that a cross resolves "who was I notified of" from two records.
+struct LLAux {
+    double uDis, uSpeed, fDis, fSpeed, llLen, startLen;
+    int32_t uTempl, fTempl;
+};
+static_assert(sizeof(LLAux) == 56, "laneLink aux record layout");
+
+// What finishing a vehicle that leaves its drivable needs beyond its slot; valid = the caller requested it early
+// (actionOneRing, round A), otherwise it is loaded here.
+struct LeaverPrefetch {
+    bool valid;
+    double nextLen;  // length of the next drivable (nd0 >= 0)
+    int vid, route, routePos;
+};
+
 // Everything the per-step kernels read.  Passed by value (kernel argument segment).
 struct StepCtx {
     DevNet n;
@@ -145,6 +173,11 @@ struct StepCtx {
     int2 *llGate;             // [K] {bit0 RoadLink::isAvailable, bits1-2 RoadLinkType, bit3 has crosses ; end lane}
     int32_t *laneTail;        // [L] Drivable::getLastVehicle() of the lane after this step's admission (slot or -1)
     int2 *admitRec;           // [L] {admitted vid, its successor in the lane's FIFO}: what k_scan needs to commit the pop
+    // dense layout without lane change and tiling ("kd_" kernels, cfx_dense_kernels.h): the tail records of the ring layout
+    // (two buffers by step parity + this step's view) and the wide gate records; null otherwise
+    const TailRec *tailR;
+    TailRec *tailW, *tailNow;
+    int4 *llGate4;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
     int32_t step;
     double interval;
     LcDev lc;
@@ -263,6 +296,14 @@ __device__ __forceinline__ Tail tailNowOf(const StepCtx &c, int d) { return tail
 // ... and as the leader search saw it (lastSlotForLeader)
 __device__ __forceinline__ Tail tailForLeader(const StepCtx &c, int d, bool viewerNew, int viewerLane) {
     return tailAt(c, lastSlotForLeader(c, d, viewerNew, viewerLane));
+}
+
+__device__ __forceinline__ int4 gateRecord(const StepCtx &c, int k) { return c.llGate4[k]; }  // (cfx_dense_kernels.h)
+__device__ __forceinline__ Tail tailOfRec(const TailRec &r) { return Tail{r.slot, r.templ, r.prevDrv, r.dis, r.speed}; }
+__device__ __forceinline__ Tail tailIfCurrent(const TailRec &r, int wantTag) {
+    Tail t = tailOfRec(r);
+    if (r.tag != wantTag) t.slot = -1;
+    return t;
 }
 
 // ControllerInfo::blocker of the vehicle in `slot`, as a current-generation slot (-1 none).

@@ -16,6 +16,7 @@
 #include "cfx_kernels.h"
 #include "cfx_lc_kernels.h"
 #include "cfx_ring_kernels.h"
+#include "cfx_dense_kernels.h"
 
 using namespace cfxd;
 
@@ -157,6 +158,12 @@ struct cfx_engine {
     hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
     int poolN = 0;                     // priorities supplied for the next / current step
     bool pollPending = false;          // a lane-change step has run and was not polled yet
+
+    // ---- dense layout with tail records (cfx_dense_kernels.h): engines without lane change and tiling ----
+    TailRec *dTail[2] = {nullptr, nullptr}, *dTailNow = nullptr;
+    int4 *dGate4 = nullptr;
+    bool tailsValid = false;           // the records describe the current generation (false after reset / load / resize)
+    bool useTails() const { return !ring && !lc.on && !tiled; }
 
     // ---- ring layout (cfx_ring_kernels.h): per-drivable ring segments, committed in place ----
     bool ring = false;                 // this engine uses it (decided at cfx_create; cfx_halo_config may still switch to dense)
@@ -316,6 +323,12 @@ struct cfx_engine {
         c.step = (int32_t) step;
         c.interval = cfg.interval;
         c.lc = lc;
+        if (dTailNow && useTails()) {
+            c.tailR = dTail[(step + 1) & 1];  // written by step - 1
+            c.tailW = dTail[step & 1];
+            c.tailNow = dTailNow;
+            c.llGate4 = dGate4;
+        }
         return c;
     }
 
@@ -595,6 +608,7 @@ struct cfx_engine {
     int resetState() {
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
+        tailsValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
         pollPending = false;
         poolN = 0;
@@ -1094,9 +1108,21 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->lc.pool = e->dPool;
         e->lc.insCap = e->poolN;
     }
+    const bool tails = e->useTails();
+    if (tails && !e->dTailNow) {
+        if ((rc = e->allocRaw(&e->dTail[0], (size_t) e->D))) return rc;
+        if ((rc = e->allocRaw(&e->dTail[1], (size_t) e->D))) return rc;
+        if ((rc = e->allocRaw(&e->dTailNow, (size_t) e->D))) return rc;
+        if ((rc = e->allocRaw(&e->dGate4, (size_t) std::max(e->K, 1)))) return rc;
+    }
     StepCtx c = e->ctx();
+    if (tails && !e->tailsValid) {  // after a reset / cfx_load_state: the records of the generation the step starts from
+        hipLaunchKernelGGL(kd_init_tails, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->dTail[0], e->dTail[1]);
+        e->tailsValid = true;
+    }
     const size_t slotBound = std::min(need, e->slotCap);
-    e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
+    if (tails) e->launch(PK_ADMIT, kd_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
+    else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
     if (e->lc.on) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
@@ -1143,8 +1169,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
-        e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
-                  nVehBlocks);
+        if (tails) e->launch(PK_ACTION, kd_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq, nVehBlocks);
+        else e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
+                       nVehBlocks);
     }
     if (useBig)
         e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
@@ -1166,7 +1193,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
               e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat,
-              e->exactTimes() ? 1 : 0);
+              e->exactTimes() ? 1 : 0, (const int32_t *) e->cnt[nxt].p);
     if (e->lc.on)
         hipLaunchKernelGGL(k_lc_clear, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, e->lc, (const int32_t *) e->gen[nxt].vid,
                            (const int32_t *) e->segStart[nxt].p, (int) e->D);

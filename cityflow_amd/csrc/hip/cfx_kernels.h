@@ -1315,7 +1315,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
                           int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, double *finTerm,
                           int finCap, int32_t *jobCount, HostMirror *hostMirror, int32_t *finTicket, int nStatBlocks,
-                          int exactTimes) {
+                          int exactTimes, const int32_t *cntNext) {
     // The launch carries extra blocks that only do the step's finish statistics (they read just the current
     // generation and the finish list, both complete before this kernel starts), in parallel with the compaction.
     const int nBody = (int) gridDim.x - nStatBlocks;
@@ -1404,6 +1404,17 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
             ns = tStartNext + (cntNow(c, nd) - tLeave) + rank;
         }
         oldToNew[s] = ns;
+        if (c.tailW && ns == tStartNext + cntNext[t] - 1) {
+            // the vehicle that ends up last in its drivable leaves the tail record of this step's end (cfx_dense_kernels.h)
+            TailRec r;
+            r.dis = ndis;
+            r.speed = nspeed;
+            r.slot = ns;
+            r.templ = templ;
+            r.prevDrv = nd == -1 ? prevDrv : d;
+            r.tag = c.step;
+            c.tailW[t] = r;
+        }
         nx.vid[ns] = vid;
         nx.templ[ns] = templ;
         nx.dis[ns] = ndis;

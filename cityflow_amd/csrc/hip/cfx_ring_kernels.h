@@ -26,26 +26,6 @@
 
 namespace cfxd {
 
-// The last vehicle of a drivable, kept as ONE 32-byte record so that its readers — the leader search of every head of a
-// drivable, Lane::canEnter, the admission check, the notify sources — do one load instead of a chain through
-// {ring geometry, head, count} -> slot -> {dis, speed, template}.  `tag` is the step the record was written in: a record is
-// the truth about the END of step `tag`, so "tag != step - 1" means nobody wrote one last step = the drivable was empty
-// (every non-empty drivable's tail vehicle rewrites it every step; kr_commit does where the tail changed hands).
-struct TailRec {
-    double dis, speed;
-    int32_t slot, templ, prevDrv, tag;
-};
-static_assert(sizeof(TailRec) == 32, "tail record layout");
-
-// Per-laneLink notify sources beyond llDyn = {u, f, first vehicle on the laneLink, vehicles on it}: the state of u (the
-// vehicle that just left onto the end lane) and f (the approaching vehicle on the start lane) and the two lengths the
-// distances are measured with, so that a cross resolves "who was I notified of" from two records.
-struct LLAux {
-    double uDis, uSpeed, fDis, fSpeed, llLen, startLen;
-    int32_t uTempl, fTempl;
-};
-static_assert(sizeof(LLAux) == 56, "laneLink aux record layout");
-
 struct RingCtx {
     DevNet n;
     DevTables t;
@@ -97,7 +77,6 @@ __device__ __forceinline__ int lastSlotForLeader(const RingCtx &c, int d, bool v
     if (viewerNew && d < viewerLane && d < c.n.L && c.admitStep[d] == c.step) n += 1;
     return n > 0 ? ringSlot(c.ringGeo[d], c.head[d], n - 1) : -1;
 }
-__device__ __forceinline__ Tail tailOfRec(const TailRec &r) { return Tail{r.slot, r.templ, r.prevDrv, r.dis, r.speed}; }
 __device__ __forceinline__ Tail tailCommitted(const RingCtx &c, int d) {  // Drivable::getLastVehicle after the last commit
     const TailRec r = c.tailR[d];
     Tail t = tailOfRec(r);
@@ -162,14 +141,6 @@ constexpr int kRingIdxBits = 20;  // list index inside a drivable (ring capaciti
 
 // Tail of Engine::vehicleControl on the ring layout: stayers are committed right here (their slot does not move), leavers
 // leave a MoverRec / a finish record and a mark in the next generation.
-// What finishing a vehicle that leaves its drivable needs beyond its slot; valid = the caller requested it early
-// (actionOneRing, round A), otherwise it is loaded here.
-struct LeaverPrefetch {
-    bool valid;
-    double nextLen;  // length of the next drivable (nd0 >= 0)
-    int vid, route, routePos;
-};
-
 // Tail of Engine::vehicleControl on the ring layout (engine.cpp:212-221, Vehicle::setDeltaDistance vehicle.cpp:49-68):
 // stayers are committed right here (their slot does not move), leavers leave a MoverRec / a finish record and a mark in
 // the next generation.
@@ -589,15 +560,12 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
 // (round A: tails of the drivables ahead, the gate record of the next laneLink, the length of the next drivable and the
 // identity columns of a vehicle that may leave), then everything that depends on those (round B: the tail of the lane
 // behind the next laneLink), and only then is anything decided — the wave waits for memory twice instead of six times.
-__device__ __forceinline__ Tail tailIfCurrent(const TailRec &r, int wantTag) {
-    Tail t = tailOfRec(r);
-    if (r.tag != wantTag) t.slot = -1;
-    return t;
-}
+__device__ __forceinline__ int4 gateRecord(const RingCtx &c, int k) { return c.llGate[k]; }
+__device__ __forceinline__ bool viewerIsNew(const RingCtx &, const SlotIn &in, int) { return in.laneAdmitted && in.nNow == 1; }
 
-template <class Push>
-__device__ __forceinline__ void actionOneRing(const RingCtx &c, const RingOut &o, const cfx_vehicle_template *tv, const int s,
-                                              const SlotIn &in, Push push) {
+template <class C, class Out, class Push>
+__device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const cfx_vehicle_template *tv, const int s,
+                                                const SlotIn &in, Push push) {
     const int d = in.d, templIdx = in.templIdx, nd0 = in.nd0, flags = in.flags, L = c.n.L;
     const double speed = in.speed, dis = in.dis;
     const cfx_vehicle_template &t = tv[templIdx];
@@ -623,7 +591,7 @@ __device__ __forceinline__ void actionOneRing(const RingCtx &c, const RingOut &o
     if (linkHead) endRec = c.tailR[nd0];
     int4 gate = make_int4(0, 0, 0, 0);
     const int gateLink = onLane ? nd0 - L : d - L;
-    if (related) gate = c.llGate[gateLink];
+    if (related) gate = gateRecord(c, gateLink);
     // may it run past the end of its drivable this step?  (only a hint: decides what is requested early)
     LeaverPrefetch lp{false, 0.0, 0, 0, 0};
     if (dlen - dis <= (speed + t.max_pos_acc * interval) * interval + 1.0) {
@@ -677,7 +645,7 @@ __device__ __forceinline__ void actionOneRing(const RingCtx &c, const RingOut &o
                 } else {
                     // second hop: the lane behind the laneLink (dist <= bound implies `approaching`: its records are here).
                     // A vehicle admitted this step sees this step's admissions on lanes before its own (lastSlotForLeader).
-                    const bool viewerNew = in.laneAdmitted && in.nNow == 1;
+                    const bool viewerNew = viewerIsNew(c, in, d);
                     const int endLane = gate.y;
                     best = (viewerNew && endLane < d) ? tailOfRec(laneNow) : tailIfCurrent(laneCommitted, c.step - 1);
                     if (best.slot >= 0) {
@@ -760,7 +728,7 @@ __device__ __forceinline__ void actionOneRing(const RingCtx &c, const RingOut &o
         }
         v = min2(v, iv);
     }
-    finishAction<false>(c, o, t, s, d, 0, speed, dis, dlen, nd0, v, -1, in.idx, in.nNow, lp);
+    finishAction<false>(c, o, t, s, d, in.vid, speed, dis, dlen, nd0, v, -1, in.idx, in.nNow, lp);
 }
 
 // ---------------------------------------------------------------------------------------------- phase 3 + 4
@@ -888,7 +856,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             in.lm = sLM[i];
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
             in.laneAdmitted = sAdm[i] != 0;
-            actionOneRing(c, o, tv, slot, in, push);
+            actionOneRounds(c, o, tv, slot, in, push);
         }
         __syncthreads();
         TRACE_STAMP(3);
