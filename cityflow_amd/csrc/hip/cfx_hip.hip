@@ -502,6 +502,7 @@ struct cfx_engine {
         size_t run = 0;
         for (int d = 0; d < D; ++d) {
             double want = std::ceil(hDrvLength[d] / minLen) + 6.0;
+            if (cfg.ring_capacity_percent > 0) want = std::max(2.0, want * cfg.ring_capacity_percent / 100.0);
             want *= ringScale;
             size_t cap = 8;
             while ((double) cap < want && cap < (1u << (kRingIdxBits - 1))) cap <<= 1;
@@ -1300,6 +1301,12 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
 }
 
 int32_t cfx_get_layout(cfx_engine *e) { return !e ? CFX_ERR_INVALID : (e->ring ? CFX_LAYOUT_RING : CFX_LAYOUT_DENSE); }
+int32_t cfx_get_ring_info(cfx_engine *e, int64_t *slots, int32_t *scale) {
+    if (!e) return CFX_ERR_INVALID;
+    if (slots) *slots = e->ring ? (int64_t) e->ringSlots : 0;
+    if (scale) *scale = e->ringScale;
+    return CFX_OK;
+}
 
 int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;

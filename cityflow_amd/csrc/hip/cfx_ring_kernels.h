@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
             c.tailW[d] = tail;
         }
         if (n > geo.y) k.sc->overflow = 8;
-        else if (n + 8 > geo.y && geo.y >= 15) k.sc->ringNearFull = 1;
+        else if (n + min(8, (geo.y + 1) / 2) > geo.y) k.sc->ringNearFull = 1;  // (the host doubles every capacity)
         c.head[d] = head;
         c.cnt[d] = n;
         k.scratch[d] = make_int4(0, -1, -1, 0);

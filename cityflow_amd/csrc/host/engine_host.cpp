@@ -48,6 +48,7 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_get_tl_state)
     CFX_FN(cfx_get_scalars)
     CFX_FN(cfx_get_layout)
+    CFX_FN(cfx_get_ring_info)
     CFX_FN(cfx_get_lane_counts)
     CFX_FN(cfx_get_lane_waiting_counts)
     CFX_FN(cfx_get_vehicles)
@@ -113,6 +114,7 @@ EngineConfig readEngineConfig(const std::string &configFile) {
             c.debugSync = x->boolAt("debugSync", false) ? 1 : 0;
             if (x->find("device")) c.device = x->intAt("device");
             if (x->find("ringLanesPerWave")) c.ringLanesPerWave = x->intAt("ringLanesPerWave");
+            if (x->find("ringCapacityPercent")) c.ringCapacityPercent = x->intAt("ringCapacityPercent");
             c.exactShadowPeek = x->boolAt("exactShadowPeek", false);
             if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
         }
@@ -130,6 +132,7 @@ void EngineConfig::apply(cfx_config &cc) const {
     cc.layout = layout;
     cc.debug_sync = debugSync;
     cc.ring_lanes_per_wave = ringLanesPerWave;
+    cc.ring_capacity_percent = ringCapacityPercent;
     cc.device = 0;
     // one process per GPU under torch.distributed.run: the launcher's LOCAL_RANK names the device
     if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);

@@ -39,6 +39,7 @@ struct Backend {
     CFX_FN(cfx_get_tl_state)
     CFX_FN(cfx_get_scalars)
     CFX_FN(cfx_get_layout)
+    CFX_FN(cfx_get_ring_info)
     CFX_FN(cfx_get_lane_counts)
     CFX_FN(cfx_get_lane_waiting_counts)
     CFX_FN(cfx_get_vehicles)
@@ -141,6 +142,12 @@ public:
     const HostRoadNet &net() const { return *net_; }
     const Spawner &spawner() const { return spawner_; }
     std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
+    std::pair<int64_t, int> ringInfo() {
+        int64_t slots = 0;
+        int32_t scale = 1;
+        be_.cfx_get_ring_info(dev_, &slots, &scale);
+        return {slots, scale};
+    }
     std::string layoutName() {
         const int l = be_.cfx_get_layout(dev_);
         return l == CFX_LAYOUT_RING ? "ring" : (l == CFX_LAYOUT_DENSE ? "dense" : "n/a");
@@ -184,7 +191,7 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
     int seed = 0;
     std::string dir, roadnetFile, flowFile;
     // optional "cfx" object (ignored by the reference): implementation choices that never change results
-    int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0;
+    int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0, ringCapacityPercent = 0;
     bool exactShadowPeek = false;  // host: Spawner::exactPeekOnly
     int hostThreads = -1;          // VectorEngine: worker threads for the per-environment host work (-1 auto, 0 serial)
     void apply(cfx_config &cc) const;  // interval, flags, the choices above, device (config > CITYFLOW_AMD_DEVICE > LOCAL_RANK)

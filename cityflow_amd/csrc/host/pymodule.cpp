@@ -426,6 +426,7 @@ PYBIND11_MODULE(_cityflow, m) {
                  return d;
              })
         .def("_layout", &EngineHost::layoutName)
+        .def("_ring_info", &EngineHost::ringInfo, "(total ring slots, capacity scale) of the ring layout")
         .def("_profile_enable", &EngineHost::profileEnable, "on"_a)
         .def("_profile_read", &EngineHost::profileRead)
         .def("_vehicle_id", [](EngineHost &e, int vid) { return e.vehicleId(vid); }, "vid"_a)

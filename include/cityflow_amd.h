@@ -103,6 +103,8 @@ typedef struct cfx_config {
                                * CFX_LAYOUT_RING (per-drivable ring segments, committed in place; not with lane_change) */
     int32_t debug_sync;       /* synchronise after every kernel of a step and name the one that faulted (developer aid) */
     int32_t ring_lanes_per_wave; /* ring layout: lanes one 256-thread workgroup of the action kernel owns (4, 8, 16, 32; 0 = default) */
+    int32_t ring_capacity_percent; /* ring layout: initial ring capacities as a percentage of the bumper-to-bumper bound
+                                    * (0 = 100).  Small values make the growth path run (tests); results never depend on it */
 } cfx_config;
 #define CFX_CROSS_AUTO 0
 #define CFX_CROSS_LATENCY 1
@@ -213,6 +215,9 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out);
 /* the vehicle layout this engine runs on: CFX_LAYOUT_DENSE or CFX_LAYOUT_RING (what cfx_config::layout = AUTO resolved to;
  * CPU implementations report CFX_LAYOUT_AUTO) */
 int32_t cfx_get_layout(cfx_engine *e);
+/* ring layout: total slots of all rings and how often every capacity has been doubled so far (1 = never; 0 slots on other
+ * layouts / implementations) */
+int32_t cfx_get_ring_info(cfx_engine *e, int64_t *slots, int32_t *capacity_scale);
 int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out /*[n_lanes]*/);         /* getLaneVehicleCount */
 int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out /*[n_lanes]*/); /* speed < 0.1 (engine.cpp:641) */
 int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view);

@@ -1041,6 +1041,12 @@ extern "C" {
 
 int32_t cfx_abi_version(void) { return CFX_ABI_VERSION; }
 int32_t cfx_get_layout(cfx_engine *e) { return e ? CFX_LAYOUT_AUTO : CFX_ERR_INVALID; }
+int32_t cfx_get_ring_info(cfx_engine *e, int64_t *slots, int32_t *scale) {
+    if (!e) return CFX_ERR_INVALID;
+    if (slots) *slots = 0;
+    if (scale) *scale = 1;
+    return CFX_OK;
+}
 const char *cfx_backend_name(void) { return "cpu-twin"; }
 
 int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {

@@ -140,3 +140,23 @@ def test_travel_time_sum_keeps_the_reference_order(mod, scen, workdir, interval,
             assert_same_state(hip, tw, "interval %s (%s) step %d" % (interval, layout, s + 1))
     assert hip._scalars()["finished_vehicle_count"] > 100
     assert hip.get_average_travel_time() == tw.get_average_travel_time()
+
+
+def test_ring_growth_path(mod, scen, workdir):
+    """Rings start at a third of their bumper-to-bumper capacity (config "cfx": ringCapacityPercent): lanes fill up, the
+    commit raises its near-full flag, the next step doubles every capacity and carries the vehicles over (gather ->
+    re-allocate -> scatter) — several times during the run, with the state equal to the twin's throughout."""
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_dense.json"), 400, seed=7,
+                            interval=2.0, base_flow=os.path.join(d, "flow.json"))
+    cfg = scen.materialize("grid_6x6", workdir, flow_file=flow)
+    hip, tw = _pair(mod, cfg, layout="ring", ringCapacityPercent=30)
+    for s in range(400):
+        hip.next_step()
+        tw.next_step()
+        if s % 4 == 3:
+            assert_same_state(hip, tw, "growing rings step %d" % (s + 1))
+    assert hip.get_vehicle_count() > 3000
+    slots, scale = hip._ring_info()
+    assert hip._layout() == "ring" and scale >= 2 and slots > 0, (slots, scale)
