@@ -145,3 +145,50 @@ def test_push_vehicle_with_initial_speed(mod, ref_module, scen, workdir, tmp_pat
         assert checkpoint_record(ours) == checkpoint_record(ref), s
     assert ours.get_vehicle_speed() == ref.get_vehicle_speed()
     time.sleep(0.1)
+
+
+def out_of_order_archive(mod, scen, workdir):
+    """An Archive in which, on several lanes, the SECOND vehicle of the list stands right at the lane's end at speed while
+    the first is far behind: the next step removes a vehicle from the middle of a drivable's list while its head stays."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    for _ in range(300):
+        tw.next_step()
+    path = os.path.join(os.path.dirname(cfg), "archive_out_of_order.json")
+    tw.snapshot().dump(path)
+    arc = json.load(open(path))
+    by_id = {v["id"]: v for v in arc["vehicles"]}
+    lens = dict(zip(tw._drivable_ids(), tw._flat_net()["drv_length"]))
+    edited = 0
+    for name, dr in arc["drivables"].items():
+        vs = dr.get("vehicles", [])
+        if len(vs) < 3 or "_TO_" in name or edited >= 12:
+            continue
+        first, second, third = by_id[vs[0]], by_id[vs[1]], by_id[vs[2]]
+        if lens[name] - first["dis"] < 20.0:
+            continue                                                # (keep the head of the list well away from the end)
+        second["dis"], second["speed"] = lens[name] - 0.5, 10.0    # the second: past the first, about to leave the lane
+        # the archive carries leader / gap as state (the reference does not recompute them on load): keep them consistent
+        second["gap"] = first["dis"] - first["len"] - second["dis"]
+        third["gap"] = second["dis"] - second["len"] - third["dis"]
+        edited += 1
+    assert edited >= 4
+    json.dump(arc, open(path, "w"))
+    return cfg, path
+
+
+def test_out_of_order_archive_twin_equals_reference(mod, ref_module, scen, workdir):
+    """(CPU) the twin handles the edited archive like the reference: this is what pins the device test below."""
+    import time
+    cfg, path = out_of_order_archive(mod, scen, workdir)
+    ref = ref_module.Engine(cfg, 1)
+    tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    ref.load_from_file(path)
+    tw.load_from_file(path)
+    for s in range(40):
+        ref.next_step()
+        tw.next_step()
+        assert ref.get_lane_vehicle_count() == tw.get_lane_vehicle_count(), s
+        assert ref.get_vehicle_speed() == tw.get_vehicle_speed() and ref.get_vehicle_distance() == tw.get_vehicle_distance(), s
+        assert ref.get_lane_vehicles() == tw.get_lane_vehicles(), s
+    time.sleep(0.2)

@@ -160,3 +160,19 @@ def test_ring_growth_path(mod, scen, workdir):
     assert hip.get_vehicle_count() > 3000
     slots, scale = hip._ring_info()
     assert hip._layout() == "ring" and scale >= 2 and slots > 0, (slots, scale)
+
+
+@pytest.mark.parametrize("layout", ["dense", "ring"])
+def test_leavers_that_are_not_a_prefix(mod, scen, workdir, layout):
+    """Both layouts assume "leavers are a prefix of the list" on their fast path and take an exact general path otherwise
+    (in-ring compaction / counted ranks).  Traffic never produces the general case without lane change; a hand-edited
+    Archive does."""
+    from test_edge_cases import out_of_order_archive
+    cfg, path = out_of_order_archive(mod, scen, workdir)
+    hip, tw = _pair(mod, cfg, layout=layout)
+    hip.load_from_file(path)
+    tw.load_from_file(path)
+    for s in range(60):
+        hip.next_step()
+        tw.next_step()
+        assert_same_state(hip, tw, "out-of-order archive (%s) step %d" % (layout, s + 1))
