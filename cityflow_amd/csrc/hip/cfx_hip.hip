@@ -178,7 +178,8 @@ struct cfx_engine {
     int32_t *rHead = nullptr, *rCnt = nullptr, *slotOf = nullptr;
     int4 *rScratch = nullptr;
     SlotArrays rs{};                   // per-slot state that changes only when a vehicle enters a drivable
-    double *rDis[2] = {nullptr, nullptr}, *rSpeed[2] = {nullptr, nullptr};  // the two generations a step alternates
+    double2 *rKin[2] = {nullptr, nullptr};  // [slot] {dis, speed}: the two generations a step alternates
+    int4 *rMeta = nullptr;                  // [slot] {template, next drivable, flags, enterLaneLinkTime}
     int rcur = 0;
     int2 *rBlk[2] = {nullptr, nullptr};  // by step parity
     TailRec *rTail[2] = {nullptr, nullptr}, *rTailNow = nullptr;  // [D] per-drivable tail records (by step parity; this step's view)
@@ -452,10 +453,9 @@ struct cfx_engine {
         c.t.nextStart = dNextStart.p;
         c.t.nextLL = dNextLL.p;
         c.s = rs;
-        c.s.dis = rDis[rcur];
-        c.s.speed = rSpeed[rcur];
-        c.disN = rDis[rcur ^ 1];
-        c.speedN = rSpeed[rcur ^ 1];
+        c.kin = rKin[rcur];
+        c.kinN = rKin[rcur ^ 1];
+        c.meta = rMeta;
         c.blkR = rBlk[(step + 1) & 1];  // written by step - 1
         c.blkW = rBlk[step & 1];
         c.slotOf = slotOf;
@@ -487,9 +487,8 @@ struct cfx_engine {
     }
     int ringFree() {
         int rc = 0;
-        rc |= freeRaw(&rs.vid) | freeRaw(&rs.drv) | freeRaw(&rs.prevDrv) | freeRaw(&rs.next) | freeRaw(&rs.enterLLT) |
-              freeRaw(&rs.routePos) | freeRaw(&rs.templ) | freeRaw(&rs.route) | freeRaw(&rs.flags) | freeRaw(&rBlk[0]) | freeRaw(&rBlk[1]) |
-              freeRaw(&rDis[0]) | freeRaw(&rDis[1]) | freeRaw(&rSpeed[0]) | freeRaw(&rSpeed[1]) | freeRaw(&rMovers) |
+        rc |= freeRaw(&rs.vid) | freeRaw(&rs.drv) | freeRaw(&rs.prevDrv) | freeRaw(&rs.routePos) | freeRaw(&rs.route) |
+              freeRaw(&rBlk[0]) | freeRaw(&rBlk[1]) | freeRaw(&rKin[0]) | freeRaw(&rKin[1]) | freeRaw(&rMeta) | freeRaw(&rMovers) |
               freeRaw(&dRingGeo) | freeRaw(&rJobs) | freeRaw(&rJobRecs);
         return rc ? CFX_ERR_DEVICE : CFX_OK;
     }
@@ -515,13 +514,12 @@ struct cfx_engine {
         ringMinLen = minLen;
         int rc;
 #define RALLOC(ptr) if ((rc = allocRaw(&ptr, ringSlots))) return rc;
-        RALLOC(rs.vid) RALLOC(rs.drv) RALLOC(rs.prevDrv) RALLOC(rs.next) RALLOC(rs.enterLLT) RALLOC(rs.routePos) RALLOC(rs.templ)
-        RALLOC(rs.route) RALLOC(rs.flags) RALLOC(rBlk[0]) RALLOC(rBlk[1]) RALLOC(rDis[0]) RALLOC(rDis[1]) RALLOC(rSpeed[0]) RALLOC(rSpeed[1]) RALLOC(rMovers)
+        RALLOC(rs.vid) RALLOC(rs.drv) RALLOC(rs.prevDrv) RALLOC(rs.routePos) RALLOC(rs.route)
+        RALLOC(rBlk[0]) RALLOC(rBlk[1]) RALLOC(rKin[0]) RALLOC(rKin[1]) RALLOC(rMeta) RALLOC(rMovers)
 #undef RALLOC
         HIP_TRY(hipMemsetAsync(rBlk[0], 0xFF, ringSlots * sizeof(int2), stream));
         HIP_TRY(hipMemsetAsync(rBlk[1], 0xFF, ringSlots * sizeof(int2), stream));
-        HIP_TRY(hipMemsetAsync(rs.templ, 0, ringSlots * 4, stream));
-        HIP_TRY(hipMemsetAsync(rs.flags, 0, ringSlots, stream));
+        HIP_TRY(hipMemsetAsync(rMeta, 0, ringSlots * sizeof(int4), stream));
         if ((rc = upload(&dRingGeo, hRingGeo.data(), hRingGeo.size()))) return rc;
         rJobCap = (int) std::max<size_t>(4096, ringSlots / 8);
         if ((rc = allocRaw(&rJobs, (size_t) rJobCap * kJobShards))) return rc;
@@ -1003,7 +1001,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const size_t activeEst = (size_t) (pr & 0xFFFFFFFFu) + (size_t) e->nQueueLanes * 4;
         e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->sc);
         RING_CHECK("kr_admit")
-        RingOut ro{c.disN, c.speedN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
+        RingOut ro{c.kinN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
         {
             // One workgroup = B threads over G lanes (or B laneLinks).  G is picked so that a block's vehicles fit one pass

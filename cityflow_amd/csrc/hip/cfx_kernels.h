@@ -162,6 +162,14 @@ __global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, 
     admitStep[lane] = c.step;  // cnt[], the FIFO pop and the running count follow in k_scan (see cntNow)
 }
 
+// The per-slot columns the cross phase reads, through accessors: the ring layout keeps them in two 16-byte records per
+// slot (cfx_ring_kernels.h: RingCtx::kin / meta) and overloads these.
+template <class C> __device__ __forceinline__ double slotDis(const C &c, int s) { return c.s.dis[s]; }
+template <class C> __device__ __forceinline__ double slotSpeed(const C &c, int s) { return c.s.speed[s]; }
+template <class C> __device__ __forceinline__ int slotTempl(const C &c, int s) { return c.s.templ[s]; }
+template <class C> __device__ __forceinline__ int slotNext(const C &c, int s) { return c.s.next[s]; }
+template <class C> __device__ __forceinline__ int slotEnterLLT(const C &c, int s) { return c.s.enterLLT[s]; }
+
 // Per-laneLink sources of Engine::threadNotifyCross (engine.cpp:317-372): the vehicle that just left
 // onto the end lane (331-332), the vehicles on the laneLink (344), the first vehicle of the start lane if
 // it heads here on green (362-363).  Which of them a particular cross sees is resolved by notifiedAt().
@@ -194,8 +202,8 @@ __device__ inline int notifiedAt(const C &c, const cfx_vehicle_template *tv, int
     const int4 dyn = c.llDyn[k];  // {u, f, segStart, cnt} written by llstate(): one 16-byte load
     const int u = dyn.x;
     if (u >= 0) {
-        double udis = c.s.dis[u];
-        double vehDistance = udis - tv[c.s.templ[u]].len;
+        double udis = slotDis(c, u);
+        double vehDistance = udis - tv[slotTempl(c, u)].len;
         double crossDistance = c.n.drvLength[d] - x;
         if (crossDistance + vehDistance < 0.0) {
             *distOut = -(udis + crossDistance);
@@ -206,8 +214,8 @@ __device__ inline int notifiedAt(const C &c, const cfx_vehicle_template *tv, int
     const SegWalk walk = segWalk(c, d, dyn.z);  // from the laneLink's first vehicle backwards
     for (int i = 0; i < n; ++i) {
         int w = walk.at(i);
-        double vehDistance = c.s.dis[w];
-        if (!(vehDistance > x) || (vehDistance - x - tv[c.s.templ[w]].len <= 0.0)) {
+        double vehDistance = slotDis(c, w);
+        if (!(vehDistance > x) || (vehDistance - x - tv[slotTempl(c, w)].len <= 0.0)) {
             *distOut = x - vehDistance;
             return w;
         }
@@ -215,7 +223,7 @@ __device__ inline int notifiedAt(const C &c, const cfx_vehicle_template *tv, int
     const int f = dyn.y;
     if (f >= 0) {
         int startLane = c.n.llStartLane[k];
-        *distOut = (c.n.drvLength[startLane] - c.s.dis[f]) + x;
+        *distOut = (c.n.drvLength[startLane] - slotDis(c, f)) + x;
         return f;
     }
     return -1;
@@ -238,8 +246,8 @@ __device__ inline Notified notified(const C &c, const cfx_vehicle_template *tv, 
     Notified nf{-1, 0, 0.0, 0.0, false, 0, make_int2(-1, -1)};
     nf.slot = notifiedAt(c, tv, k, x, &nf.dist);
     if (nf.slot >= 0) {
-        nf.templ = c.s.templ[nf.slot];
-        nf.speed = c.s.speed[nf.slot];
+        nf.templ = slotTempl(c, nf.slot);
+        nf.speed = slotSpeed(c, nf.slot);
     }
     return nf;
 }
@@ -291,7 +299,7 @@ __device__ inline bool canPassDecide(const C &c, const cfx_vehicle_template *tv,
                 } else if (foeSteps < mySteps) {
                     yield = 1;
                 } else {
-                    int myT = c.s.enterLLT[selfSlot], foeT = nf.pre ? nf.enterLLT : c.s.enterLLT[foeSlot];
+                    int myT = slotEnterLLT(c, selfSlot), foeT = nf.pre ? nf.enterLLT : slotEnterLLT(c, foeSlot);
                     if (myT == foeT) {
                         if (d1 == d2) {
                             yield = c.vPriority[c.s.vid[selfSlot]] > c.vPriority[c.s.vid[foeSlot]] ? -1 : 1;
@@ -906,10 +914,10 @@ __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q)
             while (j0 + jl >= shardEnd[shard]) ++shard;
             const int s = q.jobs[(size_t) shard * q.capacity + (j0 + jl - (shard ? shardEnd[shard - 1] : 0))];
             const int d = c.s.drv[s];
-            const int templ = c.s.templ[s];
-            const double speed = c.s.speed[s];
-            const double dis = c.s.dis[s];
-            const int nd0 = c.s.next[s];
+            const int templ = slotTempl(c, s);
+            const double speed = slotSpeed(c, s);
+            const double dis = slotDis(c, s);
+            const int nd0 = slotNext(c, s);
             const bool onLane = d < c.n.L;
             const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
             const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
@@ -948,9 +956,9 @@ __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q)
             const cfx_vehicle_template &t = tv[sTempl[tid]];
             const double speed = sSpeed[tid], d0 = sD0[tid];
             const int d = c.s.drv[s];
-            const double dis = c.s.dis[s];
+            const double dis = slotDis(c, s);
             const double dlen = c.n.drvLength[d];
-            const int nd0 = c.s.next[s];
+            const int nd0 = slotNext(c, s);
             double iv = o.parkedInterSpeed(s);  // partial intersection speed parked by k_action
             int blockerSlot = -1;
             const int e = sFirst[tid];

@@ -29,8 +29,13 @@ namespace cfxd {
 struct RingCtx {
     DevNet n;
     DevTables t;
-    SlotArrays s;            // dis / speed: the CURRENT generation; `blocker` is not used (see blk)
-    double *disN, *speedN;   // the NEXT generation of the two arrays a step rewrites
+    SlotArrays s;            // the COLD columns only: vid, drv, prevDrv, routePos, route (the rest is null here)
+    // what every vehicle's action reads, as two 16-byte records per slot (a ring is sparsely filled: five separate
+    // columns cost five partly used lines per lane, two records cost two):
+    double2 *kin;            // [slot] {dis, speed}, the CURRENT generation
+    double2 *kinN;           // the NEXT generation (all a vehicle that stays on its drivable writes)
+    int4 *meta;              // [slot] {template, next drivable (Router::getNextDrivable(0), cached), flags (bit 0: a custom
+                             // speed is pending), ControllerInfo::enterLaneLinkTime}; written when a vehicle enters a drivable
     // [slot] {blocker vid, step it was set in}, two buffers by step parity: a step WRITES the blockers it sets into
     // blkW (parity of this step) while every reader — the deadlock walk of Cross::canPass — looks at what the previous step
     // left in blkR, as the reference's buffered commit does (Vehicle::update vehicle.cpp:133-138)
@@ -108,6 +113,12 @@ __device__ __forceinline__ int blockerOf(const RingCtx &c, int slot) {
     return (b.x >= 0 && b.y == c.step - 1) ? c.slotOf[b.x] : -1;
 }
 __device__ __forceinline__ int keepBlocker(const RingCtx &, int blockerSlot) { return blockerSlot; }
+// the shared cross-phase templates' view of a slot (cfx_kernels.h: slotDis ...)
+__device__ __forceinline__ double slotDis(const RingCtx &c, int s) { return c.kin[s].x; }
+__device__ __forceinline__ double slotSpeed(const RingCtx &c, int s) { return c.kin[s].y; }
+__device__ __forceinline__ int slotTempl(const RingCtx &c, int s) { return c.meta[s].x; }
+__device__ __forceinline__ int slotNext(const RingCtx &c, int s) { return c.meta[s].y; }
+__device__ __forceinline__ int slotEnterLLT(const RingCtx &c, int s) { return c.meta[s].w; }
 
 // What a vehicle that changes drivable leaves behind for kr_commit, at its OLD slot's index (written by 3-5 % of the
 // vehicles; the ring arrays themselves are not touched, so the leavers' slots may be recycled while this is read).
@@ -118,7 +129,7 @@ struct MoverRec {
 static_assert(sizeof(MoverRec) == 48, "mover record layout");
 
 struct RingOut {
-    double *disN, *speedN;
+    double2 *kinN;
     int2 *blk;
     int4 *scratch;       // [D] {vehicles leaving, largest list index among them, head of the entrant list, entrants}
     MoverRec *movers;    // [slot]
@@ -126,16 +137,10 @@ struct RingOut {
     long long *finKey;   // finishers of the step: (drivable << 20 | list index) = the reference's removal order
     int32_t *finVid;
     int finCap;
-    __device__ __forceinline__ void park(int s, double v, double iv) const {
-        speedN[s] = v;
-        disN[s] = iv;
-    }
-    __device__ __forceinline__ double parkedSpeed(int s) const { return speedN[s]; }
-    __device__ __forceinline__ double parkedInterSpeed(int s) const { return disN[s]; }
-    __device__ __forceinline__ void keep(int s, double dis, double speed) const {
-        disN[s] = dis;
-        speedN[s] = speed;
-    }
+    __device__ __forceinline__ void park(int s, double v, double iv) const { kinN[s] = make_double2(iv, v); }
+    __device__ __forceinline__ double parkedSpeed(int s) const { return kinN[s].y; }
+    __device__ __forceinline__ double parkedInterSpeed(int s) const { return kinN[s].x; }
+    __device__ __forceinline__ void keep(int s, double dis, double speed) const { kinN[s] = make_double2(dis, speed); }
 };
 constexpr int kRingIdxBits = 20;  // list index inside a drivable (ring capacities stay far below 2^20)
 
@@ -189,28 +194,27 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
         nNow = cntNow(c, d);
     }
     if (newDrv == -1) {
-        o.disN[s] = ndis;
-        o.speedN[s] = v;
+        o.kinN[s] = make_double2(ndis, v);
         if (bv >= 0) o.blk[s] = make_int2(bv, c.step);
         if (idx == nNow - 1) {  // the last vehicle of its drivable leaves the tail record of this step's end
             TailRec r;
             r.dis = ndis;
             r.speed = v;
             r.slot = s;
-            r.templ = c.s.templ[s];
+            r.templ = c.meta[s].x;
             r.prevDrv = c.s.prevDrv[s];
             r.tag = c.step;
             c.tailW[d] = r;
         }
         return;
     }
-    o.speedN[s] = -1.0;  // "left its drivable": what kr_commit's general path looks at (a speed is never negative)
+    o.kinN[s].y = -1.0;  // "left its drivable": what kr_commit's general path looks at (a speed is never negative)
     atomicAdd(&o.scratch[d].x, 1);
     atomicMax(&o.scratch[d].y, idx);
     if (newDrv >= 0) {
         MoverRec r;
         r.vid = lp.vid;
-        r.templ = c.s.templ[s];
+        r.templ = c.meta[s].x;
         r.route = lp.route;
         r.routePos = lp.routePos;
         r.oldDrv = d;
@@ -306,14 +310,10 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep
                 c.s.vid[slot] = w;
                 c.s.drv[slot] = lane;
                 c.s.prevDrv[slot] = -1;
-                c.s.next[slot] = next;
-                c.s.enterLLT[slot] = CFX_INT_MAX;  // ControllerInfo ctor vehicle.cpp:10-13
                 c.s.routePos[slot] = 0;
-                c.s.templ[slot] = wt;
                 c.s.route[slot] = route;
-                c.s.flags[slot] = pending;
-                c.s.dis[slot] = 0.0;
-                c.s.speed[slot] = v0;
+                c.meta[slot] = make_int4(wt, next, pending, CFX_INT_MAX);  // (enterLaneLinkTime: ControllerInfo ctor vehicle.cpp:10-13)
+                c.kin[slot] = make_double2(0.0, v0);
                 c.slotOf[w] = slot;
                 c.admitRec[lane] = make_int2(w, nextWait);
                 admitStep[lane] = c.step;  // cnt[] and the FIFO pop follow in kr_commit (see cntNow)
@@ -343,7 +343,7 @@ __device__ inline void llstateRing(const RingCtx &c, int k) {
     const Tail tu = tailNowOf(c, endLane);
     const int u = (tu.slot >= 0 && tu.prevDrv == d) ? tu.slot : -1;
     int f = cntNow(c, startLane) > 0 ? firstSlot(c, startLane) : -1;
-    if (f >= 0 && !(c.s.next[f] == d && llAvailable(c, k))) f = -1;
+    if (f >= 0 && !(c.meta[f].y == d && llAvailable(c, k))) f = -1;
     const int nOn = c.cnt[d];
     c.llDyn[k] = make_int4(u, f, firstSlot(c, d), nOn);
     if (u >= 0 || f >= 0 || nOn > 0) {
@@ -352,9 +352,10 @@ __device__ inline void llstateRing(const RingCtx &c, int k) {
         a.uSpeed = tu.speed;
         a.uTempl = tu.templ;
         if (f >= 0) {
-            a.fDis = c.s.dis[f];
-            a.fSpeed = c.s.speed[f];
-            a.fTempl = c.s.templ[f];
+            const double2 kf = c.kin[f];
+            a.fDis = kf.x;
+            a.fSpeed = kf.y;
+            a.fTempl = c.meta[f].x;
         }
         a.llLen = c.n.drvLength[d];
         a.startLen = c.n.drvLength[startLane];
@@ -371,7 +372,7 @@ __device__ __forceinline__ int blockerOfNotified(const RingCtx &c, const Notifie
     return (nf.blk.x >= 0 && nf.blk.y == c.step - 1) ? c.slotOf[nf.blk.x] : -1;
 }
 __device__ __forceinline__ void notifiedExtras(const RingCtx &c, Notified &nf) {  // requested now, used (maybe) much later
-    nf.enterLLT = c.s.enterLLT[nf.slot];
+    nf.enterLLT = c.meta[nf.slot].w;
     nf.blk = c.blkR[nf.slot];
     nf.pre = true;
 }
@@ -402,12 +403,13 @@ __device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_temp
         const SegWalk walk = segWalk(c, c.n.L + k, dyn.z);
         for (int i = 0; i < dyn.w; ++i) {
             const int w = walk.at(i);
-            const double vehDistance = c.s.dis[w];
-            const int wt = c.s.templ[w];
+            const double2 kw = c.kin[w];
+            const double vehDistance = kw.x;
+            const int wt = c.meta[w].x;
             if (!(vehDistance > x) || (vehDistance - x - tv[wt].len <= 0.0)) {
                 nf.slot = w;
                 nf.templ = wt;
-                nf.speed = c.s.speed[w];
+                nf.speed = kw.y;
                 nf.dist = x - vehDistance;
                 notifiedExtras(c, nf);
                 return nf;
@@ -823,13 +825,13 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             i = lo;
             idx = qv - sPre[i];
             slot = ringSlot(sGeo[i], sHead[i], idx);
-            in.dis = c.s.dis[slot];
-            in.speed = c.s.speed[slot];
-            in.templIdx = c.s.templ[slot];
-            if (t > 0) {
-                in.nd0 = c.s.next[slot];
-                in.flags = c.s.flags[slot];
-            }
+            const double2 kv = c.kin[slot];  // the two records of the slot: 2 x 16 B, adjacent lanes adjacent in memory
+            const int4 mv = c.meta[slot];
+            in.dis = kv.x;
+            in.speed = kv.y;
+            in.templIdx = mv.x;
+            in.nd0 = mv.y;
+            in.flags = mv.z;
             sDis[t] = in.dis;
             sSpeed[t] = in.speed;
             sTempl[t] = in.templIdx;
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             }
             if (in.flags & 1) {
                 in.vid = c.s.vid[slot];
-                c.s.flags[slot] = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+                c.meta[slot].z = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
             }
             in.lm = sLM[i];
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
@@ -897,15 +899,11 @@ __device__ inline void ringCopySlot(const RingCtx &c, int from, int to) {  // ge
     c.s.vid[to] = c.s.vid[from];
     c.s.drv[to] = c.s.drv[from];
     c.s.prevDrv[to] = c.s.prevDrv[from];
-    c.s.next[to] = c.s.next[from];
-    c.s.enterLLT[to] = c.s.enterLLT[from];
     c.s.routePos[to] = c.s.routePos[from];
-    c.s.templ[to] = c.s.templ[from];
     c.s.route[to] = c.s.route[from];
-    c.s.flags[to] = c.s.flags[from];
+    c.meta[to] = c.meta[from];
     c.blkW[to] = c.blkW[from];  // (the other buffer's records expire with this step)
-    c.disN[to] = c.disN[from];
-    c.speedN[to] = c.speedN[from];
+    c.kinN[to] = c.kinN[from];
     c.slotOf[c.s.vid[from]] = to;
 }
 
@@ -1024,7 +1022,7 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
                 int wr = n - 1;
                 for (int r = n - 1; r >= 0; --r) {
                     const int from = ringSlot(geo, head, r);
-                    if (c.speedN[from] < 0.0) continue;
+                    if (c.kinN[from].y < 0.0) continue;
                     if (wr != r) ringCopySlot(c, from, ringSlot(geo, head, wr));
                     --wr;
                 }
@@ -1054,13 +1052,11 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
             c.s.vid[slot] = r.vid;
             c.s.drv[slot] = d;
             c.s.prevDrv[slot] = r.oldDrv;
-            c.s.templ[slot] = r.templ;
             c.s.route[slot] = r.route;
-            c.s.flags[slot] = 0;
             c.blkW[slot] = make_int2(r.blockerVid, c.step);
-            int next;
+            int next, enterLLT;
             if (d < c.n.L) {  // Router::update router.cpp:78-94, then Router::getNextDrivable from the road it stopped at
-                c.s.enterLLT[slot] = CFX_INT_MAX;
+                enterLLT = CFX_INT_MAX;
                 const int base = c.t.routeStart[r.route], len = c.t.routeStart[r.route + 1] - base;
                 const int road = c.n.laneRoad[d];
                 while (rp < len && c.t.routeRoads[base + rp] != road) ++rp;
@@ -1070,13 +1066,12 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
                     next = ll < 0 ? -1 : c.n.L + ll;
                 }
             } else {
-                c.s.enterLLT[slot] = c.step;
+                enterLLT = c.step;
                 next = c.n.llEndLane[d - c.n.L];
             }
             c.s.routePos[slot] = rp;
-            c.s.next[slot] = next;
-            c.disN[slot] = r.dis;
-            c.speedN[slot] = r.speed;
+            c.meta[slot] = make_int4(r.templ, next, 0, enterLLT);
+            c.kinN[slot] = make_double2(r.dis, r.speed);
             c.slotOf[r.vid] = slot;
             if (rank > tailRank) {  // the last of the entrants becomes the drivable's tail
                 tailRank = rank;
@@ -1097,10 +1092,11 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
                 tail.slot = -1;
             } else {  // (the general path above may have moved the tail vehicle; with a prefix of leavers this rewrites the same)
                 const int ts = ringSlot(geo, head, n - 1);
-                tail.dis = c.disN[ts];
-                tail.speed = c.speedN[ts];
+                const double2 kt = c.kinN[ts];
+                tail.dis = kt.x;
+                tail.speed = kt.y;
                 tail.slot = ts;
-                tail.templ = c.s.templ[ts];
+                tail.templ = c.meta[ts].x;
                 tail.prevDrv = c.s.prevDrv[ts];
             }
             tail.tag = c.step;
@@ -1136,14 +1132,22 @@ __global__ void kr_gather(RingCtx c, const int32_t *off, RingDense out, int want
         out.drv[o + i] = d;
         out.prevDrv[o + i] = c.s.prevDrv[s];
         out.blockerVid[o + i] = blockerVid(c, s);
-        out.enterLLT[o + i] = c.s.enterLLT[s];
+        const double2 kv = c.kin[s];
+        const int4 mv = c.meta[s];
+        out.enterLLT[o + i] = mv.w;
         out.routePos[o + i] = c.s.routePos[s];
-        out.flags[o + i] = c.s.flags[s];
-        out.dis[o + i] = c.s.dis[s];
-        out.speed[o + i] = c.s.speed[s];
-        if (wantLeader) {
+        out.flags[o + i] = (uint8_t) mv.z;
+        out.dis[o + i] = kv.x;
+        out.speed[o + i] = kv.y;
+        if (wantLeader) {  // Vehicle::updateLeaderAndGap as of now (findLeader of cfx_kernels.h)
             double gap = 0;
-            const int ls = findLeader(c, c.t.templ, s, d, i == 0, c.s.dis[s], c.t.templ[c.s.templ[s]].approach_dist, &gap);
+            int ls;
+            if (i > 0) {
+                ls = ringSlot(geo, head, i - 1);
+                gap = c.kin[ls].x - c.t.templ[c.meta[ls].x].len - kv.x;
+            } else {
+                ls = findHeadLeader(c, c.t.templ, s, d, kv.x, c.t.templ[mv.x].approach_dist, mv.y, c.n.drvLength[d], &gap).slot;
+            }
             out.leaderVid[o + i] = ls >= 0 ? c.s.vid[ls] : -1;
             out.gap[o + i] = gap;
         }
@@ -1165,15 +1169,11 @@ __global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTa
         c.s.vid[s] = v;
         c.s.drv[s] = d;
         c.s.prevDrv[s] = in.prevDrv[j];
-        c.s.enterLLT[s] = in.enterLLT[j];
         c.s.routePos[s] = in.routePos[j];
-        c.s.templ[s] = vt.templ[v];
         c.s.route[s] = route;
-        c.s.flags[s] = in.flags[j];
         const_cast<int2 *>(c.blkR)[s] = make_int2(in.blockerVid[j], c.step - 1);
-        c.s.dis[s] = in.dis[j];
-        c.s.speed[s] = in.speed[j];
-        c.s.next[s] = nextOf(c.n, c.t, d, route, in.routePos[j]);
+        c.kin[s] = make_double2(in.dis[j], in.speed[j]);
+        c.meta[s] = make_int4(vt.templ[v], nextOf(c.n, c.t, d, route, in.routePos[j]), in.flags[j], in.enterLLT[j]);
         c.slotOf[v] = s;
         if (i == n - 1) {
             TailRec r;
@@ -1202,21 +1202,21 @@ __global__ void kr_lane_waiting(RingCtx c, int32_t *out) {  // Engine::getLaneWa
     const int2 geo = c.ringGeo[lane];
     const int head = c.head[lane], n = c.cnt[lane];
     int k = 0;
-    for (int i = 0; i < n; ++i) k += c.s.speed[ringSlot(geo, head, i)] < 0.1;
+    for (int i = 0; i < n; ++i) k += c.kin[ringSlot(geo, head, i)].y < 0.1;
     out[lane] = k;
 }
 
 // Vehicle::setCustomSpeed / Router::setRoute / lookup of one running vehicle: its slot is known
 __global__ void kr_set_speed(RingCtx c, int vid) {
     const int s = c.slotOf[vid];
-    if (s >= 0) c.s.flags[s] |= 1;
+    if (s >= 0) c.meta[s].z |= 1;
 }
 __global__ void kr_set_route(RingCtx c, int vid, int route) {
     const int s = c.slotOf[vid];
     if (s < 0) return;
     c.s.route[s] = route;
     c.s.routePos[s] = 0;
-    c.s.next[s] = nextOf(c.n, c.t, c.s.drv[s], route, 0);
+    c.meta[s].y = nextOf(c.n, c.t, c.s.drv[s], route, 0);
 }
 __global__ void kr_find_vehicle(RingCtx c, int vid, int32_t *out /*[2]: drivable, routePos*/) {
     const int s = c.slotOf[vid];
@@ -1245,11 +1245,11 @@ __global__ void kr_validate(RingCtx c, JobQueue q, int nVid, int nRoutes, int ri
         for (int i = 0; i < n && i <= geo.y; ++i) {
             const int s = ringSlot(geo, c.head[d], i);
             if (c.s.drv[s] != d) bad(2, d, i, s, c.s.drv[s]);
-            if ((unsigned) c.s.templ[s] >= (unsigned) c.t.nTempl) bad(3, d, i, s, c.s.templ[s]);
+            if ((unsigned) c.meta[s].x >= (unsigned) c.t.nTempl) bad(3, d, i, s, c.meta[s].x);
             if ((unsigned) c.s.vid[s] >= (unsigned) nVid) bad(4, d, i, s, c.s.vid[s]);
             else if (c.slotOf[c.s.vid[s]] != s) bad(5, d, i, s, c.slotOf[c.s.vid[s]]);
             if ((unsigned) c.s.route[s] >= (unsigned) nRoutes) bad(6, d, i, s, c.s.route[s]);
-            if (c.s.next[s] < -1 || c.s.next[s] >= D) bad(7, d, i, s, c.s.next[s]);
+            if (c.meta[s].y < -1 || c.meta[s].y >= D) bad(7, d, i, s, c.meta[s].y);
             if (c.s.prevDrv[s] < -1 || c.s.prevDrv[s] >= D) bad(8, d, i, s, c.s.prevDrv[s]);
             const int2 b = c.blkR[s];
             if (b.x < -1 || b.x >= nVid) bad(9, d, i, s, b.x);
