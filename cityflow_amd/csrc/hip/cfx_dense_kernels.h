@@ -143,8 +143,11 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
     c.tailNow[d] = now;
 }
 
-// k_action of cfx_kernels.h with the rounds-organised per-vehicle phase
-__global__ __launch_bounds__(kActBlock) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
+// k_action of cfx_kernels.h with the rounds-organised per-vehicle phase.  One slot per thread, no loop: nothing is kept
+// alive across iterations, which is the difference between four and five waves per SIMD (86 registers against 109); the
+// host sizes the grid to its bound on the slots, and a bound that turns out too small is an error, not a skipped vehicle.
+constexpr int kDenseActBlock = 256;
+__global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
     if ((int) blockIdx.x >= nVehicleBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
         llstate(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
         return;
@@ -160,14 +163,13 @@ __global__ __launch_bounds__(kActBlock) void kd_action(StepCtx c, ActionOut o, J
         tv = sT;
     }
     const int S = c.segStart[c.n.L + c.n.K];
-    const int stride = nVehicleBlocks * blockDim.x;
-    const PushJob push{q};
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
-        SlotIn in = loadSlot(c, s);
-        if (in.vid < 0) continue;
-        if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
-        actionOneRounds(c, o, tv, s, in, push);
-    }
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0 && S > nVehicleBlocks * (int) blockDim.x) o.sc->overflow = 10;
+    if (s >= S) return;
+    SlotIn in = loadSlot(c, s);
+    if (in.vid < 0) return;
+    if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
+    actionOneRounds(c, o, tv, s, in, PushJob{q});
 }
 
 // The tail records after cfx_load_state / cfx_reset (k_scatter keeps them up afterwards): one thread per drivable

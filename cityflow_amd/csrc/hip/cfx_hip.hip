@@ -433,6 +433,7 @@ struct cfx_engine {
         if (out.overflow == 7) return fail("lane change: inconsistent pair state (k_lc_resolve did not converge)");
         if (out.overflow == 8) return fail("ring layout: a drivable's ring of slots is full");
         if (out.overflow == 9) return fail("cross phase: job queue capacity exceeded");
+        if (out.overflow == 10) return fail("action phase: more slots in use than the host's bound (internal error)");
         if (out.overflow) return fail("device capacity overflow (finish list)");
         return CFX_OK;
     }
@@ -1001,18 +1002,22 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const size_t activeEst = (size_t) (pr & 0xFFFFFFFFu) + (size_t) e->nQueueLanes * 4;
         e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->sc);
         RING_CHECK("kr_admit")
+        const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;  // which form of the cross phase (§4)
+        RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
         RingOut ro{c.kinN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
         {
             // One workgroup = B threads over G lanes (or B laneLinks).  G is picked so that a block's vehicles fit one pass
             // (B - 1) with room for uneven lanes; small networks take small blocks (every block resident at once, the step
-            // is bound by the slowest block's chain), large ones big blocks (fuller waves: throughput).
-            // cfx_config::ring_lanes_per_wave = G + 1000 * (B / 256) overrides both (developer knob).
+            // is bound by the slowest block's chain), large ones full blocks (throughput).
+            // cfx_config::ring_lanes_per_wave = G + 1000 * (B / 256) overrides both (developer knob; B = 256 or 512).
             int G = e->ringG, Bsel = 256;
             const int want = e->cfg.ring_lanes_per_wave;
             if (want > 0) {
                 G = std::max(1, want % 1000);
-                Bsel = want >= 4000 ? 1024 : (want >= 2000 ? 512 : 256);
+                Bsel = want >= 2000 ? 512 : 256;
+            } else if (useBig) {
+                G = 28;  // many rounds of blocks anyway: full blocks, a second pass where the lanes are dense (throughput)
             } else if (e->mirrorValid) {
                 // adapt to the traffic: the densest block of a recent step (pinned mirror, possibly a few steps old) should
                 // fit one pass with some room; results do not depend on G
@@ -1036,9 +1041,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             G = std::min(G, Bsel);
             const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;
             const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(Bsel);
-            if (Bsel == 256) e->launch(PK_ACTION, kr_action<256>, grid, block, c, ro, jq, e->rJobRecs, G, nLaneBlocks, nLLBlocks);
-            else if (Bsel == 512) e->launch(PK_ACTION, kr_action<512>, grid, block, c, ro, jq, e->rJobRecs, G, nLaneBlocks, nLLBlocks);
-            else e->launch(PK_ACTION, kr_action<1024>, grid, block, c, ro, jq, e->rJobRecs, G, nLaneBlocks, nLLBlocks);
+            if (Bsel == 256) e->launch(PK_ACTION, kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+            else e->launch(PK_ACTION, kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
         }
         RING_CHECK("kr_action")
         if (dbg) {
@@ -1054,7 +1058,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 return e->fail(buf);
             }
         }
-        const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;
         if (useBig)
             e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
@@ -1168,7 +1171,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
-        if (tails) e->launch(PK_ACTION, kd_action, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq, nVehBlocks);
+        if (tails) {
+            const int nv = (int) ((slotBound + kDenseActBlock - 1) / kDenseActBlock), nl = (e->K + kDenseActBlock - 1) / kDenseActBlock;
+            e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
+        }
         else e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
                        nVehBlocks);
     }
@@ -1744,6 +1750,16 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     if (e->ring) {
         // the caller's arrays ARE the dense staging view (Drivable::vehicles order); kr_scatter_in (below, once the vehicle
         // table is on the device) puts them on the rings
+        // rings that are too small for the archive (capacities from a fraction of the bound, or an archive from a denser
+        // state than this engine has seen): double every capacity until it fits — the growth path of a running engine
+        for (;;) {
+            bool fits = true;
+            for (int d = 0; d < D && fits; ++d) fits = cnt[d] + std::min(8, (e->hRingGeo[d].y + 1) / 2) <= e->hRingGeo[d].y;
+            if (fits) break;
+            if (e->ringScale >= 4096) return e->fail("cfx_load_state: more vehicles on one drivable than its ring can hold");
+            e->ringGrowRequested = true;
+            if ((rc = e->ringEnsure())) return rc;
+        }
         for (int d = 0; d < D; ++d) {
             segStart[d + 1] = segStart[d] + cnt[d];
             if (cnt[d] > e->hRingGeo[d].y) return e->fail("cfx_load_state: more vehicles on one drivable than its ring holds");

@@ -447,6 +447,7 @@ struct RingPush {
         }
         const size_t at = (size_t) shard * q.capacity + idx;
         q.jobs[at] = s;
+        if (!recs) return;  // (the throughput form of the cross phase reads the slots)
         RingJob r{};
         r.slot = s;
         r.d = j.d;
@@ -578,19 +579,17 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
     const bool custom = (flags & 1) != 0;
 
     // ================= round A: requests that depend on nothing but the slot
-    const bool hopHead = head && onLane && nextIsLink && in.hop.x != -2;  // head of a lane: tails of the laneLinks leaving it
+    const bool hopHead = head && onLane && nextIsLink && in.hop.x != -2 && in.hop.w < 0;  // head of a lane: tails of the (up to three) laneLinks leaving it
     const bool linkHead = head && !onLane;                                // head of a laneLink: tail of its end lane
-    TailRec hopRec[4];
+    // (a head is either a lane's or a laneLink's: the first record is the lane head's first hop or the laneLink head's end lane)
+    TailRec hopRec[3];
     double linkLen = 0.0;
+    if ((hopHead && in.hop.x >= 0) || linkHead) hopRec[0] = *(linkHead ? &c.tailR[nd0] : &c.tailNow[L + in.hop.x]);
     if (hopHead) {
-        if (in.hop.x >= 0) hopRec[0] = c.tailNow[L + in.hop.x];
         if (in.hop.y >= 0) hopRec[1] = c.tailNow[L + in.hop.y];
         if (in.hop.z >= 0) hopRec[2] = c.tailNow[L + in.hop.z];
-        if (in.hop.w >= 0) hopRec[3] = c.tailNow[L + in.hop.w];
         linkLen = c.n.drvLength[nd0];
     }
-    TailRec endRec{};
-    if (linkHead) endRec = c.tailR[nd0];
     int4 gate = make_int4(0, 0, 0, 0);
     const int gateLink = onLane ? nd0 - L : d - L;
     if (related) gate = gateRecord(c, gateLink);
@@ -603,8 +602,6 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         lp.route = c.s.route[s];
         lp.routePos = c.s.routePos[s];
     }
-    double customSpeed = 0.0;
-    if (custom) customSpeed = c.vCustomSpeed[in.vid];
 
     // ================= round B: what hangs on the gate record (a lane's vehicle near the intersection)
     const bool approaching = related && nextIsLink;  // (a vehicle ON a laneLink has nd0 = its end lane)
@@ -627,8 +624,8 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         double dist = dlen - dis;
         if (hopHead) {
             // first hop: the last vehicles of all laneLinks leaving this lane, closest first (findHeadLeader, `consider`)
-            for (int q = 0; q < 4; ++q) {
-                const int ll = q == 0 ? in.hop.x : (q == 1 ? in.hop.y : (q == 2 ? in.hop.z : in.hop.w));
+            for (int q = 0; q < 3; ++q) {
+                const int ll = q == 0 ? in.hop.x : (q == 1 ? in.hop.y : in.hop.z);
                 if (ll < 0) continue;
                 const Tail cand = tailOfRec(hopRec[q]);
                 if (cand.slot >= 0) {
@@ -660,7 +657,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
                 }
             }
         } else if (linkHead) {
-            best = tailIfCurrent(endRec, c.step - 1);
+            best = tailIfCurrent(hopRec[0], c.step - 1);
             if (best.slot >= 0) {
                 gap = dist + best.dis - tv[best.templ].len;
                 resolved = true;
@@ -684,6 +681,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
     v = min2(v, speed + t.max_pos_acc * interval);
     v = min2(v, in.lm.y);
     double cf;  // Vehicle::getCarFollowSpeed vehicle.cpp:212-238
+    const double customSpeed = custom ? c.vCustomSpeed[in.vid] : 0.0;  // (rare: loaded where it is used)
     if (ls < 0) {
         cf = custom ? customSpeed : t.max_speed;
     } else if (custom) {
