@@ -125,6 +125,7 @@ struct cfx_engine {
     bool tiled = false;
     HaloDev halo{};
     std::vector<uint8_t> hLaneSpare;   // per lane; empty when not tiled
+    std::vector<uint8_t> hLaneGhost;   // per lane; empty when not tiled
     int64_t spareTotal = 0;            // sum of spare slots over lanes
     char *dHaloSend = nullptr, *dHaloRecv = nullptr;
     char *hHaloSend = nullptr, *hHaloRecv = nullptr;  // pinned staging
@@ -1735,7 +1736,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     const int L = e->L, D = e->D, nV = s->n_vehicles, nR = s->n_running;
     if ((rc = e->ensureVidCap((size_t) nV + 1))) return rc;
     if (e->ring && (rc = e->ringEnsure())) return rc;
-    if (!e->ring && (rc = e->ensureSlotCap((size_t) nR + L + 1))) return rc;
+    if (!e->ring && (rc = e->ensureSlotCap((size_t) nR + (e->tiled ? (size_t) e->spareTotal : (size_t) L) + 1))) return rc;
     // ---- layout: vehicles of drivable d, then one spare slot for lanes
     std::vector<int32_t> cnt(D, 0), segStart(D + 1, 0);
     for (int i = 0; i < nR; ++i) {
@@ -1788,7 +1789,8 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         HIP_TRY(up(e->rd.speed, s->r_speed, (size_t) nR * 8));
         HIP_TRY(hipStreamSynchronize(e->stream));  // blk / flags die with this scope
     }
-    for (int d = 0; d < D && !e->ring; ++d) segStart[d + 1] = segStart[d] + cnt[d] + (d < L ? 1 : 0);
+    // (a tile's lanes own laneSpare[l] empty slots each: room for a step's migrants on import lanes)
+    for (int d = 0; d < D && !e->ring; ++d) segStart[d + 1] = segStart[d] + cnt[d] + (d < L ? (e->tiled ? (int) e->hLaneSpare[d] : 1) : 0);
     const int S = e->ring ? 0 : segStart[D];
     std::vector<int32_t> vid(S, -1), drv(S, -1), prev(S, -1), next(S, -1), blk(S, -1), ellt(S, CFX_INT_MAX), rpos(S, 0),
         templ(S, 0), route(S, 0), slotOfVid(std::max(nV, 1), -1);
@@ -1818,7 +1820,10 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         }
         for (int i = 0; i < nR; ++i) {  // blockers: vid -> slot (oldToNew is reset to identity below)
             int b = s->r_blocker_vid[i];
-            blk[slotOfVid[s->r_vid[i]]] = (b >= 0 && b < nV) ? slotOfVid[b] : -1;
+            int bs = (b >= 0 && b < nV) ? slotOfVid[b] : -1;
+            // tiling: a blocker that is the proxy on a ghost lane is kept by vehicle id (keepBlocker, cfx_kernels.h)
+            if (bs >= 0 && e->tiled && drv[bs] < L && e->hLaneGhost[drv[bs]]) bs = -(b + 2);
+            blk[slotOfVid[s->r_vid[i]]] = bs;
         }
     }
     // ---- uploads
@@ -1864,6 +1869,8 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     HIP_TRY(up(e->remain, s->tl_remain, (size_t) e->I * 8));
     DevScalars sc{};
     sc.active = nR;
+    if (e->tiled)  // the vehicle on a ghost lane is the frozen proxy of the owner's tail: not one of this tile's vehicles
+        for (int i = 0; i < nR; ++i) sc.active -= s->r_drivable[i] < L && e->hLaneGhost[s->r_drivable[i]];
     sc.finishedCnt = s->finished_vehicle_count;
     sc.cumulativeTravelTime = s->cumulative_travel_time;
     sc.vehicleSteps = s->vehicle_steps;
@@ -1874,7 +1881,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     e->step = s->step;
     e->spawned = nV;
     e->spawnedHere = nV;
-    e->liveUpper = nR;
+    e->liveUpper = nR + 2 * (int64_t) e->halo.nGhost;
     for (int i = 0; i < s->n_waiting; ++i)
         if (!e->laneQueued[s->w_lane[i]]) {
             e->laneQueued[s->w_lane[i]] = 1;
@@ -1970,6 +1977,7 @@ int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
         if (h->import_lane[i] < 0 || h->import_lane[i] >= e->L) return CFX_ERR_INVALID;
         e->hLaneSpare[h->import_lane[i]] = 1 + CFX_HALO_MAX_MIGRANTS;
     }
+    e->hLaneGhost = ghost;
     e->spareTotal = 0;
     for (uint8_t v : e->hLaneSpare) e->spareTotal += v;
     int rc;

@@ -347,7 +347,9 @@ void EngineHost::load(const Archive &a) {
 }
 
 // Archive(Engine&, filename) archive.cpp:345-550: rebuild an Archive from the reference's JSON format.
-void EngineHost::loadFromFile(const std::string &path) {
+void EngineHost::loadFromFile(const std::string &path) { load(readArchiveFile(path, net_, spawner_, laneChange_)); }
+
+Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadNet> &net_, Spawner &spawner_, bool laneChange_) {
     Json root = Json::parseFile(path);
     Archive a;
     a.net = net_;
@@ -539,7 +541,7 @@ void EngineHost::loadFromFile(const std::string &path) {
     a.routeStart = spawner_.routes.routeStart;
     a.routeRoads = spawner_.routes.roads;
     for (const HostFlow &f : spawner_.flows) a.flowIds.push_back(f.id);
-    load(a);
+    return a;
 }
 
 }  // namespace cfa

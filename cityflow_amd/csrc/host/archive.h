@@ -45,4 +45,8 @@ public:
     std::string vehicleId(int vid) const;
 };
 
+// Archive(Engine&, filename) archive.cpp:345-550: the reference's JSON format -> Archive.  Interns the vehicle templates
+// and routes the file needs in `spawner` (their indices are what the archive's vehicle table refers to).
+Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadNet> &net, Spawner &spawner, bool laneChange);
+
 }  // namespace cfa

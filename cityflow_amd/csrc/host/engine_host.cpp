@@ -96,6 +96,10 @@ EngineConfig readEngineConfig(const std::string &configFile) {
         c.roadnetFile = cfg.stringAt("roadnetFile");
         c.flowFile = cfg.stringAt("flowFile");
         c.saveReplay = cfg.boolAt("saveReplay");
+        if (c.saveReplay) {
+            c.roadnetLogFile = cfg.stringAt("roadnetLogFile");
+            c.replayLogFile = cfg.stringAt("replayLogFile");
+        }
         if (const Json *x = cfg.find("cfx")) {
             if (!x->isObject()) throw JsonError("cfx: expected an object");
             auto choice = [x](const char *key, std::initializer_list<const char *> names) {

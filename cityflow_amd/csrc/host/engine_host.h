@@ -190,6 +190,7 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
     bool rlTrafficLight = false, laneChange = false, saveReplay = false;
     int seed = 0;
     std::string dir, roadnetFile, flowFile;
+    std::string roadnetLogFile, replayLogFile;  // required with saveReplay (engine.cpp:73-77)
     // optional "cfx" object (ignored by the reference): implementation choices that never change results
     int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0, ringCapacityPercent = 0;
     bool exactShadowPeek = false;  // host: Spawner::exactPeekOnly

@@ -581,6 +581,21 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("sync", &TiledEngineHost::sync)
         .def("lane_ids", &TiledEngineHost::laneIds)
         .def("owner", &TiledEngineHost::owner, "owning tile of every intersection (index order of the roadnet file)")
+        .def("snapshot", &TiledEngineHost::snapshot, "Archive of the whole network (every tile in this process)")
+        .def("load", &TiledEngineHost::load, "archive"_a, "every process loads the same archive and keeps its tiles' part")
+        .def("load_from_file", &TiledEngineHost::loadFromFile, "path"_a)
+        .def("set_vehicle_route", &TiledEngineHost::setRoute, "vehicle_id"_a, "route"_a)
+        .def("set_replay_file", &TiledEngineHost::setReplayLogFile, "replay_file"_a)
+        .def("set_save_replay", &TiledEngineHost::setSaveReplay, "open"_a)
+        .def("_snapshot_part", [](TiledEngineHost &e) { return py::bytes(e.snapshotPart()); },
+             "the state of this process's tiles, for _snapshot_from_parts on every process (in rank order)")
+        .def("_snapshot_from_parts",
+             [](TiledEngineHost &e, const std::vector<py::bytes> &parts) {
+                 std::vector<std::string> blobs;
+                 for (const py::bytes &b : parts) blobs.push_back((std::string) b);
+                 return e.snapshotFromParts(blobs);
+             },
+             "parts"_a)
         .def("_set_status_reducer", &TiledEngineHost::setStatusReducer, "fn"_a)
         .def("_host_seconds", &TiledEngineHost::hostSeconds,
              "(spawner, submit) cumulative host wall seconds of this process since the last reset")

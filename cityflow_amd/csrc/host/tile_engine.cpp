@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cstring>
 #include <iostream>
 #include <numeric>
@@ -516,7 +517,7 @@ void TileEngine::setPhases(const std::vector<int32_t> &globalInter, const std::v
     if (!in.empty()) check(be_->cfx_set_tl_phases(dev_, (int32_t) in.size(), in.data(), ph.data()), "cfx_set_tl_phases");
 }
 
-void TileEngine::appendVehicles(VehicleSnapshot &out) {
+void TileEngine::appendVehicles(VehicleSnapshot &out, std::vector<double> *customSpeed) {
     const int cap = (int) scalars().active_vehicle_count + 2 * (int) tn_.ghostLane.size() + 16;
     std::vector<int32_t> vid(cap), drv(cap), prev(cap), lead(cap), blk(cap), ellt(cap), rpos(cap);
     std::vector<double> dis(cap), speed(cap), gap(cap);
@@ -533,6 +534,11 @@ void TileEngine::appendVehicles(VehicleSnapshot &out) {
     v.speed = speed.data();
     v.gap = gap.data();
     check(be_->cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
+    std::vector<double> custom;
+    if (customSpeed) {  // same order as cfx_get_vehicles
+        custom.resize((size_t) std::max(v.count, 1));
+        if (v.count) check(be_->cfx_get_custom_speeds(dev_, v.count, custom.data()), "cfx_get_custom_speeds");
+    }
     const int nL = (int) tn_.laneL2G.size(), gL = (int) tn_.laneG2L.size();
     auto toGlobal = [&](int d) {
         if (d <= -2) return gL + (-d - 2);  // a migrant's laneLink of origin (kept as global id)
@@ -552,17 +558,130 @@ void TileEngine::appendVehicles(VehicleSnapshot &out) {
         out.speed.push_back(speed[i]);
         out.gap.push_back(gap[i]);
         out.count += 1;
+        if (customSpeed) customSpeed->push_back(custom[i]);
     }
 }
 
-void TileEngine::appendWaiting(std::vector<int32_t> &vids) {
+void TileEngine::appendWaiting(std::vector<int32_t> &vids, std::vector<int32_t> *lanes) {
     cfx_scalars sc = scalars();
     int cap = (int) sc.spawned_vehicle_count + 16;
     std::vector<int32_t> v(cap), l(cap);
     int32_t n = 0;
     check(be_->cfx_get_waiting(dev_, cap, v.data(), l.data(), &n), "cfx_get_waiting");
     for (int i = 0; i < n; ++i)
-        if (!tn_.laneGhost[l[i]]) vids.push_back(v[i]);  // ghost lanes only mirror their owner's queue
+        if (!tn_.laneGhost[l[i]]) {  // ghost lanes only mirror their owner's queue
+            vids.push_back(v[i]);
+            if (lanes) lanes->push_back(tn_.laneL2G[l[i]]);
+        }
+}
+
+void TileEngine::setVehicleRoute(int vid, int route) {
+    check(be_->cfx_set_vehicle_route(dev_, vid, route), "cfx_set_vehicle_route");
+}
+
+void TileEngine::trafficLights(const std::vector<int> &owner, std::vector<int32_t> &phase, std::vector<double> &remain) {
+    const size_t nI = tn_.interL2G.size();
+    std::vector<int32_t> ph(std::max<size_t>(nI, 1));
+    std::vector<double> rem(std::max<size_t>(nI, 1));
+    check(be_->cfx_get_tl_state(dev_, ph.data(), rem.data()), "cfx_get_tl_state");
+    for (size_t i = 0; i < nI; ++i) {
+        const int g = tn_.interL2G[i];
+        if (owner[g] != tn_.rank) continue;
+        phase[g] = ph[i];
+        remain[g] = rem[i];
+    }
+}
+
+void TileEngine::loadState(const Archive &a, bool takesTotals) {
+    const DeviceState &d = a.dev;
+    const int nV = (int) a.host.vehicles.size();
+    const int nL = (int) tn_.laneL2G.size(), nK = (int) tn_.llL2G.size(), gL = (int) tn_.laneG2L.size();
+    std::vector<int32_t> prio(std::max(nV, 1)), templ(std::max(nV, 1)), route(std::max(nV, 1));
+    std::vector<double> enter(std::max(nV, 1));
+    std::vector<uint8_t> vstate(std::max(nV, 1), 0);
+    for (int v = 0; v < nV; ++v) {
+        prio[v] = a.host.vehicles[v].priority;
+        templ[v] = a.host.vehicles[v].templ;
+        route[v] = a.host.vehicles[v].route;
+        enter[v] = a.host.vehicles[v].enterTime;
+        if (d.vState[v] == 2 && takesTotals) vstate[v] = 2;  // (the job takes the maximum over the tiles)
+    }
+    auto localOf = [&](int g) {  // global drivable -> this tile's, or -1
+        if (g < 0) return -1;
+        if (g < gL) return (int) tn_.laneG2L[g];
+        const int k = tn_.llG2L[g - gL];
+        return k < 0 ? -1 : nL + k;
+    };
+    // the archive lists the running vehicles drivable by drivable, front to back: bucket them by local drivable
+    std::vector<std::vector<int>> on((size_t) nL + nK);
+    for (size_t i = 0; i < d.rVid.size(); ++i) {
+        const int ld = localOf(d.rDrivable[i]);
+        if (ld < 0) continue;
+        if (ld < nL && tn_.laneGhost[ld]) on[ld].assign(1, (int) i);  // a ghost lane keeps its tail only (the proxy)
+        else on[ld].push_back((int) i);
+    }
+    std::vector<int32_t> rVid, rDrv, rPrev, rBlk, rEllt, rPos;
+    std::vector<double> rDis, rSpeed, rCustom;
+    const double nan = __builtin_nan("");
+    for (int ld = 0; ld < nL + nK; ++ld)
+        for (int i : on[ld]) {
+            const bool proxy = ld < nL && tn_.laneGhost[ld];
+            const int vid = d.rVid[i];
+            rVid.push_back(vid);
+            rDrv.push_back(ld);
+            const int gp = d.rPrevDrivable[i];
+            int lp = localOf(gp);
+            if (lp < 0 && gp >= gL) lp = -((gp - gL) + 2);  // a laneLink of another tile, kept as its global id (cfx_halo_import)
+            rPrev.push_back(lp);
+            rBlk.push_back(proxy ? -1 : d.rBlocker[i]);
+            rEllt.push_back(proxy ? INT_MAX : d.rEnterLLTime[i]);
+            rPos.push_back(proxy ? 0 : d.rRoutePos[i]);
+            rDis.push_back(d.rDis[i]);
+            rSpeed.push_back(d.rSpeed[i]);
+            rCustom.push_back(proxy || d.rCustomSpeed.empty() ? nan : d.rCustomSpeed[i]);
+            if (!proxy) vstate[vid] = 1;
+        }
+    std::vector<int32_t> wVid, wLane;
+    for (size_t i = 0; i < d.wVid.size(); ++i) {
+        const int ll = tn_.laneG2L[d.wLane[i]];
+        if (ll < 0) continue;
+        wVid.push_back(d.wVid[i]);
+        wLane.push_back(ll);
+    }
+    const size_t nI = tn_.interL2G.size();
+    std::vector<int32_t> tlPhase(std::max<size_t>(nI, 1));
+    std::vector<double> tlRemain(std::max<size_t>(nI, 1));
+    for (size_t i = 0; i < nI; ++i) {
+        tlPhase[i] = d.tlPhase[tn_.interL2G[i]];
+        tlRemain[i] = d.tlRemain[tn_.interL2G[i]];
+    }
+    cfx_state st{};
+    st.step = d.step;
+    st.finished_vehicle_count = takesTotals ? d.finished : 0;
+    st.vehicle_steps = takesTotals ? d.vehicleSteps : 0;
+    st.cumulative_travel_time = takesTotals ? d.cumulativeTravelTime : 0.0;
+    st.n_vehicles = nV;
+    st.v_priority = prio.data();
+    st.v_templ = templ.data();
+    st.v_route = route.data();
+    st.v_enter_time = enter.data();
+    st.v_state = vstate.data();
+    st.n_running = (int) rVid.size();
+    st.r_vid = rVid.data();
+    st.r_drivable = rDrv.data();
+    st.r_prev_drivable = rPrev.data();
+    st.r_blocker_vid = rBlk.data();
+    st.r_enter_ll_time = rEllt.data();
+    st.r_route_pos = rPos.data();
+    st.r_dis = rDis.data();
+    st.r_speed = rSpeed.data();
+    st.r_custom_speed = rCustom.data();
+    st.n_waiting = (int) wVid.size();
+    st.w_vid = wVid.data();
+    st.w_lane = wLane.data();
+    st.tl_phase = tlPhase.data();
+    st.tl_remain = tlRemain.data();
+    check(be_->cfx_load_state(dev_, &st), "cfx_load_state");
 }
 
 void TileEngine::setVehicleSpeed(int vid, double speed) {
@@ -582,9 +701,6 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
     if (cfg_.laneChange) throw std::runtime_error("TiledEngine: laneChange=true is not implemented for the tiled engine (single Engine only)");
-    if (cfg_.saveReplay)
-        std::cerr << "[cityflow_amd] saveReplay: the tiled engine writes no replay files (use cityflow.Engine for replays)"
-                  << std::endl;
     nTiles_ = rows * cols;
     owner_ = gridPartition(*net_, rows, cols);
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
@@ -610,6 +726,16 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         return s == 2;
     });
     for (auto &t : tiles_) t->uploadTables(spawner_);
+    saveReplayInConfig_ = saveReplay_ = cfg_.saveReplay;
+    if (saveReplay_) {  // Engine::setLogFile engine.cpp:773-778
+        if (!allLocal_) {
+            std::cerr << "[cityflow_amd] saveReplay: only the process that runs every tile writes replay files" << std::endl;
+            saveReplay_ = saveReplayInConfig_ = false;
+        } else {
+            if (!writeRoadnetLog(*net_, cfg_.dir + cfg_.roadnetLogFile)) std::cerr << "write roadnet log file error" << std::endl;
+            replay_.open(cfg_.dir + cfg_.replayLogFile);
+        }
+    }
 }
 
 void TiledEngineHost::flushPhases() {
@@ -667,6 +793,7 @@ void TiledEngineHost::stepBeginDevice() {
 
 void TiledEngineHost::stepEndDevice() {
     for (auto &t : tiles_) t->haloImportDevice();
+    if (saveReplay_) updateLog();
     step_ += 1;
 }
 
@@ -687,6 +814,7 @@ void TiledEngineHost::stepEnd() {
         if (mailboxes_) t->haloWait();
         else t->haloImport();
     }
+    if (saveReplay_) updateLog();
     step_ += 1;
 }
 
@@ -1000,6 +1128,262 @@ void TiledEngineHost::setVehicleSpeed(const std::string &id, double speed) {
     int st = vid >= 0 ? statusOf(vid) : 2;
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + id + "' not found");
     for (auto &t : tiles_) t->setVehicleSpeed(vid, speed);
+}
+
+}  // namespace cfa
+
+// ---------------------------------------------------------------- archive, routes, replay
+namespace cfa {
+
+namespace {
+// a snapshot PART on the wire: counted runs of plain values, in the order snapshotPart() writes them
+struct PartWriter {
+    std::string out;
+    template <typename T> void scalar(T v) { out.append((const char *) &v, sizeof v); }
+    template <typename T> void vec(const std::vector<T> &v) {
+        scalar<uint64_t>(v.size());
+        if (!v.empty()) out.append((const char *) v.data(), v.size() * sizeof(T));
+    }
+};
+struct PartReader {
+    const std::string &in;
+    size_t at = 0;
+    explicit PartReader(const std::string &s) : in(s) {}
+    template <typename T> T scalar() {
+        if (at + sizeof(T) > in.size()) throw std::runtime_error("tiling: truncated snapshot part");
+        T v;
+        memcpy(&v, in.data() + at, sizeof v);
+        at += sizeof v;
+        return v;
+    }
+    template <typename T> std::vector<T> vec() {
+        const uint64_t n = scalar<uint64_t>();
+        if (at + n * sizeof(T) > in.size()) throw std::runtime_error("tiling: truncated snapshot part");
+        std::vector<T> v((size_t) n);
+        if (n) memcpy(v.data(), in.data() + at, (size_t) n * sizeof(T));
+        at += (size_t) n * sizeof(T);
+        return v;
+    }
+};
+}  // namespace
+
+std::string TiledEngineHost::snapshotPart() {
+    flushPhases();
+    PartWriter w;
+    const cfx_scalars sc = scalars();  // sums over the local tiles
+    w.scalar<int64_t>((int64_t) step_);
+    w.scalar<int64_t>(sc.finished_vehicle_count);
+    w.scalar<int64_t>(sc.vehicle_steps);
+    w.scalar<double>(sc.cumulative_travel_time);
+    const int nV = (int) spawner_.vehicles.size();
+    std::vector<uint8_t> vState((size_t) nV, 0);
+    if (nV)
+        for (auto &t : tiles_) t->mergeStatus(0, nV, vState.data());
+    w.vec(vState);
+    VehicleSnapshot all;
+    std::vector<double> custom;
+    for (auto &t : tiles_) t->appendVehicles(all, &custom);
+    w.vec(all.vid);
+    w.vec(all.drivable);
+    w.vec(all.prevDrivable);
+    w.vec(all.leader);
+    w.vec(all.blocker);
+    w.vec(all.enterLLTime);
+    w.vec(all.routePos);
+    w.vec(all.dis);
+    w.vec(all.speed);
+    w.vec(all.gap);
+    w.vec(custom);
+    std::vector<int32_t> wVid, wLane;
+    for (auto &t : tiles_) t->appendWaiting(wVid, &wLane);
+    w.vec(wVid);
+    w.vec(wLane);
+    const size_t nI = net_->inters.size();
+    std::vector<int32_t> phase(nI, -1);  // -1: not one of this process's intersections
+    std::vector<double> remain(nI, 0.0);
+    for (auto &t : tiles_) t->trafficLights(owner_, phase, remain);
+    w.vec(phase);
+    w.vec(remain);
+    return std::move(w.out);
+}
+
+Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts) {
+    Archive a;
+    a.host = spawner_.saveState();
+    a.net = net_;
+    a.templates = spawner_.templates;
+    a.routeStart = spawner_.routes.routeStart;
+    a.routeRoads = spawner_.routes.roads;
+    for (const HostFlow &f : spawner_.flows) a.flowIds.push_back(f.id);
+    DeviceState &d = a.dev;
+    d.step = (int64_t) step_;
+    const int nV = (int) spawner_.vehicles.size();
+    d.vState.assign((size_t) nV, 0);
+    const size_t nI = net_->inters.size();
+    d.tlPhase.assign(nI, 0);
+    d.tlRemain.assign(nI, 0.0);
+    VehicleSnapshot all;
+    std::vector<double> custom;
+    std::vector<int32_t> wVid, wLane;
+    for (const std::string &blob : parts) {
+        PartReader r(blob);
+        if (r.scalar<int64_t>() != d.step) throw std::runtime_error("tiling: snapshot parts of different steps");
+        d.finished += r.scalar<int64_t>();
+        d.vehicleSteps += r.scalar<int64_t>();
+        d.cumulativeTravelTime += r.scalar<double>();
+        const std::vector<uint8_t> vs = r.vec<uint8_t>();
+        if ((int) vs.size() != nV) throw std::runtime_error("tiling: snapshot part of a different vehicle table");
+        for (int v = 0; v < nV; ++v) d.vState[v] = std::max(d.vState[v], vs[v]);
+        auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
+        app(all.vid, r.vec<int32_t>());
+        app(all.drivable, r.vec<int32_t>());
+        app(all.prevDrivable, r.vec<int32_t>());
+        app(all.leader, r.vec<int32_t>());
+        app(all.blocker, r.vec<int32_t>());
+        app(all.enterLLTime, r.vec<int32_t>());
+        app(all.routePos, r.vec<int32_t>());
+        app(all.dis, r.vec<double>());
+        app(all.speed, r.vec<double>());
+        app(all.gap, r.vec<double>());
+        app(custom, r.vec<double>());
+        app(wVid, r.vec<int32_t>());
+        app(wLane, r.vec<int32_t>());
+        const std::vector<int32_t> ph = r.vec<int32_t>();
+        const std::vector<double> rem = r.vec<double>();
+        if (ph.size() != nI || rem.size() != nI) throw std::runtime_error("tiling: snapshot part of a different road network");
+        for (size_t i = 0; i < nI; ++i)
+            if (ph[i] >= 0) {
+                d.tlPhase[i] = ph[i];
+                d.tlRemain[i] = rem[i];
+            }
+    }
+    // every drivable belongs to exactly one tile, which lists it front to back: a stable sort by global drivable gives
+    // Drivable::vehicles order over the whole network (the same for the waiting buffers, lane by lane)
+    std::vector<int> idx(all.vid.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return all.drivable[x] < all.drivable[y]; });
+    for (int i : idx) {
+        d.rVid.push_back(all.vid[i]);
+        d.rDrivable.push_back(all.drivable[i]);
+        d.rPrevDrivable.push_back(all.prevDrivable[i]);
+        d.rLeader.push_back(all.leader[i]);
+        d.rBlocker.push_back(all.blocker[i]);
+        d.rEnterLLTime.push_back(all.enterLLTime[i]);
+        d.rRoutePos.push_back(all.routePos[i]);
+        d.rDis.push_back(all.dis[i]);
+        d.rSpeed.push_back(all.speed[i]);
+        d.rGap.push_back(all.gap[i]);
+        d.rCustomSpeed.push_back(custom[i]);
+    }
+    idx.resize(wVid.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return wLane[x] < wLane[y]; });
+    for (int i : idx) {
+        d.wVid.push_back(wVid[i]);
+        d.wLane.push_back(wLane[i]);
+    }
+    return a;
+}
+
+Archive TiledEngineHost::snapshot() {
+    if (!allLocal_) throw std::runtime_error("tiling: snapshot() needs every tile in this process; gather snapshot_part() of every process");
+    return snapshotFromParts({snapshotPart()});
+}
+
+void TiledEngineHost::load(const Archive &a) {
+    if (!a.dev.rLcFlags.empty()) throw std::runtime_error("TiledEngine.load: the archive carries lane-change state");
+    if (a.net.get() != net_.get() && a.net->lanes.size() != net_->lanes.size())
+        throw std::runtime_error("TiledEngine.load: archive belongs to a different road network");
+    pendingInter_.clear();
+    pendingPhase_.clear();
+    spawner_.loadState(a.host);
+    for (auto &t : tiles_) {
+        t->uploadTables(spawner_);
+        t->loadState(a, t->tile().rank == 0);
+    }
+    step_ = (size_t) a.dev.step;
+}
+
+void TiledEngineHost::loadFromFile(const std::string &path) { load(readArchiveFile(path, net_, spawner_, false)); }
+
+// Engine::setRoute engine.cpp:852-866 + Router::setRoute router.cpp:245-264 (EngineHost::setRoute)
+bool TiledEngineHost::setRoute(const std::string &vehicleId, const std::vector<std::string> &anchorIds) {
+    const int vid = spawner_.vidOfId(vehicleId);
+    if (vid < 0) return false;
+    const int state = statusOf(vid);
+    if (state == 2) return false;
+    std::vector<int> anchors;
+    for (const auto &id : anchorIds) {
+        auto it = net_->roadIndex.find(id);
+        if (it == net_->roadIndex.end()) return false;
+        anchors.push_back(it->second);
+    }
+    const int L = (int) net_->lanes.size();
+    int drivable = -1, routePos = -1;
+    if (state == 0) {  // still in a waiting buffer: its drivable is its first lane, iCurRoad = begin
+        drivable = spawner_.vehicles[vid].firstLane;
+        routePos = 0;
+    } else {  // where it runs: known to the process that has its tile
+        VehicleSnapshot s;
+        snapshotVehicles(s);
+        for (int i = 0; i < s.count; ++i)
+            if (s.vid[i] == vid) {
+                drivable = s.drivable[i];
+                routePos = s.routePos[i];
+            }
+        if (reduceStatus_) {
+            drivable = reduceStatus_(drivable + 1) - 1;
+            routePos = reduceStatus_(routePos + 1) - 1;
+        }
+        if (drivable < 0) return false;
+    }
+    if (drivable >= L) return false;  // on a laneLink (router.cpp:246)
+    const RouteTable &rt = spawner_.routes;
+    const int route = spawner_.vehicles[vid].route;
+    const int curRoad = rt.roads[rt.routeStart[route] + routePos];
+    std::vector<int> newAnchors{curRoad};
+    newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
+    std::vector<int> seq;
+    if (!spawner_.expandRoute(newAnchors, seq)) return false;
+    const int newRoute = spawner_.internRoute(seq);
+    // Router::onValidLane (router.h:66-68) under the new route: a next drivable exists or this is the last road
+    const RouteTable &rt2 = spawner_.routes;
+    const int laneIdx = net_->lanes[drivable].index;
+    const bool hasNext = rt2.nextLL[rt2.nextStart[rt2.routeStart[newRoute]] + laneIdx] >= 0;
+    const bool lastRoad = seq.size() == 1;
+    if (!hasNext && !lastRoad) return false;
+    for (auto &t : tiles_) {
+        t->uploadTables(spawner_);
+        t->setVehicleRoute(vid, newRoute);
+    }
+    spawner_.setVehicleRoute(vid, newRoute);
+    return true;
+}
+
+// Engine::updateLog (engine.cpp:518-554): the state after the step, lights after TrafficLight::passTime
+void TiledEngineHost::updateLog() {
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    std::vector<int32_t> phase(net_->inters.size(), 0);
+    std::vector<double> remain(net_->inters.size(), 0.0);
+    for (auto &t : tiles_) t->trafficLights(owner_, phase, remain);
+    replay_.writeStep(*net_, spawner_, s, phase);
+}
+
+void TiledEngineHost::setReplayLogFile(const std::string &logFile) {
+    if (!saveReplayInConfig_) {
+        std::cerr << "saveReplay is not set to true in config file!" << std::endl;
+        return;
+    }
+    replay_.open(cfg_.dir + logFile);
+}
+
+void TiledEngineHost::setSaveReplay(bool open) {
+    if (!saveReplayInConfig_) {
+        std::cerr << "saveReplay is not set to true in config file!" << std::endl;
+        return;
+    }
+    saveReplay_ = open;
 }
 
 }  // namespace cfa

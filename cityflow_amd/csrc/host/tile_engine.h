@@ -23,7 +23,9 @@
 #include <tuple>
 #include <vector>
 
+#include "archive.h"
 #include "engine_host.h"
+#include "replay.h"
 
 namespace cfa {
 
@@ -95,9 +97,18 @@ public:
     cfx_scalars scalars();
     void mergeStatus(int first, int n, uint8_t *inout);              // inout[i] = max(inout[i], local state)
     void setPhases(const std::vector<int32_t> &globalInter, const std::vector<int32_t> &phase);  // owned ones are applied
-    void appendVehicles(VehicleSnapshot &out);  // owned running vehicles, global drivable ids (unsorted across tiles)
-    void appendWaiting(std::vector<int32_t> &vids);  // vehicles queued on the lanes this tile owns
+    // owned running vehicles, global drivable ids (unsorted across tiles); customSpeed: their pending custom speeds (NaN none)
+    void appendVehicles(VehicleSnapshot &out, std::vector<double> *customSpeed = nullptr);
+    // vehicles queued on the lanes this tile owns, queue by queue in FIFO order; lanes: their (global) lanes
+    void appendWaiting(std::vector<int32_t> &vids, std::vector<int32_t> *lanes = nullptr);
     void setVehicleSpeed(int vid, double speed);
+    void setVehicleRoute(int vid, int route);  // on every tile: a vehicle takes its route along when it migrates
+    // traffic lights of the intersections this tile owns, into the network-wide arrays
+    void trafficLights(const std::vector<int> &owner, std::vector<int32_t> &phase, std::vector<double> &remain);
+    // Archive::resume for this tile's part of a network-wide archive (archive.cpp:73-126): the vehicles on the drivables it
+    // owns, the proxy (= the tail) of every ghost lane, the waiting buffers of its lanes (owned and mirrored), its lights.
+    // The job's totals (finished vehicles, travel-time sum, vehicle steps) go to ONE tile (takesTotals): the job sums them.
+    void loadState(const Archive &a, bool takesTotals);
 
     const TileNet &tile() const { return tn_; }
     std::vector<char> send, recv;
@@ -178,6 +189,19 @@ public:
     void setVehicleSpeed(const std::string &id, double speed);
     void setRandomSeed(int seed) { spawner_.seed(seed); }
     void snapshotVehicles(VehicleSnapshot &out);  // local tiles, sorted by global drivable
+    // ---- archive (reference src/engine/archive.cpp; EngineHost::snapshot / load / loadFromFile): every process loads the
+    //      same archive and keeps its tiles' part.  A snapshot is assembled from one PART per process (opaque bytes: the
+    //      state of the local tiles); with every tile local snapshot() does both steps.
+    std::string snapshotPart();
+    Archive snapshotFromParts(const std::vector<std::string> &parts);
+    Archive snapshot();
+    void load(const Archive &a);
+    void loadFromFile(const std::string &path);
+    // Engine::setRoute engine.cpp:852-866.  Several processes: the status reducer also merges the vehicle's position.
+    bool setRoute(const std::string &vehicleId, const std::vector<std::string> &anchorIds);
+    // replay (engine.cpp:518-554,773-790): written by the process that runs every tile
+    void setReplayLogFile(const std::string &logFile);
+    void setSaveReplay(bool open);
     void sync();
     // cumulative host wall time of this process since the last reset: {inside the spawner, submitting the steps (kernel
     // launches; includes back-pressure waits when the device is the bottleneck)}
@@ -205,6 +229,9 @@ private:
     double hostSpawnSec_ = 0, hostSubmitSec_ = 0;  // wall time of this process inside the spawner / the ABI calls of a step
     std::vector<int32_t> pendingInter_, pendingPhase_;
     std::function<int(int)> reduceStatus_;
+    ReplayWriter replay_;
+    bool saveReplay_ = false, saveReplayInConfig_ = false;
+    void updateLog();
     void flushPhases();
     int statusOf(int vid);  // merged over the local tiles (and the reducer)
 };

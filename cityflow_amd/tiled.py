@@ -259,6 +259,30 @@ class DistributedEngine:
     def set_vehicle_speed(self, vehicle_id, speed):
         self._eng.set_vehicle_speed(vehicle_id, speed)
 
+    def set_vehicle_route(self, vehicle_id, route):
+        """Engine::setRoute: every rank makes the same call (the route tables stay identical); where the vehicle runs is
+        merged through the status reducer."""
+        return self._eng.set_vehicle_route(vehicle_id, route)
+
+    # ---- archive (reference src/engine/archive.cpp): a snapshot is assembled on every rank from one part per rank; a load
+    #      needs no communication — every rank reads the same archive and keeps its tile's part
+    def snapshot(self):
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self._eng._snapshot_part(), group=self._halo)
+        return self._eng._snapshot_from_parts(parts)
+
+    def load(self, archive):
+        self._eng.sync()
+        dist.barrier(group=self._halo)  # nobody reuses a mailbox buffer a neighbour has not consumed yet
+        self._eng.load(archive)
+        dist.barrier(group=self._halo)
+
+    def load_from_file(self, path):
+        self._eng.sync()
+        dist.barrier(group=self._halo)
+        self._eng.load_from_file(path)
+        dist.barrier(group=self._halo)
+
     # a priority collision in the spawner asks "has vehicle X finished?"; every rank asks at the same point of the
     # same RNG stream, so a collective is legal here and keeps the streams identical
     def _reduce_status(self, status):

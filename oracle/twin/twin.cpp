@@ -1372,7 +1372,8 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
             x.sendUrgency = 1;
         }
         e->order[x.drivable].push_back(s->r_vid[i]);
-        e->active += 1;
+        if (e->onGhost(x)) x.running = true;  // tiling: the frozen proxy of the owner's tail, not one of this tile's vehicles
+        else e->active += 1;
     }
     for (int i = 0; i < s->n_waiting; ++i) {
         e->veh[s->w_vid[i]].drivable = s->w_lane[i];

@@ -134,6 +134,16 @@ def test_two_ranks_gloo(scen, workdir, tmp_path, mailboxes):
     assert "TILED_OK 200" in out.stdout
 
 
+@pytest.mark.parametrize("mailboxes", ["0", "1"])
+def test_two_ranks_archive_and_routes_gloo(scen, workdir, tmp_path, mailboxes):
+    """snapshot (one part per rank) / load (no communication) / setRoute (position merged over ranks) with one tile per
+    process: tests/tiled_worker.py, CFX_TEST_ARCHIVE."""
+    cfg = dense_cfg(scen, workdir, "grid_6x6", 60, 5, 1.0)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 2, 1, 120, 2, free_port(), {"CFX_TEST_MAILBOXES": mailboxes, "CFX_TEST_ARCHIVE": "1"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 120" in out.stdout and "ARCHIVE_OK" in out.stdout
+
+
 def test_two_ranks_device_resident_messages_gloo(scen, workdir, tmp_path):
     """The "rccl" transport's code path (messages stay in the engine's buffers, one P2P batch on the default group) with
     the CPU twin, whose device buffers are host memory, over gloo."""
@@ -297,3 +307,143 @@ def test_tiled_full_api_twin(mod, scen, workdir):
 @pytest.mark.gpu
 def test_tiled_full_api_hip(mod, scen, workdir):
     _api_compare(mod, scen.materialize("grid_6x6", workdir), mod._default_backend_path(), 2, 2)
+
+
+# ---- archive, routes, replay on the tiled engine (reference src/engine/archive.cpp, engine.cpp:852-866, 518-554) ----------
+def _same_now(ref, til, where):
+    assert np.array_equal(ref.get_lane_vehicle_count_array(), til.get_lane_vehicle_count_array()), where
+    assert np.array_equal(ref.get_lane_waiting_vehicle_count_array(), til.get_lane_waiting_vehicle_count_array()), where
+    same_state(ref._vehicle_state(), til._vehicle_state(), where)
+    sa, sb = ref._scalars(), til._scalars()
+    for k in ("active_vehicle_count", "finished_vehicle_count", "cumulative_travel_time", "step"):
+        assert sa[k] == sb[k], (where, k, sa[k], sb[k])
+
+
+def _archive_compare(mod, cfg, lib, rows, cols, tmp_path, mailboxes=False):
+    """snapshot / load / dump / load_from_file on tiles: archives travel in both directions between one engine and the tiles,
+    in memory and through the reference's JSON format, and the run that follows a load is the run that followed the snapshot"""
+    ref = mod.Engine._with_backend(cfg, 1, lib)
+    til = mod.TiledEngine(cfg, rows, cols, [], lib)
+    if mailboxes:
+        til.enable_mailboxes("testa_%d_%d%d" % (os.getpid(), rows, cols))
+    for s in range(140):
+        if s == 100:
+            v = sorted(ref.get_vehicle_speed())[3]
+            ref.set_vehicle_speed(v, 2.5)  # a custom speed pending in the archive
+            til.set_vehicle_speed(v, 2.5)
+        ref.next_step()
+        til.next_step()
+    ref.set_vehicle_speed(sorted(ref.get_vehicle_speed())[5], 1.0)
+    til.set_vehicle_speed(sorted(til.get_vehicle_speed())[5], 1.0)
+    a_ref, a_til = ref.snapshot(), til.snapshot()
+    p_ref, p_til = str(tmp_path / "ref.json"), str(tmp_path / "til.json")
+    a_ref.dump(p_ref)
+    a_til.dump(p_til)
+    import json
+    assert json.load(open(p_ref)) == json.load(open(p_til))  # the tiles' archive IS the single engine's
+    after = []
+    for s in range(60):
+        ref.next_step()
+        til.next_step()
+        after.append((ref.get_lane_vehicle_count_array().copy(), ref._scalars()["cumulative_travel_time"]))
+    _same_now(ref, til, "after the snapshot")
+    # tiles <- their own archive; tiles <- the single engine's archive; single engine <- the tiles' archive
+    for name, load in (("tiles <- tiles", lambda: til.load(a_til)), ("tiles <- engine", lambda: til.load(a_ref)),
+                       ("tiles <- file", lambda: til.load_from_file(p_ref))):
+        load()
+        if name == "tiles <- file":
+            ref.load_from_file(p_ref)  # (a file load numbers the vehicles anew)
+        else:
+            ref.load(a_til)
+        _same_now(ref, til, name + ": right after the load")
+        for s in range(60):
+            ref.next_step()
+            til.next_step()
+            if name != "tiles <- file":  # (the JSON format does not carry pending custom speeds: reference archive.cpp)
+                assert np.array_equal(til.get_lane_vehicle_count_array(), after[s][0]), (name, s)
+        if name == "tiles <- file":
+            ref.load_from_file(p_til)
+            til.load_from_file(p_til)
+            for s in range(60):
+                ref.next_step()
+                til.next_step()
+        _same_now(ref, til, name + ": 60 steps later")
+    # an older archive after a newer state, and a reset in between
+    til.reset()
+    ref.reset()
+    til.load(a_ref)
+    ref.load(a_ref)
+    for s in range(30):
+        ref.next_step()
+        til.next_step()
+    _same_now(ref, til, "load after reset")
+
+
+def test_tiled_archive_twin(mod, scen, workdir, tmp_path):
+    _archive_compare(mod, dense_cfg(scen, workdir, "grid_6x6", 80, 3, 1.0), TWIN_LIB, 2, 2, tmp_path)
+
+
+def test_tiled_archive_mailboxes_twin(mod, scen, workdir, tmp_path):
+    _archive_compare(mod, dense_cfg(scen, workdir, "grid_6x6", 80, 3, 1.0), TWIN_LIB, 2, 3, tmp_path, mailboxes=True)
+
+
+@pytest.mark.gpu
+def test_tiled_archive_hip(mod, scen, workdir, tmp_path):
+    _archive_compare(mod, dense_cfg(scen, workdir, "grid_6x6", 80, 3, 1.0), mod._default_backend_path(), 2, 2, tmp_path)
+
+
+def _route_compare(mod, cfg, lib, rows, cols):
+    """Engine::setRoute on tiles: same verdicts, same traffic afterwards (the vehicle takes its new route across the cut)"""
+    ref = mod.Engine._with_backend(cfg, 1, lib)
+    til = mod.TiledEngine(cfg, rows, cols, [], lib)
+    info = {"length": 4.0, "maxSpeed": 12.0, "minGap": 2.0}
+    ref.push_vehicle(info, ["road_0_1_0", "road_1_1_0"])
+    til.push_vehicle(info, ["road_0_1_0", "road_1_1_0"])
+    verdicts = []
+    for s in range(200):
+        if s in (3, 30, 31, 60):
+            # waiting or running on its first roads: send it across the vertical cut; once with a road that does not exist;
+            # once with a road that cannot follow
+            for anchors in (["road_2_1_0", "road_3_1_0", "road_4_1_0"], ["no_such_road"], ["road_0_1_0"]):
+                a = ref.set_vehicle_route("manually_pushed_0", anchors)
+                b = til.set_vehicle_route("manually_pushed_0", anchors)
+                assert a == b, (s, anchors, a, b)
+                verdicts.append(a)
+        if s == 100:  # some flow vehicles as well, whatever state they are in
+            for v in sorted(ref.get_vehicles(True))[:12]:
+                assert ref.set_vehicle_route(v, ["road_3_2_1"]) == til.set_vehicle_route(v, ["road_3_2_1"]), v
+        ref.next_step()
+        til.next_step()
+        if s % 10 == 9:
+            _same_now(ref, til, "step %d" % s)
+    assert any(verdicts) and not all(verdicts)
+    assert ref.set_vehicle_route("flow_999_0", ["road_1_1_0"]) is False and til.set_vehicle_route("flow_999_0", ["road_1_1_0"]) is False
+    assert ref.get_vehicle_info("manually_pushed_0") == til.get_vehicle_info("manually_pushed_0")
+
+
+def test_tiled_set_route_twin(mod, scen, workdir):
+    _route_compare(mod, scen.materialize("grid_6x6", workdir), TWIN_LIB, 2, 2)
+
+
+@pytest.mark.gpu
+def test_tiled_set_route_hip(mod, scen, workdir):
+    _route_compare(mod, scen.materialize("grid_6x6", workdir), mod._default_backend_path(), 2, 2)
+
+
+def test_tiled_replay_twin(mod, scen, workdir, tmp_path):
+    """saveReplay on tiles: the same roadnet log and the same replay lines as one engine (engine.cpp:518-554)"""
+    outs = []
+    for kind in ("single", "tiled"):
+        cfg = scen.materialize("grid_6x6", workdir, saveReplay=True, roadnetLogFile="rn_%s.json" % kind, replayLogFile="rp_%s.txt" % kind)
+        eng = mod.Engine._with_backend(cfg, 1, TWIN_LIB) if kind == "single" else mod.TiledEngine(cfg, 2, 2, [], TWIN_LIB)
+        for s in range(120):
+            if s == 60:
+                eng.set_save_replay(False)
+            if s == 80:
+                eng.set_save_replay(True)
+            eng.next_step()
+        d = os.path.dirname(cfg)
+        del eng
+        outs.append((open(os.path.join(d, "rn_%s.json" % kind)).read(), open(os.path.join(d, "rp_%s.txt" % kind)).read()))
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1] == outs[1][1] and outs[0][1].count("\n") == 100

@@ -60,6 +60,41 @@ def main():
             assert eng.get_vehicle_distance() == single.get_vehicle_distance()
             assert eng.get_lane_vehicles() == single.get_lane_vehicles()
     assert crossed > 0
+    if os.environ.get("CFX_TEST_ARCHIVE") == "1":
+        # archive and routes over ranks: the snapshot assembled from every rank's part is the single engine's; after a load
+        # (no communication: every rank keeps its tile's part) both go on identically; setRoute gives the same verdicts
+        import json
+        import tempfile
+        arch, arch1 = eng.snapshot(), single.snapshot()
+        with tempfile.TemporaryDirectory() as tmp:
+            arch.dump(os.path.join(tmp, "a.json"))
+            arch1.dump(os.path.join(tmp, "b.json"))
+            assert json.load(open(os.path.join(tmp, "a.json"))) == json.load(open(os.path.join(tmp, "b.json")))
+        later = []
+        for s in range(40):
+            eng.next_step()
+            single.next_step()
+            later.append(single.get_lane_vehicle_count_array().copy())
+        eng.load(arch1)
+        single.load(arch)
+        moved = 0
+        for s in range(40):
+            if s == 5:
+                for v in sorted(single.get_vehicles(True))[:30]:
+                    a, b = single.set_vehicle_route(v, ["road_3_2_1"]), eng.set_vehicle_route(v, ["road_3_2_1"])
+                    assert a == b, (rank, v, a, b)
+                    moved += int(a)
+            eng.next_step()
+            single.next_step()
+            if s < 5:
+                assert np.array_equal(eng.get_lane_vehicle_count_array(), later[s]), (rank, s)
+            assert np.array_equal(eng.get_lane_vehicle_count_array(), single.get_lane_vehicle_count_array()), (rank, s)
+        assert eng.get_vehicle_distance() == single.get_vehicle_distance()
+        sa, sb = single._scalars(), eng.scalars()
+        for k in ("active_vehicle_count", "finished_vehicle_count", "cumulative_travel_time"):
+            assert sa[k] == sb[k], (rank, k, sa[k], sb[k])
+        if rank == 0:
+            print("ARCHIVE_OK routes changed", moved)
     dist.barrier()
     if rank == 0:
         print("TILED_OK", steps, single.get_vehicle_count(), "transport", eng.transport)
