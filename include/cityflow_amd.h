@@ -305,7 +305,12 @@ int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vi
  *   migrant block (CFX_HALO_MIG_BYTES): int32 count, int32 pad, then CFX_HALO_MAX_MIGRANTS records
  *       {int32 vid, int32 route_pos, int32 prev_lanelink (global id), int32 pad, double dis, double speed}
  *   tail block (CFX_HALO_TAIL_BYTES):   {int32 vid (-1: lane empty), int32 prev_lanelink (global id or -1),
- *                                        double dis, double speed} */
+ *                                        double dis, double speed}
+ * cfx_load_state on a tile (Archive::resume, archive.cpp:73-126, for one tile of a network-wide archive): the running
+ * vehicles of the drivables the tile owns; for every ghost lane at most ONE vehicle, the lane's tail — it becomes the proxy
+ * (not counted as running here, never stepped); r_prev_drivable of a vehicle that came from another tile's laneLink as
+ * -(global laneLink id + 2), as migrants carry it; waiting buffers of owned AND ghost lanes (a ghost lane mirrors its
+ * owner's queue); finished_vehicle_count / cumulative_travel_time / vehicle_steps on one tile of the job only. */
 #define CFX_HALO_MAX_MIGRANTS 8
 #define CFX_HALO_MIG_BYTES (8 + CFX_HALO_MAX_MIGRANTS * 32)
 #define CFX_HALO_TAIL_BYTES 24
