@@ -105,7 +105,7 @@ struct LcDev {
     int32_t *parkList;              // [slot capacity]
     int32_t *parkIdx;               // [vid] index in parkList (valid for this step's parked real vehicles)
     int32_t *parkDep;               // [slot capacity] scratch of k_lc_resolve: the item each item has to wait for
-    int32_t *parkCount;             // [1]
+    int32_t *parkCount;             // [2] parked items; of them, items that wait for another one (k_lc_resolve)
     // neighbours that the schedule walk could only name provisionally (shadows of this very step): {vid, which, record}
     int32_t *fixList;               // [3 * fixCap]
     int32_t *fixCount;              // [1]

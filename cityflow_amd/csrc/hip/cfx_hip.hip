@@ -153,7 +153,6 @@ struct cfx_engine {
     int32_t *lcWidth = nullptr;        // [D + 1] slots per drivable of the rebuilt layout (scan input)
     void *scanTemp = nullptr;          // hipcub::DeviceScan work space
     size_t scanTempBytes = 0;
-    int32_t *dPool = nullptr;          // priorities of the step's shadows (device)
     int32_t *hPool = nullptr;          // ... pinned staging
     int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1] overflow code, [2..] their parents in walk order
     hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
@@ -616,7 +615,7 @@ struct cfx_engine {
         if (lc.on) {
             HIP_TRY(hipMemsetAsync(lc.roadCand, 0, (size_t) std::max(R, 1) * sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.insHead, 0xFF, (size_t) std::max(L, 1) * sizeof(int32_t), stream));
-            HIP_TRY(hipMemsetAsync(lc.parkCount, 0, sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.parkCount, 0, 2 * sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.fixCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.insCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.candAllCount, 0, sizeof(int32_t), stream));
@@ -850,8 +849,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         HIP_TRY(hipMemset(lc.insHead, 0xFF, (size_t) std::max(e->L, 1) * sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.insCount, 1))) return rc;
         HIP_TRY(hipMemset(lc.insCount, 0, sizeof(int32_t)));
-        if ((rc = e->allocRaw(&lc.parkCount, 1))) return rc;
-        HIP_TRY(hipMemset(lc.parkCount, 0, sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.parkCount, 2))) return rc;
+        HIP_TRY(hipMemset(lc.parkCount, 0, 2 * sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.roadCandList, (size_t) std::max(e->R, 1) * kLcRoadCand))) return rc;
         if ((rc = e->allocRaw(&e->lcWidth, (size_t) e->D + 1))) return rc;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, e->scanTempBytes, e->lcWidth, e->segStart[0].p, e->D + 1, e->stream));
@@ -1108,7 +1107,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
 
     if (e->lc.on) {  // per-step fields of the lane-change context
         e->lc.firstShadowVid = (int) e->spawned;
-        e->lc.pool = e->dPool;
+        e->lc.pool = e->hPool;  // pinned: k_lc_assign reads the few priorities it hands out straight from the host's buffer
         e->lc.insCap = e->poolN;
     }
     const bool tails = e->useTails();
@@ -1142,7 +1141,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         LC_CHECK("k_lc_plan")
         hipLaunchKernelGGL(k_lc_order, dim3(gridStride(std::max<size_t>(slotBound / 16, 256))), dim3(kBlock), 0, st, e->lc);
         LC_CHECK("k_lc_order")
-        hipLaunchKernelGGL(k_lc_schedule, dim3(gridFor(e->R)), dim3(kBlock), 0, st, c, e->sc, (const int32_t *) e->vt.priority);
+        hipLaunchKernelGGL(k_lc_schedule, dim3((e->R + kLcSchedBlock - 1) / kLcSchedBlock), dim3(kLcSchedBlock), 0, st, c, e->sc,
+                           (const int32_t *) e->vt.priority);
         LC_CHECK("k_lc_schedule")
         hipLaunchKernelGGL(k_lc_assign, dim3(1), dim3(1024), 0, st, c, e->vt, e->sc, e->hPoll);
         LC_CHECK("k_lc_assign")
@@ -1186,7 +1186,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                   dim3(kCrossBlock), c, ao, jq);
-    if (e->lc.on) hipLaunchKernelGGL(k_lc_resolve, dim3(1), dim3(kBlock), 0, st, c, ao, e->oldToNew2);  // (scratch is free here)
+    if (e->lc.on) {  // (oldToNew2: scratch that is free here)
+        hipLaunchKernelGGL(k_lc_resolve, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound / 8 + kBlock - 1) / kBlock), 1024)),
+                           dim3(kBlock), 0, st, c, ao, e->oldToNew2);
+        hipLaunchKernelGGL(k_lc_resolve_rest, dim3(1), dim3(kBlock), 0, st, c, ao, e->oldToNew2);
+    }
     int32_t *const scanTicket = e->nScanBlocks > kScanResidentTiles ? e->scanTicket : nullptr;
     e->launch(PK_SCAN, k_scan, dim3(e->nScanBlocks), dim3(kBlock), (int) e->D, (int) e->L, (const int32_t *) e->cnt[e->cur].p, e->cs,
               e->scanGranules, scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
@@ -1630,10 +1634,9 @@ int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *prioriti
     HIP_TRY(hipSetDevice(e->device));
     int rc;
     if (e->pollPending) return e->fail("cfx_lane_change_supply: the previous lane-change step was not polled"), CFX_ERR_STATE;
-    if (n > e->lc.insCap || !e->dPool) {  // (re)allocate pool, records and the landing buffer of the poll
+    if (n > e->lc.insCap || !e->hPool) {  // (re)allocate pool, records and the landing buffer of the poll
         HIP_TRY(hipStreamSynchronize(e->stream));
         const size_t cap = std::max<size_t>((size_t) n, 1024);
-        if ((rc = e->grow(&e->dPool, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.ins, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.insNext, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.fixList, 0, 3 * 8 * cap))) return rc;
@@ -1646,7 +1649,6 @@ int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *prioriti
     }
     // (the previous step was polled, so the device is done with the pinned staging buffer)
     memcpy(e->hPool, priorities, (size_t) n * sizeof(int32_t));
-    HIP_TRY(hipMemcpyAsync(e->dPool, e->hPool, (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     e->poolN = n;
     return CFX_OK;
 }

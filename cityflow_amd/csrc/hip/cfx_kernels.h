@@ -550,6 +550,12 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
                 const int idx = atomicAdd(c.lc.parkCount, 1);
                 c.lc.parkList[idx] = vid;
                 c.lc.parkIdx[vid] = idx;
+                // whom this item has to wait for in k_lc_resolve (lcResolveDep), as the tables stand in this phase — nothing
+                // writes them between the schedule walk and the resolve: the changing vehicle whose signal it (or its
+                // shadow) holds, if that one comes earlier in the walk.  Kept as that vehicle's number (-1: nobody).
+                const int r = pt == 1 ? c.lc.partner[vid] : vid;
+                const int from = c.lc.recvFrom[r];
+                c.lc.parkDep[idx] = (from >= 0 && from < vid && c.lc.changing[from] && c.lc.ptype[from] == 1) ? from : -1;
             }
             return;
         }

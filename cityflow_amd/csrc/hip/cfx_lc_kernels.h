@@ -37,7 +37,8 @@ __device__ __forceinline__ double lcSegStart(const StepCtx &c, int lane, int i) 
 
 // Lane::initSegments roadnet.cpp:863-875, one thread per lane: front to back, every vehicle goes to the highest segment
 // whose start it has reached — as long as the vehicles in front of it did (the list is walked once).  Segment numbers
-// therefore never increase along the list, whatever the distances are.
+// therefore never increase along the list, whatever the distances are.  (One thread per slot taking the minimum over the
+// vehicles ahead was measured: twice as slow — the segment starts are FP64 divisions, recomputed per pair.)
 __global__ void k_lc_segments(StepCtx c) {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= c.n.L) return;
@@ -180,7 +181,16 @@ struct LcNeighbour {
 // Engine::scheduleLaneChange engine.cpp:792-810 for ONE road: its candidates in the order of the reference's walk
 // (k_lc_order; include/cityflow_amd.h "Lane change").  Roads are independent in this phase: a target lane is on the
 // candidate's own road, and the laneLinks the leader search looks into do not change.
-__global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriority) {
+// The walk's work lists (a road's candidates, the members of one segment, the road's shadows so far) are indexed at run
+// time: they live in LDS, a private row per thread — as thread-local arrays they were 1.7 KB of scratch memory per
+// thread, every access a trip to the memory system in a walk that is one chain of dependent accesses.
+constexpr int kLcSchedBlock = 32;
+constexpr int kLcSegItems = 64;
+__global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriority) {
+    __shared__ int sLocalRec[kLcSchedBlock][kLcRoadInserts];
+    __shared__ int sCandVid[kLcSchedBlock][kLcRoadCand], sCandSlot[kLcSchedBlock][kLcRoadCand], sCandKey[kLcSchedBlock][kLcRoadCand];
+    __shared__ int sItemRef[kLcSchedBlock][kLcSegItems];
+    __shared__ double sItemDis[kLcSchedBlock][kLcSegItems];
     const int road = blockIdx.x * blockDim.x + threadIdx.x;
     if (road >= c.n.R) return;
     const LcDev &lc = c.lc;
@@ -190,11 +200,13 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
     const cfx_vehicle_template *tv = c.t.templ;
     const int l0 = lc.roadLaneStart[road], l1 = lc.roadLaneStart[road + 1];
     const int s0 = c.segStart[l0], s1 = c.segStart[l1 - 1] + cntNow(c, l1 - 1);
-    int localRec[kLcRoadInserts];  // global record indices of this road's shadows so far
+    int(&localRec)[kLcRoadInserts] = sLocalRec[threadIdx.x];  // global record indices of this road's shadows so far
     int nLocal = 0;
     // the road's candidates in walk order (threadPlanLaneChange's buffer after the sort; the walk never creates new ones)
     constexpr int kCand = kLcRoadCand;
-    int candVid[kCand], candSlot[kCand], candKey[kCand];
+    int(&candVid)[kCand] = sCandVid[threadIdx.x];
+    int(&candSlot)[kCand] = sCandSlot[threadIdx.x];
+    int(&candKey)[kCand] = sCandKey[threadIdx.x];
     int nCand = 0;
     const bool tooMany = nListed > kCand;
     if (!tooMany)
@@ -246,9 +258,9 @@ __global__ void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriorit
         int followerRec = -1;                    // ... the earlier shadow it is
         const int tb = c.segStart[target], tn = cntNow(c, target);
         const int mySeg = lc.segOfSlot[s], nSeg = lc.laneNumSegs[target];
-        constexpr int kItems = 64;
-        int itemRef[kItems];  // >= 0 existing index in the lane; < 0: -(local shadow index + 1)
-        double itemDis[kItems];
+        constexpr int kItems = kLcSegItems;
+        int(&itemRef)[kItems] = sItemRef[threadIdx.x];  // >= 0 existing index in the lane; < 0: -(local shadow index + 1)
+        double(&itemDis)[kItems] = sItemDis[threadIdx.x];
         auto buildSegment = [&](int i) {  // the sequence of segment i of the target lane
             int m = 0;
             // segment numbers never increase along the list (k_lc_segments): the members are one run
@@ -604,7 +616,7 @@ __global__ void k_lc_compose(int32_t *oldToNew, const int32_t *oldToNew2, int n,
 // The vehicles k_action / k_cross parked (finishAction), in the order of the reference's walk (creation order = ascending
 // vid; a shadow is handled inside its real vehicle's turn, engine.cpp:195-205): yield as the tables stand NOW, the rest of
 // getNextSpeed, the move; for a changing pair the common speed, the lateral offset and its end (finish), the shadow leaving
-// its lane (abort) — engine.cpp:223-244.  Sequential by nature; one block sorts, one thread walks.
+// its lane (abort) — engine.cpp:223-244.  The walk's order matters only along explicit dependencies (below).
 __device__ inline double lcParkedSpeed(const StepCtx &c, int vid, int s, int turn) {
     const cfx_vehicle_template &t = c.t.templ[c.s.templ[s]];
     const int d = c.s.drv[s];
@@ -614,93 +626,102 @@ __device__ inline double lcParkedSpeed(const StepCtx &c, int vid, int s, int tur
 }
 
 // The only thing an item needs from the walk order is: has the changing vehicle whose signal I (or my shadow) received —
-// if it comes earlier in the walk — already been handled?  So every thread takes items and the block goes through rounds;
-// an item runs in the round after the one it depends on.  Chains are short (one changing vehicle signalling the shadow of
-// the next), so a few rounds do.
-__device__ inline int lcResolveDep(const LcDev &lc, int p) {
-    // the vehicle evaluated in p's turn that can hold a signal: p itself if it is single, its shadow if p leads a pair
-    const int r = lc.ptype[p] == 1 ? lc.partner[p] : p;
-    const int src = lc.recvFrom[r];
-    if (src >= 0 && src < p && lc.changing[src] && lc.ptype[src] == 1) return lc.parkIdx[src];
-    return -1;
+// if it comes earlier in the walk — already been handled?  finishAction notes that vehicle when it parks the item
+// (LcDev::parkDep).  Items that wait for nobody — nearly all — are independent of one another: k_lc_resolve does them with
+// one thread each over the whole device; the few that wait run afterwards in one block, in rounds, an item in the round
+// after the one it depends on (chains are short: one changing vehicle signalling the shadow of the next).
+__device__ inline void lcResolveItem(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template *tv, int p) {
+    const LcDev &lc = c.lc;
+    const int s = lc.slotOf[p];
+    const int pd = c.s.drv[s];
+    const cfx_vehicle_template &tp = tv[c.s.templ[s]];
+    if (lc.ptype[p] != 1) {  // a single vehicle that was signalled by an earlier changing vehicle
+        const double v = lcParkedSpeed(c, p, s, p);
+        commitMove(c, o, s, pd, p, computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], v),
+                   lc.bBlocker[p], true);
+        return;
+    }
+    const int q = lc.partner[p];
+    const int qs = lc.slotOf[q];
+    const int qd = c.s.drv[qs];
+    const cfx_vehicle_template &tq = tv[c.s.templ[qs]];
+    const double ns = min2(lcParkedSpeed(c, p, s, p), lcParkedSpeed(c, q, qs, p));
+    MoveOut mp = computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], ns);
+    MoveOut mq = computeMove(c, tq, qs, qd, c.s.speed[qs], c.s.dis[qs], c.n.drvLength[qd], c.s.next[qs], ns);
+    bool pCounted = true;
+    // the real vehicle: lateral offset, LaneChange::finishChanging lanechange.cpp:115-127
+    if (lc.changing[p]) {
+        const int dir = lc.sigSend[p] ? lc.sendDir[p] : 0;
+        const double maxOffset = (lc.laneWidth[lc.sendTarget[p]] + lc.laneWidth[pd]) / 2;
+        double newOffset = fabs(lc.offset[p] + max2(0.2 * mp.v, 1) * c.interval * dir);
+        newOffset = min2(newOffset, maxOffset);
+        lc.offset[p] = newOffset * dir;
+        if (newOffset >= maxOffset) {
+            lc.changing[p] = 0;
+            lc.lcFinished[p] = 1;
+            lc.lastChangeTime[p] = c.step * c.interval;
+            lc.ptype[q] = 0;  // the shadow is the vehicle from now on (the host moves the id with it)
+            lc.offset[q] = 0.0;
+            lc.partner[q] = -1;
+            lc.partner[p] = -1;
+            // clearSignal: LATER vehicles of the walk see the signal's neighbours cleared, earlier ones (whose items may
+            // run at the same time) must not: lcYieldSpeed decides by lcFinished and the turn
+            lc.lastDir[p] = lc.sigSend[p] ? lc.sendDir[p] : 0;
+            lc.sigSend[p] = 0;
+            lc.recvFrom[p] = -1;
+            mp.newDrv = -2;  // Vehicle::finishChanging: setEnd(true)
+            pCounted = false;
+        }
+    }
+    // the shadow: leaving the target lane before the change is complete aborts it (vehicle.cpp:412-416)
+    if (lc.ptype[q] == 2 && mq.newDrv >= 0) {
+        mq.newDrv = -2;  // the shadow ends — and counts as a finished vehicle, as in the reference
+        lc.changing[p] = 0;
+        lc.ptype[p] = 0;
+        lc.offset[p] = 0.0;
+        lc.partner[p] = -1;
+        lc.tLeader[q] = lc.tFollower[q] = -1;
+        lc.lastDir[q] = 0;
+        lc.recvFrom[q] = -1;
+    }
+    commitMove(c, o, s, pd, p, mp, lc.bBlocker[p], pCounted);
+    commitMove(c, o, qs, qd, q, mq, lc.bBlocker[q], true);
 }
 
+// the items that wait for nobody: one thread each
 __global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capacity] scratch*/) {
     const LcDev &lc = c.lc;
-    const cfx_vehicle_template *tv = c.t.templ;
     const int n = *lc.parkCount;
-    __shared__ int sLeft;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        done[i] = 0;
-        lc.parkDep[i] = lcResolveDep(lc, lc.parkList[i]);  // against the tables as k_action saw them
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (lc.parkDep[i] >= 0) {  // listed for k_lc_resolve_rest (in candAll: the schedule walk is done with it)
+            done[i] = 0;
+            lc.candAll[atomicAdd(&lc.parkCount[1], 1)] = i;
+            continue;
+        }
+        lcResolveItem(c, o, c.t.templ, lc.parkList[i]);
+        done[i] = 1;
     }
-    __syncthreads();
-    for (int round = 1;; ++round) {
+}
+
+// ... and the ones that wait, in rounds (round 1 was k_lc_resolve); one block
+__global__ void k_lc_resolve_rest(StepCtx c, ActionOut o, int32_t *done) {
+    const LcDev &lc = c.lc;
+    const int m = lc.parkCount[1];
+    __shared__ int sLeft;
+    for (int round = 2; m > 0; ++round) {
         if (threadIdx.x == 0) sLeft = 0;
         __syncthreads();
         int left = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            const int i = lc.candAll[j];
             if (done[i]) continue;
-            const int p = lc.parkList[i];
-            const int dep = lc.parkDep[i];
-            if (dep >= 0 && !(done[dep] != 0 && done[dep] < round)) {
+            const int dep = lc.parkIdx[lc.parkDep[i]];  // (a changing vehicle is parked in every step)
+            if (!(done[dep] != 0 && done[dep] < round)) {
                 left += 1;
                 continue;
             }
-            const int s = lc.slotOf[p];
-            const int pd = c.s.drv[s];
-            const cfx_vehicle_template &tp = tv[c.s.templ[s]];
-            if (lc.ptype[p] != 1) {  // a single vehicle that was signalled by an earlier changing vehicle
-                const double v = lcParkedSpeed(c, p, s, p);
-                commitMove(c, o, s, pd, p, computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], v),
-                           lc.bBlocker[p], true);
-            } else {
-                const int q = lc.partner[p];
-                const int qs = lc.slotOf[q];
-                const int qd = c.s.drv[qs];
-                const cfx_vehicle_template &tq = tv[c.s.templ[qs]];
-                const double ns = min2(lcParkedSpeed(c, p, s, p), lcParkedSpeed(c, q, qs, p));
-                MoveOut mp = computeMove(c, tp, s, pd, c.s.speed[s], c.s.dis[s], c.n.drvLength[pd], c.s.next[s], ns);
-                MoveOut mq = computeMove(c, tq, qs, qd, c.s.speed[qs], c.s.dis[qs], c.n.drvLength[qd], c.s.next[qs], ns);
-                bool pCounted = true;
-                // the real vehicle: lateral offset, LaneChange::finishChanging lanechange.cpp:115-127
-                if (lc.changing[p]) {
-                    const int dir = lc.sigSend[p] ? lc.sendDir[p] : 0;
-                    const double maxOffset = (lc.laneWidth[lc.sendTarget[p]] + lc.laneWidth[pd]) / 2;
-                    double newOffset = fabs(lc.offset[p] + max2(0.2 * mp.v, 1) * c.interval * dir);
-                    newOffset = min2(newOffset, maxOffset);
-                    lc.offset[p] = newOffset * dir;
-                    if (newOffset >= maxOffset) {
-                        lc.changing[p] = 0;
-                        lc.lcFinished[p] = 1;
-                        lc.lastChangeTime[p] = c.step * c.interval;
-                        lc.ptype[q] = 0;  // the shadow is the vehicle from now on (the host moves the id with it)
-                        lc.offset[q] = 0.0;
-                        lc.partner[q] = -1;
-                        lc.partner[p] = -1;
-                        // clearSignal: LATER vehicles of the walk see the signal's neighbours cleared, earlier ones (whose
-                        // items may run in this very round) must not: lcYieldSpeed decides by lcFinished and the turn
-                        lc.lastDir[p] = lc.sigSend[p] ? lc.sendDir[p] : 0;
-                        lc.sigSend[p] = 0;
-                        lc.recvFrom[p] = -1;
-                        mp.newDrv = -2;  // Vehicle::finishChanging: setEnd(true)
-                        pCounted = false;
-                    }
-                }
-                // the shadow: leaving the target lane before the change is complete aborts it (vehicle.cpp:412-416)
-                if (lc.ptype[q] == 2 && mq.newDrv >= 0) {
-                    mq.newDrv = -2;  // the shadow ends — and counts as a finished vehicle, as in the reference
-                    lc.changing[p] = 0;
-                    lc.ptype[p] = 0;
-                    lc.offset[p] = 0.0;
-                    lc.partner[p] = -1;
-                    lc.tLeader[q] = lc.tFollower[q] = -1;
-                    lc.lastDir[q] = 0;
-                    lc.recvFrom[q] = -1;
-                }
-                commitMove(c, o, s, pd, p, mp, lc.bBlocker[p], pCounted);
-                commitMove(c, o, qs, qd, q, mq, lc.bBlocker[q], true);
-            }
+            lcResolveItem(c, o, c.t.templ, lc.parkList[i]);
             __threadfence_block();
             done[i] = round;
         }
@@ -713,7 +734,8 @@ __global__ void k_lc_resolve(StepCtx c, ActionOut o, int32_t *done /*[slot capac
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *lc.parkCount = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) lc.parkCount[0] = lc.parkCount[1] = 0;
 }
 
 // threadUpdateAction's clearSignal (engine.cpp:424, lanechange.cpp:129-138) for every vehicle of the new generation, and
