@@ -936,36 +936,77 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if ((rc = e->ensureVidCap((size_t) e->spawned + (size_t) n + (size_t) e->poolN))) return rc;
     }
     // ---- phase 0/1 tail: hand the spawn records to the device
+    SpawnBatch batch;  // (ring layout: the records go with kr_admit's arguments)
+    batch.n = 0;
+    batch.firstNewVid = 0;
     if (n > 0) {
         // the batch carries the next n vehicle numbers, each once, in any order (checked in full by the CPU twin)
         if (recs[0].vid < e->spawned || recs[0].vid >= e->spawned + n)
             return e->fail("cfx_step: spawn records must continue the dense vid sequence");
         if ((rc = e->ensureVidCap((size_t) e->spawned + n))) return rc;
-        if ((size_t) n > e->recCap) {
-            size_t nc = std::max<size_t>((size_t) n * 2, 1024);
-            if ((rc = e->grow(&e->dRecs, 0, nc))) return rc;
-            e->recCap = nc;
-        }
-        if ((size_t) n > e->stageCap) {
-            HIP_TRY(hipStreamSynchronize(st));
-            size_t nc = std::max<size_t>((size_t) n * 2, 1024);
-            for (int i = 0; i < cfx_engine::kStages; ++i) {
-                if (e->hStage[i]) HIP_TRY(hipHostFree(e->hStage[i]));
-                HIP_TRY(hipHostMalloc((void **) &e->hStage[i], nc * sizeof(cfx_spawn), hipHostMallocDefault));
-                if (!e->stageEvent[i]) HIP_TRY(hipEventCreateWithFlags(&e->stageEvent[i], hipEventDisableTiming));
-                e->stageBusy[i] = false;
+        // ring layout: a step's few records go with kr_admit's arguments (each lane's thread links its own): no launch.  They
+        // fit if they are few, all for lanes of this engine, and all enter at the same time (what a host spawner produces:
+        // Engine::getCurrentTime); record i of the batch is vehicle spawned + i, whatever order they came in
+        bool inArgs = e->ring && n <= kAdmitRecs;
+        if (inArgs) {
+            batch.n = (int) n;
+            batch.firstNewVid = (int) e->spawned;
+            batch.enterTime = recs[0].enter_time;
+            int order[kAdmitRecs];
+            bool seen[kAdmitRecs] = {};
+            for (int i = 0; inArgs && i < n; ++i) {
+                const int64_t off = (int64_t) recs[i].vid - e->spawned;
+                inArgs = off >= 0 && off < n && !seen[off] && recs[i].lane >= 0 && recs[i].enter_time == batch.enterTime &&
+                         recs[i].templ < 32768;
+                if (inArgs) seen[off] = true;
+                order[i] = i;
             }
-            e->stageCap = nc;
+            if (inArgs) {
+                std::sort(order, order + n, [recs](int x, int y) {
+                    return recs[x].lane != recs[y].lane ? recs[x].lane < recs[y].lane : recs[x].vid < recs[y].vid;
+                });
+                for (int j = 0; j < n; ++j) {
+                    const cfx_spawn &r = recs[order[j]];
+                    batch.lane[j] = r.lane;
+                    batch.prevWait[j] = r.prev_wait;
+                    batch.route[j] = r.route;
+                    batch.priority[j] = r.priority;
+                    batch.templ[j] = (int16_t) r.templ;
+                    batch.vidOff[j] = (int16_t) (r.vid - e->spawned);
+                }
+            } else {
+                batch.n = 0;
+            }
         }
-        const int si = e->stageIdx;
-        e->stageIdx = (si + 1) % cfx_engine::kStages;
-        if (e->stageBusy[si]) HIP_TRY(hipEventSynchronize(e->stageEvent[si]));
-        memcpy(e->hStage[si], recs, (size_t) n * sizeof(cfx_spawn));
-        // the kernel reads the pinned (device-visible) staging buffer itself: no separate copy launch
-        e->launch(PK_SPAWN, k_spawn_link, dim3(gridFor(n)), dim3(kBlock), (const cfx_spawn *) e->hStage[si], (int) n,
-                  (int) e->spawned, e->vt, e->waitHead, e->lc);
-        HIP_TRY(hipEventRecord(e->stageEvent[si], st));
-        e->stageBusy[si] = true;
+        if (inArgs) {
+            // (nothing to launch)
+        } else {
+            if ((size_t) n > e->recCap) {
+                size_t nc = std::max<size_t>((size_t) n * 2, 1024);
+                if ((rc = e->grow(&e->dRecs, 0, nc))) return rc;
+                e->recCap = nc;
+            }
+            if ((size_t) n > e->stageCap) {
+                HIP_TRY(hipStreamSynchronize(st));
+                size_t nc = std::max<size_t>((size_t) n * 2, 1024);
+                for (int i = 0; i < cfx_engine::kStages; ++i) {
+                    if (e->hStage[i]) HIP_TRY(hipHostFree(e->hStage[i]));
+                    HIP_TRY(hipHostMalloc((void **) &e->hStage[i], nc * sizeof(cfx_spawn), hipHostMallocDefault));
+                    if (!e->stageEvent[i]) HIP_TRY(hipEventCreateWithFlags(&e->stageEvent[i], hipEventDisableTiming));
+                    e->stageBusy[i] = false;
+                }
+                e->stageCap = nc;
+            }
+            const int si = e->stageIdx;
+            e->stageIdx = (si + 1) % cfx_engine::kStages;
+            if (e->stageBusy[si]) HIP_TRY(hipEventSynchronize(e->stageEvent[si]));
+            memcpy(e->hStage[si], recs, (size_t) n * sizeof(cfx_spawn));
+            // the kernel reads the pinned (device-visible) staging buffer itself: no separate copy launch
+            e->launch(PK_SPAWN, k_spawn_link, dim3(gridFor(n)), dim3(kBlock), (const cfx_spawn *) e->hStage[si], (int) n,
+                      (int) e->spawned, e->vt, e->waitHead, e->lc);
+            HIP_TRY(hipEventRecord(e->stageEvent[si], st));
+            e->stageBusy[si] = true;
+        }
         e->spawned += n;
     }
     // ---- slot capacity.  Two host-side upper bounds of the vehicles that can be running after this step:
@@ -1000,7 +1041,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // running vehicles as of the last step the device has completed (stale by the few steps the host runs ahead):
         // only sizes the cross phase's grid and picks its organisation
         const size_t activeEst = (size_t) (pr & 0xFFFFFFFFu) + (size_t) e->nQueueLanes * 4;
-        e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->sc);
+        e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
         RING_CHECK("kr_admit")
         const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;  // which form of the cross phase (§4)
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then

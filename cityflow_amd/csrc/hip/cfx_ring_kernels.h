@@ -240,11 +240,30 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
 // Engine::handleWaiting engine.cpp:502-516 + Lane::available roadnet.cpp:428-435, one thread per drivable (laneLink
 // threads write the gate records, as in the dense layout's k_admit).  The running count is raised here — the finish
 // statistics of this step (extra blocks of kr_commit) read it while kr_commit's other blocks commit the rest.
-__global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, DevScalars *sc) {
+// A step's few spawn records travel IN THE KERNEL ARGUMENTS of kr_admit (k_spawn_link's job, phase 0/1 tail, without its
+// launch and without a read of host memory: every wave gets them where it gets its other arguments, through the scalar
+// cache).  More records than fit: k_spawn_link runs first.
+// The batch is kept by columns, SORTED BY LANE (a lane's thread finds its records by a binary search in the LDS copy of
+// `lane[]`); record j is the vehicle firstNewVid + vidOff[j]; all vehicles of a step enter at the same time
+// (Engine::getCurrentTime).  Kernel arguments stay well below 4 KB.
+constexpr int kAdmitRecs = 128;
+struct SpawnBatch {
+    int n, firstNewVid;
+    double enterTime;
+    int32_t lane[kAdmitRecs], prevWait[kAdmitRecs], route[kAdmitRecs], priority[kAdmitRecs];
+    int16_t templ[kAdmitRecs], vidOff[kAdmitRecs];
+};
+static_assert(sizeof(SpawnBatch) + sizeof(RingCtx) + sizeof(VidTable) + 64 <= 3584, "kr_admit's arguments must stay well below 4 KB");
+
+__global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep, int32_t *waitHead, VidTable vt, DevScalars *sc,
+                                                   const SpawnBatch batch) {
     __shared__ int sAdmitted;
     __shared__ cfx_vehicle_template sT[kLdsTempl];
+    __shared__ int sLane[kAdmitRecs];
     const cfx_vehicle_template *tv = c.t.templ;
+    const int nRecs = batch.n, firstNewVid = batch.firstNewVid;
     if (threadIdx.x == 0) sAdmitted = 0;
+    if ((int) threadIdx.x < nRecs) sLane[threadIdx.x] = batch.lane[threadIdx.x];
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep
         road = c.n.laneRoad[d];
         laneIdx = c.n.laneIndex[d];
     }
-    // ---- round 2: the head of the lane's waiting queue
+    // ---- round 2: the head of the lane's waiting queue (as the last step left it)
     int wt = 0, route = 0, nextWait = -1;
     uint8_t pending = 0;
     if (w >= 0) {
@@ -277,7 +296,54 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep
         nextWait = vt.nextWait[w];
         pending = vt.pendingCustom[w];
     }
-    __syncthreads();  // (templates staged)
+    __syncthreads();  // (templates and the batch's lanes staged)
+    if (nRecs > 0) {
+        // the vehicle table of the new vehicles (k_spawn_link): block 0.  Nobody reads these rows in this kernel — a vehicle
+        // that is admitted in the step it appears in is taken from its record
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < nRecs; i += blockDim.x) {
+                const int v = firstNewVid + batch.vidOff[i];
+                vt.priority[v] = batch.priority[i];
+                vt.templ[v] = batch.templ[i];
+                vt.route[v] = batch.route[i];
+                vt.enterTime[v] = batch.enterTime;
+                vt.state[v] = 0;
+                vt.pendingCustom[v] = 0;
+            }
+        if (isLane) {
+            // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367; nextWait[] of a new vehicle was pre-set to -1): this
+            // lane's records, in any order — each hangs behind its predecessor, or becomes the head where the predecessor
+            // has left the queue
+            int lo = 0, hi = nRecs;  // first record of this lane
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sLane[mid] < d) lo = mid + 1;
+                else hi = mid;
+            }
+            int headRec = -1;
+            for (int j = lo; j < nRecs && sLane[j] == d; ++j) {
+                const int pv = batch.prevWait[j], v = firstNewVid + batch.vidOff[j];
+                bool becomesHead = pv < 0;
+                if (pv >= firstNewVid) vt.nextWait[pv] = v;      // predecessor in this very batch: certainly still queued
+                else if (pv >= 0) {
+                    if (vt.state[pv] != 0) becomesHead = true;  // predecessor already admitted => the FIFO is empty
+                    else vt.nextWait[pv] = v;
+                }
+                if (becomesHead) headRec = j;
+            }
+            if (headRec >= 0) {
+                w = firstNewVid + batch.vidOff[headRec];
+                wt = batch.templ[headRec];
+                route = batch.route[headRec];
+                pending = 0;
+                nextWait = -1;
+                waitHead[d] = w;
+            }
+            if (w >= 0)  // whoever was hung behind the head just now (this thread's own store: taken from the record)
+                for (int j = lo; j < nRecs && sLane[j] == d; ++j)
+                    if (batch.prevWait[j] == w) nextWait = firstNewVid + batch.vidOff[j];
+        }
+    }
     if (inRange) {
         // this step's view of the drivable's tail: what the last step left, or the vehicle admitted below
         TailRec now = committed;
