@@ -587,6 +587,15 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("set_vehicle_route", &TiledEngineHost::setRoute, "vehicle_id"_a, "route"_a)
         .def("set_replay_file", &TiledEngineHost::setReplayLogFile, "replay_file"_a)
         .def("set_save_replay", &TiledEngineHost::setSaveReplay, "open"_a)
+        .def("_wants_replay", &TiledEngineHost::wantsReplay)
+        .def("_replay_part", [](TiledEngineHost &e) { return py::bytes(e.replayPart()); })
+        .def("_replay_write",
+             [](TiledEngineHost &e, const std::vector<py::bytes> &parts) {
+                 std::vector<std::string> blobs;
+                 for (const py::bytes &b : parts) blobs.push_back((std::string) b);
+                 e.replayWrite(blobs);
+             },
+             "parts"_a)
         .def("_snapshot_part", [](TiledEngineHost &e) { return py::bytes(e.snapshotPart()); },
              "the state of this process's tiles, for _snapshot_from_parts on every process (in rank order)")
         .def("_snapshot_from_parts",

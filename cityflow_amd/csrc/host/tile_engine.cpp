@@ -727,14 +727,12 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
     });
     for (auto &t : tiles_) t->uploadTables(spawner_);
     saveReplayInConfig_ = saveReplay_ = cfg_.saveReplay;
-    if (saveReplay_) {  // Engine::setLogFile engine.cpp:773-778
-        if (!allLocal_) {
-            std::cerr << "[cityflow_amd] saveReplay: only the process that runs every tile writes replay files" << std::endl;
-            saveReplay_ = saveReplayInConfig_ = false;
-        } else {
-            if (!writeRoadnetLog(*net_, cfg_.dir + cfg_.roadnetLogFile)) std::cerr << "write roadnet log file error" << std::endl;
-            replay_.open(cfg_.dir + cfg_.replayLogFile);
-        }
+    // Engine::setLogFile engine.cpp:773-778.  One tile per process: the process of tile 0 is the writer; every process hands
+    // the caller its part of a step (replayPart) and the caller gives the writer all of them (replayWrite).
+    replayWriter_ = std::find(localRanks_.begin(), localRanks_.end(), 0) != localRanks_.end();
+    if (saveReplay_ && replayWriter_) {
+        if (!writeRoadnetLog(*net_, cfg_.dir + cfg_.roadnetLogFile)) std::cerr << "write roadnet log file error" << std::endl;
+        replay_.open(cfg_.dir + cfg_.replayLogFile);
     }
 }
 
@@ -793,7 +791,7 @@ void TiledEngineHost::stepBeginDevice() {
 
 void TiledEngineHost::stepEndDevice() {
     for (auto &t : tiles_) t->haloImportDevice();
-    if (saveReplay_) updateLog();
+    if (saveReplay_ && allLocal_) updateLog();
     step_ += 1;
 }
 
@@ -814,7 +812,7 @@ void TiledEngineHost::stepEnd() {
         if (mailboxes_) t->haloWait();
         else t->haloImport();
     }
-    if (saveReplay_) updateLog();
+    if (saveReplay_ && allLocal_) updateLog();
     step_ += 1;
 }
 
@@ -1361,13 +1359,40 @@ bool TiledEngineHost::setRoute(const std::string &vehicleId, const std::vector<s
 }
 
 // Engine::updateLog (engine.cpp:518-554): the state after the step, lights after TrafficLight::passTime
-void TiledEngineHost::updateLog() {
+void TiledEngineHost::updateLog() { replayWrite({replayPart()}); }
+
+// what the replay line of the step that has just finished needs from this process: its vehicles' {number, drivable,
+// distance} and the phases of its intersections
+std::string TiledEngineHost::replayPart() {
+    PartWriter w;
     VehicleSnapshot s;
-    snapshotVehicles(s);
-    std::vector<int32_t> phase(net_->inters.size(), 0);
+    for (auto &t : tiles_) t->appendVehicles(s);
+    w.vec(s.vid);
+    w.vec(s.drivable);
+    w.vec(s.dis);
+    std::vector<int32_t> phase(net_->inters.size(), -1);
     std::vector<double> remain(net_->inters.size(), 0.0);
     for (auto &t : tiles_) t->trafficLights(owner_, phase, remain);
-    replay_.writeStep(*net_, spawner_, s, phase);
+    w.vec(phase);
+    return std::move(w.out);
+}
+
+void TiledEngineHost::replayWrite(const std::vector<std::string> &parts) {
+    if (!replayWriter_) return;
+    VehicleSnapshot s;
+    std::vector<int32_t> phase(net_->inters.size(), 0);
+    for (const std::string &blob : parts) {
+        PartReader r(blob);
+        auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
+        app(s.vid, r.vec<int32_t>());
+        app(s.drivable, r.vec<int32_t>());
+        app(s.dis, r.vec<double>());
+        const std::vector<int32_t> ph = r.vec<int32_t>();
+        for (size_t i = 0; i < ph.size() && i < phase.size(); ++i)
+            if (ph[i] >= 0) phase[i] = ph[i];
+    }
+    s.count = (int) s.vid.size();
+    replay_.writeStep(*net_, spawner_, s, phase);  // (orders the vehicles itself: vehiclePool order)
 }
 
 void TiledEngineHost::setReplayLogFile(const std::string &logFile) {
@@ -1375,7 +1400,7 @@ void TiledEngineHost::setReplayLogFile(const std::string &logFile) {
         std::cerr << "saveReplay is not set to true in config file!" << std::endl;
         return;
     }
-    replay_.open(cfg_.dir + logFile);
+    if (replayWriter_) replay_.open(cfg_.dir + logFile);
 }
 
 void TiledEngineHost::setSaveReplay(bool open) {

@@ -202,6 +202,10 @@ public:
     // replay (engine.cpp:518-554,773-790): written by the process that runs every tile
     void setReplayLogFile(const std::string &logFile);
     void setSaveReplay(bool open);
+    // one tile per process: after every step each process's replayPart() goes to the process of tile 0, which writes the line
+    bool wantsReplay() const { return saveReplay_; }
+    std::string replayPart();
+    void replayWrite(const std::vector<std::string> &parts);
     void sync();
     // cumulative host wall time of this process since the last reset: {inside the spawner, submitting the steps (kernel
     // launches; includes back-pressure waits when the device is the bottleneck)}
@@ -230,7 +234,7 @@ private:
     std::vector<int32_t> pendingInter_, pendingPhase_;
     std::function<int(int)> reduceStatus_;
     ReplayWriter replay_;
-    bool saveReplay_ = false, saveReplayInConfig_ = false;
+    bool saveReplay_ = false, saveReplayInConfig_ = false, replayWriter_ = true;
     void updateLog();
     void flushPhases();
     int statusOf(int vid);  // merged over the local tiles (and the reducer)

@@ -146,7 +146,26 @@ class DistributedEngine:
                 "rccl": "RCCL send/recv of device-resident messages, one batch per step",
                 "gloo": "staged through host buffers over gloo"}[self.transport]
 
+    def _replay(self):
+        # saveReplay with one tile per process: every rank's part of the step's line goes to rank 0, which writes it
+        if not self._eng._wants_replay():
+            return
+        parts = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(self._eng._replay_part(), parts, dst=0, group=self._halo)
+        if self.rank == 0:
+            self._eng._replay_write(parts)
+
+    def set_save_replay(self, open):
+        self._eng.set_save_replay(open)
+
+    def set_replay_file(self, replay_file):
+        self._eng.set_replay_file(replay_file)
+
     def next_step(self):
+        self._step()
+        self._replay()
+
+    def _step(self):
         if self.transport == "rccl":
             self._eng.step_begin_device()  # spawn, the step's kernels, halo export; returns when the messages are complete
             ops = []

@@ -144,6 +144,14 @@ def test_two_ranks_archive_and_routes_gloo(scen, workdir, tmp_path, mailboxes):
     assert "TILED_OK 120" in out.stdout and "ARCHIVE_OK" in out.stdout
 
 
+def test_two_ranks_replay_gloo(scen, workdir, tmp_path):
+    """saveReplay with one tile per process: the replay file rank 0 writes equals the single engine's (tests/tiled_worker.py)."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 30, 2, free_port(), {"CFX_TEST_MAILBOXES": "1", "CFX_TEST_REPLAY": "1"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "REPLAY_OK" in out.stdout
+
+
 def test_two_ranks_device_resident_messages_gloo(scen, workdir, tmp_path):
     """The "rccl" transport's code path (messages stay in the engine's buffers, one P2P batch on the default group) with
     the CPU twin, whose device buffers are host memory, over gloo."""

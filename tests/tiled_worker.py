@@ -95,9 +95,46 @@ def main():
             assert sa[k] == sb[k], (rank, k, sa[k], sb[k])
         if rank == 0:
             print("ARCHIVE_OK routes changed", moved)
+    final_transport, final_count = eng.transport, single.get_vehicle_count()
+    if os.environ.get("CFX_TEST_REPLAY") == "1":
+        # saveReplay with one tile per process: rank 0 writes the lines from every rank's part; same file as one engine's
+        del eng, single
+        import json
+        base = json.load(open(cfg))
+        d = os.path.dirname(cfg)
+        outs = {}
+        for kind in ("single", "tiled"):
+            c = dict(base, saveReplay=True, roadnetLogFile="w_rn_%s.json" % kind, replayLogFile="w_rp_%s.txt" % kind)
+            path = os.path.join(d, "w_cfg_%s.json" % kind)
+            if rank == 0:
+                json.dump(c, open(path, "w"))
+            dist.barrier()
+            if kind == "single":
+                if rank == 0:
+                    e = m.Engine._with_backend(path, 1, lib)
+                    for s in range(60):
+                        e.next_step()
+                    del e
+            else:
+                e = DistributedEngine(path, rows, cols, backend_library=lib, halo_group=halo, transport=transport)
+                for s in range(60):
+                    if s == 20:
+                        e.set_save_replay(False)
+                    if s == 21:
+                        e.set_save_replay(True)
+                    e.next_step()
+                del e
+            dist.barrier()
+        if rank == 0:
+            a, b = open(os.path.join(d, "w_rp_single.txt")).read().split("\n"), open(os.path.join(d, "w_rp_tiled.txt")).read().split("\n")
+            assert len(a) == 61 and len(b) == 60, (len(a), len(b))
+            assert a[:20] + a[21:] == b, "replay lines differ"
+            assert open(os.path.join(d, "w_rn_single.json")).read() == open(os.path.join(d, "w_rn_tiled.json")).read()
+            print("REPLAY_OK")
+        eng = single = None
     dist.barrier()
     if rank == 0:
-        print("TILED_OK", steps, single.get_vehicle_count(), "transport", eng.transport)
+        print("TILED_OK", steps, final_count, "transport", final_transport)
     dist.destroy_process_group()
 
 
