@@ -176,3 +176,41 @@ def test_leavers_that_are_not_a_prefix(mod, scen, workdir, layout):
         hip.next_step()
         tw.next_step()
         assert_same_state(hip, tw, "out-of-order archive (%s) step %d" % (layout, s + 1))
+
+
+def test_many_spawns_per_lane_in_one_step(mod, scen, workdir):
+    """The ring step links a step's spawn records inside kr_admit (they travel in its kernel arguments, sorted by lane): 60
+    flows that all start on the same three lanes put ~20 records on a lane in one step — chains inside the batch, heads where
+    the queue had drained, appends behind vehicles still waiting — and a second phase with more records than the arguments
+    hold takes the k_spawn_link path on the same queues.  Lane::pushWaitingVehicle roadnet.h:365-367, engine.cpp:502-516."""
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flows = json.load(open(os.path.join(d, "flow.json")))
+    proto = [f for f in flows if len(f["route"]) >= 3][:3]
+    out = []
+    for i in range(60):      # 60 records per step on 3 roads (9 lanes), every step
+        f = json.loads(json.dumps(proto[i % 3]))
+        f.update(interval=1.0, startTime=0, endTime=60)
+        out.append(f)
+    for i in range(200):     # later: 260 records per step (> kAdmitRecs) for a while, then back to few
+        f = json.loads(json.dumps(flows[i % len(flows)]))
+        f.update(interval=1.0, startTime=30, endTime=45)
+        out.append(f)
+    for i in range(20):
+        f = json.loads(json.dumps(flows[(7 * i) % len(flows)]))
+        f.update(interval=3.0, startTime=0, endTime=-1)
+        out.append(f)
+    flow_file = os.path.join(d, "flow_same_lanes.json")
+    with open(flow_file, "w") as fh:
+        json.dump(out, fh)
+    cfg = scen.materialize("grid_6x6", workdir, flow_file=flow_file)
+    for layout in ("ring", "dense"):
+        hip, tw = _pair(mod, cfg, layout=layout)
+        for s in range(220):
+            hip.next_step()
+            tw.next_step()
+            if s < 70 or s % 10 == 9:
+                assert_same_state(hip, tw, "same-lane spawns (%s) step %d" % (layout, s + 1))
+                assert np.array_equal(hip.get_lane_waiting_vehicle_count_array(), tw.get_lane_waiting_vehicle_count_array()), (layout, s)
+        assert hip._scalars()["spawned_vehicle_count"] > 6000
+        assert hip.get_average_travel_time() == tw.get_average_travel_time()
