@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the hot path (one `next_step()` of the MI355X-native CityFlow engine = one "step").
 
-Workload (N=1): BASELINE.json configs[2] — the reference generator's 30x30 grid (tests/golden/scenarios/
+Workload (N=1): BASELINE.json configs[2] — the reference generator's 30x30 grid (cityflow_amd/data/scenarios/
 grid_30x30, produced by /root/reference/tools/generator) with ~100k concurrently running vehicles.  The stock
 generator's demand never gets near 100k, so 3000 seeded interior-origin flows (one vehicle
 every 6 s each, for the first 240 s) are added on top of the 120 stock flows.  The workload is the network at

@@ -1,6 +1,6 @@
 """Scenario fixtures for tests and bench.py.
 
-The road networks / flows under tests/golden/scenarios/ were produced by the reference's own generator
+The road networks / flows under cityflow_amd/data/scenarios/ were produced by the reference's own generator
 and examples (tests/golden/make_scenarios.py); they are stored gzip-compressed and materialised into a
 work directory together with a config.json here.  Nothing in this module touches /root/reference.
 
@@ -16,8 +16,7 @@ import random
 import shutil
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCENARIO_DIR = os.path.join(ROOT, "tests", "golden", "scenarios")
+SCENARIO_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "scenarios")
 
 NAMES = ("example_1x1", "grid_6x6", "grid_30x30")
 

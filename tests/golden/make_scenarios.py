@@ -1,4 +1,4 @@
-"""Regenerates tests/golden/scenarios/* from the reference tree (only runnable where /root/reference exists).
+"""Regenerates cityflow_amd/data/scenarios/* from the reference tree (only runnable where /root/reference exists).
 
   example_1x1  : the reference's own examples/{roadnet,flow}.json (the only scenario its tests use)
   grid_6x6     : tools/generator/generate_grid_scenario.py 6 6 --tlPlan --interval 1.0   
@@ -16,7 +16,7 @@ import tempfile
 
 REF = os.environ.get("CITYFLOW_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "scenarios")
+OUT = os.path.join(os.path.dirname(os.path.dirname(HERE)), "cityflow_amd", "data", "scenarios")
 
 
 def pack(src, dst):

@@ -19,7 +19,7 @@ def _norm(net):
 
 def test_generator_reproduces_reference_fixtures(scen):
     for n in (6, 30):
-        d = os.path.join(GOLDEN, "scenarios", "grid_%dx%d" % (n, n))
+        d = os.path.join(scen.SCENARIO_DIR, "grid_%dx%d" % (n, n))
         with gzip.open(os.path.join(d, "roadnet.json.gz")) as f:
             fixture = _norm(json.load(f))
         assert fixture == _norm(scen.grid_roadnet(n, n)), "roadnet %dx%d" % (n, n)  # every float bit-identical
