@@ -587,6 +587,14 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("set_vehicle_route", &TiledEngineHost::setRoute, "vehicle_id"_a, "route"_a)
         .def("set_replay_file", &TiledEngineHost::setReplayLogFile, "replay_file"_a)
         .def("set_save_replay", &TiledEngineHost::setSaveReplay, "open"_a)
+        .def("_vehicles_keyed", &TiledEngineHost::vehiclesKeyed, "include_waiting"_a = false, "local (priority, id) pairs")
+        .def("_runs_here", &TiledEngineHost::runsHere, "vehicle_id"_a)
+        .def("_local_status", [](TiledEngineHost &e) { return toArray(e.localStatus()); })
+        .def("_average_travel_time_from",
+             [](TiledEngineHost &e, double cumulative, int64_t finished, py::array_t<uint8_t, py::array::c_style | py::array::forcecast> st) {
+                 return e.averageTravelTimeFrom(cumulative, finished, std::vector<uint8_t>(st.data(), st.data() + st.size()));
+             },
+             "cumulative"_a, "finished"_a, "status"_a)
         .def("_wants_replay", &TiledEngineHost::wantsReplay)
         .def("_replay_part", [](TiledEngineHost &e) { return py::bytes(e.replayPart()); })
         .def("_replay_write",

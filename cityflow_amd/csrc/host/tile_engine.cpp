@@ -996,7 +996,7 @@ int TiledEngineHost::statusOf(int vid) {
 }
 
 // getVehicles engine.cpp:619-626 — vehiclePool (priority) order
-std::vector<std::string> TiledEngineHost::getVehicles(bool includeWaiting) {
+std::vector<std::pair<int32_t, std::string>> TiledEngineHost::vehiclesKeyed(bool includeWaiting) {
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::vector<std::pair<int32_t, int32_t>> byPriority;
@@ -1007,9 +1007,33 @@ std::vector<std::string> TiledEngineHost::getVehicles(bool includeWaiting) {
         for (int32_t v : wv) byPriority.emplace_back(spawner_.vehicles[v].priority, v);
     }
     std::sort(byPriority.begin(), byPriority.end());
-    std::vector<std::string> ret;
-    for (auto &p : byPriority) ret.emplace_back(spawner_.vehicleId(p.second));
+    std::vector<std::pair<int32_t, std::string>> ret;
+    for (auto &p : byPriority) ret.emplace_back(p.first, spawner_.vehicleId(p.second));
     return ret;
+}
+
+std::vector<std::string> TiledEngineHost::getVehicles(bool includeWaiting) {
+    std::vector<std::string> ret;
+    for (auto &p : vehiclesKeyed(includeWaiting)) ret.push_back(std::move(p.second));
+    return ret;
+}
+
+bool TiledEngineHost::runsHere(const std::string &vehicleId) {
+    const int vid = spawner_.vidOfId(vehicleId);
+    if (vid < 0) return false;
+    VehicleSnapshot s;
+    snapshotVehicles(s);
+    for (int i = 0; i < s.count; ++i)
+        if (s.vid[i] == vid) return true;
+    return false;
+}
+
+std::vector<uint8_t> TiledEngineHost::localStatus() {
+    const int total = (int) spawner_.vehicles.size();
+    std::vector<uint8_t> st((size_t) total, 0);
+    if (total)
+        for (auto &t : tiles_) t->mergeStatus(0, total, st.data());
+    return st;
 }
 
 std::map<std::string, std::vector<std::string>> TiledEngineHost::getLaneVehicles() {
@@ -1082,13 +1106,13 @@ std::map<std::string, std::string> TiledEngineHost::getVehicleInfo(const std::st
 
 // getAverageTravelTime engine.cpp:682-691 (finished part summed per tile)
 double TiledEngineHost::getAverageTravelTime() {
-    cfx_scalars sc = scalars();
-    double tt = sc.cumulative_travel_time;
-    int64_t n = sc.finished_vehicle_count;
+    const cfx_scalars sc = scalars();
+    return averageTravelTimeFrom(sc.cumulative_travel_time, sc.finished_vehicle_count, localStatus());
+}
+
+double TiledEngineHost::averageTravelTimeFrom(double tt, int64_t n, const std::vector<uint8_t> &st) const {
     const int total = (int) spawner_.vehicles.size();
-    std::vector<uint8_t> st((size_t) std::max(total, 1), 0);
-    if (total)
-        for (auto &t : tiles_) t->mergeStatus(0, total, st.data());
+    if ((int) st.size() != total) throw std::runtime_error("tiling: vehicle status of a different vehicle table");
     std::vector<std::pair<int32_t, double>> live;
     for (int v = 0; v < total; ++v)
         if (st[v] != 2) live.emplace_back(spawner_.vehicles[v].priority, spawner_.vehicles[v].enterTime);

@@ -185,6 +185,11 @@ public:
     std::string getLeader(const std::string &vehicleId);
     std::map<std::string, std::string> getVehicleInfo(const std::string &vehicleId);
     double getAverageTravelTime();
+    // several processes: the pieces the caller reduces over the ranks (cityflow_amd/tiled.py: DistributedEngine)
+    std::vector<std::pair<int32_t, std::string>> vehiclesKeyed(bool includeWaiting);  // local {priority, id}
+    bool runsHere(const std::string &vehicleId);                                       // on a drivable one of the local tiles owns
+    std::vector<uint8_t> localStatus();                                                // per vehicle number, merged over the local tiles
+    double averageTravelTimeFrom(double cumulative, int64_t finished, const std::vector<uint8_t> &status) const;
     void pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads);
     void setVehicleSpeed(const std::string &id, double speed);
     void setRandomSeed(int seed) { spawner_.seed(seed); }

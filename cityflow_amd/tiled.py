@@ -272,6 +272,36 @@ class DistributedEngine:
             out.update(p)  # a lane belongs to exactly one tile
         return out
 
+    def get_vehicles(self, include_waiting=False):
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self._eng._vehicles_keyed(include_waiting), group=self._halo)
+        return [vid for _, vid in sorted(p for part in parts for p in part)]  # vehiclePool order = by priority (unique)
+
+    def get_vehicle_info(self, vehicle_id):
+        """Every rank makes the same call; the rank that runs the vehicle has the details."""
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self._eng.get_vehicle_info(vehicle_id), group=self._halo)
+        return max(parts, key=len)
+
+    def get_leader(self, vehicle_id):
+        mine = self._eng.get_leader(vehicle_id)  # raises on every rank alike if the vehicle is unknown or has finished
+        parts = [None] * self.world
+        dist.all_gather_object(parts, mine if self._eng._runs_here(vehicle_id) else None, group=self._halo)
+        found = [p for p in parts if p is not None]
+        return found[0] if found else ""
+
+    def get_average_travel_time(self):
+        s = self._eng._scalars()
+        tt = self._sum([s["cumulative_travel_time"]], torch.float64)
+        fin = self._sum([s["finished_vehicle_count"]], torch.int64)
+        st = torch.as_tensor(np.ascontiguousarray(self._eng._local_status()), dtype=torch.uint8).to(self._device)
+        if st.numel():
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        return self._eng._average_travel_time_from(float(tt[0]), int(fin[0]), st.cpu().numpy())
+
+    def set_random_seed(self, seed):
+        self._eng.set_random_seed(seed)  # every rank alike: the spawners stay identical
+
     def push_vehicle(self, info, roads):
         self._eng.push_vehicle(info, roads)  # every rank makes the same call (the spawners stay identical)
 

@@ -90,6 +90,18 @@ def main():
                 assert np.array_equal(eng.get_lane_vehicle_count_array(), later[s]), (rank, s)
             assert np.array_equal(eng.get_lane_vehicle_count_array(), single.get_lane_vehicle_count_array()), (rank, s)
         assert eng.get_vehicle_distance() == single.get_vehicle_distance()
+        # the rest of the reference's query API over ranks
+        assert eng.get_vehicles() == single.get_vehicles() and eng.get_vehicles(True) == single.get_vehicles(True)
+        assert eng.get_average_travel_time() == single.get_average_travel_time()
+        some = single.get_vehicles(True)
+        for v in some[:25] + some[-25:]:
+            assert eng.get_vehicle_info(v) == single.get_vehicle_info(v), (rank, v)
+            assert eng.get_leader(v) == single.get_leader(v), (rank, v)
+        try:
+            eng.get_leader("flow_999_0")
+            raise AssertionError("unknown vehicle accepted")
+        except RuntimeError:
+            pass
         sa, sb = single._scalars(), eng.scalars()
         for k in ("active_vehicle_count", "finished_vehicle_count", "cumulative_travel_time"):
             assert sa[k] == sb[k], (rank, k, sa[k], sb[k])
