@@ -1347,6 +1347,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->live_enter_time_sum = 0.0;  // not maintained on the device path
     out->vehicle_steps = s.vehicleSteps;
     out->tie_events = s.tieEvents;
+    for (int i = 0; i < 8; ++i) out->tie_drivables[i] = s.tieEvents > i ? s.tieDrv[i] : -1;
     return CFX_OK;
 }
 
@@ -2297,6 +2298,24 @@ int32_t cfx_trace_dump(const char *path, int32_t blocks) {
     return 0;
 }
 #endif
+
+__global__ void k_device_spin(long long ticks, double *sink) {  // wall_clock64: 100 MHz on gfx950
+    const long long t0 = (long long) wall_clock64();
+    double x = 1.0 + threadIdx.x * 1e-9;
+    while ((long long) wall_clock64() - t0 < ticks)
+        for (int i = 0; i < 64; ++i) x = x * 1.0000001 + 1e-12;
+    if (x == 0.12345) *sink = x;
+}
+
+int32_t cfx_device_spin(cfx_engine *e, int64_t microseconds) {
+    if (!e || microseconds < 0) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    if (microseconds > 2000000) microseconds = 2000000;
+    hipLaunchKernelGGL(k_device_spin, dim3(1024), dim3(256), 0, e->stream, (long long) microseconds * 100LL, (double *) e->sc);
+    HIP_TRY(hipGetLastError());
+    return CFX_OK;
+}
 
 int32_t cfx_profile_kernel_count(void) { return kNumProfKernels; }
 const char *cfx_profile_kernel_name(int32_t k) { return (k >= 0 && k < kNumProfKernels) ? kProfNames[k] : ""; }

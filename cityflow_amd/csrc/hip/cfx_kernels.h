@@ -55,6 +55,7 @@ struct DevScalars {
     int ringNearFull;          // ring layout: some drivable's ring is within 8 vehicles of its capacity (sticky)
     int actionMaxT;            // ring layout: most vehicles one block of the action kernel had (blocks above 3/4 of a pass report)
     long long tieEvents;       // cfx_scalars::tie_events
+    int tieDrv[8];             // cfx_scalars::tie_drivables (event i at index i % 8)
 };
 
 struct HostMirror {  // pinned host copy of the end-of-step scalars (written by k_scatter's statistics block)
@@ -1413,7 +1414,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
                 double od = b.dis[j];
                 const bool tieBefore = od == ndis && c.s.vid[j] < vid;
                 rank += (od > ndis) || tieBefore;
-                if (tieBefore) atomicAdd((unsigned long long *) &sc->tieEvents, 1ULL);
+                if (tieBefore) sc->tieDrv[atomicAdd((unsigned long long *) &sc->tieEvents, 1ULL) & 7ULL] = nd;
             }
             ns = tStartNext + (cntNow(c, nd) - tLeave) + rank;
         }

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
                 const double od = k.movers[f].dis;
                 const bool tieBefore = od == r.dis && k.movers[f].vid < r.vid;
                 rank += (od > r.dis) || tieBefore;
-                if (tieBefore) atomicAdd((unsigned long long *) &k.sc->tieEvents, 1ULL);
+                if (tieBefore) k.sc->tieDrv[atomicAdd((unsigned long long *) &k.sc->tieEvents, 1ULL) & 7ULL] = d;
             }
             ++m;
             if (n + rank > geo.y) {  // the ring is full: refuse (reported as an error by the next cfx_step / getter)

@@ -74,6 +74,7 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)
     CFX_FN(cfx_profile_read)
+    CFX_FN(cfx_device_spin)
 #undef CFX_FN
     if (cfx_abi_version() != CFX_ABI_VERSION)
         throw std::runtime_error("cityflow_amd: ABI version mismatch in '" + libPath + "'");

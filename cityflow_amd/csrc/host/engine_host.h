@@ -65,6 +65,7 @@ struct Backend {
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)
     CFX_FN(cfx_profile_read)
+    CFX_FN(cfx_device_spin)
 #undef CFX_FN
     void open(const std::string &libPath);  // throws std::runtime_error
     ~Backend();
@@ -135,6 +136,7 @@ public:
     cfx_scalars scalars();
     void sync();
     void profileEnable(bool on);
+    void deviceSpin(long long microseconds) { check(be_.cfx_device_spin(dev_, microseconds), "cfx_device_spin"); }
     std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
 
     std::shared_ptr<void> bindingCache;  // opaque per-engine cache owned by the language binding (lane id key objects)

@@ -423,11 +423,16 @@ PYBIND11_MODULE(_cityflow, m) {
                  d["live_enter_time_sum"] = s.live_enter_time_sum;
                  d["vehicle_steps"] = s.vehicle_steps;
                  d["tie_events"] = s.tie_events;
+                 py::list td;
+                 for (int i = 0; i < 8; ++i)
+                     if (s.tie_drivables[i] >= 0) td.append(s.tie_drivables[i]);
+                 d["tie_drivables"] = td;
                  return d;
              })
         .def("_layout", &EngineHost::layoutName)
         .def("_ring_info", &EngineHost::ringInfo, "(total ring slots, capacity scale) of the ring layout")
         .def("_profile_enable", &EngineHost::profileEnable, "on"_a)
+        .def("_device_spin", &EngineHost::deviceSpin, "microseconds"_a)
         .def("_profile_read", &EngineHost::profileRead)
         .def("_vehicle_id", [](EngineHost &e, int vid) { return e.vehicleId(vid); }, "vid"_a)
         .def("_vehicle_ids",
@@ -617,6 +622,9 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("_host_seconds", &TiledEngineHost::hostSeconds,
              "(spawner, submit) cumulative host wall seconds of this process since the last reset")
         .def("_profile_enable", &TiledEngineHost::profileEnable, "local_tile"_a, "on"_a)
+        .def("_device_spin", &TiledEngineHost::deviceSpin, "microseconds"_a)
+        .def("backend_name", &TiledEngineHost::backendName)
+        .def("_layout", &TiledEngineHost::layoutName)
         .def("_profile_read", &TiledEngineHost::profileRead, "local_tile"_a)
         .def("_vehicle_state",
              [](TiledEngineHost &e) {

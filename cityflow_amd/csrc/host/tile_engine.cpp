@@ -901,6 +901,7 @@ std::map<std::string, int> TiledEngineHost::getLaneWaitingVehicleCount() {
 
 cfx_scalars TiledEngineHost::scalars() {
     cfx_scalars sum{};
+    for (int &d : sum.tie_drivables) d = -1;  // (tile-local indices: not reported)
     for (auto &t : tiles_) {
         cfx_scalars s = t->scalars();
         sum.active_vehicle_count += s.active_vehicle_count;

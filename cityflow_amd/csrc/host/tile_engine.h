@@ -91,6 +91,11 @@ public:
     void reset();
     void sync();
     void profileEnable(bool on);
+    void deviceSpin(long long microseconds) { check(be_->cfx_device_spin(dev_, microseconds), "cfx_device_spin"); }
+    std::string layoutName() {
+        const int l = be_->cfx_get_layout(dev_);
+        return l == CFX_LAYOUT_RING ? "ring" : (l == CFX_LAYOUT_DENSE ? "dense" : "n/a");
+    }
     std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
 
     void addLaneCounts(std::vector<int32_t> &global, bool waiting);  // writes the lanes this tile owns
@@ -216,6 +221,9 @@ public:
     // launches; includes back-pressure waits when the device is the bottleneck)}
     std::pair<double, double> hostSeconds() const { return std::make_pair(hostSpawnSec_, hostSubmitSec_); }
     void profileEnable(int localTile, bool on) { tiles_.at(localTile)->profileEnable(on); }
+    void deviceSpin(long long microseconds) { for (auto &t : tiles_) t->deviceSpin(microseconds); }
+    std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
+    std::string layoutName() { return tiles_.empty() ? "n/a" : tiles_.front()->layoutName(); }
     std::map<std::string, std::pair<double, int64_t>> profileRead(int localTile) { return tiles_.at(localTile)->profileRead(); }
     std::vector<int> owner() const { return owner_; }
     std::vector<std::string> laneIds() const;

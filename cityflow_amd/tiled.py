@@ -111,25 +111,42 @@ class DistributedEngine:
         return job[0]
 
     def _setup(self, transport):
+        # Every rank runs the same sequence of collectives whatever happens locally: a local failure becomes ok = False
+        # and is agreed on afterwards (a rank that raised between two collectives would leave the others waiting).
+        def local(fn, *a):
+            try:
+                r = fn(*a)
+                return True if r is None else bool(r)
+            except Exception as exc:  # noqa: BLE001
+                self._setup_error = str(exc)[:160]
+                return False
+
         if transport == "device":
             job = self._job_name()
-            ok = self._eng.device_mailbox_phase(job, 1)
+            ok = local(self._eng.device_mailbox_phase, job, 1)
             if not self._all_ok(ok):  # nobody has attached anything yet: the next transport can still be tried
-                self._eng.unlink_mailboxes()
+                local(self._eng.unlink_mailboxes)
                 return False
-            ok = self._eng.device_mailbox_phase(job, 2)
+            ok = local(self._eng.device_mailbox_phase, job, 2)
             dist.barrier(group=self._halo)
-            self._eng.unlink_mailboxes()
+            local(self._eng.unlink_mailboxes)
             return ok
         if transport == "host":
-            self._eng.enable_mailboxes(self._job_name())
+            job = self._job_name()
+            ok = local(self._eng.enable_mailboxes, job)
             dist.barrier(group=self._halo)   # every process has mapped its mailboxes ...
-            self._eng.unlink_mailboxes()     # ... so the names can go
-            return True
+            local(self._eng.unlink_mailboxes)  # ... so the names can go
+            return ok
         if transport == "rccl":
             if dist.get_backend() != "nccl" and self._device.type != "cpu":
                 raise RuntimeError("the rccl transport needs the nccl (RCCL) process group")
             # (a CPU engine's "device" buffers are host memory and the default group is gloo: same code path, for tests)
+            if self._device.type != "cpu":
+                # the tensors below are labelled with torch's current device: it must be the one the engine's buffers are on
+                want = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+                if torch.cuda.current_device() != want:
+                    raise RuntimeError("the rccl transport needs torch.cuda.set_device(LOCAL_RANK %% device_count) before the "
+                                       "engine is built (current device %d, engine on %d)" % (torch.cuda.current_device(), want))
             sp, sn, rp, rn = self._eng.halo_device_buffers(0)
             self._dsend = _device_bytes(sp, sn, self._device)
             self._drecv = _device_bytes(rp, rn, self._device)
@@ -163,7 +180,8 @@ class DistributedEngine:
 
     def next_step(self):
         self._step()
-        self._replay()
+        if self.world > 1:  # (one process running every tile writes its replay line itself, TiledEngineHost::stepEnd)
+            self._replay()
 
     def _step(self):
         if self.transport == "rccl":
@@ -215,11 +233,11 @@ class DistributedEngine:
 
     def scalars(self):
         s = self._eng._scalars()
-        ints = self._sum([s["active_vehicle_count"], s["finished_vehicle_count"], s["vehicle_steps"]], torch.int64)
+        ints = self._sum([s["active_vehicle_count"], s["finished_vehicle_count"], s["vehicle_steps"], s["tie_events"]], torch.int64)
         tt = self._sum([s["cumulative_travel_time"]], torch.float64)
         return {"step": s["step"], "spawned_vehicle_count": s["spawned_vehicle_count"],
                 "active_vehicle_count": int(ints[0]), "finished_vehicle_count": int(ints[1]),
-                "vehicle_steps": int(ints[2]), "cumulative_travel_time": float(tt[0])}
+                "vehicle_steps": int(ints[2]), "tie_events": int(ints[3]), "cumulative_travel_time": float(tt[0])}
 
     def local_scalars(self):
         return self._eng._scalars()

@@ -149,6 +149,10 @@ typedef struct cfx_scalars {
      * the reference's own order of such a pair depends on heap addresses and thread timing; this ABI breaks the tie by
      * vehicle number.  A comparison with the reference is well defined only while this counter stands still. */
     int64_t tie_events;
+    /* the drivables (index space above) that received the most recent tie events: event number i (counting from 0 since
+     * the last reset / load) is kept at index i % 8; -1 = none yet, or not known (a tiled engine does not report them).
+     * A checker uses them to see WHERE two correct engines may differ from then on. */
+    int32_t tie_drivables[8];
 } cfx_scalars;
 
 /* Full per-vehicle state of every running vehicle, caller-allocated SoA (any pointer may be NULL).
@@ -383,6 +387,10 @@ int32_t cfx_profile_kernel_count(void);
 const char *cfx_profile_kernel_name(int32_t k);
 int32_t cfx_profile_enable(cfx_engine *e, int32_t on);
 int32_t cfx_profile_read(cfx_engine *e, double *total_ms, int64_t *launches);
+/* Measurement aid: keeps the device busy with plain arithmetic for about `microseconds` on the engine's stream (returns at
+ * once; the engine's next kernels queue behind it).  A benchmark calls it right before its warm-up steps so that a short
+ * timed region is not measured on clocks that are still ramping up after host-only work.  Touches no engine state. */
+int32_t cfx_device_spin(cfx_engine *e, int64_t microseconds);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,7 @@ struct cfx_engine {
     std::vector<int32_t> curPhase;               // TrafficLight::curPhaseIndex
     std::vector<double> remain;                  // TrafficLight::remainDuration
     int64_t step = 0, active = 0, finishedCnt = 0, vehicleSteps = 0, tieEvents = 0;
+    int32_t tieDrv[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // cfx_scalars::tie_drivables
     double cumulativeTravelTime = 0;
     std::string err;
     // lane change: per lane the Segments (roadnet.h:198-236), each a list of vehicles front to back; the priorities the
@@ -956,7 +957,7 @@ struct cfx_engine {
                          [this](int32_t a, int32_t b) { return veh[a].bDis > veh[b].bDis; });
         for (size_t i = 0; i < pushBuffer.size(); ++i)  // cfx_scalars::tie_events: equal distance into the same drivable
             for (size_t j = i + 1; j < pushBuffer.size() && veh[pushBuffer[j]].bDis == veh[pushBuffer[i]].bDis; ++j)
-                tieEvents += veh[pushBuffer[j]].bDrv == veh[pushBuffer[i]].bDrv;
+                if (veh[pushBuffer[j]].bDrv == veh[pushBuffer[i]].bDrv) tieDrv[tieEvents++ & 7] = veh[pushBuffer[i]].bDrv;
         if (tiled) inCntStep.assign(order.size(), 0);
         for (int32_t vid : pushBuffer) {
             Veh &v = veh[vid];
@@ -1193,6 +1194,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->live_enter_time_sum = s;
     out->vehicle_steps = e->vehicleSteps;
     out->tie_events = e->tieEvents;
+    for (int i = 0; i < 8; ++i) out->tie_drivables[i] = e->tieEvents > i ? e->tieDrv[i] : -1;
     return CFX_OK;
 }
 
@@ -1511,5 +1513,6 @@ int32_t cfx_profile_kernel_count(void) { return 0; }
 const char *cfx_profile_kernel_name(int32_t) { return ""; }
 int32_t cfx_profile_enable(cfx_engine *, int32_t) { return CFX_OK; }
 int32_t cfx_profile_read(cfx_engine *, double *, int64_t *) { return CFX_OK; }
+int32_t cfx_device_spin(cfx_engine *, int64_t) { return CFX_OK; }
 
 }  // extern "C"
