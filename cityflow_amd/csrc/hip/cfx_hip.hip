@@ -16,6 +16,7 @@
 #include "cfx_kernels.h"
 #include "cfx_lc_kernels.h"
 #include "cfx_ring_kernels.h"
+#include "cfx_ring2_kernels.h"
 #include "cfx_dense_kernels.h"
 
 using namespace cfxd;
@@ -192,6 +193,11 @@ struct cfx_engine {
     RingJob *rJobRecs = nullptr;
     LLAux *rLLAux = nullptr;
     int4 *rLLGate = nullptr;
+    // second form of the ring step (cfx_ring2_kernels.h)
+    LLSrc *rLLSrc = nullptr;                  // [K]
+    unsigned long long *rInterGreen = nullptr;  // [I]
+    unsigned long long *rLLOcc = nullptr;       // [mask words]
+    bool ringV2 = false;                      // cfx_config::ring_lanes_per_wave / 10000 == 3 selects it (developer knob)
     RingDense rd{};                    // dense staging view (getters, archive, growth)
     size_t rdCap = 0;
     int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
@@ -472,6 +478,10 @@ struct cfx_engine {
         c.interMask = interMask;
         c.llGate = rLLGate;
         c.llAux = rLLAux;
+        c.llSrc = rLLSrc;
+        c.interGreen = rInterGreen;
+        c.llOcc = rLLOcc;
+        c.sparseNow = ringV2 ? 1 : 0;
         c.laneTail = laneTail;
         c.admitRec = admitRec;
         c.step = (int32_t) step;
@@ -535,6 +545,9 @@ struct cfx_engine {
             if ((rc = allocRaw(&rTailNow, (size_t) D))) return rc;
             if ((rc = allocRaw(&rLLAux, (size_t) K))) return rc;
             if ((rc = allocRaw(&rLLGate, (size_t) K))) return rc;
+            if ((rc = allocRaw(&rLLSrc, (size_t) std::max(K, 1)))) return rc;
+            if ((rc = allocRaw(&rInterGreen, (size_t) std::max(I, 1)))) return rc;
+            if ((rc = allocRaw(&rLLOcc, (size_t) std::max(nMaskWords, 1)))) return rc;
             rFinCap = std::max(1 << 16, L * 8);
             if ((rc = allocRaw(&rFinKey, (size_t) rFinCap))) return rc;
             if ((rc = allocRaw(&rFinVid, (size_t) rFinCap))) return rc;
@@ -572,6 +585,15 @@ struct cfx_engine {
         *totalOut = total;
         return CFX_OK;
     }
+    // Records that are valid "for the step in their tag" must not survive a change of the step counter (reset, load) or of
+    // the slots they name (rebuilt rings); the occupancy bits are rebuilt by kr_scatter_in.
+    int ringClearStepTags() {
+        HIP_TRY(hipMemsetAsync(rTailNow, 0xFF, (size_t) D * sizeof(TailRec), stream));
+        HIP_TRY(hipMemsetAsync(rLLSrc, 0xFF, (size_t) std::max(K, 1) * sizeof(LLSrc), stream));
+        HIP_TRY(hipMemsetAsync(rLLOcc, 0, (size_t) std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(interMask, 0, (size_t) std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
+        return CFX_OK;
+    }
     // (Re)build the rings: first use, a shorter vehicle template than the capacities were computed for, or growth.
     bool ringGrowRequested = false;
     int ringEnsure() {
@@ -595,6 +617,7 @@ struct cfx_engine {
         hipLaunchKernelGGL(kr_reset, dim3(gridFor(D)), dim3(kBlock), 0, stream, D, rHead, rCnt, rScratch);
         HIP_TRY(hipMemsetAsync(rTail[0], 0xFF, (size_t) D * sizeof(TailRec), stream));  // slot -1: empty
         HIP_TRY(hipMemsetAsync(rTail[1], 0xFF, (size_t) D * sizeof(TailRec), stream));
+        if ((rc = ringClearStepTags())) return rc;
         if (total) {
             hipLaunchKernelGGL(kr_scatter_in, dim3(gridFor(D)), dim3(kBlock), 0, stream, rctx(), (const int32_t *) rOff, rd, vt);
             const int zero = 0;
@@ -654,6 +677,10 @@ struct cfx_engine {
             hipLaunchKernelGGL(kr_reset, dim3(gridFor(D)), dim3(kBlock), 0, stream, D, rHead, rCnt, rScratch);
             HIP_TRY(hipMemsetAsync(rTail[0], 0xFF, (size_t) D * sizeof(TailRec), stream));
             HIP_TRY(hipMemsetAsync(rTail[1], 0xFF, (size_t) D * sizeof(TailRec), stream));
+            {
+                const int rcClear = ringClearStepTags();
+                if (rcClear) return rcClear;
+            }
             // blocker records carry step numbers, which start over
             HIP_TRY(hipMemsetAsync(rBlk[0], 0xFF, ringSlots * sizeof(int2), stream));
             HIP_TRY(hipMemsetAsync(rBlk[1], 0xFF, ringSlots * sizeof(int2), stream));
@@ -727,6 +754,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     // ~150 k running vehicles (30x30: 56 vs 61 us / step) and behind once that state no longer sits in the caches
     // (60x60: 112 vs 101, 100x100: 227 vs 191).  Lanes are the proxy for size known at creation.
     e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change && n->n_lanes <= 20000);
+    e->ringV2 = cfg->ring_lanes_per_wave / 10000 == 3;
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
     e->timesDyadic = cfx_engine::dyadic(cfg->interval);
     e->R = n->n_roads;
@@ -808,7 +836,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         for (int x = 0; x < e->E; ++x) {
             int pe = n->x_peer[x], pll = n->x_ll[pe];
             xdd[x] = make_double2(n->x_dist[x], n->x_dist[pe]);
-            xpack[x] = make_int4(pll, llLocal[pll], n->ll_type[pll], 0);
+            xpack[x] = make_int4(pll, llLocal[pll], n->ll_type[pll], n->ll_roadlink[pll]);
         }
         if ((rc = e->uploadConst(d.drvLM, lm.data(), lm.size()))) return rc;
         if ((rc = e->uploadConst(d.xDD, xdd.data(), xdd.size()))) return rc;
@@ -817,14 +845,52 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         for (int k = 0; k < e->K; ++k)
             llpack[k] = make_int4(n->ll_x_start[k], n->ll_x_start[k + 1], maskStart[n->ll_inter[k]], n->ll_type[k]);
         if ((rc = e->uploadConst(d.llPack, llpack.data(), llpack.size()))) return rc;
-        std::vector<int4> ll4((size_t) e->L);
+        std::vector<int4> ll4((size_t) e->L), le4((size_t) e->L);
         for (int l = 0; l < e->L; ++l) {
             const int b = n->lane_ll_start[l], cnt = n->lane_ll_start[l + 1] - b;
-            int v[4] = {-1, -1, -1, -1};
-            for (int q = 0; q < cnt && q < 4; ++q) v[q] = n->lane_ll[b + q];
+            int v[4] = {-1, -1, -1, -1}, en[4] = {-1, -1, -1, -1};
+            for (int q = 0; q < cnt && q < 4; ++q) {
+                v[q] = n->lane_ll[b + q];
+                en[q] = n->ll_end_lane[v[q]];
+            }
             ll4[l] = cnt > 4 ? make_int4(-2, -2, -2, -2) : make_int4(v[0], v[1], v[2], v[3]);
+            le4[l] = cnt > 4 ? make_int4(-1, -1, -1, -1) : make_int4(en[0], en[1], en[2], en[3]);
         }
         if ((rc = e->uploadConst(d.laneLL4, ll4.data(), ll4.size()))) return rc;
+        if ((rc = e->uploadConst(d.laneEnd4, le4.data(), le4.size()))) return rc;
+        {   // static tables of the second form of the ring step (cfx_ring2_kernels.h)
+            std::vector<int4> info((size_t) e->L), inter4((size_t) e->L), peer((size_t) e->K);
+            std::vector<double> rest((size_t) e->E);
+            for (int l = 0; l < e->L; ++l) {
+                const int b = n->lane_ll_start[l], cnt = n->lane_ll_start[l + 1] - b;
+                int v[4] = {-1, -1, -1, -1};
+                for (int q = 0; q < cnt && q < 4; ++q) {
+                    const int k = n->lane_ll[b + q];
+                    v[q] = n->ll_roadlink[k] | (n->ll_type[k] << 16) | ((n->ll_x_start[k + 1] > n->ll_x_start[k] ? 1 : 0) << 18);
+                }
+                info[l] = cnt > 4 ? make_int4(-1, -1, -1, -1) : make_int4(v[0], v[1], v[2], v[3]);
+                const int in = cnt > 0 ? n->ll_inter[n->lane_ll[b]] : -1;
+                inter4[l] = in < 0 ? make_int4(-1, 0, 0, 0)
+                                   : make_int4(in, maskStart[in], maskStart[in + 1] - maskStart[in], n->inter_n_roadlinks[in]);
+            }
+            for (int k = 0; k < e->K; ++k) {
+                unsigned long long m = 0;
+                for (int x = n->ll_x_start[k]; x < n->ll_x_start[k + 1]; ++x) {
+                    const int bit = llLocal[n->x_ll[n->x_peer[x]]];
+                    if (bit < 64) m |= 1ULL << bit;
+                }
+                if (nLL[n->ll_inter[k]] > 64) m = ~0ULL;  // (more laneLinks than one word holds: no filtering at this intersection)
+                peer[k] = make_int4((int) (unsigned) (m & 0xFFFFFFFFULL), (int) (unsigned) (m >> 32), n->ll_x_start[k], n->ll_x_start[k + 1]);
+            }
+            for (int x = 0; x < e->E; ++x) {
+                const int pe = n->x_peer[x];
+                rest[x] = n->drv_length[e->L + n->x_ll[pe]] - n->x_dist[pe];
+            }
+            if ((rc = e->uploadConst(d.laneInfo4, info.data(), info.size()))) return rc;
+            if ((rc = e->uploadConst(d.laneInter4, inter4.data(), inter4.size()))) return rc;
+            if ((rc = e->uploadConst(d.llPeer, peer.data(), peer.size()))) return rc;
+            if ((rc = e->uploadConst(d.xPeerRest, rest.data(), rest.size()))) return rc;
+        }
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
@@ -1041,9 +1107,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // running vehicles as of the last step the device has completed (stale by the few steps the host runs ahead):
         // only sizes the cross phase's grid and picks its organisation
         const size_t activeEst = (size_t) (pr & 0xFFFFFFFFu) + (size_t) e->nQueueLanes * 4;
-        e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
+        const bool v2 = e->ringV2;  // the second form of the step (cfx_ring2_kernels.h)
+        if (v2) e->launch(PK_ADMIT, kr2_admit, dim3(gridFor(std::max(e->L, e->I))), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
+        else e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
         RING_CHECK("kr_admit")
-        const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;  // which form of the cross phase (§4)
+        const bool useBig = !v2 && (e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000);  // which form of the cross phase (§4)
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
         RingOut ro{c.kinN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
@@ -1051,14 +1119,18 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // One workgroup = B threads over G lanes (or B laneLinks).  G is picked so that a block's vehicles fit one pass
             // (B - 1) with room for uneven lanes; small networks take small blocks (every block resident at once, the step
             // is bound by the slowest block's chain), large ones full blocks (throughput).
-            // cfx_config::ring_lanes_per_wave = G + 1000 * (B / 256) overrides both (developer knob; B = 256 or 512).
+            // cfx_config::ring_lanes_per_wave = G + 1000 * (B / 256) overrides both (developer knob; B = 256 or 512);
+            // + 10000 forces the wave form of the action kernel (kw_action; the default above 240 k vehicles), + 20000 the
+            // block form (kr_action; the default below), + 30000 the second form of the whole step (cfx_ring2_kernels.h).
             int G = e->ringG, Bsel = 256;
-            const int want = e->cfg.ring_lanes_per_wave;
+            const int form = e->cfg.ring_lanes_per_wave / 10000;
+            const bool blockForm = form == 2 || (form == 0 && !(useBig || activeEst > 240000));
+            const int want = e->cfg.ring_lanes_per_wave % 10000;
             if (want > 0) {
                 G = std::max(1, want % 1000);
                 Bsel = want >= 2000 ? 512 : 256;
-            } else if (useBig) {
-                G = 28;  // many rounds of blocks anyway: full blocks, a second pass where the lanes are dense (throughput)
+            } else if (useBig || activeEst > 240000) {
+                G = 28;  // many rounds of blocks anyway: full blocks, a second chunk where the lanes are dense (throughput)
             } else if (e->mirrorValid) {
                 // adapt to the traffic: the densest block of a recent step (pinned mirror, possibly a few steps old) should
                 // fit one pass with some room; results do not depend on G
@@ -1081,12 +1153,20 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             }
             G = std::min(G, Bsel);
             const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;
-            const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(Bsel);
-            if (Bsel == 256) e->launch(PK_ACTION, kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-            else e->launch(PK_ACTION, kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+            const dim3 grid(nLaneBlocks + (v2 ? 1 : 2) * nLLBlocks), block(Bsel);
+            if (v2) {
+                if (Bsel == 256) e->launch(PK_ACTION, kw2_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks);
+                else e->launch(PK_ACTION, kw2_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks);
+            } else if (blockForm) {
+                if (Bsel == 256) e->launch(PK_ACTION, kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                else e->launch(PK_ACTION, kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+            } else {
+                if (Bsel == 256) e->launch(PK_ACTION, kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                else e->launch(PK_ACTION, kw_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+            }
         }
         RING_CHECK("kr_action")
-        if (dbg) {
+        if (dbg && !v2) {
             HIP_TRY(hipMemsetAsync(e->laneOut, 0, 8 * sizeof(int32_t), st));
             hipLaunchKernelGGL(kr_validate, dim3(gridFor(std::max(e->D, 16))), dim3(kBlock), 0, st, c, jq, (int) e->spawned,
                                (int) e->hRouteStart.size() - 1, (int) e->ringSlots, e->laneOut);
@@ -1099,7 +1179,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 return e->fail(buf);
             }
         }
-        if (useBig)
+        if (v2)
+            e->launch(PK_CROSS, kr2_cross,
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
+                      dim3(kCrossBlock), c, ro, jq, (const RingJob *) e->rJobRecs);
+        else if (useBig)
             e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
                       dim3(kCross2Block), c, ro, jq);
@@ -1986,6 +2070,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     }
     if (e->ring) {  // (needs the vehicle table and e->step: the blockers' validity tag is "set in the previous step")
         if (e->spawned) HIP_TRY(hipMemsetAsync(e->slotOf, 0xFF, (size_t) e->spawned * sizeof(int32_t), e->stream));
+        if ((rc = e->ringClearStepTags())) return rc;
         hipLaunchKernelGGL(kr_scatter_in, dim3(gridFor(D)), dim3(kBlock), 0, e->stream, e->rctx(), (const int32_t *) e->rOff, e->rd, e->vt);
     } else
     // cached next drivable of every slot (uses the device copies of the route tables)

@@ -581,6 +581,7 @@ struct SlotIn {  // everything the action phase loads by slot index alone
     double2 lm;      // {length, max speed} of the drivable
     int4 hop;        // the laneLinks leaving the vehicle's lane if the loader holds them (x = -2: not), see findHeadLeader
     bool laneAdmitted;  // ring layout: the vehicle's lane admitted a vehicle this step
+    int endLane;        // the lane behind the vehicle's next laneLink if the loader knows it (-1: read it from the gate record)
 };
 
 // Every load that depends only on the slot index is issued up front, before the first branch, so the memory
@@ -606,12 +607,14 @@ __device__ __forceinline__ SlotIn loadSlot(const StepCtx &c, int s) {
     in.lm = c.n.drvLM[in.d >= 0 ? in.d : 0];  // (an empty spare slot carries drivable -1)
     in.hop = make_int4(-2, -2, -2, -2);
     in.laneAdmitted = false;
+    in.endLane = -1;
     return in;
 }
 
 struct JobInfo {  // what the action phase knows about a vehicle it hands to the cross phase (the ring layout passes it on)
     int d, idx, nNow, templ, nd0, laneLink, gateFlags, xs, xe;
     double speed, dis, dlen, v, iv;
+    int maskBase;  // second form of the ring step: first mask word of the laneLink's intersection
 };
 // the gate record of a laneLink: {light | type | has crosses, end lane} (dense) + {first, end cross entry} (ring)
 __device__ __forceinline__ int gateXs(const int2 &) { return 0; }

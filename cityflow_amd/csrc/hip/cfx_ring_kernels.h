@@ -62,9 +62,27 @@ struct RingCtx {
     int4 *llGate;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
     int32_t *laneTail;
     int2 *admitRec;
+    // second form of the step (cfx_ring2_kernels.h)
+    struct LLSrc *llSrc;              // [K] notify sources written by the lanes' admission threads (tagged with the step)
+    unsigned long long *interGreen;   // [I] roadLinks that are available in the intersection's current phase (bit = roadLink index)
+    unsigned long long *llOcc;        // [mask words] laneLinks with vehicles ON them (kept up by kr_commit; interMask holds the
+                                      //              laneLinks that have a source on an adjoining lane this step)
+    int sparseNow;                    // tailNow holds records of THIS step's admissions only (tag == step), see tailNowOf
     int32_t step;
     double interval;
 };
+
+// The notify sources of one laneLink beside the vehicles on it (Engine::threadNotifyCross engine.cpp:331-342, 362-363): u = the
+// vehicle that has just left it onto its end lane (that lane's tail), f = the first vehicle of its start lane if it heads
+// here (whether the light lets it is the reader's test).  Each half is written by the thread of the lane the vehicle is on
+// and is valid for the step in its tag; `blk` = the vehicle's blocker (a vehicle number) if it was set in the last step.
+struct LLSrc {
+    int32_t uSlot, uTempl, uTag, uBlk;
+    double uDis, uSpeed;
+    int32_t fSlot, fTempl, fTag, fBlk;
+    double fRest, fSpeed;  // fRest = length of the start lane - the vehicle's distance
+};
+static_assert(sizeof(LLSrc) == 64, "laneLink source record layout");
 
 __device__ __forceinline__ int ringSlot(const int2 geo, int head, int i) { return geo.x + ((head + i) & geo.y); }
 
@@ -89,7 +107,13 @@ __device__ __forceinline__ Tail tailCommitted(const RingCtx &c, int d) {  // Dri
     return t;
 }
 __device__ __forceinline__ Tail tailNowOf(const RingCtx &c, int d) {
-    return c.betweenSteps ? tailCommitted(c, d) : tailOfRec(c.tailNow[d]);
+    if (c.betweenSteps) return tailCommitted(c, d);
+    if (!c.sparseNow) return tailOfRec(c.tailNow[d]);
+    if (d < c.n.L) {  // (second form of the step: only a lane that admitted a vehicle this step has a record of this step)
+        const TailRec r = c.tailNow[d];
+        if (r.tag == c.step) return tailOfRec(r);
+    }
+    return tailCommitted(c, d);
 }
 __device__ __forceinline__ Tail tailForLeader(const RingCtx &c, int d, bool viewerNew, int viewerLane) {
     return (viewerNew && d < viewerLane && d < c.n.L) ? tailNowOf(c, d) : tailCommitted(c, d);
@@ -659,6 +683,16 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
     int4 gate = make_int4(0, 0, 0, 0);
     const int gateLink = onLane ? nd0 - L : d - L;
     if (related) gate = gateRecord(c, gateLink);
+    // the lane behind the next laneLink (a lane's vehicle near the intersection): Lane::canEnter looks at it as of this step,
+    // the leader search two drivables ahead as of the last commit.  Where the loader knows the lane (the static table of
+    // the vehicle's own lane) the records are requested here, with everything else; otherwise they hang on the gate record
+    const bool approaching = related && nextIsLink;  // (a vehicle ON a laneLink has nd0 = its end lane)
+    const bool endKnown = approaching && in.endLane >= 0;
+    TailRec laneNow{}, laneCommitted{};
+    if (endKnown) {
+        laneNow = c.tailNow[in.endLane];
+        if (hopHead) laneCommitted = c.tailR[in.endLane];
+    }
     // may it run past the end of its drivable this step?  (only a hint: decides what is requested early)
     LeaverPrefetch lp{false, 0.0, 0, 0, 0};
     if (dlen - dis <= (speed + t.max_pos_acc * interval) * interval + 1.0) {
@@ -669,12 +703,10 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         lp.routePos = c.s.routePos[s];
     }
 
-    // ================= round B: what hangs on the gate record (a lane's vehicle near the intersection)
-    const bool approaching = related && nextIsLink;  // (a vehicle ON a laneLink has nd0 = its end lane)
-    TailRec laneNow{}, laneCommitted{};
-    if (approaching) {
-        laneNow = c.tailNow[gate.y];                     // Lane::canEnter looks at the lane as of this step
-        if (hopHead) laneCommitted = c.tailR[gate.y];    // the leader search two drivables ahead, as of the last commit
+    // ================= round B: what hangs on the gate record (only where the end lane was not known above)
+    if (approaching && !endKnown) {
+        laneNow = c.tailNow[gate.y];
+        if (hopHead) laneCommitted = c.tailR[gate.y];
     }
 
     // ================= leader / gap (Vehicle::updateLeaderAndGap vehicle.cpp:157-196)
@@ -922,6 +954,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             in.lm = sLM[i];
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
             in.laneAdmitted = sAdm[i] != 0;
+            in.endLane = -1;
             actionOneRounds(c, o, tv, slot, in, push);
         }
         __syncthreads();
@@ -931,6 +964,146 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
 #ifdef CFX_TRACE
     if (t == 0) g_trace[(size_t) w * 8 + 5] = T;
 #endif
+}
+
+// The same phase with WAVE-granular passes (the default).  The preamble is kr_action's — the block's first threads read the
+// rings and lane tables of G lanes (or B laneLinks), one block-wide prefix sum, ONE barrier — but the block's vehicle list is
+// then dealt out in chunks of 64 to the block's wavefronts, each of which runs on its own: a vehicle takes its leader's
+// {dis, speed, template} from the lane below it in the wavefront (`__shfl_up`; lane 0 of a chunk loads the vehicle ahead of
+// the chunk together with its own), so there is no LDS window and no barrier in the loop.  A block of 190 vehicles keeps
+// three wavefronts busy and lets the fourth go at once (the block form keeps 256 threads through two barriers per pass);
+// large networks take more lanes per block and every wavefront walks several chunks.  The end lanes of the laneLinks that
+// leave a lane come with the lane's static tables, so the tail records behind the next laneLink are requested in round A.
+template <int B>
+__global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
+    const int w = (int) blockIdx.x, t = (int) threadIdx.x;
+    if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
+        llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
+        return;
+    }
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    __shared__ int sPre[B + 1];
+    __shared__ int2 sGeo[B];
+    __shared__ int sHead[B];
+    __shared__ double2 sLM[B];
+    __shared__ int4 sHop[B];
+    __shared__ int4 sEnd[B];
+    __shared__ unsigned char sAdm[B];
+    __shared__ int sWave[B / 64];
+    const cfx_vehicle_template *tv = c.t.templ;
+    const bool laneBlock = w < nLaneBlocks;
+    const int g = laneBlock ? G : B;
+    const int d0 = laneBlock ? w * G : c.n.L + (w - nLaneBlocks) * B;
+    const int dEnd = laneBlock ? c.n.L : c.n.L + c.n.K;
+    const int dMine = d0 + t;
+    int n = 0;
+    if (t < g && dMine < dEnd) {
+        const int2 geo = c.ringGeo[dMine];
+        const int head = c.head[dMine];
+        n = c.cnt[dMine];
+        const bool admitted = laneBlock && c.admitStep[dMine] == c.step;
+        if (admitted) n += 1;
+        sAdm[t] = admitted ? 1 : 0;
+        sLM[t] = c.n.drvLM[dMine];
+        sHop[t] = laneBlock ? c.n.laneLL4[dMine] : make_int4(-2, -2, -2, -2);
+        sEnd[t] = laneBlock ? c.n.laneEnd4[dMine] : make_int4(-1, -1, -1, -1);
+        sGeo[t] = geo;
+        sHead[t] = head;
+    }
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = t; i < nd; i += B) dst[i] = src[i];
+        tv = sT;
+    }
+    int incl = n;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += up;
+    }
+    if constexpr (B > 64) {
+        if ((t & 63) == 63) sWave[t >> 6] = incl;
+        __syncthreads();
+        for (int i = 0; i < (t >> 6); ++i) incl += sWave[i];
+    }
+    sPre[t + 1] = incl;
+    if (t == 0) sPre[0] = 0;
+    __syncthreads();
+    const int T = sPre[B];
+    // feedback for the host's choice of lanes per block (small networks: every wavefront should need one chunk only)
+    if (t == 0 && T > B * 3 / 4) atomicMax(&o.sc->actionMaxT, T);
+    const RingPush push{q, jobRecs, c.n.L};
+    const int lane = t & 63;
+    for (int q0 = (t >> 6) * 64; q0 < T; q0 += B) {  // chunk q0 / 64 belongs to wavefront (q0 / 64) mod (B / 64)
+        const int qv = q0 + lane;
+        const bool valid = qv < T;
+        int i = 0, idx = 0, slot = 0;
+        int2 geo = make_int2(0, 0);
+        int head = 0;
+        SlotIn in;
+        in.vid = 0;  // (the vehicle number is loaded where it is needed: custom speed, leaving the drivable)
+        in.dis = 0.0;
+        in.speed = 0.0;
+        in.templIdx = 0;
+        in.nd0 = -1;
+        in.flags = 0;
+        double2 kp = make_double2(0.0, 0.0);
+        int tp = 0;
+        if (valid) {
+            int lo = 0, hi = g;  // the drivable this list position belongs to: the last i with sPre[i] <= qv
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (sPre[mid] <= qv) lo = mid;
+                else hi = mid;
+            }
+            i = lo;
+            idx = qv - sPre[i];
+            geo = sGeo[i];
+            head = sHead[i];
+            slot = ringSlot(geo, head, idx);
+            const double2 kv = c.kin[slot];  // the two records of the slot: 2 x 16 B, adjacent lanes adjacent in memory
+            const int4 mv = c.meta[slot];
+            if (lane == 0 && idx > 0) {  // the vehicle ahead of the chunk: this lane's leader
+                const int ls = ringSlot(geo, head, idx - 1);
+                kp = c.kin[ls];
+                tp = c.meta[ls].x;
+            }
+            in.dis = kv.x;
+            in.speed = kv.y;
+            in.templIdx = mv.x;
+            in.nd0 = mv.y;
+            in.flags = mv.z;
+        }
+        // the leader inside the drivable is the lane below (all lanes take part in the exchange)
+        const double disUp = __shfl_up(in.dis, 1, 64), speedUp = __shfl_up(in.speed, 1, 64);
+        const int templUp = __shfl_up(in.templIdx, 1, 64);
+        if (!valid) continue;  // (a chunk's invalid lanes are its last ones: nobody reads them)
+        in.d = d0 + i;
+        in.head = idx == 0;
+        in.idx = idx;
+        in.nNow = sPre[i + 1] - sPre[i];
+        in.leaderSlot = 0;
+        in.disPrev = lane == 0 ? kp.x : disUp;
+        in.speedPrev = lane == 0 ? kp.y : speedUp;
+        in.templPrev = lane == 0 ? tp : templUp;
+        if (idx > 0) in.leaderSlot = ringSlot(geo, head, idx - 1);
+        if (in.flags & 1) {
+            in.vid = c.s.vid[slot];
+            c.meta[slot].z = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+        }
+        in.lm = sLM[i];
+        in.hop = make_int4(-2, -2, -2, -2);
+        in.endLane = -1;
+        if (in.nd0 >= c.n.L) {
+            in.hop = sHop[i];
+            const int4 en = sEnd[i];
+            const int ll = in.nd0 - c.n.L;
+            in.endLane = in.hop.x == ll ? en.x : (in.hop.y == ll ? en.y : (in.hop.z == ll ? en.z : (in.hop.w == ll ? en.w : -1)));
+        }
+        in.laneAdmitted = sAdm[i] != 0;
+        actionOneRounds(c, o, tv, slot, in, push);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- phase 5 + 6 + 8
@@ -1073,6 +1246,7 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
         const int2 geo = c.ringGeo[d];
         int head = c.head[d];
         int n = c.cnt[d];
+        const int nWas = n;
         if (admitted) {  // commit this step's admission (phase 2): the FIFO pop and the vehicle's state
             const int2 rec = c.admitRec[d];
             k.waitHead[d] = rec.y;
@@ -1170,6 +1344,12 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
         else if (n + min(8, (geo.y + 1) / 2) > geo.y) k.sc->ringNearFull = 1;  // (the host doubles every capacity)
         c.head[d] = head;
         c.cnt[d] = n;
+        if (d >= c.n.L && (nWas > 0) != (n > 0)) {  // "this laneLink has vehicles on it", for the cross phase of the second form
+            const int kk = d - c.n.L, bit = c.n.llLocal[kk];
+            unsigned long long *word = &c.llOcc[c.n.llPack[kk].z + (bit >> 6)];
+            if (n > 0) atomicOr(word, 1ULL << (bit & 63));
+            else atomicAnd(word, ~(1ULL << (bit & 63)));
+        }
         k.scratch[d] = make_int4(0, -1, -1, 0);
     }
 }
@@ -1225,6 +1405,10 @@ __global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTa
     const int n = off[d + 1] - off[d];
     c.head[d] = 0;
     c.cnt[d] = n;
+    if (d >= c.n.L && n > 0) {  // (llOcc was cleared by the caller)
+        const int kk = d - c.n.L, bit = c.n.llLocal[kk];
+        atomicOr(&c.llOcc[c.n.llPack[kk].z + (bit >> 6)], 1ULL << (bit & 63));
+    }
     const int2 geo = c.ringGeo[d];
     for (int i = 0; i < n; ++i) {
         const int s = geo.x + i, j = off[d] + i;

@@ -85,6 +85,30 @@ def test_forced_choices_congested_grid(mod, scen, workdir, cross, layout):
     assert hip.get_vehicle_count() > 3000
 
 
+@pytest.mark.parametrize("form", [10000, 20000, 30000])
+def test_ring_step_forms_equal_twin(mod, scen, workdir, form):
+    """The forms of the ring step that `auto` picks by size, forced (cfx.ringLanesPerWave / 10000: 1 = wave-granular action
+    kernel kw_action, 2 = block form kr_action, 3 = the second form of the whole step, cfx_ring2_kernels.h: sources of
+    Engine::threadNotifyCross written per lane, no gate records, sparse tailNow) on the 1x1 example (up to 118 crosses per
+    laneLink, an intersection with more than 64 laneLinks) and the congested 6x6."""
+    hip, tw = _pair(mod, scen.materialize("example_1x1", workdir), layout="ring", ringLanesPerWave=form)
+    for s in range(400):
+        hip.next_step()
+        tw.next_step()
+        assert_same_state(hip, tw, "1x1 form %d step %d" % (form, s + 1))
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_dense.json"), 400, seed=7,
+                            interval=2.0, base_flow=os.path.join(d, "flow.json"))
+    hip, tw = _pair(mod, scen.materialize("grid_6x6", workdir, flow_file=flow), layout="ring", ringLanesPerWave=form + 6)
+    for s in range(300):
+        hip.next_step()
+        tw.next_step()
+        if s % 2 == 1:
+            assert_same_state(hip, tw, "dense 6x6 form %d step %d" % (form, s + 1))
+    assert hip.get_vehicle_count() > 2500
+
+
 @pytest.mark.parametrize("cross,layout", CHOICES)
 @pytest.mark.parametrize("seed", [11, 14])
 def test_forced_choices_irregular_networks(mod, scen, workdir, seed, cross, layout):
