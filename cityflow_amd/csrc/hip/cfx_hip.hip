@@ -446,7 +446,10 @@ struct cfx_engine {
 
 
     // ------------------------------------------------------------------------------------------ ring layout
-    RingCtx rctx(bool stepping = false) const {
+    // `atStep` / `atRcur`: the context of an EARLIER step (the deferred commit of step - 1, see settle)
+    RingCtx rctx(bool stepping = false, int64_t atStep = -1, int atRcur = -1) const {
+        const int64_t step = atStep >= 0 ? atStep : this->step;
+        const int rcur = atRcur >= 0 ? atRcur : this->rcur;
         RingCtx c{};
         c.tailR = rTail[(step + 1) & 1];
         c.tailW = rTail[step & 1];
@@ -594,6 +597,32 @@ struct cfx_engine {
         HIP_TRY(hipMemsetAsync(interMask, 0, (size_t) std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
         return CFX_OK;
     }
+    // ---- the commit of a step may ride with the NEXT step's admission (kr_admit<true>: one launch less per step).  Until
+    //      then it is pending; anything else that looks at the state launches it on its own first.
+    bool ringMerge = true;       // cfx_config::ring_lanes_per_wave / 10000 == 4 turns the deferral off (developer knob)
+    bool commitPending = false;  // the commit of step - 1 has not been launched yet (its lights were advanced by kr_cross)
+    size_t activeEstimate() const {
+        const unsigned long long pr = __atomic_load_n(&hMirror->progress, __ATOMIC_RELAXED);
+        return (size_t) (pr & 0xFFFFFFFFu) + (size_t) nQueueLanes * 4;
+    }
+    RingCommit commitArgs(size_t activeEst, bool lightsDone, int *nStatOut) {
+        const int nStat = (int) std::min<size_t>(std::max<size_t>(1, activeEst >> 16), 64);
+        *nStatOut = nStat;
+        return RingCommit{rScratch, rMovers, waitHead, curPhase, remain, (int) cfg.rl_traffic_light, (int) nMaskWords,
+                          sc, rFinKey, rFinVid, rFinTerm, rFinCap, jobCount,
+                          tiled ? (HostMirror *) nullptr : hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
+                          lightsDone ? 1 : 0};
+    }
+    int settle() {
+        if (!commitPending) return CFX_OK;
+        commitPending = false;
+        int nStat = 1;
+        const RingCommit rk = commitArgs(activeEstimate(), true, &nStat);
+        launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(D, std::max(I, nMaskWords))) + nStat), dim3(kBlock),
+               rctx(true, step - 1, rcur ^ 1), rk, vt);
+        HIP_TRY(hipGetLastError());
+        return CFX_OK;
+    }
     // (Re)build the rings: first use, a shorter vehicle template than the capacities were computed for, or growth.
     bool ringGrowRequested = false;
     int ringEnsure() {
@@ -603,6 +632,7 @@ struct cfx_engine {
         minLen = std::max(minLen, 0.25);
         if (ringBuilt && !(minLen < ringMinLen) && !ringGrowRequested) return CFX_OK;
         int rc;
+        if ((rc = settle())) return rc;
         int32_t total = 0;
         if (ringBuilt) {  // carry the running vehicles over
             if ((rc = ringGather(false, &total))) return rc;
@@ -629,6 +659,7 @@ struct cfx_engine {
     }
 
     int resetState() {
+        commitPending = false;  // (whatever a deferred commit would have written is overwritten below)
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
         tailsValid = false;
@@ -754,7 +785,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     // ~150 k running vehicles (30x30: 56 vs 61 us / step) and behind once that state no longer sits in the caches
     // (60x60: 112 vs 101, 100x100: 227 vs 191).  Lanes are the proxy for size known at creation.
     e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change && n->n_lanes <= 20000);
-    e->ringV2 = cfg->ring_lanes_per_wave / 10000 == 3;
+    e->ringV2 = (cfg->ring_lanes_per_wave / 10000) % 10 == 3;
+    e->ringMerge = (cfg->ring_lanes_per_wave / 10000) % 10 != 4;
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
     e->timesDyadic = cfx_engine::dyadic(cfg->interval);
     e->R = n->n_roads;
@@ -1047,6 +1079,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if (inArgs) {
             // (nothing to launch)
         } else {
+            if ((rc = e->settle())) return rc;  // (k_spawn_link looks at what the previous step's commit leaves)
             if ((size_t) n > e->recCap) {
                 size_t nc = std::max<size_t>((size_t) n * 2, 1024);
                 if ((rc = e->grow(&e->dRecs, 0, nc))) return rc;
@@ -1108,10 +1141,25 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // only sizes the cross phase's grid and picks its organisation
         const size_t activeEst = (size_t) (pr & 0xFFFFFFFFu) + (size_t) e->nQueueLanes * 4;
         const bool v2 = e->ringV2;  // the second form of the step (cfx_ring2_kernels.h)
-        if (v2) e->launch(PK_ADMIT, kr2_admit, dim3(gridFor(std::max(e->L, e->I))), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
-        else e->launch(PK_ADMIT, kr_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
-        RING_CHECK("kr_admit")
         const bool useBig = !v2 && (e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000);  // which form of the cross phase (§4)
+        // This step's commit rides with the next step's admission (one launch less per step) where the step runs kr_cross,
+        // which then advances the lights; the previous step's, if it is still pending, goes with this step's admission.
+        const bool deferCommit = e->ringMerge && !v2 && !useBig && !dbg && !e->tiled;
+        if (e->commitPending && v2) {
+            if ((rc = e->settle())) return rc;
+        }
+        if (v2) {
+            e->launch(PK_ADMIT, kr2_admit, dim3(gridFor(std::max(e->L, e->I))), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
+        } else if (e->commitPending) {
+            e->commitPending = false;
+            int nStatPrev = 1;
+            const RingCommit rkPrev = e->commitArgs(activeEst, true, &nStatPrev);
+            e->launch(PK_ADMIT, kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
+                      e->admitStep, e->waitHead, e->vt, e->sc, batch, rkPrev);
+        } else {
+            e->launch(PK_ADMIT, kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{});
+        }
+        RING_CHECK("kr_admit")
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
         RingOut ro{c.kinN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
@@ -1123,7 +1171,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // + 10000 forces the wave form of the action kernel (kw_action; the default above 240 k vehicles), + 20000 the
             // block form (kr_action; the default below), + 30000 the second form of the whole step (cfx_ring2_kernels.h).
             int G = e->ringG, Bsel = 256;
-            const int form = e->cfg.ring_lanes_per_wave / 10000;
+            const int form = (e->cfg.ring_lanes_per_wave / 10000) % 10;
             const bool blockForm = form == 2 || (form == 0 && !(useBig || activeEst > 240000));
             const int want = e->cfg.ring_lanes_per_wave % 10000;
             if (want > 0) {
@@ -1153,6 +1201,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             }
             G = std::min(G, Bsel);
             const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;
+            // (first form: as many blocks again at the end of the grid compute the laneLinks' notify sources)
             const dim3 grid(nLaneBlocks + (v2 ? 1 : 2) * nLLBlocks), block(Bsel);
             if (v2) {
                 if (Bsel == 256) e->launch(PK_ACTION, kw2_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks);
@@ -1188,16 +1237,28 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
                       dim3(kCross2Block), c, ro, jq);
         else
+        {
+            // one 16-lane group per queued vehicle; sized by the job count of the last step the device has reported (every
+            // block of the grid pays the prologue, and blocks that find no job still take a wavefront slot for it)
+            size_t groups = activeEst / 4;
+            if (e->mirrorValid) {
+                const int lastJobs = __atomic_load_n(&e->hMirror->sc.nCrossJobs, __ATOMIC_RELAXED);
+                if (lastJobs > 0) groups = std::min<size_t>(groups, (size_t) lastJobs + (size_t) lastJobs / 4 + 256);
+            }
             e->launch(PK_CROSS, kr_cross,
-                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
-                      dim3(kCrossBlock), c, ro, jq, (const RingJob *) e->rJobRecs);
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (groups * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
+                      dim3(kCrossBlock), c, ro, jq, (const RingJob *) e->rJobRecs,
+                      RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
+        }
         RING_CHECK("k_cross")
-        const int nStat = (int) std::min<size_t>(std::max<size_t>(1, activeEst >> 16), 64);
-        RingCommit rk{e->rScratch, e->rMovers, e->waitHead, e->curPhase, e->remain, (int) e->cfg.rl_traffic_light, (int) e->nMaskWords,
-                      e->sc, e->rFinKey, e->rFinVid, e->rFinTerm, e->rFinCap, e->jobCount,
-                      e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat, e->vt.state, e->slotOf, e->exactTimes() ? 1 : 0};
-        e->launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
-        RING_CHECK("kr_commit")
+        if (deferCommit) {
+            e->commitPending = true;  // launched by the next cfx_step (with its admission) or by settle()
+        } else {
+            int nStat = 1;
+            const RingCommit rk = e->commitArgs(activeEst, false, &nStat);
+            e->launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
+            RING_CHECK("kr_commit")
+        }
 #undef RING_CHECK
         HIP_TRY(hipGetLastError());
         e->rcur ^= 1;
@@ -1343,6 +1404,7 @@ int32_t cfx_sync(cfx_engine *e) {
     if (!e) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     HIP_TRY(hipStreamSynchronize(e->stream));
     return CFX_OK;
 }
@@ -1366,6 +1428,7 @@ int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
         return CFX_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream
     HIP_TRY(hipMemcpyAsync(e->curPhase + inter, &phase, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1376,6 +1439,7 @@ int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const
     if (!e || n < 0 || (n && (!inters || !phases))) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     for (int i = 0; i < n; ++i)
         if (inters[i] < 0 || inters[i] >= e->I || phases[i] < 0) {
             e->err = "cfx_set_tl_phases: index out of range";
@@ -1411,6 +1475,7 @@ int32_t cfx_get_tl_state(cfx_engine *e, int32_t *phase, double *remain) {
     if (!e) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     if (phase) HIP_TRY(hipMemcpyAsync(phase, e->curPhase, e->I * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (remain) HIP_TRY(hipMemcpyAsync(remain, e->remain, e->I * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1420,6 +1485,7 @@ int32_t cfx_get_tl_state(cfx_engine *e, int32_t *phase, double *remain) {
 int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     (void) hipSetDevice(e->device);
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     DevScalars s;
     int rc = e->readScalars(s);
     if (rc) return rc;
@@ -1447,6 +1513,7 @@ int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     if (e->ring && !e->ringBuilt) {  // nothing has run yet
         memset(out, 0, e->L * sizeof(int32_t));
         return CFX_OK;
@@ -1461,6 +1528,7 @@ int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     int rc;
     if ((rc = e->syncTables())) return rc;
     if (e->ring && (rc = e->ringEnsure())) return rc;
@@ -1477,6 +1545,7 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
     if (!e || !view) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     int rc;
     if ((rc = e->syncTables())) return rc;
     if (e->ring) {
@@ -1637,6 +1706,7 @@ int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first, int32_t n, uint8_t 
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     if (n) HIP_TRY(hipMemcpyAsync(out, e->vt.state + first, (size_t) n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return CFX_OK;
@@ -1646,6 +1716,7 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
     if (!e || !nOut) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     // The waiting FIFOs are linked lists through the vid table; walk them on the host (debug / API path).
     std::vector<int32_t> head(e->L), next((size_t) e->spawned);
     HIP_TRY(hipMemcpyAsync(head.data(), e->waitHead, e->L * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1674,6 +1745,7 @@ int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     uint8_t st = 0;
     HIP_TRY(hipMemcpyAsync(&st, e->vt.state + vid, 1, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1704,6 +1776,7 @@ int32_t cfx_set_vehicle_route(cfx_engine *e, int32_t vid, int32_t route) {
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     int rc = e->syncTables();
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->vt.route + vid, &route, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
@@ -1728,6 +1801,7 @@ int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *dri
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     int rc = e->syncTables();
     if (rc) return rc;
     uint8_t st = 0;
@@ -1814,6 +1888,7 @@ int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     if (e->ring) {
         int rc;
         if ((rc = e->syncTables()) || (rc = e->ringEnsure())) return rc;

@@ -56,6 +56,9 @@ struct DevScalars {
     int actionMaxT;            // ring layout: most vehicles one block of the action kernel had (blocks above 3/4 of a pass report)
     long long tieEvents;       // cfx_scalars::tie_events
     int tieDrv[8];             // cfx_scalars::tie_drivables (event i at index i % 8)
+    // ring layout: vehicles admitted by the step of that parity, folded into `active` by that step's commit (the admission of
+    // step t + 1 may run in the same launch as the commit of step t, which reads and rewrites `active`)
+    long long admitPending[2];
 };
 
 struct HostMirror {  // pinned host copy of the end-of-step scalars (written by k_scatter's statistics block)

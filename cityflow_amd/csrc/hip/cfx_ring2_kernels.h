@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void kr2_admit(RingCtx c, int32_t *admitSte
     }
     __syncthreads();
     // Engine::activeVehicleCount: one global atomic per block (phase 4 of this very step counts the admitted vehicles)
-    if (threadIdx.x == 0 && sAdmitted) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) sAdmitted);
+    if (threadIdx.x == 0 && sAdmitted) atomicAdd((unsigned long long *) &sc->admitPending[c.step & 1], (unsigned long long) sAdmitted);
 }
 
 // Cross::notifyVehicles / notifyDistances of a cross on laneLink k (what the sweep of engine.cpp:327-369 would have written

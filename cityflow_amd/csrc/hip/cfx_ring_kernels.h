@@ -277,10 +277,97 @@ struct SpawnBatch {
     int32_t lane[kAdmitRecs], prevWait[kAdmitRecs], route[kAdmitRecs], priority[kAdmitRecs];
     int16_t templ[kAdmitRecs], vidOff[kAdmitRecs];
 };
-static_assert(sizeof(SpawnBatch) + sizeof(RingCtx) + sizeof(VidTable) + 64 <= 3584, "kr_admit's arguments must stay well below 4 KB");
+static_assert(sizeof(SpawnBatch) + sizeof(RingCtx) + sizeof(VidTable) + 256 <= 4096, "kr_admit's arguments must stay below 4 KB");
 
-__global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep, int32_t *waitHead, VidTable vt, DevScalars *sc,
-                                                   const SpawnBatch batch) {
+struct RingCommit {
+    int4 *scratch;
+    const MoverRec *movers;
+    int32_t *waitHead;
+    int32_t *curPhase;
+    double *remain;
+    int rlTrafficLight, nMaskWords;
+    DevScalars *sc;
+    const long long *finKey;
+    const int32_t *finVid;
+    double *finTerm;
+    int finCap;
+    int32_t *jobCount;
+    HostMirror *hostMirror;
+    int32_t *finTicket;
+    int nStatBlocks;
+    uint8_t *vStateW;
+    int32_t *slotOfW;  // a finished vehicle's entry becomes -1 (blocker chains end there)
+    int exactTimes;  // every time involved is a multiple of 2^-10: the travel-time sum is order-free (exactFinishStatistics)
+    int lightsDone;  // the step's cross kernel has already advanced the lights (kr_cross with lights.on)
+};
+struct CommitOut {  // what a drivable's commit leaves, for the admission that follows it in the same thread
+    int touched, head, n, tailWritten;
+    TailRec tail;
+};
+__device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, const int d, CommitOut *out = nullptr);
+__device__ inline void commitStatBlock(const RingCtx &c, const RingCommit &k, const VidTable &vt, int part);
+__device__ inline int commitStatBlocks(const RingCommit &k);
+__device__ inline void commitClearMasks(const RingCtx &c, const RingCommit &k, int gid, int stride);
+
+// COMMIT = true: the launch also commits the PREVIOUS step (kr_commit's work, drivable by drivable, in front of the drivable's
+// admission; its statistics blocks at the end of the grid).  `cIn` is then the context of the step being committed and the
+// admission runs on the next step's view of it.  What a lane's admission reads of the commit is what its own thread wrote —
+// its tail, its count, its queue — except the lights, which the cross kernel of the committed step has already advanced.
+template <bool COMMIT>
+__global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitStep, int32_t *waitHead, VidTable vt, DevScalars *sc,
+                                                   const SpawnBatch batch, const RingCommit k) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool isLane = d < cIn.n.L, inRange = d < cIn.n.L + cIn.n.K;
+    // what the admission needs and the commit in front of it leaves alone — or changes through this very thread, which then
+    // knows the new value: requested here, before the commit's own chain of loads, so that the two overlap
+    TailRec committed{};
+    int w = -1, n = 0, head = 0, road = 0, laneIdx = 0;
+    int2 geo = make_int2(0, 0);
+    int wt = 0, route = 0, nextWait = -1;
+    uint8_t pending = 0;
+    if constexpr (COMMIT) {
+        const int nBody = (int) gridDim.x - commitStatBlocks(k);
+        if ((int) blockIdx.x >= nBody) {
+            commitStatBlock(cIn, k, vt, (int) blockIdx.x - nBody);
+            return;
+        }
+        commitClearMasks(cIn, k, d, nBody * (int) blockDim.x);
+        if (inRange) committed = cIn.tailW[d];  // (the record of the step being committed, unless its tail changes hands below)
+        if (isLane) {
+            w = waitHead[d];
+            if (admitStep[d] == cIn.step) w = cIn.admitRec[d].y;  // (the commit below pops the vehicle admitted last step)
+            n = cIn.cnt[d];
+            geo = cIn.ringGeo[d];
+            head = cIn.head[d];
+            road = cIn.n.laneRoad[d];
+            laneIdx = cIn.n.laneIndex[d];
+            if (w >= 0) {
+                wt = vt.templ[w];
+                route = vt.route[w];
+                nextWait = vt.nextWait[w];
+                pending = vt.pendingCustom[w];
+            }
+        }
+        if (inRange) {
+            CommitOut co;
+            commitDrivable(cIn, k, d, &co);
+            if (co.touched) {
+                head = co.head;
+                n = co.n;
+                if (co.tailWritten) committed = co.tail;
+            }
+        }
+    }
+    RingCtx c = cIn;
+    if constexpr (COMMIT) {  // the next step's view: what the commit wrote is what the admission reads
+        c.step = cIn.step + 1;
+        c.tailR = cIn.tailW;
+        c.tailW = const_cast<TailRec *>(cIn.tailR);
+        c.kin = cIn.kinN;
+        c.kinN = cIn.kin;
+        c.blkR = cIn.blkW;
+        c.blkW = const_cast<int2 *>(cIn.blkR);
+    }
     __shared__ int sAdmitted;
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     __shared__ int sLane[kAdmitRecs];
@@ -295,30 +382,25 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep
         for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
         tv = sT;
     }
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool isLane = d < c.n.L, inRange = d < c.n.L + c.n.K;
-    // ---- round 1: everything that hangs on the drivable alone (a lane's ring position is requested whether or not it
-    //      will admit: the kernel is bound by its longest chain of dependent loads, not by bytes)
-    TailRec committed{};
-    int w = -1, n = 0, head = 0, road = 0, laneIdx = 0;
-    int2 geo = make_int2(0, 0);
-    if (inRange) committed = c.tailR[d];
-    if (isLane) {
-        w = waitHead[d];
-        n = c.cnt[d];
-        geo = c.ringGeo[d];
-        head = c.head[d];
-        road = c.n.laneRoad[d];
-        laneIdx = c.n.laneIndex[d];
-    }
-    // ---- round 2: the head of the lane's waiting queue (as the last step left it)
-    int wt = 0, route = 0, nextWait = -1;
-    uint8_t pending = 0;
-    if (w >= 0) {
-        wt = vt.templ[w];
-        route = vt.route[w];
-        nextWait = vt.nextWait[w];
-        pending = vt.pendingCustom[w];
+    if constexpr (!COMMIT) {
+        // ---- round 1: everything that hangs on the drivable alone (a lane's ring position is requested whether or not it
+        //      will admit: the kernel is bound by its longest chain of dependent loads, not by bytes)
+        if (inRange) committed = c.tailR[d];
+        if (isLane) {
+            w = waitHead[d];
+            n = c.cnt[d];
+            geo = c.ringGeo[d];
+            head = c.head[d];
+            road = c.n.laneRoad[d];
+            laneIdx = c.n.laneIndex[d];
+        }
+        // ---- round 2: the head of the lane's waiting queue (as the last step left it)
+        if (w >= 0) {
+            wt = vt.templ[w];
+            route = vt.route[w];
+            nextWait = vt.nextWait[w];
+            pending = vt.pendingCustom[w];
+        }
     }
     __syncthreads();  // (templates and the batch's lanes staged)
     if (nRecs > 0) {
@@ -420,8 +502,8 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx c, int32_t *admitStep
         c.tailNow[d] = now;
     }
     __syncthreads();
-    // Engine::activeVehicleCount: one global atomic per block (phase 4 of this very step counts the admitted vehicles)
-    if (threadIdx.x == 0 && sAdmitted) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) sAdmitted);
+    // Engine::activeVehicleCount: one global atomic per block; the step's commit folds the sum into the running count
+    if (threadIdx.x == 0 && sAdmitted) atomicAdd((unsigned long long *) &sc->admitPending[c.step & 1], (unsigned long long) sAdmitted);
 }
 
 // Per-laneLink sources of Engine::threadNotifyCross (llstate of cfx_kernels.h) on the ring layout: the tails come from
@@ -568,7 +650,16 @@ __device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action 
 // Second half of Vehicle::getIntersectionRelatedSpeed (k_cross of cfx_kernels.h) from job records: one 16-lane group per
 // queued vehicle, one cross per lane and round, first failing lane of the first failing round = the first cross that
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
-__global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs) {
+struct RingLights {  // TrafficLight::passTime of the step, done by the cross kernel when the step's commit is deferred
+    int32_t *curPhase;
+    double *remain;
+    int on;
+};
+__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride);
+
+__global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs, RingLights lights) {
+    // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
+    if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
     __shared__ int shardEnd[kJobShards];
@@ -597,6 +688,7 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
     }
     __syncthreads();
     const int nJ = shardEnd[kJobShards - 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) o.sc->nCrossJobs = nJ;  // (sizes the next steps' grids, through the host mirror)
     XSTAMP(1);
     const int g = threadIdx.x % kCrossGroup;
     const int groupsPerBlock = blockDim.x / kCrossGroup;
@@ -902,6 +994,8 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
     const int T = sPre[B];
     // feedback for the host's choice of lanes per block (a block that needs a second pass is the step's slowest)
     if (t == 0 && T > (B - 1) * 3 / 4) atomicMax(&o.sc->actionMaxT, T);
+    // (letting the laneLink blocks compute their own laneLinks' notify sources instead of the trailing blocks was measured in
+    // round 3: 12.4 -> 14.9 us at 30x30 — the laneLink blocks then become the longest ones)
     TRACE_STAMP(1);
     const RingPush push{q, jobRecs, c.n.L};
     for (int qb = 0; qb < T; qb += B - 1) {
@@ -1111,26 +1205,6 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
 // are appended behind the stayers by descending new distance (std::sort with vehicleCmp engine.h:21-23; ties: lower vid
 // first, as in the twin).  Also commits the step's admission (FIFO pop, running count), Router::update of the entrants,
 // TrafficLight::passTime, and re-arms the step's scratch.  Extra blocks do the finish statistics in the reference's order.
-struct RingCommit {
-    int4 *scratch;
-    const MoverRec *movers;
-    int32_t *waitHead;
-    int32_t *curPhase;
-    double *remain;
-    int rlTrafficLight, nMaskWords;
-    DevScalars *sc;
-    const long long *finKey;
-    const int32_t *finVid;
-    double *finTerm;
-    int finCap;
-    int32_t *jobCount;
-    HostMirror *hostMirror;
-    int32_t *finTicket;
-    int nStatBlocks;
-    uint8_t *vStateW;
-    int32_t *slotOfW;  // a finished vehicle's entry becomes -1 (blocker chains end there)
-    int exactTimes;  // every time involved is a multiple of 2^-10: the travel-time sum is order-free (exactFinishStatistics)
-};
 
 __device__ inline void ringCopySlot(const RingCtx &c, int from, int to) {  // general path only: one list element moves
     c.s.vid[to] = c.s.vid[from];
@@ -1155,9 +1229,19 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
     int F = sc->nFinishedStep;
     if (F > k.finCap) F = k.finCap;
     const double now = c.step * c.interval;
-    if (k.exactTimes)
-        return exactFinishStatistics(now, vt, sc, F, [&](int i) { return k.finVid[i]; }, k.vStateW, k.finTicket, part, nParts, 0,
-                                     k.slotOfW);
+    // this step's admissions (kr_admit counted them by step parity) belong to the vehicles that took the step
+    auto foldAdmissions = [&]() {
+        const long long a = sc->admitPending[c.step & 1];
+        sc->admitPending[c.step & 1] = 0;
+        sc->vehicleSteps += a;
+        sc->active += a;
+    };
+    if (k.exactTimes) {
+        const bool lastBlock = exactFinishStatistics(now, vt, sc, F, [&](int i) { return k.finVid[i]; }, k.vStateW, k.finTicket, part,
+                                                     nParts, 0, k.slotOfW);
+        if (lastBlock && threadIdx.x == 0) foldAdmissions();
+        return lastBlock;
+    }
     const bool inLds = nParts == 1 && F <= kFinLds;
     const int per = (F + nParts - 1) / nParts;
     const int lo = part * per, hi = min(F, lo + per);
@@ -1201,157 +1285,179 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
         sc->finishedCnt += F;
         sc->active -= F;
         sc->nFinishedStep = 0;
+        foldAdmissions();
     }
     return last;
+}
+
+// One drivable's commit (the body of kr_commit's loop; kr_admit<true> runs it in front of the NEXT step's admission).
+__device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, const int d, CommitOut *out) {
+    const int4 sc = k.scratch[d];  // {leavers, largest list index among them, entrant list, entrants}
+    const bool admitted = d < c.n.L && c.admitStep[d] == c.step;
+    if (out) out->touched = 0;
+    if (!admitted && sc.x == 0 && sc.z < 0) return;  // nothing happened on this drivable: nothing is written
+    const int2 geo = c.ringGeo[d];
+    int head = c.head[d];
+    int n = c.cnt[d];
+    const int nWas = n;
+    if (admitted) {  // commit this step's admission (phase 2): the FIFO pop and the vehicle's state
+        const int2 rec = c.admitRec[d];
+        k.waitHead[d] = rec.y;
+        k.vStateW[rec.x] = 1;
+        n += 1;
+    }
+    if (sc.x > 0) {
+        if (sc.y + 1 != sc.x) {
+            // leavers are not a prefix of the list (a vehicle ran past the end of its drivable before the one ahead of
+            // it did): close the gaps, stayers keep their order and move towards the tail
+            int wr = n - 1;
+            for (int r = n - 1; r >= 0; --r) {
+                const int from = ringSlot(geo, head, r);
+                if (c.kinN[from].y < 0.0) continue;
+                if (wr != r) ringCopySlot(c, from, ringSlot(geo, head, wr));
+                --wr;
+            }
+        }
+        head = (head + sc.x) & geo.y;
+        n -= sc.x;
+    }
+    int m = 0, tailRank = -1;
+    TailRec tail{};
+    for (int e = sc.z; e >= 0; e = k.movers[e].nextIn) {
+        const MoverRec r = k.movers[e];
+        int rank = 0;
+        for (int f = sc.z; f >= 0; f = k.movers[f].nextIn) {
+            if (f == e) continue;
+            const double od = k.movers[f].dis;
+            const bool tieBefore = od == r.dis && k.movers[f].vid < r.vid;
+            rank += (od > r.dis) || tieBefore;
+            if (tieBefore) k.sc->tieDrv[atomicAdd((unsigned long long *) &k.sc->tieEvents, 1ULL) & 7ULL] = d;
+        }
+        ++m;
+        if (n + rank > geo.y) {  // the ring is full: refuse (reported as an error by the next cfx_step / getter)
+            k.sc->overflow = 8;
+            continue;
+        }
+        const int slot = ringSlot(geo, head, n + rank);
+        int rp = r.routePos;
+        c.s.vid[slot] = r.vid;
+        c.s.drv[slot] = d;
+        c.s.prevDrv[slot] = r.oldDrv;
+        c.s.route[slot] = r.route;
+        c.blkW[slot] = make_int2(r.blockerVid, c.step);
+        int next, enterLLT;
+        if (d < c.n.L) {  // Router::update router.cpp:78-94, then Router::getNextDrivable from the road it stopped at
+            enterLLT = CFX_INT_MAX;
+            const int base = c.t.routeStart[r.route], len = c.t.routeStart[r.route + 1] - base;
+            const int road = c.n.laneRoad[d];
+            while (rp < len && c.t.routeRoads[base + rp] != road) ++rp;
+            next = -1;
+            if (rp < len) {
+                const int ll = c.t.nextLL[c.t.nextStart[base + rp] + c.n.laneIndex[d]];
+                next = ll < 0 ? -1 : c.n.L + ll;
+            }
+        } else {
+            enterLLT = c.step;
+            next = c.n.llEndLane[d - c.n.L];
+        }
+        c.s.routePos[slot] = rp;
+        c.meta[slot] = make_int4(r.templ, next, 0, enterLLT);
+        c.kinN[slot] = make_double2(r.dis, r.speed);
+        c.slotOf[r.vid] = slot;
+        if (rank > tailRank) {  // the last of the entrants becomes the drivable's tail
+            tailRank = rank;
+            tail.dis = r.dis;
+            tail.speed = r.speed;
+            tail.slot = slot;
+            tail.templ = r.templ;
+            tail.prevDrv = r.oldDrv;
+        }
+    }
+    n += m;
+    // the tail record of this step's end where the tail changed hands (a tail that stayed wrote its own, finishAction)
+    if (tailRank >= 0) {
+        tail.tag = c.step;
+        c.tailW[d] = tail;
+    } else if (sc.x > 0) {
+        if (n == 0) {
+            tail.slot = -1;
+        } else {  // (the general path above may have moved the tail vehicle; with a prefix of leavers this rewrites the same)
+            const int ts = ringSlot(geo, head, n - 1);
+            const double2 kt = c.kinN[ts];
+            tail.dis = kt.x;
+            tail.speed = kt.y;
+            tail.slot = ts;
+            tail.templ = c.meta[ts].x;
+            tail.prevDrv = c.s.prevDrv[ts];
+        }
+        tail.tag = c.step;
+        c.tailW[d] = tail;
+    }
+    if (n > geo.y) k.sc->overflow = 8;
+    else if (n + min(8, (geo.y + 1) / 2) > geo.y) k.sc->ringNearFull = 1;  // (the host doubles every capacity)
+    c.head[d] = head;
+    c.cnt[d] = n;
+    if (d >= c.n.L && (nWas > 0) != (n > 0)) {  // "this laneLink has vehicles on it", for the cross phase of the second form
+        const int kk = d - c.n.L, bit = c.n.llLocal[kk];
+        unsigned long long *word = &c.llOcc[c.n.llPack[kk].z + (bit >> 6)];
+        if (n > 0) atomicOr(word, 1ULL << (bit & 63));
+        else atomicAnd(word, ~(1ULL << (bit & 63)));
+    }
+    k.scratch[d] = make_int4(0, -1, -1, 0);
+    if (out) {
+        out->touched = 1;
+        out->head = head;
+        out->n = n;
+        out->tailWritten = (tailRank >= 0 || sc.x > 0) ? 1 : 0;
+        out->tail = tail;
+    }
+}
+
+__device__ inline int commitStatBlocks(const RingCommit &k) { return k.nStatBlocks; }
+// one of the statistics blocks at the end of a commit's grid
+__device__ inline void commitStatBlock(const RingCtx &c, const RingCommit &k, const VidTable &vt, int part) {
+    if (part == 0 && threadIdx.x < kJobShards) k.jobCount[threadIdx.x * kJobShardStride] = 0;
+    const bool last = ringFinishStatistics(c, vt, k, part, k.nStatBlocks);
+    if (last && threadIdx.x == 0 && k.hostMirror) {
+        k.hostMirror->sc = *k.sc;
+        k.sc->actionMaxT = 0;
+        k.hostMirror->slots = (int32_t) k.sc->active;
+        __hip_atomic_store(&k.hostMirror->progress, ((unsigned long long) (c.step + 1) << 32) | (unsigned) k.sc->active,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__device__ inline void commitClearMasks(const RingCtx &c, const RingCommit &k, int gid, int stride) {
+    for (int i = gid; i < k.nMaskWords; i += stride) c.interMask[i] = 0ULL;
+}
+// TrafficLight::passTime trafficlight.cpp:29-37 for every intersection (threads gid, gid + stride, ...)
+__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride) {
+    for (int i = gid; i < n.I; i += stride) {
+        if (n.interVirtual[i]) continue;
+        const int ps = n.interPhaseStart[i];
+        const int np = n.interPhaseStart[i + 1] - ps;
+        double rem = remain[i] - interval;
+        int ph = curPhase[i];
+        while (rem <= 0.0) {
+            ph = (ph + 1) % np;
+            rem += n.phaseTime[ps + ph];
+        }
+        remain[i] = rem;
+        curPhase[i] = ph;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, VidTable vt) {
     const int nBody = (int) gridDim.x - k.nStatBlocks;
     if ((int) blockIdx.x >= nBody) {
-        const int part = (int) blockIdx.x - nBody;
-        if (part == 0 && threadIdx.x < kJobShards) k.jobCount[threadIdx.x * kJobShardStride] = 0;
-        const bool last = ringFinishStatistics(c, vt, k, part, k.nStatBlocks);
-        if (last && threadIdx.x == 0 && k.hostMirror) {
-            k.hostMirror->sc = *k.sc;
-            k.sc->actionMaxT = 0;
-            k.hostMirror->slots = (int32_t) k.sc->active;
-            __hip_atomic_store(&k.hostMirror->progress, ((unsigned long long) (c.step + 1) << 32) | (unsigned) k.sc->active,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        commitStatBlock(c, k, vt, (int) blockIdx.x - nBody);
         return;
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = nBody * blockDim.x;
-    for (int i = gid; i < k.nMaskWords; i += stride) c.interMask[i] = 0ULL;
-    if (!k.rlTrafficLight) {
-        for (int i = gid; i < c.n.I; i += stride) {  // TrafficLight::passTime trafficlight.cpp:29-37
-            if (c.n.interVirtual[i]) continue;
-            const int ps = c.n.interPhaseStart[i];
-            const int np = c.n.interPhaseStart[i + 1] - ps;
-            double rem = k.remain[i] - c.interval;
-            int ph = k.curPhase[i];
-            while (rem <= 0.0) {
-                ph = (ph + 1) % np;
-                rem += c.n.phaseTime[ps + ph];
-            }
-            k.remain[i] = rem;
-            k.curPhase[i] = ph;
-        }
-    }
+    commitClearMasks(c, k, gid, stride);
+    if (!k.rlTrafficLight && !k.lightsDone) passTimeAll(c.n, k.curPhase, k.remain, c.interval, gid, stride);
     const int D = c.n.L + c.n.K;
-    for (int d = gid; d < D; d += stride) {
-        const int4 sc = k.scratch[d];  // {leavers, largest list index among them, entrant list, entrants}
-        const bool admitted = d < c.n.L && c.admitStep[d] == c.step;
-        if (!admitted && sc.x == 0 && sc.z < 0) continue;  // nothing happened on this drivable: nothing is written
-        const int2 geo = c.ringGeo[d];
-        int head = c.head[d];
-        int n = c.cnt[d];
-        const int nWas = n;
-        if (admitted) {  // commit this step's admission (phase 2): the FIFO pop and the vehicle's state
-            const int2 rec = c.admitRec[d];
-            k.waitHead[d] = rec.y;
-            k.vStateW[rec.x] = 1;
-            n += 1;
-        }
-        if (sc.x > 0) {
-            if (sc.y + 1 != sc.x) {
-                // leavers are not a prefix of the list (a vehicle ran past the end of its drivable before the one ahead of
-                // it did): close the gaps, stayers keep their order and move towards the tail
-                int wr = n - 1;
-                for (int r = n - 1; r >= 0; --r) {
-                    const int from = ringSlot(geo, head, r);
-                    if (c.kinN[from].y < 0.0) continue;
-                    if (wr != r) ringCopySlot(c, from, ringSlot(geo, head, wr));
-                    --wr;
-                }
-            }
-            head = (head + sc.x) & geo.y;
-            n -= sc.x;
-        }
-        int m = 0, tailRank = -1;
-        TailRec tail{};
-        for (int e = sc.z; e >= 0; e = k.movers[e].nextIn) {
-            const MoverRec r = k.movers[e];
-            int rank = 0;
-            for (int f = sc.z; f >= 0; f = k.movers[f].nextIn) {
-                if (f == e) continue;
-                const double od = k.movers[f].dis;
-                const bool tieBefore = od == r.dis && k.movers[f].vid < r.vid;
-                rank += (od > r.dis) || tieBefore;
-                if (tieBefore) k.sc->tieDrv[atomicAdd((unsigned long long *) &k.sc->tieEvents, 1ULL) & 7ULL] = d;
-            }
-            ++m;
-            if (n + rank > geo.y) {  // the ring is full: refuse (reported as an error by the next cfx_step / getter)
-                k.sc->overflow = 8;
-                continue;
-            }
-            const int slot = ringSlot(geo, head, n + rank);
-            int rp = r.routePos;
-            c.s.vid[slot] = r.vid;
-            c.s.drv[slot] = d;
-            c.s.prevDrv[slot] = r.oldDrv;
-            c.s.route[slot] = r.route;
-            c.blkW[slot] = make_int2(r.blockerVid, c.step);
-            int next, enterLLT;
-            if (d < c.n.L) {  // Router::update router.cpp:78-94, then Router::getNextDrivable from the road it stopped at
-                enterLLT = CFX_INT_MAX;
-                const int base = c.t.routeStart[r.route], len = c.t.routeStart[r.route + 1] - base;
-                const int road = c.n.laneRoad[d];
-                while (rp < len && c.t.routeRoads[base + rp] != road) ++rp;
-                next = -1;
-                if (rp < len) {
-                    const int ll = c.t.nextLL[c.t.nextStart[base + rp] + c.n.laneIndex[d]];
-                    next = ll < 0 ? -1 : c.n.L + ll;
-                }
-            } else {
-                enterLLT = c.step;
-                next = c.n.llEndLane[d - c.n.L];
-            }
-            c.s.routePos[slot] = rp;
-            c.meta[slot] = make_int4(r.templ, next, 0, enterLLT);
-            c.kinN[slot] = make_double2(r.dis, r.speed);
-            c.slotOf[r.vid] = slot;
-            if (rank > tailRank) {  // the last of the entrants becomes the drivable's tail
-                tailRank = rank;
-                tail.dis = r.dis;
-                tail.speed = r.speed;
-                tail.slot = slot;
-                tail.templ = r.templ;
-                tail.prevDrv = r.oldDrv;
-            }
-        }
-        n += m;
-        // the tail record of this step's end where the tail changed hands (a tail that stayed wrote its own, finishAction)
-        if (tailRank >= 0) {
-            tail.tag = c.step;
-            c.tailW[d] = tail;
-        } else if (sc.x > 0) {
-            if (n == 0) {
-                tail.slot = -1;
-            } else {  // (the general path above may have moved the tail vehicle; with a prefix of leavers this rewrites the same)
-                const int ts = ringSlot(geo, head, n - 1);
-                const double2 kt = c.kinN[ts];
-                tail.dis = kt.x;
-                tail.speed = kt.y;
-                tail.slot = ts;
-                tail.templ = c.meta[ts].x;
-                tail.prevDrv = c.s.prevDrv[ts];
-            }
-            tail.tag = c.step;
-            c.tailW[d] = tail;
-        }
-        if (n > geo.y) k.sc->overflow = 8;
-        else if (n + min(8, (geo.y + 1) / 2) > geo.y) k.sc->ringNearFull = 1;  // (the host doubles every capacity)
-        c.head[d] = head;
-        c.cnt[d] = n;
-        if (d >= c.n.L && (nWas > 0) != (n > 0)) {  // "this laneLink has vehicles on it", for the cross phase of the second form
-            const int kk = d - c.n.L, bit = c.n.llLocal[kk];
-            unsigned long long *word = &c.llOcc[c.n.llPack[kk].z + (bit >> 6)];
-            if (n > 0) atomicOr(word, 1ULL << (bit & 63));
-            else atomicAnd(word, ~(1ULL << (bit & 63)));
-        }
-        k.scratch[d] = make_int4(0, -1, -1, 0);
-    }
+    for (int d = gid; d < D; d += stride) commitDrivable(c, k, d);
 }
 
 // ---------------------------------------------------------------------------------------------- slow paths
