@@ -698,6 +698,9 @@ def main():
         print(json.dumps({"leg": leg, "records": recs}), flush=True)
         os._exit(0)  # (reference destructor race)
     args = parse_args()
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)  # `kill -USR1 <pid>` prints where a rank is (a hung collective)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
     job = Job(args)

@@ -36,8 +36,10 @@ def _write_json_atomic(path, obj):
 
 
 def _gunzip(src, dst):
-    with gzip.open(src, "rb") as f, open(dst, "wb") as out:
+    tmp = "%s.tmp%d" % (dst, os.getpid())  # (write-then-rename: several ranks may materialize the same scenario at once)
+    with gzip.open(src, "rb") as f, open(tmp, "wb") as out:
         shutil.copyfileobj(f, out)
+    os.replace(tmp, dst)
 
 
 def materialize(name, workdir=None, flow_file=None, **config):
@@ -62,7 +64,9 @@ def materialize(name, workdir=None, flow_file=None, **config):
     if flow_file is not None:
         flow_name = os.path.basename(flow_file)
         if os.path.abspath(os.path.dirname(flow_file)) != os.path.abspath(d):
-            shutil.copyfile(flow_file, os.path.join(d, flow_name))
+            tmp = os.path.join(d, "%s.tmp%d" % (flow_name, os.getpid()))
+            shutil.copyfile(flow_file, tmp)
+            os.replace(tmp, os.path.join(d, flow_name))
     cfg = {
         "interval": 1.0, "seed": 0, "dir": d + "/", "roadnetFile": "roadnet.json", "flowFile": flow_name,
         "rlTrafficLight": False, "laneChange": False, "saveReplay": False,
@@ -75,8 +79,7 @@ def materialize(name, workdir=None, flow_file=None, **config):
 
     tag = "_".join("%s-%s" % (k, _val(config[k])) for k in sorted(config)) if config else "default"
     path = os.path.join(d, "config_%s_%s.json" % (flow_name.replace(".json", ""), tag))
-    with open(path, "w") as f:
-        json.dump(cfg, f)
+    _write_json_atomic(path, cfg)  # (another rank may be reading it: a rewrite must never show a truncated file)
     return path
 
 

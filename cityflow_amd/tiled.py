@@ -57,7 +57,11 @@ class DistributedEngine:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         if rows * cols != self.world:
             raise ValueError("rows * cols must equal the world size (one tile per process)")
-        self._eng = _cityflow.TiledEngine(config_file, rows, cols, [self.rank], backend_library)
+        built_error = None
+        try:
+            self._eng = _cityflow.TiledEngine(config_file, rows, cols, [self.rank], backend_library)
+        except Exception as exc:  # noqa: BLE001 - agreed on below: every rank must leave the constructor the same way
+            built_error = str(exc)[:300]
         # host-side group for the halo (the buffers live in host memory); reuse the default group if it is gloo
         if halo_group is not None:
             self._halo = halo_group
@@ -65,6 +69,9 @@ class DistributedEngine:
             self._halo = dist.group.WORLD
         else:  # bounded waits: a rank that failed to set up must not leave the others in a barrier for the default 30 min
             self._halo = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+        if not self._all_ok(built_error is None):  # (a rank that raised alone would leave the others in the collectives below)
+            raise RuntimeError("DistributedEngine: the tile could not be built on every rank" +
+                               (": " + built_error if built_error else ""))
         self._peers = self._eng.peers(0)
         self._send = torch.from_numpy(self._eng.send_buffer(0))  # zero-copy views of the C++ staging buffers
         self._recv = torch.from_numpy(self._eng.recv_buffer(0))
