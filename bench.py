@@ -333,7 +333,8 @@ def roofline_from_profile(prof, vehicle_steps, workload_tag, note, with_traffic=
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_us": avg_s * 1e6, "vehicles_per_launch": vehicles_per_launch,
         "algorithmic_bytes_per_vehicle": ACTION_BYTES_PER_VEHICLE, "measured_over": note,
-        "kernel_us_per_step": {k: ms / max(n, 1) * 1e3 for k, (ms, n) in prof.items() if n},
+        "kernel_us_per_step": {k: ms / act_n * 1e3 for k, (ms, n) in prof.items() if n},  # (a kernel that runs in some steps only counts its share)
+        "kernel_launches_per_step": {k: n / float(act_n) for k, (ms, n) in prof.items() if n},
         "sum_kernel_ms_per_step": sum(ms for ms, _n in prof.values()) / act_n,
     }
 
@@ -388,6 +389,7 @@ def parse_args():
     ap.add_argument("--weak", action="store_true",
                     help="N>1: grow the grid with N (every GPU owns a 30x30 block) instead of tiling the N=1 workload itself")
     ap.add_argument("--tile-block", type=int, default=30, help=argparse.SUPPRESS)
+    ap.add_argument("--cfx", default="", help=argparse.SUPPRESS)  # developer: implementation choices, "key=value,key=value"
     args = ap.parse_args()
     if args.scale_steps is None:
         args.scale_steps = 50 if args.backend_lib == "" else 0
@@ -682,7 +684,7 @@ def scale_leg(job, args, n_steps):
         prof = eng._profile_read()
         eng._profile_enable(False)
         s1 = eng._scalars()
-        roof = roofline_from_profile(prof, s1["vehicle_steps"] - s0["vehicle_steps"], "%dx%d" % (args.scale_grid, args.scale_grid),
+        roof = roofline_from_profile(prof, s1["vehicle_steps"] - s0["vehicle_steps"], scen,
                                      "%d instrumented steps" % n_steps)
         if roof:
             roof["config"] = out
@@ -730,6 +732,9 @@ def main():
     else:
         workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_rank%d" % rank)
         cfg = build_workload(workdir, seed=rank, scenario=args.scenario, n_extra=args.extra_flows)
+        if args.cfx:
+            cfg = with_config(cfg, "cfx", cfx={k: (int(v) if v.lstrip("-").isdigit() else v)
+                                                for k, v in (kv.split("=") for kv in args.cfx.split(","))})
         if on_gpu:
             eng = _cityflow.Engine(cfg, 1)  # HIP engine on device LOCAL_RANK; raises if the extension/GPU is missing
             assert eng.backend_name() == "hip-gfx950"
@@ -904,6 +909,7 @@ def main():
                 "ranks_share_devices": job.shared_devices if world > 1 else None,
                 "halo": halo_name,
                 "layout": layout,
+                "cfx": args.cfx or None,
                 "halo_probe_failures": halo_notes or None,
                 "host_us_per_step": ({"spawner": round((host1[0] - host0[0]) / args.steps * 1e6, 1),
                                       "submit": round((host1[1] - host0[1]) / args.steps * 1e6, 1)} if tiled else None),
