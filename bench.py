@@ -789,8 +789,10 @@ def main():
 
     # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream).  Tiled runs: every
     #      rank keeps stepping (the tiles are coupled), rank 0 instruments its own tile, halo kernels included.
+    # (not where several ranks share one device: their kernels take turns on it, so per-kernel times say nothing about a tile,
+    # and the instrumented rank — every launch bracketed by events — falls behind its neighbour's bounded halo wait)
     roofline = None
-    if on_gpu and args.profile_steps > 0 and (rank == 0 or tiled):
+    if on_gpu and args.profile_steps > 0 and (rank == 0 or tiled) and not (tiled and job.shared_devices):
         scp0 = eng.local_scalars() if tiled else eng._scalars()
         if rank == 0:
             (eng._eng._profile_enable(0, True) if tiled else eng._profile_enable(True))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CFX_ABI_VERSION 3
+#define CFX_ABI_VERSION 4
 
 typedef enum cfx_status {
     CFX_OK = 0,

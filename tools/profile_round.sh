@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collect a round's profiles on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <tag> [workload]        e.g. r03_v2 bench | r03_v2 gen_100x100 | r03_v2 grid_6x6
+#   tools/profile_round.sh <tag> [workload] [extra bench.py flags]      e.g. r03_v2 bench | r03_v2 gen_100x100 | r03_v2 grid_6x6
+#   (extra flags, e.g. "--cfx layout=ring,ringLanesPerWave=30000", select a non-default form of the step; say so in the tag)
 # kernel trace of the bench command on that workload + FETCH_SIZE / WRITE_SIZE in separate PMC passes (MI355X_MICROARCH.md),
 # summaries written under gpurun_out/<tag>_<workload>_* (copy the ones to keep into profiles/).  The full default bench line
 # (all legs) is a separate call: `python bench.py > gpurun_out/<tag>_bench.json`.
@@ -15,7 +16,7 @@ case $wl in
   gen_100x100) extra="--scenario gen_100x100 --extra-flows 33000" ;;
   *) extra="--scenario $wl --extra-flows 0" ;;
 esac
-common="--cpu-seconds 0 --rl-seconds 0 --scale-steps 0 $extra"
+common="--cpu-seconds 0 --rl-seconds 0 --scale-steps 0 $extra ${3:-}"
 pre=${tag}_${wl}
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $out/${pre}_trace -o bench -- python $OLDPWD/bench.py $common --profile-steps 0 > $out/${pre}_trace.log 2>&1
