@@ -1144,7 +1144,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const bool useBig = !v2 && (e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000);  // which form of the cross phase (§4)
         // This step's commit rides with the next step's admission (one launch less per step) where the step runs kr_cross,
         // which then advances the lights; the previous step's, if it is still pending, goes with this step's admission.
-        const bool deferCommit = e->ringMerge && !v2 && !useBig && !dbg && !e->tiled;
+        const bool deferCommit = e->ringMerge && !v2 && !dbg && !e->tiled;
         if (e->commitPending && v2) {
             if ((rc = e->settle())) return rc;
         }
@@ -1235,7 +1235,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         else if (useBig)
             e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
-                      dim3(kCross2Block), c, ro, jq);
+                      dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
         {
             // one 16-lane group per queued vehicle; sized by the job count of the last step the device has reported (every
@@ -1367,7 +1367,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
     if (useBig)
         e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
-                  dim3(kCross2Block), c, ao, jq);
+                  dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0});
     else
         e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),

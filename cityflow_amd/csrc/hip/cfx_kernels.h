@@ -879,8 +879,32 @@ constexpr int kCross2Block = 256;
 constexpr int kCross2Jobs = 64;
 constexpr int kCross2Work = 2048;
 
+struct RingLights {  // TrafficLight::passTime of the step, done by the cross kernel when the step's commit is deferred (ring layout)
+    int32_t *curPhase;
+    double *remain;
+    int on;
+};
+// TrafficLight::passTime trafficlight.cpp:29-37 for every intersection (threads gid, gid + stride, ...)
+__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride) {
+    for (int i = gid; i < n.I; i += stride) {
+        if (n.interVirtual[i]) continue;
+        const int ps = n.interPhaseStart[i];
+        const int np = n.interPhaseStart[i + 1] - ps;
+        double rem = remain[i] - interval;
+        int ph = curPhase[i];
+        while (rem <= 0.0) {
+            ph = (ph + 1) % np;
+            rem += n.phaseTime[ps + ph];
+        }
+        remain[i] = rem;
+        curPhase[i] = ph;
+    }
+}
+
 template <bool LC, class C = StepCtx, class Out = ActionOut>
-__global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q) {
+__global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0}) {
+    // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
+    if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     __shared__ int shardEnd[kJobShards];
     __shared__ int sS[kCross2Jobs], sT1[kCross2Jobs], sTempl[kCross2Jobs], sFirst[kCross2Jobs];

@@ -650,12 +650,6 @@ __device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action 
 // Second half of Vehicle::getIntersectionRelatedSpeed (k_cross of cfx_kernels.h) from job records: one 16-lane group per
 // queued vehicle, one cross per lane and round, first failing lane of the first failing round = the first cross that
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
-struct RingLights {  // TrafficLight::passTime of the step, done by the cross kernel when the step's commit is deferred
-    int32_t *curPhase;
-    double *remain;
-    int on;
-};
-__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride);
 
 __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs, RingLights lights) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
@@ -1428,22 +1422,6 @@ __device__ inline void commitStatBlock(const RingCtx &c, const RingCommit &k, co
 }
 __device__ inline void commitClearMasks(const RingCtx &c, const RingCommit &k, int gid, int stride) {
     for (int i = gid; i < k.nMaskWords; i += stride) c.interMask[i] = 0ULL;
-}
-// TrafficLight::passTime trafficlight.cpp:29-37 for every intersection (threads gid, gid + stride, ...)
-__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride) {
-    for (int i = gid; i < n.I; i += stride) {
-        if (n.interVirtual[i]) continue;
-        const int ps = n.interPhaseStart[i];
-        const int np = n.interPhaseStart[i + 1] - ps;
-        double rem = remain[i] - interval;
-        int ph = curPhase[i];
-        while (rem <= 0.0) {
-            ph = (ph + 1) % np;
-            rem += n.phaseTime[ps + ph];
-        }
-        remain[i] = rem;
-        curPhase[i] = ph;
-    }
 }
 
 __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, VidTable vt) {
