@@ -168,6 +168,10 @@ __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, Action
     if (s >= S) return;
     SlotIn in = loadSlot(c, s);
     if (in.vid < 0) return;
+    if (c.n.laneGhost && in.d < c.n.L && c.n.laneGhost[in.d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
+        o.keep(s, in.dis, in.speed);
+        return;
+    }
     if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
     actionOneRounds(c, o, tv, s, in, PushJob{q});
 }

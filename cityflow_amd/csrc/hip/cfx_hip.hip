@@ -164,7 +164,7 @@ struct cfx_engine {
     TailRec *dTail[2] = {nullptr, nullptr}, *dTailNow = nullptr;
     int4 *dGate4 = nullptr;
     bool tailsValid = false;           // the records describe the current generation (false after reset / load / resize)
-    bool useTails() const { return !ring && !lc.on && !tiled; }
+    bool useTails() const { return !ring && !lc.on; }  // (tiles too since round 3: the halo kernels keep the cut lanes' records up)
 
     // ---- ring layout (cfx_ring_kernels.h): per-drivable ring segments, committed in place ----
     bool ring = false;                 // this engine uses it (decided at cfx_create; cfx_halo_config may still switch to dense)

@@ -1580,6 +1580,25 @@ __device__ inline void haloClearSlot(const SlotArrays &s, int slot) {
     s.blocker[slot] = -1;
 }
 
+// Tiles on the dense kernels with tail records (kd_admit / kd_action): the halo changes a cut lane's last vehicle after the
+// step's scatter has written the lane's tail record — the proxy of a ghost lane, the migrants appended to an import lane —
+// so the halo kernels rewrite that record.  They run after cfx_step has returned: `c` is already the NEXT step's context and
+// the records of the step that has just finished are its tailR (tag = c.step - 1).
+__device__ inline void haloWriteTail(const StepCtx &c, int lane, int slot) {
+    if (!c.tailR) return;
+    TailRec r{};
+    r.slot = -1;
+    if (slot >= 0) {
+        r.dis = c.s.dis[slot];
+        r.speed = c.s.speed[slot];
+        r.slot = slot;
+        r.templ = c.s.templ[slot];
+        r.prevDrv = c.s.prevDrv[slot];
+    }
+    r.tag = c.step - 1;
+    const_cast<TailRec *>(c.tailR)[lane] = r;
+}
+
 __device__ inline int haloGlobalPrev(const StepCtx &c, const HaloDev &h, int prevDrv) {
     if (prevDrv >= c.n.L) return h.llGlobal[prevDrv - c.n.L];
     if (prevDrv <= -2) return -prevDrv - 2;  // a migrant's laneLink of origin, kept as its global id
@@ -1634,6 +1653,7 @@ __device__ inline void haloExportLane(const StepCtx &c, int32_t *cnt, const Halo
             for (int s = base + 1; s < base + n; ++s) haloClearSlot(c.s, s);
             cnt[g] = 1;
             atomicAdd((unsigned long long *) &sc->active, (unsigned long long) (-(long long) in));
+            haloWriteTail(c, g, base);
         }
         return;
     }
@@ -1726,6 +1746,7 @@ __global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, HaloIO io, Vid
         if (m > 0) {
             cnt[l] = n + m;
             atomicAdd((unsigned long long *) &sc->active, (unsigned long long) m);
+            haloWriteTail(c, l, base + n + m - 1);
         }
         return;
     }
@@ -1738,6 +1759,7 @@ __global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, HaloIO io, Vid
         for (int s = base + (t.vid >= 0 ? 1 : 0); s < base + n; ++s) haloClearSlot(c.s, s);
         if (t.vid < 0) {
             cnt[g] = 0;
+            haloWriteTail(c, g, -1);
             return;
         }
         int prev = -1;
@@ -1758,6 +1780,7 @@ __global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, HaloIO io, Vid
         c.s.dis[base] = t.dis;
         c.s.speed[base] = t.speed;
         cnt[g] = 1;
+        haloWriteTail(c, g, base);
     }
 }
 

@@ -122,10 +122,12 @@ def test_forced_choices_irregular_networks(mod, scen, workdir, seed, cross, layo
     assert hip.get_vehicle_count() > 150
 
 
-@pytest.mark.parametrize("n,flows_per_100,min_running,twin_steps,layout", [
-    (60, 333, 300000, 20, "dense"), (60, 333, 300000, 20, "ring"), (100, 333, 900000, 8, "auto")])
-def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_running, twin_steps, layout):
-    """Sizes where the engine switches to its throughput kernels by itself (k_cross2 above 240 k slots)."""
+@pytest.mark.parametrize("n,flows_per_100,min_running,twin_steps,layout,rl", [
+    (60, 333, 300000, 20, "dense", False), (60, 333, 300000, 20, "ring", False), (100, 333, 900000, 8, "auto", True)])
+def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_running, twin_steps, layout, rl):
+    """Sizes where the engine switches to its throughput kernels by itself (k_cross2 above 240 k slots).  The 100x100 case is
+    BASELINE.json configs[4] as an RL agent drives it: rlTrafficLight, a new phase for every signal through set_tl_phases
+    (during the build-up and between the compared steps) and the lane-count observation read every step — HIP == twin."""
     base = scen.generate_grid(n, n, workdir)
     d = os.path.dirname(base)
     n_extra = n * n * flows_per_100 // 100
@@ -135,17 +137,27 @@ def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_
                          base_flow=os.path.join(d, "flow.json"), end_time=240)
     cfg = os.path.join(d, "config_pin.json")
     with open(cfg, "w") as f:
-        json.dump(dict(json.load(open(base)), flowFile=os.path.basename(flow)), f)
+        json.dump(dict(json.load(open(base)), flowFile=os.path.basename(flow), rlTrafficLight=rl), f)
     hip = mod.Engine(_with_cfx(cfg, layout=layout), 1)
-    for _ in range(300):
+    rng = np.random.default_rng(99)
+    n_inter = len(hip.intersection_ids())
+    for s in range(300):
+        if rl and s % 15 == 0:
+            hip.set_tl_phases(rng.integers(0, 8, size=n_inter).astype(np.int32))
         hip.next_step()
     assert hip.get_vehicle_count() >= min_running
     tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
     tw.load(hip.snapshot())
     assert_same_state(hip, tw, "%dx%d after the transfer" % (n, n))
     for s in range(twin_steps):
+        if rl and s % 2 == 0:  # the agent's action
+            ph = rng.integers(0, 8, size=n_inter).astype(np.int32)
+            hip.set_tl_phases(ph)
+            tw.set_tl_phases(ph)
         hip.next_step()
         tw.next_step()
+        if rl:  # the agent's observation
+            assert np.array_equal(hip.get_lane_vehicle_count_array(), tw.get_lane_vehicle_count_array()), s
         if s % 4 == 3 or s == twin_steps - 1:
             assert_same_state(hip, tw, "%dx%d %s step %d after the transfer" % (n, n, layout, s + 1))
 
