@@ -58,8 +58,15 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
 
 // Engine::handleWaiting + Lane::available from the lane's tail record; this step's view of every drivable's tail, the wide
 // gate records, and the compaction scratch of the step (k_admit of cfx_kernels.h does the same through the slots).
-__global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, CompactScratch cs) {
+// A step's few spawn records travel in the kernel arguments (SpawnBatch, cfx_ring_kernels.h: kr_admit does the same): each
+// lane's thread links its own records into its waiting queue, block 0 writes the vehicle table — no k_spawn_link launch.
+// (Tiles: a record whose lane belongs to another tile has lane -1; only its vehicle-table row is written.)
+__global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep, int32_t *waitHead, VidTable vt, CompactScratch cs,
+                                                   const SpawnBatch batch) {
     __shared__ cfx_vehicle_template sT[kLdsTempl];
+    __shared__ int sLane[kAdmitRecs];
+    const int nRecs = batch.n, firstNewVid = batch.firstNewVid;
+    if ((int) threadIdx.x < nRecs) sLane[threadIdx.x] = batch.lane[threadIdx.x];
     const cfx_vehicle_template *tv = c.t.templ;
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
@@ -89,6 +96,53 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
         pending = vt.pendingCustom[w];
     }
     __syncthreads();
+    if (nRecs > 0) {
+        // the vehicle table of the new vehicles (k_spawn_link): block 0.  Nobody reads these rows in this kernel — a vehicle
+        // that is admitted in the step it appears in is taken from its record
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < nRecs; i += blockDim.x) {
+                const int v = firstNewVid + batch.vidOff[i];
+                vt.priority[v] = batch.priority[i];
+                vt.templ[v] = batch.templ[i];
+                vt.route[v] = batch.route[i];
+                vt.enterTime[v] = batch.enterTime;
+                vt.state[v] = 0;
+                vt.pendingCustom[v] = 0;
+            }
+        if (isLane) {
+            // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367; nextWait[] of a new vehicle was pre-set to -1): this
+            // lane's records, in any order — each hangs behind its predecessor, or becomes the head where the predecessor
+            // has left the queue
+            int lo = 0, hi = nRecs;  // first record of this lane
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sLane[mid] < d) lo = mid + 1;
+                else hi = mid;
+            }
+            int headRec = -1;
+            for (int j = lo; j < nRecs && sLane[j] == d; ++j) {
+                const int pv = batch.prevWait[j], v = firstNewVid + batch.vidOff[j];
+                bool becomesHead = pv < 0;
+                if (pv >= firstNewVid) vt.nextWait[pv] = v;      // predecessor in this very batch: certainly still queued
+                else if (pv >= 0) {
+                    if (vt.state[pv] != 0) becomesHead = true;  // predecessor already admitted => the FIFO is empty
+                    else vt.nextWait[pv] = v;
+                }
+                if (becomesHead) headRec = j;
+            }
+            if (headRec >= 0) {
+                w = firstNewVid + batch.vidOff[headRec];
+                wt = batch.templ[headRec];
+                route = batch.route[headRec];
+                pending = 0;
+                nextWait = -1;
+                waitHead[d] = w;
+            }
+            if (w >= 0)  // whoever was hung behind the head just now (this thread's own store: taken from the record)
+                for (int j = lo; j < nRecs && sLane[j] == d; ++j)
+                    if (batch.prevWait[j] == w) nextWait = firstNewVid + batch.vidOff[j];
+        }
+    }
     if (!inRange) return;
     cs.leaveCnt[d] = 0;
     cs.maxLeaveIdx[d] = -1;

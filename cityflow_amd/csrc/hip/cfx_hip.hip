@@ -1045,7 +1045,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // ring layout: a step's few records go with kr_admit's arguments (each lane's thread links its own): no launch.  They
         // fit if they are few, all for lanes of this engine, and all enter at the same time (what a host spawner produces:
         // Engine::getCurrentTime); record i of the batch is vehicle spawned + i, whatever order they came in
-        bool inArgs = e->ring && n <= kAdmitRecs;
+        bool inArgs = (e->ring || e->useTails()) && n <= kAdmitRecs;  // (kr_admit / kd_admit take the batch)
         if (inArgs) {
             batch.n = (int) n;
             batch.firstNewVid = (int) e->spawned;
@@ -1054,7 +1054,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             bool seen[kAdmitRecs] = {};
             for (int i = 0; inArgs && i < n; ++i) {
                 const int64_t off = (int64_t) recs[i].vid - e->spawned;
-                inArgs = off >= 0 && off < n && !seen[off] && recs[i].lane >= 0 && recs[i].enter_time == batch.enterTime &&
+                inArgs = off >= 0 && off < n && !seen[off] && recs[i].lane >= -1 && recs[i].enter_time == batch.enterTime &&
                          recs[i].templ < 32768;
                 if (inArgs) seen[off] = true;
                 order[i] = i;
@@ -1309,7 +1309,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->tailsValid = true;
     }
     const size_t slotBound = std::min(need, e->slotCap);
-    if (tails) e->launch(PK_ADMIT, kd_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
+    if (tails) e->launch(PK_ADMIT, kd_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
     else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
     if (e->lc.on) {
