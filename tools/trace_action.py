@@ -4,13 +4,13 @@ sys.path.insert(0, ROOT)
 import bench
 from cityflow_amd import _cityflow
 lib = os.path.join(ROOT, "tools", "libexp_trace.so")
-cfg = bench.build_workload("/tmp/cfa_exp", 0)
+cfg = bench.with_config(bench.build_workload("/tmp/cfa_exp", 0), "trace", cfx={"ringLanesPerWave": 20014})  # block form, 14 lanes per block
 dll = ctypes.CDLL(lib)
 eng = _cityflow.Engine._with_backend(cfg, 1, lib)
 dll.cfx_trace_dump(b"/tmp/x", 0)  # arm
 for _ in range(320): eng.next_step()
 eng.sync()
-nb = 11160 // 16 + 1 + 2 * ((32400 + 255) // 256)
+nb = (11160 + 13) // 14 + 2 * ((32400 + 255) // 256)
 dll.cfx_trace_dump(b"/tmp/trace.bin", 4096 + 2048)
 full = np.fromfile("/tmp/trace.bin", dtype=np.int64).reshape(-1, 8)
 a = full[:nb]
@@ -26,7 +26,7 @@ print("  busy blocks: counts done avg %.2f | record loaded avg %.2f max %.2f | c
 print("  idle blocks end avg %.2f max %.2f" % (xus(x[len(busy):, 4]).mean(), xus(x[len(busy):, 4]).max()))
 t0 = a[:, 0].min()
 us = lambda x: (x - t0) / 100.0  # 100 MHz wall clock
-nl = 11160 // 16 + 1
+nl = (11160 + 13) // 14
 lane, ll, st = a[:nl], a[nl:nl + 127], a[nl + 127:]
 print("blocks", len(a), "first start 0, last start %.2f us" % us(a[:, 0].max()))
 for name, blk in (("lane blocks", lane), ("laneLink blocks", ll)):
