@@ -18,7 +18,7 @@ __device__ __forceinline__ bool viewerIsNew(const StepCtx &c, const SlotIn &in, 
 template <bool LC>
 __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template &t, int s, int d, int vid,
                                     double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int /*idx*/,
-                                    int /*nNow*/, LeaverPrefetch lp) {
+                                    int /*nNow*/, LeaverPrefetch lp, int /*flags*/ = -1) {
     static_assert(!LC, "lane change runs on k_action");
     v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
     v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);

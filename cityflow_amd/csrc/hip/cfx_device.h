@@ -158,6 +158,9 @@ struct LeaverPrefetch {
     bool valid;
     double nextLen;  // length of the next drivable (nd0 >= 0)
     int vid, route, routePos;
+    // ring layout, the LAST vehicle of its drivable (it rewrites the drivable's tail record): where it came from
+    bool prevValid;
+    int prevDrv;
 };
 
 // Everything the per-step kernels read.  Passed by value (kernel argument segment).

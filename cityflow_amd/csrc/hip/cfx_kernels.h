@@ -585,6 +585,7 @@ struct SlotIn {  // everything the action phase loads by slot index alone
     int4 hop;        // the laneLinks leaving the vehicle's lane if the loader holds them (x = -2: not), see findHeadLeader
     bool laneAdmitted;  // ring layout: the vehicle's lane admitted a vehicle this step
     int endLane;        // the lane behind the vehicle's next laneLink if the loader knows it (-1: read it from the gate record)
+    int lastRoadFlags;  // ring layout: the slot's flags with bit 1 = "on the last road of its route" (-1: not known, walk the route)
 };
 
 // Every load that depends only on the slot index is issued up front, before the first branch, so the memory
@@ -611,6 +612,7 @@ __device__ __forceinline__ SlotIn loadSlot(const StepCtx &c, int s) {
     in.hop = make_int4(-2, -2, -2, -2);
     in.laneAdmitted = false;
     in.endLane = -1;
+    in.lastRoadFlags = -1;
     return in;
 }
 

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void kr2_admit(RingCtx c, int32_t *admitSte
             c.s.prevDrv[slot] = -1;
             c.s.routePos[slot] = 0;
             c.s.route[slot] = route;
-            c.meta[slot] = make_int4(wt, next, pending, CFX_INT_MAX);  // (enterLaneLinkTime: ControllerInfo ctor vehicle.cpp:10-13)
+            c.meta[slot] = make_int4(wt, next, pending | ((next < 0 && isLastRoad(c, lane, route)) ? 2 : 0), CFX_INT_MAX);  // (ControllerInfo ctor vehicle.cpp:10-13; flags bit 1: finishAction)
             c.kin[slot] = make_double2(0.0, v0);
             c.slotOf[w] = slot;
             c.admitRec[lane] = make_int2(w, nextWait);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(B, 4) void kw2_action(RingCtx c, RingOut o, JobQueu
         int vid = 0;
         if (custom) {
             vid = c.s.vid[s];
-            c.meta[s].z = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+            c.meta[s].z = flags & ~1;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
         }
         // which of its lane's laneLinks the vehicle takes next
         int4 hop = make_int4(-2, -2, -2, -2);
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(B, 4) void kw2_action(RingCtx c, RingOut o, JobQueu
             }
             v = min2(v, iv);
         }
-        finishAction<false>(c, o, tt, s, d, vid, speed, dis, dlen, nd0, v, -1, idx, nNow, lp);
+        finishAction<false>(c, o, tt, s, d, vid, speed, dis, dlen, nd0, v, -1, idx, nNow, lp, flags);
     }
 }
 

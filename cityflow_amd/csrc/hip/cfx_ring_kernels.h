@@ -176,10 +176,17 @@ constexpr int kRingIdxBits = 20;  // list index inside a drivable (ring capaciti
 template <bool LC>
 __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cfx_vehicle_template &t, int s, int d, int /*vid*/,
                                     double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int idx = -1,
-                                    int nNow = -1, LeaverPrefetch lp = LeaverPrefetch{false, 0.0, 0, 0, 0}) {
+                                    int nNow = -1, LeaverPrefetch lp = LeaverPrefetch{false, 0.0, 0, 0, 0}, int flags = -1) {
     static_assert(!LC, "the ring layout does not run lane change");
     v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
-    v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);
+    // speedTail of cfx_kernels.h (vehicle.cpp:325-331).  "Is this the last road of the route" (Router::onValidLane, router.h:66-68)
+    // is bit 1 of the slot's flags, set when the vehicle entered the lane: a vehicle on its last road otherwise walks
+    // route -> routeStart -> routeRoads, three dependent loads in the middle of its wavefront's phase, every step
+    if (nd0 < 0) {
+        const bool lastRoad = flags >= 0 ? (flags & 2) != 0 : isLastRoad(c, d, c.s.route[s]);
+        if (!lastRoad) v = min2(v, noCollisionSpeed(0, 1, speed, t.max_neg_acc, dlen - dis, c.interval, t.min_gap));
+    }
+    v = max2(v, speed - t.max_neg_acc * c.interval);
     // computeMove (cfx_kernels.h) with the first hop's two lengths in registers
     double deltaDis;
     if (v < 0) {
@@ -226,7 +233,7 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
             r.speed = v;
             r.slot = s;
             r.templ = c.meta[s].x;
-            r.prevDrv = c.s.prevDrv[s];
+            r.prevDrv = lp.prevValid ? lp.prevDrv : c.s.prevDrv[s];
             r.tag = c.step;
             c.tailW[d] = r;
         }
@@ -484,7 +491,8 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 c.s.prevDrv[slot] = -1;
                 c.s.routePos[slot] = 0;
                 c.s.route[slot] = route;
-                c.meta[slot] = make_int4(wt, next, pending, CFX_INT_MAX);  // (enterLaneLinkTime: ControllerInfo ctor vehicle.cpp:10-13)
+                const int onLast = (next < 0 && isLastRoad(c, lane, route)) ? 2 : 0;  // (flags bit 1, see finishAction)
+                c.meta[slot] = make_int4(wt, next, pending | onLast, CFX_INT_MAX);  // (enterLaneLinkTime: ControllerInfo ctor vehicle.cpp:10-13)
                 c.kin[slot] = make_double2(0.0, v0);
                 c.slotOf[w] = slot;
                 c.admitRec[lane] = make_int2(w, nextWait);
@@ -788,6 +796,10 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         lp.route = c.s.route[s];
         lp.routePos = c.s.routePos[s];
     }
+    if (in.idx >= 0 && in.idx == in.nNow - 1) {  // (ring layout) the drivable's last vehicle: it will rewrite the tail record
+        lp.prevValid = true;
+        lp.prevDrv = c.s.prevDrv[s];
+    }
 
     // ================= round B: what hangs on the gate record (only where the end lane was not known above)
     if (approaching && !endKnown) {
@@ -912,7 +924,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         }
         v = min2(v, iv);
     }
-    finishAction<false>(c, o, t, s, d, in.vid, speed, dis, dlen, nd0, v, -1, in.idx, in.nNow, lp);
+    finishAction<false>(c, o, t, s, d, in.vid, speed, dis, dlen, nd0, v, -1, in.idx, in.nNow, lp, in.lastRoadFlags);
 }
 
 // ---------------------------------------------------------------------------------------------- phase 3 + 4
@@ -1016,6 +1028,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             in.templIdx = mv.x;
             in.nd0 = mv.y;
             in.flags = mv.z;
+            in.lastRoadFlags = mv.z;
             sDis[t] = in.dis;
             sSpeed[t] = in.speed;
             sTempl[t] = in.templIdx;
@@ -1037,7 +1050,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             }
             if (in.flags & 1) {
                 in.vid = c.s.vid[slot];
-                c.meta[slot].z = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+                c.meta[slot].z = in.flags & ~1;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
             }
             in.lm = sLM[i];
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
@@ -1162,6 +1175,7 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
             in.templIdx = mv.x;
             in.nd0 = mv.y;
             in.flags = mv.z;
+            in.lastRoadFlags = mv.z;
         }
         // the leader inside the drivable is the lane below (all lanes take part in the exchange)
         const double disUp = __shfl_up(in.dis, 1, 64), speedUp = __shfl_up(in.speed, 1, 64);
@@ -1178,7 +1192,7 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
         if (idx > 0) in.leaderSlot = ringSlot(geo, head, idx - 1);
         if (in.flags & 1) {
             in.vid = c.s.vid[slot];
-            c.meta[slot].z = 0;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+            c.meta[slot].z = in.flags & ~1;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
         }
         in.lm = sLM[i];
         in.hop = make_int4(-2, -2, -2, -2);
@@ -1339,7 +1353,7 @@ __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, con
         c.s.prevDrv[slot] = r.oldDrv;
         c.s.route[slot] = r.route;
         c.blkW[slot] = make_int2(r.blockerVid, c.step);
-        int next, enterLLT;
+        int next, enterLLT, onLast = 0;
         if (d < c.n.L) {  // Router::update router.cpp:78-94, then Router::getNextDrivable from the road it stopped at
             enterLLT = CFX_INT_MAX;
             const int base = c.t.routeStart[r.route], len = c.t.routeStart[r.route + 1] - base;
@@ -1350,12 +1364,13 @@ __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, con
                 const int ll = c.t.nextLL[c.t.nextStart[base + rp] + c.n.laneIndex[d]];
                 next = ll < 0 ? -1 : c.n.L + ll;
             }
+            if (next < 0 && road == c.t.routeRoads[base + len - 1]) onLast = 2;  // Router::isLastRoad: flags bit 1 (finishAction)
         } else {
             enterLLT = c.step;
             next = c.n.llEndLane[d - c.n.L];
         }
         c.s.routePos[slot] = rp;
-        c.meta[slot] = make_int4(r.templ, next, 0, enterLLT);
+        c.meta[slot] = make_int4(r.templ, next, onLast, enterLLT);
         c.kinN[slot] = make_double2(r.dis, r.speed);
         c.slotOf[r.vid] = slot;
         if (rank > tailRank) {  // the last of the entrants becomes the drivable's tail
@@ -1464,7 +1479,7 @@ __global__ void kr_gather(RingCtx c, const int32_t *off, RingDense out, int want
         const int4 mv = c.meta[s];
         out.enterLLT[o + i] = mv.w;
         out.routePos[o + i] = c.s.routePos[s];
-        out.flags[o + i] = (uint8_t) mv.z;
+        out.flags[o + i] = (uint8_t) (mv.z & 1);
         out.dis[o + i] = kv.x;
         out.speed[o + i] = kv.y;
         if (wantLeader) {  // Vehicle::updateLeaderAndGap as of now (findLeader of cfx_kernels.h)
@@ -1505,7 +1520,8 @@ __global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTa
         c.s.route[s] = route;
         const_cast<int2 *>(c.blkR)[s] = make_int2(in.blockerVid[j], c.step - 1);
         c.kin[s] = make_double2(in.dis[j], in.speed[j]);
-        c.meta[s] = make_int4(vt.templ[v], nextOf(c.n, c.t, d, route, in.routePos[j]), in.flags[j], in.enterLLT[j]);
+        const int nextD = nextOf(c.n, c.t, d, route, in.routePos[j]);
+        c.meta[s] = make_int4(vt.templ[v], nextD, (in.flags[j] & 1) | ((nextD < 0 && isLastRoad(c, d, route)) ? 2 : 0), in.enterLLT[j]);
         c.slotOf[v] = s;
         if (i == n - 1) {
             TailRec r;
@@ -1548,7 +1564,9 @@ __global__ void kr_set_route(RingCtx c, int vid, int route) {
     if (s < 0) return;
     c.s.route[s] = route;
     c.s.routePos[s] = 0;
-    c.meta[s].y = nextOf(c.n, c.t, c.s.drv[s], route, 0);
+    const int dNow = c.s.drv[s], nextD = nextOf(c.n, c.t, dNow, route, 0);
+    c.meta[s].y = nextD;
+    c.meta[s].z = (c.meta[s].z & 1) | ((nextD < 0 && isLastRoad(c, dNow, route)) ? 2 : 0);
 }
 __global__ void kr_find_vehicle(RingCtx c, int vid, int32_t *out /*[2]: drivable, routePos*/) {
     const int s = c.slotOf[vid];
