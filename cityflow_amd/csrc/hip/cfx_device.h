@@ -161,6 +161,7 @@ struct LeaverPrefetch {
     // ring layout, the LAST vehicle of its drivable (it rewrites the drivable's tail record): where it came from
     bool prevValid;
     int prevDrv;
+    int templP1;  // the vehicle's template index + 1 where the caller holds it (0: read it from the slot)
 };
 
 // Everything the per-step kernels read.  Passed by value (kernel argument segment).
