@@ -482,9 +482,10 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 // Router::getNextDrivable for a vehicle on the first road of its route (router.cpp:49-76): its lane is on
                 // route position 0, so the table row is known without walking the route; anything else takes the walk
                 const int base = c.t.routeStart[route];
+                const int road0 = c.t.routeRoads[base], row0 = c.t.nextStart[base];  // (one round, not two)
                 int next;
-                if (c.t.routeRoads[base] == road) {
-                    const int ll = c.t.nextLL[c.t.nextStart[base] + laneIdx];
+                if (road0 == road) {
+                    const int ll = c.t.nextLL[row0 + laneIdx];
                     next = ll < 0 ? -1 : c.n.L + ll;
                 } else {
                     next = nextOf(c.n, c.t, lane, route, 0);
@@ -1391,14 +1392,29 @@ __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, con
         if (d < c.n.L) {  // Router::update router.cpp:78-94, then Router::getNextDrivable from the road it stopped at
             enterLLT = CFX_INT_MAX;
             const int base = c.t.routeStart[r.route], len = c.t.routeStart[r.route + 1] - base;
-            const int road = c.n.laneRoad[d];
-            while (rp < len && c.t.routeRoads[base + rp] != road) ++rp;
+            const int road = c.n.laneRoad[d], laneIdx = c.n.laneIndex[d];
+            // The road is almost always at the vehicle's route position or the one behind it: both are looked at in one
+            // round, together with their rows of the next-drivable table and the route's last road (the loop form walked
+            // routeRoads -> routeRoads -> nextStart -> nextLL one load after the other, per entrant).
+            const int p0 = rp < len ? rp : len - 1, p1 = rp + 1 < len ? rp + 1 : len - 1;
+            const int road0 = c.t.routeRoads[base + p0], road1 = c.t.routeRoads[base + p1];
+            int row = c.t.nextStart[base + p0];
+            const int row1 = c.t.nextStart[base + p1], roadLast = c.t.routeRoads[base + len - 1];
+            if (rp < len && road0 != road) {
+                ++rp;
+                row = row1;
+                if (rp < len && road1 != road) {
+                    ++rp;
+                    while (rp < len && c.t.routeRoads[base + rp] != road) ++rp;
+                    if (rp < len) row = c.t.nextStart[base + rp];
+                }
+            }
             next = -1;
             if (rp < len) {
-                const int ll = c.t.nextLL[c.t.nextStart[base + rp] + c.n.laneIndex[d]];
+                const int ll = c.t.nextLL[row + laneIdx];
                 next = ll < 0 ? -1 : c.n.L + ll;
             }
-            if (next < 0 && road == c.t.routeRoads[base + len - 1]) onLast = 2;  // Router::isLastRoad: flags bit 1 (finishAction)
+            if (next < 0 && road == roadLast) onLast = 2;  // Router::isLastRoad: flags bit 1 (finishAction)
         } else {
             enterLLT = c.step;
             next = c.n.llEndLane[d - c.n.L];
