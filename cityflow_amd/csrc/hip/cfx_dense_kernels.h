@@ -18,10 +18,15 @@ __device__ __forceinline__ bool viewerIsNew(const StepCtx &c, const SlotIn &in, 
 template <bool LC>
 __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const cfx_vehicle_template &t, int s, int d, int vid,
                                     double speed, double dis, double dlen, int nd0, double v, int blockerSlot, int /*idx*/,
-                                    int /*nNow*/, LeaverPrefetch lp, int /*flags*/ = -1) {
+                                    int /*nNow*/, LeaverPrefetch lp, int flags = -1) {
     static_assert(!LC, "lane change runs on k_action");
     v = min2(v, 100);  // SimpleLaneChange::yieldSpeed without signals
-    v = speedTail(c, t, s, d, speed, dis, dlen, nd0, v);
+    // speedTail of cfx_kernels.h (vehicle.cpp:325-331) with Router::onValidLane's "last road" from the slot's flags (lastRoadBit)
+    if (nd0 < 0) {
+        const bool lastRoad = flags >= 0 ? (flags & 2) != 0 : isLastRoad(c, d, c.s.route[s]);
+        if (!lastRoad) v = min2(v, noCollisionSpeed(0, 1, speed, t.max_neg_acc, dlen - dis, c.interval, t.min_gap));
+    }
+    v = max2(v, speed - t.max_neg_acc * c.interval);
     MoveOut m;
     double deltaDis;
     if (v < 0) {
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
             c.s.routePos[slot] = 0;
             c.s.templ[slot] = wt;
             c.s.route[slot] = route;
-            c.s.flags[slot] = pending;
+            c.s.flags[slot] = (uint8_t) (pending | lastRoadBit(c, lane, route, next));
             c.s.dis[slot] = 0.0;
             c.s.speed[slot] = v0;
             c.laneTail[lane] = slot;
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, Action
         o.keep(s, in.dis, in.speed);
         return;
     }
+    in.lastRoadFlags = in.flags;  // (k_scatter / kd_admit / the halo import keep bit 1 up on this path)
     if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
     actionOneRounds(c, o, tv, s, in, PushJob{q});
 }

@@ -276,6 +276,13 @@ template <class C> __device__ __forceinline__ bool isLastRoad(const C &c, int d,
     return c.n.laneRoad[d] == c.t.routeRoads[c.t.routeStart[route + 1] - 1];
 }
 
+// Bit 1 of a slot's flags: the vehicle is on the LAST road of its route (Router::isLastRoad) — kept where its next drivable
+// is kept (set when it enters a lane with nothing behind it), so that Router::onValidLane (router.h:66-68) in every step's
+// speed tail is a bit test instead of a walk route -> routeStart -> routeRoads.
+template <class C> __device__ __forceinline__ int lastRoadBit(const C &c, int d, int route, int next) {
+    return (next < 0 && isLastRoad(c, d, route)) ? 2 : 0;
+}
+
 // Layout accessors of the dense layout (the ring layout overloads them on its own context, cfx_ring_kernels.h)
 __device__ __forceinline__ int committedCount(const StepCtx &c, int d) { return c.cnt[d]; }
 __device__ __forceinline__ int firstSlot(const StepCtx &c, int d) { return c.segStart[d]; }  // Drivable::getFirstVehicle

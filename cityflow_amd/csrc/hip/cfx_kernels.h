@@ -1414,6 +1414,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         const int prevDrv = c.s.prevDrv[s];
         const int next = c.s.next[s];
         const int enterLLT = c.s.enterLLT[s];
+        const int oldFlags = c.s.flags[s];
         int rp = c.s.routePos[s];
         if (vid < 0 || nd == -2) {  // spare slot, or finished: removed
             oldToNew[s] = -1;
@@ -1467,9 +1468,9 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         nx.dis[ns] = ndis;
         nx.speed[ns] = nspeed;
         nx.blocker[ns] = nblocker;  // old-generation slot; resolved through oldToNew when read
-        nx.flags[ns] = 0;           // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
         nx.route[ns] = route;
         if (nd == -1) {
+            nx.flags[ns] = (uint8_t) (oldFlags & 2);  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122); bit 1: lastRoadBit
             nx.drv[ns] = d;
             nx.prevDrv[ns] = prevDrv;
             nx.next[ns] = next;
@@ -1487,7 +1488,9 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
                 nx.enterLLT[ns] = c.step;
             }
             nx.routePos[ns] = rp;
-            nx.next[ns] = nextOf(c.n, c.t, nd, route, rp);
+            const int nextNew = nextOf(c.n, c.t, nd, route, rp);
+            nx.next[ns] = nextNew;
+            nx.flags[ns] = (uint8_t) lastRoadBit(c, nd, route, nextNew);
         }
     }
 }
@@ -1509,7 +1512,9 @@ __global__ void k_set_route(StepCtx c, int vid, int route) {
         if (c.s.vid[s] == vid) {
             c.s.route[s] = route;
             c.s.routePos[s] = 0;
-            c.s.next[s] = nextOf(c.n, c.t, c.s.drv[s], route, 0);
+            const int next = nextOf(c.n, c.t, c.s.drv[s], route, 0);
+            c.s.next[s] = next;
+            c.s.flags[s] = (uint8_t) ((c.s.flags[s] & 1) | lastRoadBit(c, c.s.drv[s], route, next));
         }
 }
 
@@ -1523,7 +1528,11 @@ __global__ void k_refresh_next(StepCtx c) {  // after cfx_load_state: Router::ge
     const int S = c.segStart[c.n.L + c.n.K];
     const int stride = gridDim.x * blockDim.x;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride)
-        if (c.s.vid[s] >= 0) c.s.next[s] = nextOf(c.n, c.t, c.s.drv[s], c.s.route[s], c.s.routePos[s]);
+        if (c.s.vid[s] >= 0) {
+            const int d = c.s.drv[s], route = c.s.route[s], next = nextOf(c.n, c.t, d, route, c.s.routePos[s]);
+            c.s.next[s] = next;
+            c.s.flags[s] = (uint8_t) ((c.s.flags[s] & 1) | lastRoadBit(c, d, route, next));
+        }
 }
 
 __global__ void k_find_vehicle(StepCtx c, int vid, int32_t *out /*[2]: drivable, routePos*/) {
@@ -1734,13 +1743,14 @@ __global__ void k_halo_import(StepCtx c, int32_t *cnt, HaloDev h, HaloIO io, Vid
             c.s.vid[s] = r.vid;
             c.s.drv[s] = l;
             c.s.prevDrv[s] = r.prevLL >= 0 ? -(r.prevLL + 2) : -1;
-            c.s.next[s] = nextOf(c.n, c.t, l, route, r.routePos);
+            const int nextM = nextOf(c.n, c.t, l, route, r.routePos);
+            c.s.next[s] = nextM;
             c.s.blocker[s] = -1;  // a vehicle that left its laneLink this step was not yielding (no blocker set)
             c.s.enterLLT[s] = CFX_INT_MAX;
             c.s.routePos[s] = r.routePos;
             c.s.templ[s] = vt.templ[r.vid];
             c.s.route[s] = route;
-            c.s.flags[s] = 0;
+            c.s.flags[s] = (uint8_t) lastRoadBit(c, l, route, nextM);
             c.s.dis[s] = r.dis;
             c.s.speed[s] = r.speed;
             vt.state[r.vid] = 1;
