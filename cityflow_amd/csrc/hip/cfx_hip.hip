@@ -183,7 +183,6 @@ struct cfx_engine {
     int4 *rMeta = nullptr;                  // [slot] {template, next drivable, flags, enterLaneLinkTime}
     int rcur = 0;
     int2 *rBlk[2] = {nullptr, nullptr};  // by step parity
-    int32_t *rBlkSlot = nullptr;         // [slot] blockers as slots, resolved per step by the action kernel
     TailRec *rTail[2] = {nullptr, nullptr}, *rTailNow = nullptr;  // [D] per-drivable tail records (by step parity; this step's view)
     MoverRec *rMovers = nullptr;
     long long *rFinKey = nullptr;
@@ -470,8 +469,6 @@ struct cfx_engine {
         c.blkR = rBlk[(step + 1) & 1];  // written by step - 1
         c.blkW = rBlk[step & 1];
         c.slotOf = slotOf;
-        c.blkSlot = rBlkSlot;
-        c.blkResolved = (stepping && !ringV2) ? 1 : 0;  // (the first form's action kernels resolve them; getters walk the records)
         c.vState = vt.state;
         c.ringGeo = dRingGeo;
         c.head = rHead;
@@ -505,7 +502,7 @@ struct cfx_engine {
     int ringFree() {
         int rc = 0;
         rc |= freeRaw(&rs.vid) | freeRaw(&rs.drv) | freeRaw(&rs.prevDrv) | freeRaw(&rs.routePos) | freeRaw(&rs.route) |
-              freeRaw(&rBlk[0]) | freeRaw(&rBlk[1]) | freeRaw(&rBlkSlot) | freeRaw(&rKin[0]) | freeRaw(&rKin[1]) | freeRaw(&rMeta) | freeRaw(&rMovers) |
+              freeRaw(&rBlk[0]) | freeRaw(&rBlk[1]) | freeRaw(&rKin[0]) | freeRaw(&rKin[1]) | freeRaw(&rMeta) | freeRaw(&rMovers) |
               freeRaw(&dRingGeo) | freeRaw(&rJobs) | freeRaw(&rJobRecs);
         return rc ? CFX_ERR_DEVICE : CFX_OK;
     }
@@ -532,7 +529,7 @@ struct cfx_engine {
         int rc;
 #define RALLOC(ptr) if ((rc = allocRaw(&ptr, ringSlots))) return rc;
         RALLOC(rs.vid) RALLOC(rs.drv) RALLOC(rs.prevDrv) RALLOC(rs.routePos) RALLOC(rs.route)
-        RALLOC(rBlk[0]) RALLOC(rBlk[1]) RALLOC(rKin[0]) RALLOC(rKin[1]) RALLOC(rMeta) RALLOC(rMovers) RALLOC(rBlkSlot)
+        RALLOC(rBlk[0]) RALLOC(rBlk[1]) RALLOC(rKin[0]) RALLOC(rKin[1]) RALLOC(rMeta) RALLOC(rMovers)
 #undef RALLOC
         HIP_TRY(hipMemsetAsync(rBlk[0], 0xFF, ringSlots * sizeof(int2), stream));
         HIP_TRY(hipMemsetAsync(rBlk[1], 0xFF, ringSlots * sizeof(int2), stream));

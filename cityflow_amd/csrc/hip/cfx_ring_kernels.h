@@ -42,10 +42,6 @@ struct RingCtx {
     const int2 *blkR;
     int2 *blkW;
     int32_t *slotOf;         // [vid] slot of a running vehicle (-1: not on this engine)
-    // [slot] the vehicle's blocker as a slot, resolved for THIS step by the action kernel (blkR -> slotOf once per vehicle
-    // instead of once per link of every deadlock walk of the cross phase); valid while blkResolved
-    int32_t *blkSlot;
-    int blkResolved;
     const uint8_t *vState;   // [vid] 0 waiting, 1 running, 2 finished
     const int2 *ringGeo;     // [D] {base, cap - 1}
     // tails: two buffers by step parity (a step reads what the previous one left in tailR and writes tailW), plus the view
@@ -137,7 +133,6 @@ __device__ __forceinline__ int blockerVid(const RingCtx &c, int slot) {
 }
 // (chain walks: a finished vehicle's slotOf entry is -1 — the finish statistics clear it — so two loads per link)
 __device__ __forceinline__ int blockerOf(const RingCtx &c, int slot) {
-    if (c.blkResolved) return c.blkSlot[slot];
     const int2 b = c.blkR[slot];
     return (b.x >= 0 && b.y == c.step - 1) ? c.slotOf[b.x] : -1;
 }
@@ -555,12 +550,11 @@ __device__ inline void llstateRing(const RingCtx &c, int k) {
 // notifiedAt + the notified vehicle's state (cfx_kernels.h) from the two laneLink records
 __device__ __forceinline__ int blockerOfNotified(const RingCtx &c, const Notified &nf) {
     if (!nf.pre) return blockerOf(c, nf.slot);
-    if (nf.blk.y == -2) return nf.blk.x;  // (already a slot: notifiedExtras with resolved blockers)
     return (nf.blk.x >= 0 && nf.blk.y == c.step - 1) ? c.slotOf[nf.blk.x] : -1;
 }
 __device__ __forceinline__ void notifiedExtras(const RingCtx &c, Notified &nf) {  // requested now, used (maybe) much later
     nf.enterLLT = c.meta[nf.slot].w;
-    nf.blk = c.blkResolved ? make_int2(c.blkSlot[nf.slot], -2) : c.blkR[nf.slot];
+    nf.blk = c.blkR[nf.slot];
     nf.pre = true;
 }
 __device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x, const int4 dyn,
@@ -1033,7 +1027,6 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
         const int qv = qb + t - 1;  // thread 0 holds the vehicle ahead of the window (leader data only)
         const bool valid = qv >= 0 && qv < T;
         int i = 0, idx = 0, slot = 0;
-        int2 bk = make_int2(-1, -1);
         SlotIn in;
         in.vid = -1;
         if (valid) {
@@ -1049,7 +1042,6 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             slot = ringSlot(sGeo[i], sHead[i], idx);
             const double2 kv = c.kin[slot];  // the two records of the slot: 2 x 16 B, adjacent lanes adjacent in memory
             const int4 mv = c.meta[slot];
-            bk = c.blkR[slot];
             in.dis = kv.x;
             in.speed = kv.y;
             in.templIdx = mv.x;
@@ -1083,11 +1075,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
             in.laneAdmitted = sAdm[i] != 0;
             in.endLane = -1;
-            // the vehicle's blocker as a slot, once per step, for the deadlock walks of the cross phase (blockerOf): requested
-            // here, stored behind the vehicle's phase (a store in front of it would hold the phase's requests back)
-            const int bs = (bk.x >= 0 && bk.y == c.step - 1) ? c.slotOf[bk.x] : -1;
             actionOneRounds(c, o, tv, slot, in, push);
-            c.blkSlot[slot] = bs;
         }
         __syncthreads();
         TRACE_STAMP(3);
@@ -1174,7 +1162,6 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
         int2 geo = make_int2(0, 0);
         int head = 0;
         SlotIn in;
-        int2 bk = make_int2(-1, -1);
         in.vid = 0;  // (the vehicle number is loaded where it is needed: custom speed, leaving the drivable)
         in.dis = 0.0;
         in.speed = 0.0;
@@ -1197,7 +1184,6 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
             slot = ringSlot(geo, head, idx);
             const double2 kv = c.kin[slot];  // the two records of the slot: 2 x 16 B, adjacent lanes adjacent in memory
             const int4 mv = c.meta[slot];
-            bk = c.blkR[slot];
             if (lane == 0 && idx > 0) {  // the vehicle ahead of the chunk: this lane's leader
                 const int ls = ringSlot(geo, head, idx - 1);
                 kp = c.kin[ls];
@@ -1237,9 +1223,7 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
             in.endLane = in.hop.x == ll ? en.x : (in.hop.y == ll ? en.y : (in.hop.z == ll ? en.z : (in.hop.w == ll ? en.w : -1)));
         }
         in.laneAdmitted = sAdm[i] != 0;
-        const int bs = (bk.x >= 0 && bk.y == c.step - 1) ? c.slotOf[bk.x] : -1;  // (see kr_action)
         actionOneRounds(c, o, tv, slot, in, push);
-        c.blkSlot[slot] = bs;
     }
 }
 
