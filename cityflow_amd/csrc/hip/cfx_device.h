@@ -162,6 +162,7 @@ struct LeaverPrefetch {
     bool prevValid;
     int prevDrv;
     int templP1;  // the vehicle's template index + 1 where the caller holds it (0: read it from the slot)
+    int blockerVidP2;  // the blocker's vehicle number + 2 where the caller holds it (0: read it from the blocker's slot)
 };
 
 // Everything the per-step kernels read.  Passed by value (kernel argument segment).

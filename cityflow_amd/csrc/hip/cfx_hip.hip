@@ -124,6 +124,7 @@ struct cfx_engine {
 
     // ---- tiling (cfx_halo_config) ----
     bool tiled = false;
+    bool mailboxesFineGrained = true;  // cfx_halo_mailbox_alloc never had to fall back to a plain allocation
     HaloDev halo{};
     std::vector<uint8_t> hLaneSpare;   // per lane; empty when not tiled
     std::vector<uint8_t> hLaneGhost;   // per lane; empty when not tiled
@@ -2346,6 +2347,7 @@ int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **devic
         (void) hipGetLastError();
         if (p) (void) hipFree(p);
         p = nullptr;
+        e->mailboxesFineGrained = false;
         if (hipMalloc(&p, bytes) != hipSuccess || hipIpcGetMemHandle(&h, p) != hipSuccess) {
             (void) hipGetLastError();
             if (p) (void) hipFree(p);
@@ -2360,6 +2362,8 @@ int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **devic
     *devicePtr = p;
     return CFX_OK;
 }
+
+int32_t cfx_halo_mailbox_fine_grained(cfx_engine *e) { return e && e->mailboxesFineGrained ? 1 : 0; }
 
 int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t *handle, void **devicePtr) {
     if (!e || !e->tiled || !handle || !devicePtr) return CFX_ERR_INVALID;

@@ -242,6 +242,7 @@ struct Notified {
     bool pre;
     int enterLLT;
     int2 blk;
+    int vid;  // (with `pre`) the vehicle's number: what a yielding vehicle records as its blocker
 };
 // the notified vehicle's blocker as a slot, from what notified() brought along if it did
 template <class C> __device__ __forceinline__ int blockerOfNotified(const C &c, const Notified &nf) { return blockerOf(c, nf.slot); }

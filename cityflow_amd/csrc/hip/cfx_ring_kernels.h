@@ -218,7 +218,7 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
             }
         }
     }
-    const int bv = blockerSlot >= 0 ? c.s.vid[blockerSlot] : -1;
+    const int bv = blockerSlot >= 0 ? (lp.blockerVidP2 > 0 ? lp.blockerVidP2 - 2 : c.s.vid[blockerSlot]) : -1;
     if (idx < 0) {  // (cross phase of the generic kernels: the job carries the slot only)
         const int2 geo = c.ringGeo[d];
         idx = (s - geo.x - c.head[d]) & geo.y;
@@ -555,6 +555,7 @@ __device__ __forceinline__ int blockerOfNotified(const RingCtx &c, const Notifie
 __device__ __forceinline__ void notifiedExtras(const RingCtx &c, Notified &nf) {  // requested now, used (maybe) much later
     nf.enterLLT = c.meta[nf.slot].w;
     nf.blk = c.blkR[nf.slot];
+    nf.vid = c.s.vid[nf.slot];
     nf.pre = true;
 }
 __device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x, const int4 dyn,
@@ -582,18 +583,23 @@ __device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_temp
     }
     if (dyn.w > 0) {
         const SegWalk walk = segWalk(c, c.n.L + k, dyn.z);
-        for (int i = 0; i < dyn.w; ++i) {
-            const int w = walk.at(i);
-            const double2 kw = c.kin[w];
-            const double vehDistance = kw.x;
-            const int wt = c.meta[w].x;
-            if (!(vehDistance > x) || (vehDistance - x - tv[wt].len <= 0.0)) {
-                nf.slot = w;
-                nf.templ = wt;
-                nf.speed = kw.y;
-                nf.dist = x - vehDistance;
-                notifiedExtras(c, nf);
-                return nf;
+        for (int i = 0; i < dyn.w; i += 2) {  // two vehicles per round of loads (the walk stops at the first that matches)
+            const int w0 = walk.at(i), w1 = walk.at(i + 1 < dyn.w ? i + 1 : i);
+            const double2 k0 = c.kin[w0], k1 = c.kin[w1];
+            const int t0 = c.meta[w0].x, t1 = c.meta[w1].x;
+            for (int q = 0; q < 2 && i + q < dyn.w; ++q) {
+                const int w = q ? w1 : w0;
+                const double2 kw = q ? k1 : k0;
+                const double vehDistance = kw.x;
+                const int wt = q ? t1 : t0;
+                if (!(vehDistance > x) || (vehDistance - x - tv[wt].len <= 0.0)) {
+                    nf.slot = w;
+                    nf.templ = wt;
+                    nf.speed = kw.y;
+                    nf.dist = x - vehDistance;
+                    notifiedExtras(c, nf);
+                    return nf;
+                }
             }
         }
     }
@@ -728,13 +734,17 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
         for (int e0 = jr.xs; e0 < jr.xe; e0 += kCrossGroup) {
             const int e = e0 + g;
             bool fail = false;
-            int foe = -1;
+            int foe = -1, foeVid = -2;
             double dOn = 0.0;
             if (e < jr.xe) {
                 const double2 dd = c.n.xDD[e];  // {distance on this laneLink, distance on the peer laneLink}
                 const int4 xp = c.n.xPack[e];   // {peer laneLink, peer bit, peer roadLink type, -}
                 dOn = dd.x;
-                if (!(dOn < d0)) fail = !canPassActive(c, tv, s, self, dOn, jr.t1, d0, xp.x, dd.y, xp.z, &foe);
+                if (!(dOn < d0)) {
+                    const Notified nf = notified(c, tv, xp.x, dd.y);
+                    fail = !canPassDecide(c, tv, s, self, dOn, jr.t1, d0, nf, xp.z, &foe);
+                    if (nf.slot >= 0 && nf.pre) foeVid = nf.vid;  // (came with the notified vehicle's other columns)
+                }
             }
             const unsigned long long ball = __ballot(fail);
             const unsigned gm = (unsigned) ((ball >> groupShift) & ((1ULL << kCrossGroup) - 1ULL));
@@ -743,6 +753,8 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
                 const int src = groupShift + first;
                 const double fdOn = __shfl(dOn, src, 64);
                 blockerSlot = __shfl(foe, src, 64);
+                const int bvid = __shfl(foeVid, src, 64);
+                if (blockerSlot >= 0 && bvid >= 0) lp.blockerVidP2 = bvid + 2;
                 iv = min2(iv, stopBeforeSpeed(self, fdOn - d0 - t.yield_distance, c.interval));
                 break;
             }

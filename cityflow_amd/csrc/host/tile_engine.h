@@ -83,6 +83,7 @@ public:
     // with a barrier between them: every tile allocates the mailboxes of its incoming messages and publishes their handles
     // (tiny shm records <prefix>_h_<from>_<to>), then opens the ones it sends into.  false: not possible here.
     bool allocDeviceMailboxes(const std::string &prefix);
+    bool mailboxesFineGrained() const { return be_->cfx_halo_mailbox_fine_grained(dev_) != 0; }
     bool attachDeviceMailboxes(const std::string &prefix);
     const char *mailboxKind() const { return !mailboxes_ ? "none" : (deviceMailboxes_ ? "device" : "host"); }
     void haloPost();
@@ -223,6 +224,11 @@ public:
     void profileEnable(int localTile, bool on) { tiles_.at(localTile)->profileEnable(on); }
     void deviceSpin(long long microseconds) { for (auto &t : tiles_) t->deviceSpin(microseconds); }
     std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
+    bool deviceMailboxesFineGrained() const {
+        for (auto &t : tiles_)
+            if (!t->mailboxesFineGrained()) return false;
+        return true;
+    }
     std::string layoutName() { return tiles_.empty() ? "n/a" : tiles_.front()->layoutName(); }
     std::map<std::string, std::pair<double, int64_t>> profileRead(int localTile) { return tiles_.at(localTile)->profileRead(); }
     std::vector<int> owner() const { return owner_; }

@@ -131,6 +131,10 @@ class DistributedEngine:
         if transport == "device":
             job = self._job_name()
             ok = local(self._eng.device_mailbox_phase, job, 1)
+            if ok and not self._eng.device_mailboxes_fine_grained():
+                # plain device memory behind a mailbox (the platform would not export fine-grained memory): a kernel on
+                # ANOTHER GPU is not guaranteed to see the sender's stores while it runs — fine only on one shared device
+                ok = self._device.type == "cpu" or torch.cuda.device_count() == 1
             if not self._all_ok(ok):  # nobody has attached anything yet: the next transport can still be tried
                 local(self._eng.unlink_mailboxes)
                 return False

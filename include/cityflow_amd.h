@@ -370,6 +370,11 @@ typedef struct cfx_halo_peer {
 #define CFX_IPC_HANDLE_BYTES 64
 int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t message_bytes, void **device_ptr, uint8_t handle[CFX_IPC_HANDLE_BYTES]);
 int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t handle[CFX_IPC_HANDLE_BYTES], void **device_ptr);
+/* 1: every mailbox cfx_halo_mailbox_alloc has handed out so far is fine-grained device memory (a kernel on ANOTHER GPU sees
+ * the sender's stores while both kernels run); 0: some are plain allocations, because the platform would not export
+ * fine-grained memory — good between processes that share one GPU, not guaranteed across two: the caller should then use the
+ * host-memory mailboxes unless all tiles sit on one device. */
+int32_t cfx_halo_mailbox_fine_grained(cfx_engine *e);
 /* The staged exchange with the messages left in device memory (for a device-to-device transport such as RCCL send / recv
  * on these very buffers): cfx_halo_export(e, NULL) then writes the send buffer only on the device, cfx_halo_import(e, NULL)
  * reads the recv buffer from the device.  Both buffers are fixed for the life of the engine. */

@@ -1456,6 +1456,8 @@ int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **ptr, 
     memcpy(handle + 8, ptr, sizeof(void *));
     return CFX_OK;
 }
+int32_t cfx_halo_mailbox_fine_grained(cfx_engine *) { return 1; }
+
 int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t *handle, void **ptr) {
     if (!e || !e->tiled || !handle || !ptr) return CFX_ERR_INVALID;
     long long pid = 0;
