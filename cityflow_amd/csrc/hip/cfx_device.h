@@ -89,12 +89,18 @@ struct LcInsert {  // one shadow created in this step (Engine::insertShadow engi
     int32_t anchor, seg;
     double seq;
 };
+// What a shadow copies from its parent's slot (Vehicle copy constructor vehicle.cpp:28-36), taken by k_lc_assign while the
+// parent still is where the schedule walk saw it — k_lc_insert may move it.
+struct LcStage {
+    double speed;
+    int32_t prevDrv, enterLLT, routePos, templ, route, flags;
+};
 struct LcDev {
     int on;
     const double *laneWidth;        // [L] Lane::width
     const int32_t *roadLaneStart;   // [R+1] lanes of a road are contiguous
     const int32_t *laneNumSegs;     // [L] Lane::segments.size()
-    int32_t *segOfSlot;             // [slot capacity] Vehicle::segmentIndex as Lane::initSegments assigns it (k_lc_segments)
+    int32_t *segOfSlot;             // [slot capacity] Vehicle::segmentIndex as Lane::initSegments assigns it (lcInitSegments, k_admit)
     // LaneChangeInfo vehicle.h:74-79
     int8_t *ptype;                  // 0 none, 1 real vehicle of a changing pair, 2 shadow
     int32_t *partner;               // vid or -1
@@ -128,6 +134,10 @@ struct LcDev {
     LcInsert *ins;
     int32_t *insCount;              // [1]
     int insCap;
+    LcStage *insStage;              // [insCap]
+    int32_t *insLanes;              // [L] the lanes that get shadows in this step (k_lc_schedule -> k_lc_insert)
+    int32_t *insLaneCount;          // [1]
+    int32_t *newToOld;              // [slot capacity] inverse of oldToNew for the slots k_scatter filled
     const int32_t *pool;            // priorities the host's generator would hand out next (cfx_lane_change_supply)
     int firstShadowVid;
 };
@@ -173,6 +183,7 @@ struct StepCtx {
     const int32_t *segStart;  // [D+1]
     const int32_t *cnt;       // [D] live vehicles per drivable (spare excluded unless filled)
     const int32_t *admitStep; // [L] step index of the lane's latest admission
+    int admissionsVisible;    // lane change, from k_action on: the leader search sees this step's admissions (lastSlotForLeader)
     const int32_t *curPhase;  // [I]
     const int32_t *oldToNew;  // slot of previous generation -> slot of current generation (-1 removed)
     const int32_t *vPriority; // [vid]
@@ -247,7 +258,10 @@ __device__ __forceinline__ int lastSlot(const StepCtx &c, int d) {
 // of the previous step (engine.cpp:429-442), i.e. before this step's admissions, except for a vehicle
 // admitted this step on lane B, whose search runs inside handleWaiting and therefore sees admissions on
 // lanes A < B (engine.cpp:503,512).
+// With lane change the reference runs the leader pass once more after the planning phase (engine.cpp:571-575): from then
+// on — k_action, k_cross — every vehicle sees every admission of the step.
 __device__ __forceinline__ int lastSlotForLeader(const StepCtx &c, int d, bool viewerNew, int viewerLane) {
+    if (c.admissionsVisible) return lastSlot(c, d);
     int n = c.cnt[d];
     if (viewerNew && d < viewerLane && d < c.n.L && c.admitStep[d] == c.step) n += 1;
     return n > 0 ? c.segStart[d] + n - 1 : -1;

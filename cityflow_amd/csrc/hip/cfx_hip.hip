@@ -152,9 +152,6 @@ struct cfx_engine {
     // ---- lane change (cfx_config::lane_change) ----
     LcDev lc{};                        // device tables (vid-indexed ones grow with the vehicle table)
     int32_t *oldToNew2 = nullptr;      // [slot] scratch of the mid-step rebuild
-    int32_t *lcWidth = nullptr;        // [D + 1] slots per drivable of the rebuilt layout (scan input)
-    void *scanTemp = nullptr;          // hipcub::DeviceScan work space
-    size_t scanTempBytes = 0;
     int32_t *hPool = nullptr;          // ... pinned staging
     int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1] overflow code, [2..] their parents in walk order
     hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
@@ -390,6 +387,7 @@ struct cfx_engine {
 #undef GROW_SCRATCH
         if ((rc = grow(&oldToNew, keep, nc))) return rc;  // committed blockers point through it
         if (lc.on && (rc = grow(&oldToNew2, 0, nc))) return rc;
+        if (lc.on && (rc = grow(&lc.newToOld, keep, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkList, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkDep, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.candAll, 0, nc))) return rc;
@@ -441,6 +439,7 @@ struct cfx_engine {
         if (out.overflow == 8) return fail("ring layout: a drivable's ring of slots is full");
         if (out.overflow == 9) return fail("cross phase: job queue capacity exceeded");
         if (out.overflow == 10) return fail("action phase: more slots in use than the host's bound (internal error)");
+        if (out.overflow == 11) return fail("lane change: no room behind the layout for the lanes that got shadows in one step");
         if (out.overflow) return fail("device capacity overflow (finish list)");
         return CFX_OK;
     }
@@ -674,6 +673,7 @@ struct cfx_engine {
             HIP_TRY(hipMemsetAsync(lc.fixCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.insCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.candAllCount, 0, sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.insLaneCount, 0, sizeof(int32_t), stream));
         }
         timesDyadic = dyadic(cfg.interval);
         cumLoaded = 0.0;
@@ -951,13 +951,9 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         if ((rc = e->allocRaw(&lc.parkCount, 2))) return rc;
         HIP_TRY(hipMemset(lc.parkCount, 0, 2 * sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.roadCandList, (size_t) std::max(e->R, 1) * kLcRoadCand))) return rc;
-        if ((rc = e->allocRaw(&e->lcWidth, (size_t) e->D + 1))) return rc;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, e->scanTempBytes, e->lcWidth, e->segStart[0].p, e->D + 1, e->stream));
-        {
-            char *tmp = nullptr;
-            if ((rc = e->allocRaw(&tmp, e->scanTempBytes))) return rc;
-            e->scanTemp = tmp;
-        }
+        if ((rc = e->allocRaw(&lc.insLanes, (size_t) e->L))) return rc;
+        if ((rc = e->allocRaw(&lc.insLaneCount, 1))) return rc;
+        HIP_TRY(hipMemset(lc.insLaneCount, 0, sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.fixCount, 1))) return rc;
         HIP_TRY(hipMemset(lc.fixCount, 0, sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.candAllCount, 1))) return rc;
@@ -1273,7 +1269,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         return e->tiled ? e->liveUpper : std::min(a, e->liveUpper);
     };
     const int64_t shadowRoom = e->lc.on ? e->poolN : 0;  // this step's shadows
-    size_t need = (size_t) (bound() + spare + shadowRoom) + 1;
+    // ... and the lanes that get them move behind the layout's end (k_lc_insert): room for a quarter of the vehicles
+    constexpr int64_t kLcMoveRoom = 32768;
+    auto moveRoom = [e, &bound]() { return e->lc.on ? kLcMoveRoom + bound() / 4 : (int64_t) 0; };
+    size_t need = (size_t) (bound() + spare + shadowRoom + moveRoom()) + 1;
     if (need > e->slotCap && !e->tiled) {
         // the device's own count as of the last step it has completed, read without waiting for it
         const unsigned long long pr = __atomic_load_n(&e->hMirror->progress, __ATOMIC_RELAXED);
@@ -1281,14 +1280,14 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if (done > 0 && done <= e->step) {
             // since then: at most one admission per queueing lane and step, and (lane change) that step's shadows
             e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + (e->nQueueLanes + shadowRoom) * (e->step + 1 - done));
-            need = (size_t) (bound() + spare + shadowRoom) + 1;
+            need = (size_t) (bound() + spare + shadowRoom + moveRoom()) + 1;
         }
     }
     if (need > e->slotCap) {
         DevScalars s;
         if ((rc = e->readScalars(s))) return rc;  // refreshes finishedKnown too
         e->liveUpper = s.active + 2 * (int64_t) e->halo.nGhost + e->nQueueLanes;
-        need = (size_t) (bound() + spare + shadowRoom) + 1;
+        need = (size_t) (bound() + spare + shadowRoom + moveRoom()) + 1;
         if ((rc = e->ensureSlotCap(need))) return rc;
     }
 
@@ -1316,14 +1315,12 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     if (e->lc.on) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
         // with the step's shadows in place (cfx_lc_kernels.h)
-        const int mid = e->cur ^ 1;
         const bool dbgSync = e->cfg.debug_sync != 0;  // developer aid: name the kernel that faults
 #define LC_CHECK(name)                                                                                     \
     if (dbgSync) {                                                                                         \
         hipError_t er = hipStreamSynchronize(st);                                                          \
         if (er != hipSuccess) return e->fail(std::string("lane change: ") + name + ": " + hipGetErrorString(er)); \
     }
-        hipLaunchKernelGGL(k_lc_segments, dim3(gridFor(e->L)), dim3(kBlock), 0, st, c);
         hipLaunchKernelGGL(k_lc_plan, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         LC_CHECK("k_lc_plan")
         hipLaunchKernelGGL(k_lc_order, dim3(gridStride(std::max<size_t>(slotBound / 16, 256))), dim3(kBlock), 0, st, e->lc);
@@ -1335,21 +1332,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         LC_CHECK("k_lc_assign")
         HIP_TRY(hipEventRecord(e->pollEvent, st));  // cfx_lane_change_poll waits for this, not for the whole step
         e->pollPending = true;
-        hipLaunchKernelGGL(k_lc_width, dim3(gridFor(e->D + 1)), dim3(kBlock), 0, st, c, e->waitHead, e->vt, e->sc, e->net.laneSpare,
-                           e->lcWidth, e->cnt[mid].p);
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(e->scanTemp, e->scanTempBytes, e->lcWidth, e->segStart[mid].p, e->D + 1, st));
-        LC_CHECK("k_lc_width/scan")
-        hipLaunchKernelGGL(k_lc_move, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c, e->gen[mid],
-                           (const int32_t *) e->segStart[mid].p, e->oldToNew2);
-        LC_CHECK("k_lc_move")
-        hipLaunchKernelGGL(k_lc_compose, dim3(gridFor(std::max<size_t>(e->slotCap, (size_t) e->L))), dim3(kBlock), 0, st, e->oldToNew,
-                           (const int32_t *) e->oldToNew2, (int) e->slotCap, e->admitStep, e->lc.insHead, (int) e->L, (int) e->step,
-                           (const int32_t *) e->segStart[e->cur].p, (int) e->D, (const int32_t *) e->segStart[mid].p,
-                           (const int32_t *) e->cnt[mid].p, e->gen[mid].vid, e->gen[mid].drv, e->laneTail);
-        LC_CHECK("k_lc_compose")
+        hipLaunchKernelGGL(k_lc_insert, dim3(256), dim3(64), 0, st, c, e->sc, e->oldToNew, e->segStart[e->cur].p, e->cnt[e->cur].p,
+                           (int) e->slotCap);
+        LC_CHECK("k_lc_insert")
         HIP_TRY(hipGetLastError());
-        e->cur = mid;
-        c = e->ctx();
+        c.admissionsVisible = 1;
     }
     const int nxt = e->cur ^ 1;
     // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
@@ -1391,9 +1378,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
               e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat,
               e->exactTimes() ? 1 : 0, (const int32_t *) e->cnt[nxt].p);
-    if (e->lc.on)
-        hipLaunchKernelGGL(k_lc_clear, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, e->lc, (const int32_t *) e->gen[nxt].vid,
-                           (const int32_t *) e->segStart[nxt].p, (int) e->D);
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;
@@ -1840,6 +1824,7 @@ int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *prioriti
         const size_t cap = std::max<size_t>((size_t) n, 1024);
         if ((rc = e->grow(&e->lc.ins, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.insNext, 0, cap))) return rc;
+        if ((rc = e->grow(&e->lc.insStage, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.fixList, 0, 3 * 8 * cap))) return rc;
         e->lc.fixCap = (int) (8 * cap);
         if (e->hPool) HIP_TRY(hipHostFree(e->hPool));
@@ -2050,6 +2035,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     std::vector<int32_t> ident(S);
     for (int i = 0; i < S; ++i) ident[i] = i;
     HIP_TRY(up(e->oldToNew, ident.data(), S * 4));
+    if (e->lc.on) HIP_TRY(up(e->lc.newToOld, ident.data(), S * 4));
     HIP_TRY(hipStreamSynchronize(e->stream));
     }
     // vehicle table + waiting FIFOs

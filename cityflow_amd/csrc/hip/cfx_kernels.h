@@ -122,6 +122,21 @@ __global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidT
     }
 }
 
+// Lane::initSegments roadnet.cpp:863-875 for one lane (lane change only; the start of Engine::nextStep's planning phase,
+// engine.cpp:571): front to back, every vehicle goes to the highest segment whose start (Lane::startPos roadnet.cpp:859) it
+// has reached — as long as the vehicles in front of it did (the list is walked once).  Segment numbers therefore never
+// increase along the list, whatever the distances are.  (One thread per slot taking the minimum over the vehicles ahead was
+// measured: twice as slow — the segment starts are FP64 divisions, recomputed per pair.)  `n` counts this step's admission.
+__device__ inline void lcInitSegments(const StepCtx &c, int lane, int base, int n) {
+    int it = 0;
+    const int nSeg = c.lc.laneNumSegs[lane];
+    const double len = c.n.drvLength[lane];
+    for (int i = nSeg - 1; i >= 0 && it < n; --i) {
+        const double start = i * len / nSeg;
+        while (it < n && c.s.dis[base + it] >= start) c.lc.segOfSlot[base + it++] = i;
+    }
+}
+
 // Engine::handleWaiting engine.cpp:502-516 + Lane::available roadnet.cpp:428-435
 __global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, CompactScratch cs) {
     int lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,11 +156,18 @@ __global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, 
     int n = c.cnt[lane];
     int base = c.segStart[lane];
     c.laneTail[lane] = n > 0 ? base + n - 1 : -1;  // overwritten below if a vehicle is admitted
-    if (w < 0) return;
-    int wt = vt.templ[w];
-    if (n > 0) {
-        int tail = base + n - 1;
-        if (!(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) return;
+    bool admit = w >= 0;
+    int wt = 0;
+    if (admit) {
+        wt = vt.templ[w];
+        if (n > 0) {
+            int tail = base + n - 1;
+            if (!(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) admit = false;
+        }
+    }
+    if (!admit) {
+        if (c.lc.on) lcInitSegments(c, lane, base, n);
+        return;
     }
     int slot = base + n;  // the lane's spare slot
     int route = vt.route[w];
@@ -164,6 +186,7 @@ __global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, 
     c.laneTail[lane] = slot;
     c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
     admitStep[lane] = c.step;  // cnt[], the FIFO pop and the running count follow in k_scan (see cntNow)
+    if (c.lc.on) lcInitSegments(c, lane, base, n + 1);
 }
 
 // The per-slot columns the cross phase reads, through accessors: the ring layout keeps them in two 16-byte records per
@@ -1384,6 +1407,11 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = nBody * blockDim.x;
     if (gid == 0 && scanTicket) *scanTicket = 0;  // k_scan of this step is done; re-arm it for the next one
+    if (gid == 0 && c.lc.on) {  // the lane-change lists of this step are consumed
+        *c.lc.insCount = 0;
+        *c.lc.candAllCount = 0;
+        *c.lc.insLaneCount = 0;
+    }
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
     if (!rlTrafficLight) {
         for (int i = gid; i < c.n.I; i += stride) {
@@ -1492,6 +1520,20 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
             const int nextNew = nextOf(c.n, c.t, nd, route, rp);
             nx.next[ns] = nextNew;
             nx.flags[ns] = (uint8_t) lastRoadBit(c, nd, route, nextNew);
+        }
+        if (c.lc.on) {
+            // threadUpdateAction's clearSignal (engine.cpp:424, lanechange.cpp:129-138) for every vehicle that stays in the
+            // network, and where it now is.  (Nothing in this kernel reads these tables.)
+            const LcDev &lc = c.lc;
+            lc.newToOld[ns] = s;  // (k_lc_insert: a vehicle it moves corrects its oldToNew entry)
+            lc.slotOf[vid] = ns;
+            lc.tLeader[vid] = -1;
+            lc.tFollower[vid] = -1;
+            lc.lastDir[vid] = lc.sigSend[vid] ? lc.sendDir[vid] : 0;
+            if (!lc.changing[vid]) {
+                lc.sigSend[vid] = 0;
+                lc.recvFrom[vid] = -1;
+            }
         }
     }
 }

@@ -1,21 +1,20 @@
 // Lane change on the device (reference src/vehicle/lanechange.cpp, engine.cpp:374-400,571-575,792-820; the semantics are
 // the CPU twin's, oracle/twin/twin.cpp, which is pinned against the reference).  Only launched when the engine was created
 // with cfx_config::lane_change; the per-step order is
-//   k_spawn_link, k_admit                     as always (the admission sits in the lane's spare slot)
-//   k_lc_plan       Lane::initSegments + threadPlanLaneChange: every real vehicle makes its signal
+//   k_spawn_link, k_admit                     as always (the admission sits in the lane's spare slot) + Lane::initSegments
+//   k_lc_plan       threadPlanLaneChange: every real vehicle makes its signal
 //   k_lc_order      the position of every candidate in the reference's walk (creation order put through std::sort)
 //   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in that order
 //   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in walk order
-//   k_lc_width, scan, k_lc_move, k_lc_compose    the order is rebuilt once (admissions committed, shadows in place)
+//   k_lc_insert     LaneChange::insertShadow: the lanes that get shadows make room in place
 //   k_action, k_cross                         as always; a changing pair parks its two next speeds
 //   k_lc_resolve    the vehicles whose step depends on an earlier vehicle of the reference's walk: changing pairs (common
 //                   speed, lateral offset, finish / abort, engine.cpp:195-205,223-244) and vehicles they signalled
-//   k_scan, k_scatter                         as always
-//   k_lc_clear      LaneChange::clearSignal for every vehicle (engine.cpp:424) + slot of every vehicle
+//   k_scan, k_scatter                         as always + LaneChange::clearSignal for every vehicle (engine.cpp:424)
 // The reference finds a vehicle's neighbours in another lane through per-lane segment lists (Lane::initSegments,
 // getVehicleAfterDistance / BeforeDistance, roadnet.cpp:863-898) — indexed with the segment number the vehicle has on its
 // OWN lane, and inserts a shadow before the follower found that way.  On roads whose lanes differ in length that is not
-// "the neighbours by distance", and the lane list can even lose its distance order.  k_lc_segments assigns the segment
+// "the neighbours by distance", and the lane list can even lose its distance order.  lcInitSegments (k_admit) assigns the segment
 // numbers exactly as initSegments does and every search below walks the lists the way the reference does.
 #pragma once
 
@@ -28,26 +27,6 @@ constexpr int kLcRoadInserts = 32;  // shadows one road can get in one step (mor
 // LaneChange::planChange lanechange.cpp:23-25
 __device__ __forceinline__ bool lcPlanChange(const LcDev &lc, int vid, int drv) {
     return (lc.sigSend[vid] && lc.sendTarget[vid] >= 0 && lc.sendTarget[vid] != drv) || lc.changing[vid];
-}
-
-// Lane::startPos of segment i (roadnet.cpp:859)
-__device__ __forceinline__ double lcSegStart(const StepCtx &c, int lane, int i) {
-    return i * c.n.drvLength[lane] / c.lc.laneNumSegs[lane];
-}
-
-// Lane::initSegments roadnet.cpp:863-875, one thread per lane: front to back, every vehicle goes to the highest segment
-// whose start it has reached — as long as the vehicles in front of it did (the list is walked once).  Segment numbers
-// therefore never increase along the list, whatever the distances are.  (One thread per slot taking the minimum over the
-// vehicles ahead was measured: twice as slow — the segment starts are FP64 divisions, recomputed per pair.)
-__global__ void k_lc_segments(StepCtx c) {
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= c.n.L) return;
-    const int base = c.segStart[lane], n = cntNow(c, lane);
-    int it = 0;
-    for (int i = c.lc.laneNumSegs[lane] - 1; i >= 0 && it < n; --i) {
-        const double start = lcSegStart(c, lane, i);
-        while (it < n && c.s.dis[base + it] >= start) c.lc.segOfSlot[base + it++] = i;
-    }
 }
 
 // Lane::getVehicleAfterDistance(dis, seg) roadnet.cpp:889-898 over the lane's existing vehicles: segments seg, seg+1, ...
@@ -263,7 +242,7 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
         double(&itemDis)[kItems] = sItemDis[threadIdx.x];
         auto buildSegment = [&](int i) {  // the sequence of segment i of the target lane
             int m = 0;
-            // segment numbers never increase along the list (k_lc_segments): the members are one run
+            // segment numbers never increase along the list (lcInitSegments, k_admit): the members are one run
             int lo = 0, hi = tn;
             while (lo < hi) {  // first index whose segment number is <= i
                 const int mid = (lo + hi) >> 1;
@@ -418,6 +397,7 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
                     // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
                     // later candidate of this walk that copies itself (its own shadow) copies this gap too
                     if (follower.vid >= 0) lc.gap[follower.vid] = dis - t.len - follower.dis;
+                    if (lc.insHead[target] < 0) lc.insLanes[atomicAdd(lc.insLaneCount, 1)] = target;
                     lc.insNext[idx] = lc.insHead[target];  // only this thread touches this road's lanes
                     lc.insHead[target] = idx;
                     localRec[nLocal++] = idx;
@@ -443,6 +423,11 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc,
         if (i < 1024) sRank[i] = rank;
         const LcInsert r = lc.ins[i];
         const int p = r.parentVid, v = lc.firstShadowVid + rank;
+        {
+            const int ps = r.parentSlot;
+            lc.insStage[i] = LcStage{c.s.speed[ps], c.s.prevDrv[ps], c.s.enterLLT[ps], c.s.routePos[ps], c.s.templ[ps],
+                                     c.s.route[ps], (int) c.s.flags[ps]};
+        }
         vt.priority[v] = lc.pool[rank];
         vt.templ[v] = vt.templ[p];
         vt.route[v] = vt.route[p];
@@ -495,122 +480,106 @@ __global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc,
     }
 }
 
-// New layout after the walk: per lane its vehicles (this step's admission committed: the FIFO pop, the vehicle's state,
-// the running count) plus its shadows.  k_lc_width -> exclusive scan (hipcub); spare slots and lane tails: k_lc_compose.
-__global__ void k_lc_width(StepCtx c, int32_t *waitHead, VidTable vt, DevScalars *sc, const uint8_t *laneSpare, int32_t *width,
-                           int32_t *cntNext) {
+// LaneChange::insertShadow lanechange.cpp:83-95 for every lane that gets shadows in this step (~75 of 14 k at the
+// benchmark's size): the lane's vehicles MOVE to fresh slots behind the layout's end — room for them and the shadows is taken
+// from segStart[D] itself, which every later kernel of the step reads as the number of slots — each behind the shadows that
+// go in front of it, and the shadows take the gaps: right before their target follower (LcInsert::anchor / seq), written
+// from what k_lc_assign staged of their parents.  The lane's old slots are left empty (vid -1) and its start points to the
+// new ones until k_scan / k_scatter lay the next generation out; nothing else of the layout moves, the step's admission
+// stays the pending one (cntNow).  Stored blockers stay valid: they are slots of the PREVIOUS generation that go through
+// oldToNew, and a moved vehicle's entry there is found through newToOld (k_scatter).  One 64-thread block per listed lane.
+__global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, DevScalars *sc, int32_t *oldToNew, int32_t *segStartNow,
+                                                  int32_t *cntNow_, int slotCap) {
     const LcDev &lc = c.lc;
+    __shared__ int sRec[kLcRoadInserts], sAnchor[kLcRoadInserts];
+    __shared__ double sSeq[kLcRoadInserts];
+    __shared__ int sM, sBase;
+    const int nLanes = *lc.insLaneCount;
+    const int tid = threadIdx.x;
     const int D = c.n.L + c.n.K;
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d > D) return;
-    if (d == D) {
-        width[d] = 0;  // so that the exclusive scan leaves the total at [D]
-        return;
-    }
-    int live = c.cnt[d], spare = 0;
-    if (d < c.n.L) {
-        if (c.admitStep[d] == c.step) {  // commit the admission (what k_scan does in a step without lane change; admitStep
-            live += 1;                   //  itself is cleared after k_lc_move, which still needs it)
-            const int2 rec = c.admitRec[d];
-            waitHead[d] = rec.y;
-            vt.state[rec.x] = 1;
-            atomicAdd((unsigned long long *) &sc->active, 1ULL);
-        }
-        for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) live += 1;
-        spare = laneSpare ? (int) laneSpare[d] : 1;
-    }
-    cntNext[d] = live;
-    width[d] = live + spare;
-}
-
-// Every vehicle to its place in the new layout; shadows are written from their parents (Vehicle copy constructor +
-// LaneChange::insertShadow lanechange.cpp:83-93) and go where the reference's list insertion put them: right before their
-// target follower (LcInsert::anchor / seq).
-__global__ void k_lc_move(StepCtx c, SlotArrays nx, const int32_t *segStartNext, int32_t *oldToNew2) {
-    const LcDev &lc = c.lc;
-    const int nIns = min(*lc.insCount, lc.insCap);
-    const int S = c.segStart[c.n.L + c.n.K];
-    const int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S + nIns; s += stride) {
-        if (s < S) {
-            const int vid = c.s.vid[s];
-            if (vid < 0) {
-                oldToNew2[s] = -1;
-                continue;
+    for (int w = blockIdx.x; w < nLanes; w += gridDim.x) {
+        const int d = lc.insLanes[w];
+        const int base = c.segStart[d];
+        const int live = c.cnt[d];
+        const bool admitted = c.admitStep[d] == c.step;
+        const int n = live + (admitted ? 1 : 0);
+        __syncthreads();  // (the previous lane's lists are consumed)
+        if (tid == 0) {
+            int m = 0;
+            for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) {
+                if (m < kLcRoadInserts) {  // (a road's limit in k_lc_schedule, so a lane's too)
+                    sRec[m] = r;
+                    sAnchor[m] = lc.ins[r].anchor;
+                    sSeq[m] = lc.ins[r].seq;
+                }
+                ++m;
             }
-            const int d = c.s.drv[s];
-            const double dis = c.s.dis[s];
-            const int k = s - c.segStart[d];
+            sM = m;
+            lc.insHead[d] = -1;
+            const int nb = m <= kLcRoadInserts ? atomicAdd(&segStartNow[D], n + m) : -1;
+            sBase = (nb >= 0 && nb + n + m <= slotCap) ? nb : -1;
+        }
+        __syncthreads();
+        const int m = sM, nbase = sBase;
+        if (nbase < 0) {  // no room behind the layout (the host reserves it, cfx_step): the step is not valid
+            if (tid == 0) sc->overflow = 11;
+            continue;
+        }
+        for (int k = tid; k < n; k += 64) {
+            const int s = base + k;
             int shift = 0;
-            if (d < c.n.L)
-                for (int r = lc.insHead[d]; r >= 0; r = lc.insNext[r]) shift += lc.ins[r].anchor <= k;
-            const int ns = segStartNext[d] + k + shift;
-            oldToNew2[s] = ns;
+            for (int j = 0; j < m; ++j) shift += sAnchor[j] <= k;
+            const int ns = nbase + k + shift;
+            const int vid = c.s.vid[s];
+            c.s.vid[ns] = vid;
+            c.s.drv[ns] = d;
+            c.s.prevDrv[ns] = c.s.prevDrv[s];
+            c.s.next[ns] = c.s.next[s];
+            c.s.blocker[ns] = c.s.blocker[s];
+            c.s.enterLLT[ns] = c.s.enterLLT[s];
+            c.s.routePos[ns] = c.s.routePos[s];
+            c.s.templ[ns] = c.s.templ[s];
+            c.s.route[ns] = c.s.route[s];
+            c.s.flags[ns] = c.s.flags[s];
+            c.s.dis[ns] = c.s.dis[s];
+            c.s.speed[ns] = c.s.speed[s];
             lc.slotOf[vid] = ns;
-            nx.vid[ns] = vid;
-            nx.drv[ns] = d;
-            nx.prevDrv[ns] = c.s.prevDrv[s];
-            nx.next[ns] = c.s.next[s];
-            nx.blocker[ns] = c.s.blocker[s];  // still a slot of the PREVIOUS generation (oldToNew is composed, k_lc_compose)
-            nx.enterLLT[ns] = c.s.enterLLT[s];
-            nx.routePos[ns] = c.s.routePos[s];
-            nx.templ[ns] = c.s.templ[s];
-            nx.route[ns] = c.s.route[s];
-            nx.flags[ns] = c.s.flags[s];
-            nx.dis[ns] = dis;
-            nx.speed[ns] = c.s.speed[s];
-        } else {
-            const int i = s - S;
-            const LcInsert r = lc.ins[i];
-            const int ps = r.parentSlot, lane = r.lane;
-            int before = r.anchor;  // existing vehicles in front of it
-            for (int q = lc.insHead[lane]; q >= 0; q = lc.insNext[q]) {
-                if (q == i) continue;
-                const LcInsert &o = lc.ins[q];
-                before += (o.anchor < r.anchor) || (o.anchor == r.anchor && o.seq < r.seq);
+            if (!(admitted && k == live)) {  // (this step's admission has no previous slot)
+                const int old = lc.newToOld[s];
+                if (old >= 0) oldToNew[old] = ns;
             }
-            const int ns = segStartNext[lane] + before;
-            const int vid = lc.partner[r.parentVid];  // set by k_lc_assign
-            const int route = c.s.route[ps], routePos = c.s.routePos[ps];
+            c.s.vid[s] = -1;
+            c.s.drv[s] = -1;
+        }
+        if (tid < m) {
+            const int r = sRec[tid];
+            const LcInsert rec = lc.ins[r];
+            const LcStage st = lc.insStage[r];
+            int before = rec.anchor;  // existing vehicles in front of it, and the shadows that go before it
+            for (int q = 0; q < m; ++q)
+                if (q != tid) before += (sAnchor[q] < rec.anchor) || (sAnchor[q] == rec.anchor && sSeq[q] < rec.seq);
+            const int ns = nbase + before;
+            const int vid = lc.partner[rec.parentVid];  // set by k_lc_assign
             lc.slotOf[vid] = ns;
-            nx.vid[ns] = vid;
-            nx.drv[ns] = lane;
-            nx.prevDrv[ns] = c.s.prevDrv[ps];
-            nx.next[ns] = nextOf(c.n, c.t, lane, route, routePos);
-            nx.blocker[ns] = -1;
-            nx.enterLLT[ns] = c.s.enterLLT[ps];
-            nx.routePos[ns] = routePos;
-            nx.templ[ns] = c.s.templ[ps];
-            nx.route[ns] = route;
-            nx.flags[ns] = c.s.flags[ps];
-            nx.dis[ns] = r.dis;
-            nx.speed[ns] = c.s.speed[ps];
+            c.s.vid[ns] = vid;
+            c.s.drv[ns] = d;
+            c.s.prevDrv[ns] = st.prevDrv;
+            c.s.next[ns] = nextOf(c.n, c.t, d, st.route, st.routePos);
+            c.s.blocker[ns] = -1;
+            c.s.enterLLT[ns] = st.enterLLT;
+            c.s.routePos[ns] = st.routePos;
+            c.s.templ[ns] = st.templ;
+            c.s.route[ns] = st.route;
+            c.s.flags[ns] = (uint8_t) st.flags;
+            c.s.dis[ns] = rec.dis;
+            c.s.speed[ns] = st.speed;
+        }
+        if (tid == 0) {
+            segStartNow[d] = nbase;
+            cntNow_[d] = live + m;  // (the admission stays pending behind them: cntNow)
+            c.laneTail[d] = nbase + n + m - 1;
         }
     }
-}
-
-// oldToNew maps slots of the previous generation to the current one (stored blockers go through it); the current one just
-// moved
-// ... and per lane: the spare slots and the tail of the new layout; nothing is pending any more
-__global__ void k_lc_compose(int32_t *oldToNew, const int32_t *oldToNew2, int n, int32_t *admitStep, int32_t *insHead, int L,
-                             int step, const int32_t *segStartBefore, int D, const int32_t *segStartNext,
-                             const int32_t *cntNext, int32_t *vidNext, int32_t *drvNext, int32_t *laneTail) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int S = segStartBefore[D];  // slots of the layout that just moved; oldToNew beyond the previous generation's
-                                      // slots is never written (and never read through a stored blocker): leave it alone
-    if (i < L) {
-        if (admitStep[i] == step) admitStep[i] = -1;  // the rebuilt order contains this step's admissions and shadows
-        insHead[i] = -1;
-        const int start = segStartNext[i], live = cntNext[i], end = segStartNext[i + 1];
-        for (int j = start + live; j < end; ++j) {
-            vidNext[j] = -1;
-            drvNext[j] = -1;
-        }
-        laneTail[i] = live > 0 ? start + live - 1 : -1;
-    }
-    if (i >= n) return;
-    const int v = oldToNew[i];
-    if (v >= 0 && v < S) oldToNew[i] = oldToNew2[v];
 }
 
 // The vehicles k_action / k_cross parked (finishAction), in the order of the reference's walk (creation order = ascending
@@ -736,28 +705,6 @@ __global__ void k_lc_resolve_rest(StepCtx c, ActionOut o, int32_t *done) {
     }
     __syncthreads();
     if (threadIdx.x == 0) lc.parkCount[0] = lc.parkCount[1] = 0;
-}
-
-// threadUpdateAction's clearSignal (engine.cpp:424, lanechange.cpp:129-138) for every vehicle of the new generation, and
-// where it now is
-__global__ void k_lc_clear(LcDev lc, const int32_t *vidNew, const int32_t *segStartNew, int D) {
-    const int S = segStartNew[D];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the step's lists are consumed
-        *lc.insCount = 0;
-        *lc.candAllCount = 0;
-    }
-    const int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
-        const int v = vidNew[s];
-        if (v < 0) continue;
-        lc.slotOf[v] = s;
-        lc.tLeader[v] = -1;
-        lc.tFollower[v] = -1;
-        lc.lastDir[v] = lc.sigSend[v] ? lc.sendDir[v] : 0;
-        if (lc.changing[v]) continue;
-        lc.sigSend[v] = 0;
-        lc.recvFrom[v] = -1;
-    }
 }
 
 }  // namespace cfxd
