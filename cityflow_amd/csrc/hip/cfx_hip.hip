@@ -161,6 +161,7 @@ struct cfx_engine {
     // ---- dense layout with tail records (cfx_dense_kernels.h): engines without lane change and tiling ----
     TailRec *dTail[2] = {nullptr, nullptr}, *dTailNow = nullptr;
     int4 *dGate4 = nullptr;
+    bool lcSegValid = false;           // lane change: segOfSlot holds every vehicle's own segment (k_scatter / k_lc_naive)
     bool tailsValid = false;           // the records describe the current generation (false after reset / load / resize)
     bool useTails() const { return !ring && !lc.on; }  // (tiles too since round 3: the halo kernels keep the cut lanes' records up)
 
@@ -391,7 +392,7 @@ struct cfx_engine {
         if (lc.on && (rc = grow(&lc.parkList, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkDep, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.candAll, 0, nc))) return rc;
-        if (lc.on && (rc = grow(&lc.segOfSlot, 0, nc))) return rc;
+        if (lc.on && (rc = grow(&lc.segOfSlot, keep, nc))) return rc;  // (k_scatter leaves the next step's input in it)
         slotCap = nc;
         return CFX_OK;
     }
@@ -663,6 +664,7 @@ struct cfx_engine {
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
         tailsValid = false;
+        lcSegValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
         pollPending = false;
         poolN = 0;
@@ -1309,6 +1311,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->tailsValid = true;
     }
     const size_t slotBound = std::min(need, e->slotCap);
+    if (e->lc.on && !e->lcSegValid) {  // after a reset / cfx_load_state
+        hipLaunchKernelGGL(k_lc_naive, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
+        e->lcSegValid = true;
+    }
     if (tails) e->launch(PK_ADMIT, kd_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
     else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
@@ -1325,8 +1331,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         LC_CHECK("k_lc_plan")
         hipLaunchKernelGGL(k_lc_order, dim3(gridStride(std::max<size_t>(slotBound / 16, 256))), dim3(kBlock), 0, st, e->lc);
         LC_CHECK("k_lc_order")
-        hipLaunchKernelGGL(k_lc_schedule, dim3((e->R + kLcSchedBlock - 1) / kLcSchedBlock), dim3(kLcSchedBlock), 0, st, c, e->sc,
-                           (const int32_t *) e->vt.priority);
+        hipLaunchKernelGGL(k_lc_schedule, dim3(e->R), dim3(64), 0, st, c, e->sc, (const int32_t *) e->vt.priority);
         LC_CHECK("k_lc_schedule")
         hipLaunchKernelGGL(k_lc_assign, dim3(1), dim3(1024), 0, st, c, e->vt, e->sc, e->hPoll);
         LC_CHECK("k_lc_assign")

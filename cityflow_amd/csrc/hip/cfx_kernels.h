@@ -122,18 +122,42 @@ __global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidT
     }
 }
 
-// Lane::initSegments roadnet.cpp:863-875 for one lane (lane change only; the start of Engine::nextStep's planning phase,
-// engine.cpp:571): front to back, every vehicle goes to the highest segment whose start (Lane::startPos roadnet.cpp:859) it
-// has reached — as long as the vehicles in front of it did (the list is walked once).  Segment numbers therefore never
-// increase along the list, whatever the distances are.  (One thread per slot taking the minimum over the vehicles ahead was
-// measured: twice as slow — the segment starts are FP64 divisions, recomputed per pair.)  `n` counts this step's admission.
-__device__ inline void lcInitSegments(const StepCtx &c, int lane, int base, int n) {
-    int it = 0;
+// Lane::initSegments roadnet.cpp:863-875 (lane change only; the start of Engine::nextStep's planning phase, engine.cpp:571)
+// walks a lane front to back and gives every vehicle the highest segment whose start (Lane::startPos roadnet.cpp:859) it has
+// reached — as long as the vehicles in front of it did: segment(it) = min(segment(it - 1), highest i with start_i <= dis).
+// The second term depends on the vehicle alone: whoever puts a vehicle into a lane slot leaves it in segOfSlot (k_scatter for
+// the vehicles that stay in the network, 0 for an admission, k_lc_naive after a load), and the lane's thread in k_admit only
+// takes the running minimum — no FP64 division and no dependent load in that walk (it was 12 us as a walk over distances).
+__device__ __forceinline__ int lcNaiveSegment(const StepCtx &c, int lane, double dis) {
     const int nSeg = c.lc.laneNumSegs[lane];
     const double len = c.n.drvLength[lane];
-    for (int i = nSeg - 1; i >= 0 && it < n; --i) {
-        const double start = i * len / nSeg;
-        while (it < n && c.s.dis[base + it] >= start) c.lc.segOfSlot[base + it++] = i;
+    int i = (int) (dis * nSeg / len);  // an estimate; the comparisons below are the reference's own expression
+    i = i < 0 ? 0 : (i > nSeg - 1 ? nSeg - 1 : i);
+    while (i + 1 < nSeg && (i + 1) * len / nSeg <= dis) ++i;
+    while (i > 0 && i * len / nSeg > dis) --i;
+    return i;
+}
+__device__ inline void lcInitSegments(const StepCtx &c, int base, int n, bool admitted) {
+    int32_t *seg = c.lc.segOfSlot + base;
+    int run = CFX_INT_MAX;
+    for (int it0 = 0; it0 < n; it0 += 8) {
+        int v[8];
+        for (int q = 0; q < 8; ++q) v[q] = it0 + q < n ? seg[it0 + q] : CFX_INT_MAX;
+        for (int q = 0; q < 8; ++q)
+            if (it0 + q < n) {
+                run = run < v[q] ? run : v[q];
+                seg[it0 + q] = run;
+            }
+    }
+    if (admitted) seg[n] = 0;  // distance 0: segment 0, whatever is in front of it
+}
+// ... after cfx_load_state (and a reset): one thread per slot
+__global__ void k_lc_naive(StepCtx c) {
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
+        const int d = c.s.drv[s];
+        if (c.s.vid[s] >= 0 && d >= 0 && d < c.n.L) c.lc.segOfSlot[s] = lcNaiveSegment(c, d, c.s.dis[s]);
     }
 }
 
@@ -166,7 +190,7 @@ __global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, 
         }
     }
     if (!admit) {
-        if (c.lc.on) lcInitSegments(c, lane, base, n);
+        if (c.lc.on) lcInitSegments(c, base, n, false);
         return;
     }
     int slot = base + n;  // the lane's spare slot
@@ -186,7 +210,7 @@ __global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, 
     c.laneTail[lane] = slot;
     c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
     admitStep[lane] = c.step;  // cnt[], the FIFO pop and the running count follow in k_scan (see cntNow)
-    if (c.lc.on) lcInitSegments(c, lane, base, n + 1);
+    if (c.lc.on) lcInitSegments(c, base, n, true);
 }
 
 // The per-slot columns the cross phase reads, through accessors: the ring layout keeps them in two 16-byte records per
@@ -1526,6 +1550,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
             // network, and where it now is.  (Nothing in this kernel reads these tables.)
             const LcDev &lc = c.lc;
             lc.newToOld[ns] = s;  // (k_lc_insert: a vehicle it moves corrects its oldToNew entry)
+            if (t < c.n.L) lc.segOfSlot[ns] = lcNaiveSegment(c, t, ndis);  // (lcInitSegments of the next step)
             lc.slotOf[vid] = ns;
             lc.tLeader[vid] = -1;
             lc.tFollower[vid] = -1;

@@ -160,48 +160,95 @@ struct LcNeighbour {
 // Engine::scheduleLaneChange engine.cpp:792-810 for ONE road: its candidates in the order of the reference's walk
 // (k_lc_order; include/cityflow_amd.h "Lane change").  Roads are independent in this phase: a target lane is on the
 // candidate's own road, and the laneLinks the leader search looks into do not change.
-// The walk's work lists (a road's candidates, the members of one segment, the road's shadows so far) are indexed at run
-// time: they live in LDS, a private row per thread — as thread-local arrays they were 1.7 KB of scratch memory per
-// thread, every access a trip to the memory system in a walk that is one chain of dependent accesses.
-constexpr int kLcSchedBlock = 32;
+// The walk itself is strictly sequential — one chain of dependent accesses per candidate (its own fields, the target lane's
+// segment lists searched twice, the neighbours found, the road's shadows so far).  One WAVE per road: its 64 lanes first
+// copy what the walk will look at into LDS in a few coalesced rounds — every slot of the road's lanes {vehicle, distance,
+// speed, segment, length and deceleration of its template}, the lanes' {start, count, segments}, the candidates with their
+// walk positions — then lane 0 walks, and a step of the chain costs an LDS access instead of a trip to HBM.  A road with more
+// slots than the stage holds is walked from global memory (same code, `staged` false).
 constexpr int kLcSegItems = 64;
-__global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriority) {
-    __shared__ int sLocalRec[kLcSchedBlock][kLcRoadInserts];
-    __shared__ int sCandVid[kLcSchedBlock][kLcRoadCand], sCandSlot[kLcSchedBlock][kLcRoadCand], sCandKey[kLcSchedBlock][kLcRoadCand];
-    __shared__ int sItemRef[kLcSchedBlock][kLcSegItems];
-    __shared__ double sItemDis[kLcSchedBlock][kLcSegItems];
-    const int road = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kLcSchedStage = 384;  // slots of one road's lanes kept in LDS
+constexpr int kLcSchedLanes = 8;    // lanes of one road whose layout is kept in LDS
+__global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriority) {
+    __shared__ int localRec[kLcRoadInserts];  // global record indices of this road's shadows so far ...
+    __shared__ int insLane[kLcRoadInserts], insSeg[kLcRoadInserts], insAnchor[kLcRoadInserts], insParent[kLcRoadInserts];
+    __shared__ double insDis[kLcRoadInserts], insSeq[kLcRoadInserts];  // ... and what later candidates read of them
+    __shared__ int candVid[kLcRoadCand], candSlot[kLcRoadCand], candKey[kLcRoadCand];
+    __shared__ int itemRef[kLcSegItems];  // >= 0 existing index in the lane; < 0: -(local shadow index + 1)
+    __shared__ double itemDis[kLcSegItems];
+    __shared__ double stDis[kLcSchedStage], stSpeed[kLcSchedStage], stLen[kLcSchedStage], stNegAcc[kLcSchedStage];
+    __shared__ int stVid[kLcSchedStage], stSeg[kLcSchedStage], stDrv[kLcSchedStage];
+    __shared__ int lnStart[kLcSchedLanes], lnCnt[kLcSchedLanes], lnSegs[kLcSchedLanes];
+    const int road = blockIdx.x;
     if (road >= c.n.R) return;
     const LcDev &lc = c.lc;
     const int nListed = lc.roadCand[road];
     if (nListed == 0) return;
-    lc.roadCand[road] = 0;
+    const int tid = threadIdx.x;
     const cfx_vehicle_template *tv = c.t.templ;
     const int l0 = lc.roadLaneStart[road], l1 = lc.roadLaneStart[road + 1];
     const int s0 = c.segStart[l0], s1 = c.segStart[l1 - 1] + cntNow(c, l1 - 1);
-    int(&localRec)[kLcRoadInserts] = sLocalRec[threadIdx.x];  // global record indices of this road's shadows so far
+    const bool staged = s1 - s0 <= kLcSchedStage && l1 - l0 <= kLcSchedLanes;
+    if (staged) {
+        for (int i = tid; i < s1 - s0; i += 64) {
+            const int q = s0 + i;
+            const int v = c.s.vid[q];
+            stVid[i] = v;
+            stDrv[i] = c.s.drv[q];
+            stDis[i] = c.s.dis[q];
+            stSpeed[i] = c.s.speed[q];
+            stSeg[i] = lc.segOfSlot[q];
+            if (v >= 0) {  // (a lane's spare slot holds nothing)
+                const cfx_vehicle_template &tq = tv[c.s.templ[q]];
+                stLen[i] = tq.len;
+                stNegAcc[i] = tq.max_neg_acc;
+            }
+        }
+        if (tid < l1 - l0) {
+            lnStart[tid] = c.segStart[l0 + tid];
+            lnCnt[tid] = cntNow(c, l0 + tid);
+            lnSegs[tid] = lc.laneNumSegs[l0 + tid];
+        }
+    }
+    const bool tooMany = nListed > kLcRoadCand;
+    if (!tooMany && tid < nListed) {  // the road's candidates with their walk positions (sorted below)
+        const int2 e = lc.roadCandList[(size_t) road * kLcRoadCand + tid];
+        candVid[tid] = e.x;
+        candSlot[tid] = e.y;
+        candKey[tid] = lc.candPos[e.x];
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    lc.roadCand[road] = 0;
+    // accessors: a slot of this road's lanes, a lane of this road
+    auto slotVid = [&](int q) { return staged ? stVid[q - s0] : c.s.vid[q]; };
+    auto slotDrv = [&](int q) { return staged ? stDrv[q - s0] : c.s.drv[q]; };
+    auto slotDisOf = [&](int q) { return staged ? stDis[q - s0] : c.s.dis[q]; };
+    auto slotSpeedOf = [&](int q) { return staged ? stSpeed[q - s0] : c.s.speed[q]; };
+    auto slotSeg = [&](int q) { return staged ? stSeg[q - s0] : lc.segOfSlot[q]; };
+    auto slotLen = [&](int q) { return staged ? stLen[q - s0] : tv[c.s.templ[q]].len; };
+    auto slotNegAcc = [&](int q) { return staged ? stNegAcc[q - s0] : tv[c.s.templ[q]].max_neg_acc; };
+    auto laneStart = [&](int lane) { return staged ? lnStart[lane - l0] : c.segStart[lane]; };
+    auto laneCount = [&](int lane) { return staged ? lnCnt[lane - l0] : cntNow(c, lane); };
+    auto laneSegs = [&](int lane) { return staged ? lnSegs[lane - l0] : lc.laneNumSegs[lane]; };
     int nLocal = 0;
     // the road's candidates in walk order (threadPlanLaneChange's buffer after the sort; the walk never creates new ones)
-    constexpr int kCand = kLcRoadCand;
-    int(&candVid)[kCand] = sCandVid[threadIdx.x];
-    int(&candSlot)[kCand] = sCandSlot[threadIdx.x];
-    int(&candKey)[kCand] = sCandKey[threadIdx.x];
     int nCand = 0;
-    const bool tooMany = nListed > kCand;
-    if (!tooMany)
-        for (int j = 0; j < nListed; ++j) {
-            const int2 e = lc.roadCandList[(size_t) road * kLcRoadCand + j];
-            const int key = lc.candPos[e.x];
-            int i = nCand++;
+    if (!tooMany) {
+        nCand = nListed;
+        for (int j = 1; j < nCand; ++j) {  // insertion sort by walk position
+            const int v = candVid[j], q = candSlot[j], key = candKey[j];
+            int i = j;
             for (; i > 0 && candKey[i - 1] > key; --i) {
                 candVid[i] = candVid[i - 1];
                 candSlot[i] = candSlot[i - 1];
                 candKey[i] = candKey[i - 1];
             }
-            candVid[i] = e.x;
-            candSlot[i] = e.y;
+            candVid[i] = v;
+            candSlot[i] = q;
             candKey[i] = key;
         }
+    }
     int lastKey = -1;
     for (int ci = 0;; ++ci) {
         int vid, s;
@@ -214,8 +261,8 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
             s = -1;
             int best = CFX_INT_MAX;
             for (int q = s0; q < s1; ++q) {
-                const int w = c.s.vid[q];
-                if (w < 0 || lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
+                const int w = slotVid(q);
+                if (w < 0 || lc.ptype[w] == 2 || !lcPlanChange(lc, w, slotDrv(q))) continue;
                 const int key = lc.candPos[w];
                 if (key <= lastKey || key >= best) continue;
                 best = key;
@@ -225,43 +272,41 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
             if (s < 0) break;
             lastKey = best;
         }
-        const int d = c.s.drv[s];
+        const int d = slotDrv(s);
         const int target = lc.sendTarget[vid];
-        const double dis = c.s.dis[s];
-        const cfx_vehicle_template &t = tv[c.s.templ[s]];
+        const double dis = slotDisOf(s);
+        const double myLen = slotLen(s), myNegAcc = slotNegAcc(s);
         // --- LaneChange::updateLeaderAndFollower lanechange.cpp:27-60 on the target lane as it is NOW: its segment lists,
         // walked with the candidate's own segment number, earlier shadows of this walk included (each sits in the segment
         // its parent's number names, at the place Segment::insertVehicle gave it, roadnet.cpp:943-947)
         LcNeighbour leader{-1, 0, 0, 0, 0}, follower{-1, 0, 0, 0, 0};
-        int followerAnchor = cntNow(c, target);  // lane-list position of the follower: existing index, or ...
-        int followerRec = -1;                    // ... the earlier shadow it is
-        const int tb = c.segStart[target], tn = cntNow(c, target);
-        const int mySeg = lc.segOfSlot[s], nSeg = lc.laneNumSegs[target];
+        const int tb = laneStart(target), tn = laneCount(target);
+        int followerAnchor = tn;  // lane-list position of the follower: existing index, or ...
+        int followerRec = -1;     // ... the earlier shadow it is
+        const int mySeg = slotSeg(s), nSeg = laneSegs(target);
         constexpr int kItems = kLcSegItems;
-        int(&itemRef)[kItems] = sItemRef[threadIdx.x];  // >= 0 existing index in the lane; < 0: -(local shadow index + 1)
-        double(&itemDis)[kItems] = sItemDis[threadIdx.x];
         auto buildSegment = [&](int i) {  // the sequence of segment i of the target lane
             int m = 0;
-            // segment numbers never increase along the list (lcInitSegments, k_admit): the members are one run
+            // segment numbers never increase along the list (lcInitSegments): the members are one run
             int lo = 0, hi = tn;
             while (lo < hi) {  // first index whose segment number is <= i
                 const int mid = (lo + hi) >> 1;
-                if (lc.segOfSlot[tb + mid] > i) lo = mid + 1;
+                if (slotSeg(tb + mid) > i) lo = mid + 1;
                 else hi = mid;
             }
-            for (int k = lo; k < tn && lc.segOfSlot[tb + k] == i; ++k) {
+            for (int k = lo; k < tn && slotSeg(tb + k) == i; ++k) {
                 if (m == kItems) {
                     sc->overflow = 6;
                     break;
                 }
                 itemRef[m] = k;
-                itemDis[m++] = c.s.dis[tb + k];
+                itemDis[m++] = slotDisOf(tb + k);
             }
             for (int j = 0; j < nLocal; ++j) {
-                const LcInsert &r = lc.ins[localRec[j]];
-                if (r.lane != target || r.seg != i) continue;
+                if (insLane[j] != target || insSeg[j] != i) continue;
+                const double rdis = insDis[j];
                 int p = 0;
-                while (p < m && itemDis[p] > r.dis) ++p;  // before the first member that is not further ahead
+                while (p < m && itemDis[p] > rdis) ++p;  // before the first member that is not further ahead
                 if (m == kItems) {
                     sc->overflow = 6;
                     break;
@@ -271,7 +316,7 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
                     itemDis[q] = itemDis[q - 1];
                 }
                 itemRef[p] = -(j + 1);
-                itemDis[p] = r.dis;
+                itemDis[p] = rdis;
                 ++m;
             }
             return m;
@@ -279,13 +324,11 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
         auto neighbourOf = [&](int ref) {
             if (ref >= 0) {
                 const int ns = tb + ref;
-                const cfx_vehicle_template &tl = tv[c.s.templ[ns]];
-                return LcNeighbour{c.s.vid[ns], c.s.dis[ns], tl.len, c.s.speed[ns], tl.max_neg_acc};
+                return LcNeighbour{slotVid(ns), slotDisOf(ns), slotLen(ns), slotSpeedOf(ns), slotNegAcc(ns)};
             }
             const int j = -ref - 1;
-            const LcInsert &r = lc.ins[localRec[j]];
-            const cfx_vehicle_template &tp = tv[c.s.templ[r.parentSlot]];
-            return LcNeighbour{-(localRec[j] + 2), r.dis, tp.len, c.s.speed[r.parentSlot], tp.max_neg_acc};
+            const int ps = insParent[j];
+            return LcNeighbour{-(localRec[j] + 2), insDis[j], slotLen(ps), slotSpeedOf(ps), slotNegAcc(ps)};
         };
         for (int i = mySeg; i < nSeg && leader.vid == -1; ++i) {  // getVehicleAfterDistance: back to front
             const int m = buildSegment(i);
@@ -301,7 +344,7 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
                 if (itemDis[p] < dis) {
                     follower = neighbourOf(itemRef[p]);
                     if (itemRef[p] >= 0) followerAnchor = itemRef[p];
-                    else followerRec = localRec[-itemRef[p] - 1];
+                    else followerRec = -itemRef[p] - 1;  // (index in the road's local list)
                     break;
                 }
         }
@@ -328,7 +371,7 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
         } else {
             leaderGap = leader.dis - dis - leader.len;
         }
-        if (follower.vid != -1) followerGap = dis - follower.dis - t.len;
+        if (follower.vid != -1) followerGap = dis - follower.dis - myLen;
         lc.tLeader[vid] = leader.vid;
         lc.tFollower[vid] = follower.vid;
         for (int w = 0; w < 2; ++w) {  // shadows of this step get their numbers in k_lc_assign
@@ -364,8 +407,8 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
         }
         // --- insert a shadow? engine.cpp:800-806, LaneChange::isGapValid lanechange.h:80
         if (lcPlanChange(lc, vid, d) && lc.sigSend[vid] && lc.recvFrom[vid] < 0 && !lc.changing[vid] && d < c.n.L) {
-            const double speed = c.s.speed[s];
-            const double safeAfter = 0.5 * speed * speed / t.max_neg_acc;
+            const double speed = slotSpeedOf(s);
+            const double safeAfter = 0.5 * speed * speed / myNegAcc;
             const double safeBefore = follower.vid != -1 ? 0.5 * follower.speed * follower.speed / follower.maxNegAcc : 0.0;
             if (leaderGap >= safeAfter && followerGap >= safeBefore) {
                 const int idx = atomicAdd(lc.insCount, 1);
@@ -378,29 +421,32 @@ __global__ __launch_bounds__(kLcSchedBlock) void k_lc_schedule(StepCtx c, DevSca
                     int anchor = followerAnchor;
                     double seq;
                     if (followerRec >= 0) {  // before an earlier shadow: same anchor, between it and its predecessor
-                        const LcInsert &fr = lc.ins[followerRec];
-                        anchor = fr.anchor;
-                        double prev = fr.seq - 2.0;
-                        for (int j = 0; j < nLocal; ++j) {
-                            const LcInsert &o = lc.ins[localRec[j]];
-                            if (o.lane == target && o.anchor == anchor && o.seq < fr.seq && o.seq > prev) prev = o.seq;
-                        }
-                        seq = (prev + fr.seq) / 2;
+                        anchor = insAnchor[followerRec];
+                        const double fseq = insSeq[followerRec];
+                        double prev = fseq - 2.0;
+                        for (int j = 0; j < nLocal; ++j)
+                            if (insLane[j] == target && insAnchor[j] == anchor && insSeq[j] < fseq && insSeq[j] > prev) prev = insSeq[j];
+                        seq = (prev + fseq) / 2;
                     } else {                 // before an existing vehicle (or at the end): behind the shadows already there
                         seq = 0.0;
-                        for (int j = 0; j < nLocal; ++j) {
-                            const LcInsert &o = lc.ins[localRec[j]];
-                            if (o.lane == target && o.anchor == anchor && o.seq >= seq) seq = o.seq + 1.0;
-                        }
+                        for (int j = 0; j < nLocal; ++j)
+                            if (insLane[j] == target && insAnchor[j] == anchor && insSeq[j] >= seq) seq = insSeq[j] + 1.0;
                     }
                     lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid], anchor, mySeg, seq};
                     // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
                     // later candidate of this walk that copies itself (its own shadow) copies this gap too
-                    if (follower.vid >= 0) lc.gap[follower.vid] = dis - t.len - follower.dis;
+                    if (follower.vid >= 0) lc.gap[follower.vid] = dis - myLen - follower.dis;
                     if (lc.insHead[target] < 0) lc.insLanes[atomicAdd(lc.insLaneCount, 1)] = target;
                     lc.insNext[idx] = lc.insHead[target];  // only this thread touches this road's lanes
                     lc.insHead[target] = idx;
-                    localRec[nLocal++] = idx;
+                    localRec[nLocal] = idx;
+                    insLane[nLocal] = target;
+                    insSeg[nLocal] = mySeg;
+                    insAnchor[nLocal] = anchor;
+                    insParent[nLocal] = s;
+                    insDis[nLocal] = dis;
+                    insSeq[nLocal] = seq;
+                    ++nLocal;
                     lc.changing[vid] = 1;  // LaneChange::insertShadow lanechange.cpp:71-76 (later candidates must see it)
                 }
             }
