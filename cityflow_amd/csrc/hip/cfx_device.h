@@ -89,12 +89,6 @@ struct LcInsert {  // one shadow created in this step (Engine::insertShadow engi
     int32_t anchor, seg;
     double seq;
 };
-// What a shadow copies from its parent's slot (Vehicle copy constructor vehicle.cpp:28-36), taken by k_lc_assign while the
-// parent still is where the schedule walk saw it — k_lc_insert may move it.
-struct LcStage {
-    double speed;
-    int32_t prevDrv, enterLLT, routePos, templ, route, flags;
-};
 struct LcDev {
     int on;
     const double *laneWidth;        // [L] Lane::width
@@ -119,7 +113,7 @@ struct LcDev {
     int32_t *parkList;              // [slot capacity]
     int32_t *parkIdx;               // [vid] index in parkList (valid for this step's parked real vehicles)
     int32_t *parkDep;               // [slot capacity] scratch of k_lc_resolve: the item each item has to wait for
-    int32_t *parkCount;             // [2] parked items; of them, items that wait for another one (k_lc_resolve)
+    int32_t *parkCount;             // [4] parked items; of them, items that wait for another one; k_lc_resolve's ticket
     // neighbours that the schedule walk could only name provisionally (shadows of this very step): {vid, which, record}
     int32_t *fixList;               // [3 * fixCap]
     int32_t *fixCount;              // [1]
@@ -134,7 +128,7 @@ struct LcDev {
     LcInsert *ins;
     int32_t *insCount;              // [1]
     int insCap;
-    LcStage *insStage;              // [insCap]
+    int32_t *insKey;                // [insCap] walk position of the shadow's parent: shadows are numbered in that order
     int32_t *insLanes;              // [L] the lanes that get shadows in this step (k_lc_schedule -> k_lc_insert)
     int32_t *insLaneCount;          // [1]
     int32_t *newToOld;              // [slot capacity] inverse of oldToNew for the slots k_scatter filled

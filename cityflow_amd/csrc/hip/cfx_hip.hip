@@ -671,7 +671,7 @@ struct cfx_engine {
         if (lc.on) {
             HIP_TRY(hipMemsetAsync(lc.roadCand, 0, (size_t) std::max(R, 1) * sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.insHead, 0xFF, (size_t) std::max(L, 1) * sizeof(int32_t), stream));
-            HIP_TRY(hipMemsetAsync(lc.parkCount, 0, 2 * sizeof(int32_t), stream));
+            HIP_TRY(hipMemsetAsync(lc.parkCount, 0, 4 * sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.fixCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.insCount, 0, sizeof(int32_t), stream));
             HIP_TRY(hipMemsetAsync(lc.candAllCount, 0, sizeof(int32_t), stream));
@@ -950,8 +950,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         HIP_TRY(hipMemset(lc.insHead, 0xFF, (size_t) std::max(e->L, 1) * sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.insCount, 1))) return rc;
         HIP_TRY(hipMemset(lc.insCount, 0, sizeof(int32_t)));
-        if ((rc = e->allocRaw(&lc.parkCount, 2))) return rc;
-        HIP_TRY(hipMemset(lc.parkCount, 0, 2 * sizeof(int32_t)));
+        if ((rc = e->allocRaw(&lc.parkCount, 4))) return rc;
+        HIP_TRY(hipMemset(lc.parkCount, 0, 4 * sizeof(int32_t)));
         if ((rc = e->allocRaw(&lc.roadCandList, (size_t) std::max(e->R, 1) * kLcRoadCand))) return rc;
         if ((rc = e->allocRaw(&lc.insLanes, (size_t) e->L))) return rc;
         if ((rc = e->allocRaw(&lc.insLaneCount, 1))) return rc;
@@ -1295,7 +1295,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
 
     if (e->lc.on) {  // per-step fields of the lane-change context
         e->lc.firstShadowVid = (int) e->spawned;
-        e->lc.pool = e->hPool;  // pinned: k_lc_assign reads the few priorities it hands out straight from the host's buffer
+        e->lc.pool = e->hPool;  // pinned: k_lc_insert reads the few priorities it hands out straight from the host's buffer
         e->lc.insCap = e->poolN;
     }
     const bool tails = e->useTails();
@@ -1329,17 +1329,13 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
         hipLaunchKernelGGL(k_lc_plan, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         LC_CHECK("k_lc_plan")
-        hipLaunchKernelGGL(k_lc_order, dim3(gridStride(std::max<size_t>(slotBound / 16, 256))), dim3(kBlock), 0, st, e->lc);
-        LC_CHECK("k_lc_order")
         hipLaunchKernelGGL(k_lc_schedule, dim3(e->R), dim3(64), 0, st, c, e->sc, (const int32_t *) e->vt.priority);
         LC_CHECK("k_lc_schedule")
-        hipLaunchKernelGGL(k_lc_assign, dim3(1), dim3(1024), 0, st, c, e->vt, e->sc, e->hPoll);
-        LC_CHECK("k_lc_assign")
+        hipLaunchKernelGGL(k_lc_insert, dim3(256), dim3(64), 0, st, c, e->vt, e->sc, e->hPoll, e->oldToNew, e->segStart[e->cur].p,
+                           e->cnt[e->cur].p, (int) e->slotCap);
+        LC_CHECK("k_lc_insert")
         HIP_TRY(hipEventRecord(e->pollEvent, st));  // cfx_lane_change_poll waits for this, not for the whole step
         e->pollPending = true;
-        hipLaunchKernelGGL(k_lc_insert, dim3(256), dim3(64), 0, st, c, e->sc, e->oldToNew, e->segStart[e->cur].p, e->cnt[e->cur].p,
-                           (int) e->slotCap);
-        LC_CHECK("k_lc_insert")
         HIP_TRY(hipGetLastError());
         c.admissionsVisible = 1;
     }
@@ -1829,7 +1825,7 @@ int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *prioriti
         const size_t cap = std::max<size_t>((size_t) n, 1024);
         if ((rc = e->grow(&e->lc.ins, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.insNext, 0, cap))) return rc;
-        if ((rc = e->grow(&e->lc.insStage, 0, cap))) return rc;
+        if ((rc = e->grow(&e->lc.insKey, 0, cap))) return rc;
         if ((rc = e->grow(&e->lc.fixList, 0, 3 * 8 * cap))) return rc;
         e->lc.fixCap = (int) (8 * cap);
         if (e->hPool) HIP_TRY(hipHostFree(e->hPool));

@@ -1435,6 +1435,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         *c.lc.insCount = 0;
         *c.lc.candAllCount = 0;
         *c.lc.insLaneCount = 0;
+        *c.lc.fixCount = 0;
     }
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
     if (!rlTrafficLight) {

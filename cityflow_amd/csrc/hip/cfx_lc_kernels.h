@@ -3,10 +3,10 @@
 // with cfx_config::lane_change; the per-step order is
 //   k_spawn_link, k_admit                     as always (the admission sits in the lane's spare slot) + Lane::initSegments
 //   k_lc_plan       threadPlanLaneChange: every real vehicle makes its signal
-//   k_lc_order      the position of every candidate in the reference's walk (creation order put through std::sort)
-//   k_lc_schedule   scheduleLaneChange: one thread per road walks the road's candidates in that order
-//   k_lc_assign     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in walk order
-//   k_lc_insert     LaneChange::insertShadow: the lanes that get shadows make room in place
+//   k_lc_schedule   scheduleLaneChange: one wave per road takes the position of its candidates in the reference's walk
+//                   (creation order put through std::sort) and walks them in that order
+//   k_lc_insert     Engine::insertShadow: vehicle numbers and priorities of the step's shadows, in walk order, and
+//                   LaneChange::insertShadow: the lanes that get shadows move behind the layout's end, shadows in place
 //   k_action, k_cross                         as always; a changing pair parks its two next speeds
 //   k_lc_resolve    the vehicles whose step depends on an earlier vehicle of the reference's walk: changing pairs (common
 //                   speed, lateral offset, finish / abort, engine.cpp:195-205,223-244) and vehicles they signalled
@@ -139,15 +139,12 @@ __device__ inline int lcSortedPosition(int i, int n) {
     return x;
 }
 
-__global__ void k_lc_order(LcDev lc) {
-    const int n = *lc.candAllCount;
-    const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int me = lc.candAll[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += lc.candAll[j] < me;
-        lc.candPos[me] = lcSortedPosition(rank, n);
-    }
+// ... taken by the road's wave in k_lc_schedule: creation rank of `me` among the step's candidates, all 64 lanes counting
+__device__ __forceinline__ int lcWalkPosition(const LcDev &lc, int me, int nAll, int tid) {
+    int less = 0;
+    for (int i = tid; i < nAll; i += 64) less += lc.candAll[i] < me;
+    for (int off = 32; off > 0; off >>= 1) less += __shfl_down(less, off, 64);
+    return lcSortedPosition(__shfl(less, 0, 64), nAll);
 }
 
 // What the schedule walk knows about "a vehicle in the target lane": an existing one (slot) or a shadow inserted earlier
@@ -211,11 +208,33 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
         }
     }
     const bool tooMany = nListed > kLcRoadCand;
-    if (!tooMany && tid < nListed) {  // the road's candidates with their walk positions (sorted below)
+    const int nAll = *lc.candAllCount;
+    if (!tooMany && tid < nListed) {  // the road's candidates (sorted by walk position below)
         const int2 e = lc.roadCandList[(size_t) road * kLcRoadCand + tid];
         candVid[tid] = e.x;
         candSlot[tid] = e.y;
-        candKey[tid] = lc.candPos[e.x];
+    }
+    __syncthreads();
+    // Walk positions (the `std::sort` of scheduleLaneChange, lcSortedPosition): the creation rank of a candidate is the
+    // number of the step's candidates with a smaller vehicle number — counted here, by the wave that needs it, over the
+    // step's list (a few KB, read by every road's wave: it stays in L2).  k_lc_assign reads candPos of the shadows' parents.
+    if (!tooMany) {
+        for (int j = 0; j < nListed; ++j) {
+            const int me = candVid[j];
+            const int key = lcWalkPosition(lc, me, nAll, tid);
+            if (tid == 0) {
+                candKey[j] = key;
+                lc.candPos[me] = key;
+            }
+        }
+    } else {  // (slow, rare) every candidate on the road, found the way the walk below finds them
+        for (int q = s0; q < s1; ++q) {
+            const int w = c.s.vid[q];
+            if (w < 0 || lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
+            const int key = lcWalkPosition(lc, w, nAll, tid);
+            if (tid == 0) lc.candPos[w] = key;
+        }
+        __threadfence_block();
     }
     __syncthreads();
     if (tid != 0) return;
@@ -251,11 +270,12 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     }
     int lastKey = -1;
     for (int ci = 0;; ++ci) {
-        int vid, s;
+        int vid, s, myKey;
         if (!tooMany) {
             if (ci >= nCand) break;
             vid = candVid[ci];
             s = candSlot[ci];
+            myKey = candKey[ci];
         } else {  // more candidates than the local list holds: pick the next one by scanning (slow, rare)
             vid = -1;
             s = -1;
@@ -271,6 +291,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
             }
             if (s < 0) break;
             lastKey = best;
+            myKey = best;
         }
         const int d = slotDrv(s);
         const int target = lc.sendTarget[vid];
@@ -433,6 +454,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                             if (insLane[j] == target && insAnchor[j] == anchor && insSeq[j] >= seq) seq = insSeq[j] + 1.0;
                     }
                     lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid], anchor, mySeg, seq};
+                    lc.insKey[idx] = myKey;  // shadows are created, and numbered, in walk order (k_lc_insert)
                     // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
                     // later candidate of this walk that copies itself (its own shadow) copies this gap too
                     if (follower.vid >= 0) lc.gap[follower.vid] = dis - myLen - follower.dis;
@@ -454,95 +476,40 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     }
 }
 
-// Engine::insertShadow engine.cpp:812-820 + the Vehicle copy constructor vehicle.cpp:28-36 for every shadow of the step:
-// vehicle numbers and the supplied priorities go out in creation order = ascending parent vid.  One block.
-__global__ void k_lc_assign(StepCtx c, VidTable vt, DevScalars *sc,
-                            int32_t *pollOut /*pinned: [0] count, [1] overflow code of the walk, [2..] parents*/) {
+// Engine::insertShadow engine.cpp:812-820 + the Vehicle copy constructor vehicle.cpp:28-36 + LaneChange::insertShadow
+// lanechange.cpp:83-95 for every lane that gets shadows in this step (~75 of 14 k at the benchmark's size), one 64-thread
+// block per listed lane.
+//  * Vehicle numbers and the supplied priorities go out in creation order = walk order: a shadow's number is the count of the
+//    step's shadows whose parent comes earlier in the walk (LcDev::insKey).
+//  * The lane's vehicles MOVE to fresh slots behind the layout's end — room for them and the shadows is taken from
+//    segStart[D] itself, which every later kernel of the step reads as the number of slots — each behind the shadows that go
+//    in front of it, and the shadows take the gaps: right before their target follower (LcInsert::anchor / seq), copied from
+//    their parents' slots (a parent's lane may be moving at the same time: its old slot keeps everything but the vehicle
+//    number).  The lane's old slots are left empty (vid -1) and its start points to the new ones until k_scan / k_scatter lay
+//    the next generation out; nothing else of the layout moves, the step's admission stays the pending one (cntNow).
+//    Stored blockers stay valid: they are slots of the PREVIOUS generation that go through oldToNew, and a moved vehicle's
+//    entry there is found through newToOld (k_scatter).
+//  * Report for cfx_lane_change_poll (pinned memory + event: the host waits for this kernel, not for the step).
+__global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevScalars *sc,
+                                                  int32_t *pollOut /*pinned: [0] count, [1] overflow code of the walk, [2..] parents*/,
+                                                  int32_t *oldToNew, int32_t *segStartNow, int32_t *cntNow_, int slotCap) {
     const LcDev &lc = c.lc;
-    int n = *lc.insCount;
-    if (n > lc.insCap) n = lc.insCap;
-    __shared__ int sRank[1024];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int me = lc.candPos[lc.ins[i].parentVid];  // shadows are created in walk order
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += lc.candPos[lc.ins[j].parentVid] < me;
-        if (i < 1024) sRank[i] = rank;
-        const LcInsert r = lc.ins[i];
-        const int p = r.parentVid, v = lc.firstShadowVid + rank;
-        {
-            const int ps = r.parentSlot;
-            lc.insStage[i] = LcStage{c.s.speed[ps], c.s.prevDrv[ps], c.s.enterLLT[ps], c.s.routePos[ps], c.s.templ[ps],
-                                     c.s.route[ps], (int) c.s.flags[ps]};
-        }
-        vt.priority[v] = lc.pool[rank];
-        vt.templ[v] = vt.templ[p];
-        vt.route[v] = vt.route[p];
-        vt.enterTime[v] = vt.enterTime[p];
-        vt.customSpeed[v] = vt.customSpeed[p];
-        vt.pendingCustom[v] = 0;
-        vt.nextWait[v] = -1;
-        vt.state[v] = 1;
-        lc.ptype[v] = 2;  // setParent
-        lc.partner[v] = p;
-        lc.offset[v] = lc.offset[p];
-        lc.sigSend[v] = 0;
-        lc.sendDir[v] = 0;
-        lc.sendUrg[v] = 0;
-        lc.lastDir[v] = 0;
-        lc.changing[v] = 0;
-        lc.lcFinished[v] = 0;
-        lc.sendTarget[v] = -1;
-        lc.recvFrom[v] = r.recvFrom;
-        lc.tLeader[v] = -1;
-        lc.tFollower[v] = -1;
-        lc.leaderGap[v] = 0.0;
-        lc.followerGap[v] = 0.0;
-        lc.lastChangeTime[v] = 0.0;
-        lc.gap[v] = r.gap;  // ControllerInfo is copied; the leader pass (k_action) refreshes it where a leader exists
-        lc.slotOf[v] = -1;
-        lc.ptype[p] = 1;  // setShadow
-        lc.partner[p] = v;
-        pollOut[2 + rank] = p;
-    }
-    __syncthreads();
-    // shadows named provisionally (-(record + 2)) in the walk get their numbers
-    int nFix = *lc.fixCount;
-    if (nFix > lc.fixCap) nFix = lc.fixCap;
-    for (int i = threadIdx.x; i < nFix; i += blockDim.x) {
-        const int w = lc.fixList[3 * i], which = lc.fixList[3 * i + 1], rec = lc.fixList[3 * i + 2];
-        int rank = 0;
-        if (rec < 1024) rank = sRank[rec];
-        else for (int j = 0; j < n; ++j) rank += lc.candPos[lc.ins[j].parentVid] < lc.candPos[lc.ins[rec].parentVid];
-        if (which) lc.tFollower[w] = lc.firstShadowVid + rank;
-        else lc.tLeader[w] = lc.firstShadowVid + rank;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *lc.fixCount = 0;
-    if (threadIdx.x == 0) {
-        sc->active += n;  // activeVehicleCount++ per shadow
-        pollOut[0] = *lc.insCount;  // > insCap tells the host the supply was too small
-        pollOut[1] = sc->overflow;  // a capacity of the schedule walk was exceeded: the step is not valid
-        __threadfence_system();
-    }
-}
-
-// LaneChange::insertShadow lanechange.cpp:83-95 for every lane that gets shadows in this step (~75 of 14 k at the
-// benchmark's size): the lane's vehicles MOVE to fresh slots behind the layout's end — room for them and the shadows is taken
-// from segStart[D] itself, which every later kernel of the step reads as the number of slots — each behind the shadows that
-// go in front of it, and the shadows take the gaps: right before their target follower (LcInsert::anchor / seq), written
-// from what k_lc_assign staged of their parents.  The lane's old slots are left empty (vid -1) and its start points to the
-// new ones until k_scan / k_scatter lay the next generation out; nothing else of the layout moves, the step's admission
-// stays the pending one (cntNow).  Stored blockers stay valid: they are slots of the PREVIOUS generation that go through
-// oldToNew, and a moved vehicle's entry there is found through newToOld (k_scatter).  One 64-thread block per listed lane.
-__global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, DevScalars *sc, int32_t *oldToNew, int32_t *segStartNow,
-                                                  int32_t *cntNow_, int slotCap) {
-    const LcDev &lc = c.lc;
-    __shared__ int sRec[kLcRoadInserts], sAnchor[kLcRoadInserts];
+    __shared__ int sRec[kLcRoadInserts], sAnchor[kLcRoadInserts], sVid[kLcRoadInserts];
     __shared__ double sSeq[kLcRoadInserts];
     __shared__ int sM, sBase;
     const int nLanes = *lc.insLaneCount;
+    int nIns = *lc.insCount;
+    if (nIns > lc.insCap) nIns = lc.insCap;
     const int tid = threadIdx.x;
     const int D = c.n.L + c.n.K;
+    // creation rank of record `rec` among the step's shadows, counted by the whole wave
+    auto rankOf = [&](int rec) {
+        const int key = lc.insKey[rec];
+        int less = 0;
+        for (int j = tid; j < nIns; j += 64) less += lc.insKey[j] < key;
+        for (int off = 32; off > 0; off >>= 1) less += __shfl_down(less, off, 64);
+        return __shfl(less, 0, 64);
+    };
     for (int w = blockIdx.x; w < nLanes; w += gridDim.x) {
         const int d = lc.insLanes[w];
         const int base = c.segStart[d];
@@ -571,6 +538,11 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, DevScalars *sc, int
             if (tid == 0) sc->overflow = 11;
             continue;
         }
+        for (int q = 0; q < m; ++q) {
+            const int rank = rankOf(sRec[q]);
+            if (tid == 0) sVid[q] = lc.firstShadowVid + rank;
+        }
+        __syncthreads();
         for (int k = tid; k < n; k += 64) {
             const int s = base + k;
             int shift = 0;
@@ -600,31 +572,80 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, DevScalars *sc, int
         if (tid < m) {
             const int r = sRec[tid];
             const LcInsert rec = lc.ins[r];
-            const LcStage st = lc.insStage[r];
+            const int p = rec.parentVid, ps = rec.parentSlot, v = sVid[tid], rank = v - lc.firstShadowVid;
+            // the new vehicle (Engine::insertShadow, Vehicle copy constructor, setShadow / setParent)
+            vt.priority[v] = lc.pool[rank];
+            vt.templ[v] = vt.templ[p];
+            vt.route[v] = vt.route[p];
+            vt.enterTime[v] = vt.enterTime[p];
+            vt.customSpeed[v] = vt.customSpeed[p];
+            vt.pendingCustom[v] = 0;
+            vt.nextWait[v] = -1;
+            vt.state[v] = 1;
+            lc.ptype[v] = 2;  // setParent
+            lc.partner[v] = p;
+            lc.offset[v] = lc.offset[p];
+            lc.sigSend[v] = 0;
+            lc.sendDir[v] = 0;
+            lc.sendUrg[v] = 0;
+            lc.lastDir[v] = 0;
+            lc.changing[v] = 0;
+            lc.lcFinished[v] = 0;
+            lc.sendTarget[v] = -1;
+            lc.recvFrom[v] = rec.recvFrom;
+            lc.tLeader[v] = -1;
+            lc.tFollower[v] = -1;
+            lc.leaderGap[v] = 0.0;
+            lc.followerGap[v] = 0.0;
+            lc.lastChangeTime[v] = 0.0;
+            lc.gap[v] = rec.gap;  // ControllerInfo is copied; the leader pass (k_action) refreshes it where a leader exists
+            lc.ptype[p] = 1;  // setShadow
+            lc.partner[p] = v;
+            pollOut[2 + rank] = p;
+            // ... and its place in the lane
             int before = rec.anchor;  // existing vehicles in front of it, and the shadows that go before it
             for (int q = 0; q < m; ++q)
                 if (q != tid) before += (sAnchor[q] < rec.anchor) || (sAnchor[q] == rec.anchor && sSeq[q] < rec.seq);
             const int ns = nbase + before;
-            const int vid = lc.partner[rec.parentVid];  // set by k_lc_assign
-            lc.slotOf[vid] = ns;
-            c.s.vid[ns] = vid;
+            const int route = c.s.route[ps], routePos = c.s.routePos[ps];
+            lc.slotOf[v] = ns;
+            c.s.vid[ns] = v;
             c.s.drv[ns] = d;
-            c.s.prevDrv[ns] = st.prevDrv;
-            c.s.next[ns] = nextOf(c.n, c.t, d, st.route, st.routePos);
+            c.s.prevDrv[ns] = c.s.prevDrv[ps];
+            c.s.next[ns] = nextOf(c.n, c.t, d, route, routePos);
             c.s.blocker[ns] = -1;
-            c.s.enterLLT[ns] = st.enterLLT;
-            c.s.routePos[ns] = st.routePos;
-            c.s.templ[ns] = st.templ;
-            c.s.route[ns] = st.route;
-            c.s.flags[ns] = (uint8_t) st.flags;
+            c.s.enterLLT[ns] = c.s.enterLLT[ps];
+            c.s.routePos[ns] = routePos;
+            c.s.templ[ns] = c.s.templ[ps];
+            c.s.route[ns] = route;
+            c.s.flags[ns] = c.s.flags[ps];
             c.s.dis[ns] = rec.dis;
-            c.s.speed[ns] = st.speed;
+            c.s.speed[ns] = c.s.speed[ps];
         }
         if (tid == 0) {
             segStartNow[d] = nbase;
             cntNow_[d] = live + m;  // (the admission stays pending behind them: cntNow)
             c.laneTail[d] = nbase + n + m - 1;
         }
+    }
+    // shadows named provisionally (-(record + 2)) in the walk get their numbers (fixCount is cleared by k_scatter)
+    int nFix = *lc.fixCount;
+    if (nFix > lc.fixCap) nFix = lc.fixCap;
+    for (int i0 = blockIdx.x * 64; i0 < nFix; i0 += gridDim.x * 64) {
+        const int i = i0 + tid;
+        if (i < nFix) {
+            const int who = lc.fixList[3 * i], which = lc.fixList[3 * i + 1], key = lc.insKey[lc.fixList[3 * i + 2]];
+            int rank = 0;
+            for (int j = 0; j < nIns; ++j) rank += lc.insKey[j] < key;
+            if (which) lc.tFollower[who] = lc.firstShadowVid + rank;
+            else lc.tLeader[who] = lc.firstShadowVid + rank;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        sc->active += nIns;  // activeVehicleCount++ per shadow
+        pollOut[0] = *lc.insCount;  // > insCap tells the host the supply was too small
+        pollOut[1] = sc->overflow;  // a capacity of the schedule walk was exceeded: the step is not valid
+        __threadfence_system();
     }
 }
 
