@@ -234,6 +234,15 @@ __device__ __forceinline__ void lcInitVid(const LcDev &lc, int v) {
     lc.slotOf[v] = -1;
 }
 
+// A step's few spawn records as kernel arguments of the admission kernel (kr_admit, cfx_ring_kernels.h, has the story)
+constexpr int kAdmitRecs = 128;
+struct SpawnBatch {
+    int n, firstNewVid;
+    double enterTime;
+    int32_t lane[kAdmitRecs], prevWait[kAdmitRecs], route[kAdmitRecs], priority[kAdmitRecs];
+    int16_t templ[kAdmitRecs], vidOff[kAdmitRecs];
+};
+
 // Vehicles on drivable d as phases 3/4 see them.  cnt[] is the committed count; a lane's admission of THIS step
 // (Engine::handleWaiting, phase 2) is not folded into it until the compaction (k_scan) — it is the flag
 // admitStep[lane] == step plus the vehicle written into the lane's spare slot — so that nothing phase 2 writes is

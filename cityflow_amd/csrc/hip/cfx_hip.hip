@@ -1044,7 +1044,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // ring layout: a step's few records go with kr_admit's arguments (each lane's thread links its own): no launch.  They
         // fit if they are few, all for lanes of this engine, and all enter at the same time (what a host spawner produces:
         // Engine::getCurrentTime); record i of the batch is vehicle spawned + i, whatever order they came in
-        bool inArgs = (e->ring || e->useTails()) && n <= kAdmitRecs;  // (kr_admit / kd_admit take the batch)
+        bool inArgs = n <= kAdmitRecs;  // (kr_admit / kd_admit / k_admit take the batch)
         if (inArgs) {
             batch.n = (int) n;
             batch.firstNewVid = (int) e->spawned;
@@ -1316,7 +1316,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->lcSegValid = true;
     }
     if (tails) e->launch(PK_ADMIT, kd_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
-    else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, (const int32_t *) e->waitHead, e->vt, e->cs);
+    else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
     if (e->lc.on) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt

@@ -161,40 +161,102 @@ __global__ void k_lc_naive(StepCtx c) {
     }
 }
 
-// Engine::handleWaiting engine.cpp:502-516 + Lane::available roadnet.cpp:428-435
-__global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, VidTable vt, CompactScratch cs) {
-    int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= c.n.L + c.n.K) return;
+// Engine::handleWaiting engine.cpp:502-516 + Lane::available roadnet.cpp:428-435 (engines with lane change: the others
+// run kr_admit / kd_admit).  A step's few spawn records travel in the kernel arguments (SpawnBatch: kr_admit has the story):
+// each lane's thread links its own records into its waiting queue, block 0 writes the vehicle table — no k_spawn_link launch.
+__global__ __launch_bounds__(kBlock) void k_admit(StepCtx c, int32_t *admitStep, int32_t *waitHead, VidTable vt, CompactScratch cs,
+                                                  const SpawnBatch batch) {
+    __shared__ int sLane[kAdmitRecs];
+    const int nRecs = batch.n, firstNewVid = batch.firstNewVid;
+    if ((int) threadIdx.x < nRecs) sLane[threadIdx.x] = batch.lane[threadIdx.x];
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool isLane = lane < c.n.L, inRange = lane < c.n.L + c.n.K;
+    int w = -1, n = 0, base = 0;
+    if (isLane) {
+        w = waitHead[lane];
+        n = c.cnt[lane];
+        base = c.segStart[lane];
+    }
+    int wt = 0, route = 0, nextWait = -1;
+    uint8_t pending = 0;
+    if (w >= 0) {
+        wt = vt.templ[w];
+        route = vt.route[w];
+        nextWait = vt.nextWait[w];
+        pending = vt.pendingCustom[w];
+    }
+    __syncthreads();
+    if (nRecs > 0) {
+        // the vehicle table of the new vehicles (k_spawn_link): block 0.  Nobody reads these rows in this kernel — a vehicle
+        // that is admitted in the step it appears in is taken from its record
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < nRecs; i += blockDim.x) {
+                const int v = firstNewVid + batch.vidOff[i];
+                if (c.lc.on) lcInitVid(c.lc, v);
+                vt.priority[v] = batch.priority[i];
+                vt.templ[v] = batch.templ[i];
+                vt.route[v] = batch.route[i];
+                vt.enterTime[v] = batch.enterTime;
+                vt.state[v] = 0;
+                vt.pendingCustom[v] = 0;
+            }
+        if (isLane) {
+            // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367; nextWait[] of a new vehicle was pre-set to -1): this
+            // lane's records, in any order — each hangs behind its predecessor, or becomes the head where the predecessor
+            // has left the queue
+            int lo = 0, hi = nRecs;  // first record of this lane
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sLane[mid] < lane) lo = mid + 1;
+                else hi = mid;
+            }
+            int headRec = -1;
+            for (int j = lo; j < nRecs && sLane[j] == lane; ++j) {
+                const int pv = batch.prevWait[j], v = firstNewVid + batch.vidOff[j];
+                bool becomesHead = pv < 0;
+                if (pv >= firstNewVid) vt.nextWait[pv] = v;      // predecessor in this very batch: certainly still queued
+                else if (pv >= 0) {
+                    if (vt.state[pv] != 0) becomesHead = true;  // predecessor already admitted => the FIFO is empty
+                    else vt.nextWait[pv] = v;
+                }
+                if (becomesHead) headRec = j;
+            }
+            if (headRec >= 0) {
+                w = firstNewVid + batch.vidOff[headRec];
+                wt = batch.templ[headRec];
+                route = batch.route[headRec];
+                pending = 0;
+                nextWait = -1;
+                waitHead[lane] = w;
+            }
+            if (w >= 0)  // whoever was hung behind the head just now (this thread's own store: taken from the record)
+                for (int j = lo; j < nRecs && sLane[j] == lane; ++j)
+                    if (batch.prevWait[j] == w) nextWait = firstNewVid + batch.vidOff[j];
+        }
+    }
+    if (!inRange) return;
     cs.leaveCnt[lane] = 0;  // compaction scratch of every drivable (lanes and laneLinks) for this step
     cs.maxLeaveIdx[lane] = -1;
     cs.inCnt[lane] = 0;
     cs.inHead[lane] = -1;
-    if (lane >= c.n.L) {
+    if (!isLane) {
         // laneLink thread: the gate record k_action needs about "the next laneLink" in one load
         const int k = lane - c.n.L;
         int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
         c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);
         return;
     }
-    int w = waitHead[lane];
-    int n = c.cnt[lane];
-    int base = c.segStart[lane];
     c.laneTail[lane] = n > 0 ? base + n - 1 : -1;  // overwritten below if a vehicle is admitted
     bool admit = w >= 0;
-    int wt = 0;
-    if (admit) {
-        wt = vt.templ[w];
-        if (n > 0) {
-            int tail = base + n - 1;
-            if (!(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) admit = false;
-        }
+    if (admit && n > 0) {
+        int tail = base + n - 1;
+        if (!(c.s.dis[tail] > c.t.templ[c.s.templ[tail]].len + c.t.templ[wt].min_gap)) admit = false;
     }
     if (!admit) {
         if (c.lc.on) lcInitSegments(c, base, n, false);
         return;
     }
     int slot = base + n;  // the lane's spare slot
-    int route = vt.route[w];
     c.s.vid[slot] = w;
     c.s.drv[slot] = lane;
     c.s.prevDrv[slot] = -1;
@@ -204,11 +266,11 @@ __global__ void k_admit(StepCtx c, int32_t *admitStep, const int32_t *waitHead, 
     c.s.routePos[slot] = 0;
     c.s.templ[slot] = wt;
     c.s.route[slot] = route;
-    c.s.flags[slot] = vt.pendingCustom[w];
+    c.s.flags[slot] = pending;
     c.s.dis[slot] = 0.0;
     c.s.speed[slot] = c.t.templ[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
     c.laneTail[lane] = slot;
-    c.admitRec[lane] = make_int2(w, vt.nextWait[w]);
+    c.admitRec[lane] = make_int2(w, nextWait);
     admitStep[lane] = c.step;  // cnt[], the FIFO pop and the running count follow in k_scan (see cntNow)
     if (c.lc.on) lcInitSegments(c, base, n, true);
 }

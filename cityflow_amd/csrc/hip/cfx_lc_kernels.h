@@ -33,8 +33,14 @@ __device__ __forceinline__ bool lcPlanChange(const LcDev &lc, int vid, int drv) 
 // each back to front = the list from the last vehicle of segment >= seg towards the front.  Returns the index in the lane.
 __device__ inline int lcAfterIdx(const StepCtx &c, int lane, double dis, int seg) {
     const int base = c.segStart[lane], n = cntNow(c, lane);
-    int e = n - 1;
-    while (e >= 0 && c.lc.segOfSlot[base + e] < seg) --e;
+    // segment numbers never increase along the list (lcInitSegments): the last vehicle of a segment >= seg by bisection
+    int lo = 0, hi = n;
+    while (lo < hi) {  // first index whose segment number is < seg
+        const int mid = (lo + hi) >> 1;
+        if (c.lc.segOfSlot[base + mid] < seg) hi = mid;
+        else lo = mid + 1;
+    }
+    const int e = lo - 1;
     for (int k = e; k >= 0; --k)
         if (c.s.dis[base + k] >= dis) return k;
     return -1;

@@ -277,13 +277,7 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
 // The batch is kept by columns, SORTED BY LANE (a lane's thread finds its records by a binary search in the LDS copy of
 // `lane[]`); record j is the vehicle firstNewVid + vidOff[j]; all vehicles of a step enter at the same time
 // (Engine::getCurrentTime).  Kernel arguments stay well below 4 KB.
-constexpr int kAdmitRecs = 128;
-struct SpawnBatch {
-    int n, firstNewVid;
-    double enterTime;
-    int32_t lane[kAdmitRecs], prevWait[kAdmitRecs], route[kAdmitRecs], priority[kAdmitRecs];
-    int16_t templ[kAdmitRecs], vidOff[kAdmitRecs];
-};
+// (kAdmitRecs, SpawnBatch: cfx_device.h — the dense layouts' admission kernels take the batch too)
 static_assert(sizeof(SpawnBatch) + sizeof(RingCtx) + sizeof(VidTable) + 256 <= 4096, "kr_admit's arguments must stay below 4 KB");
 
 struct RingCommit {
