@@ -1310,7 +1310,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         hipLaunchKernelGGL(kd_init_tails, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->dTail[0], e->dTail[1]);
         e->tailsValid = true;
     }
-    const size_t slotBound = std::min(need, e->slotCap);
+    // grids: the slots the layout can hold; with lane change the room reserved for moving lanes lies behind them and is
+    // covered by the kernels' stride loops in the (rare) step that uses much of it
+    const size_t slotBound = std::min(need - (size_t) moveRoom() + (e->lc.on ? (size_t) 4096 : 0), e->slotCap);
     if (e->lc.on && !e->lcSegValid) {  // after a reset / cfx_load_state
         hipLaunchKernelGGL(k_lc_naive, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         e->lcSegValid = true;

@@ -29,29 +29,70 @@ __device__ __forceinline__ bool lcPlanChange(const LcDev &lc, int vid, int drv) 
     return (lc.sigSend[vid] && lc.sendTarget[vid] >= 0 && lc.sendTarget[vid] != drv) || lc.changing[vid];
 }
 
-// Lane::getVehicleAfterDistance(dis, seg) roadnet.cpp:889-898 over the lane's existing vehicles: segments seg, seg+1, ...
-// each back to front = the list from the last vehicle of segment >= seg towards the front.  Returns the index in the lane.
-__device__ inline int lcAfterIdx(const StepCtx &c, int lane, double dis, int seg) {
-    const int base = c.segStart[lane], n = cntNow(c, lane);
-    // segment numbers never increase along the list (lcInitSegments): the last vehicle of a segment >= seg by bisection
-    int lo = 0, hi = n;
-    while (lo < hi) {  // first index whose segment number is < seg
-        const int mid = (lo + hi) >> 1;
-        if (c.lc.segOfSlot[base + mid] < seg) hi = mid;
-        else lo = mid + 1;
+// SimpleLaneChange::estimateGap lanechange.cpp:221-226 for the two neighbour lanes of a vehicle AT ONCE (either may be
+// switched off): Lane::getVehicleAfterDistance(dis, seg) roadnet.cpp:889-898 over a lane's vehicles — segments seg, seg+1,
+// ... each back to front = the list from the last vehicle of a segment >= seg towards the front (segment numbers never
+// increase along the list, lcInitSegments: that vehicle is found by bisection).  The two searches are chains of dependent
+// loads of the same length; they advance in lockstep, every round's two loads in flight together.
+__device__ inline void lcEstimateGap2(const StepCtx &c, const cfx_vehicle_template *tv, bool doA, int laneA, bool doB, int laneB,
+                                      double dis, int seg, double *estA, double *estB) {
+    int baseA = 0, nA = 0, baseB = 0, nB = 0;
+    double lenA = 0.0, lenB = 0.0;
+    if (doA) {
+        baseA = c.segStart[laneA];
+        nA = cntNow(c, laneA);
+        lenA = c.n.drvLength[laneA];
     }
-    const int e = lo - 1;
-    for (int k = e; k >= 0; --k)
-        if (c.s.dis[base + k] >= dis) return k;
-    return -1;
-}
-
-// SimpleLaneChange::estimateGap lanechange.cpp:221-226
-__device__ inline double lcEstimateGap(const StepCtx &c, int lane, double dis, int seg) {
-    const int k = lcAfterIdx(c, lane, dis, seg);
-    if (k < 0) return c.n.drvLength[lane] - dis;
-    const int ls = c.segStart[lane] + k;
-    return c.s.dis[ls] - dis - c.t.templ[c.s.templ[ls]].len;
+    if (doB) {
+        baseB = c.segStart[laneB];
+        nB = cntNow(c, laneB);
+        lenB = c.n.drvLength[laneB];
+    }
+    int loA = 0, hiA = nA, loB = 0, hiB = nB;
+    while (loA < hiA || loB < hiB) {  // first index whose segment number is < seg
+        const bool a = loA < hiA, b = loB < hiB;
+        const int midA = (loA + hiA) >> 1, midB = (loB + hiB) >> 1;
+        int sa = 0, sb = 0;
+        if (a) sa = c.lc.segOfSlot[baseA + midA];
+        if (b) sb = c.lc.segOfSlot[baseB + midB];
+        if (a) {
+            if (sa < seg) hiA = midA;
+            else loA = midA + 1;
+        }
+        if (b) {
+            if (sb < seg) hiB = midB;
+            else loB = midB + 1;
+        }
+    }
+    int kA = loA - 1, kB = loB - 1;  // ... and from there towards the front: the first vehicle at or beyond `dis`
+    bool fa = kA < 0, fb = kB < 0;
+    double dA = 0.0, dB = 0.0;
+    while (!fa || !fb) {
+        double xa = 0.0, xb = 0.0;
+        if (!fa) xa = c.s.dis[baseA + kA];
+        if (!fb) xb = c.s.dis[baseB + kB];
+        if (!fa) {
+            if (xa >= dis) {
+                fa = true;
+                dA = xa;
+            } else if (--kA < 0) {
+                fa = true;
+            }
+        }
+        if (!fb) {
+            if (xb >= dis) {
+                fb = true;
+                dB = xb;
+            } else if (--kB < 0) {
+                fb = true;
+            }
+        }
+    }
+    int tA = 0, tB = 0;
+    if (kA >= 0) tA = c.s.templ[baseA + kA];
+    if (kB >= 0) tB = c.s.templ[baseB + kB];
+    if (doA) *estA = kA >= 0 ? dA - dis - tv[tA].len : lenA - dis;
+    if (doB) *estB = kB >= 0 ? dB - dis - tv[tB].len : lenB - dis;
 }
 
 // threadPlanLaneChange engine.cpp:374-390 + SimpleLaneChange::makeSignal lanechange.cpp:151-184, one thread per slot.
@@ -100,19 +141,18 @@ __global__ void k_lc_plan(StepCtx c) {
                 const int route = c.s.route[s], routePos = c.s.routePos[s];
                 const bool lastRoad = isLastRoad(c, d, route);
                 const int li = c.n.laneIndex[d];
-                double outerEst = 0;
-                if (li < nLanes - 1) {
-                    if (lastRoad || nextOf(c.n, c.t, d + 1, route, routePos) >= 0) {
-                        outerEst = lcEstimateGap(c, d + 1, dis, c.lc.segOfSlot[s]);
-                        if (outerEst > gap + t.len) target = d + 1;
-                    }
+                // the outer lane first, then the inner one if it is better still (makeSignal lanechange.cpp:160-175)
+                const bool tryOut = li < nLanes - 1, tryIn = li > 0;
+                int nOut = -1, nIn = -1;
+                if (!lastRoad) {
+                    if (tryOut) nOut = nextOf(c.n, c.t, d + 1, route, routePos);
+                    if (tryIn) nIn = nextOf(c.n, c.t, d - 1, route, routePos);
                 }
-                if (li > 0) {
-                    if (lastRoad || nextOf(c.n, c.t, d - 1, route, routePos) >= 0) {
-                        const double innerEst = lcEstimateGap(c, d - 1, dis, c.lc.segOfSlot[s]);
-                        if (innerEst > gap + t.len && innerEst > outerEst) target = d - 1;
-                    }
-                }
+                const bool evalOut = tryOut && (lastRoad || nOut >= 0), evalIn = tryIn && (lastRoad || nIn >= 0);
+                double outerEst = 0, innerEst = 0;
+                if (evalOut || evalIn) lcEstimateGap2(c, tv, evalOut, d + 1, evalIn, d - 1, dis, c.lc.segOfSlot[s], &outerEst, &innerEst);
+                if (evalOut && outerEst > gap + t.len) target = d + 1;
+                if (evalIn && innerEst > gap + t.len && innerEst > outerEst) target = d - 1;
                 urgency = 1;
                 if (target >= 0) dir = target == d + 1 ? 1 : -1;  // LaneChange::getDirection lanechange.cpp:104-113
             }
