@@ -212,6 +212,19 @@ __device__ __forceinline__ int d2i(double x) {
     return (int) x;
 }
 
+// One slot of a device-wide list for every lane of the wave that wants one: ONE atomic per wave on the list's counter (the
+// lanes that are active here), not one per lane — thousands of same-address atomics in a kernel serialise in the L2.
+// Returns the lane's index, -1 for a lane that did not ask.
+__device__ __forceinline__ int waveListAppend(int32_t *counter, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ULL) return -1;
+    const int lane = (int) (threadIdx.x & 63u), leader = __ffsll((long long) m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return want ? base + __popcll(m & ((1ULL << lane) - 1ULL)) : -1;
+}
+
 // New vehicle numbers start clean (LaneChange ctor lanechange.h:50, LaneChangeInfo vehicle.h:74-79)
 __device__ __forceinline__ void lcInitVid(const LcDev &lc, int v) {
     lc.ptype[v] = 0;

@@ -661,7 +661,7 @@ __device__ inline void finishAction(const StepCtx &c, const ActionOut &o, const 
             c.lc.bSpeed[vid] = v;  // before the yield
             c.lc.bBlocker[vid] = blockerSlot;
             if (pt != 2) {  // a shadow goes with its real vehicle
-                const int idx = atomicAdd(c.lc.parkCount, 1);
+                const int idx = waveListAppend(c.lc.parkCount, true);  // (one atomic for the lanes of the wave that park here)
                 c.lc.parkList[idx] = vid;
                 c.lc.parkIdx[vid] = idx;
                 // whom this item has to wait for in k_lc_resolve (lcResolveDep), as the tables stand in this phase — nothing

@@ -103,65 +103,73 @@ __global__ void k_lc_plan(StepCtx c) {
     const LcDev &lc = c.lc;
     const int S = c.segStart[c.n.L + c.n.K];
     const int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
-        const int vid = c.s.vid[s];
-        if (vid < 0) continue;
-        const int d = c.s.drv[s];
-        lc.slotOf[vid] = s;
-        const cfx_vehicle_template &t = tv[c.s.templ[s]];
-        const double dis = c.s.dis[s];
-        {
-            const bool head = s == 0 || c.s.drv[s - 1] != d;
-            double gap;
-            const int ls = findLeader(c, tv, s, d, head, dis, t.approach_dist, &gap);
-            if (ls >= 0) lc.gap[vid] = gap;
+    // (whole waves go round together: the step's candidate list is appended to once per wave, waveListAppend)
+    for (int s0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); s0 < S; s0 += stride) {
+        const int s = s0 + (int) (threadIdx.x & 63u);
+        const int vid = s < S ? c.s.vid[s] : -1;
+        bool isCand = false;
+        int d = -1;
+        if (vid >= 0) {
+            d = c.s.drv[s];
+            lc.slotOf[vid] = s;
+            const cfx_vehicle_template &t = tv[c.s.templ[s]];
+            const double dis = c.s.dis[s];
+            {
+                const bool head = s == 0 || c.s.drv[s - 1] != d;
+                double gap;
+                const int ls = findLeader(c, tv, s, d, head, dis, t.approach_dist, &gap);
+                if (ls >= 0) lc.gap[vid] = gap;
+            }
+            if (lc.ptype[vid] == 2) {
+                // shadows make no signals (isReal)
+            } else if (lc.changing[vid]) {  // keeps the signal it started with; still a candidate (it signals its neighbours)
+                isCand = d < c.n.L;
+            } else if (!(c.step * c.interval - lc.lastChangeTime[vid] < 3 /*coolingTime*/)) {
+                int target = -1, dir = 0, urgency = 0;
+                if (d < c.n.L) {
+                    const double dlen = c.n.drvLength[d];
+                    bool go = !(dlen - dis < 30);
+                    const double gap = lc.gap[vid];
+                    const double expectedGap = 2 * t.len + 4 * c.interval * t.max_speed;
+                    if (go && (gap > expectedGap || gap < 1.5 * t.len)) go = false;
+                    if (go) {
+                        const int road = c.n.laneRoad[d];
+                        const int nLanes = lc.roadLaneStart[road + 1] - lc.roadLaneStart[road];
+                        const int route = c.s.route[s], routePos = c.s.routePos[s];
+                        const bool lastRoad = isLastRoad(c, d, route);
+                        const int li = c.n.laneIndex[d];
+                        // the outer lane first, then the inner one if it is better still (makeSignal lanechange.cpp:160-175)
+                        const bool tryOut = li < nLanes - 1, tryIn = li > 0;
+                        int nOut = -1, nIn = -1;
+                        if (!lastRoad) {
+                            if (tryOut) nOut = nextOf(c.n, c.t, d + 1, route, routePos);
+                            if (tryIn) nIn = nextOf(c.n, c.t, d - 1, route, routePos);
+                        }
+                        const bool evalOut = tryOut && (lastRoad || nOut >= 0), evalIn = tryIn && (lastRoad || nIn >= 0);
+                        double outerEst = 0, innerEst = 0;
+                        if (evalOut || evalIn)
+                            lcEstimateGap2(c, tv, evalOut, d + 1, evalIn, d - 1, dis, c.lc.segOfSlot[s], &outerEst, &innerEst);
+                        if (evalOut && outerEst > gap + t.len) target = d + 1;
+                        if (evalIn && innerEst > gap + t.len && innerEst > outerEst) target = d - 1;
+                        urgency = 1;
+                        if (target >= 0) dir = target == d + 1 ? 1 : -1;  // LaneChange::getDirection lanechange.cpp:104-113
+                    }
+                }
+                lc.sigSend[vid] = 1;
+                lc.sendTarget[vid] = target;
+                lc.sendDir[vid] = (int8_t) dir;
+                lc.sendUrg[vid] = (int8_t) urgency;
+                isCand = target >= 0;
+            }
         }
-        if (lc.ptype[vid] == 2) continue;  // shadows make no signals (isReal)
-        auto candidate = [&]() {
+        // a candidate goes into its road's list (the schedule walk) and into the step's (its position in that walk)
+        if (isCand) {
             const int road = c.n.laneRoad[d];
             const int i = atomicAdd(&lc.roadCand[road], 1);
             if (i < kLcRoadCand) lc.roadCandList[(size_t) road * kLcRoadCand + i] = make_int2(vid, s);
-            lc.candAll[atomicAdd(lc.candAllCount, 1)] = vid;
-        };
-        if (lc.changing[vid]) {            // keeps the signal it started with; still a candidate (it signals its neighbours)
-            if (d < c.n.L) candidate();
-            continue;
         }
-        if (c.step * c.interval - lc.lastChangeTime[vid] < 3 /*coolingTime*/) continue;
-        int target = -1, dir = 0, urgency = 0;
-        if (d < c.n.L) {
-            const double dlen = c.n.drvLength[d];
-            bool go = !(dlen - dis < 30);
-            const double gap = lc.gap[vid];
-            const double expectedGap = 2 * t.len + 4 * c.interval * t.max_speed;
-            if (go && (gap > expectedGap || gap < 1.5 * t.len)) go = false;
-            if (go) {
-                const int road = c.n.laneRoad[d];
-                const int nLanes = lc.roadLaneStart[road + 1] - lc.roadLaneStart[road];
-                const int route = c.s.route[s], routePos = c.s.routePos[s];
-                const bool lastRoad = isLastRoad(c, d, route);
-                const int li = c.n.laneIndex[d];
-                // the outer lane first, then the inner one if it is better still (makeSignal lanechange.cpp:160-175)
-                const bool tryOut = li < nLanes - 1, tryIn = li > 0;
-                int nOut = -1, nIn = -1;
-                if (!lastRoad) {
-                    if (tryOut) nOut = nextOf(c.n, c.t, d + 1, route, routePos);
-                    if (tryIn) nIn = nextOf(c.n, c.t, d - 1, route, routePos);
-                }
-                const bool evalOut = tryOut && (lastRoad || nOut >= 0), evalIn = tryIn && (lastRoad || nIn >= 0);
-                double outerEst = 0, innerEst = 0;
-                if (evalOut || evalIn) lcEstimateGap2(c, tv, evalOut, d + 1, evalIn, d - 1, dis, c.lc.segOfSlot[s], &outerEst, &innerEst);
-                if (evalOut && outerEst > gap + t.len) target = d + 1;
-                if (evalIn && innerEst > gap + t.len && innerEst > outerEst) target = d - 1;
-                urgency = 1;
-                if (target >= 0) dir = target == d + 1 ? 1 : -1;  // LaneChange::getDirection lanechange.cpp:104-113
-            }
-        }
-        lc.sigSend[vid] = 1;
-        lc.sendTarget[vid] = target;
-        lc.sendDir[vid] = (int8_t) dir;
-        lc.sendUrg[vid] = (int8_t) urgency;
-        if (target >= 0) candidate();
+        const int at = waveListAppend(lc.candAllCount, isCand);
+        if (isCand) lc.candAll[at] = vid;
     }
 }
 
