@@ -102,7 +102,11 @@ typedef struct cfx_config {
     int32_t layout;           /* vehicle order in HBM: CFX_LAYOUT_AUTO, CFX_LAYOUT_DENSE (rebuilt every step),
                                * CFX_LAYOUT_RING (per-drivable ring segments, committed in place; not with lane_change) */
     int32_t debug_sync;       /* synchronise after every kernel of a step and name the one that faulted (developer aid) */
-    int32_t ring_lanes_per_wave; /* ring layout: lanes one 256-thread workgroup of the action kernel owns (4, 8, 16, 32; 0 = default) */
+    int32_t ring_lanes_per_wave; /* ring layout, developer knob (0 = the engine decides everything): digits v = G + 1000 * (B / 256)
+                                  * + 10000 * F.  G: lanes one workgroup of the action kernel owns (0 = adaptive); B: its
+                                  * workgroup size (256 / 512 / 1024); F: form of the step — 0 by size, 1 wave-granular action
+                                  * kernel, 2 block-granular, 3 the second form (cfx_ring2_kernels.h), 4 as 0 with the commit
+                                  * as a launch of its own.  Results never depend on it (tests/test_parity_pins.py) */
     int32_t ring_capacity_percent; /* ring layout: initial ring capacities as a percentage of the bumper-to-bumper bound
                                     * (0 = 100).  Small values make the growth path run (tests); results never depend on it */
 } cfx_config;
