@@ -151,7 +151,7 @@ struct cfx_engine {
 
     // ---- lane change (cfx_config::lane_change) ----
     LcDev lc{};                        // device tables (vid-indexed ones grow with the vehicle table)
-    int32_t *oldToNew2 = nullptr;      // [slot] scratch of the mid-step rebuild
+    int32_t *oldToNew2 = nullptr;      // [slot] lane change: scratch of k_lc_resolve (which items are done)
     int32_t *hPool = nullptr;          // ... pinned staging
     int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1] overflow code, [2..] their parents in walk order
     hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
@@ -1363,7 +1363,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                   dim3(kCrossBlock), c, ao, jq);
-    if (e->lc.on) {  // (oldToNew2: scratch that is free here)
+    if (e->lc.on) {
         hipLaunchKernelGGL(k_lc_resolve, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound / 8 + kBlock - 1) / kBlock), 1024)),
                            dim3(kBlock), 0, st, c, ao, e->oldToNew2);
         hipLaunchKernelGGL(k_lc_resolve_rest, dim3(1), dim3(kBlock), 0, st, c, ao, e->oldToNew2);

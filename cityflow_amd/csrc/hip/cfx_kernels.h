@@ -513,7 +513,10 @@ __device__ inline int findLeader(const C &c, const cfx_vehicle_template *tv, int
         *gapOut = c.s.dis[ls] - tv[c.s.templ[ls]].len - myDis;
         return ls;
     }
-    return findHeadLeader(c, tv, s, d, myDis, bound, c.s.next[s], c.n.drvLength[d], gapOut).slot;
+    const int nd0 = c.s.next[s];
+    // (the head's own lane: its laneLinks in one load, as the action kernels pass them)
+    const int4 hop = (d < c.n.L && nd0 >= c.n.L) ? c.n.laneLL4[d] : make_int4(-2, -2, -2, -2);
+    return findHeadLeader(c, tv, s, d, myDis, bound, nd0, c.n.drvLength[d], gapOut, hop).slot;
 }
 
 // Tail of Engine::vehicleControl for one vehicle once its intersection speed is known: the rest of
@@ -880,7 +883,11 @@ __global__ __launch_bounds__(kActBlock) void k_action(StepCtx c, ActionOut o, Jo
     const int S = c.segStart[c.n.L + c.n.K];
     const int stride = nVehicleBlocks * blockDim.x;
     const PushJob push{q};
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) actionOne<LC>(c, o, tv, s, loadSlot(c, s), push);
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += stride) {
+        SlotIn in = loadSlot(c, s);
+        if (in.vid >= 0 && in.head && in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (findHeadLeader's first hop)
+        actionOne<LC>(c, o, tv, s, in, push);
+    }
 }
 
 // Second half of Vehicle::getIntersectionRelatedSpeed (vehicle.cpp:357-375): the walk over the crosses of the
