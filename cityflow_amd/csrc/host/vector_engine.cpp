@@ -217,7 +217,8 @@ void VectorEngineHost::workerLoop() {
 }
 
 void VectorEngineHost::forEachEnv(void (VectorEngineHost::*fn)(int)) {
-    if (R_ < 32 || hostThreads_ == 0) {  // a handful of environments: waking threads costs more than it saves
+    // a handful of environments: waking threads costs more than it saves — unless the config asks for them (cfx.hostThreads > 0)
+    if (hostThreads_ == 0 || (hostThreads_ < 0 && R_ < 32) || R_ < 2) {
         for (int r = 0; r < R_; ++r) (this->*fn)(r);
         return;
     }
