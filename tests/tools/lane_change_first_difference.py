@@ -1,12 +1,12 @@
 """Developer aid: the HIP engine and the CPU twin side by side on the bench.py workload with laneChange true, every vehicle
 field compared after EVERY step; prints the first step that differs, which fields, and the vehicles concerned."""
 import sys, json, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 sys.argv = [sys.argv[0]]
 import bench
 from cityflow_amd import _cityflow
-TWIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'libcfx_twin.so')
+TWIN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'oracle', '_ref', 'libcfx_twin.so')
 cfg = bench.build_workload("/tmp/cfa_lcdbg", 0, scenario="grid_30x30")
 c = json.load(open(cfg)); c["laneChange"] = True
 path = cfg.replace(".json", "_lc.json"); json.dump(c, open(path, "w"))
