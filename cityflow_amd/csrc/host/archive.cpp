@@ -264,7 +264,10 @@ Archive EngineHost::snapshot() {
     d.rPrevDrivable = s.prevDrivable;
     d.rBlocker = s.blocker;
     d.rEnterLLTime = s.enterLLTime;
-    d.rRoutePos = s.routePos;
+    // Router::iCurRoad of an archived vehicle: the Router copy constructor restarts it at route.begin() (router.cpp:11-14 — the
+    // archive holds copies, Archive::copyVehiclePool) and Router::update brings it to the current road when the vehicle next
+    // enters a lane; until then get_vehicle_info lists the whole route, as the reference's does after a load
+    d.rRoutePos.assign(s.routePos.size(), 0);
     d.rLeader = s.leader;
     d.rDis = s.dis;
     d.rSpeed = s.speed;
@@ -478,7 +481,6 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
     }
     d.vState.assign(nV, 0);
     const Json &drivables = root.objectAt("drivables");
-    const RouteTable &rt = spawner_.routes;
     for (int dv = 0; dv < L + (int) net_->laneLinks.size(); ++dv) {
         const Json &jd = drivables.objectAt(net_->drivableId(dv).c_str());
         for (const Json &jid : jd.arrayAt("vehicles").items) {
@@ -490,13 +492,9 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
             d.rPrevDrivable.push_back(y.prev);
             d.rBlocker.push_back(y.blocker.empty() ? -1 : vidOf.at(y.blocker));
             d.rEnterLLTime.push_back(y.ellt);
-            // Router::iCurRoad: the copy constructor restarts it at route.begin() (router.cpp:11-14) and
-            // Router::update advances it to the current road; the first occurrence is equivalent.
-            int road = dv < L ? net_->lanes[dv].road : net_->lanes[net_->laneLinks[dv - L].startLane].road;
-            int r = a.host.vehicles[vid].route, pos = 0;
-            int n = rt.routeStart[r + 1] - rt.routeStart[r];
-            while (pos < n && rt.roads[rt.routeStart[r] + pos] != road) ++pos;
-            d.rRoutePos.push_back(pos < n ? pos : 0);
+            // Router::iCurRoad: the copy constructor restarts it at route.begin() (router.cpp:11-14); Router::update
+            // advances it to the current road when the vehicle next enters a lane
+            d.rRoutePos.push_back(0);
             d.rLeader.push_back(-1);
             d.rDis.push_back(y.dis);
             d.rSpeed.push_back(y.speed);

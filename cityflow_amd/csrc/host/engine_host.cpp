@@ -669,8 +669,12 @@ bool EngineHost::setRoute(const std::string &vehicleId, const std::vector<std::s
         routePos = 0;
     }
     if (drivable >= L) return false;  // on a laneLink (router.cpp:246)
-    const RouteTable &rt = spawner_.routes;
-    int curRoad = rt.roads[rt.routeStart[route] + routePos];
+    // Router::setRoute starts the new route at *iCurRoad, which is the road of the vehicle's lane — except between a load and
+    // the vehicle's next lane, when the restarted cursor (archive.cpp) still names the route's FIRST road and the reference
+    // builds a route the vehicle is not on (then asserts or walks off it); the lane's road is what it means
+    (void) routePos;
+    (void) route;
+    const int curRoad = net_->lanes[drivable].road;
     std::vector<int> newAnchors{curRoad};
     newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
     std::vector<int> seq;

@@ -1292,7 +1292,7 @@ Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts
         d.rLeader.push_back(all.leader[i]);
         d.rBlocker.push_back(all.blocker[i]);
         d.rEnterLLTime.push_back(all.enterLLTime[i]);
-        d.rRoutePos.push_back(all.routePos[i]);
+        d.rRoutePos.push_back(0);  // (Router copy constructor: see EngineHost::snapshot, archive.cpp)
         d.rDis.push_back(all.dis[i]);
         d.rSpeed.push_back(all.speed[i]);
         d.rGap.push_back(all.gap[i]);
