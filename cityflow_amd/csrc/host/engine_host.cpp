@@ -451,10 +451,13 @@ std::vector<std::string> EngineHost::getVehicles(bool includeWaiting) {
         waitingVehicles(wv, wl);
         for (int32_t v : wv) byPriority.emplace_back(spawner_.vehicles[v].priority, v);
     }
+    std::vector<std::pair<int32_t, std::string>> pushed;  // pushed since the last step: in vehiclePool already (engine.cpp:605-613)
+    if (includeWaiting) spawner_.pendingPushed(pushed);
+    for (size_t i = 0; i < pushed.size(); ++i) byPriority.emplace_back(pushed[i].first, -1 - (int32_t) i);
     std::sort(byPriority.begin(), byPriority.end());
     std::vector<std::string> ret;
     ret.reserve(byPriority.size());
-    for (auto &p : byPriority) ret.emplace_back(spawner_.vehicleId(p.second));
+    for (auto &p : byPriority) ret.emplace_back(p.second >= 0 ? spawner_.vehicleId(p.second) : pushed[(size_t) (-1 - p.second)].second);
     return ret;
 }
 
@@ -508,11 +511,22 @@ int EngineHost::vidOf(const std::string &id) {
     return alive.empty() ? root : alive[0];
 }
 
+// A vehicle pushed (push_vehicle) since the last step: it gets its vehicle number with the next step's spawn records, but the
+// reference's vehiclePool / vehicleMap hold it from the moment of the call (Engine::pushVehicle engine.cpp:605-613).
+bool EngineHost::isPendingPushed(const std::string &id) const {
+    std::vector<std::pair<int32_t, std::string>> pushed;
+    spawner_.pendingPushed(pushed);
+    for (const auto &p : pushed)
+        if (p.second == id) return true;
+    return false;
+}
+
 // getLeader engine.cpp:836-850
 std::string EngineHost::getLeader(const std::string &vehicleId) {
     int vid = vidOf(vehicleId);
     uint8_t st = 2;
     if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
+    if (vid < 0 && isPendingPushed(vehicleId)) return "";  // known to the reference's vehicleMap, without a leader yet
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
     if (st == 0) return "";
     VehicleSnapshot s;
@@ -540,6 +554,8 @@ std::map<std::string, std::string> EngineHost::getVehicleInfo(const std::string 
     int vid = vidOf(vehicleId);
     uint8_t st = 2;
     if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
+    // pushed since the last step: known to the reference's vehicleMap, not running (Vehicle::getInfo vehicle.cpp:437-438)
+    if (vid < 0 && isPendingPushed(vehicleId)) return {{"running", "0"}};
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
     std::map<std::string, std::string> info;
     info["running"] = std::to_string(st == 1);
@@ -586,6 +602,11 @@ double EngineHost::getAverageTravelTime() {
     for (auto &p : live) {
         tt += now - p.second;
         n++;
+    }
+    {  // vehicles pushed since the last step are in the reference's vehiclePool already: they entered now (+ 0.0 each)
+        std::vector<std::pair<int32_t, std::string>> pushed;
+        spawner_.pendingPushed(pushed);
+        n += (int64_t) pushed.size();
     }
     return n == 0 ? 0 : tt / n;
 }

@@ -157,6 +157,7 @@ public:
     }
     std::string vehicleId(int vid, bool shadow = false) const { return spawner_.vehicleId(vid, shadow); }
     bool laneChange() const { return laneChange_; }
+    bool isPendingPushed(const std::string &id) const;
     int vidOf(const std::string &id);  // -1 if unknown
     double interval() const { return interval_; }
     size_t step() const { return step_; }

@@ -458,6 +458,11 @@ uint64_t Spawner::idSortKey(int vid) const {
     return fold((uint64_t) r.flow, 8, true) * pow11_10 + fold((uint64_t) r.number, 10, false);
 }
 
+void Spawner::pendingPushed(std::vector<std::pair<int32_t, std::string>> &out) const {
+    for (const VehicleRecord &r : pendingRecords_)
+        if (r.flow < 0) out.emplace_back(r.priority, "manually_pushed_" + std::to_string(r.number));
+}
+
 int Spawner::vidOfId(const std::string &id) const {
     auto number = [](const std::string &t, int &out) {
         if (t.empty() || t.size() > 9) return false;

@@ -114,6 +114,9 @@ public:
 
     std::string vehicleId(int vid, bool shadow = false) const;  // shadow: "<id>_shadow" (until its change completes)
     int vidOfId(const std::string &id) const;  // inverse of vehicleId (-1 if unknown)
+    // vehicles pushed (push_vehicle) since the last step: they get their vehicle numbers with the next step's spawn records,
+    // but the reference already lists them (Engine::pushVehicle puts them into vehiclePool at once, engine.cpp:605-613)
+    void pendingPushed(std::vector<std::pair<int32_t, std::string>> &priorityAndId) const;
     // An integer that orders vehicles exactly like their id strings compare ("flow_<f>_<n>" / "manually_pushed_<n>", i.e.
     // the key order of the reference's std::map<std::string, ...> getters) without building or comparing strings.
     uint64_t idSortKey(int vid) const;

@@ -325,6 +325,11 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("get_vehicle_count", &EngineHost::getVehicleCount)
         .def("get_vehicles", [](EngineHost &e, bool w) -> py::object {
                  if (e.laneChange()) return py::cast(e.getVehicles(w));  // ids change with state ("_shadow"): no id cache
+                 if (w) {  // vehicles pushed since the last step have no vehicle number yet (EngineHost::getVehicles lists them)
+                     std::vector<std::pair<int32_t, std::string>> pushed;
+                     e.spawner().pendingPushed(pushed);
+                     if (!pushed.empty()) return py::cast(e.getVehicles(w));
+                 }
                  return vehicleList(e, w);
              }, "include_waiting"_a = false)
         // dict[str, int] in std::map (lexicographic) key order like the reference, built from cached key objects
