@@ -134,3 +134,65 @@ def test_random_control_and_query_calls_equal_reference(mod, ref_module, scen, w
         assert checkpoint_record(tw) == checkpoint_record(ref), "seed %d round %d" % (seed, round_)
     time.sleep(0.2)  # reference destructor race (SURVEY.md §5.2)
     del ref
+
+
+@pytest.mark.parametrize("interval,seed", [(0.5, 21), (0.5, 22), (1.0, 23)])
+def test_waiting_finished_and_reseeded_vehicles_equal_reference(mod, ref_module, scen, workdir, interval, seed):
+    """... with a step length other than 1 s, and the calls whose subject is NOT a running vehicle: a custom speed for a vehicle
+    that still waits in its lane's buffer (it takes effect in its first step), queries about a vehicle that has left the
+    network (both raise), a new random seed without a reset, `reset(False)` in the middle."""
+    # (0.5 s: the 1x1 example; 1 s: the congested 6x6 grid, whose entry lanes have vehicles waiting)
+    base = (scen.materialize("example_1x1", workdir, interval=interval, rlTrafficLight=True, seed=int(seed)) if interval != 1.0
+            else _config(scen, workdir, True))
+    ref, tw = ref_module.Engine(base, 1), mod.Engine._with_backend(base, 1, TWIN_LIB)
+    rng = np.random.default_rng(seed)
+    seen = set()
+    exercised = {"waiting": 0, "gone": 0}
+    for round_ in range(40):
+        for _ in range(int(rng.integers(1, 6))):
+            op = int(rng.integers(0, 8))
+            if op <= 2:
+                for _ in range(int(rng.integers(1, 25))):
+                    ref.next_step()
+                    tw.next_step()
+            elif op == 3:  # a vehicle that waits in a lane's buffer
+                everybody, running = tw.get_vehicles(True), set(tw.get_vehicles())
+                assert everybody == ref.get_vehicles(True) and running == set(ref.get_vehicles())
+                waiting = [v for v in everybody if v not in running]
+                if waiting:
+                    vid = waiting[int(rng.integers(0, len(waiting)))]
+                    v = float(rng.uniform(0.0, 9.0))
+                    ref.set_vehicle_speed(vid, v)
+                    tw.set_vehicle_speed(vid, v)
+                    assert ref.get_vehicle_info(vid) == tw.get_vehicle_info(vid) == {"running": "0"}
+                    assert ref.get_leader(vid) == tw.get_leader(vid) == ""
+                    exercised["waiting"] += 1
+            elif op == 4:  # a vehicle that has left the network
+                now = set(tw.get_vehicles(True))
+                gone = sorted(seen - now)
+                seen |= now
+                if gone:
+                    vid = gone[int(rng.integers(0, len(gone)))]
+                    for e in (ref, tw):
+                        for call in (lambda: e.get_vehicle_info(vid), lambda: e.get_leader(vid), lambda: e.set_vehicle_speed(vid, 1.0)):
+                            with pytest.raises(RuntimeError, match="not found"):
+                                call()
+                        assert e.set_vehicle_route(vid, ["road_1_0_1"]) is False
+                    exercised["gone"] += 1
+            elif op == 5:
+                ref.set_random_seed(int(seed) * 100 + round_)
+                tw.set_random_seed(int(seed) * 100 + round_)
+            elif op == 6:
+                ph = int(rng.integers(0, 8))
+                ref.set_tl_phase("intersection_1_1", ph)
+                tw.set_tl_phase("intersection_1_1", ph)
+            elif op == 7 and round_ == 25:
+                ref.reset(False)
+                tw.reset(False)
+                seen.clear()
+        assert checkpoint_record(tw) == checkpoint_record(ref), "interval %s seed %d round %d" % (interval, seed, round_)
+        assert ref.get_current_time() == tw.get_current_time()
+        assert ref.get_lane_waiting_vehicle_count() == tw.get_lane_waiting_vehicle_count()
+    assert exercised["gone"] > 0 and (interval != 1.0 or exercised["waiting"] > 0), exercised
+    time.sleep(0.2)  # reference destructor race (SURVEY.md §5.2)
+    del ref
