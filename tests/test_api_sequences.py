@@ -127,6 +127,10 @@ def test_random_control_and_query_calls_equal_reference(mod, ref_module, scen, w
                 ref.push_vehicle(info, route)
                 tw.push_vehicle(info, route)
             elif op == 8 and round_ in (9, 17):
+                # (one step first: the reference's reset frees the vehicles but leaves those pushed since the last step in
+                # their road's planRouteBuffer — the next step would walk freed memory)
+                ref.next_step()
+                tw.next_step()
                 ref.set_random_seed(int(seed) + round_)
                 tw.set_random_seed(int(seed) + round_)
                 ref.reset(True)
