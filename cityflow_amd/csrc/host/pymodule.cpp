@@ -599,6 +599,8 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("set_vehicle_route", &TiledEngineHost::setRoute, "vehicle_id"_a, "route"_a)
         .def("set_replay_file", &TiledEngineHost::setReplayLogFile, "replay_file"_a)
         .def("set_save_replay", &TiledEngineHost::setSaveReplay, "open"_a)
+        .def("_pending_pushed_keyed", &TiledEngineHost::pendingPushedKeyed,
+             "(priority, id) of the vehicles pushed since the last step: every rank holds the same ones")
         .def("_vehicles_keyed", &TiledEngineHost::vehiclesKeyed, "include_waiting"_a = false, "local (priority, id) pairs")
         .def("_runs_here", &TiledEngineHost::runsHere, "vehicle_id"_a)
         .def("_local_status", [](TiledEngineHost &e) { return toArray(e.localStatus()); })

@@ -1013,9 +1013,28 @@ std::vector<std::pair<int32_t, std::string>> TiledEngineHost::vehiclesKeyed(bool
     return ret;
 }
 
+// Vehicles pushed (push_vehicle) since the last step: in the reference's vehiclePool from the moment of the call
+// (EngineHost::isPendingPushed, engine_host.cpp); every rank's spawner holds the same ones.
+std::vector<std::pair<int32_t, std::string>> TiledEngineHost::pendingPushedKeyed() const {
+    std::vector<std::pair<int32_t, std::string>> pushed;
+    spawner_.pendingPushed(pushed);
+    return pushed;
+}
+
+bool TiledEngineHost::isPendingPushed(const std::string &id) const {
+    for (const auto &p : pendingPushedKeyed())
+        if (p.second == id) return true;
+    return false;
+}
+
 std::vector<std::string> TiledEngineHost::getVehicles(bool includeWaiting) {
+    std::vector<std::pair<int32_t, std::string>> keyed = vehiclesKeyed(includeWaiting);
+    if (includeWaiting) {
+        for (auto &p : pendingPushedKeyed()) keyed.push_back(std::move(p));
+        std::sort(keyed.begin(), keyed.end());  // (priorities are unique)
+    }
     std::vector<std::string> ret;
-    for (auto &p : vehiclesKeyed(includeWaiting)) ret.push_back(std::move(p.second));
+    for (auto &p : keyed) ret.push_back(std::move(p.second));
     return ret;
 }
 
@@ -1067,6 +1086,7 @@ std::map<std::string, double> TiledEngineHost::getVehicleDistance() {
 
 std::string TiledEngineHost::getLeader(const std::string &vehicleId) {
     int vid = spawner_.vidOfId(vehicleId);
+    if (vid < 0 && isPendingPushed(vehicleId)) return "";
     int st = vid >= 0 ? statusOf(vid) : 2;
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
     if (st == 0) return "";
@@ -1079,6 +1099,7 @@ std::string TiledEngineHost::getLeader(const std::string &vehicleId) {
 
 std::map<std::string, std::string> TiledEngineHost::getVehicleInfo(const std::string &vehicleId) {
     int vid = spawner_.vidOfId(vehicleId);
+    if (vid < 0 && isPendingPushed(vehicleId)) return {{"running", "0"}};
     int st = vid >= 0 ? statusOf(vid) : 2;
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + vehicleId + "' not found");
     std::map<std::string, std::string> info;
@@ -1125,6 +1146,7 @@ double TiledEngineHost::averageTravelTimeFrom(double tt, int64_t n, const std::v
         tt += now - p.second;
         n++;
     }
+    n += (int64_t) pendingPushedKeyed().size();  // (entered now: + 0.0 each, EngineHost::getAverageTravelTime)
     return n == 0 ? 0 : tt / n;
 }
 
@@ -1361,9 +1383,8 @@ bool TiledEngineHost::setRoute(const std::string &vehicleId, const std::vector<s
         if (drivable < 0) return false;
     }
     if (drivable >= L) return false;  // on a laneLink (router.cpp:246)
-    const RouteTable &rt = spawner_.routes;
-    const int route = spawner_.vehicles[vid].route;
-    const int curRoad = rt.roads[rt.routeStart[route] + routePos];
+    (void) routePos;  // (the lane's road, not the cursor's: EngineHost::setRoute, engine_host.cpp)
+    const int curRoad = net_->lanes[drivable].road;
     std::vector<int> newAnchors{curRoad};
     newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
     std::vector<int> seq;

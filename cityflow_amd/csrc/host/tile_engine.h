@@ -192,6 +192,8 @@ public:
     std::map<std::string, std::string> getVehicleInfo(const std::string &vehicleId);
     double getAverageTravelTime();
     // several processes: the pieces the caller reduces over the ranks (cityflow_amd/tiled.py: DistributedEngine)
+    std::vector<std::pair<int32_t, std::string>> pendingPushedKeyed() const;  // pushed since the last step (same on every rank)
+    bool isPendingPushed(const std::string &id) const;
     std::vector<std::pair<int32_t, std::string>> vehiclesKeyed(bool includeWaiting);  // local {priority, id}
     bool runsHere(const std::string &vehicleId);                                       // on a drivable one of the local tiles owns
     std::vector<uint8_t> localStatus();                                                // per vehicle number, merged over the local tiles

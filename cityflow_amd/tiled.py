@@ -304,7 +304,10 @@ class DistributedEngine:
     def get_vehicles(self, include_waiting=False):
         parts = [None] * self.world
         dist.all_gather_object(parts, self._eng._vehicles_keyed(include_waiting), group=self._halo)
-        return [vid for _, vid in sorted(p for part in parts for p in part)]  # vehiclePool order = by priority (unique)
+        keyed = [p for part in parts for p in part]
+        if include_waiting:  # pushed since the last step: every rank's spawner holds the same ones, listed once
+            keyed += self._eng._pending_pushed_keyed()
+        return [vid for _, vid in sorted(keyed)]  # vehiclePool order = by priority (unique)
 
     def get_vehicle_info(self, vehicle_id):
         """Every rank makes the same call; the rank that runs the vehicle has the details."""

@@ -200,3 +200,91 @@ def test_waiting_finished_and_reseeded_vehicles_equal_reference(mod, ref_module,
     assert exercised["gone"] > 0 and (interval != 1.0 or exercised["waiting"] > 0), exercised
     time.sleep(0.2)  # reference destructor race
     del ref
+
+
+@pytest.mark.parametrize("seed", [1, 2, 27])
+def test_tiled_random_calls_equal_single_engine(mod, scen, workdir, seed):
+    """The same kind of sequence on `TiledEngine` (2x2, 2x3, 3x2 or 1x3 tiles of the 6x6 grid, all on the CPU twin) and on a
+    single engine: every getter's return value, `set_vehicle_route`'s verdicts, vehicles pushed and listed before their first
+    step, snapshot / load and reset in the middle — equal call by call (seed 27: a reroute right after a load)."""
+    rl = seed % 2 == 0
+    cfg = _config(scen, workdir, rl)
+    rows, cols = ((2, 2), (2, 3), (3, 2), (1, 3))[seed % 4]
+    one, til = mod.Engine._with_backend(cfg, 1, TWIN_LIB), mod.TiledEngine(cfg, rows, cols, [], TWIN_LIB)
+    rng = np.random.default_rng(seed)
+    with open(os.path.join(os.path.dirname(cfg), "roadnet.json")) as f:
+        net = json.load(f)
+    roads = [r["id"] for r in net["roads"]]
+    inters = [i["id"] for i in net["intersections"] if not i["virtual"]]
+    archives = None
+
+    def both(name, *a):
+        x, y = getattr(one, name)(*a), getattr(til, name)(*a)
+        assert x == y, (name, a, str(x)[:200], str(y)[:200])
+        return x
+
+    for round_ in range(20):
+        for _ in range(int(rng.integers(1, 7))):
+            op = int(rng.integers(0, 12))
+            if op <= 2:
+                for _ in range(int(rng.integers(1, 15))):
+                    one.next_step()
+                    til.next_step()
+            elif op == 3:
+                both("get_lane_vehicle_count")
+                both("get_lane_waiting_vehicle_count")
+                both("get_vehicle_count")
+            elif op == 4 and rl:
+                for i in rng.choice(len(inters), size=5, replace=False):
+                    ph = int(rng.integers(0, 8))
+                    one.set_tl_phase(inters[int(i)], ph)
+                    til.set_tl_phase(inters[int(i)], ph)
+            elif op == 5:
+                sp = both("get_vehicle_speed")
+                both("get_vehicle_distance")
+                if sp:
+                    vid = sorted(sp)[int(rng.integers(0, len(sp)))]
+                    v = float(rng.uniform(0, 12))
+                    one.set_vehicle_speed(vid, v)
+                    til.set_vehicle_speed(vid, v)
+                    both("get_vehicle_info", vid)
+                    both("get_leader", vid)
+            elif op == 6:
+                both("get_vehicles", True)
+                both("get_vehicles", False)
+                both("get_lane_vehicles")
+            elif op == 7:
+                ids = both("get_vehicles", True)
+                if ids:
+                    vid = sorted(ids)[int(rng.integers(0, len(ids)))]
+                    info = both("get_vehicle_info", vid)
+                    if info.get("road"):
+                        x, y, dirn = (int(q) for q in info["road"].split("_")[1:])
+                        a = "road_%d_%d_%d" % (x + (1, 0, -1, 0)[dirn], y + (0, 1, 0, -1)[dirn], int(rng.integers(0, 4)))
+                        if a in roads:
+                            both("set_vehicle_route", vid, [a])
+                            both("get_vehicle_info", vid)
+            elif op == 8:
+                info = {"length": float(rng.uniform(3, 8)), "maxSpeed": float(rng.uniform(8, 16)), "minGap": 2.5}
+                start = roads[int(rng.integers(0, len(roads)))]
+                x, y, dirn = (int(q) for q in start.split("_")[1:])
+                nxt = "road_%d_%d_%d" % (x + (1, 0, -1, 0)[dirn], y + (0, 1, 0, -1)[dirn], dirn)
+                route = [start, nxt] if nxt in roads else [start]
+                one.push_vehicle(info, route)
+                til.push_vehicle(info, route)
+                both("get_vehicles", True)
+                both("get_average_travel_time")
+            elif op == 9:
+                if archives is None or rng.random() < 0.5:
+                    archives = (one.snapshot(), til.snapshot())
+                else:
+                    one.load(archives[0])
+                    til.load(archives[1])
+            elif op == 10 and round_ == 12:
+                one.reset(False)
+                til.reset(False)
+                archives = None
+            elif op == 11:
+                both("get_average_travel_time")
+                both("get_current_time")
+        assert checkpoint_record(one) == checkpoint_record(til), (seed, round_)

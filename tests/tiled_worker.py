@@ -102,6 +102,20 @@ def main():
             raise AssertionError("unknown vehicle accepted")
         except RuntimeError:
             pass
+        # a vehicle pushed and asked about before its first step (listed once although every rank's spawner holds it)
+        for e in (single, eng):
+            e.push_vehicle({"length": 6.0, "maxSpeed": 12.0}, ["road_1_1_0", "road_2_1_0"])
+        listed = single.get_vehicles(True)
+        assert eng.get_vehicles(True) == listed and sum(v.startswith("manually_pushed") for v in listed) == 1
+        pushed = [v for v in listed if v.startswith("manually_pushed")][0]
+        assert eng.get_vehicle_info(pushed) == single.get_vehicle_info(pushed) == {"running": "0"}
+        assert eng.get_leader(pushed) == single.get_leader(pushed) == ""
+        assert eng.get_average_travel_time() == single.get_average_travel_time()
+        for _ in range(3):
+            eng.next_step()
+            single.next_step()
+        assert eng.get_vehicles(True) == single.get_vehicles(True)
+        assert eng.get_vehicle_info(pushed) == single.get_vehicle_info(pushed)
         sa, sb = single._scalars(), eng.scalars()
         for k in ("active_vehicle_count", "finished_vehicle_count", "cumulative_travel_time"):
             assert sa[k] == sb[k], (rank, k, sa[k], sb[k])
