@@ -288,3 +288,69 @@ def test_tiled_random_calls_equal_single_engine(mod, scen, workdir, seed):
                 both("get_average_travel_time")
                 both("get_current_time")
         assert checkpoint_record(one) == checkpoint_record(til), (seed, round_)
+
+
+def _comparable_dump(path):
+    """An Archive file without the two things that cannot be equal: Lane::history (it feeds only the unused DURATION router
+    and is not kept by this engine) and ControllerInfo::gap of a vehicle without a leader (uninitialised memory in the
+    reference's dump)."""
+    with open(path) as f:
+        d = json.load(f)
+    for dv in d["drivables"].values():
+        for k in ("history", "historyVehicleNum", "historyAverageSpeed"):
+            dv.pop(k, None)
+    for v in d["vehicles"]:
+        if not v.get("leader"):
+            v.pop("gap", None)
+    return d
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_archive_files_cross_loaded_in_the_middle_of_sequences(mod, ref_module, scen, workdir, tmp_path, seed):
+    """`snapshot().dump()` of the reference and of this engine at random moments of a sequence with custom speeds, pushed
+    vehicles and full waiting buffers: the files are equal (see _comparable_dump), each engine loads the OTHER's file (or its
+    own) and both go on identically — again and again in one run (archive.cpp:153-550)."""
+    rl = seed % 2 == 0
+    cfg = _config(scen, workdir, rl)
+    ref, tw = ref_module.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    rng = np.random.default_rng(seed)
+    exchanged = 0
+    for round_ in range(14):
+        for _ in range(int(rng.integers(1, 5))):
+            op = int(rng.integers(0, 7))
+            if op <= 2:
+                for _ in range(int(rng.integers(1, 25))):
+                    ref.next_step()
+                    tw.next_step()
+            elif op == 3:
+                sp = tw.get_vehicle_speed()
+                assert sp == ref.get_vehicle_speed()
+                if sp:
+                    vid = sorted(sp)[int(rng.integers(0, len(sp)))]
+                    v = float(rng.uniform(0, 12))
+                    ref.set_vehicle_speed(vid, v)
+                    tw.set_vehicle_speed(vid, v)
+            elif op == 4:
+                exchanged += 1
+                p_ref, p_tw = str(tmp_path / ("ref%d.json" % exchanged)), str(tmp_path / ("tw%d.json" % exchanged))
+                ref.snapshot().dump(p_ref)
+                tw.snapshot().dump(p_tw)
+                assert _comparable_dump(p_ref) == _comparable_dump(p_tw), (seed, round_)
+                if rng.random() < 0.5:
+                    tw.load_from_file(p_ref)
+                    ref.load_from_file(p_tw)
+                else:
+                    tw.load_from_file(p_tw)
+                    ref.load_from_file(p_ref)
+            elif op == 5:
+                assert ref.get_lane_vehicle_count() == tw.get_lane_vehicle_count()
+            elif op == 6:
+                info = {"length": float(rng.uniform(3, 8)), "maxSpeed": float(rng.uniform(8, 16)), "minGap": 2.5}
+                ref.push_vehicle(info, ["road_1_1_0", "road_2_1_0"])
+                tw.push_vehicle(info, ["road_1_1_0", "road_2_1_0"])
+                ref.next_step()
+                tw.next_step()
+        assert checkpoint_record(tw) == checkpoint_record(ref), (seed, round_)
+    assert exchanged >= 2
+    time.sleep(0.2)  # reference destructor race (SURVEY.md §5.2)
+    del ref
