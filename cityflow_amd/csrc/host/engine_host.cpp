@@ -327,7 +327,9 @@ cfx_scalars EngineHost::scalars() {
 }
 
 void EngineHost::reset(bool resetRnd) {
-    lcPollPending_ = false;  // cfx_reset drops the pending report with everything else
+    // (lane change: the generator must first get past the last step's shadow draws — the reference made them inside that
+    // step, and without a reseed the stream goes on from there)
+    settleLaneChange();
     pendingPhaseInter_.clear();  // TrafficLight::reset puts every light back to phase 0 anyway
     pendingPhaseValue_.clear();
     check(be_.cfx_reset(dev_), "cfx_reset");
@@ -715,6 +717,7 @@ bool EngineHost::setRoute(const std::string &vehicleId, const std::vector<std::s
 
 // pushVehicle(map, vector) engine.cpp:693-717
 void EngineHost::pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads) {
+    settleLaneChange();  // the new vehicle's priority is drawn now: after the last step's shadow draws, as in the reference
     auto get = [&info](const char *k, double d) {
         auto it = info.find(k);
         return it == info.end() ? d : it->second;

@@ -110,7 +110,10 @@ public:
     double getCurrentTime() const { return step_ * interval_; }
     double getAverageTravelTime();
     void setTrafficLightPhase(const std::string &id, int phaseIndex);
-    void setRandomSeed(int seed) { spawner_.seed(seed); }
+    void setRandomSeed(int seed) {
+        settleLaneChange();  // (the pending shadow draws belong to the old stream)
+        spawner_.seed(seed);
+    }
     void pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads);
     void reset(bool resetRnd);
     void setVehicleSpeed(const std::string &id, double speed);                        // engine.cpp:827-834

@@ -372,6 +372,40 @@ def test_lane_change_with_control_calls_reference_vs_twin(scen, workdir):
         assert r["count"] > 100
 
 
+@pytest.mark.parametrize("seed", [0, 3])
+def test_lane_change_random_control_scripts_reference_vs_twin(scen, workdir, seed):
+    """Random scripts of control calls between the steps of a lane-change run — signal phases, vehicles pushed with an initial
+    speed (also right after a step that created shadows: the new vehicle's priority is drawn AFTER those shadows' — found by
+    the fuzz run of tests/tools/lane_change_control_fuzz.py), custom speeds on the real vehicles of changing pairs — on the reference
+    (ascending `new Vehicle` addresses, own process) and on the twin: every getter's result equal at the end."""
+    if not os.path.exists(os.path.join(REF_DIR, "libmonotonic_new.so")):
+        pytest.skip("oracle/_ref reference build not present")
+    import numpy as np
+    veh = {"length": 5.0, "width": 2.0, "maxPosAcc": 2.0, "maxNegAcc": 4.5, "usualPosAcc": 2.0, "usualNegAcc": 4.5,
+           "minGap": 2.5, "maxSpeed": 16.67, "headwayTime": 1.5}
+    routes = [["road_0_1_0", "road_1_1_0"], ["road_1_0_1", "road_1_1_1"], ["road_2_1_2", "road_1_1_2"], ["road_1_2_3", "road_1_1_3"],
+              ["road_0_1_0", "road_1_1_1"], ["road_1_0_1", "road_1_1_2"]]
+    rng = np.random.default_rng(seed)
+    rl = bool(seed % 2)
+    steps = int(rng.integers(120, 320))
+    script = {}
+    for s in range(steps):
+        if rl and rng.random() < 0.08:
+            script.setdefault(str(s), []).append(["set_tl_phase", "intersection_1_1", int(rng.integers(0, 8))])
+        if rng.random() < 0.03:
+            v = dict(veh, speed=float(rng.uniform(0, 8)), maxSpeed=float(rng.uniform(9, 17)), length=float(rng.uniform(4, 7)))
+            script.setdefault(str(s), []).append(["push_vehicle", v, routes[int(rng.integers(0, len(routes)))]])
+        if rng.random() < 0.1:
+            script.setdefault(str(s), []).append(["slow_changing", int(rng.integers(1, 5)), float(rng.uniform(0, 9))])
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True, rlTrafficLight=rl, interval=(1.0, 0.5)[seed % 3 == 0],
+                           seed=int(seed))
+    env = {"CFX_LC_SCRIPT": json.dumps(script)}
+    r = lcp.run("ref", cfg, steps, env=dict(lcp.reference_env(), **env))
+    t = lcp.run("twin", cfg, steps, env=env)
+    assert lcp.compare(r, t) == [], seed
+    assert r["count"] > 100 and any(c[0] == "push_vehicle" for calls in script.values() for c in calls)
+
+
 def test_shadow_priority_peek_exact_loop(scen, workdir, lc_golden):
     """The host offers the step the priorities its generator would hand out next.  Normally that is n plain draws (fast
     path); a draw that meets a live priority or repeats sends it through the exact redraw loop of the Vehicle constructor
