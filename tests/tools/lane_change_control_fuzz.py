@@ -33,12 +33,20 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             script.setdefault(str(s), []).append(["push_vehicle", v, roads_1x1[int(rng.integers(0, len(roads_1x1)))]])
         if rng.random() < 0.1:
             script.setdefault(str(s), []).append(["slow_changing", int(rng.integers(1, 5)), float(rng.uniform(0, 9))])
+        if rng.random() < 0.01:  # (right after a step that may have created shadows: their draws belong to the old stream)
+            script.setdefault(str(s), []).append(["set_random_seed", int(rng.integers(0, 1000))])
+        if s > 60 and rng.random() < 0.004:
+            script.setdefault(str(s), []).append(["reset", bool(rng.integers(0, 2))])
     kw = {"rlTrafficLight": rl, "interval": (1.0, 0.5)[seed % 3 == 0], "seed": int(seed)}
     cfg = scen.materialize("example_1x1", wd, laneChange=True, **kw)
     env = {"CFX_LC_SCRIPT": json.dumps(script)}
     try:
-        r = lcp.run("ref", cfg, steps, env=dict(lcp.reference_env(), **env))
         t = lcp.run("twin", cfg, steps, env=env)
+        try:
+            r = lcp.run("ref", cfg, steps, env=dict(lcp.reference_env(), **env))
+        except RuntimeError as e:  # (e.g. `reset` in the middle of lane changes can crash the reference)
+            print("reference failed", seed, kw, steps, str(e)[-200:], flush=True)
+            continue
         d = lcp.compare(r, t)
         print(("ok" if not d else "FAIL"), seed, kw, steps, "calls", sum(len(v) for v in script.values()), "shadows", r["count"] - len(r["speed"]), d, flush=True)
         bad += bool(d)
