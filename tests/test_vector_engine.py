@@ -57,6 +57,27 @@ def test_vector_engine_threaded_spawners_twin(mod, scen, workdir):
            lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), envs=40, steps=100)
 
 
+def test_vector_engine_explicit_host_threads_twin(mod, scen, workdir):
+    """`"cfx": {"hostThreads": 3}` puts the spawners of even a handful of environments on the thread pool (automatic only from
+    32 environments on); results do not depend on it."""
+    import json
+    base = scen.materialize("example_1x1", workdir)
+    c = json.load(open(base))
+    c["cfx"] = {"hostThreads": 3}
+    threaded = base.replace(".json", "_ht3.json")
+    with open(threaded, "w") as f:
+        json.dump(c, f)
+    vec = mod.VectorEngine._with_backend(threaded, 6, 1, TWIN_LIB)
+    ser = mod.VectorEngine._with_backend(base, 6, 1, TWIN_LIB)
+    for s in range(120):
+        vec.next_step()
+        ser.next_step()
+        if s % 20 == 19:
+            assert np.array_equal(vec.get_lane_vehicle_count_array(), ser.get_lane_vehicle_count_array()), s
+    for e in range(6):
+        assert vec.get_vehicle_speed(e) == ser.get_vehicle_speed(e)
+
+
 def test_vector_engine_reset(mod, scen, workdir):
     vec = mod.VectorEngine._with_backend(scen.materialize("example_1x1", workdir), 2, 1, TWIN_LIB)
     for _ in range(60):
