@@ -692,22 +692,37 @@ bool EngineHost::setRoute(const std::string &vehicleId, const std::vector<std::s
         routePos = 0;
     }
     if (drivable >= L) return false;  // on a laneLink (router.cpp:246)
-    // Router::setRoute starts the new route at *iCurRoad, which is the road of the vehicle's lane — except between a load and
-    // the vehicle's next lane, when the restarted cursor (archive.cpp) still names the route's FIRST road and the reference
-    // builds a route the vehicle is not on (then asserts or walks off it); the lane's road is what it means
-    (void) routePos;
-    (void) route;
-    const int curRoad = net_->lanes[drivable].road;
-    std::vector<int> newAnchors{curRoad};
-    newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
+    // Router::setRoute starts the new route at *iCurRoad.  That is the road of the vehicle's lane — except between a load and
+    // the vehicle's next lane, when the restarted cursor (archive.cpp) still names the route's FIRST road: the reference then
+    // plans from there, and the result is good where that path leads through the road the vehicle is on (its cursor catches
+    // up at the next lane); where it does not, the reference walks off its own route (assertion, router.cpp:58) — only then
+    // the new route starts at the lane's road here.
+    const int laneRoad = net_->lanes[drivable].road;
+    const RouteTable &rt = spawner_.routes;
+    const int cursorRoad = rt.roads[rt.routeStart[route] + routePos];
     std::vector<int> seq;
-    if (!spawner_.expandRoute(newAnchors, seq)) return false;
+    auto plan = [&](int from) {
+        std::vector<int> newAnchors{from};
+        newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
+        return spawner_.expandRoute(newAnchors, seq);
+    };
+    auto positionOf = [&](int road) {
+        for (size_t i = 0; i < seq.size(); ++i)
+            if (seq[i] == road) return (int) i;
+        return -1;
+    };
+    if (!plan(cursorRoad)) return false;
+    int pos = positionOf(laneRoad);
+    if (pos < 0) {
+        if (!plan(laneRoad)) return false;
+        pos = 0;
+    }
     int newRoute = spawner_.internRoute(seq);
     // Router::onValidLane (router.h:66-68) under the new route: a next drivable exists or this is the last road
     const RouteTable &rt2 = spawner_.routes;
     int laneIdx = net_->lanes[drivable].index;
-    bool hasNext = rt2.nextLL[rt2.nextStart[rt2.routeStart[newRoute]] + laneIdx] >= 0;
-    bool lastRoad = seq.size() == 1;
+    bool hasNext = rt2.nextLL[rt2.nextStart[rt2.routeStart[newRoute] + pos] + laneIdx] >= 0;
+    bool lastRoad = seq.back() == laneRoad;
     if (!hasNext && !lastRoad) return false;
     uploadNewTablesIfAny();
     check(be_.cfx_set_vehicle_route(dev_, vid, newRoute), "cfx_set_vehicle_route");

@@ -1383,18 +1383,34 @@ bool TiledEngineHost::setRoute(const std::string &vehicleId, const std::vector<s
         if (drivable < 0) return false;
     }
     if (drivable >= L) return false;  // on a laneLink (router.cpp:246)
-    (void) routePos;  // (the lane's road, not the cursor's: EngineHost::setRoute, engine_host.cpp)
-    const int curRoad = net_->lanes[drivable].road;
-    std::vector<int> newAnchors{curRoad};
-    newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
+    // (the start road of the new route: EngineHost::setRoute, engine_host.cpp — the cursor's road where the path from there
+    // leads through the vehicle's lane's road, that road itself otherwise)
+    const int laneRoad = net_->lanes[drivable].road;
+    const RouteTable &rt = spawner_.routes;
+    const int cursorRoad = rt.roads[rt.routeStart[spawner_.vehicles[vid].route] + routePos];
     std::vector<int> seq;
-    if (!spawner_.expandRoute(newAnchors, seq)) return false;
+    auto plan = [&](int from) {
+        std::vector<int> newAnchors{from};
+        newAnchors.insert(newAnchors.end(), anchors.begin(), anchors.end());
+        return spawner_.expandRoute(newAnchors, seq);
+    };
+    auto positionOf = [&](int road) {
+        for (size_t i = 0; i < seq.size(); ++i)
+            if (seq[i] == road) return (int) i;
+        return -1;
+    };
+    if (!plan(cursorRoad)) return false;
+    int pos = positionOf(laneRoad);
+    if (pos < 0) {
+        if (!plan(laneRoad)) return false;
+        pos = 0;
+    }
     const int newRoute = spawner_.internRoute(seq);
     // Router::onValidLane (router.h:66-68) under the new route: a next drivable exists or this is the last road
     const RouteTable &rt2 = spawner_.routes;
     const int laneIdx = net_->lanes[drivable].index;
-    const bool hasNext = rt2.nextLL[rt2.nextStart[rt2.routeStart[newRoute]] + laneIdx] >= 0;
-    const bool lastRoad = seq.size() == 1;
+    const bool hasNext = rt2.nextLL[rt2.nextStart[rt2.routeStart[newRoute] + pos] + laneIdx] >= 0;
+    const bool lastRoad = seq.back() == laneRoad;
     if (!hasNext && !lastRoad) return false;
     for (auto &t : tiles_) {
         t->uploadTables(spawner_);
