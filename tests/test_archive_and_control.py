@@ -183,3 +183,33 @@ def test_string_getters_order_and_cache(mod, ref_module, scen, workdir):
     assert sorted(vids, key=ours._id_sort_key) == sorted(vids, key=lambda v: ids[v])
     time.sleep(0.2)
     del ref
+
+
+def test_set_vehicle_route_between_a_load_and_the_next_lane(mod, ref_module, scen, workdir):
+    """After a load the reference's routers point at their route's FIRST road again (Router copy constructor, router.cpp:11-14)
+    until the vehicle enters its next lane: `get_vehicle_info` lists the whole route, and `set_vehicle_route` plans from that
+    first road — the new route then begins behind the vehicle.  Same here (where the reference's result is usable at all)."""
+    cfg = scen.materialize("grid_6x6", workdir)
+    ours, ref = make(mod, cfg), ref_module.Engine(cfg, 1)
+    run(ours, 120)
+    run(ref, 120)
+    ours.load(ours.snapshot())
+    ref.load(ref.snapshot())
+    rerouted = 0
+    for vid in sorted(ref.get_vehicles()):
+        info = ref.get_vehicle_info(vid)
+        assert info == ours.get_vehicle_info(vid), vid
+        roads = info["route"].split()
+        if "road" in info and info["road"] in roads[1:]:  # on a lane, and no longer on its route's first road
+            a, b = ref.set_vehicle_route(vid, [roads[-1]]), ours.set_vehicle_route(vid, [roads[-1]])
+            assert a == b, vid
+            got = ours.get_vehicle_info(vid)
+            assert ref.get_vehicle_info(vid) == got, vid
+            rerouted += int(a and got["route"].split()[0] != info["road"])
+        if rerouted >= 10:
+            break
+    assert rerouted >= 3  # new routes that begin behind the vehicle
+    run(ours, 80)
+    run(ref, 80)
+    assert checkpoint_record(ours) == checkpoint_record(ref)
+    time.sleep(0.1)
