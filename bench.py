@@ -930,9 +930,12 @@ def main():
         }
         print(json.dumps(out), flush=True)
     job.barrier()
-    if job.dist is not None:
-        job.dist.destroy_process_group()
     sys.stdout.flush()
+    sys.stderr.flush()
+    if job.dist is not None:
+        # every rank is past the last barrier and the line is out: leave without the process group's teardown (gloo's
+        # occasionally aborts a rank on the way out, which a launcher reports as a failed run)
+        os._exit(0)
 
 
 if __name__ == "__main__":

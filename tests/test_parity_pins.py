@@ -34,10 +34,19 @@ def _with_cfx(path, **cfx):
     return out
 
 
-def _pair(mod, cfg, **cfx):
-    hip = mod.Engine(_with_cfx(cfg, **cfx) if cfx else cfg, 1)
+def _hip(mod, cfg):
+    hip = mod.Engine(cfg, 1)
     assert hip.backend_name() == "hip-gfx950"
-    return hip, mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    return hip
+
+
+def _twin_device(mod, cfg):
+    """The CPU shadows' "device": the same host on the twin library (the "cfx" object of the config is ignored there)."""
+    return mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+
+
+def _pair(mod, cfg, device=_hip, **cfx):
+    return device(mod, _with_cfx(cfg, **cfx) if cfx else cfg), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
 
 
 def _bench_cfg(workdir):
@@ -122,12 +131,9 @@ def test_forced_choices_irregular_networks(mod, scen, workdir, seed, cross, layo
     assert hip.get_vehicle_count() > 150
 
 
-@pytest.mark.parametrize("n,flows_per_100,min_running,twin_steps,layout,rl", [
-    (60, 333, 300000, 20, "dense", False), (60, 333, 300000, 20, "ring", False), (100, 333, 900000, 8, "auto", True)])
-def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_running, twin_steps, layout, rl):
-    """Sizes where the engine switches to its throughput kernels by itself (k_cross2 above 240 k slots).  The 100x100 case is
-    BASELINE.json configs[4] as an RL agent drives it: rlTrafficLight, a new phase for every signal through set_tl_phases
-    (during the build-up and between the compared steps) and the lane-count observation read every step — HIP == twin."""
+def large_checkpoint_body(mod, scen, workdir, device, n, flows_per_100, min_running, twin_steps, layout, rl, build_steps=300):
+    """Body shared by the GPU test below (device = the HIP engine) and its CPU shadow in tests/test_pin_shadows.py (device =
+    the same host on the twin library), so that a host-side change that makes it stale shows without a GPU."""
     base = scen.generate_grid(n, n, workdir)
     d = os.path.dirname(base)
     n_extra = n * n * flows_per_100 // 100
@@ -138,28 +144,48 @@ def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_
     cfg = os.path.join(d, "config_pin.json")
     with open(cfg, "w") as f:
         json.dump(dict(json.load(open(base)), flowFile=os.path.basename(flow), rlTrafficLight=rl), f)
-    hip = mod.Engine(_with_cfx(cfg, layout=layout), 1)
+    hip = device(_with_cfx(cfg, layout=layout))
     rng = np.random.default_rng(99)
     n_inter = len(hip.intersection_ids())
-    for s in range(300):
+    for s in range(build_steps):
         if rl and s % 15 == 0:
             hip.set_tl_phases(rng.integers(0, 8, size=n_inter).astype(np.int32))
         hip.next_step()
     assert hip.get_vehicle_count() >= min_running
+    # One Archive goes into all three engines: a load restarts every route cursor at the route's first road (the reference's
+    # Router copy constructor, router.cpp:11-14; archive.cpp here), so an engine that loaded is compared with engines that
+    # loaded, field for field.  `live` keeps running without the load: it must take the very same steps (nextOf searches
+    # forward from the cursor, cfx_device.h / router.cpp:49-58), everything but the cursor itself equal.
+    snap = hip.snapshot()
+    live = hip
+    hip = device(_with_cfx(cfg, layout=layout))
+    hip.load(snap)
     tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
-    tw.load(hip.snapshot())
+    tw.load(snap)
     assert_same_state(hip, tw, "%dx%d after the transfer" % (n, n))
+    assert_same_state(hip, live, "%dx%d loaded copy vs the live engine" % (n, n), skip=("route_pos",))
     for s in range(twin_steps):
         if rl and s % 2 == 0:  # the agent's action
             ph = rng.integers(0, 8, size=n_inter).astype(np.int32)
-            hip.set_tl_phases(ph)
-            tw.set_tl_phases(ph)
-        hip.next_step()
-        tw.next_step()
+            for e in (hip, tw, live):
+                e.set_tl_phases(ph)
+        for e in (hip, tw, live):
+            e.next_step()
         if rl:  # the agent's observation
             assert np.array_equal(hip.get_lane_vehicle_count_array(), tw.get_lane_vehicle_count_array()), s
+            assert np.array_equal(hip.get_lane_vehicle_count_array(), live.get_lane_vehicle_count_array()), s
         if s % 4 == 3 or s == twin_steps - 1:
             assert_same_state(hip, tw, "%dx%d %s step %d after the transfer" % (n, n, layout, s + 1))
+            assert_same_state(hip, live, "%dx%d %s step %d: loaded copy vs live" % (n, n, layout, s + 1), skip=("route_pos",))
+
+
+@pytest.mark.parametrize("n,flows_per_100,min_running,twin_steps,layout,rl", [
+    (60, 333, 300000, 20, "dense", False), (60, 333, 300000, 20, "ring", False), (100, 333, 900000, 8, "auto", True)])
+def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_running, twin_steps, layout, rl):
+    """Sizes where the engine switches to its throughput kernels by itself (k_cross2 above 240 k slots).  The 100x100 case is
+    BASELINE.json configs[4] as an RL agent drives it: rlTrafficLight, a new phase for every signal through set_tl_phases
+    (during the build-up and between the compared steps) and the lane-count observation read every step — HIP == twin."""
+    large_checkpoint_body(mod, scen, workdir, lambda c: _hip(mod, c), n, flows_per_100, min_running, twin_steps, layout, rl)
 
 
 @pytest.mark.parametrize("layout", ["dense", "ring"])
@@ -179,6 +205,10 @@ def test_travel_time_sum_keeps_the_reference_order(mod, scen, workdir, interval,
 
 
 def test_ring_growth_path(mod, scen, workdir):
+    ring_growth_body(mod, scen, workdir, _hip)
+
+
+def ring_growth_body(mod, scen, workdir, device, steps=400):
     """Rings start at a third of their bumper-to-bumper capacity (config "cfx": ringCapacityPercent): lanes fill up, the
     commit raises its near-full flag, the next step doubles every capacity and carries the vehicles over (gather ->
     re-allocate -> scatter) — several times during the run, with the state equal to the twin's throughout."""
@@ -187,12 +217,14 @@ def test_ring_growth_path(mod, scen, workdir):
     flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_dense.json"), 400, seed=7,
                             interval=2.0, base_flow=os.path.join(d, "flow.json"))
     cfg = scen.materialize("grid_6x6", workdir, flow_file=flow)
-    hip, tw = _pair(mod, cfg, layout="ring", ringCapacityPercent=30)
-    for s in range(400):
+    hip, tw = _pair(mod, cfg, device, layout="ring", ringCapacityPercent=30)
+    for s in range(steps):
         hip.next_step()
         tw.next_step()
         if s % 4 == 3:
             assert_same_state(hip, tw, "growing rings step %d" % (s + 1))
+    if device is not _hip:
+        return
     assert hip.get_vehicle_count() > 3000
     slots, scale = hip._ring_info()
     assert hip._layout() == "ring" and scale >= 2 and slots > 0, (slots, scale)
@@ -215,6 +247,10 @@ def test_leavers_that_are_not_a_prefix(mod, scen, workdir, layout):
 
 
 def test_many_spawns_per_lane_in_one_step(mod, scen, workdir):
+    many_spawns_body(mod, scen, workdir, _hip)
+
+
+def many_spawns_body(mod, scen, workdir, device, layouts=("ring", "dense")):
     """The ring step links a step's spawn records inside kr_admit (they travel in its kernel arguments, sorted by lane): 60
     flows that all start on the same three lanes put ~20 records on a lane in one step — chains inside the batch, heads where
     the queue had drained, appends behind vehicles still waiting — and a second phase with more records than the arguments
@@ -240,8 +276,8 @@ def test_many_spawns_per_lane_in_one_step(mod, scen, workdir):
     with open(flow_file, "w") as fh:
         json.dump(out, fh)
     cfg = scen.materialize("grid_6x6", workdir, flow_file=flow_file)
-    for layout in ("ring", "dense"):
-        hip, tw = _pair(mod, cfg, layout=layout)
+    for layout in layouts:
+        hip, tw = _pair(mod, cfg, device, layout=layout)
         for s in range(220):
             hip.next_step()
             tw.next_step()

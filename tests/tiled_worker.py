@@ -161,7 +161,12 @@ def main():
     dist.barrier()
     if rank == 0:
         print("TILED_OK", steps, final_count, "transport", final_transport)
-    dist.destroy_process_group()
+    dist.barrier()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    # no destroy_process_group(): gloo's teardown occasionally aborts a rank that has already printed its verdict
+    # ("terminate called without an active exception", seen once in ~50 runs); every rank is past the last barrier here
+    os._exit(0)
 
 
 if __name__ == "__main__":
