@@ -36,13 +36,6 @@ struct DevNet {
     const int4 *llPack;             // [K] {first cross entry, end of cross entries, mask word base of its intersection, RoadLinkType}
     const int4 *laneLL4;            // [L] the lane's laneLinks (Lane::laneLinks order, -1 padded); x = -2: more than four, use the CSR
     const int4 *laneEnd4;           // [L] the end lanes of those laneLinks (same positions; -1 padded / unknown)
-    // second form of the ring step (cfx_ring2_kernels.h): what a vehicle needs to know about the laneLink ahead comes with
-    // its lane's static tables instead of a per-step gate record
-    const int4 *laneInfo4;          // [L] per laneLink of laneLL4: roadLink index | RoadLinkType << 16 | has crosses << 18 (-1: none)
-    const int4 *laneInter4;         // [L] {intersection the lane ends in (-1: no laneLinks), its first mask word, its mask words, its roadLinks}
-    const int4 *llPeer;             // [K] {bits (llLocal) of the laneLinks this one crosses: low, high word — meaningful if the
-                                    //      intersection has <= 64 laneLinks —, first cross entry, end of cross entries}
-    const double *xPeerRest;        // [E] length of the peer laneLink - the peer entry's distance (Cross::notify's crossDistance)
     // tiling (cfx_halo_config); both null for an engine that owns its whole network
     const uint8_t *laneGhost;       // [L] 1: lane owned by a neighbouring tile; its vehicles are frozen proxies
     const uint8_t *laneSpare;       // [L] spare slots behind the lane's vehicles (1 admission + halo migrants)

@@ -11,12 +11,10 @@
 #include <string>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
 
 #include "cfx_kernels.h"
 #include "cfx_lc_kernels.h"
 #include "cfx_ring_kernels.h"
-#include "cfx_ring2_kernels.h"
 #include "cfx_dense_kernels.h"
 
 using namespace cfxd;
@@ -102,6 +100,17 @@ struct cfx_engine {
     size_t dPadded() const { return (size_t) ((D + kScanTile - 1) / kScanTile) * kScanTile; }
     int32_t *laneOut = nullptr;
     int32_t *hLaneOut = nullptr;  // pinned landing buffer of the per-lane getters (a D2H copy into pageable memory is staged twice)
+    // The observation of a control loop (Engine::getLaneVehicleCount engine.cpp:628-634 read after every step): once the
+    // caller has asked for the lane counts, every step's commit writes the counts it changes straight into this pinned host
+    // array (kr_commit / k_scan, a few hundred 4-byte stores over PCIe), the step no longer defers its commit to the next
+    // admission, and the getter is a wait for the stream plus a host memcpy — no launch, no copy engine.  `hCntValid`: the
+    // array equals the device's counts as of the last step enqueued (every commit since it was filled has published);
+    // `observing` is dropped again after kObserveIdle steps without a read.
+    int32_t *hCnt = nullptr;
+    bool hCntValid = false, observing = false;
+    int observeIdle = 0;
+    static constexpr int kObserveIdle = 8;
+    int32_t *publishTo() const { return (observing && hCntValid && !tiled) ? hCnt : nullptr; }
     int cross2 = -1;                // cross phase: 1 = k_cross2 (throughput), 0 = k_cross (latency), -1 = by size
     HostMirror *hMirror = nullptr;  // pinned; valid while the last thing that changed the scalars was a step
     bool mirrorValid = false;
@@ -192,16 +201,9 @@ struct cfx_engine {
     RingJob *rJobRecs = nullptr;
     LLAux *rLLAux = nullptr;
     int4 *rLLGate = nullptr;
-    // second form of the ring step (cfx_ring2_kernels.h)
-    LLSrc *rLLSrc = nullptr;                  // [K]
-    unsigned long long *rInterGreen = nullptr;  // [I]
-    unsigned long long *rLLOcc = nullptr;       // [mask words]
-    bool ringV2 = false;                      // cfx_config::ring_lanes_per_wave / 10000 == 3 selects it (developer knob)
     RingDense rd{};                    // dense staging view (getters, archive, growth)
     size_t rdCap = 0;
     int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
-    void *rScanTemp = nullptr;
-    size_t rScanTempBytes = 0;
 
     // Are the interval, every enter time seen so far and the travel-time sum multiples of 2^-10 below 2^42?  Then the
     // finish statistics need no order (exactFinishStatistics).  Sticky false once anything else shows up.
@@ -482,10 +484,6 @@ struct cfx_engine {
         c.interMask = interMask;
         c.llGate = rLLGate;
         c.llAux = rLLAux;
-        c.llSrc = rLLSrc;
-        c.interGreen = rInterGreen;
-        c.llOcc = rLLOcc;
-        c.sparseNow = ringV2 ? 1 : 0;
         c.laneTail = laneTail;
         c.admitRec = admitRec;
         c.step = (int32_t) step;
@@ -549,17 +547,10 @@ struct cfx_engine {
             if ((rc = allocRaw(&rTailNow, (size_t) D))) return rc;
             if ((rc = allocRaw(&rLLAux, (size_t) K))) return rc;
             if ((rc = allocRaw(&rLLGate, (size_t) K))) return rc;
-            if ((rc = allocRaw(&rLLSrc, (size_t) std::max(K, 1)))) return rc;
-            if ((rc = allocRaw(&rInterGreen, (size_t) std::max(I, 1)))) return rc;
-            if ((rc = allocRaw(&rLLOcc, (size_t) std::max(nMaskWords, 1)))) return rc;
             rFinCap = std::max(1 << 16, L * 8);
             if ((rc = allocRaw(&rFinKey, (size_t) rFinCap))) return rc;
             if ((rc = allocRaw(&rFinVid, (size_t) rFinCap))) return rc;
             if ((rc = allocRaw(&rFinTerm, (size_t) rFinCap))) return rc;
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, rScanTempBytes, rCnt, rOff, D + 1, stream));
-            char *tmp = nullptr;
-            if ((rc = allocRaw(&tmp, rScanTempBytes))) return rc;
-            rScanTemp = tmp;
             HIP_TRY(hipMemsetAsync(rCnt, 0, ((size_t) D + 1) * sizeof(int32_t), stream));
         }
         return CFX_OK;
@@ -578,7 +569,7 @@ struct cfx_engine {
     }
     // ring order -> dense staging arrays (Drivable::vehicles order); returns the number of running vehicles
     int ringGather(bool wantLeader, int32_t *totalOut) {
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(rScanTemp, rScanTempBytes, rCnt, rOff, D + 1, stream));
+        hipLaunchKernelGGL(kr_offsets, dim3(1), dim3(kOffBlock), 0, stream, (const int32_t *) rCnt, rOff, D + 1);
         int32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, rOff + D, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -593,8 +584,6 @@ struct cfx_engine {
     // the slots they name (rebuilt rings); the occupancy bits are rebuilt by kr_scatter_in.
     int ringClearStepTags() {
         HIP_TRY(hipMemsetAsync(rTailNow, 0xFF, (size_t) D * sizeof(TailRec), stream));
-        HIP_TRY(hipMemsetAsync(rLLSrc, 0xFF, (size_t) std::max(K, 1) * sizeof(LLSrc), stream));
-        HIP_TRY(hipMemsetAsync(rLLOcc, 0, (size_t) std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(interMask, 0, (size_t) std::max(nMaskWords, 1) * sizeof(unsigned long long), stream));
         return CFX_OK;
     }
@@ -612,7 +601,7 @@ struct cfx_engine {
         return RingCommit{rScratch, rMovers, waitHead, curPhase, remain, (int) cfg.rl_traffic_light, (int) nMaskWords,
                           sc, rFinKey, rFinVid, rFinTerm, rFinCap, jobCount,
                           tiled ? (HostMirror *) nullptr : hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
-                          lightsDone ? 1 : 0};
+                          lightsDone ? 1 : 0, publishTo()};
     }
     int settle() {
         if (!commitPending) return CFX_OK;
@@ -663,6 +652,7 @@ struct cfx_engine {
         commitPending = false;  // (whatever a deferred commit would have written is overwritten below)
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
+        hCntValid = false;
         tailsValid = false;
         lcSegValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
@@ -761,6 +751,7 @@ void cfx_destroy(cfx_engine *e) {
     }
     for (void *p : e->ipcOpened) (void) hipIpcCloseMemHandle(p);
     if (e->hLaneOut) (void) hipHostFree(e->hLaneOut);
+    if (e->hCnt) (void) hipHostFree(e->hCnt);
     if (e->hMirror) (void) hipHostFree(e->hMirror);
     if (e->hHaloSend) (void) hipHostFree(e->hHaloSend);
     if (e->hHaloRecv) (void) hipHostFree(e->hHaloRecv);
@@ -788,7 +779,6 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     // ~150 k running vehicles (30x30: 56 vs 61 us / step) and behind once that state no longer sits in the caches
     // (60x60: 112 vs 101, 100x100: 227 vs 191).  Lanes are the proxy for size known at creation.
     e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change && n->n_lanes <= 20000);
-    e->ringV2 = (cfg->ring_lanes_per_wave / 10000) % 10 == 3;
     e->ringMerge = (cfg->ring_lanes_per_wave / 10000) % 10 != 4;
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
     e->timesDyadic = cfx_engine::dyadic(cfg->interval);
@@ -846,6 +836,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->laneOut, (size_t) e->L))) return rc;
     HIP_TRY(hipHostMalloc((void **) &e->hMirror, sizeof(HostMirror), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **) &e->hLaneOut, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **) &e->hCnt, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
     if ((rc = e->allocRaw(&e->finTicket, 4))) return rc;  // [0] ticket, [2..3] 64-bit total of exactFinishStatistics
     HIP_TRY(hipMemset(e->finTicket, 0, 4 * sizeof(int32_t)));
     if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
@@ -893,39 +884,6 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         }
         if ((rc = e->uploadConst(d.laneLL4, ll4.data(), ll4.size()))) return rc;
         if ((rc = e->uploadConst(d.laneEnd4, le4.data(), le4.size()))) return rc;
-        {   // static tables of the second form of the ring step (cfx_ring2_kernels.h)
-            std::vector<int4> info((size_t) e->L), inter4((size_t) e->L), peer((size_t) e->K);
-            std::vector<double> rest((size_t) e->E);
-            for (int l = 0; l < e->L; ++l) {
-                const int b = n->lane_ll_start[l], cnt = n->lane_ll_start[l + 1] - b;
-                int v[4] = {-1, -1, -1, -1};
-                for (int q = 0; q < cnt && q < 4; ++q) {
-                    const int k = n->lane_ll[b + q];
-                    v[q] = n->ll_roadlink[k] | (n->ll_type[k] << 16) | ((n->ll_x_start[k + 1] > n->ll_x_start[k] ? 1 : 0) << 18);
-                }
-                info[l] = cnt > 4 ? make_int4(-1, -1, -1, -1) : make_int4(v[0], v[1], v[2], v[3]);
-                const int in = cnt > 0 ? n->ll_inter[n->lane_ll[b]] : -1;
-                inter4[l] = in < 0 ? make_int4(-1, 0, 0, 0)
-                                   : make_int4(in, maskStart[in], maskStart[in + 1] - maskStart[in], n->inter_n_roadlinks[in]);
-            }
-            for (int k = 0; k < e->K; ++k) {
-                unsigned long long m = 0;
-                for (int x = n->ll_x_start[k]; x < n->ll_x_start[k + 1]; ++x) {
-                    const int bit = llLocal[n->x_ll[n->x_peer[x]]];
-                    if (bit < 64) m |= 1ULL << bit;
-                }
-                if (nLL[n->ll_inter[k]] > 64) m = ~0ULL;  // (more laneLinks than one word holds: no filtering at this intersection)
-                peer[k] = make_int4((int) (unsigned) (m & 0xFFFFFFFFULL), (int) (unsigned) (m >> 32), n->ll_x_start[k], n->ll_x_start[k + 1]);
-            }
-            for (int x = 0; x < e->E; ++x) {
-                const int pe = n->x_peer[x];
-                rest[x] = n->drv_length[e->L + n->x_ll[pe]] - n->x_dist[pe];
-            }
-            if ((rc = e->uploadConst(d.laneInfo4, info.data(), info.size()))) return rc;
-            if ((rc = e->uploadConst(d.laneInter4, inter4.data(), inter4.size()))) return rc;
-            if ((rc = e->uploadConst(d.llPeer, peer.data(), peer.size()))) return rc;
-            if ((rc = e->uploadConst(d.xPeerRest, rest.data(), rest.size()))) return rc;
-        }
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
@@ -1025,6 +983,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     if (e->ring) {
         if (e->mirrorValid && __atomic_load_n(&e->hMirror->sc.ringNearFull, __ATOMIC_RELAXED) != 0) e->ringGrowRequested = true;
         if ((rc = e->ringEnsure())) return rc;
+    }
+    if (e->observing && ++e->observeIdle > cfx_engine::kObserveIdle) {  // nobody has read the lane counts for a while
+        e->observing = false;
+        e->hCntValid = false;
     }
 
     if (e->lc.on) {
@@ -1139,17 +1101,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // running vehicles as of the last step the device has completed (stale by the few steps the host runs ahead):
         // only sizes the cross phase's grid and picks its organisation
         const size_t activeEst = (size_t) (pr & 0xFFFFFFFFu) + (size_t) e->nQueueLanes * 4;
-        const bool v2 = e->ringV2;  // the second form of the step (cfx_ring2_kernels.h)
-        const bool useBig = !v2 && (e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000);  // which form of the cross phase (§4)
+        const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;  // which form of the cross phase (§4)
         // This step's commit rides with the next step's admission (one launch less per step) where the step runs kr_cross,
         // which then advances the lights; the previous step's, if it is still pending, goes with this step's admission.
-        const bool deferCommit = e->ringMerge && !v2 && !dbg && !e->tiled;
-        if (e->commitPending && v2) {
-            if ((rc = e->settle())) return rc;
-        }
-        if (v2) {
-            e->launch(PK_ADMIT, kr2_admit, dim3(gridFor(std::max(e->L, e->I))), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch);
-        } else if (e->commitPending) {
+        const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing;  // (a caller that reads the lane counts after every step wants the commit now)
+        if (e->commitPending) {
             e->commitPending = false;
             int nStatPrev = 1;
             const RingCommit rkPrev = e->commitArgs(activeEst, true, &nStatPrev);
@@ -1168,7 +1124,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // is bound by the slowest block's chain), large ones full blocks (throughput).
             // cfx_config::ring_lanes_per_wave = G + 1000 * (B / 256) overrides both (developer knob; B = 256 or 512);
             // + 10000 forces the wave form of the action kernel (kw_action; the default above 240 k vehicles), + 20000 the
-            // block form (kr_action; the default below), + 30000 the second form of the whole step (cfx_ring2_kernels.h).
+            // block form (kr_action; the default below).
             int G = e->ringG, Bsel = 256;
             const int form = (e->cfg.ring_lanes_per_wave / 10000) % 10;
             const bool blockForm = form == 2 || (form == 0 && !(useBig || activeEst > 240000));
@@ -1201,11 +1157,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             G = std::min(G, Bsel);
             const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;
             // (first form: as many blocks again at the end of the grid compute the laneLinks' notify sources)
-            const dim3 grid(nLaneBlocks + (v2 ? 1 : 2) * nLLBlocks), block(Bsel);
-            if (v2) {
-                if (Bsel == 256) e->launch(PK_ACTION, kw2_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks);
-                else e->launch(PK_ACTION, kw2_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks);
-            } else if (blockForm) {
+            const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(Bsel);
+            if (blockForm) {
                 if (Bsel == 256) e->launch(PK_ACTION, kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
                 else e->launch(PK_ACTION, kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
             } else {
@@ -1214,7 +1167,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             }
         }
         RING_CHECK("kr_action")
-        if (dbg && !v2) {
+        if (dbg) {
             HIP_TRY(hipMemsetAsync(e->laneOut, 0, 8 * sizeof(int32_t), st));
             hipLaunchKernelGGL(kr_validate, dim3(gridFor(std::max(e->D, 16))), dim3(kBlock), 0, st, c, jq, (int) e->spawned,
                                (int) e->hRouteStart.size() - 1, (int) e->ringSlots, e->laneOut);
@@ -1227,11 +1180,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 return e->fail(buf);
             }
         }
-        if (v2)
-            e->launch(PK_CROSS, kr2_cross,
-                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
-                      dim3(kCrossBlock), c, ro, jq, (const RingJob *) e->rJobRecs);
-        else if (useBig)
+        if (useBig)
             e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
                       dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
@@ -1372,7 +1321,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     e->launch(PK_SCAN, k_scan, dim3(e->nScanBlocks), dim3(kBlock), (int) e->D, (int) e->L, (const int32_t *) e->cnt[e->cur].p, e->cs,
               e->scanGranules, scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
               e->gen[nxt].drv, e->sc, e->net.laneSpare, (const int32_t *) e->admitStep, (int) e->step, e->waitHead, e->vt,
-              e->net.laneGhost, (const int2 *) e->admitRec);
+              e->net.laneGhost, (const int2 *) e->admitRec, e->publishTo(), e->lc.on ? 1 : 0);
     // finish statistics: one extra block per 64 k slots (a rank sort of the step's finishers, see finishStatistics)
     const int nStat = (int) std::min<size_t>(std::max<size_t>(1, slotBound >> 16), 64);
     e->launch(PK_SCATTER, k_scatter,
@@ -1506,9 +1455,14 @@ int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
         memset(out, 0, e->L * sizeof(int32_t));
         return CFX_OK;
     }
-    HIP_TRY(hipMemcpyAsync(e->hLaneOut, e->ring ? e->rCnt : e->cnt[e->cur].p, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    e->observeIdle = 0;
+    if (!(e->hCntValid && e->observing)) {  // first read (or first after a load / reset / pause): fetch, and have the steps publish from now on
+        HIP_TRY(hipMemcpyAsync(e->hCnt, e->ring ? e->rCnt : e->cnt[e->cur].p, e->L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        e->hCntValid = !e->tiled;
+        e->observing = !e->tiled;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    memcpy(out, e->hLaneOut, e->L * sizeof(int32_t));
+    memcpy(out, e->hCnt, e->L * sizeof(int32_t));
     return CFX_OK;
 }
 

@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
                                                  int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
                                                  int32_t *drvNext, DevScalars *sc, const uint8_t *laneSpare,
                                                  const int32_t *admitStep, int step, int32_t *waitHead, VidTable vt,
-                                                 const uint8_t *laneGhost, const int2 *admitRec) {
+                                                 const uint8_t *laneGhost, const int2 *admitRec, int32_t *hostCnt, int hostAll) {
     __shared__ int smem[kBlock / 64];
     __shared__ int wsum[kBlock / 64];
     __shared__ int tileShared;
@@ -1468,6 +1468,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
     ps[1] = make_int4(offs[4], offs[5], offs[6], offs[7]);
     pn[0] = make_int4(live[0], live[1], live[2], live[3]);
     pn[1] = make_int4(live[4], live[5], live[6], live[7]);
+    if (hostCnt)  // a caller observes the lane counts: the lanes whose count changed, straight into its pinned host array
+        for (int i = 0; i < kScanItems; ++i)
+            if (base + i < L && (hostAll || live[i] != cntv[i])) hostCnt[base + i] = live[i];
     if (base + kScanItems == D) segStartNext[D] = off0;  // D a multiple of 8 and this is the last thread with work
 }
 

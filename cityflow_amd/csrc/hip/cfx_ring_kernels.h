@@ -62,27 +62,9 @@ struct RingCtx {
     int4 *llGate;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
     int32_t *laneTail;
     int2 *admitRec;
-    // second form of the step (cfx_ring2_kernels.h)
-    struct LLSrc *llSrc;              // [K] notify sources written by the lanes' admission threads (tagged with the step)
-    unsigned long long *interGreen;   // [I] roadLinks that are available in the intersection's current phase (bit = roadLink index)
-    unsigned long long *llOcc;        // [mask words] laneLinks with vehicles ON them (kept up by kr_commit; interMask holds the
-                                      //              laneLinks that have a source on an adjoining lane this step)
-    int sparseNow;                    // tailNow holds records of THIS step's admissions only (tag == step), see tailNowOf
     int32_t step;
     double interval;
 };
-
-// The notify sources of one laneLink beside the vehicles on it (Engine::threadNotifyCross engine.cpp:331-342, 362-363): u = the
-// vehicle that has just left it onto its end lane (that lane's tail), f = the first vehicle of its start lane if it heads
-// here (whether the light lets it is the reader's test).  Each half is written by the thread of the lane the vehicle is on
-// and is valid for the step in its tag; `blk` = the vehicle's blocker (a vehicle number) if it was set in the last step.
-struct LLSrc {
-    int32_t uSlot, uTempl, uTag, uBlk;
-    double uDis, uSpeed;
-    int32_t fSlot, fTempl, fTag, fBlk;
-    double fRest, fSpeed;  // fRest = length of the start lane - the vehicle's distance
-};
-static_assert(sizeof(LLSrc) == 64, "laneLink source record layout");
 
 __device__ __forceinline__ int ringSlot(const int2 geo, int head, int i) { return geo.x + ((head + i) & geo.y); }
 
@@ -108,12 +90,7 @@ __device__ __forceinline__ Tail tailCommitted(const RingCtx &c, int d) {  // Dri
 }
 __device__ __forceinline__ Tail tailNowOf(const RingCtx &c, int d) {
     if (c.betweenSteps) return tailCommitted(c, d);
-    if (!c.sparseNow) return tailOfRec(c.tailNow[d]);
-    if (d < c.n.L) {  // (second form of the step: only a lane that admitted a vehicle this step has a record of this step)
-        const TailRec r = c.tailNow[d];
-        if (r.tag == c.step) return tailOfRec(r);
-    }
-    return tailCommitted(c, d);
+    return tailOfRec(c.tailNow[d]);
 }
 __device__ __forceinline__ Tail tailForLeader(const RingCtx &c, int d, bool viewerNew, int viewerLane) {
     return (viewerNew && d < viewerLane && d < c.n.L) ? tailNowOf(c, d) : tailCommitted(c, d);
@@ -300,6 +277,7 @@ struct RingCommit {
     int32_t *slotOfW;  // a finished vehicle's entry becomes -1 (blocker chains end there)
     int exactTimes;  // every time involved is a multiple of 2^-10: the travel-time sum is order-free (exactFinishStatistics)
     int lightsDone;  // the step's cross kernel has already advanced the lights (kr_cross with lights.on)
+    int32_t *hostCnt;  // pinned host copy of the lane counts, kept up by the commit while a caller observes them (or null)
 };
 struct CommitOut {  // what a drivable's commit leaves, for the admission that follows it in the same thread
     int touched, head, n, tailWritten;
@@ -1332,7 +1310,6 @@ __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, con
     const int2 geo = c.ringGeo[d];
     int head = c.head[d];
     int n = c.cnt[d];
-    const int nWas = n;
     if (admitted) {  // commit this step's admission (phase 2): the FIFO pop and the vehicle's state
         const int2 rec = c.admitRec[d];
         k.waitHead[d] = rec.y;
@@ -1446,12 +1423,7 @@ __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, con
     else if (n + min(8, (geo.y + 1) / 2) > geo.y) k.sc->ringNearFull = 1;  // (the host doubles every capacity)
     c.head[d] = head;
     c.cnt[d] = n;
-    if (d >= c.n.L && (nWas > 0) != (n > 0)) {  // "this laneLink has vehicles on it", for the cross phase of the second form
-        const int kk = d - c.n.L, bit = c.n.llLocal[kk];
-        unsigned long long *word = &c.llOcc[c.n.llPack[kk].z + (bit >> 6)];
-        if (n > 0) atomicOr(word, 1ULL << (bit & 63));
-        else atomicAnd(word, ~(1ULL << (bit & 63)));
-    }
+    if (k.hostCnt && d < c.n.L) k.hostCnt[d] = n;  // (the host's copy: a lane that was not touched keeps its value there too)
     k.scratch[d] = make_int4(0, -1, -1, 0);
     if (out) {
         out->touched = 1;
@@ -1544,10 +1516,6 @@ __global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTa
     const int n = off[d + 1] - off[d];
     c.head[d] = 0;
     c.cnt[d] = n;
-    if (d >= c.n.L && n > 0) {  // (llOcc was cleared by the caller)
-        const int kk = d - c.n.L, bit = c.n.llLocal[kk];
-        atomicOr(&c.llOcc[c.n.llPack[kk].z + (bit >> 6)], 1ULL << (bit & 63));
-    }
     const int2 geo = c.ringGeo[d];
     for (int i = 0; i < n; ++i) {
         const int s = geo.x + i, j = off[d] + i;
@@ -1573,6 +1541,41 @@ __global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTa
             r.tag = c.step - 1;
             const_cast<TailRec *>(c.tailR)[d] = r;
         }
+    }
+}
+
+// Exclusive prefix sum of the per-drivable counts (out[0] = 0 ... out[n - 1]): where each drivable's vehicles start in the
+// dense staging view of the getters / snapshot / ring growth — off the step's path, so ONE 1024-thread block walks the array
+// 4096 elements at a time (four per thread, a wavefront scan, the wavefront totals through LDS) and carries the running
+// total; 44 k drivables (30x30) are 11 rounds, 481 k (100x100) 118.
+constexpr int kOffBlock = 1024;
+__global__ __launch_bounds__(kOffBlock) void kr_offsets(const int32_t *in, int32_t *out, int n) {
+    __shared__ int sWaveSum[kOffBlock / 64];
+    __shared__ int sCarry;
+    const int t = (int) threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) sCarry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += kOffBlock * 4) {
+        const int i0 = base + t * 4;
+        int v[4];
+        for (int j = 0; j < 4; ++j) v[j] = i0 + j < n ? in[i0 + j] : 0;
+        const int mine = v[0] + v[1] + v[2] + v[3];
+        int incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) sWaveSum[wv] = incl;
+        __syncthreads();
+        int before = sCarry + incl - mine;
+        for (int i = 0; i < wv; ++i) before += sWaveSum[i];
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < n) out[i0 + j] = before;
+            before += v[j];
+        }
+        __syncthreads();
+        if (t == kOffBlock - 1) sCarry = before;  // (the last thread's running total = everything up to the end of this round)
+        __syncthreads();
     }
 }
 

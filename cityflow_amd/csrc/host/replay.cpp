@@ -64,48 +64,75 @@ Pt directionByDistance(const std::vector<Pt> &points, double dis) {
 
 }  // namespace
 
+// The "outline" polygon of an intersection in the roadnet log (what the frontend draws): the convex hull of the
+// intersection's centre and, per adjoining road, the two corners of the road's mouth (plus the two corners one
+// `deltaWidth` further up the road where the road is long enough).  Values must equal Intersection::getOutline
+// (/root/reference/src/roadnet/roadnet.cpp:750-818) to the bit, which fixes three things the geometry leaves open:
+//   * the corner arithmetic's operation order (FP64, no contraction);
+//   * the pivot = FIRST candidate of minimal y (the reference's std::min_element), removed from the candidates by position;
+//   * the order of candidates with EQUAL polar angle around the pivot: the reference hands an unstable std::sort a
+//     comparator on the angle, so the permutation is libstdc++'s introsort's for that comparator's answers.  Sorting
+//     (angle, point) pairs by the precomputed angle asks the same questions in the same order, so it moves the elements
+//     the same way — and calls atan2 once per candidate instead of twice per comparison.
+// The scan is Graham's: a candidate pops every hull vertex at which the path would not turn strictly one way.
+namespace {
+struct MouthCorners {
+    Pt near[2], far[2];
+    bool hasFar;
+};
+MouthCorners roadMouth(const HostRoadNet &net, const HostInter &in, int ii, int r) {
+    const HostRoad &road = net.roads[r];
+    Pt along = unit(sub(net.inters[road.endInter].point, net.inters[road.startInter].point));
+    const Pt across{-along.y, along.x};  // Point::normal of the road's direction BEFORE it is turned towards the intersection
+    if (road.startInter == ii) along = Pt{-along.x, -along.y};
+    double roadWidth = 0;
+    for (int j = 0; j < road.nLanes; ++j) roadWidth += net.lanes[road.laneStart + j].width;
+    double step = 0.5 * (in.width < roadWidth ? in.width : roadWidth);  // min2double / max2double of utility.h
+    step = step > 5 ? step : 5;
+    MouthCorners m;
+    m.near[0] = sub(in.point, mul(along, in.width));
+    m.near[1] = sub(m.near[0], mul(across, roadWidth));
+    m.hasFar = step < net.averageLength(r);
+    if (m.hasFar) {
+        m.far[0] = sub(m.near[0], mul(along, step));
+        m.far[1] = sub(m.near[1], mul(along, step));
+    }
+    return m;
+}
+}  // namespace
+
 std::vector<Pt> intersectionOutline(const HostRoadNet &net, int ii) {
     const HostInter &in = net.inters[ii];
-    std::vector<Pt> points;
-    points.push_back(in.point);
+    std::vector<Pt> cand{in.point};
     for (int r : in.roads) {
-        const HostRoad &road = net.roads[r];
-        Pt roadDirect = unit(sub(net.inters[road.endInter].point, net.inters[road.startInter].point));
-        Pt pDirect{-roadDirect.y, roadDirect.x};  // Point::normal
-        if (road.startInter == ii) roadDirect = Pt{-roadDirect.x, -roadDirect.y};
-        double roadWidth = 0;
-        for (int j = 0; j < road.nLanes; ++j) roadWidth += net.lanes[road.laneStart + j].width;
-        double deltaWidth = 0.5 * (in.width < roadWidth ? in.width : roadWidth);
-        deltaWidth = deltaWidth > 5 ? deltaWidth : 5;
-        Pt pointA = sub(in.point, mul(roadDirect, in.width));
-        Pt pointB = sub(pointA, mul(pDirect, roadWidth));
-        points.push_back(pointA);
-        points.push_back(pointB);
-        if (deltaWidth < net.averageLength(r)) {
-            points.push_back(sub(pointA, mul(roadDirect, deltaWidth)));
-            points.push_back(sub(pointB, mul(roadDirect, deltaWidth)));
-        }
+        const MouthCorners m = roadMouth(net, in, ii, r);
+        cand.insert(cand.end(), m.near, m.near + 2);
+        if (m.hasFar) cand.insert(cand.end(), m.far, m.far + 2);
     }
-    auto minIter = std::min_element(points.begin(), points.end(), [](const Pt &a, const Pt &b) { return a.y < b.y; });
-    const Pt p0 = *minIter;
-    std::vector<Pt> stack{p0};
-    points.erase(minIter);
-    std::sort(points.begin(), points.end(), [&p0](const Pt &a, const Pt &b) { return ang(sub(a, p0)) < ang(sub(b, p0)); });
-    for (const Pt &point : points) {
-        Pt p2 = stack.back();
-        if (stack.size() < 2) {
-            if (point.x != p2.x || point.y != p2.y) stack.push_back(point);
+    size_t pivotAt = 0;
+    for (size_t i = 1; i < cand.size(); ++i)
+        if (cand[i].y < cand[pivotAt].y) pivotAt = i;
+    const Pt pivot = cand[pivotAt];
+    struct Keyed {
+        double angle;
+        Pt p;
+    };
+    std::vector<Keyed> rest;
+    rest.reserve(cand.size());
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (i != pivotAt) rest.push_back(Keyed{ang(sub(cand[i], pivot)), cand[i]});
+    std::sort(rest.begin(), rest.end(), [](const Keyed &a, const Keyed &b) { return a.angle < b.angle; });
+    std::vector<Pt> hull{pivot};
+    for (const Keyed &k : rest) {
+        const Pt &q = k.p;
+        if (hull.size() == 1) {  // (only here does the reference drop a candidate that coincides with the hull's top)
+            if (q.x != pivot.x || q.y != pivot.y) hull.push_back(q);
             continue;
         }
-        Pt p1 = stack[stack.size() - 2];
-        while (stack.size() > 1 && cross(sub(point, p2), sub(p2, p1)) >= 0) {
-            p2 = p1;
-            stack.pop_back();
-            if (stack.size() > 1) p1 = stack[stack.size() - 2];
-        }
-        stack.push_back(point);
+        while (hull.size() >= 2 && cross(sub(q, hull.back()), sub(hull.back(), hull[hull.size() - 2])) >= 0) hull.pop_back();
+        hull.push_back(q);
     }
-    return stack;
+    return hull;
 }
 
 bool writeRoadnetLog(const HostRoadNet &net, const std::string &path) {

@@ -93,3 +93,29 @@ def test_replay_hip_equals_twin(mod, scen, workdir):
         b.next_step()
     del a, b
     assert open(log_a).read() == open(log_b).read()
+
+
+@pytest.mark.parametrize("seed", [3, 11, 14, 27])
+def test_roadnet_log_outlines_match_reference_on_irregular_networks(mod, scen, workdir, ref_module, seed):
+    """Intersection::getOutline (roadnet.cpp:750-818) on jittered intersections, bent roads and T / L junctions: hull pops,
+    collinear candidates and equal polar angles occur there, which the axis-aligned grids never produce — every outline point
+    equal to the reference's as a double."""
+    from test_irregular import irregular
+    base = irregular(scen, workdir, seed)
+    c = json.load(open(base))
+    logs = []
+    for tag in ("ref", "mine"):
+        cc = dict(c, saveReplay=True, roadnetLogFile="roadnet_log_irr%d_%s.json" % (seed, tag), replayLogFile="replay_irr%d_%s.txt" % (seed, tag))
+        path = os.path.join(os.path.dirname(base), "config_replay_irr%d_%s.json" % (seed, tag))
+        with open(path, "w") as f:
+            json.dump(cc, f)
+        logs.append((path, cc["dir"] + cc["roadnetLogFile"]))
+    ref = ref_module.Engine(logs[0][0], 1)
+    mine = mod.Engine._with_backend(logs[1][0], 1, TWIN_LIB)
+    ref.next_step()
+    mine.next_step()
+    time.sleep(0.2)
+    del ref, mine
+    a, b = json.load(open(logs[0][1])), json.load(open(logs[1][1]))
+    assert a == b
+    assert sum(len(n["outline"]) for n in a["static"]["nodes"]) > 100
