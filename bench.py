@@ -575,6 +575,27 @@ def judge_parity(cps, gpu_recs, gpu_details, ref_recs, detail_dir, threads, flat
     return ok, excused, rows
 
 
+def _rl_loop(e, n, mode, offset, n_inter, real_ids):
+    """n iterations of: a phase for every signal, one step, the per-lane vehicle counts; returns iterations per second."""
+    import numpy as np
+    t0 = time.perf_counter()
+    for s in range(n):
+        ph = ((offset + s) // 10) % 8
+        if mode == "array":
+            e.set_tl_phases(np.full(n_inter, ph, dtype=np.int32))
+            e.next_step()
+            obs = e.get_lane_vehicle_count_array()
+        else:
+            for iid in real_ids:
+                e.set_tl_phase(iid, ph)
+            e.next_step()
+            obs = e.get_lane_vehicle_count()
+    if hasattr(e, "sync"):
+        e.sync()
+    assert len(obs) > 0
+    return n / (time.perf_counter() - t0)
+
+
 def rl_loop_leg(job, args, cfg, workdir, state_dump):
     """RL-style use of the headline network (BASELINE configs[4]'s second half): every step set the phase of
     every signal, step, read the per-lane vehicle counts (reference calls: engine.cpp:628-634, 719-725).  Three ways: the
@@ -591,22 +612,7 @@ def rl_loop_leg(job, args, cfg, workdir, state_dump):
     n_inter = len(ids)
 
     def loop(e, n, mode, offset):
-        t0 = time.perf_counter()
-        for s in range(n):
-            ph = ((offset + s) // 10) % 8
-            if mode == "array":
-                e.set_tl_phases(np.full(n_inter, ph, dtype=np.int32))
-                e.next_step()
-                obs = e.get_lane_vehicle_count_array()
-            else:
-                for iid in real_ids:
-                    e.set_tl_phase(iid, ph)
-                e.next_step()
-                obs = e.get_lane_vehicle_count()
-        if hasattr(e, "sync"):
-            e.sync()
-        assert len(obs) > 0
-        return n / (time.perf_counter() - t0)
+        return _rl_loop(e, n, mode, offset, n_inter, real_ids)
 
     loop(eng, 20, "array", 0)  # warm-up
     out = {"network": "%s, rlTrafficLight, %d signals set and %d lane counts read every step" % (args.scenario, len(real_ids), len(eng.lane_ids())),
@@ -686,6 +692,16 @@ def scale_leg(job, args, n_steps):
         s1 = eng._scalars()
         roof = roofline_from_profile(prof, s1["vehicle_steps"] - s0["vehicle_steps"], scen,
                                      "%d instrumented steps" % n_steps)
+        if args.rl_seconds > 0:
+            # BASELINE configs[4] as an RL agent drives it: the same state under rlTrafficLight, every signal set, one step
+            # and the per-lane counts read, every iteration (array API)
+            rl = _cityflow.Engine(with_config(cfg, "rl", rlTrafficLight=True), 1)
+            rl.load(eng.snapshot())
+            n_inter = len(rl.intersection_ids())
+            _rl_loop(rl, 10, "array", 0, n_inter, None)
+            out["rl_loop"] = {"signals_set_per_step": n_inter, "lane_counts_read_per_step": len(rl.lane_ids()),
+                              "array_api_steps_per_sec": _rl_loop(rl, 60, "array", 10, n_inter, None)}
+            del rl
         if roof:
             roof["config"] = out
             return roof
@@ -787,6 +803,13 @@ def main():
                           "lights": {k: (int(x["curPhaseIndex"]), float(x["remainDuration"])) for k, x in lights.items()}}
         del end_arch
 
+    # ---- a longer window behind the driver-shaped one (a 20-step region is under a millisecond of device time): 200 more
+    #      steps of the same run, timed the same way; reported beside the headline, never instead of it
+    if args.steps >= 200:
+        ms_per_step_200 = elapsed / args.steps * 1e3
+    else:
+        ms_per_step_200 = timed_steps(job, eng, 200) / 200 * 1e3
+
     # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream).  Tiled runs: every
     #      rank keeps stepping (the tiles are coupled), rank 0 instruments its own tile, halo kernels included.
     # (not where several ranks share one device: their kernels take turns on it, so per-kernel times say nothing about a tile,
@@ -886,6 +909,7 @@ def main():
         out = {
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_200": ms_per_step_200,
             "higher_is_better": True, "scaling": None if world == 1 else ("strong" if (tiled and strong) else "weak"),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "steps_per_sec": args.steps * (1 if tiled else world) / elapsed,

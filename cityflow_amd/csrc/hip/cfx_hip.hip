@@ -2308,6 +2308,14 @@ int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **devic
 
 int32_t cfx_halo_mailbox_fine_grained(cfx_engine *e) { return e && e->mailboxesFineGrained ? 1 : 0; }
 
+int32_t cfx_device_identity(cfx_engine *e, char *buf, int32_t capacity) {
+    if (!e || !buf || capacity < 2) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipDeviceGetPCIBusId(buf, capacity, e->device));
+    buf[capacity - 1] = 0;
+    return CFX_OK;
+}
+
 int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t *handle, void **devicePtr) {
     if (!e || !e->tiled || !handle || !devicePtr) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };

@@ -537,6 +537,8 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("halo_transport", &TiledEngineHost::haloTransport)
         .def("device_mailboxes_fine_grained", &TiledEngineHost::deviceMailboxesFineGrained,
              "False if a device mailbox fell back to a plain allocation (safe only while every tile is on the same device)")
+        .def("device_identities", &TiledEngineHost::deviceIdentities,
+             "Physical device of each local tile (PCI bus id; \"cpu\" on the CPU twin): equal strings = one shared device")
         .def("halo_device_buffers", [](TiledEngineHost &e, int i) { return e.haloDeviceBuffers(i); }, "i"_a,
              "(send pointer, send bytes, recv pointer, recv bytes) of local tile i's device-resident halo messages")
         .def("step_begin_device", &TiledEngineHost::stepBeginDevice, "step_begin with the halo left in the device buffers")

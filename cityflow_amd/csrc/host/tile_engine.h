@@ -84,6 +84,10 @@ public:
     // (tiny shm records <prefix>_h_<from>_<to>), then opens the ones it sends into.  false: not possible here.
     bool allocDeviceMailboxes(const std::string &prefix);
     bool mailboxesFineGrained() const { return be_->cfx_halo_mailbox_fine_grained(dev_) != 0; }
+    std::string deviceIdentity() const {
+        char buf[64] = {0};
+        return be_->cfx_device_identity(dev_, buf, (int32_t) sizeof buf) == CFX_OK ? std::string(buf) : std::string("?");
+    }
     bool attachDeviceMailboxes(const std::string &prefix);
     const char *mailboxKind() const { return !mailboxes_ ? "none" : (deviceMailboxes_ ? "device" : "host"); }
     void haloPost();
@@ -230,6 +234,12 @@ public:
         for (auto &t : tiles_)
             if (!t->mailboxesFineGrained()) return false;
         return true;
+    }
+    // the physical devices of this process's tiles (equal strings = one device), in tile order
+    std::vector<std::string> deviceIdentities() const {
+        std::vector<std::string> out;
+        for (auto &t : tiles_) out.push_back(t->deviceIdentity());
+        return out;
     }
     std::string layoutName() { return tiles_.empty() ? "n/a" : tiles_.front()->layoutName(); }
     std::map<std::string, std::pair<double, int64_t>> profileRead(int localTile) { return tiles_.at(localTile)->profileRead(); }

@@ -112,6 +112,15 @@ class DistributedEngine:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._halo)
         return int(flag.item()) == 1
 
+    def _all_on_one_device(self):
+        """True if every tile of every rank reports the same PHYSICAL device (cfx_device_identity: the PCI bus id; the CPU
+        twin says "cpu").  A collective: every rank calls it at the same point."""
+        mine = list(self._eng.device_identities())
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self._halo)
+        ids = {i for part in everyone for i in part}
+        return len(ids) == 1 and "?" not in ids
+
     def _job_name(self):
         job = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if self.rank == 0 else None]
         dist.broadcast_object_list(job, src=0, group=self._halo)
@@ -131,10 +140,13 @@ class DistributedEngine:
         if transport == "device":
             job = self._job_name()
             ok = local(self._eng.device_mailbox_phase, job, 1)
+            one_device = self._all_on_one_device()  # (a collective: every rank, whatever happened locally)
             if ok and not self._eng.device_mailboxes_fine_grained():
                 # plain device memory behind a mailbox (the platform would not export fine-grained memory): a kernel on
                 # ANOTHER GPU is not guaranteed to see the sender's stores while it runs — fine only on one shared device
-                ok = self._device.type == "cpu" or torch.cuda.device_count() == 1
+                # (decided from the engines, not from torch: the process group may be gloo over HIP engines, and with a
+                # per-rank HIP_VISIBLE_DEVICES every rank sees "one device" while sitting on a different GPU)
+                ok = one_device
             if not self._all_ok(ok):  # nobody has attached anything yet: the next transport can still be tried
                 local(self._eng.unlink_mailboxes)
                 return False

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CFX_ABI_VERSION 4
+#define CFX_ABI_VERSION 5
 
 typedef enum cfx_status {
     CFX_OK = 0,
@@ -379,6 +379,10 @@ int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t handle[CFX_IPC_HANDLE
  * fine-grained memory — good between processes that share one GPU, not guaranteed across two: the caller should then use the
  * host-memory mailboxes unless all tiles sit on one device. */
 int32_t cfx_halo_mailbox_fine_grained(cfx_engine *e);
+/* The PHYSICAL device the engine runs on, as a NUL-terminated string that is equal for two engines exactly if they share
+ * a device whatever each process's visible-device numbering is (HIP: the PCI bus id, e.g. "0000:05:00.0"; a CPU
+ * implementation: "cpu").  A caller that is offered plain (coarse-grained) device mailboxes compares it over all ranks. */
+int32_t cfx_device_identity(cfx_engine *e, char *buf, int32_t capacity);
 /* The staged exchange with the messages left in device memory (for a device-to-device transport such as RCCL send / recv
  * on these very buffers): cfx_halo_export(e, NULL) then writes the send buffer only on the device, cfx_halo_import(e, NULL)
  * reads the recv buffer from the device.  Both buffers are fixed for the life of the engine. */

@@ -1457,6 +1457,11 @@ int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **ptr, 
     return CFX_OK;
 }
 int32_t cfx_halo_mailbox_fine_grained(cfx_engine *) { return 1; }
+int32_t cfx_device_identity(cfx_engine *e, char *buf, int32_t capacity) {
+    if (!e || !buf || capacity < 4) return CFX_ERR_INVALID;
+    memcpy(buf, "cpu", 4);
+    return CFX_OK;
+}
 
 int32_t cfx_halo_mailbox_open(cfx_engine *e, const uint8_t *handle, void **ptr) {
     if (!e || !e->tiled || !handle || !ptr) return CFX_ERR_INVALID;
