@@ -217,14 +217,36 @@ void VectorEngineHost::workerLoop() {
 }
 
 void VectorEngineHost::forEachEnv(void (VectorEngineHost::*fn)(int)) {
-    // a handful of environments: waking threads costs more than it saves — unless the config asks for them (cfx.hostThreads > 0)
-    if (hostThreads_ == 0 || (hostThreads_ < 0 && R_ < 32) || R_ < 2) {
+    // Whether waking threads pays depends on the work per environment, not on their number: 16 replicas of a city-scale
+    // network spend ~13 us each in their spawner (200 us serial), 16 replicas of a 6x6 grid 1.6 us (a wake-up costs more).
+    // Auto (cfx.hostThreads < 0): the first kAutoProbe batches run serially and are timed; from then on the pool is used if
+    // a serial batch took more than kAutoSerialUs.  cfx.hostThreads > 0 asks for the pool, 0 for the serial loop.
+    constexpr int kAutoProbe = 24;
+    constexpr double kAutoSerialUs = 40.0;
+    bool serial = hostThreads_ == 0 || R_ < 2;
+    if (!serial && hostThreads_ < 0) {
+        if (R_ >= 32) {
+            serial = false;
+        } else if (R_ < 4) {
+            serial = true;
+        } else if (autoBatches_ < kAutoProbe) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < R_; ++r) (this->*fn)(r);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            autoSerialUs_ = std::max(autoSerialUs_, 0.0) + us;
+            if (++autoBatches_ == kAutoProbe) autoUsePool_ = autoSerialUs_ / kAutoProbe > kAutoSerialUs;
+            return;
+        } else {
+            serial = !autoUsePool_;
+        }
+    }
+    if (serial) {
         for (int r = 0; r < R_; ++r) (this->*fn)(r);
         return;
     }
     if (workers_.empty()) {
         unsigned hw = std::thread::hardware_concurrency();
-        int n = (int) std::min<unsigned>(std::min<unsigned>(hw > 2 ? hw / 2 : 1, 16u), (unsigned) R_ / 8);
+        int n = (int) std::min<unsigned>(std::min<unsigned>(hw > 2 ? hw / 2 : 1, 16u), (unsigned) std::max(R_ / 2, 1));
         if (hostThreads_ > 0) n = std::min(hostThreads_, R_);
         for (int i = 0; i + 1 < n; ++i) workers_.emplace_back([this] { workerLoop(); });
     }

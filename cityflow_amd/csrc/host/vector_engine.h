@@ -61,6 +61,9 @@ private:
     cfx_engine *dev_ = nullptr;
     int R_ = 1, L_ = 0, K_ = 0, I_ = 0, routesPerEnv_ = 0;
     int hostThreads_ = -1;  // config "cfx": {"hostThreads": n}: -1 auto, 0 serial
+    int autoBatches_ = 0;          // auto: serial batches timed so far (forEachEnv)
+    double autoSerialUs_ = 0.0;    //       their total time
+    bool autoUsePool_ = false;     //       the verdict once enough of them were seen
     double interval_ = 1.0;
     bool rlTrafficLight_ = false;
     size_t step_ = 0;
