@@ -81,6 +81,7 @@ struct cfx_engine {
     CompactScratch cs{};
     int32_t *oldToNew = nullptr;
     int32_t *finList = nullptr, *finTicket = nullptr, *crossJobs = nullptr, *jobCount = nullptr;
+    int32_t *finCount = nullptr;  // [kFinShards * 32] counters of the finisher lists (FinMap)
     // getter scratch
     int32_t *viewLeader = nullptr;
     double *viewGap = nullptr;
@@ -601,7 +602,7 @@ struct cfx_engine {
         return RingCommit{rScratch, rMovers, waitHead, curPhase, remain, (int) cfg.rl_traffic_light, (int) nMaskWords,
                           sc, rFinKey, rFinVid, rFinTerm, rFinCap, jobCount,
                           tiled ? (HostMirror *) nullptr : hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
-                          lightsDone ? 1 : 0, publishTo()};
+                          lightsDone ? 1 : 0, publishTo(), finCount};
     }
     int settle() {
         if (!commitPending) return CFX_OK;
@@ -718,6 +719,8 @@ struct cfx_engine {
         HIP_TRY(hipMemsetAsync(scanGranules, 0, (size_t) nScanBlocks * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(scanTicket, 0, sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(jobCount, 0, (size_t) kJobShards * kJobShardStride * sizeof(int32_t), stream));
+        if (finCount) HIP_TRY(hipMemsetAsync(finCount, 0, (size_t) kFinShards * 32 * sizeof(int32_t), stream));
+        if (finTicket) HIP_TRY(hipMemsetAsync(finTicket, 0, 4 * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(oldToNew, 0xFF, slotCap * sizeof(int32_t), stream));
         if (vidCap) HIP_TRY(hipMemsetAsync(vt.nextWait, 0xFF, vidCap * sizeof(int32_t), stream));
         HIP_TRY(hipGetLastError());
@@ -839,6 +842,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     HIP_TRY(hipHostMalloc((void **) &e->hCnt, std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t), hipHostMallocDefault));
     if ((rc = e->allocRaw(&e->finTicket, 4))) return rc;  // [0] ticket, [2..3] 64-bit total of exactFinishStatistics
     HIP_TRY(hipMemset(e->finTicket, 0, 4 * sizeof(int32_t)));
+    if ((rc = e->allocRaw(&e->finCount, (size_t) kFinShards * 32))) return rc;
+    HIP_TRY(hipMemset(e->finCount, 0, (size_t) kFinShards * 32 * sizeof(int32_t)));
     if ((rc = e->allocRaw(&e->llDyn, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->llGate, (size_t) e->K))) return rc;
     if ((rc = e->allocRaw(&e->laneTail, (size_t) e->L))) return rc;
@@ -1116,7 +1121,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         }
         RING_CHECK("kr_admit")
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
-        RingOut ro{c.kinN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap};
+        RingOut ro{c.kinN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap, e->finCount};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
         {
             // One workgroup = B threads over G lanes (or B laneLinks).  G is picked so that a block's vehicles fit one pass
@@ -1268,7 +1273,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
     if (tails) e->launch(PK_ADMIT, kd_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
     else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
-    ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap};
+    ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap, e->finCount};
     if (e->lc.on) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
         // with the step's shadows in place (cfx_lc_kernels.h)
@@ -1329,7 +1334,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
               e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat,
-              e->exactTimes() ? 1 : 0, (const int32_t *) e->cnt[nxt].p);
+              e->exactTimes() ? 1 : 0, (const int32_t *) e->cnt[nxt].p, e->finCount);
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;

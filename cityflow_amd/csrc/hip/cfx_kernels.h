@@ -83,6 +83,42 @@ struct CompactScratch {
 // counters one cache line apart.
 constexpr int kJobShards = 16;
 constexpr int kJobShardStride = 32;  // ints between two counters (128 B)
+// The step's finished vehicles are listed the same way: kFinShards lists (shard = block index & 15), each with its own
+// counter one cache line from the next.  With ONE list, the ~5 000 vehicles that finish in a step of a 1 M-vehicle network
+// queue up behind a single word of the L2 (a returning atomic each, ~100-200 per microsecond and word) — tens of
+// microseconds inside kernels that take 50.  The statistics blocks read the shards as one list through FinMap.
+constexpr int kFinShards = 16;
+struct FinMap {  // (in LDS) running totals of the shards' counts: list position i lives in the shard whose total first exceeds i
+    int end[kFinShards];
+};
+// all threads of the block; returns the number of finishers
+__device__ inline int finMapLoad(FinMap &m, const int32_t *finCount, int finCap) {
+    if (threadIdx.x == 0) {
+        const int capShard = finCap / kFinShards;
+        int run = 0;
+        for (int i = 0; i < kFinShards; ++i) {
+            run += min(finCount[i * 32], capShard);
+            m.end[i] = run;
+        }
+    }
+    __syncthreads();
+    return m.end[kFinShards - 1];
+}
+__device__ __forceinline__ int finAt(const FinMap &m, int finCap, int i) {  // where list position i is stored
+    int sh = 0;
+    while (i >= m.end[sh]) ++sh;
+    return sh * (finCap / kFinShards) + (i - (sh ? m.end[sh - 1] : 0));
+}
+__device__ __forceinline__ void finCountsClear(int32_t *finCount) {
+    for (int i = 0; i < kFinShards; ++i) finCount[i * 32] = 0;
+}
+// a place in the block's shard for a vehicle that finishes now (-1: the shard is full)
+__device__ __forceinline__ int finPlace(int32_t *finCount, int finCap) {
+    const int shard = blockIdx.x & (kFinShards - 1), capShard = finCap / kFinShards;
+    const int idx = atomicAdd(&finCount[shard * 32], 1);
+    return idx < capShard ? shard * capShard + idx : -1;
+}
+
 struct JobQueue {
     int32_t *count;    // [kJobShards * kJobShardStride]
     int32_t *jobs;     // [kJobShards * capacity]
@@ -530,6 +566,7 @@ struct ActionOut {
     DevScalars *sc;
     int32_t *finList;
     int finCap;
+    int32_t *finCount;  // [kFinShards * 32], see FinMap
     // a vehicle handed to the cross phase: its two partial speeds wait in the action buffer
     __device__ __forceinline__ void park(int s, double v, double iv) const {
         b.speed[s] = v;
@@ -624,8 +661,8 @@ __device__ inline void commitMove(const StepCtx &c, const ActionOut &o, int s, i
         } else {
             o.vt.state[vid] = 2;
             if (counted) {
-                int idx = atomicAdd(&o.sc->nFinishedStep, 1);
-                if (idx < o.finCap) o.finList[idx] = s;
+                const int at = finPlace(o.finCount, o.finCap);
+                if (at >= 0) o.finList[at] = s;
                 else o.sc->overflow = 1;
             } else {
                 atomicAdd(&o.sc->nLeftUncounted, 1);
@@ -853,11 +890,24 @@ __device__ __forceinline__ void actionOne(const C &c, const Out &o, const cfx_ve
 
 // queue for the cross phase.  The counter is sharded: one word takes only ~88 returning atomics per us (MI355X guide,
 // "dequeue"), and a step issues one per wave.
+// A place in the block's shard of the job queue for every lane of the wavefront that pushes a job right now (= the lanes
+// active at the call): ONE returning atomic per wavefront instead of one per vehicle.  A step of the 30x30 workload queues
+// ~12 k vehicles; with one atomic each that is ~800 same-address atomics per shard, which the L2 serialises at ~90 per
+// microsecond and word — several microseconds of queueing inside a 12 us kernel.
+__device__ __forceinline__ int jobQueuePlace(const JobQueue &q) {
+    const int shard = blockIdx.x & (kJobShards - 1);
+    const unsigned long long m = __ballot(1);
+    const int lane = (int) (threadIdx.x & 63u), leader = __ffsll((long long) m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&q.count[shard * kJobShardStride], __popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + __popcll(m & ((1ULL << lane) - 1ULL));
+}
 struct PushJob {
     JobQueue q;
     __device__ __forceinline__ void operator()(int s, const JobInfo &) const {
         const int shard = blockIdx.x & (kJobShards - 1);
-        const int idx = atomicAdd(&q.count[shard * kJobShardStride], 1);
+        const int idx = jobQueuePlace(q);
         if (idx < q.capacity) q.jobs[(size_t) shard * q.capacity + idx] = s;
         else *q.overflow = 9;
     }
@@ -1243,7 +1293,7 @@ __device__ inline double orderedSum(double cum, int F, double *term, const doubl
 // arrive (ticket) folds the total into cumulativeTravelTime.  `finTicket[0]` = ticket, `finTicket[2..3]` = 64-bit total.
 template <class VidAt>
 __device__ inline bool exactFinishStatistics(double now, const VidTable &vt, DevScalars *sc, int F, VidAt vidAt, uint8_t *stateW,
-                                             int32_t *finTicket, int part, int nParts, int nUncounted,
+                                             int32_t *finTicket, int part, int nParts, int nUncounted, int32_t *finCount,
                                              int32_t *slotOfW = nullptr) {
     __shared__ long long sAcc[kBlock / 64];
     __shared__ int lastShared;
@@ -1282,7 +1332,7 @@ __device__ inline bool exactFinishStatistics(double now, const VidTable &vt, Dev
         sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
         sc->finishedCnt += F;
         sc->active -= F + nUncounted;
-        sc->nFinishedStep = 0;
+        finCountsClear(finCount);
         sc->nLeftUncounted = 0;
     }
     return true;
@@ -1293,28 +1343,29 @@ __device__ inline bool exactFinishStatistics(double now, const VidTable &vt, Dev
 // finished slots in LDS, then one thread adds the travel times in that order (FP64 addition is not
 // associative; the reference adds sequentially).  Executed by one whole block.
 __device__ inline bool finishStatistics(const StepCtx &c, const VidTable &vt, DevScalars *sc, const int32_t *finList,
-                                        double *finTerm, int finCap, int32_t *finTicket, int part, int nParts, int exactTimes) {
+                                        double *finTerm, int finCap, int32_t *finTicket, int part, int nParts, int exactTimes,
+                                        int32_t *finCount) {
     __shared__ int fin[kFinLds];
     __shared__ double term[kFinLds];
     __shared__ int lastShared;
-    int F = sc->nFinishedStep;
-    if (F > finCap) F = finCap;
+    __shared__ FinMap fm;
+    const int F = finMapLoad(fm, finCount, finCap);
     const double now = c.step * c.interval;  // Engine::getCurrentTime engine.cpp:678-680
     if (exactTimes)
-        return exactFinishStatistics(now, vt, sc, F, [&](int i) { return c.s.vid[finList[i]]; }, nullptr, finTicket, part, nParts,
-                                     sc->nLeftUncounted);
+        return exactFinishStatistics(now, vt, sc, F, [&](int i) { return c.s.vid[finList[finAt(fm, finCap, i)]]; }, nullptr, finTicket,
+                                     part, nParts, sc->nLeftUncounted, finCount);
     // this block ranks finishers [lo, hi); every block walks the whole list, chunk by chunk through LDS
     const bool inLds = nParts == 1 && F <= kFinLds;  // the common case never leaves the block
     const int per = (F + nParts - 1) / nParts;
     const int lo = part * per, hi = min(F, lo + per);
     for (int base = lo; base < hi; base += blockDim.x) {
         const int i = base + (int) threadIdx.x;
-        const int me = i < hi ? finList[i] : 0;
+        const int me = i < hi ? finList[finAt(fm, finCap, i)] : 0;
         int rank = 0;
         for (int cb = 0; cb < F; cb += kFinLds) {
             const int cn = min(kFinLds, F - cb);
             __syncthreads();
-            for (int j = threadIdx.x; j < cn; j += blockDim.x) fin[j] = finList[cb + j];
+            for (int j = threadIdx.x; j < cn; j += blockDim.x) fin[j] = finList[finAt(fm, finCap, cb + j)];
             __syncthreads();
             if (i < hi)
                 for (int j = 0; j < cn; ++j) rank += fin[j] < me;
@@ -1343,7 +1394,7 @@ __device__ inline bool finishStatistics(const StepCtx &c, const VidTable &vt, De
         sc->vehicleSteps += sc->active;  // everybody counted as active took this step's phase 4
         sc->finishedCnt += F;
         sc->active -= F + sc->nLeftUncounted;
-        sc->nFinishedStep = 0;
+        finCountsClear(finCount);
         sc->nLeftUncounted = 0;
     }
     return last;
@@ -1398,9 +1449,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
         vals[i] = d < D ? nl + (d < L ? (laneSpare ? (int) laneSpare[d] : 1) : 0) : 0;
         sum += vals[i];
     }
+    int nAdm = 0;
     if (admittedMask) {
         // commit this step's admissions (phase 2): the FIFO pop, the vehicle's state and the running count
-        int nAdm = 0;
         for (int i = 0; i < kScanItems; ++i)
             if ((admittedMask >> i) & 1u) {
                 const int d = base + i;
@@ -1409,7 +1460,11 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
                 // tiling: an admission onto a ghost lane only mirrors the owner's (same queue, same tail, same decision)
                 nAdm += !(laneGhost && laneGhost[d]);
             }
-        if (nAdm) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) nAdm);
+    }
+    {   // Engine::activeVehicleCount: one atomic per wavefront (a large network admits thousands of vehicles per step)
+        int waveAdm = nAdm;
+        for (int off = 32; off > 0; off >>= 1) waveAdm += __shfl_down(waveAdm, off, 64);
+        if ((threadIdx.x & 63) == 0 && waveAdm) atomicAdd((unsigned long long *) &sc->active, (unsigned long long) waveAdm);
     }
     // in-wave inclusive scan of the per-thread sums, wave totals to LDS
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1482,14 +1537,14 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
                           int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, double *finTerm,
                           int finCap, int32_t *jobCount, HostMirror *hostMirror, int32_t *finTicket, int nStatBlocks,
-                          int exactTimes, const int32_t *cntNext) {
+                          int exactTimes, const int32_t *cntNext, int32_t *finCount) {
     // The launch carries extra blocks that only do the step's finish statistics (they read just the current
     // generation and the finish list, both complete before this kernel starts), in parallel with the compaction.
     const int nBody = (int) gridDim.x - nStatBlocks;
     if ((int) blockIdx.x >= nBody) {
         const int part = (int) blockIdx.x - nBody;
         if (part == 0 && threadIdx.x < kJobShards) jobCount[threadIdx.x * kJobShardStride] = 0;  // k_cross of this step is done
-        const bool last = finishStatistics(c, vt, sc, finList, finTerm, finCap, finTicket, part, nStatBlocks, exactTimes);
+        const bool last = finishStatistics(c, vt, sc, finList, finTerm, finCap, finTicket, part, nStatBlocks, exactTimes, finCount);
         if (last && threadIdx.x == 0 && hostMirror) {
             // the step's scalars and slot count, also left in pinned host memory: a getter then needs the stream
             // synchronisation only, not a device-to-host copy on top of it

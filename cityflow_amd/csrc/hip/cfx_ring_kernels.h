@@ -138,6 +138,7 @@ struct RingOut {
     long long *finKey;   // finishers of the step: (drivable << 20 | list index) = the reference's removal order
     int32_t *finVid;
     int finCap;
+    int32_t *finCount;   // [kFinShards * 32]: the finishers are listed per shard (FinMap, cfx_kernels.h)
     __device__ __forceinline__ void park(int s, double v, double iv) const { kinN[s] = make_double2(iv, v); }
     __device__ __forceinline__ double parkedSpeed(int s) const { return kinN[s].y; }
     __device__ __forceinline__ double parkedInterSpeed(int s) const { return kinN[s].x; }
@@ -234,8 +235,8 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
         r.nextIn = atomicExch(&o.scratch[newDrv].z, s);
         o.movers[s] = r;
     } else {
-        const int f = atomicAdd(&o.sc->nFinishedStep, 1);
-        if (f < o.finCap) {
+        const int f = finPlace(o.finCount, o.finCap);
+        if (f >= 0) {
             o.finKey[f] = ((long long) d << kRingIdxBits) | idx;
             o.finVid[f] = lp.vid;
         } else {
@@ -278,6 +279,7 @@ struct RingCommit {
     int exactTimes;  // every time involved is a multiple of 2^-10: the travel-time sum is order-free (exactFinishStatistics)
     int lightsDone;  // the step's cross kernel has already advanced the lights (kr_cross with lights.on)
     int32_t *hostCnt;  // pinned host copy of the lane counts, kept up by the commit while a caller observes them (or null)
+    int32_t *finCount; // [kFinShards * 32] the finisher lists' counters
 };
 struct CommitOut {  // what a drivable's commit leaves, for the admission that follows it in the same thread
     int touched, head, n, tailWritten;
@@ -599,7 +601,7 @@ struct RingPush {
     int L;
     __device__ __forceinline__ void operator()(int s, const JobInfo &j) const {
         const int shard = blockIdx.x & (kJobShards - 1);
-        const int idx = atomicAdd(&q.count[shard * kJobShardStride], 1);
+        const int idx = jobQueuePlace(q);  // (one atomic per wavefront)
         if (idx >= q.capacity) {
             *q.overflow = 9;
             return;
@@ -1236,9 +1238,9 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
     __shared__ long long fin[kFinLds];
     __shared__ double term[kFinLds];
     __shared__ int lastShared;
+    __shared__ FinMap fm;
     DevScalars *sc = k.sc;
-    int F = sc->nFinishedStep;
-    if (F > k.finCap) F = k.finCap;
+    const int F = finMapLoad(fm, k.finCount, k.finCap);
     const double now = c.step * c.interval;
     // this step's admissions (kr_admit counted them by step parity) belong to the vehicles that took the step
     auto foldAdmissions = [&]() {
@@ -1248,8 +1250,8 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
         sc->active += a;
     };
     if (k.exactTimes) {
-        const bool lastBlock = exactFinishStatistics(now, vt, sc, F, [&](int i) { return k.finVid[i]; }, k.vStateW, k.finTicket, part,
-                                                     nParts, 0, k.slotOfW);
+        const bool lastBlock = exactFinishStatistics(now, vt, sc, F, [&](int i) { return k.finVid[finAt(fm, k.finCap, i)]; }, k.vStateW,
+                                                     k.finTicket, part, nParts, 0, k.finCount, k.slotOfW);
         if (lastBlock && threadIdx.x == 0) foldAdmissions();
         return lastBlock;
     }
@@ -1258,18 +1260,19 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
     const int lo = part * per, hi = min(F, lo + per);
     for (int base = lo; base < hi; base += blockDim.x) {
         const int i = base + (int) threadIdx.x;
-        const long long me = i < hi ? k.finKey[i] : 0;
+        const int at = i < hi ? finAt(fm, k.finCap, i) : 0;
+        const long long me = i < hi ? k.finKey[at] : 0;
         int rank = 0;
         for (int cb = 0; cb < F; cb += kFinLds) {
             const int cn = min(kFinLds, F - cb);
             __syncthreads();
-            for (int j = threadIdx.x; j < cn; j += blockDim.x) fin[j] = k.finKey[cb + j];
+            for (int j = threadIdx.x; j < cn; j += blockDim.x) fin[j] = k.finKey[finAt(fm, k.finCap, cb + j)];
             __syncthreads();
             if (i < hi)
                 for (int j = 0; j < cn; ++j) rank += fin[j] < me;
         }
         if (i < hi) {
-            const int vid = k.finVid[i];
+            const int vid = k.finVid[at];
             const double tt = now - vt.enterTime[vid];
             k.vStateW[vid] = 2;
             k.slotOfW[vid] = -1;
@@ -1295,7 +1298,7 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
         sc->vehicleSteps += sc->active;
         sc->finishedCnt += F;
         sc->active -= F;
-        sc->nFinishedStep = 0;
+        finCountsClear(k.finCount);
         foldAdmissions();
     }
     return last;
