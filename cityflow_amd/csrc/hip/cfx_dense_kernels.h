@@ -213,6 +213,14 @@ __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, Action
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
+    // The slot's columns are requested BEFORE the block waits for the template table in LDS and for the slot count: three
+    // rounds of loads that depend on nothing but the thread index travel together instead of one after the other (round 4:
+    // the barrier used to stand in front of the slot loads — a sixth of a wavefront's life at 1 M vehicles).  A slot index
+    // beyond the slots in use is still inside the arrays (the grid covers the host's bound on them, below their capacity):
+    // what comes back is discarded.
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    SlotIn in = loadSlot(c, s < o.finCap ? s : o.finCap - 1);  // (finCap = the slot arrays' capacity; s < S below implies s < finCap)
+    const int S = c.segStart[c.n.L + c.n.K];
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
@@ -221,11 +229,8 @@ __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, Action
         __syncthreads();
         tv = sT;
     }
-    const int S = c.segStart[c.n.L + c.n.K];
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0 && S > nVehicleBlocks * (int) blockDim.x) o.sc->overflow = 10;
     if (s >= S) return;
-    SlotIn in = loadSlot(c, s);
     if (in.vid < 0) return;
     if (c.n.laneGhost && in.d < c.n.L && c.n.laneGhost[in.d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
         o.keep(s, in.dis, in.speed);

@@ -758,7 +758,9 @@ __device__ __forceinline__ SlotIn loadSlot(const StepCtx &c, int s) {
     in.leaderSlot = sp;
     in.idx = -1;
     in.nNow = -1;
-    in.lm = c.n.drvLM[in.d >= 0 ? in.d : 0];  // (an empty spare slot carries drivable -1)
+    // (an empty spare slot carries drivable -1; a slot beyond the ones in use, which kd_action reads before it knows the slot
+    // count, anything)
+    in.lm = c.n.drvLM[(in.d >= 0 && in.d < c.n.L + c.n.K) ? in.d : 0];
     in.hop = make_int4(-2, -2, -2, -2);
     in.laneAdmitted = false;
     in.endLane = -1;

@@ -641,11 +641,13 @@ __device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action 
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
 
 __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs, RingLights lights) {
-    // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
-    if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel.
+    // They are advanced by the LAST blocks of the grid — the host sizes it with room to spare, so those have the fewest jobs)
+    if (lights.on)
+        passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, ((int) gridDim.x - 1 - (int) blockIdx.x) * (int) blockDim.x + (int) threadIdx.x,
+                    gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
-    __shared__ int shardEnd[kJobShards];
 #ifdef CFX_TRACE
     const int traceRow = 4096 + (int) blockIdx.x;
 #define XSTAMP(k) if (threadIdx.x == 0) g_trace[(size_t) traceRow * 8 + (k)] = (long long) wall_clock64()
@@ -653,7 +655,19 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
 #define XSTAMP(k)
 #endif
     XSTAMP(0);
-    if (threadIdx.x < kJobShards) shardEnd[threadIdx.x] = min(q.count[threadIdx.x * kJobShardStride], q.capacity);
+    // A block works on ONE shard of the queue — the one its index names, as the action kernel's blocks fill them — so all it
+    // needs to know is that shard's count (no prefix over the shards, no second barrier), and the first job record of every
+    // group is requested together with that count and the template table instead of after them: the record's place is known
+    // from the block and group index alone; a record beyond the shard's count is read (the shard's room is allocated) and dropped.
+    const int g = threadIdx.x % kCrossGroup;
+    const int groupsPerBlock = blockDim.x / kCrossGroup;
+    const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);
+    const int shard = (int) blockIdx.x & (kJobShards - 1);
+    const int blocksOfShard = ((int) gridDim.x - shard + kJobShards - 1) / kJobShards;
+    const int jFirst = ((int) blockIdx.x / kJobShards) * groupsPerBlock + (int) threadIdx.x / kCrossGroup;
+    const RingJob *const shardRecs = recs + (size_t) shard * q.capacity;
+    RingJob jr = shardRecs[jFirst < q.capacity ? jFirst : q.capacity - 1];
+    const int nShard = min(q.count[shard * kJobShardStride], q.capacity);
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
@@ -661,32 +675,21 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
         for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
         tv = sT;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < kJobShards; ++i) {
-            run += shardEnd[i];
-            shardEnd[i] = run;
-        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (sizes the next steps' grids, through the host mirror)
+        int nJ = 0;
+        for (int i = 0; i < kJobShards; ++i) nJ += min(q.count[i * kJobShardStride], q.capacity);
+        o.sc->nCrossJobs = nJ;
     }
     __syncthreads();
-    const int nJ = shardEnd[kJobShards - 1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) o.sc->nCrossJobs = nJ;  // (sizes the next steps' grids, through the host mirror)
     XSTAMP(1);
-    const int g = threadIdx.x % kCrossGroup;
-    const int groupsPerBlock = blockDim.x / kCrossGroup;
-    const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);
-    for (int j = blockIdx.x * groupsPerBlock + threadIdx.x / kCrossGroup; j < nJ; j += gridDim.x * groupsPerBlock) {
-        int shard = 0;
-        while (j >= shardEnd[shard]) ++shard;
-        const RingJob jr = recs[(size_t) shard * q.capacity + (j - (shard ? shardEnd[shard - 1] : 0))];
+    for (int j = jFirst; j < nShard; j += blocksOfShard * groupsPerBlock) {
+        if (j != jFirst) jr = shardRecs[j];  // (the grid is sized for one job per group; a second one is loaded where it is needed)
         const int s = jr.slot;
         const cfx_vehicle_template &t = tv[jr.templ];
         const double d0 = jr.d0;
         VehRef self{jr.speed, &t};
         double iv = jr.iv;
         int blockerSlot = -1;
-        if (jr.slot == -12345) return;
         // what the vehicle's finish may need, requested by the lane that will finish it while the group walks the crosses:
         // the identity columns of a vehicle that may leave its drivable, where the drivable's last vehicle came from
         LeaverPrefetch lp{false, 0.0, 0, 0, 0};
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
     }
     XSTAMP(4);
 #ifdef CFX_TRACE
-    if (threadIdx.x == 0) g_trace[(size_t) traceRow * 8 + 5] = nJ;
+    if (threadIdx.x == 0) g_trace[(size_t) traceRow * 8 + 5] = nShard;
 #endif
 }
 
