@@ -206,21 +206,14 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
 // alive across iterations, which is the difference between four and five waves per SIMD (86 registers against 109); the
 // host sizes the grid to its bound on the slots, and a bound that turns out too small is an error, not a skipped vehicle.
 constexpr int kDenseActBlock = 256;
-__global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
+__global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks, JobRec *jobRecs,
+                                                                int jobRecCap) {
     if ((int) blockIdx.x >= nVehicleBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
         llstate(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
-    // The slot's columns are requested BEFORE the block waits for the template table in LDS and for the slot count: three
-    // rounds of loads that depend on nothing but the thread index travel together instead of one after the other (round 4:
-    // the barrier used to stand in front of the slot loads — a sixth of a wavefront's life at 1 M vehicles).  A slot index
-    // beyond the slots in use is still inside the arrays (the grid covers the host's bound on them, below their capacity):
-    // what comes back is discarded.
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    SlotIn in = loadSlot(c, s < o.finCap ? s : o.finCap - 1);  // (finCap = the slot arrays' capacity; s < S below implies s < finCap)
-    const int S = c.segStart[c.n.L + c.n.K];
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
@@ -229,8 +222,13 @@ __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, Action
         __syncthreads();
         tv = sT;
     }
+    // (requesting the slot's columns in front of this barrier — so that they travel with the template table and the slot
+    // count — was measured in round 4: 9.5 -> 9.3 us at 30x30, 46.8 -> 48.5 us at 1 M vehicles; not kept)
+    const int S = c.segStart[c.n.L + c.n.K];
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0 && S > nVehicleBlocks * (int) blockDim.x) o.sc->overflow = 10;
     if (s >= S) return;
+    SlotIn in = loadSlot(c, s);
     if (in.vid < 0) return;
     if (c.n.laneGhost && in.d < c.n.L && c.n.laneGhost[in.d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
         o.keep(s, in.dis, in.speed);
@@ -238,7 +236,7 @@ __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, Action
     }
     in.lastRoadFlags = in.flags;  // (k_scatter / kd_admit / the halo import keep bit 1 up on this path)
     if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
-    actionOneRounds(c, o, tv, s, in, PushJob{q});
+    actionOneRounds(c, o, tv, s, in, PushJobRec{q, jobRecs, c.n.L, jobRecCap});  // (records where k_cross2 follows, else null)
 }
 
 // The tail records after cfx_load_state / cfx_reset (k_scatter keeps them up afterwards): one thread per drivable
