@@ -206,8 +206,7 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
 // alive across iterations, which is the difference between four and five waves per SIMD (86 registers against 109); the
 // host sizes the grid to its bound on the slots, and a bound that turns out too small is an error, not a skipped vehicle.
 constexpr int kDenseActBlock = 256;
-__global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks, JobRec *jobRecs,
-                                                                int jobRecCap) {
+__global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
     if ((int) blockIdx.x >= nVehicleBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
         llstate(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
         return;
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, Action
     }
     in.lastRoadFlags = in.flags;  // (k_scatter / kd_admit / the halo import keep bit 1 up on this path)
     if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
-    actionOneRounds(c, o, tv, s, in, PushJobRec{q, jobRecs, c.n.L, jobRecCap});  // (records where k_cross2 follows, else null)
+    actionOneRounds(c, o, tv, s, in, PushJob{q});
 }
 
 // The tail records after cfx_load_state / cfx_reset (k_scatter keeps them up afterwards): one thread per drivable

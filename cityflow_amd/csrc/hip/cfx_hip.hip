@@ -200,8 +200,6 @@ struct cfx_engine {
     int rFinCap = 0, rJobCap = 0;
     int32_t *rJobs = nullptr;
     RingJob *rJobRecs = nullptr;
-    JobRec *dJobRecs = nullptr;  // dense layout, k_cross2 after kd_action: [kJobShards * dJobRecCap]
-    int dJobRecCap = 0;
     LLAux *rLLAux = nullptr;
     int4 *rLLGate = nullptr;
     RingDense rd{};                    // dense staging view (getters, archive, growth)
@@ -1122,7 +1120,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             e->launch(PK_ADMIT, kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{});
         }
         RING_CHECK("kr_admit")
-        RingJob *const jobRecs = e->rJobRecs;  // (both forms of the cross phase start from the job records)
+        RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
         RingOut ro{c.kinN, c.blkW, e->rScratch, e->rMovers, e->sc, e->rFinKey, e->rFinVid, e->rFinCap, e->finCount};
         JobQueue jq{e->jobCount, e->rJobs, e->rJobCap, &e->sc->overflow};
         {
@@ -1188,10 +1186,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             }
         }
         if (useBig)
-            e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut, true>,
+            e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
-                      dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0},
-                      (const JobRec *) e->rJobRecs, 0);
+                      dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
         {
             // one 16-lane group per queued vehicle; sized by the job count of the last step the device has reported (every
@@ -1303,34 +1300,19 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     // throughput (far fewer wave-rounds per vehicle).  They break even at ~220 k slots on the MI355X.
     const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
     JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap, &e->sc->overflow};
-    // Job records for the throughput form of the cross phase (k_cross2 after kd_action: the record saves it three dependent
-    // rounds per batch).  A shard holds an eighth of the slots (twice its share if EVERY vehicle were queued); more is
-    // overflow 9, like a full queue.
-    JobRec *denseRecs = nullptr;
-    if (useBig && tails) {
-        const int want = (int) (e->slotCap / 8 + 1024);
-        if (e->dJobRecCap != want) {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (e->dJobRecs && (rc = e->freeRaw(&e->dJobRecs))) return rc;
-            if ((rc = e->allocRaw(&e->dJobRecs, (size_t) want * kJobShards))) return rc;
-            e->dJobRecCap = want;
-        }
-        denseRecs = e->dJobRecs;
-    }
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
         if (tails) {
             const int nv = (int) ((slotBound + kDenseActBlock - 1) / kDenseActBlock), nl = (e->K + kDenseActBlock - 1) / kDenseActBlock;
-            e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv, denseRecs, e->dJobRecCap);
+            e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
         }
         else e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
                        nVehBlocks);
     }
     if (useBig)
-        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : (denseRecs ? k_cross2<false, StepCtx, ActionOut, true> : k_cross2<false>),
-                  dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
-                  dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0}, (const JobRec *) denseRecs, e->dJobRecCap);
+        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
+                  dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0});
     else
         e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),

@@ -771,8 +771,7 @@ __device__ __forceinline__ SlotIn loadSlot(const StepCtx &c, int s) {
 struct JobInfo {  // what the action phase knows about a vehicle it hands to the cross phase (the ring layout passes it on)
     int d, idx, nNow, templ, nd0, laneLink, gateFlags, xs, xe;
     double speed, dis, dlen, v, iv;
-    int maskBase;  // (unused)
-    int vid;       // the vehicle's number where the action phase has loaded it (dense layout), else 0
+    int maskBase;  // second form of the ring step: first mask word of the laneLink's intersection
 };
 // the gate record of a laneLink: {light | type | has crosses, end lane} (dense) + {first, end cross entry} (ring)
 __device__ __forceinline__ int gateXs(const int2 &) { return 0; }
@@ -906,51 +905,6 @@ __device__ __forceinline__ int jobQueuePlace(const JobQueue &q) {
     base = __shfl(base, leader, 64);
     return base + __popcll(m & ((1ULL << lane) - 1ULL));
 }
-// A vehicle handed to the cross phase, with everything the action phase already knew about it: the cross phase starts
-// from ONE record instead of the chain slot -> {drivable, template, speed, dis, next} -> {length, laneLink record}.
-struct JobRec {
-    int32_t slot, d, idx, nNow, xs, xe, t1, templ, nd0, vid, pad1, pad2;
-    double d0, speed, v, iv, dis, dlen;
-};
-static_assert(sizeof(JobRec) == 96, "cross job record layout");
-// ... and the push that writes it (the ring layout's kernels; the dense layout's kd_action where the throughput form of the
-// cross phase follows).  `recs` null: only the slot is queued (k_cross reads the rest through the slot).  A shard holds
-// recCap records (0: as many as the queue holds slots).
-struct PushJobRec {
-    JobQueue q;
-    JobRec *recs;
-    int L;
-    int recCap;
-    __device__ __forceinline__ void operator()(int s, const JobInfo &j) const {
-        const int shard = blockIdx.x & (kJobShards - 1);
-        const int idx = jobQueuePlace(q);  // (one atomic per wavefront)
-        const int rcap = recCap > 0 ? recCap : q.capacity;
-        if (idx >= q.capacity || (recs && idx >= rcap)) {
-            *q.overflow = 9;
-            return;
-        }
-        q.jobs[(size_t) shard * q.capacity + idx] = s;
-        if (!recs) return;
-        JobRec r{};
-        r.slot = s;
-        r.d = j.d;
-        r.idx = j.idx;
-        r.nNow = j.nNow;
-        r.xs = j.xs;
-        r.xe = j.xe;
-        r.t1 = (j.gateFlags >> 1) & 3;
-        r.templ = j.templ;
-        r.nd0 = j.nd0;
-        r.vid = j.vid;
-        r.d0 = j.d < L ? -(j.dlen - j.dis) : j.dis;
-        r.speed = j.speed;
-        r.v = j.v;
-        r.iv = j.iv;
-        r.dis = j.dis;
-        r.dlen = j.dlen;
-        recs[(size_t) shard * rcap + idx] = r;
-    }
-};
 struct PushJob {
     JobQueue q;
     __device__ __forceinline__ void operator()(int s, const JobInfo &) const {
@@ -1008,6 +962,18 @@ template <bool LC, class C = StepCtx, class Out = ActionOut>
 __global__ __launch_bounds__(kCrossBlock) void k_cross(C c, Out o, JobQueue q) {
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
+    // A block works on ONE shard of the queue (the one its index names), so it needs that shard's count only — no prefix over
+    // the shards, no second barrier — and every group's first queue entry is requested together with the count and the
+    // template table (its place follows from the block and group index; an entry beyond the count is read and dropped).
+    const int g = threadIdx.x % kCrossGroup;                       // lane inside the group
+    const int groupsPerBlock = blockDim.x / kCrossGroup;
+    const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);  // first wave-lane of this group
+    const int shard = (int) blockIdx.x & (kJobShards - 1);
+    const int blocksOfShard = ((int) gridDim.x - shard + kJobShards - 1) / kJobShards;
+    const int jFirst = ((int) blockIdx.x / kJobShards) * groupsPerBlock + (int) threadIdx.x / kCrossGroup;
+    const int32_t *const shardJobs = q.jobs + (size_t) shard * q.capacity;
+    const int sFirstJob = shardJobs[jFirst < q.capacity ? jFirst : q.capacity - 1];
+    const int nShard = min(q.count[shard * kJobShardStride], q.capacity);
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
@@ -1016,24 +982,8 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(C c, Out o, JobQueue q) {
         __syncthreads();
         tv = sT;
     }
-    // job j of the concatenated shards -> (shard, index)
-    __shared__ int shardEnd[kJobShards];
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < kJobShards; ++i) {
-            run += min(q.count[i * kJobShardStride], q.capacity);
-            shardEnd[i] = run;
-        }
-    }
-    __syncthreads();
-    const int nJ = shardEnd[kJobShards - 1];
-    const int g = threadIdx.x % kCrossGroup;                       // lane inside the group
-    const int groupsPerBlock = blockDim.x / kCrossGroup;
-    const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);  // first wave-lane of this group
-    for (int j = blockIdx.x * groupsPerBlock + threadIdx.x / kCrossGroup; j < nJ; j += gridDim.x * groupsPerBlock) {
-        int shard = 0;
-        while (j >= shardEnd[shard]) ++shard;
-        const int s = q.jobs[(size_t) shard * q.capacity + (j - (shard ? shardEnd[shard - 1] : 0))];
+    for (int j = jFirst; j < nShard; j += blocksOfShard * groupsPerBlock) {
+        const int s = j == jFirst ? sFirstJob : shardJobs[j];
         const int d = c.s.drv[s];
         const cfx_vehicle_template &t = tv[c.s.templ[s]];
         const double speed = c.s.speed[s];
@@ -1092,6 +1042,11 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(C c, Out o, JobQueue q) {
 //      (crosses are sorted by distance, so "lowest entry" is the reference's "first cross that cannot be passed");
 //   C  one thread per vehicle turns that cross into the yield speed / blocker and finishes the vehicle.
 // Same results as k_cross (which stops at the first failing round: the later rounds it skips cannot lower the minimum).
+// (Round 4: starting pass A from 96-byte job records written by the action kernel — as kr_cross does — instead of queue ->
+// slot columns -> laneLink record takes two dependent rounds out of pass A and one out of pass C; built, parity-green and
+// measured at 1 M vehicles: k_cross2 58.3 -> 56.9 us on the dense layout against +0.9 us for writing the records, 66 -> 76 us
+// on the ring layout (eight more registers: a wavefront less per SIMD), 80 -> 84 us for sixteen batched 30x30 networks.  Taken
+// out again: this kernel's time is its three barrier-separated passes times the blocks that are not resident, not pass A's chain.)
 constexpr int kCross2Block = 256;
 constexpr int kCross2Jobs = 64;
 constexpr int kCross2Work = 2048;
@@ -1118,19 +1073,14 @@ __device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *r
     }
 }
 
-// REC: the jobs come with records (`recs`, written by the action kernel's PushJobRec) instead of through the slot columns.
-template <bool LC, class C = StepCtx, class Out = ActionOut, bool REC = false>
-__global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0},
-                                                         const JobRec *recs = nullptr, int recCap = 0) {
+template <bool LC, class C = StepCtx, class Out = ActionOut>
+__global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0}) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
     if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     __shared__ int shardEnd[kJobShards];
     __shared__ int sS[kCross2Jobs], sT1[kCross2Jobs], sTempl[kCross2Jobs], sFirst[kCross2Jobs];
     __shared__ double sD0[kCross2Jobs], sSpeed[kCross2Jobs];
-    // with job records (`recs`): what pass C would otherwise read again through the slot
-    __shared__ int sD[kCross2Jobs], sNd0[kCross2Jobs], sVid[kCross2Jobs], sIdx[kCross2Jobs], sNNow[kCross2Jobs];
-    __shared__ double sDis[kCross2Jobs], sDlen[kCross2Jobs], sV[kCross2Jobs], sIV[kCross2Jobs];
     __shared__ int sWorkJob[kCross2Work], sWorkE[kCross2Work];
     __shared__ int sNWork;
     const cfx_vehicle_template *tv = c.t.templ;
@@ -1153,7 +1103,6 @@ __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q,
     const int tid = threadIdx.x;
     const int g = tid % kCrossGroup, group = tid / kCrossGroup;
     constexpr int kGroups = kCross2Block / kCrossGroup;
-    const int rcap = recCap > 0 ? recCap : q.capacity;
     // Cross::canPass for the vehicle in slot `s` at cross entry e; a failing cross competes for "first of the vehicle"
     auto evaluate = [&](int jl, int s, double speed, int templ, int t1, double d0, int e) {
         const double2 dd = c.n.xDD[e];
@@ -1172,66 +1121,33 @@ __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q,
             if (j0 + jl >= nJ) continue;
             int shard = 0;
             while (j0 + jl >= shardEnd[shard]) ++shard;
-            const int jIn = j0 + jl - (shard ? shardEnd[shard - 1] : 0);
-            int s, templ, t1, xs, xe, maskBase;
-            double speed, d0;
-            if constexpr (REC) {
-                // the job's record (written by the action kernel): one round to the record, one to the laneLink's static
-                // record and the cross entries — instead of queue -> slot columns -> laneLink record -> entries
-                const JobRec jr = recs[(size_t) shard * rcap + jIn];
-                s = jr.slot;
-                templ = jr.templ;
-                speed = jr.speed;
-                d0 = jr.d0;
-                t1 = jr.t1;
-                xs = jr.xs;
-                xe = jr.xe;
-                const int laneLink = (jr.d < c.n.L ? jr.nd0 : jr.d) - c.n.L;
-                maskBase = c.n.llPack[laneLink].z;
-                if (g == 0) {
-                    sD[jl] = jr.d;
-                    sNd0[jl] = jr.nd0;
-                    sVid[jl] = jr.vid;
-                    sIdx[jl] = jr.idx;
-                    sNNow[jl] = jr.nNow;
-                    sDis[jl] = jr.dis;
-                    sDlen[jl] = jr.dlen;
-                    sV[jl] = jr.v;
-                    sIV[jl] = jr.iv;
-                }
-            } else {
-                s = q.jobs[(size_t) shard * q.capacity + jIn];
-                const int d = c.s.drv[s];
-                templ = slotTempl(c, s);
-                speed = slotSpeed(c, s);
-                const double dis = slotDis(c, s);
-                const int nd0 = slotNext(c, s);
-                const bool onLane = d < c.n.L;
-                const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
-                const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
-                d0 = onLane ? -(c.n.drvLength[d] - dis) : dis;
-                t1 = lp.w;
-                xs = lp.x;
-                xe = lp.y;
-                maskBase = lp.z;
-            }
+            const int s = q.jobs[(size_t) shard * q.capacity + (j0 + jl - (shard ? shardEnd[shard - 1] : 0))];
+            const int d = c.s.drv[s];
+            const int templ = slotTempl(c, s);
+            const double speed = slotSpeed(c, s);
+            const double dis = slotDis(c, s);
+            const int nd0 = slotNext(c, s);
+            const bool onLane = d < c.n.L;
+            const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
+            const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
+            const double d0 = onLane ? -(c.n.drvLength[d] - dis) : dis;
             if (g == 0) {
                 sS[jl] = s;
-                sT1[jl] = t1;
+                sT1[jl] = lp.w;
                 sTempl[jl] = templ;
                 sD0[jl] = d0;
                 sSpeed[jl] = speed;
             }
-            for (int e = xs + g; e < xe; e += kCrossGroup) {
+            for (int e = lp.x + g; e < lp.y; e += kCrossGroup) {
                 if (c.n.xDD[e].x < d0) continue;  // the cross is already behind the vehicle
                 const int bit = c.n.xPack[e].y;
-                if (!((c.interMask[maskBase + (bit >> 6)] >> (bit & 63)) & 1ULL)) continue;  // nobody to yield to there
+                if (!((c.interMask[lp.z + (bit >> 6)] >> (bit & 63)) & 1ULL)) continue;  // nobody to yield to there
                 const int w = atomicAdd(&sNWork, 1);
                 if (w < kCross2Work) {
                     sWorkJob[w] = jl;
                     sWorkE[w] = e;
                 } else {
-                    evaluate(jl, s, speed, templ, t1, d0, e);  // list full (very busy junctions): look at it right away
+                    evaluate(jl, s, speed, templ, lp.w, d0, e);  // list full (very busy junctions): look at it right away
                 }
             }
         }
@@ -1248,27 +1164,11 @@ __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q,
             const int s = sS[tid];
             const cfx_vehicle_template &t = tv[sTempl[tid]];
             const double speed = sSpeed[tid], d0 = sD0[tid];
-            int d, nd0, vid, idx = -1, nNow = -1;
-            double dis, dlen, v0, iv;
-            if constexpr (REC) {
-                d = sD[tid];
-                nd0 = sNd0[tid];
-                vid = sVid[tid];
-                idx = sIdx[tid];
-                nNow = sNNow[tid];
-                dis = sDis[tid];
-                dlen = sDlen[tid];
-                v0 = sV[tid];
-                iv = sIV[tid];
-            } else {
-                d = c.s.drv[s];
-                dis = slotDis(c, s);
-                dlen = c.n.drvLength[d];
-                nd0 = slotNext(c, s);
-                iv = o.parkedInterSpeed(s);  // partial intersection speed parked by k_action
-                v0 = o.parkedSpeed(s);
-                vid = c.s.vid[s];
-            }
+            const int d = c.s.drv[s];
+            const double dis = slotDis(c, s);
+            const double dlen = c.n.drvLength[d];
+            const int nd0 = slotNext(c, s);
+            double iv = o.parkedInterSpeed(s);  // partial intersection speed parked by k_action
             int blockerSlot = -1;
             const int e = sFirst[tid];
             if (e != CFX_INT_MAX) {
@@ -1279,7 +1179,7 @@ __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q,
                 iv = min2(iv, stopBeforeSpeed(self, dd.x - d0 - t.yield_distance, c.interval));
                 blockerSlot = keepBlocker(c, blockerSlot);
             }
-            finishAction<LC>(c, o, t, s, d, vid, speed, dis, dlen, nd0, min2(v0, iv), blockerSlot, idx, nNow);
+            finishAction<LC>(c, o, t, s, d, c.s.vid[s], speed, dis, dlen, nd0, min2(o.parkedSpeed(s), iv), blockerSlot);
         }
         __syncthreads();
     }

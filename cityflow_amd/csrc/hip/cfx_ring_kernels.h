@@ -587,9 +587,47 @@ __device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_temp
     return nf;
 }
 
-// The job records of the cross phase (JobRec, PushJobRec: cfx_kernels.h)
-using RingJob = JobRec;
-using RingPush = PushJobRec;
+// A vehicle handed to the cross phase, with everything the action phase already knew about it: the cross phase starts
+// from ONE record instead of the chain slot -> {drivable, template, speed, dis, next} -> {length, laneLink record}.
+struct RingJob {
+    int32_t slot, d, idx, nNow, xs, xe, t1, templ, nd0, pad0, pad1, pad2;
+    double d0, speed, v, iv, dis, dlen;
+};
+static_assert(sizeof(RingJob) == 96, "cross job record layout");
+
+struct RingPush {
+    JobQueue q;
+    RingJob *recs;
+    int L;
+    __device__ __forceinline__ void operator()(int s, const JobInfo &j) const {
+        const int shard = blockIdx.x & (kJobShards - 1);
+        const int idx = jobQueuePlace(q);  // (one atomic per wavefront)
+        if (idx >= q.capacity) {
+            *q.overflow = 9;
+            return;
+        }
+        const size_t at = (size_t) shard * q.capacity + idx;
+        q.jobs[at] = s;
+        if (!recs) return;  // (the throughput form of the cross phase reads the slots)
+        RingJob r{};
+        r.slot = s;
+        r.d = j.d;
+        r.idx = j.idx;
+        r.nNow = j.nNow;
+        r.xs = j.xs;
+        r.xe = j.xe;
+        r.t1 = (j.gateFlags >> 1) & 3;
+        r.templ = j.templ;
+        r.nd0 = j.nd0;
+        r.d0 = j.d < L ? -(j.dlen - j.dis) : j.dis;
+        r.speed = j.speed;
+        r.v = j.v;
+        r.iv = j.iv;
+        r.dis = j.dis;
+        r.dlen = j.dlen;
+        recs[at] = r;
+    }
+};
 
 #ifdef CFX_TRACE
 __device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action kernel's phases (developer build only)
@@ -888,10 +926,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
             if (nextIsLink && typeIsTurn((gate.x >> 1) & 3)) iv = min2(iv, t.turn_speed);
             if (gate.x & 8) {  // the crosses of the laneLink: the cross phase takes over, with everything known here
                 o.park(s, v, iv);
-                JobInfo ji{d, in.idx, in.nNow, templIdx, nd0, gateLink, gate.x, gate.z, gate.w, speed, dis, dlen, v, iv};
-                ji.maskBase = 0;
-                ji.vid = in.vid;
-                push(s, ji);
+                push(s, JobInfo{d, in.idx, in.nNow, templIdx, nd0, gateLink, gate.x, gate.z, gate.w, speed, dis, dlen, v, iv});
                 return;
             }
         }
@@ -976,7 +1011,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
     // (letting the laneLink blocks compute their own laneLinks' notify sources instead of the trailing blocks was measured in
     // round 3: 12.4 -> 14.9 us at 30x30 — the laneLink blocks then become the longest ones)
     TRACE_STAMP(1);
-    const RingPush push{q, jobRecs, c.n.L, 0};
+    const RingPush push{q, jobRecs, c.n.L};
     for (int qb = 0; qb < T; qb += B - 1) {
         const int qv = qb + t - 1;  // thread 0 holds the vehicle ahead of the window (leader data only)
         const bool valid = qv >= 0 && qv < T;
@@ -1107,7 +1142,7 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
     const int T = sPre[B];
     // feedback for the host's choice of lanes per block (small networks: every wavefront should need one chunk only)
     if (t == 0 && T > B * 3 / 4) atomicMax(&o.sc->actionMaxT, T);
-    const RingPush push{q, jobRecs, c.n.L, 0};
+    const RingPush push{q, jobRecs, c.n.L};
     const int lane = t & 63;
     for (int q0 = (t >> 6) * 64; q0 < T; q0 += B) {  // chunk q0 / 64 belongs to wavefront (q0 / 64) mod (B / 64)
         const int qv = q0 + lane;
