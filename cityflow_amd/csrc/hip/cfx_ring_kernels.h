@@ -587,6 +587,100 @@ __device__ inline Notified notifiedFrom(const RingCtx &c, const cfx_vehicle_temp
     return nf;
 }
 
+// The same for kr_cross, whose group holds a vehicle's whole chain and pays every dependent round in full (k_cross2 keeps the
+// version above: its pass B is bound by resident wavefronts, and the columns held here cost one).
+__device__ inline Notified notifiedEagerFrom(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x, const int4 dyn,
+                                        const LLAux &a) {
+    Notified nf{-1, 0, 0.0, 0.0, false, 0, make_int2(-1, -1)};
+    if (dyn.x < 0 && dyn.y < 0 && dyn.w == 0) return nf;  // nobody to yield to on that laneLink
+    // ONE round for what hangs on the laneLink's two records in the usual case: the first two vehicles on the laneLink, and of
+    // the first one also the columns the decision may want of the notified vehicle (its enterLaneLinkTime comes with the
+    // 16-byte meta record; its blocker record; its number).  Round 3 fetched those in a round of their own once the notified
+    // vehicle was known; the other candidates (u, the second vehicle, f) still do — holding theirs too costs a wavefront per SIMD.
+    const SegWalk walk = segWalk(c, c.n.L + k, dyn.z);
+    const bool haveU = dyn.x >= 0, haveOn = dyn.w > 0;
+    const int w0 = haveOn ? walk.at(0) : 0, w1 = haveOn ? walk.at(dyn.w > 1 ? 1 : 0) : 0;
+    double2 k0 = make_double2(0.0, 0.0), k1 = k0;
+    int4 m0 = make_int4(0, 0, 0, 0), m1 = m0;
+    int2 b0 = make_int2(-1, -1);
+    int v0 = 0;
+    if (haveOn) {  // (the blocker record and the number only of the first vehicle — the usual answer; registers)
+        k0 = c.kin[w0];
+        k1 = c.kin[w1];
+        m0 = c.meta[w0];
+        m1 = c.meta[w1];
+        b0 = c.blkR[w0];
+        v0 = c.s.vid[w0];
+    }
+    if (haveU) {
+        const double vehDistance = a.uDis - tv[a.uTempl].len;
+        const double crossDistance = a.llLen - x;
+        if (crossDistance + vehDistance < 0.0) {
+            nf.slot = dyn.x;
+            nf.templ = a.uTempl;
+            nf.speed = a.uSpeed;
+            nf.dist = -(a.uDis + crossDistance);
+            notifiedExtras(c, nf);
+            return nf;
+        }
+    }
+    if (haveOn) {
+        for (int q = 0; q < 2 && q < dyn.w; ++q) {  // the first two came with the round above
+            const double2 kw = q ? k1 : k0;
+            const int4 mw = q ? m1 : m0;
+            const double vehDistance = kw.x;
+            if (!(vehDistance > x) || (vehDistance - x - tv[mw.x].len <= 0.0)) {
+                nf.slot = q ? w1 : w0;
+                nf.templ = mw.x;
+                nf.speed = kw.y;
+                nf.dist = x - vehDistance;
+                if (q == 0) {
+                    nf.enterLLT = mw.w;
+                    nf.blk = b0;
+                    nf.vid = v0;
+                    nf.pre = true;
+                } else {
+                    notifiedExtras(c, nf);
+                }
+                return nf;
+            }
+        }
+        for (int i = 2; i < dyn.w; i += 2) {  // two vehicles per round of loads (the walk stops at the first that matches)
+            const int x0 = walk.at(i), x1 = walk.at(i + 1 < dyn.w ? i + 1 : i);
+            const double2 q0 = c.kin[x0], q1 = c.kin[x1];
+            const int t0 = c.meta[x0].x, t1 = c.meta[x1].x;
+            for (int q = 0; q < 2 && i + q < dyn.w; ++q) {
+                const int w = q ? x1 : x0;
+                const double2 kw = q ? q1 : q0;
+                const double vehDistance = kw.x;
+                const int wt = q ? t1 : t0;
+                if (!(vehDistance > x) || (vehDistance - x - tv[wt].len <= 0.0)) {
+                    nf.slot = w;
+                    nf.templ = wt;
+                    nf.speed = kw.y;
+                    nf.dist = x - vehDistance;
+                    notifiedExtras(c, nf);
+                    return nf;
+                }
+            }
+        }
+    }
+    if (dyn.y >= 0) {
+        nf.slot = dyn.y;
+        nf.templ = a.fTempl;
+        nf.speed = a.fSpeed;
+        nf.dist = (a.startLen - a.fDis) + x;
+        notifiedExtras(c, nf);
+    }
+    return nf;
+}
+
+__device__ inline Notified notifiedEager(const RingCtx &c, const cfx_vehicle_template *tv, int k, double x) {
+    const int4 dyn = c.llDyn[k];
+    const LLAux a = c.llAux[k];
+    return notifiedEagerFrom(c, tv, k, x, dyn, a);
+}
+
 // A vehicle handed to the cross phase, with everything the action phase already knew about it: the cross phase starts
 // from ONE record instead of the chain slot -> {drivable, template, speed, dis, next} -> {length, laneLink record}.
 struct RingJob {
@@ -640,7 +734,7 @@ __device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action 
 // queued vehicle, one cross per lane and round, first failing lane of the first failing round = the first cross that
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
 
-__global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs, RingLights lights) {
+__global__ __launch_bounds__(kCrossBlock, 4) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs, RingLights lights) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel.
     // They are advanced by the LAST blocks of the grid — the host sizes it with room to spare, so those have the fewest jobs)
     if (lights.on)
@@ -659,6 +753,9 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
     // needs to know is that shard's count (no prefix over the shards, no second barrier), and the first job record of every
     // group is requested together with that count and the template table instead of after them: the record's place is known
     // from the block and group index alone; a record beyond the shard's count is read (the shard's room is allocated) and dropped.
+    // (All four 16-lane groups of a wavefront take a job although their chains differ and a wavefront walks divergent
+    // branches one after the other: measured in round 4 with two / one working group per wavefront and a grid to match —
+    // 15.4 -> 17.1 / 23.1 us at 30x30; what counts is how many wavefronts the launch needs.)
     const int g = threadIdx.x % kCrossGroup;
     const int groupsPerBlock = blockDim.x / kCrossGroup;
     const int groupShift = (threadIdx.x & 63) & ~(kCrossGroup - 1);
@@ -718,7 +815,7 @@ __global__ __launch_bounds__(kCrossBlock) void kr_cross(RingCtx c, RingOut o, Jo
                 const int4 xp = c.n.xPack[e];   // {peer laneLink, peer bit, peer roadLink type, -}
                 dOn = dd.x;
                 if (!(dOn < d0)) {
-                    const Notified nf = notified(c, tv, xp.x, dd.y);
+                    const Notified nf = notifiedEager(c, tv, xp.x, dd.y);
                     fail = !canPassDecide(c, tv, s, self, dOn, jr.t1, d0, nf, xp.z, &foe);
                     if (nf.slot >= 0 && nf.pre) foeVid = nf.vid;  // (came with the notified vehicle's other columns)
                 }
@@ -1063,7 +1160,7 @@ __global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q,
             in.lm = sLM[i];
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
             in.laneAdmitted = sAdm[i] != 0;
-            in.endLane = -1;
+            in.endLane = -1;  // (the end lanes from the lane's static tables, as kw_action has them: measured in round 4, 12.0 us either way)
             actionOneRounds(c, o, tv, slot, in, push);
         }
         __syncthreads();
