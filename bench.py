@@ -898,6 +898,15 @@ def main():
     if rank == 0 and world == 1 and args.rl_seconds > 0 and want_checks:
         rl_loop = rl_loop_leg(job, args, cfg, workdir, state_dump)
     halo_name = eng.halo_transport() if tiled else None
+    # what every rank ended on, so that the first run across several physical GPUs describes itself: transport, the physical
+    # device of its tile (PCI bus id), and whether the RCCL group came up with all ranks
+    halo_by_rank, rccl_ranks = None, None
+    if tiled and job.dist is not None:
+        mine = {"rank": rank, "transport": eng.transport, "device": list(eng._eng.device_identities())}
+        parts = [None] * world
+        job.dist.all_gather_object(parts, mine)
+        halo_by_rank = parts
+        rccl_ranks = job.dist.get_world_size() if job.backend == "nccl" else 0
     layout = eng._eng._layout() if tiled else eng._layout()
     n_lanes = len(eng.lane_ids())
     del eng
@@ -934,6 +943,8 @@ def main():
                 "process_group": job.backend,
                 "ranks_share_devices": job.shared_devices if world > 1 else None,
                 "halo": halo_name,
+                "halo_by_rank": halo_by_rank,
+                "rccl_ranks": rccl_ranks,
                 "layout": layout,
                 "cfx": args.cfx or None,
                 "halo_probe_failures": halo_notes or None,

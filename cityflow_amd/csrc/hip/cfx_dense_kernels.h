@@ -202,13 +202,37 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
     c.tailNow[d] = now;
 }
 
+// llstate of cfx_kernels.h (the per-laneLink sources of Engine::threadNotifyCross) from the records this path keeps: the end
+// lane's tail is ONE 32-byte record (tailNow) instead of laneTail -> slot -> {template, previous drivable, dis, speed}, and
+// the light is the bit kd_admit has just put into the laneLink's gate record instead of the chain intersection -> phase ->
+// availability table.  Same values, two dependent rounds instead of four — these blocks are a quarter of kd_action's grid
+// on a large network and start last.
+__device__ inline void llstateTails(const StepCtx &c, int k) {
+    if (k >= c.n.K) return;
+    const int d = c.n.L + k;
+    const int endLane = c.n.llEndLane[k], startLane = c.n.llStartLane[k];
+    const int gateFlags = c.llGate4[k].x;
+    const int nOn = c.cnt[d], firstOn = c.segStart[d];
+    const TailRec tu = c.tailNow[endLane];
+    const int nStart = cntNow(c, startLane);
+    int f = nStart > 0 ? c.segStart[startLane] : -1;
+    const int u = (tu.slot >= 0 && tu.prevDrv == d) ? tu.slot : -1;
+    if (f >= 0 && !((gateFlags & 1) && c.s.next[f] == d)) f = -1;
+    c.llDyn[k] = make_int4(u, f, firstOn, nOn);
+    if (u >= 0 || f >= 0 || nOn > 0) {
+        const int in = c.n.llInter[k];
+        const int bit = c.n.llLocal[k];
+        atomicOr(&c.interMask[c.n.interMaskStart[in] + (bit >> 6)], 1ULL << (bit & 63));
+    }
+}
+
 // k_action of cfx_kernels.h with the rounds-organised per-vehicle phase.  One slot per thread, no loop: nothing is kept
 // alive across iterations, which is the difference between four and five waves per SIMD (86 registers against 109); the
 // host sizes the grid to its bound on the slots, and a bound that turns out too small is an error, not a skipped vehicle.
 constexpr int kDenseActBlock = 256;
 __global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
     if ((int) blockIdx.x >= nVehicleBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
-        llstate(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
+        llstateTails(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -107,6 +108,7 @@ struct cfx_engine {
     // admission, and the getter is a wait for the stream plus a host memcpy — no launch, no copy engine.  `hCntValid`: the
     // array equals the device's counts as of the last step enqueued (every commit since it was filled has published);
     // `observing` is dropped again after kObserveIdle steps without a read.
+    std::map<int32_t, double> futureCustom;  // cfx_set_vehicle_speed for vehicle numbers the next spawn records will create
     int32_t *hCnt = nullptr;
     bool hCntValid = false, observing = false;
     int observeIdle = 0;
@@ -444,6 +446,7 @@ struct cfx_engine {
         if (out.overflow == 9) return fail("cross phase: job queue capacity exceeded");
         if (out.overflow == 10) return fail("action phase: more slots in use than the host's bound (internal error)");
         if (out.overflow == 11) return fail("lane change: no room behind the layout for the lanes that got shadows in one step");
+        if (out.overflow == 12) return fail("lane change: more shadows on one lane in one step than k_lc_insert places (kLcRoadInserts)");
         if (out.overflow) return fail("device capacity overflow (finish list)");
         return CFX_OK;
     }
@@ -654,6 +657,7 @@ struct cfx_engine {
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
         hCntValid = false;
+        futureCustom.clear();
         tailsValid = false;
         lcSegValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
@@ -1012,6 +1016,12 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // fit if they are few, all for lanes of this engine, and all enter at the same time (what a host spawner produces:
         // Engine::getCurrentTime); record i of the batch is vehicle spawned + i, whatever order they came in
         bool inArgs = n <= kAdmitRecs;  // (kr_admit / kd_admit / k_admit take the batch)
+        // a custom speed waiting for one of these vehicles has to be in the vehicle table before the admission looks at it:
+        // the records then take the k_spawn_link path and the speeds follow it on the stream (rare: push_vehicle + set_vehicle_speed)
+        std::vector<std::pair<int32_t, double>> customNow;
+        for (const auto &fc : e->futureCustom)
+            if (fc.first < e->spawned + n) customNow.push_back(fc);
+        if (!customNow.empty()) inArgs = false;
         if (inArgs) {
             batch.n = (int) n;
             batch.firstNewVid = (int) e->spawned;
@@ -1071,9 +1081,18 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                       (int) e->spawned, e->vt, e->waitHead, e->lc);
             HIP_TRY(hipEventRecord(e->stageEvent[si], st));
             e->stageBusy[si] = true;
+            if (!customNow.empty()) {  // Vehicle::setCustomSpeed on a vehicle still in its waiting buffer (cfx_set_vehicle_speed)
+                const uint8_t one = 1;
+                for (const auto &fc : customNow) {
+                    HIP_TRY(hipMemcpyAsync(e->vt.customSpeed + fc.first, &fc.second, sizeof(double), hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(e->vt.pendingCustom + fc.first, &one, 1, hipMemcpyHostToDevice, st));
+                }
+                HIP_TRY(hipStreamSynchronize(st));  // (the sources live on this frame)
+            }
         }
         e->spawned += n;
     }
+    e->futureCustom.clear();  // (what this batch did not create was not a vehicle of this step)
     // ---- slot capacity.  Two host-side upper bounds of the vehicles that can be running after this step:
     //   (a) spawned - finished (as of the last read)           — tight while nobody queues for long;
     //   (b) running (as of the last read) + what can have been admitted since: at most one vehicle per step on every
@@ -1225,9 +1244,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         return e->tiled ? e->liveUpper : std::min(a, e->liveUpper);
     };
     const int64_t shadowRoom = e->lc.on ? e->poolN : 0;  // this step's shadows
-    // ... and the lanes that get them move behind the layout's end (k_lc_insert): room for a quarter of the vehicles
-    constexpr int64_t kLcMoveRoom = 32768;
-    auto moveRoom = [e, &bound]() { return e->lc.on ? kLcMoveRoom + bound() / 4 : (int64_t) 0; };
+    // ... and the lanes that get them move behind the layout's end (k_lc_insert), each at most once per step, with the shadows
+    // they receive: all running vehicles plus the step's shadows is a true bound of what can move (round 3 reserved a heuristic
+    // quarter of the vehicles, which a dense jam in which every lane gets a shadow could exceed: ADVICE round 3)
+    auto moveRoom = [e, &bound, shadowRoom]() { return e->lc.on ? bound() + shadowRoom + 64 : (int64_t) 0; };
     size_t need = (size_t) (bound() + spare + shadowRoom + moveRoom()) + 1;
     if (need > e->slotCap && !e->tiled) {
         // the device's own count as of the last step it has completed, read without waiting for it
@@ -1686,6 +1706,11 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
 }
 
 int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
+    if (e && vid >= e->spawned && vid < e->spawned + 65536) {
+        // a vehicle the next spawn records will create (pushed since the last step): kept until then, see cfx_step
+        e->futureCustom[vid] = speed;
+        return CFX_OK;
+    }
     if (!e || vid < 0 || vid >= e->spawned) {
         if (e) e->err = "cfx_set_vehicle_speed: no such vehicle";
         return CFX_ERR_INVALID;

@@ -588,8 +588,8 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevSca
         }
         __syncthreads();
         const int m = sM, nbase = sBase;
-        if (nbase < 0) {  // no room behind the layout (the host reserves it, cfx_step): the step is not valid
-            if (tid == 0) sc->overflow = 11;
+        if (nbase < 0) {  // too many shadows for one lane, or no room behind the layout (the host reserves a true bound, cfx_step)
+            if (tid == 0) sc->overflow = m > kLcRoadInserts ? 12 : 11;
             continue;
         }
         for (int q = 0; q < m; ++q) {

@@ -668,6 +668,16 @@ void EngineHost::trafficLightState(std::vector<int32_t> &phase, std::vector<doub
 // setVehicleSpeed engine.cpp:827-834
 void EngineHost::setVehicleSpeed(const std::string &id, double speed) {
     int vid = vidOf(id);
+    if (vid < 0) {
+        // pushed since the last step: the reference finds it in vehicleMap and keeps the speed in the vehicle's buffer for
+        // its first step (Vehicle::setCustomSpeed vehicle.h:128-131).  The device keeps it for the number the vehicle will get.
+        const int future = spawner_.pendingPushedVid(id);
+        if (future == -2) return;  // (its route is invalid: planRoute drops it at the next step; the speed dies with it)
+        if (future >= 0) {
+            check(be_.cfx_set_vehicle_speed(dev_, future, speed), "cfx_set_vehicle_speed");
+            return;
+        }
+    }
     uint8_t st = 2;
     if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + id + "' not found");

@@ -463,6 +463,15 @@ void Spawner::pendingPushed(std::vector<std::pair<int32_t, std::string>> &out) c
         if (r.flow < 0) out.emplace_back(r.priority, "manually_pushed_" + std::to_string(r.number));
 }
 
+int Spawner::pendingPushedVid(const std::string &id) const {
+    int next = (int) vehicles.size();
+    for (const VehicleRecord &r : pendingRecords_) {
+        if (r.flow < 0 && id == "manually_pushed_" + std::to_string(r.number)) return r.route >= 0 ? next : -2;
+        if (r.route >= 0) ++next;
+    }
+    return -1;
+}
+
 int Spawner::vidOfId(const std::string &id) const {
     auto number = [](const std::string &t, int &out) {
         if (t.empty() || t.size() > 9) return false;

@@ -117,6 +117,9 @@ public:
     // vehicles pushed (push_vehicle) since the last step: they get their vehicle numbers with the next step's spawn records,
     // but the reference already lists them (Engine::pushVehicle puts them into vehiclePool at once, engine.cpp:605-613)
     void pendingPushed(std::vector<std::pair<int32_t, std::string>> &priorityAndId) const;
+    // The vehicle number the next step will give a vehicle pushed since the last step (push_vehicle creates its vehicles
+    // before the step's flows create theirs): -1 unknown id, -2 known but its route is invalid (it never enters the network)
+    int pendingPushedVid(const std::string &id) const;
     // An integer that orders vehicles exactly like their id strings compare ("flow_<f>_<n>" / "manually_pushed_<n>", i.e.
     // the key order of the reference's std::map<std::string, ...> getters) without building or comparing strings.
     uint64_t idSortKey(int vid) const;

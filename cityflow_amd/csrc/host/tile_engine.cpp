@@ -1170,6 +1170,14 @@ void TiledEngineHost::pushVehicle(const std::map<std::string, double> &info, con
 
 void TiledEngineHost::setVehicleSpeed(const std::string &id, double speed) {
     int vid = spawner_.vidOfId(id);
+    if (vid < 0) {  // pushed since the last step (EngineHost::setVehicleSpeed): every tile keeps the speed for the number to come
+        const int future = spawner_.pendingPushedVid(id);
+        if (future == -2) return;
+        if (future >= 0) {
+            for (auto &t : tiles_) t->setVehicleSpeed(future, speed);
+            return;
+        }
+    }
     int st = vid >= 0 ? statusOf(vid) : 2;
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + id + "' not found");
     for (auto &t : tiles_) t->setVehicleSpeed(vid, speed);

@@ -235,7 +235,10 @@ int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first_vid, int32_t n, uint
 int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *lane, int32_t *n);
 
 /* Vehicle::setCustomSpeed (vehicle.h:128-131, used by getCarFollowSpeed vehicle.cpp:214,220-221): overrides
- * the car-following target for the vehicle's next step only (Vehicle::update clears it, vehicle.cpp:120-122). */
+ * the car-following target for the vehicle's next step only (Vehicle::update clears it, vehicle.cpp:120-122).
+ * A vid at or beyond the vehicles created so far names a vehicle the NEXT cfx_step's spawn records will create (a vehicle
+ * pushed since the last step, which Engine::setVehicleSpeed engine.cpp:827-834 already finds): the speed is kept and is in
+ * place before that step's admission; it is dropped if that step does not create the vehicle. */
 int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed);
 /* Switch a waiting or running vehicle to route `route` (already added with cfx_add_routes) whose first road is the
  * road the vehicle is on; Router::iCurRoad restarts at 0 (Router::setRoute router.cpp:245-264 after its checks,

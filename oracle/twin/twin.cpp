@@ -16,6 +16,7 @@
 #include <cstring>
 #include <unistd.h>
 #include <deque>
+#include <map>
 #include <limits>
 #include <string>
 #include <vector>
@@ -89,6 +90,7 @@ struct cfx_engine {
     std::vector<std::vector<std::vector<int32_t>>> segments;
     std::vector<int32_t> shadowPool, shadowParents;
     bool shadowOverflow = false;
+    std::map<int32_t, double> futureCustom;      // custom speeds of vehicles the next spawn records will create
     // tiling (cfx_halo_config): same protocol as the HIP engine, restated on the object model
     bool tiled = false;
     std::vector<uint8_t> laneGhost, ghostHadEntrants;
@@ -897,9 +899,17 @@ struct cfx_engine {
             v.enterTime = s.enter_time;
             v.speed = templ[s.templ].initial_speed;  // VehicleInfo::speed (engine.cpp:696)
             v.drivable = s.lane;  // Vehicle::setFirstDrivable vehicle.cpp:422-424
+            {
+                auto fc = futureCustom.find(s.vid);  // Vehicle::setCustomSpeed on a vehicle pushed since the last step
+                if (fc != futureCustom.end()) {
+                    v.customSpeed = fc->second;
+                    v.customSet = true;
+                }
+            }
             veh[s.vid] = v;
             if (s.lane >= 0) waiting[s.lane].push_back(s.vid);  // lane -1: the vehicle starts in another tile
         }
+        futureCustom.clear();  // (whatever was not created by this batch was not a vehicle of the next step)
         handleWaiting();
         shadowParents.clear();
         if (cfg.lane_change) {  // engine.cpp:571-575
@@ -1014,6 +1024,7 @@ struct cfx_engine {
     void resetState() {
         generation += 1;
         veh.clear();
+        futureCustom.clear();
         shadowParents.clear();
         shadowPool.clear();
         shadowOverflow = false;
@@ -1279,6 +1290,10 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
 }
 
 int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
+    if (vid >= (int32_t) e->veh.size() && vid < (int32_t) e->veh.size() + 65536) {
+        e->futureCustom[vid] = speed;  // a vehicle the next spawn records will create (include/cityflow_amd.h)
+        return CFX_OK;
+    }
     if (vid < 0 || vid >= (int32_t) e->veh.size() || e->veh[vid].finished) {
         e->err = "cfx_set_vehicle_speed: no such live vehicle";
         return CFX_ERR_INVALID;

@@ -6,6 +6,8 @@ import os
 import subprocess
 import time
 
+import pytest
+
 from conftest import REF_DIR, TWIN_LIB, checkpoint_record
 
 
@@ -144,6 +146,34 @@ def test_push_vehicle_with_initial_speed(mod, ref_module, scen, workdir, tmp_pat
         ref.next_step()
         assert checkpoint_record(ours) == checkpoint_record(ref), s
     assert ours.get_vehicle_speed() == ref.get_vehicle_speed()
+    time.sleep(0.1)
+
+
+def test_custom_speed_on_a_vehicle_pushed_since_the_last_step(mod, ref_module, scen, workdir):
+    """Engine::setVehicleSpeed (engine.cpp:827-834) finds a vehicle in vehicleMap from the moment push_vehicle created it: the
+    speed waits in the vehicle's buffer and caps its FIRST step (getCarFollowSpeed vehicle.cpp:214,220), also when the vehicle
+    has to queue behind another one first.  Round 3 raised "not found" here."""
+    cfg = scen.materialize("example_1x1", workdir)
+    ours, ref = _both(mod, ref_module, cfg)
+    for s in range(80):
+        if s in (2, 20, 21):
+            for e in (ours, ref):
+                n0 = len(e.get_vehicles(True))
+                e.push_vehicle({"speed": 6.0, "maxSpeed": 14.0}, ["road_2_1_2", "road_1_1_3"])
+                e.push_vehicle({"speed": 2.0}, ["road_2_1_2", "road_1_1_3"])      # same first road: queues behind
+                e.push_vehicle({}, ["road_1_0_1", "road_1_1_0"])
+                new = sorted(v for v in e.get_vehicles(True) if v.startswith("manually_pushed_"))[-3:]
+                assert len(e.get_vehicles(True)) == n0 + 3
+                e.set_vehicle_speed(new[0], 1.25)
+                e.set_vehicle_speed(new[1], 0.5)
+                e.set_vehicle_speed(new[2], 3.0)
+                e.set_vehicle_speed(new[2], 2.0)   # the later call wins
+        ours.next_step()
+        ref.next_step()
+        assert checkpoint_record(ours) == checkpoint_record(ref), s
+        assert ours.get_vehicle_speed() == ref.get_vehicle_speed(), s
+    with pytest.raises(RuntimeError):
+        ours.set_vehicle_speed("manually_pushed_999", 1.0)
     time.sleep(0.1)
 
 

@@ -95,3 +95,33 @@ def test_push_vehicle_with_initial_speed_hip(mod, ref_module, scen, workdir, tmp
         assert checkpoint_record(hip) == checkpoint_record(ref), s
     time.sleep(0.2)
     del ref
+
+
+@pytest.mark.parametrize("layout", ["ring", "dense"])
+def test_custom_speed_on_a_pushed_vehicle_hip_equals_twin(mod, scen, workdir, layout):
+    """set_vehicle_speed on vehicles pushed since the last step (engine.cpp:827-834): the device keeps the speed for the
+    vehicle number to come and the step that creates the vehicle takes the k_spawn_link path so that the admission sees it
+    (tests/test_edge_cases.py pins the host + twin side of this against the reference)."""
+    import json
+    from conftest import assert_same_state
+    base = scen.materialize("example_1x1", workdir)
+    c = json.load(open(base))
+    c["cfx"] = {"layout": layout}
+    cfg = base.replace(".json", "_pushspeed_%s.json" % layout)
+    with open(cfg, "w") as f:
+        json.dump(c, f)
+    hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(base, 1, TWIN_LIB)
+    for s in range(80):
+        if s in (2, 20, 21):
+            for e in (hip, tw):
+                e.push_vehicle({"speed": 6.0, "maxSpeed": 14.0}, ["road_2_1_2", "road_1_1_3"])
+                e.push_vehicle({"speed": 2.0}, ["road_2_1_2", "road_1_1_3"])
+                e.push_vehicle({}, ["road_1_0_1", "road_1_1_0"])
+                new = sorted(v for v in e.get_vehicles(True) if v.startswith("manually_pushed_"))[-3:]
+                e.set_vehicle_speed(new[0], 1.25)
+                e.set_vehicle_speed(new[1], 0.5)
+                e.set_vehicle_speed(new[2], 2.0)
+        hip.next_step()
+        tw.next_step()
+        assert_same_state(hip, tw, "pushed + custom speed (%s) step %d" % (layout, s + 1))
+    assert hip.get_vehicle_speed() == tw.get_vehicle_speed()
