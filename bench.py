@@ -721,6 +721,11 @@ def main():
     faulthandler.register(signal.SIGUSR1, all_threads=True)  # `kill -USR1 <pid>` prints where a rank is (a hung collective)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
+    # stdout carries ONE line, the result.  Libraries that print from C++ (gloo announces every group it connects on fd 1)
+    # would put theirs in front of it: from here on fd 1 is stderr, and the line goes to the descriptor saved here.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     job = Job(args)
     rank, world, on_gpu = job.rank, job.world, job.on_gpu
     strong = not args.weak
@@ -963,7 +968,8 @@ def main():
             "parity": parity_detail,
             "rl_loop": rl_loop,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     job.barrier()
     sys.stdout.flush()
     sys.stderr.flush()

@@ -498,7 +498,10 @@ __device__ inline void llstateRing(const RingCtx &c, int k) {
     const Tail tu = tailNowOf(c, endLane);
     const int u = (tu.slot >= 0 && tu.prevDrv == d) ? tu.slot : -1;
     int f = cntNow(c, startLane) > 0 ? firstSlot(c, startLane) : -1;
-    if (f >= 0 && !(c.meta[f].y == d && llAvailable(c, k))) f = -1;
+    // (RoadLink::isAvailable is bit 0 of the gate record kr_admit wrote for this step: one load instead of the chain
+    // intersection -> phase -> availability table)
+    const bool green = (c.llGate[k].x & 1) != 0;
+    if (f >= 0 && !(green && c.meta[f].y == d)) f = -1;
     const int nOn = c.cnt[d];
     c.llDyn[k] = make_int4(u, f, firstSlot(c, d), nOn);
     if (u >= 0 || f >= 0 || nOn > 0) {
