@@ -6,7 +6,7 @@
 # summaries written under gpurun_out/<tag>_<workload>_* (copy the ones to keep into profiles/).  The full default bench line
 # (all legs) is a separate call: `python bench.py > gpurun_out/<tag>_bench.json`.
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 wl=${2:-bench}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
