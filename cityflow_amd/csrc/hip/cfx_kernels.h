@@ -1086,59 +1086,23 @@ __global__ void k_init_gates(DevNet n, const int32_t *curPhase, GateOut g) {
     const int flags = gateFlagsOf(n, k, n.interAvailStart[in] + curPhase[in] * n.interNRL[in]);
     g.gate4[k] = make_int4(flags, n.llEndLane[k], n.llXStart[k], n.llXStart[k + 1]);
 }
-// TrafficLight::passTime trafficlight.cpp:29-37 for every intersection, by WHOLE blocks (every thread of the calling block,
-// convergently: there are barriers inside): block `blockRank` of `nBlocks` takes intersections blockRank * blockDim.x + tid,
-// ... + nBlocks * blockDim.x.  The intersections whose phase changed are listed in LDS and the block then rewrites the light
-// bit of their laneLinks' gate records one (intersection, laneLink) pair per thread — the phase-changing thread walking its
-// three dozen laneLinks by itself made it the longest thread of its kernel (round 4: kr_cross 15.4 -> 18.2 us).
-__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int blockRank, int nBlocks,
+// TrafficLight::passTime trafficlight.cpp:29-37 for every intersection (threads gid, gid + stride, ...)
+__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride,
                                    const GateOut &gates) {
-    __shared__ int sChanged[kBlock], sPhase[kBlock], sPairEnd[kBlock];
-    __shared__ int sN;
-    const int t = (int) threadIdx.x, B = (int) blockDim.x;  // (B <= kBlock: every caller's block is 256 threads)
-    for (int base = blockRank * B; base < n.I; base += nBlocks * B) {
-        if (t == 0) sN = 0;
-        __syncthreads();
-        const int i = base + t;
-        if (i < n.I && !n.interVirtual[i]) {
-            const int ps = n.interPhaseStart[i];
-            const int np = n.interPhaseStart[i + 1] - ps;
-            double rem = remain[i] - interval;
-            const int ph0 = curPhase[i];
-            int ph = ph0;
-            while (rem <= 0.0) {
-                ph = (ph + 1) % np;
-                rem += n.phaseTime[ps + ph];
-            }
-            remain[i] = rem;
-            curPhase[i] = ph;
-            if (ph != ph0 && gates.gate4) {
-                const int at = atomicAdd(&sN, 1);
-                sChanged[at] = i;
-                sPhase[at] = ph;
-            }
+    for (int i = gid; i < n.I; i += stride) {
+        if (n.interVirtual[i]) continue;
+        const int ps = n.interPhaseStart[i];
+        const int np = n.interPhaseStart[i + 1] - ps;
+        double rem = remain[i] - interval;
+        const int ph0 = curPhase[i];
+        int ph = ph0;
+        while (rem <= 0.0) {
+            ph = (ph + 1) % np;
+            rem += n.phaseTime[ps + ph];
         }
-        __syncthreads();
-        const int nc = sN;
-        if (nc > 0) {
-            if (t == 0) {  // running totals of the changed intersections' laneLink counts
-                int run = 0;
-                for (int c = 0; c < nc; ++c) {
-                    run += n.interLLStart[sChanged[c] + 1] - n.interLLStart[sChanged[c]];
-                    sPairEnd[c] = run;
-                }
-            }
-            __syncthreads();
-            const int nPairs = sPairEnd[nc - 1];
-            for (int p = t; p < nPairs; p += B) {
-                int c = 0;
-                while (p >= sPairEnd[c]) ++c;
-                const int in = sChanged[c];
-                const int k = n.interLL[n.interLLStart[in] + (p - (c ? sPairEnd[c - 1] : 0))];
-                gates.gate4[k].x = gateFlagsOf(n, k, n.interAvailStart[in] + sPhase[c] * n.interNRL[in]);
-            }
-        }
-        __syncthreads();
+        remain[i] = rem;
+        curPhase[i] = ph;
+        if (ph != ph0) gateLightsOf(n, i, ph, gates);
     }
 }
 
@@ -1146,7 +1110,7 @@ template <bool LC, class C = StepCtx, class Out = ActionOut>
 __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0}) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
     if (lights.on)
-        passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, (int) blockIdx.x, (int) gridDim.x, lights.gates);
+        passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, lights.gates);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     __shared__ int shardEnd[kJobShards];
     __shared__ int sS[kCross2Jobs], sT1[kCross2Jobs], sTempl[kCross2Jobs], sFirst[kCross2Jobs];
@@ -1638,7 +1602,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         *c.lc.fixCount = 0;
     }
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
-    if (!rlTrafficLight) passTimeAll(c.n, curPhase, remain, c.interval, (int) blockIdx.x, nBody, gates);
+    if (!rlTrafficLight) passTimeAll(c.n, curPhase, remain, c.interval, gid, stride, gates);
     const int S = c.segStart[c.n.L + c.n.K];
     for (int s = gid; s < S; s += stride) {
         // Round 1: everything indexed by the slot itself, issued before the first branch (the kernel is bound by

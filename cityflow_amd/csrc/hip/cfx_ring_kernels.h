@@ -737,7 +737,8 @@ __global__ __launch_bounds__(kCrossBlock, 4) void kr_cross(RingCtx c, RingOut o,
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel.
     // They are advanced by the LAST blocks of the grid — the host sizes it with room to spare, so those have the fewest jobs)
     if (lights.on)
-        passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, (int) gridDim.x - 1 - (int) blockIdx.x, (int) gridDim.x, lights.gates);
+        passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, ((int) gridDim.x - 1 - (int) blockIdx.x) * (int) blockDim.x + (int) threadIdx.x,
+                    gridDim.x * blockDim.x, lights.gates);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
 #ifdef CFX_TRACE
@@ -1561,7 +1562,7 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = nBody * blockDim.x;
     commitClearMasks(c, k, gid, stride);
-    if (!k.rlTrafficLight && !k.lightsDone) passTimeAll(c.n, k.curPhase, k.remain, c.interval, (int) blockIdx.x, nBody, GateOut{c.llGate});
+    if (!k.rlTrafficLight && !k.lightsDone) passTimeAll(c.n, k.curPhase, k.remain, c.interval, gid, stride, GateOut{c.llGate});
     const int D = c.n.L + c.n.K;
     for (int d = gid; d < D; d += stride) commitDrivable(c, k, d);
 }
