@@ -155,7 +155,12 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
     cs.inHead[d] = -1;
     TailRec now = committed;
     if (committed.tag != c.step - 1) now.slot = -1;
-    if (isLane) {  // (a laneLink's gate record is kept by whoever changes a phase: GateOut, cfx_kernels.h)
+    if (!isLane) {
+        const int k = d - c.n.L;
+        int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+        c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);  // (k_cross / llstate of the generic kernels)
+        c.llGate4[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+    } else {
         const int lane = d;
         c.laneTail[lane] = n > 0 ? base + n - 1 : -1;  // overwritten below if a vehicle is admitted
         bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435

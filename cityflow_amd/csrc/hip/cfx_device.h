@@ -36,8 +36,6 @@ struct DevNet {
     const int4 *llPack;             // [K] {first cross entry, end of cross entries, mask word base of its intersection, RoadLinkType}
     const int4 *laneLL4;            // [L] the lane's laneLinks (Lane::laneLinks order, -1 padded); x = -2: more than four, use the CSR
     const int4 *laneEnd4;           // [L] the end lanes of those laneLinks (same positions; -1 padded / unknown)
-    const int32_t *interLLStart;    // [I+1] the laneLinks of an intersection ...
-    const int32_t *interLL;         // [K]   ... as a CSR (whoever changes a phase rewrites their gate records, GateOut)
     // tiling (cfx_halo_config); both null for an engine that owns its whole network
     const uint8_t *laneGhost;       // [L] 1: lane owned by a neighbouring tile; its vehicles are frozen proxies
     const uint8_t *laneSpare;       // [L] spare slots behind the lane's vehicles (1 admission + halo migrants)

@@ -109,20 +109,6 @@ struct cfx_engine {
     // array equals the device's counts as of the last step enqueued (every commit since it was filled has published);
     // `observing` is dropped again after kObserveIdle steps without a read.
     std::map<int32_t, double> futureCustom;  // cfx_set_vehicle_speed for vehicle numbers the next spawn records will create
-    // The laneLinks' gate records (GateOut, cfx_kernels.h) are kept by whoever changes a phase; `gatesValid` = they match the
-    // current phases (false after a reset / load / (re)allocation: the next step rebuilds them all first)
-    bool gatesValid = false;
-    std::vector<int32_t> phaseSeen;  // cfx_set_tl_phases: the call that last named each intersection (duplicates: last one wins)
-    int32_t phaseCall = 0;
-    GateOut gateOut() const { return GateOut{ring ? rLLGate : (useTails() ? dGate4 : nullptr)}; }
-    int ensureGates() {
-        if (gatesValid) return CFX_OK;
-        const GateOut g = gateOut();
-        if (g.gate4) hipLaunchKernelGGL(k_init_gates, dim3(gridFor(std::max(K, 1))), dim3(kBlock), 0, stream, net, (const int32_t *) curPhase, g);
-        HIP_TRY(hipGetLastError());
-        gatesValid = true;
-        return CFX_OK;
-    }
     int32_t *hCnt = nullptr;
     bool hCntValid = false, observing = false;
     int observeIdle = 0;
@@ -565,7 +551,6 @@ struct cfx_engine {
             if ((rc = allocRaw(&rTailNow, (size_t) D))) return rc;
             if ((rc = allocRaw(&rLLAux, (size_t) K))) return rc;
             if ((rc = allocRaw(&rLLGate, (size_t) K))) return rc;
-            gatesValid = false;
             rFinCap = std::max(1 << 16, L * 8);
             if ((rc = allocRaw(&rFinKey, (size_t) rFinCap))) return rc;
             if ((rc = allocRaw(&rFinVid, (size_t) rFinCap))) return rc;
@@ -672,7 +657,6 @@ struct cfx_engine {
         HIP_TRY(hipStreamSynchronize(stream));
         mirrorValid = false;
         hCntValid = false;
-        gatesValid = false;
         futureCustom.clear();
         tailsValid = false;
         lcSegValid = false;
@@ -912,15 +896,6 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
-        {   // the laneLinks of each intersection (gate records: GateOut)
-            std::vector<int32_t> llStart((size_t) e->I + 1, 0), ll((size_t) std::max(e->K, 1));
-            for (int k = 0; k < e->K; ++k) llStart[(size_t) n->ll_inter[k] + 1] += 1;
-            for (int i = 0; i < e->I; ++i) llStart[(size_t) i + 1] += llStart[(size_t) i];
-            std::vector<int32_t> fill(llStart.begin(), llStart.end() - 1);
-            for (int k = 0; k < e->K; ++k) ll[(size_t) fill[(size_t) n->ll_inter[k]]++] = k;
-            if ((rc = e->uploadConst(d.interLLStart, llStart.data(), llStart.size()))) return rc;
-            if ((rc = e->uploadConst(d.interLL, ll.data(), ll.size()))) return rc;
-        }
         if ((rc = e->allocRaw(&e->interMask, (size_t) std::max(e->nMaskWords, 1)))) return rc;
     }
     if ((rc = e->allocRaw(&e->curPhase, (size_t) e->I))) return rc;
@@ -1137,7 +1112,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
 
     if (e->ring) {
         // ---- ring layout: admit, action (+ notify sources), cross, commit — no scan, no scatter
-        if ((rc = e->ensureGates())) return rc;
         RingCtx c = e->rctx(true);
         const bool dbg = e->cfg.debug_sync != 0;  // developer aid: name the kernel that faults
 #define RING_CHECK(name)                                                                                          \
@@ -1233,7 +1207,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if (useBig)
             e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
-                      dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0, e->gateOut()});
+                      dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
         {
             // one 16-lane group per queued vehicle; sized by the job count of the last step the device has reported (every
@@ -1246,7 +1220,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             e->launch(PK_CROSS, kr_cross,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (groups * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                       dim3(kCrossBlock), c, ro, jq, (const RingJob *) e->rJobRecs,
-                      RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0, e->gateOut()});
+                      RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         }
         RING_CHECK("k_cross")
         if (deferCommit) {
@@ -1300,13 +1274,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
     const bool tails = e->useTails();
     if (tails && !e->dTailNow) {
-        e->gatesValid = false;  // (the gate records are allocated below)
         if ((rc = e->allocRaw(&e->dTail[0], (size_t) e->D))) return rc;
         if ((rc = e->allocRaw(&e->dTail[1], (size_t) e->D))) return rc;
         if ((rc = e->allocRaw(&e->dTailNow, (size_t) e->D))) return rc;
         if ((rc = e->allocRaw(&e->dGate4, (size_t) std::max(e->K, 1)))) return rc;
     }
-    if ((rc = e->ensureGates())) return rc;
     StepCtx c = e->ctx();
     if (tails && !e->tailsValid) {  // after a reset / cfx_load_state: the records of the generation the step starts from
         hipLaunchKernelGGL(kd_init_tails, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->dTail[0], e->dTail[1]);
@@ -1360,7 +1332,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
     if (useBig)
         e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
-                  dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0, GateOut{nullptr}});
+                  dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0});
     else
         e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
@@ -1382,7 +1354,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
               e->finTerm, (int) e->slotCap, e->jobCount, e->tiled ? (HostMirror *) nullptr : e->hMirror, e->finTicket, nStat,
-              e->exactTimes() ? 1 : 0, (const int32_t *) e->cnt[nxt].p, e->finCount, e->gateOut());
+              e->exactTimes() ? 1 : 0, (const int32_t *) e->cnt[nxt].p, e->finCount);
     HIP_TRY(hipGetLastError());
     e->cur = nxt;
     e->step += 1;
@@ -1417,9 +1389,12 @@ int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
         e->err = "cfx_set_tl_phase: negative phase";
         return CFX_ERR_INVALID;
     }
-    // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream.  Through the batched
-    // call: its kernel also rewrites the light bit of the intersection's gate records
-    return cfx_set_tl_phases(e, 1, &inter, &phase);
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream
+    HIP_TRY(hipMemcpyAsync(e->curPhase + inter, &phase, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
 }
 
 int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const int32_t *phases) {
@@ -1449,29 +1424,9 @@ int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const
     const int si = e->phaseStageIdx;
     e->phaseStageIdx = (si + 1) % cfx_engine::kStages;
     if (e->phaseStageBusy[si]) HIP_TRY(hipEventSynchronize(e->phaseStageEvent[si]));
-    // an intersection named more than once keeps the LAST phase (as successive TrafficLight::setPhase calls would): each
-    // intersection goes to the device once, so that one thread writes its phase and its laneLinks' gate records
-    if (e->phaseSeen.size() != (size_t) e->I) e->phaseSeen.assign((size_t) e->I, 0);
-    e->phaseCall += 1;
-    if (e->phaseCall == INT32_MAX) {
-        e->phaseSeen.assign((size_t) e->I, 0);
-        e->phaseCall = 1;
-    }
-    {
-        int32_t *outI = e->hPhaseStage[si], *outP = e->hPhaseStage[si] + n;
-        int m = 0;
-        for (int i = n - 1; i >= 0; --i) {  // from the back: the first one seen is the one that wins
-            if (e->phaseSeen[(size_t) inters[i]] == e->phaseCall) continue;
-            e->phaseSeen[(size_t) inters[i]] = e->phaseCall;
-            outI[m] = inters[i];
-            outP[m] = phases[i];
-            ++m;
-        }
-        if (m < n) memmove(outI + m, outP, (size_t) m * sizeof(int32_t));  // (the kernel reads pairs[i], pairs[n + i] with n = m)
-        n = m;
-    }
-    if (n) hipLaunchKernelGGL(k_set_phases, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->hPhaseStage[si], n, e->curPhase, e->net,
-                              e->gatesValid ? e->gateOut() : GateOut{nullptr});  // (invalid records are rebuilt in full by the next step)
+    memcpy(e->hPhaseStage[si], inters, (size_t) n * sizeof(int32_t));
+    memcpy(e->hPhaseStage[si] + n, phases, (size_t) n * sizeof(int32_t));
+    if (n) hipLaunchKernelGGL(k_set_phases, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->hPhaseStage[si], n, e->curPhase);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->phaseStageEvent[si], e->stream));
     e->phaseStageBusy[si] = true;

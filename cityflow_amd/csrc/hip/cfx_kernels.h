@@ -1051,66 +1051,32 @@ constexpr int kCross2Block = 256;
 constexpr int kCross2Jobs = 64;
 constexpr int kCross2Work = 2048;
 
-// The GATE RECORD of a laneLink — {RoadLink::isAvailable | RoadLinkType << 1 | has crosses << 3, end lane, first cross entry,
-// end of cross entries}: what a vehicle near the intersection reads of the laneLink ahead in one 16-byte load — has ONE
-// dynamic bit, the light.  Until round 3 the admission kernel recomputed every record every step (intersection -> phase ->
-// availability table: three dependent rounds for each of K laneLinks, behind the commit in the same thread).  A light
-// changes every few seconds: the records are now kept by whoever changes a phase — TrafficLight::passTime's thread for its
-// intersection's laneLinks, k_set_phases (TrafficLight::setPhase), and k_init_gates after a reset / load / (re)allocation.
-struct GateOut {
-    int4 *gate4;  // [K], or null where the engine keeps none (lane change: k_admit writes its own 8-byte form every step)
-};
 struct RingLights {  // TrafficLight::passTime of the step, done by the cross kernel when the step's commit is deferred (ring layout)
     int32_t *curPhase;
     double *remain;
     int on;
-    GateOut gates;
 };
-__device__ __forceinline__ int gateFlagsOf(const DevNet &n, int k, int availBase) {  // availBase: the phase's row of the table
-    return (n.phaseAvail[availBase + n.llRoadLink[k]] ? 1 : 0) | (n.llType[k] << 1) | (n.llXStart[k + 1] > n.llXStart[k] ? 8 : 0);
-}
-// the light bit of every laneLink of intersection `in` under `phase` (RoadLink::isAvailable roadnet.h:429-431)
-__device__ inline void gateLightsOf(const DevNet &n, int in, int phase, const GateOut &g) {
-    if (!g.gate4) return;
-    const int base = n.interAvailStart[in] + phase * n.interNRL[in];
-    for (int j = n.interLLStart[in]; j < n.interLLStart[in + 1]; ++j) {
-        const int k = n.interLL[j];
-        g.gate4[k].x = gateFlagsOf(n, k, base);
-    }
-}
-// every record in full, from the current phases: one thread per laneLink
-__global__ void k_init_gates(DevNet n, const int32_t *curPhase, GateOut g) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n.K || !g.gate4) return;
-    const int in = n.llInter[k];
-    const int flags = gateFlagsOf(n, k, n.interAvailStart[in] + curPhase[in] * n.interNRL[in]);
-    g.gate4[k] = make_int4(flags, n.llEndLane[k], n.llXStart[k], n.llXStart[k + 1]);
-}
 // TrafficLight::passTime trafficlight.cpp:29-37 for every intersection (threads gid, gid + stride, ...)
-__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride,
-                                   const GateOut &gates) {
+__device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride) {
     for (int i = gid; i < n.I; i += stride) {
         if (n.interVirtual[i]) continue;
         const int ps = n.interPhaseStart[i];
         const int np = n.interPhaseStart[i + 1] - ps;
         double rem = remain[i] - interval;
-        const int ph0 = curPhase[i];
-        int ph = ph0;
+        int ph = curPhase[i];
         while (rem <= 0.0) {
             ph = (ph + 1) % np;
             rem += n.phaseTime[ps + ph];
         }
         remain[i] = rem;
         curPhase[i] = ph;
-        if (ph != ph0) gateLightsOf(n, i, ph, gates);
     }
 }
 
 template <bool LC, class C = StepCtx, class Out = ActionOut>
 __global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0}) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
-    if (lights.on)
-        passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, lights.gates);
+    if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     __shared__ int shardEnd[kJobShards];
     __shared__ int sS[kCross2Jobs], sT1[kCross2Jobs], sTempl[kCross2Jobs], sFirst[kCross2Jobs];
@@ -1574,7 +1540,7 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
                           int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, double *finTerm,
                           int finCap, int32_t *jobCount, HostMirror *hostMirror, int32_t *finTicket, int nStatBlocks,
-                          int exactTimes, const int32_t *cntNext, int32_t *finCount, GateOut gates) {
+                          int exactTimes, const int32_t *cntNext, int32_t *finCount) {
     // The launch carries extra blocks that only do the step's finish statistics (they read just the current
     // generation and the finish list, both complete before this kernel starts), in parallel with the compaction.
     const int nBody = (int) gridDim.x - nStatBlocks;
@@ -1602,7 +1568,21 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         *c.lc.fixCount = 0;
     }
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
-    if (!rlTrafficLight) passTimeAll(c.n, curPhase, remain, c.interval, gid, stride, gates);
+    if (!rlTrafficLight) {
+        for (int i = gid; i < c.n.I; i += stride) {
+            if (c.n.interVirtual[i]) continue;
+            int ps = c.n.interPhaseStart[i];
+            int np = c.n.interPhaseStart[i + 1] - ps;
+            double rem = remain[i] - c.interval;
+            int ph = curPhase[i];
+            while (rem <= 0.0) {
+                ph = (ph + 1) % np;
+                rem += c.n.phaseTime[ps + ph];
+            }
+            remain[i] = rem;
+            curPhase[i] = ph;
+        }
+    }
     const int S = c.segStart[c.n.L + c.n.K];
     for (int s = gid; s < S; s += stride) {
         // Round 1: everything indexed by the slot itself, issued before the first branch (the kernel is bound by
@@ -1738,13 +1718,9 @@ __global__ void k_set_route(StepCtx c, int vid, int route) {
 }
 
 // TrafficLight::setPhase (trafficlight.cpp:39-41) for n (intersection, phase) pairs read from pinned host memory
-// (the host hands over each intersection at most once per call) — and the light bit of its laneLinks' gate records
-__global__ void k_set_phases(const int32_t *pairs, int n, int32_t *curPhase, DevNet net, GateOut gates) {
+__global__ void k_set_phases(const int32_t *pairs, int n, int32_t *curPhase) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int in = pairs[i], ph = pairs[n + i];
-    curPhase[in] = ph;
-    gateLightsOf(net, in, ph, gates);
+    if (i < n) curPhase[pairs[i]] = pairs[n + i];
 }
 
 __global__ void k_refresh_next(StepCtx c) {  // after cfx_load_state: Router::getNextDrivable(0) of every vehicle

@@ -435,7 +435,11 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
         // this step's view of the drivable's tail: what the last step left, or the vehicle admitted below
         TailRec now = committed;
         if (committed.tag != c.step - 1) now.slot = -1;
-        if (isLane) {  // (a laneLink's gate record is kept by whoever changes a phase: GateOut, cfx_kernels.h)
+        if (!isLane) {
+            const int k = d - c.n.L;
+            int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+            c.llGate[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+        } else {
             const int lane = d;
             bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435
             if (admit && now.slot >= 0 && !(now.dis > tv[now.templ].len + tv[wt].min_gap)) admit = false;
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(kCrossBlock, 4) void kr_cross(RingCtx c, RingOut o,
     // They are advanced by the LAST blocks of the grid — the host sizes it with room to spare, so those have the fewest jobs)
     if (lights.on)
         passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, ((int) gridDim.x - 1 - (int) blockIdx.x) * (int) blockDim.x + (int) threadIdx.x,
-                    gridDim.x * blockDim.x, lights.gates);
+                    gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
 #ifdef CFX_TRACE
@@ -1562,7 +1566,7 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = nBody * blockDim.x;
     commitClearMasks(c, k, gid, stride);
-    if (!k.rlTrafficLight && !k.lightsDone) passTimeAll(c.n, k.curPhase, k.remain, c.interval, gid, stride, GateOut{c.llGate});
+    if (!k.rlTrafficLight && !k.lightsDone) passTimeAll(c.n, k.curPhase, k.remain, c.interval, gid, stride);
     const int D = c.n.L + c.n.K;
     for (int d = gid; d < D; d += stride) commitDrivable(c, k, d);
 }
