@@ -155,7 +155,12 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
     cs.inHead[d] = -1;
     TailRec now = committed;
     if (committed.tag != c.step - 1) now.slot = -1;
-    if (isLane) {  // (nothing per step for a laneLink's gate: static record + the intersection's green word, cfx_device.h)
+    if (!isLane) {
+        const int k = d - c.n.L;
+        int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+        c.llGate[k] = make_int2(flags, c.n.llEndLane[k]);  // (k_cross / llstate of the generic kernels)
+        c.llGate4[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+    } else {
         const int lane = d;
         c.laneTail[lane] = n > 0 ? base + n - 1 : -1;  // overwritten below if a vehicle is admitted
         bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435
@@ -206,14 +211,13 @@ __device__ inline void llstateTails(const StepCtx &c, int k) {
     if (k >= c.n.K) return;
     const int d = c.n.L + k;
     const int endLane = c.n.llEndLane[k], startLane = c.n.llStartLane[k];
-    const int4 gs = c.n.gateS[k];
-    const bool lightGreen = gsGreen(c, k, gs, c.n.green[gs.w]);
+    const int gateFlags = c.llGate4[k].x;
     const int nOn = c.cnt[d], firstOn = c.segStart[d];
     const TailRec tu = c.tailNow[endLane];
     const int nStart = cntNow(c, startLane);
     int f = nStart > 0 ? c.segStart[startLane] : -1;
     const int u = (tu.slot >= 0 && tu.prevDrv == d) ? tu.slot : -1;
-    if (f >= 0 && !(lightGreen && c.s.next[f] == d)) f = -1;
+    if (f >= 0 && !((gateFlags & 1) && c.s.next[f] == d)) f = -1;
     c.llDyn[k] = make_int4(u, f, firstOn, nOn);
     if (u >= 0 || f >= 0 || nOn > 0) {
         const int in = c.n.llInter[k];

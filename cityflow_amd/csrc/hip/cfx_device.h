@@ -36,16 +36,6 @@ struct DevNet {
     const int4 *llPack;             // [K] {first cross entry, end of cross entries, mask word base of its intersection, RoadLinkType}
     const int4 *laneLL4;            // [L] the lane's laneLinks (Lane::laneLinks order, -1 padded); x = -2: more than four, use the CSR
     const int4 *laneEnd4;           // [L] the end lanes of those laneLinks (same positions; -1 padded / unknown)
-    // What a vehicle near an intersection reads of the laneLink ahead, as ONE static 16-byte record (gateOf below), and the
-    // one thing about it that changes — the light — as a word per intersection that whoever changes a phase keeps up
-    // (TrafficLight::passTime, TrafficLight::setPhase, init / load): bit r = roadLink r is available in the current phase.
-    // Until round 3 the admission kernels recomputed a dynamic gate record for every laneLink every step (intersection ->
-    // phase -> availability table, three dependent rounds behind the commit in the same thread).
-    const int4 *gateS;              // [K] {RoadLinkType << 1 | has crosses << 3 | roadLink bit << 4 | slow << 10 | crosses << 11,
-                                    //      end lane, first cross entry, intersection}; slow: > 64 roadLinks, use llAvailable
-    const unsigned long long *phaseGreen;  // [total phases] the green word of intersection i in phase p at interPhaseStart[i] + p
-    unsigned long long *green;      // [I] the green word of the intersection's CURRENT phase (dynamic; lives here because
-                                    //     every kernel that changes a phase has the network at hand)
     // tiling (cfx_halo_config); both null for an engine that owns its whole network
     const uint8_t *laneGhost;       // [L] 1: lane owned by a neighbouring tile; its vehicles are frozen proxies
     const uint8_t *laneSpare;       // [L] spare slots behind the lane's vehicles (1 admission + halo migrants)
@@ -198,6 +188,7 @@ struct StepCtx {
     // (two buffers by step parity + this step's view) and the wide gate records; null otherwise
     const TailRec *tailR;
     TailRec *tailW, *tailNow;
+    int4 *llGate4;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
     int32_t step;
     double interval;
     LcDev lc;
@@ -291,15 +282,6 @@ template <class C> __device__ __forceinline__ bool llAvailable(const C &c, int k
     return c.n.phaseAvail[c.n.interAvailStart[in] + c.curPhase[in] * c.n.interNRL[in] + c.n.llRoadLink[k]] != 0;
 }
 __device__ __forceinline__ bool typeIsTurn(int t) { return t == 1 || t == 2; }  // roadnet.h:433-435
-// the static gate record's parts, and the light from the intersection's green word (RoadLink::isAvailable roadnet.h:429-431)
-__device__ __forceinline__ int gsEndLane(const int4 &g) { return g.y; }
-__device__ __forceinline__ int gsXs(const int4 &g) { return g.z; }
-__device__ __forceinline__ int gsXe(const int4 &g) { return g.z + (int) ((unsigned) g.x >> 11); }
-__device__ __forceinline__ int gsFlags(const int4 &g) { return g.x & 14; }  // RoadLinkType << 1 | has crosses << 3
-template <class C> __device__ __forceinline__ bool gsGreen(const C &c, int k, const int4 &g, unsigned long long greenWord) {
-    if (g.x & (1 << 10)) return llAvailable(c, k);
-    return ((greenWord >> ((g.x >> 4) & 63)) & 1ULL) != 0ULL;
-}
 
 // Router::getNextDrivable(const Drivable*) router.cpp:49-76 through the static per-route table.
 __device__ __forceinline__ int nextOf(const DevNet &n, const DevTables &t, int d, int route, int routePos) {
@@ -359,6 +341,7 @@ __device__ __forceinline__ Tail tailForLeader(const StepCtx &c, int d, bool view
     return tailAt(c, lastSlotForLeader(c, d, viewerNew, viewerLane));
 }
 
+__device__ __forceinline__ int4 gateRecord(const StepCtx &c, int k) { return c.llGate4[k]; }  // (cfx_dense_kernels.h)
 __device__ __forceinline__ Tail tailOfRec(const TailRec &r) { return Tail{r.slot, r.templ, r.prevDrv, r.dis, r.speed}; }
 __device__ __forceinline__ Tail tailIfCurrent(const TailRec &r, int wantTag) {
     Tail t = tailOfRec(r);

@@ -109,8 +109,6 @@ struct cfx_engine {
     // array equals the device's counts as of the last step enqueued (every commit since it was filled has published);
     // `observing` is dropped again after kObserveIdle steps without a read.
     std::map<int32_t, double> futureCustom;  // cfx_set_vehicle_speed for vehicle numbers the next spawn records will create
-    std::vector<int32_t> phaseSeen;  // cfx_set_tl_phases: the call that last named each intersection (duplicates: last one wins)
-    int32_t phaseCall = 0;
     int32_t *hCnt = nullptr;
     bool hCntValid = false, observing = false;
     int observeIdle = 0;
@@ -174,6 +172,7 @@ struct cfx_engine {
 
     // ---- dense layout with tail records (cfx_dense_kernels.h): engines without lane change and tiling ----
     TailRec *dTail[2] = {nullptr, nullptr}, *dTailNow = nullptr;
+    int4 *dGate4 = nullptr;
     bool lcSegValid = false;           // lane change: segOfSlot holds every vehicle's own segment (k_scatter / k_lc_naive)
     bool tailsValid = false;           // the records describe the current generation (false after reset / load / resize)
     bool useTails() const { return !ring && !lc.on; }  // (tiles too since round 3: the halo kernels keep the cut lanes' records up)
@@ -204,6 +203,7 @@ struct cfx_engine {
     int32_t *rJobs = nullptr;
     RingJob *rJobRecs = nullptr;
     LLAux *rLLAux = nullptr;
+    int4 *rLLGate = nullptr;
     RingDense rd{};                    // dense staging view (getters, archive, growth)
     size_t rdCap = 0;
     int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
@@ -338,6 +338,7 @@ struct cfx_engine {
             c.tailR = dTail[(step + 1) & 1];  // written by step - 1
             c.tailW = dTail[step & 1];
             c.tailNow = dTailNow;
+            c.llGate4 = dGate4;
         }
         return c;
     }
@@ -485,6 +486,7 @@ struct cfx_engine {
         c.vCustomSpeed = vt.customSpeed;
         c.llDyn = llDyn;
         c.interMask = interMask;
+        c.llGate = rLLGate;
         c.llAux = rLLAux;
         c.laneTail = laneTail;
         c.admitRec = admitRec;
@@ -548,6 +550,7 @@ struct cfx_engine {
             if ((rc = allocRaw(&rTail[1], (size_t) D))) return rc;
             if ((rc = allocRaw(&rTailNow, (size_t) D))) return rc;
             if ((rc = allocRaw(&rLLAux, (size_t) K))) return rc;
+            if ((rc = allocRaw(&rLLGate, (size_t) K))) return rc;
             rFinCap = std::max(1 << 16, L * 8);
             if ((rc = allocRaw(&rFinKey, (size_t) rFinCap))) return rc;
             if ((rc = allocRaw(&rFinVid, (size_t) rFinCap))) return rc;
@@ -893,31 +896,6 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
-        {   // the static gate record of every laneLink and the green word of every phase (DevNet::gateS / phaseGreen / green)
-            std::vector<int4> gs((size_t) std::max(e->K, 1));
-            for (int k = 0; k < e->K; ++k) {
-                const int in = n->ll_inter[k], rl = n->ll_roadlink[k];
-                const int nX = n->ll_x_start[k + 1] - n->ll_x_start[k];
-                if (nX >= (1 << 20)) return e->fail("cfx_create: a laneLink with more than 2^20 crosses");
-                const int slow = n->inter_n_roadlinks[in] > 64 ? 1 : 0;
-                const int pack = (n->ll_type[k] << 1) | (nX > 0 ? 8 : 0) | ((rl & 63) << 4) | (slow << 10) | (nX << 11);
-                gs[(size_t) k] = make_int4(pack, n->ll_end_lane[k], n->ll_x_start[k], in);
-            }
-            std::vector<unsigned long long> pg((size_t) std::max(n->n_phases, 1), 0ULL);
-            for (int i = 0; i < e->I; ++i) {
-                const int nRL = n->inter_n_roadlinks[i];
-                for (int p = n->inter_phase_start[i]; p < n->inter_phase_start[i + 1]; ++p) {
-                    const uint8_t *row = n->phase_avail + n->inter_avail_start[i] + (size_t) (p - n->inter_phase_start[i]) * nRL;
-                    unsigned long long w = 0ULL;
-                    for (int r = 0; r < nRL && r < 64; ++r)
-                        if (row[r]) w |= 1ULL << r;
-                    pg[(size_t) p] = w;
-                }
-            }
-            if ((rc = e->uploadConst(d.gateS, gs.data(), gs.size()))) return rc;
-            if ((rc = e->uploadConst(d.phaseGreen, pg.data(), pg.size()))) return rc;
-            if ((rc = e->allocRaw(&d.green, (size_t) std::max(e->I, 1)))) return rc;
-        }
         if ((rc = e->allocRaw(&e->interMask, (size_t) std::max(e->nMaskWords, 1)))) return rc;
     }
     if ((rc = e->allocRaw(&e->curPhase, (size_t) e->I))) return rc;
@@ -1299,6 +1277,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if ((rc = e->allocRaw(&e->dTail[0], (size_t) e->D))) return rc;
         if ((rc = e->allocRaw(&e->dTail[1], (size_t) e->D))) return rc;
         if ((rc = e->allocRaw(&e->dTailNow, (size_t) e->D))) return rc;
+        if ((rc = e->allocRaw(&e->dGate4, (size_t) std::max(e->K, 1)))) return rc;
     }
     StepCtx c = e->ctx();
     if (tails && !e->tailsValid) {  // after a reset / cfx_load_state: the records of the generation the step starts from
@@ -1410,9 +1389,12 @@ int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
         e->err = "cfx_set_tl_phase: negative phase";
         return CFX_ERR_INVALID;
     }
-    // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream.  Through the batched
-    // call: its kernel takes the intersection's green word along
-    return cfx_set_tl_phases(e, 1, &inter, &phase);
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream
+    HIP_TRY(hipMemcpyAsync(e->curPhase + inter, &phase, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CFX_OK;
 }
 
 int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const int32_t *phases) {
@@ -1442,28 +1424,9 @@ int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const
     const int si = e->phaseStageIdx;
     e->phaseStageIdx = (si + 1) % cfx_engine::kStages;
     if (e->phaseStageBusy[si]) HIP_TRY(hipEventSynchronize(e->phaseStageEvent[si]));
-    // an intersection named more than once keeps the LAST phase (as successive TrafficLight::setPhase calls would): each
-    // intersection goes to the device once, so that one thread writes its phase and its green word
-    if (e->phaseSeen.size() != (size_t) e->I) e->phaseSeen.assign((size_t) e->I, 0);
-    e->phaseCall += 1;
-    if (e->phaseCall == INT32_MAX) {
-        e->phaseSeen.assign((size_t) e->I, 0);
-        e->phaseCall = 1;
-    }
-    {
-        int32_t *outI = e->hPhaseStage[si], *outP = e->hPhaseStage[si] + n;
-        int m = 0;
-        for (int i = n - 1; i >= 0; --i) {  // from the back: the first one seen is the one that wins
-            if (e->phaseSeen[(size_t) inters[i]] == e->phaseCall) continue;
-            e->phaseSeen[(size_t) inters[i]] = e->phaseCall;
-            outI[m] = inters[i];
-            outP[m] = phases[i];
-            ++m;
-        }
-        if (m < n) memmove(outI + m, outP, (size_t) m * sizeof(int32_t));  // (the kernel reads pairs[i], pairs[m + i])
-        n = m;
-    }
-    if (n) hipLaunchKernelGGL(k_set_phases, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->hPhaseStage[si], n, e->curPhase, e->net);
+    memcpy(e->hPhaseStage[si], inters, (size_t) n * sizeof(int32_t));
+    memcpy(e->hPhaseStage[si] + n, phases, (size_t) n * sizeof(int32_t));
+    if (n) hipLaunchKernelGGL(k_set_phases, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->hPhaseStage[si], n, e->curPhase);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->phaseStageEvent[si], e->stream));
     e->phaseStageBusy[si] = true;
@@ -2080,7 +2043,6 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     HIP_TRY(up(e->vt.nextWait, nextWait.data(), (size_t) nV * 4));
     HIP_TRY(up(e->waitHead, waitHead.data(), (size_t) L * 4));
     HIP_TRY(up(e->curPhase, s->tl_phase, (size_t) e->I * 4));
-    hipLaunchKernelGGL(k_init_green, dim3(gridFor(std::max(e->I, 1))), dim3(kBlock), 0, e->stream, e->net, (const int32_t *) e->curPhase);
     HIP_TRY(up(e->remain, s->tl_remain, (size_t) e->I * 8));
     DevScalars sc{};
     sc.active = nR;

@@ -1056,23 +1056,20 @@ struct RingLights {  // TrafficLight::passTime of the step, done by the cross ke
     double *remain;
     int on;
 };
-// TrafficLight::passTime trafficlight.cpp:29-37 for every intersection (threads gid, gid + stride, ...); a phase that
-// changes takes the intersection's green word along (DevNet::green)
+// TrafficLight::passTime trafficlight.cpp:29-37 for every intersection (threads gid, gid + stride, ...)
 __device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *remain, double interval, int gid, int stride) {
     for (int i = gid; i < n.I; i += stride) {
         if (n.interVirtual[i]) continue;
         const int ps = n.interPhaseStart[i];
         const int np = n.interPhaseStart[i + 1] - ps;
         double rem = remain[i] - interval;
-        const int ph0 = curPhase[i];
-        int ph = ph0;
+        int ph = curPhase[i];
         while (rem <= 0.0) {
             ph = (ph + 1) % np;
             rem += n.phaseTime[ps + ph];
         }
         remain[i] = rem;
         curPhase[i] = ph;
-        if (ph != ph0) n.green[i] = n.phaseGreen[ps + ph];
     }
 }
 
@@ -1571,7 +1568,21 @@ __global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays 
         *c.lc.fixCount = 0;
     }
     for (int i = gid; i < nMaskWords; i += stride) c.interMask[i] = 0ULL;
-    if (!rlTrafficLight) passTimeAll(c.n, curPhase, remain, c.interval, gid, stride);
+    if (!rlTrafficLight) {
+        for (int i = gid; i < c.n.I; i += stride) {
+            if (c.n.interVirtual[i]) continue;
+            int ps = c.n.interPhaseStart[i];
+            int np = c.n.interPhaseStart[i + 1] - ps;
+            double rem = remain[i] - c.interval;
+            int ph = curPhase[i];
+            while (rem <= 0.0) {
+                ph = (ph + 1) % np;
+                rem += c.n.phaseTime[ps + ph];
+            }
+            remain[i] = rem;
+            curPhase[i] = ph;
+        }
+    }
     const int S = c.segStart[c.n.L + c.n.K];
     for (int s = gid; s < S; s += stride) {
         // Round 1: everything indexed by the slot itself, issued before the first branch (the kernel is bound by
@@ -1707,13 +1718,9 @@ __global__ void k_set_route(StepCtx c, int vid, int route) {
 }
 
 // TrafficLight::setPhase (trafficlight.cpp:39-41) for n (intersection, phase) pairs read from pinned host memory
-// (the host hands over each intersection at most once per call); the intersection's green word goes with its phase
-__global__ void k_set_phases(const int32_t *pairs, int n, int32_t *curPhase, DevNet net) {
+__global__ void k_set_phases(const int32_t *pairs, int n, int32_t *curPhase) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int in = pairs[i], ph = pairs[n + i];
-    curPhase[in] = ph;
-    net.green[in] = net.phaseGreen[net.interPhaseStart[in] + ph];
+    if (i < n) curPhase[pairs[i]] = pairs[n + i];
 }
 
 __global__ void k_refresh_next(StepCtx c) {  // after cfx_load_state: Router::getNextDrivable(0) of every vehicle
@@ -2030,14 +2037,6 @@ __global__ void k_init_lights(DevNet n, int32_t *curPhase, double *remain) {  //
     if (i >= n.I) return;
     curPhase[i] = 0;
     remain[i] = n.interVirtual[i] ? 0.0 : n.phaseTime[n.interPhaseStart[i]];
-    n.green[i] = n.interVirtual[i] ? 0ULL : n.phaseGreen[n.interPhaseStart[i]];
-}
-
-// the green words from the current phases (after cfx_load_state put the phases in place)
-__global__ void k_init_green(DevNet n, const int32_t *curPhase) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n.I) return;
-    n.green[i] = n.interVirtual[i] ? 0ULL : n.phaseGreen[n.interPhaseStart[i] + curPhase[i]];
 }
 
 }  // namespace cfxd

@@ -59,6 +59,7 @@ struct RingCtx {
     int4 *llDyn;
     struct LLAux *llAux;     // [K] what a cross needs of a laneLink's notify sources beyond llDyn (written where active)
     unsigned long long *interMask;
+    int4 *llGate;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
     int32_t *laneTail;
     int2 *admitRec;
     int32_t step;
@@ -434,7 +435,11 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
         // this step's view of the drivable's tail: what the last step left, or the vehicle admitted below
         TailRec now = committed;
         if (committed.tag != c.step - 1) now.slot = -1;
-        if (isLane) {  // (nothing per step for a laneLink's gate: static record + the intersection's green word, cfx_device.h)
+        if (!isLane) {
+            const int k = d - c.n.L;
+            int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+            c.llGate[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+        } else {
             const int lane = d;
             bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435
             if (admit && now.slot >= 0 && !(now.dis > tv[now.templ].len + tv[wt].min_gap)) admit = false;
@@ -495,11 +500,7 @@ __device__ inline void llstateRing(const RingCtx &c, int k) {
     int f = cntNow(c, startLane) > 0 ? firstSlot(c, startLane) : -1;
     // (RoadLink::isAvailable is bit 0 of the gate record kr_admit wrote for this step: one load instead of the chain
     // intersection -> phase -> availability table)
-    bool green = false;
-    if (f >= 0) {
-        const int4 gs = c.n.gateS[k];
-        green = gsGreen(c, k, gs, c.n.green[gs.w]);
-    }
+    const bool green = (c.llGate[k].x & 1) != 0;
     if (f >= 0 && !(green && c.meta[f].y == d)) f = -1;
     const int nOn = c.cnt[d];
     c.llDyn[k] = make_int4(u, f, firstSlot(c, d), nOn);
@@ -853,6 +854,7 @@ __global__ __launch_bounds__(kCrossBlock, 4) void kr_cross(RingCtx c, RingOut o,
 // (round A: tails of the drivables ahead, the gate record of the next laneLink, the length of the next drivable and the
 // identity columns of a vehicle that may leave), then everything that depends on those (round B: the tail of the lane
 // behind the next laneLink), and only then is anything decided — the wave waits for memory twice instead of six times.
+__device__ __forceinline__ int4 gateRecord(const RingCtx &c, int k) { return c.llGate[k]; }
 __device__ __forceinline__ bool viewerIsNew(const RingCtx &, const SlotIn &in, int) { return in.laneAdmitted && in.nNow == 1; }
 
 template <class C, class Out, class Push>
@@ -879,9 +881,9 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         if (in.hop.z >= 0) hopRec[2] = c.tailNow[L + in.hop.z];
         linkLen = c.n.drvLength[nd0];
     }
-    int4 gate = make_int4(0, 0, 0, 0);  // the STATIC gate record of the laneLink ahead (DevNet::gateS); its light is a round-B load
+    int4 gate = make_int4(0, 0, 0, 0);
     const int gateLink = onLane ? nd0 - L : d - L;
-    if (related) gate = c.n.gateS[gateLink];
+    if (related) gate = gateRecord(c, gateLink);
     // the lane behind the next laneLink (a lane's vehicle near the intersection): Lane::canEnter looks at it as of this step,
     // the leader search two drivables ahead as of the last commit.  Where the loader knows the lane (the static table of
     // the vehicle's own lane) the records are requested here, with everything else; otherwise they hang on the gate record
@@ -907,10 +909,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
     }
     lp.templP1 = templIdx + 1;
 
-    // ================= round B: what hangs on the gate record: the intersection's green word, and the lane behind the laneLink
-    // where it was not known above
-    unsigned long long greenWord = 0ULL;
-    if (approaching) greenWord = c.n.green[gate.w];
+    // ================= round B: what hangs on the gate record (only where the end lane was not known above)
     if (approaching && !endKnown) {
         laneNow = c.tailNow[gate.y];
         if (hopHead) laneCommitted = c.tailR[gate.y];
@@ -1009,7 +1008,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         double iv = t.max_speed;
         bool done = false;
         if (nextIsLink) {
-            bool blocked = !gsGreen(c, gateLink, gate, greenWord);
+            bool blocked = !(gate.x & 1);
             if (!blocked) {  // Lane::canEnter roadnet.cpp:437-445
                 const Tail tail = tailOfRec(laneNow);
                 if (tail.slot >= 0) blocked = !(tail.dis > tv[tail.templ].len + t.len || tail.speed >= 2);
@@ -1027,7 +1026,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
             if (nextIsLink && typeIsTurn((gate.x >> 1) & 3)) iv = min2(iv, t.turn_speed);
             if (gate.x & 8) {  // the crosses of the laneLink: the cross phase takes over, with everything known here
                 o.park(s, v, iv);
-                push(s, JobInfo{d, in.idx, in.nNow, templIdx, nd0, gateLink, gsFlags(gate), gsXs(gate), gsXe(gate), speed, dis, dlen, v, iv});
+                push(s, JobInfo{d, in.idx, in.nNow, templIdx, nd0, gateLink, gate.x, gate.z, gate.w, speed, dis, dlen, v, iv});
                 return;
             }
         }
