@@ -109,6 +109,8 @@ struct cfx_engine {
     // array equals the device's counts as of the last step enqueued (every commit since it was filled has published);
     // `observing` is dropped again after kObserveIdle steps without a read.
     std::map<int32_t, double> futureCustom;  // cfx_set_vehicle_speed for vehicle numbers the next spawn records will create
+    std::vector<int32_t> phaseSeen;  // cfx_set_tl_phases: the call that last named each intersection (duplicates: last one wins)
+    int32_t phaseCall = 0;
     int32_t *hCnt = nullptr;
     bool hCntValid = false, observing = false;
     int observeIdle = 0;
@@ -1424,8 +1426,29 @@ int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const
     const int si = e->phaseStageIdx;
     e->phaseStageIdx = (si + 1) % cfx_engine::kStages;
     if (e->phaseStageBusy[si]) HIP_TRY(hipEventSynchronize(e->phaseStageEvent[si]));
-    memcpy(e->hPhaseStage[si], inters, (size_t) n * sizeof(int32_t));
-    memcpy(e->hPhaseStage[si] + n, phases, (size_t) n * sizeof(int32_t));
+    // An intersection named more than once keeps the LAST phase, as successive TrafficLight::setPhase calls would
+    // (trafficlight.cpp:39-41; a host that collects set_tl_phase calls between two steps hands them over in one call): each
+    // intersection goes to the device once — k_set_phases writes one thread per pair, and two threads writing one
+    // intersection's phase would leave whichever came last in time, not in the list.
+    if (e->phaseSeen.size() != (size_t) e->I) e->phaseSeen.assign((size_t) e->I, 0);
+    e->phaseCall += 1;
+    if (e->phaseCall == INT32_MAX) {
+        e->phaseSeen.assign((size_t) e->I, 0);
+        e->phaseCall = 1;
+    }
+    {
+        int32_t *outI = e->hPhaseStage[si], *outP = e->hPhaseStage[si] + n;
+        int m = 0;
+        for (int i = n - 1; i >= 0; --i) {  // from the back: the first one seen is the one that wins
+            if (e->phaseSeen[(size_t) inters[i]] == e->phaseCall) continue;
+            e->phaseSeen[(size_t) inters[i]] = e->phaseCall;
+            outI[m] = inters[i];
+            outP[m] = phases[i];
+            ++m;
+        }
+        if (m < n) memmove(outI + m, outP, (size_t) m * sizeof(int32_t));  // (the kernel reads pairs[i] and pairs[m + i])
+        n = m;
+    }
     if (n) hipLaunchKernelGGL(k_set_phases, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->hPhaseStage[si], n, e->curPhase);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->phaseStageEvent[si], e->stream));

@@ -125,3 +125,32 @@ def test_custom_speed_on_a_pushed_vehicle_hip_equals_twin(mod, scen, workdir, la
         tw.next_step()
         assert_same_state(hip, tw, "pushed + custom speed (%s) step %d" % (layout, s + 1))
     assert hip.get_vehicle_speed() == tw.get_vehicle_speed()
+
+
+def test_repeated_set_tl_phase_before_a_step_last_call_wins(mod, scen, workdir):
+    """Several set_tl_phase calls on one intersection between two steps: TrafficLight::setPhase (trafficlight.cpp:39-41) leaves
+    the LAST one.  The host hands the collected calls to the device in one batch; the device must not let two threads race
+    for one intersection's phase."""
+    import json
+    base = scen.materialize("grid_6x6", workdir)
+    c = json.load(open(base))
+    c["rlTrafficLight"] = True
+    cfg = base.replace(".json", "_rl_repeat.json")
+    with open(cfg, "w") as f:
+        json.dump(c, f)
+    hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    ids = hip.intersection_ids()
+    virt = hip._flat_net()["inter_virtual"]
+    real = [iid for i, iid in enumerate(ids) if not virt[i]]
+    for s in range(120):
+        if s % 3 == 0:
+            for e in (hip, tw):
+                for rep in range(4):  # four calls per intersection, the last one decides
+                    for j, iid in enumerate(real):
+                        e.set_tl_phase(iid, (s + 3 * rep + j) % 8)
+        hip.next_step()
+        tw.next_step()
+        assert hip._tl_state()[0].tolist() == tw._tl_state()[0].tolist(), s
+        if s % 10 == 9:
+            from conftest import assert_same_state
+            assert_same_state(hip, tw, "repeated set_tl_phase step %d" % (s + 1))
