@@ -230,7 +230,10 @@ __device__ inline void llstateTails(const StepCtx &c, int k) {
 // alive across iterations, which is the difference between four and five waves per SIMD (86 registers against 109); the
 // host sizes the grid to its bound on the slots, and a bound that turns out too small is an error, not a skipped vehicle.
 constexpr int kDenseActBlock = 256;
-__global__ __launch_bounds__(kDenseActBlock, 5) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
+#ifndef CFX_KD_ACTION_WAVES
+#define CFX_KD_ACTION_WAVES 5
+#endif
+__global__ __launch_bounds__(kDenseActBlock, CFX_KD_ACTION_WAVES) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
     if ((int) blockIdx.x >= nVehicleBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
         llstateTails(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
         return;

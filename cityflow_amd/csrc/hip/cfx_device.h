@@ -163,7 +163,13 @@ struct LeaverPrefetch {
 };
 
 // Everything the per-step kernels read.  Passed by value (kernel argument segment).
+#ifndef CFX_CROSS2_WAVES
+#define CFX_CROSS2_WAVES 7
+#endif
 struct StepCtx {
+    // wavefronts per SIMD k_cross2's register allocation leaves room for on this context (cfx_kernels.h; measured: 7 blocks
+    // of the kernel per CU — what its LDS allows — instead of the 6 that 77 registers give: 58 -> 43-54 us at 1 M vehicles)
+    static constexpr int kCross2Waves = CFX_CROSS2_WAVES;
     DevNet n;
     DevTables t;
     SlotArrays s;             // current generation

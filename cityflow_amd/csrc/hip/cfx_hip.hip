@@ -18,6 +18,12 @@
 #include "cfx_ring_kernels.h"
 #include "cfx_dense_kernels.h"
 
+// k_cross2's grid on the dense layout: one block per kCross2Jobs slots of the layout's bound, at most this many (the
+// kernel strides over the queue, so any grid is correct; blocks beyond the queue's length only pay the prologue)
+#ifndef CFX_CROSS2_MAX_GRID
+#define CFX_CROSS2_MAX_GRID 16384
+#endif
+
 using namespace cfxd;
 
 namespace {
@@ -1333,7 +1339,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                        nVehBlocks);
     }
     if (useBig)
-        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), 16384)),
+        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), CFX_CROSS2_MAX_GRID)),
                   dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0});
     else
         e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,

@@ -32,6 +32,25 @@ constexpr int kCrossBlock = CFX_CROSS_BLOCK;  // k_cross workgroup (16-lane grou
 #define CFX_LDS_TEMPL 32
 #endif
 constexpr int kLdsTempl = CFX_LDS_TEMPL;   // vehicle templates staged in LDS by k_action (104 B each)
+// Wavefronts per SIMD the register allocation of a kernel is asked to leave room for (second argument of __launch_bounds__;
+// 0 = whatever the compiler arrives at).  Build-time knobs for A/B runs (tools/exp_bench.py with differently built
+// libraries); the defaults are what was measured best.
+#ifndef CFX_SCATTER_WAVES
+#define CFX_SCATTER_WAVES 0
+#endif
+#ifndef CFX_SCAN_WAVES
+#define CFX_SCAN_WAVES 0
+#endif
+#if CFX_SCAN_WAVES > 0
+#define CFX_SCAN_BOUNDS __launch_bounds__(kBlock, CFX_SCAN_WAVES)
+#else
+#define CFX_SCAN_BOUNDS __launch_bounds__(kBlock)
+#endif
+#if CFX_SCATTER_WAVES > 0
+#define CFX_SCATTER_BOUNDS __launch_bounds__(kBlock, CFX_SCATTER_WAVES)
+#else
+#define CFX_SCATTER_BOUNDS
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // Vehicle table (indexed by vid, never permuted)
@@ -1049,7 +1068,10 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(C c, Out o, JobQueue q) {
 // out again: this kernel's time is its three barrier-separated passes times the blocks that are not resident, not pass A's chain.)
 constexpr int kCross2Block = 256;
 constexpr int kCross2Jobs = 64;
-constexpr int kCross2Work = 2048;
+#ifndef CFX_CROSS2_WORK
+#define CFX_CROSS2_WORK 2048
+#endif
+constexpr int kCross2Work = CFX_CROSS2_WORK;
 
 struct RingLights {  // TrafficLight::passTime of the step, done by the cross kernel when the step's commit is deferred (ring layout)
     int32_t *curPhase;
@@ -1074,7 +1096,7 @@ __device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *r
 }
 
 template <bool LC, class C = StepCtx, class Out = ActionOut>
-__global__ __launch_bounds__(kCross2Block) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0}) {
+__global__ __launch_bounds__(kCross2Block, C::kCross2Waves) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0}) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
     if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
@@ -1403,7 +1425,7 @@ __device__ inline bool finishStatistics(const StepCtx &c, const VidTable &vt, De
     return last;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cnt, CompactScratch cs,
+__global__ CFX_SCAN_BOUNDS void k_scan(int D, int L, const int32_t *cnt, CompactScratch cs,
                                                  unsigned long long *granules, int32_t *ticket, unsigned epoch,
                                                  int32_t *segStartNext, int32_t *cntNext, int32_t *vidNext,
                                                  int32_t *drvNext, DevScalars *sc, const uint8_t *laneSpare,
@@ -1536,7 +1558,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(int D, int L, const int32_t *cn
 // (Engine::threadUpdateLocation / updateLocation engine.cpp:282-315,477-494; Vehicle::update
 // vehicle.cpp:107-143; Router::update router.cpp:78-94).  Low thread ids also advance the traffic
 // lights (TrafficLight::passTime trafficlight.cpp:29-37) and clear the active-laneLink masks.
-__global__ void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
+__global__ CFX_SCATTER_BOUNDS void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
                           int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, double *finTerm,
                           int finCap, int32_t *jobCount, HostMirror *hostMirror, int32_t *finTicket, int nStatBlocks,

@@ -27,6 +27,9 @@
 namespace cfxd {
 
 struct RingCtx {
+    // (k_cross2 on the ring layout needs 95 registers; asking for 7 wavefronts per SIMD spills and was measured slower,
+    // 66 -> 72 us at 1 M vehicles: 5 = as the compiler has it)
+    static constexpr int kCross2Waves = 5;
     DevNet n;
     DevTables t;
     SlotArrays s;            // the COLD columns only: vid, drv, prevDrv, routePos, route (the rest is null here)
@@ -737,7 +740,18 @@ __device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action 
 // queued vehicle, one cross per lane and round, first failing lane of the first failing round = the first cross that
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
 
-__global__ __launch_bounds__(kCrossBlock, 4) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs, RingLights lights) {
+#ifndef CFX_KR_CROSS_WAVES
+#define CFX_KR_CROSS_WAVES 4
+#endif
+#ifndef CFX_KR_ACTION_WAVES
+#define CFX_KR_ACTION_WAVES 0
+#endif
+#if CFX_KR_ACTION_WAVES > 0
+#define CFX_KR_ACTION_BOUNDS(B) __launch_bounds__(B, CFX_KR_ACTION_WAVES)
+#else
+#define CFX_KR_ACTION_BOUNDS(B) __launch_bounds__(B)
+#endif
+__global__ __launch_bounds__(kCrossBlock, CFX_KR_CROSS_WAVES) void kr_cross(RingCtx c, RingOut o, JobQueue q, const RingJob *recs, RingLights lights) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel.
     // They are advanced by the LAST blocks of the grid — the host sizes it with room to spare, so those have the fewest jobs)
     if (lights.on)
@@ -1046,7 +1060,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
 constexpr int kRingWave = 64;
 
 template <int B>
-__global__ __launch_bounds__(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
+__global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
     TRACE_STAMP(0);
     if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase

@@ -1,7 +1,7 @@
 """Developer tool: A/B of implementation choices (config "cfx") with the measurement rounds INTERLEAVED — every engine is
 built once, then round after round each engine in turn reloads the same Archive, takes a few instrumented steps and a timed
 run — so clock and thermal drift of the box hit every choice alike.  Prints the median per-kernel time and wall time per step.
-usage: python tools/ab_bench.py [scenario] [rounds=N] 'layout=ring' 'layout=ring,ringLanesPerWave=40000' ..."""
+usage: python tools/ab_bench.py [scenario] [rounds=N] 'layout=ring' 'layout=ring,ringLanesPerWave=40000' 'layout=dense,lib=gpurun_exp/libx.so' ..."""
 import json, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,14 +23,17 @@ running = base.get_vehicle_count()
 del base
 engines = []
 for i, spec in enumerate(args):
-    cfx = {}
+    cfx, lib = {}, None
     for kv in spec.split(","):
         k, v = kv.split("=")
-        cfx[k] = int(v) if v.lstrip("-").isdigit() else v
+        if k == "lib":  # a differently built device library (tools/README.md)
+            lib = os.path.abspath(v)
+        else:
+            cfx[k] = int(v) if v.lstrip("-").isdigit() else v
     c = json.load(open(cfg)); c["cfx"] = cfx
     path = cfg.replace(".json", "_ab%d.json" % i)
     json.dump(c, open(path, "w"))
-    engines.append((spec, _cityflow.Engine(path, 1), {}, []))
+    engines.append((spec, _cityflow.Engine._with_backend(path, 1, lib) if lib else _cityflow.Engine(path, 1), {}, []))
 steps_timed = int(os.environ.get("CFX_AB_STEPS", 200))
 for r in range(rounds):
     for spec, eng, res, wall in engines:

@@ -12,7 +12,8 @@ cfg = bench.build_workload("/tmp/cfa_vec", 0, scenario=os.environ.get("CFX_VEC_S
                            n_extra=int(os.environ.get("CFX_VEC_EXTRA", bench.N_EXTRA_FLOWS)))
 for R in rs:
     t0 = time.perf_counter()
-    eng = _cityflow.VectorEngine(cfg, R, 1)
+    lib = os.environ.get("CFX_VEC_LIB")  # a differently built device library
+    eng = _cityflow.VectorEngine._with_backend(cfg, R, 1, os.path.abspath(lib)) if lib else _cityflow.VectorEngine(cfg, R, 1)
     t_load = time.perf_counter() - t0
     for _ in range(300):
         eng.next_step()
