@@ -229,7 +229,12 @@ __device__ inline void llstateTails(const StepCtx &c, int k) {
 // k_action of cfx_kernels.h with the rounds-organised per-vehicle phase.  One slot per thread, no loop: nothing is kept
 // alive across iterations, which is the difference between four and five waves per SIMD (86 registers against 109); the
 // host sizes the grid to its bound on the slots, and a bound that turns out too small is an error, not a skipped vehicle.
-constexpr int kDenseActBlock = 256;
+// (workgroup size measured at 1 M vehicles, round 4: 64 -> 43.7 us, 128 -> 44.1, 256 -> 45.6, 512 -> 49.2; a wavefront that
+// has finished its slots makes room for the next one without waiting for three others)
+#ifndef CFX_KD_ACT_BLOCK
+#define CFX_KD_ACT_BLOCK 64
+#endif
+constexpr int kDenseActBlock = CFX_KD_ACT_BLOCK;
 #ifndef CFX_KD_ACTION_WAVES
 #define CFX_KD_ACTION_WAVES 5
 #endif

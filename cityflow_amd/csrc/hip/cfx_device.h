@@ -60,7 +60,8 @@ struct SlotArrays {
     int32_t *routePos;  // Router::iCurRoad as index into the route
     int32_t *templ;     // vehicle template index
     int32_t *route;     // route index
-    uint8_t *flags;     // bit 0: a custom speed is pending (Buffer::isCustomSpeedSet, vehicle.h:62)
+    uint8_t *flags;     // bit 0: a custom speed is pending (Buffer::isCustomSpeedSet, vehicle.h:62); bit 2 (kFlagStateGap): the
+                        // gap of this step's car following is the one the loaded state carried (vGapState), not the derived one
     double *dis;        // ControllerInfo::dis
     double *speed;      // VehicleInfo::speed
 };
@@ -163,6 +164,10 @@ struct LeaverPrefetch {
 };
 
 // Everything the per-step kernels read.  Passed by value (kernel argument segment).
+// Slot flag bits (SlotArrays::flags, the ring layout's meta.z): 1 = custom speed pending, 2 = on the last road of the route,
+// 4 = the first step after cfx_load_state takes the vehicle's gap from the state (ControllerInfo::gap is stored state in the
+// reference, include/cityflow_amd.h cfx_state::r_gap); like bit 0 it lives for one step.
+constexpr int kFlagCustom = 1, kFlagLastRoad = 2, kFlagStateGap = 4;
 #ifndef CFX_CROSS2_WAVES
 #define CFX_CROSS2_WAVES 7
 #endif
@@ -181,6 +186,7 @@ struct StepCtx {
     const int32_t *oldToNew;  // slot of previous generation -> slot of current generation (-1 removed)
     const int32_t *vPriority; // [vid]
     const double *vCustomSpeed; // [vid] Buffer::customSpeed, valid where the slot flag / pending flag is set
+    const double *vGapState;    // [vid] ControllerInfo::gap as cfx_load_state got it (cfx_state::r_gap), where flag bit 2 is set
     // per-laneLink notification sources of this step (phase 3, Engine::threadNotifyCross)
     // [K] {u: vehicle that just left onto the end lane (slot or -1), f: first vehicle of the start lane heading for
     //      this laneLink on green (slot or -1), segStart, cnt of the laneLink}: everything notifiedAt() needs

@@ -334,6 +334,7 @@ struct cfx_engine {
         c.oldToNew = oldToNew;
         c.vPriority = vt.priority;
         c.vCustomSpeed = vt.customSpeed;
+        c.vGapState = vt.gapState;
         c.llDyn = llDyn;
         c.llGate = llGate;
         c.laneTail = laneTail;
@@ -363,6 +364,7 @@ struct cfx_engine {
         if ((rc = grow(&vt.enterTime, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.state, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.customSpeed, (size_t) spawned, nc))) return rc;
+        if ((rc = grow(&vt.gapState, (size_t) spawned, nc))) return rc;
         if ((rc = grow(&vt.pendingCustom, (size_t) spawned, nc))) return rc;
         if (lc.on) {
 #define GROW_LC(f) if ((rc = grow(&lc.f, (size_t) spawned, nc))) return rc;
@@ -492,6 +494,7 @@ struct cfx_engine {
         c.curPhase = curPhase;
         c.vPriority = vt.priority;
         c.vCustomSpeed = vt.customSpeed;
+        c.vGapState = vt.gapState;
         c.llDyn = llDyn;
         c.interMask = interMask;
         c.llGate = rLLGate;
@@ -1953,6 +1956,13 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream) : hipSuccess;
     };
     std::vector<double> customR(std::max(nV, 1), 0.0);
+    // ControllerInfo::gap as the state carries it: used instead of the derived gap in the first step (kFlagStateGap, cfx_device.h)
+    std::vector<double> gapState(std::max(nV, 1), 0.0);
+    auto stateGapOf = [&](int i, int v) {
+        if (!s->r_gap || !(s->r_gap[i] == s->r_gap[i])) return 0;
+        gapState[v] = s->r_gap[i];
+        return kFlagStateGap;
+    };
     if (e->ring) {
         // the caller's arrays ARE the dense staging view (Drivable::vehicles order); kr_scatter_in (below, once the vehicle
         // table is on the device) puts them on the rings
@@ -1982,6 +1992,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
                 flags[i] = 1;
                 customR[v] = s->r_custom_speed[i];
             }
+            flags[i] |= (uint8_t) stateGapOf(i, v);
         }
         HIP_TRY(up(e->rOff, segStart.data(), ((size_t) D + 1) * 4));
         HIP_TRY(up(e->rd.vid, s->r_vid, (size_t) nR * 4));
@@ -2022,6 +2033,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
                 flags[sl] = 1;
                 custom[v] = s->r_custom_speed[i];
             }
+            flags[sl] |= (uint8_t) stateGapOf(i, v);
         }
         for (int i = 0; i < nR; ++i) {  // blockers: vid -> slot (oldToNew is reset to identity below)
             int b = s->r_blocker_vid[i];
@@ -2068,6 +2080,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     HIP_TRY(up(e->vt.enterTime, s->v_enter_time, (size_t) nV * 8));
     HIP_TRY(up(e->vt.state, s->v_state, (size_t) nV));
     HIP_TRY(up(e->vt.customSpeed, custom.data(), (size_t) nV * 8));
+    HIP_TRY(up(e->vt.gapState, gapState.data(), (size_t) nV * 8));
     HIP_TRY(hipMemsetAsync(e->vt.pendingCustom, 0, std::max(nV, 1), e->stream));
     HIP_TRY(up(e->vt.nextWait, nextWait.data(), (size_t) nV * 4));
     HIP_TRY(up(e->waitHead, waitHead.data(), (size_t) L * 4));

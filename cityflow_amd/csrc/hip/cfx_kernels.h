@@ -58,6 +58,7 @@ struct VidTable {
     int32_t *priority, *templ, *route, *nextWait;
     double *enterTime;
     double *customSpeed;     // Buffer::customSpeed (set_vehicle_speed)
+    double *gapState;        // ControllerInfo::gap of the loaded state (StepCtx::vGapState)
     uint8_t *state;          // 0 waiting, 1 running, 2 finished
     uint8_t *pendingCustom;  // custom speed set while the vehicle was still waiting
 };
@@ -830,6 +831,7 @@ __device__ __forceinline__ void actionOne(const C &c, const Out &o, const cfx_ve
         leaderTempl = lead.templ;
         leaderSpeed = lead.speed;
     }
+    if ((flags & kFlagStateGap) && ls >= 0) gap = c.vGapState[vid];  // first step after a load: the state's gap (cfx_state::r_gap)
     if constexpr (LC) {
         if (ls >= 0) c.lc.gap[vid] = gap;  // lane change reads ControllerInfo::gap as stored state
     }
@@ -1735,7 +1737,7 @@ __global__ void k_set_route(StepCtx c, int vid, int route) {
             c.s.routePos[s] = 0;
             const int next = nextOf(c.n, c.t, c.s.drv[s], route, 0);
             c.s.next[s] = next;
-            c.s.flags[s] = (uint8_t) ((c.s.flags[s] & 1) | lastRoadBit(c, c.s.drv[s], route, next));
+            c.s.flags[s] = (uint8_t) ((c.s.flags[s] & (kFlagCustom | kFlagStateGap)) | lastRoadBit(c, c.s.drv[s], route, next));
         }
 }
 
@@ -1752,7 +1754,7 @@ __global__ void k_refresh_next(StepCtx c) {  // after cfx_load_state: Router::ge
         if (c.s.vid[s] >= 0) {
             const int d = c.s.drv[s], route = c.s.route[s], next = nextOf(c.n, c.t, d, route, c.s.routePos[s]);
             c.s.next[s] = next;
-            c.s.flags[s] = (uint8_t) ((c.s.flags[s] & 1) | lastRoadBit(c, d, route, next));
+            c.s.flags[s] = (uint8_t) ((c.s.flags[s] & (kFlagCustom | kFlagStateGap)) | lastRoadBit(c, d, route, next));
         }
 }
 
@@ -2030,6 +2032,7 @@ __global__ void k_leader_view(StepCtx c, int32_t *leaderSlot, double *gapOut) {
         double gap = 0;
         bool head = s == 0 || c.s.drv[s - 1] != d;
         leaderSlot[s] = findLeader(c, c.t.templ, s, d, head, c.s.dis[s], c.t.templ[c.s.templ[s]].approach_dist, &gap);
+        if ((c.s.flags[s] & kFlagStateGap) && leaderSlot[s] >= 0) gap = c.vGapState[c.s.vid[s]];  // not stepped since the load
         gapOut[s] = gap;
     }
 }

@@ -118,7 +118,7 @@ __global__ void k_lc_plan(StepCtx c) {
                 const bool head = s == 0 || c.s.drv[s - 1] != d;
                 double gap;
                 const int ls = findLeader(c, tv, s, d, head, dis, t.approach_dist, &gap);
-                if (ls >= 0) lc.gap[vid] = gap;
+                if (ls >= 0) lc.gap[vid] = (c.s.flags[s] & kFlagStateGap) ? c.vGapState[vid] : gap;  // (first step after a load: the state's)
             }
             if (lc.ptype[vid] == 2) {
                 // shadows make no signals (isReal)

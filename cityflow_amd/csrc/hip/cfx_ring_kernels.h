@@ -59,6 +59,7 @@ struct RingCtx {
     const int32_t *curPhase;
     const int32_t *vPriority;
     const double *vCustomSpeed;
+    const double *vGapState;  // as StepCtx::vGapState
     int4 *llDyn;
     struct LLAux *llAux;     // [K] what a cross needs of a laneLink's notify sources beyond llDyn (written where active)
     unsigned long long *interMask;
@@ -994,6 +995,8 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
         leaderSpeed = best.speed;
     }
 
+    if ((flags & kFlagStateGap) && ls >= 0) gap = c.vGapState[in.vid];  // first step after a load: the state's gap (rare, like the custom speed)
+
     // ================= Vehicle::getNextSpeed vehicle.cpp:308-335
     double v = t.max_speed;
     v = min2(v, speed + t.max_pos_acc * interval);
@@ -1170,9 +1173,9 @@ __global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue
                 in.templPrev = sTempl[t - 1];
                 in.leaderSlot = ringSlot(sGeo[i], sHead[i], idx - 1);
             }
-            if (in.flags & 1) {
+            if (in.flags & (kFlagCustom | kFlagStateGap)) {
                 in.vid = c.s.vid[slot];
-                c.meta[slot].z = in.flags & ~1;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+                c.meta[slot].z = in.flags & ~(kFlagCustom | kFlagStateGap);  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
             }
             in.lm = sLM[i];
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
@@ -1312,9 +1315,9 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
         in.speedPrev = lane == 0 ? kp.y : speedUp;
         in.templPrev = lane == 0 ? tp : templUp;
         if (idx > 0) in.leaderSlot = ringSlot(geo, head, idx - 1);
-        if (in.flags & 1) {
+        if (in.flags & (kFlagCustom | kFlagStateGap)) {
             in.vid = c.s.vid[slot];
-            c.meta[slot].z = in.flags & ~1;  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+            c.meta[slot].z = in.flags & ~(kFlagCustom | kFlagStateGap);  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
         }
         in.lm = sLM[i];
         in.hop = make_int4(-2, -2, -2, -2);
@@ -1611,7 +1614,7 @@ __global__ void kr_gather(RingCtx c, const int32_t *off, RingDense out, int want
         const int4 mv = c.meta[s];
         out.enterLLT[o + i] = mv.w;
         out.routePos[o + i] = c.s.routePos[s];
-        out.flags[o + i] = (uint8_t) (mv.z & 1);
+        out.flags[o + i] = (uint8_t) (mv.z & (kFlagCustom | kFlagStateGap));
         out.dis[o + i] = kv.x;
         out.speed[o + i] = kv.y;
         if (wantLeader) {  // Vehicle::updateLeaderAndGap as of now (findLeader of cfx_kernels.h)
@@ -1623,6 +1626,7 @@ __global__ void kr_gather(RingCtx c, const int32_t *off, RingDense out, int want
             } else {
                 ls = findHeadLeader(c, c.t.templ, s, d, kv.x, c.t.templ[mv.x].approach_dist, mv.y, c.n.drvLength[d], &gap).slot;
             }
+            if ((mv.z & kFlagStateGap) && ls >= 0) gap = c.vGapState[c.s.vid[s]];  // not stepped since the load: the state's gap
             out.leaderVid[o + i] = ls >= 0 ? c.s.vid[ls] : -1;
             out.gap[o + i] = gap;
         }
@@ -1649,7 +1653,7 @@ __global__ void kr_scatter_in(RingCtx c, const int32_t *off, RingDense in, VidTa
         const_cast<int2 *>(c.blkR)[s] = make_int2(in.blockerVid[j], c.step - 1);
         c.kin[s] = make_double2(in.dis[j], in.speed[j]);
         const int nextD = nextOf(c.n, c.t, d, route, in.routePos[j]);
-        c.meta[s] = make_int4(vt.templ[v], nextD, (in.flags[j] & 1) | ((nextD < 0 && isLastRoad(c, d, route)) ? 2 : 0), in.enterLLT[j]);
+        c.meta[s] = make_int4(vt.templ[v], nextD, (in.flags[j] & (kFlagCustom | kFlagStateGap)) | ((nextD < 0 && isLastRoad(c, d, route)) ? 2 : 0), in.enterLLT[j]);
         c.slotOf[v] = s;
         if (i == n - 1) {
             TailRec r;
@@ -1729,7 +1733,7 @@ __global__ void kr_set_route(RingCtx c, int vid, int route) {
     c.s.routePos[s] = 0;
     const int dNow = c.s.drv[s], nextD = nextOf(c.n, c.t, dNow, route, 0);
     c.meta[s].y = nextD;
-    c.meta[s].z = (c.meta[s].z & 1) | ((nextD < 0 && isLastRoad(c, dNow, route)) ? 2 : 0);
+    c.meta[s].z = (c.meta[s].z & (kFlagCustom | kFlagStateGap)) | ((nextD < 0 && isLastRoad(c, dNow, route)) ? 2 : 0);
 }
 __global__ void kr_find_vehicle(RingCtx c, int vid, int32_t *out /*[2]: drivable, routePos*/) {
     const int s = c.slotOf[vid];

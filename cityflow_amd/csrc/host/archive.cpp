@@ -4,6 +4,8 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -15,8 +17,17 @@ namespace cfa {
 
 namespace {
 
-void num(std::string &o, double v) {  // round-trip exact; NaN/Inf spelled the way python's json accepts
-    char buf[40];
+// A decimal literal for `v` that BOTH kinds of reader turn back into exactly `v`: a correctly rounding one (strtod, Python's
+// json) and the reference's own (rapidjson's default number reader, json_number.h — which is an ulp or two off on many 16- and
+// 17-digit literals, so that "%.17g" alone would not survive the reference's, or this engine's, load_from_file).  The shortest
+// of %.15g / %.16g / %.17g that does it; failing those, one of the neighbouring 17-digit decimals inside v's rounding interval,
+// written d.ddde±x; failing that too (not seen in 10^7 random doubles) %.17g, exact for correctly rounding readers.
+bool readsBackBothWays(const char *lit, double v) {
+    const JsonNumber n = parseJsonNumber(lit, lit + strlen(lit));
+    return n.ok && n.d == v && strtod(lit, nullptr) == v;
+}
+void num(std::string &o, double v) {  // NaN/Inf spelled the way python's json accepts
+    char buf[64];
     if (v != v) {
         o += "NaN";
         return;
@@ -24,6 +35,99 @@ void num(std::string &o, double v) {  // round-trip exact; NaN/Inf spelled the w
     if (std::isinf(v)) {
         o += v > 0 ? "Infinity" : "-Infinity";
         return;
+    }
+    for (int prec = 15; prec <= 17; ++prec) {
+        snprintf(buf, sizeof buf, "%.*g", prec, v);
+        if (readsBackBothWays(buf, v)) {
+            o += buf;
+            if (!strpbrk(buf, ".eEn")) o += ".0";
+            return;
+        }
+    }
+    // v = m x 10^e with a 17-digit m: try m +- 1, 2, ...
+    snprintf(buf, sizeof buf, "%.16e", std::fabs(v));  // d.dddddddddddddddde+xx
+    long long m = 0;
+    for (const char *q = buf; *q && *q != 'e'; ++q)
+        if (*q != '.') m = m * 10 + (*q - '0');
+    const int e10 = atoi(strchr(buf, 'e') + 1);
+    for (int k = 1; k <= 40; ++k)
+        for (int sign = -1; sign <= 1; sign += 2) {
+            const long long mk = m + sign * k;
+            if (mk < 10000000000000000LL || mk > 99999999999999999LL) continue;
+            char digits[24];
+            snprintf(digits, sizeof digits, "%lld", mk);
+            snprintf(buf, sizeof buf, "%s%c.%se%d", v < 0 ? "-" : "", digits[0], digits + 1, e10);
+            if (readsBackBothWays(buf, v)) {
+                o += buf;
+                return;
+            }
+        }
+    // an integer A with 2^53 <= A < 2^64 that IS a double, and a power of ten: the reference's reader takes all of A's digits
+    // into its 64-bit accumulator, converts without error and divides (or multiplies) once by an exact power of ten
+    {
+        const double a = std::fabs(v);
+        for (int k = -22; k <= 22; ++k) {
+            const double scaled = k >= 0 ? a * jsonnum::pow10Table(k) : a / jsonnum::pow10Table(-k);
+            if (!(scaled >= 9007199254740992.0 && scaled < 18446744073709551615.0 * 0.999)) continue;
+            for (int step = 0; step < 5; ++step) {
+                double A = scaled;
+                for (int i = 0; i < (step + 1) / 2; ++i) A = std::nextafter(A, step % 2 ? 1e300 : 0.0);
+                if (!(A >= 9007199254740992.0 && A < 18446744073709549568.0)) continue;
+                snprintf(buf, sizeof buf, "%s%llue%d", v < 0 ? "-" : "", (unsigned long long) A, -k);
+                if (readsBackBothWays(buf, v)) {
+                    o += buf;
+                    return;
+                }
+            }
+        }
+    }
+    // More digits than the reader's 64-bit accumulator holds: 19 significant digits and z zeros, times 10^-(k + z).  The
+    // reader continues such an integer in a double (x 10 per further digit) and divides by the double nearest to a power of
+    // ten beyond 10^22 — every z is one more, differently rounded, attempt at landing on v.
+    {
+        const long double a = std::fabs((long double) v);
+        int k = 0;
+        long double x = a;
+        while (x < 1e18L && k < 60) x *= 10.0L, ++k;
+        while (x >= 1e19L && k > -60) x /= 10.0L, --k;
+        const unsigned long long m19 = (unsigned long long) (x + 0.5L);
+        static const int deltas[] = {0, 1, -1, 2, -2, 4, -4, 7, -7, 11, -11, 16, -16, 24, -24, 36, -36};
+        char zeros[24];
+        for (int z = 1; z <= 16; ++z) {
+            memset(zeros, '0', (size_t) z);
+            zeros[z] = 0;
+            for (int d : deltas) {
+                snprintf(buf, sizeof buf, "%s%llu%se%d", v < 0 ? "-" : "", m19 + (long long) d, zeros, -(k + z));
+                if (readsBackBothWays(buf, v)) {
+                    o += buf;
+                    return;
+                }
+            }
+        }
+    }
+    // No literal that both kinds of reader return exactly (about 1 double in 7000 at simulation magnitudes: mantissa close to 2,
+    // where v's rounding interval is narrower than the spacing of every significand the reference's reader can form for it).  The
+    // file is for engines to load, so the reference's reader wins: an integer S with k > 22 digits behind it, S / 10^k inside v's
+    // interval as that reader divides (by the double nearest to 10^k); a correctly rounding reader then sees a neighbour of v.
+    {
+        const long double a = std::fabs((long double) v);
+        char big[400];
+        for (int k = 23; k <= 290; ++k) {
+            const double s0 = (double) (a * powl(10.0L, k));
+            if (!(s0 < 1e300)) break;
+            // (the reader builds S digit by digit in a double and may arrive a few units below the literal: the doubles around
+            // the target are all tried, the reader itself decides)
+            for (int step = 0; step < 15; ++step) {
+                double S = s0;
+                for (int i = 0; i < (step + 1) / 2; ++i) S = std::nextafter(S, step % 2 ? 1e308 : 0.0);
+                snprintf(big, sizeof big, "%s%.0fe%d", v < 0 ? "-" : "", S, -k);
+                const JsonNumber n = parseJsonNumber(big, big + strlen(big));
+                if (n.ok && n.d == v) {
+                    o += big;
+                    return;
+                }
+            }
+        }
     }
     snprintf(buf, sizeof buf, "%.17g", v);
     o += buf;
@@ -44,6 +148,12 @@ void key(std::string &o, const char *k) {
 }
 
 }  // namespace
+
+std::string formatJsonNumber(double v) {
+    std::string o;
+    num(o, v);
+    return o;
+}
 
 std::string Archive::vehicleId(int vid) const {
     const VehicleRecord &r = host.vehicles[vid];
@@ -328,8 +438,8 @@ void EngineHost::load(const Archive &a) {
     st.r_dis = d.rDis.data();
     st.r_speed = d.rSpeed.data();
     st.r_custom_speed = d.rCustomSpeed.empty() ? nullptr : d.rCustomSpeed.data();
+    if (d.rGap.size() == d.rVid.size() && !d.rGap.empty()) st.r_gap = d.rGap.data();  // stored state: the first step's gap
     if (laneChange_ && !d.rLcFlags.empty()) {
-        st.r_gap = d.rGap.data();
         st.r_lc_partner_vid = d.rLcPartner.data();
         st.r_lc_flags = d.rLcFlags.data();
         st.r_lc_offset = d.rLcOffset.data();
@@ -444,6 +554,8 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
         const Json *bl = jv.find("blocker");
         if (bl) y.blocker = bl->s;
         y.running = jv.boolAt("running");
+        // ControllerInfo::gap is read like every other field (archive.cpp:402); an archive written without it: recomputed
+        y.gap = jv.find("gap") && jv.find("gap")->isNumber() ? jv.find("gap")->asDouble() : std::nan("");
         if (laneChange_) {
             y.shadow = isShadow;
             y.gap = jv.numberAt("gap");

@@ -47,6 +47,10 @@ public:
 
 // Archive(Engine&, filename) archive.cpp:345-550: the reference's JSON format -> Archive.  Interns the vehicle templates
 // and routes the file needs in `spawner` (their indices are what the archive's vehicle table refers to).
+// The literal Archive::dump writes for a double: one that a correctly rounding reader AND the reference's (rapidjson's
+// default number reader, json_number.h) both turn back into exactly `v`.
+std::string formatJsonNumber(double v);
+
 Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadNet> &net, Spawner &spawner, bool laneChange);
 
 }  // namespace cfa

@@ -1,8 +1,8 @@
 // Minimal JSON DOM for the host loader (config / roadnet / flow files).
 //
-// Numbers are converted with correctly rounded strtod(); integer literals keep an exact int64.
-// (The reference reads JSON through rapidjson, which is an empty submodule in the reference tree —
-// see DESIGN.md "parity unpinned at the JSON-number boundary".)
+// Numbers are converted the way the reference's reader converts them — rapidjson's default (not correctly rounded) number
+// parser, restated in json_number.h (the library itself is an empty submodule in the reference tree); integer literals keep
+// an exact int64.
 #pragma once
 
 #include <cstdint>
@@ -13,6 +13,8 @@
 #include <string>
 #include <utility>
 #include <vector>
+
+#include "json_number.h"
 
 namespace cfa {
 
@@ -255,28 +257,16 @@ private:
                         v.d = -std::strtod("inf", nullptr);
                         return;
                     }
-                    const char *s0 = p;
-                    bool integral = true;
-                    if (p < end && *p == '-') ++p;
-                    while (p < end) {
-                        char ch = *p;
-                        if (ch >= '0' && ch <= '9') {
-                        } else if (ch == '.' || ch == 'e' || ch == 'E' || ch == '+' || ch == '-') {
-                            integral = false;
-                        } else
-                            break;
-                        ++p;
-                    }
-                    if (p == s0 || (p == s0 + 1 && *s0 == '-')) fail("invalid value");
-                    std::string tok(s0, p - s0);
+                    // the reference's reader (rapidjson, default flags), not strtod: json_number.h
+                    const JsonNumber num = parseJsonNumber(p, end);
+                    if (!num.ok) fail("invalid value");
+                    p = num.end;
                     v.kind = Number;
-                    if (integral && tok.size() <= 18) {
+                    v.d = num.d;
+                    // Int / Uint / Int64 / Uint64 events; beyond the int64 range the value is kept as its double only
+                    if (num.integral && (num.negative ? num.magnitude <= (1ull << 63) : num.magnitude < (1ull << 63))) {
                         v.integral = true;
-                        v.i = strtoll(tok.c_str(), nullptr, 10);
-                        v.d = (double) v.i;
-                    } else {
-                        v.integral = false;
-                        v.d = strtod(tok.c_str(), nullptr);
+                        v.i = num.negative ? (int64_t) (~num.magnitude + 1) : (int64_t) num.magnitude;
                     }
                     return;
                 }

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <iostream>
 
+#include "archive.h"
 #include "engine_host.h"
 #include "tile_engine.h"
 #include "vector_engine.h"
@@ -678,6 +679,13 @@ PYBIND11_MODULE(_cityflow, m) {
           "steps"_a);
     m.def("_spawn_benchmark", &spawnBenchmark, "roadnet_file"_a, "flow_file"_a, "interval"_a, "seed"_a, "skip"_a, "steps"_a);
     m.def("_default_backend_path", &cfa::defaultBackendPath);
+    // test hooks: the host's number reader (the reference's: rapidjson's default, json_number.h) and Archive.dump's writer
+    m.def("_parse_json_number", [](const std::string &lit) {
+        cfa::Json v = cfa::Json::parseText(lit);
+        if (!v.isNumber()) throw std::runtime_error("not a number");
+        return py::make_tuple(v.asDouble(), v.integral);
+    });
+    m.def("_format_json_number", &cfa::formatJsonNumber);
 #ifdef CITYFLOW_AMD_VERSION
     m.attr("__version__") = CITYFLOW_AMD_VERSION;
 #else

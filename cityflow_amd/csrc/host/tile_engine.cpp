@@ -621,8 +621,9 @@ void TileEngine::loadState(const Archive &a, bool takesTotals) {
         else on[ld].push_back((int) i);
     }
     std::vector<int32_t> rVid, rDrv, rPrev, rBlk, rEllt, rPos;
-    std::vector<double> rDis, rSpeed, rCustom;
+    std::vector<double> rDis, rSpeed, rCustom, rGap;
     const double nan = __builtin_nan("");
+    const bool haveGap = d.rGap.size() == d.rVid.size();
     for (int ld = 0; ld < nL + nK; ++ld)
         for (int i : on[ld]) {
             const bool proxy = ld < nL && tn_.laneGhost[ld];
@@ -639,6 +640,7 @@ void TileEngine::loadState(const Archive &a, bool takesTotals) {
             rDis.push_back(d.rDis[i]);
             rSpeed.push_back(d.rSpeed[i]);
             rCustom.push_back(proxy || d.rCustomSpeed.empty() ? nan : d.rCustomSpeed[i]);
+            rGap.push_back(proxy || !haveGap ? nan : d.rGap[i]);  // ControllerInfo::gap is state (cfx_state::r_gap)
             if (!proxy) vstate[vid] = 1;
         }
     std::vector<int32_t> wVid, wLane;
@@ -676,6 +678,7 @@ void TileEngine::loadState(const Archive &a, bool takesTotals) {
     st.r_dis = rDis.data();
     st.r_speed = rSpeed.data();
     st.r_custom_speed = rCustom.data();
+    st.r_gap = rGap.data();
     st.n_waiting = (int) wVid.size();
     st.w_vid = wVid.data();
     st.w_lane = wLane.data();

@@ -264,9 +264,15 @@ typedef struct cfx_state {
     const int32_t *r_vid, *r_drivable, *r_prev_drivable, *r_blocker_vid, *r_enter_ll_time, *r_route_pos;
     const double *r_dis, *r_speed;
     const double *r_custom_speed;    /* NaN where no custom speed is pending; may be NULL */
+    /* ControllerInfo::gap is STORED state in the reference: Vehicle::getCarFollowSpeed (vehicle.cpp:212-238) reads what
+     * updateLeaderAndGap left at the end of the previous step, and Archive::resume restores it with the vehicle.  An engine
+     * that derives leader and gap from the order at the start of a step uses r_gap[i] INSTEAD of the derived gap in the first
+     * step after the load, for every vehicle that has a leader then (NaN, or r_gap == NULL: the derived one).  The two are the
+     * same number unless the archive came through a file whose `dis` / `gap` literals were not read back exactly — the
+     * reference's JSON reader is not correctly rounded (csrc/host/json_number.h).  Lane change: makeSignal reads it too. */
+    const double *r_gap;
     /* lane change (all may be NULL = no lane-change state): what of LaneChange / LaneChangeInfo outlives a step —
      * signals received, target leader / follower are cleared by every step's clearSignal (engine.cpp:424) */
-    const double *r_gap;             /* ControllerInfo::gap (stored state: makeSignal reads it without a leader) */
     const int32_t *r_lc_partner_vid, *r_lc_last_dir, *r_lc_target_lane, *r_lc_direction;
     const uint8_t *r_lc_flags;       /* CFX_LC_* */
     const double *r_lc_offset, *r_lc_last_change_time, *r_lc_waiting_time;

@@ -4,10 +4,10 @@
 // reference sources under /root/reference/src compile into oracle/_ref/ (see oracle/Makefile).
 // Nothing in the product path (cityflow_amd/) includes this header.
 //
-// Numeric note: decimal -> double conversion uses correctly rounded strtod();
-// real rapidjson (default flags) may differ by <= a few ULP on >= 17-digit literals.  The product
-// host parser also uses strtod, so oracle and product agree by construction ("parity unpinned at the
-// JSON-number boundary" is stated in DESIGN.md).
+// Numeric note: decimal -> double conversion follows real rapidjson's DEFAULT number reader (not a
+// correctly rounded strtod: it can be an ulp or two off on 16/17-digit literals) as restated in number_reader.h from the
+// library's published algorithm; the product's host parser has its own restatement (csrc/host/json_number.h) and
+// oracle/probe_json_number.cpp compares the two.  What stays unpinned: the library itself is not here to run.
 #ifndef ORACLE_RAPIDJSON_SHIM_DOCUMENT_H
 #define ORACLE_RAPIDJSON_SHIM_DOCUMENT_H
 
@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 #include <utility>
+
+#include "number_reader.h"
 
 namespace rapidjson {
 
@@ -288,8 +290,13 @@ inline void Value::writeTo(std::string &out) const {
                 if (num_ != num_) { out += "NaN"; break; }
                 if (num_ > 1.7976931348623157e308) { out += "Infinity"; break; }
                 if (num_ < -1.7976931348623157e308) { out += "-Infinity"; break; }
-                // %.17g round-trips every finite double exactly through strtod
-                snprintf(buf, sizeof buf, "%.17g", num_);
+                // real rapidjson's Writer prints Grisu2's digits: near-shortest, and exact for a correctly rounding reader
+                // — NOT for the library's own default reader (number_reader.h), so the reference's dump -> load_from_file
+                // can move a value by an ulp.  Modelled by the shortest of %.15g / %.16g / %.17g that strtod reads back.
+                for (int prec = 15; prec <= 17; ++prec) {
+                    snprintf(buf, sizeof buf, "%.*g", prec, num_);
+                    if (strtod(buf, nullptr) == num_) break;
+                }
                 out += buf;
                 if (!strpbrk(buf, ".eEn")) out += ".0";  // keep it a "double" literal
             }
@@ -478,23 +485,18 @@ struct Parser {
             else if (lit("-Infinity")) v.num_ = -strtod("inf", nullptr);
             else ok = false;
         } else if (c == '-' || (c >= '0' && c <= '9')) {
-            const char *s = p;
-            bool integral = true;
-            if (*p == '-') ++p;
-            while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) {
-                if (*p == '.' || *p == 'e' || *p == 'E') integral = false;
-                ++p;
+            // real rapidjson's default number reader, not strtod (number_reader.h)
+            const shim_number::Parsed num = shim_number::read(p, (size_t) (end - p));
+            if (!num.ok) {
+                ok = false;
+                return;
             }
-            std::string tok(s, p - s);
+            p += num.length;
             v.kind_ = kNumberType;
-            if (integral && tok.size() <= 18) {
-                v.isInt_ = true;
-                v.int_ = strtoll(tok.c_str(), nullptr, 10);
-                v.num_ = (double) v.int_;
-            } else {
-                v.isInt_ = false;
-                v.num_ = strtod(tok.c_str(), nullptr);
-            }
+            v.num_ = num.value;
+            const bool fits = num.isInteger && (num.negative ? num.absInt <= (1ull << 63) : num.absInt < (1ull << 63));
+            v.isInt_ = fits;
+            v.int_ = fits ? (num.negative ? (int64_t) (0 - num.absInt) : (int64_t) num.absInt) : 0;
         } else {
             ok = false;
         }

@@ -1400,13 +1400,22 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
         e->curPhase[i] = s->tl_phase[i];
         e->remain[i] = s->tl_remain[i];
     }
-    for (auto &list : e->order) {  // leader / gap are a function of the order (engine.cpp:429-442)
+    for (auto &list : e->order) {  // the leaders are a function of the order (engine.cpp:429-442)
         int leader = -1;
         for (int32_t vid : list) {
             e->updateLeaderAndGap(e->veh[vid], leader);
             leader = vid;
         }
     }
+    // ... ControllerInfo::gap is STATE: the first step's car following reads what the archive holds (Archive::resume copies
+    // the vehicles, archive.cpp:73-126; getCarFollowSpeed vehicle.cpp:212-238), which is what updateLeaderAndGap left at the
+    // end of the archived step — the same number as the one just recomputed, unless the archive came through a file whose
+    // `dis` and `gap` literals were not read back exactly (the reference's JSON reader is not correctly rounded)
+    if (s->r_gap)
+        for (int i = 0; i < s->n_running; ++i) {
+            Veh &x = e->veh[s->r_vid[i]];
+            if (x.leader >= 0 && s->r_gap[i] == s->r_gap[i]) x.gap = s->r_gap[i];
+        }
     return CFX_OK;
 }
 

@@ -124,3 +124,37 @@ def assert_same_state(a, b, where="", skip=()):
         assert ca[k] == cb[k], "%s: scalar %s differs (%r vs %r)" % (where, k, ca[k], cb[k])
     pa, pb = a._tl_state(), b._tl_state()
     assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]), where + ": traffic-light state differs"
+
+
+def dump_json_exact(obj, path):
+    """json.dump for files the engines will read: every float as the literal Archive.dump itself would write — one that a
+    correctly rounding reader AND the reference's reader (rapidjson's default number reader, which is an ulp or two off on
+    many of the 16/17-digit literals `repr` produces; csrc/host/json_number.h) both turn back into exactly that float."""
+    from cityflow_amd import _cityflow
+    out = []
+
+    def emit(x):
+        if isinstance(x, dict):
+            out.append("{")
+            for i, (k, v) in enumerate(x.items()):
+                if i:
+                    out.append(",")
+                out.append(json.dumps(str(k)))
+                out.append(":")
+                emit(v)
+            out.append("}")
+        elif isinstance(x, (list, tuple)):
+            out.append("[")
+            for i, v in enumerate(x):
+                if i:
+                    out.append(",")
+                emit(v)
+            out.append("]")
+        elif isinstance(x, float):
+            out.append(_cityflow._format_json_number(x))
+        else:
+            out.append(json.dumps(x))
+
+    emit(obj)
+    with open(path, "w") as f:
+        f.write("".join(out))

@@ -290,12 +290,16 @@ def test_tiled_random_calls_equal_single_engine(mod, scen, workdir, seed):
         assert checkpoint_record(one) == checkpoint_record(til), (seed, round_)
 
 
-def _comparable_dump(path):
+def _comparable_dump(path, written_by_reference):
     """An Archive file without the two things that cannot be equal: Lane::history (it feeds only the unused DURATION router
     and is not kept by this engine) and ControllerInfo::gap of a vehicle without a leader (uninitialised memory in the
     reference's dump)."""
+    from cityflow_amd import _cityflow
+    # The numbers each writer MEANT.  The reference's writer (rapidjson's Writer: near-shortest digits) guarantees them to a
+    # correctly rounding reader; this engine's writer guarantees them to the reference's own reader (rapidjson's default number
+    # reader, csrc/host/json_number.h), for which no such literal exists for about one double in a thousand.
     with open(path) as f:
-        d = json.load(f)
+        d = json.load(f) if written_by_reference else json.load(f, parse_float=lambda lit: _cityflow._parse_json_number(lit)[0])
     for dv in d["drivables"].values():
         for k in ("history", "historyVehicleNum", "historyAverageSpeed"):
             dv.pop(k, None)
@@ -308,8 +312,8 @@ def _comparable_dump(path):
 @pytest.mark.parametrize("seed", [3, 4])
 def test_archive_files_cross_loaded_in_the_middle_of_sequences(mod, ref_module, scen, workdir, tmp_path, seed):
     """`snapshot().dump()` of the reference and of this engine at random moments of a sequence with custom speeds, pushed
-    vehicles and full waiting buffers: the files are equal (see _comparable_dump), each engine loads the OTHER's file (or its
-    own) and both go on identically — again and again in one run (archive.cpp:153-550)."""
+    vehicles and full waiting buffers: the files are equal (see _comparable_dump), both engines load one of the two files
+    and go on identically — again and again in one run (archive.cpp:153-550)."""
     rl = seed % 2 == 0
     cfg = _config(scen, workdir, rl)
     ref, tw = ref_module.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
@@ -335,13 +339,14 @@ def test_archive_files_cross_loaded_in_the_middle_of_sequences(mod, ref_module, 
                 p_ref, p_tw = str(tmp_path / ("ref%d.json" % exchanged)), str(tmp_path / ("tw%d.json" % exchanged))
                 ref.snapshot().dump(p_ref)
                 tw.snapshot().dump(p_tw)
-                assert _comparable_dump(p_ref) == _comparable_dump(p_tw), (seed, round_)
-                if rng.random() < 0.5:
-                    tw.load_from_file(p_ref)
-                    ref.load_from_file(p_tw)
-                else:
-                    tw.load_from_file(p_tw)
-                    ref.load_from_file(p_ref)
+                assert _comparable_dump(p_ref, True) == _comparable_dump(p_tw, False), (seed, round_)
+                # Both load the SAME file, the reference's or this engine's.  The reference's reader (rapidjson's default
+                # number reader, restated in csrc/host/json_number.h) is not correctly rounded: a file the reference wrote
+                # (near-shortest digits) can come back an ulp off — in both engines alike, `dis`, `speed` and the stored `gap`
+                # each on its own; this engine's file (literals chosen to survive that reader) comes back as it was saved.
+                which = p_ref if rng.random() < 0.5 else p_tw
+                tw.load_from_file(which)
+                ref.load_from_file(which)
             elif op == 5:
                 assert ref.get_lane_vehicle_count() == tw.get_lane_vehicle_count()
             elif op == 6:

@@ -1,6 +1,8 @@
 """CPU: Archive (snapshot / load / dump / load_from_file), set_vehicle_speed, set_vehicle_route on the host + CPU twin,
 mirroring the reference's tests/python/test_archive.py and checked live against the unmodified reference engine.
 The same scenarios run on the HIP engine in tests/test_hip_api.py (-m gpu)."""
+import json
+import os
 import time
 
 import pytest
@@ -61,7 +63,13 @@ def test_archive_roundtrips_twin(mod, scen, workdir, tmp_path):
 
 
 def test_archive_json_is_interchangeable_with_reference(mod, ref_module, scen, workdir, tmp_path):
-    """A dump written here loads into the reference engine and vice versa; both continue identically."""
+    """A dump written here loads into the reference engine and vice versa.  Files are read the way the reference reads them —
+    rapidjson's default number reader, which is not correctly rounded (csrc/host/json_number.h) — so:
+    * a file THIS engine writes (every double as a literal that reader returns exactly) loads into either engine as the very
+      state that was saved: both continue exactly like the engine that kept running;
+    * a file the REFERENCE writes (near-shortest digits) may come back an ulp off in either engine — the reference's own
+      dump -> load_from_file is lossy that way; both engines read the same values from it, the stored gap included
+      (cfx_state::r_gap), and continue bit-identically."""
     cfg = scen.materialize("example_1x1", workdir)
     ours, ref = make(mod, cfg), ref_module.Engine(cfg, 1)
     run(ours, 150)
@@ -74,9 +82,9 @@ def test_archive_json_is_interchangeable_with_reference(mod, ref_module, scen, w
     run(ref, 120)
     want = checkpoint_record(ref)
     assert checkpoint_record(ours) == want
-    # cross-load
+    # this engine's file, loaded by both
     ours2, ref2 = make(mod, cfg), ref_module.Engine(cfg, 1)
-    ours2.load_from_file(p_ref)
+    ours2.load_from_file(p_ours)
     ref2.load_from_file(p_ours)
     assert ours2.get_current_time() == 150.0 and ref2.get_current_time() == 150.0
     assert ours2.get_lane_vehicle_count() == ref2.get_lane_vehicle_count()
@@ -84,7 +92,84 @@ def test_archive_json_is_interchangeable_with_reference(mod, ref_module, scen, w
     run(ref2, 120)
     assert checkpoint_record(ours2) == want
     assert checkpoint_record(ref2) == want
+    # the reference's file, loaded by both
+    ours3, ref3 = make(mod, cfg), ref_module.Engine(cfg, 1)
+    ours3.load_from_file(p_ref)
+    ref3.load_from_file(p_ref)
+    assert ours3.get_current_time() == 150.0 and ref3.get_current_time() == 150.0
+    assert ours3.get_vehicle_distance() == ref3.get_vehicle_distance()
+    for _ in range(120):
+        ours3.next_step()
+        ref3.next_step()
+        assert ours3.get_vehicle_distance() == ref3.get_vehicle_distance()
+    assert checkpoint_record(ours3) == checkpoint_record(ref3)
     time.sleep(0.1)
+
+
+def lossy_archive_file(mod, scen, workdir, name="grid_6x6", steps=300, lane_change=False):
+    """An Archive file as Python's json writes it: every double as its `repr` — the shortest literal a correctly rounding
+    reader returns exactly, which the reference's reader (rapidjson's default number reader, csrc/host/json_number.h) gets an
+    ulp or two wrong for about one 16/17-digit literal in six.  So `dis`, `speed` and the stored `gap` of a vehicle come back
+    each with its own error: the first step after the load must take its gap from the file (cfx_state::r_gap), not from the
+    positions."""
+    cfg = scen.materialize(name, workdir, laneChange=True) if lane_change else scen.materialize(name, workdir)
+    tw = make(mod, cfg)
+    run(tw, steps)
+    path = os.path.join(os.path.dirname(cfg), "archive_lossy_%s_%d.json" % (name, int(lane_change)))
+    tw.snapshot().dump(path)
+    with open(path) as f:
+        arc = json.load(f)
+    with open(path, "w") as f:
+        json.dump(arc, f)
+    # (the point of the file: it does NOT come back as it was written)
+    moved = sum(mod._parse_json_number(repr(v["dis"]))[0] != v["dis"] for v in arc["vehicles"])
+    assert moved > 0
+    return cfg, path
+
+
+def lossy_archive_body(cfg, path, make_a, make_b, steps=40):
+    """Both engines load the file and are equal — right after the load (what a dump would show, the gap included) and after
+    every one of the following steps, bit for bit."""
+    a, b = make_a(cfg), make_b(cfg)
+    a.load_from_file(path)
+    b.load_from_file(path)
+
+    def same(where):
+        assert a.get_lane_vehicles() == b.get_lane_vehicles(), where
+        assert a.get_vehicle_speed() == b.get_vehicle_speed(), where
+        assert a.get_vehicle_distance() == b.get_vehicle_distance(), where
+        sa, sb = a._vehicle_state(), b._vehicle_state()
+        has = sa["leader"] >= 0
+        assert (sa["leader"] >= 0).tolist() == (sb["leader"] >= 0).tolist(), where
+        assert sa["gap"][has].tolist() == sb["gap"][has].tolist(), where + ": gap"
+
+    same("after the load")
+    for s in range(steps):
+        a.next_step()
+        b.next_step()
+        same("step %d after the load" % (s + 1))
+    return a, b
+
+
+def test_lossy_archive_file_twin_equals_reference(mod, ref_module, scen, workdir):
+    cfg, path = lossy_archive_file(mod, scen, workdir)
+    ref, tw = ref_module.Engine(cfg, 1), make(mod, cfg)
+    ref.load_from_file(path)
+    tw.load_from_file(path)
+    assert ref.get_vehicle_distance() == tw.get_vehicle_distance()
+    for s in range(40):
+        ref.next_step()
+        tw.next_step()
+        assert ref.get_vehicle_speed() == tw.get_vehicle_speed() and ref.get_vehicle_distance() == tw.get_vehicle_distance(), s
+        assert ref.get_lane_vehicles() == tw.get_lane_vehicles(), s
+    time.sleep(0.2)
+
+
+def test_lossy_archive_body_on_the_twin(mod, scen, workdir):
+    """(CPU shadow of tests/test_hip_api.py::test_lossy_archive_file_hip_equals_twin: the twin against itself through the
+    same body, so that a host-side change that breaks the body shows without a GPU)"""
+    cfg, path = lossy_archive_file(mod, scen, workdir)
+    lossy_archive_body(cfg, path, lambda c: make(mod, c), lambda c: make(mod, c), steps=5)
 
 
 def control_script(e, steps=160):

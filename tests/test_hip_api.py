@@ -4,7 +4,7 @@ import time
 import pytest
 
 from conftest import TWIN_LIB, checkpoint_record
-from test_archive_and_control import archive_roundtrips, control_script, run
+from test_archive_and_control import archive_roundtrips, control_script, lossy_archive_body, lossy_archive_file, run
 
 pytestmark = pytest.mark.gpu
 
@@ -154,3 +154,22 @@ def test_repeated_set_tl_phase_before_a_step_last_call_wins(mod, scen, workdir):
         if s % 10 == 9:
             from conftest import assert_same_state
             assert_same_state(hip, tw, "repeated set_tl_phase step %d" % (s + 1))
+
+
+@pytest.mark.parametrize("layout", ["dense", "ring"])
+def test_lossy_archive_file_hip_equals_twin(mod, scen, workdir, layout):
+    """An Archive file whose doubles do not survive the reference's JSON reader (Python's `repr` literals): the HIP engine takes
+    the first step's gaps from the loaded state like the twin — which tests/test_archive_and_control.py pins to the reference
+    on this very file — on both vehicle layouts; equal right after the load and after each of 40 steps."""
+    import json
+    cfg, path = lossy_archive_file(mod, scen, workdir)
+    c = json.load(open(cfg))
+    c["cfx"] = {"layout": layout}
+    cfg_l = cfg.replace(".json", "_%s.json" % layout)
+    json.dump(c, open(cfg_l, "w"))
+    lossy_archive_body(cfg, path, lambda _c: mod.Engine(cfg_l, 1), lambda c_: mod.Engine._with_backend(c_, 1, TWIN_LIB))
+
+
+def test_lossy_archive_file_lane_change_hip_equals_twin(mod, scen, workdir):
+    cfg, path = lossy_archive_file(mod, scen, workdir, lane_change=True)
+    lossy_archive_body(cfg, path, lambda c: mod.Engine(c, 1), lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), steps=30)

@@ -1,0 +1,178 @@
+"""CPU: decimal literal -> double exactly as the reference's JSON reader does it.
+
+The reference reads every file through rapidjson with the DEFAULT parse flags (reference src/utility/utility.cpp:96-114), whose
+number reader is not a correctly rounded strtod (GenericReader::ParseNumber + internal::StrtodNormalPrecision).  rapidjson is an
+empty submodule of the reference tree, so its published algorithm is restated three times, independently written, and the three
+are compared here:
+  * csrc/host/json_number.h            the product's host loader (over the character stream),
+  * oracle/rapidjson_shim/.../number_reader.h   what the reference build of oracle/_ref reads through (over digit groups),
+  * `reader` below                     plain Python integers and floats.
+What stays unpinned is the library itself: it is not here to run."""
+import os
+import random
+import struct
+import subprocess
+
+import pytest
+
+from conftest import REF_DIR
+
+
+def reader(lit):
+    """rapidjson's ParseNumber (64-bit build, no kParseFullPrecisionFlag) -> (is_integer_event, value as GetDouble())."""
+    i, n = 0, len(lit)
+    minus = lit[0] == "-"
+    if minus:
+        i = 1
+    digit = lambda k: k < n and lit[k].isdigit()
+    sig, d, in_double, counted = 0, 0.0, False, 0
+    if lit[i] == "0":
+        i += 1
+    else:
+        sig = int(lit[i])
+        i += 1
+        lim32, last32 = (214748364, "8") if minus else (429496729, "5")
+        wide = False
+        while digit(i):
+            if sig >= lim32 and (sig != lim32 or lit[i] > last32):
+                wide = True
+                break
+            sig = sig * 10 + int(lit[i])
+            i += 1
+            counted += 1
+        if wide:
+            lim64, last64 = (0x0CCCCCCCCCCCCCCC, "8") if minus else (0x1999999999999999, "5")
+            while digit(i):
+                if sig >= lim64 and (sig != lim64 or lit[i] > last64):
+                    d, in_double = float(sig), True
+                    break
+                sig = sig * 10 + int(lit[i])
+                i += 1
+                counted += 1
+        if in_double:
+            while digit(i):
+                d = d * 10 + int(lit[i])
+                i += 1
+    real, taken = in_double, 0
+    if i < n and lit[i] == ".":
+        i += 1
+        if not in_double:
+            while digit(i):
+                if sig > 0x1FFFFFFFFFFFFF:
+                    break
+                sig = sig * 10 + int(lit[i])
+                i += 1
+                taken += 1
+                if sig:
+                    counted += 1
+            d, in_double = float(sig), True
+        while digit(i):
+            if counted < 17:
+                d = d * 10.0 + int(lit[i])
+                taken += 1
+                if d > 0.0:
+                    counted += 1
+            i += 1
+        real = True
+    exp = 0
+    if i < n and lit[i] in "eE":
+        i += 1
+        if not in_double:
+            d, in_double = float(sig), True
+        real = True
+        neg = False
+        if lit[i] in "+-":
+            neg = lit[i] == "-"
+            i += 1
+        exp = int(lit[i])
+        i += 1
+        if neg:
+            max_exp = (-taken + 2147483639) // 10
+            while digit(i):
+                exp = exp * 10 + int(lit[i])
+                i += 1
+                if exp > max_exp:
+                    while digit(i):
+                        i += 1
+            exp = -exp
+        else:
+            while digit(i):
+                exp = exp * 10 + int(lit[i])
+                i += 1
+    if not real:
+        return True, float(-sig if minus else sig)
+    p = exp - taken
+    once = lambda x, q: 0.0 if q < -308 else (x * float("1e%d" % q) if q >= 0 else x / float("1e%d" % -q))
+    d = once(once(d, -308), p + 308) if p < -308 else once(d, p)
+    return False, -d if minus else d
+
+
+def random_literal(rng):
+    shape = rng.randrange(7)
+    if shape == 6:  # what Python's json writes for a double
+        x = struct.unpack("<d", struct.pack("<Q", rng.getrandbits(52) | (rng.randrange(950, 1100) << 52)))[0]
+        return repr(-x if rng.random() < 0.5 else x)
+    s = "-" if rng.random() < 0.5 else ""
+    s += "0" if rng.random() < 0.12 else str(rng.randrange(1, 10)) + "".join(rng.choice("0123456789") for _ in range(rng.randrange(24 if shape == 0 else 6)))
+    if shape != 0 or rng.random() < 0.5:
+        if rng.random() < 0.9:
+            s += "." + "".join(rng.choice("0123456789") for _ in range(rng.randrange(1, 30 if shape == 1 else 19)))
+        if rng.random() < 0.3:
+            s += rng.choice("eE") + rng.choice(["", "+", "-"]) + str(rng.randrange(300 if shape == 2 else 30))
+    return s
+
+
+def test_product_reader_equals_the_python_restatement(mod):
+    rng = random.Random(20240924)
+    off = 0
+    for _ in range(60000):
+        lit = random_literal(rng)
+        is_int, want = reader(lit)
+        if want == float("inf") or want == float("-inf"):
+            continue  # rapidjson: kParseErrorNumberTooBig
+        got, got_int = mod._parse_json_number(lit)
+        assert struct.pack("<d", got) == struct.pack("<d", want), lit
+        assert got_int == (is_int and abs(want) < 2.0 ** 63), lit  # (an Uint64 beyond the int64 range is kept as its double here)
+        off += float(lit) != want
+    assert off > 1000  # (it really is a different function from strtod)
+
+
+def test_shim_reader_equals_product_reader():
+    probe = os.path.join(REF_DIR, "probe_json_number")
+    if not os.path.exists(probe):
+        pytest.skip("oracle/_ref/probe_json_number not built")
+    out = subprocess.run([probe, "400000", "77"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert " disagreements 0 " in out.stdout
+
+
+def test_short_literals_are_read_like_strtod(mod):
+    """Up to 15 significant digits and a small exponent: one exact integer, one exact power of ten, one rounding."""
+    rng = random.Random(5)
+    for lit in ["0", "-0", "0.0", "-0.0", "1", "16.67", "0.1", "2.5", "300", "1e-3", "4.5", "11.111", "1E5", "123456789012345"]:
+        assert mod._parse_json_number(lit)[0] == float(lit), lit
+    for _ in range(20000):
+        lit = "%.*g" % (rng.randrange(1, 16), rng.uniform(-1, 1) * 10 ** rng.randrange(-6, 7))
+        assert mod._parse_json_number(lit)[0] == float(lit), lit
+    assert mod._parse_json_number("-0")[0] == 0.0 and str(mod._parse_json_number("-0")[0]) == "0.0"  # the INTEGER zero
+    assert str(mod._parse_json_number("-0.0")[0]) == "-0.0"
+    assert mod._parse_json_number("18446744073709551616")[0] == 2.0 ** 64  # beyond the 64-bit accumulator
+
+
+def test_archive_writer_survives_both_readers(mod):
+    """Archive.dump's literal for a double: read back exactly by the reference's reader (what load_from_file of either engine
+    uses) — and, wherever such a literal exists, by a correctly rounding reader too."""
+    rng = random.Random(9)
+    n, lost, strtod_off = 150000, 0, 0
+    for i in range(n):
+        v = rng.uniform(0, 400) if i % 2 else rng.uniform(-1e4, 1e4) * 10 ** rng.randrange(-6, 2)
+        lit = mod._format_json_number(v)
+        back = mod._parse_json_number(lit)[0]
+        assert back == reader(lit)[1]
+        lost += back != v
+        strtod_off += float(lit) != v
+    assert lost <= n * 3e-5, lost            # (doubles no literal reaches through that reader: about 1 in 10^5)
+    assert strtod_off <= n * 5e-4, strtod_off
+    for v in (0.0, 1.0, -1.0, 0.5, 16.67, 1e22, 1e-7, 123456.789):
+        assert float(mod._format_json_number(v)) == v
+    assert mod._format_json_number(float("nan")) == "NaN" and mod._format_json_number(float("inf")) == "Infinity"
