@@ -831,7 +831,12 @@ __device__ __forceinline__ void actionOne(const C &c, const Out &o, const cfx_ve
         leaderTempl = lead.templ;
         leaderSpeed = lead.speed;
     }
-    if ((flags & kFlagStateGap) && ls >= 0) gap = c.vGapState[vid];  // first step after a load: the state's gap (cfx_state::r_gap)
+    // First step after a load: the state's gap (cfx_state::r_gap).  Not with lane change: there the reference refreshes every
+    // leader and gap between planLaneChange and getAction (Engine::nextStep engine.cpp:571-575) — the stored gap is read by
+    // makeSignal only (k_lc_plan).
+    if constexpr (!LC) {
+        if ((flags & kFlagStateGap) && ls >= 0) gap = c.vGapState[vid];
+    }
     if constexpr (LC) {
         if (ls >= 0) c.lc.gap[vid] = gap;  // lane change reads ControllerInfo::gap as stored state
     }

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevSca
             c.s.routePos[ns] = routePos;
             c.s.templ[ns] = c.s.templ[ps];
             c.s.route[ns] = route;
-            c.s.flags[ns] = c.s.flags[ps];
+            c.s.flags[ns] = c.s.flags[ps] & ~kFlagStateGap;  // (insertShadow computes the shadow's leader and gap)
             c.s.dis[ns] = rec.dis;
             c.s.speed[ns] = c.s.speed[ps];
         }

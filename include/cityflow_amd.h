@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CFX_ABI_VERSION 5
+#define CFX_ABI_VERSION 6
 
 typedef enum cfx_status {
     CFX_OK = 0,
