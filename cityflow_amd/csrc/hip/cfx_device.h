@@ -116,6 +116,7 @@ struct LcDev {
     int32_t *roadCand;              // [R] candidates on the road (plan -> schedule)
     int2 *roadCandList;             // [R * kLcRoadCand] {vid, slot} of the first candidates of each road
     int32_t *candAll;               // [slot capacity] all candidates of the step
+    int32_t *candAllEnv;            // [slot capacity] ... and the environment each belongs to (batched environments, below)
     int32_t *candAllCount;          // [1]
     int32_t *candPos;               // [vid] position of a candidate in the reference's walk (k_lc_order)
     int32_t *insHead, *insNext;     // [L] / [insCap] records of a target lane, linked
@@ -128,7 +129,12 @@ struct LcDev {
     int32_t *newToOld;              // [slot capacity] inverse of oldToNew for the slots k_scatter filled
     const int32_t *pool;            // priorities the host's generator would hand out next (cfx_lane_change_supply)
     int firstShadowVid;
+    // Batched environments (cfx_config::n_envs): environment of a road = road / roadsPerEnv (one environment: roadsPerEnv = R);
+    // every environment has its own schedule walk (lcWalkPosition) and its own poolPerEnv priorities pool[env * poolPerEnv ...];
+    // shadows are created environment by environment: LcDev::insKey = (environment << kLcEnvShift) + walk position
+    int roadsPerEnv, poolPerEnv;
 };
+constexpr int kLcEnvShift = 20;
 
 // The last vehicle of a drivable, kept as ONE 32-byte record so that its readers — the leader search of every head of a
 // drivable, Lane::canEnter, the admission check, the notify sources — do one load instead of a chain through

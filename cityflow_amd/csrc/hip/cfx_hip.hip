@@ -407,6 +407,7 @@ struct cfx_engine {
         if (lc.on && (rc = grow(&lc.parkList, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.parkDep, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.candAll, 0, nc))) return rc;
+        if (lc.on && (rc = grow(&lc.candAllEnv, 0, nc))) return rc;
         if (lc.on && (rc = grow(&lc.segOfSlot, keep, nc))) return rc;  // (k_scatter leaves the next step's input in it)
         slotCap = nc;
         return CFX_OK;
@@ -919,6 +920,14 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if (cfg->lane_change) {
         LcDev &lc = e->lc;
         lc.on = 1;
+        // batched environments (cfx_config::n_envs): E disjoint copies of one network, index spaces concatenated copy by copy
+        const int nEnvs = cfg->n_envs > 1 ? cfg->n_envs : 1;
+        if (e->R % nEnvs != 0 || nEnvs >= (1 << (31 - kLcEnvShift))) {
+            e->err = "cfx_create: n_envs does not divide the number of roads (or is too large)";
+            return CFX_ERR_INVALID;
+        }
+        lc.roadsPerEnv = std::max(e->R / nEnvs, 1);
+        lc.poolPerEnv = 0;
         if ((rc = e->uploadConst(lc.laneWidth, n->lane_width, (size_t) e->L))) return rc;
         if ((rc = e->uploadConst(lc.roadLaneStart, n->road_lane_start, (size_t) e->R + 1))) return rc;
         if ((rc = e->uploadConst(lc.laneNumSegs, n->lane_n_segments, (size_t) e->L))) return rc;
@@ -1838,6 +1847,9 @@ int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *prioriti
     HIP_TRY(hipSetDevice(e->device));
     int rc;
     if (e->pollPending) return e->fail("cfx_lane_change_supply: the previous lane-change step was not polled"), CFX_ERR_STATE;
+    const int nEnvs = e->cfg.n_envs > 1 ? e->cfg.n_envs : 1;
+    if (n % nEnvs != 0) return e->fail("cfx_lane_change_supply: n must be a multiple of cfx_config::n_envs"), CFX_ERR_INVALID;
+    e->lc.poolPerEnv = n / nEnvs;
     if (n > e->lc.insCap || !e->hPool) {  // (re)allocate pool, records and the landing buffer of the poll
         HIP_TRY(hipStreamSynchronize(e->stream));
         const size_t cap = std::max<size_t>((size_t) n, 1024);

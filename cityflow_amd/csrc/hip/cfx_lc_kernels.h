@@ -169,7 +169,10 @@ __global__ void k_lc_plan(StepCtx c) {
             if (i < kLcRoadCand) lc.roadCandList[(size_t) road * kLcRoadCand + i] = make_int2(vid, s);
         }
         const int at = waveListAppend(lc.candAllCount, isCand);
-        if (isCand) lc.candAll[at] = vid;
+        if (isCand) {
+            lc.candAll[at] = vid;
+            lc.candAllEnv[at] = c.n.laneRoad[d] / lc.roadsPerEnv;
+        }
     }
 }
 
@@ -194,11 +197,19 @@ __device__ inline int lcSortedPosition(int i, int n) {
 }
 
 // ... taken by the road's wave in k_lc_schedule: creation rank of `me` among the step's candidates, all 64 lanes counting
-__device__ __forceinline__ int lcWalkPosition(const LcDev &lc, int me, int nAll, int tid) {
-    int less = 0;
-    for (int i = tid; i < nAll; i += 64) less += lc.candAll[i] < me;
-    for (int off = 32; off > 0; off >>= 1) less += __shfl_down(less, off, 64);
-    return lcSortedPosition(__shfl(less, 0, 64), nAll);
+// (batched environments: every environment is an Engine of its own — rank and count among ITS candidates)
+__device__ __forceinline__ int lcWalkPosition(const LcDev &lc, int me, int env, int nAll, int tid) {
+    int less = 0, mine = 0;
+    for (int i = tid; i < nAll; i += 64) {
+        const bool same = lc.candAllEnv[i] == env;
+        mine += same;
+        less += same && lc.candAll[i] < me;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        less += __shfl_down(less, off, 64);
+        mine += __shfl_down(mine, off, 64);
+    }
+    return lcSortedPosition(__shfl(less, 0, 64), __shfl(mine, 0, 64));
 }
 
 // What the schedule walk knows about "a vehicle in the target lane": an existing one (slot) or a shadow inserted earlier
@@ -233,6 +244,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     const int road = blockIdx.x;
     if (road >= c.n.R) return;
     const LcDev &lc = c.lc;
+    const int env = road / lc.roadsPerEnv;
     const int nListed = lc.roadCand[road];
     if (nListed == 0) return;
     const int tid = threadIdx.x;
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     if (!tooMany) {
         for (int j = 0; j < nListed; ++j) {
             const int me = candVid[j];
-            const int key = lcWalkPosition(lc, me, nAll, tid);
+            const int key = lcWalkPosition(lc, me, env, nAll, tid);
             if (tid == 0) {
                 candKey[j] = key;
                 lc.candPos[me] = key;
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
         for (int q = s0; q < s1; ++q) {
             const int w = c.s.vid[q];
             if (w < 0 || lc.ptype[w] == 2 || !lcPlanChange(lc, w, c.s.drv[q])) continue;
-            const int key = lcWalkPosition(lc, w, nAll, tid);
+            const int key = lcWalkPosition(lc, w, env, nAll, tid);
             if (tid == 0) lc.candPos[w] = key;
         }
         __threadfence_block();
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                             if (insLane[j] == target && insAnchor[j] == anchor && insSeq[j] >= seq) seq = insSeq[j] + 1.0;
                     }
                     lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid], anchor, mySeg, seq};
-                    lc.insKey[idx] = myKey;  // shadows are created, and numbered, in walk order (k_lc_insert)
+                    lc.insKey[idx] = (env << kLcEnvShift) + myKey;  // shadows are created, and numbered, in walk order (k_lc_insert)
                     // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
                     // later candidate of this walk that copies itself (its own shadow) copies this gap too
                     if (follower.vid >= 0) lc.gap[follower.vid] = dis - myLen - follower.dis;
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevSca
                                                   int32_t *pollOut /*pinned: [0] count, [1] overflow code of the walk, [2..] parents*/,
                                                   int32_t *oldToNew, int32_t *segStartNow, int32_t *cntNow_, int slotCap) {
     const LcDev &lc = c.lc;
-    __shared__ int sRec[kLcRoadInserts], sAnchor[kLcRoadInserts], sVid[kLcRoadInserts];
+    __shared__ int sRec[kLcRoadInserts], sAnchor[kLcRoadInserts], sVid[kLcRoadInserts], sPool[kLcRoadInserts];
     __shared__ double sSeq[kLcRoadInserts];
     __shared__ int sM, sBase;
     const int nLanes = *lc.insLaneCount;
@@ -557,12 +569,20 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevSca
     const int tid = threadIdx.x;
     const int D = c.n.L + c.n.K;
     // creation rank of record `rec` among the step's shadows, counted by the whole wave
+    // (.x among all of them: the vehicle number; .y among its environment's: the priority it takes)
     auto rankOf = [&](int rec) {
         const int key = lc.insKey[rec];
-        int less = 0;
-        for (int j = tid; j < nIns; j += 64) less += lc.insKey[j] < key;
-        for (int off = 32; off > 0; off >>= 1) less += __shfl_down(less, off, 64);
-        return __shfl(less, 0, 64);
+        int less = 0, lessEnv = 0;
+        for (int j = tid; j < nIns; j += 64) {
+            const int kj = lc.insKey[j];
+            less += kj < key;
+            lessEnv += kj < key && (kj >> kLcEnvShift) == (key >> kLcEnvShift);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            less += __shfl_down(less, off, 64);
+            lessEnv += __shfl_down(lessEnv, off, 64);
+        }
+        return make_int2(__shfl(less, 0, 64), __shfl(lessEnv, 0, 64));
     };
     for (int w = blockIdx.x; w < nLanes; w += gridDim.x) {
         const int d = lc.insLanes[w];
@@ -593,8 +613,12 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevSca
             continue;
         }
         for (int q = 0; q < m; ++q) {
-            const int rank = rankOf(sRec[q]);
-            if (tid == 0) sVid[q] = lc.firstShadowVid + rank;
+            const int2 rank = rankOf(sRec[q]);
+            if (tid == 0) {
+                sVid[q] = lc.firstShadowVid + rank.x;
+                sPool[q] = rank.y < lc.poolPerEnv ? (lc.insKey[sRec[q]] >> kLcEnvShift) * lc.poolPerEnv + rank.y : -1;
+                if (sPool[q] < 0) sc->overflow = 5;  // an environment used up its share of the supplied priorities
+            }
         }
         __syncthreads();
         for (int k = tid; k < n; k += 64) {
@@ -628,7 +652,7 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevSca
             const LcInsert rec = lc.ins[r];
             const int p = rec.parentVid, ps = rec.parentSlot, v = sVid[tid], rank = v - lc.firstShadowVid;
             // the new vehicle (Engine::insertShadow, Vehicle copy constructor, setShadow / setParent)
-            vt.priority[v] = lc.pool[rank];
+            vt.priority[v] = sPool[tid] >= 0 ? lc.pool[sPool[tid]] : 0;
             vt.templ[v] = vt.templ[p];
             vt.route[v] = vt.route[p];
             vt.enterTime[v] = vt.enterTime[p];

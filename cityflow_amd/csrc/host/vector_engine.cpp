@@ -17,6 +17,8 @@ struct ReplicatedNet {
     std::vector<int32_t> laneRoad, laneIndex, laneLLStart, laneLL, roadLaneStart, llStartLane, llEndLane, llInter,
         llRoadLink, llType, llXStart, xPeer, xLL, interVirtual, interNRL, interPhaseStart, interAvailStart;
     std::vector<uint8_t> phaseAvail;
+    std::vector<double> laneWidth;          // lane change only
+    std::vector<int32_t> laneNSegments;
 
     void build(const cfx_net &n, int R) {
         const int L = n.n_lanes, K = n.n_lanelinks, Rd = n.n_roads, I = n.n_inters, E = n.n_xentries, P = n.n_phases,
@@ -103,6 +105,13 @@ struct ReplicatedNet {
         flat.inter_avail_start = interAvailStart.data();
         flat.phase_time = phaseTime.data();
         flat.phase_avail = phaseAvail.data();
+        if (n.lane_width && n.lane_n_segments) {  // lane change
+            laneWidth.resize((size_t) L * R);
+            for (int r = 0; r < R; ++r) std::copy(n.lane_width, n.lane_width + L, laneWidth.begin() + (size_t) r * L);
+            rep(laneNSegments, n.lane_n_segments, L, 0);
+            flat.lane_width = laneWidth.data();
+            flat.lane_n_segments = laneNSegments.data();
+        }
     }
 };
 
@@ -112,7 +121,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     : R_(numEnvs) {
     if (numEnvs < 1) throw std::runtime_error("VectorEngine: num_envs must be >= 1");
     EngineConfig cfg = readEngineConfig(configFile);
-    if (cfg.laneChange) throw std::runtime_error("VectorEngine: laneChange=true is not implemented for batched environments (single Engine only)");
+    laneChange_ = cfg.laneChange;
     interval_ = cfg.interval;
     rlTrafficLight_ = cfg.rlTrafficLight;
     hostThreads_ = cfg.hostThreads;
@@ -121,6 +130,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
         for (int r = 0; r < R_; ++r) {
             spawners_.emplace_back(new Spawner());
             spawners_.back()->init(net_.get(), interval_, threadNum, cfg.seed + r);
+            spawners_.back()->exactPeekOnly = cfg.exactShadowPeek;
             spawners_.back()->loadFlows(cfg.dir + cfg.flowFile);
         }
     } catch (const std::exception &e) {
@@ -136,6 +146,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
     cfx_config cc{};
     cfg.apply(cc);
+    cc.n_envs = R_;  // (lane change: every environment has its own schedule walk and priority stream)
     int32_t rc = be_.cfx_create(&rn.flat, &cc, &dev_);
     if (rc != CFX_OK || !dev_) {
         const char *msg = be_.cfx_last_error(nullptr);
@@ -295,11 +306,49 @@ void VectorEngineHost::check(int32_t rc, const char *what) {
     throw std::runtime_error(std::string("cityflow_amd: ") + what + " failed (" + std::to_string(rc) + "): " + (msg ? msg : ""));
 }
 
+// Lane change: which vehicles got a shadow in the last step (EngineHost::settleLaneChange for R environments).  The device lists
+// the parents environment by environment, each environment's in the order of its own schedule walk; shadow i of the list has
+// the global number (vehicles before the step's batch) + (the batch) + i, and each spawner numbers ITS shadows in that order.
+void VectorEngineHost::settleLaneChange() {
+    if (!lcPollPending_) return;
+    lcPollPending_ = false;
+    shadowParents_.resize((size_t) shadowPoolPerEnv_ * R_);
+    int32_t k = 0;
+    check(be_.cfx_lane_change_poll(dev_, (int32_t) shadowParents_.size(), shadowParents_.data(), &k), "cfx_lane_change_poll");
+    std::vector<std::vector<int32_t>> perEnv((size_t) R_);
+    int lastEnv = 0;
+    for (int i = 0; i < k; ++i) {
+        const auto gl = globalToLocal_.at((size_t) shadowParents_[(size_t) i]);
+        if (gl.first < lastEnv) throw std::runtime_error("VectorEngine: lane-change poll is not in environment order");
+        lastEnv = gl.first;
+        Spawner &sp = *spawners_[(size_t) gl.first];
+        const int32_t localShadow = (int32_t) (sp.vehicles.size() + perEnv[(size_t) gl.first].size());
+        perEnv[(size_t) gl.first].push_back(gl.second);
+        const int32_t globalShadow = (int32_t) globalToLocal_.size();
+        globalToLocal_.emplace_back(gl.first, localShadow);
+        localToGlobal_[(size_t) gl.first].push_back(globalShadow);
+    }
+    int most = 0;
+    for (int r = 0; r < R_; ++r) {
+        spawners_[(size_t) r]->commitShadows(perEnv[(size_t) r]);
+        most = std::max(most, (int) perEnv[(size_t) r].size());
+    }
+    if (4 * most > shadowPoolPerEnv_) shadowPoolPerEnv_ = 8 * most;  // stay well clear of a step's demand
+}
+
+// an environment's share of the priorities this step's shadows would draw, after the step's own spawn draws
+void VectorEngineHost::peekEnv(int r) {
+    std::vector<int32_t> &tmp = envPeek_[(size_t) r];
+    spawners_[(size_t) r]->peekShadowPriorities(shadowPoolPerEnv_, tmp);
+    std::copy(tmp.begin(), tmp.end(), shadowPool_.begin() + (size_t) r * shadowPoolPerEnv_);
+}
+
 void VectorEngineHost::nextStep() {
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     envRecs_.resize((size_t) R_);
     envBase_.resize((size_t) R_);
+    settleLaneChange();  // every generator must be past the last step's shadow draws before this step's spawns
     forEachEnv(&VectorEngineHost::spawnEnv);
     const auto t1 = clk::now();
     int32_t total = 0;
@@ -314,8 +363,15 @@ void VectorEngineHost::nextStep() {
     globalToLocal_.resize(globalToLocal_.size() + (size_t) total);
     recs_.resize((size_t) total);
     forEachEnv(&VectorEngineHost::translateEnv);
+    if (laneChange_) {
+        shadowPool_.resize((size_t) shadowPoolPerEnv_ * R_);
+        envPeek_.resize((size_t) R_);
+        forEachEnv(&VectorEngineHost::peekEnv);
+        check(be_.cfx_lane_change_supply(dev_, (int32_t) shadowPool_.size(), shadowPool_.data()), "cfx_lane_change_supply");
+    }
     const auto t2 = clk::now();
     check(be_.cfx_step(dev_, recs_.data(), (int32_t) recs_.size()), "cfx_step");
+    lcPollPending_ = laneChange_;
     const auto t3 = clk::now();
     hostSpawnSec_ += std::chrono::duration<double>(t1 - t0).count();
     hostTranslateSec_ += std::chrono::duration<double>(t2 - t1).count();
@@ -324,6 +380,7 @@ void VectorEngineHost::nextStep() {
 }
 
 void VectorEngineHost::reset(bool resetRnd) {
+    settleLaneChange();  // (without a reseed the generators go on from behind the last step's shadow draws)
     check(be_.cfx_reset(dev_), "cfx_reset");
     for (auto &sp : spawners_) sp->reset(resetRnd);
     for (auto &v : localToGlobal_) v.clear();
@@ -408,18 +465,22 @@ std::map<std::string, int> VectorEngineHost::getLaneVehicleCount(int env) {
 
 std::map<std::string, double> VectorEngineHost::getVehicleSpeed(int env) {
     if (env < 0 || env >= R_) throw std::out_of_range("env index out of range");
+    settleLaneChange();  // (the shadows of the last step have their numbers then)
     int cap = (int) scalars().active_vehicle_count + 16;
     std::vector<int32_t> vid(cap), drv(cap);
     std::vector<double> speed(cap);
+    std::vector<uint8_t> lcFlags(laneChange_ ? cap : 0);
     cfx_vehicle_view v{};
     v.capacity = cap;
     v.vid = vid.data();
     v.drivable = drv.data();
     v.speed = speed.data();
+    if (laneChange_) v.lc_flags = lcFlags.data();
     check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
     std::map<std::string, double> ret;
     for (int i = 0; i < v.count; ++i) {
         const auto &gl = globalToLocal_[vid[i]];
+        if (laneChange_ && (lcFlags[i] & CFX_LC_SHADOW)) continue;  // Engine::getRunningVehicles lists real vehicles only
         if (gl.first == env) ret.emplace(spawners_[env]->vehicleId(gl.second), speed[i]);
     }
     return ret;

@@ -4,7 +4,8 @@
 // once per environment, and the car-following kernel finally gets enough vehicles per launch to approach the
 // HBM roofline.  Each environment has its own flows and its own std::mt19937 (seed + env index)
 // and evolves exactly like a standalone Engine built from the same config with that seed
-// (tests/test_vector_engine.py).
+// (tests/test_vector_engine.py) — with laneChange: true as well: the device takes each environment's lane-change
+// schedule walk and priority stream separately (cfx_config::n_envs).
 #pragma once
 
 #include <atomic>
@@ -75,6 +76,13 @@ private:
     void forEachEnv(void (VectorEngineHost::*fn)(int));  // fn(env) for every environment, on the pool from 32 envs on
     void spawnEnv(int r);
     void translateEnv(int r);
+    void peekEnv(int r);
+    // lane change (laneChange: true): as EngineHost, per environment (include/cityflow_amd.h "Lane change", n_envs)
+    void settleLaneChange();
+    bool laneChange_ = false, lcPollPending_ = false;
+    int shadowPoolPerEnv_ = 256;
+    std::vector<int32_t> shadowPool_, shadowParents_;
+    std::vector<std::vector<int32_t>> envPeek_;
     void workerLoop();
     void runEnvs();
     void (VectorEngineHost::*poolFn_)(int) = nullptr;

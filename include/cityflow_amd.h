@@ -109,6 +109,11 @@ typedef struct cfx_config {
                                   * as a launch of its own.  Results never depend on it (tests/test_parity_pins.py) */
     int32_t ring_capacity_percent; /* ring layout: initial ring capacities as a percentage of the bumper-to-bumper bound
                                     * (0 = 100).  Small values make the growth path run (tests); results never depend on it */
+    int32_t n_envs;           /* 0 or 1: one simulation.  E > 1: the network is E disjoint copies of one network with their
+                               * index spaces concatenated copy by copy (roads, lanes, laneLinks, intersections: n_roads etc. are
+                               * multiples of E) — E independent simulations advanced by one engine (batched environments).  Only
+                               * lane change needs to know: each environment has its own schedule walk and its own priority
+                               * stream (see "Lane change" below) */
 } cfx_config;
 #define CFX_CROSS_AUTO 0
 #define CFX_CROSS_LATENCY 1
@@ -303,7 +308,11 @@ int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out);
  * libstdc++'s introsort permutes more than 16 equal elements.  This ABI fixes the walk to: candidates in creation order
  * (ascending vid = the address order of a heap that never reuses memory), put through that very permutation (a closed
  * function of the candidate count; `lcSortedPosition`, csrc/hip/cfx_lc_kernels.h).  Shadows are numbered, and take the
- * supplied priorities, in walk order.  More than n shadows in one step: CFX_ERR_CAPACITY from the poll. */
+ * supplied priorities, in walk order.  More than n shadows in one step: CFX_ERR_CAPACITY from the poll.
+ * Batched environments (cfx_config::n_envs = E > 1): every environment is its own Engine in the reference, so the walk above is
+ * taken per environment (its candidates in ascending vid, put through the permutation of ITS candidate count), the
+ * environments one after the other; n must be a multiple of E and environment e takes its priorities from
+ * priorities[e * n / E ...]; the poll lists the parents environment by environment, shadows are numbered in that order. */
 int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *priorities);
 int32_t cfx_lane_change_poll(cfx_engine *e, int32_t capacity, int32_t *parent_vid, int32_t *n);
 

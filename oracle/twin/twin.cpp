@@ -476,8 +476,17 @@ struct cfx_engine {
     }
     // Engine::insertShadow engine.cpp:812-820 + Vehicle copy constructor vehicle.cpp:28-36 + LaneChange::insertShadow
     // lanechange.cpp:71-102
+    // batched environments (cfx_config::n_envs): the environment a lane belongs to, and each one's share of the supplied priorities
+    int nEnvs() const { return cfg.n_envs > 1 ? cfg.n_envs : 1; }
+    int envOfLane(int d) const {  // (a drivable: a laneLink belongs where its start lane does)
+        if (nEnvs() == 1) return 0;
+        return net.laneRoad[d < net.L ? d : net.llStartLane[d - net.L]] / (net.R / nEnvs());
+    }
+    std::vector<int> shadowsOfEnv;
     void insertShadow(int pv) {
-        if (shadowParents.size() >= shadowPool.size()) {
+        const int env = envOfLane(veh[pv].drivable);
+        const size_t perEnv = shadowPool.size() / (size_t) nEnvs();
+        if ((size_t) shadowsOfEnv[env] >= perEnv) {
             shadowOverflow = true;
             return;
         }
@@ -487,7 +496,7 @@ struct cfx_engine {
             veh.push_back(copy);
         }
         Veh &p = veh[pv], &s = veh[sv];
-        s.priority = shadowPool[shadowParents.size()];
+        s.priority = shadowPool[(size_t) env * perEnv + (size_t) shadowsOfEnv[env]++];
         shadowParents.push_back(pv);
         s.sigSend = false;
         s.sendTarget = -1;
@@ -538,8 +547,20 @@ struct cfx_engine {
         // 16 candidates libstdc++'s introsort permutes them (a closed function of the count, see lcSortedPosition in
         // cityflow_amd/csrc/hip/cfx_lc_kernels.h).  The same call on the same sequence gives the same permutation; the ABI
         // defines the walk order as exactly this.
-        std::sort(buffer.begin(), buffer.end(),
-                  [this](int32_t a, int32_t b) { return veh[a].sendUrgency > veh[b].sendUrgency; });
+        // Batched environments: each is an Engine of its own in the reference — its candidates, its sort, its walk; the
+        // environments one after the other (include/cityflow_amd.h "Lane change").
+        shadowsOfEnv.assign((size_t) nEnvs(), 0);
+        if (nEnvs() > 1) {
+            std::stable_sort(buffer.begin(), buffer.end(),
+                             [this](int32_t a, int32_t b) { return envOfLane(veh[a].drivable) < envOfLane(veh[b].drivable); });
+        }
+        for (size_t lo = 0; lo < buffer.size();) {
+            size_t hi = lo;
+            while (hi < buffer.size() && envOfLane(veh[buffer[hi]].drivable) == envOfLane(veh[buffer[lo]].drivable)) ++hi;
+            std::sort(buffer.begin() + lo, buffer.begin() + hi,
+                      [this](int32_t a, int32_t b) { return veh[a].sendUrgency > veh[b].sendUrgency; });
+            lo = hi;
+        }
         veh.reserve(veh.size() + buffer.size());  // references stay valid across insertShadow
         for (int32_t vid : buffer) {
             Veh &v = veh[vid];

@@ -6,8 +6,11 @@ import pytest
 from conftest import TWIN_LIB
 
 
-def _check(mod, scen, workdir, make_vec, make_single, name="example_1x1", envs=3, steps=150, rl=False):
+def _check(mod, scen, workdir, make_vec, make_single, name="example_1x1", envs=3, steps=150, rl=False, lane_change=False,
+           every=10):
     kw = {"rlTrafficLight": True} if rl else {}
+    if lane_change:
+        kw["laneChange"] = True
     vec = make_vec(scen.materialize(name, workdir, **kw), envs)
     singles = [make_single(scen.materialize(name, workdir, seed=e, **kw)) for e in range(envs)]
     inter_ids = vec.intersection_ids()
@@ -26,7 +29,7 @@ def _check(mod, scen, workdir, make_vec, make_single, name="example_1x1", envs=3
         vec.next_step()
         for e in singles:
             e.next_step()
-        if s % 10 == 9:
+        if s % every == every - 1:
             counts = vec.get_lane_vehicle_count_array()
             waits = vec.get_lane_waiting_vehicle_count_array()
             assert counts.shape == (envs, len(vec.lane_ids()))
@@ -78,6 +81,36 @@ def test_vector_engine_explicit_host_threads_twin(mod, scen, workdir):
         assert vec.get_vehicle_speed(e) == ser.get_vehicle_speed(e)
 
 
+def test_vector_engine_lane_change_twin(mod, scen, workdir):
+    """laneChange: true in batched environments: every environment's lane-change schedule walk (candidates in creation order
+    through std::sort's permutation of ITS candidate count) and shadow priorities (ITS generator) are its own
+    (cfx_config::n_envs; reference engine.cpp:374-400,792-820 per Engine) — each environment equals the standalone engine with
+    its seed after every step, shadows alive and changes completing all along."""
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine._with_backend(c, n, 1, TWIN_LIB),
+           lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), envs=3, steps=200, lane_change=True, every=1)
+
+
+def test_vector_engine_lane_change_grid_twin(mod, scen, workdir):
+    """(the 6x6 grid, where lanes fill up from step ~370 on and vehicles start to change)"""
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine._with_backend(c, n, 1, TWIN_LIB),
+           lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), name="grid_6x6", envs=2, steps=470, lane_change=True, every=5)
+
+
+def test_vector_engine_lane_change_reset_twin(mod, scen, workdir):
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True)
+    vec = mod.VectorEngine._with_backend(cfg, 2, 1, TWIN_LIB)
+    for _ in range(80):
+        vec.next_step()
+    a = vec.get_lane_vehicle_count_array().copy()
+    sp = [vec.get_vehicle_speed(e) for e in range(2)]
+    vec.reset(True)
+    assert vec.get_vehicle_count() == 0
+    for _ in range(80):
+        vec.next_step()
+    assert np.array_equal(a, vec.get_lane_vehicle_count_array())
+    assert sp == [vec.get_vehicle_speed(e) for e in range(2)]
+
+
 def test_vector_engine_reset(mod, scen, workdir):
     vec = mod.VectorEngine._with_backend(scen.materialize("example_1x1", workdir), 2, 1, TWIN_LIB)
     for _ in range(60):
@@ -100,6 +133,22 @@ def test_vector_engine_hip(mod, scen, workdir):
 def test_vector_engine_hip_rl(mod, scen, workdir):
     _check(mod, scen, workdir, lambda c, n: mod.VectorEngine(c, n, 1), lambda c: mod.Engine(c, 1), name="grid_6x6",
            envs=3, steps=80, rl=True)
+
+
+@pytest.mark.gpu
+def test_vector_engine_lane_change_hip(mod, scen, workdir):
+    """laneChange: true, 4 batched 6x6 environments on the HIP engine == 4 standalone HIP engines (which
+    tests/test_lane_change.py pins to the twin and the reference) after every 5th step, and == the batched twin."""
+    _check(mod, scen, workdir, lambda c, n: mod.VectorEngine(c, n, 1), lambda c: mod.Engine(c, 1), name="grid_6x6",
+           envs=3, steps=470, lane_change=True, every=5)
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True)
+    hip, twin = mod.VectorEngine(cfg, 5, 1), mod.VectorEngine._with_backend(cfg, 5, 1, TWIN_LIB)
+    for s in range(200):
+        hip.next_step()
+        twin.next_step()
+        assert np.array_equal(hip.get_lane_vehicle_count_array(), twin.get_lane_vehicle_count_array()), s
+    for e in range(5):
+        assert hip.get_vehicle_speed(e) == twin.get_vehicle_speed(e)
 
 
 @pytest.mark.gpu
