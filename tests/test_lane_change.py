@@ -113,11 +113,10 @@ def test_lane_change_api_surface(mod, scen, workdir):
     assert sorted(v for lane in eng.get_lane_vehicles().values() for v in lane if v.endswith("_shadow")) == sorted(shadows)
 
 
-def test_batched_and_tiled_engines_refuse_lane_change(mod, scen, workdir):
-    """Lane change is built for the single engine; the batched and the tiled hosts must say so, not ignore the flag."""
+def test_tiled_engine_refuses_lane_change(mod, scen, workdir):
+    """Lane change is built for the single engine and for batched environments (tests/test_vector_engine.py); the tiled host
+    must say that it is not, and not ignore the flag (the schedule walk is ONE order over the candidates of all tiles)."""
     cfg = scen.materialize("example_1x1", workdir, laneChange=True)
-    with pytest.raises(RuntimeError, match="laneChange"):
-        mod.VectorEngine._with_backend(cfg, 2, 1, TWIN_LIB)
     with pytest.raises(RuntimeError, match="laneChange"):
         mod.TiledEngine(cfg, 1, 2, [], TWIN_LIB)
 
