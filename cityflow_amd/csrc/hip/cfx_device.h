@@ -136,6 +136,45 @@ struct LcDev {
 };
 constexpr int kLcEnvShift = 20;
 
+// Lane::history (roadnet.h:305-316) with cfx_config::lane_history: per lane a ring of kLaneHistoryMax {vehicle count, mean
+// speed} records — stored record-major, [record][lane], so that the lanes' threads, which all write the same record number in a
+// step, write adjacent words — and the two running aggregates.
+constexpr int kLaneHistoryMax = CFX_LANE_HISTORY_MAX;
+struct LaneHistDev {
+    int32_t *num;    // [kLaneHistoryMax * L]
+    double *avg;     // [kLaneHistoryMax * L]
+    int32_t *head;   // [L] index of the oldest record
+    int32_t *len;    // [L]
+    int32_t *hNum;   // [L] Lane::historyVehicleNum
+    double *hAvg;    // [L] Lane::historyAverageSpeed
+    int L;
+};
+// Lane::updateHistory roadnet.cpp:900-915, expression for expression (the speeds summed in the lane's list order)
+template <class SpeedAt>
+__device__ inline void laneHistoryStep(const LaneHistDev &h, int lane, int n, SpeedAt speedAt) {
+    int head = h.head[lane], len = h.len[lane], hn = h.hNum[lane];
+    double speedSum = hn * h.hAvg[lane];
+    while (len > 240) {
+        const int fn = h.num[(size_t) head * h.L + lane];
+        hn -= fn;
+        speedSum -= fn * h.avg[(size_t) head * h.L + lane];
+        head = head + 1 == kLaneHistoryMax ? 0 : head + 1;
+        --len;
+    }
+    double curSpeedSum = 0;
+    hn += n;
+    for (int i = 0; i < n; ++i) curSpeedSum += speedAt(i);
+    speedSum += curSpeedSum;
+    int tail = head + len;
+    if (tail >= kLaneHistoryMax) tail -= kLaneHistoryMax;
+    h.num[(size_t) tail * h.L + lane] = n;
+    h.avg[(size_t) tail * h.L + lane] = n ? curSpeedSum / n : 0;
+    h.head[lane] = head;
+    h.len[lane] = len + 1;
+    h.hNum[lane] = hn;
+    h.hAvg[lane] = hn ? speedSum / hn : 0;
+}
+
 // The last vehicle of a drivable, kept as ONE 32-byte record so that its readers — the leader search of every head of a
 // drivable, Lane::canEnter, the admission check, the notify sources — do one load instead of a chain through
 // {ring geometry, head, count} -> slot -> {dis, speed, template}.  `tag` is the step the record was written in: a record is

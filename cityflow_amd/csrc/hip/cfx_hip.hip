@@ -76,6 +76,7 @@ struct cfx_engine {
 
     // ---- vehicle table ----
     VidTable vt{};
+    LaneHistDev hist{};                // Lane::history, with cfx_config::lane_history (not on tiles)
     size_t vidCap = 0;
     int64_t spawned = 0;
 
@@ -917,6 +918,23 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if ((rc = e->allocRaw(&e->scanTicket, 1))) return rc;
     if ((rc = e->allocRaw(&e->jobCount, (size_t) kJobShards * kJobShardStride))) return rc;
     if ((rc = e->allocRaw(&e->sc, 1))) return rc;
+    if (cfg->lane_history) {
+        LaneHistDev &h = e->hist;
+        const size_t nL = (size_t) std::max(e->L, 1);
+        h.L = e->L;
+        if ((rc = e->allocRaw(&h.num, nL * kLaneHistoryMax))) return rc;
+        if ((rc = e->allocRaw(&h.avg, nL * kLaneHistoryMax))) return rc;
+        if ((rc = e->allocRaw(&h.head, nL))) return rc;
+        if ((rc = e->allocRaw(&h.len, nL))) return rc;
+        if ((rc = e->allocRaw(&h.hNum, nL))) return rc;
+        if ((rc = e->allocRaw(&h.hAvg, nL))) return rc;
+        HIP_TRY(hipMemset(h.num, 0, nL * kLaneHistoryMax * sizeof(int32_t)));
+        HIP_TRY(hipMemset(h.avg, 0, nL * kLaneHistoryMax * sizeof(double)));
+        HIP_TRY(hipMemset(h.head, 0, nL * sizeof(int32_t)));
+        HIP_TRY(hipMemset(h.len, 0, nL * sizeof(int32_t)));
+        HIP_TRY(hipMemset(h.hNum, 0, nL * sizeof(int32_t)));
+        HIP_TRY(hipMemset(h.hAvg, 0, nL * sizeof(double)));
+    }
     if (cfg->lane_change) {
         LcDev &lc = e->lc;
         lc.on = 1;
@@ -1148,7 +1166,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;  // which form of the cross phase (§4)
         // This step's commit rides with the next step's admission (one launch less per step) where the step runs kr_cross,
         // which then advances the lights; the previous step's, if it is still pending, goes with this step's admission.
-        const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing;  // (a caller that reads the lane counts after every step wants the commit now)
+        const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing && !e->hist.num;  // (a caller that reads the lane counts after every step wants the commit now)
         if (e->commitPending) {
             e->commitPending = false;
             int nStatPrev = 1;
@@ -1256,6 +1274,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->rcur ^= 1;
         e->step += 1;
         e->mirrorValid = !e->tiled;
+        if (e->hist.num && !e->tiled) {  // Lane::updateHistory, on the committed state
+            hipLaunchKernelGGL(kr_lane_history, dim3(gridFor(e->L)), dim3(kBlock), 0, st, e->rctx(), e->hist);
+            HIP_TRY(hipGetLastError());
+        }
         return CFX_OK;
     }
     const int64_t spare = e->tiled ? e->spareTotal : (int64_t) e->L;
@@ -1334,6 +1356,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->pollPending = true;
         HIP_TRY(hipGetLastError());
         c.admissionsVisible = 1;
+        // the leader / gap pass between planLaneChange and getAction takes a history record too (engine.cpp:571-575, 429-442);
+        // k_lc_insert has moved the lanes that got shadows: the context is taken anew
+        if (e->hist.num && !e->tiled) hipLaunchKernelGGL(k_lane_history, dim3(gridFor(e->L)), dim3(kBlock), 0, st, e->ctx(), e->hist);
     }
     const int nxt = e->cur ^ 1;
     // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
@@ -1379,6 +1404,64 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     e->cur = nxt;
     e->step += 1;
     e->mirrorValid = !e->tiled;
+    if (e->hist.num && !e->tiled) {  // Lane::updateHistory, on the committed state
+        hipLaunchKernelGGL(k_lane_history, dim3(gridFor(e->L)), dim3(kBlock), 0, st, e->ctx(), e->hist);
+        HIP_TRY(hipGetLastError());
+    }
+    return CFX_OK;
+}
+
+// Lane::history as the ABI shows it: lane-major, oldest record first (the device keeps a ring per lane, record-major)
+int32_t cfx_get_lane_history(cfx_engine *e, cfx_lane_history *out) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    if (!e->hist.num) return e->fail("cfx_get_lane_history: the engine was created without cfx_config::lane_history"), CFX_ERR_STATE;
+    if (out->n_lanes != e->L) return e->fail("cfx_get_lane_history: n_lanes"), CFX_ERR_INVALID;
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;
+    const size_t L = (size_t) e->L, M = (size_t) kLaneHistoryMax;
+    std::vector<int32_t> num(M * L), head(L);
+    std::vector<double> avg(M * L);
+    HIP_TRY(hipMemcpyAsync(num.data(), e->hist.num, M * L * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(avg.data(), e->hist.avg, M * L * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(head.data(), e->hist.head, L * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out->len, e->hist.len, L * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out->history_vehicle_num, e->hist.hNum, L * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out->history_average_speed, e->hist.hAvg, L * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (size_t l = 0; l < L; ++l)
+        for (int i = 0; i < out->len[l]; ++i) {
+            const size_t r = ((size_t) head[l] + (size_t) i) % M;
+            out->vehicle_num[l * M + (size_t) i] = num[r * L + l];
+            out->average_speed[l * M + (size_t) i] = avg[r * L + l];
+        }
+    return CFX_OK;
+}
+
+int32_t cfx_set_lane_history(cfx_engine *e, const cfx_lane_history *in) {
+    if (!e || !in) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    if (!e->hist.num) return e->fail("cfx_set_lane_history: the engine was created without cfx_config::lane_history"), CFX_ERR_STATE;
+    if (in->n_lanes != e->L) return e->fail("cfx_set_lane_history: n_lanes"), CFX_ERR_INVALID;
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rcSettle = e->settle()) return rcSettle;
+    const size_t L = (size_t) e->L, M = (size_t) kLaneHistoryMax;
+    std::vector<int32_t> num(M * L, 0), head(L, 0);
+    std::vector<double> avg(M * L, 0.0);
+    for (size_t l = 0; l < L; ++l) {
+        if (in->len[l] < 0 || in->len[l] > kLaneHistoryMax) return e->fail("cfx_set_lane_history: len out of range"), CFX_ERR_INVALID;
+        for (int i = 0; i < in->len[l]; ++i) {
+            num[(size_t) i * L + l] = in->vehicle_num[l * M + (size_t) i];
+            avg[(size_t) i * L + l] = in->average_speed[l * M + (size_t) i];
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(e->hist.num, num.data(), M * L * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->hist.avg, avg.data(), M * L * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->hist.head, head.data(), L * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->hist.len, in->len, L * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->hist.hNum, in->history_vehicle_num, L * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->hist.hAvg, in->history_average_speed, L * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return CFX_OK;
 }
 

@@ -2042,6 +2042,16 @@ __global__ void k_leader_view(StepCtx c, int32_t *leaderSlot, double *gapOut) {
     }
 }
 
+// Lane::updateHistory for every lane, as a part of Engine::threadUpdateLeaderAndGap (engine.cpp:429-442): at the end of a step,
+// and with lane change also between planLaneChange and getAction (engine.cpp:571-575) — the lane lists then hold this step's
+// admissions and shadows already (cntNow)
+__global__ void k_lane_history(StepCtx c, LaneHistDev h) {
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= c.n.L) return;
+    const int base = c.segStart[lane];
+    laneHistoryStep(h, lane, cntNow(c, lane), [&](int i) { return c.s.speed[base + i]; });
+}
+
 __global__ void k_lane_waiting(StepCtx c, int32_t *out) {  // Engine::getLaneWaitingVehicleCount engine.cpp:636-648
     int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= c.n.L) return;

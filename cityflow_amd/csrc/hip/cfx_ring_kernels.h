@@ -1711,6 +1711,14 @@ __global__ void kr_reset(int D, int32_t *head, int32_t *cnt, int4 *scratch) {
     scratch[d] = make_int4(0, -1, -1, 0);
 }
 
+__global__ void kr_lane_history(RingCtx c, LaneHistDev h) {  // k_lane_history of cfx_kernels.h on the rings, after the commit
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= c.n.L) return;
+    const int2 geo = c.ringGeo[lane];
+    const int head = c.head[lane];
+    laneHistoryStep(h, lane, c.cnt[lane], [&](int i) { return c.kin[ringSlot(geo, head, i)].y; });
+}
+
 __global__ void kr_lane_waiting(RingCtx c, int32_t *out) {  // Engine::getLaneWaitingVehicleCount engine.cpp:636-648
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= c.n.L) return;

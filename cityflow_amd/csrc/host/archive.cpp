@@ -307,10 +307,20 @@ void Archive::dump(const std::string &path) const {
                     str(o, vehicleId(perLaneWait[d][i]));
                 }
                 o += "],";
-                // Lane history feeds only the never-selected RouterType::DURATION
-                key(o, "history"); o += "[],";
-                key(o, "historyVehicleNum"); o += "0,";
-                key(o, "historyAverageSpeed"); o += "0.0";
+                // Lane::history (archive.cpp:286-294): {vehicle count, mean speed} pairs, flat.  It feeds only the never-selected
+                // RouterType::DURATION and is kept only with "cfx": {"laneHistory": true}; empty otherwise
+                key(o, "history");
+                o += '[';
+                const bool have = (int) dev.hLen.size() == L;
+                for (int i = 0; have && i < dev.hLen[d]; ++i) {
+                    if (i) o += ',';
+                    o += std::to_string(dev.hVehicleNum[(size_t) d * CFX_LANE_HISTORY_MAX + i]);
+                    o += ',';
+                    num(o, dev.hAverageSpeed[(size_t) d * CFX_LANE_HISTORY_MAX + i]);
+                }
+                o += "],";
+                key(o, "historyVehicleNum"); o += std::to_string(have ? dev.hHistoryVehicleNum[d] : 0); o += ',';
+                key(o, "historyAverageSpeed"); num(o, have ? dev.hHistoryAverageSpeed[d] : 0.0);
             }
             o += '}';
         }
@@ -367,6 +377,17 @@ Archive EngineHost::snapshot() {
     int nV = (int) spawner_.vehicles.size();
     d.vState.resize(nV);
     if (nV) check(be_.cfx_get_vehicle_status(dev_, 0, nV, d.vState.data()), "cfx_get_vehicle_status");
+    if (laneHistory_) {
+        const size_t nL = net_->lanes.size();
+        d.hLen.resize(nL);
+        d.hVehicleNum.assign(nL * CFX_LANE_HISTORY_MAX, 0);
+        d.hAverageSpeed.assign(nL * CFX_LANE_HISTORY_MAX, 0.0);
+        d.hHistoryVehicleNum.resize(nL);
+        d.hHistoryAverageSpeed.resize(nL);
+        cfx_lane_history h{(int32_t) nL, d.hLen.data(), d.hVehicleNum.data(), d.hAverageSpeed.data(), d.hHistoryVehicleNum.data(),
+                           d.hHistoryAverageSpeed.data()};
+        check(be_.cfx_get_lane_history(dev_, &h), "cfx_get_lane_history");
+    }
     VehicleSnapshot s;
     snapshotVehicles(s);
     d.rVid = s.vid;
@@ -455,6 +476,12 @@ void EngineHost::load(const Archive &a) {
     st.tl_phase = d.tlPhase.data();
     st.tl_remain = d.tlRemain.data();
     check(be_.cfx_load_state(dev_, &st), "cfx_load_state");
+    if (laneHistory_ && d.hLen.size() == net_->lanes.size()) {  // Archive::resume archive.cpp:107-109 (an archive without it: as it is)
+        cfx_lane_history h{(int32_t) d.hLen.size(), const_cast<int32_t *>(d.hLen.data()), const_cast<int32_t *>(d.hVehicleNum.data()),
+                           const_cast<double *>(d.hAverageSpeed.data()), const_cast<int32_t *>(d.hHistoryVehicleNum.data()),
+                           const_cast<double *>(d.hHistoryAverageSpeed.data())};
+        check(be_.cfx_set_lane_history(dev_, &h), "cfx_set_lane_history");
+    }
     step_ = (size_t) d.step;
     vehicleEpoch_ += 1;  // vehicle numbers of the archive replace the current ones
 }
@@ -630,6 +657,25 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
                 d.wLane.push_back(dv);
                 a.host.lastWaitVid[dv] = vid;
             }
+            // archive.cpp:508-521 (records beyond what the list can hold cannot have been written by either engine)
+            if (d.hLen.empty()) {
+                d.hLen.assign((size_t) L, 0);
+                d.hVehicleNum.assign((size_t) L * CFX_LANE_HISTORY_MAX, 0);
+                d.hAverageSpeed.assign((size_t) L * CFX_LANE_HISTORY_MAX, 0.0);
+                d.hHistoryVehicleNum.assign((size_t) L, 0);
+                d.hHistoryAverageSpeed.assign((size_t) L, 0.0);
+            }
+            const Json *jh = jd.find("history");
+            if (jh && jh->isArray()) {
+                const size_t pairs = std::min<size_t>(jh->items.size() / 2, CFX_LANE_HISTORY_MAX);
+                for (size_t i = 0; i < pairs; ++i) {
+                    d.hVehicleNum[(size_t) dv * CFX_LANE_HISTORY_MAX + i] = (int32_t) jh->items[2 * i].i;
+                    d.hAverageSpeed[(size_t) dv * CFX_LANE_HISTORY_MAX + i] = jh->items[2 * i + 1].asDouble();
+                }
+                d.hLen[(size_t) dv] = (int32_t) pairs;
+            }
+            if (const Json *x = jd.find("historyVehicleNum")) d.hHistoryVehicleNum[(size_t) dv] = (int32_t) x->i;
+            if (const Json *x = jd.find("historyAverageSpeed")) d.hHistoryAverageSpeed[(size_t) dv] = x->asDouble();
         }
     }
     const Json &flows = root.objectAt("flows");

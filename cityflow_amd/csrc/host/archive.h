@@ -29,6 +29,9 @@ struct DeviceState {
     std::vector<int32_t> wVid, wLane;  // waiting buffers, lane by lane
     std::vector<int32_t> tlPhase;
     std::vector<double> tlRemain;
+    // Lane::history (cfx_lane_history, include/cityflow_amd.h); all empty where it is not kept ("cfx": {"laneHistory": true})
+    std::vector<int32_t> hLen, hVehicleNum, hHistoryVehicleNum;  // [L], [L * CFX_LANE_HISTORY_MAX], [L]
+    std::vector<double> hAverageSpeed, hHistoryAverageSpeed;
 };
 
 class Archive {

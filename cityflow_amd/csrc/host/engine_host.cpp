@@ -77,6 +77,8 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_profile_enable)
     CFX_FN(cfx_profile_read)
     CFX_FN(cfx_device_spin)
+    CFX_FN(cfx_get_lane_history)
+    CFX_FN(cfx_set_lane_history)
 #undef CFX_FN
     if (cfx_abi_version() != CFX_ABI_VERSION)
         throw std::runtime_error("cityflow_amd: ABI version mismatch in '" + libPath + "'");
@@ -123,6 +125,7 @@ EngineConfig readEngineConfig(const std::string &configFile) {
             if (x->find("ringLanesPerWave")) c.ringLanesPerWave = x->intAt("ringLanesPerWave");
             if (x->find("ringCapacityPercent")) c.ringCapacityPercent = x->intAt("ringCapacityPercent");
             c.exactShadowPeek = x->boolAt("exactShadowPeek", false);
+            c.laneHistory = x->boolAt("laneHistory", false);
             if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
         }
     } catch (const JsonError &e) {
@@ -135,6 +138,7 @@ void EngineConfig::apply(cfx_config &cc) const {
     cc.interval = interval;
     cc.rl_traffic_light = rlTrafficLight ? 1 : 0;
     cc.lane_change = laneChange ? 1 : 0;
+    cc.lane_history = laneHistory ? 1 : 0;
     cc.cross_mode = crossMode;
     cc.layout = layout;
     cc.debug_sync = debugSync;
@@ -183,6 +187,7 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
     cfx_config cc{};
     readEngineConfig(configFile).apply(cc);
+    laneHistory_ = cc.lane_history != 0;
     int32_t rc = be_.cfx_create(&net_->flat(), &cc, &dev_);
     if (rc != CFX_OK || !dev_) {
         const char *msg = be_.cfx_last_error(nullptr);
@@ -663,6 +668,18 @@ void EngineHost::trafficLightState(std::vector<int32_t> &phase, std::vector<doub
     phase.resize(net_->inters.size());
     remain.resize(net_->inters.size());
     check(be_.cfx_get_tl_state(dev_, phase.data(), remain.data()), "cfx_get_tl_state");
+}
+
+void EngineHost::laneHistory(std::vector<int32_t> &len, std::vector<int32_t> &vehicleNum, std::vector<double> &averageSpeed,
+                             std::vector<int32_t> &historyVehicleNum, std::vector<double> &historyAverageSpeed) {
+    const size_t nL = net_->lanes.size();
+    len.assign(nL, 0);
+    vehicleNum.assign(nL * CFX_LANE_HISTORY_MAX, 0);
+    averageSpeed.assign(nL * CFX_LANE_HISTORY_MAX, 0.0);
+    historyVehicleNum.assign(nL, 0);
+    historyAverageSpeed.assign(nL, 0.0);
+    cfx_lane_history h{(int32_t) nL, len.data(), vehicleNum.data(), averageSpeed.data(), historyVehicleNum.data(), historyAverageSpeed.data()};
+    check(be_.cfx_get_lane_history(dev_, &h), "cfx_get_lane_history");
 }
 
 // setVehicleSpeed engine.cpp:827-834

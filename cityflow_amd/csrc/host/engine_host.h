@@ -68,6 +68,8 @@ struct Backend {
     CFX_FN(cfx_profile_enable)
     CFX_FN(cfx_profile_read)
     CFX_FN(cfx_device_spin)
+    CFX_FN(cfx_get_lane_history)
+    CFX_FN(cfx_set_lane_history)
 #undef CFX_FN
     void open(const std::string &libPath);  // throws std::runtime_error
     ~Backend();
@@ -134,6 +136,9 @@ public:
     void setTrafficLightPhaseIndexed(int inter, int phase);
     void setTrafficLightPhases(const std::vector<int32_t> &phases);  // [n_intersections]; virtual ones ignored
     void trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain);
+    // Lane::history as the device keeps it ("cfx": {"laneHistory": true}; cfx_get_lane_history): lane-major, oldest record first
+    void laneHistory(std::vector<int32_t> &len, std::vector<int32_t> &vehicleNum, std::vector<double> &averageSpeed,
+                     std::vector<int32_t> &historyVehicleNum, std::vector<double> &historyAverageSpeed);
     void snapshotVehicles(VehicleSnapshot &out, unsigned fields = kSnapAll);
     // changes whenever vehicle numbers are reassigned (reset, load): per-vehicle caches of a language binding key on it
     uint64_t vehicleEpoch() const { return vehicleEpoch_; }
@@ -176,6 +181,7 @@ private:
     cfx_engine *dev_ = nullptr;
     double interval_ = 1.0;
     bool rlTrafficLight_ = false, laneChange_ = false, saveReplay_ = false, saveReplayInConfig_ = false;
+    bool laneHistory_ = false;  // "cfx": {"laneHistory": true}
     ReplayWriter replay_;
     void updateLog();  // Engine::updateLog engine.cpp:518-554
     int seed_ = 0, threadNum_ = 1;
@@ -202,6 +208,7 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
     // optional "cfx" object (ignored by the reference): implementation choices that never change results
     int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0, ringCapacityPercent = 0;
     bool exactShadowPeek = false;  // host: Spawner::exactPeekOnly
+    bool laneHistory = false;      // keep Lane::history on the device (cfx_config::lane_history): Archive dumps then carry it
     int hostThreads = -1;          // VectorEngine: worker threads for the per-environment host work (-1 auto, 0 serial)
     void apply(cfx_config &cc) const;  // interval, flags, the choices above, device (config > CITYFLOW_AMD_DEVICE > LOCAL_RANK)
 };

@@ -410,6 +410,19 @@ PYBIND11_MODULE(_cityflow, m) {
                  e.waitingVehicles(v, l);
                  return py::make_tuple(toArray(v), toArray(l));
              })
+        .def("_lane_history",
+             [](EngineHost &e) {  // test hook: cfx_get_lane_history; arrays [L], [L, 241], [L, 241], [L], [L]
+                 std::vector<int32_t> len, num, hn;
+                 std::vector<double> avg, ha;
+                 e.laneHistory(len, num, avg, hn, ha);
+                 py::dict d;
+                 d["len"] = toArray(len);
+                 d["vehicle_num"] = toArray(num);
+                 d["average_speed"] = toArray(avg);
+                 d["history_vehicle_num"] = toArray(hn);
+                 d["history_average_speed"] = toArray(ha);
+                 return d;
+             })
         .def("_tl_state",
              [](EngineHost &e) {
                  std::vector<int32_t> p;

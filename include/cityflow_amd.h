@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CFX_ABI_VERSION 6
+#define CFX_ABI_VERSION 7
 
 typedef enum cfx_status {
     CFX_OK = 0,
@@ -109,6 +109,8 @@ typedef struct cfx_config {
                                   * as a launch of its own.  Results never depend on it (tests/test_parity_pins.py) */
     int32_t ring_capacity_percent; /* ring layout: initial ring capacities as a percentage of the bumper-to-bumper bound
                                     * (0 = 100).  Small values make the growth path run (tests); results never depend on it */
+    int32_t lane_history;     /* keep Lane::history (roadnet.cpp:900-915; see cfx_get_lane_history) — one more pass over the lanes
+                               * per step, for numbers only Archive dumps show; not on tiles */
     int32_t n_envs;           /* 0 or 1: one simulation.  E > 1: the network is E disjoint copies of one network with their
                                * index spaces concatenated copy by copy (roads, lanes, laneLinks, intersections: n_roads etc. are
                                * multiples of E) — E independent simulations advanced by one engine (batched environments).  Only
@@ -291,6 +293,26 @@ typedef struct cfx_state {
 int32_t cfx_load_state(cfx_engine *e, const cfx_state *s);
 /* pending custom speeds of the running vehicles, same order as cfx_get_vehicles (NaN = none) */
 int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out);
+
+/* ---- Lane::history (reference src/roadnet/roadnet.h:305-316, Lane::updateHistory roadnet.cpp:900-915, called for every lane at
+ * the end of every step, engine.cpp:429-442): the last steps' {vehicle count, mean speed} per lane — up to
+ * CFX_LANE_HISTORY_MAX records, the list is trimmed to 240 BEFORE a step's record is appended — and the two running aggregates
+ * historyVehicleNum / historyAverageSpeed, kept up with the reference's own recurrence (the sum of the speeds is taken in the
+ * lane's list order; the popped records' share is subtracted from historyVehicleNum * historyAverageSpeed, a product formed anew
+ * every step).  It feeds Road::getAverageSpeed / the DURATION router, which nothing in the reference can select (router.h:42);
+ * what makes it visible is Archive::dump (archive.cpp:286-294).  Kept only with cfx_config::lane_history; Engine::reset does
+ * NOT clear it (Lane::reset roadnet.cpp:832-835), cfx_load_state leaves it alone — Archive::resume's part is cfx_set_lane_history. */
+#define CFX_LANE_HISTORY_MAX 241
+typedef struct cfx_lane_history {
+    int32_t n_lanes;                /* in: must equal the engine's */
+    int32_t *len;                   /* [n_lanes] records held */
+    int32_t *vehicle_num;           /* [n_lanes * CFX_LANE_HISTORY_MAX] lane-major, oldest record first */
+    double *average_speed;          /* [n_lanes * CFX_LANE_HISTORY_MAX] */
+    int32_t *history_vehicle_num;   /* [n_lanes] Lane::historyVehicleNum */
+    double *history_average_speed;  /* [n_lanes] Lane::historyAverageSpeed */
+} cfx_lane_history;
+int32_t cfx_get_lane_history(cfx_engine *e, cfx_lane_history *out);       /* CFX_ERR_STATE: the engine does not keep it */
+int32_t cfx_set_lane_history(cfx_engine *e, const cfx_lane_history *in);
 
 /* ---- Lane change (cfx_config::lane_change = 1; reference src/vehicle/lanechange.cpp, engine.cpp:374-400,792-820) ----
  * A vehicle that starts to change lane gets a SHADOW in the target lane: a new vehicle (`new Vehicle(*v, id + "_shadow")`,

@@ -91,6 +91,30 @@ struct cfx_engine {
     std::vector<int32_t> shadowPool, shadowParents;
     bool shadowOverflow = false;
     std::map<int32_t, double> futureCustom;      // custom speeds of vehicles the next spawn records will create
+    // Lane::history / historyVehicleNum / historyAverageSpeed (roadnet.h:305-316), with cfx_config::lane_history
+    struct LaneHistory {
+        std::deque<std::pair<int32_t, double>> records;
+        int32_t vehicleNum = 0;
+        double averageSpeed = 0;
+    };
+    std::vector<LaneHistory> laneHistory;
+    // Lane::updateHistory roadnet.cpp:900-915
+    void updateHistory(int lane) {
+        LaneHistory &h = laneHistory[(size_t) lane];
+        double speedSum = h.vehicleNum * h.averageSpeed;
+        while (h.records.size() > 240) {
+            h.vehicleNum -= h.records.front().first;
+            speedSum -= h.records.front().first * h.records.front().second;
+            h.records.pop_front();
+        }
+        double curSpeedSum = 0;
+        const int vehicleNum = (int) order[(size_t) lane].size();
+        h.vehicleNum += vehicleNum;
+        for (int32_t vid : order[(size_t) lane]) curSpeedSum += veh[(size_t) vid].speed;
+        speedSum += curSpeedSum;
+        h.records.emplace_back(vehicleNum, vehicleNum ? curSpeedSum / vehicleNum : 0);
+        h.averageSpeed = h.vehicleNum ? speedSum / h.vehicleNum : 0;
+    }
     // tiling (cfx_halo_config): same protocol as the HIP engine, restated on the object model
     bool tiled = false;
     std::vector<uint8_t> laneGhost, ghostHadEntrants;
@@ -787,13 +811,16 @@ struct cfx_engine {
     }
 
     // threadUpdateLeaderAndGap engine.cpp:429-442 (lane history is dead state)
+    // Engine::threadUpdateLeaderAndGap engine.cpp:429-442: the lanes' history is a part of this pass — with lane change it
+    // therefore gets TWO records per step (the pass also runs between planLaneChange and getAction, engine.cpp:571-575)
     void leaderAndGapPass() {
-        for (auto &list : order) {
+        for (size_t d = 0; d < order.size(); ++d) {
             int leader = -1;
-            for (int32_t vid : list) {
+            for (int32_t vid : order[d]) {
                 updateLeaderAndGap(veh[vid], leader);
                 leader = vid;
             }
+            if (cfg.lane_history && !tiled && (int) d < net.L) updateHistory((int) d);  // (not kept on tiles)
         }
     }
 
@@ -1130,6 +1157,7 @@ int32_t cfx_create(const cfx_net *n, const cfx_config *cfg, cfx_engine **out) {
     }
     e->order.assign(D, {});
     e->waiting.assign(t.L, {});
+    e->laneHistory.assign((size_t) t.L, {});
     e->notifyVid.assign(t.E, -1);
     e->notifyDist.assign(t.E, 0.0);
     e->curPhase.assign(t.I, 0);
@@ -1166,6 +1194,43 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
 }
 int32_t cfx_sync(cfx_engine *) { return CFX_OK; }
 
+int32_t cfx_get_lane_history(cfx_engine *e, cfx_lane_history *out) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    if (!e->cfg.lane_history) {
+        e->err = "cfx_get_lane_history: the engine was created without cfx_config::lane_history";
+        return CFX_ERR_STATE;
+    }
+    if (out->n_lanes != e->net.L) return CFX_ERR_INVALID;
+    for (int l = 0; l < e->net.L; ++l) {
+        const auto &h = e->laneHistory[(size_t) l];
+        out->len[l] = (int32_t) h.records.size();
+        for (size_t i = 0; i < h.records.size(); ++i) {
+            out->vehicle_num[(size_t) l * CFX_LANE_HISTORY_MAX + i] = h.records[i].first;
+            out->average_speed[(size_t) l * CFX_LANE_HISTORY_MAX + i] = h.records[i].second;
+        }
+        out->history_vehicle_num[l] = h.vehicleNum;
+        out->history_average_speed[l] = h.averageSpeed;
+    }
+    return CFX_OK;
+}
+int32_t cfx_set_lane_history(cfx_engine *e, const cfx_lane_history *in) {
+    if (!e || !in) return CFX_ERR_INVALID;
+    if (!e->cfg.lane_history) {
+        e->err = "cfx_set_lane_history: the engine was created without cfx_config::lane_history";
+        return CFX_ERR_STATE;
+    }
+    if (in->n_lanes != e->net.L) return CFX_ERR_INVALID;
+    for (int l = 0; l < e->net.L; ++l) {
+        auto &h = e->laneHistory[(size_t) l];
+        if (in->len[l] < 0 || in->len[l] > CFX_LANE_HISTORY_MAX) return CFX_ERR_INVALID;
+        h.records.clear();
+        for (int i = 0; i < in->len[l]; ++i)
+            h.records.emplace_back(in->vehicle_num[(size_t) l * CFX_LANE_HISTORY_MAX + i], in->average_speed[(size_t) l * CFX_LANE_HISTORY_MAX + i]);
+        h.vehicleNum = in->history_vehicle_num[l];
+        h.averageSpeed = in->history_average_speed[l];
+    }
+    return CFX_OK;
+}
 int32_t cfx_lane_change_supply(cfx_engine *e, int32_t n, const int32_t *priorities) {
     if (n < 0 || (n && !priorities)) return CFX_ERR_INVALID;
     e->shadowPool.assign(priorities, priorities + n);

@@ -29,7 +29,7 @@ for i, spec in enumerate(args):
         if k == "lib":  # a differently built device library (tools/README.md)
             lib = os.path.abspath(v)
         else:
-            cfx[k] = int(v) if v.lstrip("-").isdigit() else v
+            cfx[k] = int(v) if v.lstrip("-").isdigit() else {"true": True, "false": False}.get(v, v)
     c = json.load(open(cfg)); c["cfx"] = cfx
     path = cfg.replace(".json", "_ab%d.json" % i)
     json.dump(c, open(path, "w"))
