@@ -224,3 +224,34 @@ def test_out_of_order_archive_twin_equals_reference(mod, ref_module, scen, workd
         assert ref.get_vehicle_speed() == tw.get_vehicle_speed() and ref.get_vehicle_distance() == tw.get_vehicle_distance(), s
         assert ref.get_lane_vehicles() == tw.get_lane_vehicles(), s
     time.sleep(0.2)
+
+
+def test_set_route_on_a_pushed_vehicle(mod, scen, workdir):
+    """`set_vehicle_route` on a vehicle pushed since the last step.  The reference dies there — Router::setRoute
+    (router.cpp:245-246) asks `vehicle->getCurDrivable()->isLaneLink()` and the drivable is null until planRoute has run at the
+    next step (engine.cpp:450-470); run in a process of its own.  This engine answers false and goes on."""
+    import sys
+    import textwrap
+    cfg = scen.materialize("example_1x1", workdir)
+    if os.path.exists(os.path.join(REF_DIR, "libcityflow_ref.a")) or any(f.startswith("cityflow_ref") for f in os.listdir(REF_DIR)):
+        code = textwrap.dedent("""
+            import sys
+            sys.path.insert(0, %r)
+            import cityflow_ref
+            e = cityflow_ref.Engine(%r, 1)
+            for _ in range(5):
+                e.next_step()
+            e.push_vehicle({"speed": 3.0}, ["road_2_1_2", "road_1_1_3"])
+            print("pushed", flush=True)
+            print("answer", e.set_vehicle_route("manually_pushed_0", ["road_1_1_3"]), flush=True)
+        """ % (REF_DIR, cfg))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        assert "pushed" in r.stdout and "answer" not in r.stdout and r.returncode < 0, (r.returncode, r.stdout, r.stderr[-300:])
+    tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    for _ in range(5):
+        tw.next_step()
+    tw.push_vehicle({"speed": 3.0}, ["road_2_1_2", "road_1_1_3"])
+    assert tw.set_vehicle_route("manually_pushed_0", ["road_1_1_3"]) is False
+    tw.next_step()
+    assert "manually_pushed_0" in tw.get_vehicles(True)
+    assert tw.set_vehicle_route("manually_pushed_0", ["road_1_1_3"]) in (True, False)  # (known to the device from here on)
