@@ -171,7 +171,7 @@ __global__ void k_lc_plan(StepCtx c) {
         const int at = waveListAppend(lc.candAllCount, isCand);
         if (isCand) {
             lc.candAll[at] = vid;
-            lc.candAllEnv[at] = c.n.laneRoad[d] / lc.roadsPerEnv;
+            if (lc.roadsPerEnv < c.n.R) lc.candAllEnv[at] = c.n.laneRoad[d] / lc.roadsPerEnv;  // (batched environments only)
         }
     }
 }
@@ -199,6 +199,12 @@ __device__ inline int lcSortedPosition(int i, int n) {
 // ... taken by the road's wave in k_lc_schedule: creation rank of `me` among the step's candidates, all 64 lanes counting
 // (batched environments: every environment is an Engine of its own — rank and count among ITS candidates)
 __device__ __forceinline__ int lcWalkPosition(const LcDev &lc, int me, int env, int nAll, int tid) {
+    if (env < 0) {  // one environment: every candidate of the step is one of its own
+        int less = 0;
+        for (int i = tid; i < nAll; i += 64) less += lc.candAll[i] < me;
+        for (int off = 32; off > 0; off >>= 1) less += __shfl_down(less, off, 64);
+        return lcSortedPosition(__shfl(less, 0, 64), nAll);
+    }
     int less = 0, mine = 0;
     for (int i = tid; i < nAll; i += 64) {
         const bool same = lc.candAllEnv[i] == env;
@@ -244,7 +250,8 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     const int road = blockIdx.x;
     if (road >= c.n.R) return;
     const LcDev &lc = c.lc;
-    const int env = road / lc.roadsPerEnv;
+    const bool oneEnv = lc.roadsPerEnv >= c.n.R;
+    const int env = oneEnv ? -1 : road / lc.roadsPerEnv;  // (-1: lcWalkPosition counts all candidates)
     const int nListed = lc.roadCand[road];
     if (nListed == 0) return;
     const int tid = threadIdx.x;
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                             if (insLane[j] == target && insAnchor[j] == anchor && insSeq[j] >= seq) seq = insSeq[j] + 1.0;
                     }
                     lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid], anchor, mySeg, seq};
-                    lc.insKey[idx] = (env << kLcEnvShift) + myKey;  // shadows are created, and numbered, in walk order (k_lc_insert)
+                    lc.insKey[idx] = ((oneEnv ? 0 : env) << kLcEnvShift) + myKey;  // shadows are created, and numbered, in walk order (k_lc_insert)
                     // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
                     // later candidate of this walk that copies itself (its own shadow) copies this gap too
                     if (follower.vid >= 0) lc.gap[follower.vid] = dis - myLen - follower.dis;
@@ -570,8 +577,16 @@ __global__ __launch_bounds__(64) void k_lc_insert(StepCtx c, VidTable vt, DevSca
     const int D = c.n.L + c.n.K;
     // creation rank of record `rec` among the step's shadows, counted by the whole wave
     // (.x among all of them: the vehicle number; .y among its environment's: the priority it takes)
+    const bool oneEnv = lc.roadsPerEnv >= c.n.R;
     auto rankOf = [&](int rec) {
         const int key = lc.insKey[rec];
+        if (oneEnv) {
+            int less = 0;
+            for (int j = tid; j < nIns; j += 64) less += lc.insKey[j] < key;
+            for (int off = 32; off > 0; off >>= 1) less += __shfl_down(less, off, 64);
+            less = __shfl(less, 0, 64);
+            return make_int2(less, less);
+        }
         int less = 0, lessEnv = 0;
         for (int j = tid; j < nIns; j += 64) {
             const int kj = lc.insKey[j];
