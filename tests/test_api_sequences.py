@@ -290,7 +290,7 @@ def test_tiled_random_calls_equal_single_engine(mod, scen, workdir, seed):
         assert checkpoint_record(one) == checkpoint_record(til), (seed, round_)
 
 
-def _comparable_dump(path, written_by_reference):
+def _comparable_dump(path, written_by_reference, keep_history=False):
     """An Archive file without the two things that cannot be equal: Lane::history (it feeds only the unused DURATION router
     and is not kept by this engine) and ControllerInfo::gap of a vehicle without a leader (uninitialised memory in the
     reference's dump)."""
@@ -302,20 +302,27 @@ def _comparable_dump(path, written_by_reference):
         d = json.load(f) if written_by_reference else json.load(f, parse_float=lambda lit: _cityflow._parse_json_number(lit)[0])
     for dv in d["drivables"].values():
         for k in ("history", "historyVehicleNum", "historyAverageSpeed"):
-            dv.pop(k, None)
+            if not keep_history:
+                dv.pop(k, None)
     for v in d["vehicles"]:
         if not v.get("leader"):
             v.pop("gap", None)
     return d
 
 
-@pytest.mark.parametrize("seed", [3, 4])
-def test_archive_files_cross_loaded_in_the_middle_of_sequences(mod, ref_module, scen, workdir, tmp_path, seed):
+@pytest.mark.parametrize("seed,history", [(3, False), (4, False), (5, True), (6, True)])
+def test_archive_files_cross_loaded_in_the_middle_of_sequences(mod, ref_module, scen, workdir, tmp_path, seed, history):
     """`snapshot().dump()` of the reference and of this engine at random moments of a sequence with custom speeds, pushed
     vehicles and full waiting buffers: the files are equal (see _comparable_dump), both engines load one of the two files
     and go on identically — again and again in one run (archive.cpp:153-550)."""
     rl = seed % 2 == 0
     cfg = _config(scen, workdir, rl)
+    if history:  # Lane::history kept ("cfx": {"laneHistory": true}) and compared too: it travels with the files (archive.cpp:286-294)
+        c = json.load(open(cfg))
+        c["cfx"] = {"laneHistory": True}
+        cfg = cfg.replace(".json", "_history.json")
+        with open(cfg, "w") as f:
+            json.dump(c, f)
     ref, tw = ref_module.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
     rng = np.random.default_rng(seed)
     exchanged = 0
@@ -339,7 +346,7 @@ def test_archive_files_cross_loaded_in_the_middle_of_sequences(mod, ref_module, 
                 p_ref, p_tw = str(tmp_path / ("ref%d.json" % exchanged)), str(tmp_path / ("tw%d.json" % exchanged))
                 ref.snapshot().dump(p_ref)
                 tw.snapshot().dump(p_tw)
-                assert _comparable_dump(p_ref, True) == _comparable_dump(p_tw, False), (seed, round_)
+                assert _comparable_dump(p_ref, True, history) == _comparable_dump(p_tw, False, history), (seed, round_)
                 # Both load the SAME file, the reference's or this engine's.  The reference's reader (rapidjson's default
                 # number reader, restated in csrc/host/json_number.h) is not correctly rounded: a file the reference wrote
                 # (near-shortest digits) can come back an ulp off — in both engines alike, `dis`, `speed` and the stored `gap`
