@@ -10,6 +10,11 @@ from cityflow_amd import _cityflow
 # default: the bench.py workload; CFX_VEC_SCENARIO=grid_6x6 CFX_VEC_EXTRA=0 gives the stock small grid RL work uses
 cfg = bench.build_workload("/tmp/cfa_vec", 0, scenario=os.environ.get("CFX_VEC_SCENARIO", "grid_30x30"),
                            n_extra=int(os.environ.get("CFX_VEC_EXTRA", bench.N_EXTRA_FLOWS)))
+if os.environ.get("CFX_VEC_LC"):  # the same with laneChange: true (every environment its own lane-change schedule)
+    c = json.load(open(cfg))
+    c["laneChange"] = True
+    cfg = cfg.replace(".json", "_lc.json")
+    json.dump(c, open(cfg, "w"))
 for R in rs:
     t0 = time.perf_counter()
     lib = os.environ.get("CFX_VEC_LIB")  # a differently built device library
