@@ -96,6 +96,27 @@ def test_vector_engine_lane_change_grid_twin(mod, scen, workdir):
            lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), name="grid_6x6", envs=2, steps=470, lane_change=True, every=5)
 
 
+def test_vector_engine_lane_change_threaded_spawners_twin(mod, scen, workdir):
+    """... with the environments' spawners, shadow-priority peeks and record translation on the host thread pool
+    (`"cfx": {"hostThreads": 3}`) and with the exact redraw loop of the peek forced (`exactShadowPeek`): same results."""
+    import json
+    base = scen.materialize("example_1x1", workdir, laneChange=True)
+    c = json.load(open(base))
+    c["cfx"] = {"hostThreads": 3, "exactShadowPeek": True}
+    threaded = base.replace(".json", "_lc_ht3.json")
+    with open(threaded, "w") as f:
+        json.dump(c, f)
+    vec = mod.VectorEngine._with_backend(threaded, 6, 1, TWIN_LIB)
+    ser = mod.VectorEngine._with_backend(base, 6, 1, TWIN_LIB)
+    for s in range(150):
+        vec.next_step()
+        ser.next_step()
+        assert np.array_equal(vec.get_lane_vehicle_count_array(), ser.get_lane_vehicle_count_array()), s
+    for e in range(6):
+        assert vec.get_vehicle_speed(e) == ser.get_vehicle_speed(e)
+    assert vec.get_vehicle_count() > sum(len(vec.get_vehicle_speed(e)) for e in range(6))  # shadows alive
+
+
 def test_vector_engine_lane_change_reset_twin(mod, scen, workdir):
     cfg = scen.materialize("example_1x1", workdir, laneChange=True)
     vec = mod.VectorEngine._with_backend(cfg, 2, 1, TWIN_LIB)
