@@ -176,3 +176,29 @@ def test_archive_writer_survives_both_readers(mod):
     for v in (0.0, 1.0, -1.0, 0.5, 16.67, 1e22, 1e-7, 123456.789):
         assert float(mod._format_json_number(v)) == v
     assert mod._format_json_number(float("nan")) == "NaN" and mod._format_json_number(float("inf")) == "Infinity"
+
+
+def test_reader_meets_rapidjsons_own_unit_test_expectations(mod):
+    """The literals rapidjson's own reader tests run through BOTH readers (test/unittest/readertest.cpp, `TestParseDouble<false>`:
+    the default, not-full-precision one is held to EXPECT_DOUBLE_EQ, i.e. within 4 units in the last place of the exact value;
+    the underflowing ones to exactly 0).  Not a pin of the bits — the library publishes none for this reader — but what it
+    promises of it."""
+    def ulps(a, b):
+        ia, ib = struct.unpack("<q", struct.pack("<d", a))[0], struct.unpack("<q", struct.pack("<d", b))[0]
+        return abs(ia - ib)
+
+    for lit in ["0.0", "-0.0", "1.0", "-1.0", "1.5", "-1.5", "3.1416", "1E10", "1e10", "1E+10", "1E-10", "-1E10", "-1e10", "-1E+10",
+                "-1E-10", "1.234E+10", "1.234E-10", "1.79769e+308", "2.22507e-308", "-1.79769e+308", "-2.22507e-308",
+                "4.9406564584124654e-324", "2.2250738585072009e-308", "2.2250738585072014e-308", "1.7976931348623157e+308",
+                "18446744073709551616", "-9223372036854775809", "0.9868011474609375", "123e34", "45913141877270640000.0",
+                "2.2250738585072011e-308", "0.017976931348623157e+310", "2.2250738585072012e-308", "0.999999999999999944488848768742172978818416595458984375",
+                "1.00000000000000011102230246251565404236316680908203125", "72057594037927928.0", "72057594037927936.0",
+                "9223372036854774784.0", "9223372036854775808.0", "10141204801825834086073718800384", "5708990770823839207320493820740630171355185151999e-3",
+                "2.225073858507201136057409796709131975934819546351645648023426109724822222021076945516529523908135087914149158913039621106870086438694594645527657207407820621743379988141063267329253552286881372149012981122451451889849057222307285255133155755015914397476397983411801999323962548289017107081850690630666655994938275772572015763062690663332647565300009245888316433037779791869612049497390377829704905051080609940730262937128958950003583799967207254304360284078895771796150945516748243471030702609144621572289880258182545180325707018860872113128079512233426288368622321503775666622503982534335974568884423900265498198385487948292206894721689831099698365846814022854243330660339850886445804001034933970427567186443383770486037861622771738545623065874679014086723327636718749999999999999999999999999999999999999e-308"]:
+        got = mod._parse_json_number(lit)[0]
+        want = float(lit)
+        assert ulps(got, want) <= 4, (lit, got, want)
+        assert got == reader(lit)[1]
+    for lit in ["1e-10000", "1e-00011111111111", "-1e-00011111111111", "1e-214748363", "1e-214748364", "1e-21474836311"]:
+        got = mod._parse_json_number(lit)[0]
+        assert got == 0.0 and (str(got) == "-0.0") == lit.startswith("-"), lit
