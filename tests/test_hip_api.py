@@ -54,9 +54,11 @@ def test_control_calls_hip_equals_twin_and_reference(mod, scen, workdir):
 def test_control_calls_hip_equals_reference(mod, ref_module, scen, workdir):
     cfg = scen.materialize("example_1x1", workdir)
     a = control_script(mod.Engine(cfg, 1))
-    b = control_script(ref_module.Engine(cfg, 1))
+    ref = ref_module.Engine(cfg, 1)  # (kept alive over a pause: the reference's destructor races with its worker threads)
+    b = control_script(ref)
+    time.sleep(0.2)
+    del ref
     assert a == b
-    time.sleep(0.1)
 
 
 def test_reference_dump_loads_into_hip(mod, ref_module, scen, workdir, tmp_path):
