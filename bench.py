@@ -385,6 +385,7 @@ def parse_args():
     ap.add_argument("--scale-flows", type=int, default=SCALE_FLOWS, help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="auto", help=argparse.SUPPRESS)
     ap.add_argument("--backend-lib", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--no-halo", action="store_true", help=argparse.SUPPRESS)  # test: as if no halo transport came up
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of one tiled network")
     ap.add_argument("--weak", action="store_true",
                     help="N>1: grow the grid with N (every GPU owns a 30x30 block) instead of tiling the N=1 workload itself")
@@ -743,6 +744,7 @@ def main():
     from cityflow_amd import _cityflow
 
     tiled = world > 1 and not args.replicas
+    tiling_failed = False
     eng, halo_notes, rows, cols = None, [], 1, 1
     if tiled:
         rows, cols = tile_grid(world)
@@ -757,10 +759,20 @@ def main():
                 build_tiled_workload(workdir, rows, cols, args.tile_block, args.extra_flows)
             job.barrier()
             cfg = os.path.join(workdir, "gen_%dx%d" % (args.tile_block * rows, args.tile_block * cols), "config_bench.json")
-        eng = make_tiled(job, cfg, rows, cols, args.backend_lib, halo_notes)
+        if args.no_halo:
+            halo_notes.append("--no-halo")
+        else:
+            eng = make_tiled(job, cfg, rows, cols, args.backend_lib, halo_notes)
         if eng is None:
-            raise SystemExit("bench.py: no halo transport works on this machine (%s)" % "; ".join(halo_notes))
-    else:
+            # No halo transport works between these ranks (every rank agrees: make_tiled).  Rather than no line at all: N
+            # independent replicas of the N = 1 workload — weak scaling, no exchange — and the line says so
+            # (`config.parallelism`, `config.halo_probe_failures`).
+            sys.stderr.write("bench.py: no halo transport works on this machine (%s): running independent replicas\n"
+                             % "; ".join(halo_notes))
+            tiled, tiling_failed = False, True
+            args.replicas = True
+            rows, cols = 1, 1
+    if not tiled:
         workdir = os.path.join(tempfile.gettempdir(), "cityflow_amd_bench_rank%d" % rank)
         cfg = build_workload(workdir, seed=rank, scenario=args.scenario, n_extra=args.extra_flows)
         if args.cfx:
@@ -970,7 +982,8 @@ def main():
                 "host_us_per_step": ({"spawner": round((host1[0] - host0[0]) / args.steps * 1e6, 1),
                                       "submit": round((host1[1] - host0[1]) / args.steps * 1e6, 1)} if tiled else None),
                 "parallelism": ("tiles %dx%d + halo" % (rows, cols)) if tiled else (
-                    "replica x%d" % world if world > 1 else "1 gpu"),
+                    ("replica x%d" % world + (" (one tiled network was asked for: no halo transport came up)" if tiling_failed else ""))
+                    if world > 1 else "1 gpu"),
             },
             "roofline": roofline,
             "roofline_at_scale": scale if world == 1 else None,

@@ -151,3 +151,21 @@ def test_bench_single_rank_twin(tmp_path):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["roofline"] is None and d["cpu_baseline"] is None
     assert d["warmup"] == 10 and "20 simulated seconds" in d["config"]["state"]  # the workload state does not depend on --warmup
+
+
+def test_bench_falls_back_to_replicas_when_no_halo_transport_comes_up(tmp_path):
+    """An N > 1 run on a machine where no halo transport can be set up between the ranks still prints its line: N independent
+    replicas (weak scaling), and says that this is not what was asked for."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--build-up-steps", "60",
+           "--cpu-seconds", "1", "--scenario", "grid_6x6", "--extra-flows", "20", "--dist-backend", "gloo", "--backend-lib", TWIN_LIB,
+           "--no-halo"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("replica x2") and "no halo transport" in d["config"]["parallelism"]
+    assert d["config"]["halo_probe_failures"] == ["--no-halo"]
