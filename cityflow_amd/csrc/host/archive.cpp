@@ -669,12 +669,12 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
             if (jh && jh->isArray()) {
                 const size_t pairs = std::min<size_t>(jh->items.size() / 2, CFX_LANE_HISTORY_MAX);
                 for (size_t i = 0; i < pairs; ++i) {
-                    d.hVehicleNum[(size_t) dv * CFX_LANE_HISTORY_MAX + i] = (int32_t) jh->items[2 * i].i;
+                    d.hVehicleNum[(size_t) dv * CFX_LANE_HISTORY_MAX + i] = (int32_t) jh->items[2 * i].asDouble();
                     d.hAverageSpeed[(size_t) dv * CFX_LANE_HISTORY_MAX + i] = jh->items[2 * i + 1].asDouble();
                 }
                 d.hLen[(size_t) dv] = (int32_t) pairs;
             }
-            if (const Json *x = jd.find("historyVehicleNum")) d.hHistoryVehicleNum[(size_t) dv] = (int32_t) x->i;
+            if (const Json *x = jd.find("historyVehicleNum")) d.hHistoryVehicleNum[(size_t) dv] = (int32_t) x->asDouble();
             if (const Json *x = jd.find("historyAverageSpeed")) d.hHistoryAverageSpeed[(size_t) dv] = x->asDouble();
         }
     }
