@@ -117,6 +117,47 @@ def test_vector_engine_lane_change_threaded_spawners_twin(mod, scen, workdir):
     assert vec.get_vehicle_count() > sum(len(vec.get_vehicle_speed(e)) for e in range(6))  # shadows alive
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_vector_engine_lane_change_random_control_twin(mod, scen, workdir, seed):
+    """Batched environments with lane change under random control — every signal set per environment, resets with and without
+    a new seed in the middle of lane changes: every environment still equals its standalone engine after every step."""
+    rng = np.random.default_rng(seed)
+    envs = 3
+    cfg = scen.materialize("example_1x1", workdir, laneChange=True, rlTrafficLight=True)
+    vec = mod.VectorEngine._with_backend(cfg, envs, 1, TWIN_LIB)
+    singles = [mod.Engine._with_backend(scen.materialize("example_1x1", workdir, laneChange=True, rlTrafficLight=True, seed=e), 1, TWIN_LIB)
+               for e in range(envs)]
+    inter_ids = vec.intersection_ids()
+    shadows = 0
+    for s in range(260):
+        r = rng.random()
+        if r < 0.15:
+            ph = rng.integers(0, 8, size=(envs, len(inter_ids))).astype(np.int32)
+            for e in range(envs):
+                for i, iid in enumerate(inter_ids):
+                    try:
+                        singles[e].set_tl_phase(iid, int(ph[e, i]))
+                    except (IndexError, RuntimeError):
+                        pass  # virtual intersections
+            vec.set_tl_phases(ph)
+        elif r < 0.17 and s > 30:
+            reseed = bool(rng.integers(0, 2))
+            vec.reset(reseed)
+            for e in singles:
+                e.reset(reseed)
+        vec.next_step()
+        for e in singles:
+            e.next_step()
+        counts = vec.get_lane_vehicle_count_array()
+        for e in range(envs):
+            assert np.array_equal(counts[e], singles[e].get_lane_vehicle_count_array()), (s, e)
+        if s % 7 == 0:
+            for e in range(envs):
+                assert vec.get_vehicle_speed(e) == singles[e].get_vehicle_speed(), (s, e)
+            shadows = max(shadows, vec.get_vehicle_count() - sum(len(vec.get_vehicle_speed(e)) for e in range(envs)))
+    assert shadows > 0
+
+
 def test_vector_engine_lane_change_reset_twin(mod, scen, workdir):
     cfg = scen.materialize("example_1x1", workdir, laneChange=True)
     vec = mod.VectorEngine._with_backend(cfg, 2, 1, TWIN_LIB)
