@@ -41,11 +41,35 @@ struct DevNet {
     const uint8_t *laneSpare;       // [L] spare slots behind the lane's vehicles (1 admission + halo migrants)
 };
 
+constexpr int kInlineTempl = 2;
 struct DevTables {
     const cfx_vehicle_template *templ;
     int nTempl;
     const int32_t *routeStart, *routeRoads, *nextStart, *nextLL;
+    // the first kInlineTempl templates BY VALUE (they travel in the kernel arguments): a network whose vehicles share one or
+    // two templates — the usual case — stages its LDS copy from scalar registers instead of behind a round trip to memory at the
+    // top of every block (1.3-1.6 us of a ~9 us block at 1 M vehicles)
+    cfx_vehicle_template inl[kInlineTempl];
 };
+// A block's LDS copy of the template table (all threads; ends with a barrier).  Returns the table to index: LDS, or the
+// table in memory when it has more entries than the LDS copy holds.
+template <class C, int N>
+__device__ __forceinline__ const cfx_vehicle_template *stageTemplateTable(const C &c, cfx_vehicle_template (&sT)[N]) {
+    if (c.t.nTempl > N) return c.t.templ;
+    if (c.t.nTempl <= kInlineTempl) {
+        if (threadIdx.x == 0) {
+            sT[0] = c.t.inl[0];
+            if (c.t.nTempl > 1) sT[1] = c.t.inl[1];
+        }
+    } else {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    return sT;
+}
 
 // Committed per-slot state (double-buffered: rewritten in slot order by the compaction).
 struct SlotArrays {
@@ -195,6 +219,15 @@ struct LLAux {
 };
 static_assert(sizeof(LLAux) == 56, "laneLink aux record layout");
 
+// ... the dense layout's, for the three-launch cross phase (k_cross3_eval): also the first vehicle ON the laneLink, so that the
+// usual answers of "who was this cross notified of" — u, the first vehicle on the laneLink, f — come from the laneLink's two
+// records in ONE round instead of a chain of slot gathers
+struct LLAuxD {
+    double uDis, uSpeed, fDis, fSpeed, oDis, oSpeed, llLen, startLen;
+    int32_t uTempl, fTempl, oTempl, pad;
+};
+static_assert(sizeof(LLAuxD) == 80, "dense laneLink aux record layout");
+
 // What finishing a vehicle that leaves its drivable needs beyond its slot; valid = the caller requested it early
 // (actionOneRing, round A), otherwise it is loaded here.
 struct LeaverPrefetch {
@@ -246,12 +279,34 @@ struct StepCtx {
     const TailRec *tailR;
     TailRec *tailW, *tailNow;
     int4 *llGate4;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
+    // cfx_config::dense_form bit 1 (kd_admit over the lanes only): a laneLink's gate record is rewritten only when its
+    // intersection's phase has changed (kd_admit<true>), its tail as this step sees it is the committed record (linkTailNow)
+    int laneAdmit;
+    LLAuxD *llAuxD;           // [K] with the three-launch cross phase (dense_form bit 3), else null
     int32_t step;
     double interval;
     LcDev lc;
 };
 
 namespace cfxd {
+
+// Developer build (-DCFX_TRACE): per-block wall-clock stamps (100 MHz) of ONE kernel's phases, chosen at build time with
+// -DCFX_TRACE_KERNEL=<id> (0: the ring layout's kr_action / kr_cross as tools/trace_action.py reads them; 1 k_cross3_list, 2
+// k_cross3_eval, 3 k_cross3_finish, 4 kd_action_heavy, 5 kd_action_light, 6 kd_action, 7 k_scatter, 8 k_cross2); row = block index
+#ifdef CFX_TRACE
+__device__ long long *g_trace;  // [65536 * 8]
+#ifndef CFX_TRACE_KERNEL
+#define CFX_TRACE_KERNEL 0
+#endif
+#define KSTAMP(id, k)                                                                                       \
+    if (CFX_TRACE_KERNEL == (id) && threadIdx.x == 0 && blockIdx.x < 65536)                                  \
+    g_trace[(size_t) blockIdx.x * 8 + (k)] = (long long) wall_clock64()
+#define KNOTE(id, k, v)                                                                                     \
+    if (CFX_TRACE_KERNEL == (id) && threadIdx.x == 0 && blockIdx.x < 65536) g_trace[(size_t) blockIdx.x * 8 + (k)] = (long long) (v)
+#else
+#define KSTAMP(id, k)
+#define KNOTE(id, k, v)
+#endif
 
 __device__ __forceinline__ double min2(double x, double y) { return x < y ? x : y; }  // utility.h:70-72
 __device__ __forceinline__ double max2(double x, double y) { return x > y ? x : y; }  // utility.h:66-68
@@ -299,12 +354,17 @@ __device__ __forceinline__ void lcInitVid(const LcDev &lc, int v) {
 
 // A step's few spawn records as kernel arguments of the admission kernel (kr_admit, cfx_ring_kernels.h, has the story)
 constexpr int kAdmitRecs = 128;
-struct SpawnBatch {
+// ... and kd_admit of a large network, whose stock flows alone produce a few hundred records per step (100x100: 400), takes
+// up to kAdmitRecsBig of them the same way (20 KB of arguments; the runtime takes 32 KB and more, tools/kernarg_probe.hip)
+constexpr int kAdmitRecsBig = 1024;
+template <int N> struct SpawnBatchT {
     int n, firstNewVid;
     double enterTime;
-    int32_t lane[kAdmitRecs], prevWait[kAdmitRecs], route[kAdmitRecs], priority[kAdmitRecs];
-    int16_t templ[kAdmitRecs], vidOff[kAdmitRecs];
+    int32_t lane[N], prevWait[N], route[N], priority[N];
+    int16_t templ[N], vidOff[N];
 };
+using SpawnBatch = SpawnBatchT<kAdmitRecs>;
+using SpawnBatchBig = SpawnBatchT<kAdmitRecsBig>;
 
 // Vehicles on drivable d as phases 3/4 see them.  cnt[] is the committed count; a lane's admission of THIS step
 // (Engine::handleWaiting, phase 2) is not folded into it until the compaction (k_scan) — it is the flag
@@ -399,6 +459,20 @@ __device__ __forceinline__ Tail tailForLeader(const StepCtx &c, int d, bool view
 }
 
 __device__ __forceinline__ int4 gateRecord(const StepCtx &c, int k) { return c.llGate4[k]; }  // (cfx_dense_kernels.h)
+// Drivable::getLastVehicle of laneLink d (an index >= L) as this step's phases 3 / 4 see it, as a tail record.  Nothing is admitted
+// onto a laneLink, so it is the committed record with the "written last step" test — which is all kd_admit did for these
+// records; with cfx_config::dense_form bit 1 that kernel no longer visits the laneLinks
+__device__ __forceinline__ TailRec linkTailNow(const StepCtx &c, int d) {
+    if (!c.laneAdmit) return c.tailNow[d];
+    TailRec r = c.tailR[d];
+    if (r.tag != c.step - 1) r.slot = -1;
+    return r;
+}
+__device__ __forceinline__ TailRec firstHopRecord(const StepCtx &c, bool linkHead, int endLane, int firstLink) {  // (actionOneRounds)
+    TailRec r = *(linkHead ? &c.tailR[endLane] : (c.laneAdmit ? &c.tailR[firstLink] : &c.tailNow[firstLink]));
+    if (!linkHead && c.laneAdmit && r.tag != c.step - 1) r.slot = -1;
+    return r;
+}
 __device__ __forceinline__ Tail tailOfRec(const TailRec &r) { return Tail{r.slot, r.templ, r.prevDrv, r.dis, r.speed}; }
 __device__ __forceinline__ Tail tailIfCurrent(const TailRec &r, int wantTag) {
     Tail t = tailOfRec(r);

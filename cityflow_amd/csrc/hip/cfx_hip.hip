@@ -20,8 +20,8 @@
 
 // k_cross2's grid on the dense layout: one block per kCross2Jobs slots of the layout's bound, at most this many (the
 // kernel strides over the queue, so any grid is correct; blocks beyond the queue's length only pay the prologue)
-#ifndef CFX_CROSS2_MAX_GRID
-#define CFX_CROSS2_MAX_GRID 16384
+#ifndef CFX_CROSS2_BLOCKS_PER_CU
+#define CFX_CROSS2_BLOCKS_PER_CU 7  // k_cross2 on the dense layout: what its LDS lets a CU hold
 #endif
 
 using namespace cfxd;
@@ -30,11 +30,14 @@ namespace {
 
 std::string g_createError;
 
-enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, PK_HALO_EXPORT, PK_HALO_IMPORT, PK_COMMIT, kNumProfKernels };
+#ifndef CFX_DENSE_FORM_DEFAULT
+#define CFX_DENSE_FORM_DEFAULT 0  // what cfx_config::dense_form = 0 means (see include/cityflow_amd.h)
+#endif
+enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, PK_HALO_EXPORT, PK_HALO_IMPORT, PK_COMMIT, PK_ACTION_HEAVY, PK_CROSS_EVAL, PK_CROSS_FINISH, kNumProfKernels };
 // names of the step's phases; the ring layout runs kr_admit / kr_action / k_cross<.., RingCtx> / kr_commit under the first
 // four and the last name (it has no scan / scatter)
 const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_action", "k_cross", "k_scan", "k_scatter",
-                                                 "k_halo_export", "k_halo_import", "k_commit"};
+                                                 "k_halo_export", "k_halo_import", "k_commit", "k_action_heavy", "k_cross_eval", "k_cross_finish"};
 
 #define HIP_TRY(call)                                                                                  \
     do {                                                                                               \
@@ -58,6 +61,7 @@ inline int gridStride(size_t n) { return (int) std::min<size_t>(std::max<size_t>
 
 struct cfx_engine {
     int device = 0;
+    int nCU = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     hipStream_t stream = nullptr;
     cfx_config cfg{};
     int R = 0, L = 0, K = 0, D = 0, I = 0, E = 0;
@@ -173,6 +177,13 @@ struct cfx_engine {
     // ---- lane change (cfx_config::lane_change) ----
     LcDev lc{};                        // device tables (vid-indexed ones grow with the vehicle table)
     int32_t *oldToNew2 = nullptr;      // [slot] lane change: scratch of k_lc_resolve (which items are done)
+    // dense layout, cfx_config::dense_form: which organisation of the step's kernels (cfx_dense_kernels.h); results never depend on it
+    int denseForm = 0;
+    bool splitAction() const { return (denseForm & 1) != 0; }
+    bool laneAdmit() const { return (denseForm & 2) != 0 && useTails() && !tiled; }
+    int32_t *gatePhase = nullptr;      // [2 I] laneAdmit(): the phase each intersection's gate records stand for (-1: none), by step parity
+    int32_t *heavyList = nullptr, *heavyCount = nullptr;  // the vehicles kd_action_light leaves to kd_action_heavy; two counters by step parity
+    size_t heavyCap = 0;
     int32_t *hPool = nullptr;          // ... pinned staging
     int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1] overflow code, [2..] their parents in walk order
     hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
@@ -183,7 +194,18 @@ struct cfx_engine {
     TailRec *dTail[2] = {nullptr, nullptr}, *dTailNow = nullptr;
     int4 *dGate4 = nullptr;
     bool lcSegValid = false;           // lane change: segOfSlot holds every vehicle's own segment (k_scatter / k_lc_naive)
+    // the cross phase in three launches (cfx_config::dense_form bit 3; k_cross3_* of cfx_kernels.h): its lists
+    bool cross3() const { return (denseForm & 8) != 0 && !ring && !lc.on; }
+    CrossJobRec *x3Rec = nullptr;
+    unsigned long long *x3First = nullptr;
+    LLAuxD *x3Aux = nullptr;
+    int32_t *x3PairCount = nullptr;
+    int2 *x3Pairs = nullptr;
+    size_t x3Cap = 0;                  // slots the per-slot lists are allocated for
+    int x3PairCap = 0;                 // pairs per shard
     bool tailsValid = false;           // the records describe the current generation (false after reset / load / resize)
+    bool heavyDirty = false;           // the heavy list's counters may hold a count (set wherever tailsValid is dropped)
+    bool x3Dirty = false;              // ... the pair lists' counters likewise
     bool useTails() const { return !ring && !lc.on; }  // (tiles too since round 3: the halo kernels keep the cut lanes' records up)
 
     // ---- ring layout (cfx_ring_kernels.h): per-drivable ring segments, committed in place ----
@@ -323,6 +345,7 @@ struct cfx_engine {
         c.n = net;
         c.t.templ = dTempl.p;
         c.t.nTempl = (int) hTempl.size();
+        for (int i = 0; i < kInlineTempl && i < (int) hTempl.size(); ++i) c.t.inl[i] = hTempl[i];
         c.t.routeStart = dRouteStart.p;
         c.t.routeRoads = dRouteRoads.p;
         c.t.nextStart = dNextStart.p;
@@ -349,6 +372,8 @@ struct cfx_engine {
             c.tailW = dTail[step & 1];
             c.tailNow = dTailNow;
             c.llGate4 = dGate4;
+            c.laneAdmit = laneAdmit() ? 1 : 0;
+            c.llAuxD = x3Aux;  // (null unless the three-launch cross phase runs)
         }
         return c;
     }
@@ -477,6 +502,7 @@ struct cfx_engine {
         c.n = net;
         c.t.templ = dTempl.p;
         c.t.nTempl = (int) hTempl.size();
+        for (int i = 0; i < kInlineTempl && i < (int) hTempl.size(); ++i) c.t.inl[i] = hTempl[i];
         c.t.routeStart = dRouteStart.p;
         c.t.routeRoads = dRouteRoads.p;
         c.t.nextStart = dNextStart.p;
@@ -672,6 +698,9 @@ struct cfx_engine {
         hCntValid = false;
         futureCustom.clear();
         tailsValid = false;
+        heavyDirty = true;
+        x3Dirty = true;
+        if (gatePhase) HIP_TRY(hipMemsetAsync(gatePhase, 0xFF, (size_t) 2 * std::max(I, 1) * sizeof(int32_t), stream));
         lcSegValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
         pollPending = false;
@@ -789,6 +818,10 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     if (ndev <= 0) return e->fail("no HIP device visible");
     e->device = cfg->device % ndev;
     HIP_TRY(hipSetDevice(e->device));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) e->nCU = cus;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->cfg = *cfg;
     e->cross2 = cfg->cross_mode == CFX_CROSS_THROUGHPUT ? 1 : cfg->cross_mode == CFX_CROSS_LATENCY ? 0 : -1;
@@ -800,6 +833,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     // (60x60: 112 vs 101, 100x100: 227 vs 191).  Lanes are the proxy for size known at creation.
     e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change && n->n_lanes <= 20000);
     e->ringMerge = (cfg->ring_lanes_per_wave / 10000) % 10 != 4;
+    e->denseForm = cfg->dense_form ? (cfg->dense_form & 255) : CFX_DENSE_FORM_DEFAULT;
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
     e->timesDyadic = cfx_engine::dyadic(cfg->interval);
     e->R = n->n_roads;
@@ -909,7 +943,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
-        if ((rc = e->allocRaw(&e->interMask, (size_t) std::max(e->nMaskWords, 1)))) return rc;
+        if ((rc = e->allocRaw(&e->interMask, (size_t) std::max(e->nMaskWords, 1) + 2))) return rc;  // (+2: k_cross3_list reads two words per intersection)
     }
     if ((rc = e->allocRaw(&e->curPhase, (size_t) e->I))) return rc;
     if ((rc = e->allocRaw(&e->remain, (size_t) e->I))) return rc;
@@ -1042,9 +1076,25 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if ((rc = e->ensureVidCap((size_t) e->spawned + (size_t) n + (size_t) e->poolN))) return rc;
     }
     // ---- phase 0/1 tail: hand the spawn records to the device
-    SpawnBatch batch;  // (ring layout: the records go with kr_admit's arguments)
+    SpawnBatchBig batch;  // (the records go with the admission kernel's arguments: up to kAdmitRecs, kd_admit up to kAdmitRecsBig)
     batch.n = 0;
     batch.firstNewVid = 0;
+    const int batchRoom = (e->useTails() && (e->denseForm & 4)) ? kAdmitRecsBig : kAdmitRecs;
+    auto smallBatch = [&batch]() {  // (the kernels that take at most kAdmitRecs records)
+        SpawnBatch b;
+        b.n = batch.n;
+        b.firstNewVid = batch.firstNewVid;
+        b.enterTime = batch.enterTime;
+        for (int i = 0; i < batch.n && i < kAdmitRecs; ++i) {
+            b.lane[i] = batch.lane[i];
+            b.prevWait[i] = batch.prevWait[i];
+            b.route[i] = batch.route[i];
+            b.priority[i] = batch.priority[i];
+            b.templ[i] = batch.templ[i];
+            b.vidOff[i] = batch.vidOff[i];
+        }
+        return b;
+    };
     if (n > 0) {
         // the batch carries the next n vehicle numbers, each once, in any order (checked in full by the CPU twin)
         if (recs[0].vid < e->spawned || recs[0].vid >= e->spawned + n)
@@ -1053,7 +1103,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // ring layout: a step's few records go with kr_admit's arguments (each lane's thread links its own): no launch.  They
         // fit if they are few, all for lanes of this engine, and all enter at the same time (what a host spawner produces:
         // Engine::getCurrentTime); record i of the batch is vehicle spawned + i, whatever order they came in
-        bool inArgs = n <= kAdmitRecs;  // (kr_admit / kd_admit / k_admit take the batch)
+        bool inArgs = n <= batchRoom;  // (kr_admit / kd_admit / k_admit take the batch)
         // a custom speed waiting for one of these vehicles has to be in the vehicle table before the admission looks at it:
         // the records then take the k_spawn_link path and the speeds follow it on the stream (rare: push_vehicle + set_vehicle_speed)
         std::vector<std::pair<int32_t, double>> customNow;
@@ -1064,8 +1114,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             batch.n = (int) n;
             batch.firstNewVid = (int) e->spawned;
             batch.enterTime = recs[0].enter_time;
-            int order[kAdmitRecs];
-            bool seen[kAdmitRecs] = {};
+            int order[kAdmitRecsBig];
+            bool seen[kAdmitRecsBig] = {};
             for (int i = 0; inArgs && i < n; ++i) {
                 const int64_t off = (int64_t) recs[i].vid - e->spawned;
                 inArgs = off >= 0 && off < n && !seen[off] && recs[i].lane >= -1 && recs[i].enter_time == batch.enterTime &&
@@ -1172,9 +1222,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             int nStatPrev = 1;
             const RingCommit rkPrev = e->commitArgs(activeEst, true, &nStatPrev);
             e->launch(PK_ADMIT, kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
-                      e->admitStep, e->waitHead, e->vt, e->sc, batch, rkPrev);
+                      e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), rkPrev);
         } else {
-            e->launch(PK_ADMIT, kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{});
+            e->launch(PK_ADMIT, kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{});
         }
         RING_CHECK("kr_admit")
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
@@ -1244,7 +1294,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         }
         if (useBig)
             e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
-                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + kCross2Jobs - 1) / kCross2Jobs), 16384)),
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) 5 * e->nCU)),  // (5 blocks per CU: 95 registers)
                       dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
         {
@@ -1321,6 +1371,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if ((rc = e->allocRaw(&e->dTailNow, (size_t) e->D))) return rc;
         if ((rc = e->allocRaw(&e->dGate4, (size_t) std::max(e->K, 1)))) return rc;
     }
+    if (tails && e->cross3() && !e->x3Aux) {
+        if ((rc = e->allocRaw(&e->x3Aux, (size_t) std::max(e->K, 1)))) return rc;
+    }
     StepCtx c = e->ctx();
     if (tails && !e->tailsValid) {  // after a reset / cfx_load_state: the records of the generation the step starts from
         hipLaunchKernelGGL(kd_init_tails, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->dTail[0], e->dTail[1]);
@@ -1329,12 +1382,29 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     // grids: the slots the layout can hold; with lane change the room reserved for moving lanes lies behind them and is
     // covered by the kernels' stride loops in the (rare) step that uses much of it
     const size_t slotBound = std::min(need - (size_t) moveRoom() + (e->lc.on ? (size_t) 4096 : 0), e->slotCap);
+    // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
+    // throughput (far fewer wave-rounds per vehicle).  They break even at ~220 k slots on the MI355X.
+    const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
+    if (!(useBig && e->cross3())) c.llAuxD = nullptr;  // (only k_cross3_eval reads the laneLinks' aux records)
     if (e->lc.on && !e->lcSegValid) {  // after a reset / cfx_load_state
         hipLaunchKernelGGL(k_lc_naive, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         e->lcSegValid = true;
     }
-    if (tails) e->launch(PK_ADMIT, kd_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
-    else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch);
+    if (tails && c.laneAdmit) {
+        if (!e->gatePhase) {
+            if ((rc = e->allocRaw(&e->gatePhase, (size_t) 2 * std::max(e->I, 1)))) return rc;
+            HIP_TRY(hipMemsetAsync(e->gatePhase, 0xFF, (size_t) 2 * std::max(e->I, 1) * sizeof(int32_t), st));
+        }
+        if (batch.n > kAdmitRecs)
+            e->launch(PK_ADMIT, kd_admit<true, kAdmitRecsBig>, dim3(gridFor(e->L)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch, e->gatePhase);
+        else
+            e->launch(PK_ADMIT, kd_admit<true, kAdmitRecs>, dim3(gridFor(e->L)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch(), e->gatePhase);
+    } else if (tails) {
+        if (batch.n > kAdmitRecs)
+            e->launch(PK_ADMIT, kd_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch, (int32_t *) nullptr);
+        else
+            e->launch(PK_ADMIT, kd_admit<false, kAdmitRecs>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch(), (int32_t *) nullptr);
+    } else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch());
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap, e->finCount};
     if (e->lc.on) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
@@ -1363,20 +1433,75 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     const int nxt = e->cur ^ 1;
     // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
     // throughput (far fewer wave-rounds per vehicle).  They break even at ~220 k slots on the MI355X.
-    const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
     JobQueue jq{e->jobCount, e->crossJobs, (int) e->slotCap, &e->sc->overflow};
     {
         const int nVehBlocks = (int) std::min<size_t>(std::max<size_t>(1, (slotBound + kActBlock - 1) / kActBlock), 8192);
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
         if (tails) {
             const int nv = (int) ((slotBound + kDenseActBlock - 1) / kDenseActBlock), nl = (e->K + kDenseActBlock - 1) / kDenseActBlock;
-            e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
+            if (e->splitAction()) {
+                // followers far from their lane's end in a light launch, the rest listed for a heavy one (cfx_dense_kernels.h)
+                if (!e->heavyCount) {
+                    if ((rc = e->allocRaw(&e->heavyCount, (size_t) 2 * kHeavyShards * kHeavyCountStride))) return rc;
+                    HIP_TRY(hipMemsetAsync(e->heavyCount, 0, (size_t) 2 * kHeavyShards * kHeavyCountStride * sizeof(int32_t), st));
+                }
+                if (e->heavyCap < e->slotCap + 8192) {  // (every shard's room rounded up to whole wavefronts)
+                    if ((rc = e->grow(&e->heavyList, 0, e->slotCap + 8192))) return rc;
+                    e->heavyCap = e->slotCap + 8192;
+                }
+                if (e->heavyDirty) {  // after a reset / cfx_load_state the step counter's parity may have changed hands
+                    HIP_TRY(hipMemsetAsync(e->heavyCount, 0, (size_t) 2 * kHeavyShards * kHeavyCountStride * sizeof(int32_t), st));
+                    e->heavyDirty = false;
+                }
+                int32_t *const hc = e->heavyCount + (e->step & 1) * kHeavyShards * kHeavyCountStride,
+                               *const hn = e->heavyCount + ((e->step + 1) & 1) * kHeavyShards * kHeavyCountStride;
+                const int nvl = (int) ((slotBound + kDenseLightBlock - 1) / kDenseLightBlock), nll = (e->K + kDenseLightBlock - 1) / kDenseLightBlock;
+                const int shardCap = heavyShardCap(nvl * (kDenseLightBlock / 64));
+                e->launch(PK_ACTION, kd_action_light, dim3(nvl + nll), dim3(kDenseLightBlock), c, ao, e->heavyList, hc, hn, nvl);
+                e->launch(PK_ACTION_HEAVY, kd_action_heavy, dim3(kHeavyShards * (shardCap / 64)), dim3(kDenseActBlock), c, ao, jq,
+                          (const int32_t *) e->heavyList, (const int32_t *) hc, shardCap);
+            } else {
+                e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
+            }
         }
         else e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
                        nVehBlocks);
     }
-    if (useBig)
-        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + kCross2Jobs - 1) / kCross2Jobs), CFX_CROSS2_MAX_GRID)),
+    if (useBig && e->cross3()) {
+        if (e->x3Cap < e->slotCap) {
+            if ((rc = e->grow(&e->x3Rec, 0, e->slotCap))) return rc;
+            if ((rc = e->grow(&e->x3First, 0, e->slotCap))) return rc;
+            e->x3PairCap = (int) std::max<size_t>(8192, e->slotCap / 16);  // (4 pairs per slot in all: a vehicle lists ~3 where traffic is dense)
+            if ((rc = e->grow(&e->x3Pairs, 0, (size_t) e->x3PairCap * kPairShards))) return rc;
+            e->x3Cap = e->slotCap;
+        }
+        if (!e->x3PairCount) {
+            if ((rc = e->allocRaw(&e->x3PairCount, (size_t) 2 * kPairShards * kJobShardStride))) return rc;
+            HIP_TRY(hipMemsetAsync(e->x3PairCount, 0, (size_t) 2 * kPairShards * kJobShardStride * sizeof(int32_t), st));
+        }
+        if (e->x3Dirty) {  // after a reset / cfx_load_state the step counter's parity may have changed hands
+            HIP_TRY(hipMemsetAsync(e->x3PairCount, 0, (size_t) 2 * kPairShards * kJobShardStride * sizeof(int32_t), st));
+            e->x3Dirty = false;
+        }
+        Cross3 x3{e->x3Rec, e->x3First, e->x3Pairs, e->x3PairCount + (e->step & 1) * kPairShards * kJobShardStride,
+                  e->x3PairCount + ((e->step + 1) & 1) * kPairShards * kJobShardStride, e->x3PairCap};
+        // grids from the last completed step's counts (pinned mirror; the kernels stride over what a grid does not cover)
+        size_t jobsPerShard = (slotBound + kJobShards - 1) / kJobShards, pairsPerShard = (size_t) e->x3PairCap;
+        if (e->mirrorValid) {
+            const int lastJobs = __atomic_load_n(&e->hMirror->sc.nCrossJobs, __ATOMIC_RELAXED);
+            const int lastPairs = __atomic_load_n(&e->hMirror->sc.nCrossPairsMax, __ATOMIC_RELAXED);
+            if (lastJobs > 0) jobsPerShard = std::min(jobsPerShard, (size_t) lastJobs / kJobShards + (size_t) lastJobs / (4 * kJobShards) + 512);
+            if (lastPairs > 0) pairsPerShard = std::min(pairsPerShard, (size_t) lastPairs + (size_t) lastPairs / 4 + 512);
+        }
+        const int gridJ = kJobShards * (int) ((jobsPerShard + kCross3Block - 1) / kCross3Block);
+        const int gridL = kJobShards * (int) ((jobsPerShard * kCross3Quad + kCross3Block - 1) / kCross3Block);  // (a quad of lanes per vehicle)
+        const int gridP = kPairShards * (int) ((pairsPerShard + kCross3Block - 1) / kCross3Block);
+        e->launch(PK_CROSS, k_cross3_list<false>, dim3(gridL), dim3(kCross3Block), c, ao, jq, x3, RingLights{nullptr, nullptr, 0});
+        e->launch(PK_CROSS_EVAL, k_cross3_eval<false>, dim3(gridP), dim3(kCross3Block), c, ao, x3);
+        e->launch(PK_CROSS_FINISH, k_cross3_finish<false>, dim3(gridJ), dim3(kCross3Block), c, ao, jq, x3);
+    } else if (useBig)
+        // (the blocks the chip holds at once — 7 per CU: the kernel's LDS — or fewer for a short queue: the kernel sizes its batches)
+        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + 15) / 16), (size_t) CFX_CROSS2_BLOCKS_PER_CU * e->nCU)),
                   dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0});
     else
         e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
@@ -1394,7 +1519,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
               e->net.laneGhost, (const int2 *) e->admitRec, e->publishTo(), e->lc.on ? 1 : 0);
     // finish statistics: one extra block per 64 k slots (a rank sort of the step's finishers, see finishStatistics)
     const int nStat = (int) std::min<size_t>(std::max<size_t>(1, slotBound >> 16), 64);
-    e->launch(PK_SCATTER, k_scatter,
+    e->launch(PK_SCATTER, e->lc.on ? k_scatter<true> : k_scatter<false>,
               dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, e->ab,
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
@@ -1584,6 +1709,10 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->vehicle_steps = s.vehicleSteps;
     out->tie_events = s.tieEvents;
     for (int i = 0; i < 8; ++i) out->tie_drivables[i] = s.tieEvents > i ? s.tieDrv[i] : -1;
+    out->diag_cross_jobs = s.nCrossJobs;
+    out->diag_cross_pairs_max = s.nCrossPairsMax;
+    out->diag_heavy = s.nHeavy;
+    out->diag_pad = 0;
     return CFX_OK;
 }
 
@@ -2571,6 +2700,10 @@ int32_t cfx_trace_dump(const char *path, int32_t blocks) {
         return 0;
     }
     (void) hipDeviceSynchronize();
+    if (blocks < 0) {  // clear the stamps (a kernel whose blocks do not all stamp in every step)
+        (void) hipMemset(buf, 0, (size_t) 65536 * 8 * sizeof(long long));
+        return 0;
+    }
     std::vector<long long> h((size_t) blocks * 8);
     (void) hipMemcpy(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
     FILE *f = fopen(path, "wb");

@@ -71,6 +71,8 @@ struct DevScalars {
     int nFinishedStep;         // finished vehicles of the step in flight
     int overflow;              // set when an internal capacity was exceeded
     int nCrossJobs;            // vehicles queued for k_cross in the step in flight
+    int nHeavy;                // split action phase: vehicles the light launch listed for the heavy one in the last step
+    int nCrossPairsMax;        // three-launch cross phase: most (vehicle, cross) pairs one shard of the list held in the last step
     int nLeftUncounted;        // lane change: real vehicles of completed changes that left this step (not "finished")
     int ringNearFull;          // ring layout: some drivable's ring is within 8 vehicles of its capacity (sticky)
     int actionMaxT;            // ring layout: most vehicles one block of the action kernel had (blocks above 3/4 of a pass report)
@@ -1035,7 +1037,9 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(C c, Out o, JobQueue q) {
                 const double2 dd = c.n.xDD[e];   // {distance on this laneLink, distance on the peer laneLink}
                 const int4 xp = c.n.xPack[e];    // {peer laneLink, peer bit, peer roadLink type, -}
                 dOn = dd.x;
-                if (!(dOn < d0)) {
+                // (Cross::canPass lets a vehicle that can no longer yield pass before it looks at the other laneLink's vehicle,
+                // roadnet.cpp:617-618: tested here on what the lane already holds, in front of the notified vehicle's gathers)
+                if (!(dOn < d0) && canYield(self, dOn - d0)) {
                     if ((c.interMask[mb + (xp.y >> 6)] >> (xp.y & 63)) & 1ULL)
                         fail = !canPassActive(c, tv, s, self, dOn, t1, d0, xp.x, dd.y, xp.z, &foe);
                 }
@@ -1075,8 +1079,18 @@ __global__ __launch_bounds__(kCrossBlock) void k_cross(C c, Out o, JobQueue q) {
 // out again: this kernel's time is its three barrier-separated passes times the blocks that are not resident, not pass A's chain.)
 constexpr int kCross2Block = 256;
 constexpr int kCross2Jobs = 64;
+// The vehicles of a batch follow from the queue's length and the grid — ceil(jobs / blocks), in sixteens, up to kCross2JobsMax
+// — so that a grid of exactly the blocks the chip holds at once (the host asks for 7 per CU on the dense layout, 5 on the ring
+// layout: LDS / registers) takes the whole queue in ONE residency round.  (Round 5, measured with per-block stamps at 1 M
+// vehicles: 140 k queued vehicles were 2 200 fixed batches of 64 against 1 792 resident blocks — two rounds of a ~30 us batch,
+// the second one a quarter full, behind 14 000 empty blocks: 61 -> 48 us.)
+constexpr int kCross2JobsMax = 128;
+#ifndef CFX_CROSS2_A2U
+#define CFX_CROSS2_A2U 4
+#endif
+constexpr int kA2U = CFX_CROSS2_A2U;  // cross entries a thread of pass A2 requests per round
 #ifndef CFX_CROSS2_WORK
-#define CFX_CROSS2_WORK 2048
+#define CFX_CROSS2_WORK 1472  // (listed pairs per batch; what keeps the block's LDS at a seventh of a CU's)
 #endif
 constexpr int kCross2Work = CFX_CROSS2_WORK;
 
@@ -1105,11 +1119,17 @@ __device__ inline void passTimeAll(const DevNet &n, int32_t *curPhase, double *r
 template <bool LC, class C = StepCtx, class Out = ActionOut>
 __global__ __launch_bounds__(kCross2Block, C::kCross2Waves) void k_cross2(C c, Out o, JobQueue q, RingLights lights = RingLights{nullptr, nullptr, 0}) {
     // (nothing in this kernel reads the lights: the approaching vehicles' light test is folded into llDyn by the action kernel)
+    KSTAMP(8, 0);
     if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     __shared__ int shardEnd[kJobShards];
-    __shared__ int sS[kCross2Jobs], sT1[kCross2Jobs], sTempl[kCross2Jobs], sFirst[kCross2Jobs];
-    __shared__ double sD0[kCross2Jobs], sSpeed[kCross2Jobs];
+    __shared__ int sS[kCross2JobsMax], sT1[kCross2JobsMax], sTempl[kCross2JobsMax], sXs[kCross2JobsMax], sXe[kCross2JobsMax], sMb[kCross2JobsMax];
+    __shared__ unsigned long long sMask0[kCross2JobsMax];
+    __shared__ int sOff[kCross2JobsMax];
+    // (lowest failing cross entry << 32) | the vehicle that cross yields to: entries are unique per vehicle, so the minimum of
+    // these is the minimum over the entries, and pass C needs no second look at the cross (Cross::getFoeVehicle)
+    __shared__ unsigned long long sFirst[kCross2JobsMax];
+    __shared__ double sD0[kCross2JobsMax], sSpeed[kCross2JobsMax];
     __shared__ int sWorkJob[kCross2Work], sWorkE[kCross2Work];
     __shared__ int sNWork;
     const cfx_vehicle_template *tv = c.t.templ;
@@ -1129,8 +1149,10 @@ __global__ __launch_bounds__(kCross2Block, C::kCross2Waves) void k_cross2(C c, O
     }
     __syncthreads();
     const int nJ = shardEnd[kJobShards - 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) o.sc->nCrossJobs = nJ;  // (diagnostics; sizes the grids of the other forms)
+    KSTAMP(8, 1);
+    KNOTE(8, 5, nJ);
     const int tid = threadIdx.x;
-    const int g = tid % kCrossGroup, group = tid / kCrossGroup;
     constexpr int kGroups = kCross2Block / kCrossGroup;
     // Cross::canPass for the vehicle in slot `s` at cross entry e; a failing cross competes for "first of the vehicle"
     auto evaluate = [&](int jl, int s, double speed, int templ, int t1, double d0, int e) {
@@ -1138,49 +1160,107 @@ __global__ __launch_bounds__(kCross2Block, C::kCross2Waves) void k_cross2(C c, O
         const int4 xp = c.n.xPack[e];
         VehRef self{speed, &tv[templ]};
         int foe;
-        if (!canPassActive(c, tv, s, self, dd.x, t1, d0, xp.x, dd.y, xp.z, &foe)) atomicMin(&sFirst[jl], e);
+        if (!canPassActive(c, tv, s, self, dd.x, t1, d0, xp.x, dd.y, xp.z, &foe))
+            atomicMin(&sFirst[jl], ((unsigned long long) (unsigned) e << 32) | (unsigned long long) (unsigned) foe);
     };
-    for (int j0 = blockIdx.x * kCross2Jobs; j0 < nJ; j0 += gridDim.x * kCross2Jobs) {
-        if (tid < kCross2Jobs) sFirst[tid] = CFX_INT_MAX;
+    const int jpb = min(kCross2JobsMax, max(kGroups, (((nJ + (int) gridDim.x - 1) / (int) gridDim.x) + kGroups - 1) / kGroups * kGroups));
+    for (int j0 = blockIdx.x * jpb; j0 < nJ; j0 += gridDim.x * jpb) {
+        if (tid < jpb) sFirst[tid] = ~0ULL;
         if (tid == 0) sNWork = 0;
         __syncthreads();
-        // ---- pass A: list the (vehicle, cross) pairs that need a look
-        for (int rep = 0; rep < kCross2Jobs / kGroups; ++rep) {
-            const int jl = rep * kGroups + group;
-            if (j0 + jl >= nJ) continue;
-            int shard = 0;
-            while (j0 + jl >= shardEnd[shard]) ++shard;
-            const int s = q.jobs[(size_t) shard * q.capacity + (j0 + jl - (shard ? shardEnd[shard - 1] : 0))];
-            const int d = c.s.drv[s];
-            const int templ = slotTempl(c, s);
-            const double speed = slotSpeed(c, s);
-            const double dis = slotDis(c, s);
-            const int nd0 = slotNext(c, s);
-            const bool onLane = d < c.n.L;
-            const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
-            const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
-            const double d0 = onLane ? -(c.n.drvLength[d] - dis) : dis;
-            if (g == 0) {
-                sS[jl] = s;
-                sT1[jl] = lp.w;
-                sTempl[jl] = templ;
-                sD0[jl] = d0;
-                sSpeed[jl] = speed;
+        // ---- pass A1: one thread per vehicle of the batch: its record (queue -> slot columns -> laneLink record) into LDS.
+        // (Until round 5 every 16-lane group walked this chain for its own vehicle, rep after rep: with all of the chip's blocks
+        // in pass A at the same time that was 5 us per rep and 26 of the batch's 39 us at 1 M vehicles.)
+        if (tid < jpb) {
+            int xs = 0, xe = 0;
+            if (j0 + tid < nJ) {
+                int shard = 0;
+                while (j0 + tid >= shardEnd[shard]) ++shard;
+                const int s = q.jobs[(size_t) shard * q.capacity + (j0 + tid - (shard ? shardEnd[shard - 1] : 0))];
+                const int d = c.s.drv[s];
+                const int templ = slotTempl(c, s);
+                const double speed = slotSpeed(c, s);
+                const double dis = slotDis(c, s);
+                const int nd0 = slotNext(c, s);
+                const bool onLane = d < c.n.L;
+                const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
+                const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
+                sS[tid] = s;
+                sT1[tid] = lp.w;
+                sTempl[tid] = templ;
+                sD0[tid] = onLane ? -(c.n.drvLength[d] - dis) : dis;
+                sSpeed[tid] = speed;
+                sMb[tid] = lp.z;
+                sMask0[tid] = c.interMask[lp.z];  // (the intersection's first 64 laneLinks: all of them on most networks)
+                xs = lp.x;
+                xe = lp.y;
             }
-            for (int e = lp.x + g; e < lp.y; e += kCrossGroup) {
-                if (c.n.xDD[e].x < d0) continue;  // the cross is already behind the vehicle
-                const int bit = c.n.xPack[e].y;
-                if (!((c.interMask[lp.z + (bit >> 6)] >> (bit & 63)) & 1ULL)) continue;  // nobody to yield to there
+            sXs[tid] = xs;
+            sXe[tid] = xe;
+        }
+        __syncthreads();
+        if (j0 == (int) blockIdx.x * jpb) { KSTAMP(8, 7); }
+        // ---- pass A2: the batch's cross entries as ONE flat list (vehicle by vehicle, a prefix sum of their counts in LDS), four
+        // per thread and round of loads: which of them need a look.  (16-lane groups walking vehicle after vehicle were one
+        // dependent round per rep — 12 us of a 32 us batch with every block of the chip in this pass at once.)
+        if (tid < kCross2JobsMax) {  // inclusive prefix sum of the vehicles' entry counts: two wavefronts, then the second adds the first's total
+            int v = tid < jpb ? sXe[tid] - sXs[tid] : 0;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(v, off, 64);
+                if ((tid & 63) >= off) v += up;
+            }
+            sOff[tid] = v;
+        }
+        __syncthreads();
+        if (tid >= 64 && tid < kCross2JobsMax) sOff[tid] += sOff[63];
+        __syncthreads();
+        const int nE = sOff[kCross2JobsMax - 1];
+        for (int f0 = tid; f0 < nE; f0 += kA2U * kCross2Block) {
+            int jl4[kA2U], e4[kA2U];
+            double dOn4[kA2U];
+            int bit4[kA2U];
+#pragma unroll
+            for (int u = 0; u < kA2U; ++u) {
+                const int f = f0 + u * kCross2Block;
+                jl4[u] = -1;
+                if (f < nE) {
+                    int lo = 0, hi = kCross2JobsMax - 1;  // first vehicle whose inclusive count exceeds f
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (sOff[mid] > f) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    jl4[u] = lo;
+                    e4[u] = sXs[lo] + (f - (lo ? sOff[lo - 1] : 0));
+                    dOn4[u] = c.n.xDD[e4[u]].x;
+                    bit4[u] = c.n.xPack[e4[u]].y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kA2U; ++u) {
+                const int jl = jl4[u];
+                if (jl < 0) continue;
+                const double d0 = sD0[jl], speed = sSpeed[jl];
+                if (dOn4[u] < d0) continue;  // the cross is already behind the vehicle
+                // a vehicle that can no longer yield at this cross passes it whoever comes (Cross::canPass roadnet.cpp:617-618,
+                // tested before the other vehicle is looked at): such a pair needs no pass B
+                const int templ = sTempl[jl];
+                const VehRef self{speed, &tv[templ]};
+                if (!canYield(self, dOn4[u] - d0)) continue;
+                const int bit = bit4[u];
+                const unsigned long long word = (bit >> 6) == 0 ? sMask0[jl] : c.interMask[sMb[jl] + (bit >> 6)];
+                if (!((word >> (bit & 63)) & 1ULL)) continue;  // nobody to yield to there
                 const int w = atomicAdd(&sNWork, 1);
                 if (w < kCross2Work) {
                     sWorkJob[w] = jl;
-                    sWorkE[w] = e;
+                    sWorkE[w] = e4[u];
                 } else {
-                    evaluate(jl, s, speed, templ, lp.w, d0, e);  // list full (very busy junctions): look at it right away
+                    evaluate(jl, sS[jl], speed, templ, sT1[jl], d0, e4[u]);  // list full (very busy junctions): look at it right away
                 }
             }
         }
         __syncthreads();
+        if (j0 == (int) blockIdx.x * jpb) { KSTAMP(8, 2); }
         // ---- pass B: one thread per listed pair
         const int nW = sNWork < kCross2Work ? sNWork : kCross2Work;
         for (int w = tid; w < nW; w += kCross2Block) {
@@ -1188,8 +1268,9 @@ __global__ __launch_bounds__(kCross2Block, C::kCross2Waves) void k_cross2(C c, O
             evaluate(jl, sS[jl], sSpeed[jl], sTempl[jl], sT1[jl], sD0[jl], sWorkE[w]);
         }
         __syncthreads();
+        if (j0 == (int) blockIdx.x * jpb) { KSTAMP(8, 3); }
         // ---- pass C: one thread per vehicle
-        if (tid < kCross2Jobs && j0 + tid < nJ) {
+        if (tid < jpb && j0 + tid < nJ) {
             const int s = sS[tid];
             const cfx_vehicle_template &t = tv[sTempl[tid]];
             const double speed = sSpeed[tid], d0 = sD0[tid];
@@ -1199,19 +1280,316 @@ __global__ __launch_bounds__(kCross2Block, C::kCross2Waves) void k_cross2(C c, O
             const int nd0 = slotNext(c, s);
             double iv = o.parkedInterSpeed(s);  // partial intersection speed parked by k_action
             int blockerSlot = -1;
-            const int e = sFirst[tid];
-            if (e != CFX_INT_MAX) {
-                const double2 dd = c.n.xDD[e];
-                double d2;
-                blockerSlot = notifiedAt(c, tv, c.n.xPack[e].x, dd.y, &d2);  // the vehicle that cross made us yield to
+            const unsigned long long ff = sFirst[tid];
+            if (ff != ~0ULL) {
+                const int e = (int) (ff >> 32);
+                blockerSlot = (int) (unsigned) ff;  // the vehicle that cross made us yield to (pass B kept it with the entry)
                 VehRef self{speed, &t};
-                iv = min2(iv, stopBeforeSpeed(self, dd.x - d0 - t.yield_distance, c.interval));
+                iv = min2(iv, stopBeforeSpeed(self, c.n.xDD[e].x - d0 - t.yield_distance, c.interval));
                 blockerSlot = keepBlocker(c, blockerSlot);
             }
             finishAction<LC>(c, o, t, s, d, c.s.vid[s], speed, dis, dlen, nd0, min2(o.parkedSpeed(s), iv), blockerSlot);
         }
         __syncthreads();
+        if (j0 == (int) blockIdx.x * jpb) { KSTAMP(8, 4); }
     }
+    KSTAMP(8, 6);
+}
+
+// notified() for k_cross3_eval on the dense layout: from the laneLink's two records (llDyn + LLAuxD, written by llstateTails)
+// where they are kept — u, the first vehicle on the laneLink and f need no slot gather; a vehicle further back on the laneLink
+// takes the walk.  Same values as notifiedAt + the notified vehicle's template and speed.
+template <class C> __device__ __forceinline__ Notified crossNotified(const C &c, const cfx_vehicle_template *tv, int k, double x) {
+    return notified(c, tv, k, x);
+}
+__device__ inline Notified crossNotified(const StepCtx &c, const cfx_vehicle_template *tv, int k, double x) {
+    if (!c.llAuxD) return notified(c, tv, k, x);
+    const int4 dyn = c.llDyn[k];
+    Notified nf{-1, 0, 0.0, 0.0, false, 0, make_int2(-1, -1)};
+    if (dyn.x < 0 && dyn.y < 0 && dyn.w == 0) return nf;  // nobody to yield to on that laneLink (its aux record is stale)
+    const LLAuxD a = c.llAuxD[k];
+    if (dyn.x >= 0) {
+        const double vehDistance = a.uDis - tv[a.uTempl].len;
+        const double crossDistance = a.llLen - x;
+        if (crossDistance + vehDistance < 0.0) {
+            nf.slot = dyn.x;
+            nf.templ = a.uTempl;
+            nf.speed = a.uSpeed;
+            nf.dist = -(a.uDis + crossDistance);
+            return nf;
+        }
+    }
+    if (dyn.w > 0) {
+        if (!(a.oDis > x) || (a.oDis - x - tv[a.oTempl].len <= 0.0)) {
+            nf.slot = dyn.z;
+            nf.templ = a.oTempl;
+            nf.speed = a.oSpeed;
+            nf.dist = x - a.oDis;
+            return nf;
+        }
+        for (int i = 1; i < dyn.w; ++i) {
+            const int w = dyn.z + i;
+            const double vehDistance = c.s.dis[w];
+            const int wt = c.s.templ[w];
+            if (!(vehDistance > x) || (vehDistance - x - tv[wt].len <= 0.0)) {
+                nf.slot = w;
+                nf.templ = wt;
+                nf.speed = c.s.speed[w];
+                nf.dist = x - vehDistance;
+                return nf;
+            }
+        }
+    }
+    if (dyn.y >= 0) {
+        nf.slot = dyn.y;
+        nf.templ = a.fTempl;
+        nf.speed = a.fSpeed;
+        nf.dist = (a.startLen - a.fDis) + x;
+    }
+    return nf;
+}
+
+// ---- the cross phase in three launches (cfx_config::dense_form bit 3) --------------------------------------------------------
+// k_cross2 keeps a 256-thread block on 64 vehicles for three barrier-separated passes: pass A walks its 64 vehicles in four
+// rounds of sixteen 16-lane groups (four chains of dependent loads one after the other), pass C leaves three wavefronts of
+// four idle, and at 1 M vehicles the ~3 000 batches of a step do not fit the chip at once (7 blocks per CU by LDS): the kernel
+// lasts two residency rounds of a ~30 us batch.  Here every pass is a launch of its own with ONE THREAD PER ITEM and the
+// lists in HBM — the fewest wavefront-rounds the phase can be done in, and every launch fits the chip:
+//   k_cross3_list     one thread per queued vehicle: its record {speed, d0, template, roadLink type}, and the (vehicle, cross)
+//                     pairs that need Cross::canPass — cross ahead, the vehicle can still yield there (roadnet.cpp:617-618),
+//                     peer laneLink active — appended to one of kPairShards lists (one returning atomic per wavefront and
+//                     16 crosses; a vehicle's crosses are requested 16 at a time, not one per dependent round);
+//   k_cross3_eval     one thread per listed pair: Cross::canPass; atomicMin keeps the vehicle's lowest failing cross entry
+//                     (crosses are sorted by distance: the reference's first cross that cannot be passed);
+//   k_cross3_finish   one thread per queued vehicle: that cross's yield speed and blocker, the rest of the vehicle's step.
+// Same results as k_cross / k_cross2.  The lists' lengths are known on the device only: the host sizes the grids from the last
+// completed step's counts (pinned mirror) with room to spare, and every kernel strides over what its grid does not cover.
+constexpr int kPairShards = 64;
+constexpr int kCross3Block = 256;
+constexpr unsigned long long kCross3None = ~0ULL;
+// the vehicle's first failing cross with the vehicle it yields to there (Cross::getFoeVehicle): entries are unique per vehicle,
+// so the minimum over (entry << 32 | foe) is the minimum over the entries, and the finish needs no second look at the cross
+__device__ __forceinline__ void cross3Fail(unsigned long long *first, int s, int e, int foe) {
+    atomicMin(&first[s], ((unsigned long long) (unsigned) e << 32) | (unsigned long long) (unsigned) foe);
+}
+struct CrossJobRec {  // what k_cross3_eval needs of the vehicle: one 32-byte gather by slot
+    double speed, d0;
+    int32_t templ, t1, pad0, pad1;
+};
+static_assert(sizeof(CrossJobRec) == 32, "cross job record layout");
+struct Cross3 {
+    CrossJobRec *rec;      // [slot]
+    unsigned long long *first;  // [slot] (lowest failing cross entry of the vehicle << 32) | the vehicle that cross yields to; kCross3None: none
+    int2 *pairs;           // [kPairShards * pairCap] {slot, cross entry}
+    int32_t *pairCount;    // [kPairShards * kJobShardStride] this step's counters
+    int32_t *pairCountNext;  // ... the next step's (other parity): cleared by this step's first launch
+    int pairCap;           // per shard
+};
+// block b of a launch over the job queue: shard b % kJobShards, entries (b / kJobShards) * blockDim + thread, then strides
+struct JobWalk {
+    int shard, idx, stride, n;
+};
+__device__ __forceinline__ JobWalk jobWalk(const JobQueue &q) {
+    JobWalk w;
+    w.shard = (int) blockIdx.x & (kJobShards - 1);
+    w.idx = ((int) blockIdx.x / kJobShards) * (int) blockDim.x + (int) threadIdx.x;
+    w.stride = (((int) gridDim.x + kJobShards - 1 - w.shard) / kJobShards) * (int) blockDim.x;
+    w.n = min(q.count[w.shard * kJobShardStride], q.capacity);
+    return w;
+}
+
+template <class C>
+__device__ __forceinline__ const cfx_vehicle_template *stageTemplates(const C &c, cfx_vehicle_template *sT) {
+    if (c.t.nTempl > kLdsTempl) return c.t.templ;
+    const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+    const double *src = (const double *) c.t.templ;
+    double *dst = (double *) sT;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return sT;
+}
+
+// FOUR lanes per queued vehicle (a quad): they read the vehicle's crosses four consecutive entries at a time — one cache line
+// per quad and load instead of one per lane (one lane per vehicle walking its own run of entries made every load instruction
+// of a wavefront touch 64 different lines: 12 us of a 25 us launch went into those two loops, profiles/r05_trace_notes.txt)
+constexpr int kCross3Quad = 4;
+#ifndef CFX_X3_LIST_WAVES
+#define CFX_X3_LIST_WAVES 6
+#endif
+template <bool LC, class C = StepCtx, class Out = ActionOut>
+__global__ __launch_bounds__(kCross3Block, CFX_X3_LIST_WAVES) void k_cross3_list(C c, Out o, JobQueue q, Cross3 x, RingLights lights) {
+    KSTAMP(1, 0);
+    if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    if (blockIdx.x == 0 && threadIdx.x < kPairShards) x.pairCountNext[threadIdx.x * kJobShardStride] = 0;
+    constexpr int kJobsPerBlock = kCross3Block / kCross3Quad;
+    const int shardJ = (int) blockIdx.x & (kJobShards - 1);
+    const int nJ = min(q.count[shardJ * kJobShardStride], q.capacity);
+    const int jFirst = ((int) blockIdx.x / kJobShards) * kJobsPerBlock + (int) threadIdx.x / kCross3Quad;
+    const int jStride = (((int) gridDim.x + kJobShards - 1 - shardJ) / kJobShards) * kJobsPerBlock;
+    const int ql = (int) threadIdx.x & (kCross3Quad - 1);  // lane inside the quad
+    const cfx_vehicle_template *tv = stageTemplates(c, sT);
+    KSTAMP(1, 1);
+    KNOTE(1, 5, nJ);
+    const int wave = (int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    int32_t *const counter = x.pairCount + (wave & (kPairShards - 1)) * kJobShardStride;
+    int2 *const list = x.pairs + (size_t) (wave & (kPairShards - 1)) * x.pairCap;
+    const int lane = (int) (threadIdx.x & 63u);
+    // (the loops are wavefront-uniform: a quad without a vehicle walks an empty range)
+    for (int j = jFirst; __any(j < nJ); j += jStride) {
+        const bool have = j < nJ;
+        int s = 0, xs = 0, xe = 0, t1 = 0, templ = 0, maskBase = 0;
+        double speed = 0.0, d0 = 0.0;
+        if (have) {
+            s = q.jobs[(size_t) shardJ * q.capacity + j];
+            const int d = c.s.drv[s];
+            templ = slotTempl(c, s);
+            speed = slotSpeed(c, s);
+            const double dis = slotDis(c, s);
+            const int nd0 = slotNext(c, s);
+            const bool onLane = d < c.n.L;
+            const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
+            const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
+            d0 = onLane ? -(c.n.drvLength[d] - dis) : dis;
+            xs = lp.x;
+            xe = lp.y;
+            maskBase = lp.z;
+            t1 = lp.w;
+            if (ql == 0) {
+                CrossJobRec r;
+                r.speed = speed;
+                r.d0 = d0;
+                r.templ = templ;
+                r.t1 = t1;
+                r.pad0 = r.pad1 = 0;
+                x.rec[s] = r;
+                x.first[s] = kCross3None;
+            }
+        }
+        KSTAMP(1, 2);
+        const VehRef self{speed, &tv[templ]};
+        // the first two words of the intersection's active-laneLink mask (128 laneLinks: every intersection but monsters),
+        // requested with the first crosses instead of behind them
+        const unsigned long long m0 = c.interMask[maskBase], m1 = c.interMask[maskBase + 1];
+        for (int e0 = xs; __any(e0 < xe); e0 += 32) {
+            // the quad's next 32 crosses: lane ql takes entries e0 + ql, + 4, + 8, ... — {distance on this laneLink}, {peer's bit}
+            unsigned want = 0u;
+            double dOn[8];
+            int bit[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + kCross3Quad * k + ql;
+                const bool in = e < xe;
+                dOn[k] = in ? c.n.xDD[e].x : -1.0;
+                bit[k] = in ? c.n.xPack[e].y : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!(e0 + kCross3Quad * k + ql < xe)) continue;
+                if (dOn[k] < d0) continue;                  // the cross is already behind the vehicle
+                if (!canYield(self, dOn[k] - d0)) continue;  // it passes whoever comes (Cross::canPass roadnet.cpp:617-618)
+                const int wd = bit[k] >> 6;
+                const unsigned long long word = wd == 0 ? m0 : (wd == 1 ? m1 : c.interMask[maskBase + wd]);
+                if (!((word >> (bit[k] & 63)) & 1ULL)) continue;  // nobody to yield to there
+                want |= 1u << k;
+            }
+            // room in the wavefront's shard for everything its lanes list in this round: one returning atomic
+            const int mine = __popc(want);
+            int incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (total == 0) continue;
+            int base = 0;
+            if (lane == 63) base = atomicAdd(counter, total);
+            base = __shfl(base, 63, 64) + incl - mine;
+            unsigned rest = want;
+            while (rest) {
+                const int k = __ffs(rest) - 1;
+                rest &= rest - 1u;
+                const int e = e0 + kCross3Quad * k + ql;
+                if (base < x.pairCap) {
+                    list[base] = make_int2(s, e);
+                } else {  // list full (cannot happen with the host's sizing; never silent): look at the cross right away
+                    const double2 dd = c.n.xDD[e];
+                    const int4 xp = c.n.xPack[e];
+                    int foe;
+                    if (!canPassActive(c, tv, s, self, dd.x, t1, d0, xp.x, dd.y, xp.z, &foe)) cross3Fail(x.first, s, e, foe);
+                }
+                ++base;
+            }
+        }
+        KSTAMP(1, 3);
+    }
+    KSTAMP(1, 4);
+}
+
+template <bool LC, class C = StepCtx, class Out = ActionOut>
+__global__ __launch_bounds__(kCross3Block) void k_cross3_eval(C c, Out o, Cross3 x) {
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const int shard = (int) blockIdx.x & (kPairShards - 1);
+    const int n = min(x.pairCount[shard * kJobShardStride], x.pairCap);
+    const int first = ((int) blockIdx.x / kPairShards) * (int) blockDim.x + (int) threadIdx.x;
+    const int stride = (((int) gridDim.x + kPairShards - 1 - shard) / kPairShards) * (int) blockDim.x;
+    if (first - (int) threadIdx.x >= n) return;
+    KSTAMP(2, 0);
+    KNOTE(2, 5, n);
+    int2 pr = make_int2(0, 0);
+    if (first < n) pr = x.pairs[(size_t) shard * x.pairCap + first];  // (requested in front of the template barrier)
+    const cfx_vehicle_template *tv = stageTemplates(c, sT);
+    for (int i = first; i < n; i += stride) {
+        if (i != first) pr = x.pairs[(size_t) shard * x.pairCap + i];
+        const int s = pr.x, e = pr.y;
+        const CrossJobRec r = x.rec[s];
+        const double2 dd = c.n.xDD[e];
+        const int4 xp = c.n.xPack[e];
+        const VehRef self{r.speed, &tv[r.templ]};
+        int foe;
+        if (!canPassDecide(c, tv, s, self, dd.x, r.t1, r.d0, crossNotified(c, tv, xp.x, dd.y), xp.z, &foe)) cross3Fail(x.first, s, e, foe);
+    }
+    KSTAMP(2, 4);
+}
+
+template <bool LC, class C = StepCtx, class Out = ActionOut>
+__global__ __launch_bounds__(kCross3Block) void k_cross3_finish(C c, Out o, JobQueue q, Cross3 x) {
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (sizes the next steps' grids, through the host mirror)
+        int nJ = 0, maxPairs = 0;
+        for (int i = 0; i < kJobShards; ++i) nJ += min(q.count[i * kJobShardStride], q.capacity);
+        for (int i = 0; i < kPairShards; ++i) maxPairs = max(maxPairs, x.pairCount[i * kJobShardStride]);
+        o.sc->nCrossJobs = nJ;
+        o.sc->nCrossPairsMax = maxPairs;
+    }
+    const JobWalk w = jobWalk(q);
+    if (w.idx - (int) threadIdx.x >= w.n) return;
+    KSTAMP(3, 0);
+    KNOTE(3, 5, w.n);
+    int s0 = 0;
+    if (w.idx < w.n) s0 = q.jobs[(size_t) w.shard * q.capacity + w.idx];
+    const cfx_vehicle_template *tv = stageTemplates(c, sT);
+    for (int j = w.idx; j < w.n; j += w.stride) {
+        const int s = j == w.idx ? s0 : q.jobs[(size_t) w.shard * q.capacity + j];
+        const CrossJobRec r = x.rec[s];
+        const unsigned long long ff = x.first[s];
+        const cfx_vehicle_template &t = tv[r.templ];
+        const int d = c.s.drv[s];
+        const double dis = slotDis(c, s);
+        const double dlen = c.n.drvLength[d];
+        const int nd0 = slotNext(c, s);
+        double iv = o.parkedInterSpeed(s);  // partial intersection speed parked by the action kernel
+        int blockerSlot = -1;
+        if (ff != kCross3None) {
+            const int e = (int) (ff >> 32);
+            blockerSlot = (int) (unsigned) ff;  // the vehicle that cross made us yield to (k_cross3_eval kept it with the entry)
+            VehRef self{r.speed, &t};
+            iv = min2(iv, stopBeforeSpeed(self, c.n.xDD[e].x - r.d0 - t.yield_distance, c.interval));
+            blockerSlot = keepBlocker(c, blockerSlot);
+        }
+        finishAction<LC>(c, o, t, s, d, c.s.vid[s], r.speed, dis, dlen, nd0, min2(o.parkedSpeed(s), iv), blockerSlot);
+    }
+    KSTAMP(3, 4);
 }
 
 // Phase 5b in ONE launch: single-pass exclusive scan of the new segment sizes over drivables.
@@ -1565,6 +1943,7 @@ __global__ CFX_SCAN_BOUNDS void k_scan(int D, int L, const int32_t *cnt, Compact
 // (Engine::threadUpdateLocation / updateLocation engine.cpp:282-315,477-494; Vehicle::update
 // vehicle.cpp:107-143; Router::update router.cpp:78-94).  Low thread ids also advance the traffic
 // lights (TrafficLight::passTime trafficlight.cpp:29-37) and clear the active-laneLink masks.
+template <bool LC>  // (lane change as a separate instantiation: the common configuration carries none of its registers)
 __global__ CFX_SCATTER_BOUNDS void k_scatter(StepCtx c, ActionBuf b, CompactScratch cs, SlotArrays nx, const int32_t *segStartNext,
                           int32_t *oldToNew, int32_t *curPhase, double *remain, int rlTrafficLight, int nMaskWords,
                           int32_t *scanTicket, VidTable vt, DevScalars *sc, const int32_t *finList, double *finTerm,
@@ -1590,7 +1969,7 @@ __global__ CFX_SCATTER_BOUNDS void k_scatter(StepCtx c, ActionBuf b, CompactScra
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = nBody * blockDim.x;
     if (gid == 0 && scanTicket) *scanTicket = 0;  // k_scan of this step is done; re-arm it for the next one
-    if (gid == 0 && c.lc.on) {  // the lane-change lists of this step are consumed
+    if (LC && gid == 0 && c.lc.on) {  // the lane-change lists of this step are consumed
         *c.lc.insCount = 0;
         *c.lc.candAllCount = 0;
         *c.lc.insLaneCount = 0;
@@ -1705,7 +2084,7 @@ __global__ CFX_SCATTER_BOUNDS void k_scatter(StepCtx c, ActionBuf b, CompactScra
             nx.next[ns] = nextNew;
             nx.flags[ns] = (uint8_t) lastRoadBit(c, nd, route, nextNew);
         }
-        if (c.lc.on) {
+        if (LC && c.lc.on) {
             // threadUpdateAction's clearSignal (engine.cpp:424, lanechange.cpp:129-138) for every vehicle that stays in the
             // network, and where it now is.  (Nothing in this kernel reads these tables.)
             const LcDev &lc = c.lc;

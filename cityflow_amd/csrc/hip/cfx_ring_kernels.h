@@ -731,7 +731,6 @@ struct RingPush {
 };
 
 #ifdef CFX_TRACE
-__device__ long long *g_trace;  // [blocks * 8] wall-clock stamps of the action kernel's phases (developer build only)
 #define TRACE_STAMP(k) if (t == 0) g_trace[(size_t) w * 8 + (k)] = (long long) wall_clock64()
 #else
 #define TRACE_STAMP(k)
@@ -832,7 +831,13 @@ __global__ __launch_bounds__(kCrossBlock, CFX_KR_CROSS_WAVES) void kr_cross(Ring
                 const double2 dd = c.n.xDD[e];  // {distance on this laneLink, distance on the peer laneLink}
                 const int4 xp = c.n.xPack[e];   // {peer laneLink, peer bit, peer roadLink type, -}
                 dOn = dd.x;
+                // (a vehicle that can no longer yield passes whoever comes, Cross::canPass roadnet.cpp:617-618: tested in front
+                // of the notified vehicle's gathers)
+#ifdef CFX_NO_RING_PREFILTER
                 if (!(dOn < d0)) {
+#else
+                if (!(dOn < d0) && canYield(self, dOn - d0)) {
+#endif
                     const Notified nf = notifiedEager(c, tv, xp.x, dd.y);
                     fail = !canPassDecide(c, tv, s, self, dOn, jr.t1, d0, nf, xp.z, &foe);
                     if (nf.slot >= 0 && nf.pre) foeVid = nf.vid;  // (came with the notified vehicle's other columns)
@@ -870,6 +875,11 @@ __global__ __launch_bounds__(kCrossBlock, CFX_KR_CROSS_WAVES) void kr_cross(Ring
 // identity columns of a vehicle that may leave), then everything that depends on those (round B: the tail of the lane
 // behind the next laneLink), and only then is anything decided — the wave waits for memory twice instead of six times.
 __device__ __forceinline__ int4 gateRecord(const RingCtx &c, int k) { return c.llGate[k]; }
+__device__ __forceinline__ TailRec linkTailNow(const RingCtx &c, int d) { return c.tailNow[d]; }  // (kr_admit writes every drivable's)
+// the first record a head of a drivable requests: a laneLink head's end lane as committed, or a lane head's first laneLink as of now
+__device__ __forceinline__ TailRec firstHopRecord(const RingCtx &c, bool linkHead, int endLane, int firstLink) {
+    return *(linkHead ? &c.tailR[endLane] : &c.tailNow[firstLink]);
+}
 __device__ __forceinline__ bool viewerIsNew(const RingCtx &, const SlotIn &in, int) { return in.laneAdmitted && in.nNow == 1; }
 
 template <class C, class Out, class Push>
@@ -890,10 +900,10 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
     // (a head is either a lane's or a laneLink's: the first record is the lane head's first hop or the laneLink head's end lane)
     TailRec hopRec[3];
     double linkLen = 0.0;
-    if ((hopHead && in.hop.x >= 0) || linkHead) hopRec[0] = *(linkHead ? &c.tailR[nd0] : &c.tailNow[L + in.hop.x]);
+    if ((hopHead && in.hop.x >= 0) || linkHead) hopRec[0] = firstHopRecord(c, linkHead, nd0, L + in.hop.x);
     if (hopHead) {
-        if (in.hop.y >= 0) hopRec[1] = c.tailNow[L + in.hop.y];
-        if (in.hop.z >= 0) hopRec[2] = c.tailNow[L + in.hop.z];
+        if (in.hop.y >= 0) hopRec[1] = linkTailNow(c, L + in.hop.y);
+        if (in.hop.z >= 0) hopRec[2] = linkTailNow(c, L + in.hop.z);
         linkLen = c.n.drvLength[nd0];
     }
     int4 gate = make_int4(0, 0, 0, 0);

@@ -124,6 +124,7 @@ EngineConfig readEngineConfig(const std::string &configFile) {
             if (x->find("device")) c.device = x->intAt("device");
             if (x->find("ringLanesPerWave")) c.ringLanesPerWave = x->intAt("ringLanesPerWave");
             if (x->find("ringCapacityPercent")) c.ringCapacityPercent = x->intAt("ringCapacityPercent");
+            if (x->find("denseForm")) c.denseForm = x->intAt("denseForm");
             c.exactShadowPeek = x->boolAt("exactShadowPeek", false);
             c.laneHistory = x->boolAt("laneHistory", false);
             if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
@@ -144,6 +145,7 @@ void EngineConfig::apply(cfx_config &cc) const {
     cc.debug_sync = debugSync;
     cc.ring_lanes_per_wave = ringLanesPerWave;
     cc.ring_capacity_percent = ringCapacityPercent;
+    cc.dense_form = denseForm;
     cc.device = 0;
     // one process per GPU under torch.distributed.run: the launcher's LOCAL_RANK names the device
     if (const char *dev = getenv("LOCAL_RANK")) cc.device = atoi(dev);

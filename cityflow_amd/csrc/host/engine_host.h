@@ -206,7 +206,7 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
     std::string dir, roadnetFile, flowFile;
     std::string roadnetLogFile, replayLogFile;  // required with saveReplay (engine.cpp:73-77)
     // optional "cfx" object (ignored by the reference): implementation choices that never change results
-    int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0, ringCapacityPercent = 0;
+    int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0, ringCapacityPercent = 0, denseForm = 0;
     bool exactShadowPeek = false;  // host: Spawner::exactPeekOnly
     bool laneHistory = false;      // keep Lane::history on the device (cfx_config::lane_history): Archive dumps then carry it
     int hostThreads = -1;          // VectorEngine: worker threads for the per-environment host work (-1 auto, 0 serial)

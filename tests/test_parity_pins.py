@@ -249,7 +249,7 @@ def test_many_spawns_per_lane_in_one_step(mod, scen, workdir):
     many_spawns_body(mod, scen, workdir, _hip)
 
 
-def many_spawns_body(mod, scen, workdir, device, layouts=("ring", "dense")):
+def many_spawns_body(mod, scen, workdir, device, layouts=("ring", "dense"), **cfx):
     """The ring step links a step's spawn records inside kr_admit (they travel in its kernel arguments, sorted by lane): 60
     flows that all start on the same three lanes put ~20 records on a lane in one step — chains inside the batch, heads where
     the queue had drained, appends behind vehicles still waiting — and a second phase with more records than the arguments
@@ -276,7 +276,7 @@ def many_spawns_body(mod, scen, workdir, device, layouts=("ring", "dense")):
         json.dump(out, fh)
     cfg = scen.materialize("grid_6x6", workdir, flow_file=flow_file)
     for layout in layouts:
-        hip, tw = _pair(mod, cfg, device, layout=layout)
+        hip, tw = _pair(mod, cfg, device, layout=layout, **cfx)
         for s in range(220):
             hip.next_step()
             tw.next_step()

@@ -1,6 +1,8 @@
 """Developer tool: A/B of implementation choices (config "cfx") with the measurement rounds INTERLEAVED — every engine is
 built once, then round after round each engine in turn reloads the same Archive, takes a few instrumented steps and a timed
 run — so clock and thermal drift of the box hit every choice alike.  Prints the median per-kernel time and wall time per step.
+After the last round every engine has taken the same steps from the same Archive: their states are compared field by field with the
+first engine's (a choice that changes a result shows here before any pinned test is asked).
 usage: python tools/ab_bench.py [scenario] [rounds=N] 'layout=ring' 'layout=ring,ringLanesPerWave=40000' 'layout=dense,lib=gpurun_exp/libx.so' ..."""
 import json, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,6 +62,16 @@ for r in range(rounds):
         eng.sync()
         wall.append((time.perf_counter() - t0) / steps_timed * 1e6)
 print("scenario", scenario, "running", running, "rounds", rounds)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+try:
+    from conftest import assert_same_state
+    for spec, eng, _res, _wall in engines[1:]:
+        assert_same_state(engines[0][1], eng, "%s vs %s" % (engines[0][0], spec))
+    print("states equal after the last round:", len(engines), "engines")
+except AssertionError as ex:
+    print("STATE MISMATCH:", ex)
 for spec, eng, res, wall in engines:
+    sc = eng._scalars()
+    print("   diag", spec, {k: v for k, v in sc.items() if k.startswith("diag_")}, "running", sc["active_vehicle_count"])
     med = {k: round(statistics.median(v), 2) for k, v in res.items()}
     print("%-46s %s sum %.1f | wall us/step median %.1f min %.1f" % (spec, med, sum(med.values()), statistics.median(wall), min(wall)), flush=True)
