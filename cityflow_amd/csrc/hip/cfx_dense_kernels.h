@@ -251,40 +251,9 @@ __device__ inline void llstateTails(const StepCtx &c, int k) {
     const int nStart = cntNow(c, startLane);
     int f = nStart > 0 ? c.segStart[startLane] : -1;
     const int u = (tu.slot >= 0 && tu.prevDrv == d) ? tu.slot : -1;
-    // (with the three-launch cross phase: the state of f and of the first vehicle on the laneLink, requested with f's next drivable)
-    double fDis = 0.0, fSpeed = 0.0, oDis = 0.0, oSpeed = 0.0;
-    int fTempl = 0, oTempl = 0;
-    if (c.llAuxD) {
-        if (f >= 0) {
-            fDis = c.s.dis[f];
-            fSpeed = c.s.speed[f];
-            fTempl = c.s.templ[f];
-        }
-        if (nOn > 0) {
-            oDis = c.s.dis[firstOn];
-            oSpeed = c.s.speed[firstOn];
-            oTempl = c.s.templ[firstOn];
-        }
-    }
     if (f >= 0 && !((gateFlags & 1) && c.s.next[f] == d)) f = -1;
     c.llDyn[k] = make_int4(u, f, firstOn, nOn);
     if (u >= 0 || f >= 0 || nOn > 0) {
-        if (c.llAuxD) {
-            LLAuxD a;
-            a.uDis = tu.dis;
-            a.uSpeed = tu.speed;
-            a.uTempl = tu.templ;
-            a.fDis = fDis;
-            a.fSpeed = fSpeed;
-            a.fTempl = fTempl;
-            a.oDis = oDis;
-            a.oSpeed = oSpeed;
-            a.oTempl = oTempl;
-            a.llLen = c.n.drvLength[d];
-            a.startLen = c.n.drvLength[startLane];
-            a.pad = 0;
-            c.llAuxD[k] = a;
-        }
         const int in = c.n.llInter[k];
         const int bit = c.n.llLocal[k];
         atomicOr(&c.interMask[c.n.interMaskStart[in] + (bit >> 6)], 1ULL << (bit & 63));
@@ -303,39 +272,15 @@ constexpr int kDenseActBlock = CFX_KD_ACT_BLOCK;
 #ifndef CFX_KD_ACTION_WAVES
 #define CFX_KD_ACTION_WAVES 5
 #endif
-// the lane behind the vehicle's next laneLink from its own lane's static tables (as kw_action has it): Lane::canEnter's record is
-// then requested with everything else instead of behind the gate record
-__device__ __forceinline__ void knownEndLane(const StepCtx &c, SlotIn &in) {
-#ifdef CFX_KD_ENDLANE
-    const int4 en = c.n.laneEnd4[in.d];
-    const int ll = in.nd0 - c.n.L;
-    in.endLane = in.hop.x == ll ? en.x : (in.hop.y == ll ? en.y : (in.hop.z == ll ? en.z : (in.hop.w == ll ? en.w : -1)));
-#endif
-}
-// where the per-laneLink blocks (llstateTails) sit in the action launch: behind the vehicle blocks, or (CFX_LLSTATE_FIRST) in front
-__device__ __forceinline__ bool llstateBlock(int nVehicleBlocks, int *vehicleBlock, int *llBlock) {
-#ifdef CFX_LLSTATE_FIRST
-    const int nLL = (int) gridDim.x - nVehicleBlocks;
-    *vehicleBlock = (int) blockIdx.x - nLL;
-    *llBlock = (int) blockIdx.x;
-    return (int) blockIdx.x < nLL;
-#else
-    *vehicleBlock = (int) blockIdx.x;
-    *llBlock = (int) blockIdx.x - nVehicleBlocks;
-    return (int) blockIdx.x >= nVehicleBlocks;
-#endif
-}
 __global__ __launch_bounds__(kDenseActBlock, CFX_KD_ACTION_WAVES) void kd_action(StepCtx c, ActionOut o, JobQueue q, int nVehicleBlocks) {
-    int vb, lb;
     KSTAMP(6, 0);
-    if (llstateBlock(nVehicleBlocks, &vb, &lb)) {  // the per-laneLink notify sources for the cross phase
-        llstateTails(c, lb * (int) blockDim.x + (int) threadIdx.x);
+    if ((int) blockIdx.x >= nVehicleBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
+        llstateTails(c, ((int) blockIdx.x - nVehicleBlocks) * (int) blockDim.x + (int) threadIdx.x);
         KSTAMP(6, 4);
         KNOTE(6, 5, 1);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
-#ifdef CFX_NO_INLINE_TEMPL
     const cfx_vehicle_template *tv = c.t.templ;
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
@@ -345,14 +290,11 @@ __global__ __launch_bounds__(kDenseActBlock, CFX_KD_ACTION_WAVES) void kd_action
         __syncthreads();
         tv = sT;
     }
-#else
-    const cfx_vehicle_template *tv = stageTemplateTable(c, sT);
-#endif
     KSTAMP(6, 1);
     // (requesting the slot's columns in front of this barrier — so that they travel with the template table and the slot
     // count — was measured in round 4: 9.5 -> 9.3 us at 30x30, 46.8 -> 48.5 us at 1 M vehicles; not kept)
     const int S = c.segStart[c.n.L + c.n.K];
-    const int s = vb * (int) blockDim.x + (int) threadIdx.x;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0 && S > nVehicleBlocks * (int) blockDim.x) o.sc->overflow = 10;
     if (s < S) {
         SlotIn in = loadSlot(c, s);
@@ -361,164 +303,12 @@ __global__ __launch_bounds__(kDenseActBlock, CFX_KD_ACTION_WAVES) void kd_action
                 o.keep(s, in.dis, in.speed);
             } else {
                 in.lastRoadFlags = in.flags;  // (k_scatter / kd_admit / the halo import keep bit 1 up on this path)
-                if (in.d < c.n.L && in.nd0 >= c.n.L) {
-                    in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
-                    knownEndLane(c, in);
-                }
+                if (in.d < c.n.L && in.nd0 >= c.n.L) in.hop = c.n.laneLL4[in.d];  // (requested with the slot's columns)
                 actionOneRounds(c, o, tv, s, in, PushJob{q});
             }
         }
     }
     KSTAMP(6, 4);
-}
-
-// ---- kd_action in two launches (cfx_config::dense_form bit 0) -------------------------------------------
-// Every wavefront of kd_action walks all four dependent rounds of actionOneRounds, because every 64 consecutive slots hold
-// the heads of several lanes — yet about two vehicles in three are plain followers far from their lane's end: their leader is
-// the previous slot, they neither look at a gate nor at a tail record, and they cannot leave their lane in this step.
-//   kd_action_light   every slot; finishes those followers after TWO rounds (the slot's columns; the lane's constants) with a
-//                     fraction of the registers (eight wavefronts per SIMD), lists every other vehicle;
-//   kd_action_heavy   one thread per listed vehicle, full wavefronts of them: actionOneRounds as it is.
-// Same arithmetic, expression for expression (the follower branch of actionOneRounds + the stayer half of finishAction).
-// The list is kept in kHeavyShards shards, a light wavefront appends to the shard its number names (ONE returning atomic per
-// wavefront; one word takes ~88 of those per microsecond, and 18 k wavefronts on one counter made the light launch last 214 us
-// at 1 M vehicles): a shard receives at most every kHeavyShards-th wavefront's vehicles, so its room is known on the host, and
-// a heavy block works on the shard ITS number names — no prefix over the shards.  The counters exist twice, by step parity: a
-// step's light launch clears the set the NEXT step will count in (nobody reads that one during this step), so no memset sits
-// between the launches.
-#ifndef CFX_KD_LIGHT_BLOCK
-#define CFX_KD_LIGHT_BLOCK 256
-#endif
-constexpr int kDenseLightBlock = CFX_KD_LIGHT_BLOCK;
-#ifndef CFX_KD_LIGHT_WAVES
-#define CFX_KD_LIGHT_WAVES 8
-#endif
-constexpr int kHeavyShards = 64;
-constexpr int kHeavyCountStride = 32;  // ints between two counters (a cache line apart)
-// room per shard for a light grid of nWaves wavefronts
-__host__ __device__ constexpr int heavyShardCap(int nWaves) { return ((nWaves + kHeavyShards - 1) / kHeavyShards) * 64; }
-__global__ __launch_bounds__(kDenseLightBlock, CFX_KD_LIGHT_WAVES) void kd_action_light(StepCtx c, ActionOut o, int32_t *heavyList,
-                                                                                       int32_t *heavyCount, int32_t *heavyCountNext, int nVehicleBlocks) {
-    int vb, lb;
-    KSTAMP(5, 0);
-    if (llstateBlock(nVehicleBlocks, &vb, &lb)) {  // the per-laneLink notify sources for the cross phase
-        llstateTails(c, lb * (int) blockDim.x + (int) threadIdx.x);
-        KSTAMP(5, 4);
-        KNOTE(5, 5, 1);
-        return;
-    }
-    __shared__ cfx_vehicle_template sT[kLdsTempl];
-    const cfx_vehicle_template *tv = c.t.templ;
-    if (c.t.nTempl <= kLdsTempl) {
-        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
-        const double *src = (const double *) c.t.templ;
-        double *dst = (double *) sT;
-        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        tv = sT;
-    }
-    KSTAMP(5, 1);
-    const int S = c.segStart[c.n.L + c.n.K];
-    const int s = vb * (int) blockDim.x + (int) threadIdx.x;
-    if (s == 0 && S > nVehicleBlocks * (int) blockDim.x) o.sc->overflow = 10;
-    if (vb == 0 && threadIdx.x < kHeavyShards) heavyCountNext[threadIdx.x * kHeavyCountStride] = 0;
-    bool heavy = false;
-    if (s < S) {
-        const SlotIn in = loadSlot(c, s);
-        if (in.vid >= 0) {
-            if (c.n.laneGhost && in.d < c.n.L && c.n.laneGhost[in.d]) {  // tiling: proxy of a neighbour's vehicle, not stepped here
-                o.keep(s, in.dis, in.speed);
-            } else {
-                const cfx_vehicle_template &t = tv[in.templIdx];
-                const double interval = c.interval, speed = in.speed, dis = in.dis, dlen = in.lm.x;
-                const bool onLane = in.d < c.n.L, nextIsLink = in.nd0 >= c.n.L;
-                const bool related = !onLane || (nextIsLink && dlen - dis <= t.approach_dist);  // Vehicle::isIntersectionRelated
-                // (the bound actionOneRounds prefetches a possible leaver with: v <= speed + maxPosAcc * interval)
-                const bool mayLeave = dlen - dis <= (speed + t.max_pos_acc * interval) * interval + 1.0;
-                heavy = in.head || related || mayLeave || (in.flags & (kFlagCustom | kFlagStateGap)) != 0;
-                if (!heavy) {
-                    const cfx_vehicle_template &tl = tv[in.templPrev];
-                    const double gap = in.disPrev - tl.len - dis, leaderSpeed = in.speedPrev;
-                    double v = t.max_speed;
-                    v = min2(v, speed + t.max_pos_acc * interval);
-                    v = min2(v, in.lm.y);
-                    double cf = noCollisionSpeed(leaderSpeed, tl.max_neg_acc, speed, t.max_neg_acc, gap, interval, 0);
-                    double assumeDecel = 0;
-                    if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
-                    cf = min2(cf, noCollisionSpeed(leaderSpeed, tl.usual_neg_acc, speed, t.usual_neg_acc, gap, interval, t.min_gap));
-                    cf = min2(cf, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) /
-                                      (t.headway_time + interval / 2));
-                    v = min2(v, cf);
-                    v = min2(v, 100);
-                    if (in.nd0 < 0 && !(in.flags & kFlagLastRoad))
-                        v = min2(v, noCollisionSpeed(0, 1, speed, t.max_neg_acc, dlen - dis, interval, t.min_gap));
-                    v = max2(v, speed - t.max_neg_acc * interval);
-                    double deltaDis;
-                    if (v < 0) {
-                        deltaDis = 0.5 * speed * speed / t.max_neg_acc;
-                        v = 0;
-                    } else {
-                        deltaDis = (speed + v) * interval / 2;
-                    }
-                    const double ndis = deltaDis + dis;
-                    if (ndis > dlen) {
-                        heavy = true;  // (the bound above rules it out; the heavy kernel would do it right anyway)
-                    } else {
-                        o.b.dis[s] = ndis;
-                        o.b.speed[s] = v;
-                        o.b.drv[s] = -1;
-                        o.b.blocker[s] = -1;
-                    }
-                }
-            }
-        }
-    }
-    const int wave = vb * (int) (blockDim.x >> 6) + (int) (threadIdx.x >> 6);
-    const int shard = wave & (kHeavyShards - 1);
-    KSTAMP(5, 2);
-    const int at = waveListAppend(heavyCount + shard * kHeavyCountStride, heavy);
-    if (heavy) heavyList[(size_t) shard * heavyShardCap(nVehicleBlocks * (int) (blockDim.x >> 6)) + at] = s;
-    KSTAMP(5, 4);
-}
-
-// (block b works on shard b % kHeavyShards, on its entries [64 * (b / kHeavyShards), + 64); the grid covers every shard's room — the
-// lists' lengths are known on the device only — and a block beyond its shard's count returns at once)
-__global__ __launch_bounds__(kDenseActBlock, CFX_KD_ACTION_WAVES) void kd_action_heavy(StepCtx c, ActionOut o, JobQueue q,
-                                                                                      const int32_t *heavyList, const int32_t *heavyCount, int shardCap) {
-    static_assert(kDenseActBlock == 64, "one wavefront per block: a block's entries are 64 consecutive ones of its shard");
-    __shared__ cfx_vehicle_template sT[kLdsTempl];
-    const cfx_vehicle_template *tv = c.t.templ;
-    const int shard = (int) blockIdx.x & (kHeavyShards - 1);
-    const int i = ((int) blockIdx.x / kHeavyShards) * 64 + (int) threadIdx.x;
-    const int n = heavyCount[shard * kHeavyCountStride];
-    if (blockIdx.x == 0) {  // (diagnostics: cfx_scalars::diag_heavy)
-        int tot = heavyCount[(int) threadIdx.x * kHeavyCountStride];
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-        if (threadIdx.x == 0) o.sc->nHeavy = tot;
-    }
-    if (i - (int) threadIdx.x >= n) return;
-    KSTAMP(4, 0);
-    int s = 0;
-    if (i < n) s = heavyList[(size_t) shard * shardCap + i];  // (requested in front of the template barrier)
-    if (c.t.nTempl <= kLdsTempl) {
-        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
-        const double *src = (const double *) c.t.templ;
-        double *dst = (double *) sT;
-        for (int k = threadIdx.x; k < nd; k += blockDim.x) dst[k] = src[k];
-        __syncthreads();
-        tv = sT;
-    }
-    KSTAMP(4, 1);
-    if (i < n) {
-        SlotIn in = loadSlot(c, s);
-        in.lastRoadFlags = in.flags;
-        if (in.d < c.n.L && in.nd0 >= c.n.L) {
-            in.hop = c.n.laneLL4[in.d];
-            knownEndLane(c, in);
-        }
-        actionOneRounds(c, o, tv, s, in, PushJob{q});
-    }
-    KSTAMP(4, 4);
 }
 
 // The tail records after cfx_load_state / cfx_reset (k_scatter keeps them up afterwards): one thread per drivable

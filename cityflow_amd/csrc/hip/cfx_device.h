@@ -41,35 +41,11 @@ struct DevNet {
     const uint8_t *laneSpare;       // [L] spare slots behind the lane's vehicles (1 admission + halo migrants)
 };
 
-constexpr int kInlineTempl = 2;
 struct DevTables {
     const cfx_vehicle_template *templ;
     int nTempl;
     const int32_t *routeStart, *routeRoads, *nextStart, *nextLL;
-    // the first kInlineTempl templates BY VALUE (they travel in the kernel arguments): a network whose vehicles share one or
-    // two templates — the usual case — stages its LDS copy from scalar registers instead of behind a round trip to memory at the
-    // top of every block (1.3-1.6 us of a ~9 us block at 1 M vehicles)
-    cfx_vehicle_template inl[kInlineTempl];
 };
-// A block's LDS copy of the template table (all threads; ends with a barrier).  Returns the table to index: LDS, or the
-// table in memory when it has more entries than the LDS copy holds.
-template <class C, int N>
-__device__ __forceinline__ const cfx_vehicle_template *stageTemplateTable(const C &c, cfx_vehicle_template (&sT)[N]) {
-    if (c.t.nTempl > N) return c.t.templ;
-    if (c.t.nTempl <= kInlineTempl) {
-        if (threadIdx.x == 0) {
-            sT[0] = c.t.inl[0];
-            if (c.t.nTempl > 1) sT[1] = c.t.inl[1];
-        }
-    } else {
-        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
-        const double *src = (const double *) c.t.templ;
-        double *dst = (double *) sT;
-        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-    return sT;
-}
 
 // Committed per-slot state (double-buffered: rewritten in slot order by the compaction).
 struct SlotArrays {
@@ -187,7 +163,24 @@ __device__ inline void laneHistoryStep(const LaneHistDev &h, int lane, int n, Sp
     }
     double curSpeedSum = 0;
     hn += n;
-    for (int i = 0; i < n; ++i) curSpeedSum += speedAt(i);
+    // (the additions stay in list order — FP64 addition is not associative — but eight speeds are requested at a time: one
+    // round trip to memory per eight vehicles instead of one per vehicle)
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = speedAt(i + k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) curSpeedSum += v[k];
+    }
+    {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i + k < n ? speedAt(i + k) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i + k < n) curSpeedSum += v[k];
+    }
     speedSum += curSpeedSum;
     int tail = head + len;
     if (tail >= kLaneHistoryMax) tail -= kLaneHistoryMax;
@@ -218,15 +211,6 @@ struct LLAux {
     int32_t uTempl, fTempl;
 };
 static_assert(sizeof(LLAux) == 56, "laneLink aux record layout");
-
-// ... the dense layout's, for the three-launch cross phase (k_cross3_eval): also the first vehicle ON the laneLink, so that the
-// usual answers of "who was this cross notified of" — u, the first vehicle on the laneLink, f — come from the laneLink's two
-// records in ONE round instead of a chain of slot gathers
-struct LLAuxD {
-    double uDis, uSpeed, fDis, fSpeed, oDis, oSpeed, llLen, startLen;
-    int32_t uTempl, fTempl, oTempl, pad;
-};
-static_assert(sizeof(LLAuxD) == 80, "dense laneLink aux record layout");
 
 // What finishing a vehicle that leaves its drivable needs beyond its slot; valid = the caller requested it early
 // (actionOneRing, round A), otherwise it is loaded here.
@@ -282,7 +266,6 @@ struct StepCtx {
     // cfx_config::dense_form bit 1 (kd_admit over the lanes only): a laneLink's gate record is rewritten only when its
     // intersection's phase has changed (kd_admit<true>), its tail as this step sees it is the committed record (linkTailNow)
     int laneAdmit;
-    LLAuxD *llAuxD;           // [K] with the three-launch cross phase (dense_form bit 3), else null
     int32_t step;
     double interval;
     LcDev lc;
@@ -291,8 +274,8 @@ struct StepCtx {
 namespace cfxd {
 
 // Developer build (-DCFX_TRACE): per-block wall-clock stamps (100 MHz) of ONE kernel's phases, chosen at build time with
-// -DCFX_TRACE_KERNEL=<id> (0: the ring layout's kr_action / kr_cross as tools/trace_action.py reads them; 1 k_cross3_list, 2
-// k_cross3_eval, 3 k_cross3_finish, 4 kd_action_heavy, 5 kd_action_light, 6 kd_action, 7 k_scatter, 8 k_cross2); row = block index
+// -DCFX_TRACE_KERNEL=<id> (0: the ring layout's kr_action / kr_cross as tools/trace_action.py reads them; 6 kd_action, 8 k_cross2;
+// tools/trace_kernel.py); row = block index
 #ifdef CFX_TRACE
 __device__ long long *g_trace;  // [65536 * 8]
 #ifndef CFX_TRACE_KERNEL

@@ -31,13 +31,13 @@ namespace {
 std::string g_createError;
 
 #ifndef CFX_DENSE_FORM_DEFAULT
-#define CFX_DENSE_FORM_DEFAULT 0  // what cfx_config::dense_form = 0 means (see include/cityflow_amd.h)
+#define CFX_DENSE_FORM_DEFAULT 6  // what cfx_config::dense_form = 0 means (include/cityflow_amd.h): lanes-only admission, 1024 spawn records in its arguments
 #endif
-enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, PK_HALO_EXPORT, PK_HALO_IMPORT, PK_COMMIT, PK_ACTION_HEAVY, PK_CROSS_EVAL, PK_CROSS_FINISH, kNumProfKernels };
+enum ProfKernel { PK_SPAWN = 0, PK_ADMIT, PK_ACTION, PK_CROSS, PK_SCAN, PK_SCATTER, PK_HALO_EXPORT, PK_HALO_IMPORT, PK_COMMIT, kNumProfKernels };
 // names of the step's phases; the ring layout runs kr_admit / kr_action / k_cross<.., RingCtx> / kr_commit under the first
 // four and the last name (it has no scan / scatter)
 const char *const kProfNames[kNumProfKernels] = {"k_spawn_link", "k_admit", "k_action", "k_cross", "k_scan", "k_scatter",
-                                                 "k_halo_export", "k_halo_import", "k_commit", "k_action_heavy", "k_cross_eval", "k_cross_finish"};
+                                                 "k_halo_export", "k_halo_import", "k_commit"};
 
 #define HIP_TRY(call)                                                                                  \
     do {                                                                                               \
@@ -179,11 +179,8 @@ struct cfx_engine {
     int32_t *oldToNew2 = nullptr;      // [slot] lane change: scratch of k_lc_resolve (which items are done)
     // dense layout, cfx_config::dense_form: which organisation of the step's kernels (cfx_dense_kernels.h); results never depend on it
     int denseForm = 0;
-    bool splitAction() const { return (denseForm & 1) != 0; }
     bool laneAdmit() const { return (denseForm & 2) != 0 && useTails() && !tiled; }
     int32_t *gatePhase = nullptr;      // [2 I] laneAdmit(): the phase each intersection's gate records stand for (-1: none), by step parity
-    int32_t *heavyList = nullptr, *heavyCount = nullptr;  // the vehicles kd_action_light leaves to kd_action_heavy; two counters by step parity
-    size_t heavyCap = 0;
     int32_t *hPool = nullptr;          // ... pinned staging
     int32_t *hPoll = nullptr;          // pinned: [0] shadows created by the step, [1] overflow code, [2..] their parents in walk order
     hipEvent_t pollEvent = nullptr;    // the part of the step cfx_lane_change_poll has to wait for
@@ -194,18 +191,7 @@ struct cfx_engine {
     TailRec *dTail[2] = {nullptr, nullptr}, *dTailNow = nullptr;
     int4 *dGate4 = nullptr;
     bool lcSegValid = false;           // lane change: segOfSlot holds every vehicle's own segment (k_scatter / k_lc_naive)
-    // the cross phase in three launches (cfx_config::dense_form bit 3; k_cross3_* of cfx_kernels.h): its lists
-    bool cross3() const { return (denseForm & 8) != 0 && !ring && !lc.on; }
-    CrossJobRec *x3Rec = nullptr;
-    unsigned long long *x3First = nullptr;
-    LLAuxD *x3Aux = nullptr;
-    int32_t *x3PairCount = nullptr;
-    int2 *x3Pairs = nullptr;
-    size_t x3Cap = 0;                  // slots the per-slot lists are allocated for
-    int x3PairCap = 0;                 // pairs per shard
     bool tailsValid = false;           // the records describe the current generation (false after reset / load / resize)
-    bool heavyDirty = false;           // the heavy list's counters may hold a count (set wherever tailsValid is dropped)
-    bool x3Dirty = false;              // ... the pair lists' counters likewise
     bool useTails() const { return !ring && !lc.on; }  // (tiles too since round 3: the halo kernels keep the cut lanes' records up)
 
     // ---- ring layout (cfx_ring_kernels.h): per-drivable ring segments, committed in place ----
@@ -345,7 +331,6 @@ struct cfx_engine {
         c.n = net;
         c.t.templ = dTempl.p;
         c.t.nTempl = (int) hTempl.size();
-        for (int i = 0; i < kInlineTempl && i < (int) hTempl.size(); ++i) c.t.inl[i] = hTempl[i];
         c.t.routeStart = dRouteStart.p;
         c.t.routeRoads = dRouteRoads.p;
         c.t.nextStart = dNextStart.p;
@@ -373,7 +358,6 @@ struct cfx_engine {
             c.tailNow = dTailNow;
             c.llGate4 = dGate4;
             c.laneAdmit = laneAdmit() ? 1 : 0;
-            c.llAuxD = x3Aux;  // (null unless the three-launch cross phase runs)
         }
         return c;
     }
@@ -502,7 +486,6 @@ struct cfx_engine {
         c.n = net;
         c.t.templ = dTempl.p;
         c.t.nTempl = (int) hTempl.size();
-        for (int i = 0; i < kInlineTempl && i < (int) hTempl.size(); ++i) c.t.inl[i] = hTempl[i];
         c.t.routeStart = dRouteStart.p;
         c.t.routeRoads = dRouteRoads.p;
         c.t.nextStart = dNextStart.p;
@@ -644,7 +627,7 @@ struct cfx_engine {
         return RingCommit{rScratch, rMovers, waitHead, curPhase, remain, (int) cfg.rl_traffic_light, (int) nMaskWords,
                           sc, rFinKey, rFinVid, rFinTerm, rFinCap, jobCount,
                           tiled ? (HostMirror *) nullptr : hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
-                          lightsDone ? 1 : 0, publishTo(), finCount};
+                          lightsDone ? 1 : 0, publishTo(), finCount, tiled ? LaneHistDev{} : hist};
     }
     int settle() {
         if (!commitPending) return CFX_OK;
@@ -698,8 +681,6 @@ struct cfx_engine {
         hCntValid = false;
         futureCustom.clear();
         tailsValid = false;
-        heavyDirty = true;
-        x3Dirty = true;
         if (gatePhase) HIP_TRY(hipMemsetAsync(gatePhase, 0xFF, (size_t) 2 * std::max(I, 1) * sizeof(int32_t), stream));
         lcSegValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
@@ -943,7 +924,7 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         if ((rc = e->uploadConst(d.llLocal, llLocal.data(), llLocal.size()))) return rc;
         if ((rc = e->uploadConst(d.xPeerBit, xPeerBit.data(), xPeerBit.size()))) return rc;
         if ((rc = e->uploadConst(d.interMaskStart, maskStart.data(), maskStart.size()))) return rc;
-        if ((rc = e->allocRaw(&e->interMask, (size_t) std::max(e->nMaskWords, 1) + 2))) return rc;  // (+2: k_cross3_list reads two words per intersection)
+        if ((rc = e->allocRaw(&e->interMask, (size_t) std::max(e->nMaskWords, 1)))) return rc;
     }
     if ((rc = e->allocRaw(&e->curPhase, (size_t) e->I))) return rc;
     if ((rc = e->allocRaw(&e->remain, (size_t) e->I))) return rc;
@@ -1216,7 +1197,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;  // which form of the cross phase (§4)
         // This step's commit rides with the next step's admission (one launch less per step) where the step runs kr_cross,
         // which then advances the lights; the previous step's, if it is still pending, goes with this step's admission.
-        const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing && !e->hist.num;  // (a caller that reads the lane counts after every step wants the commit now)
+        const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing;  // (Lane::history rides with the commit)  // (a caller that reads the lane counts after every step wants the commit now)
         if (e->commitPending) {
             e->commitPending = false;
             int nStatPrev = 1;
@@ -1324,10 +1305,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->rcur ^= 1;
         e->step += 1;
         e->mirrorValid = !e->tiled;
-        if (e->hist.num && !e->tiled) {  // Lane::updateHistory, on the committed state
-            hipLaunchKernelGGL(kr_lane_history, dim3(gridFor(e->L)), dim3(kBlock), 0, st, e->rctx(), e->hist);
-            HIP_TRY(hipGetLastError());
-        }
         return CFX_OK;
     }
     const int64_t spare = e->tiled ? e->spareTotal : (int64_t) e->L;
@@ -1371,9 +1348,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if ((rc = e->allocRaw(&e->dTailNow, (size_t) e->D))) return rc;
         if ((rc = e->allocRaw(&e->dGate4, (size_t) std::max(e->K, 1)))) return rc;
     }
-    if (tails && e->cross3() && !e->x3Aux) {
-        if ((rc = e->allocRaw(&e->x3Aux, (size_t) std::max(e->K, 1)))) return rc;
-    }
     StepCtx c = e->ctx();
     if (tails && !e->tailsValid) {  // after a reset / cfx_load_state: the records of the generation the step starts from
         hipLaunchKernelGGL(kd_init_tails, dim3(gridFor(e->D)), dim3(kBlock), 0, st, c, e->dTail[0], e->dTail[1]);
@@ -1385,7 +1359,6 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     // Two organisations of the cross walk: for latency (fewest dependent rounds per vehicle) and, for large networks, for
     // throughput (far fewer wave-rounds per vehicle).  They break even at ~220 k slots on the MI355X.
     const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : slotBound > 240000;
-    if (!(useBig && e->cross3())) c.llAuxD = nullptr;  // (only k_cross3_eval reads the laneLinks' aux records)
     if (e->lc.on && !e->lcSegValid) {  // after a reset / cfx_load_state
         hipLaunchKernelGGL(k_lc_naive, dim3(gridStride(slotBound)), dim3(kBlock), 0, st, c);
         e->lcSegValid = true;
@@ -1439,67 +1412,12 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
         if (tails) {
             const int nv = (int) ((slotBound + kDenseActBlock - 1) / kDenseActBlock), nl = (e->K + kDenseActBlock - 1) / kDenseActBlock;
-            if (e->splitAction()) {
-                // followers far from their lane's end in a light launch, the rest listed for a heavy one (cfx_dense_kernels.h)
-                if (!e->heavyCount) {
-                    if ((rc = e->allocRaw(&e->heavyCount, (size_t) 2 * kHeavyShards * kHeavyCountStride))) return rc;
-                    HIP_TRY(hipMemsetAsync(e->heavyCount, 0, (size_t) 2 * kHeavyShards * kHeavyCountStride * sizeof(int32_t), st));
-                }
-                if (e->heavyCap < e->slotCap + 8192) {  // (every shard's room rounded up to whole wavefronts)
-                    if ((rc = e->grow(&e->heavyList, 0, e->slotCap + 8192))) return rc;
-                    e->heavyCap = e->slotCap + 8192;
-                }
-                if (e->heavyDirty) {  // after a reset / cfx_load_state the step counter's parity may have changed hands
-                    HIP_TRY(hipMemsetAsync(e->heavyCount, 0, (size_t) 2 * kHeavyShards * kHeavyCountStride * sizeof(int32_t), st));
-                    e->heavyDirty = false;
-                }
-                int32_t *const hc = e->heavyCount + (e->step & 1) * kHeavyShards * kHeavyCountStride,
-                               *const hn = e->heavyCount + ((e->step + 1) & 1) * kHeavyShards * kHeavyCountStride;
-                const int nvl = (int) ((slotBound + kDenseLightBlock - 1) / kDenseLightBlock), nll = (e->K + kDenseLightBlock - 1) / kDenseLightBlock;
-                const int shardCap = heavyShardCap(nvl * (kDenseLightBlock / 64));
-                e->launch(PK_ACTION, kd_action_light, dim3(nvl + nll), dim3(kDenseLightBlock), c, ao, e->heavyList, hc, hn, nvl);
-                e->launch(PK_ACTION_HEAVY, kd_action_heavy, dim3(kHeavyShards * (shardCap / 64)), dim3(kDenseActBlock), c, ao, jq,
-                          (const int32_t *) e->heavyList, (const int32_t *) hc, shardCap);
-            } else {
-                e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
-            }
+            e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
         }
         else e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
                        nVehBlocks);
     }
-    if (useBig && e->cross3()) {
-        if (e->x3Cap < e->slotCap) {
-            if ((rc = e->grow(&e->x3Rec, 0, e->slotCap))) return rc;
-            if ((rc = e->grow(&e->x3First, 0, e->slotCap))) return rc;
-            e->x3PairCap = (int) std::max<size_t>(8192, e->slotCap / 16);  // (4 pairs per slot in all: a vehicle lists ~3 where traffic is dense)
-            if ((rc = e->grow(&e->x3Pairs, 0, (size_t) e->x3PairCap * kPairShards))) return rc;
-            e->x3Cap = e->slotCap;
-        }
-        if (!e->x3PairCount) {
-            if ((rc = e->allocRaw(&e->x3PairCount, (size_t) 2 * kPairShards * kJobShardStride))) return rc;
-            HIP_TRY(hipMemsetAsync(e->x3PairCount, 0, (size_t) 2 * kPairShards * kJobShardStride * sizeof(int32_t), st));
-        }
-        if (e->x3Dirty) {  // after a reset / cfx_load_state the step counter's parity may have changed hands
-            HIP_TRY(hipMemsetAsync(e->x3PairCount, 0, (size_t) 2 * kPairShards * kJobShardStride * sizeof(int32_t), st));
-            e->x3Dirty = false;
-        }
-        Cross3 x3{e->x3Rec, e->x3First, e->x3Pairs, e->x3PairCount + (e->step & 1) * kPairShards * kJobShardStride,
-                  e->x3PairCount + ((e->step + 1) & 1) * kPairShards * kJobShardStride, e->x3PairCap};
-        // grids from the last completed step's counts (pinned mirror; the kernels stride over what a grid does not cover)
-        size_t jobsPerShard = (slotBound + kJobShards - 1) / kJobShards, pairsPerShard = (size_t) e->x3PairCap;
-        if (e->mirrorValid) {
-            const int lastJobs = __atomic_load_n(&e->hMirror->sc.nCrossJobs, __ATOMIC_RELAXED);
-            const int lastPairs = __atomic_load_n(&e->hMirror->sc.nCrossPairsMax, __ATOMIC_RELAXED);
-            if (lastJobs > 0) jobsPerShard = std::min(jobsPerShard, (size_t) lastJobs / kJobShards + (size_t) lastJobs / (4 * kJobShards) + 512);
-            if (lastPairs > 0) pairsPerShard = std::min(pairsPerShard, (size_t) lastPairs + (size_t) lastPairs / 4 + 512);
-        }
-        const int gridJ = kJobShards * (int) ((jobsPerShard + kCross3Block - 1) / kCross3Block);
-        const int gridL = kJobShards * (int) ((jobsPerShard * kCross3Quad + kCross3Block - 1) / kCross3Block);  // (a quad of lanes per vehicle)
-        const int gridP = kPairShards * (int) ((pairsPerShard + kCross3Block - 1) / kCross3Block);
-        e->launch(PK_CROSS, k_cross3_list<false>, dim3(gridL), dim3(kCross3Block), c, ao, jq, x3, RingLights{nullptr, nullptr, 0});
-        e->launch(PK_CROSS_EVAL, k_cross3_eval<false>, dim3(gridP), dim3(kCross3Block), c, ao, x3);
-        e->launch(PK_CROSS_FINISH, k_cross3_finish<false>, dim3(gridJ), dim3(kCross3Block), c, ao, jq, x3);
-    } else if (useBig)
+    if (useBig)
         // (the blocks the chip holds at once — 7 per CU: the kernel's LDS — or fewer for a short queue: the kernel sizes its batches)
         e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + 15) / 16), (size_t) CFX_CROSS2_BLOCKS_PER_CU * e->nCU)),
                   dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0});
@@ -1710,8 +1628,6 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->tie_events = s.tieEvents;
     for (int i = 0; i < 8; ++i) out->tie_drivables[i] = s.tieEvents > i ? s.tieDrv[i] : -1;
     out->diag_cross_jobs = s.nCrossJobs;
-    out->diag_cross_pairs_max = s.nCrossPairsMax;
-    out->diag_heavy = s.nHeavy;
     out->diag_pad = 0;
     return CFX_OK;
 }

@@ -71,8 +71,6 @@ struct DevScalars {
     int nFinishedStep;         // finished vehicles of the step in flight
     int overflow;              // set when an internal capacity was exceeded
     int nCrossJobs;            // vehicles queued for k_cross in the step in flight
-    int nHeavy;                // split action phase: vehicles the light launch listed for the heavy one in the last step
-    int nCrossPairsMax;        // three-launch cross phase: most (vehicle, cross) pairs one shard of the list held in the last step
     int nLeftUncounted;        // lane change: real vehicles of completed changes that left this step (not "finished")
     int ringNearFull;          // ring layout: some drivable's ring is within 8 vehicles of its capacity (sticky)
     int actionMaxT;            // ring layout: most vehicles one block of the action kernel had (blocks above 3/4 of a pass report)
@@ -1294,302 +1292,6 @@ __global__ __launch_bounds__(kCross2Block, C::kCross2Waves) void k_cross2(C c, O
         if (j0 == (int) blockIdx.x * jpb) { KSTAMP(8, 4); }
     }
     KSTAMP(8, 6);
-}
-
-// notified() for k_cross3_eval on the dense layout: from the laneLink's two records (llDyn + LLAuxD, written by llstateTails)
-// where they are kept — u, the first vehicle on the laneLink and f need no slot gather; a vehicle further back on the laneLink
-// takes the walk.  Same values as notifiedAt + the notified vehicle's template and speed.
-template <class C> __device__ __forceinline__ Notified crossNotified(const C &c, const cfx_vehicle_template *tv, int k, double x) {
-    return notified(c, tv, k, x);
-}
-__device__ inline Notified crossNotified(const StepCtx &c, const cfx_vehicle_template *tv, int k, double x) {
-    if (!c.llAuxD) return notified(c, tv, k, x);
-    const int4 dyn = c.llDyn[k];
-    Notified nf{-1, 0, 0.0, 0.0, false, 0, make_int2(-1, -1)};
-    if (dyn.x < 0 && dyn.y < 0 && dyn.w == 0) return nf;  // nobody to yield to on that laneLink (its aux record is stale)
-    const LLAuxD a = c.llAuxD[k];
-    if (dyn.x >= 0) {
-        const double vehDistance = a.uDis - tv[a.uTempl].len;
-        const double crossDistance = a.llLen - x;
-        if (crossDistance + vehDistance < 0.0) {
-            nf.slot = dyn.x;
-            nf.templ = a.uTempl;
-            nf.speed = a.uSpeed;
-            nf.dist = -(a.uDis + crossDistance);
-            return nf;
-        }
-    }
-    if (dyn.w > 0) {
-        if (!(a.oDis > x) || (a.oDis - x - tv[a.oTempl].len <= 0.0)) {
-            nf.slot = dyn.z;
-            nf.templ = a.oTempl;
-            nf.speed = a.oSpeed;
-            nf.dist = x - a.oDis;
-            return nf;
-        }
-        for (int i = 1; i < dyn.w; ++i) {
-            const int w = dyn.z + i;
-            const double vehDistance = c.s.dis[w];
-            const int wt = c.s.templ[w];
-            if (!(vehDistance > x) || (vehDistance - x - tv[wt].len <= 0.0)) {
-                nf.slot = w;
-                nf.templ = wt;
-                nf.speed = c.s.speed[w];
-                nf.dist = x - vehDistance;
-                return nf;
-            }
-        }
-    }
-    if (dyn.y >= 0) {
-        nf.slot = dyn.y;
-        nf.templ = a.fTempl;
-        nf.speed = a.fSpeed;
-        nf.dist = (a.startLen - a.fDis) + x;
-    }
-    return nf;
-}
-
-// ---- the cross phase in three launches (cfx_config::dense_form bit 3) --------------------------------------------------------
-// k_cross2 keeps a 256-thread block on 64 vehicles for three barrier-separated passes: pass A walks its 64 vehicles in four
-// rounds of sixteen 16-lane groups (four chains of dependent loads one after the other), pass C leaves three wavefronts of
-// four idle, and at 1 M vehicles the ~3 000 batches of a step do not fit the chip at once (7 blocks per CU by LDS): the kernel
-// lasts two residency rounds of a ~30 us batch.  Here every pass is a launch of its own with ONE THREAD PER ITEM and the
-// lists in HBM — the fewest wavefront-rounds the phase can be done in, and every launch fits the chip:
-//   k_cross3_list     one thread per queued vehicle: its record {speed, d0, template, roadLink type}, and the (vehicle, cross)
-//                     pairs that need Cross::canPass — cross ahead, the vehicle can still yield there (roadnet.cpp:617-618),
-//                     peer laneLink active — appended to one of kPairShards lists (one returning atomic per wavefront and
-//                     16 crosses; a vehicle's crosses are requested 16 at a time, not one per dependent round);
-//   k_cross3_eval     one thread per listed pair: Cross::canPass; atomicMin keeps the vehicle's lowest failing cross entry
-//                     (crosses are sorted by distance: the reference's first cross that cannot be passed);
-//   k_cross3_finish   one thread per queued vehicle: that cross's yield speed and blocker, the rest of the vehicle's step.
-// Same results as k_cross / k_cross2.  The lists' lengths are known on the device only: the host sizes the grids from the last
-// completed step's counts (pinned mirror) with room to spare, and every kernel strides over what its grid does not cover.
-constexpr int kPairShards = 64;
-constexpr int kCross3Block = 256;
-constexpr unsigned long long kCross3None = ~0ULL;
-// the vehicle's first failing cross with the vehicle it yields to there (Cross::getFoeVehicle): entries are unique per vehicle,
-// so the minimum over (entry << 32 | foe) is the minimum over the entries, and the finish needs no second look at the cross
-__device__ __forceinline__ void cross3Fail(unsigned long long *first, int s, int e, int foe) {
-    atomicMin(&first[s], ((unsigned long long) (unsigned) e << 32) | (unsigned long long) (unsigned) foe);
-}
-struct CrossJobRec {  // what k_cross3_eval needs of the vehicle: one 32-byte gather by slot
-    double speed, d0;
-    int32_t templ, t1, pad0, pad1;
-};
-static_assert(sizeof(CrossJobRec) == 32, "cross job record layout");
-struct Cross3 {
-    CrossJobRec *rec;      // [slot]
-    unsigned long long *first;  // [slot] (lowest failing cross entry of the vehicle << 32) | the vehicle that cross yields to; kCross3None: none
-    int2 *pairs;           // [kPairShards * pairCap] {slot, cross entry}
-    int32_t *pairCount;    // [kPairShards * kJobShardStride] this step's counters
-    int32_t *pairCountNext;  // ... the next step's (other parity): cleared by this step's first launch
-    int pairCap;           // per shard
-};
-// block b of a launch over the job queue: shard b % kJobShards, entries (b / kJobShards) * blockDim + thread, then strides
-struct JobWalk {
-    int shard, idx, stride, n;
-};
-__device__ __forceinline__ JobWalk jobWalk(const JobQueue &q) {
-    JobWalk w;
-    w.shard = (int) blockIdx.x & (kJobShards - 1);
-    w.idx = ((int) blockIdx.x / kJobShards) * (int) blockDim.x + (int) threadIdx.x;
-    w.stride = (((int) gridDim.x + kJobShards - 1 - w.shard) / kJobShards) * (int) blockDim.x;
-    w.n = min(q.count[w.shard * kJobShardStride], q.capacity);
-    return w;
-}
-
-template <class C>
-__device__ __forceinline__ const cfx_vehicle_template *stageTemplates(const C &c, cfx_vehicle_template *sT) {
-    if (c.t.nTempl > kLdsTempl) return c.t.templ;
-    const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
-    const double *src = (const double *) c.t.templ;
-    double *dst = (double *) sT;
-    for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-    return sT;
-}
-
-// FOUR lanes per queued vehicle (a quad): they read the vehicle's crosses four consecutive entries at a time — one cache line
-// per quad and load instead of one per lane (one lane per vehicle walking its own run of entries made every load instruction
-// of a wavefront touch 64 different lines: 12 us of a 25 us launch went into those two loops, profiles/r05_trace_notes.txt)
-constexpr int kCross3Quad = 4;
-#ifndef CFX_X3_LIST_WAVES
-#define CFX_X3_LIST_WAVES 6
-#endif
-template <bool LC, class C = StepCtx, class Out = ActionOut>
-__global__ __launch_bounds__(kCross3Block, CFX_X3_LIST_WAVES) void k_cross3_list(C c, Out o, JobQueue q, Cross3 x, RingLights lights) {
-    KSTAMP(1, 0);
-    if (lights.on) passTimeAll(c.n, lights.curPhase, lights.remain, c.interval, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-    __shared__ cfx_vehicle_template sT[kLdsTempl];
-    if (blockIdx.x == 0 && threadIdx.x < kPairShards) x.pairCountNext[threadIdx.x * kJobShardStride] = 0;
-    constexpr int kJobsPerBlock = kCross3Block / kCross3Quad;
-    const int shardJ = (int) blockIdx.x & (kJobShards - 1);
-    const int nJ = min(q.count[shardJ * kJobShardStride], q.capacity);
-    const int jFirst = ((int) blockIdx.x / kJobShards) * kJobsPerBlock + (int) threadIdx.x / kCross3Quad;
-    const int jStride = (((int) gridDim.x + kJobShards - 1 - shardJ) / kJobShards) * kJobsPerBlock;
-    const int ql = (int) threadIdx.x & (kCross3Quad - 1);  // lane inside the quad
-    const cfx_vehicle_template *tv = stageTemplates(c, sT);
-    KSTAMP(1, 1);
-    KNOTE(1, 5, nJ);
-    const int wave = (int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    int32_t *const counter = x.pairCount + (wave & (kPairShards - 1)) * kJobShardStride;
-    int2 *const list = x.pairs + (size_t) (wave & (kPairShards - 1)) * x.pairCap;
-    const int lane = (int) (threadIdx.x & 63u);
-    // (the loops are wavefront-uniform: a quad without a vehicle walks an empty range)
-    for (int j = jFirst; __any(j < nJ); j += jStride) {
-        const bool have = j < nJ;
-        int s = 0, xs = 0, xe = 0, t1 = 0, templ = 0, maskBase = 0;
-        double speed = 0.0, d0 = 0.0;
-        if (have) {
-            s = q.jobs[(size_t) shardJ * q.capacity + j];
-            const int d = c.s.drv[s];
-            templ = slotTempl(c, s);
-            speed = slotSpeed(c, s);
-            const double dis = slotDis(c, s);
-            const int nd0 = slotNext(c, s);
-            const bool onLane = d < c.n.L;
-            const int laneLink = onLane ? nd0 - c.n.L : d - c.n.L;
-            const int4 lp = c.n.llPack[laneLink];  // {first entry, end of entries, mask word base, RoadLinkType}
-            d0 = onLane ? -(c.n.drvLength[d] - dis) : dis;
-            xs = lp.x;
-            xe = lp.y;
-            maskBase = lp.z;
-            t1 = lp.w;
-            if (ql == 0) {
-                CrossJobRec r;
-                r.speed = speed;
-                r.d0 = d0;
-                r.templ = templ;
-                r.t1 = t1;
-                r.pad0 = r.pad1 = 0;
-                x.rec[s] = r;
-                x.first[s] = kCross3None;
-            }
-        }
-        KSTAMP(1, 2);
-        const VehRef self{speed, &tv[templ]};
-        // the first two words of the intersection's active-laneLink mask (128 laneLinks: every intersection but monsters),
-        // requested with the first crosses instead of behind them
-        const unsigned long long m0 = c.interMask[maskBase], m1 = c.interMask[maskBase + 1];
-        for (int e0 = xs; __any(e0 < xe); e0 += 32) {
-            // the quad's next 32 crosses: lane ql takes entries e0 + ql, + 4, + 8, ... — {distance on this laneLink}, {peer's bit}
-            unsigned want = 0u;
-            double dOn[8];
-            int bit[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int e = e0 + kCross3Quad * k + ql;
-                const bool in = e < xe;
-                dOn[k] = in ? c.n.xDD[e].x : -1.0;
-                bit[k] = in ? c.n.xPack[e].y : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (!(e0 + kCross3Quad * k + ql < xe)) continue;
-                if (dOn[k] < d0) continue;                  // the cross is already behind the vehicle
-                if (!canYield(self, dOn[k] - d0)) continue;  // it passes whoever comes (Cross::canPass roadnet.cpp:617-618)
-                const int wd = bit[k] >> 6;
-                const unsigned long long word = wd == 0 ? m0 : (wd == 1 ? m1 : c.interMask[maskBase + wd]);
-                if (!((word >> (bit[k] & 63)) & 1ULL)) continue;  // nobody to yield to there
-                want |= 1u << k;
-            }
-            // room in the wavefront's shard for everything its lanes list in this round: one returning atomic
-            const int mine = __popc(want);
-            int incl = mine;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            const int total = __shfl(incl, 63, 64);
-            if (total == 0) continue;
-            int base = 0;
-            if (lane == 63) base = atomicAdd(counter, total);
-            base = __shfl(base, 63, 64) + incl - mine;
-            unsigned rest = want;
-            while (rest) {
-                const int k = __ffs(rest) - 1;
-                rest &= rest - 1u;
-                const int e = e0 + kCross3Quad * k + ql;
-                if (base < x.pairCap) {
-                    list[base] = make_int2(s, e);
-                } else {  // list full (cannot happen with the host's sizing; never silent): look at the cross right away
-                    const double2 dd = c.n.xDD[e];
-                    const int4 xp = c.n.xPack[e];
-                    int foe;
-                    if (!canPassActive(c, tv, s, self, dd.x, t1, d0, xp.x, dd.y, xp.z, &foe)) cross3Fail(x.first, s, e, foe);
-                }
-                ++base;
-            }
-        }
-        KSTAMP(1, 3);
-    }
-    KSTAMP(1, 4);
-}
-
-template <bool LC, class C = StepCtx, class Out = ActionOut>
-__global__ __launch_bounds__(kCross3Block) void k_cross3_eval(C c, Out o, Cross3 x) {
-    __shared__ cfx_vehicle_template sT[kLdsTempl];
-    const int shard = (int) blockIdx.x & (kPairShards - 1);
-    const int n = min(x.pairCount[shard * kJobShardStride], x.pairCap);
-    const int first = ((int) blockIdx.x / kPairShards) * (int) blockDim.x + (int) threadIdx.x;
-    const int stride = (((int) gridDim.x + kPairShards - 1 - shard) / kPairShards) * (int) blockDim.x;
-    if (first - (int) threadIdx.x >= n) return;
-    KSTAMP(2, 0);
-    KNOTE(2, 5, n);
-    int2 pr = make_int2(0, 0);
-    if (first < n) pr = x.pairs[(size_t) shard * x.pairCap + first];  // (requested in front of the template barrier)
-    const cfx_vehicle_template *tv = stageTemplates(c, sT);
-    for (int i = first; i < n; i += stride) {
-        if (i != first) pr = x.pairs[(size_t) shard * x.pairCap + i];
-        const int s = pr.x, e = pr.y;
-        const CrossJobRec r = x.rec[s];
-        const double2 dd = c.n.xDD[e];
-        const int4 xp = c.n.xPack[e];
-        const VehRef self{r.speed, &tv[r.templ]};
-        int foe;
-        if (!canPassDecide(c, tv, s, self, dd.x, r.t1, r.d0, crossNotified(c, tv, xp.x, dd.y), xp.z, &foe)) cross3Fail(x.first, s, e, foe);
-    }
-    KSTAMP(2, 4);
-}
-
-template <bool LC, class C = StepCtx, class Out = ActionOut>
-__global__ __launch_bounds__(kCross3Block) void k_cross3_finish(C c, Out o, JobQueue q, Cross3 x) {
-    __shared__ cfx_vehicle_template sT[kLdsTempl];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (sizes the next steps' grids, through the host mirror)
-        int nJ = 0, maxPairs = 0;
-        for (int i = 0; i < kJobShards; ++i) nJ += min(q.count[i * kJobShardStride], q.capacity);
-        for (int i = 0; i < kPairShards; ++i) maxPairs = max(maxPairs, x.pairCount[i * kJobShardStride]);
-        o.sc->nCrossJobs = nJ;
-        o.sc->nCrossPairsMax = maxPairs;
-    }
-    const JobWalk w = jobWalk(q);
-    if (w.idx - (int) threadIdx.x >= w.n) return;
-    KSTAMP(3, 0);
-    KNOTE(3, 5, w.n);
-    int s0 = 0;
-    if (w.idx < w.n) s0 = q.jobs[(size_t) w.shard * q.capacity + w.idx];
-    const cfx_vehicle_template *tv = stageTemplates(c, sT);
-    for (int j = w.idx; j < w.n; j += w.stride) {
-        const int s = j == w.idx ? s0 : q.jobs[(size_t) w.shard * q.capacity + j];
-        const CrossJobRec r = x.rec[s];
-        const unsigned long long ff = x.first[s];
-        const cfx_vehicle_template &t = tv[r.templ];
-        const int d = c.s.drv[s];
-        const double dis = slotDis(c, s);
-        const double dlen = c.n.drvLength[d];
-        const int nd0 = slotNext(c, s);
-        double iv = o.parkedInterSpeed(s);  // partial intersection speed parked by the action kernel
-        int blockerSlot = -1;
-        if (ff != kCross3None) {
-            const int e = (int) (ff >> 32);
-            blockerSlot = (int) (unsigned) ff;  // the vehicle that cross made us yield to (k_cross3_eval kept it with the entry)
-            VehRef self{r.speed, &t};
-            iv = min2(iv, stopBeforeSpeed(self, c.n.xDD[e].x - r.d0 - t.yield_distance, c.interval));
-            blockerSlot = keepBlocker(c, blockerSlot);
-        }
-        finishAction<LC>(c, o, t, s, d, c.s.vid[s], r.speed, dis, dlen, nd0, min2(o.parkedSpeed(s), iv), blockerSlot);
-    }
-    KSTAMP(3, 4);
 }
 
 // Phase 5b in ONE launch: single-pass exclusive scan of the new segment sizes over drivables.

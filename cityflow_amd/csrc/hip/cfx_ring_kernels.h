@@ -284,6 +284,7 @@ struct RingCommit {
     int lightsDone;  // the step's cross kernel has already advanced the lights (kr_cross with lights.on)
     int32_t *hostCnt;  // pinned host copy of the lane counts, kept up by the commit while a caller observes them (or null)
     int32_t *finCount; // [kFinShards * 32] the finisher lists' counters
+    LaneHistDev hist;  // Lane::history (num == nullptr: not kept): a lane's record is taken by the thread that commits the lane
 };
 struct CommitOut {  // what a drivable's commit leaves, for the admission that follows it in the same thread
     int touched, head, n, tailWritten;
@@ -342,6 +343,9 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 if (co.tailWritten) committed = co.tail;
             }
         }
+        // Lane::updateHistory on the committed lane (engine.cpp:429-442): its vehicles in list order, their new speeds in the
+        // generation the action phase wrote (the movers-in by this very thread just now)
+        if (isLane && k.hist.num) laneHistoryStep(k.hist, d, n, [&](int i) { return cIn.kinN[ringSlot(geo, head, i)].y; });
     }
     RingCtx c = cIn;
     if constexpr (COMMIT) {  // the next step's view: what the commit wrote is what the admission reads
@@ -1595,7 +1599,15 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
     commitClearMasks(c, k, gid, stride);
     if (!k.rlTrafficLight && !k.lightsDone) passTimeAll(c.n, k.curPhase, k.remain, c.interval, gid, stride);
     const int D = c.n.L + c.n.K;
-    for (int d = gid; d < D; d += stride) commitDrivable(c, k, d);
+    for (int d = gid; d < D; d += stride) {
+        CommitOut co;
+        commitDrivable(c, k, d, &co);
+        if (d < c.n.L && k.hist.num) {
+            const int2 geo = c.ringGeo[d];
+            const int head = co.touched ? co.head : c.head[d], n = co.touched ? co.n : c.cnt[d];
+            laneHistoryStep(k.hist, d, n, [&](int i) { return c.kinN[ringSlot(geo, head, i)].y; });
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- slow paths

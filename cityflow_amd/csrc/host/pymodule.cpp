@@ -447,8 +447,6 @@ PYBIND11_MODULE(_cityflow, m) {
                      if (s.tie_drivables[i] >= 0) td.append(s.tie_drivables[i]);
                  d["tie_drivables"] = td;
                  d["diag_cross_jobs"] = s.diag_cross_jobs;
-                 d["diag_cross_pairs_max"] = s.diag_cross_pairs_max;
-                 d["diag_heavy"] = s.diag_heavy;
                  return d;
              })
         .def("_layout", &EngineHost::layoutName)

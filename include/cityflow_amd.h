@@ -117,14 +117,10 @@ typedef struct cfx_config {
                                * lane change needs to know: each environment has its own schedule walk and its own priority
                                * stream (see "Lane change" below) */
     int32_t dense_form;       /* dense layout, developer knob (0 = the engine decides): 256 + a bit mask of how the step's kernels
-                               * are organised — 1: the action phase as a light launch over every slot (plain followers far from
-                               * their lane's end) and a heavy one over the listed rest; 2: the admission kernel over the lanes
-                               * only (laneLink gates kept by whoever changes a light, laneLink tails read from the committed
-                               * records); 4: up to 1024 (instead of 128) spawn records of a step travel in the admission kernel's arguments; 8:
-                               * the throughput form of the cross phase as three launches with one thread per item (list the
-                               * (vehicle, cross) pairs, evaluate them, finish the vehicles) instead of k_cross2.  Results
-                               * never depend on it
-                               * (tests/test_parity_pins.py) */
+                               * are organised — 2: the admission kernel over the lanes only (a laneLink's gate record rewritten
+                               * only when its intersection's phase has changed, laneLink tails read from the committed
+                               * records); 4: up to 1024 (instead of 128) spawn records of a step travel in the admission
+                               * kernel's arguments.  256 = both off.  Results never depend on it (tests/test_dense_forms.py) */
 } cfx_config;
 #define CFX_CROSS_AUTO 0
 #define CFX_CROSS_LATENCY 1
@@ -173,9 +169,9 @@ typedef struct cfx_scalars {
      * the last reset / load) is kept at index i % 8; -1 = none yet, or not known (a tiled engine does not report them).
      * A checker uses them to see WHERE two correct engines may differ from then on. */
     int32_t tie_drivables[8];
-    /* diagnostics of the last step (0 where an implementation does not count them; never part of a result): vehicles handed to
-     * the cross phase, the most (vehicle, cross) pairs one shard of its list held, vehicles the action phase listed as heavy */
-    int32_t diag_cross_jobs, diag_cross_pairs_max, diag_heavy, diag_pad;
+    /* diagnostic of the last step (0 where an implementation does not count it; never part of a result): vehicles handed to
+     * the cross phase */
+    int32_t diag_cross_jobs, diag_pad;
 } cfx_scalars;
 
 /* Full per-vehicle state of every running vehicle, caller-allocated SoA (any pointer may be NULL).

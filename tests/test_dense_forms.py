@@ -1,12 +1,12 @@
 """GPU (-m gpu): the organisations of the dense layout's step that cfx_config::dense_form selects (config "cfx": denseForm =
-256 + bits; include/cityflow_amd.h) against the CPU twin — bit 0: the action phase as a light launch over every slot plus a
-heavy one over the listed rest (kd_action_light / kd_action_heavy, cfx_dense_kernels.h); bit 1: the admission kernel over the
-lanes only; bit 2: up to 1024 spawn records of a step in the admission kernel's arguments; bit 3: the throughput form of the
-cross phase as three launches with one thread per item (k_cross3_list / _eval / _finish, cfx_kernels.h).  256 = every bit off (the single kd_action, kd_admit over all drivables).  Each form is forced on the networks
-where the step's corner cases live (the 1x1 example with up to 118 crosses per laneLink, the congested 6x6, irregular
-networks, the bench workload through its demand build-up, an RL-driven run that changes phases every other step) and must
-give the twin's bits on every vehicle field.  Reference semantics: src/engine/engine.cpp:402-413 (threadGetAction),
-502-516 (handleWaiting), src/vehicle/vehicle.cpp:308-335 (getNextSpeed)."""
+256 + bits; include/cityflow_amd.h) against the CPU twin — bit 1: the admission kernel over the lanes only (kd_admit<true>: a
+laneLink's gate record rewritten only when its intersection's phase has changed, laneLink tails read from the committed
+records); bit 2: up to 1024 spawn records of a step in the admission kernel's arguments.  256 = both off (kd_admit over all
+drivables, k_spawn_link beyond 128 records); 0 (the default) = both on.  Each form is forced on the networks where the step's
+corner cases live (the 1x1 example with up to 118 crosses per laneLink, the congested 6x6, irregular networks, the bench workload
+through its demand build-up, an RL-driven run that changes phases every other step, resets and loads in between) with both forms
+of the cross phase, and must give the twin's bits on every vehicle field.  Reference semantics: src/engine/engine.cpp:502-516
+(handleWaiting), 317-372 (threadNotifyCross), src/roadnet/roadnet.cpp:603-676 (Cross::canPass), roadnet.h:429-431 (isAvailable)."""
 import json
 import os
 
@@ -18,19 +18,17 @@ from test_parity_pins import _pair, _bench_cfg, _hip, many_spawns_body
 
 pytestmark = pytest.mark.gpu
 
-FORMS = [256, 257, 258, 259, 263, 264, 270, 271]
+FORMS = [256, 258, 260, 262]
 
 
 def _cross_for(form):
-    """Bit 3 replaces the THROUGHPUT form of the cross phase, which small networks only run when told to."""
-    return "throughput" if form & 8 else "auto"
+    """Small networks run the throughput form of the cross phase (k_cross2) only when told to: half of the forms do."""
+    return "throughput" if form & 2 else "auto"
 
 
 @pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("cross", ["latency", "throughput"])
 def test_dense_forms_example_every_step(mod, scen, workdir, form, cross):
-    if form & 8 and cross == "latency":
-        pytest.skip("bit 3 is a form of the throughput cross phase")
     hip, tw = _pair(mod, scen.materialize("example_1x1", workdir), layout="dense", crossMode=cross, denseForm=form)
     for s in range(400):
         hip.next_step()
@@ -115,7 +113,7 @@ def test_dense_forms_rl_control_and_reset(mod, scen, workdir, form):
     drive(hip2, tw2, 60, "rl after load")
 
 
-@pytest.mark.parametrize("form", [257, 259, 270])
+@pytest.mark.parametrize("form", [256, 262])
 def test_dense_forms_bench_workload(mod, workdir, form):
     import bench
     hip, tw = _pair(mod, _bench_cfg(workdir), layout="dense", crossMode="throughput", denseForm=form)
@@ -129,7 +127,7 @@ def test_dense_forms_bench_workload(mod, workdir, form):
     assert hip.get_average_travel_time() == tw.get_average_travel_time()
 
 
-@pytest.mark.parametrize("form", [260, 262, 263])
+@pytest.mark.parametrize("form", [260, 262])
 def test_dense_forms_many_spawns_per_lane(mod, scen, workdir, form):
     """Hundreds of spawn records in one step, ~20 of them on one lane, travel in kd_admit's arguments (bit 2: up to 1024; the
     body is tests/test_parity_pins.py's: chains inside the batch, heads where the queue had drained, appends behind vehicles
