@@ -55,6 +55,7 @@ template <typename T> struct DBuf {
 
 inline int gridFor(size_t n) { return (int) std::max<size_t>(1, (n + kBlock - 1) / kBlock); }
 // grid-stride kernels over slots: enough blocks to fill 256 CUs x 8, never more than needed
+constexpr size_t kInitialVidCap = (size_t) 1 << 22;  // vehicle numbers the tables are sized for at creation (46 B each; 100 with lane change)
 inline int gridStride(size_t n) { return (int) std::min<size_t>(std::max<size_t>(1, (n + kBlock - 1) / kBlock), 2048); }
 
 }  // namespace
@@ -120,6 +121,7 @@ struct cfx_engine {
     // array equals the device's counts as of the last step enqueued (every commit since it was filled has published);
     // `observing` is dropped again after kObserveIdle steps without a read.
     std::map<int32_t, double> futureCustom;  // cfx_set_vehicle_speed for vehicle numbers the next spawn records will create
+    int64_t droppedFutureSpeeds = 0;         // ... of which the next step's records then did not create the vehicle
     std::vector<int32_t> phaseSeen;  // cfx_set_tl_phases: the call that last named each intersection (duplicates: last one wins)
     int32_t phaseCall = 0;
     int32_t *hCnt = nullptr;
@@ -312,6 +314,27 @@ struct cfx_engine {
         *p = np;
         return CFX_OK;
     }
+    // ... without draining the stream: the copy is ordered on the stream like everything else, the old array is freed later
+    // (retired; hipFree waits for the device) — at the next cfx_sync / reset / destroy.  For the tables that grow with the
+    // vehicles ever created: a step that doubles them does not stall (round 4: ten arrays x (malloc + drain + free) = 70 ms).
+    std::vector<void *> retired;
+    template <typename T> int growDeferred(T **p, size_t keep, size_t newCap) {
+        T *np = nullptr;
+        int rc = allocRaw(&np, newCap);
+        if (rc) return rc;
+        if (*p && keep) HIP_TRY(hipMemcpyAsync(np, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        if (*p) retired.push_back(*p);  // (still in `owned`: cfx_destroy frees whatever is left)
+        *p = np;
+        return CFX_OK;
+    }
+    int freeRetired() {  // only where the stream is known to be idle
+        for (void *q : retired) {
+            forget(q);
+            HIP_TRY(hipFree(q));
+        }
+        retired.clear();
+        return CFX_OK;
+    }
     template <typename T> int upload(T **dst, const T *src, size_t n) {
         int rc = allocRaw(dst, n);
         if (rc) return rc;
@@ -364,20 +387,23 @@ struct cfx_engine {
 
     int ensureVidCap(size_t need) {
         if (need <= vidCap) return CFX_OK;
-        size_t nc = std::max<size_t>(need, std::max<size_t>(vidCap * 2, 1 << 16));
+        // (cfx_config::ring_capacity_percent below 100 — the tests' "start small" knob — also starts the vehicle tables small,
+        // so that their growth path runs)
+        const size_t first = (cfg.ring_capacity_percent > 0 && cfg.ring_capacity_percent < 100) ? (size_t) 1 << 12 : kInitialVidCap;
+        size_t nc = std::max<size_t>(need, std::max<size_t>(vidCap * 2, first));
         int rc;
-        if (ring && (rc = grow(&slotOf, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.priority, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.templ, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.route, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.nextWait, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.enterTime, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.state, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.customSpeed, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.gapState, (size_t) spawned, nc))) return rc;
-        if ((rc = grow(&vt.pendingCustom, (size_t) spawned, nc))) return rc;
+        if (ring && (rc = growDeferred(&slotOf, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.priority, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.templ, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.route, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.nextWait, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.enterTime, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.state, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.customSpeed, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.gapState, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.pendingCustom, (size_t) spawned, nc))) return rc;
         if (lc.on) {
-#define GROW_LC(f) if ((rc = grow(&lc.f, (size_t) spawned, nc))) return rc;
+#define GROW_LC(f) if ((rc = growDeferred(&lc.f, (size_t) spawned, nc))) return rc;
             GROW_LC(ptype) GROW_LC(partner) GROW_LC(offset) GROW_LC(sigSend) GROW_LC(sendDir) GROW_LC(sendUrg) GROW_LC(lastDir)
             GROW_LC(changing) GROW_LC(lcFinished) GROW_LC(sendTarget) GROW_LC(recvFrom) GROW_LC(tLeader) GROW_LC(tFollower)
             GROW_LC(leaderGap) GROW_LC(followerGap) GROW_LC(lastChangeTime) GROW_LC(gap) GROW_LC(slotOf) GROW_LC(bSpeed)
@@ -677,6 +703,7 @@ struct cfx_engine {
     int resetState() {
         commitPending = false;  // (whatever a deferred commit would have written is overwritten below)
         HIP_TRY(hipStreamSynchronize(stream));
+        if (!retired.empty() && freeRetired()) return CFX_ERR_DEVICE;
         mirrorValid = false;
         hCntValid = false;
         futureCustom.clear();
@@ -982,8 +1009,20 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
         HIP_TRY(hipMemset(lc.candAllCount, 0, sizeof(int32_t)));
         HIP_TRY(hipEventCreateWithFlags(&e->pollEvent, hipEventDisableTiming));
     }
-    if ((rc = e->ensureSlotCap((size_t) e->L + 4096))) return rc;
-    if ((rc = e->ensureVidCap(1 << 16))) return rc;
+    // Capacities for the run, taken once: slots for half of what the network holds bumper to bumper (5 m per vehicle; the
+    // dense layout only — the ring layout has its own rings), vehicle numbers for kInitialVidCap vehicles between two resets.
+    // Both still grow when a run outgrows them, the vehicle tables without draining the stream (growDeferred) — but a step of
+    // an ordinary run never allocates (round 4's 70 ms hiccup in the 200-step windows was the vehicle table doubling from 64 k).
+    {
+        size_t slots = (size_t) e->L + 4096;
+        if (!e->ring) {
+            double jam = 0;
+            for (int d = 0; d < e->D; ++d) jam += std::ceil(e->hDrvLength[d] / 5.0);
+            slots = std::max(slots, std::min<size_t>((size_t) (jam / 2) + (size_t) e->L + 4096, (size_t) 1 << 24));
+        }
+        if ((rc = e->ensureSlotCap(slots))) return rc;
+    }
+    if ((rc = e->ensureVidCap(1))) return rc;
     return e->resetState();
 }
 
@@ -1161,7 +1200,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         }
         e->spawned += n;
     }
-    e->futureCustom.clear();  // (what this batch did not create was not a vehicle of this step)
+    for (const auto &fc : e->futureCustom)  // (what this batch did not create was not a vehicle of this step: counted, not silent)
+        if (fc.first >= e->spawned) e->droppedFutureSpeeds += 1;
+    e->futureCustom.clear();
     // ---- slot capacity.  Two host-side upper bounds of the vehicles that can be running after this step:
     //   (a) spawned - finished (as of the last read)           — tight while nobody queues for long;
     //   (b) running (as of the last read) + what can have been admitted since: at most one vehicle per step on every
@@ -1514,6 +1555,7 @@ int32_t cfx_sync(cfx_engine *e) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!e->retired.empty()) return e->freeRetired();  // (arrays a growing vehicle table left behind: the stream is idle now)
     return CFX_OK;
 }
 
@@ -1628,7 +1670,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->tie_events = s.tieEvents;
     for (int i = 0; i < 8; ++i) out->tie_drivables[i] = s.tieEvents > i ? s.tieDrv[i] : -1;
     out->diag_cross_jobs = s.nCrossJobs;
-    out->diag_pad = 0;
+    out->dropped_future_speeds = (int32_t) std::min<int64_t>(e->droppedFutureSpeeds, INT32_MAX);
     return CFX_OK;
 }
 
@@ -1875,14 +1917,16 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
 }
 
 int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
-    if (e && vid >= e->spawned && vid < e->spawned + 65536) {
-        // a vehicle the next spawn records will create (pushed since the last step): kept until then, see cfx_step
+    if (!e) return CFX_ERR_INVALID;
+    if (vid < 0 || vid >= e->spawned + CFX_FUTURE_SPEED_WINDOW) {
+        e->err = "cfx_set_vehicle_speed: no such vehicle";
+        return CFX_ERR_INVALID;
+    }
+    if (vid >= e->spawned) {
+        // a vehicle the next spawn records will create (pushed since the last step): kept until then, see cfx_step — which
+        // counts the speeds whose vehicle its records did not create (cfx_scalars::dropped_future_speeds)
         e->futureCustom[vid] = speed;
         return CFX_OK;
-    }
-    if (!e || vid < 0 || vid >= e->spawned) {
-        if (e) e->err = "cfx_set_vehicle_speed: no such vehicle";
-        return CFX_ERR_INVALID;
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));

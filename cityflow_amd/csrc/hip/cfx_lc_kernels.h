@@ -527,6 +527,8 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                             if (insLane[j] == target && insAnchor[j] == anchor && insSeq[j] >= seq) seq = insSeq[j] + 1.0;
                     }
                     lc.ins[idx] = LcInsert{vid, s, target, -1, dis, lc.gap[vid], anchor, mySeg, seq};
+                    // (a walk position beyond the field would spill into the next environment's range: code 12, never silent)
+                    if (!oneEnv && myKey >= (1 << kLcEnvShift)) sc->overflow = 12;
                     lc.insKey[idx] = ((oneEnv ? 0 : env) << kLcEnvShift) + myKey;  // shadows are created, and numbered, in walk order (k_lc_insert)
                     // LaneChange::insertShadow lanechange.cpp:98-100: the follower's leader is the shadow from now on — a
                     // later candidate of this walk that copies itself (its own shadow) copies this gap too

@@ -45,6 +45,9 @@ public:
     std::vector<std::string> flowIds;
 
     void dump(const std::string &path) const;
+    // numbers of the last dump() that NO decimal literal makes the reference's reader return exactly (about one double in 10^5:
+    // archive.cpp num()); they are written with 17 digits — exact for a correctly rounding reader — and reported on stderr
+    mutable long lastDumpInexact = 0;
     std::string vehicleId(int vid) const;
 };
 
@@ -53,6 +56,7 @@ public:
 // The literal Archive::dump writes for a double: one that a correctly rounding reader AND the reference's (rapidjson's
 // default number reader, json_number.h) both turn back into exactly `v`.
 std::string formatJsonNumber(double v);
+long inexactJsonNumbers();  // how many numbers formatted on this thread so far had no such literal (see Archive::lastDumpInexact)
 
 Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadNet> &net, Spawner &spawner, bool laneChange);
 

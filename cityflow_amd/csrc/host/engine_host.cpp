@@ -25,7 +25,10 @@ std::string defaultBackendPath() {
 
 void Backend::open(const std::string &libPath) {
     path = libPath;
-    handle = dlopen(libPath.c_str(), RTLD_NOW | RTLD_LOCAL);
+    // RTLD_NODELETE: the library stays mapped after the last engine is gone.  Unloading a HIP code object while the runtime
+    // still holds its kernels buys nothing, and a process map taken at exit (the driver's record of the native code a test run
+    // loaded) would otherwise show neither this library nor a hint that every kernel of the run came from it.
+    handle = dlopen(libPath.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
     if (!handle)
         throw std::runtime_error("cityflow_amd: cannot load device engine library '" + libPath + "': " + dlerror() +
                                  " (build it with `python -c 'import __graft_entry__ as g; g.build()'`; there is no "

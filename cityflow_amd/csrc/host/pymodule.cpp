@@ -447,6 +447,7 @@ PYBIND11_MODULE(_cityflow, m) {
                      if (s.tie_drivables[i] >= 0) td.append(s.tie_drivables[i]);
                  d["tie_drivables"] = td;
                  d["diag_cross_jobs"] = s.diag_cross_jobs;
+                 d["dropped_future_speeds"] = s.dropped_future_speeds;
                  return d;
              })
         .def("_layout", &EngineHost::layoutName)
@@ -685,7 +686,9 @@ PYBIND11_MODULE(_cityflow, m) {
 
     py::class_<cfa::Archive>(m, "Archive")
         .def(py::init([](EngineHost &e) { return e.snapshot(); }), "engine"_a)
-        .def("dump", &cfa::Archive::dump, "path"_a);
+        .def("dump", &cfa::Archive::dump, "path"_a)
+        .def_readonly("_last_dump_inexact", &cfa::Archive::lastDumpInexact,
+                      "numbers of the last dump() the reference's JSON reader cannot be made to return exactly (written with 17 digits)");
 
     m.def("_load_roadnet", &loadRoadnet, "path"_a);
     m.def("_roadnet_probe", &roadnetProbe, "path"_a);
@@ -700,6 +703,7 @@ PYBIND11_MODULE(_cityflow, m) {
         return py::make_tuple(v.asDouble(), v.integral);
     });
     m.def("_format_json_number", &cfa::formatJsonNumber);
+    m.def("_inexact_json_numbers", &cfa::inexactJsonNumbers);
 #ifdef CITYFLOW_AMD_VERSION
     m.attr("__version__") = CITYFLOW_AMD_VERSION;
 #else

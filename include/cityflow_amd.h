@@ -108,7 +108,9 @@ typedef struct cfx_config {
                                   * kernel, 2 block-granular, 3 the second form (cfx_ring2_kernels.h), 4 as 0 with the commit
                                   * as a launch of its own.  Results never depend on it (tests/test_parity_pins.py) */
     int32_t ring_capacity_percent; /* ring layout: initial ring capacities as a percentage of the bumper-to-bumper bound
-                                    * (0 = 100).  Small values make the growth path run (tests); results never depend on it */
+                                    * (0 = 100).  Small values make the growth path run (tests) — of the rings and, below 100,
+                                    * of the vehicle tables too (they start at 4 k instead of 4 M vehicle numbers); results
+                                    * never depend on it */
     int32_t lane_history;     /* keep Lane::history (roadnet.cpp:900-915; see cfx_get_lane_history) — one more pass over the lanes
                                * per step, for numbers only Archive dumps show; not on tiles */
     int32_t n_envs;           /* 0 or 1: one simulation.  E > 1: the network is E disjoint copies of one network with their
@@ -171,7 +173,10 @@ typedef struct cfx_scalars {
     int32_t tie_drivables[8];
     /* diagnostic of the last step (0 where an implementation does not count it; never part of a result): vehicles handed to
      * the cross phase */
-    int32_t diag_cross_jobs, diag_pad;
+    int32_t diag_cross_jobs;
+    /* cfx_set_vehicle_speed calls for a vehicle number the NEXT cfx_step was expected to create (see there) whose step then did
+     * not create it, since the engine was created: such a speed is dropped, and counted here */
+    int32_t dropped_future_speeds;
 } cfx_scalars;
 
 /* Full per-vehicle state of every running vehicle, caller-allocated SoA (any pointer may be NULL).
@@ -253,7 +258,10 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
  * the car-following target for the vehicle's next step only (Vehicle::update clears it, vehicle.cpp:120-122).
  * A vid at or beyond the vehicles created so far names a vehicle the NEXT cfx_step's spawn records will create (a vehicle
  * pushed since the last step, which Engine::setVehicleSpeed engine.cpp:827-834 already finds): the speed is kept and is in
- * place before that step's admission; it is dropped if that step does not create the vehicle. */
+ * place before that step's admission; it is dropped if that step does not create the vehicle — counted in
+ * cfx_scalars::dropped_future_speeds.  Only the next CFX_FUTURE_SPEED_WINDOW vehicle numbers are accepted that way; anything
+ * beyond (or negative) is CFX_ERR_INVALID. */
+#define CFX_FUTURE_SPEED_WINDOW 65536
 int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed);
 /* Switch a waiting or running vehicle to route `route` (already added with cfx_add_routes) whose first road is the
  * road the vehicle is on; Router::iCurRoad restarts at 0 (Router::setRoute router.cpp:245-264 after its checks,

@@ -1292,7 +1292,7 @@ int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     out->vehicle_steps = e->vehicleSteps;
     out->tie_events = e->tieEvents;
     for (int i = 0; i < 8; ++i) out->tie_drivables[i] = e->tieEvents > i ? e->tieDrv[i] : -1;
-    out->diag_cross_jobs = out->diag_pad = 0;
+    out->diag_cross_jobs = out->dropped_future_speeds = 0;
     return CFX_OK;
 }
 

@@ -73,7 +73,7 @@ class _ShadowEngine:
         object.__setattr__(self, "_cfg", cfg)
 
     def backend_name(self):
-        return "hip-gfx950"
+        return "hip-gfx950(shadow:twin)"  # distinguishable in any log: this is NOT the device
 
     def _layout(self):
         with open(self._cfg) as f:
@@ -145,6 +145,12 @@ def ref_module():
     except ImportError:
         pytest.skip("oracle/_ref/cityflow_ref not built (needs /root/reference)")
     return cityflow_ref
+
+
+def assert_hip_backend(eng):
+    """The engine runs on the HIP device library — or, under CFX_SHADOW_GPU, on the twin that says it stands in for it."""
+    name = eng.backend_name()
+    assert name == ("hip-gfx950(shadow:twin)" if SHADOW_GPU else "hip-gfx950"), name
 
 
 def lane_hash(counts):

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TWIN_LIB, assert_same_state
+from conftest import TWIN_LIB, assert_same_state, assert_hip_backend
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,8 @@ def _engines(mod, scen, workdir, rl):
     ring = cfg.replace(".json", "_ring.json")
     json.dump(c, open(ring, "w"))
     hip = mod.Engine(ring, 1)
-    assert hip.backend_name() == "hip-gfx950" and hip._layout() == "ring"
+    assert_hip_backend(hip)
+    assert hip._layout() == "ring"
     return hip, mod.Engine._with_backend(cfg, 1, TWIN_LIB)
 
 

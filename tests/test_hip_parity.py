@@ -10,14 +10,14 @@ import time
 import numpy as np
 import pytest
 
-from conftest import TWIN_LIB, assert_same_state, checkpoint_record
+from conftest import TWIN_LIB, assert_same_state, checkpoint_record, assert_hip_backend
 
 pytestmark = pytest.mark.gpu
 
 
 def _pair(mod, cfg):
     hip = mod.Engine(cfg, 1)
-    assert hip.backend_name() == "hip-gfx950"
+    assert_hip_backend(hip)
     return hip, mod.Engine._with_backend(cfg, 1, TWIN_LIB)
 
 

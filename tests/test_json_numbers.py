@@ -202,3 +202,42 @@ def test_reader_meets_rapidjsons_own_unit_test_expectations(mod):
     for lit in ["1e-10000", "1e-00011111111111", "-1e-00011111111111", "1e-214748363", "1e-214748364", "1e-21474836311"]:
         got = mod._parse_json_number(lit)[0]
         assert got == 0.0 and (str(got) == "-0.0") == lit.startswith("-"), lit
+
+
+def test_archive_literals_are_checked_as_emitted_and_the_rest_is_counted():
+    """Archive.dump's number writer (csrc/host/archive.cpp num()): every literal is verified in the form it is written in —
+    the ".0" / "e0" an integer-valued double gets included (round 4 checked the bare digits and appended ".0" afterwards:
+    4 % of the integer doubles in [2^53, 1e17) then read back wrong through the reference's fraction path) — and the doubles
+    for which NO literal makes the reference's reader return them (mantissa close to 2, about one in 10^5 at simulation
+    magnitudes; the reference's own dumps come back an ulp off there too) are written with 17 digits and COUNTED, never
+    silently: Archive.dump reports the count (Archive._last_dump_inexact, a warning on stderr)."""
+    import random
+    from cityflow_amd import _cityflow as m
+    fmt, parse, counted = m._format_json_number, m._parse_json_number, m._inexact_json_numbers
+    import math
+    rng = random.Random(20250925)
+    n, off, only_ref = 120000, 0, 0
+    before = counted()
+    for _ in range(n):
+        x = rng.uniform(0.0, 3000.0)
+        lit = fmt(x)
+        ref_exact, strtod_exact = parse(lit)[0] == x, float(lit) == x
+        assert ref_exact or strtod_exact, (x, lit)  # at least one kind of reader always gets the value back
+        assert abs(float(lit) - x) <= 4 * math.ulp(x) and abs(parse(lit)[0] - x) <= math.ulp(x), (x, lit)
+        if not strtod_exact:
+            only_ref += 1                           # (a literal for the reference's reader only: the file is for engines to load)
+        if not ref_exact:
+            off += 1
+    assert off == counted() - before                # every value the reference's reader misses was counted
+    assert off <= n // 5000, off                    # ... and they are rare (measured: ~1 in 10^5)
+    assert only_ref <= n // 500, only_ref           # (measured: ~1 in 10^4)
+    before = counted()
+    for _ in range(40000):
+        x = float(rng.randrange(2 ** 53, 10 ** 17))
+        lit = fmt(x)
+        assert float(lit) == x and parse(lit)[0] == x, (x, lit)
+        assert any(c in lit for c in ".eE"), lit    # (never an integer event for a field the loader reads as a double)
+    assert counted() == before
+    for x in (0.0, 1.0, 5.0, 16.67, 1e-300, 123456789012345680.0, 2.0 ** 53, 2.0 ** 63, 1e22, 1e23):
+        lit = fmt(x)
+        assert float(lit) == x and parse(lit)[0] == x, (x, lit)

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import REF_DIR, TWIN_LIB
+from conftest import REF_DIR, TWIN_LIB, assert_hip_backend
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
@@ -137,7 +137,7 @@ def test_hip_lane_change_equals_twin_every_step(mod, scen, workdir, name, steps)
     6x6: every vehicle changes lane on its last road from step 378 on."""
     cfg = scen.materialize(name, workdir, laneChange=True)
     hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
-    assert hip.backend_name() == "hip-gfx950"
+    assert_hip_backend(hip)
     shadows = 0
     for s in range(steps):
         hip.next_step()

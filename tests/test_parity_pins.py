@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TWIN_LIB, assert_same_state
+from conftest import TWIN_LIB, assert_same_state, assert_hip_backend
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def _with_cfx(path, **cfx):
 
 def _hip(mod, cfg):
     hip = mod.Engine(cfg, 1)
-    assert hip.backend_name() == "hip-gfx950"
+    assert_hip_backend(hip)
     return hip
 
 

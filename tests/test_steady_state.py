@@ -1,0 +1,66 @@
+"""GPU (-m gpu): a long run without reset() neither stalls nor grows.  The reference frees a vehicle when it finishes
+(src/engine/engine.cpp:296-310) and allocates one when it is created; here the device tables are sized once (cfx_create: slots
+for half the network's bumper-to-bumper capacity, vehicle numbers for 4 M vehicles between two resets) and a step of an
+ordinary run allocates nothing — round 4's driver run showed a 70 ms next_step() where the vehicle table doubled from 64 k."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import TWIN_LIB, assert_same_state, assert_hip_backend
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ten_thousand_steps_without_a_stall_or_growth(mod, workdir):
+    import bench
+    import torch
+    cfg = bench.build_workload(workdir, 0, scenario="grid_30x30")
+    eng = mod.Engine(cfg, 1)
+    assert_hip_backend(eng)
+    for _ in range(bench.BUILD_UP_STEPS):
+        eng.next_step()
+    eng.sync()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    worst, t_all = 0.0, time.perf_counter()
+    for s in range(10000):
+        t0 = time.perf_counter()
+        eng.next_step()
+        worst = max(worst, time.perf_counter() - t0)
+        if s % 500 == 499:
+            eng.sync()  # (the host must not run arbitrarily far ahead of the device)
+    eng.sync()
+    total = time.perf_counter() - t_all
+    free1 = torch.cuda.mem_get_info(0)[0]
+    sc = eng._scalars()
+    assert sc["spawned_vehicle_count"] > 300000 and sc["active_vehicle_count"] > 20000, sc
+    assert worst < 1e-3, "one next_step() took %.2f ms" % (worst * 1e3)
+    assert free0 - free1 < 8 << 20, "device memory grew by %d MiB over 10 000 steps" % ((free0 - free1) >> 20)
+    assert total / 10000 < 200e-6, "%.1f us per step over the long run" % (total / 10000 * 1e6)
+
+
+def test_vehicle_tables_grow_without_draining_the_stream(mod, scen, workdir):
+    """The growth path itself (config "cfx": ringCapacityPercent below 100 starts the vehicle tables at 4 k numbers): they double
+    several times during the run — new arrays, a copy ordered on the stream, the old ones freed at the next sync — with the state
+    equal to the twin's throughout, on both layouts."""
+    import json
+    import os
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_dense.json"), 400, seed=7,
+                            interval=2.0, base_flow=os.path.join(d, "flow.json"))
+    cfg = scen.materialize("grid_6x6", workdir, flow_file=flow)
+    for layout in ("ring", "dense"):
+        c = json.load(open(cfg))
+        c["cfx"] = {"layout": layout, "ringCapacityPercent": 60}
+        path = cfg.replace(".json", "_smallvid_%s.json" % layout)
+        with open(path, "w") as f:
+            json.dump(c, f)
+        hip = mod.Engine(path, 1)
+        tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+        for s in range(500):
+            hip.next_step()
+            tw.next_step()
+            if s % 25 == 24:
+                assert_same_state(hip, tw, "growing vehicle tables (%s) step %d" % (layout, s + 1))
+        assert hip._scalars()["spawned_vehicle_count"] > 30000  # (4 k -> 8 k -> 16 k -> 32 k -> 64 k)
