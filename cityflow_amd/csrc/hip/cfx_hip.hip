@@ -2564,6 +2564,17 @@ int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **devic
 
 int32_t cfx_halo_mailbox_fine_grained(cfx_engine *e) { return e && e->mailboxesFineGrained ? 1 : 0; }
 
+int32_t cfx_device_memory(cfx_engine *e, int64_t *free_bytes, int64_t *total_bytes) {
+    if (!e) return CFX_ERR_INVALID;
+    auto fail = [e](const std::string &m) { return e->fail(m); };
+    HIP_TRY(hipSetDevice(e->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t) f;
+    if (total_bytes) *total_bytes = (int64_t) t;
+    return CFX_OK;
+}
+
 int32_t cfx_device_identity(cfx_engine *e, char *buf, int32_t capacity) {
     if (!e || !buf || capacity < 2) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };

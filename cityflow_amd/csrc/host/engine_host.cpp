@@ -72,6 +72,7 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_halo_mailbox_open)
     CFX_FN(cfx_halo_mailbox_fine_grained)
     CFX_FN(cfx_device_identity)
+    CFX_FN(cfx_device_memory)
     CFX_FN(cfx_halo_device_buffers)
     CFX_FN(cfx_halo_post)
     CFX_FN(cfx_halo_wait)

@@ -60,6 +60,7 @@ struct Backend {
     CFX_FN(cfx_halo_mailbox_open)
     CFX_FN(cfx_halo_mailbox_fine_grained)
     CFX_FN(cfx_device_identity)
+    CFX_FN(cfx_device_memory)
     CFX_FN(cfx_halo_device_buffers)
     CFX_FN(cfx_halo_post)
     CFX_FN(cfx_halo_wait)
@@ -147,6 +148,11 @@ public:
     void sync();
     void profileEnable(bool on);
     void deviceSpin(long long microseconds) { check(be_.cfx_device_spin(dev_, microseconds), "cfx_device_spin"); }
+    std::pair<long long, long long> deviceMemory() {  // {free, total} bytes of the engine's device
+        int64_t f = 0, t = 0;
+        check(be_.cfx_device_memory(dev_, &f, &t), "cfx_device_memory");
+        return {(long long) f, (long long) t};
+    }
     std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
 
     std::shared_ptr<void> bindingCache;  // opaque per-engine cache owned by the language binding (lane id key objects)

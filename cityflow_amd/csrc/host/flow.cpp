@@ -242,7 +242,7 @@ void Spawner::peekShadowPriorities(int n, std::vector<int32_t> &out) {
             livePriority_.prefetch(peekPriorities_[(size_t) i]);
         }
         bool clean = true;
-        for (int i = 0; i < n && clean; ++i) clean = livePriority_.find(peekPriorities_[(size_t) i]) == nullptr;
+        for (int i = 0; i < n && clean; ++i) clean = !livePriority_.contains(peekPriorities_[(size_t) i]);
         if (clean) {  // no value twice: a small open-addressing table (entries are value + 2^32, empty = -1)
             size_t cap = 64;
             while (cap < (size_t) n * 4) cap <<= 1;
@@ -272,9 +272,9 @@ void Spawner::peekShadowPriorities(int n, std::vector<int32_t> &out) {
             priority = (int32_t) peek();
             ++draws;
             if (std::find(peekPriorities_.begin(), peekPriorities_.end(), priority) != peekPriorities_.end()) continue;
-            int32_t *owner = livePriority_.find(priority);
-            if (!owner) break;
-            if (*owner >= 0 && isFinished_ && isFinished_(*owner)) {
+            int32_t owner;
+            if (!livePriority_.lookup(priority, owner)) break;
+            if (owner >= 0 && isFinished_ && isFinished_(owner)) {
                 livePriority_.erase(priority);
                 break;
             }
@@ -315,10 +315,10 @@ int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> 
     int32_t priority;
     for (;;) {
         priority = (int32_t) rnd();
-        int32_t *owner = livePriority_.find(priority);
-        if (!owner) break;
+        int32_t owner;
+        if (!livePriority_.lookup(priority, owner)) break;
         // Host bookkeeping is a superset of the live set; settle it exactly before redrawing.
-        if (*owner >= 0 && isFinished && isFinished(*owner)) {
+        if (owner >= 0 && isFinished && isFinished(owner)) {
             livePriority_.erase(priority);
             break;
         }

@@ -11,6 +11,7 @@
 // LENGTH metric, so it is evaluated once per flow / per pushed vehicle instead of once per spawn.
 #pragma once
 
+#include <deque>
 #include <functional>
 #include <map>
 #include <random>
@@ -73,7 +74,9 @@ public:
     std::vector<cfx_vehicle_template> templates;
     RouteTable routes;
     std::vector<HostFlow> flows;
-    std::vector<VehicleRecord> vehicles;  // by vid, since the last reset
+    // by vid, since the last reset.  A deque: it grows chunk by chunk — a vector of a million 40-byte records relocates
+    // tens of megabytes when it doubles, a 5-10 ms next_step() in the middle of a long run (tests/test_steady_state.py)
+    std::deque<VehicleRecord> vehicles;
     std::vector<std::vector<int32_t>> flowVids;  // [flow][per-flow number] -> vid (-1: dropped, invalid route)
     std::vector<int32_t> manualVids;             // [manuallyPushCnt value] -> vid or -1
     std::mt19937 rnd;
@@ -133,7 +136,7 @@ public:
     // Everything that changes while stepping, for Archive-style snapshot / restore (archive.cpp:62-66,161-165).
     struct State {
         std::vector<FlowDyn> flows;
-        std::vector<VehicleRecord> vehicles;
+        std::deque<VehicleRecord> vehicles;
         std::vector<std::vector<int32_t>> flowVids;
         std::vector<int32_t> manualVids, lastWaitVid;
         std::mt19937 rnd;

@@ -454,6 +454,7 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("_ring_info", &EngineHost::ringInfo, "(total ring slots, capacity scale) of the ring layout")
         .def("_profile_enable", &EngineHost::profileEnable, "on"_a)
         .def("_device_spin", &EngineHost::deviceSpin, "microseconds"_a)
+        .def("_device_memory", &EngineHost::deviceMemory, "(free, total) bytes of the engine's device")
         .def("_profile_read", &EngineHost::profileRead)
         .def("_vehicle_id", [](EngineHost &e, int vid) { return e.vehicleId(vid); }, "vid"_a)
         .def("_vehicle_ids",

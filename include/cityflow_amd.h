@@ -439,6 +439,9 @@ int32_t cfx_halo_mailbox_fine_grained(cfx_engine *e);
  * a device whatever each process's visible-device numbering is (HIP: the PCI bus id, e.g. "0000:05:00.0"; a CPU
  * implementation: "cpu").  A caller that is offered plain (coarse-grained) device mailboxes compares it over all ranks. */
 int32_t cfx_device_identity(cfx_engine *e, char *buf, int32_t capacity);
+/* Free and total memory of that device in bytes (hipMemGetInfo; a CPU implementation: 0, 0) — what a long run is checked
+ * against: a step of an ordinary run allocates nothing (tests/test_steady_state.py). */
+int32_t cfx_device_memory(cfx_engine *e, int64_t *free_bytes, int64_t *total_bytes);
 /* The staged exchange with the messages left in device memory (for a device-to-device transport such as RCCL send / recv
  * on these very buffers): cfx_halo_export(e, NULL) then writes the send buffer only on the device, cfx_halo_import(e, NULL)
  * reads the recv buffer from the device.  Both buffers are fixed for the life of the engine. */

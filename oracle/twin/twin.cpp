@@ -1568,6 +1568,13 @@ int32_t cfx_halo_mailbox_alloc(cfx_engine *e, int32_t messageBytes, void **ptr, 
     return CFX_OK;
 }
 int32_t cfx_halo_mailbox_fine_grained(cfx_engine *) { return 1; }
+int32_t cfx_device_memory(cfx_engine *e, int64_t *free_bytes, int64_t *total_bytes) {
+    if (!e) return CFX_ERR_INVALID;
+    if (free_bytes) *free_bytes = 0;
+    if (total_bytes) *total_bytes = 0;
+    return CFX_OK;
+}
+
 int32_t cfx_device_identity(cfx_engine *e, char *buf, int32_t capacity) {
     if (!e || !buf || capacity < 4) return CFX_ERR_INVALID;
     memcpy(buf, "cpu", 4);
