@@ -99,13 +99,14 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
         road = c.n.laneRoad[d];
         laneIdx = c.n.laneIndex[d];
     }
-    int wt = 0, route = 0, nextWait = -1;
+    int wt = 0, route = 0, nextWait = -1, fn = kFirstNextUnknown;
     uint8_t pending = 0;
     if (w >= 0) {
         wt = vt.templ[w];
         route = vt.route[w];
         nextWait = vt.nextWait[w];
         pending = vt.pendingCustom[w];
+        fn = vt.firstNext[w];
     }
     __syncthreads();
     if (nRecs > 0) {
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
                 vt.enterTime[v] = batch.enterTime;
                 vt.state[v] = 0;
                 vt.pendingCustom[v] = 0;
+                vt.firstNext[v] = batch.firstNext[i];
             }
         if (isLane) {
             // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367; nextWait[] of a new vehicle was pre-set to -1): this
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
                 w = firstNewVid + batch.vidOff[headRec];
                 wt = batch.templ[headRec];
                 route = batch.route[headRec];
+                fn = batch.firstNext[headRec];
                 pending = 0;
                 nextWait = -1;
                 waitHead[d] = w;
@@ -200,14 +203,8 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
         bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435
         if (admit && now.slot >= 0 && !(now.dis > tv[now.templ].len + tv[wt].min_gap)) admit = false;
         if (admit) {
-            const int rbase = c.t.routeStart[route];
-            int next;
-            if (c.t.routeRoads[rbase] == road) {  // the lane is on route position 0 (kr_admit)
-                const int ll = c.t.nextLL[c.t.nextStart[rbase] + laneIdx];
-                next = ll < 0 ? -1 : c.n.L + ll;
-            } else {
-                next = nextOf(c.n, c.t, lane, route, 0);
-            }
+            int next, onLast;  // Router::getNextDrivable(0) and Router::isLastRoad: known since the vehicle was created (VidTable::firstNext)
+            admittedNext(c, fn, lane, road, laneIdx, route, &next, &onLast);
             const int slot = base + n;  // the lane's spare slot
             const double v0 = tv[wt].initial_speed;
             c.s.vid[slot] = w;
@@ -219,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void kd_admit(StepCtx c, int32_t *admitStep
             c.s.routePos[slot] = 0;
             c.s.templ[slot] = wt;
             c.s.route[slot] = route;
-            c.s.flags[slot] = (uint8_t) (pending | lastRoadBit(c, lane, route, next));
+            c.s.flags[slot] = (uint8_t) (pending | onLast);
             c.s.dis[slot] = 0.0;
             c.s.speed[slot] = v0;
             c.laneTail[lane] = slot;
@@ -280,6 +277,10 @@ __global__ __launch_bounds__(kDenseActBlock, CFX_KD_ACTION_WAVES) void kd_action
         KNOTE(6, 5, 1);
         return;
     }
+    // (the host's grid covers its BOUND on the slots in use; a block wholly beyond the slots that are in use — a sixth of the
+    // grid at 1 M vehicles — leaves before it stages anything)
+    const int S = c.segStart[c.n.L + c.n.K];
+    if ((int) (blockIdx.x * blockDim.x) >= S) return;
     __shared__ cfx_vehicle_template sT[kLdsTempl];
     const cfx_vehicle_template *tv = c.t.templ;
     if (c.t.nTempl <= kLdsTempl) {
@@ -293,7 +294,6 @@ __global__ __launch_bounds__(kDenseActBlock, CFX_KD_ACTION_WAVES) void kd_action
     KSTAMP(6, 1);
     // (requesting the slot's columns in front of this barrier — so that they travel with the template table and the slot
     // count — was measured in round 4: 9.5 -> 9.3 us at 30x30, 46.8 -> 48.5 us at 1 M vehicles; not kept)
-    const int S = c.segStart[c.n.L + c.n.K];
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0 && S > nVehicleBlocks * (int) blockDim.x) o.sc->overflow = 10;
     if (s < S) {

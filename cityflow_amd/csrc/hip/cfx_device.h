@@ -344,6 +344,7 @@ template <int N> struct SpawnBatchT {
     int n, firstNewVid;
     double enterTime;
     int32_t lane[N], prevWait[N], route[N], priority[N];
+    int32_t firstNext[N];  // VidTable::firstNext of the new vehicle (cfx_step looks it up in its host copy of the route tables)
     int16_t templ[N], vidOff[N];
 };
 using SpawnBatch = SpawnBatchT<kAdmitRecs>;

@@ -200,6 +200,22 @@ struct cfx_engine {
     bool ring = false;                 // this engine uses it (decided at cfx_create; cfx_halo_config may still switch to dense)
     bool ringBuilt = false;
     std::vector<double> hDrvLength;    // host copy of cfx_net::drv_length (ring capacities)
+    std::vector<int32_t> hLaneRoad, hLaneIndex;  // host copies of cfx_net::lane_road / lane_index (firstNextOf)
+    // Router::getNextDrivable(0) of a vehicle waiting on `lane` with route `route`, as VidTable::firstNext keeps it (nextOf +
+    // lastRoadBit of cfx_device.h on the host copies of the tables): looked up once per spawn record
+    int32_t firstNextOf(int lane, int route) const {
+        if (lane < 0 || lane >= L || route < 0 || route + 1 >= (int) hRouteStart.size()) return kFirstNextUnknown;
+        const int road = hLaneRoad[lane], base = hRouteStart[route], len = hRouteStart[route + 1] - base;
+        int p = 0;
+        while (p < len && hRouteRoads[base + p] != road) ++p;
+        int next = -1;
+        if (p < len) {
+            const int ll = hNextLL[hNextStart[base + p] + hLaneIndex[lane]];
+            next = ll < 0 ? -1 : L + ll;
+        }
+        if (next >= 0) return next;
+        return (len > 0 && hRouteRoads[base + len - 1] == road) ? -2 : -1;
+    }
     std::vector<int2> hRingGeo;        // [D] {base, cap - 1}
     size_t ringSlots = 0;
     double ringMinLen = 0.0;           // shortest vehicle template the capacities were computed for
@@ -223,6 +239,7 @@ struct cfx_engine {
     RingJob *rJobRecs = nullptr;
     LLAux *rLLAux = nullptr;
     int4 *rLLGate = nullptr;
+    int32_t *rGatePhase = nullptr;     // [2 I] RingCtx::gatePhase
     RingDense rd{};                    // dense staging view (getters, archive, growth)
     size_t rdCap = 0;
     int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
@@ -402,6 +419,7 @@ struct cfx_engine {
         if ((rc = growDeferred(&vt.customSpeed, (size_t) spawned, nc))) return rc;
         if ((rc = growDeferred(&vt.gapState, (size_t) spawned, nc))) return rc;
         if ((rc = growDeferred(&vt.pendingCustom, (size_t) spawned, nc))) return rc;
+        if ((rc = growDeferred(&vt.firstNext, (size_t) spawned, nc))) return rc;
         if (lc.on) {
 #define GROW_LC(f) if ((rc = growDeferred(&lc.f, (size_t) spawned, nc))) return rc;
             GROW_LC(ptype) GROW_LC(partner) GROW_LC(offset) GROW_LC(sigSend) GROW_LC(sendDir) GROW_LC(sendUrg) GROW_LC(lastDir)
@@ -535,6 +553,7 @@ struct cfx_engine {
         c.llDyn = llDyn;
         c.interMask = interMask;
         c.llGate = rLLGate;
+        c.gatePhase = rGatePhase;
         c.llAux = rLLAux;
         c.laneTail = laneTail;
         c.admitRec = admitRec;
@@ -599,6 +618,8 @@ struct cfx_engine {
             if ((rc = allocRaw(&rTailNow, (size_t) D))) return rc;
             if ((rc = allocRaw(&rLLAux, (size_t) K))) return rc;
             if ((rc = allocRaw(&rLLGate, (size_t) K))) return rc;
+            if ((rc = allocRaw(&rGatePhase, (size_t) 2 * std::max(I, 1)))) return rc;
+            HIP_TRY(hipMemsetAsync(rGatePhase, 0xFF, (size_t) 2 * std::max(I, 1) * sizeof(int32_t), stream));
             rFinCap = std::max(1 << 16, L * 8);
             if ((rc = allocRaw(&rFinKey, (size_t) rFinCap))) return rc;
             if ((rc = allocRaw(&rFinVid, (size_t) rFinCap))) return rc;
@@ -709,6 +730,7 @@ struct cfx_engine {
         futureCustom.clear();
         tailsValid = false;
         if (gatePhase) HIP_TRY(hipMemsetAsync(gatePhase, 0xFF, (size_t) 2 * std::max(I, 1) * sizeof(int32_t), stream));
+        if (rGatePhase) HIP_TRY(hipMemsetAsync(rGatePhase, 0xFF, (size_t) 2 * std::max(I, 1) * sizeof(int32_t), stream));
         lcSegValid = false;
         if (hMirror) hMirror->progress = 0;  // the stream is idle: nothing is writing it
         pollPending = false;
@@ -843,6 +865,8 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     e->ringMerge = (cfg->ring_lanes_per_wave / 10000) % 10 != 4;
     e->denseForm = cfg->dense_form ? (cfg->dense_form & 255) : CFX_DENSE_FORM_DEFAULT;
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
+    e->hLaneRoad.assign(n->lane_road, n->lane_road + n->n_lanes);
+    e->hLaneIndex.assign(n->lane_index, n->lane_index + n->n_lanes);
     e->timesDyadic = cfx_engine::dyadic(cfg->interval);
     e->R = n->n_roads;
     e->L = n->n_lanes;
@@ -1110,6 +1134,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             b.prevWait[i] = batch.prevWait[i];
             b.route[i] = batch.route[i];
             b.priority[i] = batch.priority[i];
+            b.firstNext[i] = batch.firstNext[i];
             b.templ[i] = batch.templ[i];
             b.vidOff[i] = batch.vidOff[i];
         }
@@ -1153,6 +1178,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                     batch.prevWait[j] = r.prev_wait;
                     batch.route[j] = r.route;
                     batch.priority[j] = r.priority;
+                    batch.firstNext[j] = e->firstNextOf(r.lane, r.route);
                     batch.templ[j] = (int16_t) r.templ;
                     batch.vidOff[j] = (int16_t) (r.vid - e->spawned);
                 }
@@ -1965,6 +1991,7 @@ int32_t cfx_set_vehicle_route(cfx_engine *e, int32_t vid, int32_t route) {
     int rc = e->syncTables();
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->vt.route + vid, &route, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) (e->vt.firstNext + vid), kFirstNextUnknown, 1, e->stream));  // (a waiting vehicle: its admission walks the new route)
     if (e->ring) {
         if ((rc = e->ringEnsure())) return rc;
         uint8_t st = 0;
@@ -2266,6 +2293,7 @@ int32_t cfx_load_state(cfx_engine *e, const cfx_state *s) {
     HIP_TRY(up(e->vt.customSpeed, custom.data(), (size_t) nV * 8));
     HIP_TRY(up(e->vt.gapState, gapState.data(), (size_t) nV * 8));
     HIP_TRY(hipMemsetAsync(e->vt.pendingCustom, 0, std::max(nV, 1), e->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) e->vt.firstNext, kFirstNextUnknown, (size_t) std::max(nV, 1), e->stream));  // (waiting vehicles: the walk)
     HIP_TRY(up(e->vt.nextWait, nextWait.data(), (size_t) nV * 4));
     HIP_TRY(up(e->waitHead, waitHead.data(), (size_t) L * 4));
     HIP_TRY(up(e->curPhase, s->tl_phase, (size_t) e->I * 4));

@@ -61,7 +61,30 @@ struct VidTable {
     double *gapState;        // ControllerInfo::gap of the loaded state (StepCtx::vGapState)
     uint8_t *state;          // 0 waiting, 1 running, 2 finished
     uint8_t *pendingCustom;  // custom speed set while the vehicle was still waiting
+    // Router::getNextDrivable(0) of a WAITING vehicle on the lane it waits on, known when it is created (the host holds the
+    // route tables: cfx_step looks it up for every spawn record) — the admission then needs no walk route -> first road ->
+    // row -> laneLink behind its decision: >= 0 the drivable, -1 none, -2 none and the lane is on the route's last road
+    // (Router::isLastRoad: slot flag bit 1), kFirstNextUnknown: take the walk (after a load, a new route, a k_spawn_link batch)
+    int32_t *firstNext;
 };
+constexpr int kFirstNextUnknown = -3;
+// the next drivable and the last-road flag of a vehicle that is admitted onto `lane` now
+template <class C>
+__device__ __forceinline__ void admittedNext(const C &c, int fn, int lane, int road, int laneIdx, int route, int *next, int *onLast) {
+    if (fn != kFirstNextUnknown) {
+        *next = fn >= 0 ? fn : -1;
+        *onLast = fn == -2 ? 2 : 0;
+        return;
+    }
+    const int base = c.t.routeStart[route];
+    if (c.t.routeRoads[base] == road) {  // the lane is on route position 0: the table row is known without walking the route
+        const int ll = c.t.nextLL[c.t.nextStart[base] + laneIdx];
+        *next = ll < 0 ? -1 : c.n.L + ll;
+    } else {
+        *next = nextOf(c.n, c.t, lane, route, 0);
+    }
+    *onLast = (*next < 0 && isLastRoad(c, lane, route)) ? 2 : 0;
+}
 
 struct DevScalars {
     long long active;          // Engine::activeVehicleCount
@@ -165,6 +188,7 @@ __global__ void k_spawn_link(const cfx_spawn *recs, int n, int firstNewVid, VidT
     vt.enterTime[r.vid] = r.enter_time;
     vt.state[r.vid] = 0;
     vt.pendingCustom[r.vid] = 0;
+    vt.firstNext[r.vid] = kFirstNextUnknown;  // (this path is the rare one: the admission walks the route)
     if (r.lane < 0) return;  // tiling: the vehicle starts in another tile; only its static record is kept here
     // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367).  nextWait[] was pre-set to -1.
     if (r.prev_wait < 0) {
@@ -248,6 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_admit(StepCtx c, int32_t *admitStep,
         if (blockIdx.x == 0)
             for (int i = threadIdx.x; i < nRecs; i += blockDim.x) {
                 const int v = firstNewVid + batch.vidOff[i];
+                vt.firstNext[v] = batch.firstNext[i];
                 if (c.lc.on) lcInitVid(c.lc, v);
                 vt.priority[v] = batch.priority[i];
                 vt.templ[v] = batch.templ[i];

@@ -64,6 +64,9 @@ struct RingCtx {
     struct LLAux *llAux;     // [K] what a cross needs of a laneLink's notify sources beyond llDyn (written where active)
     unsigned long long *interMask;
     int4 *llGate;            // [K] {light | type | has crosses, end lane, first cross entry, end of cross entries}
+    // [2 I] the phase each intersection's gate records stand for (-1: none), by step parity: kr_admit rewrites a laneLink's
+    // record only when its intersection shows another phase than in the last step (kd_admit<true> has the story)
+    int32_t *gatePhase;
     int32_t *laneTail;
     int2 *admitRec;
     int32_t step;
@@ -258,9 +261,9 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
 // cache).  More records than fit: k_spawn_link runs first.
 // The batch is kept by columns, SORTED BY LANE (a lane's thread finds its records by a binary search in the LDS copy of
 // `lane[]`); record j is the vehicle firstNewVid + vidOff[j]; all vehicles of a step enter at the same time
-// (Engine::getCurrentTime).  Kernel arguments stay well below 4 KB.
+// (Engine::getCurrentTime).  Kernel arguments stay at a few KB.
 // (kAdmitRecs, SpawnBatch: cfx_device.h — the dense layouts' admission kernels take the batch too)
-static_assert(sizeof(SpawnBatch) + sizeof(RingCtx) + sizeof(VidTable) + 256 <= 4096, "kr_admit's arguments must stay below 4 KB");
+static_assert(sizeof(SpawnBatch) + sizeof(RingCtx) + sizeof(VidTable) + 256 <= 8192, "kr_admit's arguments: a few KB (the runtime takes 32 KB and more, tools/kernarg_probe.hip)");
 
 struct RingCommit {
     int4 *scratch;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
     TailRec committed{};
     int w = -1, n = 0, head = 0, road = 0, laneIdx = 0;
     int2 geo = make_int2(0, 0);
-    int wt = 0, route = 0, nextWait = -1;
+    int wt = 0, route = 0, nextWait = -1, fn = kFirstNextUnknown;
     uint8_t pending = 0;
     if constexpr (COMMIT) {
         const int nBody = (int) gridDim.x - commitStatBlocks(k);
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 route = vt.route[w];
                 nextWait = vt.nextWait[w];
                 pending = vt.pendingCustom[w];
+                fn = vt.firstNext[w];
             }
         }
         if (inRange) {
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
             route = vt.route[w];
             nextWait = vt.nextWait[w];
             pending = vt.pendingCustom[w];
+            fn = vt.firstNext[w];
         }
     }
     __syncthreads();  // (templates and the batch's lanes staged)
@@ -404,6 +409,7 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 vt.enterTime[v] = batch.enterTime;
                 vt.state[v] = 0;
                 vt.pendingCustom[v] = 0;
+                vt.firstNext[v] = batch.firstNext[i];
             }
         if (isLane) {
             // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367; nextWait[] of a new vehicle was pre-set to -1): this
@@ -430,6 +436,7 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 w = firstNewVid + batch.vidOff[headRec];
                 wt = batch.templ[headRec];
                 route = batch.route[headRec];
+                fn = batch.firstNext[headRec];
                 pending = 0;
                 nextWait = -1;
                 waitHead[d] = w;
@@ -444,9 +451,17 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
         TailRec now = committed;
         if (committed.tag != c.step - 1) now.slot = -1;
         if (!isLane) {
-            const int k = d - c.n.L;
-            int flags = (llAvailable(c, k) ? 1 : 0) | (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
-            c.llGate[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+            // RoadLink::isAvailable (roadnet.h:429-431) into the laneLink's gate record — only when the intersection's phase is
+            // not the one the record was written for: the lights change every few seconds, the chain intersection -> phase ->
+            // availability table behind the commit was walked for every laneLink in every step
+            const int k = d - c.n.L, in = c.n.llInter[k];
+            const int ph = c.curPhase[in];
+            if (c.gatePhase[((c.step + 1) & 1) * c.n.I + in] != ph) {
+                const int flags = (c.n.phaseAvail[c.n.interAvailStart[in] + ph * c.n.interNRL[in] + c.n.llRoadLink[k]] != 0 ? 1 : 0) |
+                                  (c.n.llType[k] << 1) | (c.n.llXStart[k + 1] > c.n.llXStart[k] ? 8 : 0);
+                c.llGate[k] = make_int4(flags, c.n.llEndLane[k], c.n.llXStart[k], c.n.llXStart[k + 1]);
+            }
+            if (c.n.llLocal[k] == 0) c.gatePhase[(c.step & 1) * c.n.I + in] = ph;
         } else {
             const int lane = d;
             bool admit = w >= 0;  // Lane::available roadnet.cpp:428-435
@@ -456,17 +471,10 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 admit = false;
             }
             if (admit) {
-                // Router::getNextDrivable for a vehicle on the first road of its route (router.cpp:49-76): its lane is on
-                // route position 0, so the table row is known without walking the route; anything else takes the walk
-                const int base = c.t.routeStart[route];
-                const int road0 = c.t.routeRoads[base], row0 = c.t.nextStart[base];  // (one round, not two)
-                int next;
-                if (road0 == road) {
-                    const int ll = c.t.nextLL[row0 + laneIdx];
-                    next = ll < 0 ? -1 : c.n.L + ll;
-                } else {
-                    next = nextOf(c.n, c.t, lane, route, 0);
-                }
+                // Router::getNextDrivable(0) (router.cpp:49-76) and Router::isLastRoad of the admitted vehicle: known since it was
+                // created (VidTable::firstNext) — the walk route -> first road -> row -> laneLink used to sit behind the commit
+                int next, onLast;
+                admittedNext(c, fn, lane, road, laneIdx, route, &next, &onLast);
                 const int slot = ringSlot(geo, head, n);
                 const double v0 = tv[wt].initial_speed;  // VehicleInfo::speed: 0 unless pushed with a speed
                 c.s.vid[slot] = w;
@@ -474,7 +482,6 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 c.s.prevDrv[slot] = -1;
                 c.s.routePos[slot] = 0;
                 c.s.route[slot] = route;
-                const int onLast = (next < 0 && isLastRoad(c, lane, route)) ? 2 : 0;  // (flags bit 1, see finishAction)
                 c.meta[slot] = make_int4(wt, next, pending | onLast, CFX_INT_MAX);  // (enterLaneLinkTime: ControllerInfo ctor vehicle.cpp:10-13)
                 c.kin[slot] = make_double2(0.0, v0);
                 c.slotOf[w] = slot;

@@ -169,3 +169,30 @@ def test_bench_falls_back_to_replicas_when_no_halo_transport_comes_up(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"].startswith("replica x2") and "no halo transport" in d["config"]["parallelism"]
     assert d["config"]["halo_probe_failures"] == ["--no-halo"]
+
+
+def test_bench_eight_ranks_on_config3_gloo(tmp_path):
+    """BASELINE.json configs[3] as the driver will launch it on an 8-GPU node — `bench.py --gpus 8` under torch.distributed.run,
+    the 30x30 network cut 2x4, one tile per rank, halo every step — with gloo and the CPU twin standing in for the devices: the
+    plumbing of the first 8-rank run (tile cut, 8-way halo group, per-rank spawners, max-over-ranks timing, rank 0's single
+    line) cannot be met for the first time on the hardware.  The tiles' lane counts equal the single engine's after the same
+    steps (reference: one Engine over the whole network, src/engine/engine.cpp:566-594)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TMPDIR=str(tmp_path))
+    common = ["--steps", "12", "--warmup", "6", "--build-up-steps", "60", "--cpu-seconds", "0", "--rl-seconds", "0", "--scale-steps", "0",
+              "--profile-steps", "0", "--scenario", "grid_30x30", "--extra-flows", "400", "--backend-lib", TWIN_LIB]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo"] + common
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["tiling_failed"] is False
+    assert d["config"]["parallelism"] == "tiles 2x4 + halo" and "grid_30x30" in d["config"]["workload"]
+    assert d["value"] > 0 and d["config"]["running_vehicles_start"] > 1000
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=dict(os.environ, TMPDIR=str(tmp_path)),
+                            capture_output=True, text=True, timeout=900)
+    assert single.returncode == 0, single.stderr[-2000:]
+    one = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["lane_count_hash_end"] == one["config"]["lane_count_hash_end"]
+    assert d["config"]["running_vehicles_end"] == one["config"]["running_vehicles_end"]
