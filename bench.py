@@ -855,11 +855,23 @@ def main():
             if not tiled:
                 eng._profile_read()
                 scp0 = eng._scalars()
-        for _ in range(args.profile_steps):
-            eng.next_step()
-        prof = None
+        # (read in four chunks: the totals give the averages the roofline is priced with; the per-kernel MEDIAN over the chunks
+        # is reported beside them — one launch that a box hiccup stretches to milliseconds moves a 100-launch average by tens of
+        # microseconds, and says nothing about the kernel)
+        prof, chunks = None, []
+        n_chunks = 4 if args.profile_steps >= 40 else 1
+        for ci in range(n_chunks):
+            n_here = args.profile_steps // n_chunks + (args.profile_steps % n_chunks if ci == n_chunks - 1 else 0)
+            for _ in range(n_here):
+                eng.next_step()
+            if rank == 0:
+                part = eng._eng._profile_read(0) if tiled else eng._profile_read()
+                chunks.append(part)
+                if prof is None:
+                    prof = {k: (ms, n) for k, (ms, n) in part.items()}
+                else:
+                    prof = {k: (prof.get(k, (0.0, 0))[0] + ms, prof.get(k, (0.0, 0))[1] + n) for k, (ms, n) in part.items()}
         if rank == 0:
-            prof = eng._eng._profile_read(0) if tiled else eng._profile_read()
             (eng._eng._profile_enable(0, False) if tiled else eng._profile_enable(False))
         eng.sync()
         scp1 = eng.local_scalars() if tiled else eng._scalars()
@@ -868,6 +880,14 @@ def main():
                 prof, scp1["vehicle_steps"] - scp0["vehicle_steps"], "bench" if args.scenario == "grid_30x30" else args.scenario,
                 "%d instrumented steps following the timed region%s" % (args.profile_steps, " (rank 0's tile)" if tiled else ""),
                 with_traffic=not tiled)
+            if roofline and len(chunks) > 1:
+                per = {}
+                for part in chunks:
+                    steps_here = max((n for _ms, n in part.values()), default=0)
+                    for k, (ms, n) in part.items():
+                        if n and steps_here:
+                            per.setdefault(k, []).append(ms / steps_here * 1e3)
+                roofline["kernel_us_per_step_median_of_%d_chunks" % len(chunks)] = {k: sorted(v)[len(v) // 2] for k, v in per.items()}
 
     # ---- in-run parity and the CPU baseline (rank 0; a tiled run is compared with ONE engine on rank 0's device)
     cpu, legs, parity_in_run, parity_excused, parity_detail = None, None, None, None, None

@@ -1,7 +1,8 @@
 """BASELINE.json configs[4] — 100x100 grid, ~1M running vehicles, 8 tiles, per-step set_tl_phase / get_lane_vehicle_count
 RL calls — through the size-independent property the tiling offers: the tiled network (2x4 tiles, halo through GPU
 mailboxes; all on the one GPU of the test box) and the single engine, driven by the same random signal plan and read
-back through the RL getters every step, must agree exactly.  The same loop runs small on the CPU twin."""
+back through the RL getters every step, must agree exactly — and, from a checkpoint of that run on, both must agree with
+the CPU twin (the oracle) step by step under the same agent.  The same loop runs small on the CPU twin."""
 import os
 import time
 
@@ -27,7 +28,7 @@ def build(scen, workdir, n, flows_per_100_inters, **config):
     return path
 
 
-def rl_loop(mod, cfg, rows, cols, lib, warmup, steps, min_running):
+def rl_loop(mod, cfg, rows, cols, lib, warmup, steps, min_running, twin_steps=0):
     single = mod.Engine._with_backend(cfg, 1, lib)
     tiled = mod.TiledEngine(cfg, rows, cols, [], lib)
     tiled.enable_mailboxes("full_%d_%d" % (os.getpid(), rows * cols))
@@ -54,17 +55,40 @@ def rl_loop(mod, cfg, rows, cols, lib, warmup, steps, min_running):
             bad = np.nonzero(va[k] != vb[k])[0]
             raise AssertionError("field %s differs for %d vehicles; first: vid %s drivable %s single %s tiled %s" % (
                 k, bad.size, va["vid"][bad[:5]], va["drivable"][bad[:5]], va[k][bad[:5]], vb[k][bad[:5]]))
+    if twin_steps:
+        # ... and against the ORACLE at this checkpoint: the state goes into the CPU twin (and into a fresh engine of `lib`: a
+        # load restarts every route cursor, so loaded engines are compared with loaded engines) through an Archive; the three
+        # take the same agent-driven steps — the tiles included, which never loaded — every vehicle field compared
+        from conftest import assert_same_state
+        snap = single.snapshot()
+        loaded = mod.Engine._with_backend(cfg, 1, lib)
+        loaded.load(snap)
+        tw = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+        tw.load(snap)
+        del snap
+        assert_same_state(loaded, tw, "%dx%d tiles' checkpoint in the twin" % (rows, cols))
+        for s in range(twin_steps):
+            if s % 3 == 0:
+                ph = rng.integers(0, 8, size=n_inter).astype(np.int32)
+                for e in (loaded, tw, tiled):
+                    e.set_tl_phases(ph)
+            for e in (loaded, tw, tiled):
+                e.next_step()
+            a = loaded.get_lane_vehicle_count_array()
+            assert np.array_equal(a, tw.get_lane_vehicle_count_array()), "twin step %d" % s
+            assert np.array_equal(a, tiled.get_lane_vehicle_count_array()), "tiles, twin step %d" % s
+        assert_same_state(loaded, tw, "after %d agent-driven steps from the checkpoint" % twin_steps)
     return sa["active_vehicle_count"]
 
 
 def test_rl_loop_12x12_twin(mod, scen, workdir):
     cfg = build(scen, workdir, 12, 330)
-    rl_loop(mod, cfg, 2, 2, TWIN_LIB, warmup=150, steps=30, min_running=5000)
+    rl_loop(mod, cfg, 2, 2, TWIN_LIB, warmup=150, steps=30, min_running=5000, twin_steps=6)
 
 
 @pytest.mark.gpu
 def test_config5_100x100_one_million_vehicles(mod, scen, workdir):
     t0 = time.time()
     cfg = build(scen, workdir, 100, 333)
-    running = rl_loop(mod, cfg, 2, 4, mod._default_backend_path(), warmup=300, steps=40, min_running=900000)
+    running = rl_loop(mod, cfg, 2, 4, mod._default_backend_path(), warmup=300, steps=40, min_running=900000, twin_steps=12)
     print("100x100: %d running vehicles, %.0f s" % (running, time.time() - t0))

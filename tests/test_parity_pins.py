@@ -179,7 +179,7 @@ def large_checkpoint_body(mod, scen, workdir, device, n, flows_per_100, min_runn
 
 
 @pytest.mark.parametrize("n,flows_per_100,min_running,twin_steps,layout,rl", [
-    (60, 333, 300000, 20, "dense", False), (60, 333, 300000, 20, "ring", False), (100, 333, 900000, 8, "auto", True)])
+    (60, 333, 300000, 20, "dense", False), (60, 333, 300000, 20, "ring", False), (100, 333, 900000, 60, "auto", True)])
 def test_large_checkpoint_equals_twin(mod, scen, workdir, n, flows_per_100, min_running, twin_steps, layout, rl):
     """Sizes where the engine switches to its throughput kernels by itself (k_cross2 above 240 k slots).  The 100x100 case is
     BASELINE.json configs[4] as an RL agent drives it: rlTrafficLight, a new phase for every signal through set_tl_phases
