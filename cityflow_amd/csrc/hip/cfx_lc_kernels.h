@@ -254,6 +254,8 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     const int env = oneEnv ? -1 : road / lc.roadsPerEnv;  // (-1: lcWalkPosition counts all candidates)
     const int nListed = lc.roadCand[road];
     if (nListed == 0) return;
+    KSTAMP(9, 0);
+    KNOTE(9, 5, nListed);
     const int tid = threadIdx.x;
     const cfx_vehicle_template *tv = c.t.templ;
     const int l0 = lc.roadLaneStart[road], l1 = lc.roadLaneStart[road + 1];
@@ -280,8 +282,10 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
             lnSegs[tid] = lc.laneNumSegs[l0 + tid];
         }
     }
+    KSTAMP(9, 1);
     const bool tooMany = nListed > kLcRoadCand;
     const int nAll = *lc.candAllCount;
+    KNOTE(9, 7, nAll);
     if (!tooMany && tid < nListed) {  // the road's candidates (sorted by walk position below)
         const int2 e = lc.roadCandList[(size_t) road * kLcRoadCand + tid];
         candVid[tid] = e.x;
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
         __threadfence_block();
     }
     __syncthreads();
+    KSTAMP(9, 2);
     if (tid != 0) return;
     lc.roadCand[road] = 0;
     // accessors: a slot of this road's lanes, a lane of this road
@@ -549,6 +554,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
             }
         }
     }
+    KSTAMP(9, 4);
 }
 
 // Engine::insertShadow engine.cpp:812-820 + the Vehicle copy constructor vehicle.cpp:28-36 + LaneChange::insertShadow

@@ -505,6 +505,7 @@ void EngineHost::load(const Archive &a) {
     st.tl_phase = d.tlPhase.data();
     st.tl_remain = d.tlRemain.data();
     check(be_.cfx_load_state(dev_, &st), "cfx_load_state");
+    forgetPhases();  // (the lights now show the archive's phases)
     if (laneHistory_ && d.hLen.size() == net_->lanes.size()) {  // Archive::resume archive.cpp:107-109 (an archive without it: as it is)
         cfx_lane_history h{(int32_t) d.hLen.size(), const_cast<int32_t *>(d.hLen.data()), const_cast<int32_t *>(d.hVehicleNum.data()),
                            const_cast<double *>(d.hAverageSpeed.data()), const_cast<int32_t *>(d.hHistoryVehicleNum.data()),

@@ -245,11 +245,28 @@ void EngineHost::uploadNewTablesIfAny() {
 }
 
 // ---------------------------------------------------------------- stepping
+bool EngineHost::onlyChangedPhases(std::vector<int32_t> &inters, std::vector<int32_t> &phases) {
+    if (!rlTrafficLight_) return !inters.empty();  // (the device advances the lights itself: nothing is known here)
+    if (knownPhase_.size() != net_->inters.size()) knownPhase_.assign(net_->inters.size(), -1);
+    size_t keep = 0;
+    for (size_t i = 0; i < inters.size(); ++i) {  // (in call order: a later call for the same intersection wins, as on the device)
+        if (knownPhase_[(size_t) inters[i]] == phases[i]) continue;
+        knownPhase_[(size_t) inters[i]] = phases[i];
+        inters[keep] = inters[i];
+        phases[keep] = phases[i];
+        ++keep;
+    }
+    inters.resize(keep);
+    phases.resize(keep);
+    return keep > 0;
+}
+
 void EngineHost::flushPhases() {
     if (pendingPhaseInter_.empty()) return;
-    check(be_.cfx_set_tl_phases(dev_, (int32_t) pendingPhaseInter_.size(), pendingPhaseInter_.data(),
-                                pendingPhaseValue_.data()),
-          "cfx_set_tl_phases");
+    if (onlyChangedPhases(pendingPhaseInter_, pendingPhaseValue_))
+        check(be_.cfx_set_tl_phases(dev_, (int32_t) pendingPhaseInter_.size(), pendingPhaseInter_.data(),
+                                    pendingPhaseValue_.data()),
+              "cfx_set_tl_phases");
     pendingPhaseInter_.clear();
     pendingPhaseValue_.clear();
 }
@@ -344,6 +361,7 @@ void EngineHost::reset(bool resetRnd) {
     settleLaneChange();
     pendingPhaseInter_.clear();  // TrafficLight::reset puts every light back to phase 0 anyway
     pendingPhaseValue_.clear();
+    forgetPhases();
     check(be_.cfx_reset(dev_), "cfx_reset");
     spawner_.reset(resetRnd);
     step_ = 0;
@@ -652,7 +670,8 @@ void EngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) {
         inters.push_back((int32_t) i);
         ph.push_back(phases[i]);
     }
-    check(be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data()), "cfx_set_tl_phases");
+    if (onlyChangedPhases(inters, ph))
+        check(be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data()), "cfx_set_tl_phases");
 }
 
 // setTrafficLightPhase engine.cpp:719-725

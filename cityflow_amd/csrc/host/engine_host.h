@@ -200,6 +200,13 @@ private:
     bool lcPollPending_ = false;
     void settleLaneChange();
     std::vector<int32_t> pendingPhaseInter_, pendingPhaseValue_;  // set_tl_phase calls since the last flush
+    // rlTrafficLight: the phase the device shows at every intersection, as far as this host knows (-1: not known) — with agent
+    // control nothing but these calls changes a phase (TrafficLight::passTime does not run, trafficlight.cpp:29-37), so an
+    // agent that sets every signal every step uploads only the ones it actually changes; forgotten on reset / load
+    std::vector<int32_t> knownPhase_;
+    void forgetPhases() { knownPhase_.assign(knownPhase_.size(), -1); }
+    // keeps of (inters, phases) what differs from knownPhase_ and records it; false: nothing left to send
+    bool onlyChangedPhases(std::vector<int32_t> &inters, std::vector<int32_t> &phases);
     void flushPhases();
     std::vector<int32_t> laneIdOrder_;
     uint64_t vehicleEpoch_ = 0;

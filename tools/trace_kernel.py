@@ -11,6 +11,9 @@ sys.argv = [sys.argv[0]]
 import bench
 from cityflow_amd import _cityflow
 cfg = bench.build_workload("/tmp/cfa_exp", 0, scenario=os.environ.get("CFX_TRACE_SCENARIO", "gen_100x100"), n_extra=int(os.environ.get("CFX_EXP_EXTRA", 33000)))
+if os.environ.get("CFX_TRACE_LC"):  # the lane-change step: the state is built with lane change too
+    c0 = json.load(open(cfg)); c0["laneChange"] = True
+    cfg = cfg.replace(".json", "_lcbase.json"); json.dump(c0, open(cfg, "w"))
 base = _cityflow.Engine(cfg, 1)
 for _ in range(300):
     base.next_step()
@@ -20,6 +23,8 @@ for spec in specs:
     kid, form = spec.split("=")
     lib = os.path.join(ROOT, "gpurun_exp", "lib_tr%s.so" % kid)
     c = json.load(open(cfg)); c["cfx"] = {"layout": "dense", "denseForm": int(form)}
+    if os.environ.get("CFX_TRACE_LC"):
+        c["laneChange"] = True
     cfg2 = cfg.replace(".json", "_tr%s.json" % kid); json.dump(c, open(cfg2, "w"))
     dll = ctypes.CDLL(lib)
     eng = _cityflow.Engine._with_backend(cfg2, 1, lib)
