@@ -1123,7 +1123,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     SpawnBatchBig batch;  // (the records go with the admission kernel's arguments: up to kAdmitRecs, kd_admit up to kAdmitRecsBig)
     batch.n = 0;
     batch.firstNewVid = 0;
-    const int batchRoom = (e->useTails() && (e->denseForm & 4)) ? kAdmitRecsBig : kAdmitRecs;
+    // (the ring layout too: more records than the small batch holds kept the step from riding its commit with the next
+    // admission, and cost a launch of their own; a step with up to kAdmitRecs records runs the small instantiation as before)
+    const int batchRoom = ((e->useTails() && (e->denseForm & 4)) || e->ring) ? kAdmitRecsBig : kAdmitRecs;
     auto smallBatch = [&batch]() {  // (the kernels that take at most kAdmitRecs records)
         SpawnBatch b;
         b.n = batch.n;
@@ -1269,10 +1271,17 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             e->commitPending = false;
             int nStatPrev = 1;
             const RingCommit rkPrev = e->commitArgs(activeEst, true, &nStatPrev);
-            e->launch(PK_ADMIT, kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
-                      e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), rkPrev);
+            if (batch.n > kAdmitRecs)
+                e->launch(PK_ADMIT, kr_admit<true, kAdmitRecsBig>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
+                          e->admitStep, e->waitHead, e->vt, e->sc, batch, rkPrev);
+            else
+                e->launch(PK_ADMIT, kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
+                          e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), rkPrev);
         } else {
-            e->launch(PK_ADMIT, kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{});
+            if (batch.n > kAdmitRecs)
+                e->launch(PK_ADMIT, kr_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{});
+            else
+                e->launch(PK_ADMIT, kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{});
         }
         RING_CHECK("kr_admit")
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then

@@ -302,9 +302,9 @@ __device__ inline void commitClearMasks(const RingCtx &c, const RingCommit &k, i
 // admission; its statistics blocks at the end of the grid).  `cIn` is then the context of the step being committed and the
 // admission runs on the next step's view of it.  What a lane's admission reads of the commit is what its own thread wrote —
 // its tail, its count, its queue — except the lights, which the cross kernel of the committed step has already advanced.
-template <bool COMMIT>
+template <bool COMMIT, int NB = kAdmitRecs>  // NB: spawn records the arguments hold (kAdmitRecsBig on large networks, as kd_admit)
 __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitStep, int32_t *waitHead, VidTable vt, DevScalars *sc,
-                                                   const SpawnBatch batch, const RingCommit k) {
+                                                   const SpawnBatchT<NB> batch, const RingCommit k) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     const bool isLane = d < cIn.n.L, inRange = d < cIn.n.L + cIn.n.K;
     // what the admission needs and the commit in front of it leaves alone — or changes through this very thread, which then
@@ -363,11 +363,11 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
     }
     __shared__ int sAdmitted;
     __shared__ cfx_vehicle_template sT[kLdsTempl];
-    __shared__ int sLane[kAdmitRecs];
+    __shared__ int sLane[NB];
     const cfx_vehicle_template *tv = c.t.templ;
     const int nRecs = batch.n, firstNewVid = batch.firstNewVid;
     if (threadIdx.x == 0) sAdmitted = 0;
-    if ((int) threadIdx.x < nRecs) sLane[threadIdx.x] = batch.lane[threadIdx.x];
+    for (int i = threadIdx.x; i < nRecs; i += blockDim.x) sLane[i] = batch.lane[i];
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
