@@ -327,7 +327,7 @@ def roofline_from_profile(prof, vehicle_steps, workload_tag, note, with_traffic=
     vehicles_per_launch = vehicle_steps / float(act_n)
     avg_s = act_ms / act_n / 1e3
     achieved = ACTION_BYTES_PER_VEHICLE * vehicles_per_launch / avg_s / 1e9
-    traffic, traffic_src = pmc_traffic(("kr_action", "kw_action", "kd_action", "k_action"), workload_tag) if with_traffic else (None, None)
+    traffic, traffic_src = pmc_traffic(("kr_action", "kw_action", "kl_action", "kd_action", "k_action"), workload_tag) if with_traffic else (None, None)
     return {
         "bound": "hbm", "kernel": "k_action", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -274,16 +274,23 @@ struct StepCtx {
 namespace cfxd {
 
 // Developer build (-DCFX_TRACE): per-block wall-clock stamps (100 MHz) of ONE kernel's phases, chosen at build time with
-// -DCFX_TRACE_KERNEL=<id> (0: the ring layout's kr_action / kr_cross as tools/trace_action.py reads them; 6 kd_action, 8 k_cross2;
+// -DCFX_TRACE_KERNEL=<id> (0: the ring layout's kr_action / kr_cross as tools/trace_action.py reads them; 6 kd_action, 8 k_cross2, 9 k_lc_schedule, 10 kr_index, 11 kl_action;
 // tools/trace_kernel.py); row = block index
 #ifdef CFX_TRACE
 __device__ long long *g_trace;  // [65536 * 8]
 #ifndef CFX_TRACE_KERNEL
 #define CFX_TRACE_KERNEL 0
 #endif
+// (-DCFX_TRACE_CYCLES: the shader clock instead, s_memtime — spans within a block only.  A kernel whose blocks all start
+//  together queues up on the ONE wall clock: 1880 blocks stamping at once measured 10 us per stamp, round 5)
+#ifdef CFX_TRACE_CYCLES
+#define KCLOCK() clock64()
+#else
+#define KCLOCK() wall_clock64()
+#endif
 #define KSTAMP(id, k)                                                                                       \
     if (CFX_TRACE_KERNEL == (id) && threadIdx.x == 0 && blockIdx.x < 65536)                                  \
-    g_trace[(size_t) blockIdx.x * 8 + (k)] = (long long) wall_clock64()
+    g_trace[(size_t) blockIdx.x * 8 + (k)] = (long long) KCLOCK()
 #define KNOTE(id, k, v)                                                                                     \
     if (CFX_TRACE_KERNEL == (id) && threadIdx.x == 0 && blockIdx.x < 65536) g_trace[(size_t) blockIdx.x * 8 + (k)] = (long long) (v)
 #else

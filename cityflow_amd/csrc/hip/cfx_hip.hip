@@ -240,6 +240,10 @@ struct cfx_engine {
     LLAux *rLLAux = nullptr;
     int4 *rLLGate = nullptr;
     int32_t *rGatePhase = nullptr;     // [2 I] RingCtx::gatePhase
+    int4 *rList = nullptr;             // the step's vehicle list (kr_index -> kl_action), grown with the running vehicles
+    size_t rListCap = 0;
+    int32_t *rListCount = nullptr;     // [2] {entries, kr_index's tile ticket}
+    unsigned long long *rIdxGranules = nullptr;  // [tiles of 256 drivables] {epoch, vehicles}
     RingDense rd{};                    // dense staging view (getters, archive, growth)
     size_t rdCap = 0;
     int32_t *rOff = nullptr;           // [D + 1] exclusive prefix sum of rCnt
@@ -794,6 +798,10 @@ struct cfx_engine {
         HIP_TRY(hipMemsetAsync(sc, 0, sizeof(DevScalars), stream));
         HIP_TRY(hipMemsetAsync(scanGranules, 0, (size_t) nScanBlocks * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(scanTicket, 0, sizeof(int32_t), stream));
+        if (rIdxGranules) {  // (the epochs are step numbers, which start over)
+            HIP_TRY(hipMemsetAsync(rIdxGranules, 0, (size_t) gridFor(D) * sizeof(unsigned long long), stream));
+            HIP_TRY(hipMemsetAsync(rListCount, 0, 2 * sizeof(int32_t), stream));
+        }
         HIP_TRY(hipMemsetAsync(jobCount, 0, (size_t) kJobShards * kJobShardStride * sizeof(int32_t), stream));
         if (finCount) HIP_TRY(hipMemsetAsync(finCount, 0, (size_t) kFinShards * 32 * sizeof(int32_t), stream));
         if (finTicket) HIP_TRY(hipMemsetAsync(finTicket, 0, 4 * sizeof(int32_t), stream));
@@ -1323,6 +1331,37 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 }
                 G = e->ringG;
             }
+            // + 30000: the list form (kr_index + kl_action; the default where the cross phase runs k_cross2)
+            const bool listForm = (form == 3 || (form == 0 && !e->tiled && (useBig || activeEst > 240000)));
+            if (listForm) {
+                // a TRUE bound of the vehicles this step can list (the list and the launch are sized by it): what the device
+                // reported after the last step it has completed plus one admission per queueing lane and step since
+                const int64_t done = (int64_t) (pr >> 32);
+                if (done > 0 && done <= e->step)
+                    e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + e->nQueueLanes * (e->step + 1 - done));
+                const size_t listBound = (size_t) std::min<int64_t>(e->liveUpper, (int64_t) e->ringSlots);
+                const size_t needList = (listBound + kBlock - 1) / kBlock * kBlock + kBlock;
+                if (needList > e->rListCap) {
+                    const size_t nc = std::max(needList + needList / 4, e->rListCap * 2) / kBlock * kBlock;
+                    int rc = e->growDeferred(&e->rList, 0, nc);  // (rebuilt every step: nothing to keep)
+                    if (rc) return rc;
+                    e->rListCap = nc;
+                    if (!e->rListCount) {
+                        if ((rc = e->allocRaw(&e->rListCount, 2)) || (rc = e->allocRaw(&e->rIdxGranules, (size_t) gridFor(e->D)))) return rc;
+                        HIP_TRY(hipMemsetAsync(e->rIdxGranules, 0, (size_t) gridFor(e->D) * sizeof(unsigned long long), st));
+                        HIP_TRY(hipMemsetAsync(e->rListCount, 0, 2 * sizeof(int32_t), st));
+                    }
+                }
+                const int nVehBlocks = (int) (needList / kBlock);  // (every entry a block of the launch reads exists)
+                const int nLL = (e->K + kBlock - 1) / kBlock;
+                const int nIdxTiles = (int) ((e->D + kIndexTile - 1) / kIndexTile);
+                int32_t *const idxTicket = nIdxTiles > kScanResidentTiles ? e->rListCount + 1 : nullptr;  // (1024 threads: two blocks per CU)
+                e->launch(PK_SCAN, kr_index, dim3(nIdxTiles), dim3(kIndexBlock), c, e->rIdxGranules, idxTicket, (unsigned) (e->step + 1),
+                          e->rList, (int) e->rListCap, e->rListCount, e->sc);
+                RING_CHECK("kr_index")
+                e->launch(PK_ACTION, kl_action, dim3(nVehBlocks + nLL), dim3(kBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
+                          (const int32_t *) e->rListCount, nVehBlocks, idxTicket);
+            } else {
             G = std::min(G, Bsel);
             const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;
             // (first form: as many blocks again at the end of the grid compute the laneLinks' notify sources)
@@ -1333,6 +1372,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             } else {
                 if (Bsel == 256) e->launch(PK_ACTION, kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
                 else e->launch(PK_ACTION, kw_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+            }
             }
         }
         RING_CHECK("kr_action")

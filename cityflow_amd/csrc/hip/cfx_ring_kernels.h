@@ -1354,6 +1354,236 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
     }
 }
 
+// The LIST form of the phase (large networks).  kw_action pays a block-wide preamble — ring geometry, prefix sum, a binary
+// search per vehicle — before its first slot load, and a block's vehicles rarely fill its chunks (28 lanes x 4.3 vehicles =
+// 120 of 256 threads at 1 M vehicles).  Here the step first writes the list of its vehicles, {slot, drivable, list index,
+// vehicles on the drivable | admitted << 31} in drivable order (kr_index: an exclusive scan over the drivables' counts with
+// the decoupled look-back k_scan uses, then the entries), and kl_action is
+// one thread per list entry: round 1 the entry, round 2 the slot's two records, the leader's (wavefront exchange) and the
+// drivable's static tables, then rounds A / B / C of actionOneRounds — the dense layout's chain of four rounds, on rings.
+constexpr int kIndexBlock = 1024;                      // threads per tile (sixteen wavefronts share a tile's expansion)
+constexpr int kIndexItems = 1;                         // drivables per thread
+constexpr int kIndexTile = kIndexBlock * kIndexItems;  // drivables per tile: 100x100 is 470 tiles, all resident at once
+constexpr int kIndexWindow = 8192;                // list entries a tile expands per pass (a tile holds about 4400 at 1 M vehicles)
+
+// One tile = 1024 drivables, one per thread.  A tile publishes its TOTAL right after its block scan
+// (nothing waits on a predecessor before publishing: no serial chain through the tiles), adds up its predecessors' totals,
+// and expands its drivables into list entries through LDS: every thread marks the window positions its drivables own (two
+// bytes each), then the block writes the window's entries side by side, 16 bytes per thread.  Tiles are block indices while
+// the whole grid is certainly resident (1024 tiles = a million drivables); beyond that they are handed out in start order
+// by a ticket — 11 ns each, the rate of returning atomics on one word: 1880 tiles of 256 drivables spent 21 of their 32 us
+// queueing for it (profiles/r05_trace_kr_index.txt).
+__global__ __launch_bounds__(kIndexBlock) void kr_index(RingCtx c, unsigned long long *granules, int32_t *ticket, unsigned epoch,
+                                                   int4 *list, int listCap, int32_t *listCount, DevScalars *sc) {
+    static_assert(kIndexTile <= 65536, "a window position names its drivable in two bytes");
+    __shared__ int smem[kIndexBlock / 64];
+    __shared__ int wsum[kIndexBlock / 64];
+    __shared__ int tileShared;
+    __shared__ int sOff[kIndexTile], sHead[kIndexTile], sN[kIndexTile];
+    __shared__ int2 sGeo[kIndexTile];
+    __shared__ unsigned short sOwner[kIndexWindow];
+    const int t = (int) threadIdx.x;
+    KSTAMP(10, 0);
+    int tile = (int) blockIdx.x;
+    if (ticket) {
+        if (t == 0) tileShared = atomicAdd(ticket, 1);
+        __syncthreads();
+        tile = tileShared;
+    }
+    const int D = c.n.L + c.n.K;
+    const int d0 = tile * kIndexTile + t * kIndexItems;
+    int n[kIndexItems], head[kIndexItems], adm[kIndexItems];
+    int2 geo[kIndexItems];
+    int sum = 0;
+    for (int i = 0; i < kIndexItems; ++i) {
+        const int d = d0 + i;
+        n[i] = 0;
+        head[i] = 0;
+        adm[i] = -1;
+        geo[i] = make_int2(0, 0);
+        if (d < D) {
+            n[i] = c.cnt[d];
+            head[i] = c.head[d];
+            geo[i] = c.ringGeo[d];
+            if (d < c.n.L) adm[i] = c.admitStep[d];
+        }
+    }
+    for (int i = 0; i < kIndexItems; ++i) {
+        adm[i] = (d0 + i < c.n.L && adm[i] == c.step) ? 1 : 0;
+        n[i] += adm[i];
+        sum += n[i];
+    }
+    const int lane = t & 63, w = t >> 6;
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < kIndexBlock / 64; ++i) {
+            smem[i] = run;
+            run += wsum[i];
+        }
+        tileShared = run;
+        __hip_atomic_store(&granules[tile], ((unsigned long long) epoch << 32) | (unsigned) run, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    KSTAMP(10, 1);
+    const int offT = smem[w] + incl - sum;  // this thread's first entry within the tile
+    const int T = tileShared;
+    __syncthreads();
+    {
+        int off = offT;
+        for (int i = 0; i < kIndexItems; ++i) {
+            const int o = t * kIndexItems + i;
+            sOff[o] = off;
+            sHead[o] = head[i];
+            sN[o] = n[i] | (adm[i] << 31);
+            sGeo[o] = geo[i];
+            off += n[i];
+        }
+    }
+    int pre = 0;
+    for (int p = t; p < tile; p += kIndexBlock) {
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned long long x = __hip_atomic_load(&granules[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned) (x >> 32) == epoch) {
+                pre += (int) (unsigned) x;
+                break;
+            }
+            if (++spins > kSpinLimit) {  // cannot happen unless a tile died; do not hang the device
+                sc->overflow = 2;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    const int tileOff = blockReduceSum(pre, smem);
+    KSTAMP(10, 2);
+    for (int w0 = 0; w0 < T; w0 += kIndexWindow) {
+        int off = offT;
+        for (int i = 0; i < kIndexItems; ++i) {
+            const int lo = max(0, w0 - off), hi = min(n[i], w0 + kIndexWindow - off);
+            for (int j = lo; j < hi; ++j) sOwner[off + j - w0] = (unsigned short) (t * kIndexItems + i);
+            off += n[i];
+        }
+        __syncthreads();
+        const int wn = min(kIndexWindow, T - w0);
+        for (int q = t; q < wn; q += kIndexBlock) {
+            const int o = sOwner[q];
+            const int idx = w0 + q - sOff[o];
+            const int at = tileOff + w0 + q;
+            if (at < listCap) list[at] = make_int4(ringSlot(sGeo[o], sHead[o], idx), tile * kIndexTile + o, idx, sN[o]);
+        }
+        __syncthreads();
+    }
+    KSTAMP(10, 3);
+    if (tile == (int) gridDim.x - 1 && t == 0) {
+        *listCount = min(tileOff + T, listCap);
+        if (tileOff + T > listCap) sc->overflow = 13;  // the host sizes the list from its own bound of the running vehicles
+    }
+}
+
+#ifndef CFX_KL_WAVES
+#define CFX_KL_WAVES 5  // (97 registers unasked: one more than five wavefronts per SIMD allow; 48.5 us instead of 51.8.  6 spills: 73.7)
+#endif
+#define CFX_KL_BOUNDS __launch_bounds__(kBlock, CFX_KL_WAVES)
+__global__ CFX_KL_BOUNDS void kl_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, const int4 *list,
+                                                    const int32_t *listCount, int nVehBlocks, int32_t *ticket) {
+    const int w = (int) blockIdx.x, t = (int) threadIdx.x;
+    if (w >= nVehBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
+        llstateRing(c, (w - nVehBlocks) * kBlock + t);
+        return;
+    }
+    __shared__ cfx_vehicle_template sT[kLdsTempl];
+    const int qv = w * kBlock + t;
+    const int total = *listCount;
+    if (qv == 0 && ticket) *ticket = 0;  // kr_index of this step is done; re-arm its tile counter for the next one
+    KSTAMP(11, 0);
+    const int4 e = list[qv];  // (the list is allocated to whole blocks of the launch)
+    int ls = 0;
+    if ((t & 63) == 0 && qv > 0) ls = list[qv - 1].x;  // the vehicle ahead of the wavefront's first one, if it has a leader
+    if (w * kBlock >= total) return;
+    const cfx_vehicle_template *tv = c.t.templ;
+    if (c.t.nTempl <= kLdsTempl) {
+        const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
+        const double *src = (const double *) c.t.templ;
+        double *dst = (double *) sT;
+        for (int i = t; i < nd; i += kBlock) dst[i] = src[i];
+        tv = sT;
+        __syncthreads();
+    }
+    const bool valid = qv < total;
+    const int lane = t & 63;
+    const int slot = valid ? e.x : 0, d = e.y, idx = valid ? e.z : 0;
+    KSTAMP(11, 1);
+    SlotIn in;
+    in.vid = 0;  // (the vehicle number is loaded where it is needed: custom speed, leaving the drivable)
+    in.dis = 0.0;
+    in.speed = 0.0;
+    in.templIdx = 0;
+    in.nd0 = -1;
+    in.flags = 0;
+    double2 kp = make_double2(0.0, 0.0);
+    int tp = 0;
+    double2 lm = make_double2(0.0, 0.0);
+    int4 hop = make_int4(-2, -2, -2, -2), en = make_int4(-1, -1, -1, -1);
+    if (valid) {
+        const double2 kv = c.kin[slot];
+        const int4 mv = c.meta[slot];
+        lm = c.n.drvLM[d];
+        if (d < c.n.L) {
+            hop = c.n.laneLL4[d];
+            en = c.n.laneEnd4[d];
+        }
+        if (idx > 0 && lane == 0) {
+            kp = c.kin[ls];
+            tp = c.meta[ls].x;
+        }
+        in.dis = kv.x;
+        in.speed = kv.y;
+        in.templIdx = mv.x;
+        in.nd0 = mv.y;
+        in.flags = mv.z;
+        in.lastRoadFlags = mv.z;
+    }
+    const int slotUp = __shfl_up(slot, 1, 64);
+    const double disUp = __shfl_up(in.dis, 1, 64), speedUp = __shfl_up(in.speed, 1, 64);
+    const int templUp = __shfl_up(in.templIdx, 1, 64);
+    if (!valid) return;
+    if (lane != 0) ls = slotUp;
+    in.d = d;
+    in.head = idx == 0;
+    in.idx = idx;
+    in.nNow = e.w & 0x7fffffff;
+    in.leaderSlot = idx > 0 ? ls : 0;
+    in.disPrev = lane == 0 ? kp.x : disUp;
+    in.speedPrev = lane == 0 ? kp.y : speedUp;
+    in.templPrev = lane == 0 ? tp : templUp;
+    if (in.flags & (kFlagCustom | kFlagStateGap)) {
+        in.vid = c.s.vid[slot];
+        c.meta[slot].z = in.flags & ~(kFlagCustom | kFlagStateGap);  // Vehicle::update clears isCustomSpeedSet (vehicle.cpp:120-122)
+    }
+    in.lm = lm;
+    in.hop = make_int4(-2, -2, -2, -2);
+    in.endLane = -1;
+    if (in.nd0 >= c.n.L) {
+        in.hop = hop;
+        const int ll = in.nd0 - c.n.L;
+        in.endLane = hop.x == ll ? en.x : (hop.y == ll ? en.y : (hop.z == ll ? en.z : (hop.w == ll ? en.w : -1)));
+    }
+    in.laneAdmitted = e.w < 0;
+    const RingPush push{q, jobRecs, c.n.L};
+    KSTAMP(11, 2);
+    actionOneRounds(c, o, tv, slot, in, push);
+    KSTAMP(11, 3);
+}
+
 // ---------------------------------------------------------------------------------------------- phase 5 + 6 + 8
 // Commit: one thread per drivable.  Leavers are (almost always) a prefix of the list: the head moves past them.  Entrants
 // are appended behind the stayers by descending new distance (std::sort with vehicleCmp engine.h:21-23; ties: lower vid

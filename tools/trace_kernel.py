@@ -22,7 +22,7 @@ del base
 for spec in specs:
     kid, form = spec.split("=")
     lib = os.path.join(ROOT, "gpurun_exp", "lib_tr%s.so" % kid)
-    c = json.load(open(cfg)); c["cfx"] = {"layout": "dense", "denseForm": int(form)}
+    c = json.load(open(cfg)); c["cfx"] = {"layout": os.environ.get("CFX_TRACE_LAYOUT", "dense"), "denseForm": int(form)}
     if os.environ.get("CFX_TRACE_LC"):
         c["laneChange"] = True
     cfg2 = cfg.replace(".json", "_tr%s.json" % kid); json.dump(c, open(cfg2, "w"))
@@ -45,7 +45,8 @@ for spec in specs:
     if not len(a):
         continue
     t0 = a[:, 0].min()
-    endcol = 6 if (a[:, 6] > 0).any() and kid == "8" else 4
+    endcol = 6 if (a[:, 6] > 0).any() and kid == "8" else (4 if (a[:, 4] > 0).any() else 3)
+    a = a[a[:, endcol] > 0]
     us = lambda x: (x - t0) / 100.0
     print("   start: avg %.2f p90 %.2f max %.2f us | end: avg %.2f p50 %.2f p90 %.2f max %.2f us" % (
         us(a[:, 0]).mean(), np.percentile(us(a[:, 0]), 90), us(a[:, 0]).max(), us(a[:, endcol]).mean(),
@@ -65,6 +66,11 @@ for spec in specs:
         b = a[a[:, 7] > 0]
         if len(b):
             print("   stamp 7 (k_cross2: after pass A1) present in %d blocks: at avg %.2f us after the block's start" % (len(b), ((b[:, 7] - b[:, 0]) / 100.0).mean()))
+    if os.environ.get("CFX_TRACE_RAW"):  # stamps in time order, whatever their slot numbers mean in this build
+        for k in range(1, 8):
+            if (a[:, k] > t0).all():
+                d = (a[:, k] - a[:, 0]) / 100.0
+                print("   raw stamp %d: avg %.2f p50 %.2f p90 %.2f max %.2f us after the block's start" % (k, d.mean(), np.percentile(d, 50), np.percentile(d, 90), d.max()))
     part = [k for k in (2, 3) if not (a[:, k] > 0).all() and (a[:, k] > 0).any()]
     for k in part:
         b = a[a[:, k] > 0]
