@@ -865,11 +865,12 @@ static int32_t createImpl(cfx_engine *e, const cfx_net *n, const cfx_config *cfg
     e->cross2 = cfg->cross_mode == CFX_CROSS_THROUGHPUT ? 1 : cfg->cross_mode == CFX_CROSS_LATENCY ? 0 : -1;
     if (cfg->layout == CFX_LAYOUT_RING && cfg->lane_change)
         return e->fail("cfx_create: layout ring does not run lane change (its mid-lane insertions use the dense layout)");
-    // auto: the ring layout commits a step with a fraction of the dense layout's data movement, but its state is spread
-    // over every ring's capacity (~7 slots per vehicle at the usual densities) — measured on the MI355X it is ahead up to
-    // ~150 k running vehicles (30x30: 56 vs 61 us / step) and behind once that state no longer sits in the caches
-    // (60x60: 112 vs 101, 100x100: 227 vs 191).  Lanes are the proxy for size known at creation.
-    e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change && n->n_lanes <= 20000);
+    // auto: the ring layout wherever it runs (not lane change; a tiled engine goes back to the dense layout in
+    // cfx_halo_config).  It commits a step with a fraction of the dense layout's data movement; until round 5 its action
+    // phase walked the lanes, which a large, sparsely filled network made slower than the dense layout (100x100: 227 vs 191
+    // us) — with the list form of the action phase (kr_index + kl_action) it is ahead at every size measured: 100x100 with
+    // 72 k / 277 k / 970 k running vehicles 54.7 / 86 / 141 us per step against 69.4 / 100 / 157.6 on the dense layout.
+    e->ring = cfg->layout == CFX_LAYOUT_RING || (cfg->layout == CFX_LAYOUT_AUTO && !cfg->lane_change);
     e->ringMerge = (cfg->ring_lanes_per_wave / 10000) % 10 != 4;
     e->denseForm = cfg->dense_form ? (cfg->dense_form & 255) : CFX_DENSE_FORM_DEFAULT;
     e->hDrvLength.assign(n->drv_length, n->drv_length + n->n_lanes + n->n_lanelinks);
@@ -1332,7 +1333,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 G = e->ringG;
             }
             // + 30000: the list form (kr_index + kl_action; the default where the cross phase runs k_cross2)
-            const bool listForm = (form == 3 || (form == 0 && !e->tiled && (useBig || activeEst > 240000)));
+            // (the lane-walking forms cost per lane, the list per vehicle plus 8 to 12 us for the list: 30x30, 10.8 k lanes, 90 k
+            //  vehicles: 41.0 us per step in block form, 49.0 with the list; 100x100, 120 k lanes, 72 k vehicles: 97.1 and 54.7)
+            const bool listForm = form == 3 || (form == 0 && !e->tiled && (useBig || activeEst > 240000 || e->L > 20000));
             if (listForm) {
                 // a TRUE bound of the vehicles this step can list (the list and the launch are sized by it): what the device
                 // reported after the last step it has completed plus one admission per queueing lane and step since
@@ -1391,7 +1394,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         }
         if (useBig)
             e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
-                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) 5 * e->nCU)),  // (5 blocks per CU: 95 registers)
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) CFX_RING_CROSS2_WAVES * e->nCU)),  // (5 blocks per CU: 95 registers)
                       dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
         {

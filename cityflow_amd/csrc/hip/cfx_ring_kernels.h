@@ -29,7 +29,10 @@ namespace cfxd {
 struct RingCtx {
     // (k_cross2 on the ring layout needs 95 registers; asking for 7 wavefronts per SIMD spills and was measured slower,
     // 66 -> 72 us at 1 M vehicles: 5 = as the compiler has it)
-    static constexpr int kCross2Waves = 5;
+#ifndef CFX_RING_CROSS2_WAVES
+#define CFX_RING_CROSS2_WAVES 5  // (6: 80 registers, 21 spilled, 47.0 us at 1 M vehicles; 7: 72 / 44, 52.5 us; 5: 43.7 us)
+#endif
+    static constexpr int kCross2Waves = CFX_RING_CROSS2_WAVES;
     DevNet n;
     DevTables t;
     SlotArrays s;            // the COLD columns only: vid, drv, prevDrv, routePos, route (the rest is null here)

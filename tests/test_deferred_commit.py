@@ -16,14 +16,14 @@ from conftest import TWIN_LIB, assert_same_state, assert_hip_backend
 pytestmark = pytest.mark.gpu
 
 
-def _engines(mod, scen, workdir, rl):
+def _engines(mod, scen, workdir, rl, form=0):
     base = scen.materialize("grid_6x6", workdir)
     d = os.path.dirname(base)
     flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_mix.json"), 250, seed=23, interval=3.0,
                             base_flow=os.path.join(d, "flow.json"))
     cfg = scen.materialize("grid_6x6", workdir, flow_file=flow, rlTrafficLight=rl)
     c = json.load(open(cfg))
-    c["cfx"] = {"layout": "ring"}
+    c["cfx"] = {"layout": "ring", "ringLanesPerWave": form}  # (30000: the list form of the action phase)
     ring = cfg.replace(".json", "_ring.json")
     json.dump(c, open(ring, "w"))
     hip = mod.Engine(ring, 1)
@@ -32,9 +32,9 @@ def _engines(mod, scen, workdir, rl):
     return hip, mod.Engine._with_backend(cfg, 1, TWIN_LIB)
 
 
-@pytest.mark.parametrize("rl,seed", [(True, 1), (True, 2), (False, 3)])
-def test_random_call_sequences_equal_twin(mod, scen, workdir, rl, seed):
-    hip, tw = _engines(mod, scen, workdir, rl)
+@pytest.mark.parametrize("rl,seed,form", [(True, 1, 0), (True, 2, 0), (False, 3, 0), (True, 4, 30000), (False, 5, 30000)])
+def test_random_call_sequences_equal_twin(mod, scen, workdir, rl, seed, form):
+    hip, tw = _engines(mod, scen, workdir, rl, form)
     rng = np.random.default_rng(seed)
     n_inter = len(hip.intersection_ids())
     archives = None
