@@ -1,0 +1,38 @@
+"""Developer probe: where an RL iteration's time goes on the headline network (rlTrafficLight): steps alone, steps with a
+sync each, steps with the lane counts read, phases set with and without the read.  us per iteration, 400 iterations each."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.argv = [sys.argv[0]]
+import bench
+from cityflow_amd import _cityflow
+cfg = bench.build_workload("/tmp/cfa_exp", 0, scenario="grid_30x30")
+rl = bench.with_config(cfg, "rl", rlTrafficLight=True)
+e = _cityflow.Engine(rl, 1)
+for _ in range(300):
+    e.next_step()
+e.sync()
+n_inter = len(e.intersection_ids())
+N = 400
+
+
+def run(name, body):
+    for s in range(20):
+        body(s)
+    e.sync()
+    t0 = time.perf_counter()
+    for s in range(N):
+        body(s)
+    e.sync()
+    print("%-58s %7.1f us" % (name, (time.perf_counter() - t0) / N * 1e6), flush=True)
+
+
+run("next_step", lambda s: e.next_step())
+run("next_step + sync", lambda s: (e.next_step(), e.sync()))
+run("next_step + lane counts", lambda s: (e.next_step(), e.get_lane_vehicle_count_array()))
+run("set_tl_phases (changing every 10) + next_step", lambda s: (e.set_tl_phases(np.full(n_inter, (s // 10) % 8, dtype=np.int32)), e.next_step()))
+run("set_tl_phases (changing every step) + next_step", lambda s: (e.set_tl_phases(np.full(n_inter, s % 8, dtype=np.int32)), e.next_step()))
+run("set_tl_phases (every 10) + next_step + lane counts", lambda s: (e.set_tl_phases(np.full(n_inter, (s // 10) % 8, dtype=np.int32)), e.next_step(), e.get_lane_vehicle_count_array()))
+run("lane counts alone (no step between)", lambda s: e.get_lane_vehicle_count_array())
+run("np.full alone", lambda s: np.full(n_inter, (s // 10) % 8, dtype=np.int32))
