@@ -1335,7 +1335,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // + 30000: the list form (kr_index + kl_action; the default where the cross phase runs k_cross2)
             // (the lane-walking forms cost per lane, the list per vehicle plus 8 to 12 us for the list: 30x30, 10.8 k lanes, 90 k
             //  vehicles: 41.0 us per step in block form, 49.0 with the list; 100x100, 120 k lanes, 72 k vehicles: 97.1 and 54.7)
-            const bool listForm = form == 3 || (form == 0 && !e->tiled && (useBig || activeEst > 240000 || e->L > 20000));
+            const bool listForm = form == 3 || form == 6 || (form == 0 && !e->tiled && (useBig || activeEst > 240000 || e->L > 20000));
             if (listForm) {
                 // a TRUE bound of the vehicles this step can list (the list and the launch are sized by it): what the device
                 // reported after the last step it has completed plus one admission per queueing lane and step since
@@ -1358,7 +1358,9 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 const int nVehBlocks = (int) (needList / kBlock);  // (every entry a block of the launch reads exists)
                 const int nLL = (e->K + kBlock - 1) / kBlock;
                 const int nIdxTiles = (int) ((e->D + kIndexTile - 1) / kIndexTile);
-                int32_t *const idxTicket = nIdxTiles > kScanResidentTiles ? e->rListCount + 1 : nullptr;  // (1024 threads: two blocks per CU)
+                // (1024 threads: two blocks per CU.  Form 6 hands the tiles out by ticket whatever their number: the path of networks
+                //  above half a million drivables, for the tests)
+                int32_t *const idxTicket = (nIdxTiles > kScanResidentTiles || form == 6) ? e->rListCount + 1 : nullptr;
                 e->launch(PK_SCAN, kr_index, dim3(nIdxTiles), dim3(kIndexBlock), c, e->rIdxGranules, idxTicket, (unsigned) (e->step + 1),
                           e->rList, (int) e->rListCap, e->rListCount, e->sc);
                 RING_CHECK("kr_index")

@@ -105,7 +105,8 @@ typedef struct cfx_config {
     int32_t ring_lanes_per_wave; /* ring layout, developer knob (0 = the engine decides everything): digits v = G + 1000 * (B / 256)
                                   * + 10000 * F.  G: lanes one workgroup of the action kernel owns (0 = adaptive); B: its
                                   * workgroup size (256 / 512 / 1024); F: form of the step — 0 by size, 1 wave-granular action
-                                  * kernel, 2 block-granular, 3 one thread per entry of the step's vehicle list (kr_index + kl_action), 4 as 0 with the commit
+                                  * kernel, 2 block-granular, 3 one thread per entry of the step's vehicle list (kr_index + kl_action; 6: its tiles handed out by
+                                  * ticket, as on networks above 524 k drivables), 4 as 0 with the commit
                                   * as a launch of its own.  Results never depend on it (tests/test_parity_pins.py) */
     int32_t ring_capacity_percent; /* ring layout: initial ring capacities as a percentage of the bumper-to-bumper bound
                                     * (0 = 100).  Small values make the growth path run (tests) — of the rings and, below 100,

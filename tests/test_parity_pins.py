@@ -94,10 +94,10 @@ def test_forced_choices_congested_grid(mod, scen, workdir, cross, layout):
     assert hip.get_vehicle_count() > 3000
 
 
-@pytest.mark.parametrize("form", [10000, 20000, 30000])
+@pytest.mark.parametrize("form", [10000, 20000, 30000, 60000])
 def test_ring_step_forms_equal_twin(mod, scen, workdir, form):
     """The forms of the ring layout's action kernel that `auto` picks by size, forced (cfx.ringLanesPerWave / 10000:
-    1 = wave-granular kw_action, 2 = block form kr_action, 3 = vehicle list kr_index + kl_action) on the 1x1 example (up to 118 crosses per laneLink, an
+    1 = wave-granular kw_action, 2 = block form kr_action, 3 = vehicle list kr_index + kl_action, 6 = the same with the list's tiles handed out by ticket) on the 1x1 example (up to 118 crosses per laneLink, an
     intersection with more than 64 laneLinks) and the congested 6x6."""
     hip, tw = _pair(mod, scen.materialize("example_1x1", workdir), layout="ring", ringLanesPerWave=form)
     for s in range(400):
