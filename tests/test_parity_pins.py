@@ -117,6 +117,26 @@ def test_ring_step_forms_equal_twin(mod, scen, workdir, form):
     assert hip.get_vehicle_count() > 2500
 
 
+def test_ring_list_form_free_running_equals_dense_layout(mod, workdir):
+    """The list form of the ring layout's action phase sizes its vehicle list and its launch from a host-side bound of the
+    running vehicles while the host runs steps ahead of the device: 3000 steps of the bench workload from an empty network
+    without a single synchronisation (the list grows from nothing), then every field equal to the dense layout's — an
+    engine that shares neither the layout nor the action kernel with it — and 40 more steps compared one by one."""
+    cfg = _bench_cfg(workdir)
+    lst = _hip(mod, _with_cfx(cfg, layout="ring", ringLanesPerWave=30000))
+    dense = _hip(mod, _with_cfx(cfg, layout="dense"))
+    for _ in range(3000):
+        lst.next_step()
+    for _ in range(3000):
+        dense.next_step()
+    assert_same_state(lst, dense, "after 3000 free-running steps")
+    assert lst.get_vehicle_count() > 50000
+    for s in range(40):
+        lst.next_step()
+        dense.next_step()
+        assert_same_state(lst, dense, "step %d after the free run" % (s + 1))
+
+
 @pytest.mark.parametrize("cross,layout", CHOICES)
 @pytest.mark.parametrize("seed", [11, 14])
 def test_forced_choices_irregular_networks(mod, scen, workdir, seed, cross, layout):
