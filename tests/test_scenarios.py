@@ -51,3 +51,26 @@ def test_generated_3x5_grid_reference_vs_twin(mod, scen, workdir, ref_module):
     assert ref.get_vehicle_count() > 50
     time.sleep(0.2)  # reference destructor race
     del ref
+
+
+def test_bench_roofline_is_priced_with_the_chunk_median_when_one_launch_is_an_outlier():
+    """bench.chunk_medians: an instrumented run read in parts; one launch that the box stretched to milliseconds must not
+    price the roofline (both figures stay in the line, and the choice is named)."""
+    import bench
+    veh = 87890.0
+    chunks = [{"k_action": (0.3125, 25), "k_cross": (0.4, 25)} for _ in range(4)]      # 12.5 us per launch
+    chunks[2] = {"k_action": (76.3, 25), "k_cross": (0.4, 25)}                           # one 76 ms launch among them
+    prof = {"k_action": (sum(c["k_action"][0] for c in chunks), 100), "k_cross": (1.6, 100)}
+    roof = bench.roofline_from_profile(prof, veh * 100, "no-such-workload", "test", with_traffic=False)
+    assert roof["avg_launch_us"] > 700
+    bench.chunk_medians(roof, chunks)
+    assert abs(roof["avg_launch_us"] - 12.5) < 1e-9 and roof["avg_launch_us_all_launches"] > 700
+    assert roof["duration_estimator"].startswith("median of 4 chunk averages")
+    assert abs(roof["frac"] - 48 * veh / 12.5e-6 / 1e9 / 8000.0) < 1e-12
+    # a run without an outlier keeps the plain average
+    calm = [{"k_action": (0.3125 + 0.001 * i, 25)} for i in range(4)]
+    prof = {"k_action": (sum(c["k_action"][0] for c in calm), 100)}
+    roof = bench.roofline_from_profile(prof, veh * 100, "no-such-workload", "test", with_traffic=False)
+    before = roof["avg_launch_us"]
+    bench.chunk_medians(roof, calm)
+    assert roof["avg_launch_us"] == before and roof["duration_estimator"] == "average over all instrumented launches"
