@@ -389,6 +389,7 @@ void Archive::dump(const std::string &path) const {
 
 // ------------------------------------------------------------------------------------------ EngineHost side
 Archive EngineHost::snapshot() {
+    dropAhead();
     settleLaneChange();
     Archive a;
     a.host = spawner_.saveState();
@@ -448,6 +449,7 @@ Archive EngineHost::snapshot() {
 }
 
 void EngineHost::load(const Archive &a) {
+    dropAhead();
     settleLaneChange();
     if (laneChange_ != !a.dev.rLcFlags.empty() && !a.dev.rVid.empty())
         throw std::runtime_error("Engine.load: the archive was taken with a different laneChange setting");
@@ -517,7 +519,10 @@ void EngineHost::load(const Archive &a) {
 }
 
 // Archive(Engine&, filename) archive.cpp:345-550: rebuild an Archive from the reference's JSON format.
-void EngineHost::loadFromFile(const std::string &path) { load(readArchiveFile(path, net_, spawner_, laneChange_)); }
+void EngineHost::loadFromFile(const std::string &path) {
+    dropAhead();
+    load(readArchiveFile(path, net_, spawner_, laneChange_));
+}
 
 Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadNet> &net_, Spawner &spawner_, bool laneChange_) {
     Json root = Json::parseFile(path);

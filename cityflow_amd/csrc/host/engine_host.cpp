@@ -132,6 +132,7 @@ EngineConfig readEngineConfig(const std::string &configFile) {
             c.exactShadowPeek = x->boolAt("exactShadowPeek", false);
             c.laneHistory = x->boolAt("laneHistory", false);
             if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
+            c.spawnAhead = x->boolAt("spawnAhead", true);
         }
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
@@ -186,6 +187,9 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
         }
         spawner_.init(net_.get(), interval_, threadNum_, seed_);
         spawner_.exactPeekOnly = readEngineConfig(configFile).exactShadowPeek;
+        // (lane change: the step's shadows draw from the generator after the step's spawns, and how many is known only when
+        //  the device has scheduled them — the next step's spawner cannot run before that)
+        spawnAhead_ = readEngineConfig(configFile).spawnAhead && !laneChange_;
         spawner_.loadFlows(dir_ + flowFile);
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
@@ -294,10 +298,22 @@ void EngineHost::settleLaneChange() {
     if (4 * k > shadowPoolSize_) shadowPoolSize_ = 8 * k;  // stay well clear of a step's demand
 }
 
+void EngineHost::dropAhead() {
+    if (!aheadValid_) return;
+    aheadValid_ = false;
+    spawner_.rollbackAhead();
+}
+
 void EngineHost::nextStep() {
     flushPhases();
     settleLaneChange();  // the generator must be past the last step's shadow draws before this step's spawns
-    spawner_.step(step_, spawnBuf_);
+    if (aheadValid_) {  // this step's records were made while the device ran the last step
+        aheadValid_ = false;
+        spawner_.commitAhead();
+        spawnBuf_.swap(aheadBuf_);
+    } else {
+        spawner_.step(step_, spawnBuf_);
+    }
     uploadNewTablesIfAny();
     if (laneChange_) {  // the priorities this step's shadows would draw, after the step's own spawn draws
         spawner_.peekShadowPriorities(shadowPoolSize_, shadowPool_);
@@ -307,6 +323,20 @@ void EngineHost::nextStep() {
     lcPollPending_ = laneChange_;
     if (saveReplay_) updateLog();
     step_ += 1;
+    if (spawnAhead_) {
+        // The next step's spawner, now: its records depend on nothing the device is computing (a priority that collides with
+        // a vehicle the host believes alive asks the device, as always — for the state after THIS step, which is the state the
+        // next step would ask for), so the work overlaps the device's step instead of standing between a caller's
+        // observation and its next step.  Any call other than nextStep / signals / counts takes it back first.
+        spawner_.beginAhead();
+        try {
+            spawner_.step(step_, aheadBuf_);
+        } catch (...) {
+            spawner_.rollbackAhead();
+            throw;
+        }
+        aheadValid_ = true;
+    }
 }
 
 // Engine::updateLog (engine.cpp:518-554): the state after the step, lights after TrafficLight::passTime
@@ -356,6 +386,7 @@ cfx_scalars EngineHost::scalars() {
 }
 
 void EngineHost::reset(bool resetRnd) {
+    dropAhead();
     // (lane change: the generator must first get past the last step's shadow draws — the reference made them inside that
     // step, and without a reseed the stream goes on from there)
     settleLaneChange();
@@ -410,6 +441,7 @@ std::map<std::string, int> EngineHost::getLaneWaitingVehicleCount() {
 }
 
 void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
+    dropAhead();
     settleLaneChange();
     int cap = (int) scalars().active_vehicle_count + 16;
     cfx_vehicle_view v{};
@@ -451,6 +483,7 @@ void EngineHost::snapshotVehicles(VehicleSnapshot &s, unsigned fields) {
 }
 
 void EngineHost::waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t> &lane) {
+    dropAhead();
     settleLaneChange();
     cfx_scalars sc = scalars();
     // spawned - finished - running, unless the state came from an archive (finished vehicles are not in its vehicle
@@ -473,6 +506,7 @@ void EngineHost::waitingVehicles(std::vector<int32_t> &vid, std::vector<int32_t>
 
 // getVehicles engine.cpp:619-626 — vehiclePool (priority) order
 std::vector<std::string> EngineHost::getVehicles(bool includeWaiting) {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::vector<std::pair<int32_t, int32_t>> byPriority;
@@ -494,6 +528,7 @@ std::vector<std::string> EngineHost::getVehicles(bool includeWaiting) {
 }
 
 std::map<std::string, std::vector<std::string>> EngineHost::getLaneVehicles() {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, std::vector<std::string>> ret;
@@ -506,6 +541,7 @@ std::map<std::string, std::vector<std::string>> EngineHost::getLaneVehicles() {
 }
 
 std::map<std::string, double> EngineHost::getVehicleSpeed() {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, double> ret;
@@ -515,6 +551,7 @@ std::map<std::string, double> EngineHost::getVehicleSpeed() {
 }
 
 std::map<std::string, double> EngineHost::getVehicleDistance() {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, double> ret;
@@ -524,6 +561,7 @@ std::map<std::string, double> EngineHost::getVehicleDistance() {
 }
 
 int EngineHost::vidOf(const std::string &id) {
+    dropAhead();
     settleLaneChange();
     if (!laneChange_) return spawner_.vidOfId(id);
     // An id is carried by a chain of vehicles: the flow's vehicle, then each shadow that took it over when its lane change
@@ -545,7 +583,8 @@ int EngineHost::vidOf(const std::string &id) {
 
 // A vehicle pushed (push_vehicle) since the last step: it gets its vehicle number with the next step's spawn records, but the
 // reference's vehiclePool / vehicleMap hold it from the moment of the call (Engine::pushVehicle engine.cpp:605-613).
-bool EngineHost::isPendingPushed(const std::string &id) const {
+bool EngineHost::isPendingPushed(const std::string &id) {
+    dropAhead();
     std::vector<std::pair<int32_t, std::string>> pushed;
     spawner_.pendingPushed(pushed);
     for (const auto &p : pushed)
@@ -555,6 +594,7 @@ bool EngineHost::isPendingPushed(const std::string &id) const {
 
 // getLeader engine.cpp:836-850
 std::string EngineHost::getLeader(const std::string &vehicleId) {
+    dropAhead();
     int vid = vidOf(vehicleId);
     uint8_t st = 2;
     if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
@@ -583,6 +623,7 @@ std::string EngineHost::getLeader(const std::string &vehicleId) {
 
 // Vehicle::getInfo vehicle.cpp:435-457
 std::map<std::string, std::string> EngineHost::getVehicleInfo(const std::string &vehicleId) {
+    dropAhead();
     int vid = vidOf(vehicleId);
     uint8_t st = 2;
     if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
@@ -617,6 +658,7 @@ std::map<std::string, std::string> EngineHost::getVehicleInfo(const std::string 
 // getAverageTravelTime engine.cpp:682-691: same summation order (vehiclePool = ascending priority),
 // so the result is bit-identical to the single-threaded reference for any interval.
 double EngineHost::getAverageTravelTime() {
+    dropAhead();
     settleLaneChange();
     cfx_scalars sc = scalars();
     double tt = sc.cumulative_travel_time;
@@ -709,6 +751,7 @@ void EngineHost::laneHistory(std::vector<int32_t> &len, std::vector<int32_t> &ve
 
 // setVehicleSpeed engine.cpp:827-834
 void EngineHost::setVehicleSpeed(const std::string &id, double speed) {
+    dropAhead();
     int vid = vidOf(id);
     if (vid < 0) {
         // pushed since the last step: the reference finds it in vehicleMap and keeps the speed in the vehicle's buffer for
@@ -728,6 +771,7 @@ void EngineHost::setVehicleSpeed(const std::string &id, double speed) {
 
 // Engine::setRoute engine.cpp:852-866 + Router::setRoute router.cpp:245-264
 bool EngineHost::setRoute(const std::string &vehicleId, const std::vector<std::string> &anchorIds) {
+    dropAhead();
     int vid = vidOf(vehicleId);
     if (vid < 0) return false;
     int32_t state = 2, drivable = -1, routePos = -1, route = -1;
@@ -785,6 +829,7 @@ bool EngineHost::setRoute(const std::string &vehicleId, const std::vector<std::s
 
 // pushVehicle(map, vector) engine.cpp:693-717
 void EngineHost::pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads) {
+    dropAhead();
     settleLaneChange();  // the new vehicle's priority is drawn now: after the last step's shadow draws, as in the reference
     auto get = [&info](const char *k, double d) {
         auto it = info.find(k);

@@ -115,6 +115,7 @@ public:
     double getAverageTravelTime();
     void setTrafficLightPhase(const std::string &id, int phaseIndex);
     void setRandomSeed(int seed) {
+        dropAhead();
         settleLaneChange();  // (the pending shadow draws belong to the old stream)
         spawner_.seed(seed);
     }
@@ -158,7 +159,10 @@ public:
     std::shared_ptr<void> bindingCache;  // opaque per-engine cache owned by the language binding (lane id key objects)
 
     const HostRoadNet &net() const { return *net_; }
-    const Spawner &spawner() const { return spawner_; }
+    const Spawner &spawner() {  // (the state as of the last step: a step taken ahead is taken back first)
+        dropAhead();
+        return spawner_;
+    }
     std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
     std::pair<int64_t, int> ringInfo() {
         int64_t slots = 0;
@@ -172,7 +176,7 @@ public:
     }
     std::string vehicleId(int vid, bool shadow = false) const { return spawner_.vehicleId(vid, shadow); }
     bool laneChange() const { return laneChange_; }
-    bool isPendingPushed(const std::string &id) const;
+    bool isPendingPushed(const std::string &id);
     int vidOf(const std::string &id);  // -1 if unknown
     double interval() const { return interval_; }
     size_t step() const { return step_; }
@@ -195,6 +199,11 @@ private:
     size_t step_ = 0;
     int templatesUploaded_ = 0, routesUploaded_ = 0;
     std::vector<cfx_spawn> spawnBuf_;
+    // The NEXT step's spawn records, computed right after this step was handed to the device (Spawner::beginAhead): consumed
+    // by the next nextStep(), taken back (dropAhead) by every other call that could see or change the spawner's state.
+    bool spawnAhead_ = true, aheadValid_ = false;
+    std::vector<cfx_spawn> aheadBuf_;
+    void dropAhead();
     std::vector<int32_t> shadowPool_, shadowParents_;  // lane change: priorities offered to / parents reported by a step
     int shadowPoolSize_ = 1024;
     bool lcPollPending_ = false;
@@ -223,6 +232,7 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
     bool exactShadowPeek = false;  // host: Spawner::exactPeekOnly
     bool laneHistory = false;      // keep Lane::history on the device (cfx_config::lane_history): Archive dumps then carry it
     int hostThreads = -1;          // VectorEngine: worker threads for the per-environment host work (-1 auto, 0 serial)
+    bool spawnAhead = true;        // Engine: run the spawner of step t+1 right after step t is handed to the device (EngineHost::nextStep)
     void apply(cfx_config &cc) const;  // interval, flags, the choices above, device (config > CITYFLOW_AMD_DEVICE > LOCAL_RANK)
 };
 EngineConfig readEngineConfig(const std::string &configFile);  // throws std::runtime_error("load config failed! ...")

@@ -319,7 +319,7 @@ int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> 
         if (!livePriority_.lookup(priority, owner)) break;
         // Host bookkeeping is a superset of the live set; settle it exactly before redrawing.
         if (owner >= 0 && isFinished && isFinished(owner)) {
-            livePriority_.erase(priority);
+            priorityErase(priority);
             break;
         }
     }
@@ -333,7 +333,7 @@ int Spawner::newVehicle(int flow, int number, int templ, const std::vector<int> 
     rec.enterTime = stepIndex * interval_;  // Engine::getCurrentTime engine.cpp:678-680
     rec.firstLane = -1;
     pendingRecords_.push_back(rec);
-    livePriority_.set(priority, -1);
+    prioritySet(priority, -1);
     Pending p;
     p.index = (int) pendingRecords_.size() - 1;
     p.firstRoad = anchors[0];
@@ -345,6 +345,70 @@ void Spawner::pushManual(int templ, const std::vector<int> &anchors, size_t step
     std::vector<int> seq;
     int route = expandRoute(anchors, seq) ? internRoute(seq) : -1;
     newVehicle(-1, manualCnt_++, templ, anchors, route, stepIndex, isFinished_);
+}
+
+void Spawner::prioritySet(int32_t key, int32_t value) {
+    if (journal_.active) {
+        PriorityUndo u{key, -1, false};
+        u.had = livePriority_.lookup(key, u.old);
+        journal_.priorities.push_back(u);
+    }
+    livePriority_.set(key, value);
+}
+
+void Spawner::priorityErase(int32_t key) {
+    if (journal_.active) {
+        PriorityUndo u{key, -1, false};
+        u.had = livePriority_.lookup(key, u.old);
+        journal_.priorities.push_back(u);
+    }
+    livePriority_.erase(key);
+}
+
+void Spawner::beginAhead() {
+    if (!pending_.empty() || !pendingRecords_.empty()) throw std::runtime_error("spawner: a step ahead with vehicles still pending");
+    journal_.active = true;
+    journal_.rnd = rnd;
+    journal_.activeFlows = activeFlows_;
+    journal_.flowDyn.resize(activeFlows_.size());
+    for (size_t i = 0; i < activeFlows_.size(); ++i) {
+        const HostFlow &f = flows[(size_t) activeFlows_[i]];
+        journal_.flowDyn[i] = FlowDyn{f.nowTime, f.currentTime, f.cnt, f.valid};
+    }
+    journal_.nVehicles = vehicles.size();
+    journal_.priorities.clear();
+    journal_.vidTables.clear();
+    journal_.lastWait.clear();
+}
+
+void Spawner::commitAhead() { journal_.active = false; }
+
+void Spawner::rollbackAhead() {
+    if (!journal_.active) return;
+    journal_.active = false;
+    rnd = journal_.rnd;
+    activeFlows_ = journal_.activeFlows;
+    for (size_t i = 0; i < activeFlows_.size(); ++i) {
+        HostFlow &f = flows[(size_t) activeFlows_[i]];
+        const FlowDyn &d = journal_.flowDyn[i];
+        f.nowTime = d.nowTime;
+        f.currentTime = d.currentTime;
+        f.cnt = d.cnt;
+        f.valid = d.valid;
+    }
+    for (size_t i = journal_.priorities.size(); i-- > 0;) {
+        const PriorityUndo &u = journal_.priorities[i];
+        if (u.had) livePriority_.set(u.key, u.old);
+        else livePriority_.erase(u.key);
+    }
+    for (size_t i = journal_.vidTables.size(); i-- > 0;) {
+        std::vector<int32_t> &tbl = journal_.vidTables[i].first >= 0 ? flowVids[(size_t) journal_.vidTables[i].first] : manualVids;
+        tbl.resize(journal_.vidTables[i].second);
+    }
+    for (size_t i = journal_.lastWait.size(); i-- > 0;) lastWaitVid_[(size_t) journal_.lastWait[i].first] = journal_.lastWait[i].second;
+    vehicles.resize(journal_.nVehicles);
+    pending_.clear();
+    pendingRecords_.clear();
 }
 
 void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
@@ -408,9 +472,10 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
             int vid = vidOfPending_[p.index];
             rec.firstLane = lane;
             vehicles[(size_t) vid] = rec;
-            livePriority_.set(rec.priority, vid);
+            prioritySet(rec.priority, vid);
             {
                 std::vector<int32_t> &tbl = rec.flow >= 0 ? flowVids[rec.flow] : manualVids;
+                if (journal_.active) journal_.vidTables.emplace_back(rec.flow >= 0 ? rec.flow : -1, tbl.size());
                 if ((int) tbl.size() <= rec.number) tbl.resize(rec.number + 1, -1);
                 tbl[rec.number] = vid;
             }
@@ -422,6 +487,7 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
             s.lane = lane;
             s.prev_wait = lastWaitVid_[lane];
             s.enter_time = rec.enterTime;
+            if (journal_.active) journal_.lastWait.emplace_back(lane, lastWaitVid_[lane]);
             lastWaitVid_[lane] = vid;
             out.push_back(s);
         } else {
@@ -429,7 +495,7 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
                 std::cerr << "[warning] Invalid route '" << flows[rec.flow].id << "'. Omitted by default." << std::endl;
                 flows[rec.flow].valid = false;
             }
-            livePriority_.erase(rec.priority);
+            priorityErase(rec.priority);
         }
     }
     pending_.clear();

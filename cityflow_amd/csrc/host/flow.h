@@ -148,6 +148,17 @@ public:
     void loadState(const State &st);
     int manualCount() const { return manualCnt_; }
 
+    // ---- a step taken AHEAD of time.  The host of a single engine runs the spawner of step t+1 right after it has handed
+    //      step t to the device (the records depend on nothing the device computes, except through the rare priority
+    //      collision, which asks the device as it always does): the work overlaps the device's step instead of standing
+    //      between a caller's observation and its next step.  Until the next step consumes the records (commitAhead) any
+    //      other call that could see or change the spawner's state takes the step back first (rollbackAhead): everything
+    //      step() changes is journalled while `ahead` is on.
+    void beginAhead();
+    void commitAhead();
+    void rollbackAhead();
+    bool aheadActive() const { return journal_.active; }
+
 private:
     struct Pending {
         int index;  // into pendingRecords_
@@ -156,6 +167,24 @@ private:
     void rebuildActiveFlows();
     int newVehicle(int flow, int number, int templ, const std::vector<int> &anchors, int route, size_t stepIndex,
                    const std::function<bool(int)> &isFinished);
+
+    struct PriorityUndo {
+        int32_t key, old;
+        bool had;
+    };
+    struct Journal {
+        bool active = false;
+        std::mt19937 rnd;
+        std::vector<int32_t> activeFlows;
+        std::vector<FlowDyn> flowDyn;  // of activeFlows, in that order
+        size_t nVehicles = 0;
+        std::vector<PriorityUndo> priorities;
+        std::vector<std::pair<int32_t, size_t>> vidTables;  // (flow, or -1 = manualVids; its size before the append)
+        std::vector<std::pair<int32_t, int32_t>> lastWait;  // (lane, what it held)
+    };
+    Journal journal_;
+    void prioritySet(int32_t key, int32_t value);
+    void priorityErase(int32_t key);
 
     const HostRoadNet *net_ = nullptr;
     double interval_ = 1.0;

@@ -272,8 +272,10 @@ py::bytes roadnetProbe(const std::string &path) {
     return py::bytes(out);
 }
 
+// ahead: 0 every step taken plainly; 1 every step taken ahead and consumed (Spawner::beginAhead / commitAhead); 2 every step
+// taken ahead, taken back (rollbackAhead) and then taken plainly — what a call between two steps does to the host's step ahead
 py::list spawnSchedule(const std::string &roadnetFile, const std::string &flowFile, double interval, int seed,
-                       int threadNum, int steps) {
+                       int threadNum, int steps, int ahead) {
     cfa::HostRoadNet net;
     net.load(roadnetFile);
     cfa::Spawner sp;
@@ -282,7 +284,18 @@ py::list spawnSchedule(const std::string &roadnetFile, const std::string &flowFi
     py::list out;
     std::vector<cfx_spawn> recs;
     for (int s = 0; s < steps; ++s) {
-        sp.step((size_t) s, recs);
+        if (ahead) {
+            sp.beginAhead();
+            sp.step((size_t) s, recs);
+            if (ahead == 2) {
+                sp.rollbackAhead();
+                sp.step((size_t) s, recs);
+            } else {
+                sp.commitAhead();
+            }
+        } else {
+            sp.step((size_t) s, recs);
+        }
         py::list stepList;
         for (const cfx_spawn &r : recs)
             stepList.append(py::make_tuple(sp.vehicleId(r.vid), r.priority, net.laneId(r.lane), r.enter_time, r.templ,
@@ -694,7 +707,7 @@ PYBIND11_MODULE(_cityflow, m) {
     m.def("_load_roadnet", &loadRoadnet, "path"_a);
     m.def("_roadnet_probe", &roadnetProbe, "path"_a);
     m.def("_spawn_schedule", &spawnSchedule, "roadnet_file"_a, "flow_file"_a, "interval"_a, "seed"_a, "thread_num"_a,
-          "steps"_a);
+          "steps"_a, "ahead"_a = 0);
     m.def("_spawn_benchmark", &spawnBenchmark, "roadnet_file"_a, "flow_file"_a, "interval"_a, "seed"_a, "skip"_a, "steps"_a);
     m.def("_default_backend_path", &cfa::defaultBackendPath);
     // test hooks: the host's number reader (the reference's: rapidjson's default, json_number.h) and Archive.dump's writer

@@ -7,14 +7,19 @@ sys.path.insert(0, ROOT)
 sys.argv = [sys.argv[0]]
 import bench
 from cityflow_amd import _cityflow
-cfg = bench.build_workload("/tmp/cfa_exp", 0, scenario="grid_30x30")
+scenario = os.environ.get("CFX_RL_SCENARIO", "grid_30x30")  # gen_100x100 with CFX_RL_EXTRA=33000: the 1 M-vehicle network
+cfg = bench.build_workload("/tmp/cfa_exp", 0, scenario=scenario, n_extra=int(os.environ.get("CFX_RL_EXTRA", bench.N_EXTRA_FLOWS)))
+if os.environ.get("CFX_RL_SPAWN_AHEAD") == "0":  # the host's step ahead off ("cfx": {"spawnAhead": false})
+    import json
+    c = json.load(open(cfg)); c["cfx"] = {"spawnAhead": False}
+    cfg = cfg.replace(".json", "_noahead.json"); json.dump(c, open(cfg, "w"))
 rl = bench.with_config(cfg, "rl", rlTrafficLight=True)
 e = _cityflow.Engine(rl, 1)
 for _ in range(300):
     e.next_step()
 e.sync()
 n_inter = len(e.intersection_ids())
-N = 400
+N = int(os.environ.get("CFX_RL_ITERS", 400))
 
 
 def run(name, body):
