@@ -318,7 +318,7 @@ def pmc_traffic(kernel_names, workload):
     return None, None
 
 
-def roofline_from_profile(prof, vehicle_steps, workload_tag, note, with_traffic=True):
+def roofline_from_profile(prof, vehicle_steps, workload_tag, note, with_traffic=True, symbols=None):
     """The car-following kernel's achieved algorithmic bandwidth from an instrumented run: `prof` = {kernel: (total ms,
     launches)} of cfx_profile_read, `vehicle_steps` = vehicles that took those steps."""
     act_ms, act_n = prof.get("k_action", (0.0, 0))
@@ -329,7 +329,8 @@ def roofline_from_profile(prof, vehicle_steps, workload_tag, note, with_traffic=
     achieved = ACTION_BYTES_PER_VEHICLE * vehicles_per_launch / avg_s / 1e9
     traffic, traffic_src = pmc_traffic(("kr_action", "kw_action", "kl_action", "kd_action", "k_action"), workload_tag) if with_traffic else (None, None)
     return {
-        "bound": "hbm", "kernel": "k_action", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": (symbols or {}).get("k_action", "k_action"), "profile_slot": "k_action",
+        "kernels_by_slot": symbols or None, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_us": avg_s * 1e6, "vehicles_per_launch": vehicles_per_launch,
         "algorithmic_bytes_per_vehicle": ACTION_BYTES_PER_VEHICLE, "measured_over": note,
@@ -358,16 +359,15 @@ def chunk_medians(roofline, chunks):
     if not act:
         return
     act_med = sorted(act)[len(act) // 2]
-    roofline["avg_launch_us_all_launches"] = roofline["avg_launch_us"]
+    # `avg_launch_us`, `achieved` and `frac` stay what they say — the plain average over every instrumented launch; the figures
+    # priced with the median of the parts' averages stand beside them under their own names
     roofline["avg_launch_us_median_of_chunk_averages"] = act_med
+    roofline["achieved_median_priced"] = ACTION_BYTES_PER_VEHICLE * roofline["vehicles_per_launch"] / (act_med * 1e-6) / 1e9
+    roofline["frac_median_priced"] = roofline["achieved_median_priced"] / HBM_PEAK_GBS
+    roofline["duration_estimator"] = "average over all instrumented launches"
     if abs(roofline["avg_launch_us"] - act_med) > 0.25 * act_med:
-        roofline["duration_estimator"] = "median of %d chunk averages (an outlier launch moved the plain average to %.1f us)" % (
-            len(act), roofline["avg_launch_us"])
-        roofline["avg_launch_us"] = act_med
-        roofline["achieved"] = ACTION_BYTES_PER_VEHICLE * roofline["vehicles_per_launch"] / (act_med * 1e-6) / 1e9
-        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
-    else:
-        roofline["duration_estimator"] = "average over all instrumented launches"
+        roofline["outlier_note"] = "an outlier launch moved the plain average (%.1f us) off the median of %d chunk averages (%.1f us)" % (
+            roofline["avg_launch_us"], len(act), act_med)
 
 
 # ------------------------------------------------------------------------------------------------ launching
@@ -390,10 +390,12 @@ def self_launch(n):
 
 
 def warm_gpu_clocks(eng, tiled):
-    """50 ms of plain device work on the engine's stream right before the warm-up steps (cfx_device_spin): after seconds of
+    """250 ms of plain device work on the engine's stream right before the warm-up steps (cfx_device_spin): after seconds of
     host-only work (JSON load) the GPU sits in its idle power state, and a timed region of a millisecond (20 steps) would
-    otherwise be measured on ramping clocks.  Not simulation work; touches no engine state."""
-    (eng._eng if tiled else eng)._device_spin(50000)
+    otherwise be measured on ramping clocks (and whatever the power management does in the first tenths of a second of load
+    would land in the windows behind it).  Not simulation work; touches no engine state.  The sustained figure is
+    `ms_per_step_200`: a thousand steps behind the timed region."""
+    (eng._eng if tiled else eng)._device_spin(250000)
 
 
 def parse_args():
@@ -519,25 +521,46 @@ def total_scalars(job, eng, tiled):
     return s
 
 
-def timed_steps(job, eng, n):
-    """EXACTLY n steps bracketed by a barrier + device synchronisation on both sides; MAX over ranks."""
+def timed_steps(job, eng, n, detail=None):
+    """EXACTLY n steps bracketed by a barrier + device synchronisation on both sides; MAX over ranks.
+    `detail` (a dict, filled on this rank): every next_step() call of the window is stamped with the host clock as well (two
+    clock reads per step, ~0.1 us) — the slowest call and its index, how long the closing synchronisation waited, and what
+    the device library says about its own cfx_step calls (cfx_get_host_stats: slowest call, the step it belonged to, and
+    whether it drained the stream, regrew the rings or grew a table).  A window that comes out slower than its neighbours
+    then says where the time went: inside one host call (which, and why), or on the device behind calls that all returned
+    at once."""
     job.barrier()
     eng.sync()
-    trace = os.environ.get("CFX_BENCH_TRACE")  # developer aid: the slowest next_step() calls of the window, to stderr
+    single = getattr(eng, "_host_stats", None) if detail is not None else None
+    if single:
+        single(True)
     calls = []
     t0 = time.perf_counter()
-    for _ in range(n):
-        if trace:
-            t1 = time.perf_counter()
-        eng.next_step()
-        if trace:
-            calls.append(time.perf_counter() - t1)
+    if detail is None:
+        for _ in range(n):
+            eng.next_step()
+    else:
+        t1 = t0
+        for _ in range(n):
+            eng.next_step()
+            t2 = time.perf_counter()
+            calls.append(t2 - t1)
+            t1 = t2
+    t_sync = time.perf_counter()
     eng.sync()
+    t_end = time.perf_counter()
     job.barrier()
-    if trace:
-        worst = sorted(range(len(calls)), key=lambda i: -calls[i])[:5]
-        sys.stderr.write("[bench trace] %d steps, slowest next_step() calls (index, us): %s\n"
-                         % (n, [(i, round(calls[i] * 1e6)) for i in worst]))
+    if detail is not None and calls:
+        worst = max(range(len(calls)), key=lambda i: calls[i])
+        detail.update({"ms_per_step": (t_end - t0) / n * 1e3, "worst_next_step_us": round(calls[worst] * 1e6, 1),
+                       "worst_next_step_index": worst, "median_next_step_us": round(sorted(calls)[len(calls) // 2] * 1e6, 1),
+                       "next_step_calls_over_1ms": sum(1 for c in calls if c > 1e-3),
+                       "closing_sync_ms": round((t_end - t_sync) * 1e3, 3)})
+        if single:
+            hs = single(True)
+            detail["device_library"] = {"worst_cfx_step_us": round(hs["worst_step_call_us"], 1), "at_step": hs["worst_step_call_at"],
+                                        "cause_bits": hs["worst_step_call_cause"], "cfx_step_calls_over_1ms": hs["calls_over_1ms"],
+                                        "ring_regrows_total": hs["ring_regrows_total"], "table_grows_total": hs["table_grows_total"]}
     return job.reduce([time.perf_counter() - t0], "MAX")[0]
 
 
@@ -738,7 +761,7 @@ def scale_leg(job, args, n_steps):
         eng._profile_enable(False)
         s1 = eng._scalars()
         roof = roofline_from_profile(prof, s1["vehicle_steps"] - s0["vehicle_steps"], scen,
-                                     "%d instrumented steps" % n_steps)
+                                     "%d instrumented steps" % n_steps, symbols=eng._profile_symbols())
         chunk_medians(roof, chunks)
         if args.rl_seconds > 0:
             # BASELINE configs[4] as an RL agent drives it: the same state under rlTrafficLight, every signal set, one step
@@ -867,16 +890,22 @@ def main():
                           "lights": {k: (int(x["curPhaseIndex"]), float(x["remainDuration"])) for k, x in lights.items()}}
         del end_arch
 
-    # ---- a longer window behind the driver-shaped one (a 20-step region is under a millisecond of device time): 200 more
-    #      steps of the same run, timed the same way; reported beside the headline, never instead of it
-    # (Two windows, both reported, their MEAN as the named figure — not the better one: a stall inside a window is part of
-    # what a caller sees.  Since round 5 the vehicle table is sized for the run at creation and grows by whole chunks
-    # without draining the stream, so the windows agree; `ms_per_step_200_windows` has both.)
+    # ---- longer windows behind the driver-shaped one (a 20-step region is under a millisecond of device time): five more
+    #      windows of 200 steps of the same run, timed the same way; reported beside the headline, never instead of it.
+    # All windows are reported, their MEAN is the named figure — not the best one: a stall inside a window is part of what
+    # a caller sees.  Every window carries where its slowest call was and what the device library did in it
+    # (`sustained_windows`), so that a window that disagrees with its neighbours names its cause in the line itself.
+    window_details = []
     if args.steps >= 200:
         ms_200_windows = [elapsed / args.steps * 1e3]
     else:
-        ms_200_windows = [timed_steps(job, eng, 200) / 200 * 1e3 for _ in range(2)]
+        ms_200_windows = []
+        for _ in range(5):
+            det = {}
+            ms_200_windows.append(timed_steps(job, eng, 200, det) / 200 * 1e3)
+            window_details.append(det)
     ms_per_step_200 = sum(ms_200_windows) / len(ms_200_windows)
+    ms_per_step_200_median = sorted(ms_200_windows)[len(ms_200_windows) // 2]
 
     # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream).  Tiled runs: every
     #      rank keeps stepping (the tiles are coupled), rank 0 instruments its own tile, halo kernels included.
@@ -916,7 +945,7 @@ def main():
             roofline = roofline_from_profile(
                 prof, scp1["vehicle_steps"] - scp0["vehicle_steps"], "bench" if args.scenario == "grid_30x30" else args.scenario,
                 "%d instrumented steps following the timed region%s" % (args.profile_steps, " (rank 0's tile)" if tiled else ""),
-                with_traffic=not tiled)
+                with_traffic=not tiled, symbols=None if tiled else eng._profile_symbols())
             chunk_medians(roofline, chunks)
 
     # ---- in-run parity and the CPU baseline (rank 0; a tiled run is compared with ONE engine on rank 0's device)
@@ -1000,6 +1029,7 @@ def main():
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_200": ms_per_step_200, "ms_per_step_200_windows": ms_200_windows,
+            "ms_per_step_200_median": ms_per_step_200_median, "sustained_windows": window_details or None,
             "higher_is_better": True, "scaling": None if world == 1 else ("strong" if (tiled and strong) else "weak"),
             # one tiled network was asked for and no halo transport came up: the line below is N independent replicas, NOT a
             # multi-GPU run of one network (also in config.parallelism / config.halo_probe_failures)

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -271,10 +272,19 @@ struct cfx_engine {
     size_t evUsed = 0;                          // pairs in use
     double profMs[kNumProfKernels] = {};
     int64_t profLaunches[kNumProfKernels] = {};
+    const char *slotSymbol[kNumProfKernels] = {};  // the kernel launched last in each timing slot (cfx_profile_kernel_symbol)
+    // ---- where the host's time inside cfx_step goes (cfx_get_host_stats) ----
+    cfx_host_stats hostStats{};
+    int stallCause = 0;  // CFX_STALL_* bits raised by the running cfx_step call
 
     // Launch `kernel`; while profiling, with the dispatch's own start / stop timestamps (hipExtLaunchKernel records the
     // events at the kernel's begin and end, the same clock readings a rocprofv3 kernel trace reports — a pair of
     // hipEventRecord calls around the launch would add the marker packets' latency, ~3 us, to every kernel).
+    template <typename K, typename... A>
+    void launchNamed(int kernelId, const char *symbol, K kernel, dim3 grid, dim3 block, A... args) {
+        slotSymbol[kernelId] = symbol;
+        launch(kernelId, kernel, grid, block, args...);
+    }
     template <typename K, typename... A>
     void launch(int kernelId, K kernel, dim3 grid, dim3 block, A... args) {
         if (profiling) {
@@ -408,6 +418,8 @@ struct cfx_engine {
 
     int ensureVidCap(size_t need) {
         if (need <= vidCap) return CFX_OK;
+        stallCause |= CFX_STALL_VID_GROW;
+        hostStats.table_grows_total += 1;
         // (cfx_config::ring_capacity_percent below 100 — the tests' "start small" knob — also starts the vehicle tables small,
         // so that their growth path runs)
         const size_t first = (cfg.ring_capacity_percent > 0 && cfg.ring_capacity_percent < 100) ? (size_t) 1 << 12 : kInitialVidCap;
@@ -441,6 +453,8 @@ struct cfx_engine {
 
     int ensureSlotCap(size_t need) {
         if (need <= slotCap) return CFX_OK;
+        stallCause |= CFX_STALL_SLOT_GROW;
+        hostStats.table_grows_total += 1;
         // refresh the live bound first: maybe no growth is needed
         size_t nc = std::max<size_t>(need + need / 2, 1 << 14);
         // the current generation must be preserved; everything else is scratch
@@ -485,6 +499,7 @@ struct cfx_engine {
             return CFX_OK;
         };
         // kernels in flight may still read the old buffers: drain before (re)uploading
+        stallCause |= CFX_STALL_TABLES;
         HIP_TRY(hipStreamSynchronize(stream));
         int rc;
         if ((rc = up(dTempl, hTempl))) return rc;
@@ -498,6 +513,7 @@ struct cfx_engine {
     }
 
     int readScalars(DevScalars &out) {
+        stallCause |= CFX_STALL_SCALARS;
         if (mirrorValid) {
             HIP_TRY(hipStreamSynchronize(stream));
             out = hMirror->sc;
@@ -685,7 +701,7 @@ struct cfx_engine {
         commitPending = false;
         int nStat = 1;
         const RingCommit rk = commitArgs(activeEstimate(), true, &nStat);
-        launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(D, std::max(I, nMaskWords))) + nStat), dim3(kBlock),
+        launchNamed(PK_COMMIT, "kr_commit", kr_commit, dim3(gridStride((size_t) std::max(D, std::max(I, nMaskWords))) + nStat), dim3(kBlock),
                rctx(true, step - 1, rcur ^ 1), rk, vt);
         HIP_TRY(hipGetLastError());
         return CFX_OK;
@@ -702,6 +718,8 @@ struct cfx_engine {
         if ((rc = settle())) return rc;
         int32_t total = 0;
         if (ringBuilt) {  // carry the running vehicles over
+            stallCause |= CFX_STALL_RING_REGROW;
+            hostStats.ring_regrows_total += 1;
             if ((rc = ringGather(false, &total))) return rc;
             HIP_TRY(hipStreamSynchronize(stream));
             if ((rc = ringFree())) return rc;
@@ -1101,8 +1119,48 @@ int32_t cfx_add_routes(cfx_engine *e, int32_t nRoutes, const int32_t *routeStart
     return CFX_OK;
 }
 
+}  // extern "C"
+static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n);
+extern "C" {
+
 int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     if (!e || n < 0 || (n && !recs)) return CFX_ERR_INVALID;
+    // (the host's own time in here is accounted: cfx_get_host_stats)
+    e->stallCause = 0;
+    const int64_t at = e->step;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t rc = stepImpl(e, recs, n);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    cfx_host_stats &hs = e->hostStats;
+    hs.step_calls += 1;
+    hs.step_call_us_sum += us;
+    if (us > 1000.0) hs.calls_over_1ms += 1;
+    if (us > hs.worst_step_call_us) {
+        hs.worst_step_call_us = us;
+        hs.worst_step_call_at = at;
+        hs.worst_step_call_cause = e->stallCause;
+    }
+    return rc;
+}
+
+int32_t cfx_get_host_stats(cfx_engine *e, cfx_host_stats *out, int32_t reset) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    *out = e->hostStats;
+    if (reset) {
+        const int64_t rr = e->hostStats.ring_regrows_total, tg = e->hostStats.table_grows_total;
+        e->hostStats = cfx_host_stats{};
+        e->hostStats.ring_regrows_total = rr;
+        e->hostStats.table_grows_total = tg;
+    }
+    return CFX_OK;
+}
+
+const char *cfx_profile_kernel_symbol(cfx_engine *e, int32_t k) {
+    return (e && k >= 0 && k < kNumProfKernels && e->slotSymbol[k]) ? e->slotSymbol[k] : "";
+}
+
+}  // extern "C"
+static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
     int rc;
@@ -1207,6 +1265,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 e->recCap = nc;
             }
             if ((size_t) n > e->stageCap) {
+                e->stallCause |= CFX_STALL_STAGE_GROW;
                 HIP_TRY(hipStreamSynchronize(st));
                 size_t nc = std::max<size_t>((size_t) n * 2, 1024);
                 for (int i = 0; i < cfx_engine::kStages; ++i) {
@@ -1222,7 +1281,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             if (e->stageBusy[si]) HIP_TRY(hipEventSynchronize(e->stageEvent[si]));
             memcpy(e->hStage[si], recs, (size_t) n * sizeof(cfx_spawn));
             // the kernel reads the pinned (device-visible) staging buffer itself: no separate copy launch
-            e->launch(PK_SPAWN, k_spawn_link, dim3(gridFor(n)), dim3(kBlock), (const cfx_spawn *) e->hStage[si], (int) n,
+            e->launchNamed(PK_SPAWN, "k_spawn_link", k_spawn_link, dim3(gridFor(n)), dim3(kBlock), (const cfx_spawn *) e->hStage[si], (int) n,
                       (int) e->spawned, e->vt, e->waitHead, e->lc);
             HIP_TRY(hipEventRecord(e->stageEvent[si], st));
             e->stageBusy[si] = true;
@@ -1281,16 +1340,16 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             int nStatPrev = 1;
             const RingCommit rkPrev = e->commitArgs(activeEst, true, &nStatPrev);
             if (batch.n > kAdmitRecs)
-                e->launch(PK_ADMIT, kr_admit<true, kAdmitRecsBig>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
+                e->launchNamed(PK_ADMIT, "kr_admit<true, kAdmitRecsBig>", kr_admit<true, kAdmitRecsBig>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
                           e->admitStep, e->waitHead, e->vt, e->sc, batch, rkPrev);
             else
-                e->launch(PK_ADMIT, kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
+                e->launchNamed(PK_ADMIT, "kr_admit<true>", kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
                           e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), rkPrev);
         } else {
             if (batch.n > kAdmitRecs)
-                e->launch(PK_ADMIT, kr_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{});
+                e->launchNamed(PK_ADMIT, "kr_admit<false, kAdmitRecsBig>", kr_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{});
             else
-                e->launch(PK_ADMIT, kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{});
+                e->launchNamed(PK_ADMIT, "kr_admit<false>", kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{});
         }
         RING_CHECK("kr_admit")
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
@@ -1345,6 +1404,8 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 const size_t listBound = (size_t) std::min<int64_t>(e->liveUpper, (int64_t) e->ringSlots);
                 const size_t needList = (listBound + kBlock - 1) / kBlock * kBlock + kBlock;
                 if (needList > e->rListCap) {
+                    e->stallCause |= CFX_STALL_LIST_GROW;
+                    e->hostStats.table_grows_total += 1;
                     const size_t nc = std::max(needList + needList / 4, e->rListCap * 2) / kBlock * kBlock;
                     int rc = e->growDeferred(&e->rList, 0, nc);  // (rebuilt every step: nothing to keep)
                     if (rc) return rc;
@@ -1361,10 +1422,10 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 // (1024 threads: two blocks per CU.  Form 6 hands the tiles out by ticket whatever their number: the path of networks
                 //  above half a million drivables, for the tests)
                 int32_t *const idxTicket = (nIdxTiles > kScanResidentTiles || form == 6) ? e->rListCount + 1 : nullptr;
-                e->launch(PK_SCAN, kr_index, dim3(nIdxTiles), dim3(kIndexBlock), c, e->rIdxGranules, idxTicket, (unsigned) (e->step + 1),
+                e->launchNamed(PK_SCAN, "kr_index", kr_index, dim3(nIdxTiles), dim3(kIndexBlock), c, e->rIdxGranules, idxTicket, (unsigned) (e->step + 1),
                           e->rList, (int) e->rListCap, e->rListCount, e->sc);
                 RING_CHECK("kr_index")
-                e->launch(PK_ACTION, kl_action, dim3(nVehBlocks + nLL), dim3(kBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
+                e->launchNamed(PK_ACTION, "kl_action", kl_action, dim3(nVehBlocks + nLL), dim3(kBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
                           (const int32_t *) e->rListCount, nVehBlocks, idxTicket);
             } else {
             G = std::min(G, Bsel);
@@ -1372,11 +1433,11 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // (first form: as many blocks again at the end of the grid compute the laneLinks' notify sources)
             const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(Bsel);
             if (blockForm) {
-                if (Bsel == 256) e->launch(PK_ACTION, kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                else e->launch(PK_ACTION, kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256>", kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                else e->launchNamed(PK_ACTION, "kr_action<512>", kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
             } else {
-                if (Bsel == 256) e->launch(PK_ACTION, kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                else e->launch(PK_ACTION, kw_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256>", kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                else e->launchNamed(PK_ACTION, "kw_action<512>", kw_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
             }
             }
         }
@@ -1395,7 +1456,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             }
         }
         if (useBig)
-            e->launch(PK_CROSS, k_cross2<false, RingCtx, RingOut>,
+            e->launchNamed(PK_CROSS, "k_cross2<false, RingCtx, RingOut>", k_cross2<false, RingCtx, RingOut>,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) CFX_RING_CROSS2_WAVES * e->nCU)),  // (5 blocks per CU: 95 registers)
                       dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
@@ -1407,7 +1468,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 const int lastJobs = __atomic_load_n(&e->hMirror->sc.nCrossJobs, __ATOMIC_RELAXED);
                 if (lastJobs > 0) groups = std::min<size_t>(groups, (size_t) lastJobs + (size_t) lastJobs / 4 + 256);
             }
-            e->launch(PK_CROSS, kr_cross,
+            e->launchNamed(PK_CROSS, "kr_cross", kr_cross,
                       dim3((int) std::min<size_t>(std::max<size_t>(64, (groups * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                       dim3(kCrossBlock), c, ro, jq, (const RingJob *) e->rJobRecs,
                       RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
@@ -1418,7 +1479,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         } else {
             int nStat = 1;
             const RingCommit rk = e->commitArgs(activeEst, false, &nStat);
-            e->launch(PK_COMMIT, kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
+            e->launchNamed(PK_COMMIT, "kr_commit", kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
             RING_CHECK("kr_commit")
         }
 #undef RING_CHECK
@@ -1490,15 +1551,15 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             HIP_TRY(hipMemsetAsync(e->gatePhase, 0xFF, (size_t) 2 * std::max(e->I, 1) * sizeof(int32_t), st));
         }
         if (batch.n > kAdmitRecs)
-            e->launch(PK_ADMIT, kd_admit<true, kAdmitRecsBig>, dim3(gridFor(e->L)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch, e->gatePhase);
+            e->launchNamed(PK_ADMIT, "kd_admit<true, kAdmitRecsBig>", kd_admit<true, kAdmitRecsBig>, dim3(gridFor(e->L)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch, e->gatePhase);
         else
-            e->launch(PK_ADMIT, kd_admit<true, kAdmitRecs>, dim3(gridFor(e->L)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch(), e->gatePhase);
+            e->launchNamed(PK_ADMIT, "kd_admit<true, kAdmitRecs>", kd_admit<true, kAdmitRecs>, dim3(gridFor(e->L)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch(), e->gatePhase);
     } else if (tails) {
         if (batch.n > kAdmitRecs)
-            e->launch(PK_ADMIT, kd_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch, (int32_t *) nullptr);
+            e->launchNamed(PK_ADMIT, "kd_admit<false, kAdmitRecsBig>", kd_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, batch, (int32_t *) nullptr);
         else
-            e->launch(PK_ADMIT, kd_admit<false, kAdmitRecs>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch(), (int32_t *) nullptr);
-    } else e->launch(PK_ADMIT, k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch());
+            e->launchNamed(PK_ADMIT, "kd_admit<false, kAdmitRecs>", kd_admit<false, kAdmitRecs>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch(), (int32_t *) nullptr);
+    } else e->launchNamed(PK_ADMIT, "k_admit", k_admit, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->cs, smallBatch());
     ActionOut ao{e->ab, e->cs, e->vt, e->sc, e->finList, (int) e->slotCap, e->finCount};
     if (e->lc.on) {
         // Engine::nextStep engine.cpp:571-575: initSegments, planLaneChange (+ scheduleLaneChange), and the order rebuilt
@@ -1533,17 +1594,17 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const int nLLBlocks = (e->K + kActBlock - 1) / kActBlock;
         if (tails) {
             const int nv = (int) ((slotBound + kDenseActBlock - 1) / kDenseActBlock), nl = (e->K + kDenseActBlock - 1) / kDenseActBlock;
-            e->launch(PK_ACTION, kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
+            e->launchNamed(PK_ACTION, "kd_action", kd_action, dim3(nv + nl), dim3(kDenseActBlock), c, ao, jq, nv);
         }
-        else e->launch(PK_ACTION, e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
+        else e->launchNamed(PK_ACTION, e->lc.on ? "k_action<true>" : "k_action<false>", e->lc.on ? k_action<true> : k_action<false>, dim3(nVehBlocks + nLLBlocks), dim3(kActBlock), c, ao, jq,
                        nVehBlocks);
     }
     if (useBig)
         // (the blocks the chip holds at once — 7 per CU: the kernel's LDS — or fewer for a short queue: the kernel sizes its batches)
-        e->launch(PK_CROSS, e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + 15) / 16), (size_t) CFX_CROSS2_BLOCKS_PER_CU * e->nCU)),
+        e->launchNamed(PK_CROSS, e->lc.on ? "k_cross2<true>" : "k_cross2<false>", e->lc.on ? k_cross2<true> : k_cross2<false>, dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound + 15) / 16), (size_t) CFX_CROSS2_BLOCKS_PER_CU * e->nCU)),
                   dim3(kCross2Block), c, ao, jq, RingLights{nullptr, nullptr, 0});
     else
-        e->launch(PK_CROSS, e->lc.on ? k_cross<true> : k_cross<false>,
+        e->launchNamed(PK_CROSS, e->lc.on ? "k_cross<true>" : "k_cross<false>", e->lc.on ? k_cross<true> : k_cross<false>,
                   dim3((int) std::min<size_t>(std::max<size_t>(1, (slotBound * 16 + kCrossBlock - 1) / kCrossBlock), 32768)),
                   dim3(kCrossBlock), c, ao, jq);
     if (e->lc.on) {
@@ -1552,13 +1613,13 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         hipLaunchKernelGGL(k_lc_resolve_rest, dim3(1), dim3(kBlock), 0, st, c, ao, e->oldToNew2);
     }
     int32_t *const scanTicket = e->nScanBlocks > kScanResidentTiles ? e->scanTicket : nullptr;
-    e->launch(PK_SCAN, k_scan, dim3(e->nScanBlocks), dim3(kBlock), (int) e->D, (int) e->L, (const int32_t *) e->cnt[e->cur].p, e->cs,
+    e->launchNamed(PK_SCAN, "k_scan", k_scan, dim3(e->nScanBlocks), dim3(kBlock), (int) e->D, (int) e->L, (const int32_t *) e->cnt[e->cur].p, e->cs,
               e->scanGranules, scanTicket, (unsigned) (e->step + 1), e->segStart[nxt].p, e->cnt[nxt].p, e->gen[nxt].vid,
               e->gen[nxt].drv, e->sc, e->net.laneSpare, (const int32_t *) e->admitStep, (int) e->step, e->waitHead, e->vt,
               e->net.laneGhost, (const int2 *) e->admitRec, e->publishTo(), e->lc.on ? 1 : 0);
     // finish statistics: one extra block per 64 k slots (a rank sort of the step's finishers, see finishStatistics)
     const int nStat = (int) std::min<size_t>(std::max<size_t>(1, slotBound >> 16), 64);
-    e->launch(PK_SCATTER, e->lc.on ? k_scatter<true> : k_scatter<false>,
+    e->launchNamed(PK_SCATTER, e->lc.on ? "k_scatter<true>" : "k_scatter<false>", e->lc.on ? k_scatter<true> : k_scatter<false>,
               dim3(gridStride(std::max<size_t>(slotBound, (size_t) std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, e->ab,
               e->cs, e->gen[nxt], (const int32_t *) e->segStart[nxt].p, e->oldToNew, e->curPhase, e->remain,
               (int) e->cfg.rl_traffic_light, (int) e->nMaskWords, scanTicket, e->vt, e->sc, (const int32_t *) e->finList,
@@ -1574,6 +1635,7 @@ int32_t cfx_step(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
     return CFX_OK;
 }
+extern "C" {
 
 // Lane::history as the ABI shows it: lane-major, oldest record first (the device keeps a ring per lane, record-major)
 int32_t cfx_get_lane_history(cfx_engine *e, cfx_lane_history *out) {
@@ -2711,7 +2773,7 @@ int32_t cfx_halo_post(cfx_engine *e) {
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;  // every peer implies at least one cut lane, so n > 0 with peers
     if (n) {
-        e->launch(PK_HALO_EXPORT, k_halo_export, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail,
+        e->launchNamed(PK_HALO_EXPORT, "k_halo_export", k_halo_export, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail,
                   (const int32_t *) e->cs.inCnt, io, e->sc);
     }
     HIP_TRY(hipGetLastError());
@@ -2734,7 +2796,7 @@ int32_t cfx_halo_wait(cfx_engine *e) {
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;
     if (n) {  // includes the wait for the neighbours' epochs
-        e->launch(PK_HALO_IMPORT, k_halo_import, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail, io,
+        e->launchNamed(PK_HALO_IMPORT, "k_halo_import", k_halo_import, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail, io,
                   e->vt, e->sc);
     }
     HIP_TRY(hipGetLastError());

@@ -80,6 +80,8 @@ void Backend::open(const std::string &libPath) {
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)
     CFX_FN(cfx_profile_read)
+    CFX_FN(cfx_profile_kernel_symbol)
+    CFX_FN(cfx_get_host_stats)
     CFX_FN(cfx_device_spin)
     CFX_FN(cfx_get_lane_history)
     CFX_FN(cfx_set_lane_history)
@@ -377,6 +379,22 @@ std::map<std::string, std::pair<double, int64_t>> EngineHost::profileRead() {
     std::map<std::string, std::pair<double, int64_t>> out;
     for (int k = 0; k < n; ++k) out[be_.cfx_profile_kernel_name(k)] = std::make_pair(ms[k], cnt[k]);
     return out;
+}
+
+std::map<std::string, std::string> EngineHost::profileSymbols() {
+    std::map<std::string, std::string> out;
+    const int n = be_.cfx_profile_kernel_count();
+    for (int k = 0; k < n; ++k) {
+        const char *s = be_.cfx_profile_kernel_symbol(dev_, k);
+        if (s && *s) out[be_.cfx_profile_kernel_name(k)] = s;
+    }
+    return out;
+}
+
+cfx_host_stats EngineHost::hostStats(bool reset) {
+    cfx_host_stats s{};
+    check(be_.cfx_get_host_stats(dev_, &s, reset ? 1 : 0), "cfx_get_host_stats");
+    return s;
 }
 
 cfx_scalars EngineHost::scalars() {

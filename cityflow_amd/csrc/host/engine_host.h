@@ -68,6 +68,8 @@ struct Backend {
     CFX_FN(cfx_profile_kernel_name)
     CFX_FN(cfx_profile_enable)
     CFX_FN(cfx_profile_read)
+    CFX_FN(cfx_profile_kernel_symbol)
+    CFX_FN(cfx_get_host_stats)
     CFX_FN(cfx_device_spin)
     CFX_FN(cfx_get_lane_history)
     CFX_FN(cfx_set_lane_history)
@@ -155,6 +157,8 @@ public:
         return {(long long) f, (long long) t};
     }
     std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
+    std::map<std::string, std::string> profileSymbols();  // timing slot -> symbol of the kernel launched last in it
+    cfx_host_stats hostStats(bool reset);
 
     std::shared_ptr<void> bindingCache;  // opaque per-engine cache owned by the language binding (lane id key objects)
 

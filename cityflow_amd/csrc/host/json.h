@@ -33,6 +33,7 @@ public:
     std::string s;
     std::vector<Json> items;                             // Array
     std::vector<std::pair<std::string, Json>> members;   // Object (file order)
+    mutable size_t hint_ = 0;                            // where find() looks first
 
     bool isObject() const { return kind == Object; }
     bool isArray() const { return kind == Array; }
@@ -41,9 +42,18 @@ public:
     bool isBool() const { return kind == True || kind == False; }
     bool isInt() const { return kind == Number && integral && i >= INT32_MIN && i <= INT32_MAX; }
 
+    // (the search starts behind the member found last: a reader that asks for an object's members in file order — an Archive's
+    // 481 k drivables on a 100x100 grid — pays one comparison per lookup instead of half the object)
     const Json *find(const char *name) const {
-        for (auto &m : members)
-            if (m.first == name) return &m.second;
+        const size_t n = members.size();
+        size_t at = hint_ < n ? hint_ : 0;
+        for (size_t k = 0; k < n; ++k) {
+            if (members[at].first == name) {
+                hint_ = at + 1;
+                return &members[at].second;
+            }
+            if (++at == n) at = 0;
+        }
         return nullptr;
     }
     // Mirrors the reference's getJsonMember<T> error wording (utility.h:92-136) so config errors read alike.
@@ -96,6 +106,11 @@ public:
         FILE *fp = fopen(path.c_str(), "rb");
         if (!fp) throw JsonError("cannot open " + path);
         std::string text;
+        if (fseek(fp, 0, SEEK_END) == 0) {  // (one allocation of the file's size)
+            const long size = ftell(fp);
+            if (size > 0) text.reserve((size_t) size);
+            fseek(fp, 0, SEEK_SET);
+        }
         char buf[1 << 16];
         size_t n;
         while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
@@ -104,7 +119,7 @@ public:
     }
 
     static Json parseText(const std::string &text) {
-        Cursor c{text.data(), text.data() + text.size(), 1};
+        Cursor c{text.data(), text.data() + text.size(), 1, {}, 0};
         Json root;
         c.value(root);
         c.ws();
@@ -116,6 +131,14 @@ private:
     struct Cursor {
         const char *p, *end;
         size_t line;
+        // how many children the previous container at each nesting depth had: siblings are mostly of one shape (an Archive's
+        // vehicles: 97 k objects of 35 members), so the next one reserves exactly that and its vector never reallocates
+        std::vector<uint32_t> lastCount;
+        size_t depth;
+        uint32_t &shape() {
+            if (lastCount.size() <= depth) lastCount.resize(depth + 1, 0);
+            return lastCount[depth];
+        }
 
         [[noreturn]] void fail(const char *what) const {
             throw JsonError("Json parsing error at line " + std::to_string(line) + ": " + what);
@@ -134,13 +157,12 @@ private:
         void str(std::string &out) {
             ++p;
             for (;;) {
+                const char *run = p;  // (plain characters are appended a run at a time)
+                while (p < end && *p != '"' && *p != '\\') ++p;
+                if (p > run) out.append(run, (size_t) (p - run));
                 if (p >= end) fail("unterminated string");
                 char ch = *p++;
                 if (ch == '"') return;
-                if (ch != '\\') {
-                    out.push_back(ch);
-                    continue;
-                }
                 if (p >= end) fail("bad escape");
                 char e = *p++;
                 switch (e) {
@@ -180,6 +202,8 @@ private:
                         ++p;
                         return;
                     }
+                    v.members.reserve(shape());
+                    ++depth;
                     for (;;) {
                         ws();
                         if (p >= end || *p != '"') fail("expected member name");
@@ -196,6 +220,8 @@ private:
                         }
                         if (p < end && *p == '}') {
                             ++p;
+                            --depth;
+                            shape() = (uint32_t) v.members.size();
                             return;
                         }
                         fail("expected ',' or '}'");
@@ -209,6 +235,8 @@ private:
                         ++p;
                         return;
                     }
+                    v.items.reserve(shape());
+                    ++depth;
                     for (;;) {
                         v.items.emplace_back();
                         value(v.items.back());
@@ -219,6 +247,8 @@ private:
                         }
                         if (p < end && *p == ']') {
                             ++p;
+                            --depth;
+                            shape() = (uint32_t) v.items.size();
                             return;
                         }
                         fail("expected ',' or ']'");

@@ -469,6 +469,20 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("_device_spin", &EngineHost::deviceSpin, "microseconds"_a)
         .def("_device_memory", &EngineHost::deviceMemory, "(free, total) bytes of the engine's device")
         .def("_profile_read", &EngineHost::profileRead)
+        .def("_profile_symbols", &EngineHost::profileSymbols, "timing slot -> symbol of the kernel launched last in it")
+        .def("_host_stats", [](EngineHost &e, bool reset) {
+            const cfx_host_stats s = e.hostStats(reset);
+            py::dict d;
+            d["step_calls"] = s.step_calls;
+            d["step_call_us_mean"] = s.step_calls ? s.step_call_us_sum / (double) s.step_calls : 0.0;
+            d["worst_step_call_us"] = s.worst_step_call_us;
+            d["worst_step_call_at"] = s.worst_step_call_at;
+            d["worst_step_call_cause"] = s.worst_step_call_cause;
+            d["calls_over_1ms"] = s.calls_over_1ms;
+            d["ring_regrows_total"] = s.ring_regrows_total;
+            d["table_grows_total"] = s.table_grows_total;
+            return d;
+        }, "reset"_a = false, "host time inside cfx_step (cfx_get_host_stats)")
         .def("_vehicle_id", [](EngineHost &e, int vid) { return e.vehicleId(vid); }, "vid"_a)
         .def("_vehicle_ids",
              [](EngineHost &e, py::array_t<int32_t> vids) {

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CFX_ABI_VERSION 8
+#define CFX_ABI_VERSION 9
 
 typedef enum cfx_status {
     CFX_OK = 0,
@@ -460,6 +460,33 @@ int32_t cfx_profile_kernel_count(void);
 const char *cfx_profile_kernel_name(int32_t k);
 int32_t cfx_profile_enable(cfx_engine *e, int32_t on);
 int32_t cfx_profile_read(cfx_engine *e, double *total_ms, int64_t *launches);
+/* The symbol of the kernel the engine launched LAST in timing slot k (the slots are roles — "k_action" is the car-following
+ * launch whatever its organisation; this names the one that ran: "kr_action<256>", "kl_action", "kd_action", ...).  "" before
+ * the first launch in that slot, and from CPU implementations. */
+const char *cfx_profile_kernel_symbol(cfx_engine *e, int32_t k);
+
+/* Where the HOST's time inside cfx_step went (never part of a result): every cfx_step call is timed with the host's steady
+ * clock; a call that had to wait for the device or allocate says why.  `worst_*` describe the slowest call since the last
+ * cfx_get_host_stats(e, out, 1) (reset = 1 clears everything but the *_total counters). */
+#define CFX_STALL_TABLES 1       /* new templates / routes were uploaded: the stream was drained first (cfx_add_*) */
+#define CFX_STALL_RING_REGROW 2  /* ring layout: the rings were rebuilt with doubled capacities (gather, drain, reallocate) */
+#define CFX_STALL_SLOT_GROW 4    /* dense layout: the slot arrays grew (drains) */
+#define CFX_STALL_VID_GROW 8     /* the per-vehicle tables grew (allocation only; the copy is ordered on the stream) */
+#define CFX_STALL_SCALARS 16     /* the scalars were read back to decide something (overflow report, capacity bound) */
+#define CFX_STALL_STAGE_GROW 32  /* the spawn staging buffers grew (drains) */
+#define CFX_STALL_LIST_GROW 64   /* the step's vehicle list grew (allocation only) */
+typedef struct cfx_host_stats {
+    int64_t step_calls;           /* cfx_step calls since the last clearing read */
+    double step_call_us_sum;      /* their host time */
+    double worst_step_call_us;    /* the slowest of them ... */
+    int64_t worst_step_call_at;   /* ... the engine step it submitted ... */
+    int32_t worst_step_call_cause;/* ... and the CFX_STALL_* bits raised inside it (0: nothing of the above — the time went into
+                                   * the HIP runtime's launch path, e.g. a full queue) */
+    int32_t calls_over_1ms;       /* calls that took more than a millisecond */
+    int64_t ring_regrows_total;   /* since the engine was created */
+    int64_t table_grows_total;    /* vid-table + slot-array + list growths since the engine was created */
+} cfx_host_stats;
+int32_t cfx_get_host_stats(cfx_engine *e, cfx_host_stats *out, int32_t reset);
 /* Measurement aid: keeps the device busy with plain arithmetic for about `microseconds` on the engine's stream (returns at
  * once; the engine's next kernels queue behind it).  A benchmark calls it right before its warm-up steps so that a short
  * timed region is not measured on clocks that are still ramping up after host-only work.  Touches no engine state. */

@@ -198,6 +198,7 @@ protected:
     std::string str_;
     std::vector<Value> arr_;
     std::vector<Member> *obj_ = nullptr;  // pointer because Member is incomplete here
+    mutable size_t findHint_ = 0;         // where FindMember looks first
 };
 
 struct Member {
@@ -256,10 +257,20 @@ inline Value::ConstMemberIterator Value::MemberEnd() const {
     const std::vector<Member> &m = obj_ ? *obj_ : empty;
     return m.data() + m.size();
 }
+// (same result as the library's linear search — member names are unique in the files this reads — but the search starts
+// behind the member found last: Archive's loader asks for an object's members in file order, and a 100x100 grid's archive has
+// 481 k drivables in one object)
 inline Value::ConstMemberIterator Value::FindMember(const char *name) const {
-    ConstMemberIterator e = MemberEnd();
-    for (ConstMemberIterator it = MemberBegin(); it != e; ++it)
-        if (it->name.str_ == name) return it;
+    ConstMemberIterator b = MemberBegin(), e = MemberEnd();
+    const size_t n = (size_t) (e - b);
+    size_t at = findHint_ < n ? findHint_ : 0;
+    for (size_t k = 0; k < n; ++k) {
+        if ((b + at)->name.str_ == name) {
+            findHint_ = at + 1;
+            return b + at;
+        }
+        if (++at == n) at = 0;
+    }
     return e;
 }
 
@@ -346,6 +357,13 @@ struct Parser {
     const char *p, *end;
     bool ok = true;
     size_t line = 1;
+    // children of the previous container at each nesting depth: siblings are mostly of one shape, the next one reserves that
+    std::vector<unsigned> lastCount;
+    size_t depth = 0;
+    unsigned &shape() {
+        if (lastCount.size() <= depth) lastCount.resize(depth + 1, 0);
+        return lastCount[depth];
+    }
 
     void ws() {
         while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) {
@@ -393,7 +411,9 @@ struct Parser {
                 }
                 ++p;
             } else {
-                out += *p++;
+                const char *run = p;  // (plain characters are appended a run at a time)
+                while (p < end && *p != '"' && *p != '\\') ++p;
+                out.append(run, (size_t) (p - run));
             }
         }
         if (p >= end) {
@@ -418,6 +438,8 @@ struct Parser {
                 ++p;
                 return;
             }
+            v.obj_->reserve(shape());
+            ++depth;
             while (ok) {
                 ws();
                 if (p >= end || *p != '"') {
@@ -442,6 +464,8 @@ struct Parser {
                 }
                 if (p < end && *p == '}') {
                     ++p;
+                    --depth;
+                    shape() = (unsigned) v.obj_->size();
                     return;
                 }
                 ok = false;
@@ -454,6 +478,8 @@ struct Parser {
                 ++p;
                 return;
             }
+            v.arr_.reserve(shape());
+            ++depth;
             while (ok) {
                 v.arr_.emplace_back();
                 parseValue(v.arr_.back());
@@ -464,6 +490,8 @@ struct Parser {
                 }
                 if (p < end && *p == ']') {
                     ++p;
+                    --depth;
+                    shape() = (unsigned) v.arr_.size();
                     return;
                 }
                 ok = false;

@@ -1636,6 +1636,12 @@ int32_t cfx_halo_wait(cfx_engine *e) {
 
 int32_t cfx_profile_kernel_count(void) { return 0; }
 const char *cfx_profile_kernel_name(int32_t) { return ""; }
+const char *cfx_profile_kernel_symbol(cfx_engine *, int32_t) { return ""; }
+int32_t cfx_get_host_stats(cfx_engine *e, cfx_host_stats *out, int32_t) {
+    if (!e || !out) return CFX_ERR_INVALID;
+    *out = cfx_host_stats{};
+    return CFX_OK;
+}
 int32_t cfx_profile_enable(cfx_engine *, int32_t) { return CFX_OK; }
 int32_t cfx_profile_read(cfx_engine *, double *, int64_t *) { return CFX_OK; }
 int32_t cfx_device_spin(cfx_engine *, int64_t) { return CFX_OK; }

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(mod, lib):
     for s in _declared_symbols():
         assert hasattr(dll, s), "%s does not export %s" % (path, s)
     dll.cfx_abi_version.restype = ctypes.c_int32
-    assert dll.cfx_abi_version() == 8
+    assert dll.cfx_abi_version() == 9
     dll.cfx_backend_name.restype = ctypes.c_char_p
     assert dll.cfx_backend_name() == (b"hip-gfx950" if lib == "hip" else b"cpu-twin")
 

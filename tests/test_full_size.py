@@ -92,3 +92,58 @@ def test_config5_100x100_one_million_vehicles(mod, scen, workdir):
     cfg = build(scen, workdir, 100, 333)
     running = rl_loop(mod, cfg, 2, 4, mod._default_backend_path(), warmup=300, steps=40, min_running=900000, twin_steps=12)
     print("100x100: %d running vehicles, %.0f s" % (running, time.time() - t0))
+
+
+# ---- BASELINE.json configs[4] against the REFERENCE ITSELF -------------------------------------------------------------
+# tests/golden/reference_large.json: the unmodified reference engine (one thread, Vehicle objects at creation-ordered
+# addresses — the reproducible reference, see tests/golden/make_large_goldens.py) stepped from step 0 on bench.py's
+# `roofline_at_scale` workload (gen_100x100 + 33 000 seeded flows, ~1.04 M running vehicles past step 300).
+def _large_golden():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_large.json")
+    with open(path) as f:
+        return json.load(f)
+
+
+def _large_record(eng, with_phases, real):
+    import hashlib
+    from conftest import state_hash
+    arr = eng.get_lane_vehicle_count_array().astype(np.int32)
+    rec = {"vehicle_count": eng.get_vehicle_count(), "lane_sum": int(arr.sum()),
+           "lane_array_sha256": hashlib.sha256(arr.tobytes()).hexdigest(),
+           "state_hash": state_hash(eng.get_vehicle_speed(), eng.get_vehicle_distance()),
+           "average_travel_time": float(eng.get_average_travel_time()).hex()}
+    if with_phases:
+        ph, rm = eng._tl_state()
+        h = hashlib.sha256()
+        for k, p, r in sorted(zip(eng.intersection_ids(), ph.tolist(), rm.tolist())):
+            if k in real:
+                h.update(("%s %d %s\n" % (k, int(p), float(r).hex())).encode())
+        rec["phase_hash"] = h.hexdigest()
+    return rec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["auto", "dense"])
+def test_config5_one_million_vehicles_matches_reference_goldens(mod, workdir, layout):
+    """HIP engine from step 0 on the 100x100 / 1 M vehicle workload == the reference's own records at steps 150, 305, 320,
+    340: vehicle count, every lane's count, average travel time, every vehicle's (speed, distance) bits, signal phases.
+    `auto` is the ring layout's list form at this size (kr_index + kl_action + k_cross2), `dense` the scan / scatter layout."""
+    import json
+    import bench
+    from test_parity_pins import _with_cfx
+    t0 = time.time()
+    gold = _large_golden()
+    cfg = bench.build_workload(workdir, 0, scenario="gen_%dx%d" % (bench.SCALE_GRID, bench.SCALE_GRID), n_extra=bench.SCALE_FLOWS)
+    eng = mod.Engine(_with_cfx(cfg, layout=layout) if layout != "auto" else cfg, 1)
+    assert len(eng.lane_ids()) == gold["n_lanes"]
+    net = eng._flat_net()
+    real = {k for k, v in zip(eng.intersection_ids(), net["inter_virtual"]) if not v}
+    want = {int(k): v for k, v in gold["checkpoints"].items()}
+    for s in range(1, max(want) + 1):
+        eng.next_step()
+        if s in want:
+            got = _large_record(eng, "phase_hash" in want[s], real)
+            assert got == want[s], "step %d (%s layout), ties so far %d" % (s, layout, eng._scalars()["tie_events"])
+    assert eng.get_vehicle_count() > 1000000
+    print("100x100 vs reference goldens (%s, %s): %.0f s" % (layout, eng._layout(), time.time() - t0))
