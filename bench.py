@@ -203,6 +203,61 @@ def tie_neighbourhood(flat, drivables):
     return out
 
 
+# ---- BASELINE configs[4] (100x100, ~1 M vehicles) against records the REFERENCE ITSELF produced -------------------------------
+# tests/golden/reference_large.json (tests/golden/make_large_goldens.py: the unmodified reference, one thread, stepped from step 0
+# on exactly the scale leg's workload).  Running the reference live at this size does not fit a bench run: constructing its
+# engine on this network takes ~1 minute and loading a 1.1 GB Archive of 1 M vehicles ~2 more (measured), before its first step.
+def scale_golden(scen, n_flows):
+    path = os.path.join(ROOT, "tests", "golden", "reference_large.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        g = json.load(f)
+    if not g.get("workload", "").startswith("%s " % scen) or ("%d seeded" % n_flows) not in g["workload"]:
+        return None
+    return g
+
+
+def scale_record(eng, real=None):
+    """What a checkpoint of the 1 M-vehicle run is compared by: vehicle count, every lane's count (array order), average travel
+    time, the id-keyed hash of every vehicle's exact (speed, distance), the id-free hash of the multiset of those pairs, and
+    (with `real` = ids of the non-virtual intersections) the signal phases."""
+    import numpy as np
+    arr = eng.get_lane_vehicle_count_array().astype(np.int32)
+    speed, distance = eng.get_vehicle_speed(), eng.get_vehicle_distance()
+    kin = hashlib.sha256()
+    for pair in sorted((float(speed[k]).hex(), float(distance[k]).hex()) for k in speed):
+        kin.update(("%s %s\n" % pair).encode())
+    rec = {"vehicle_count": eng.get_vehicle_count(), "lane_sum": int(arr.sum()),
+           "lane_array_sha256": hashlib.sha256(arr.tobytes()).hexdigest(),
+           "state_hash": _state_hash(speed, distance), "kinematics_hash": kin.hexdigest(),
+           "average_travel_time": float(eng.get_average_travel_time()).hex()}
+    if real is not None:
+        ph, rm = eng._tl_state()
+        h = hashlib.sha256()
+        for k, p, r in sorted(zip(eng.intersection_ids(), ph.tolist(), rm.tolist())):
+            if k in real:
+                h.update(("%s %d %s\n" % (k, int(p), float(r).hex())).encode())
+        rec["phase_hash"] = h.hexdigest()
+    return rec
+
+
+def scale_compare(got, want, ties_here):
+    """One checkpoint against the golden record: every field against the reference's; which vehicle id carries which (speed,
+    distance) against the reference's while no exact-distance tie has happened, against the twin's (recorded beside it)
+    afterwards — the reference's own order of a tied pair is a function of its unstable global sort, heap addresses and thread
+    timing (tests/golden/make_large_goldens.py)."""
+    out = {f: got.get(f) == want[f] for f in ("vehicle_count", "lane_sum", "lane_array_sha256", "kinematics_hash",
+                                              "average_travel_time", "phase_hash") if f in want and f in got}
+    out["exact_distance_ties_so_far"] = ties_here
+    out["ties_equal_twin"] = ties_here == want.get("twin_tie_events")
+    out["vehicle_ids_equal_twin"] = got["state_hash"] == want.get("twin_state_hash")
+    out["vehicle_ids_equal_reference"] = got["state_hash"] == want["state_hash"]
+    need = [v for k, v in out.items() if k not in ("exact_distance_ties_so_far", "vehicle_ids_equal_reference")]
+    out["equal"] = bool(all(need) and (ties_here > 0 or out["vehicle_ids_equal_reference"]))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ CPU legs
 def cpu_baseline(cfg, budget_s, threads, state_dump, warmup=0, checkpoints=(), detail_dir=None, gpu_hashes=None):
     """The unmodified reference engine (oracle/_ref) on the host cores, started from EXACTLY the state the GPU engine
@@ -727,11 +782,32 @@ def scale_leg(job, args, n_steps):
             return {"error": "no halo transport: " + "; ".join(notes)}
     else:
         eng = _cityflow.Engine(cfg, 1) if job.on_gpu else _cityflow.Engine._with_backend(cfg, 1, args.backend_lib)
-    for _ in range(args.build_up_steps + 10):
-        eng.next_step()
+    # parity at this size: checkpoints of tests/golden/reference_large.json the run passes outside its timed region
+    golden = None if tiled else scale_golden(scen, args.scale_flows)
+    want = {int(k): v for k, v in golden["checkpoints"].items()} if golden else {}
+    parity_cps, at = {}, 0
+    real = None
+    if golden:
+        flat = eng._flat_net()
+        real = {k for k, v in zip(eng.intersection_ids(), flat["inter_virtual"]) if not v}
+
+    def advance(n):
+        nonlocal at
+        for _ in range(n):
+            eng.next_step()
+            at += 1
+            if at in want and at > 300:  # (records of a million vehicles through the dict getters: ~10 s each)
+                got = scale_record(eng, real if "phase_hash" in want[at] else None)
+                parity_cps[at] = scale_compare(got, want[at], int(eng._scalars()["tie_events"]))
+
+    advance(args.build_up_steps + 10)
     eng.sync()
     sc0 = total_scalars(job, eng, tiled)
     elapsed = timed_steps(job, eng, n_steps)
+    at += n_steps
+    if at in want:  # the end of the timed region itself
+        parity_cps[at] = scale_compare(scale_record(eng, real if "phase_hash" in want[at] else None), want[at],
+                                       int(eng._scalars()["tie_events"]))
     sc1 = total_scalars(job, eng, tiled)
     veh_steps = sc1["vehicle_steps"] - sc0["vehicle_steps"]
     out = {"workload": "%s (generator-format grid, --tlPlan, interval 1.0) + %d seeded interior flows; state after %d steps"
@@ -748,6 +824,7 @@ def scale_leg(job, args, n_steps):
         eng._profile_enable(True)
         for _ in range(3):
             eng.next_step()
+        at += 3 + n_steps  # (and the instrumented steps below)
         eng._profile_read()
         s0 = eng._scalars()
         prof, chunks = {}, []
@@ -773,8 +850,25 @@ def scale_leg(job, args, n_steps):
             out["rl_loop"] = {"signals_set_per_step": n_inter, "lane_counts_read_per_step": len(rl.lane_ids()),
                               "array_api_steps_per_sec": _rl_loop(rl, 60, "array", 10, n_inter, None)}
             del rl
+        later = [s for s in sorted(want) if s > at]
+        if later and later[0] - at <= 64:  # the next checkpoint behind the instrumented region
+            advance(later[0] - at)
+        if golden:
+            roof_parity = {
+                "against": "records of the unmodified reference engine (tests/golden/reference_large.json; %d thread(s), Vehicle "
+                           "objects at %s addresses), same workload from step 0" % (golden.get("reference_threads", 0),
+                                                                                   golden.get("vehicle_addresses", "heap")),
+                "kind": "reference (golden records)",
+                "checkpoints": {str(s): r for s, r in sorted(parity_cps.items())},
+                "timed_region": "steps %d..%d" % (args.build_up_steps + 11, args.build_up_steps + 10 + n_steps),
+                "all_equal": bool(parity_cps) and all(r["equal"] for r in parity_cps.values()),
+                "checked": "vehicle count, every lane's count, average travel time, the multiset of every vehicle's exact (speed, "
+                           "distance), signal phases where recorded; which id carries which pair: against the reference until "
+                           "the first exact-distance tie, against the CPU twin's record afterwards"}
+            out["parity"] = roof_parity
         if roof:
             roof["config"] = out
+            roof["parity"] = out.get("parity")
             return roof
     return {"config": out}
 

@@ -269,10 +269,12 @@ bool EngineHost::onlyChangedPhases(std::vector<int32_t> &inters, std::vector<int
 
 void EngineHost::flushPhases() {
     if (pendingPhaseInter_.empty()) return;
-    if (onlyChangedPhases(pendingPhaseInter_, pendingPhaseValue_))
-        check(be_.cfx_set_tl_phases(dev_, (int32_t) pendingPhaseInter_.size(), pendingPhaseInter_.data(),
-                                    pendingPhaseValue_.data()),
-              "cfx_set_tl_phases");
+    if (onlyChangedPhases(pendingPhaseInter_, pendingPhaseValue_)) {
+        const int32_t rc = be_.cfx_set_tl_phases(dev_, (int32_t) pendingPhaseInter_.size(), pendingPhaseInter_.data(),
+                                                 pendingPhaseValue_.data());
+        if (rc != CFX_OK) forgetPhases();  // (the cache was updated for phases the device never got: nothing is known any more)
+        check(rc, "cfx_set_tl_phases");
+    }
     pendingPhaseInter_.clear();
     pendingPhaseValue_.clear();
 }
@@ -330,14 +332,15 @@ void EngineHost::nextStep() {
         // a vehicle the host believes alive asks the device, as always — for the state after THIS step, which is the state the
         // next step would ask for), so the work overlaps the device's step instead of standing between a caller's
         // observation and its next step.  Any call other than nextStep / signals / counts takes it back first.
+        // (step t WAS taken: whatever goes wrong in the step ahead — a device error in a priority-collision query — is left
+        // to the next nextStep(), which takes that step plainly and raises it where it belongs)
         spawner_.beginAhead();
         try {
             spawner_.step(step_, aheadBuf_);
+            aheadValid_ = true;
         } catch (...) {
             spawner_.rollbackAhead();
-            throw;
         }
-        aheadValid_ = true;
     }
 }
 
@@ -730,8 +733,11 @@ void EngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) {
         inters.push_back((int32_t) i);
         ph.push_back(phases[i]);
     }
-    if (onlyChangedPhases(inters, ph))
-        check(be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data()), "cfx_set_tl_phases");
+    if (onlyChangedPhases(inters, ph)) {
+        const int32_t rc = be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data());
+        if (rc != CFX_OK) forgetPhases();
+        check(rc, "cfx_set_tl_phases");
+    }
 }
 
 // setTrafficLightPhase engine.cpp:719-725

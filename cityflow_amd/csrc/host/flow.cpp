@@ -601,6 +601,7 @@ void Spawner::loadState(const State &st) {
     rebuildActiveFlows();
     pending_.clear();
     pendingRecords_.clear();
+    journal_.active = false;  // (whatever a step ahead journalled is void)
 }
 
 void Spawner::reset(bool reseed) {
@@ -619,6 +620,7 @@ void Spawner::reset(bool reseed) {
     rebuildActiveFlows();
     pending_.clear();
     pendingRecords_.clear();
+    journal_.active = false;  // (whatever a step ahead journalled is void)
     std::fill(lastWaitVid_.begin(), lastWaitVid_.end(), -1);
     if (reseed) rnd.seed((std::mt19937::result_type) seed_);
 }

@@ -125,6 +125,7 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     interval_ = cfg.interval;
     rlTrafficLight_ = cfg.rlTrafficLight;
     hostThreads_ = cfg.hostThreads;
+    aheadEnabled_ = cfg.spawnAhead && !cfg.laneChange;
     try {
         net_->load(cfg.dir + cfg.roadnetFile);
         for (int r = 0; r < R_; ++r) {
@@ -156,6 +157,8 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
     for (int r = 0; r < R_; ++r) {
         Spawner *sp = spawners_[r].get();
         sp->setFinishedQuery([this, r](int localVid) {
+            // (a batch prepared ahead: "finished" means finished by the steps before it — wait until they are all submitted)
+            while (submitted_.load(std::memory_order_acquire) < (uint64_t) preparing_.load(std::memory_order_acquire)) std::this_thread::yield();
             std::lock_guard<std::mutex> guard(queryMutex_);  // rare (priority collision); the ABI is not re-entrant
             uint8_t st = 0;
             check(be_.cfx_get_vehicle_status(dev_, localToGlobal_[r][localVid], 1, &st), "cfx_get_vehicle_status");
@@ -179,6 +182,15 @@ VectorEngineHost::VectorEngineHost(const std::string &configFile, int numEnvs, i
 }
 
 VectorEngineHost::~VectorEngineHost() {
+    if (aheadThread_.joinable()) {
+        {
+            std::lock_guard<std::mutex> guard(aheadMutex_);
+            aheadStop_ = true;
+        }
+        aheadCv_.notify_all();
+        submitted_.store(~0ull, std::memory_order_release);  // (a query waiting for a submission that will not come)
+        aheadThread_.join();
+    }
     {
         std::lock_guard<std::mutex> guard(poolMutex_);
         poolStop_ = true;
@@ -279,12 +291,15 @@ void VectorEngineHost::forEachEnv(void (VectorEngineHost::*fn)(int)) {
 }
 
 // phases 0-1 of one environment (its own mt19937 and flows)
-void VectorEngineHost::spawnEnv(int r) { spawners_[r]->step(step_, envRecs_[r]); }
+void VectorEngineHost::spawnEnv(int r) {
+    if (journalling_) spawners_[r]->beginAhead();
+    spawners_[r]->step((size_t) preparing_.load(std::memory_order_relaxed), envRecs_[r]);
+}
 
 // an environment's records, renumbered into the device engine's index spaces, at their place in the batch
 void VectorEngineHost::translateEnv(int r) {
     int32_t g = batchFirstVid_ + envBase_[r];
-    cfx_spawn *out = recs_.data() + envBase_[r];
+    cfx_spawn *out = recsNext_.data() + envBase_[r];
     std::vector<int32_t> &l2g = localToGlobal_[r];
     const int32_t firstLocal = (int32_t) l2g.size();  // a batch holds the next dense run of local vids, in any order
     l2g.resize(l2g.size() + envRecs_[r].size());
@@ -343,12 +358,19 @@ void VectorEngineHost::peekEnv(int r) {
     std::copy(tmp.begin(), tmp.end(), shadowPool_.begin() + (size_t) r * shadowPoolPerEnv_);
 }
 
-void VectorEngineHost::nextStep() {
+// One step's batch: the R spawners, the numbering of the new vehicles (environment order), the translation into the device
+// engine's index spaces — into recsNext_.
+void VectorEngineHost::prepareBatch(size_t step, double *spawnSec, double *translateSec) {
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
+    preparing_.store((uint64_t) step, std::memory_order_release);
     envRecs_.resize((size_t) R_);
     envBase_.resize((size_t) R_);
-    settleLaneChange();  // every generator must be past the last step's shadow draws before this step's spawns
+    if (journalling_) {
+        l2gMark_ = globalToLocal_.size();
+        l2gEnvMark_.resize((size_t) R_);
+        for (int r = 0; r < R_; ++r) l2gEnvMark_[(size_t) r] = localToGlobal_[(size_t) r].size();
+    }
     forEachEnv(&VectorEngineHost::spawnEnv);
     const auto t1 = clk::now();
     int32_t total = 0;
@@ -361,47 +383,153 @@ void VectorEngineHost::nextStep() {
     }
     batchFirstVid_ = (int32_t) globalToLocal_.size();
     globalToLocal_.resize(globalToLocal_.size() + (size_t) total);
-    recs_.resize((size_t) total);
+    recsNext_.resize((size_t) total);
     forEachEnv(&VectorEngineHost::translateEnv);
+    const auto t2 = clk::now();
+    if (spawnSec) *spawnSec += std::chrono::duration<double>(t1 - t0).count();
+    if (translateSec) *translateSec += std::chrono::duration<double>(t2 - t1).count();
+}
+
+void VectorEngineHost::aheadLoop() {
+    for (;;) {
+        size_t step;
+        {
+            std::unique_lock<std::mutex> lock(aheadMutex_);
+            aheadCv_.wait(lock, [&] { return aheadStop_ || aheadState_ == kAheadWorking; });
+            if (aheadStop_) return;
+            step = aheadStep_;
+        }
+        std::string error;
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            prepareBatch(step, nullptr, nullptr);
+        } catch (const std::exception &e) {
+            error = e.what()[0] ? e.what() : "unknown error";
+        }
+        hostAheadSec_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        {
+            std::lock_guard<std::mutex> guard(aheadMutex_);
+            aheadError_ = error;
+            aheadState_ = error.empty() ? kAheadReady : kAheadFailed;
+        }
+        aheadCv_.notify_all();
+    }
+}
+
+void VectorEngineHost::kickAhead(size_t step) {
+    if (!aheadThread_.joinable()) aheadThread_ = std::thread([this] { aheadLoop(); });
+    {
+        std::lock_guard<std::mutex> guard(aheadMutex_);
+        aheadStep_ = step;
+        aheadState_ = kAheadWorking;
+    }
+    aheadCv_.notify_all();
+}
+
+void VectorEngineHost::waitAhead() {
+    std::unique_lock<std::mutex> lock(aheadMutex_);
+    aheadCv_.wait(lock, [&] { return aheadState_ != kAheadWorking; });
+}
+
+// Whatever was prepared for a step that is not going to be taken as it stands: every spawner goes back to where the last
+// step that WAS taken left it (generator, flows, priority set, vehicle tables), and so does the numbering.
+void VectorEngineHost::dropAhead() {
+    if (!aheadEnabled_) return;
+    waitAhead();
+    if (aheadState_ == kAheadReady || aheadState_ == kAheadFailed) {
+        for (auto &sp : spawners_) sp->rollbackAhead();
+        if (l2gEnvMark_.size() == (size_t) R_) {
+            globalToLocal_.resize(std::min(globalToLocal_.size(), l2gMark_));
+            for (int r = 0; r < R_; ++r)
+                localToGlobal_[(size_t) r].resize(std::min(localToGlobal_[(size_t) r].size(), l2gEnvMark_[(size_t) r]));
+        }
+    }
+    aheadState_ = kAheadIdle;
+    journalling_ = false;
+}
+
+void VectorEngineHost::nextStep() {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    settleLaneChange();  // every generator must be past the last step's shadow draws before this step's spawns
+    double spawnSec = 0, translateSec = 0;
+    bool taken = false;
+    if (aheadEnabled_) {
+        waitAhead();
+        if (aheadState_ == kAheadFailed) {  // what the ahead thread ran into is raised by the step it belonged to
+            const std::string msg = aheadError_;
+            dropAhead();
+            throw std::runtime_error(msg);
+        }
+        if (aheadState_ == kAheadReady && aheadStep_ == step_) {
+            for (auto &sp : spawners_) sp->commitAhead();
+            aheadState_ = kAheadIdle;
+            taken = true;
+            spawnSec = std::chrono::duration<double>(clk::now() - t0).count();  // (the wait is what the caller paid)
+        } else if (aheadState_ == kAheadReady) {
+            dropAhead();
+        }
+    }
+    if (!taken) {
+        journalling_ = false;
+        prepareBatch(step_, &spawnSec, &translateSec);
+    }
+    recs_.swap(recsNext_);
     if (laneChange_) {
         shadowPool_.resize((size_t) shadowPoolPerEnv_ * R_);
         envPeek_.resize((size_t) R_);
         forEachEnv(&VectorEngineHost::peekEnv);
         check(be_.cfx_lane_change_supply(dev_, (int32_t) shadowPool_.size(), shadowPool_.data()), "cfx_lane_change_supply");
     }
+    if (aheadEnabled_) {  // the next step's batch, beside this step's submission and the device's work
+        journalling_ = true;
+        kickAhead(step_ + 1);
+    }
     const auto t2 = clk::now();
-    check(be_.cfx_step(dev_, recs_.data(), (int32_t) recs_.size()), "cfx_step");
+    {
+        std::lock_guard<std::mutex> guard(queryMutex_);  // (a priority collision on the ahead thread asks the device too)
+        check(be_.cfx_step(dev_, recs_.data(), (int32_t) recs_.size()), "cfx_step");
+    }
+    submitted_.store((uint64_t) step_ + 1, std::memory_order_release);
     lcPollPending_ = laneChange_;
     const auto t3 = clk::now();
-    hostSpawnSec_ += std::chrono::duration<double>(t1 - t0).count();
-    hostTranslateSec_ += std::chrono::duration<double>(t2 - t1).count();
+    hostSpawnSec_ += spawnSec;
+    hostTranslateSec_ += translateSec;
     hostSubmitSec_ += std::chrono::duration<double>(t3 - t2).count();
     step_ += 1;
 }
 
 void VectorEngineHost::reset(bool resetRnd) {
+    dropAhead();
     settleLaneChange();  // (without a reseed the generators go on from behind the last step's shadow draws)
-    check(be_.cfx_reset(dev_), "cfx_reset");
+    {
+        std::lock_guard<std::mutex> guard(queryMutex_);
+        check(be_.cfx_reset(dev_), "cfx_reset");
+    }
     for (auto &sp : spawners_) sp->reset(resetRnd);
     for (auto &v : localToGlobal_) v.clear();
     globalToLocal_.clear();
     step_ = 0;
-    hostSpawnSec_ = hostTranslateSec_ = hostSubmitSec_ = 0;
+    submitted_.store(0, std::memory_order_release);
+    hostSpawnSec_ = hostTranslateSec_ = hostSubmitSec_ = hostAheadSec_ = 0;
 }
 
 std::vector<int32_t> VectorEngineHost::laneVehicleCounts() {
+    std::lock_guard<std::mutex> guard(queryMutex_);  // (the ABI is not re-entrant: the ahead thread may be asking the device)
     std::vector<int32_t> out((size_t) R_ * L_);
     check(be_.cfx_get_lane_counts(dev_, out.data()), "cfx_get_lane_counts");
     return out;
 }
 
 std::vector<int32_t> VectorEngineHost::laneWaitingVehicleCounts() {
+    std::lock_guard<std::mutex> guard(queryMutex_);  // (the ABI is not re-entrant: the ahead thread may be asking the device)
     std::vector<int32_t> out((size_t) R_ * L_);
     check(be_.cfx_get_lane_waiting_counts(dev_, out.data()), "cfx_get_lane_waiting_counts");
     return out;
 }
 
 cfx_scalars VectorEngineHost::scalars() {
+    std::lock_guard<std::mutex> guard(queryMutex_);  // (the ABI is not re-entrant: the ahead thread may be asking the device)
     cfx_scalars s{};
     check(be_.cfx_get_scalars(dev_, &s), "cfx_get_scalars");
     return s;
@@ -409,11 +537,18 @@ cfx_scalars VectorEngineHost::scalars() {
 
 int64_t VectorEngineHost::totalVehicleCount() { return scalars().active_vehicle_count; }
 
-void VectorEngineHost::sync() { check(be_.cfx_sync(dev_), "cfx_sync"); }
+void VectorEngineHost::sync() {
+    std::lock_guard<std::mutex> guard(queryMutex_);
+    check(be_.cfx_sync(dev_), "cfx_sync");
+}
 
-void VectorEngineHost::profileEnable(bool on) { check(be_.cfx_profile_enable(dev_, on ? 1 : 0), "cfx_profile_enable"); }
+void VectorEngineHost::profileEnable(bool on) {
+    std::lock_guard<std::mutex> guard(queryMutex_);
+    check(be_.cfx_profile_enable(dev_, on ? 1 : 0), "cfx_profile_enable");
+}
 
 std::map<std::string, std::pair<double, int64_t>> VectorEngineHost::profileRead() {
+    std::lock_guard<std::mutex> guard(queryMutex_);  // (the ABI is not re-entrant: the ahead thread may be asking the device)
     int n = be_.cfx_profile_kernel_count();
     std::vector<double> ms(n > 0 ? n : 1);
     std::vector<int64_t> cnt(n > 0 ? n : 1);
@@ -440,6 +575,7 @@ void VectorEngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases)
             inters.push_back(r * I_ + i);
             ph.push_back(p);
         }
+    std::lock_guard<std::mutex> guard(queryMutex_);
     check(be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data()), "cfx_set_tl_phases");
 }
 
@@ -465,6 +601,7 @@ std::map<std::string, int> VectorEngineHost::getLaneVehicleCount(int env) {
 
 std::map<std::string, double> VectorEngineHost::getVehicleSpeed(int env) {
     if (env < 0 || env >= R_) throw std::out_of_range("env index out of range");
+    if (aheadEnabled_) waitAhead();  // (the numbering tables are the ahead thread's while it works)
     settleLaneChange();  // (the shadows of the last step have their numbers then)
     int cap = (int) scalars().active_vehicle_count + 16;
     std::vector<int32_t> vid(cap), drv(cap);
@@ -476,7 +613,10 @@ std::map<std::string, double> VectorEngineHost::getVehicleSpeed(int env) {
     v.drivable = drv.data();
     v.speed = speed.data();
     if (laneChange_) v.lc_flags = lcFlags.data();
-    check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
+    {
+        std::lock_guard<std::mutex> guard(queryMutex_);
+        check(be_.cfx_get_vehicles(dev_, &v), "cfx_get_vehicles");
+    }
     std::map<std::string, double> ret;
     for (int i = 0; i < v.count; ++i) {
         const auto &gl = globalToLocal_[vid[i]];

@@ -45,8 +45,9 @@ public:
     void profileEnable(bool on);
     std::map<std::string, std::pair<double, int64_t>> profileRead();
     std::string backendName() const { return be_.cfx_backend_name(); }
-    // cumulative host wall seconds since the last reset: {spawners, record translation, cfx_step (launches + back-pressure)}
-    std::vector<double> hostSeconds() const { return {hostSpawnSec_, hostTranslateSec_, hostSubmitSec_}; }
+    // cumulative host wall seconds since the last reset, ON THE CALLER'S PATH: {spawners (with the batch prepared a step ahead:
+    // the wait for it), record translation, cfx_step (launches + back-pressure)}, then the ahead thread's own busy time
+    std::vector<double> hostSeconds() const { return {hostSpawnSec_, hostTranslateSec_, hostSubmitSec_, hostAheadSec_}; }
     // per-environment id-keyed view, for parity tests against a standalone Engine
     std::map<std::string, double> getVehicleSpeed(int env);
     std::map<std::string, int> getLaneVehicleCount(int env);
@@ -68,7 +69,8 @@ private:
     double interval_ = 1.0;
     bool rlTrafficLight_ = false;
     size_t step_ = 0;
-    std::vector<cfx_spawn> recs_;
+    std::vector<cfx_spawn> recs_;       // the batch being handed to the device
+    std::vector<cfx_spawn> recsNext_;   // the batch being prepared (swapped with recs_ when a step takes it)
     std::vector<std::vector<cfx_spawn>> envRecs_;  // [env] this step's records in the environment's own numbering
 
     // The R spawners are independent (own mt19937, own flows): phases 0-1 of all environments run on a small pool of
@@ -88,7 +90,32 @@ private:
     void (VectorEngineHost::*poolFn_)(int) = nullptr;
     std::vector<int32_t> envBase_;  // [env] offset of the environment's records in this step's batch
     int32_t batchFirstVid_ = 0;
-    double hostSpawnSec_ = 0, hostTranslateSec_ = 0, hostSubmitSec_ = 0;
+    double hostSpawnSec_ = 0, hostTranslateSec_ = 0, hostSubmitSec_ = 0, hostAheadSec_ = 0;
+    // ---- the batch of step t+1 is prepared while step t is submitted and runs (config "cfx": {"spawnAhead": false} turns it
+    //      off; not with lane change, whose shadows draw from the generators after the device has scheduled them).  The
+    //      reference's Flow::nextStep / planRoute (flow.cpp:6-22, engine.cpp:450-470) depend on nothing a step computes
+    //      except through the rare priority collision, which asks the device — after step t has been handed over, as always.
+    //      One more host thread runs the R spawners and the translation (on the pool above when that pays); every spawner
+    //      journals the step (Spawner::beginAhead), so reset() can take it back.  nextStep() only waits for the batch.
+    void prepareBatch(size_t step, double *spawnSec, double *translateSec);  // spawn + number + translate into recsNext_
+    void aheadLoop();
+    void kickAhead(size_t step);
+    void waitAhead();                 // until the ahead thread is not working (rethrows what it threw)
+    void dropAhead();                 // ... and take a prepared batch back (rollback of every spawner's journal)
+    bool aheadEnabled_ = false;
+    bool journalling_ = false;        // the batch being prepared is one a reset may have to take back
+    enum AheadState { kAheadIdle, kAheadWorking, kAheadReady, kAheadFailed };
+    AheadState aheadState_ = kAheadIdle;
+    size_t aheadStep_ = 0;
+    std::string aheadError_;
+    size_t l2gMark_ = 0;              // globalToLocal_.size() before the prepared batch
+    std::vector<size_t> l2gEnvMark_;  // localToGlobal_[r].size() before it
+    std::thread aheadThread_;
+    std::mutex aheadMutex_;
+    std::condition_variable aheadCv_;
+    bool aheadStop_ = false;
+    std::atomic<uint64_t> preparing_{0};  // the step whose batch is being prepared
+    std::atomic<uint64_t> submitted_{0};  // steps handed to the device so far (a priority-collision query of step s waits for s)
     std::vector<std::thread> workers_;
     std::mutex poolMutex_, queryMutex_;
     std::condition_variable poolCv_;

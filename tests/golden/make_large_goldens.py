@@ -8,6 +8,17 @@ bytes `get_lane_vehicle_count_array().tobytes()` gives on the engine under test)
 (id, speed, distance) as exact hex floats, and — read from an Archive dump (src/engine/archive.cpp:250-300) at the last
 checkpoint — sha256 over every non-virtual intersection's (id, curPhaseIndex, remainDuration).
 
+Exact-distance ties.  Engine::updateLocation sorts ALL vehicles that change drivable in a step — one global vector, ~20 000
+entries at this size — by their new distance with std::sort (engine.cpp:480): libstdc++'s introsort, which is not stable, so
+the order of two vehicles that enter a lane with EXACTLY equal distances is a function of the whole vector, of heap addresses
+and, with several threads, of which thread pushed first.  Such ties happen a few times in 400 steps at this size (none in the
+30x30 goldens).  Two 8-thread runs of the reference agree in every count, every lane, the average travel time and the multiset
+of all (speed, distance) pairs — and differ in which vehicle id carries which pair.  include/cityflow_amd.h fixes the order
+(ties by vehicle number) and counts the events (cfx_scalars::tie_events).  So every record carries, besides the id-keyed
+`state_hash`, the id-free `kinematics_hash`; the CPU twin runs beside the reference and the record says how many ties it had
+counted by then and what ITS id-keyed hash is.  A checker asserts everything but `state_hash` against the reference, and
+`state_hash` against the reference while no tie has happened and against the twin's afterwards.
+
 The reference runs with ONE thread and its Vehicle objects at creation-ordered addresses (LD_PRELOAD of
 oracle/_ref/libmonotonic_new.so, oracle/monotonic_new.cpp; the script re-executes itself that way): where two vehicles
 enter a drivable with EXACTLY equal distances, Engine::updateLocation's unstable std::sort (engine.cpp:480) leaves their
@@ -34,7 +45,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
 
-CHECKPOINTS = [150, 305, 320, 340]
+CHECKPOINTS = [150, 305, 360, 420]  # bench.py: 305 in the build-up, 360 = end of its timed region, 420 behind its instrumented region
 
 
 def lane_array_hash(eng, lane_ids):
@@ -49,6 +60,38 @@ def state_hash(speed, distance):
     for k in sorted(speed):
         h.update(("%s %s %s\n" % (k, float(speed[k]).hex(), float(distance[k]).hex())).encode())
     return h.hexdigest()
+
+
+def kinematics_hash(speed, distance):
+    """sha256 over the sorted multiset of every running vehicle's exact (speed, distance) — no ids: what stays equal when
+    two vehicles that entered a lane with EXACTLY equal distances are listed in the other order (see the module docstring)."""
+    h = hashlib.sha256()
+    for pair in sorted((float(speed[k]).hex(), float(distance[k]).hex()) for k in speed):
+        h.update(("%s %s\n" % pair).encode())
+    return h.hexdigest()
+
+
+def record(eng, lane_ids):
+    lane_sum, lane_sha = lane_array_hash(eng, lane_ids)
+    speed, distance = eng.get_vehicle_speed(), eng.get_vehicle_distance()
+    return {"vehicle_count": eng.get_vehicle_count(), "lane_sum": lane_sum, "lane_array_sha256": lane_sha,
+            "state_hash": state_hash(speed, distance), "kinematics_hash": kinematics_hash(speed, distance),
+            "average_travel_time": float(eng.get_average_travel_time()).hex()}
+
+
+def twin_records(cfg, lane_ids, out_path):
+    """The CPU twin (oracle/twin, ties broken by vehicle number) on the same workload, in a process of its own: its records
+    and the exact-distance ties it has counted at every checkpoint."""
+    from cityflow_amd import _cityflow
+    eng = _cityflow.Engine._with_backend(cfg, 1, os.path.join(ROOT, "oracle", "_ref", "libcfx_twin.so"))
+    recs = {}
+    for s in range(1, max(CHECKPOINTS) + 1):
+        eng.next_step()
+        if s in CHECKPOINTS:
+            recs[str(s)] = dict(record(eng, lane_ids), tie_events=int(eng._scalars()["tie_events"]))
+            print("twin checkpoint", s, recs[str(s)], flush=True)
+    with open(out_path, "w") as f:
+        json.dump(recs, f)
 
 
 def phase_hash(lights, real):
@@ -82,6 +125,15 @@ def main():
     flat = _cityflow._load_roadnet(os.path.join(os.path.dirname(cfg), "roadnet.json"))
     lane_ids = flat["lane_ids"]
     real = {k for k, v in zip(flat["inter_ids"], flat["inter_virtual"]) if not v}  # (virtual intersections have no signal plan)
+    twin_out = os.path.join(work, "twin_records.json")
+    twin_pid = os.fork()
+    if twin_pid == 0:  # (the twin beside the reference: ~4 minutes on one core)
+        try:
+            os.environ.pop("LD_PRELOAD", None)
+            twin_records(cfg, lane_ids, twin_out)
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
     t0 = time.time()
     eng = cityflow_ref.Engine(cfg, args.threads)
     print("reference engine loaded in %.1f s" % (time.time() - t0), flush=True)
@@ -91,10 +143,7 @@ def main():
         if s % 25 == 0:
             print("step %d: %d vehicles, %.0f s" % (s, eng.get_vehicle_count(), time.time() - t0), flush=True)
         if s in CHECKPOINTS:
-            lane_sum, lane_sha = lane_array_hash(eng, lane_ids)
-            recs[str(s)] = {"vehicle_count": eng.get_vehicle_count(), "lane_sum": lane_sum, "lane_array_sha256": lane_sha,
-                            "state_hash": state_hash(eng.get_vehicle_speed(), eng.get_vehicle_distance()),
-                            "average_travel_time": float(eng.get_average_travel_time()).hex()}
+            recs[str(s)] = record(eng, lane_ids)
             print("checkpoint", s, recs[str(s)], flush=True)
     dump = os.path.join(work, "end.json")
     eng.snapshot().dump(dump)
@@ -102,6 +151,16 @@ def main():
         lights = json.load(f)["trafficLights"]  # (a 1.2 GB file: ~10 GB of Python objects for a minute)
     recs[str(max(CHECKPOINTS))]["phase_hash"] = phase_hash(lights, real)
     os.remove(dump)
+    os.waitpid(twin_pid, 0)
+    with open(twin_out) as f:
+        twin = json.load(f)
+    for k, r in recs.items():  # what the twin (ties by vehicle number) has at the same steps
+        tw = twin[k]
+        r["twin_tie_events"] = tw["tie_events"]
+        r["twin_state_hash"] = tw["state_hash"]
+        same = {f: tw[f] == r[f] for f in ("vehicle_count", "lane_sum", "lane_array_sha256", "kinematics_hash", "average_travel_time")}
+        if not all(same.values()):
+            raise SystemExit("the twin differs from the reference at step %s in more than which tied vehicle is which: %r" % (k, same))
     out = {"workload": "%s (cityflow_amd.scenarios.generate_grid, seed 0) + %d seeded interior flows (bench.build_workload)"
                        % (scen, args.flows),
            "reference_threads": args.threads, "vehicle_addresses": "creation-ordered" if os.environ.get("CFX_VEHICLE_SIZE") else "heap",

@@ -105,31 +105,13 @@ def _large_golden():
         return json.load(f)
 
 
-def _large_record(eng, with_phases, real):
-    import hashlib
-    from conftest import state_hash
-    arr = eng.get_lane_vehicle_count_array().astype(np.int32)
-    rec = {"vehicle_count": eng.get_vehicle_count(), "lane_sum": int(arr.sum()),
-           "lane_array_sha256": hashlib.sha256(arr.tobytes()).hexdigest(),
-           "state_hash": state_hash(eng.get_vehicle_speed(), eng.get_vehicle_distance()),
-           "average_travel_time": float(eng.get_average_travel_time()).hex()}
-    if with_phases:
-        ph, rm = eng._tl_state()
-        h = hashlib.sha256()
-        for k, p, r in sorted(zip(eng.intersection_ids(), ph.tolist(), rm.tolist())):
-            if k in real:
-                h.update(("%s %d %s\n" % (k, int(p), float(r).hex())).encode())
-        rec["phase_hash"] = h.hexdigest()
-    return rec
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["auto", "dense"])
 def test_config5_one_million_vehicles_matches_reference_goldens(mod, workdir, layout):
-    """HIP engine from step 0 on the 100x100 / 1 M vehicle workload == the reference's own records at steps 150, 305, 320,
-    340: vehicle count, every lane's count, average travel time, every vehicle's (speed, distance) bits, signal phases.
+    """HIP engine from step 0 on the 100x100 / 1 M vehicle workload == the reference's own records at steps 150, 305, 360,
+    420 (bench.py's scale leg passes the same steps): vehicle count, every lane's count, average travel time, the multiset of
+    all (speed, distance) bits, signal phases; which vehicle carries which pair: see bench.scale_compare.
     `auto` is the ring layout's list form at this size (kr_index + kl_action + k_cross2), `dense` the scan / scatter layout."""
-    import json
     import bench
     from test_parity_pins import _with_cfx
     t0 = time.time()
@@ -143,7 +125,8 @@ def test_config5_one_million_vehicles_matches_reference_goldens(mod, workdir, la
     for s in range(1, max(want) + 1):
         eng.next_step()
         if s in want:
-            got = _large_record(eng, "phase_hash" in want[s], real)
-            assert got == want[s], "step %d (%s layout), ties so far %d" % (s, layout, eng._scalars()["tie_events"])
+            got = bench.scale_record(eng, real if "phase_hash" in want[s] else None)
+            verdict = bench.scale_compare(got, want[s], int(eng._scalars()["tie_events"]))
+            assert verdict["equal"], "step %d (%s layout): %r" % (s, layout, verdict)
     assert eng.get_vehicle_count() > 1000000
     print("100x100 vs reference goldens (%s, %s): %.0f s" % (layout, eng._layout(), time.time() - t0))

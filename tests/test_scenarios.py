@@ -53,24 +53,52 @@ def test_generated_3x5_grid_reference_vs_twin(mod, scen, workdir, ref_module):
     del ref
 
 
-def test_bench_roofline_is_priced_with_the_chunk_median_when_one_launch_is_an_outlier():
-    """bench.chunk_medians: an instrumented run read in parts; one launch that the box stretched to milliseconds must not
-    price the roofline (both figures stay in the line, and the choice is named)."""
+def test_bench_roofline_keeps_plain_averages_and_reports_the_chunk_median_beside_them():
+    """bench.chunk_medians: an instrumented run read in parts.  `avg_launch_us`, `achieved` and `frac` always mean the plain
+    average over every instrumented launch; the figures priced with the median of the parts' averages stand beside them under
+    their own names, and one launch that the box stretched to milliseconds is named, not averaged away."""
     import bench
     veh = 87890.0
     chunks = [{"k_action": (0.3125, 25), "k_cross": (0.4, 25)} for _ in range(4)]      # 12.5 us per launch
     chunks[2] = {"k_action": (76.3, 25), "k_cross": (0.4, 25)}                           # one 76 ms launch among them
     prof = {"k_action": (sum(c["k_action"][0] for c in chunks), 100), "k_cross": (1.6, 100)}
-    roof = bench.roofline_from_profile(prof, veh * 100, "no-such-workload", "test", with_traffic=False)
-    assert roof["avg_launch_us"] > 700
+    roof = bench.roofline_from_profile(prof, veh * 100, "no-such-workload", "test", with_traffic=False,
+                                       symbols={"k_action": "kr_action<256>"})
+    assert roof["kernel"] == "kr_action<256>" and roof["profile_slot"] == "k_action"
+    plain, plain_frac = roof["avg_launch_us"], roof["frac"]
+    assert plain > 700
     bench.chunk_medians(roof, chunks)
-    assert abs(roof["avg_launch_us"] - 12.5) < 1e-9 and roof["avg_launch_us_all_launches"] > 700
-    assert roof["duration_estimator"].startswith("median of 4 chunk averages")
-    assert abs(roof["frac"] - 48 * veh / 12.5e-6 / 1e9 / 8000.0) < 1e-12
-    # a run without an outlier keeps the plain average
+    assert roof["avg_launch_us"] == plain and roof["frac"] == plain_frac  # unchanged meaning
+    assert abs(roof["avg_launch_us_median_of_chunk_averages"] - 12.5) < 1e-9
+    assert abs(roof["frac_median_priced"] - 48 * veh / 12.5e-6 / 1e9 / 8000.0) < 1e-12
+    assert "outlier" in roof["outlier_note"]
+    # a run without an outlier: the two agree and nothing is flagged
     calm = [{"k_action": (0.3125 + 0.001 * i, 25)} for i in range(4)]
     prof = {"k_action": (sum(c["k_action"][0] for c in calm), 100)}
     roof = bench.roofline_from_profile(prof, veh * 100, "no-such-workload", "test", with_traffic=False)
-    before = roof["avg_launch_us"]
+    assert roof["kernel"] == "k_action"  # (no symbol known: the slot's name)
     bench.chunk_medians(roof, calm)
-    assert roof["avg_launch_us"] == before and roof["duration_estimator"] == "average over all instrumented launches"
+    assert "outlier_note" not in roof and abs(roof["frac_median_priced"] - roof["frac"]) < 0.01 * roof["frac"]
+
+
+def test_scale_record_and_compare_rules(mod, scen, workdir):
+    """bench.scale_record / scale_compare (the 1 M-vehicle checkpoints of tests/golden/reference_large.json) on a small run of
+    the twin: a record equals itself; a swap of two vehicle ids is tolerated only once an exact-distance tie has been counted,
+    and then only if it is the twin's order; any other difference never is."""
+    import bench
+    from conftest import TWIN_LIB
+    eng = mod.Engine._with_backend(scen.materialize("grid_6x6", workdir), 1, TWIN_LIB)
+    for _ in range(120):
+        eng.next_step()
+    net = eng._flat_net()
+    real = {k for k, v in zip(eng.intersection_ids(), net["inter_virtual"]) if not v}
+    rec = bench.scale_record(eng, real)
+    assert rec["vehicle_count"] == eng.get_vehicle_count() > 100 and rec["lane_sum"] <= rec["vehicle_count"]
+    want = dict(rec, twin_tie_events=0, twin_state_hash=rec["state_hash"])
+    assert bench.scale_compare(rec, want, 0)["equal"]
+    swapped = dict(want, state_hash="0" * 64)  # the reference listed a tied pair the other way round
+    assert not bench.scale_compare(rec, swapped, 0)["equal"]          # ... but no tie was counted: a real difference
+    assert bench.scale_compare(rec, dict(swapped, twin_tie_events=1), 1)["equal"]  # after a tie: the twin's order is the bar
+    assert not bench.scale_compare(rec, dict(swapped, twin_tie_events=1, twin_state_hash="1" * 64), 1)["equal"]
+    assert not bench.scale_compare(rec, dict(want, lane_array_sha256="0" * 64), 0)["equal"]
+    assert not bench.scale_compare(rec, dict(want, kinematics_hash="0" * 64, twin_tie_events=1), 1)["equal"]

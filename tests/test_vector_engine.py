@@ -232,3 +232,42 @@ def test_vector_engine_hip_many_finishers(mod, scen, workdir):
             prev = a["finished_vehicle_count"]
     assert biggest > 1024
     assert np.array_equal(hip.get_lane_vehicle_count_array(), twin.get_lane_vehicle_count_array())
+
+
+def _cfx_variant(path, suffix, **cfx):
+    import json
+    c = json.load(open(path))
+    c["cfx"] = cfx
+    out = path.replace(".json", "_%s.json" % suffix)
+    with open(out, "w") as f:
+        json.dump(c, f)
+    return out
+
+
+def test_vector_engine_batch_a_step_ahead_twin(mod, scen, workdir):
+    """The batch of step t+1 is prepared on a host thread of its own while step t is submitted and runs (Flow::nextStep and
+    planRoute, reference src/flow/flow.cpp:6-22, src/engine/engine.cpp:450-470, depend on nothing the step computes).  On against
+    off (`"cfx": {"spawnAhead": false}`): every count, every speed of every environment, through resets that do and do not
+    reseed — a reset that keeps the generators must find them where the last step that was TAKEN left them, not behind the
+    step that was prepared."""
+    base = scen.materialize("example_1x1", workdir)
+    on = mod.VectorEngine._with_backend(base, 4, 1, TWIN_LIB)
+    off = mod.VectorEngine._with_backend(_cfx_variant(base, "noahead", spawnAhead=False), 4, 1, TWIN_LIB)
+    plan = [(70, None), (45, False), (60, True), (30, False)]  # (steps, reset(reseed) afterwards)
+    for steps, reseed in plan:
+        for s in range(steps):
+            on.next_step()
+            off.next_step()
+            if s % 9 == 8:  # getters between steps must not disturb the prepared batch
+                assert np.array_equal(on.get_lane_vehicle_count_array(), off.get_lane_vehicle_count_array()), s
+                assert np.array_equal(on.get_lane_waiting_vehicle_count_array(), off.get_lane_waiting_vehicle_count_array()), s
+        for e in range(4):
+            assert on.get_vehicle_speed(e) == off.get_vehicle_speed(e), e
+        assert on.get_vehicle_count() == off.get_vehicle_count() > 0
+        h = on._host_seconds()
+        assert len(h) == 4 and h[3] > 0.0  # the ahead thread did the spawners' work ...
+        assert off._host_seconds()[3] == 0.0  # ... and only where it is on
+        if reseed is not None:
+            on.reset(reseed)
+            off.reset(reseed)
+            assert on.get_vehicle_count() == 0 and on.get_current_time() == 0.0

@@ -15,6 +15,10 @@ if os.environ.get("CFX_VEC_LC"):  # the same with laneChange: true (every enviro
     c["laneChange"] = True
     cfg = cfg.replace(".json", "_lc.json")
     json.dump(c, open(cfg, "w"))
+if os.environ.get("CFX_VEC_CFX"):  # implementation choices, "key=value,key=value" (e.g. spawnAhead=false)
+    def _val(v):
+        return {"true": True, "false": False}.get(v, int(v) if v.lstrip("-").isdigit() else v)
+    cfg = bench.with_config(cfg, "cfx", cfx={k: _val(v) for k, v in (kv.split("=") for kv in os.environ["CFX_VEC_CFX"].split(","))})
 for R in rs:
     t0 = time.perf_counter()
     lib = os.environ.get("CFX_VEC_LIB")  # a differently built device library
@@ -47,6 +51,7 @@ for R in rs:
                       "env_steps_per_sec": K * R / dt, "vehicle_steps_per_sec": vs / dt,
                       "k_action_us": act_ms / act_n * 1e3, "k_action_GBps": gbs, "k_action_frac_of_8TBps": gbs / 8000.0,
                       "kernel_us": {k: round(ms / max(n, 1) * 1e3, 1) for k, (ms, n) in prof.items()},
-                      "host_us_per_step": {k: round((b - a) / K * 1e6, 1) for k, a, b in zip(("spawn", "translate", "submit"), h0, h1)},
+                      "host_us_per_step": {k: round((b - a) / K * 1e6, 1) for k, a, b in zip(("spawn", "translate", "submit", "ahead_thread"), h0, h1)},
+                      "cfx": os.environ.get("CFX_VEC_CFX"),
                       "load_s": round(t_load, 1)}), flush=True)
     del eng
