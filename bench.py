@@ -243,18 +243,20 @@ def scale_record(eng, real=None):
 
 
 def scale_compare(got, want, ties_here):
-    """One checkpoint against the golden record: every field against the reference's; which vehicle id carries which (speed,
-    distance) against the reference's while no exact-distance tie has happened, against the twin's (recorded beside it)
-    afterwards — the reference's own order of a tied pair is a function of its unstable global sort, heap addresses and thread
-    timing (tests/golden/make_large_goldens.py)."""
-    out = {f: got.get(f) == want[f] for f in ("vehicle_count", "lane_sum", "lane_array_sha256", "kinematics_hash",
-                                              "average_travel_time", "phase_hash") if f in want and f in got}
+    """One checkpoint against the golden record.  Counts, every lane, the average travel time and the signal phases against
+    the reference's at every checkpoint.  Every vehicle's exact (speed, distance) — id-keyed and as an id-free multiset —
+    against the reference's while no exact-distance tie has happened; afterwards against the CPU twin's, recorded beside it:
+    the reference's own order of a tied pair is a function of its unstable global sort, heap addresses and thread timing, and
+    the order decides which of two vehicles at one position brakes for the other (tests/golden/make_large_goldens.py)."""
+    out = {f: got.get(f) == want[f] for f in ("vehicle_count", "lane_sum", "lane_array_sha256", "average_travel_time", "phase_hash")
+           if f in want and f in got}
     out["exact_distance_ties_so_far"] = ties_here
     out["ties_equal_twin"] = ties_here == want.get("twin_tie_events")
-    out["vehicle_ids_equal_twin"] = got["state_hash"] == want.get("twin_state_hash")
-    out["vehicle_ids_equal_reference"] = got["state_hash"] == want["state_hash"]
-    need = [v for k, v in out.items() if k not in ("exact_distance_ties_so_far", "vehicle_ids_equal_reference")]
-    out["equal"] = bool(all(need) and (ties_here > 0 or out["vehicle_ids_equal_reference"]))
+    out["every_vehicle_equal_twin"] = (got["state_hash"] == want.get("twin_state_hash") and
+                                       got["kinematics_hash"] == want.get("twin_kinematics_hash"))
+    out["every_vehicle_equal_reference"] = got["state_hash"] == want["state_hash"] and got["kinematics_hash"] == want["kinematics_hash"]
+    need = [v for k, v in out.items() if k not in ("exact_distance_ties_so_far", "every_vehicle_equal_reference")]
+    out["equal"] = bool(all(need) and (ties_here > 0 or out["every_vehicle_equal_reference"]))
     return out
 
 
@@ -862,9 +864,9 @@ def scale_leg(job, args, n_steps):
                 "checkpoints": {str(s): r for s, r in sorted(parity_cps.items())},
                 "timed_region": "steps %d..%d" % (args.build_up_steps + 11, args.build_up_steps + 10 + n_steps),
                 "all_equal": bool(parity_cps) and all(r["equal"] for r in parity_cps.values()),
-                "checked": "vehicle count, every lane's count, average travel time, the multiset of every vehicle's exact (speed, "
-                           "distance), signal phases where recorded; which id carries which pair: against the reference until "
-                           "the first exact-distance tie, against the CPU twin's record afterwards"}
+                "checked": "vehicle count, every lane's count, average travel time, signal phases where recorded: against the "
+                           "reference at every checkpoint; every vehicle's exact (speed, distance), id-keyed and as a multiset: "
+                           "against the reference until the first exact-distance tie, against the CPU twin's record afterwards"}
             out["parity"] = roof_parity
         if roof:
             roof["config"] = out

@@ -1402,11 +1402,11 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 if (done > 0 && done <= e->step)
                     e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + e->nQueueLanes * (e->step + 1 - done));
                 const size_t listBound = (size_t) std::min<int64_t>(e->liveUpper, (int64_t) e->ringSlots);
-                const size_t needList = (listBound + kBlock - 1) / kBlock * kBlock + kBlock;
+                const size_t needList = (listBound + kListBlock - 1) / kListBlock * kListBlock + kListBlock;
                 if (needList > e->rListCap) {
                     e->stallCause |= CFX_STALL_LIST_GROW;
                     e->hostStats.table_grows_total += 1;
-                    const size_t nc = std::max(needList + needList / 4, e->rListCap * 2) / kBlock * kBlock;
+                    const size_t nc = std::max(needList + needList / 4, e->rListCap * 2) / kListBlock * kListBlock;
                     int rc = e->growDeferred(&e->rList, 0, nc);  // (rebuilt every step: nothing to keep)
                     if (rc) return rc;
                     e->rListCap = nc;
@@ -1416,8 +1416,8 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                         HIP_TRY(hipMemsetAsync(e->rListCount, 0, 2 * sizeof(int32_t), st));
                     }
                 }
-                const int nVehBlocks = (int) (needList / kBlock);  // (every entry a block of the launch reads exists)
-                const int nLL = (e->K + kBlock - 1) / kBlock;
+                const int nVehBlocks = (int) (needList / kListBlock);  // (every entry a block of the launch reads exists)
+                const int nLL = (e->K + kListBlock - 1) / kListBlock;
                 const int nIdxTiles = (int) ((e->D + kIndexTile - 1) / kIndexTile);
                 // (1024 threads: two blocks per CU.  Form 6 hands the tiles out by ticket whatever their number: the path of networks
                 //  above half a million drivables, for the tests)
@@ -1425,7 +1425,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 e->launchNamed(PK_SCAN, "kr_index", kr_index, dim3(nIdxTiles), dim3(kIndexBlock), c, e->rIdxGranules, idxTicket, (unsigned) (e->step + 1),
                           e->rList, (int) e->rListCap, e->rListCount, e->sc);
                 RING_CHECK("kr_index")
-                e->launchNamed(PK_ACTION, "kl_action", kl_action, dim3(nVehBlocks + nLL), dim3(kBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
+                e->launchNamed(PK_ACTION, "kl_action", kl_action, dim3(nVehBlocks + nLL), dim3(kListBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
                           (const int32_t *) e->rListCount, nVehBlocks, idxTicket);
             } else {
             G = std::min(G, Bsel);

@@ -139,6 +139,27 @@ struct MoverRec {
 };
 static_assert(sizeof(MoverRec) == 48, "mover record layout");
 
+// Streaming accesses (experiment knob CFX_KL_NT, a bit mask: 1 the list entry read by kl_action, 2 the list entries written
+// by kr_index, 4 the next-generation {dis, speed} record written by a stayer): data used once should not push the tail and
+// gate records out of the L2.
+#ifndef CFX_KL_NT
+#define CFX_KL_NT 7  // (round 6, 1 M vehicles: kl_action 49.5 -> 47.9 us, kr_index 12.2 -> 10.9; profiles/r06_exp_kl_block_nt.txt)
+#endif
+typedef int cfx_v4i __attribute__((ext_vector_type(4)));
+typedef double cfx_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int4 ntLoad4(const int4 *p) {
+    const cfx_v4i v = __builtin_nontemporal_load((const cfx_v4i *) p);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ntStore4(int4 *p, int4 x) {
+    const cfx_v4i v = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(v, (cfx_v4i *) p);
+}
+__device__ __forceinline__ void ntStore2(double2 *p, double a, double b) {
+    const cfx_v2d v = {a, b};
+    __builtin_nontemporal_store(v, (cfx_v2d *) p);
+}
+
 struct RingOut {
     double2 *kinN;
     int2 *blk;
@@ -213,7 +234,8 @@ __device__ inline void finishAction(const RingCtx &c, const RingOut &o, const cf
         nNow = cntNow(c, d);
     }
     if (newDrv == -1) {
-        o.kinN[s] = make_double2(ndis, v);
+        if (CFX_KL_NT & 4) ntStore2(&o.kinN[s], ndis, v);
+        else o.kinN[s] = make_double2(ndis, v);
         if (bv >= 0) o.blk[s] = make_int2(bv, c.step);
         if (idx == nNow - 1) {  // the last vehicle of its drivable leaves the tail record of this step's end
             TailRec r;
@@ -1481,7 +1503,11 @@ __global__ __launch_bounds__(kIndexBlock) void kr_index(RingCtx c, unsigned long
             const int o = sOwner[q];
             const int idx = w0 + q - sOff[o];
             const int at = tileOff + w0 + q;
-            if (at < listCap) list[at] = make_int4(ringSlot(sGeo[o], sHead[o], idx), tile * kIndexTile + o, idx, sN[o]);
+            if (at < listCap) {
+                const int4 entry = make_int4(ringSlot(sGeo[o], sHead[o], idx), tile * kIndexTile + o, idx, sN[o]);
+                if (CFX_KL_NT & 2) ntStore4(&list[at], entry);
+                else list[at] = entry;
+            }
         }
         __syncthreads();
     }
@@ -1495,29 +1521,33 @@ __global__ __launch_bounds__(kIndexBlock) void kr_index(RingCtx c, unsigned long
 #ifndef CFX_KL_WAVES
 #define CFX_KL_WAVES 5  // (97 registers unasked: one more than five wavefronts per SIMD allow; 48.5 us instead of 51.8.  6 spills: 73.7)
 #endif
-#define CFX_KL_BOUNDS __launch_bounds__(kBlock, CFX_KL_WAVES)
+#ifndef CFX_KL_BLOCK
+#define CFX_KL_BLOCK 256  // threads of a kl_action workgroup (a multiple of 64; the host sizes the list to whole workgroups)
+#endif
+constexpr int kListBlock = CFX_KL_BLOCK;
+#define CFX_KL_BOUNDS __launch_bounds__(kListBlock, CFX_KL_WAVES)  // (second argument: wavefronts per SIMD)
 __global__ CFX_KL_BOUNDS void kl_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, const int4 *list,
                                                     const int32_t *listCount, int nVehBlocks, int32_t *ticket) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
     if (w >= nVehBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
-        llstateRing(c, (w - nVehBlocks) * kBlock + t);
+        llstateRing(c, (w - nVehBlocks) * kListBlock + t);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
-    const int qv = w * kBlock + t;
+    const int qv = w * kListBlock + t;
     const int total = *listCount;
     if (qv == 0 && ticket) *ticket = 0;  // kr_index of this step is done; re-arm its tile counter for the next one
     KSTAMP(11, 0);
-    const int4 e = list[qv];  // (the list is allocated to whole blocks of the launch)
+    const int4 e = (CFX_KL_NT & 1) ? ntLoad4(&list[qv]) : list[qv];  // (the list is allocated to whole blocks of the launch)
     int ls = 0;
     if ((t & 63) == 0 && qv > 0) ls = list[qv - 1].x;  // the vehicle ahead of the wavefront's first one, if it has a leader
-    if (w * kBlock >= total) return;
+    if (w * kListBlock >= total) return;
     const cfx_vehicle_template *tv = c.t.templ;
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
         double *dst = (double *) sT;
-        for (int i = t; i < nd; i += kBlock) dst[i] = src[i];
+        for (int i = t; i < nd; i += kListBlock) dst[i] = src[i];
         tv = sT;
         __syncthreads();
     }

@@ -14,10 +14,15 @@ the order of two vehicles that enter a lane with EXACTLY equal distances is a fu
 and, with several threads, of which thread pushed first.  Such ties happen a few times in 400 steps at this size (none in the
 30x30 goldens).  Two 8-thread runs of the reference agree in every count, every lane, the average travel time and the multiset
 of all (speed, distance) pairs — and differ in which vehicle id carries which pair.  include/cityflow_amd.h fixes the order
-(ties by vehicle number) and counts the events (cfx_scalars::tie_events).  So every record carries, besides the id-keyed
-`state_hash`, the id-free `kinematics_hash`; the CPU twin runs beside the reference and the record says how many ties it had
-counted by then and what ITS id-keyed hash is.  A checker asserts everything but `state_hash` against the reference, and
-`state_hash` against the reference while no tie has happened and against the twin's afterwards.
+(ties by vehicle number) and counts the events (cfx_scalars::tie_events).  The order matters physically, not only for the
+labels: the pair sits at one position, whichever is listed first is the other's leader at gap -length, and the two have
+different routes — so from the first tie on a handful of vehicles around that lane evolve differently in any two engines
+(the twin and the reference differ in the id-free multiset of (speed, distance) at step 305 while every count, every lane and
+the average travel time still agree at step 420).  So every record carries the id-keyed `state_hash`, the id-free
+`kinematics_hash`, and — from the CPU twin, which runs beside the reference — the ties it had counted by then and ITS two
+hashes.  A checker asserts counts, lanes, travel time and phases against the reference at every checkpoint; the two
+per-vehicle hashes against the reference while no tie has happened, and against the twin's afterwards (the twin is pinned
+to the reference, tie-free, on every smaller network: tests/test_oracle.py).
 
 The reference runs with ONE thread and its Vehicle objects at creation-ordered addresses (LD_PRELOAD of
 oracle/_ref/libmonotonic_new.so, oracle/monotonic_new.cpp; the script re-executes itself that way): where two vehicles
@@ -158,9 +163,16 @@ def main():
         tw = twin[k]
         r["twin_tie_events"] = tw["tie_events"]
         r["twin_state_hash"] = tw["state_hash"]
-        same = {f: tw[f] == r[f] for f in ("vehicle_count", "lane_sum", "lane_array_sha256", "kinematics_hash", "average_travel_time")}
-        if not all(same.values()):
-            raise SystemExit("the twin differs from the reference at step %s in more than which tied vehicle is which: %r" % (k, same))
+        r["twin_kinematics_hash"] = tw["kinematics_hash"]
+        same = {f: tw[f] == r[f] for f in ("vehicle_count", "lane_sum", "lane_array_sha256", "average_travel_time",
+                                           "kinematics_hash", "state_hash")}
+        print("step %s: twin == reference: %r (ties counted by the twin: %d)" % (k, same, tw["tie_events"]), flush=True)
+        # counts, lanes and travel times must agree whatever happened; every vehicle's state while no tie has happened
+        must = ["vehicle_count", "lane_sum", "lane_array_sha256", "average_travel_time"]
+        if tw["tie_events"] == 0:
+            must += ["kinematics_hash", "state_hash"]
+        if not all(same[f] for f in must):
+            raise SystemExit("the twin differs from the reference at step %s beyond what an exact-distance tie explains: %r" % (k, same))
     out = {"workload": "%s (cityflow_amd.scenarios.generate_grid, seed 0) + %d seeded interior flows (bench.build_workload)"
                        % (scen, args.flows),
            "reference_threads": args.threads, "vehicle_addresses": "creation-ordered" if os.environ.get("CFX_VEHICLE_SIZE") else "heap",

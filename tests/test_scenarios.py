@@ -83,8 +83,8 @@ def test_bench_roofline_keeps_plain_averages_and_reports_the_chunk_median_beside
 
 def test_scale_record_and_compare_rules(mod, scen, workdir):
     """bench.scale_record / scale_compare (the 1 M-vehicle checkpoints of tests/golden/reference_large.json) on a small run of
-    the twin: a record equals itself; a swap of two vehicle ids is tolerated only once an exact-distance tie has been counted,
-    and then only if it is the twin's order; any other difference never is."""
+    the twin: a record equals itself; per-vehicle differences from the reference are tolerated only once an exact-distance tie
+    has been counted, and then only if they are the twin's; differences in counts, lanes or travel time never are."""
     import bench
     from conftest import TWIN_LIB
     eng = mod.Engine._with_backend(scen.materialize("grid_6x6", workdir), 1, TWIN_LIB)
@@ -94,11 +94,13 @@ def test_scale_record_and_compare_rules(mod, scen, workdir):
     real = {k for k, v in zip(eng.intersection_ids(), net["inter_virtual"]) if not v}
     rec = bench.scale_record(eng, real)
     assert rec["vehicle_count"] == eng.get_vehicle_count() > 100 and rec["lane_sum"] <= rec["vehicle_count"]
-    want = dict(rec, twin_tie_events=0, twin_state_hash=rec["state_hash"])
+    want = dict(rec, twin_tie_events=0, twin_state_hash=rec["state_hash"], twin_kinematics_hash=rec["kinematics_hash"])
     assert bench.scale_compare(rec, want, 0)["equal"]
-    swapped = dict(want, state_hash="0" * 64)  # the reference listed a tied pair the other way round
-    assert not bench.scale_compare(rec, swapped, 0)["equal"]          # ... but no tie was counted: a real difference
-    assert bench.scale_compare(rec, dict(swapped, twin_tie_events=1), 1)["equal"]  # after a tie: the twin's order is the bar
-    assert not bench.scale_compare(rec, dict(swapped, twin_tie_events=1, twin_state_hash="1" * 64), 1)["equal"]
+    other = dict(want, state_hash="0" * 64, kinematics_hash="0" * 64)  # the reference broke a tie the other way
+    assert not bench.scale_compare(rec, other, 0)["equal"]          # ... but no tie was counted: a real difference
+    assert bench.scale_compare(rec, dict(other, twin_tie_events=1), 1)["equal"]  # after a tie: the twin's record is the bar
+    assert not bench.scale_compare(rec, dict(other, twin_tie_events=1, twin_state_hash="1" * 64), 1)["equal"]
+    assert not bench.scale_compare(rec, dict(other, twin_tie_events=1, twin_kinematics_hash="1" * 64), 1)["equal"]
+    assert not bench.scale_compare(rec, dict(other, twin_tie_events=2), 1)["equal"]  # another number of ties than the twin
     assert not bench.scale_compare(rec, dict(want, lane_array_sha256="0" * 64), 0)["equal"]
-    assert not bench.scale_compare(rec, dict(want, kinematics_hash="0" * 64, twin_tie_events=1), 1)["equal"]
+    assert not bench.scale_compare(rec, dict(other, twin_tie_events=1, average_travel_time="0x0p+0"), 1)["equal"]
