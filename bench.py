@@ -915,6 +915,12 @@ def main():
                 build_tiled_workload(workdir, rows, cols, args.tile_block, args.extra_flows)
             job.barrier()
             cfg = os.path.join(workdir, "gen_%dx%d" % (args.tile_block * rows, args.tile_block * cols), "config_bench.json")
+        if args.cfx:  # (developer: implementation choices for the tiles too, e.g. ringLanesPerWave=70000 = the dense tiles of rounds 2-5)
+            if rank == 0:
+                with_config(cfg, "cfx", cfx={k: (int(v) if v.lstrip("-").isdigit() else v)
+                                              for k, v in (kv.split("=") for kv in args.cfx.split(","))})
+            job.barrier()
+            cfg = cfg.replace(".json", "_cfx.json")
         if args.no_halo:
             halo_notes.append("--no-halo")
         else:

@@ -693,7 +693,9 @@ struct cfx_engine {
         *nStatOut = nStat;
         return RingCommit{rScratch, rMovers, waitHead, curPhase, remain, (int) cfg.rl_traffic_light, (int) nMaskWords,
                           sc, rFinKey, rFinVid, rFinTerm, rFinCap, jobCount,
-                          tiled ? (HostMirror *) nullptr : hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
+                          // (a tile's `active` is final only after the halo import; its mirror serves as the stale estimate that
+                          // sizes the next steps' grids — mirrorValid stays false, nothing else reads it)
+                          hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
                           lightsDone ? 1 : 0, publishTo(), finCount, tiled ? LaneHistDev{} : hist};
     }
     int settle() {
@@ -702,11 +704,39 @@ struct cfx_engine {
         int nStat = 1;
         const RingCommit rk = commitArgs(activeEstimate(), true, &nStat);
         launchNamed(PK_COMMIT, "kr_commit", kr_commit, dim3(gridStride((size_t) std::max(D, std::max(I, nMaskWords))) + nStat), dim3(kBlock),
-               rctx(true, step - 1, rcur ^ 1), rk, vt);
+               rctx(true, step - 1, rcur ^ 1), rk, vt, RingHalo{});
         HIP_TRY(hipGetLastError());
         return CFX_OK;
     }
     // (Re)build the rings: first use, a shorter vehicle template than the capacities were computed for, or growth.
+    // ---- tiling on the rings: the export is part of the step's commit (RingHalo), the import a kernel of its own
+    int32_t *dCutIndex = nullptr;     // [L] -1 / ghost lane i / nGhost + import lane j
+    long long *dHaloActiveOut = nullptr;
+    // the halo argument of the commit launched by the step that is being submitted (epoch = the step's number + 1: what
+    // cfx_halo_post / cfx_halo_wait, called after cfx_step has returned, compute from the advanced step counter)
+    RingHalo ringHalo() const {
+        RingHalo rh{};
+        if (!tiled || !ring) return rh;
+        rh.on = 1;
+        rh.cutIndex = dCutIndex;
+        rh.activeOut = dHaloActiveOut;
+        const unsigned long long epoch = ((unsigned long long) generation << 32) | (unsigned long long) (uint32_t) (step + 1);
+        if (!mail.empty()) {
+            rh.h = haloMail;
+            const int par = (int) (epoch & 1ULL);
+            for (size_t p = 0; p < mail.size(); ++p) {
+                rh.io.send[p] = mail[p].sendDev + CFX_HALO_MAILBOX_HEADER + (size_t) par * mail[p].sendBytes;
+                rh.io.signalFlag[p] = (unsigned long long *) mail[p].sendDev;
+            }
+            rh.io.nSignal = (int) mail.size();
+            rh.io.ticket = haloTicket;
+        } else {
+            rh.h = halo;
+            rh.io.send[0] = dHaloSend;  // the staged path: cfx_halo_export copies it out
+        }
+        rh.io.epoch = epoch;
+        return rh;
+    }
     bool ringGrowRequested = false;
     int ringEnsure() {
         double minLen = 1e300;
@@ -823,6 +853,7 @@ struct cfx_engine {
         HIP_TRY(hipMemsetAsync(jobCount, 0, (size_t) kJobShards * kJobShardStride * sizeof(int32_t), stream));
         if (finCount) HIP_TRY(hipMemsetAsync(finCount, 0, (size_t) kFinShards * 32 * sizeof(int32_t), stream));
         if (finTicket) HIP_TRY(hipMemsetAsync(finTicket, 0, 4 * sizeof(int32_t), stream));
+        if (dHaloActiveOut) HIP_TRY(hipMemsetAsync(dHaloActiveOut, 0, sizeof(long long), stream));
         HIP_TRY(hipMemsetAsync(oldToNew, 0xFF, slotCap * sizeof(int32_t), stream));
         if (vidCap) HIP_TRY(hipMemsetAsync(vt.nextWait, 0xFF, vidCap * sizeof(int32_t), stream));
         HIP_TRY(hipGetLastError());
@@ -1394,13 +1425,16 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // + 30000: the list form (kr_index + kl_action; the default where the cross phase runs k_cross2)
             // (the lane-walking forms cost per lane, the list per vehicle plus 8 to 12 us for the list: 30x30, 10.8 k lanes, 90 k
             //  vehicles: 41.0 us per step in block form, 49.0 with the list; 100x100, 120 k lanes, 72 k vehicles: 97.1 and 54.7)
-            const bool listForm = form == 3 || form == 6 || (form == 0 && !e->tiled && (useBig || activeEst > 240000 || e->L > 20000));
+            const bool listForm = form == 3 || form == 6 || (form == 0 && (useBig || activeEst > 240000 || e->L > 20000));
             if (listForm) {
                 // a TRUE bound of the vehicles this step can list (the list and the launch are sized by it): what the device
                 // reported after the last step it has completed plus one admission per queueing lane and step since
                 const int64_t done = (int64_t) (pr >> 32);
+                // (a tile: plus what the halo can have brought in since — its count is as of the commit, before that step's import)
                 if (done > 0 && done <= e->step)
-                    e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + e->nQueueLanes * (e->step + 1 - done));
+                    e->liveUpper = std::min(e->liveUpper, (int64_t) (pr & 0xFFFFFFFFu) + e->nQueueLanes * (e->step + 1 - done) +
+                                                              (e->tiled ? (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS * (e->step + 2 - done) +
+                                                                              2 * (int64_t) e->halo.nGhost : 0));
                 const size_t listBound = (size_t) std::min<int64_t>(e->liveUpper, (int64_t) e->ringSlots);
                 const size_t needList = (listBound + kListBlock - 1) / kListBlock * kListBlock + kListBlock;
                 if (needList > e->rListCap) {
@@ -1479,7 +1513,8 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         } else {
             int nStat = 1;
             const RingCommit rk = e->commitArgs(activeEst, false, &nStat);
-            e->launchNamed(PK_COMMIT, "kr_commit", kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt);
+            e->launchNamed(PK_COMMIT, "kr_commit", kr_commit, dim3(gridStride((size_t) std::max(e->D, std::max(e->I, e->nMaskWords))) + nStat), dim3(kBlock), c, rk, e->vt,
+                           e->ringHalo());
             RING_CHECK("kr_commit")
         }
 #undef RING_CHECK
@@ -2508,13 +2543,10 @@ int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
         return CFX_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(e->device));
-    if (e->ring) {  // tiles run on the dense layout (its halo kernels address the spare slots behind a lane's vehicles)
-        if (e->cfg.layout == CFX_LAYOUT_RING) {
-            e->err = "cfx_halo_config: a tiled engine cannot be forced onto the ring layout";
-            return CFX_ERR_STATE;
-        }
-        e->ring = false;
-    }
+    // Tiles run on either layout.  On the rings (round 6; `layout: ring`, and what `auto` resolves to unless the developer knob
+    // cfx_config::ring_lanes_per_wave / 10000 == 7 asks for the dense tiles of rounds 2-5) the halo export is part of the step's
+    // commit and the import one small kernel: 5 launches per tile-step instead of 7.
+    if (e->ring && e->cfg.layout == CFX_LAYOUT_AUTO && (e->cfg.ring_lanes_per_wave / 10000) % 10 == 7) e->ring = false;
     std::vector<uint8_t> ghost((size_t) e->L, 0);
     e->hLaneSpare.assign((size_t) e->L, 1);
     for (int i = 0; i < h->n_ghost; ++i) {
@@ -2530,6 +2562,17 @@ int32_t cfx_halo_config(cfx_engine *e, const cfx_halo_layout *h) {
     for (uint8_t v : e->hLaneSpare) e->spareTotal += v;
     int rc;
     if ((rc = e->uploadConst(e->net.laneGhost, ghost.data(), ghost.size()))) return rc;
+    if (e->ring) {
+        std::vector<int32_t> cut((size_t) e->L, -1);
+        for (int i = 0; i < h->n_ghost; ++i) cut[(size_t) h->ghost_lane[i]] = i;
+        for (int j = 0; j < h->n_import; ++j) {
+            if (cut[(size_t) h->import_lane[j]] >= 0) return e->fail("cfx_halo_config: a lane is both a ghost and an import lane");
+            cut[(size_t) h->import_lane[j]] = h->n_ghost + j;
+        }
+        if ((rc = e->upload(&e->dCutIndex, cut.data(), cut.size()))) return rc;
+        if ((rc = e->allocRaw(&e->dHaloActiveOut, 1))) return rc;
+        HIP_TRY(hipMemset(e->dHaloActiveOut, 0, sizeof(long long)));
+    }
     if ((rc = e->uploadConst(e->net.laneSpare, e->hLaneSpare.data(), e->hLaneSpare.size()))) return rc;
     HaloDev &d = e->halo;
     d.nGhost = h->n_ghost;
@@ -2570,8 +2613,9 @@ int32_t cfx_halo_export(cfx_engine *e, void *sendHost) {
     const int n = e->halo.nGhost + e->halo.nImport;
     HaloIO io{};
     io.send[0] = e->dHaloSend;
-    if (n) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
-                              e->cs.inCnt, io, e->sc);
+    // (ring layout: the step's commit has written the messages already — RingHalo)
+    if (n && !e->ring) hipLaunchKernelGGL(k_halo_export, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
+                                          e->cs.inCnt, io, e->sc);
     HIP_TRY(hipGetLastError());
     if (e->haloSendBytes && sendHost) HIP_TRY(hipMemcpyAsync(e->hHaloSend, e->dHaloSend, (size_t) e->haloSendBytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));  // (device-to-device transports run on another stream: the message is complete)
@@ -2591,7 +2635,10 @@ int32_t cfx_halo_import(cfx_engine *e, const void *recvHost) {
     const int n = e->halo.nGhost + e->halo.nImport;
     HaloIO io{};
     io.recv[0] = e->dHaloRecv;
-    if (n) hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
+    if (n && e->ring) {
+        hipLaunchKernelGGL(kr_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->rctx(), e->halo, io, e->vt, e->sc, e->dHaloActiveOut);
+        e->hCntValid = false;
+    } else if (n) hipLaunchKernelGGL(k_halo_import, dim3(gridFor(n)), dim3(kBlock), 0, e->stream, e->ctx(), e->cnt[e->cur].p, e->halo,
                               io, e->vt, e->sc);
     HIP_TRY(hipGetLastError());
     e->liveUpper += (int64_t) e->halo.nImport * CFX_HALO_MAX_MIGRANTS;
@@ -2772,7 +2819,7 @@ int32_t cfx_halo_post(cfx_engine *e) {
     io.ticket = e->haloTicket;
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;  // every peer implies at least one cut lane, so n > 0 with peers
-    if (n) {
+    if (n && !e->ring) {  // (ring layout: the step's commit wrote the messages and published the epoch — RingHalo)
         e->launchNamed(PK_HALO_EXPORT, "k_halo_export", k_halo_export, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail,
                   (const int32_t *) e->cs.inCnt, io, e->sc);
     }
@@ -2795,7 +2842,10 @@ int32_t cfx_halo_wait(cfx_engine *e) {
     io.nWait = nPeers;
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;
-    if (n) {  // includes the wait for the neighbours' epochs
+    if (n && e->ring) {
+        e->launchNamed(PK_HALO_IMPORT, "kr_halo_import", kr_halo_import, dim3(gridFor(n)), dim3(kBlock), e->rctx(), e->haloMail, io, e->vt, e->sc,
+                       e->dHaloActiveOut);
+    } else if (n) {  // includes the wait for the neighbours' epochs
         e->launchNamed(PK_HALO_IMPORT, "k_halo_import", k_halo_import, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail, io,
                   e->vt, e->sc);
     }

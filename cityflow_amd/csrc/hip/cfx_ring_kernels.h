@@ -21,6 +21,8 @@
 // instantiated on this file's context type.
 #pragma once
 
+#include <type_traits>
+
 #include "cfx_kernels.h"
 
 
@@ -316,6 +318,7 @@ struct RingCommit {
 };
 struct CommitOut {  // what a drivable's commit leaves, for the admission that follows it in the same thread
     int touched, head, n, tailWritten;
+    int entrants;  // vehicles that entered the drivable in this step: the last `entrants` of its list (tiling: a ghost lane's migrants)
     TailRec tail;
 };
 __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, const int d, CommitOut *out = nullptr);
@@ -923,6 +926,24 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
                                                 const SlotIn &in, Push push) {
     const int d = in.d, templIdx = in.templIdx, nd0 = in.nd0, flags = in.flags, L = c.n.L;
     const double speed = in.speed, dis = in.dis;
+    if constexpr (std::is_same<C, RingCtx>::value) {
+        // tiling: a vehicle on a ghost lane is the frozen proxy of a neighbour's vehicle (or a vehicle admitted on both sides):
+        // not stepped here.  Its state goes into the next generation as it is, and the lane's last one rewrites the tail record.
+        if (c.n.laneGhost && d < L && c.n.laneGhost[d]) {
+            o.keep(s, dis, speed);
+            if (in.idx == in.nNow - 1) {
+                TailRec r;
+                r.dis = dis;
+                r.speed = speed;
+                r.slot = s;
+                r.templ = templIdx;
+                r.prevDrv = c.s.prevDrv[s];
+                r.tag = c.step;
+                c.tailW[d] = r;
+            }
+            return;
+        }
+    }
     const cfx_vehicle_template &t = tv[templIdx];
     const double interval = c.interval;
     const double dlen = in.lm.x;
@@ -1712,7 +1733,10 @@ __device__ inline bool ringFinishStatistics(const RingCtx &c, const VidTable &vt
 __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, const int d, CommitOut *out) {
     const int4 sc = k.scratch[d];  // {leavers, largest list index among them, entrant list, entrants}
     const bool admitted = d < c.n.L && c.admitStep[d] == c.step;
-    if (out) out->touched = 0;
+    if (out) {
+        out->touched = 0;
+        out->entrants = 0;
+    }
     if (!admitted && sc.x == 0 && sc.z < 0) return;  // nothing happened on this drivable: nothing is written
     const int2 geo = c.ringGeo[d];
     int head = c.head[d];
@@ -1837,6 +1861,7 @@ __device__ inline void commitDrivable(const RingCtx &c, const RingCommit &k, con
         out->head = head;
         out->n = n;
         out->tailWritten = (tailRank >= 0 || sc.x > 0) ? 1 : 0;
+        out->entrants = m;
         out->tail = tail;
     }
 }
@@ -1858,7 +1883,212 @@ __device__ inline void commitClearMasks(const RingCtx &c, const RingCommit &k, i
     for (int i = gid; i < k.nMaskWords; i += stride) c.interMask[i] = 0ULL;
 }
 
-__global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, VidTable vt) {
+// ---------------------------------------------------------------------------------------------- tiling on the rings
+// One road network over several engines (include/cityflow_amd.h, "Tiling"; the dense layout's k_halo_export / k_halo_import
+// are in cfx_kernels.h).  On the rings the EXPORT is part of the commit: the thread that commits a cut lane knows the lane's
+// entrants of the step (a ghost lane's migrants: the last `entrants` of its list) and its new tail (an import lane's report),
+// so the messages are written where those are known and no export kernel runs; the last cut lane to finish publishes the
+// step's epoch in the peers' mailboxes.  The IMPORT stays a kernel (it has to wait for the neighbours' epochs): migrants are
+// appended to the import lanes' rings, a ghost lane that had no entrant of its own takes its owner's tail as its proxy.
+// A ghost lane holds at most its proxy (plus, for one step, a vehicle admitted here as on the owner's side): frozen, never
+// stepped (actionOneRounds), leader and Lane::canEnter source for the vehicles upstream through its tail record.
+struct RingHalo {
+    int on;                   // 0: not a tile (everything below is unused)
+    const int32_t *cutIndex;  // [L] -1: not cut; i < nGhost: ghost lane i; nGhost + j: import lane j
+    HaloDev h;
+    HaloIO io;
+    long long *activeOut;     // vehicles that left this tile in the step (folded into DevScalars::active by the import kernel:
+                              // the commit launch's own statistics block rewrites `active` while the lanes are committed)
+};
+
+__device__ inline int ringHaloGlobalPrev(const RingCtx &c, const HaloDev &h, int prevDrv) {
+    if (prevDrv >= c.n.L) return h.llGlobal[prevDrv - c.n.L];
+    if (prevDrv <= -2) return -prevDrv - 2;  // a migrant's laneLink of origin, kept as its global id
+    return -1;
+}
+
+// The cut lane `d` after its commit (head / n as the commit left them, co.entrants = the step's entrants).
+__device__ inline void ringHaloExport(const RingCtx &c, const RingCommit &k, const RingHalo &rh, int d, int ci, const CommitOut &co) {
+    const HaloDev &h = rh.h;
+    const int2 geo = c.ringGeo[d];
+    int head = co.touched ? co.head : c.head[d];
+    int n = co.touched ? co.n : c.cnt[d];
+    if (ci < h.nGhost) {
+        char *blk = rh.io.send[h.ghostPeer[ci]] + h.ghostSendOff[ci];
+        const int in = co.entrants;
+        int m = in;
+        if (m > CFX_HALO_MAX_MIGRANTS) {
+            m = CFX_HALO_MAX_MIGRANTS;
+            k.sc->overflow = 3;
+        }
+        ((int32_t *) blk)[0] = m;
+        ((int32_t *) blk)[1] = 0;
+        HaloMigrant *rec = (HaloMigrant *) (blk + 8);
+        for (int j = 0; j < m; ++j) {  // entrants are appended behind the stayers, already in Lane::vehicles order
+            const int s = ringSlot(geo, head, n - in + j);
+            const double2 kv = c.kinN[s];
+            HaloMigrant r;
+            r.vid = c.s.vid[s];
+            r.routePos = c.s.routePos[s];
+            r.prevLL = ringHaloGlobalPrev(c, h, c.s.prevDrv[s]);
+            r.pad = 0;
+            r.dis = kv.x;
+            r.speed = kv.y;
+            rec[j] = r;
+        }
+        h.ghostHadEntrants[ci] = in > 0;
+        if (in > 0) {
+            // keep only the new tail as this lane's proxy: the ring's head moves onto it (its slot, its records and the lane's
+            // tail record, which the commit has just written, stay where they are); everybody else is no longer here
+            for (int j = 0; j + 1 < n; ++j) c.slotOf[c.s.vid[ringSlot(geo, head, j)]] = -1;
+            head = (head + n - 1) & geo.y;
+            c.head[d] = head;
+            c.cnt[d] = 1;
+            atomicAdd((unsigned long long *) rh.activeOut, (unsigned long long) in);
+        }
+        return;
+    }
+    const int j = ci - h.nGhost;
+    if (j < h.nImport) {  // downstream side: report the lane's tail (before this step's migrants are appended)
+        HaloTail t;
+        t.vid = -1;
+        t.prevLL = -1;
+        t.dis = 0.0;
+        t.speed = 0.0;
+        if (n > 0) {
+            const int s = ringSlot(geo, head, n - 1);
+            const double2 kv = c.kinN[s];
+            t.vid = c.s.vid[s];
+            t.prevLL = ringHaloGlobalPrev(c, h, c.s.prevDrv[s]);
+            t.dis = kv.x;
+            t.speed = kv.y;
+        }
+        *(HaloTail *) (rh.io.send[h.importPeer[j]] + h.importSendOff[j]) = t;
+    }
+}
+
+// `c` is the NEXT step's context (cfx_step has returned): c.kin is the generation the step's commit wrote, c.tailR / c.blkR the
+// records of the step that has just finished (tag c.step - 1), which the import rewrites where it changes a lane's last vehicle.
+__device__ inline void ringHaloWriteTail(const RingCtx &c, int lane, int slot) {
+    TailRec r{};
+    r.slot = -1;
+    if (slot >= 0) {
+        const double2 kv = c.kin[slot];
+        r.dis = kv.x;
+        r.speed = kv.y;
+        r.slot = slot;
+        r.templ = c.meta[slot].x;
+        r.prevDrv = c.s.prevDrv[slot];
+    }
+    r.tag = c.step - 1;
+    const_cast<TailRec *>(c.tailR)[lane] = r;
+}
+
+__global__ void kr_halo_import(RingCtx c, HaloDev h, HaloIO io, VidTable vt, DevScalars *sc, long long *activeOut) {
+    if (io.nWait > 0) {  // mailbox path: every block waits until all peers have published this epoch
+        __shared__ int ok;
+        if (threadIdx.x == 0) {
+            ok = 1;
+            for (int p = 0; p < io.nWait && ok; ++p) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(io.waitFlag[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < io.epoch) {
+                    if (++spins > (1u << 22)) {  // a peer died or fell far behind: flag it instead of hanging the device
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+        }
+        __syncthreads();
+        if (!ok) {
+            sc->overflow = 4;
+            return;
+        }
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {  // the vehicles the step's commit sent away (its own statistics block was rewriting `active` then)
+        const long long out = *activeOut;
+        if (out) {
+            *activeOut = 0;
+            atomicAdd((unsigned long long *) &sc->active, (unsigned long long) (-out));
+        }
+    }
+    if (i < h.nImport) {
+        const int l = h.importLane[i];
+        const char *blk = io.recv[h.importPeer[i]] + h.importRecvOff[i];
+        const int m = ((const int32_t *) blk)[0];
+        if (m <= 0) return;
+        const HaloMigrant *rec = (const HaloMigrant *) (blk + 8);
+        const int2 geo = c.ringGeo[l];
+        const int head = c.head[l], n = c.cnt[l];
+        if (n + m > geo.y) {
+            sc->overflow = 8;
+            return;
+        }
+        const int road = c.n.laneRoad[l];
+        int last = -1;
+        for (int j = 0; j < m; ++j) {
+            const HaloMigrant r = rec[j];
+            const int s = ringSlot(geo, head, n + j);
+            const int route = vt.route[r.vid];
+            const int next = nextOf(c.n, c.t, l, route, r.routePos);
+            const int base = c.t.routeStart[route], len = c.t.routeStart[route + 1] - base;
+            const int onLast = (next < 0 && c.t.routeRoads[base + len - 1] == road) ? 2 : 0;  // Router::isLastRoad: flags bit 1
+            c.s.vid[s] = r.vid;
+            c.s.drv[s] = l;
+            c.s.prevDrv[s] = r.prevLL >= 0 ? -(r.prevLL + 2) : -1;
+            c.s.routePos[s] = r.routePos;
+            c.s.route[s] = route;
+            c.meta[s] = make_int4(vt.templ[r.vid], next, onLast, CFX_INT_MAX);
+            c.kin[s] = make_double2(r.dis, r.speed);
+            const_cast<int2 *>(c.blkR)[s] = make_int2(-1, -1);  // a vehicle that left its laneLink this step was not yielding
+            c.slotOf[r.vid] = s;
+            vt.state[r.vid] = 1;
+            last = s;
+        }
+        c.cnt[l] = n + m;
+        atomicAdd((unsigned long long *) &sc->active, (unsigned long long) m);
+        ringHaloWriteTail(c, l, last);
+        return;
+    }
+    const int j = i - h.nImport;
+    if (j < h.nGhost && !h.ghostHadEntrants[j]) {
+        // no entrant of our own this step: the owner's tail is the lane's tail
+        const int g = h.ghostLane[j];
+        const HaloTail t = *(const HaloTail *) (io.recv[h.ghostPeer[j]] + h.ghostRecvOff[j]);
+        const int2 geo = c.ringGeo[g];
+        const int head = c.head[g], n = c.cnt[g];
+        for (int q = 0; q < n; ++q) {  // whoever stood here (the old proxy, a vehicle admitted on both sides) is the owner's
+            const int v = c.s.vid[ringSlot(geo, head, q)];
+            if (v != t.vid) c.slotOf[v] = -1;
+        }
+        if (t.vid < 0) {
+            c.cnt[g] = 0;
+            ringHaloWriteTail(c, g, -1);
+            return;
+        }
+        int prev = -1;
+        if (t.prevLL >= 0) {
+            const int k = h.llLocalOfGlobal[t.prevLL];
+            prev = k >= 0 ? c.n.L + k : -(t.prevLL + 2);
+        }
+        const int s = ringSlot(geo, head, 0);
+        c.s.vid[s] = t.vid;
+        c.s.drv[s] = g;
+        c.s.prevDrv[s] = prev;
+        c.s.routePos[s] = 0;
+        c.s.route[s] = vt.route[t.vid];
+        c.meta[s] = make_int4(vt.templ[t.vid], -1, 0, CFX_INT_MAX);
+        c.kin[s] = make_double2(t.dis, t.speed);
+        const_cast<int2 *>(c.blkR)[s] = make_int2(-1, -1);
+        c.slotOf[t.vid] = s;
+        c.cnt[g] = 1;
+        ringHaloWriteTail(c, g, s);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, VidTable vt, RingHalo rh) {
     const int nBody = (int) gridDim.x - k.nStatBlocks;
     if ((int) blockIdx.x >= nBody) {
         commitStatBlock(c, k, vt, (int) blockIdx.x - nBody);
@@ -1872,6 +2102,22 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
     for (int d = gid; d < D; d += stride) {
         CommitOut co;
         commitDrivable(c, k, d, &co);
+        if (rh.on && d < c.n.L) {  // tiling: a cut lane's message, written by the thread that has just committed the lane
+            const int ci = rh.cutIndex[d];
+            if (ci >= 0) {
+                ringHaloExport(c, k, rh, d, ci, co);
+                if (rh.io.nSignal > 0) {  // mailbox path: the last cut lane to finish publishes the step's epoch (k_halo_export)
+                    const int nCut = rh.h.nGhost + rh.h.nImport;
+                    __threadfence_system();
+                    if (atomicAdd(rh.io.ticket, 1) == nCut - 1) {
+                        __threadfence_system();
+                        *rh.io.ticket = 0;
+                        for (int p = 0; p < rh.io.nSignal; ++p)
+                            __hip_atomic_store(rh.io.signalFlag[p], rh.io.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+        }
         if (d < c.n.L && k.hist.num) {
             const int2 geo = c.ringGeo[d];
             const int head = co.touched ? co.head : c.head[d], n = co.touched ? co.n : c.cnt[d];

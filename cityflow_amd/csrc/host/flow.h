@@ -158,6 +158,8 @@ public:
     void commitAhead();
     void rollbackAhead();
     bool aheadActive() const { return journal_.active; }
+    // vehicles created by the steps that were TAKEN (a journalled step ahead not counted)
+    size_t committedVehicleCount() const { return journal_.active ? journal_.nVehicles : vehicles.size(); }
 
 private:
     struct Pending {

@@ -721,7 +721,10 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         // several local tiles spread over the visible devices (the engine takes device % device count)
         tiles_.emplace_back(new TileEngine(net_, owner_, localRanks_[i], cfg_, &be_, baseDevice + (int) i));
     }
+    aheadEnabled_ = cfg_.spawnAhead && !cfg_.laneChange && !cfg_.saveReplay;
     spawner_.setFinishedQuery([this](int vid) {
+        // (never from the ahead thread: the devices are the caller's, and over several ranks the answer is a collective)
+        if (onAheadThread_.load(std::memory_order_relaxed)) throw AheadAbandoned();
         uint8_t st = 0;
         for (auto &t : tiles_) t->mergeStatus(vid, 1, &st);
         int s = st;
@@ -739,6 +742,94 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
     }
 }
 
+TiledEngineHost::~TiledEngineHost() {
+    if (aheadThread_.joinable()) {
+        {
+            std::lock_guard<std::mutex> guard(aheadMutex_);
+            aheadStop_ = true;
+        }
+        aheadCv_.notify_all();
+        aheadThread_.join();
+    }
+}
+
+void TiledEngineHost::aheadLoop() {
+    for (;;) {
+        size_t step;
+        {
+            std::unique_lock<std::mutex> lock(aheadMutex_);
+            aheadCv_.wait(lock, [&] { return aheadStop_ || aheadState_ == kAheadWorking; });
+            if (aheadStop_) return;
+            step = aheadStep_;
+        }
+        AheadState result = kAheadReady;
+        std::string error;
+        onAheadThread_.store(true, std::memory_order_relaxed);
+        try {
+            spawner_.beginAhead();
+            spawner_.step(step, aheadBuf_);
+        } catch (const AheadAbandoned &) {
+            result = kAheadAbandoned;
+        } catch (const std::exception &e) {
+            result = kAheadFailed;
+            error = e.what();
+        }
+        onAheadThread_.store(false, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> guard(aheadMutex_);
+            aheadError_ = error;
+            aheadState_ = result;
+        }
+        aheadCv_.notify_all();
+    }
+}
+
+void TiledEngineHost::kickAhead() {
+    if (!aheadEnabled_) return;
+    if (!aheadThread_.joinable()) aheadThread_ = std::thread([this] { aheadLoop(); });
+    {
+        std::lock_guard<std::mutex> guard(aheadMutex_);
+        aheadStep_ = step_ + 1;
+        aheadState_ = kAheadWorking;
+    }
+    aheadCv_.notify_all();
+}
+
+void TiledEngineHost::waitAhead() {
+    if (!aheadEnabled_) return;
+    std::unique_lock<std::mutex> lock(aheadMutex_);
+    aheadCv_.wait(lock, [&] { return aheadState_ != kAheadWorking; });
+}
+
+// Whatever was prepared for a step that is not going to be taken as it stands: the spawner goes back to where the last step
+// that WAS taken left it.
+void TiledEngineHost::dropAhead() {
+    if (!aheadEnabled_) return;
+    waitAhead();
+    if (aheadState_ != kAheadIdle) spawner_.rollbackAhead();
+    aheadState_ = kAheadIdle;
+}
+
+size_t TiledEngineHost::committedVehicleCount() {
+    waitAhead();
+    return spawner_.committedVehicleCount();
+}
+
+void TiledEngineHost::takeBatch() {
+    if (aheadEnabled_) {
+        waitAhead();
+        if (aheadState_ == kAheadReady && aheadStep_ == step_) {
+            spawner_.commitAhead();
+            spawnBuf_.swap(aheadBuf_);
+            aheadState_ = kAheadIdle;
+            return;
+        }
+        // abandoned (a priority collision), failed (raised below, where it belongs), or prepared for another step
+        dropAhead();
+    }
+    spawner_.step(step_, spawnBuf_);
+}
+
 void TiledEngineHost::flushPhases() {
     if (pendingInter_.empty()) return;
     for (auto &t : tiles_) t->setPhases(pendingInter_, pendingPhase_);
@@ -750,7 +841,7 @@ void TiledEngineHost::stepBegin() {
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     flushPhases();
-    spawner_.step(step_, spawnBuf_);
+    takeBatch();
     const auto t1 = clk::now();
     hostSpawnSec_ += std::chrono::duration<double>(t1 - t0).count();
     struct Acc {
@@ -758,10 +849,9 @@ void TiledEngineHost::stepBegin() {
         clk::time_point t;
         ~Acc() { a += std::chrono::duration<double>(clk::now() - t).count(); }
     } acc{hostSubmitSec_, t1};
-    for (auto &t : tiles_) {
-        t->uploadTables(spawner_);
-        t->step(spawnBuf_);
-    }
+    for (auto &t : tiles_) t->uploadTables(spawner_);  // (the spawner is at rest: the ahead thread starts below)
+    kickAhead();
+    for (auto &t : tiles_) t->step(spawnBuf_);
     if (mailboxes_) {  // device-initiated: export + publish now, the import kernel of stepEnd() does the waiting
         for (auto &t : tiles_) t->haloPost();
         return;
@@ -784,11 +874,10 @@ void TiledEngineHost::stepBegin() {
 void TiledEngineHost::stepBeginDevice() {
     if (mailboxes_) throw std::runtime_error("tiling: step_begin_device() is the staged exchange; mailboxes are enabled");
     flushPhases();
-    spawner_.step(step_, spawnBuf_);
-    for (auto &t : tiles_) {
-        t->uploadTables(spawner_);
-        t->step(spawnBuf_);
-    }
+    takeBatch();
+    for (auto &t : tiles_) t->uploadTables(spawner_);
+    kickAhead();
+    for (auto &t : tiles_) t->step(spawnBuf_);
     for (auto &t : tiles_) t->haloExportDevice();
 }
 
@@ -914,7 +1003,7 @@ cfx_scalars TiledEngineHost::scalars() {
         sum.tie_events += s.tie_events;
     }
     sum.step = (int64_t) step_;
-    sum.spawned_vehicle_count = (int64_t) spawner_.vehicles.size();
+    sum.spawned_vehicle_count = (int64_t) committedVehicleCount();
     return sum;
 }
 
@@ -951,6 +1040,7 @@ void TiledEngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) 
 }
 
 void TiledEngineHost::reset(bool resetRnd) {
+    dropAhead();
     pendingInter_.clear();
     pendingPhase_.clear();
     for (auto &t : tiles_) t->reset();
@@ -964,6 +1054,7 @@ void TiledEngineHost::sync() {
 }
 
 void TiledEngineHost::snapshotVehicles(VehicleSnapshot &out) {
+    dropAhead();
     VehicleSnapshot all;
     for (auto &t : tiles_) t->appendVehicles(all);
     // every drivable belongs to exactly one tile and a tile lists it front to back: a stable sort by global
@@ -992,6 +1083,7 @@ void TiledEngineHost::snapshotVehicles(VehicleSnapshot &out) {
 namespace cfa {
 
 int TiledEngineHost::statusOf(int vid) {
+    dropAhead();
     uint8_t st = 0;
     for (auto &t : tiles_) t->mergeStatus(vid, 1, &st);
     int s = st;
@@ -1001,6 +1093,7 @@ int TiledEngineHost::statusOf(int vid) {
 
 // getVehicles engine.cpp:619-626 — vehiclePool (priority) order
 std::vector<std::pair<int32_t, std::string>> TiledEngineHost::vehiclesKeyed(bool includeWaiting) {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::vector<std::pair<int32_t, int32_t>> byPriority;
@@ -1019,18 +1112,21 @@ std::vector<std::pair<int32_t, std::string>> TiledEngineHost::vehiclesKeyed(bool
 // Vehicles pushed (push_vehicle) since the last step: in the reference's vehiclePool from the moment of the call
 // (EngineHost::isPendingPushed, engine_host.cpp); every rank's spawner holds the same ones.
 std::vector<std::pair<int32_t, std::string>> TiledEngineHost::pendingPushedKeyed() const {
+    const_cast<TiledEngineHost *>(this)->dropAhead();
     std::vector<std::pair<int32_t, std::string>> pushed;
     spawner_.pendingPushed(pushed);
     return pushed;
 }
 
 bool TiledEngineHost::isPendingPushed(const std::string &id) const {
+    const_cast<TiledEngineHost *>(this)->dropAhead();
     for (const auto &p : pendingPushedKeyed())
         if (p.second == id) return true;
     return false;
 }
 
 std::vector<std::string> TiledEngineHost::getVehicles(bool includeWaiting) {
+    dropAhead();
     std::vector<std::pair<int32_t, std::string>> keyed = vehiclesKeyed(includeWaiting);
     if (includeWaiting) {
         for (auto &p : pendingPushedKeyed()) keyed.push_back(std::move(p));
@@ -1042,6 +1138,7 @@ std::vector<std::string> TiledEngineHost::getVehicles(bool includeWaiting) {
 }
 
 bool TiledEngineHost::runsHere(const std::string &vehicleId) {
+    dropAhead();
     const int vid = spawner_.vidOfId(vehicleId);
     if (vid < 0) return false;
     VehicleSnapshot s;
@@ -1052,6 +1149,7 @@ bool TiledEngineHost::runsHere(const std::string &vehicleId) {
 }
 
 std::vector<uint8_t> TiledEngineHost::localStatus() {
+    dropAhead();
     const int total = (int) spawner_.vehicles.size();
     std::vector<uint8_t> st((size_t) total, 0);
     if (total)
@@ -1060,6 +1158,7 @@ std::vector<uint8_t> TiledEngineHost::localStatus() {
 }
 
 std::map<std::string, std::vector<std::string>> TiledEngineHost::getLaneVehicles() {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     const int L = (int) net_->lanes.size();
@@ -1072,6 +1171,7 @@ std::map<std::string, std::vector<std::string>> TiledEngineHost::getLaneVehicles
 }
 
 std::map<std::string, double> TiledEngineHost::getVehicleSpeed() {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, double> ret;
@@ -1080,6 +1180,7 @@ std::map<std::string, double> TiledEngineHost::getVehicleSpeed() {
 }
 
 std::map<std::string, double> TiledEngineHost::getVehicleDistance() {
+    dropAhead();
     VehicleSnapshot s;
     snapshotVehicles(s);
     std::map<std::string, double> ret;
@@ -1088,6 +1189,7 @@ std::map<std::string, double> TiledEngineHost::getVehicleDistance() {
 }
 
 std::string TiledEngineHost::getLeader(const std::string &vehicleId) {
+    dropAhead();
     int vid = spawner_.vidOfId(vehicleId);
     if (vid < 0 && isPendingPushed(vehicleId)) return "";
     int st = vid >= 0 ? statusOf(vid) : 2;
@@ -1101,6 +1203,7 @@ std::string TiledEngineHost::getLeader(const std::string &vehicleId) {
 }
 
 std::map<std::string, std::string> TiledEngineHost::getVehicleInfo(const std::string &vehicleId) {
+    dropAhead();
     int vid = spawner_.vidOfId(vehicleId);
     if (vid < 0 && isPendingPushed(vehicleId)) return {{"running", "0"}};
     int st = vid >= 0 ? statusOf(vid) : 2;
@@ -1131,6 +1234,7 @@ std::map<std::string, std::string> TiledEngineHost::getVehicleInfo(const std::st
 
 // getAverageTravelTime engine.cpp:682-691 (finished part summed per tile)
 double TiledEngineHost::getAverageTravelTime() {
+    dropAhead();
     const cfx_scalars sc = scalars();
     return averageTravelTimeFrom(sc.cumulative_travel_time, sc.finished_vehicle_count, localStatus());
 }
@@ -1154,6 +1258,7 @@ double TiledEngineHost::averageTravelTimeFrom(double tt, int64_t n, const std::v
 }
 
 void TiledEngineHost::pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads) {
+    dropAhead();
     auto get = [&info](const char *k, double d) {
         auto it = info.find(k);
         return it == info.end() ? d : it->second;
@@ -1172,6 +1277,7 @@ void TiledEngineHost::pushVehicle(const std::map<std::string, double> &info, con
 }
 
 void TiledEngineHost::setVehicleSpeed(const std::string &id, double speed) {
+    dropAhead();
     int vid = spawner_.vidOfId(id);
     if (vid < 0) {  // pushed since the last step (EngineHost::setVehicleSpeed): every tile keeps the speed for the number to come
         const int future = spawner_.pendingPushedVid(id);
@@ -1224,6 +1330,7 @@ struct PartReader {
 }  // namespace
 
 std::string TiledEngineHost::snapshotPart() {
+    dropAhead();
     flushPhases();
     PartWriter w;
     const cfx_scalars sc = scalars();  // sums over the local tiles
@@ -1264,6 +1371,7 @@ std::string TiledEngineHost::snapshotPart() {
 }
 
 Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts) {
+    dropAhead();
     Archive a;
     a.host = spawner_.saveState();
     a.net = net_;
@@ -1342,11 +1450,13 @@ Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts
 }
 
 Archive TiledEngineHost::snapshot() {
+    dropAhead();
     if (!allLocal_) throw std::runtime_error("tiling: snapshot() needs every tile in this process; gather snapshot_part() of every process");
     return snapshotFromParts({snapshotPart()});
 }
 
 void TiledEngineHost::load(const Archive &a) {
+    dropAhead();
     if (!a.dev.rLcFlags.empty()) throw std::runtime_error("TiledEngine.load: the archive carries lane-change state");
     if (a.net.get() != net_.get() && a.net->lanes.size() != net_->lanes.size())
         throw std::runtime_error("TiledEngine.load: archive belongs to a different road network");
@@ -1360,10 +1470,14 @@ void TiledEngineHost::load(const Archive &a) {
     step_ = (size_t) a.dev.step;
 }
 
-void TiledEngineHost::loadFromFile(const std::string &path) { load(readArchiveFile(path, net_, spawner_, false)); }
+void TiledEngineHost::loadFromFile(const std::string &path) {
+    dropAhead();
+    load(readArchiveFile(path, net_, spawner_, false));
+}
 
 // Engine::setRoute engine.cpp:852-866 + Router::setRoute router.cpp:245-264 (EngineHost::setRoute)
 bool TiledEngineHost::setRoute(const std::string &vehicleId, const std::vector<std::string> &anchorIds) {
+    dropAhead();
     const int vid = spawner_.vidOfId(vehicleId);
     if (vid < 0) return false;
     const int state = statusOf(vid);
@@ -1437,6 +1551,7 @@ void TiledEngineHost::updateLog() { replayWrite({replayPart()}); }
 // what the replay line of the step that has just finished needs from this process: its vehicles' {number, drivable,
 // distance} and the phases of its intersections
 std::string TiledEngineHost::replayPart() {
+    dropAhead();
     PartWriter w;
     VehicleSnapshot s;
     for (auto &t : tiles_) t->appendVehicles(s);
@@ -1451,6 +1566,7 @@ std::string TiledEngineHost::replayPart() {
 }
 
 void TiledEngineHost::replayWrite(const std::vector<std::string> &parts) {
+    dropAhead();
     if (!replayWriter_) return;
     VehicleSnapshot s;
     std::vector<int32_t> phase(net_->inters.size(), 0);
@@ -1469,6 +1585,7 @@ void TiledEngineHost::replayWrite(const std::vector<std::string> &parts) {
 }
 
 void TiledEngineHost::setReplayLogFile(const std::string &logFile) {
+    dropAhead();
     if (!saveReplayInConfig_) {
         std::cerr << "saveReplay is not set to true in config file!" << std::endl;
         return;
@@ -1477,6 +1594,7 @@ void TiledEngineHost::setReplayLogFile(const std::string &logFile) {
 }
 
 void TiledEngineHost::setSaveReplay(bool open) {
+    dropAhead();
     if (!saveReplayInConfig_) {
         std::cerr << "saveReplay is not set to true in config file!" << std::endl;
         return;

@@ -24,10 +24,17 @@
 #include <vector>
 
 #include "archive.h"
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "engine_host.h"
 #include "replay.h"
 
 namespace cfa {
+
+struct AheadAbandoned {};  // thrown through the spawner by a priority-collision query on the ahead thread (TiledEngineHost)
 
 // rows x cols blocks over the (sorted distinct) coordinates of the non-virtual intersections; virtual
 // intersections follow their only neighbour.  Returns the owning tile per intersection.
@@ -204,7 +211,10 @@ public:
     double averageTravelTimeFrom(double cumulative, int64_t finished, const std::vector<uint8_t> &status) const;
     void pushVehicle(const std::map<std::string, double> &info, const std::vector<std::string> &roads);
     void setVehicleSpeed(const std::string &id, double speed);
-    void setRandomSeed(int seed) { spawner_.seed(seed); }
+    void setRandomSeed(int seed) {
+        dropAhead();
+        spawner_.seed(seed);
+    }
     void snapshotVehicles(VehicleSnapshot &out);  // local tiles, sorted by global drivable
     // ---- archive (reference src/engine/archive.cpp; EngineHost::snapshot / load / loadFromFile): every process loads the
     //      same archive and keeps its tiles' part.  A snapshot is assembled from one PART per process (opaque bytes: the
@@ -246,7 +256,10 @@ public:
     std::vector<int> owner() const { return owner_; }
     std::vector<std::string> laneIds() const;
     const HostRoadNet &net() const { return *net_; }
-    std::string vehicleId(int vid) const { return spawner_.vehicleId(vid); }
+    std::string vehicleId(int vid) {
+        waitAhead();  // (the vehicle table may be growing on the ahead thread)
+        return spawner_.vehicleId(vid);
+    }
     // max-reduction of a vehicle status over all processes; identity when every tile is local
     void setStatusReducer(std::function<int(int)> r) { reduceStatus_ = std::move(r); }
 
@@ -269,6 +282,32 @@ private:
     void updateLog();
     void flushPhases();
     int statusOf(int vid);  // merged over the local tiles (and the reducer)
+    // ---- the spawner of step t+1 runs on a host thread of its own while step t is submitted and runs (every rank runs the
+    //      whole spawner: at 30x30 it was two thirds of a rank's host time per step and the tiles were host-bound).  As in
+    //      EngineHost / VectorEngineHost: Flow::nextStep + planRoute (flow.cpp:6-22, engine.cpp:450-470) depend on nothing a
+    //      step computes; the step ahead is journalled (Spawner::beginAhead) and any call that could see or change the
+    //      spawner's state takes it back first (dropAhead).  A priority collision — the one thing that asks the devices, and
+    //      over several ranks a collective — is never answered on the ahead thread: it abandons the step, which nextStep()
+    //      then takes plainly, on every rank alike.  `"cfx": {"spawnAhead": false}` turns it off; off with saveReplay.
+    void takeBatch();   // this step's spawn records into spawnBuf_ (prepared ahead, or now)
+    void kickAhead();   // start the spawner of step_ + 1
+    void waitAhead();
+    void dropAhead();
+    void aheadLoop();
+    size_t committedVehicleCount();  // vehicles created by the steps that were TAKEN
+    bool aheadEnabled_ = false;
+    enum AheadState { kAheadIdle, kAheadWorking, kAheadReady, kAheadAbandoned, kAheadFailed };
+    AheadState aheadState_ = kAheadIdle;
+    size_t aheadStep_ = 0;
+    std::vector<cfx_spawn> aheadBuf_;
+    std::string aheadError_;
+    std::thread aheadThread_;
+    std::mutex aheadMutex_;
+    std::condition_variable aheadCv_;
+    bool aheadStop_ = false;
+    std::atomic<bool> onAheadThread_{false};
+public:
+    ~TiledEngineHost();
 };
 
 }  // namespace cfa

@@ -117,3 +117,77 @@ def test_spawn_records_do_not_depend_on_when_they_were_made(mod, scen, workdir, 
     assert plain == ahead
     assert plain == back
     assert sum(len(s) for s in plain) > 300
+
+
+def _tiled_pair(mod, scen, workdir, **extra):
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_ahead.json"), 200, seed=31, interval=3.0,
+                            base_flow=os.path.join(d, "flow.json"))
+    cfg = scen.materialize("grid_6x6", workdir, flow_file=flow, **extra)
+    out = []
+    for ahead in (True, False):
+        c = json.load(open(cfg))
+        c["cfx"] = {"spawnAhead": ahead}
+        path = cfg.replace(".json", "_tiled_ahead%d.json" % ahead)
+        json.dump(c, open(path, "w"))
+        out.append(mod.TiledEngine(path, 2, 2, [], TWIN_LIB))
+    return out[0], out[1], cfg
+
+
+def test_tiled_engine_takes_the_step_ahead_on_a_thread_of_its_own(mod, scen, workdir, tmp_path):
+    """TiledEngineHost: the spawner of step t+1 runs on a host thread while step t is submitted (every rank runs the whole
+    spawner).  On against off, 2x2 tiles on the twin: an RL-style loop that consumes the batches, then the calls that take a
+    prepared step back (id getters, push_vehicle, set_random_seed, snapshot / load, reset with and without a reseed)."""
+    a, b, cfg = _tiled_pair(mod, scen, workdir, rlTrafficLight=True)
+    with open(os.path.join(os.path.dirname(cfg), "roadnet.json")) as f:
+        roads = [r["id"] for r in json.load(f)["roads"]]
+    n = len(json.load(open(os.path.join(os.path.dirname(cfg), "roadnet.json")))["intersections"])
+    rng = np.random.default_rng(23)
+
+    def same(where):
+        assert np.array_equal(a.get_lane_vehicle_count_array(), b.get_lane_vehicle_count_array()), where
+        sa, sb = a._scalars(), b._scalars()
+        for k in ("active_vehicle_count", "finished_vehicle_count", "spawned_vehicle_count", "vehicle_steps", "cumulative_travel_time"):
+            assert sa[k] == sb[k], (where, k, sa[k], sb[k])
+
+    for s in range(150):  # the loop an agent runs: the prepared batch is consumed every step
+        ph = rng.integers(0, 8, size=n).astype(np.int32)
+        for e in (a, b):
+            e.set_tl_phases(ph)
+            e.next_step()
+        same("loop step %d" % s)
+    assert a.get_vehicle_count() > 300
+    archives = None
+    for round_ in range(40):
+        for _ in range(int(rng.integers(1, 5))):
+            a.next_step()
+            b.next_step()
+        op = int(rng.integers(0, 6))
+        if op == 0:
+            assert a.get_vehicle_speed() == b.get_vehicle_speed()
+            assert a.get_vehicles(True) == b.get_vehicles(True)
+        elif op == 1:
+            info = {"length": float(rng.uniform(3.0, 8.0)), "maxSpeed": float(rng.uniform(8.0, 16.0))}
+            start = roads[int(rng.integers(0, len(roads)))]
+            for e in (a, b):
+                e.push_vehicle(info, [start])
+        elif op == 2:
+            for e in (a, b):
+                e.set_random_seed(300 + round_)
+        elif op == 3:
+            pa, pb = str(tmp_path / ("ta%d.json" % round_)), str(tmp_path / ("tb%d.json" % round_))
+            a.snapshot().dump(pa)
+            b.snapshot().dump(pb)
+            assert open(pa, "rb").read() == open(pb, "rb").read(), "Archive files differ in round %d" % round_
+            archives = (pa, pb)
+        elif op == 4 and archives:
+            a.load_from_file(archives[0])
+            b.load_from_file(archives[1])
+        elif op == 5 and round_ % 10 == 9:
+            for e in (a, b):
+                e.reset(bool(round_ % 20 == 19))
+            archives = None
+        same("round %d (op %d)" % (round_, op))
+    assert a.get_vehicle_distance() == b.get_vehicle_distance()
+    assert a.get_average_travel_time() == b.get_average_travel_time()
