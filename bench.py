@@ -43,6 +43,17 @@ import sys
 import tempfile
 import time
 
+# numpy (the array getters return numpy arrays) is imported HERE, with its BLAS worker pool cut to one thread: importing it
+# starts one OpenBLAS worker per core (63 on the 256-core benchmark host), each of which spins for ~20 ms before it goes to
+# sleep — 1.3 CPU-seconds inside 50 ms, against the container's CFS quota of 16 CPUs per 100 ms period (cgroup cpu.max
+# "1600000 100000").  Rounds 4-6 imported it lazily, with the first array getter, i.e. right behind the timed region: the kernel
+# then throttled the whole container — the stepping thread included — for the rest of the period, and ONE next_step() call of
+# the first or second sustained window took 45-80 ms, whatever it happened to be doing (measured in round 6: inside cfx_step,
+# inside the host spawner, inside a status query; tools/throttle_watch.py, profiles/r06_stall_*).  Nothing in this file uses BLAS.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+import numpy  # noqa: E402,F401  (see above: before anything is timed)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -617,7 +628,12 @@ def timed_steps(job, eng, n, detail=None):
             hs = single(True)
             detail["device_library"] = {"worst_cfx_step_us": round(hs["worst_step_call_us"], 1), "at_step": hs["worst_step_call_at"],
                                         "cause_bits": hs["worst_step_call_cause"], "cfx_step_calls_over_1ms": hs["calls_over_1ms"],
-                                        "ring_regrows_total": hs["ring_regrows_total"], "table_grows_total": hs["table_grows_total"]}
+                                        "ring_regrows_total": hs["ring_regrows_total"], "table_grows_total": hs["table_grows_total"],
+                                        "status_queries": hs["status_queries"],
+                                        "slowest_next_step_us": round(hs["slowest_next_step"][0], 1), "slowest_next_step_at": hs["slowest_next_step"][1],
+                                        "slowest_next_step_parts_us": dict(zip(("phases", "take_records", "tables", "cfx_step", "replay", "spawner_ahead"),
+                                                                               [round(x, 1) for x in hs["slowest_next_step"][2]])),
+                                        "worst_status_query_us_total_settle_copy_wait": [round(x, 1) for x in hs["worst_status_query_us"]]}
     return job.reduce([time.perf_counter() - t0], "MAX")[0]
 
 

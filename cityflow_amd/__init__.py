@@ -5,6 +5,11 @@
 extension is built in-tree by `cityflow_amd.build` (see `__graft_entry__.build()`); importing this
 package never falls back to a Python/CPU implementation.
 """
+# (the array API returns numpy arrays: imported with the package, not by the first getter in the middle of a caller's loop —
+# importing numpy starts one BLAS worker per core, each spinning for ~20 ms, which inside a CPU-quota'd container throttles
+# every thread of the process for the rest of the scheduler period: bench.py's docstring, DESIGN.md section 6)
+import numpy as _numpy  # noqa: F401
+
 try:
     from . import _cityflow
 except ImportError as exc:  # pragma: no cover - exercised only on unbuilt trees

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 
@@ -1203,6 +1204,23 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         DevScalars s;
         if ((rc = e->readScalars(s))) return rc == CFX_ERR_DEVICE ? CFX_ERR_CAPACITY : rc;
     }
+    // ---- the host's lead over the device is bounded.  A free-running caller submits a 30x30 step in ~20 us and the device takes
+    //      ~40: unbounded, the stream's backlog grows by half a step per step, and the next call that has to wait for the device
+    //      (a getter, the spawner's priority-collision query) pays for all of it — 4.5 ms behind a 200-step window.  The step's
+    //      commit publishes the number of completed steps in pinned host memory: wait (yielding) while more than kMaxLead steps
+    //      are in flight.  The device is never idle for it — kMaxLead steps of work are queued behind the one it is executing —
+    //      and a caller that synchronises every step never waits here.  (Built while looking for the 45-80 ms "stall" of the
+    //      sustained windows of rounds 4-6, which it did NOT cure: that was the container's CPU quota — bench.py's header.)
+    if (e->mirrorValid && !e->tiled) {
+        constexpr int64_t kMaxLead = 48;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            const int64_t done = (int64_t) (__atomic_load_n(&e->hMirror->progress, __ATOMIC_RELAXED) >> 32);
+            if (done <= 0 || done > e->step || e->step - done <= kMaxLead) break;
+            if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;  // (never hang on it)
+            std::this_thread::yield();
+        }
+    }
     if (e->ring) {
         if (e->mirrorValid && __atomic_load_n(&e->hMirror->sc.ringNearFull, __ATOMIC_RELAXED) != 0) e->ringGrowRequested = true;
         if ((rc = e->ringEnsure())) return rc;
@@ -2061,7 +2079,32 @@ int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first, int32_t n, uint8_t 
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
+    const auto q0 = std::chrono::steady_clock::now();
+    auto qus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
     if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    const auto q1 = std::chrono::steady_clock::now();
+    // A few bytes (the spawner's priority-collision query asks for ONE vehicle, in the middle of a run): through the engine's
+    // pinned scratch — a device-to-host copy into the caller's pageable memory makes the runtime stage or pin it per call.
+    // The call is timed (cfx_get_host_stats): behind a free-running host its cost is the wait for the stream's backlog.
+    const size_t scratchBytes = std::max<size_t>((size_t) e->L, 2) * sizeof(int32_t);
+    if (n && (size_t) n <= scratchBytes) {
+        HIP_TRY(hipMemcpyAsync(e->hLaneOut, e->vt.state + first, (size_t) n, hipMemcpyDeviceToHost, e->stream));
+        const auto q2 = std::chrono::steady_clock::now();
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const auto q3 = std::chrono::steady_clock::now();
+        memcpy(out, e->hLaneOut, (size_t) n);
+        cfx_host_stats &hs = e->hostStats;
+        hs.status_queries += 1;
+        if (qus(q0, q3) > hs.worst_status_query_us) {
+            hs.worst_status_query_us = qus(q0, q3);
+            hs.worst_status_query_settle_us = qus(q0, q1);
+            hs.worst_status_query_copy_us = qus(q1, q2);
+            hs.worst_status_query_wait_us = qus(q2, q3);
+        }
+        return CFX_OK;
+    }
     if (n) HIP_TRY(hipMemcpyAsync(out, e->vt.state + first, (size_t) n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return CFX_OK;

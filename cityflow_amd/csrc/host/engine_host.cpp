@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <iostream>
 #include <stdexcept>
@@ -309,8 +310,13 @@ void EngineHost::dropAhead() {
 }
 
 void EngineHost::nextStep() {
+    // (where a call's host time went, for the slowest call since the last read: hostStats / Engine._host_stats)
+    using clk = std::chrono::steady_clock;
+    clk::time_point lap[7];
+    lap[0] = clk::now();
     flushPhases();
     settleLaneChange();  // the generator must be past the last step's shadow draws before this step's spawns
+    lap[1] = clk::now();
     if (aheadValid_) {  // this step's records were made while the device ran the last step
         aheadValid_ = false;
         spawner_.commitAhead();
@@ -318,14 +324,32 @@ void EngineHost::nextStep() {
     } else {
         spawner_.step(step_, spawnBuf_);
     }
+    lap[2] = clk::now();
     uploadNewTablesIfAny();
     if (laneChange_) {  // the priorities this step's shadows would draw, after the step's own spawn draws
         spawner_.peekShadowPriorities(shadowPoolSize_, shadowPool_);
         check(be_.cfx_lane_change_supply(dev_, (int32_t) shadowPool_.size(), shadowPool_.data()), "cfx_lane_change_supply");
     }
+    lap[3] = clk::now();
     check(be_.cfx_step(dev_, spawnBuf_.data(), (int32_t) spawnBuf_.size()), "cfx_step");
+    lap[4] = clk::now();
     lcPollPending_ = laneChange_;
     if (saveReplay_) updateLog();
+    lap[5] = clk::now();
+    struct Note {
+        EngineHost *e;
+        clk::time_point *lap;
+        size_t at;
+        ~Note() {
+            lap[6] = clk::now();
+            const double total = std::chrono::duration<double, std::micro>(lap[6] - lap[0]).count();
+            if (total > e->slowest_.total) {
+                e->slowest_.total = total;
+                e->slowest_.step = (int64_t) at;
+                for (int i = 0; i < 6; ++i) e->slowest_.part[i] = std::chrono::duration<double, std::micro>(lap[i + 1] - lap[i]).count();
+            }
+        }
+    } note{this, lap, step_};
     step_ += 1;
     if (spawnAhead_) {
         // The next step's spawner, now: its records depend on nothing the device is computing (a priority that collides with

@@ -159,6 +159,17 @@ public:
     std::map<std::string, std::pair<double, int64_t>> profileRead();  // kernel -> (total ms, launches)
     std::map<std::string, std::string> profileSymbols();  // timing slot -> symbol of the kernel launched last in it
     cfx_host_stats hostStats(bool reset);
+    // the slowest nextStep() since the last clearing read: total us, the step, and its parts {phases + lane-change settle, this
+    // step's spawn records (taken or made), table upload + lane-change supply, cfx_step, replay log, the spawner of the step ahead}
+    struct SlowestStep {
+        double total = 0, part[6] = {};
+        int64_t step = -1;
+    };
+    SlowestStep slowestStep(bool reset) {
+        SlowestStep s = slowest_;
+        if (reset) slowest_ = SlowestStep{};
+        return s;
+    }
 
     std::shared_ptr<void> bindingCache;  // opaque per-engine cache owned by the language binding (lane id key objects)
 
@@ -206,6 +217,7 @@ private:
     // The NEXT step's spawn records, computed right after this step was handed to the device (Spawner::beginAhead): consumed
     // by the next nextStep(), taken back (dropAhead) by every other call that could see or change the spawner's state.
     bool spawnAhead_ = true, aheadValid_ = false;
+    SlowestStep slowest_;
     std::vector<cfx_spawn> aheadBuf_;
     void dropAhead();
     std::vector<int32_t> shadowPool_, shadowParents_;  // lane change: priorities offered to / parents reported by a step

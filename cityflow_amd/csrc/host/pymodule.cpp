@@ -472,7 +472,10 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("_profile_symbols", &EngineHost::profileSymbols, "timing slot -> symbol of the kernel launched last in it")
         .def("_host_stats", [](EngineHost &e, bool reset) {
             const cfx_host_stats s = e.hostStats(reset);
+            const EngineHost::SlowestStep slow = e.slowestStep(reset);
             py::dict d;
+            d["slowest_next_step"] = py::make_tuple(slow.total, slow.step, py::make_tuple(slow.part[0], slow.part[1], slow.part[2],
+                                                                                          slow.part[3], slow.part[4], slow.part[5]));
             d["step_calls"] = s.step_calls;
             d["step_call_us_mean"] = s.step_calls ? s.step_call_us_sum / (double) s.step_calls : 0.0;
             d["worst_step_call_us"] = s.worst_step_call_us;
@@ -481,6 +484,9 @@ PYBIND11_MODULE(_cityflow, m) {
             d["calls_over_1ms"] = s.calls_over_1ms;
             d["ring_regrows_total"] = s.ring_regrows_total;
             d["table_grows_total"] = s.table_grows_total;
+            d["status_queries"] = s.status_queries;
+            d["worst_status_query_us"] = py::make_tuple(s.worst_status_query_us, s.worst_status_query_settle_us,
+                                                         s.worst_status_query_copy_us, s.worst_status_query_wait_us);
             return d;
         }, "reset"_a = false, "host time inside cfx_step (cfx_get_host_stats)")
         .def("_vehicle_id", [](EngineHost &e, int vid) { return e.vehicleId(vid); }, "vid"_a)

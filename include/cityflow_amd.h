@@ -485,6 +485,11 @@ typedef struct cfx_host_stats {
     int32_t calls_over_1ms;       /* calls that took more than a millisecond */
     int64_t ring_regrows_total;   /* since the engine was created */
     int64_t table_grows_total;    /* vid-table + slot-array + list growths since the engine was created */
+    /* the slowest cfx_get_vehicle_status call since the last clearing read (the spawner's priority-collision query: the one
+     * call a free-running host makes that waits for the device), split into: launching a pending commit, enqueueing the copy,
+     * waiting for the stream */
+    double worst_status_query_us, worst_status_query_settle_us, worst_status_query_copy_us, worst_status_query_wait_us;
+    int64_t status_queries;
 } cfx_host_stats;
 int32_t cfx_get_host_stats(cfx_engine *e, cfx_host_stats *out, int32_t reset);
 /* Measurement aid: keeps the device busy with plain arithmetic for about `microseconds` on the engine's stream (returns at
