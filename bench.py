@@ -271,6 +271,26 @@ def scale_compare(got, want, ties_here):
     return out
 
 
+def usable_cpus():
+    """CPUs this process may actually use at once: the host's cores, the affinity mask, and the container's CFS quota (cgroup
+    v2 cpu.max / v1 cpu.cfs_quota_us) — a leg that starts one thread per host core inside a 16-CPU quota is throttled by the
+    kernel for most of its run, and measures the throttling."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 # ------------------------------------------------------------------------------------------------ CPU legs
 def cpu_baseline(cfg, budget_s, threads, state_dump, warmup=0, checkpoints=(), detail_dir=None, gpu_hashes=None):
     """The unmodified reference engine (oracle/_ref) on the host cores, started from EXACTLY the state the GPU engine
@@ -323,7 +343,8 @@ def cpu_baseline(cfg, budget_s, threads, state_dump, warmup=0, checkpoints=(), d
         "steps_per_sec": steps / dt,
         "sample": "%d steps from the state the GPU run's timed region starts from (the same Archive JSON, load %.1f s "
                   "untimed, then the same %d warm-up steps; %d -> %d running vehicles), %.1f s of wall time, %d thread(s) "
-                  "of %d host cores" % (steps, t_load, warmup, start_running, running, dt, threads, os.cpu_count() or 1),
+                  "of %d host cores (%d usable: affinity / container CPU quota)" % (
+                      steps, t_load, warmup, start_running, running, dt, threads, os.cpu_count() or 1, usable_cpus()),
     }, records
 
 
@@ -764,7 +785,7 @@ def rl_loop_leg(job, args, cfg, workdir, state_dump):
             sys.path.insert(0, ref_dir)
         try:
             import cityflow_ref
-            threads = min(8, os.cpu_count() or 1)
+            threads = min(8, usable_cpus())
             ref = cityflow_ref.Engine(rl_cfg, threads)
             ref.load_from_file(state_dump)
             t0, n = time.perf_counter(), 0
@@ -1069,7 +1090,7 @@ def main():
     # ---- in-run parity and the CPU baseline (rank 0; a tiled run is compared with ONE engine on rank 0's device)
     cpu, legs, parity_in_run, parity_excused, parity_detail = None, None, None, None, None
     if want_checks and rank == 0:
-        threads = args.cpu_threads or min(8, os.cpu_count() or 1)
+        threads = args.cpu_threads or min(8, usable_cpus())
         cps = checkpoints_of(args.steps)
         detail_dir = tempfile.mkdtemp(prefix="parity_", dir=workdir)
         if tiled:
@@ -1092,7 +1113,7 @@ def main():
         gpu_hashes = {str(s): r["state_hash"] for s, r in gpu_recs.items()}
         cpu, par8 = cpu_baseline(cfg, args.cpu_seconds, threads, state_dump, args.warmup, all_cps, detail_dir, gpu_hashes)
         legs, ref_recs, parity_threads = [], par8, threads
-        for t in sorted({1, os.cpu_count() or 1} - {threads}):
+        for t in sorted({1, usable_cpus()} - {threads}):  # (one thread; every CPU the container may use at once)
             if args.cpu_leg_seconds > 0 and cpu["kind"] == "reference":
                 if t == 1:  # the reproducible reference (see cpu_leg_subprocess): timing leg and parity check in one
                     leg, recs = cpu_leg_subprocess(cfg, args.cpu_leg_seconds, 1, state_dump, args.warmup, all_cps, detail_dir, gpu_hashes)

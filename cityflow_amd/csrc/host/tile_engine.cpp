@@ -757,10 +757,16 @@ void TiledEngineHost::aheadLoop() {
     for (;;) {
         size_t step;
         {
+            // While the engine is being stepped the next request arrives within tens of microseconds: poll for a moment
+            // before going to sleep on the condition variable (a wake-up through the kernel costs 10-30 us, as long as the job)
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+            while (aheadKicks_.load(std::memory_order_acquire) == aheadSeen_ && std::chrono::steady_clock::now() < until)
+                std::this_thread::yield();
             std::unique_lock<std::mutex> lock(aheadMutex_);
             aheadCv_.wait(lock, [&] { return aheadStop_ || aheadState_ == kAheadWorking; });
             if (aheadStop_) return;
             step = aheadStep_;
+            aheadSeen_ = aheadKicks_.load(std::memory_order_acquire);
         }
         AheadState result = kAheadReady;
         std::string error;
@@ -779,6 +785,7 @@ void TiledEngineHost::aheadLoop() {
             std::lock_guard<std::mutex> guard(aheadMutex_);
             aheadError_ = error;
             aheadState_ = result;
+            aheadBusy_.store(false, std::memory_order_release);
         }
         aheadCv_.notify_all();
     }
@@ -791,12 +798,18 @@ void TiledEngineHost::kickAhead() {
         std::lock_guard<std::mutex> guard(aheadMutex_);
         aheadStep_ = step_ + 1;
         aheadState_ = kAheadWorking;
+        aheadBusy_.store(true, std::memory_order_release);
+        aheadKicks_.fetch_add(1, std::memory_order_release);
     }
     aheadCv_.notify_all();
 }
 
 void TiledEngineHost::waitAhead() {
     if (!aheadEnabled_) return;
+    {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+        while (aheadBusy_.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+    }
     std::unique_lock<std::mutex> lock(aheadMutex_);
     aheadCv_.wait(lock, [&] { return aheadState_ != kAheadWorking; });
 }

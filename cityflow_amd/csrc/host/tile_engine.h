@@ -305,6 +305,9 @@ private:
     std::mutex aheadMutex_;
     std::condition_variable aheadCv_;
     bool aheadStop_ = false;
+    std::atomic<uint64_t> aheadKicks_{0};  // requests so far (the ahead thread polls it before it sleeps)
+    uint64_t aheadSeen_ = 0;
+    std::atomic<bool> aheadBusy_{false};   // a request is being worked on (the caller polls it before it sleeps)
     std::atomic<bool> onAheadThread_{false};
 public:
     ~TiledEngineHost();

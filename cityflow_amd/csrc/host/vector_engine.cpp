@@ -394,10 +394,16 @@ void VectorEngineHost::aheadLoop() {
     for (;;) {
         size_t step;
         {
+            // While the engine is being stepped the next request arrives within tens of microseconds: poll for a moment
+            // before going to sleep on the condition variable (a wake-up through the kernel costs 10-30 us, as long as the job)
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+            while (aheadKicks_.load(std::memory_order_acquire) == aheadSeen_ && std::chrono::steady_clock::now() < until)
+                std::this_thread::yield();
             std::unique_lock<std::mutex> lock(aheadMutex_);
             aheadCv_.wait(lock, [&] { return aheadStop_ || aheadState_ == kAheadWorking; });
             if (aheadStop_) return;
             step = aheadStep_;
+            aheadSeen_ = aheadKicks_.load(std::memory_order_acquire);
         }
         std::string error;
         const auto t0 = std::chrono::steady_clock::now();
@@ -411,6 +417,7 @@ void VectorEngineHost::aheadLoop() {
             std::lock_guard<std::mutex> guard(aheadMutex_);
             aheadError_ = error;
             aheadState_ = error.empty() ? kAheadReady : kAheadFailed;
+            aheadBusy_.store(false, std::memory_order_release);
         }
         aheadCv_.notify_all();
     }
@@ -422,11 +429,17 @@ void VectorEngineHost::kickAhead(size_t step) {
         std::lock_guard<std::mutex> guard(aheadMutex_);
         aheadStep_ = step;
         aheadState_ = kAheadWorking;
+        aheadBusy_.store(true, std::memory_order_release);
+        aheadKicks_.fetch_add(1, std::memory_order_release);
     }
     aheadCv_.notify_all();
 }
 
 void VectorEngineHost::waitAhead() {
+    {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+        while (aheadBusy_.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+    }
     std::unique_lock<std::mutex> lock(aheadMutex_);
     aheadCv_.wait(lock, [&] { return aheadState_ != kAheadWorking; });
 }

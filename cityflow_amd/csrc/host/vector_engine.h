@@ -114,6 +114,9 @@ private:
     std::mutex aheadMutex_;
     std::condition_variable aheadCv_;
     bool aheadStop_ = false;
+    std::atomic<uint64_t> aheadKicks_{0};  // requests so far (the ahead thread polls it before it sleeps)
+    uint64_t aheadSeen_ = 0;
+    std::atomic<bool> aheadBusy_{false};   // a request is being worked on (the caller polls it before it sleeps)
     std::atomic<uint64_t> preparing_{0};  // the step whose batch is being prepared
     std::atomic<uint64_t> submitted_{0};  // steps handed to the device so far (a priority-collision query of step s waits for s)
     std::vector<std::thread> workers_;
