@@ -345,7 +345,8 @@ __device__ __forceinline__ void lcInitVid(const LcDev &lc, int v) {
 // A step's few spawn records as kernel arguments of the admission kernel (kr_admit, cfx_ring_kernels.h, has the story)
 constexpr int kAdmitRecs = 128;
 // ... and kd_admit of a large network, whose stock flows alone produce a few hundred records per step (100x100: 400), takes
-// up to kAdmitRecsBig of them the same way (20 KB of arguments; the runtime takes 32 KB and more, tools/kernarg_probe.hip)
+// up to kAdmitRecsBig of them the same way (24.6 KB of arguments with the firstNext column; the runtime takes 128 KB, tools/kernarg_probe.hip — but every block stages the
+// lanes of ALL records, so more records per launch cost the kernel more than a k_spawn_link launch: round 6, profiles/r06_exp_*)
 constexpr int kAdmitRecsBig = 1024;
 template <int N> struct SpawnBatchT {
     int n, firstNewVid;

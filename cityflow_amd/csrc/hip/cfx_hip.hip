@@ -699,7 +699,18 @@ struct cfx_engine {
                           hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
                           lightsDone ? 1 : 0, publishTo(), finCount, tiled ? LaneHistDev{} : hist};
     }
+    // tiling on the rings, mailbox transports: cfx_halo_wait leaves the import to the next step's admission launch (one launch
+    // less per tile-step); anything else that looks at the state first sends it out as a kernel of its own
+    bool haloImportPending = false;
+    RingHaloIn pendingImport{};
     int settle() {
+        if (haloImportPending) {
+            haloImportPending = false;
+            const int n = pendingImport.h.nGhost + pendingImport.h.nImport;
+            launchNamed(PK_HALO_IMPORT, "kr_halo_import", kr_halo_import, dim3(gridFor(n)), dim3(kBlock), rctx(), pendingImport.h, pendingImport.io, vt,
+                        sc, dHaloActiveOut);
+            HIP_TRY(hipGetLastError());
+        }
         if (!commitPending) return CFX_OK;
         commitPending = false;
         int nStat = 1;
@@ -776,6 +787,7 @@ struct cfx_engine {
 
     int resetState() {
         commitPending = false;  // (whatever a deferred commit would have written is overwritten below)
+        haloImportPending = false;
         HIP_TRY(hipStreamSynchronize(stream));
         if (!retired.empty() && freeRetired()) return CFX_ERR_DEVICE;
         mirrorValid = false;
@@ -1384,21 +1396,24 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         // This step's commit rides with the next step's admission (one launch less per step) where the step runs kr_cross,
         // which then advances the lights; the previous step's, if it is still pending, goes with this step's admission.
         const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing;  // (Lane::history rides with the commit)  // (a caller that reads the lane counts after every step wants the commit now)
+        // tiling: the previous step's halo import, if cfx_halo_wait left it to this launch
+        const RingHaloIn hin = e->haloImportPending ? e->pendingImport : RingHaloIn{};
+        e->haloImportPending = false;
         if (e->commitPending) {
             e->commitPending = false;
             int nStatPrev = 1;
             const RingCommit rkPrev = e->commitArgs(activeEst, true, &nStatPrev);
             if (batch.n > kAdmitRecs)
                 e->launchNamed(PK_ADMIT, "kr_admit<true, kAdmitRecsBig>", kr_admit<true, kAdmitRecsBig>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
-                          e->admitStep, e->waitHead, e->vt, e->sc, batch, rkPrev);
+                          e->admitStep, e->waitHead, e->vt, e->sc, batch, rkPrev, RingHaloIn{});
             else
                 e->launchNamed(PK_ADMIT, "kr_admit<true>", kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
-                          e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), rkPrev);
+                          e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), rkPrev, RingHaloIn{});
         } else {
             if (batch.n > kAdmitRecs)
-                e->launchNamed(PK_ADMIT, "kr_admit<false, kAdmitRecsBig>", kr_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{});
+                e->launchNamed(PK_ADMIT, "kr_admit<false, kAdmitRecsBig>", kr_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{}, hin);
             else
-                e->launchNamed(PK_ADMIT, "kr_admit<false>", kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{});
+                e->launchNamed(PK_ADMIT, "kr_admit<false>", kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{}, hin);
         }
         RING_CHECK("kr_admit")
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then
@@ -1475,7 +1490,9 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 //  above half a million drivables, for the tests)
                 int32_t *const idxTicket = (nIdxTiles > kScanResidentTiles || form == 6) ? e->rListCount + 1 : nullptr;
                 e->launchNamed(PK_SCAN, "kr_index", kr_index, dim3(nIdxTiles), dim3(kIndexBlock), c, e->rIdxGranules, idxTicket, (unsigned) (e->step + 1),
-                          e->rList, (int) e->rListCap, e->rListCount, e->sc);
+                          // (the capacity the kernel checks is what THIS step's action launch covers, not the allocation — which has
+                          //  25 % of headroom and never shrinks: entries beyond the launch would never take their step, unflagged)
+                          e->rList, (int) std::min<size_t>(e->rListCap, (size_t) nVehBlocks * kListBlock), e->rListCount, e->sc);
                 RING_CHECK("kr_index")
                 e->launchNamed(PK_ACTION, "kl_action", kl_action, dim3(nVehBlocks + nLL), dim3(kListBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
                           (const int32_t *) e->rListCount, nVehBlocks, idxTicket);
@@ -1509,7 +1526,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         }
         if (useBig)
             e->launchNamed(PK_CROSS, "k_cross2<false, RingCtx, RingOut>", k_cross2<false, RingCtx, RingOut>,
-                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) CFX_RING_CROSS2_WAVES * e->nCU)),  // (5 blocks per CU: 95 registers)
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) CFX_RING_CROSS2_WAVES * e->nCU)),  // (one block per CU and wavefront slot the register count leaves: 4 at 115 registers)
                       dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
         {
@@ -2886,8 +2903,9 @@ int32_t cfx_halo_wait(cfx_engine *e) {
     io.epoch = epoch;
     const int n = e->halo.nGhost + e->halo.nImport;
     if (n && e->ring) {
-        e->launchNamed(PK_HALO_IMPORT, "kr_halo_import", kr_halo_import, dim3(gridFor(n)), dim3(kBlock), e->rctx(), e->haloMail, io, e->vt, e->sc,
-                       e->dHaloActiveOut);
+        // (left to the next step's admission launch — kr_admit, RingHaloIn; a getter in between sends it out itself: settle())
+        e->pendingImport = RingHaloIn{1, e->dCutIndex, e->haloMail, io, e->dHaloActiveOut};
+        e->haloImportPending = true;
     } else if (n) {  // includes the wait for the neighbours' epochs
         e->launchNamed(PK_HALO_IMPORT, "k_halo_import", k_halo_import, dim3(gridFor(n)), dim3(kBlock), e->ctx(), e->cnt[e->cur].p, e->haloMail, io,
                   e->vt, e->sc);

@@ -32,7 +32,8 @@ struct RingCtx {
     // (k_cross2 on the ring layout needs 95 registers; asking for 7 wavefronts per SIMD spills and was measured slower,
     // 66 -> 72 us at 1 M vehicles: 5 = as the compiler has it)
 #ifndef CFX_RING_CROSS2_WAVES
-#define CFX_RING_CROSS2_WAVES 5  // (6: 80 registers, 21 spilled, 47.0 us at 1 M vehicles; 7: 72 / 44, 52.5 us; 5: 43.7 us)
+#define CFX_RING_CROSS2_WAVES 4  // (6: 80 registers, 21 spilled, 47.0 us at 1 M vehicles; 7: 72 / 44, 52.5 us; 5: 96 / 9, 43.7 us; round 6: 4 = 115
+                                 //  registers, nothing spilled, no scratch segment: 37.9 against 38.2 us — kept for the missing spills)
 #endif
     static constexpr int kCross2Waves = CFX_RING_CROSS2_WAVES;
     DevNet n;
@@ -326,13 +327,235 @@ __device__ inline void commitStatBlock(const RingCtx &c, const RingCommit &k, co
 __device__ inline int commitStatBlocks(const RingCommit &k);
 __device__ inline void commitClearMasks(const RingCtx &c, const RingCommit &k, int gid, int stride);
 
+// ---------------------------------------------------------------------------------------------- tiling on the rings
+// One road network over several engines (include/cityflow_amd.h, "Tiling"; the dense layout's k_halo_export / k_halo_import
+// are in cfx_kernels.h).  On the rings the EXPORT is part of the commit: the thread that commits a cut lane knows the lane's
+// entrants of the step (a ghost lane's migrants: the last `entrants` of its list) and its new tail (an import lane's report),
+// so the messages are written where those are known and no export kernel runs; the last cut lane to finish publishes the
+// step's epoch in the peers' mailboxes.  The IMPORT stays a kernel (it has to wait for the neighbours' epochs): migrants are
+// appended to the import lanes' rings, a ghost lane that had no entrant of its own takes its owner's tail as its proxy.
+// A ghost lane holds at most its proxy (plus, for one step, a vehicle admitted here as on the owner's side): frozen, never
+// stepped (actionOneRounds), leader and Lane::canEnter source for the vehicles upstream through its tail record.
+struct RingHalo {
+    int on;                   // 0: not a tile (everything below is unused)
+    const int32_t *cutIndex;  // [L] -1: not cut; i < nGhost: ghost lane i; nGhost + j: import lane j
+    HaloDev h;
+    HaloIO io;
+    long long *activeOut;     // vehicles that left this tile in the step (folded into DevScalars::active by the import kernel:
+                              // the commit launch's own statistics block rewrites `active` while the lanes are committed)
+};
+
+__device__ inline int ringHaloGlobalPrev(const RingCtx &c, const HaloDev &h, int prevDrv) {
+    if (prevDrv >= c.n.L) return h.llGlobal[prevDrv - c.n.L];
+    if (prevDrv <= -2) return -prevDrv - 2;  // a migrant's laneLink of origin, kept as its global id
+    return -1;
+}
+
+// The cut lane `d` after its commit (head / n as the commit left them, co.entrants = the step's entrants).
+__device__ inline void ringHaloExport(const RingCtx &c, const RingCommit &k, const RingHalo &rh, int d, int ci, const CommitOut &co) {
+    const HaloDev &h = rh.h;
+    const int2 geo = c.ringGeo[d];
+    int head = co.touched ? co.head : c.head[d];
+    int n = co.touched ? co.n : c.cnt[d];
+    if (ci < h.nGhost) {
+        char *blk = rh.io.send[h.ghostPeer[ci]] + h.ghostSendOff[ci];
+        const int in = co.entrants;
+        int m = in;
+        if (m > CFX_HALO_MAX_MIGRANTS) {
+            m = CFX_HALO_MAX_MIGRANTS;
+            k.sc->overflow = 3;
+        }
+        ((int32_t *) blk)[0] = m;
+        ((int32_t *) blk)[1] = 0;
+        HaloMigrant *rec = (HaloMigrant *) (blk + 8);
+        for (int j = 0; j < m; ++j) {  // entrants are appended behind the stayers, already in Lane::vehicles order
+            const int s = ringSlot(geo, head, n - in + j);
+            const double2 kv = c.kinN[s];
+            HaloMigrant r;
+            r.vid = c.s.vid[s];
+            r.routePos = c.s.routePos[s];
+            r.prevLL = ringHaloGlobalPrev(c, h, c.s.prevDrv[s]);
+            r.pad = 0;
+            r.dis = kv.x;
+            r.speed = kv.y;
+            rec[j] = r;
+        }
+        h.ghostHadEntrants[ci] = in > 0;
+        if (in > 0) {
+            // keep only the new tail as this lane's proxy: the ring's head moves onto it (its slot, its records and the lane's
+            // tail record, which the commit has just written, stay where they are); everybody else is no longer here
+            for (int j = 0; j + 1 < n; ++j) c.slotOf[c.s.vid[ringSlot(geo, head, j)]] = -1;
+            head = (head + n - 1) & geo.y;
+            c.head[d] = head;
+            c.cnt[d] = 1;
+            atomicAdd((unsigned long long *) rh.activeOut, (unsigned long long) in);
+        }
+        return;
+    }
+    const int j = ci - h.nGhost;
+    if (j < h.nImport) {  // downstream side: report the lane's tail (before this step's migrants are appended)
+        HaloTail t;
+        t.vid = -1;
+        t.prevLL = -1;
+        t.dis = 0.0;
+        t.speed = 0.0;
+        if (n > 0) {
+            const int s = ringSlot(geo, head, n - 1);
+            const double2 kv = c.kinN[s];
+            t.vid = c.s.vid[s];
+            t.prevLL = ringHaloGlobalPrev(c, h, c.s.prevDrv[s]);
+            t.dis = kv.x;
+            t.speed = kv.y;
+        }
+        *(HaloTail *) (rh.io.send[h.importPeer[j]] + h.importSendOff[j]) = t;
+    }
+}
+
+// `c` is the NEXT step's context (cfx_step has returned): c.kin is the generation the step's commit wrote, c.tailR / c.blkR the
+// records of the step that has just finished (tag c.step - 1), which the import rewrites where it changes a lane's last vehicle.
+__device__ inline void ringHaloWriteTail(const RingCtx &c, int lane, int slot) {
+    TailRec r{};
+    r.slot = -1;
+    if (slot >= 0) {
+        const double2 kv = c.kin[slot];
+        r.dis = kv.x;
+        r.speed = kv.y;
+        r.slot = slot;
+        r.templ = c.meta[slot].x;
+        r.prevDrv = c.s.prevDrv[slot];
+    }
+    r.tag = c.step - 1;
+    const_cast<TailRec *>(c.tailR)[lane] = r;
+}
+
+// One cut lane's share of the import: `i` < nImport = import lane i (append the migrants), else ghost lane i - nImport (refresh
+// the proxy unless the lane had an entrant of its own).  Called by the import kernel, one thread per cut lane, and — round 6,
+// mailbox transports — by the lane's own thread at the top of the NEXT step's admission (kr_admit), which saves the launch.
+__device__ inline void ringHaloImportCut(const RingCtx &c, const HaloDev &h, const HaloIO &io, const VidTable &vt, DevScalars *sc, int i) {
+    if (i < h.nImport) {
+        const int l = h.importLane[i];
+        const char *blk = io.recv[h.importPeer[i]] + h.importRecvOff[i];
+        const int m = ((const int32_t *) blk)[0];
+        if (m <= 0) return;
+        const HaloMigrant *rec = (const HaloMigrant *) (blk + 8);
+        const int2 geo = c.ringGeo[l];
+        const int head = c.head[l], n = c.cnt[l];
+        if (n + m > geo.y) {
+            sc->overflow = 8;
+            return;
+        }
+        const int road = c.n.laneRoad[l];
+        int last = -1;
+        for (int j = 0; j < m; ++j) {
+            const HaloMigrant r = rec[j];
+            const int s = ringSlot(geo, head, n + j);
+            const int route = vt.route[r.vid];
+            const int next = nextOf(c.n, c.t, l, route, r.routePos);
+            const int base = c.t.routeStart[route], len = c.t.routeStart[route + 1] - base;
+            const int onLast = (next < 0 && c.t.routeRoads[base + len - 1] == road) ? 2 : 0;  // Router::isLastRoad: flags bit 1
+            c.s.vid[s] = r.vid;
+            c.s.drv[s] = l;
+            c.s.prevDrv[s] = r.prevLL >= 0 ? -(r.prevLL + 2) : -1;
+            c.s.routePos[s] = r.routePos;
+            c.s.route[s] = route;
+            c.meta[s] = make_int4(vt.templ[r.vid], next, onLast, CFX_INT_MAX);
+            c.kin[s] = make_double2(r.dis, r.speed);
+            const_cast<int2 *>(c.blkR)[s] = make_int2(-1, -1);  // a vehicle that left its laneLink this step was not yielding
+            c.slotOf[r.vid] = s;
+            vt.state[r.vid] = 1;
+            last = s;
+        }
+        c.cnt[l] = n + m;
+        atomicAdd((unsigned long long *) &sc->active, (unsigned long long) m);
+        ringHaloWriteTail(c, l, last);
+        return;
+    }
+    const int j = i - h.nImport;
+    if (j < h.nGhost && !h.ghostHadEntrants[j]) {
+        // no entrant of our own this step: the owner's tail is the lane's tail
+        const int g = h.ghostLane[j];
+        const HaloTail t = *(const HaloTail *) (io.recv[h.ghostPeer[j]] + h.ghostRecvOff[j]);
+        const int2 geo = c.ringGeo[g];
+        const int head = c.head[g], n = c.cnt[g];
+        for (int q = 0; q < n; ++q) {  // whoever stood here (the old proxy, a vehicle admitted on both sides) is the owner's
+            const int v = c.s.vid[ringSlot(geo, head, q)];
+            if (v != t.vid) c.slotOf[v] = -1;
+        }
+        if (t.vid < 0) {
+            c.cnt[g] = 0;
+            ringHaloWriteTail(c, g, -1);
+            return;
+        }
+        int prev = -1;
+        if (t.prevLL >= 0) {
+            const int k = h.llLocalOfGlobal[t.prevLL];
+            prev = k >= 0 ? c.n.L + k : -(t.prevLL + 2);
+        }
+        const int s = ringSlot(geo, head, 0);
+        c.s.vid[s] = t.vid;
+        c.s.drv[s] = g;
+        c.s.prevDrv[s] = prev;
+        c.s.routePos[s] = 0;
+        c.s.route[s] = vt.route[t.vid];
+        c.meta[s] = make_int4(vt.templ[t.vid], -1, 0, CFX_INT_MAX);
+        c.kin[s] = make_double2(t.dis, t.speed);
+        const_cast<int2 *>(c.blkR)[s] = make_int2(-1, -1);
+        c.slotOf[t.vid] = s;
+        c.cnt[g] = 1;
+        ringHaloWriteTail(c, g, s);
+    }
+}
+
+// Waits (bounded) until peer `p` has published this epoch; false: it did not (flagged, never a hang).
+__device__ inline bool ringHaloWaitPeer(const HaloIO &io, int p, DevScalars *sc) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(io.waitFlag[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < io.epoch) {
+        if (++spins > (1u << 22)) {
+            sc->overflow = 4;
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return true;
+}
+
+// What kr_admit needs to import the previous step's halo itself (on = 0: nothing pending).
+struct RingHaloIn {
+    int on;
+    const int32_t *cutIndex;
+    HaloDev h;
+    HaloIO io;
+    long long *activeOut;
+};
+
+__global__ void kr_halo_import(RingCtx c, HaloDev h, HaloIO io, VidTable vt, DevScalars *sc, long long *activeOut) {
+    if (io.nWait > 0) {  // mailbox path: every block waits until all peers have published this epoch
+        __shared__ int ok;
+        if (threadIdx.x == 0) {
+            ok = 1;
+            for (int p = 0; p < io.nWait && ok; ++p) ok = ringHaloWaitPeer(io, p, sc) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!ok) return;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {  // the vehicles the step's commit sent away (its own statistics block was rewriting `active` then)
+        const long long out = *activeOut;
+        if (out) {
+            *activeOut = 0;
+            atomicAdd((unsigned long long *) &sc->active, (unsigned long long) (-out));
+        }
+    }
+    if (i < h.nImport + h.nGhost) ringHaloImportCut(c, h, io, vt, sc, i);
+}
+
 // COMMIT = true: the launch also commits the PREVIOUS step (kr_commit's work, drivable by drivable, in front of the drivable's
 // admission; its statistics blocks at the end of the grid).  `cIn` is then the context of the step being committed and the
 // admission runs on the next step's view of it.  What a lane's admission reads of the commit is what its own thread wrote —
 // its tail, its count, its queue — except the lights, which the cross kernel of the committed step has already advanced.
 template <bool COMMIT, int NB = kAdmitRecs>  // NB: spawn records the arguments hold (kAdmitRecsBig on large networks, as kd_admit)
 __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitStep, int32_t *waitHead, VidTable vt, DevScalars *sc,
-                                                   const SpawnBatchT<NB> batch, const RingCommit k) {
+                                                   const SpawnBatchT<NB> batch, const RingCommit k, const RingHaloIn hin) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     const bool isLane = d < cIn.n.L, inRange = d < cIn.n.L + cIn.n.K;
     // what the admission needs and the commit in front of it leaves alone — or changes through this very thread, which then
@@ -380,6 +603,26 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
         if (isLane && k.hist.num) laneHistoryStep(k.hist, d, n, [&](int i) { return cIn.kinN[ringSlot(geo, head, i)].y; });
     }
     RingCtx c = cIn;
+    if constexpr (!COMMIT) {
+        // tiling, mailbox transports: the previous step's halo import, by the cut lane's own thread, in front of the lane's
+        // admission — what the import changes (the lane's count, its tail record, its slots) is what this thread reads next
+        if (hin.on) {
+            if (d == 0) {  // the vehicles the previous step's commit sent away (kr_halo_import's thread 0)
+                const long long out = *hin.activeOut;
+                if (out) {
+                    *hin.activeOut = 0;
+                    atomicAdd((unsigned long long *) &sc->active, (unsigned long long) (-out));
+                }
+            }
+            const int ci = isLane ? hin.cutIndex[d] : -1;
+            if (ci >= 0) {
+                const int nG = hin.h.nGhost;
+                const int peer = ci < nG ? hin.h.ghostPeer[ci] : hin.h.importPeer[ci - nG];
+                if (hin.io.nWait == 0 || ringHaloWaitPeer(hin.io, peer, sc))
+                    ringHaloImportCut(c, hin.h, hin.io, vt, sc, ci < nG ? hin.h.nImport + ci : ci - nG);
+            }
+        }
+    }
     if constexpr (COMMIT) {  // the next step's view: what the commit wrote is what the admission reads
         c.step = cIn.step + 1;
         c.tailR = cIn.tailW;
@@ -780,7 +1023,7 @@ struct RingPush {
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
 
 #ifndef CFX_KR_CROSS_WAVES
-#define CFX_KR_CROSS_WAVES 4
+#define CFX_KR_CROSS_WAVES 3  // (4: 128 registers, 2 spilled, 12 B of scratch; 3: 132, none: 13.9 against 14.0 us at 30x30 — round 6)
 #endif
 #ifndef CFX_KR_ACTION_WAVES
 #define CFX_KR_ACTION_WAVES 0
@@ -1881,211 +2124,6 @@ __device__ inline void commitStatBlock(const RingCtx &c, const RingCommit &k, co
 }
 __device__ inline void commitClearMasks(const RingCtx &c, const RingCommit &k, int gid, int stride) {
     for (int i = gid; i < k.nMaskWords; i += stride) c.interMask[i] = 0ULL;
-}
-
-// ---------------------------------------------------------------------------------------------- tiling on the rings
-// One road network over several engines (include/cityflow_amd.h, "Tiling"; the dense layout's k_halo_export / k_halo_import
-// are in cfx_kernels.h).  On the rings the EXPORT is part of the commit: the thread that commits a cut lane knows the lane's
-// entrants of the step (a ghost lane's migrants: the last `entrants` of its list) and its new tail (an import lane's report),
-// so the messages are written where those are known and no export kernel runs; the last cut lane to finish publishes the
-// step's epoch in the peers' mailboxes.  The IMPORT stays a kernel (it has to wait for the neighbours' epochs): migrants are
-// appended to the import lanes' rings, a ghost lane that had no entrant of its own takes its owner's tail as its proxy.
-// A ghost lane holds at most its proxy (plus, for one step, a vehicle admitted here as on the owner's side): frozen, never
-// stepped (actionOneRounds), leader and Lane::canEnter source for the vehicles upstream through its tail record.
-struct RingHalo {
-    int on;                   // 0: not a tile (everything below is unused)
-    const int32_t *cutIndex;  // [L] -1: not cut; i < nGhost: ghost lane i; nGhost + j: import lane j
-    HaloDev h;
-    HaloIO io;
-    long long *activeOut;     // vehicles that left this tile in the step (folded into DevScalars::active by the import kernel:
-                              // the commit launch's own statistics block rewrites `active` while the lanes are committed)
-};
-
-__device__ inline int ringHaloGlobalPrev(const RingCtx &c, const HaloDev &h, int prevDrv) {
-    if (prevDrv >= c.n.L) return h.llGlobal[prevDrv - c.n.L];
-    if (prevDrv <= -2) return -prevDrv - 2;  // a migrant's laneLink of origin, kept as its global id
-    return -1;
-}
-
-// The cut lane `d` after its commit (head / n as the commit left them, co.entrants = the step's entrants).
-__device__ inline void ringHaloExport(const RingCtx &c, const RingCommit &k, const RingHalo &rh, int d, int ci, const CommitOut &co) {
-    const HaloDev &h = rh.h;
-    const int2 geo = c.ringGeo[d];
-    int head = co.touched ? co.head : c.head[d];
-    int n = co.touched ? co.n : c.cnt[d];
-    if (ci < h.nGhost) {
-        char *blk = rh.io.send[h.ghostPeer[ci]] + h.ghostSendOff[ci];
-        const int in = co.entrants;
-        int m = in;
-        if (m > CFX_HALO_MAX_MIGRANTS) {
-            m = CFX_HALO_MAX_MIGRANTS;
-            k.sc->overflow = 3;
-        }
-        ((int32_t *) blk)[0] = m;
-        ((int32_t *) blk)[1] = 0;
-        HaloMigrant *rec = (HaloMigrant *) (blk + 8);
-        for (int j = 0; j < m; ++j) {  // entrants are appended behind the stayers, already in Lane::vehicles order
-            const int s = ringSlot(geo, head, n - in + j);
-            const double2 kv = c.kinN[s];
-            HaloMigrant r;
-            r.vid = c.s.vid[s];
-            r.routePos = c.s.routePos[s];
-            r.prevLL = ringHaloGlobalPrev(c, h, c.s.prevDrv[s]);
-            r.pad = 0;
-            r.dis = kv.x;
-            r.speed = kv.y;
-            rec[j] = r;
-        }
-        h.ghostHadEntrants[ci] = in > 0;
-        if (in > 0) {
-            // keep only the new tail as this lane's proxy: the ring's head moves onto it (its slot, its records and the lane's
-            // tail record, which the commit has just written, stay where they are); everybody else is no longer here
-            for (int j = 0; j + 1 < n; ++j) c.slotOf[c.s.vid[ringSlot(geo, head, j)]] = -1;
-            head = (head + n - 1) & geo.y;
-            c.head[d] = head;
-            c.cnt[d] = 1;
-            atomicAdd((unsigned long long *) rh.activeOut, (unsigned long long) in);
-        }
-        return;
-    }
-    const int j = ci - h.nGhost;
-    if (j < h.nImport) {  // downstream side: report the lane's tail (before this step's migrants are appended)
-        HaloTail t;
-        t.vid = -1;
-        t.prevLL = -1;
-        t.dis = 0.0;
-        t.speed = 0.0;
-        if (n > 0) {
-            const int s = ringSlot(geo, head, n - 1);
-            const double2 kv = c.kinN[s];
-            t.vid = c.s.vid[s];
-            t.prevLL = ringHaloGlobalPrev(c, h, c.s.prevDrv[s]);
-            t.dis = kv.x;
-            t.speed = kv.y;
-        }
-        *(HaloTail *) (rh.io.send[h.importPeer[j]] + h.importSendOff[j]) = t;
-    }
-}
-
-// `c` is the NEXT step's context (cfx_step has returned): c.kin is the generation the step's commit wrote, c.tailR / c.blkR the
-// records of the step that has just finished (tag c.step - 1), which the import rewrites where it changes a lane's last vehicle.
-__device__ inline void ringHaloWriteTail(const RingCtx &c, int lane, int slot) {
-    TailRec r{};
-    r.slot = -1;
-    if (slot >= 0) {
-        const double2 kv = c.kin[slot];
-        r.dis = kv.x;
-        r.speed = kv.y;
-        r.slot = slot;
-        r.templ = c.meta[slot].x;
-        r.prevDrv = c.s.prevDrv[slot];
-    }
-    r.tag = c.step - 1;
-    const_cast<TailRec *>(c.tailR)[lane] = r;
-}
-
-__global__ void kr_halo_import(RingCtx c, HaloDev h, HaloIO io, VidTable vt, DevScalars *sc, long long *activeOut) {
-    if (io.nWait > 0) {  // mailbox path: every block waits until all peers have published this epoch
-        __shared__ int ok;
-        if (threadIdx.x == 0) {
-            ok = 1;
-            for (int p = 0; p < io.nWait && ok; ++p) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(io.waitFlag[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < io.epoch) {
-                    if (++spins > (1u << 22)) {  // a peer died or fell far behind: flag it instead of hanging the device
-                        ok = 0;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-        }
-        __syncthreads();
-        if (!ok) {
-            sc->overflow = 4;
-            return;
-        }
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {  // the vehicles the step's commit sent away (its own statistics block was rewriting `active` then)
-        const long long out = *activeOut;
-        if (out) {
-            *activeOut = 0;
-            atomicAdd((unsigned long long *) &sc->active, (unsigned long long) (-out));
-        }
-    }
-    if (i < h.nImport) {
-        const int l = h.importLane[i];
-        const char *blk = io.recv[h.importPeer[i]] + h.importRecvOff[i];
-        const int m = ((const int32_t *) blk)[0];
-        if (m <= 0) return;
-        const HaloMigrant *rec = (const HaloMigrant *) (blk + 8);
-        const int2 geo = c.ringGeo[l];
-        const int head = c.head[l], n = c.cnt[l];
-        if (n + m > geo.y) {
-            sc->overflow = 8;
-            return;
-        }
-        const int road = c.n.laneRoad[l];
-        int last = -1;
-        for (int j = 0; j < m; ++j) {
-            const HaloMigrant r = rec[j];
-            const int s = ringSlot(geo, head, n + j);
-            const int route = vt.route[r.vid];
-            const int next = nextOf(c.n, c.t, l, route, r.routePos);
-            const int base = c.t.routeStart[route], len = c.t.routeStart[route + 1] - base;
-            const int onLast = (next < 0 && c.t.routeRoads[base + len - 1] == road) ? 2 : 0;  // Router::isLastRoad: flags bit 1
-            c.s.vid[s] = r.vid;
-            c.s.drv[s] = l;
-            c.s.prevDrv[s] = r.prevLL >= 0 ? -(r.prevLL + 2) : -1;
-            c.s.routePos[s] = r.routePos;
-            c.s.route[s] = route;
-            c.meta[s] = make_int4(vt.templ[r.vid], next, onLast, CFX_INT_MAX);
-            c.kin[s] = make_double2(r.dis, r.speed);
-            const_cast<int2 *>(c.blkR)[s] = make_int2(-1, -1);  // a vehicle that left its laneLink this step was not yielding
-            c.slotOf[r.vid] = s;
-            vt.state[r.vid] = 1;
-            last = s;
-        }
-        c.cnt[l] = n + m;
-        atomicAdd((unsigned long long *) &sc->active, (unsigned long long) m);
-        ringHaloWriteTail(c, l, last);
-        return;
-    }
-    const int j = i - h.nImport;
-    if (j < h.nGhost && !h.ghostHadEntrants[j]) {
-        // no entrant of our own this step: the owner's tail is the lane's tail
-        const int g = h.ghostLane[j];
-        const HaloTail t = *(const HaloTail *) (io.recv[h.ghostPeer[j]] + h.ghostRecvOff[j]);
-        const int2 geo = c.ringGeo[g];
-        const int head = c.head[g], n = c.cnt[g];
-        for (int q = 0; q < n; ++q) {  // whoever stood here (the old proxy, a vehicle admitted on both sides) is the owner's
-            const int v = c.s.vid[ringSlot(geo, head, q)];
-            if (v != t.vid) c.slotOf[v] = -1;
-        }
-        if (t.vid < 0) {
-            c.cnt[g] = 0;
-            ringHaloWriteTail(c, g, -1);
-            return;
-        }
-        int prev = -1;
-        if (t.prevLL >= 0) {
-            const int k = h.llLocalOfGlobal[t.prevLL];
-            prev = k >= 0 ? c.n.L + k : -(t.prevLL + 2);
-        }
-        const int s = ringSlot(geo, head, 0);
-        c.s.vid[s] = t.vid;
-        c.s.drv[s] = g;
-        c.s.prevDrv[s] = prev;
-        c.s.routePos[s] = 0;
-        c.s.route[s] = vt.route[t.vid];
-        c.meta[s] = make_int4(vt.templ[t.vid], -1, 0, CFX_INT_MAX);
-        c.kin[s] = make_double2(t.dis, t.speed);
-        const_cast<int2 *>(c.blkR)[s] = make_int2(-1, -1);
-        c.slotOf[t.vid] = s;
-        c.cnt[g] = 1;
-        ringHaloWriteTail(c, g, s);
-    }
 }
 
 __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, VidTable vt, RingHalo rh) {

@@ -41,3 +41,9 @@ run("set_tl_phases (changing every step) + next_step", lambda s: (e.set_tl_phase
 run("set_tl_phases (every 10) + next_step + lane counts", lambda s: (e.set_tl_phases(np.full(n_inter, (s // 10) % 8, dtype=np.int32)), e.next_step(), e.get_lane_vehicle_count_array()))
 run("lane counts alone (no step between)", lambda s: e.get_lane_vehicle_count_array())
 run("np.full alone", lambda s: np.full(n_inter, (s // 10) % 8, dtype=np.int32))
+_same = np.full(n_inter, 3, dtype=np.int32)
+e.set_tl_phases(_same)
+run("set_tl_phases alone, nothing changes (host filter only)", lambda s: e.set_tl_phases(_same))
+run("set_tl_phases alone, every signal changes (no step between)", lambda s: e.set_tl_phases(np.full(n_inter, s % 8, dtype=np.int32)))
+run("set_tl_phases (never changing) + next_step + lane counts", lambda s: (e.set_tl_phases(_same), e.next_step(), e.get_lane_vehicle_count_array()))
+run("set_tl_phases (changing every step) + next_step + lane counts", lambda s: (e.set_tl_phases(np.full(n_inter, s % 8, dtype=np.int32)), e.next_step(), e.get_lane_vehicle_count_array()))
