@@ -820,7 +820,10 @@ void TiledEngineHost::dropAhead() {
     if (!aheadEnabled_) return;
     waitAhead();
     if (aheadState_ != kAheadIdle) spawner_.rollbackAhead();
-    aheadState_ = kAheadIdle;
+    {
+        std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
+        aheadState_ = kAheadIdle;
+    }
 }
 
 size_t TiledEngineHost::committedVehicleCount() {
@@ -834,7 +837,10 @@ void TiledEngineHost::takeBatch() {
         if (aheadState_ == kAheadReady && aheadStep_ == step_) {
             spawner_.commitAhead();
             spawnBuf_.swap(aheadBuf_);
-            aheadState_ = kAheadIdle;
+            {
+        std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
+        aheadState_ = kAheadIdle;
+    }
             return;
         }
         // abandoned (a priority collision), failed (raised below, where it belongs), or prepared for another step

@@ -412,7 +412,8 @@ void VectorEngineHost::aheadLoop() {
         } catch (const std::exception &e) {
             error = e.what()[0] ? e.what() : "unknown error";
         }
-        hostAheadSec_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        hostAheadSec_.store(hostAheadSec_.load(std::memory_order_relaxed) +
+                                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> guard(aheadMutex_);
             aheadError_ = error;
@@ -457,7 +458,10 @@ void VectorEngineHost::dropAhead() {
                 localToGlobal_[(size_t) r].resize(std::min(localToGlobal_[(size_t) r].size(), l2gEnvMark_[(size_t) r]));
         }
     }
-    aheadState_ = kAheadIdle;
+    {
+        std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
+        aheadState_ = kAheadIdle;
+    }
     journalling_ = false;
 }
 
@@ -476,7 +480,10 @@ void VectorEngineHost::nextStep() {
         }
         if (aheadState_ == kAheadReady && aheadStep_ == step_) {
             for (auto &sp : spawners_) sp->commitAhead();
-            aheadState_ = kAheadIdle;
+            {
+        std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
+        aheadState_ = kAheadIdle;
+    }
             taken = true;
             spawnSec = std::chrono::duration<double>(clk::now() - t0).count();  // (the wait is what the caller paid)
         } else if (aheadState_ == kAheadReady) {
@@ -499,11 +506,14 @@ void VectorEngineHost::nextStep() {
         kickAhead(step_ + 1);
     }
     const auto t2 = clk::now();
+    int32_t rcStep;
     {
         std::lock_guard<std::mutex> guard(queryMutex_);  // (a priority collision on the ahead thread asks the device too)
-        check(be_.cfx_step(dev_, recs_.data(), (int32_t) recs_.size()), "cfx_step");
+        rcStep = be_.cfx_step(dev_, recs_.data(), (int32_t) recs_.size());
     }
+    // (published whatever the outcome: a query of the ahead thread that waits for this submission must not wait for ever)
     submitted_.store((uint64_t) step_ + 1, std::memory_order_release);
+    check(rcStep, "cfx_step");
     lcPollPending_ = laneChange_;
     const auto t3 = clk::now();
     hostSpawnSec_ += spawnSec;
@@ -524,7 +534,8 @@ void VectorEngineHost::reset(bool resetRnd) {
     globalToLocal_.clear();
     step_ = 0;
     submitted_.store(0, std::memory_order_release);
-    hostSpawnSec_ = hostTranslateSec_ = hostSubmitSec_ = hostAheadSec_ = 0;
+    hostSpawnSec_ = hostTranslateSec_ = hostSubmitSec_ = 0;
+    hostAheadSec_.store(0.0, std::memory_order_relaxed);
 }
 
 std::vector<int32_t> VectorEngineHost::laneVehicleCounts() {

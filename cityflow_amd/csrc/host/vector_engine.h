@@ -47,7 +47,9 @@ public:
     std::string backendName() const { return be_.cfx_backend_name(); }
     // cumulative host wall seconds since the last reset, ON THE CALLER'S PATH: {spawners (with the batch prepared a step ahead:
     // the wait for it), record translation, cfx_step (launches + back-pressure)}, then the ahead thread's own busy time
-    std::vector<double> hostSeconds() const { return {hostSpawnSec_, hostTranslateSec_, hostSubmitSec_, hostAheadSec_}; }
+    std::vector<double> hostSeconds() const {
+        return {hostSpawnSec_, hostTranslateSec_, hostSubmitSec_, hostAheadSec_.load(std::memory_order_relaxed)};
+    }
     // per-environment id-keyed view, for parity tests against a standalone Engine
     std::map<std::string, double> getVehicleSpeed(int env);
     std::map<std::string, int> getLaneVehicleCount(int env);
@@ -90,7 +92,8 @@ private:
     void (VectorEngineHost::*poolFn_)(int) = nullptr;
     std::vector<int32_t> envBase_;  // [env] offset of the environment's records in this step's batch
     int32_t batchFirstVid_ = 0;
-    double hostSpawnSec_ = 0, hostTranslateSec_ = 0, hostSubmitSec_ = 0, hostAheadSec_ = 0;
+    double hostSpawnSec_ = 0, hostTranslateSec_ = 0, hostSubmitSec_ = 0;
+    std::atomic<double> hostAheadSec_{0.0};  // (written by the ahead thread)
     // ---- the batch of step t+1 is prepared while step t is submitted and runs (config "cfx": {"spawnAhead": false} turns it
     //      off; not with lane change, whose shadows draw from the generators after the device has scheduled them).  The
     //      reference's Flow::nextStep / planRoute (flow.cpp:6-22, engine.cpp:450-470) depend on nothing a step computes
