@@ -892,6 +892,14 @@ def scale_leg(job, args, n_steps):
         later = [s for s in sorted(want) if s > at]
         if later and later[0] - at <= 64:  # the next checkpoint behind the instrumented region
             advance(later[0] - at)
+        # a longer window behind everything else (the 50-step region above starts on an idle device and is ~7 ms long): 200
+        # more free-running steps, timed the same way — reported beside `ms_per_step`, never instead of it
+        eng.sync()
+        s200a = eng._scalars()
+        t200 = timed_steps(job, eng, 200)
+        s200b = eng._scalars()
+        out["ms_per_step_200"] = t200 / 200 * 1e3
+        out["vehicle_steps_per_sec_200"] = (s200b["vehicle_steps"] - s200a["vehicle_steps"]) / t200
         if golden:
             roof_parity = {
                 "against": "records of the unmodified reference engine (tests/golden/reference_large.json; %d thread(s), Vehicle "

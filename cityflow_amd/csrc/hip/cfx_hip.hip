@@ -1526,7 +1526,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         }
         if (useBig)
             e->launchNamed(PK_CROSS, "k_cross2<false, RingCtx, RingOut>", k_cross2<false, RingCtx, RingOut>,
-                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) CFX_RING_CROSS2_WAVES * e->nCU)),  // (one block per CU and wavefront slot the register count leaves: 4 at 115 registers)
+                      dim3((int) std::min<size_t>(std::max<size_t>(64, (activeEst / 4 + 15) / 16), (size_t) CFX_RING_CROSS2_WAVES * e->nCU)),  // (5 blocks per CU: 96 registers)
                       dim3(kCross2Block), c, ro, jq, RingLights{e->curPhase, e->remain, (deferCommit && !e->cfg.rl_traffic_light) ? 1 : 0});
         else
         {

@@ -32,8 +32,9 @@ struct RingCtx {
     // (k_cross2 on the ring layout needs 95 registers; asking for 7 wavefronts per SIMD spills and was measured slower,
     // 66 -> 72 us at 1 M vehicles: 5 = as the compiler has it)
 #ifndef CFX_RING_CROSS2_WAVES
-#define CFX_RING_CROSS2_WAVES 4  // (6: 80 registers, 21 spilled, 47.0 us at 1 M vehicles; 7: 72 / 44, 52.5 us; 5: 96 / 9, 43.7 us; round 6: 4 = 115
-                                 //  registers, nothing spilled, no scratch segment: 37.9 against 38.2 us — kept for the missing spills)
+#define CFX_RING_CROSS2_WAVES 5  // (6: 80 registers, 21 spilled, 47.0 us at 1 M vehicles; 7: 72 / 44, 52.5 us; 5: 96 / 9, 43.7 us.  Round 6: 4 = 115
+                                 //  registers, nothing spilled, no scratch segment — 37.9 against 38.2 us right behind a load (tools/exp_big.py),
+                                 //  but 47.1-47.8 against 43.8 us in bench.py's 50-step leg: the spills are cheaper than the fifth wavefront)
 #endif
     static constexpr int kCross2Waves = CFX_RING_CROSS2_WAVES;
     DevNet n;
@@ -1023,7 +1024,8 @@ struct RingPush {
 // cannot be passed.  No active-laneLink mask: a lane reads the peer laneLink's two records directly.
 
 #ifndef CFX_KR_CROSS_WAVES
-#define CFX_KR_CROSS_WAVES 3  // (4: 128 registers, 2 spilled, 12 B of scratch; 3: 132, none: 13.9 against 14.0 us at 30x30 — round 6)
+#define CFX_KR_CROSS_WAVES 4  // (128 registers, 2 spilled, 12 B of scratch.  Round 6: 3 = 132 registers, none spilled: 13.9 against 14.0 us right
+                              //  behind a load, 14.8-16.1 against 14.6-15.4 us in bench.py's runs: not kept)
 #endif
 #ifndef CFX_KR_ACTION_WAVES
 #define CFX_KR_ACTION_WAVES 0
