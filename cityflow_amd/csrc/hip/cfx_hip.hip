@@ -1494,7 +1494,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                           //  25 % of headroom and never shrinks: entries beyond the launch would never take their step, unflagged)
                           e->rList, (int) std::min<size_t>(e->rListCap, (size_t) nVehBlocks * kListBlock), e->rListCount, e->sc);
                 RING_CHECK("kr_index")
-                e->launchNamed(PK_ACTION, "kl_action", kl_action, dim3(nVehBlocks + nLL), dim3(kListBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
+                e->launchNamed(PK_ACTION, e->tiled ? "kl_action<true>" : "kl_action", e->tiled ? kl_action<true> : kl_action<false>, dim3(nVehBlocks + nLL), dim3(kListBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
                           (const int32_t *) e->rListCount, nVehBlocks, idxTicket);
             } else {
             G = std::min(G, Bsel);
@@ -1502,10 +1502,16 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             // (first form: as many blocks again at the end of the grid compute the laneLinks' notify sources)
             const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(Bsel);
             if (blockForm) {
-                if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256>", kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                if (e->tiled) {  // (ghost lanes: the instantiations that know about frozen proxies)
+                    if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256, true>", kr_action<256, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                    else e->launchNamed(PK_ACTION, "kr_action<512, true>", kr_action<512, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                } else if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256>", kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
                 else e->launchNamed(PK_ACTION, "kr_action<512>", kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
             } else {
-                if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256>", kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                if (e->tiled) {
+                    if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256, true>", kw_action<256, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                    else e->launchNamed(PK_ACTION, "kw_action<512, true>", kw_action<512, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                } else if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256>", kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
                 else e->launchNamed(PK_ACTION, "kw_action<512>", kw_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
             }
             }

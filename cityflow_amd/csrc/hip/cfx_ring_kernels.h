@@ -1166,15 +1166,17 @@ __device__ __forceinline__ TailRec firstHopRecord(const RingCtx &c, bool linkHea
 }
 __device__ __forceinline__ bool viewerIsNew(const RingCtx &, const SlotIn &in, int) { return in.laneAdmitted && in.nNow == 1; }
 
-template <class C, class Out, class Push>
+// GHOST: the engine is a tile (ghost lanes exist).  A template flag, not a run-time test: inlined into the single engine's kernels
+// the frozen-proxy path cost kl_action 10 spilled registers under its five-wavefront bound (and as an out-of-line call, 74).
+template <bool GHOST = false, class C, class Out, class Push>
 __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const cfx_vehicle_template *tv, const int s,
                                                 const SlotIn &in, Push push) {
     const int d = in.d, templIdx = in.templIdx, nd0 = in.nd0, flags = in.flags, L = c.n.L;
     const double speed = in.speed, dis = in.dis;
-    if constexpr (std::is_same<C, RingCtx>::value) {
+    if constexpr (GHOST && std::is_same<C, RingCtx>::value) {
         // tiling: a vehicle on a ghost lane is the frozen proxy of a neighbour's vehicle (or a vehicle admitted on both sides):
         // not stepped here.  Its state goes into the next generation as it is, and the lane's last one rewrites the tail record.
-        if (c.n.laneGhost && d < L && c.n.laneGhost[d]) {
+        if (d < L && c.n.laneGhost[d]) {
             o.keep(s, dis, speed);
             if (in.idx == in.nNow - 1) {
                 TailRec r;
@@ -1374,7 +1376,7 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
 // read from HBM once, coalesced.
 constexpr int kRingWave = 64;
 
-template <int B>
+template <int B, bool GHOST = false>
 __global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
     TRACE_STAMP(0);
@@ -1493,7 +1495,7 @@ __global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue
             in.hop = (in.nd0 >= c.n.L) ? sHop[i] : make_int4(-2, -2, -2, -2);
             in.laneAdmitted = sAdm[i] != 0;
             in.endLane = -1;  // (the end lanes from the lane's static tables, as kw_action has them: measured in round 4, 12.0 us either way)
-            actionOneRounds(c, o, tv, slot, in, push);
+            actionOneRounds<GHOST>(c, o, tv, slot, in, push);
         }
         __syncthreads();
         TRACE_STAMP(3);
@@ -1512,7 +1514,7 @@ __global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue
 // three wavefronts busy and lets the fourth go at once (the block form keeps 256 threads through two barriers per pass);
 // large networks take more lanes per block and every wavefront walks several chunks.  The end lanes of the laneLinks that
 // leave a lane come with the lane's static tables, so the tail records behind the next laneLink are requested in round A.
-template <int B>
+template <int B, bool GHOST = false>
 __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
     if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
@@ -1641,7 +1643,7 @@ __global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q,
             in.endLane = in.hop.x == ll ? en.x : (in.hop.y == ll ? en.y : (in.hop.z == ll ? en.z : (in.hop.w == ll ? en.w : -1)));
         }
         in.laneAdmitted = sAdm[i] != 0;
-        actionOneRounds(c, o, tv, slot, in, push);
+        actionOneRounds<GHOST>(c, o, tv, slot, in, push);
     }
 }
 
@@ -1792,6 +1794,7 @@ __global__ __launch_bounds__(kIndexBlock) void kr_index(RingCtx c, unsigned long
 #endif
 constexpr int kListBlock = CFX_KL_BLOCK;
 #define CFX_KL_BOUNDS __launch_bounds__(kListBlock, CFX_KL_WAVES)  // (second argument: wavefronts per SIMD)
+template <bool GHOST = false>
 __global__ CFX_KL_BOUNDS void kl_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, const int4 *list,
                                                     const int32_t *listCount, int nVehBlocks, int32_t *ticket) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
@@ -1879,7 +1882,7 @@ __global__ CFX_KL_BOUNDS void kl_action(RingCtx c, RingOut o, JobQueue q, RingJo
     in.laneAdmitted = e.w < 0;
     const RingPush push{q, jobRecs, c.n.L};
     KSTAMP(11, 2);
-    actionOneRounds(c, o, tv, slot, in, push);
+    actionOneRounds<GHOST>(c, o, tv, slot, in, push);
     KSTAMP(11, 3);
 }
 
