@@ -1218,13 +1218,13 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     }
     // ---- the host's lead over the device is bounded.  A free-running caller submits a 30x30 step in ~20 us and the device takes
     //      ~40: unbounded, the stream's backlog grows by half a step per step, and the next call that has to wait for the device
-    //      (a getter, the spawner's priority-collision query) pays for all of it — 4.5 ms behind a 200-step window.  The step's
+    //      (a getter, the spawner's priority-collision query) pays for all of it — 4.5 ms behind a 200-step window, 2 ms with 48 steps in flight.  The step's
     //      commit publishes the number of completed steps in pinned host memory: wait (yielding) while more than kMaxLead steps
     //      are in flight.  The device is never idle for it — kMaxLead steps of work are queued behind the one it is executing —
     //      and a caller that synchronises every step never waits here.  (Built while looking for the 45-80 ms "stall" of the
     //      sustained windows of rounds 4-6, which it did NOT cure: that was the container's CPU quota — bench.py's header.)
     if (e->mirrorValid && !e->tiled) {
-        constexpr int64_t kMaxLead = 48;
+        constexpr int64_t kMaxLead = 16;  // (16 steps of a 30x30 network = 0.65 ms of queued work: what the next waiting call pays at most)
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
             const int64_t done = (int64_t) (__atomic_load_n(&e->hMirror->progress, __ATOMIC_RELAXED) >> 32);

@@ -51,7 +51,8 @@ SHADOW_SKIP = ("test_two_ranks_one_gpu", "test_four_ranks_one_gpu", "test_one_ti
                "test_tiled_device_mailboxes_hip", "test_hip_lane_change_on_the_bench_workload", "test_bench_workload_equals_twin_from_step_0",
                "test_large_checkpoint_equals_twin", "test_tiled_dense_30x30_hip_vs_twin", "test_vector_engine_hip_many_finishers",
                "test_ten_thousand_steps_without_a_stall_or_growth", "test_ring_list_form_free_running_equals_dense_layout",
-               "test_config5_one_million_vehicles_matches_reference_goldens", "test_bare_abi_on_the_hip_library_equals_twin")
+               "test_config5_one_million_vehicles_matches_reference_goldens", "test_bare_abi_on_the_hip_library_equals_twin",
+               "test_bench_sequence_free_running_without_a_stall")
 
 
 class _ShadowClass:

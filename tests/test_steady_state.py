@@ -40,6 +40,42 @@ def test_ten_thousand_steps_without_a_stall_or_growth(mod, workdir):
     assert total / 10000 < 200e-6, "%.1f us per step over the long run" % (total / 10000 * 1e6)
 
 
+def test_bench_sequence_free_running_without_a_stall(mod, workdir, tmp_path):
+    """bench.py's own sequence — demand build-up, Archive dump, load_from_file, warm-up — and then 1 000 FREE-RUNNING steps (no
+    sync inside, as bench.py's sustained windows): no next_step() call above 1.5 ms.  Rounds 4-6 saw one 45-80 ms call per
+    driver-shaped run there; it was the container's CPU quota throttled by BLAS workers a lazy `import numpy` started (DESIGN.md
+    section 6) — numpy is imported with the package now, and what a free-running caller can still meet is the spawner's
+    priority-collision query waiting for the queued steps, which cfx_step bounds to 16 (0.65 ms)."""
+    import bench
+    cfg = bench.build_workload(workdir, 0, scenario="grid_30x30")
+    eng = mod.Engine(cfg, 1)
+    assert_hip_backend(eng)
+    for _ in range(bench.BUILD_UP_STEPS):
+        eng.next_step()
+    dump = str(tmp_path / "state.json")
+    eng.snapshot().dump(dump)
+    eng.load_from_file(dump)
+    for _ in range(25):
+        eng.next_step()
+    eng.sync()
+    eng._host_stats(True)
+    calls = []
+    t1 = t_all = time.perf_counter()
+    for _ in range(1000):
+        eng.next_step()
+        t2 = time.perf_counter()
+        calls.append(t2 - t1)
+        t1 = t2
+    eng.sync()
+    total = time.perf_counter() - t_all
+    worst = max(range(len(calls)), key=lambda i: calls[i])
+    hs = eng._host_stats(True)
+    print("free-running: %.1f us per step, worst call %.0f us at %d, device library: %r" % (total / 1000 * 1e6, calls[worst] * 1e6, worst, hs))
+    assert calls[worst] < 1.5e-3, "next_step() number %d took %.2f ms (host stats: %r)" % (worst, calls[worst] * 1e3, hs)
+    assert hs["ring_regrows_total"] == 0 and hs["worst_step_call_cause"] == 0, hs
+    assert total / 1000 < 80e-6, "%.1f us per step" % (total / 1000 * 1e6)
+
+
 def test_vehicle_tables_grow_without_draining_the_stream(mod, scen, workdir):
     """The growth path itself (config "cfx": ringCapacityPercent below 100 starts the vehicle tables at 4 k numbers): they double
     several times during the run — new arrays, a copy ordered on the stream, the old ones freed at the next sync — with the state
