@@ -525,7 +525,8 @@ void EngineHost::loadFromFile(const std::string &path) {
 }
 
 Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadNet> &net_, Spawner &spawner_, bool laneChange_) {
-    Json root = Json::parseFile(path);
+    // The file is STREAMED (Json::parseFileStreamed): its `vehicles` array and `drivables` object — all but a few KB of an
+    // Archive — are handed over child by child and never held as a DOM (1 M vehicles: 1.1 GB of text, 6 GB of nodes).
     Archive a;
     a.net = net_;
     const int L = (int) net_->lanes.size();
@@ -533,24 +534,13 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
     for (int d = 0; d < L + (int) net_->laneLinks.size(); ++d) drvIndex[net_->drivableId(d)] = d;
 
     a.host = spawner_.saveState();  // flows' valid flags, manual counter; the rest is overwritten below
-    {
-        std::istringstream is(root.stringAt("rnd"));
-        is >> a.host.rnd;
-    }
     a.host.vehicles.clear();
     for (auto &v : a.host.flowVids) v.clear();
     std::fill(a.host.manualVids.begin(), a.host.manualVids.end(), -1);
     std::fill(a.host.lastWaitVid.begin(), a.host.lastWaitVid.end(), -1);
     a.host.livePriority.clear();
 
-    DeviceState &d = a.dev;
-    d.step = root.at("step").i;
-    d.finished = root.intAt("finishedVehicleCnt");
-    d.cumulativeTravelTime = root.numberAt("cumulativeTravelTime");
-    d.vehicleSteps = 0;
-
     std::map<std::string, int> vidOf;
-    const Json &vehicles = root.arrayAt("vehicles");
     struct Dyn {
         double dis, speed;
         int drivable, prev, ellt;
@@ -566,7 +556,8 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
     const std::string shadowSuffix = "_shadow";
     std::vector<std::pair<int, std::string>> shadowBase;  // (vid of a shadow, id it carries)
     std::vector<Dyn> dyn;
-    for (const Json &jv : vehicles.items) {
+    bool vehiclesDone = false;
+    auto oneVehicle = [&](const Json &jv) {
         cfx_vehicle_template t = spawner_.makeTemplate(jv.numberAt("len"), jv.numberAt("width"), jv.numberAt("maxPosAcc"),
                                                        jv.numberAt("maxNegAcc"), jv.numberAt("usualPosAcc"),
                                                        jv.numberAt("usualNegAcc"), jv.numberAt("minGap"),
@@ -645,18 +636,13 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
         }
         vidOf[fullId] = vid;
         dyn.push_back(y);
-    }
-    const int nV = (int) a.host.vehicles.size();
-    for (auto &sb : shadowBase) {  // the id a shadow carries belongs to the vehicle named so (its parent or an ancestor's heir)
-        auto it = vidOf.find(sb.second);
-        const int holder = it == vidOf.end() ? sb.first : it->second;
-        a.host.vehicles[(size_t) sb.first].root = holder;
-        a.host.shadowChains[holder].push_back(sb.first);
-    }
-    d.vState.assign(nV, 0);
-    const Json &drivables = root.objectAt("drivables");
-    for (int dv = 0; dv < L + (int) net_->laneLinks.size(); ++dv) {
-        const Json &jd = drivables.objectAt(net_->drivableId(dv).c_str());
+    };
+    // a drivable's lists (vehicles front to back, waiting buffer, history), in the order of the network's drivables
+    const int D = L + (int) net_->laneLinks.size();
+    int nextDv = 0;
+    std::map<int, Json> heldDrivables;  // those that came before the vehicles, or out of the network's order
+    DeviceState &d = a.dev;
+    auto oneDrivable = [&](int dv, const Json &jd) {
         for (const Json &jid : jd.arrayAt("vehicles").items) {
             int vid = vidOf.at(jid.s);
             const Dyn &y = dyn[vid];
@@ -712,7 +698,54 @@ Archive readArchiveFile(const std::string &path, const std::shared_ptr<HostRoadN
             if (const Json *x = jd.find("historyVehicleNum")) d.hHistoryVehicleNum[(size_t) dv] = (int32_t) x->asDouble();
             if (const Json *x = jd.find("historyAverageSpeed")) d.hHistoryAverageSpeed[(size_t) dv] = x->asDouble();
         }
+    };
+    auto afterVehicles = [&]() {
+        const int nV = (int) a.host.vehicles.size();
+        for (auto &sb : shadowBase) {  // the id a shadow carries belongs to the vehicle named so (its parent or an ancestor's heir)
+            auto it = vidOf.find(sb.second);
+            const int holder = it == vidOf.end() ? sb.first : it->second;
+            a.host.vehicles[(size_t) sb.first].root = holder;
+            a.host.shadowChains[holder].push_back(sb.first);
+        }
+        d.vState.assign(nV, 0);
+        vehiclesDone = true;
+    };
+    auto drainHeld = [&]() {  // whatever can now be taken in the network's order
+        for (auto it = heldDrivables.begin(); it != heldDrivables.end() && it->first == nextDv; it = heldDrivables.erase(it)) {
+            oneDrivable(nextDv, it->second);
+            ++nextDv;
+        }
+    };
+    Json root = Json::parseFileStreamed(path, {"vehicles", "drivables"}, [&](const std::string &member, const std::string &key, Json &child) {
+        if (member == "vehicles") {
+            if (vehiclesDone) throw std::runtime_error("load_from_file: two `vehicles` members");
+            oneVehicle(child);
+            return;
+        }
+        auto di = drvIndex.find(key);
+        if (di == drvIndex.end()) return;  // (a drivable this network does not have: ignored, as a DOM lookup by the network's ids would)
+        if (!vehiclesDone && !a.host.vehicles.empty()) afterVehicles();  // (the `vehicles` array has ended)
+        if (vehiclesDone && di->second == nextDv) {
+            oneDrivable(nextDv, child);
+            ++nextDv;
+            drainHeld();
+        } else {
+            heldDrivables[di->second] = std::move(child);
+        }
+    });
+    if (!vehiclesDone) afterVehicles();  // (no vehicles, or `drivables` came first in the file)
+    drainHeld();
+    if (nextDv != D) throw JsonError(net_->drivableId(nextDv) + " is required but missing in json file");
+    {
+        std::istringstream is(root.stringAt("rnd"));
+        is >> a.host.rnd;
     }
+
+    d.step = root.at("step").i;
+    d.finished = root.intAt("finishedVehicleCnt");
+    d.cumulativeTravelTime = root.numberAt("cumulativeTravelTime");
+    d.vehicleSteps = 0;
+
     const Json &flows = root.objectAt("flows");
     for (size_t f = 0; f < spawner_.flows.size(); ++f) {
         const Json &jf = flows.objectAt(spawner_.flows[f].id.c_str());

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -116,6 +117,104 @@ public:
         while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
         fclose(fp);
         return parseText(text);
+    }
+
+    // A file whose top level is an object with a few HUGE members (an Archive of a million vehicles: 1.1 GB, of which the
+    // `vehicles` array and the `drivables` object are all but a few KB): the members named in `streamed` are not materialised.
+    // Each of their children is parsed into a Json of its own, handed to `child(member, key, value)` — key = the child's name
+    // inside an object, empty inside an array — and dropped, so the reader's memory is one child, not the file's DOM (6 GB for
+    // that Archive, and tens of seconds of page faults where those are slow).  The returned object holds every other member;
+    // a streamed member is left in it as an empty container of its kind.
+    template <class F>
+    static Json parseFileStreamed(const std::string &path, std::initializer_list<const char *> streamed, F &&child) {
+        FILE *fp = fopen(path.c_str(), "rb");
+        if (!fp) throw JsonError("cannot open " + path);
+        std::string text;
+        if (fseek(fp, 0, SEEK_END) == 0) {
+            const long size = ftell(fp);
+            if (size > 0) text.reserve((size_t) size);
+            fseek(fp, 0, SEEK_SET);
+        }
+        char buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
+        fclose(fp);
+        Cursor c{text.data(), text.data() + text.size(), 1, {}, 0};
+        Json root;
+        c.ws();
+        if (c.p >= c.end || *c.p != '{') c.fail("expected an object at the top level");
+        ++c.p;
+        root.kind = Object;
+        c.ws();
+        if (c.p < c.end && *c.p == '}') return root;
+        c.depth = 1;
+        for (;;) {
+            c.ws();
+            if (c.p >= c.end || *c.p != '"') c.fail("expected member name");
+            root.members.emplace_back();
+            std::string &name = root.members.back().first;
+            Json &value = root.members.back().second;
+            c.str(name);
+            c.ws();
+            if (c.p >= c.end || *c.p != ':') c.fail("expected ':'");
+            ++c.p;
+            c.ws();
+            bool stream = false;
+            for (const char *s : streamed) stream = stream || name == s;
+            if (stream && c.p < c.end && (*c.p == '[' || *c.p == '{')) {
+                const bool isObject = *c.p == '{';
+                const char close = isObject ? '}' : ']';
+                ++c.p;
+                value.kind = isObject ? Object : Array;
+                c.ws();
+                if (c.p < c.end && *c.p == close) {
+                    ++c.p;
+                } else {
+                    c.depth = 2;
+                    std::string key;
+                    for (;;) {
+                        key.clear();
+                        if (isObject) {
+                            c.ws();
+                            if (c.p >= c.end || *c.p != '"') c.fail("expected member name");
+                            c.str(key);
+                            c.ws();
+                            if (c.p >= c.end || *c.p != ':') c.fail("expected ':'");
+                            ++c.p;
+                        }
+                        Json element;
+                        c.value(element);
+                        child(name, key, element);
+                        c.ws();
+                        if (c.p < c.end && *c.p == ',') {
+                            ++c.p;
+                            continue;
+                        }
+                        if (c.p < c.end && *c.p == close) {
+                            ++c.p;
+                            break;
+                        }
+                        c.fail(isObject ? "expected ',' or '}'" : "expected ',' or ']'");
+                    }
+                    c.depth = 1;
+                }
+            } else {
+                c.value(value);
+            }
+            c.ws();
+            if (c.p < c.end && *c.p == ',') {
+                ++c.p;
+                continue;
+            }
+            if (c.p < c.end && *c.p == '}') {
+                ++c.p;
+                break;
+            }
+            c.fail("expected ',' or '}'");
+        }
+        c.ws();
+        if (c.p != c.end) c.fail("trailing characters");
+        return root;
     }
 
     static Json parseText(const std::string &text) {

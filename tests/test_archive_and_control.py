@@ -298,3 +298,48 @@ def test_set_vehicle_route_between_a_load_and_the_next_lane(mod, ref_module, sce
     run(ref, 80)
     assert checkpoint_record(ours) == checkpoint_record(ref)
     time.sleep(0.1)
+
+
+def test_archive_file_is_streamed_whatever_its_member_order(mod, scen, workdir, tmp_path):
+    """load_from_file streams the file (`vehicles` and `drivables` child by child, never a DOM of the whole Archive — a million
+    vehicles are 1.1 GB of text).  The result must not depend on the order of the file's members: the same Archive rewritten with
+    sorted keys (`drivables` BEFORE `vehicles`, every drivable's members reordered, the drivables themselves in lexicographic, not
+    network, order) loads into exactly the same state; a file that lacks one of the network's drivables is refused by name."""
+    import json
+    from conftest import TWIN_LIB, assert_same_state, dump_json_exact
+    cfg = scen.materialize("grid_6x6", workdir)
+    eng = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    for _ in range(220):
+        eng.next_step()
+    plain = str(tmp_path / "plain.json")
+    eng.snapshot().dump(plain)
+    with open(plain) as f:
+        doc = json.load(f)
+    assert list(doc).index("vehicles") < list(doc).index("drivables") and len(doc["vehicles"]) > 500
+
+    def resorted(x):
+        if isinstance(x, dict):
+            return {k: resorted(x[k]) for k in sorted(x)}
+        if isinstance(x, list):
+            return [resorted(v) for v in x]
+        return x
+
+    shuffled = str(tmp_path / "sorted.json")
+    dump_json_exact(resorted(doc), shuffled)
+    a = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    b = mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    a.load_from_file(plain)
+    b.load_from_file(shuffled)
+    assert_same_state(a, b, "right after the loads")
+    assert a.get_vehicles(True) == b.get_vehicles(True)
+    for _ in range(60):
+        a.next_step()
+        b.next_step()
+    assert_same_state(a, b, "60 steps after the loads")
+    assert a.get_vehicle_speed() == b.get_vehicle_speed()
+    missing = dict(doc, drivables={k: v for i, (k, v) in enumerate(doc["drivables"].items()) if i != 7})
+    gone = list(doc["drivables"])[7]
+    broken = str(tmp_path / "missing.json")
+    dump_json_exact(missing, broken)
+    with pytest.raises(Exception, match=gone):
+        a.load_from_file(broken)
