@@ -682,6 +682,7 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("_set_status_reducer", &TiledEngineHost::setStatusReducer, "fn"_a)
         .def("_host_seconds", &TiledEngineHost::hostSeconds,
              "(spawner, submit) cumulative host wall seconds of this process since the last reset")
+        .def("_ahead_stats", &TiledEngineHost::aheadStats, "(batches taken from the step-ahead thread, batches made by the step itself, the thread's busy seconds)")
         .def("_profile_enable", &TiledEngineHost::profileEnable, "local_tile"_a, "on"_a)
         .def("_device_spin", &TiledEngineHost::deviceSpin, "microseconds"_a)
         .def("backend_name", &TiledEngineHost::backendName)

@@ -761,7 +761,7 @@ void TiledEngineHost::aheadLoop() {
             // before going to sleep on the condition variable (a wake-up through the kernel costs 10-30 us, as long as the job)
             const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
             while (aheadKicks_.load(std::memory_order_acquire) == aheadSeen_ && std::chrono::steady_clock::now() < until)
-                std::this_thread::yield();
+                __builtin_ia32_pause();  // (no system call in the loop: a yield per iteration costs the stepping thread its core's attention)
             std::unique_lock<std::mutex> lock(aheadMutex_);
             aheadCv_.wait(lock, [&] { return aheadStop_ || aheadState_ == kAheadWorking; });
             if (aheadStop_) return;
@@ -771,6 +771,7 @@ void TiledEngineHost::aheadLoop() {
         AheadState result = kAheadReady;
         std::string error;
         onAheadThread_.store(true, std::memory_order_relaxed);
+        const auto busy0 = std::chrono::steady_clock::now();
         try {
             spawner_.beginAhead();
             spawner_.step(step, aheadBuf_);
@@ -781,6 +782,8 @@ void TiledEngineHost::aheadLoop() {
             error = e.what();
         }
         onAheadThread_.store(false, std::memory_order_relaxed);
+        aheadBusySec_.store(aheadBusySec_.load(std::memory_order_relaxed) +
+                                std::chrono::duration<double>(std::chrono::steady_clock::now() - busy0).count(), std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> guard(aheadMutex_);
             aheadError_ = error;
@@ -808,7 +811,7 @@ void TiledEngineHost::waitAhead() {
     if (!aheadEnabled_) return;
     {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
-        while (aheadBusy_.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+        while (aheadBusy_.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
     }
     std::unique_lock<std::mutex> lock(aheadMutex_);
     aheadCv_.wait(lock, [&] { return aheadState_ != kAheadWorking; });
@@ -837,15 +840,17 @@ void TiledEngineHost::takeBatch() {
         if (aheadState_ == kAheadReady && aheadStep_ == step_) {
             spawner_.commitAhead();
             spawnBuf_.swap(aheadBuf_);
+            aheadTaken_ += 1;
             {
-        std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
-        aheadState_ = kAheadIdle;
-    }
+                std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
+                aheadState_ = kAheadIdle;
+            }
             return;
         }
         // abandoned (a priority collision), failed (raised below, where it belongs), or prepared for another step
         dropAhead();
     }
+    aheadRedone_ += 1;
     spawner_.step(step_, spawnBuf_);
 }
 

@@ -25,9 +25,11 @@
 
 #include "archive.h"
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <tuple>
 
 #include "engine_host.h"
 #include "replay.h"
@@ -237,6 +239,9 @@ public:
     // cumulative host wall time of this process since the last reset: {inside the spawner, submitting the steps (kernel
     // launches; includes back-pressure waits when the device is the bottleneck)}
     std::pair<double, double> hostSeconds() const { return std::make_pair(hostSpawnSec_, hostSubmitSec_); }
+    // the step-ahead thread: {batches it prepared that a step took, batches a step had to make itself (the first step, after a
+    // call that took a prepared step back, a priority collision), seconds the thread was busy}
+    std::tuple<int64_t, int64_t, double> aheadStats() const { return std::make_tuple(aheadTaken_, aheadRedone_, aheadBusySec_.load()); }
     void profileEnable(int localTile, bool on) { tiles_.at(localTile)->profileEnable(on); }
     void deviceSpin(long long microseconds) { for (auto &t : tiles_) t->deviceSpin(microseconds); }
     std::string backendName() const { return be_.cfx_backend_name ? be_.cfx_backend_name() : "?"; }
@@ -309,6 +314,8 @@ private:
     uint64_t aheadSeen_ = 0;
     std::atomic<bool> aheadBusy_{false};   // a request is being worked on (the caller polls it before it sleeps)
     std::atomic<bool> onAheadThread_{false};
+    int64_t aheadTaken_ = 0, aheadRedone_ = 0;
+    std::atomic<double> aheadBusySec_{0.0};
 public:
     ~TiledEngineHost();
 };

@@ -398,7 +398,7 @@ void VectorEngineHost::aheadLoop() {
             // before going to sleep on the condition variable (a wake-up through the kernel costs 10-30 us, as long as the job)
             const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
             while (aheadKicks_.load(std::memory_order_acquire) == aheadSeen_ && std::chrono::steady_clock::now() < until)
-                std::this_thread::yield();
+                __builtin_ia32_pause();  // (no system call in the loop: a yield per iteration costs the stepping thread its core's attention)
             std::unique_lock<std::mutex> lock(aheadMutex_);
             aheadCv_.wait(lock, [&] { return aheadStop_ || aheadState_ == kAheadWorking; });
             if (aheadStop_) return;
@@ -439,7 +439,7 @@ void VectorEngineHost::kickAhead(size_t step) {
 void VectorEngineHost::waitAhead() {
     {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
-        while (aheadBusy_.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+        while (aheadBusy_.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
     }
     std::unique_lock<std::mutex> lock(aheadMutex_);
     aheadCv_.wait(lock, [&] { return aheadState_ != kAheadWorking; });
@@ -481,9 +481,9 @@ void VectorEngineHost::nextStep() {
         if (aheadState_ == kAheadReady && aheadStep_ == step_) {
             for (auto &sp : spawners_) sp->commitAhead();
             {
-        std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
-        aheadState_ = kAheadIdle;
-    }
+                std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
+                aheadState_ = kAheadIdle;
+            }
             taken = true;
             spawnSec = std::chrono::duration<double>(clk::now() - t0).count();  // (the wait is what the caller paid)
         } else if (aheadState_ == kAheadReady) {
