@@ -772,10 +772,20 @@ void EngineHost::setTrafficLightPhase(const std::string &id, int phaseIndex) {
     }
     auto it = net_->interIndex.find(id);
     if (it == net_->interIndex.end()) throw std::runtime_error("Intersection '" + id + "' not found");
-    const HostInter &in = net_->inters[it->second];
+    setTrafficLightPhaseOf(it->second, phaseIndex);
+}
+
+// ... the same call for a caller that has resolved the id itself (the binding keeps a dict of the ids' Python strings)
+void EngineHost::setTrafficLightPhaseOf(int inter, int phaseIndex) {
+    if (!rlTrafficLight_) {
+        std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
+        return;
+    }
+    const HostInter &in = net_->inters.at((size_t) inter);
     if (in.isVirtual || phaseIndex < 0 || phaseIndex >= (int) in.phases.size())
-        throw std::out_of_range("phase index " + std::to_string(phaseIndex) + " out of range for intersection '" + id + "'");
-    setTrafficLightPhaseIndexed(it->second, phaseIndex);
+        throw std::out_of_range("phase index " + std::to_string(phaseIndex) + " out of range for intersection '" + in.id + "'");
+    pendingPhaseInter_.push_back(inter);
+    pendingPhaseValue_.push_back(phaseIndex);
 }
 
 void EngineHost::trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain) {

@@ -82,6 +82,7 @@ py::dict flatNetToDict(const cfa::HostRoadNet &net) {
 // in std::map (lexicographic) key order every call, like the reference's.
 struct LaneDictCache {
     py::list keys;
+    py::object interIdx;  // {intersection id: index in net().inters}, for set_tl_phase (built at its first call)
     py::dict master[2];
     std::vector<int32_t> last[2];
     bool filled[2] = {false, false};
@@ -235,6 +236,76 @@ py::dict laneDict(EngineHost &e, const std::vector<int32_t> &values, int which) 
     return py::reinterpret_steal<py::dict>(copy);
 }
 
+// Engine.set_tl_phase(intersection_id, phase_id) (reference src/cityflow.cpp:35, engine.cpp:719-725) as a vectorcall method of its
+// own.  An RL agent written for the reference calls it once per signal and step — 900 calls per step on the 30x30 grid — and
+// the generic binding path (argument records, a std::string per call, a std::map lookup by string comparison) costs ~0.35 us
+// per call: more than the whole device step for the 900 of them.  Here: the id's Python string is looked up in a dict kept with
+// the engine (its hash is cached in the string object), ~0.1 us per call.  Same arguments (positional or by the reference's
+// names), same errors (RuntimeError for an unknown intersection, IndexError for a phase out of range, TypeError otherwise).
+PyObject *engineSetTlPhase(PyObject *self, PyObject *const *args, Py_ssize_t nargs, PyObject *kwnames) {
+    try {
+        PyObject *idObj = nargs >= 1 ? args[0] : nullptr, *phObj = nargs >= 2 ? args[1] : nullptr;
+        const Py_ssize_t nkw = kwnames ? PyTuple_GET_SIZE(kwnames) : 0;
+        bool bad = nargs > 2;
+        for (Py_ssize_t i = 0; i < nkw && !bad; ++i) {
+            PyObject *name = PyTuple_GET_ITEM(kwnames, i);
+            if (PyUnicode_CompareWithASCIIString(name, "intersection_id") == 0 && !idObj) idObj = args[nargs + i];
+            else if (PyUnicode_CompareWithASCIIString(name, "phase_id") == 0 && !phObj) phObj = args[nargs + i];
+            else bad = true;
+        }
+        if (bad || !idObj || !phObj || !PyUnicode_Check(idObj) || PyFloat_Check(phObj) || !PyIndex_Check(phObj)) {
+            PyErr_SetString(PyExc_TypeError, "set_tl_phase(intersection_id: str, phase_id: int): incompatible arguments");
+            return nullptr;
+        }
+        // (the method descriptor has checked that `self` is an Engine; the generic caster's type lookup is a third of the call)
+        auto *inst = reinterpret_cast<py::detail::instance *>(self);
+        EngineHost *ep = inst->simple_layout ? static_cast<EngineHost *>(inst->simple_value_holder[0]) : nullptr;
+        EngineHost &e = ep ? *ep : py::cast<EngineHost &>(py::handle(self));
+        long ph;
+        if (PyLong_CheckExact(phObj)) {
+            ph = PyLong_AsLong(phObj);
+        } else {
+            PyObject *phIdx = PyNumber_Index(phObj);
+            if (!phIdx) return nullptr;
+            ph = PyLong_AsLong(phIdx);
+            Py_DECREF(phIdx);
+        }
+        if (ph == -1 && PyErr_Occurred()) return nullptr;
+        if (ph < INT32_MIN || ph > INT32_MAX) {
+            PyErr_SetString(PyExc_TypeError, "set_tl_phase: phase_id does not fit an int");
+            return nullptr;
+        }
+        LaneDictCache &c = bindingCacheOf(e);
+        if (!c.interIdx) {
+            py::dict d;
+            for (size_t i = 0; i < e.net().inters.size(); ++i) d[py::str(e.net().inters[i].id)] = py::int_(i);
+            c.interIdx = std::move(d);
+        }
+        PyObject *ix = PyDict_GetItemWithError(c.interIdx.ptr(), idObj);  // borrowed
+        if (!ix && PyErr_Occurred()) return nullptr;
+        if (ix) {
+            e.setTrafficLightPhaseOf((int) PyLong_AsLong(ix), (int) ph);
+        } else {  // (not an intersection: the message comes from where the reference's comes from)
+            Py_ssize_t len = 0;
+            const char *utf8 = PyUnicode_AsUTF8AndSize(idObj, &len);
+            if (!utf8) return nullptr;
+            e.setTrafficLightPhase(std::string(utf8, (size_t) len), (int) ph);
+        }
+        Py_RETURN_NONE;
+    } catch (py::error_already_set &err) {
+        err.restore();
+    } catch (const py::cast_error &err) {
+        PyErr_SetString(PyExc_TypeError, err.what());
+    } catch (const std::out_of_range &err) {
+        PyErr_SetString(PyExc_IndexError, err.what());
+    } catch (const std::exception &err) {
+        PyErr_SetString(PyExc_RuntimeError, err.what());
+    }
+    return nullptr;
+}
+PyMethodDef kEngineSetTlPhaseDef = {"set_tl_phase", (PyCFunction) (void (*)(void)) engineSetTlPhase, METH_FASTCALL | METH_KEYWORDS,
+                                    "set_tl_phase(self, intersection_id: str, phase_id: int) -> None"};
+
 // Host-only helpers (no device engine involved): used by the CPU test-suite to pin the loader and the
 // spawner against the reference.
 py::dict loadRoadnet(const std::string &path) {
@@ -325,7 +396,8 @@ double spawnBenchmark(const std::string &roadnetFile, const std::string &flowFil
 PYBIND11_MODULE(_cityflow, m) {
     m.doc() = "MI355X-native CityFlow step engine (drop-in for the reference `cityflow` module)";
 
-    py::class_<EngineHost>(m, "Engine")
+    py::class_<EngineHost> engineClass(m, "Engine");
+    engineClass
         .def(py::init<const std::string &, int>(), "config_file"_a, "thread_num"_a = 1)
         .def_static(
             "_with_backend",
@@ -365,7 +437,7 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("get_leader", &EngineHost::getLeader, "vehicle_id"_a)
         .def("get_current_time", &EngineHost::getCurrentTime)
         .def("get_average_travel_time", &EngineHost::getAverageTravelTime)
-        .def("set_tl_phase", &EngineHost::setTrafficLightPhase, "intersection_id"_a, "phase_id"_a)
+        // (set_tl_phase: engineSetTlPhase, attached below)
         .def("set_random_seed", &EngineHost::setRandomSeed, "seed"_a)
         .def("push_vehicle", &EngineHost::pushVehicle)
         .def("reset", &EngineHost::reset, "seed"_a = false)
@@ -507,6 +579,11 @@ PYBIND11_MODULE(_cityflow, m) {
                  return ids;
              })
         .def("_flat_net", [](EngineHost &e) { return flatNetToDict(e.net()); });
+    {
+        PyObject *descr = PyDescr_NewMethod((PyTypeObject *) engineClass.ptr(), &kEngineSetTlPhaseDef);
+        if (!descr) throw py::error_already_set();
+        engineClass.attr("set_tl_phase") = py::reinterpret_steal<py::object>(descr);
+    }
 
     using cfa::VectorEngineHost;
     py::class_<VectorEngineHost>(m, "VectorEngine",

@@ -217,6 +217,52 @@ def test_unknown_vehicle_errors(mod, scen, workdir):
     assert e.set_vehicle_route("flow_0_0", ["no_such_road"]) is False
 
 
+def test_set_tl_phase_call_forms_and_errors(mod, ref_module, scen, workdir):
+    """Engine.set_tl_phase is a vectorcall method of its own (an agent calls it once per signal and step): positional and
+    by the reference's argument names (src/cityflow.cpp:35), any integer type, the errors of the generic binding; and what it
+    sets is what the reference sets."""
+    import numpy as np
+    cfg = scen.materialize("grid_6x6", workdir, rlTrafficLight=True)
+    eng, ref = mod.Engine._with_backend(cfg, 1, TWIN_LIB), ref_module.Engine(cfg, 1)
+    net = eng._flat_net()
+    ids = eng.intersection_ids()
+    real = [i for i, v in zip(ids, net["inter_virtual"]) if not v]
+    virtual = [i for i, v in zip(ids, net["inter_virtual"]) if v]
+    for s in range(60):
+        for k, iid in enumerate(real):
+            ph = (s // 7 + k) % 4
+            if k % 3 == 0:
+                eng.set_tl_phase(iid, ph)
+            elif k % 3 == 1:
+                eng.set_tl_phase(intersection_id=iid, phase_id=np.int64(ph))
+            else:
+                eng.set_tl_phase(iid, phase_id=np.int32(ph))
+            ref.set_tl_phase(iid, ph)
+        eng.next_step()
+        ref.next_step()
+        assert eng.get_lane_vehicle_count() == ref.get_lane_vehicle_count(), s
+    assert eng.get_vehicle_speed() == ref.get_vehicle_speed()
+    assert eng.set_tl_phase(real[0], 1) is None
+    with pytest.raises(RuntimeError, match="'nope' not found"):
+        eng.set_tl_phase("nope", 1)
+    for bad in (99, -1):
+        with pytest.raises(IndexError, match="out of range for intersection '%s'" % real[0]):
+            eng.set_tl_phase(real[0], bad)
+    with pytest.raises(IndexError):
+        eng.set_tl_phase(virtual[0], 0)
+    for args, kw in (((real[0], 1.0), {}), ((real[0],), {}), ((real[0], 1, 2), {}), ((real[0],), {"phase": 1}), ((3, 1), {}),
+                     ((real[0], 1), {"phase_id": 2}), ((), {"phase_id": 2}), ((real[0], "1"), {})):
+        with pytest.raises(TypeError):
+            eng.set_tl_phase(*args, **kw)
+    with pytest.raises(TypeError):
+        mod.Engine.set_tl_phase(object(), real[0], 1)
+    # an engine without rlTrafficLight: the reference's message, nothing set (engine.cpp:719-722)
+    plain = mod.Engine._with_backend(scen.materialize("grid_6x6", workdir), 1, TWIN_LIB)
+    assert plain.set_tl_phase(real[0], 1) is None
+    time.sleep(0.2)
+    del ref
+
+
 def test_lane_count_dicts_are_fresh_sorted_and_consistent(mod, scen, workdir):
     """get_lane_vehicle_count / get_lane_waiting_vehicle_count: a new dict per call in std::map key order, equal to the
     array getters, unaffected by what the caller does to earlier results (the binding keeps a master copy up to date
