@@ -741,27 +741,39 @@ void EngineHost::setTrafficLightPhaseIndexed(int inter, int phase) {
     pendingPhaseValue_.push_back(phase);
 }
 
-void EngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) {
+void EngineHost::setTrafficLightPhases(const std::vector<int32_t> &phases) { setTrafficLightPhases(phases.data(), phases.size()); }
+
+// (an agent calls this every step and changes a signal every tenth: what the call costs when nothing changes is what it costs —
+// one pass over the real intersections' entries against the phases the device is known to hold, nothing allocated)
+void EngineHost::setTrafficLightPhases(const int32_t *phases, size_t n) {
     if (!rlTrafficLight_) {
         std::cerr << "please set rlTrafficLight to true to enable traffic light control" << std::endl;
         return;
     }
-    if (phases.size() != net_->inters.size()) throw std::runtime_error("set_tl_phases: expected one phase per intersection");
+    if (n != net_->inters.size()) throw std::runtime_error("set_tl_phases: expected one phase per intersection");
     flushPhases();
-    std::vector<int32_t> inters, ph;
-    for (size_t i = 0; i < phases.size(); ++i) {
-        const HostInter &in = net_->inters[i];
-        if (in.isVirtual) continue;
-        if (phases[i] < 0 || phases[i] >= (int) in.phases.size())
-            throw std::out_of_range("set_tl_phases: phase out of range for intersection '" + in.id + "'");
-        inters.push_back((int32_t) i);
-        ph.push_back(phases[i]);
+    if (knownPhase_.size() != n) knownPhase_.assign(n, -1);
+    if (realInter_.empty())
+        for (size_t i = 0; i < n; ++i)
+            if (!net_->inters[i].isVirtual) {
+                realInter_.push_back((int32_t) i);
+                realInterPhases_.push_back((int32_t) net_->inters[i].phases.size());
+            }
+    changedInter_.clear();
+    changedPhase_.clear();
+    for (size_t k = 0; k < realInter_.size(); ++k) {
+        const int32_t i = realInter_[k], p = phases[i];
+        if (p == knownPhase_[(size_t) i]) continue;  // (known = was valid)
+        if (p < 0 || p >= realInterPhases_[k])
+            throw std::out_of_range("set_tl_phases: phase out of range for intersection '" + net_->inters[(size_t) i].id + "'");
+        changedInter_.push_back(i);
+        changedPhase_.push_back(p);
     }
-    if (onlyChangedPhases(inters, ph)) {
-        const int32_t rc = be_.cfx_set_tl_phases(dev_, (int32_t) inters.size(), inters.data(), ph.data());
-        if (rc != CFX_OK) forgetPhases();
-        check(rc, "cfx_set_tl_phases");
-    }
+    if (changedInter_.empty()) return;
+    for (size_t k = 0; k < changedInter_.size(); ++k) knownPhase_[(size_t) changedInter_[k]] = changedPhase_[k];
+    const int32_t rc = be_.cfx_set_tl_phases(dev_, (int32_t) changedInter_.size(), changedInter_.data(), changedPhase_.data());
+    if (rc != CFX_OK) forgetPhases();
+    check(rc, "cfx_set_tl_phases");
 }
 
 // setTrafficLightPhase engine.cpp:719-725

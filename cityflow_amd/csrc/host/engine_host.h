@@ -140,6 +140,7 @@ public:
     std::vector<std::string> intersectionIds() const;
     void setTrafficLightPhaseIndexed(int inter, int phase);
     void setTrafficLightPhases(const std::vector<int32_t> &phases);  // [n_intersections]; virtual ones ignored
+    void setTrafficLightPhases(const int32_t *phases, size_t n);
     void trafficLightState(std::vector<int32_t> &phase, std::vector<double> &remain);
     // Lane::history as the device keeps it ("cfx": {"laneHistory": true}; cfx_get_lane_history): lane-major, oldest record first
     void laneHistory(std::vector<int32_t> &len, std::vector<int32_t> &vehicleNum, std::vector<double> &averageSpeed,
@@ -230,6 +231,7 @@ private:
     // control nothing but these calls changes a phase (TrafficLight::passTime does not run, trafficlight.cpp:29-37), so an
     // agent that sets every signal every step uploads only the ones it actually changes; forgotten on reset / load
     std::vector<int32_t> knownPhase_;
+    std::vector<int32_t> realInter_, realInterPhases_, changedInter_, changedPhase_;  // setTrafficLightPhases: the signals, scratch
     void forgetPhases() { knownPhase_.assign(knownPhase_.size(), -1); }
     // keeps of (inters, phases) what differs from knownPhase_ and records it; false: nothing left to send
     bool onlyChangedPhases(std::vector<int32_t> &inters, std::vector<int32_t> &phases);

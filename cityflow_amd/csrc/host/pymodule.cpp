@@ -457,7 +457,7 @@ PYBIND11_MODULE(_cityflow, m) {
         .def("set_tl_phase_indexed", &EngineHost::setTrafficLightPhaseIndexed, "intersection_index"_a, "phase_id"_a)
         .def("set_tl_phases",
              [](EngineHost &e, py::array_t<int32_t, py::array::c_style | py::array::forcecast> phases) {
-                 e.setTrafficLightPhases(std::vector<int32_t>(phases.data(), phases.data() + phases.size()));
+                 e.setTrafficLightPhases(phases.data(), (size_t) phases.size());
              },
              "phases"_a, "int array [len(intersection_ids())]; one asynchronous call sets every signal")
         .def("sync", &EngineHost::sync)

@@ -263,6 +263,54 @@ def test_set_tl_phase_call_forms_and_errors(mod, ref_module, scen, workdir):
     del ref
 
 
+def test_set_tl_phases_sends_what_changed_and_forgets_on_reset(mod, ref_module, scen, workdir):
+    """Engine.set_tl_phases(array): the call compares with the phases the device is known to hold and sends the difference; a
+    reset or a load makes nothing known.  Against the reference driven through set_tl_phase, over a reset and a load."""
+    import numpy as np
+    cfg = scen.materialize("grid_6x6", workdir, rlTrafficLight=True)
+    eng, ref = mod.Engine._with_backend(cfg, 1, TWIN_LIB), ref_module.Engine(cfg, 1)
+    ids = eng.intersection_ids()
+    virt = np.asarray(eng._flat_net()["inter_virtual"], dtype=bool)
+    rng = np.random.default_rng(5)
+    phases = np.zeros(len(ids), dtype=np.int32)
+
+    def both(n, change_every):
+        for s in range(n):
+            if change_every and s % change_every == 0:
+                phases[:] = rng.integers(0, 4, len(ids))
+            phases[virt] = 77  # (entries of virtual intersections are ignored, whatever they hold)
+            eng.set_tl_phases(phases)
+            for i, iid in enumerate(ids):
+                if not virt[i]:
+                    ref.set_tl_phase(iid, int(phases[i]))
+            eng.next_step()
+            ref.next_step()
+            assert eng.get_lane_vehicle_count() == ref.get_lane_vehicle_count(), s
+
+    both(40, 7)
+    arch_e, arch_r = eng.snapshot(), ref.snapshot()
+    both(20, 1)
+    eng.reset(False)
+    ref.reset(False)
+    both(30, None)  # the very phases of before the reset, never changing: they must reach the device again
+    eng.load(arch_e)
+    ref.load(arch_r)
+    both(30, None)
+    assert eng.get_vehicle_speed() == ref.get_vehicle_speed()
+    bad = phases.copy()
+    bad[np.flatnonzero(~virt)[3]] = 9
+    with pytest.raises(IndexError, match="out of range for intersection"):
+        eng.set_tl_phases(bad)
+    with pytest.raises(RuntimeError, match="one phase per intersection"):
+        eng.set_tl_phases(phases[:-1])
+    eng.set_tl_phases(phases)  # (the failed call left nothing behind)
+    eng.next_step()
+    ref.next_step()
+    assert eng.get_lane_vehicle_count() == ref.get_lane_vehicle_count()
+    time.sleep(0.2)
+    del ref
+
+
 def test_lane_count_dicts_are_fresh_sorted_and_consistent(mod, scen, workdir):
     """get_lane_vehicle_count / get_lane_waiting_vehicle_count: a new dict per call in std::map key order, equal to the
     array getters, unaffected by what the caller does to earlier results (the binding keeps a master copy up to date
