@@ -697,13 +697,27 @@ struct cfx_engine {
                           // (a tile's `active` is final only after the halo import; its mirror serves as the stale estimate that
                           // sizes the next steps' grids — mirrorValid stays false, nothing else reads it)
                           hMirror, finTicket, nStat, vt.state, slotOf, exactTimes() ? 1 : 0,
-                          lightsDone ? 1 : 0, publishTo(), finCount, tiled ? LaneHistDev{} : hist};
+                          lightsDone ? 1 : 0, publishTo(), finCount};
     }
     // tiling on the rings, mailbox transports: cfx_halo_wait leaves the import to the next step's admission launch (one launch
     // less per tile-step); anything else that looks at the state first sends it out as a kernel of its own
     bool haloImportPending = false;
     RingHaloIn pendingImport{};
-    int settle() {
+    // Lane::history on the rings: the record of a step is taken by trailing blocks of the NEXT step's action launch (RingHist,
+    // cfx_ring_kernels.h); `histPending`: the last submitted step's has not been.  settle() sends it out as a launch of its own —
+    // except for the callers that only read what the history does not touch (the per-step getters of an agent's loop).
+    bool histPending = false;
+    RingHist takeHist(int firstBlock) {
+        RingHist rh{};
+        rh.firstBlock = 0x7fffffff;
+        if (hist.num && ring && !tiled && histPending) {
+            rh.h = hist;
+            rh.firstBlock = firstBlock;
+            histPending = false;
+        }
+        return rh;
+    }
+    int settle(bool withHistory = true) {
         if (haloImportPending) {
             haloImportPending = false;
             const int n = pendingImport.h.nGhost + pendingImport.h.nImport;
@@ -711,13 +725,22 @@ struct cfx_engine {
                         sc, dHaloActiveOut);
             HIP_TRY(hipGetLastError());
         }
-        if (!commitPending) return CFX_OK;
-        commitPending = false;
-        int nStat = 1;
-        const RingCommit rk = commitArgs(activeEstimate(), true, &nStat);
-        launchNamed(PK_COMMIT, "kr_commit", kr_commit, dim3(gridStride((size_t) std::max(D, std::max(I, nMaskWords))) + nStat), dim3(kBlock),
-               rctx(true, step - 1, rcur ^ 1), rk, vt, RingHalo{});
-        HIP_TRY(hipGetLastError());
+        if (commitPending) {
+            commitPending = false;
+            int nStat = 1;
+            const RingCommit rk = commitArgs(activeEstimate(), true, &nStat);
+            launchNamed(PK_COMMIT, "kr_commit", kr_commit, dim3(gridStride((size_t) std::max(D, std::max(I, nMaskWords))) + nStat), dim3(kBlock),
+                   rctx(true, step - 1, rcur ^ 1), rk, vt, RingHalo{});
+            HIP_TRY(hipGetLastError());
+        }
+        if (withHistory && histPending) {
+            const RingHist rh = takeHist(0);
+            if (rh.h.num) {
+                hipLaunchKernelGGL(kr_lane_history, dim3(gridFor(L)), dim3(kBlock), 0, stream, rctx(), rh.h);
+                HIP_TRY(hipGetLastError());
+            }
+            histPending = false;
+        }
         return CFX_OK;
     }
     // (Re)build the rings: first use, a shorter vehicle template than the capacities were computed for, or growth.
@@ -786,8 +809,15 @@ struct cfx_engine {
     }
 
     int resetState() {
+        // Lane::history outlives Engine::reset (Lane::reset roadnet.cpp:832-835) and a load that does not carry it: the last
+        // step's record — and the commit it reads — first
+        if (histPending && ringBuilt) {
+            const int rc = settle();
+            if (rc) return rc;
+        }
         commitPending = false;  // (whatever a deferred commit would have written is overwritten below)
         haloImportPending = false;
+        histPending = false;
         HIP_TRY(hipStreamSynchronize(stream));
         if (!retired.empty() && freeRetired()) return CFX_ERR_DEVICE;
         mirrorValid = false;
@@ -1319,7 +1349,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         if (inArgs) {
             // (nothing to launch)
         } else {
-            if ((rc = e->settle())) return rc;  // (k_spawn_link looks at what the previous step's commit leaves)
+            if ((rc = e->settle(false))) return rc;  // (k_spawn_link looks at what the previous step's commit leaves)
             if ((size_t) n > e->recCap) {
                 size_t nc = std::max<size_t>((size_t) n * 2, 1024);
                 if ((rc = e->grow(&e->dRecs, 0, nc))) return rc;
@@ -1395,7 +1425,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         const bool useBig = e->cross2 >= 0 ? e->cross2 == 1 : activeEst > 240000;  // which form of the cross phase (§4)
         // This step's commit rides with the next step's admission (one launch less per step) where the step runs kr_cross,
         // which then advances the lights; the previous step's, if it is still pending, goes with this step's admission.
-        const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing;  // (Lane::history rides with the commit)  // (a caller that reads the lane counts after every step wants the commit now)
+        const bool deferCommit = e->ringMerge && !dbg && !e->tiled && !e->observing;  // (a caller that reads the lane counts after every step wants the commit now)
         // tiling: the previous step's halo import, if cfx_halo_wait left it to this launch
         const RingHaloIn hin = e->haloImportPending ? e->pendingImport : RingHaloIn{};
         e->haloImportPending = false;
@@ -1494,25 +1524,28 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                           //  25 % of headroom and never shrinks: entries beyond the launch would never take their step, unflagged)
                           e->rList, (int) std::min<size_t>(e->rListCap, (size_t) nVehBlocks * kListBlock), e->rListCount, e->sc);
                 RING_CHECK("kr_index")
-                e->launchNamed(PK_ACTION, e->tiled ? "kl_action<true>" : "kl_action", e->tiled ? kl_action<true> : kl_action<false>, dim3(nVehBlocks + nLL), dim3(kListBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
-                          (const int32_t *) e->rListCount, nVehBlocks, idxTicket);
+                const RingHist rh = e->takeHist(nVehBlocks + nLL);  // (the last step's Lane::history: trailing blocks of this launch)
+                const int nHist = rh.h.num ? (e->L + kListBlock - 1) / kListBlock : 0;
+                e->launchNamed(PK_ACTION, e->tiled ? "kl_action<true>" : "kl_action", e->tiled ? kl_action<true> : kl_action<false>, dim3(nVehBlocks + nLL + nHist), dim3(kListBlock), c, ro, jq, jobRecs, (const int4 *) e->rList,
+                          (const int32_t *) e->rListCount, nVehBlocks, idxTicket, rh);
             } else {
             G = std::min(G, Bsel);
             const int nLaneBlocks = (e->L + G - 1) / G, nLLBlocks = (e->K + Bsel - 1) / Bsel;
             // (first form: as many blocks again at the end of the grid compute the laneLinks' notify sources)
-            const dim3 grid(nLaneBlocks + 2 * nLLBlocks), block(Bsel);
+            const RingHist rh = e->takeHist(nLaneBlocks + 2 * nLLBlocks);  // (the last step's Lane::history: trailing blocks of this launch)
+            const dim3 grid(nLaneBlocks + 2 * nLLBlocks + (rh.h.num ? (e->L + Bsel - 1) / Bsel : 0)), block(Bsel);
             if (blockForm) {
                 if (e->tiled) {  // (ghost lanes: the instantiations that know about frozen proxies)
-                    if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256, true>", kr_action<256, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                    else e->launchNamed(PK_ACTION, "kr_action<512, true>", kr_action<512, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                } else if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256>", kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                else e->launchNamed(PK_ACTION, "kr_action<512>", kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                    if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256, true>", kr_action<256, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
+                    else e->launchNamed(PK_ACTION, "kr_action<512, true>", kr_action<512, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
+                } else if (Bsel == 256) e->launchNamed(PK_ACTION, "kr_action<256>", kr_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
+                else e->launchNamed(PK_ACTION, "kr_action<512>", kr_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
             } else {
                 if (e->tiled) {
-                    if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256, true>", kw_action<256, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                    else e->launchNamed(PK_ACTION, "kw_action<512, true>", kw_action<512, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                } else if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256>", kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
-                else e->launchNamed(PK_ACTION, "kw_action<512>", kw_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks);
+                    if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256, true>", kw_action<256, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
+                    else e->launchNamed(PK_ACTION, "kw_action<512, true>", kw_action<512, true>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
+                } else if (Bsel == 256) e->launchNamed(PK_ACTION, "kw_action<256>", kw_action<256>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
+                else e->launchNamed(PK_ACTION, "kw_action<512>", kw_action<512>, grid, block, c, ro, jq, jobRecs, G, nLaneBlocks, nLLBlocks, rh);
             }
             }
         }
@@ -1563,6 +1596,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->rcur ^= 1;
         e->step += 1;
         e->mirrorValid = !e->tiled;
+        e->histPending = e->hist.num && !e->tiled;  // (this step's Lane::history: with the next action launch, or settle())
         return CFX_OK;
     }
     const int64_t spare = e->tiled ? e->spareTotal : (int64_t) e->L;
@@ -1771,7 +1805,7 @@ int32_t cfx_sync(cfx_engine *e) {
     if (!e) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (!e->retired.empty()) return e->freeRetired();  // (arrays a growing vehicle table left behind: the stream is idle now)
     return CFX_OK;
@@ -1796,7 +1830,7 @@ int32_t cfx_set_tl_phase(cfx_engine *e, int32_t inter, int32_t phase) {
         return CFX_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     // TrafficLight::setPhase trafficlight.cpp:39-41 (remainDuration untouched); ordered on the stream
     HIP_TRY(hipMemcpyAsync(e->curPhase + inter, &phase, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1807,7 +1841,7 @@ int32_t cfx_set_tl_phases(cfx_engine *e, int32_t n, const int32_t *inters, const
     if (!e || n < 0 || (n && (!inters || !phases))) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     for (int i = 0; i < n; ++i)
         if (inters[i] < 0 || inters[i] >= e->I || phases[i] < 0) {
             e->err = "cfx_set_tl_phases: index out of range";
@@ -1864,7 +1898,7 @@ int32_t cfx_get_tl_state(cfx_engine *e, int32_t *phase, double *remain) {
     if (!e) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     if (phase) HIP_TRY(hipMemcpyAsync(phase, e->curPhase, e->I * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (remain) HIP_TRY(hipMemcpyAsync(remain, e->remain, e->I * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1874,7 +1908,7 @@ int32_t cfx_get_tl_state(cfx_engine *e, int32_t *phase, double *remain) {
 int32_t cfx_get_scalars(cfx_engine *e, cfx_scalars *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     (void) hipSetDevice(e->device);
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     DevScalars s;
     int rc = e->readScalars(s);
     if (rc) return rc;
@@ -1904,7 +1938,7 @@ int32_t cfx_get_lane_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     if (e->ring && !e->ringBuilt) {  // nothing has run yet
         memset(out, 0, e->L * sizeof(int32_t));
         return CFX_OK;
@@ -1924,7 +1958,7 @@ int32_t cfx_get_lane_waiting_counts(cfx_engine *e, int32_t *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     int rc;
     if ((rc = e->syncTables())) return rc;
     if (e->ring && (rc = e->ringEnsure())) return rc;
@@ -1941,7 +1975,7 @@ int32_t cfx_get_vehicles(cfx_engine *e, cfx_vehicle_view *view) {
     if (!e || !view) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     int rc;
     if ((rc = e->syncTables())) return rc;
     if (e->ring) {
@@ -2106,7 +2140,7 @@ int32_t cfx_get_vehicle_status(cfx_engine *e, int32_t first, int32_t n, uint8_t 
     auto qus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::micro>(b - a).count();
     };
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     const auto q1 = std::chrono::steady_clock::now();
     // A few bytes (the spawner's priority-collision query asks for ONE vehicle, in the middle of a run): through the engine's
     // pinned scratch — a device-to-host copy into the caller's pageable memory makes the runtime stage or pin it per call.
@@ -2137,7 +2171,7 @@ int32_t cfx_get_waiting(cfx_engine *e, int32_t capacity, int32_t *vid, int32_t *
     if (!e || !nOut) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     // The waiting FIFOs are linked lists through the vid table; walk them on the host (debug / API path).
     std::vector<int32_t> head(e->L), next((size_t) e->spawned);
     HIP_TRY(hipMemcpyAsync(head.data(), e->waitHead, e->L * 4, hipMemcpyDeviceToHost, e->stream));
@@ -2173,7 +2207,7 @@ int32_t cfx_set_vehicle_speed(cfx_engine *e, int32_t vid, double speed) {
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     uint8_t st = 0;
     HIP_TRY(hipMemcpyAsync(&st, e->vt.state + vid, 1, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2204,7 +2238,7 @@ int32_t cfx_set_vehicle_route(cfx_engine *e, int32_t vid, int32_t route) {
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     int rc = e->syncTables();
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->vt.route + vid, &route, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
@@ -2230,7 +2264,7 @@ int32_t cfx_get_vehicle(cfx_engine *e, int32_t vid, int32_t *state, int32_t *dri
     }
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     int rc = e->syncTables();
     if (rc) return rc;
     uint8_t st = 0;
@@ -2321,7 +2355,7 @@ int32_t cfx_get_custom_speeds(cfx_engine *e, int32_t capacity, double *out) {
     if (!e || !out) return CFX_ERR_INVALID;
     auto fail = [e](const std::string &m) { return e->fail(m); };
     HIP_TRY(hipSetDevice(e->device));
-    if (int rcSettle = e->settle()) return rcSettle;  // (ring layout: a commit deferred to the next step's admission)
+    if (int rcSettle = e->settle(false)) return rcSettle;  // (ring layout: a commit deferred to the next step's admission; Lane::history is not read here)
     if (e->ring) {
         int rc;
         if ((rc = e->syncTables()) || (rc = e->ringEnsure())) return rc;

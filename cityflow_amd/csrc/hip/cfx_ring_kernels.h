@@ -316,7 +316,6 @@ struct RingCommit {
     int lightsDone;  // the step's cross kernel has already advanced the lights (kr_cross with lights.on)
     int32_t *hostCnt;  // pinned host copy of the lane counts, kept up by the commit while a caller observes them (or null)
     int32_t *finCount; // [kFinShards * 32] the finisher lists' counters
-    LaneHistDev hist;  // Lane::history (num == nullptr: not kept): a lane's record is taken by the thread that commits the lane
 };
 struct CommitOut {  // what a drivable's commit leaves, for the admission that follows it in the same thread
     int touched, head, n, tailWritten;
@@ -599,9 +598,6 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 if (co.tailWritten) committed = co.tail;
             }
         }
-        // Lane::updateHistory on the committed lane (engine.cpp:429-442): its vehicles in list order, their new speeds in the
-        // generation the action phase wrote (the movers-in by this very thread just now)
-        if (isLane && k.hist.num) laneHistoryStep(k.hist, d, n, [&](int i) { return cIn.kinN[ringSlot(geo, head, i)].y; });
     }
     RingCtx c = cIn;
     if constexpr (!COMMIT) {
@@ -1376,12 +1372,31 @@ __device__ __forceinline__ void actionOneRounds(const C &c, const Out &o, const 
 // read from HBM once, coalesced.
 constexpr int kRingWave = 64;
 
+// Lane::updateHistory (engine.cpp:429-442, roadnet.cpp:900-915) of the PREVIOUS step, taken by trailing blocks of this step's
+// action launch: until this step's commit the lanes' lists (head, cnt — an admission of this step is not in them yet) and the
+// generation the action phase reads ARE the end of the previous step, nobody in this launch writes either, and the lanes'
+// threads have the whole launch to sum their speeds in: the history costs the step no launch and no link of anybody's chain.
+// (Until round 6 the lane's thread of the commit took it: +4 us on the merged admission.)  The host launches kr_lane_history
+// for a step whose successor has not been submitted when somebody asks (cfx_engine::settle).
+struct RingHist {
+    LaneHistDev h;   // (num == nullptr: not kept, or nothing pending)
+    int firstBlock;  // the launch's blocks from here on are history blocks, one thread per lane
+};
+__device__ inline void ringLaneHistory(const RingCtx &c, const LaneHistDev &h, int lane) {
+    if (lane >= c.n.L) return;
+    const int2 geo = c.ringGeo[lane];
+    const int head = c.head[lane];
+    laneHistoryStep(h, lane, c.cnt[lane], [&](int i) { return c.kin[ringSlot(geo, head, i)].y; });
+}
+
 template <int B, bool GHOST = false>
-__global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
+__global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks,
+                                                             const RingHist rh) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
     TRACE_STAMP(0);
-    if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
-        llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
+    if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase, then Lane::history
+        if (w >= rh.firstBlock) ringLaneHistory(c, rh.h, (w - rh.firstBlock) * B + t);
+        else llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
         TRACE_STAMP(4);
         return;
     }
@@ -1515,10 +1530,12 @@ __global__ CFX_KR_ACTION_BOUNDS(B) void kr_action(RingCtx c, RingOut o, JobQueue
 // large networks take more lanes per block and every wavefront walks several chunks.  The end lanes of the laneLinks that
 // leave a lane come with the lane's static tables, so the tail records behind the next laneLink are requested in round A.
 template <int B, bool GHOST = false>
-__global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks) {
+__global__ __launch_bounds__(B) void kw_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, int G, int nLaneBlocks, int nLLBlocks,
+                                                             const RingHist rh) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
-    if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
-        llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
+    if (w >= nLaneBlocks + nLLBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase, then Lane::history
+        if (w >= rh.firstBlock) ringLaneHistory(c, rh.h, (w - rh.firstBlock) * B + t);
+        else llstateRing(c, (w - nLaneBlocks - nLLBlocks) * B + t);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
@@ -1796,10 +1813,11 @@ constexpr int kListBlock = CFX_KL_BLOCK;
 #define CFX_KL_BOUNDS __launch_bounds__(kListBlock, CFX_KL_WAVES)  // (second argument: wavefronts per SIMD)
 template <bool GHOST = false>
 __global__ CFX_KL_BOUNDS void kl_action(RingCtx c, RingOut o, JobQueue q, RingJob *jobRecs, const int4 *list,
-                                                    const int32_t *listCount, int nVehBlocks, int32_t *ticket) {
+                                                    const int32_t *listCount, int nVehBlocks, int32_t *ticket, const RingHist rh) {
     const int w = (int) blockIdx.x, t = (int) threadIdx.x;
-    if (w >= nVehBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase
-        llstateRing(c, (w - nVehBlocks) * kListBlock + t);
+    if (w >= nVehBlocks) {  // trailing blocks: the per-laneLink notify sources for the cross phase, then Lane::history
+        if (w >= rh.firstBlock) ringLaneHistory(c, rh.h, (w - rh.firstBlock) * kListBlock + t);
+        else llstateRing(c, (w - nVehBlocks) * kListBlock + t);
         return;
     }
     __shared__ cfx_vehicle_template sT[kLdsTempl];
@@ -2161,11 +2179,6 @@ __global__ __launch_bounds__(kBlock) void kr_commit(RingCtx c, RingCommit k, Vid
                 }
             }
         }
-        if (d < c.n.L && k.hist.num) {
-            const int2 geo = c.ringGeo[d];
-            const int head = co.touched ? co.head : c.head[d], n = co.touched ? co.n : c.cnt[d];
-            laneHistoryStep(k.hist, d, n, [&](int i) { return c.kinN[ringSlot(geo, head, i)].y; });
-        }
     }
 }
 
@@ -2292,13 +2305,8 @@ __global__ void kr_reset(int D, int32_t *head, int32_t *cnt, int4 *scratch) {
     scratch[d] = make_int4(0, -1, -1, 0);
 }
 
-__global__ void kr_lane_history(RingCtx c, LaneHistDev h) {  // k_lane_history of cfx_kernels.h on the rings, after the commit
-    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= c.n.L) return;
-    const int2 geo = c.ringGeo[lane];
-    const int head = c.head[lane];
-    laneHistoryStep(h, lane, c.cnt[lane], [&](int i) { return c.kin[ringSlot(geo, head, i)].y; });
-}
+// Lane::history of the last committed step as a launch of its own (the action launch of the NEXT step takes it otherwise: RingHist)
+__global__ void kr_lane_history(RingCtx c, LaneHistDev h) { ringLaneHistory(c, h, blockIdx.x * blockDim.x + threadIdx.x); }
 
 __global__ void kr_lane_waiting(RingCtx c, int32_t *out) {  // Engine::getLaneWaitingVehicleCount engine.cpp:636-648
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;

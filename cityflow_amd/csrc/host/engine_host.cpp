@@ -133,7 +133,7 @@ EngineConfig readEngineConfig(const std::string &configFile) {
             if (x->find("ringCapacityPercent")) c.ringCapacityPercent = x->intAt("ringCapacityPercent");
             if (x->find("denseForm")) c.denseForm = x->intAt("denseForm");
             c.exactShadowPeek = x->boolAt("exactShadowPeek", false);
-            c.laneHistory = x->boolAt("laneHistory", false);
+            if (x->find("laneHistory")) c.laneHistory = x->boolAt("laneHistory", false) ? 1 : 0;
             if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
             c.spawnAhead = x->boolAt("spawnAhead", true);
         }
@@ -147,7 +147,7 @@ void EngineConfig::apply(cfx_config &cc) const {
     cc.interval = interval;
     cc.rl_traffic_light = rlTrafficLight ? 1 : 0;
     cc.lane_change = laneChange ? 1 : 0;
-    cc.lane_history = laneHistory ? 1 : 0;
+    cc.lane_history = laneHistory > 0 ? 1 : 0;
     cc.cross_mode = crossMode;
     cc.layout = layout;
     cc.debug_sync = debugSync;
@@ -199,7 +199,17 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
     }
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
     cfx_config cc{};
-    readEngineConfig(configFile).apply(cc);
+    {
+        // Lane::history (roadnet.cpp:900-915): an Archive carries it like the reference's (archive.cpp:286-294).  On the device it
+        // rides in spare blocks of the action launch: +0.5 us per step at 30x30 (1.2 %), where that launch is bound by its slowest
+        // chain — but +6.7 us (4.9 %) at 100x100 / 1 M vehicles, where the launch is bound by memory traffic and the lanes' threads
+        // read every vehicle's speed a second time (profiles/r06_exp_lane_history_*).  Not said in the config: kept where it is
+        // nearly free — networks up to kLaneHistoryAutoLanes lanes; "cfx": {"laneHistory": true / false} decides otherwise.
+        constexpr size_t kLaneHistoryAutoLanes = 20000;  // (the size from which the action phase takes its list form)
+        EngineConfig ec = readEngineConfig(configFile);
+        if (ec.laneHistory < 0) ec.laneHistory = net_->lanes.size() <= kLaneHistoryAutoLanes ? 1 : 0;
+        ec.apply(cc);
+    }
     laneHistory_ = cc.lane_history != 0;
     int32_t rc = be_.cfx_create(&net_->flat(), &cc, &dev_);
     if (rc != CFX_OK || !dev_) {

@@ -1,6 +1,6 @@
 """Lane::history (reference src/roadnet/roadnet.cpp:900-915, roadnet.h:305-316): the last 241 steps' {vehicle count, mean speed}
 of every lane and the two running aggregates.  Nothing in the reference can read them back (they feed the DURATION router,
-which cannot be selected) — what shows them is Archive.dump (archive.cpp:286-294).  Kept with `"cfx": {"laneHistory": true}`.
+which cannot be selected) — what shows them is Archive.dump (archive.cpp:286-294).  Kept by `Engine` unless `"cfx": {"laneHistory": false}`.
 CPU: the twin against the unmodified reference through the dumps of both; GPU: the HIP engine against the twin through the ABI."""
 import json
 import os
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import TWIN_LIB
+from conftest import TWIN_LIB, assert_hip_backend
 
 
 def history_cfg(scen, workdir, name, tag="", **kw):
@@ -67,11 +67,25 @@ def test_lane_history_twin_equals_reference(mod, ref_module, scen, workdir, tmp_
     time.sleep(0.2)
 
 
-def test_lane_history_is_off_by_default(mod, scen, workdir, tmp_path):
-    tw = mod.Engine._with_backend(scen.materialize("example_1x1", workdir), 1, TWIN_LIB)
+def test_lane_history_is_kept_unless_the_config_says_no(mod, scen, workdir, tmp_path):
+    """Engine keeps Lane::history by default (its dumps then carry what the reference's carry, archive.cpp:286-294);
+    `"cfx": {"laneHistory": false}` drops it, and the dump's history fields are empty."""
+    base = scen.materialize("example_1x1", workdir)
+    tw = mod.Engine._with_backend(base, 1, TWIN_LIB)
     for _ in range(5):
         tw.next_step()
     p = str(tmp_path / "d.json")
+    tw.snapshot().dump(p)
+    assert all(len(v[0]) == 10 for v in history_of(p, False, mod).values())
+    assert tw._lane_history()["len"].tolist() == [5] * len(tw.lane_ids())
+    c = json.load(open(base))
+    c["cfx"] = {"laneHistory": False}
+    off = base.replace(".json", "_nohistory.json")
+    with open(off, "w") as f:
+        json.dump(c, f)
+    tw = mod.Engine._with_backend(off, 1, TWIN_LIB)
+    for _ in range(5):
+        tw.next_step()
     tw.snapshot().dump(p)
     assert all(v[0] == [] and v[1] == 0 for v in history_of(p, False, mod).values())
     with pytest.raises(RuntimeError):
@@ -119,3 +133,55 @@ def test_lane_history_with_lane_change_hip_equals_twin(mod, scen, workdir):
     """two records per step (the leader / gap pass also runs between planLaneChange and getAction, engine.cpp:571-575)"""
     lane_history_body(history_cfg(scen, workdir, "example_1x1", laneChange=True), lambda c: mod.Engine(c, 1),
                       lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), 200)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [0, 10000, 20000, 30000])
+def test_lane_history_rides_with_the_next_action_launch(mod, scen, workdir, form):
+    """Ring layout, round 6: a step's record is taken by trailing blocks of the NEXT step's action launch (block form, wave form,
+    list form) or, when somebody asks first, by a launch of its own.  An agent's loop (signals set, lane counts read every step:
+    the commit is a launch of its own, the getters do not ask for the history), free-running stretches (the commit rides with
+    the next admission), resets and loads in between — the record of the last step before each must not get lost
+    (Lane::reset keeps the history, roadnet.cpp:832-835)."""
+    base = scen.materialize("grid_6x6", workdir, rlTrafficLight=True)
+    c = json.load(open(base))
+    c["cfx"] = {"laneHistory": True, "layout": "ring", "ringLanesPerWave": form}
+    cfg = base.replace(".json", "_history_form%d.json" % form)
+    with open(cfg, "w") as f:
+        json.dump(c, f)
+    hip, tw = mod.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
+    assert_hip_backend(hip)
+    n_inter = len(hip.intersection_ids())
+    rng = np.random.default_rng(form + 1)
+
+    def same(tag):
+        ha, hb = hip._lane_history(), tw._lane_history()
+        for k in ha:
+            assert np.array_equal(ha[k], hb[k]), (tag, k)
+        return ha
+
+    def both(f):
+        f(hip)
+        f(tw)
+
+    for round_ in range(6):
+        for s in range(int(rng.integers(20, 60))):  # an agent's loop
+            ph = rng.integers(0, 4, n_inter).astype(np.int32)
+            both(lambda e: e.set_tl_phases(ph))
+            both(lambda e: e.next_step())
+            assert np.array_equal(hip.get_lane_vehicle_count_array(), tw.get_lane_vehicle_count_array())
+            if s % 17 == 3:
+                assert hip.get_vehicle_count() == tw.get_vehicle_count()
+        same(("agent", round_))
+        for s in range(int(rng.integers(20, 60))):  # free-running
+            both(lambda e: e.next_step())
+        if round_ % 3 == 0:
+            both(lambda e: e.reset(False))  # (the record of the step before the reset is the reference's too)
+            both(lambda e: e.next_step())
+        elif round_ % 3 == 1:
+            arch = tw.snapshot()
+            for s in range(7):
+                both(lambda e: e.next_step())
+            both(lambda e: e.load(arch))
+        h = same(("free", round_))
+    assert h["len"].max() == 241 and h["history_vehicle_num"].sum() > 0

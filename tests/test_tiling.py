@@ -327,6 +327,15 @@ def _same_now(ref, til, where):
         assert sa[k] == sb[k], (where, k, sa[k], sb[k])
 
 
+def without_lane_history(dump):
+    """An Archive dump with Lane::history blanked the way a dump of tiles has it: tiles do not keep it (DESIGN.md section 7), one
+    engine does by default."""
+    for dv in dump["drivables"].values():
+        if "history" in dv:
+            dv.update(history=[], historyVehicleNum=0, historyAverageSpeed=0.0)
+    return dump
+
+
 def _archive_compare(mod, cfg, lib, rows, cols, tmp_path, mailboxes=False):
     """snapshot / load / dump / load_from_file on tiles: archives travel in both directions between one engine and the tiles,
     in memory and through the reference's JSON format, and the run that follows a load is the run that followed the snapshot"""
@@ -348,7 +357,7 @@ def _archive_compare(mod, cfg, lib, rows, cols, tmp_path, mailboxes=False):
     a_ref.dump(p_ref)
     a_til.dump(p_til)
     import json
-    assert json.load(open(p_ref)) == json.load(open(p_til))  # the tiles' archive IS the single engine's
+    assert without_lane_history(json.load(open(p_ref))) == json.load(open(p_til))  # the tiles' archive IS the single engine's
     after = []
     for s in range(60):
         ref.next_step()

