@@ -407,6 +407,14 @@ def pmc_traffic(kernel_names, workload):
     return None, None
 
 
+def history_note(roof, eng):
+    """Lane::history (kept by default on networks up to 20 k lanes) is taken by trailing blocks of the action launch: say so where
+    that launch is priced — their reads and writes are in `traffic` and in the launch's duration, not in the algorithmic bytes."""
+    if roof is not None and eng is not None and hasattr(eng, "_keeps_lane_history") and eng._keeps_lane_history():
+        roof["also_in_this_launch"] = ("Lane::history of the previous step (reference roadnet.cpp:900-915), one thread per lane in "
+                                       "trailing blocks: part of `traffic` and of the duration, not of the 48 B per vehicle")
+
+
 def roofline_from_profile(prof, vehicle_steps, workload_tag, note, with_traffic=True, symbols=None):
     """The car-following kernel's achieved algorithmic bandwidth from an instrumented run: `prof` = {kernel: (total ms,
     launches)} of cfx_profile_read, `vehicle_steps` = vehicles that took those steps."""
@@ -879,6 +887,7 @@ def scale_leg(job, args, n_steps):
         roof = roofline_from_profile(prof, s1["vehicle_steps"] - s0["vehicle_steps"], scen,
                                      "%d instrumented steps" % n_steps, symbols=eng._profile_symbols())
         chunk_medians(roof, chunks)
+        history_note(roof, eng)
         if args.rl_seconds > 0:
             # BASELINE configs[4] as an RL agent drives it: the same state under rlTrafficLight, every signal set, one step
             # and the per-lane counts read, every iteration (array API)
@@ -1094,6 +1103,7 @@ def main():
                 "%d instrumented steps following the timed region%s" % (args.profile_steps, " (rank 0's tile)" if tiled else ""),
                 with_traffic=not tiled, symbols=None if tiled else eng._profile_symbols())
             chunk_medians(roofline, chunks)
+            history_note(roofline, None if tiled else eng)
 
     # ---- in-run parity and the CPU baseline (rank 0; a tiled run is compared with ONE engine on rank 0's device)
     cpu, legs, parity_in_run, parity_excused, parity_detail = None, None, None, None, None

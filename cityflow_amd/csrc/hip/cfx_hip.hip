@@ -1755,22 +1755,25 @@ int32_t cfx_get_lane_history(cfx_engine *e, cfx_lane_history *out) {
     if (out->n_lanes != e->L) return e->fail("cfx_get_lane_history: n_lanes"), CFX_ERR_INVALID;
     HIP_TRY(hipSetDevice(e->device));
     if (int rcSettle = e->settle()) return rcSettle;
+    // (the rings are turned into the ABI's arrays on the device: 42 MB at 30x30, which a strided loop on the host took 20 ms over)
     const size_t L = (size_t) e->L, M = (size_t) kLaneHistoryMax;
-    std::vector<int32_t> num(M * L), head(L);
-    std::vector<double> avg(M * L);
-    HIP_TRY(hipMemcpyAsync(num.data(), e->hist.num, M * L * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(avg.data(), e->hist.avg, M * L * 8, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(head.data(), e->hist.head, L * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(out->len, e->hist.len, L * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(out->history_vehicle_num, e->hist.hNum, L * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(out->history_average_speed, e->hist.hAvg, L * 8, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    for (size_t l = 0; l < L; ++l)
-        for (int i = 0; i < out->len[l]; ++i) {
-            const size_t r = ((size_t) head[l] + (size_t) i) % M;
-            out->vehicle_num[l * M + (size_t) i] = num[r * L + l];
-            out->average_speed[l * M + (size_t) i] = avg[r * L + l];
-        }
+    int32_t *dNum = nullptr;
+    double *dAvg = nullptr;
+    if (hipMalloc((void **) &dNum, M * L * sizeof(int32_t)) != hipSuccess || hipMalloc((void **) &dAvg, M * L * sizeof(double)) != hipSuccess) {
+        (void) hipFree(dNum);
+        return e->fail("cfx_get_lane_history: no device memory for the staging arrays"), CFX_ERR_DEVICE;
+    }
+    hipLaunchKernelGGL(k_hist_export, dim3((unsigned) ((M * L + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, e->hist, dNum, dAvg);
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpyAsync(out->vehicle_num, dNum, M * L * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(out->average_speed, dAvg, M * L * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(out->len, e->hist.len, L * 4, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(out->history_vehicle_num, e->hist.hNum, L * 4, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(out->history_average_speed, e->hist.hAvg, L * 8, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    (void) hipFree(dNum);
+    (void) hipFree(dAvg);
+    HIP_TRY(he);
     return CFX_OK;
 }
 
@@ -1782,22 +1785,28 @@ int32_t cfx_set_lane_history(cfx_engine *e, const cfx_lane_history *in) {
     HIP_TRY(hipSetDevice(e->device));
     if (int rcSettle = e->settle()) return rcSettle;
     const size_t L = (size_t) e->L, M = (size_t) kLaneHistoryMax;
-    std::vector<int32_t> num(M * L, 0), head(L, 0);
-    std::vector<double> avg(M * L, 0.0);
-    for (size_t l = 0; l < L; ++l) {
+    for (size_t l = 0; l < L; ++l)
         if (in->len[l] < 0 || in->len[l] > kLaneHistoryMax) return e->fail("cfx_set_lane_history: len out of range"), CFX_ERR_INVALID;
-        for (int i = 0; i < in->len[l]; ++i) {
-            num[(size_t) i * L + l] = in->vehicle_num[l * M + (size_t) i];
-            avg[(size_t) i * L + l] = in->average_speed[l * M + (size_t) i];
-        }
+    int32_t *dNum = nullptr;
+    double *dAvg = nullptr;
+    if (hipMalloc((void **) &dNum, M * L * sizeof(int32_t)) != hipSuccess || hipMalloc((void **) &dAvg, M * L * sizeof(double)) != hipSuccess) {
+        (void) hipFree(dNum);
+        return e->fail("cfx_set_lane_history: no device memory for the staging arrays"), CFX_ERR_DEVICE;
     }
-    HIP_TRY(hipMemcpyAsync(e->hist.num, num.data(), M * L * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->hist.avg, avg.data(), M * L * 8, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->hist.head, head.data(), L * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->hist.len, in->len, L * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->hist.hNum, in->history_vehicle_num, L * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->hist.hAvg, in->history_average_speed, L * 8, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    hipError_t he = hipMemcpyAsync(dNum, in->vehicle_num, M * L * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(dAvg, in->average_speed, M * L * sizeof(double), hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->hist.len, in->len, L * 4, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->hist.hNum, in->history_vehicle_num, L * 4, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->hist.hAvg, in->history_average_speed, L * 8, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(k_hist_import, dim3((unsigned) ((M * L + kBlock - 1) / kBlock)), dim3(kBlock), 0, e->stream, e->hist, (const int32_t *) dNum,
+                           (const double *) dAvg);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    (void) hipFree(dNum);
+    (void) hipFree(dAvg);
+    HIP_TRY(he);
     return CFX_OK;
 }
 

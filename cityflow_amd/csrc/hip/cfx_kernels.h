@@ -2151,6 +2151,28 @@ __global__ void k_leader_view(StepCtx c, int32_t *leaderSlot, double *gapOut) {
 // Lane::updateHistory for every lane, as a part of Engine::threadUpdateLeaderAndGap (engine.cpp:429-442): at the end of a step,
 // and with lane change also between planLaneChange and getAction (engine.cpp:571-575) — the lane lists then hold this step's
 // admissions and shadows already (cntNow)
+// cfx_get_lane_history / cfx_set_lane_history: the ABI's arrays — lane-major, oldest record first, zeros behind a lane's last
+// record — from and to the device's record-major rings.  One thread per (record, lane), lanes fastest: the ring side coalesced.
+__global__ void k_hist_export(LaneHistDev h, int32_t *num, double *avg) {
+    const size_t q = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t) kLaneHistoryMax * h.L) return;
+    const int l = (int) (q % h.L), i = (int) (q / h.L);
+    const bool in = i < h.len[l];
+    int r = h.head[l] + i;
+    if (r >= kLaneHistoryMax) r -= kLaneHistoryMax;
+    num[(size_t) l * kLaneHistoryMax + i] = in ? h.num[(size_t) r * h.L + l] : 0;
+    avg[(size_t) l * kLaneHistoryMax + i] = in ? h.avg[(size_t) r * h.L + l] : 0.0;
+}
+__global__ void k_hist_import(LaneHistDev h, const int32_t *num, const double *avg) {  // (h.len is in place; the rings start at record 0)
+    const size_t q = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t) kLaneHistoryMax * h.L) return;
+    const int l = (int) (q % h.L), i = (int) (q / h.L);
+    const bool in = i < h.len[l];
+    h.num[(size_t) i * h.L + l] = in ? num[(size_t) l * kLaneHistoryMax + i] : 0;
+    h.avg[(size_t) i * h.L + l] = in ? avg[(size_t) l * kLaneHistoryMax + i] : 0.0;
+    if (i == 0) h.head[l] = 0;
+}
+
 __global__ void k_lane_history(StepCtx c, LaneHistDev h) {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= c.n.L) return;

@@ -116,6 +116,7 @@ public:
     double getCurrentTime() const { return step_ * interval_; }
     double getAverageTravelTime();
     void setTrafficLightPhase(const std::string &id, int phaseIndex);
+    bool keepsLaneHistory() const { return laneHistory_; }
     void setTrafficLightPhaseOf(int inter, int phaseIndex);  // the same, the id already resolved to its index in net().inters
     void setRandomSeed(int seed) {
         dropAhead();

@@ -495,6 +495,7 @@ PYBIND11_MODULE(_cityflow, m) {
                  e.waitingVehicles(v, l);
                  return py::make_tuple(toArray(v), toArray(l));
              })
+        .def("_keeps_lane_history", &EngineHost::keepsLaneHistory)
         .def("_lane_history",
              [](EngineHost &e) {  // test hook: cfx_get_lane_history; arrays [L], [L, 241], [L, 241], [L], [L]
                  std::vector<int32_t> len, num, hn;
