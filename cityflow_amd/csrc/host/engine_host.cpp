@@ -203,11 +203,14 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
         // Lane::history (roadnet.cpp:900-915): an Archive carries it like the reference's (archive.cpp:286-294).  On the device it
         // rides in spare blocks of the action launch: +0.5 us per step at 30x30 (1.2 %), where that launch is bound by its slowest
         // chain — but +6.7 us (4.9 %) at 100x100 / 1 M vehicles, where the launch is bound by memory traffic and the lanes' threads
-        // read every vehicle's speed a second time (profiles/r06_exp_lane_history_*).  Not said in the config: kept where it is
-        // nearly free — networks up to kLaneHistoryAutoLanes lanes; "cfx": {"laneHistory": true / false} decides otherwise.
+        // read every vehicle's speed a second time (profiles/r06_exp_lane_history_*); the dense layout (forced, or under lane
+        // change, where the reference takes TWO records per step) pays a launch per record: 188 -> 197 us per lane-change step.
+        // Not said in the config: kept where it is nearly free — the ring layout on networks up to kLaneHistoryAutoLanes lanes;
+        // "cfx": {"laneHistory": true / false} decides otherwise.
         constexpr size_t kLaneHistoryAutoLanes = 20000;  // (the size from which the action phase takes its list form)
         EngineConfig ec = readEngineConfig(configFile);
-        if (ec.laneHistory < 0) ec.laneHistory = net_->lanes.size() <= kLaneHistoryAutoLanes ? 1 : 0;
+        if (ec.laneHistory < 0)
+            ec.laneHistory = (net_->lanes.size() <= kLaneHistoryAutoLanes && !laneChange_ && ec.layout != CFX_LAYOUT_DENSE) ? 1 : 0;
         ec.apply(cc);
     }
     laneHistory_ = cc.lane_history != 0;

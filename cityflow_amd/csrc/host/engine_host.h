@@ -209,7 +209,7 @@ private:
     cfx_engine *dev_ = nullptr;
     double interval_ = 1.0;
     bool rlTrafficLight_ = false, laneChange_ = false, saveReplay_ = false, saveReplayInConfig_ = false;
-    bool laneHistory_ = false;  // "cfx": {"laneHistory": ...}; not said: kept on networks up to 20 k lanes
+    bool laneHistory_ = false;  // "cfx": {"laneHistory": ...}; not said: kept on the ring layout up to 20 k lanes, not with lane change
     ReplayWriter replay_;
     void updateLog();  // Engine::updateLog engine.cpp:518-554
     int seed_ = 0, threadNum_ = 1;
@@ -251,8 +251,8 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
     int crossMode = CFX_CROSS_AUTO, layout = CFX_LAYOUT_AUTO, debugSync = 0, device = -1, ringLanesPerWave = 0, ringCapacityPercent = 0, denseForm = 0;
     bool exactShadowPeek = false;  // host: Spawner::exactPeekOnly
     int laneHistory = -1;          // keep Lane::history on the device (cfx_config::lane_history): Archive dumps then carry it, as the
-                                   // reference's do.  -1 = not said: Engine keeps it on networks up to 20 k lanes (where it is nearly
-                                   // free, engine_host.cpp), VectorEngine and TiledEngine (no Archive of it) do not
+                                   // reference's do.  -1 = not said: Engine keeps it where it is nearly free (ring layout, up to 20 k
+                                   // lanes, no lane change: engine_host.cpp), VectorEngine and TiledEngine (no Archive of it) do not
     int hostThreads = -1;          // VectorEngine: worker threads for the per-environment host work (-1 auto, 0 serial)
     bool spawnAhead = true;        // Engine: run the spawner of step t+1 right after step t is handed to the device (EngineHost::nextStep)
     void apply(cfx_config &cc) const;  // interval, flags, the choices above, device (config > CITYFLOW_AMD_DEVICE > LOCAL_RANK)

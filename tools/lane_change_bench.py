@@ -31,9 +31,17 @@ for name in names:
         dt = time.perf_counter() - t0
         s1 = eng._scalars()
         key = "lane_change" if lc else "plain"
+        eng._profile_enable(True)  # (per-kernel times of 50 more steps, us per step)
+        for _ in range(50):
+            eng.next_step()
+        prof = eng._profile_read()
+        eng._profile_enable(False)
+        syms = eng._profile_symbols()
         out[key] = {"us_per_step": dt / K * 1e6, "running": s1["active_vehicle_count"],
                     "vehicle_steps_per_sec": (s1["vehicle_steps"] - s0["vehicle_steps"]) / dt,
                     "vehicles_created": s1["spawned_vehicle_count"] - s0["spawned_vehicle_count"]}
+        out[key]["kernel_us_per_step"] = {syms.get(k, k): round(ms / 50 * 1e3, 2) for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]) if n}
+        out[key]["lane_history_kept"] = eng._keeps_lane_history()
         if lc:
             st = eng._vehicle_state()
             out[key]["shadows_now"] = int((st["lc_flags"] & 1).sum())
