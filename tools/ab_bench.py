@@ -17,6 +17,9 @@ sys.argv = [sys.argv[0]]
 import bench
 from cityflow_amd import _cityflow
 cfg = bench.build_workload("/tmp/cfa_exp", 0, scenario=scenario, n_extra=int(os.environ.get("CFX_EXP_EXTRA", bench.N_EXTRA_FLOWS)))
+if os.environ.get("CFX_AB_LANE_CHANGE"):  # the lane-change step (the state is built with lane change too)
+    _c = json.load(open(cfg)); _c["laneChange"] = True
+    cfg = cfg.replace(".json", "_lc.json"); json.dump(_c, open(cfg, "w"))
 base = _cityflow.Engine(cfg, 1)
 for _ in range(int(os.environ.get("CFX_EXP_BUILD", 300))):
     base.next_step()
