@@ -388,11 +388,11 @@ void Archive::dump(const std::string &path) const {
 }
 
 // ------------------------------------------------------------------------------------------ EngineHost side
-Archive EngineHost::snapshot() {
+Archive EngineHost::snapshotImpl(bool hostState) {
     dropAhead();
     settleLaneChange();
     Archive a;
-    a.host = spawner_.saveState();
+    if (hostState) a.host = spawner_.saveState();  // (compactVehicles builds its own)
     a.net = net_;
     a.templates = spawner_.templates;
     a.routeStart = spawner_.routes.routeStart;
@@ -428,7 +428,9 @@ Archive EngineHost::snapshot() {
     // Router::iCurRoad of an archived vehicle: the Router copy constructor restarts it at route.begin() (router.cpp:11-14 — the
     // archive holds copies, Archive::copyVehiclePool) and Router::update brings it to the current road when the vehicle next
     // enters a lane; until then get_vehicle_info lists the whole route, as the reference's does after a load
-    d.rRoutePos.assign(s.routePos.size(), 0);
+    // (compactVehicles is not a load: the vehicles keep their place in their routes)
+    if (hostState) d.rRoutePos.assign(s.routePos.size(), 0);
+    else d.rRoutePos = s.routePos;
     d.rLeader = s.leader;
     d.rDis = s.dis;
     d.rSpeed = s.speed;
@@ -446,6 +448,48 @@ Archive EngineHost::snapshot() {
     waitingVehicles(d.wVid, d.wLane);
     trafficLightState(d.tlPhase, d.tlRemain);
     return a;
+}
+
+// Forget the finished vehicles (the reference frees a vehicle when it finishes, engine.cpp:296-310): the state as snapshot()
+// reads it, the vehicles that are still waiting or running renumbered 0 .. n-1 in their old order — creation order, which is
+// what breaks exact-distance ties — and loaded back through the very path Engine.load takes (cfx_load_state: the device's and
+// the CPU twin's tables are rebuilt for the vehicles of the archive).  Between two steps; nothing a caller can see changes
+// (ids, priorities, positions, counters, Lane::history), only the vehicle numbers behind the ABI — and what host and device
+// remember per vehicle CREATED goes back to what they need per vehicle ALIVE.
+void EngineHost::compactVehicles() {
+    if (laneChange_) throw std::runtime_error("compact_vehicles: not with laneChange (a shadow's id hangs on the vehicle it was copied from)");
+    Archive a = snapshotImpl(/*hostState=*/false);
+    const int nV = (int) spawner_.vehicles.size();
+    std::vector<int32_t> newOfOld((size_t) nV, -1);
+    int nLive = 0;
+    for (int v = 0; v < nV; ++v)
+        if (a.dev.vState[(size_t) v] != 2) newOfOld[(size_t) v] = nLive++;
+    auto renumber = [&](std::vector<int32_t> &vids) {
+        for (int32_t &v : vids) v = v >= 0 && v < nV ? newOfOld[(size_t) v] : -1;
+    };
+    DeviceState &d = a.dev;
+    renumber(d.rVid);
+    renumber(d.rBlocker);
+    renumber(d.rLeader);
+    renumber(d.wVid);
+    for (int32_t v : d.rVid)
+        if (v < 0) throw std::logic_error("compact_vehicles: a running vehicle counted as finished");
+    for (int32_t v : d.wVid)
+        if (v < 0) throw std::logic_error("compact_vehicles: a waiting vehicle counted as finished");
+    std::vector<uint8_t> state((size_t) nLive);
+    for (int v = 0; v < nV; ++v)
+        if (newOfOld[(size_t) v] >= 0) state[(size_t) newOfOld[(size_t) v]] = d.vState[(size_t) v];
+    d.vState.swap(state);
+    a.host = spawner_.compactedState(newOfOld, nLive);
+    // custom speeds of vehicles that are STILL waiting (cfx_state carries those of running vehicles only)
+    std::map<int32_t, double> stillWaiting;
+    for (const auto &kv : waitingCustom_)
+        if (kv.first >= 0 && kv.first < nV && newOfOld[(size_t) kv.first] >= 0 && d.vState[(size_t) newOfOld[(size_t) kv.first]] == 0)
+            stillWaiting[newOfOld[(size_t) kv.first]] = kv.second;
+    load(a);
+    for (const auto &kv : stillWaiting) check(be_.cfx_set_vehicle_speed(dev_, kv.first, kv.second), "cfx_set_vehicle_speed");
+    waitingCustom_.swap(stillWaiting);
+    vehicleCompactions_ += 1;
 }
 
 void EngineHost::load(const Archive &a) {
@@ -515,6 +559,7 @@ void EngineHost::load(const Archive &a) {
         check(be_.cfx_set_lane_history(dev_, &h), "cfx_set_lane_history");
     }
     step_ = (size_t) d.step;
+    waitingCustom_.clear();  // (compactVehicles puts back what it carries over)
     vehicleEpoch_ += 1;  // vehicle numbers of the archive replace the current ones
 }
 

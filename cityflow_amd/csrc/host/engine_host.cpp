@@ -136,6 +136,7 @@ EngineConfig readEngineConfig(const std::string &configFile) {
             if (x->find("laneHistory")) c.laneHistory = x->boolAt("laneHistory", false) ? 1 : 0;
             if (x->find("hostThreads")) c.hostThreads = x->intAt("hostThreads");
             c.spawnAhead = x->boolAt("spawnAhead", true);
+            if (x->find("compactVehicles")) c.compactVehicles = x->intAt("compactVehicles");
         }
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
@@ -193,6 +194,11 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
         // (lane change: the step's shadows draw from the generator after the step's spawns, and how many is known only when
         //  the device has scheduled them — the next step's spawner cannot run before that)
         spawnAhead_ = readEngineConfig(configFile).spawnAhead && !laneChange_;
+        {
+            const int64_t cv = readEngineConfig(configFile).compactVehicles;
+            compactAt_ = nextCompactAt_ = laneChange_ ? 0 : (cv < 0 ? (size_t) 3500000 : (size_t) cv);
+            compactAuto_ = cv < 0;
+        }
         spawner_.loadFlows(dir_ + flowFile);
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
@@ -364,6 +370,18 @@ void EngineHost::nextStep() {
         }
     } note{this, lap, step_};
     step_ += 1;
+    // The finished vehicles are forgotten once enough have been created since the last time (archive.cpp compactVehicles): the
+    // reference frees a vehicle when it finishes; here host and device remember every vehicle number until then.
+    // What it costs is proportional to the vehicles ALIVE (a snapshot and a load: ~0.15-0.3 us per vehicle), so the automatic
+    // policy waits for 32 times as many vehicle numbers as there were vehicles alive last time (and 3.5 M at least — the
+    // device's tables hold 4 M before they double): below 1 % of the run at 6x6 and 30x30, ~3 % at 100x100 / 1 M vehicles,
+    // where host and device then hold up to ~3.5 GB of tables instead of growing without bound.  An explicit
+    // "compactVehicles": N means every N vehicle numbers.
+    if (compactAt_ > 0 && spawner_.vehicles.size() >= nextCompactAt_) {
+        compactVehicles();
+        const size_t alive = spawner_.vehicles.size();
+        nextCompactAt_ = compactAuto_ ? std::max(compactAt_, 32 * alive) : alive + compactAt_;
+    }
     if (spawnAhead_) {
         // The next step's spawner, now: its records depend on nothing the device is computing (a priority that collides with
         // a vehicle the host believes alive asks the device, as always — for the state after THIS step, which is the state the
@@ -453,6 +471,8 @@ void EngineHost::reset(bool resetRnd) {
     forgetPhases();
     check(be_.cfx_reset(dev_), "cfx_reset");
     spawner_.reset(resetRnd);
+    waitingCustom_.clear();
+    nextCompactAt_ = compactAt_;
     step_ = 0;
     vehicleEpoch_ += 1;
 }
@@ -843,6 +863,7 @@ void EngineHost::setVehicleSpeed(const std::string &id, double speed) {
         if (future == -2) return;  // (its route is invalid: planRoute drops it at the next step; the speed dies with it)
         if (future >= 0) {
             check(be_.cfx_set_vehicle_speed(dev_, future, speed), "cfx_set_vehicle_speed");
+            waitingCustom_[future] = speed;
             return;
         }
     }
@@ -850,6 +871,9 @@ void EngineHost::setVehicleSpeed(const std::string &id, double speed) {
     if (vid >= 0) check(be_.cfx_get_vehicle_status(dev_, vid, 1, &st), "cfx_get_vehicle_status");
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + id + "' not found");
     check(be_.cfx_set_vehicle_speed(dev_, vid, speed), "cfx_set_vehicle_speed");
+    // (a vehicle still in its lane's waiting buffer keeps the speed for its first step; cfx_state carries custom speeds of
+    // running vehicles only, so compactVehicles hands these over itself)
+    if (st == 0) waitingCustom_[vid] = speed;
 }
 
 // Engine::setRoute engine.cpp:852-866 + Router::setRoute router.cpp:245-264

@@ -127,7 +127,12 @@ public:
     void reset(bool resetRnd);
     void setVehicleSpeed(const std::string &id, double speed);                        // engine.cpp:827-834
     bool setRoute(const std::string &vehicleId, const std::vector<std::string> &anchors);  // engine.cpp:852-866
-    Archive snapshot();                        // engine.h:177
+    Archive snapshot() { return snapshotImpl(true); }  // engine.h:177
+    // Forget the finished vehicles (archive.cpp).  Automatic, between two steps, once `compactAt_` vehicles have been created
+    // since the last time ("cfx": {"compactVehicles": N}; default 3.5 M = before the device's vehicle tables would double; 0 = never).
+    void compactVehicles();
+    size_t vehicleTableSize() const { return spawner_.vehicles.size(); }
+    int64_t vehicleCompactions() const { return vehicleCompactions_; }
     void load(const Archive &archive);         // engine.h:176
     void loadFromFile(const std::string &path);  // engine.cpp:822-825
     void setReplayLogFile(const std::string &logFile);  // engine.cpp:727-734
@@ -209,6 +214,11 @@ private:
     cfx_engine *dev_ = nullptr;
     double interval_ = 1.0;
     bool rlTrafficLight_ = false, laneChange_ = false, saveReplay_ = false, saveReplayInConfig_ = false;
+    Archive snapshotImpl(bool hostState);
+    std::map<int32_t, double> waitingCustom_;  // set_vehicle_speed on vehicles that were waiting (or not yet numbered) then
+    size_t compactAt_ = 3500000, nextCompactAt_ = 3500000;
+    bool compactAuto_ = true;
+    int64_t vehicleCompactions_ = 0;
     bool laneHistory_ = false;  // "cfx": {"laneHistory": ...}; not said: kept on the ring layout up to 20 k lanes, not with lane change
     ReplayWriter replay_;
     void updateLog();  // Engine::updateLog engine.cpp:518-554
@@ -254,6 +264,7 @@ struct EngineConfig {  // Engine::loadConfig engine.cpp:37-84
                                    // reference's do.  -1 = not said: Engine keeps it where it is nearly free (ring layout, up to 20 k
                                    // lanes, no lane change: engine_host.cpp), VectorEngine and TiledEngine (no Archive of it) do not
     int hostThreads = -1;          // VectorEngine: worker threads for the per-environment host work (-1 auto, 0 serial)
+    int64_t compactVehicles = -1;  // Engine: forget the finished vehicles once this many have been created since the last time (-1: 3.5 M; 0: never)
     bool spawnAhead = true;        // Engine: run the spawner of step t+1 right after step t is handed to the device (EngineHost::nextStep)
     void apply(cfx_config &cc) const;  // interval, flags, the choices above, device (config > CITYFLOW_AMD_DEVICE > LOCAL_RANK)
 };

@@ -206,6 +206,8 @@ void Spawner::loadFlows(const std::string &path) {
         flows.push_back(std::move(f));
     }
     flowVids.assign(flows.size(), {});
+    flowVidBase.assign(flows.size(), 0);
+    manualVidBase = 0;
     rebuildActiveFlows();
     // Size the priority table for the first simulated hour of this demand, so that it is not rebuilt (a stall of tens of
     // milliseconds at city scale) in the middle of a run; it still grows on demand after that.
@@ -475,9 +477,10 @@ void Spawner::step(size_t stepIndex, std::vector<cfx_spawn> &out) {
             prioritySet(rec.priority, vid);
             {
                 std::vector<int32_t> &tbl = rec.flow >= 0 ? flowVids[rec.flow] : manualVids;
+                const int at = rec.number - (rec.flow >= 0 ? flowVidBase[rec.flow] : manualVidBase);  // (numbers only grow: never below the base)
                 if (journal_.active) journal_.vidTables.emplace_back(rec.flow >= 0 ? rec.flow : -1, tbl.size());
-                if ((int) tbl.size() <= rec.number) tbl.resize(rec.number + 1, -1);
-                tbl[rec.number] = vid;
+                if ((int) tbl.size() <= at) tbl.resize(at + 1, -1);
+                tbl[at] = vid;
             }
             cfx_spawn s{};
             s.vid = vid;
@@ -549,16 +552,16 @@ int Spawner::vidOfId(const std::string &id) const {
     const std::string mp = "manually_pushed_";
     int n = 0;
     if (id.compare(0, mp.size(), mp) == 0) {
-        if (!number(id.substr(mp.size()), n) || n >= (int) manualVids.size()) return -1;
-        return manualVids[n];
+        if (!number(id.substr(mp.size()), n) || n < manualVidBase || n - manualVidBase >= (int) manualVids.size()) return -1;
+        return manualVids[n - manualVidBase];
     }
     if (id.compare(0, 5, "flow_") != 0) return -1;
     size_t us = id.find('_', 5);
     if (us == std::string::npos) return -1;
     int f = 0;
     if (!number(id.substr(5, us - 5), f) || !number(id.substr(us + 1), n)) return -1;
-    if (f >= (int) flowVids.size() || n >= (int) flowVids[f].size()) return -1;
-    return flowVids[f][n];
+    if (f >= (int) flowVids.size() || n < flowVidBase[f] || n - flowVidBase[f] >= (int) flowVids[f].size()) return -1;
+    return flowVids[f][n - flowVidBase[f]];
 }
 int Spawner::internRoute(
 const std::vector<int> &seq) {
@@ -575,11 +578,53 @@ Spawner::State Spawner::saveState() const {
     st.vehicles = vehicles;
     st.flowVids = flowVids;
     st.manualVids = manualVids;
+    st.flowVidBase = flowVidBase;
+    st.manualVidBase = manualVidBase;
     st.lastWaitVid = lastWaitVid_;
     st.rnd = rnd;
     st.manualCnt = manualCnt_;
     st.livePriority = livePriority_;
     st.shadowChains = shadowChains_;
+    return st;
+}
+
+Spawner::State Spawner::compactedState(const std::vector<int32_t> &newOfOld, int nLive) const {
+    State st;
+    for (const HostFlow &f : flows) st.flows.push_back(FlowDyn{f.nowTime, f.currentTime, f.cnt, f.valid});
+    auto renumber = [&newOfOld](int32_t v) { return v >= 0 && (size_t) v < newOfOld.size() ? newOfOld[(size_t) v] : -1; };
+    for (size_t v = 0; v < vehicles.size(); ++v)
+        if (renumber((int32_t) v) >= 0) {
+            VehicleRecord r = vehicles[v];
+            r.root = r.root >= 0 ? renumber(r.root) : -1;  // (a shadow's root is the id it carries: alive as long as a shadow of it is — kept below)
+            st.vehicles.push_back(r);
+            st.livePriority.set(r.priority, renumber((int32_t) v));
+        }
+    if ((int) st.vehicles.size() != nLive) throw std::logic_error("Spawner::compactedState: inconsistent renumbering");
+    // number -> vid tables: the finished front goes, the base moves up
+    auto table = [&renumber](const std::vector<int32_t> &tbl, int32_t base, std::vector<int32_t> &out, int32_t &outBase) {
+        size_t first = 0;
+        while (first < tbl.size() && renumber(tbl[first]) < 0) ++first;
+        outBase = base + (int32_t) first;
+        out.clear();
+        for (size_t i = first; i < tbl.size(); ++i) out.push_back(renumber(tbl[i]));
+    };
+    st.flowVids.resize(flowVids.size());
+    st.flowVidBase.assign(flowVids.size(), 0);
+    for (size_t f = 0; f < flowVids.size(); ++f) table(flowVids[f], flowVidBase[f], st.flowVids[f], st.flowVidBase[f]);
+    table(manualVids, manualVidBase, st.manualVids, st.manualVidBase);
+    // the last vehicle pushed to a lane's waiting buffer: one that has finished stands for "nobody" (a successor becomes the
+    // head of the queue either way: kr_admit / k_spawn_link look at the predecessor's state)
+    st.lastWaitVid = lastWaitVid_;
+    for (int32_t &v : st.lastWaitVid) v = renumber(v);
+    st.rnd = rnd;
+    st.manualCnt = manualCnt_;
+    for (const auto &kv : shadowChains_) {
+        const int32_t root = renumber(kv.first);
+        std::vector<int32_t> chain;
+        for (int32_t v : kv.second)
+            if (renumber(v) >= 0) chain.push_back(renumber(v));
+        if (root >= 0 && !chain.empty()) st.shadowChains.emplace(root, std::move(chain));
+    }
     return st;
 }
 
@@ -593,6 +638,9 @@ void Spawner::loadState(const State &st) {
     vehicles = st.vehicles;
     flowVids = st.flowVids;
     manualVids = st.manualVids;
+    flowVidBase = st.flowVidBase;
+    flowVidBase.resize(flows.size(), 0);
+    manualVidBase = st.manualVidBase;
     lastWaitVid_ = st.lastWaitVid;
     rnd = st.rnd;
     manualCnt_ = std::max(manualCnt_, st.manualCnt);  // manuallyPushCnt never goes back (engine.h:56)
@@ -612,7 +660,9 @@ void Spawner::reset(bool reseed) {
     }
     vehicles.clear();
     for (auto &v : flowVids) v.clear();
-    std::fill(manualVids.begin(), manualVids.end(), -1);
+    std::fill(flowVidBase.begin(), flowVidBase.end(), 0);
+    manualVids.clear();
+    manualVidBase = 0;
     livePriority_.clear();
     shadowChains_.clear();
     peekPriorities_.clear();

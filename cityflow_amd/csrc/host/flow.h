@@ -77,8 +77,11 @@ public:
     // by vid, since the last reset.  A deque: it grows chunk by chunk — a vector of a million 40-byte records relocates
     // tens of megabytes when it doubles, a 5-10 ms next_step() in the middle of a long run (tests/test_steady_state.py)
     std::deque<VehicleRecord> vehicles;
-    std::vector<std::vector<int32_t>> flowVids;  // [flow][per-flow number] -> vid (-1: dropped, invalid route)
-    std::vector<int32_t> manualVids;             // [manuallyPushCnt value] -> vid or -1
+    std::vector<std::vector<int32_t>> flowVids;  // [flow][per-flow number - flowVidBase[flow]] -> vid (-1: dropped, invalid route)
+    std::vector<int32_t> manualVids;             // [manuallyPushCnt value - manualVidBase] -> vid or -1
+    // numbers below the base belong to vehicles that have finished and been forgotten (compactedState)
+    std::vector<int32_t> flowVidBase;
+    int32_t manualVidBase = 0;
     std::mt19937 rnd;
 
     void init(const HostRoadNet *net, double interval, int threadNum, int seed);
@@ -139,6 +142,8 @@ public:
         std::deque<VehicleRecord> vehicles;
         std::vector<std::vector<int32_t>> flowVids;
         std::vector<int32_t> manualVids, lastWaitVid;
+        std::vector<int32_t> flowVidBase;
+        int32_t manualVidBase = 0;
         std::mt19937 rnd;
         int manualCnt = 0;
         FlatMapI32 livePriority;
@@ -146,6 +151,10 @@ public:
     };
     State saveState() const;
     void loadState(const State &st);
+    // The state with the finished vehicles forgotten and the others renumbered (newOfOld[vid] = new number, -1 = finished;
+    // ascending, so that creation order — what exact-distance ties and the lane-change walk go by — is kept): what the host
+    // remembers per vehicle is then bounded by the vehicles alive, not by the vehicles created (EngineHost::compactVehicles).
+    State compactedState(const std::vector<int32_t> &newOfOld, int nLive) const;
     int manualCount() const { return manualCnt_; }
 
     // ---- a step taken AHEAD of time.  The host of a single engine runs the spawner of step t+1 right after it has handed

@@ -496,6 +496,10 @@ PYBIND11_MODULE(_cityflow, m) {
                  return py::make_tuple(toArray(v), toArray(l));
              })
         .def("_keeps_lane_history", &EngineHost::keepsLaneHistory)
+        .def("_compact_vehicles", &EngineHost::compactVehicles,
+             "forget the finished vehicles now (automatic once \"cfx\": {\"compactVehicles\": N} vehicles have been created; default 3.5 M)")
+        .def("_vehicle_table", [](EngineHost &e) { return py::make_tuple(e.vehicleTableSize(), e.vehicleCompactions()); },
+             "(vehicle numbers the host holds, compactions so far)")
         .def("_lane_history",
              [](EngineHost &e) {  // test hook: cfx_get_lane_history; arrays [L], [L, 241], [L, 241], [L], [L]
                  std::vector<int32_t> len, num, hn;

@@ -22,9 +22,24 @@ def _config(scen, workdir, rl):
     return scen.materialize("grid_6x6", workdir, flow_file=flow, rlTrafficLight=rl)
 
 
-@pytest.mark.parametrize("rl,seed", [(True, 5), (True, 6), (False, 7)])
-def test_random_call_sequences_equal_reference(mod, ref_module, scen, workdir, rl, seed):
-    cfg = _config(scen, workdir, rl)
+def _compacting(cfg, every):
+    """The same config with `"cfx": {"compactVehicles": every}` (ignored by the reference): this engine forgets its finished
+    vehicles and renumbers the others every time that many have been created (EngineHost::compactVehicles) — which nothing a
+    caller can see may show."""
+    if not every:
+        return cfg
+    with open(cfg) as f:
+        c = json.load(f)
+    c["cfx"] = dict(c.get("cfx", {}), compactVehicles=every)
+    path = cfg.replace(".json", "_compact%d.json" % every)
+    with open(path, "w") as f:
+        json.dump(c, f)
+    return path
+
+
+@pytest.mark.parametrize("rl,seed,compact", [(True, 5, 0), (True, 6, 0), (False, 7, 0), (True, 5, 60), (False, 7, 25)])
+def test_random_call_sequences_equal_reference(mod, ref_module, scen, workdir, rl, seed, compact):
+    cfg = _compacting(_config(scen, workdir, rl), compact)
     ref, tw = ref_module.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
     rng = np.random.default_rng(seed)
     with open(os.path.join(os.path.dirname(cfg), "roadnet.json")) as f:
@@ -70,15 +85,16 @@ def test_random_call_sequences_equal_reference(mod, ref_module, scen, workdir, r
             archives = None
         assert checkpoint_record(tw) == checkpoint_record(ref), "rl %s seed %d round %d" % (rl, seed, round_)
         assert ref.get_current_time() == tw.get_current_time()
+    assert (tw._vehicle_table()[1] > 3) == bool(compact), tw._vehicle_table()
     time.sleep(0.2)  # reference destructor race (SURVEY.md §5.2)
     del ref
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14])
-def test_random_control_and_query_calls_equal_reference(mod, ref_module, scen, workdir, seed):
+@pytest.mark.parametrize("seed,compact", [(11, 0), (12, 0), (13, 0), (14, 0), (12, 30), (14, 80)])
+def test_random_control_and_query_calls_equal_reference(mod, ref_module, scen, workdir, seed, compact):
     """... with the per-vehicle calls: get_vehicle_info (every field), get_leader, get_vehicle_distance, set_vehicle_route with
     random anchors (the return value and everything that follows), push_vehicle, set_random_seed + reset(True)."""
-    cfg = _config(scen, workdir, False)
+    cfg = _compacting(_config(scen, workdir, False), compact)
     ref, tw = ref_module.Engine(cfg, 1), mod.Engine._with_backend(cfg, 1, TWIN_LIB)
     rng = np.random.default_rng(seed)
     with open(os.path.join(os.path.dirname(cfg), "roadnet.json")) as f:
@@ -140,14 +156,15 @@ def test_random_control_and_query_calls_equal_reference(mod, ref_module, scen, w
     del ref
 
 
-@pytest.mark.parametrize("interval,seed", [(0.5, 21), (0.5, 22), (1.0, 23)])
-def test_waiting_finished_and_reseeded_vehicles_equal_reference(mod, ref_module, scen, workdir, interval, seed):
+@pytest.mark.parametrize("interval,seed,compact", [(0.5, 21, 0), (0.5, 22, 0), (1.0, 23, 0), (0.5, 22, 8), (1.0, 23, 40)])
+def test_waiting_finished_and_reseeded_vehicles_equal_reference(mod, ref_module, scen, workdir, interval, seed, compact):
     """... with a step length other than 1 s, and the calls whose subject is NOT a running vehicle: a custom speed for a vehicle
     that still waits in its lane's buffer (it takes effect in its first step), queries about a vehicle that has left the
     network (both raise), a new random seed without a reset, `reset(False)` in the middle."""
     # (0.5 s: the 1x1 example; 1 s: the congested 6x6 grid, whose entry lanes have vehicles waiting)
     base = (scen.materialize("example_1x1", workdir, interval=interval, rlTrafficLight=True, seed=int(seed)) if interval != 1.0
             else _config(scen, workdir, True))
+    base = _compacting(base, compact)
     ref, tw = ref_module.Engine(base, 1), mod.Engine._with_backend(base, 1, TWIN_LIB)
     rng = np.random.default_rng(seed)
     seen = set()
