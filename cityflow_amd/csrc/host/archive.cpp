@@ -457,13 +457,23 @@ Archive EngineHost::snapshotImpl(bool hostState) {
 // (ids, priorities, positions, counters, Lane::history), only the vehicle numbers behind the ABI — and what host and device
 // remember per vehicle CREATED goes back to what they need per vehicle ALIVE.
 void EngineHost::compactVehicles() {
-    if (laneChange_) throw std::runtime_error("compact_vehicles: not with laneChange (a shadow's id hangs on the vehicle it was copied from)");
     Archive a = snapshotImpl(/*hostState=*/false);
     const int nV = (int) spawner_.vehicles.size();
+    std::vector<uint8_t> keep((size_t) nV, 0);
+    for (int v = 0; v < nV; ++v)
+        if (a.dev.vState[(size_t) v] != 2) {
+            keep[(size_t) v] = 1;
+            // lane change: an id travels along a chain of copies (the vehicle it was given to, its shadow, that one's shadow ...);
+            // whoever carries it now is found through the whole chain, so the chain stays — as rows of finished vehicles
+            const int root = spawner_.vehicles[(size_t) v].root >= 0 ? spawner_.vehicles[(size_t) v].root : v;
+            if (laneChange_)
+                for (int32_t w : spawner_.idChain(root))
+                    if (w >= 0 && w < nV) keep[(size_t) w] = 1;
+        }
     std::vector<int32_t> newOfOld((size_t) nV, -1);
     int nLive = 0;
     for (int v = 0; v < nV; ++v)
-        if (a.dev.vState[(size_t) v] != 2) newOfOld[(size_t) v] = nLive++;
+        if (keep[(size_t) v]) newOfOld[(size_t) v] = nLive++;
     auto renumber = [&](std::vector<int32_t> &vids) {
         for (int32_t &v : vids) v = v >= 0 && v < nV ? newOfOld[(size_t) v] : -1;
     };
@@ -471,6 +481,7 @@ void EngineHost::compactVehicles() {
     renumber(d.rVid);
     renumber(d.rBlocker);
     renumber(d.rLeader);
+    renumber(d.rLcPartner);
     renumber(d.wVid);
     for (int32_t v : d.rVid)
         if (v < 0) throw std::logic_error("compact_vehicles: a running vehicle counted as finished");

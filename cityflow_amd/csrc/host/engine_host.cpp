@@ -196,7 +196,7 @@ EngineHost::EngineHost(const std::string &configFile, int threadNum, const std::
         spawnAhead_ = readEngineConfig(configFile).spawnAhead && !laneChange_;
         {
             const int64_t cv = readEngineConfig(configFile).compactVehicles;
-            compactAt_ = nextCompactAt_ = laneChange_ ? 0 : (cv < 0 ? (size_t) 3500000 : (size_t) cv);
+            compactAt_ = nextCompactAt_ = cv < 0 ? (size_t) 3500000 : (size_t) cv;
             compactAuto_ = cv < 0;
         }
         spawner_.loadFlows(dir_ + flowFile);

@@ -96,13 +96,25 @@ def test_compaction_bounds_the_tables_and_changes_nothing_twin(mod, scen, workdi
     run_pair(a, b, 60, 30)
 
 
-def test_compaction_is_refused_with_lane_change_and_off_by_zero(mod, scen, workdir):
+def test_compaction_with_lane_change_and_off_by_zero(mod, scen, workdir):
+    """Lane change: an id travels along a chain of copies (vehicle, shadow, the shadow's shadow ...): the chains of the vehicles
+    alive stay whole, as rows of finished vehicles, and every id still finds who carries it (reference goldens with lane
+    change while compacting: tests/test_lane_change.py)."""
     base = scen.materialize("example_1x1", workdir, laneChange=True)
-    e = mod.Engine._with_backend(base, 1, TWIN_LIB)
-    for _ in range(30):
-        e.next_step()
-    with pytest.raises(RuntimeError, match="laneChange"):
-        e._compact_vehicles()
+    a = mod.Engine._with_backend(compacting(base, 9), 1, TWIN_LIB)
+    b = mod.Engine._with_backend(compacting(base, 0), 1, TWIN_LIB)
+    shadows = 0
+    for s in range(400):
+        a.next_step()
+        b.next_step()
+        if s % 20 == 19:
+            va, vb = visible(a), visible(b)
+            for k in va:
+                assert va[k] == vb[k], (s, k)
+            shadows += sum(v.endswith("_shadow") for vs in va["lane_vehicles"].values() for v in vs)
+            for v in va["vehicles"]:
+                assert a.get_vehicle_info(v) == b.get_vehicle_info(v), (s, v)
+    assert shadows > 0 and a._vehicle_table()[1] > 20 and a._vehicle_table()[0] < b._vehicle_table()[0] // 3
     off = mod.Engine._with_backend(compacting(scen.materialize("example_1x1", workdir), 0), 1, TWIN_LIB)
     for _ in range(400):
         off.next_step()
@@ -149,3 +161,21 @@ def test_compaction_on_the_bench_workload(mod, workdir, layout):
     sa, sb = a._scalars(), b._scalars()
     for k in ("active_vehicle_count", "finished_vehicle_count", "vehicle_steps", "cumulative_travel_time", "step"):
         assert sa[k] == sb[k], k
+
+
+@pytest.mark.gpu
+def test_compaction_with_lane_change_hip_equals_a_twin_that_never_compacts(mod, scen, workdir):
+    base = scen.materialize("example_1x1", workdir, laneChange=True)
+    a = mod.Engine(compacting(base, 11), 1)
+    assert_hip_backend(a)
+    b = mod.Engine._with_backend(compacting(base, 0), 1, TWIN_LIB)
+    shadows = 0
+    for s in range(500):
+        a.next_step()
+        b.next_step()
+        if s % 25 == 24:
+            va, vb = visible(a), visible(b)
+            for k in va:
+                assert va[k] == vb[k], (s, k)
+            shadows += sum(v.endswith("_shadow") for vs in va["lane_vehicles"].values() for v in vs)
+    assert shadows > 0 and a._vehicle_table()[1] > 20

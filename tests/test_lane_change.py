@@ -37,6 +37,23 @@ def test_twin_lane_change_matches_reference_goldens(scen, workdir, lc_golden, na
     assert lc_golden[name][str(steps[0])]["vehicle_count"] > lc_golden[name][str(steps[0])]["real_vehicles"]  # shadows alive
 
 
+@pytest.mark.parametrize("name,steps,every", [("example_1x1", [60, 200, 500], 7), ("grid_6x6", [400, 600], 150)])
+def test_twin_lane_change_matches_reference_goldens_while_it_forgets_finished_vehicles(scen, workdir, lc_golden, name, steps, every):
+    """... with `"cfx": {"compactVehicles": N}`: the finished vehicles forgotten and the others renumbered every N vehicles
+    (EngineHost::compactVehicles; an id's chain of copies stays whole) — the same goldens: ids with their "_shadow", the
+    priority order, every speed and distance."""
+    cfg = scen.materialize(name, workdir, laneChange=True)
+    with open(cfg) as f:
+        c = json.load(f)
+    c["cfx"] = dict(c.get("cfx", {}), compactVehicles=every)
+    cfg = cfg.replace(".json", "_compact.json")
+    with open(cfg, "w") as f:
+        json.dump(c, f)
+    for h in steps:
+        got = record(lcp.run("twin", cfg, h))
+        assert got == lc_golden[name][str(h)], (name, h)
+
+
 def test_twin_lane_change_matches_reference_live(scen, workdir):
     if not os.path.exists(os.path.join(REF_DIR, "libmonotonic_new.so")):
         pytest.skip("oracle/_ref reference build not present")
