@@ -357,6 +357,17 @@ template <int N> struct SpawnBatchT {
 };
 using SpawnBatch = SpawnBatchT<kAdmitRecs>;
 using SpawnBatchBig = SpawnBatchT<kAdmitRecsBig>;
+// More records than the arguments hold (batched environments: 16 x 30x30 makes ~2 000 a step): the same columns, sorted by
+// lane, in a pinned host buffer the admission kernel reads itself, and for every block of kBlock lanes where its lanes'
+// records begin — a block stages its own few records, not everybody's (kr_admit; round 6: instead of k_spawn_link + a commit
+// launch of its own)
+struct SpawnBatchMem {
+    int n, firstNewVid;
+    double enterTime;
+    const int32_t *lane, *prevWait, *route, *priority, *firstNext, *templ, *vidOff;
+    const int32_t *blockOff;  // [nLaneBlocks + 1]; blockOff[0] = the records without a lane here (lane -1: rows only)
+    int nLaneBlocks;
+};
 
 // Vehicles on drivable d as phases 3/4 see them.  cnt[] is the committed count; a lane's admission of THIS step
 // (Engine::handleWaiting, phase 2) is not folded into it until the compaction (k_scan) — it is the flag

@@ -145,6 +145,14 @@ struct cfx_engine {
     bool stageBusy[kStages] = {false, false, false, false};
     size_t stageCap = 0;
     int stageIdx = 0;
+    // ring layout, more spawn records than kr_admit's arguments hold: the batch's columns in pinned memory (SpawnBatchMem)
+    int32_t *hMemStage[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t memStageEvent[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    bool memStageBusy[kStages] = {false, false, false, false};
+    size_t memStageWords = 0;
+    int memStageIdx = 0;
+    std::vector<uint8_t> memSeen;
+    std::vector<int32_t> memBucket, memCursor, memOrder;
     int32_t *hPhaseStage[kStages] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t phaseStageEvent[kStages] = {nullptr, nullptr, nullptr, nullptr};
     bool phaseStageBusy[kStages] = {false, false, false, false};
@@ -920,6 +928,8 @@ void cfx_destroy(cfx_engine *e) {
     for (hipEvent_t ev : e->evPool) (void) hipEventDestroy(ev);
     for (int i = 0; i < cfx_engine::kStages; ++i) {
         if (e->hStage[i]) (void) hipHostFree(e->hStage[i]);
+        if (e->hMemStage[i]) (void) hipHostFree(e->hMemStage[i]);
+        if (e->memStageEvent[i]) (void) hipEventDestroy(e->memStageEvent[i]);
         if (e->stageEvent[i]) (void) hipEventDestroy(e->stageEvent[i]);
         if (e->hPhaseStage[i]) (void) hipHostFree(e->hPhaseStage[i]);
         if (e->phaseStageEvent[i]) (void) hipEventDestroy(e->phaseStageEvent[i]);
@@ -1281,6 +1291,9 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
     SpawnBatchBig batch;  // (the records go with the admission kernel's arguments: up to kAdmitRecs, kd_admit up to kAdmitRecsBig)
     batch.n = 0;
     batch.firstNewVid = 0;
+    SpawnBatchMem memBatch{};  // ... or, more of them on the ring layout, in pinned memory
+    bool inMem = false;
+    int memStageUsed = -1;
     // (the ring layout too: more records than the small batch holds kept the step from riding its commit with the next
     // admission, and cost a launch of their own; a step with up to kAdmitRecs records runs the small instantiation as before)
     const int batchRoom = ((e->useTails() && (e->denseForm & 4)) || e->ring) ? kAdmitRecsBig : kAdmitRecs;
@@ -1346,7 +1359,92 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
                 batch.n = 0;
             }
         }
-        if (inArgs) {
+        // ring layout, more records than the arguments hold (batched environments): the columns go into pinned memory, sorted
+        // by lane, with the offsets of every block of lanes — kr_admit reads its own lanes' records from there (SpawnBatchMem)
+        const int nLaneBlocks = (e->L + kBlock - 1) / kBlock;
+        if (!inArgs && e->ring && n > batchRoom && customNow.empty() && !e->cfg.debug_sync) {
+            inMem = true;
+            const int64_t base = e->spawned;
+            const double t0 = recs[0].enter_time;
+            // a counting sort by block of lanes (bucket 0: the records without a lane here), then each block's few records by
+            // lane — the kernel looks a lane's records up by bisection; a lane's own records may come in any order
+            e->memSeen.assign((size_t) n, 0);
+            e->memBucket.assign((size_t) nLaneBlocks + 2, 0);
+            for (int i = 0; inMem && i < n; ++i) {
+                const int64_t off = (int64_t) recs[i].vid - base;
+                inMem = off >= 0 && off < n && !e->memSeen[(size_t) off] && recs[i].lane >= -1 && recs[i].lane < e->L &&
+                        recs[i].enter_time == t0;
+                if (inMem) {
+                    e->memSeen[(size_t) off] = 1;  // (every vehicle number once)
+                    e->memBucket[(size_t) (recs[i].lane < 0 ? 0 : 1 + recs[i].lane / kBlock) + 1] += 1;
+                }
+            }
+        }
+        if (inMem) {
+            for (int q = 0; q <= nLaneBlocks; ++q) e->memBucket[(size_t) q + 1] += e->memBucket[(size_t) q];  // bucket q starts at [q]
+            e->memOrder.resize((size_t) n);
+            e->memCursor.assign(e->memBucket.begin(), e->memBucket.end() - 1);
+            for (int i = 0; i < n; ++i) e->memOrder[(size_t) e->memCursor[(size_t) (recs[i].lane < 0 ? 0 : 1 + recs[i].lane / kBlock)]++] = i;
+            for (int q = 1; q <= nLaneBlocks; ++q) {
+                int32_t *const o = e->memOrder.data();
+                const int from = e->memBucket[(size_t) q], to = e->memBucket[(size_t) q + 1];
+                if (to - from > 24) {
+                    std::stable_sort(o + from, o + to, [recs](int x, int y) { return recs[x].lane < recs[y].lane; });
+                } else {
+                    for (int j = from + 1; j < to; ++j) {
+                        const int x = o[j], lx = recs[x].lane;
+                        int i = j;
+                        for (; i > from && recs[o[i - 1]].lane > lx; --i) o[i] = o[i - 1];
+                        o[i] = x;
+                    }
+                }
+            }
+            const size_t words = (size_t) 7 * (size_t) n + (size_t) nLaneBlocks + 1;
+            if (words > e->memStageWords) {
+                e->stallCause |= CFX_STALL_STAGE_GROW;
+                HIP_TRY(hipStreamSynchronize(st));
+                const size_t nc = std::max<size_t>(words * 2, 4096);
+                for (int i = 0; i < cfx_engine::kStages; ++i) {
+                    if (e->hMemStage[i]) HIP_TRY(hipHostFree(e->hMemStage[i]));
+                    e->hMemStage[i] = nullptr;
+                    HIP_TRY(hipHostMalloc((void **) &e->hMemStage[i], nc * sizeof(int32_t), hipHostMallocDefault));
+                    if (!e->memStageEvent[i]) HIP_TRY(hipEventCreateWithFlags(&e->memStageEvent[i], hipEventDisableTiming));
+                    e->memStageBusy[i] = false;
+                }
+                e->memStageWords = nc;
+            }
+            const int si = e->memStageIdx;
+            e->memStageIdx = (si + 1) % cfx_engine::kStages;
+            if (e->memStageBusy[si]) HIP_TRY(hipEventSynchronize(e->memStageEvent[si]));
+            int32_t *const w = e->hMemStage[si];
+            int32_t *const cLane = w, *const cPrev = w + n, *const cRoute = w + 2 * (size_t) n, *const cPrio = w + 3 * (size_t) n,
+                           *const cNext = w + 4 * (size_t) n, *const cTempl = w + 5 * (size_t) n, *const cOff = w + 6 * (size_t) n,
+                           *const cBlock = w + 7 * (size_t) n;
+            for (int j = 0; j < n; ++j) {
+                const cfx_spawn &r = recs[e->memOrder[(size_t) j]];
+                cLane[j] = r.lane;
+                cPrev[j] = r.prev_wait;
+                cRoute[j] = r.route;
+                cPrio[j] = r.priority;
+                cNext[j] = e->firstNextOf(r.lane, r.route);
+                cTempl[j] = r.templ;
+                cOff[j] = (int32_t) (r.vid - e->spawned);
+            }
+            for (int q = 0; q <= nLaneBlocks; ++q) cBlock[q] = e->memBucket[(size_t) q + 1];  // block q's records: bucket q + 1
+            memBatch.n = (int) n;
+            memBatch.firstNewVid = (int) e->spawned;
+            memBatch.enterTime = recs[0].enter_time;
+            memBatch.lane = cLane;
+            memBatch.prevWait = cPrev;
+            memBatch.route = cRoute;
+            memBatch.priority = cPrio;
+            memBatch.firstNext = cNext;
+            memBatch.templ = cTempl;
+            memBatch.vidOff = cOff;
+            memBatch.blockOff = cBlock;
+            memBatch.nLaneBlocks = nLaneBlocks;
+            memStageUsed = si;
+        } else if (inArgs) {
             // (nothing to launch)
         } else {
             if ((rc = e->settle(false))) return rc;  // (k_spawn_link looks at what the previous step's commit leaves)
@@ -1433,17 +1531,26 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
             e->commitPending = false;
             int nStatPrev = 1;
             const RingCommit rkPrev = e->commitArgs(activeEst, true, &nStatPrev);
-            if (batch.n > kAdmitRecs)
+            if (inMem)
+                e->launchNamed(PK_ADMIT, "kr_admit<true, kBlock, SpawnBatchMem>", kr_admit<true, kBlock, SpawnBatchMem>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
+                          e->admitStep, e->waitHead, e->vt, e->sc, memBatch, rkPrev, RingHaloIn{});
+            else if (batch.n > kAdmitRecs)
                 e->launchNamed(PK_ADMIT, "kr_admit<true, kAdmitRecsBig>", kr_admit<true, kAdmitRecsBig>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
                           e->admitStep, e->waitHead, e->vt, e->sc, batch, rkPrev, RingHaloIn{});
             else
                 e->launchNamed(PK_ADMIT, "kr_admit<true>", kr_admit<true>, dim3(gridFor(e->D) + nStatPrev), dim3(kBlock), e->rctx(true, e->step - 1, e->rcur ^ 1),
                           e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), rkPrev, RingHaloIn{});
         } else {
-            if (batch.n > kAdmitRecs)
+            if (inMem)
+                e->launchNamed(PK_ADMIT, "kr_admit<false, kBlock, SpawnBatchMem>", kr_admit<false, kBlock, SpawnBatchMem>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, memBatch, RingCommit{}, hin);
+            else if (batch.n > kAdmitRecs)
                 e->launchNamed(PK_ADMIT, "kr_admit<false, kAdmitRecsBig>", kr_admit<false, kAdmitRecsBig>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, batch, RingCommit{}, hin);
             else
                 e->launchNamed(PK_ADMIT, "kr_admit<false>", kr_admit<false>, dim3(gridFor(e->D)), dim3(kBlock), c, e->admitStep, e->waitHead, e->vt, e->sc, smallBatch(), RingCommit{}, hin);
+        }
+        if (memStageUsed >= 0) {  // (the kernel reads the pinned buffer itself: free again when this launch is through)
+            HIP_TRY(hipEventRecord(e->memStageEvent[memStageUsed], st));
+            e->memStageBusy[memStageUsed] = true;
         }
         RING_CHECK("kr_admit")
         RingJob *const jobRecs = useBig ? nullptr : e->rJobRecs;  // k_cross2 starts from the slots: no job records then

@@ -553,11 +553,22 @@ __global__ void kr_halo_import(RingCtx c, HaloDev h, HaloIO io, VidTable vt, Dev
 // admission; its statistics blocks at the end of the grid).  `cIn` is then the context of the step being committed and the
 // admission runs on the next step's view of it.  What a lane's admission reads of the commit is what its own thread wrote —
 // its tail, its count, its queue — except the lights, which the cross kernel of the committed step has already advanced.
-template <bool COMMIT, int NB = kAdmitRecs>  // NB: spawn records the arguments hold (kAdmitRecsBig on large networks, as kd_admit)
+// NB: spawn records the arguments hold (kAdmitRecsBig on large networks, as kd_admit) — or, with Batch = SpawnBatchMem (any
+// number of records, in pinned host memory), the records of ONE block's lanes that are staged in LDS
+template <bool COMMIT, int NB = kAdmitRecs, class Batch = SpawnBatchT<NB>>
 __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitStep, int32_t *waitHead, VidTable vt, DevScalars *sc,
-                                                   const SpawnBatchT<NB> batch, const RingCommit k, const RingHaloIn hin) {
+                                                   const Batch batch, const RingCommit k, const RingHaloIn hin) {
+    constexpr bool kMem = std::is_same<Batch, SpawnBatchMem>::value;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     const bool isLane = d < cIn.n.L, inRange = d < cIn.n.L + cIn.n.K;
+    // (records in host memory: where this block's lanes' records lie — a trip over the link, requested before everything else)
+    int b0 = 0, b1 = 0;
+    if constexpr (kMem) {
+        if ((int) blockIdx.x < batch.nLaneBlocks) {
+            b0 = batch.blockOff[blockIdx.x];
+            b1 = batch.blockOff[blockIdx.x + 1];
+        }
+    }
     // what the admission needs and the commit in front of it leaves alone — or changes through this very thread, which then
     // knows the new value: requested here, before the commit's own chain of loads, so that the two overlap
     TailRec committed{};
@@ -635,7 +646,17 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
     const cfx_vehicle_template *tv = c.t.templ;
     const int nRecs = batch.n, firstNewVid = batch.firstNewVid;
     if (threadIdx.x == 0) sAdmitted = 0;
-    for (int i = threadIdx.x; i < nRecs; i += blockDim.x) sLane[i] = batch.lane[i];
+    if constexpr (kMem) {
+        for (int i = threadIdx.x; i < b1 - b0 && i < NB; i += blockDim.x) sLane[i] = batch.lane[b0 + i];
+    } else {
+        for (int i = threadIdx.x; i < nRecs; i += blockDim.x) sLane[i] = batch.lane[i];
+    }
+    // the lane of record j / the records this thread's lane can be found among
+    auto laneOfRec = [&](int j) {
+        if constexpr (kMem) return j - b0 < NB ? sLane[j - b0] : batch.lane[j];
+        else return sLane[j];
+    };
+    const int recLo = kMem ? b0 : 0, recHi = kMem ? b1 : nRecs;
     if (c.t.nTempl <= kLdsTempl) {
         const int nd = c.t.nTempl * (int) (sizeof(cfx_vehicle_template) / sizeof(double));
         const double *src = (const double *) c.t.templ;
@@ -668,8 +689,8 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
     if (nRecs > 0) {
         // the vehicle table of the new vehicles (k_spawn_link): block 0.  Nobody reads these rows in this kernel — a vehicle
         // that is admitted in the step it appears in is taken from its record
-        if (blockIdx.x == 0)
-            for (int i = threadIdx.x; i < nRecs; i += blockDim.x) {
+        auto writeRows = [&](int from, int to) {
+            for (int i = from + (int) threadIdx.x; i < to; i += blockDim.x) {
                 const int v = firstNewVid + batch.vidOff[i];
                 vt.priority[v] = batch.priority[i];
                 vt.templ[v] = batch.templ[i];
@@ -679,18 +700,24 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 vt.pendingCustom[v] = 0;
                 vt.firstNext[v] = batch.firstNext[i];
             }
+        };
+        if constexpr (kMem) {  // every block its own lanes' records; block 0 also the ones without a lane here
+            writeRows(blockIdx.x == 0 ? 0 : b0, b1);
+        } else {
+            if (blockIdx.x == 0) writeRows(0, nRecs);
+        }
         if (isLane) {
             // FIFO append (Lane::pushWaitingVehicle roadnet.h:365-367; nextWait[] of a new vehicle was pre-set to -1): this
             // lane's records, in any order — each hangs behind its predecessor, or becomes the head where the predecessor
             // has left the queue
-            int lo = 0, hi = nRecs;  // first record of this lane
+            int lo = recLo, hi = recHi;  // first record of this lane
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (sLane[mid] < d) lo = mid + 1;
+                if (laneOfRec(mid) < d) lo = mid + 1;
                 else hi = mid;
             }
             int headRec = -1;
-            for (int j = lo; j < nRecs && sLane[j] == d; ++j) {
+            for (int j = lo; j < recHi && laneOfRec(j) == d; ++j) {
                 const int pv = batch.prevWait[j], v = firstNewVid + batch.vidOff[j];
                 bool becomesHead = pv < 0;
                 if (pv >= firstNewVid) vt.nextWait[pv] = v;      // predecessor in this very batch: certainly still queued
@@ -710,7 +737,7 @@ __global__ __launch_bounds__(kBlock) void kr_admit(RingCtx cIn, int32_t *admitSt
                 waitHead[d] = w;
             }
             if (w >= 0)  // whoever was hung behind the head just now (this thread's own store: taken from the record)
-                for (int j = lo; j < nRecs && sLane[j] == d; ++j)
+                for (int j = lo; j < recHi && laneOfRec(j) == d; ++j)
                     if (batch.prevWait[j] == w) nextWait = firstNewVid + batch.vidOff[j];
         }
     }

@@ -142,6 +142,30 @@ def test_congested_dense_grid_equals_twin(mod, scen, workdir):
     assert hip.get_vehicle_count() > 3000
 
 
+def test_more_spawn_records_than_the_arguments_hold_equals_twin(mod, scen, workdir):
+    """1 500 flows at interval 1 on the 6x6 grid: > 1 024 spawn records in EVERY step, more than the admission kernel's
+    arguments hold (kAdmitRecsBig).  On the ring layout they travel in pinned memory, sorted by lane, each block of lanes
+    reading its own (SpawnBatchMem, kr_admit; Flow::nextStep flow.cpp:6-22 + Lane::pushWaitingVehicle roadnet.h:365-367 +
+    Engine::handleWaiting engine.cpp:497-520 are what it restates) — the commit keeps riding with the admission.  Every
+    field against the twin, waiting buffers included; the kernel that ran is asked for by name."""
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_many.json"), 1500, seed=31,
+                            interval=1.0, base_flow=os.path.join(d, "flow.json"), end_time=40)
+    hip, tw = _pair(mod, scen.materialize("grid_6x6", workdir, flow_file=flow))
+    for s in range(120):
+        hip.next_step()
+        tw.next_step()
+        if s < 6 or s % 5 == 4:
+            assert_same_state(hip, tw, "many records, step %d" % (s + 1))
+            (wa, la), (wb, lb) = hip._waiting(), tw._waiting()
+            assert np.array_equal(wa, wb) and np.array_equal(la, lb), s
+        if s == 20:
+            assert hip._scalars()["spawned_vehicle_count"] > 21 * 1024
+            assert "SpawnBatchMem" in hip._profile_symbols()["k_admit"], hip._profile_symbols()
+    assert hip._scalars()["finished_vehicle_count"] > 0
+
+
 def test_conservation_at_benchmark_scale(mod, scen, workdir):
     """Size-independent properties on the 30x30 benchmark workload (no oracle needed at this size)."""
     base = scen.materialize("grid_30x30", workdir)

@@ -51,6 +51,8 @@ for R in rs:
                       "env_steps_per_sec": K * R / dt, "vehicle_steps_per_sec": vs / dt,
                       "k_action_us": act_ms / act_n * 1e3, "k_action_GBps": gbs, "k_action_frac_of_8TBps": gbs / 8000.0,
                       "kernel_us": {k: round(ms / max(n, 1) * 1e3, 1) for k, (ms, n) in prof.items()},
+                      "kernel_launches_in_50_steps": {k: n for k, (ms, n) in prof.items() if n},
+                      "kernel_us_per_step": round(sum(ms for ms, n in prof.values()) / 50 * 1e3, 1),
                       "host_us_per_step": {k: round((b - a) / K * 1e6, 1) for k, a, b in zip(("spawn", "translate", "submit", "ahead_thread"), h0, h1)},
                       "cfx": os.environ.get("CFX_VEC_CFX"),
                       "load_s": round(t_load, 1)}), flush=True)
