@@ -237,16 +237,22 @@ struct LcNeighbour {
 constexpr int kLcSegItems = 64;
 constexpr int kLcSchedStage = 384;  // slots of one road's lanes kept in LDS
 constexpr int kLcSchedLanes = 8;    // lanes of one road whose layout is kept in LDS
+constexpr int kLcSchedSegs = 24;    // segments per lane for which the lanes' segment runs are tabulated (more: searched per candidate)
 __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, const int32_t *vPriority) {
     __shared__ int localRec[kLcRoadInserts];  // global record indices of this road's shadows so far ...
     __shared__ int insLane[kLcRoadInserts], insSeg[kLcRoadInserts], insAnchor[kLcRoadInserts], insParent[kLcRoadInserts];
     __shared__ double insDis[kLcRoadInserts], insSeq[kLcRoadInserts];  // ... and what later candidates read of them
     __shared__ int candVid[kLcRoadCand], candSlot[kLcRoadCand], candKey[kLcRoadCand];
+    // what a candidate's turn reads of its OWN vehicle-table rows and nobody changes during the walk: all candidates' at once
+    __shared__ int candTarget[kLcRoadCand], candPrio[kLcRoadCand];
     __shared__ int itemRef[kLcSegItems];  // >= 0 existing index in the lane; < 0: -(local shadow index + 1)
     __shared__ double itemDis[kLcSegItems];
     __shared__ double stDis[kLcSchedStage], stSpeed[kLcSchedStage], stLen[kLcSchedStage], stNegAcc[kLcSchedStage];
     __shared__ int stVid[kLcSchedStage], stSeg[kLcSchedStage], stDrv[kLcSchedStage];
     __shared__ int lnStart[kLcSchedLanes], lnCnt[kLcSchedLanes], lnSegs[kLcSchedLanes];
+    // lnRun[lane][g]: the first list index of the lane whose segment number is < g (the lane's count if there is none)
+    __shared__ int lnRun[kLcSchedLanes][kLcSchedSegs + 1];
+    __shared__ int sRunsOff;
     const int road = blockIdx.x;
     if (road >= c.n.R) return;
     const LcDev &lc = c.lc;
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
             lnSegs[tid] = lc.laneNumSegs[l0 + tid];
         }
     }
+    if (tid == 0) sRunsOff = 0;
     KSTAMP(9, 1);
     const bool tooMany = nListed > kLcRoadCand;
     const int nAll = *lc.candAllCount;
@@ -290,8 +297,32 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
         const int2 e = lc.roadCandList[(size_t) road * kLcRoadCand + tid];
         candVid[tid] = e.x;
         candSlot[tid] = e.y;
+        candTarget[tid] = lc.sendTarget[e.x];
+        candPrio[tid] = vPriority[e.x];
     }
     __syncthreads();
+    // Where each segment's run begins in every lane's list (segment numbers never increase along a list, lcInitSegments): all
+    // lanes of the wave, one (lane, segment) each — the walk below then finds "the vehicles of segments >= mine" and "... <=
+    // mine" with one LDS read instead of a bisection per segment it looks into
+    if (staged) {
+        const int stride = lnSegs[0] + 1;
+        if (stride - 1 > kLcSchedSegs) {
+            if (tid == 0) sRunsOff = 1;
+        } else {
+            for (int e = tid; e < (l1 - l0) * stride; e += 64) {
+                const int li = e / stride, g = e - li * stride;
+                if (lnSegs[li] != stride - 1) sRunsOff = 1;  // (lanes of one road have the same number of segments; otherwise: the searches)
+                const int base = lnStart[li] - s0;
+                int lo = 0, hi = lnCnt[li];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (stSeg[base + mid] >= g) lo = mid + 1;
+                    else hi = mid;
+                }
+                lnRun[li][g] = lo;
+            }
+        }
+    }
     // Walk positions (the `std::sort` of scheduleLaneChange, lcSortedPosition): the creation rank of a candidate is the
     // number of the step's candidates with a smaller vehicle number — counted here, by the wave that needs it, over the
     // step's list (a few KB, read by every road's wave: it stays in L2).  k_lc_assign reads candPos of the shadows' parents.
@@ -334,26 +365,43 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     if (!tooMany) {
         nCand = nListed;
         for (int j = 1; j < nCand; ++j) {  // insertion sort by walk position
-            const int v = candVid[j], q = candSlot[j], key = candKey[j];
+            const int v = candVid[j], q = candSlot[j], key = candKey[j], tg = candTarget[j], pr = candPrio[j];
             int i = j;
             for (; i > 0 && candKey[i - 1] > key; --i) {
                 candVid[i] = candVid[i - 1];
                 candSlot[i] = candSlot[i - 1];
                 candKey[i] = candKey[i - 1];
+                candTarget[i] = candTarget[i - 1];
+                candPrio[i] = candPrio[i - 1];
             }
             candVid[i] = v;
             candSlot[i] = q;
             candKey[i] = key;
+            candTarget[i] = tg;
+            candPrio[i] = pr;
         }
     }
     int lastKey = -1;
+#if defined(CFX_TRACE) && CFX_TRACE_KERNEL == 9
+    long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tMark = (long long) KCLOCK();
+#define LC_SPAN(acc)                                \
+    {                                               \
+        const long long now_ = (long long) KCLOCK(); \
+        acc += now_ - tMark;                        \
+        tMark = now_;                               \
+    }
+#else
+#define LC_SPAN(acc)
+#endif
     for (int ci = 0;; ++ci) {
-        int vid, s, myKey;
+        int vid, s, myKey, target = -1, myPriority = 0;
         if (!tooMany) {
             if (ci >= nCand) break;
             vid = candVid[ci];
             s = candSlot[ci];
             myKey = candKey[ci];
+            target = candTarget[ci];
+            myPriority = candPrio[ci];
         } else {  // more candidates than the local list holds: pick the next one by scanning (slow, rare)
             vid = -1;
             s = -1;
@@ -372,7 +420,10 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
             myKey = best;
         }
         const int d = slotDrv(s);
-        const int target = lc.sendTarget[vid];
+        if (tooMany) {
+            target = lc.sendTarget[vid];
+            myPriority = vPriority[vid];
+        }
         const double dis = slotDisOf(s);
         const double myLen = slotLen(s), myNegAcc = slotNegAcc(s);
         // --- LaneChange::updateLeaderAndFollower lanechange.cpp:27-60 on the target lane as it is NOW: its segment lists,
@@ -380,6 +431,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
         // its parent's number names, at the place Segment::insertVehicle gave it, roadnet.cpp:943-947)
         LcNeighbour leader{-1, 0, 0, 0, 0}, follower{-1, 0, 0, 0, 0};
         const int tb = laneStart(target), tn = laneCount(target);
+        LC_SPAN(tA)
         int followerAnchor = tn;  // lane-list position of the follower: existing index, or ...
         int followerRec = -1;     // ... the earlier shadow it is
         const int mySeg = slotSeg(s), nSeg = laneSegs(target);
@@ -429,7 +481,30 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
             const int ps = insParent[j];
             return LcNeighbour{-(localRec[j] + 2), insDis[j], slotLen(ps), slotSpeedOf(ps), slotNegAcc(ps)};
         };
-        for (int i = mySeg; i < nSeg && leader.vid == -1; ++i) {  // getVehicleAfterDistance: back to front
+        // No shadow of this walk in the target lane yet (the rule): the segment lists are runs of the lane's list, and walking
+        // segments mySeg, mySeg + 1, ... each back to front IS walking the list from the end of run mySeg towards the front;
+        // segments mySeg, mySeg - 1, ... each front to back is walking it from the start of run mySeg towards the tail.
+        bool runs = staged && !sRunsOff && mySeg <= kLcSchedSegs && nSeg <= kLcSchedSegs;
+        for (int j = 0; runs && j < nLocal; ++j)
+            if (insLane[j] == target) runs = false;
+        if (runs) {
+            const int tl = target - l0;
+            if (mySeg < nSeg)
+                for (int k = lnRun[tl][mySeg] - 1; k >= 0; --k)
+                    if (slotDisOf(tb + k) >= dis) {
+                        leader = neighbourOf(k);
+                        break;
+                    }
+            const int i0 = mySeg < nSeg ? mySeg : nSeg - 1;
+            if (i0 >= 0)
+                for (int k = lnRun[tl][i0 + 1]; k < tn; ++k)
+                    if (slotDisOf(tb + k) < dis) {
+                        follower = neighbourOf(k);
+                        followerAnchor = k;
+                        break;
+                    }
+        }
+        for (int i = mySeg; !runs && i < nSeg && leader.vid == -1; ++i) {  // getVehicleAfterDistance: back to front
             const int m = buildSegment(i);
             for (int p = m - 1; p >= 0; --p)
                 if (itemDis[p] >= dis) {
@@ -437,7 +512,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                     break;
                 }
         }
-        for (int i = mySeg < nSeg ? mySeg : nSeg - 1; i >= 0 && follower.vid == -1; --i) {  // getVehicleBeforeDistance
+        for (int i = mySeg < nSeg ? mySeg : nSeg - 1; !runs && i >= 0 && follower.vid == -1; --i) {  // getVehicleBeforeDistance
             const int m = buildSegment(i);
             for (int p = 0; p < m; ++p)
                 if (itemDis[p] < dis) {
@@ -447,6 +522,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                     break;
                 }
         }
+        LC_SPAN(tB)
         double leaderGap, followerGap = 1.7976931348623157e308;
         if (leader.vid == -1) {  // look into the laneLinks behind the target lane
             const double rest = c.n.drvLength[d] - dis;
@@ -470,6 +546,7 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
         } else {
             leaderGap = leader.dis - dis - leader.len;
         }
+        LC_SPAN(tC)
         if (follower.vid != -1) followerGap = dis - follower.dis - myLen;
         lc.tLeader[vid] = leader.vid;
         lc.tFollower[vid] = follower.vid;
@@ -488,8 +565,18 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
         lc.leaderGap[vid] = leaderGap;
         lc.followerGap[vid] = followerGap;
         // --- SimpleLaneChange::sendSignal lanechange.cpp:208-211 -> Vehicle::receiveSignal vehicle.cpp:391-401
-        const int myPriority = vPriority[vid];
         const LcNeighbour *nb[2] = {&leader, &follower};
+        // (both neighbours' rows requested together: the walk is a chain of trips to memory, each one saved is half a microsecond)
+        int nbChanging[2] = {0, 0}, nbFrom[2] = {-1, -1}, nbSig[2] = {0, 0}, nbPrio[2] = {0, 0};
+        for (int i = 0; i < 2; ++i) {
+            const int r = nb[i]->vid;
+            if (r < 0) continue;
+            nbChanging[i] = lc.changing[r];
+            nbFrom[i] = lc.recvFrom[r];
+            nbSig[i] = lc.sigSend[r];
+            nbPrio[i] = vPriority[r];
+        }
+        if (leader.vid >= 0 && leader.vid == follower.vid) nbFrom[1] = -2;  // (cannot happen; re-read below if it ever does)
         for (int i = 0; i < 2; ++i) {
             const int r = nb[i]->vid;
             if (r == -1) continue;
@@ -499,11 +586,12 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                 if (rec.recvFrom < 0 || cur < myPriority) rec.recvFrom = vid;
                 continue;
             }
-            if (lc.changing[r]) continue;
-            const int from = lc.recvFrom[r];
+            if (nbChanging[i]) continue;
+            const int from = nbFrom[i] == -2 ? lc.recvFrom[r] : nbFrom[i];
             const int cur = from >= 0 ? vPriority[from] : -1;
-            if ((from < 0 || cur < myPriority) && (!lc.sigSend[r] || vPriority[r] < myPriority)) lc.recvFrom[r] = vid;
+            if ((from < 0 || cur < myPriority) && (!nbSig[i] || nbPrio[i] < myPriority)) lc.recvFrom[r] = vid;
         }
+        LC_SPAN(tD)
         // --- insert a shadow? engine.cpp:800-806, LaneChange::isGapValid lanechange.h:80
         if (lcPlanChange(lc, vid, d) && lc.sigSend[vid] && lc.recvFrom[vid] < 0 && !lc.changing[vid] && d < c.n.L) {
             const double speed = slotSpeedOf(s);
@@ -553,7 +641,13 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
                 }
             }
         }
+        LC_SPAN(tE)
     }
+#if defined(CFX_TRACE) && CFX_TRACE_KERNEL == 9
+    // (what the walk's time went into, 10 ns ticks: own fields | segment searches, then laneLinks | signals | insertion)
+    KNOTE(9, 3, tA | (tB << 32));
+    KNOTE(9, 6, tC | (tD << 20) | (tE << 40));
+#endif
     KSTAMP(9, 4);
 }
 
