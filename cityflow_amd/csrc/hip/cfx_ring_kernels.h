@@ -2391,7 +2391,8 @@ __global__ void kr_validate(RingCtx c, JobQueue q, int nVid, int nRoutes, int ri
             else if (c.slotOf[c.s.vid[s]] != s) bad(5, d, i, s, c.slotOf[c.s.vid[s]]);
             if ((unsigned) c.s.route[s] >= (unsigned) nRoutes) bad(6, d, i, s, c.s.route[s]);
             if (c.meta[s].y < -1 || c.meta[s].y >= D) bad(7, d, i, s, c.meta[s].y);
-            if (c.s.prevDrv[s] < -1 || c.s.prevDrv[s] >= D) bad(8, d, i, s, c.s.prevDrv[s]);
+            // (a tile: a migrant's previous laneLink lies in the neighbour's tile and is kept as -(its global number + 2), ringHaloImportCut)
+            if ((c.s.prevDrv[s] < -1 && !c.n.laneGhost) || c.s.prevDrv[s] >= D) bad(8, d, i, s, c.s.prevDrv[s]);
             const int2 b = c.blkR[s];
             if (b.x < -1 || b.x >= nVid) bad(9, d, i, s, b.x);
         }

@@ -13,6 +13,12 @@ if scale:
                                n_extra=bench.SCALE_FLOWS)
 else:
     cfg = bench.build_workload("/tmp/cfa_tilek", 0)
+if os.environ.get("CFX_TILE_CFX"):  # implementation choices, "key=value,key=value".  debugSync=1: every kernel of every tile runs
+    # ALONE on the GPU (a host synchronisation behind each launch; the tiles are stepped one after the other), so the times
+    # below are a tile's own, as on a GPU of its own — without it the tiles' kernels share the device
+    def _val(v):
+        return {"true": True, "false": False}.get(v, int(v) if v.lstrip("-").isdigit() else v)
+    cfg = bench.with_config(cfg, "cfx", cfx={k: _val(v) for k, v in (kv.split("=") for kv in os.environ["CFX_TILE_CFX"].split(","))})
 eng = m.TiledEngine(cfg, rows, cols, [], "")
 eng.enable_mailboxes("tilek_%d" % os.getpid())
 for _ in range(320):
