@@ -155,6 +155,10 @@ __device__ __forceinline__ int4 ntLoad4(const int4 *p) {
     const cfx_v4i v = __builtin_nontemporal_load((const cfx_v4i *) p);
     return make_int4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ double2 ntLoad2(const double2 *p) {
+    const cfx_v2d v = __builtin_nontemporal_load((const cfx_v2d *) p);
+    return make_double2(v.x, v.y);
+}
 __device__ __forceinline__ void ntStore4(int4 *p, int4 x) {
     const cfx_v4i v = {x.x, x.y, x.z, x.w};
     __builtin_nontemporal_store(v, (cfx_v4i *) p);
@@ -1881,8 +1885,8 @@ __global__ CFX_KL_BOUNDS void kl_action(RingCtx c, RingOut o, JobQueue q, RingJo
     double2 lm = make_double2(0.0, 0.0);
     int4 hop = make_int4(-2, -2, -2, -2), en = make_int4(-1, -1, -1, -1);
     if (valid) {
-        const double2 kv = c.kin[slot];
-        const int4 mv = c.meta[slot];
+        const double2 kv = (CFX_KL_NT & 8) ? ntLoad2(&c.kin[slot]) : c.kin[slot];
+        const int4 mv = (CFX_KL_NT & 16) ? ntLoad4(&c.meta[slot]) : c.meta[slot];
         lm = c.n.drvLM[d];
         if (d < c.n.L) {
             hop = c.n.laneLL4[d];
