@@ -752,6 +752,18 @@ PYBIND11_MODULE(_cityflow, m) {
                  e.replayWrite(blobs);
              },
              "parts"_a)
+        .def("_compact_vehicles", &TiledEngineHost::compactVehicles,
+             "forget the finished vehicles now (every tile in this process; automatic once \"cfx\": {\"compactVehicles\": N} vehicles have been created; default 3.5 M)")
+        .def("_wants_compaction", &TiledEngineHost::wantsCompaction, "enough vehicles created since the last time (the same answer on every rank)")
+        .def("_compact_from_parts",
+             [](TiledEngineHost &e, const std::vector<py::bytes> &parts) {
+                 std::vector<std::string> p;
+                 for (const auto &b : parts) p.push_back(std::string(b));
+                 e.compactFromParts(p);
+             },
+             "parts"_a, "several processes: _snapshot_part() of every rank in rank order, the same call on every rank")
+        .def("_vehicle_table", [](TiledEngineHost &e) { return py::make_tuple(e.vehicleTableSize(), e.vehicleCompactions()); },
+             "(vehicle numbers the host holds, compactions so far)")
         .def("_snapshot_part", [](TiledEngineHost &e) { return py::bytes(e.snapshotPart()); },
              "the state of this process's tiles, for _snapshot_from_parts on every process (in rank order)")
         .def("_snapshot_from_parts",

@@ -722,6 +722,8 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         tiles_.emplace_back(new TileEngine(net_, owner_, localRanks_[i], cfg_, &be_, baseDevice + (int) i));
     }
     aheadEnabled_ = cfg_.spawnAhead && !cfg_.laneChange && !cfg_.saveReplay;
+    compactAt_ = nextCompactAt_ = cfg_.compactVehicles < 0 ? (size_t) 3500000 : (size_t) cfg_.compactVehicles;
+    compactAuto_ = cfg_.compactVehicles < 0;
     spawner_.setFinishedQuery([this](int vid) {
         // (never from the ahead thread: the devices are the caller's, and over several ranks the answer is a collective)
         if (onAheadThread_.load(std::memory_order_relaxed)) throw AheadAbandoned();
@@ -845,6 +847,7 @@ void TiledEngineHost::takeBatch() {
                 std::lock_guard<std::mutex> guard(aheadMutex_);  // (the ahead thread reads it under the mutex)
                 aheadState_ = kAheadIdle;
             }
+            numbersOut_ = spawner_.vehicles.size();
             return;
         }
         // abandoned (a priority collision), failed (raised below, where it belongs), or prepared for another step
@@ -852,6 +855,7 @@ void TiledEngineHost::takeBatch() {
     }
     aheadRedone_ += 1;
     spawner_.step(step_, spawnBuf_);
+    numbersOut_ = spawner_.vehicles.size();  // (the spawner is at rest here: the ahead thread is started after the batch is taken)
 }
 
 void TiledEngineHost::flushPhases() {
@@ -909,6 +913,7 @@ void TiledEngineHost::stepEndDevice() {
     for (auto &t : tiles_) t->haloImportDevice();
     if (saveReplay_ && allLocal_) updateLog();
     step_ += 1;
+    if (allLocal_ && wantsCompaction()) compactVehicles();
 }
 
 std::tuple<uintptr_t, int, uintptr_t, int> TiledEngineHost::haloDeviceBuffers(int i) {
@@ -930,6 +935,8 @@ void TiledEngineHost::stepEnd() {
     }
     if (saveReplay_ && allLocal_) updateLog();
     step_ += 1;
+    // (several processes: cityflow_amd/tiled.py gathers the parts when wantsCompaction() says so — on every rank alike)
+    if (allLocal_ && wantsCompaction()) compactVehicles();
 }
 
 void TiledEngineHost::enableMailboxes(const std::string &jobId) {
@@ -1071,6 +1078,9 @@ void TiledEngineHost::reset(bool resetRnd) {
     spawner_.reset(resetRnd);
     step_ = 0;
     hostSpawnSec_ = hostSubmitSec_ = 0;
+    waitingCustom_.clear();
+    nextCompactAt_ = compactAt_;
+    numbersOut_ = 0;
 }
 
 void TiledEngineHost::sync() {
@@ -1308,12 +1318,14 @@ void TiledEngineHost::setVehicleSpeed(const std::string &id, double speed) {
         if (future == -2) return;
         if (future >= 0) {
             for (auto &t : tiles_) t->setVehicleSpeed(future, speed);
+            waitingCustom_[future] = speed;
             return;
         }
     }
     int st = vid >= 0 ? statusOf(vid) : 2;
     if (vid < 0 || st == 2) throw std::runtime_error("Vehicle '" + id + "' not found");
     for (auto &t : tiles_) t->setVehicleSpeed(vid, speed);
+    if (st == 0) waitingCustom_[vid] = speed;  // (still in its lane's waiting buffer: compactFromParts hands it over)
 }
 
 }  // namespace cfa
@@ -1394,7 +1406,7 @@ std::string TiledEngineHost::snapshotPart() {
     return std::move(w.out);
 }
 
-Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts) {
+Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts, bool keepRoutePositions) {
     dropAhead();
     Archive a;
     a.host = spawner_.saveState();
@@ -1457,7 +1469,7 @@ Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts
         d.rLeader.push_back(all.leader[i]);
         d.rBlocker.push_back(all.blocker[i]);
         d.rEnterLLTime.push_back(all.enterLLTime[i]);
-        d.rRoutePos.push_back(0);  // (Router copy constructor: see EngineHost::snapshot, archive.cpp)
+        d.rRoutePos.push_back(keepRoutePositions ? all.routePos[i] : 0);  // (Router copy constructor: see EngineHost::snapshot, archive.cpp; compactFromParts is not a load)
         d.rDis.push_back(all.dis[i]);
         d.rSpeed.push_back(all.speed[i]);
         d.rGap.push_back(all.gap[i]);
@@ -1479,8 +1491,55 @@ Archive TiledEngineHost::snapshot() {
     return snapshotFromParts({snapshotPart()});
 }
 
+// Forget the finished vehicles: EngineHost::compactVehicles (archive.cpp) over tiles.  The state as the parts hold it, the
+// vehicles that still wait or run renumbered 0 .. n-1 in their old order (creation order: what breaks exact-distance ties),
+// every process loading the whole and keeping its tiles' part — nothing a caller can see changes.
+void TiledEngineHost::compactFromParts(const std::vector<std::string> &parts) {
+    Archive a = snapshotFromParts(parts, /*keepRoutePositions=*/true);
+    const int nV = (int) spawner_.vehicles.size();
+    DeviceState &d = a.dev;
+    std::vector<int32_t> newOfOld((size_t) nV, -1);
+    int nLive = 0;
+    for (int v = 0; v < nV; ++v)
+        if (d.vState[(size_t) v] != 2) newOfOld[(size_t) v] = nLive++;
+    auto renumber = [&](std::vector<int32_t> &vids) {
+        for (int32_t &v : vids) v = v >= 0 && v < nV ? newOfOld[(size_t) v] : -1;
+    };
+    renumber(d.rVid);
+    renumber(d.rBlocker);
+    renumber(d.rLeader);
+    renumber(d.wVid);
+    for (int32_t v : d.rVid)
+        if (v < 0) throw std::logic_error("compact_vehicles: a running vehicle counted as finished");
+    for (int32_t v : d.wVid)
+        if (v < 0) throw std::logic_error("compact_vehicles: a waiting vehicle counted as finished");
+    std::vector<uint8_t> state((size_t) nLive);
+    for (int v = 0; v < nV; ++v)
+        if (newOfOld[(size_t) v] >= 0) state[(size_t) newOfOld[(size_t) v]] = d.vState[(size_t) v];
+    d.vState.swap(state);
+    a.host = spawner_.compactedState(newOfOld, nLive);
+    // custom speeds of vehicles that are STILL waiting (cfx_state carries those of running vehicles only)
+    std::map<int32_t, double> stillWaiting;
+    for (const auto &kv : waitingCustom_)
+        if (kv.first >= 0 && kv.first < nV && newOfOld[(size_t) kv.first] >= 0 && d.vState[(size_t) newOfOld[(size_t) kv.first]] == 0)
+            stillWaiting[newOfOld[(size_t) kv.first]] = kv.second;
+    load(a);
+    for (const auto &kv : stillWaiting)
+        for (auto &t : tiles_) t->setVehicleSpeed(kv.first, kv.second);
+    waitingCustom_.swap(stillWaiting);
+    vehicleCompactions_ += 1;
+    const size_t alive = spawner_.vehicles.size();
+    nextCompactAt_ = compactAuto_ ? std::max(compactAt_, 32 * alive) : alive + compactAt_;
+}
+
+void TiledEngineHost::compactVehicles() {
+    if (!allLocal_) throw std::runtime_error("tiling: compact_vehicles() needs every tile in this process; gather _snapshot_part() of every process for _compact_from_parts()");
+    compactFromParts({snapshotPart()});
+}
+
 void TiledEngineHost::load(const Archive &a) {
     dropAhead();
+    waitingCustom_.clear();  // (compactFromParts puts back what it carries over)
     if (!a.dev.rLcFlags.empty()) throw std::runtime_error("TiledEngine.load: the archive carries lane-change state");
     if (a.net.get() != net_.get() && a.net->lanes.size() != net_->lanes.size())
         throw std::runtime_error("TiledEngine.load: archive belongs to a different road network");
@@ -1491,6 +1550,7 @@ void TiledEngineHost::load(const Archive &a) {
         t->uploadTables(spawner_);
         t->loadState(a, t->tile().rank == 0);
     }
+    numbersOut_ = spawner_.vehicles.size();
     step_ = (size_t) a.dev.step;
 }
 

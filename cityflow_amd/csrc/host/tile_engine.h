@@ -222,9 +222,21 @@ public:
     //      same archive and keeps its tiles' part.  A snapshot is assembled from one PART per process (opaque bytes: the
     //      state of the local tiles); with every tile local snapshot() does both steps.
     std::string snapshotPart();
-    Archive snapshotFromParts(const std::vector<std::string> &parts);
+    Archive snapshotFromParts(const std::vector<std::string> &parts, bool keepRoutePositions = false);
     Archive snapshot();
     void load(const Archive &a);
+    // Forget the finished vehicles (the reference frees a vehicle when it finishes, engine.cpp:296-310; EngineHost::compactVehicles,
+    // archive.cpp): the vehicles that still wait or run renumbered 0 .. n-1 in their old order and loaded back through load().
+    // `parts`: snapshotPart() of every process, in rank order — every process calls it with the same parts between the same two
+    // steps (every process runs the whole spawner, so wantsCompaction() answers alike everywhere).  Automatic with every tile in
+    // this process; cityflow_amd/tiled.py does the gather otherwise.  "cfx": {"compactVehicles": N} as for Engine.
+    void compactFromParts(const std::vector<std::string> &parts);
+    void compactVehicles();
+    // (the vehicle numbers out as of the batch the last step took: the step-ahead thread may be adding the next step's while
+    //  this is asked, and how far it has come differs from rank to rank)
+    bool wantsCompaction() const { return compactAt_ > 0 && numbersOut_ >= nextCompactAt_; }
+    int64_t vehicleCompactions() const { return vehicleCompactions_; }
+    int64_t vehicleTableSize() const { return (int64_t) numbersOut_; }
     void loadFromFile(const std::string &path);
     // Engine::setRoute engine.cpp:852-866.  Several processes: the status reducer also merges the vehicle's position.
     bool setRoute(const std::string &vehicleId, const std::vector<std::string> &anchorIds);
@@ -277,6 +289,11 @@ private:
     std::vector<std::unique_ptr<TileEngine>> tiles_;
     int nTiles_ = 1;
     bool allLocal_ = true, mailboxes_ = false;
+    size_t numbersOut_ = 0;  // vehicle numbers handed out as of the last batch taken / load / compaction
+    size_t compactAt_ = 3500000, nextCompactAt_ = 3500000;  // (EngineHost's policy: 3.5 M vehicle numbers, then 32 x the vehicles alive)
+    bool compactAuto_ = true;
+    int64_t vehicleCompactions_ = 0;
+    std::map<int32_t, double> waitingCustom_;  // set_vehicle_speed on vehicles that were waiting (or not yet numbered) then
     size_t step_ = 0;
     std::vector<cfx_spawn> spawnBuf_;
     double hostSpawnSec_ = 0, hostSubmitSec_ = 0;  // wall time of this process inside the spawner / the ABI calls of a step

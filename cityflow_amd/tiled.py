@@ -205,6 +205,20 @@ class DistributedEngine:
         self._step()
         if self.world > 1:  # (one process running every tile writes its replay line itself, TiledEngineHost::stepEnd)
             self._replay()
+            # the finished vehicles are forgotten once enough numbers are out (EngineHost::compactVehicles over tiles): every
+            # rank runs the whole spawner, so every rank says so after the same step
+            if self._eng._wants_compaction():
+                self.compact_vehicles()
+
+    def compact_vehicles(self):
+        """Forget the finished vehicles now (the reference frees a vehicle when it finishes, engine.cpp:296-310): a collective —
+        every rank's part of the state goes to every rank, which renumbers the vehicles alive and keeps its tile's part."""
+        self._eng.sync()
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self._eng._snapshot_part(), group=self._halo)
+        dist.barrier(group=self._halo)  # nobody reuses a mailbox buffer a neighbour has not consumed yet (as load())
+        self._eng._compact_from_parts(parts)
+        dist.barrier(group=self._halo)
 
     def _step(self):
         if self.transport == "rccl":

@@ -179,3 +179,71 @@ def test_compaction_with_lane_change_hip_equals_a_twin_that_never_compacts(mod, 
                 assert va[k] == vb[k], (s, k)
             shadows += sum(v.endswith("_shadow") for vs in va["lane_vehicles"].values() for v in vs)
     assert shadows > 0 and a._vehicle_table()[1] > 20
+
+
+# ---- tiles (TiledEngineHost::compactFromParts, csrc/host/tile_engine.cpp): every tile's part of the state, the vehicles alive
+#      renumbered, every tile loading its part of the whole — automatic with every tile in one process, a collective over ranks
+#      (cityflow_amd/tiled.py: DistributedEngine.compact_vehicles; tests/test_tiling.py::test_two_ranks_compaction_gloo)
+def run_tiled_pair(a, b, steps, check_every):
+    """`a`: tiles, compacting; `b`: one engine that never compacts; both take the same calls."""
+    n_inter = len(b.intersection_ids())
+    rng = np.random.default_rng(5)
+    for s in range(steps):
+        if s % 5 == 0:
+            ph = rng.integers(0, 4, n_inter).astype(np.int32)
+            a.set_tl_phases(ph)
+            b.set_tl_phases(ph)
+        a.next_step()
+        b.next_step()
+        if s % 7 == 0:
+            assert np.array_equal(a.get_lane_vehicle_count_array(), b.get_lane_vehicle_count_array()), s
+        if s % check_every == check_every - 1:
+            va, vb = visible(a), visible(b)
+            for k in va:
+                assert va[k] == vb[k], (s, k)
+            some = va["vehicles"][:: max(1, len(va["vehicles"]) // 12)]
+            for v in some:
+                assert a.get_vehicle_info(v) == b.get_vehicle_info(v), (s, v)
+                assert a.get_leader(v) == b.get_leader(v), (s, v)
+
+
+def _tiled_compaction(mod, scen, workdir, make_tiled, steps):
+    base = unsaturated_grid(scen, workdir)
+    a = make_tiled(compacting(base, 250))
+    b = mod.Engine._with_backend(compacting(base, 0), 1, TWIN_LIB)
+    peak = 0
+    for chunk in range(steps // 250):
+        run_tiled_pair(a, b, 250, 125)
+        peak = max(peak, a._vehicle_table()[0])
+        if chunk == 1:  # a custom speed for a vehicle still in its lane's waiting buffer rides through the next compaction
+            waiting = [v for v in b.get_vehicles(True) if v not in set(b.get_vehicles(False))]
+            for v in waiting[:3]:
+                a.set_vehicle_speed(v, 3.25)
+                b.set_vehicle_speed(v, 3.25)
+    held, compactions = a._vehicle_table()
+    assert b._vehicle_table()[1] == 0 and b._vehicle_table()[0] > peak and held < b._vehicle_table()[0]
+    assert compactions >= steps // 250 - 1 and peak <= 250 + len(a.get_vehicles(True)) + 400, (held, compactions, peak)
+    # archives still travel both ways between tiles that compact and an engine that does not
+    arch_a, arch_b = a.snapshot(), b.snapshot()
+    run_tiled_pair(a, b, 40, 20)
+    a.load(arch_b)
+    b.load(arch_a)
+    run_tiled_pair(a, b, 100, 50)
+    a._compact_vehicles()  # on request, too
+    run_tiled_pair(a, b, 60, 30)
+    a.reset()
+    b.reset()
+    run_tiled_pair(a, b, 60, 30)
+
+
+def test_tiled_compaction_bounds_the_tables_and_changes_nothing_twin(mod, scen, workdir):
+    _tiled_compaction(mod, scen, workdir, lambda c: mod.TiledEngine(c, 2, 3, [], TWIN_LIB), 1250)
+
+
+@pytest.mark.gpu
+def test_tiled_compaction_hip_equals_a_twin_engine_that_never_compacts(mod, scen, workdir):
+    def make(c):
+        t = mod.TiledEngine(c, 2, 2)
+        t.enable_mailboxes("compact_%d" % __import__("os").getpid())
+        return t
+    _tiled_compaction(mod, scen, workdir, make, 1000)

@@ -144,6 +144,18 @@ def test_two_ranks_archive_and_routes_gloo(scen, workdir, tmp_path, mailboxes):
     assert "TILED_OK 120" in out.stdout and "ARCHIVE_OK" in out.stdout
 
 
+@pytest.mark.parametrize("mailboxes", ["0", "1"])
+def test_two_ranks_compaction_gloo(scen, workdir, tmp_path, mailboxes):
+    """Bounded memory over ranks: the tiles forget their finished vehicles every 300 vehicle numbers — every rank's part of the
+    state gathered on every rank, the vehicles alive renumbered, every rank keeping its tile's part (DistributedEngine.
+    compact_vehicles, TiledEngineHost::compactFromParts; the reference frees a vehicle when it finishes, engine.cpp:296-310) —
+    and stay equal, id by id, to one engine that never forgets."""
+    cfg = scen.generate_grid(6, 6, workdir, flow_interval=12.0)
+    out = _torchrun(tmp_path, cfg, TWIN_LIB, 1, 2, 700, 2, free_port(), {"CFX_TEST_MAILBOXES": mailboxes, "CFX_TEST_COMPACT": "300"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 700" in out.stdout and "COMPACT_OK" in out.stdout
+
+
 def test_two_ranks_replay_gloo(scen, workdir, tmp_path):
     """saveReplay with one tile per process: the replay file rank 0 writes equals the single engine's (tests/tiled_worker.py)."""
     cfg = scen.materialize("grid_6x6", workdir)

@@ -28,12 +28,23 @@ def main():
         import datetime
         halo = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
     transport = os.environ.get("CFX_TEST_TRANSPORT") or None
+    compact = int(os.environ.get("CFX_TEST_COMPACT", "0"))
+    single_cfg = cfg
+    if compact:  # the tiles forget their finished vehicles every `compact` vehicle numbers (a collective), the single engine never
+        import json
+        base = json.load(open(cfg))
+        paths = []
+        for name, every in (("tiles", compact), ("one", 0)):
+            path = cfg.replace(".json", "_compact_%s_r%d.json" % (name, rank))
+            json.dump(dict(base, cfx=dict(base.get("cfx", {}), compactVehicles=every)), open(path, "w"))
+            paths.append(path)
+        cfg, single_cfg = paths
     eng = DistributedEngine(cfg, rows, cols, backend_library=lib, halo_group=halo, transport=transport,
                             mailboxes=None if (transport or os.environ.get("CFX_TEST_MAILBOXES") == "auto")
                             else os.environ.get("CFX_TEST_MAILBOXES", "1") == "1")
     if transport:
         assert eng.transport == transport, (eng.transport, transport)
-    single = m.Engine._with_backend(cfg, 1, lib) if lib else m.Engine(cfg, 1)
+    single = m.Engine._with_backend(single_cfg, 1, lib) if lib else m.Engine(single_cfg, 1)
     crossed = 0
     for s in range(steps):
         eng.next_step()
@@ -48,6 +59,14 @@ def main():
             sa, sb = single._scalars(), eng.scalars()
             for k in ("active_vehicle_count", "finished_vehicle_count", "cumulative_travel_time", "vehicle_steps"):
                 assert sa[k] == sb[k], (rank, s, k, sa[k], sb[k])
+            if compact:  # (vehicle numbers differ after a compaction: ids instead)
+                assert eng.get_vehicle_speed() == single.get_vehicle_speed(), (rank, s)
+                assert eng.get_vehicle_distance() == single.get_vehicle_distance(), (rank, s)
+                assert eng.get_lane_vehicles() == single.get_lane_vehicles(), (rank, s)
+                assert eng.get_vehicles(True) == single.get_vehicles(True), (rank, s)
+                assert eng.get_average_travel_time() == single.get_average_travel_time(), (rank, s)
+                crossed = max(crossed, len(eng.local_vehicle_state()["vid"]))
+                continue
             # this rank's vehicles: same per-vehicle state as on the single engine
             va, vb = single._vehicle_state(), eng.local_vehicle_state()
             pos = {int(v): i for i, v in enumerate(va["vid"])}
@@ -60,6 +79,17 @@ def main():
             assert eng.get_vehicle_distance() == single.get_vehicle_distance()
             assert eng.get_lane_vehicles() == single.get_lane_vehicles()
     assert crossed > 0
+    if compact:
+        held, times = eng._eng._vehicle_table()
+        assert times >= 2 and single._vehicle_table()[1] == 0 and held < single._vehicle_table()[0], (held, times, single._vehicle_table())
+        eng.compact_vehicles()  # on request, too (a collective)
+        for s in range(20):
+            eng.next_step()
+            single.next_step()
+            assert np.array_equal(eng.get_lane_vehicle_count_array(), single.get_lane_vehicle_count_array()), (rank, s)
+        assert eng.get_vehicle_speed() == single.get_vehicle_speed()
+        if rank == 0:
+            print("COMPACT_OK", times + 1, "compactions,", held, "of", single._vehicle_table()[0], "vehicle numbers held")
     if os.environ.get("CFX_TEST_ARCHIVE") == "1":
         # archive and routes over ranks: the snapshot assembled from every rank's part is the single engine's; after a load
         # (no communication: every rank keeps its tile's part) both go on identically; setRoute gives the same verdicts
