@@ -83,7 +83,7 @@ struct cfx_engine {
 
     // ---- vehicle table ----
     VidTable vt{};
-    LaneHistDev hist{};                // Lane::history, with cfx_config::lane_history (not on tiles)
+    LaneHistDev hist{};                // Lane::history, with cfx_config::lane_history (tiles: on the ring layout only)
     size_t vidCap = 0;
     int64_t spawned = 0;
 
@@ -718,7 +718,7 @@ struct cfx_engine {
     RingHist takeHist(int firstBlock) {
         RingHist rh{};
         rh.firstBlock = 0x7fffffff;
-        if (hist.num && ring && !tiled && histPending) {
+        if (hist.num && ring && histPending) {  // (tiles too: the step's halo import runs in front of this launch)
             rh.h = hist;
             rh.firstBlock = firstBlock;
             histPending = false;
@@ -1703,7 +1703,7 @@ static int32_t stepImpl(cfx_engine *e, const cfx_spawn *recs, int32_t n) {
         e->rcur ^= 1;
         e->step += 1;
         e->mirrorValid = !e->tiled;
-        e->histPending = e->hist.num && !e->tiled;  // (this step's Lane::history: with the next action launch, or settle())
+        e->histPending = e->hist.num != 0;  // (this step's Lane::history: with the next action launch, or settle() — on a tile behind the step's halo import)
         return CFX_OK;
     }
     const int64_t spare = e->tiled ? e->spareTotal : (int64_t) e->L;

@@ -754,6 +754,7 @@ PYBIND11_MODULE(_cityflow, m) {
              "parts"_a)
         .def("_compact_vehicles", &TiledEngineHost::compactVehicles,
              "forget the finished vehicles now (every tile in this process; automatic once \"cfx\": {\"compactVehicles\": N} vehicles have been created; default 3.5 M)")
+        .def("_keeps_lane_history", &TiledEngineHost::keepsLaneHistory)
         .def("_wants_compaction", &TiledEngineHost::wantsCompaction, "enough vehicles created since the last time (the same answer on every rank)")
         .def("_compact_from_parts",
              [](TiledEngineHost &e, const std::vector<py::bytes> &parts) {

@@ -494,6 +494,39 @@ void TileEngine::addLaneCounts(std::vector<int32_t> &global, bool waiting) {
         if (!tn_.laneGhost[l]) global[tn_.laneL2G[l]] = local[l];
 }
 
+void TileEngine::laneHistoryInto(DeviceState &d) {
+    const size_t nL = tn_.laneL2G.size(), M = CFX_LANE_HISTORY_MAX;
+    std::vector<int32_t> len(nL), num(nL * M), hNum(nL);
+    std::vector<double> avg(nL * M), hAvg(nL);
+    cfx_lane_history h{(int32_t) nL, len.data(), num.data(), avg.data(), hNum.data(), hAvg.data()};
+    check(be_->cfx_get_lane_history(dev_, &h), "cfx_get_lane_history");
+    for (size_t l = 0; l < nL; ++l) {
+        if (tn_.laneGhost[l]) continue;
+        const size_t g = (size_t) tn_.laneL2G[l];
+        d.hLen[g] = len[l];
+        d.hHistoryVehicleNum[g] = hNum[l];
+        d.hHistoryAverageSpeed[g] = hAvg[l];
+        std::copy(num.begin() + (ptrdiff_t) (l * M), num.begin() + (ptrdiff_t) ((l + 1) * M), d.hVehicleNum.begin() + (ptrdiff_t) (g * M));
+        std::copy(avg.begin() + (ptrdiff_t) (l * M), avg.begin() + (ptrdiff_t) ((l + 1) * M), d.hAverageSpeed.begin() + (ptrdiff_t) (g * M));
+    }
+}
+
+void TileEngine::setLaneHistory(const DeviceState &d) {
+    const size_t nL = tn_.laneL2G.size(), M = CFX_LANE_HISTORY_MAX;
+    std::vector<int32_t> len(nL, 0), num(nL * M, 0), hNum(nL, 0);
+    std::vector<double> avg(nL * M, 0.0), hAvg(nL, 0.0);
+    for (size_t l = 0; l < nL; ++l) {  // (a ghost lane's rows are nobody's: the lane's own history for them, harmless)
+        const size_t g = (size_t) tn_.laneL2G[l];
+        len[l] = d.hLen[g];
+        hNum[l] = d.hHistoryVehicleNum[g];
+        hAvg[l] = d.hHistoryAverageSpeed[g];
+        std::copy(d.hVehicleNum.begin() + (ptrdiff_t) (g * M), d.hVehicleNum.begin() + (ptrdiff_t) ((g + 1) * M), num.begin() + (ptrdiff_t) (l * M));
+        std::copy(d.hAverageSpeed.begin() + (ptrdiff_t) (g * M), d.hAverageSpeed.begin() + (ptrdiff_t) ((g + 1) * M), avg.begin() + (ptrdiff_t) (l * M));
+    }
+    cfx_lane_history h{(int32_t) nL, len.data(), num.data(), avg.data(), hNum.data(), hAvg.data()};
+    check(be_->cfx_set_lane_history(dev_, &h), "cfx_set_lane_history");
+}
+
 cfx_scalars TileEngine::scalars() {
     cfx_scalars s{};
     check(be_->cfx_get_scalars(dev_, &s), "cfx_get_scalars");
@@ -704,6 +737,9 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
     if (cfg_.laneChange) throw std::runtime_error("TiledEngine: laneChange=true is not implemented for the tiled engine (single Engine only)");
+    // Lane::history: EngineHost's default (kept where it is nearly free: the ring layout, networks up to 20 k lanes); the tiles
+    // take a step's record behind the step's halo import, when the vehicles that entered a cut lane in the step are on it
+    if (cfg_.laneHistory < 0) cfg_.laneHistory = (net_->lanes.size() <= 20000 && cfg_.layout != CFX_LAYOUT_DENSE) ? 1 : 0;
     nTiles_ = rows * cols;
     owner_ = gridPartition(*net_, rows, cols);
     be_.open(backendLib.empty() ? defaultBackendPath() : backendLib);
@@ -721,6 +757,9 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
         // several local tiles spread over the visible devices (the engine takes device % device count)
         tiles_.emplace_back(new TileEngine(net_, owner_, localRanks_[i], cfg_, &be_, baseDevice + (int) i));
     }
+    keepsHistory_ = cfg_.laneHistory > 0;
+    for (auto &t : tiles_)
+        if (t->layoutName() == "dense") keepsHistory_ = false;  // (dense tiles — a developer's choice — do not keep it)
     aheadEnabled_ = cfg_.spawnAhead && !cfg_.laneChange && !cfg_.saveReplay;
     compactAt_ = nextCompactAt_ = cfg_.compactVehicles < 0 ? (size_t) 3500000 : (size_t) cfg_.compactVehicles;
     compactAuto_ = cfg_.compactVehicles < 0;
@@ -1403,6 +1442,34 @@ std::string TiledEngineHost::snapshotPart() {
     for (auto &t : tiles_) t->trafficLights(owner_, phase, remain);
     w.vec(phase);
     w.vec(remain);
+    // Lane::history of the lanes this process's tiles own: {global lane, records held, the two aggregates}, then the records
+    std::vector<int32_t> hLane, hLen, hHistNum, hNum;
+    std::vector<double> hHistAvg, hAvg;
+    if (keepsHistory_) {
+        const size_t nL = net_->lanes.size(), M = CFX_LANE_HISTORY_MAX;
+        DeviceState d;
+        d.hLen.assign(nL, -1);
+        d.hVehicleNum.assign(nL * M, 0);
+        d.hAverageSpeed.assign(nL * M, 0.0);
+        d.hHistoryVehicleNum.assign(nL, 0);
+        d.hHistoryAverageSpeed.assign(nL, 0.0);
+        for (auto &t : tiles_) t->laneHistoryInto(d);
+        for (size_t g = 0; g < nL; ++g) {
+            if (d.hLen[g] < 0) continue;  // (another process's lane)
+            hLane.push_back((int32_t) g);
+            hLen.push_back(d.hLen[g]);
+            hHistNum.push_back(d.hHistoryVehicleNum[g]);
+            hHistAvg.push_back(d.hHistoryAverageSpeed[g]);
+            hNum.insert(hNum.end(), d.hVehicleNum.begin() + (ptrdiff_t) (g * M), d.hVehicleNum.begin() + (ptrdiff_t) (g * M + (size_t) d.hLen[g]));
+            hAvg.insert(hAvg.end(), d.hAverageSpeed.begin() + (ptrdiff_t) (g * M), d.hAverageSpeed.begin() + (ptrdiff_t) (g * M + (size_t) d.hLen[g]));
+        }
+    }
+    w.vec(hLane);
+    w.vec(hLen);
+    w.vec(hHistNum);
+    w.vec(hHistAvg);
+    w.vec(hNum);
+    w.vec(hAvg);
     return std::move(w.out);
 }
 
@@ -1456,6 +1523,31 @@ Archive TiledEngineHost::snapshotFromParts(const std::vector<std::string> &parts
                 d.tlPhase[i] = ph[i];
                 d.tlRemain[i] = rem[i];
             }
+        const std::vector<int32_t> hLane = r.vec<int32_t>(), hLen = r.vec<int32_t>(), hHistNum = r.vec<int32_t>();
+        const std::vector<double> hHistAvg = r.vec<double>();
+        const std::vector<int32_t> hNum = r.vec<int32_t>();
+        const std::vector<double> hAvg = r.vec<double>();
+        if (!hLane.empty()) {
+            const size_t nL = net_->lanes.size(), M = CFX_LANE_HISTORY_MAX;
+            if (d.hLen.empty()) {
+                d.hLen.assign(nL, 0);
+                d.hVehicleNum.assign(nL * M, 0);
+                d.hAverageSpeed.assign(nL * M, 0.0);
+                d.hHistoryVehicleNum.assign(nL, 0);
+                d.hHistoryAverageSpeed.assign(nL, 0.0);
+            }
+            size_t at = 0;
+            for (size_t i = 0; i < hLane.size(); ++i) {
+                const size_t g = (size_t) hLane[i], n = (size_t) hLen[i];
+                if (g >= nL || n > M || at + n > hNum.size()) throw std::runtime_error("tiling: snapshot part with a broken lane history");
+                d.hLen[g] = hLen[i];
+                d.hHistoryVehicleNum[g] = hHistNum[i];
+                d.hHistoryAverageSpeed[g] = hHistAvg[i];
+                std::copy(hNum.begin() + (ptrdiff_t) at, hNum.begin() + (ptrdiff_t) (at + n), d.hVehicleNum.begin() + (ptrdiff_t) (g * M));
+                std::copy(hAvg.begin() + (ptrdiff_t) at, hAvg.begin() + (ptrdiff_t) (at + n), d.hAverageSpeed.begin() + (ptrdiff_t) (g * M));
+                at += n;
+            }
+        }
     }
     // every drivable belongs to exactly one tile, which lists it front to back: a stable sort by global drivable gives
     // Drivable::vehicles order over the whole network (the same for the waiting buffers, lane by lane)
@@ -1549,6 +1641,8 @@ void TiledEngineHost::load(const Archive &a) {
     for (auto &t : tiles_) {
         t->uploadTables(spawner_);
         t->loadState(a, t->tile().rank == 0);
+        // Archive::resume archive.cpp:107-109 (an archive without it: the lanes keep the history they have)
+        if (keepsHistory_ && a.dev.hLen.size() == net_->lanes.size()) t->setLaneHistory(a.dev);
     }
     numbersOut_ = spawner_.vehicles.size();
     step_ = (size_t) a.dev.step;

@@ -128,6 +128,10 @@ public:
     // owns, the proxy (= the tail) of every ghost lane, the waiting buffers of its lanes (owned and mirrored), its lights.
     // The job's totals (finished vehicles, travel-time sum, vehicle steps) go to ONE tile (takesTotals): the job sums them.
     void loadState(const Archive &a, bool takesTotals);
+    // Lane::history (roadnet.cpp:900-915; cfx_get / cfx_set_lane_history) of the lanes this tile OWNS, in the network-wide arrays
+    // of an archive (a ghost lane's rows here record its proxy: the owner has the lane's)
+    void laneHistoryInto(DeviceState &d);
+    void setLaneHistory(const DeviceState &d);
 
     const TileNet &tile() const { return tn_; }
     std::vector<char> send, recv;
@@ -235,6 +239,7 @@ public:
     // (the vehicle numbers out as of the batch the last step took: the step-ahead thread may be adding the next step's while
     //  this is asked, and how far it has come differs from rank to rank)
     bool wantsCompaction() const { return compactAt_ > 0 && numbersOut_ >= nextCompactAt_; }
+    bool keepsLaneHistory() const { return keepsHistory_; }
     int64_t vehicleCompactions() const { return vehicleCompactions_; }
     int64_t vehicleTableSize() const { return (int64_t) numbersOut_; }
     void loadFromFile(const std::string &path);
@@ -289,6 +294,7 @@ private:
     std::vector<std::unique_ptr<TileEngine>> tiles_;
     int nTiles_ = 1;
     bool allLocal_ = true, mailboxes_ = false;
+    bool keepsHistory_ = false;  // Lane::history kept by the tiles (ring layout; EngineHost's default: networks up to 20 k lanes)
     size_t numbersOut_ = 0;  // vehicle numbers handed out as of the last batch taken / load / compaction
     size_t compactAt_ = 3500000, nextCompactAt_ = 3500000;  // (EngineHost's policy: 3.5 M vehicle numbers, then 32 x the vehicles alive)
     bool compactAuto_ = true;

@@ -114,8 +114,9 @@ typedef struct cfx_config {
                                     * never depend on it */
     int32_t lane_history;     /* keep Lane::history (roadnet.cpp:900-915; see cfx_get_lane_history), numbers only Archive dumps
                                * show.  Ring layout: the record of a step is taken by spare blocks of the NEXT step's action launch
-                               * (or by a launch of its own when cfx_get/set_lane_history, a reset or a load come first); not on
-                               * tiles */
+                               * (or by a launch of its own when cfx_get/set_lane_history, a reset or a load come first).  A tile
+                               * (ring layout) takes the step's record behind the step's halo import: the rows of the lanes it
+                               * owns are the lanes' history, a ghost lane's rows record its proxy */
     int32_t n_envs;           /* 0 or 1: one simulation.  E > 1: the network is E disjoint copies of one network with their
                                * index spaces concatenated copy by copy (roads, lanes, laneLinks, intersections: n_roads etc. are
                                * multiples of E) — E independent simulations advanced by one engine (batched environments).  Only

@@ -820,7 +820,9 @@ struct cfx_engine {
                 updateLeaderAndGap(veh[vid], leader);
                 leader = vid;
             }
-            if (cfg.lane_history && !tiled && (int) d < net.L) updateHistory((int) d);  // (not kept on tiles)
+            // (a tile: the step's record is taken by the pass behind the halo import — the vehicles that entered a cut lane in
+            //  this step are on it only then, as they are at the end of the step on one engine)
+            if (cfg.lane_history && (!tiled || historyPass) && (int) d < net.L) updateHistory((int) d);
         }
     }
 
@@ -925,8 +927,11 @@ struct cfx_engine {
             v.customSet = false;
             order[g].push_back(t.vid);
         }
+        historyPass = true;
         leaderAndGapPass();  // leaders found across a cut see the refreshed proxies
+        historyPass = false;
     }
+    bool historyPass = false;
 
     void stepOnce(const cfx_spawn *recs, int n) {
         // phases 0/1 happened on the host; enqueue on waiting buffers in record order

@@ -185,3 +185,69 @@ def test_lane_history_rides_with_the_next_action_launch(mod, scen, workdir, form
             both(lambda e: e.load(arch))
         h = same(("free", round_))
     assert h["len"].max() == 241 and h["history_vehicle_num"].sum() > 0
+
+
+# ---- tiles: a lane's history is kept by the tile that owns the lane; the step's record is taken behind the step's halo import
+#      (the vehicles that entered a cut lane in the step are on it only then — as they are at the end of the step on one engine)
+def tiled_history_body(mod, scen, workdir, tmp_path, make_tiled, make_single, steps):
+    import os
+    base = scen.materialize("grid_6x6", workdir)
+    d = os.path.dirname(base)
+    flow = scen.dense_flows(os.path.join(d, "roadnet.json"), os.path.join(d, "flow_hist_tiles.json"), 150, seed=17,
+                            interval=3.0, base_flow=os.path.join(d, "flow.json"))
+    cfg = scen.materialize("grid_6x6", workdir, flow_file=flow)
+    til, one = make_tiled(cfg), make_single(cfg)
+    assert til._keeps_lane_history() and one._keeps_lane_history()
+    p_t, p_o = str(tmp_path / "tiles.json"), str(tmp_path / "one.json")
+    for s in range(steps):
+        til.next_step()
+        one.next_step()
+        if s in (3, 60, steps // 2, steps - 1):
+            til.snapshot().dump(p_t)
+            one.snapshot().dump(p_o)
+            ht, ho = history_of(p_t, False, mod), history_of(p_o, False, mod)
+            assert ht == ho, (s, [k for k in ho if ht.get(k) != ho[k]][:5])
+    assert max(len(v[0]) for v in ho.values()) == 2 * min(steps, 241) and sum(v[1] for v in ho.values()) > 0
+    # through a load (the tiles take the archive's history back) and a compaction
+    arch = one.snapshot()
+    til.load(arch)
+    one.load(arch)
+    for s in range(30):
+        til.next_step()
+        one.next_step()
+        if s == 10:
+            til._compact_vehicles()
+    til.snapshot().dump(p_t)
+    one.snapshot().dump(p_o)
+    assert history_of(p_t, False, mod) == history_of(p_o, False, mod)
+    # (the rest of the two dumps: tests/test_tiling.py compares them whole.  After a LOAD the HIP tiles' `blocker` fields can
+    #  differ from one engine's where a vehicle's blocker runs in another tile — the archive names it by number, a tile resolves
+    #  numbers among its own vehicles; the blocker test of Cross::canPass only ever concerns vehicles at one intersection)
+    a, b = json.load(open(p_t)), json.load(open(p_o))
+    for dump in (a, b):
+        for v in dump["vehicles"]:
+            v.pop("blocker", None)
+    assert a == b
+
+
+@pytest.mark.parametrize("mailboxes", [False, True])
+def test_lane_history_on_tiles_twin(mod, scen, workdir, tmp_path, mailboxes):
+    def tiles(c):
+        t = mod.TiledEngine(c, 2, 3, [], TWIN_LIB)
+        if mailboxes:
+            t.enable_mailboxes("hist_tw_%d" % __import__("os").getpid())
+        return t
+    tiled_history_body(mod, scen, workdir, tmp_path, tiles, lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), 260)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mailboxes", [False, True])
+def test_lane_history_on_tiles_hip(mod, scen, workdir, tmp_path, mailboxes):
+    """HIP tiles (the record rides in the next step's action launch, behind the import in that step's admission launch — or
+    behind the import kernel of the staged exchange) against the twin on the whole network."""
+    def tiles(c):
+        t = mod.TiledEngine(c, 2, 2)
+        if mailboxes:
+            t.enable_mailboxes("hist_hip_%d" % __import__("os").getpid())
+        return t
+    tiled_history_body(mod, scen, workdir, tmp_path, tiles, lambda c: mod.Engine._with_backend(c, 1, TWIN_LIB), 300)
