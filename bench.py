@@ -1046,24 +1046,10 @@ def main():
                           "lights": {k: (int(x["curPhaseIndex"]), float(x["remainDuration"])) for k, x in lights.items()}}
         del end_arch
 
-    # ---- longer windows behind the driver-shaped one (a 20-step region is under a millisecond of device time): five more
-    #      windows of 200 steps of the same run, timed the same way; reported beside the headline, never instead of it.
-    # All windows are reported, their MEAN is the named figure — not the best one: a stall inside a window is part of what
-    # a caller sees.  Every window carries where its slowest call was and what the device library did in it
-    # (`sustained_windows`), so that a window that disagrees with its neighbours names its cause in the line itself.
-    window_details = []
-    if args.steps >= 200:
-        ms_200_windows = [elapsed / args.steps * 1e3]
-    else:
-        ms_200_windows = []
-        for _ in range(5):
-            det = {}
-            ms_200_windows.append(timed_steps(job, eng, 200, det) / 200 * 1e3)
-            window_details.append(det)
-    ms_per_step_200 = sum(ms_200_windows) / len(ms_200_windows)
-    ms_per_step_200_median = sorted(ms_200_windows)[len(ms_200_windows) // 2]
-
-    # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream).  Tiled runs: every
+    # ---- roofline leg: instrumented continuation of the same run (HIP events on the engine's stream), RIGHT BEHIND the timed
+    #      region — on the vehicles the timed region stepped (until round 6's second half it followed the sustained windows:
+    #      a thousand steps later the workload holds 15 % fewer vehicles, the launch takes as long, and the fraction read
+    #      0.034 where the same kernel on the timed region's state reads 0.039).  Tiled runs: every
     #      rank keeps stepping (the tiles are coupled), rank 0 instruments its own tile, halo kernels included.
     # (not where several ranks share one device: their kernels take turns on it, so per-kernel times say nothing about a tile,
     # and the instrumented rank — every launch bracketed by events — falls behind its neighbour's bounded halo wait)
@@ -1104,6 +1090,23 @@ def main():
                 with_traffic=not tiled, symbols=None if tiled else eng._profile_symbols())
             chunk_medians(roofline, chunks)
             history_note(roofline, None if tiled else eng)
+
+    # ---- longer windows behind the driver-shaped one (a 20-step region is under a millisecond of device time): five more
+    #      windows of 200 steps of the same run, timed the same way; reported beside the headline, never instead of it.
+    # All windows are reported, their MEAN is the named figure — not the best one: a stall inside a window is part of what
+    # a caller sees.  Every window carries where its slowest call was and what the device library did in it
+    # (`sustained_windows`), so that a window that disagrees with its neighbours names its cause in the line itself.
+    window_details = []
+    if args.steps >= 200:
+        ms_200_windows = [elapsed / args.steps * 1e3]
+    else:
+        ms_200_windows = []
+        for _ in range(5):
+            det = {}
+            ms_200_windows.append(timed_steps(job, eng, 200, det) / 200 * 1e3)
+            window_details.append(det)
+    ms_per_step_200 = sum(ms_200_windows) / len(ms_200_windows)
+    ms_per_step_200_median = sorted(ms_200_windows)[len(ms_200_windows) // 2]
 
     # ---- in-run parity and the CPU baseline (rank 0; a tiled run is compared with ONE engine on rank 0's device)
     cpu, legs, parity_in_run, parity_excused, parity_detail = None, None, None, None, None
