@@ -277,6 +277,22 @@ def test_two_ranks_one_gpu(scen, workdir, tmp_path, mailboxes):
 
 
 @pytest.mark.gpu
+def test_two_ranks_one_gpu_compaction_and_archive(scen, workdir, tmp_path):
+    """Two processes sharing this box's GPU, HIP tiles, GPU-written mailboxes: the tiles forget their finished vehicles every 300
+    vehicle numbers (a collective: every rank's part of the state on every rank, `Lane::history` in the parts) and stay equal,
+    id by id, to one engine that never forgets; then snapshot / dump (the single engine's file, history included) / load /
+    setRoute over the ranks (tests/tiled_worker.py: CFX_TEST_COMPACT, CFX_TEST_ARCHIVE)."""
+    cfg = scen.generate_grid(6, 6, workdir, flow_interval=12.0)
+    out = _torchrun(tmp_path, cfg, "", 1, 2, 700, 2, free_port(), {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": "1", "CFX_TEST_COMPACT": "300"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 700" in out.stdout and "COMPACT_OK" in out.stdout
+    cfg = dense_cfg(scen, workdir, "grid_6x6", 60, 5, 1.0)
+    out = _torchrun(tmp_path, cfg, "", 2, 1, 120, 2, free_port(), {"CITYFLOW_AMD_DEVICE": "0", "CFX_TEST_MAILBOXES": "1", "CFX_TEST_ARCHIVE": "1"})
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "TILED_OK 120" in out.stdout and "ARCHIVE_OK" in out.stdout
+
+
+@pytest.mark.gpu
 def test_four_ranks_one_gpu_mailboxes(scen, workdir, tmp_path):
     """2x2 tiles, four processes on this box's GPU: every tile has two neighbours, mailboxes in both directions."""
     cfg = scen.materialize("grid_6x6", workdir)
