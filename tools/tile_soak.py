@@ -37,5 +37,13 @@ for s in range(steps):
         snap = single.snapshot()
     if s == 2 * steps // 3 and snap is not None:  # back to an earlier state, on both
         single.load(snap); tiled.load(snap)
-print("tiles %dx%d (%s): %d steps, %d comparisons, %d running vehicles, %.0f s: equal" % (
-    rows, cols, tiled._layout(), steps, checks, single.get_vehicle_count(), time.time() - t0))
+# Lane::history (kept by ring tiles like one engine; the getters above made its record come by both ways: with the next action
+# launch and as a launch of its own): the two Archives' drivables, every record of every lane
+import json
+single.snapshot().dump("/tmp/cfa_tsoak_one.json")
+tiled.snapshot().dump("/tmp/cfa_tsoak_tiles.json")
+da, db = json.load(open("/tmp/cfa_tsoak_one.json"))["drivables"], json.load(open("/tmp/cfa_tsoak_tiles.json"))["drivables"]
+assert da == db, "Lane::history differs on %d drivables" % sum(da[k] != db.get(k) for k in da)
+assert not tiled._keeps_lane_history() or sum(len(v.get("history", [])) for v in db.values()) > 0
+print("tiles %dx%d (%s): %d steps, %d comparisons, %d running vehicles, %.0f s: equal (Lane::history of %d lanes included)" % (
+    rows, cols, tiled._layout(), steps, checks, single.get_vehicle_count(), time.time() - t0, sum("history" in v for v in db.values())))
