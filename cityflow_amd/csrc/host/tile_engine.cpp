@@ -736,7 +736,11 @@ TiledEngineHost::TiledEngineHost(const std::string &configFile, int rows, int co
     } catch (const JsonError &e) {
         throw std::runtime_error(std::string("load config failed! ") + e.what());
     }
-    if (cfg_.laneChange) throw std::runtime_error("TiledEngine: laneChange=true is not implemented for the tiled engine (single Engine only)");
+    // (what it takes — two all-gathers per step for the walk order and the shadows' numbers, a mid-step tail update across the cut,
+    //  lane-change state in the migrants' records — is written down in DESIGN.md section 7)
+    if (cfg_.laneChange)
+        throw std::runtime_error("TiledEngine: laneChange=true is not implemented for tiles (Engine and VectorEngine have it; DESIGN.md section 7 "
+                                 "lists what lane change over tiles needs)");
     // Lane::history: EngineHost's default (kept where it is nearly free: the ring layout, networks up to 20 k lanes); the tiles
     // take a step's record behind the step's halo import, when the vehicles that entered a cut lane in the step are on it
     if (cfg_.laneHistory < 0) cfg_.laneHistory = (net_->lanes.size() <= 20000 && cfg_.layout != CFX_LAYOUT_DENSE) ? 1 : 0;
