@@ -326,7 +326,25 @@ __global__ __launch_bounds__(64) void k_lc_schedule(StepCtx c, DevScalars *sc, c
     // Walk positions (the `std::sort` of scheduleLaneChange, lcSortedPosition): the creation rank of a candidate is the
     // number of the step's candidates with a smaller vehicle number — counted here, by the wave that needs it, over the
     // step's list (a few KB, read by every road's wave: it stays in L2).  k_lc_assign reads candPos of the shadows' parents.
-    if (!tooMany) {
+    if (!tooMany && env < 0 && nAll <= 4 * 64) {
+        // one environment, up to 256 candidates in the step (the bench workload: ~150): the step's list goes into registers
+        // once — four vehicle numbers per lane — and every candidate of the road is counted from there
+        int mine[4];
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 64 * q;
+            mine[q] = i < nAll ? lc.candAll[i] : CFX_INT_MAX;
+        }
+        for (int j = 0; j < nListed; ++j) {
+            const int me = candVid[j];
+            int less = (mine[0] < me) + (mine[1] < me) + (mine[2] < me) + (mine[3] < me);
+            for (int off = 32; off > 0; off >>= 1) less += __shfl_down(less, off, 64);
+            if (tid == 0) {
+                const int key = lcSortedPosition(less, nAll);
+                candKey[j] = key;
+                lc.candPos[me] = key;
+            }
+        }
+    } else if (!tooMany) {
         for (int j = 0; j < nListed; ++j) {
             const int me = candVid[j];
             const int key = lcWalkPosition(lc, me, env, nAll, tid);
