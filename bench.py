@@ -1026,7 +1026,10 @@ def main():
     sc0 = total_scalars(job, eng, tiled)
     host0 = eng._eng._host_seconds() if tiled else None
 
-    elapsed = timed_steps(job, eng, args.steps)
+    # (every call of the timed region is stamped with the host clock too — two clock reads per step beside a 40 us device step
+    # the host runs ahead of: a region that comes out slow says where, `timed_region_detail`)
+    timed_detail = {}
+    elapsed = timed_steps(job, eng, args.steps, timed_detail)
 
     host1 = eng._eng._host_seconds() if tiled else None  # this rank's host time inside the timed region
     sc1 = total_scalars(job, eng, tiled)
@@ -1189,7 +1192,7 @@ def main():
             "metric": "vehicle_steps_per_sec", "value": veh_steps / elapsed, "unit": "vehicle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_200": ms_per_step_200, "ms_per_step_200_windows": ms_200_windows,
-            "ms_per_step_200_median": ms_per_step_200_median, "sustained_windows": window_details or None,
+            "ms_per_step_200_median": ms_per_step_200_median, "sustained_windows": window_details or None, "timed_region_detail": timed_detail or None,
             "higher_is_better": True, "scaling": None if world == 1 else ("strong" if (tiled and strong) else "weak"),
             # one tiled network was asked for and no halo transport came up: the line below is N independent replicas, NOT a
             # multi-GPU run of one network (also in config.parallelism / config.halo_probe_failures)
